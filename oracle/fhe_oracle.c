@@ -1,0 +1,1031 @@
+/*
+ * fhe_oracle.c — TEST INFRASTRUCTURE ONLY (see fhe_oracle.h).
+ *
+ * Plain-C restatement of the reference's CPU algorithms for the lbcrypto::DCRTPoly hot path.
+ * Each function cites the reference file:line (relative to /root/reference/) it follows.
+ * Written from the algorithm description in SURVEY.md Appendix A; loop structure follows the
+ * reference so that operation ORDER (which matters for the double-precision paths) is the same.
+ *
+ * Parity status: PINNED (tests/test_oracle_golden.py, tests/test_oracle_vs_ref.py).
+ */
+#include "fhe_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef unsigned __int128 u128;
+
+/* ------------------------------------------------------------------------------------------
+ * a1: scalar arithmetic
+ * ---------------------------------------------------------------------------------------- */
+uint64_t orc_mulmod(uint64_t a, uint64_t b, uint64_t q) {
+    return (uint64_t)(((u128)a * b) % q);
+}
+
+uint64_t orc_powmod(uint64_t a, uint64_t e, uint64_t q) {
+    uint64_t r = 1 % q;
+    a %= q;
+    while (e) {
+        if (e & 1)
+            r = orc_mulmod(r, a, q);
+        a = orc_mulmod(a, a, q);
+        e >>= 1;
+    }
+    return r;
+}
+
+uint64_t orc_invmod(uint64_t a, uint64_t q) {
+    /* q prime on this path (all moduli are NTT primes); Fermat */
+    return orc_powmod(a % q, q - 2, q);
+}
+
+/* nbtheory.h:169-186 — GetMSB: index of the most significant set bit, 1-based; 0 for x == 0 */
+uint32_t orc_get_msb(uint64_t x) {
+    uint32_t r = 0;
+    while (x) {
+        ++r;
+        x >>= 1;
+    }
+    return r;
+}
+
+/* ubintnat.h:642-647 — mu = floor(2^(2*msb+3) / q) */
+uint64_t orc_compute_mu(uint64_t q) {
+    u128 t = (u128)1 << (2 * orc_get_msb(q) + 3);
+    return (uint64_t)(t / q);
+}
+
+/* ubintnat.h:1348-1361 — generalized Barrett, alpha = n+3 */
+uint64_t orc_mod_mul_fast(uint64_t a, uint64_t b, uint64_t q, uint64_t mu) {
+    int64_t n = (int64_t)orc_get_msb(q) - 2;
+    u128 prod = (u128)a * b;
+    u128 rv   = prod;
+    u128 t    = (u128)(uint64_t)(prod >> n) * mu; /* RShiftD keeps the low 64 bits of (prod >> n) */
+    rv -= (u128)q * (u128)(t >> (n + 7));
+    uint64_t r = (uint64_t)rv;
+    if (r >= q)
+        r -= q;
+    return r;
+}
+
+/* ubintnat.h:1437-1444 — Shoup precomputation floor(b * 2^64 / q) */
+uint64_t orc_prep_mod_mul_const(uint64_t b, uint64_t q) {
+    return (uint64_t)((((u128)b) << 64) / q);
+}
+
+/* ubintnat.h:1464-1469 — Shoup multiplication, result in [0,q) for a < q */
+uint64_t orc_mod_mul_fast_const(uint64_t a, uint64_t b, uint64_t q, uint64_t bPrecon) {
+    uint64_t qq    = (uint64_t)(((u128)a * bPrecon) >> 64) + 1;
+    int64_t yprime = (int64_t)(a * b - qq * q);
+    return (uint64_t)(yprime >= 0 ? yprime : yprime + (int64_t)q);
+}
+
+/* ubintnat.h:737-743 */
+uint64_t orc_mod_add_fast(uint64_t a, uint64_t b, uint64_t q) {
+    uint64_t r = a + b;
+    if (r >= q)
+        r -= q;
+    return r;
+}
+
+/* ubintnat.h:911-921 */
+uint64_t orc_mod_sub_fast(uint64_t a, uint64_t b, uint64_t q) {
+    if (a < b)
+        return a + q - b;
+    return a - b;
+}
+
+/* a2: mu128 = floor(2^128 / q) as the reference computes it from BigInteger(1)<<128
+ * (rns-cryptoparameters.cpp:288-293).  2^128 / q = floor((2^128 - 1) / q) unless q | 2^128, impossible for odd q. */
+void orc_barrett_mu128(uint64_t q, uint64_t mu[2]) {
+    u128 m = (~(u128)0) / q;
+    mu[0]  = (uint64_t)m;
+    mu[1]  = (uint64_t)(m >> 64);
+}
+
+/* utilities-int.h:60-99 — BarrettUint128ModUint64 */
+uint64_t orc_barrett128(uint64_t a_lo, uint64_t a_hi, uint64_t q, uint64_t mu_lo, uint64_t mu_hi) {
+    uint64_t left_hi = (uint64_t)(((u128)a_lo * mu_lo) >> 64);
+    u128 middle      = (u128)a_lo * mu_hi;
+    uint64_t mid_lo  = (uint64_t)middle;
+    uint64_t mid_hi  = (uint64_t)(middle >> 64);
+    uint64_t tmp1    = mid_lo + left_hi;
+    uint64_t carry   = tmp1 < mid_lo;
+    uint64_t tmp2    = mid_hi + carry;
+    middle           = (u128)a_hi * mu_lo;
+    mid_lo           = (uint64_t)middle;
+    mid_hi           = (uint64_t)(middle >> 64);
+    carry            = (uint64_t)(mid_lo + tmp1) < mid_lo;
+    left_hi          = mid_hi + carry;
+    tmp1             = a_hi * mu_hi + tmp2 + left_hi;
+    uint64_t r       = a_lo - tmp1 * q;
+    while (r >= q)
+        r -= q;
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * number theory (parameter reproduction)
+ * ---------------------------------------------------------------------------------------- */
+/* Deterministic Miller-Rabin for 64-bit inputs.  The reference uses a probabilistic
+ * MillerRabinPrimalityTest (nbtheory-impl.h:120-160); both agree on every 64-bit input
+ * that matters (a deterministic witness set has no false positives or negatives < 2^64). */
+int orc_is_prime(uint64_t n) {
+    static const uint64_t small[] = {2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37};
+    if (n < 2)
+        return 0;
+    for (size_t i = 0; i < sizeof(small) / sizeof(small[0]); ++i) {
+        if (n == small[i])
+            return 1;
+        if (n % small[i] == 0)
+            return 0;
+    }
+    uint64_t d = n - 1;
+    int s      = 0;
+    while ((d & 1) == 0) {
+        d >>= 1;
+        ++s;
+    }
+    for (size_t i = 0; i < sizeof(small) / sizeof(small[0]); ++i) {
+        uint64_t x = orc_powmod(small[i], d, n);
+        if (x == 1 || x == n - 1)
+            continue;
+        int comp = 1;
+        for (int r = 1; r < s; ++r) {
+            x = orc_mulmod(x, x, n);
+            if (x == n - 1) {
+                comp = 0;
+                break;
+            }
+        }
+        if (comp)
+            return 0;
+    }
+    return 1;
+}
+
+/* nbtheory-impl.h:329-347 */
+uint64_t orc_first_prime(uint32_t nBits, uint64_t m) {
+    uint64_t q    = (uint64_t)1 << nBits;
+    uint64_t r    = q % m;
+    uint64_t qNew = q + 1 - r;
+    if (r > 0)
+        qNew += m;
+    while (!orc_is_prime(qNew))
+        qNew += m;
+    return qNew;
+}
+
+/* nbtheory-impl.h:349-373 */
+uint64_t orc_last_prime(uint32_t nBits, uint64_t m) {
+    uint64_t q    = (uint64_t)1 << nBits;
+    uint64_t r    = q % m;
+    uint64_t qNew = q + 1 - r;
+    if (r < 2)
+        qNew -= m;
+    while (!orc_is_prime(qNew))
+        qNew -= m;
+    return qNew;
+}
+
+/* nbtheory-impl.h:375-383 */
+uint64_t orc_next_prime(uint64_t q, uint64_t m) {
+    uint64_t qNew = q + m;
+    while (!orc_is_prime(qNew))
+        qNew += m;
+    return qNew;
+}
+
+/* nbtheory-impl.h:385-393 */
+uint64_t orc_previous_prime(uint64_t q, uint64_t m) {
+    uint64_t qNew = q - m;
+    while (!orc_is_prime(qNew))
+        qNew -= m;
+    return qNew;
+}
+
+/* nbtheory-impl.h:183-231 — the MINIMUM primitive m-th root of unity mod q (m a power of two).
+ * The reference finds one primitive root from a random generator and then cycles through all
+ * powers coprime to m keeping the smallest; the minimum does not depend on the starting root,
+ * so any primitive root serves as the start. */
+uint64_t orc_root_of_unity(uint64_t m, uint64_t q) {
+    if ((q - 1) % m != 0)
+        return 0;
+    uint64_t e = (q - 1) / m;
+    uint64_t root = 0;
+    for (uint64_t g = 2; g < q; ++g) {
+        uint64_t r = orc_powmod(g, e, q);
+        /* primitive m-th root (m power of two) iff r^(m/2) == -1 */
+        if (orc_powmod(r, m / 2, q) == q - 1) {
+            root = r;
+            break;
+        }
+    }
+    /* all primitive roots = odd powers of root */
+    uint64_t sq    = orc_mulmod(root, root, q);
+    uint64_t x     = root;
+    uint64_t minRU = x;
+    for (uint64_t i = 1; i < m / 2; ++i) {
+        x = orc_mulmod(x, sq, q);
+        if (x < minRU)
+            minRU = x;
+    }
+    return minRU;
+}
+
+/* nbtheory.h:135-157 */
+uint32_t orc_reverse_bits(uint32_t x, uint32_t nbits) {
+    uint32_t r = 0;
+    for (uint32_t i = 0; i < nbits; ++i)
+        r |= ((x >> i) & 1u) << (nbits - 1 - i);
+    return r;
+}
+
+/* nbtheory2.cpp:264-275 */
+void orc_precompute_auto_map(uint32_t n, uint32_t k, uint32_t* precomp) {
+    uint32_t m    = n << 1;
+    uint32_t logm = orc_get_msb(m) - 1;
+    uint32_t logn = logm - 1;
+    for (uint32_t j = 0; j < n; ++j) {
+        uint32_t jTmp   = (j << 1) + 1;
+        uint32_t prod   = jTmp * k; /* 32-bit wrap-around as in the reference */
+        uint32_t idx    = (prod - ((prod >> logm) << logm)) >> 1;
+        uint32_t jrev   = orc_reverse_bits(j, logn);
+        uint32_t idxrev = orc_reverse_bits(idx, logn);
+        precomp[jrev]   = idxrev;
+    }
+}
+
+/* nbtheory2.cpp:243-262 */
+uint32_t orc_find_automorphism_index_2n_complex(int32_t i, uint32_t m) {
+    if (i == 0)
+        return 1;
+    if (i == (int32_t)m - 1)
+        return (uint32_t)i;
+    uint64_t g0 = 5;
+    if (i < 0) {
+        /* 5^-1 mod m, m power of two: Newton iteration */
+        uint64_t inv = 1;
+        for (int it = 0; it < 6; ++it)
+            inv = (inv * (2 - 5 * inv)) & (m - 1);
+        g0 = inv;
+    }
+    uint64_t g  = g0;
+    uint32_t iu = (uint32_t)(i < 0 ? -i : i);
+    for (uint32_t j = 1; j < iu; ++j)
+        g = (g * g0) & (m - 1);
+    return (uint32_t)g;
+}
+
+/* ildcrtparams.h:100-117 — LastPrime then PreviousPrime chain, roots via RootOfUnity
+ * (ilparams.h ctor -> RootOfUnity(order, modulus)) */
+void orc_dcrt_params(uint32_t order, uint32_t nLimbs, uint32_t bits, uint64_t* q, uint64_t* psi) {
+    uint64_t cur = orc_last_prime(bits, order);
+    for (uint32_t i = 0; i < nLimbs; ++i) {
+        if (i > 0)
+            cur = orc_previous_prime(cur, order);
+        q[i]   = cur;
+        psi[i] = orc_root_of_unity(order, cur);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a3..a5: NTT
+ * ---------------------------------------------------------------------------------------- */
+/* transformnat-impl.h:714-756 */
+void orc_ntt_precompute(uint64_t q, uint64_t psi, uint32_t N, uint64_t* tbl, uint64_t* tblPrecon,
+                        uint64_t* tblInv, uint64_t* tblInvPrecon, uint64_t* nInv, uint64_t* nInvPrecon) {
+    uint32_t msb    = orc_get_msb(N - 1);
+    uint64_t psiInv = orc_invmod(psi, q);
+    uint64_t x = 1, xinv = 1;
+    for (uint32_t i = 0; i < N; ++i) {
+        uint32_t iinv      = orc_reverse_bits(i, msb);
+        tbl[iinv]          = x;
+        tblPrecon[iinv]    = orc_prep_mod_mul_const(x, q);
+        x                  = orc_mulmod(x, psi, q);
+        tblInv[iinv]       = xinv;
+        tblInvPrecon[iinv] = orc_prep_mod_mul_const(xinv, q);
+        xinv               = orc_mulmod(xinv, psiInv, q);
+    }
+    /* TableCOI[msb] = (2^msb)^-1 = N^-1  (:743-750) */
+    *nInv       = orc_invmod((uint64_t)N % q, q);
+    *nInvPrecon = orc_prep_mod_mul_const(*nInv, q);
+}
+
+/* transformnat-impl.h:303-374 (GNUC branch) */
+void orc_ntt_fwd(uint64_t* x, uint32_t N, uint64_t q, const uint64_t* tbl, const uint64_t* tblPrecon) {
+    uint32_t n = N >> 1;
+    uint32_t t = n, logt = orc_get_msb(n);
+    for (uint32_t m = 1; m < n; m <<= 1, t >>= 1, --logt) {
+        for (uint32_t i = 0; i < m; ++i) {
+            uint64_t omega = tbl[i + m], pre = tblPrecon[i + m];
+            uint32_t j1 = i << logt, j2 = j1 + t;
+            for (; j1 < j2; ++j1) {
+                uint64_t of = orc_mod_mul_fast_const(x[j1 + t], omega, q, pre);
+                uint64_t lo = x[j1];
+                uint64_t hi = lo + of;
+                if (hi >= q)
+                    hi -= q;
+                if (lo < of)
+                    lo += q;
+                lo -= of;
+                x[j1]     = hi;
+                x[j1 + t] = lo;
+            }
+        }
+    }
+    for (uint32_t i = 0; i < (n << 1); i += 2) {
+        uint64_t omega = tbl[(i >> 1) + n], pre = tblPrecon[(i >> 1) + n];
+        uint64_t of = orc_mod_mul_fast_const(x[i + 1], omega, q, pre);
+        uint64_t lo = x[i];
+        uint64_t hi = lo + of;
+        if (hi >= q)
+            hi -= q;
+        if (lo < of)
+            lo += q;
+        lo -= of;
+        x[i]     = hi;
+        x[i + 1] = lo;
+    }
+}
+
+/* transformnat-impl.h:512-625 (GNUC branch) */
+void orc_ntt_inv(uint64_t* x, uint32_t N, uint64_t q, const uint64_t* tblInv, const uint64_t* tblInvPrecon,
+                 uint64_t nInv, uint64_t nInvPrecon) {
+    uint32_t n         = N;
+    uint64_t omega1Inv = orc_mod_mul_fast_const(tblInv[1], nInv, q, nInvPrecon);
+    uint64_t pre1Inv   = orc_prep_mod_mul_const(omega1Inv, q);
+    if (n > 2) {
+        for (uint32_t i = 0; i < n; i += 2) {
+            uint64_t omega = tblInv[(i + n) >> 1], pre = tblInvPrecon[(i + n) >> 1];
+            uint64_t lo = x[i], hi = x[i + 1];
+            uint64_t of = lo;
+            if (of < hi)
+                of += q;
+            of -= hi;
+            lo += hi;
+            if (lo >= q)
+                lo -= q;
+            x[i]     = lo;
+            x[i + 1] = orc_mod_mul_fast_const(of, omega, q, pre);
+        }
+    }
+    uint32_t t = 2, logt = 2;
+    for (uint32_t m = n >> 2; m > 1; m >>= 1, t <<= 1, ++logt) {
+        for (uint32_t i = 0; i < m; ++i) {
+            uint64_t omega = tblInv[i + m], pre = tblInvPrecon[i + m];
+            uint32_t j1 = i << logt, j2 = j1 + t;
+            for (; j1 < j2; ++j1) {
+                uint64_t lo = x[j1], hi = x[j1 + t];
+                uint64_t of = lo;
+                if (of < hi)
+                    of += q;
+                of -= hi;
+                lo += hi;
+                if (lo >= q)
+                    lo -= q;
+                x[j1]     = lo;
+                x[j1 + t] = orc_mod_mul_fast_const(of, omega, q, pre);
+            }
+        }
+    }
+    uint32_t j2 = n >> 1;
+    for (uint32_t j1 = 0; j1 < j2; ++j1) {
+        uint64_t lo = x[j1], hi = x[j1 + j2];
+        uint64_t of = lo;
+        if (of < hi)
+            of += q;
+        of -= hi;
+        lo += hi;
+        if (lo >= q)
+            lo -= q;
+        x[j1]      = lo;
+        x[j1 + j2] = orc_mod_mul_fast_const(of, omega1Inv, q, pre1Inv);
+    }
+    for (uint32_t i = 0; i < j2; ++i)
+        x[i] = orc_mod_mul_fast_const(x[i], nInv, q, nInvPrecon);
+}
+
+struct orc_ctx {
+    uint32_t N, L;
+    uint64_t *q, *psi;
+    uint64_t *tbl, *pre, *tblInv, *preInv; /* [L][N] */
+    uint64_t *nInv, *nInvPre;
+};
+
+orc_ctx* orc_ctx_create(uint32_t N, uint32_t nLimbs, const uint64_t* q, const uint64_t* psi) {
+    orc_ctx* c = (orc_ctx*)calloc(1, sizeof(orc_ctx));
+    c->N       = N;
+    c->L       = nLimbs;
+    c->q       = (uint64_t*)malloc(sizeof(uint64_t) * nLimbs);
+    c->psi     = (uint64_t*)malloc(sizeof(uint64_t) * nLimbs);
+    c->nInv    = (uint64_t*)malloc(sizeof(uint64_t) * nLimbs);
+    c->nInvPre = (uint64_t*)malloc(sizeof(uint64_t) * nLimbs);
+    size_t sz  = sizeof(uint64_t) * (size_t)nLimbs * N;
+    c->tbl     = (uint64_t*)malloc(sz);
+    c->pre     = (uint64_t*)malloc(sz);
+    c->tblInv  = (uint64_t*)malloc(sz);
+    c->preInv  = (uint64_t*)malloc(sz);
+    memcpy(c->q, q, sizeof(uint64_t) * nLimbs);
+    memcpy(c->psi, psi, sizeof(uint64_t) * nLimbs);
+#pragma omp parallel for schedule(dynamic)
+    for (uint32_t i = 0; i < nLimbs; ++i)
+        orc_ntt_precompute(q[i], psi[i], N, c->tbl + (size_t)i * N, c->pre + (size_t)i * N,
+                           c->tblInv + (size_t)i * N, c->preInv + (size_t)i * N, &c->nInv[i], &c->nInvPre[i]);
+    return c;
+}
+
+void orc_ctx_destroy(orc_ctx* c) {
+    if (!c)
+        return;
+    free(c->q);
+    free(c->psi);
+    free(c->nInv);
+    free(c->nInvPre);
+    free(c->tbl);
+    free(c->pre);
+    free(c->tblInv);
+    free(c->preInv);
+    free(c);
+}
+uint32_t orc_ctx_n(const orc_ctx* c) { return c->N; }
+uint32_t orc_ctx_limbs(const orc_ctx* c) { return c->L; }
+uint64_t orc_ctx_modulus(const orc_ctx* c, uint32_t limb) { return c->q[limb]; }
+
+static void ctx_fwd(const orc_ctx* c, uint64_t* x, uint32_t limb) {
+    orc_ntt_fwd(x, c->N, c->q[limb], c->tbl + (size_t)limb * c->N, c->pre + (size_t)limb * c->N);
+}
+static void ctx_inv(const orc_ctx* c, uint64_t* x, uint32_t limb) {
+    orc_ntt_inv(x, c->N, c->q[limb], c->tblInv + (size_t)limb * c->N, c->preInv + (size_t)limb * c->N,
+                c->nInv[limb], c->nInvPre[limb]);
+}
+
+/* dcrtpoly-impl.h:1932-1940 — SwitchFormat: omp parallel for over limbs, per polynomial */
+void orc_ntt_fwd_tower(const orc_ctx* c, uint64_t* x, const uint32_t* limbIdx, uint32_t nSel, uint32_t batch,
+                       int nThreads) {
+#ifdef _OPENMP
+    if (nThreads <= 0)
+        nThreads = omp_get_max_threads();
+#endif
+    for (uint32_t b = 0; b < batch; ++b) {
+#pragma omp parallel for num_threads(nThreads)
+        for (uint32_t i = 0; i < nSel; ++i)
+            ctx_fwd(c, x + ((size_t)b * nSel + i) * c->N, limbIdx ? limbIdx[i] : i);
+    }
+}
+
+void orc_ntt_inv_tower(const orc_ctx* c, uint64_t* x, const uint32_t* limbIdx, uint32_t nSel, uint32_t batch,
+                       int nThreads) {
+#ifdef _OPENMP
+    if (nThreads <= 0)
+        nThreads = omp_get_max_threads();
+#endif
+    for (uint32_t b = 0; b < batch; ++b) {
+#pragma omp parallel for num_threads(nThreads)
+        for (uint32_t i = 0; i < nSel; ++i)
+            ctx_inv(c, x + ((size_t)b * nSel + i) * c->N, limbIdx ? limbIdx[i] : i);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a7: element-wise ops
+ * ---------------------------------------------------------------------------------------- */
+/* mubintvecnat.cpp:229-236 */
+void orc_vec_add(uint64_t* out, const uint64_t* a, const uint64_t* b, size_t n, uint64_t q) {
+    for (size_t i = 0; i < n; ++i)
+        out[i] = orc_mod_add_fast(a[i], b[i], q);
+}
+/* mubintvecnat.cpp:273-279 */
+void orc_vec_sub(uint64_t* out, const uint64_t* a, const uint64_t* b, size_t n, uint64_t q) {
+    for (size_t i = 0; i < n; ++i)
+        out[i] = orc_mod_sub_fast(a[i], b[i], q);
+}
+/* mubintvecnat.cpp:325-339 — Barrett with mu computed per call */
+void orc_vec_mul(uint64_t* out, const uint64_t* a, const uint64_t* b, size_t n, uint64_t q) {
+    uint64_t mu = orc_compute_mu(q);
+    for (size_t i = 0; i < n; ++i)
+        out[i] = orc_mod_mul_fast(a[i], b[i], q, mu);
+}
+/* mubintvecnat.cpp:295-304 — Shoup with precon computed per call */
+void orc_vec_mul_const(uint64_t* out, const uint64_t* a, uint64_t c, size_t n, uint64_t q) {
+    if (c >= q)
+        c %= q;
+    uint64_t pre = orc_prep_mod_mul_const(c, q);
+    for (size_t i = 0; i < n; ++i)
+        out[i] = orc_mod_mul_fast_const(a[i], c, q, pre);
+}
+/* mubintvecnat.cpp:132-142 */
+void orc_vec_mult_acc(uint64_t* acc, const uint64_t* v, uint64_t c, size_t n, uint64_t q) {
+    if (c >= q)
+        c %= q;
+    uint64_t pre = orc_prep_mod_mul_const(c, q);
+    for (size_t i = 0; i < n; ++i)
+        acc[i] = orc_mod_add_fast(acc[i], orc_mod_mul_fast_const(v[i], c, q, pre), q);
+}
+/* dcrtpoly-impl.h:347-354 -> poly Negate -> q - v (0 stays 0 via ModSub(0, v)) */
+void orc_vec_neg(uint64_t* out, const uint64_t* a, size_t n, uint64_t q) {
+    for (size_t i = 0; i < n; ++i)
+        out[i] = orc_mod_sub_fast(0, a[i], q) % q;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a8: automorphism
+ * ---------------------------------------------------------------------------------------- */
+/* poly-impl.h:366-376 */
+void orc_automorph_eval(uint64_t* out, const uint64_t* in, uint32_t N, const uint32_t* precomp) {
+    for (uint32_t j = 0; j < N; ++j)
+        out[j] = in[precomp[j]];
+}
+/* poly-impl.h:345-353 (EVALUATION branch without a table) */
+void orc_automorph_eval_k(uint64_t* out, const uint64_t* in, uint32_t N, uint32_t k) {
+    uint32_t logn = orc_get_msb(N) - 1;
+    uint32_t mask = (1u << logn) - 1;
+    uint32_t jk   = k;
+    for (uint32_t j = 0; j < N; ++j, jk += 2 * k) {
+        uint32_t jrev   = orc_reverse_bits(j, logn);
+        uint32_t idxrev = orc_reverse_bits((jk >> 1) & mask, logn);
+        out[jrev]       = in[idxrev];
+    }
+}
+/* poly-impl.h:359-362 (COEFFICIENT branch; q - 0 = q is stored unreduced, as the reference does) */
+void orc_automorph_coeff(uint64_t* out, const uint64_t* in, uint32_t N, uint32_t k, uint64_t q) {
+    uint32_t logn = orc_get_msb(N) - 1;
+    uint32_t mask = (1u << logn) - 1;
+    uint32_t jk   = 0;
+    for (uint32_t j = 0; j < N; ++j, jk += k)
+        out[jk & mask] = ((jk >> logn) & 1u) ? q - in[j] : in[j];
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a9: centred modulus switch — mubintvecnat.cpp:109-122
+ * ---------------------------------------------------------------------------------------- */
+void orc_switch_modulus(uint64_t* v, size_t n, uint64_t oldq, uint64_t newq) {
+    uint64_t halfQ = oldq >> 1;
+    uint64_t diff  = (oldq > newq) ? (oldq - newq) : (newq - oldq);
+    if (newq > oldq) {
+        for (size_t i = 0; i < n; ++i)
+            v[i] += (v[i] > halfQ) ? diff : 0;
+    }
+    else {
+        /* ModSubEq (ubintnat.h:889-899): both operands reduced mod newq first */
+        for (size_t i = 0; i < n; ++i) {
+            uint64_t av = v[i];
+            uint64_t bv = (v[i] > halfQ) ? diff : 0;
+            if (av >= newq)
+                av %= newq;
+            if (bv >= newq)
+                bv %= newq;
+            v[i] = (av < bv) ? av + newq - bv : av - bv;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a10: ApproxSwitchCRTBasis fast path — dcrtpoly-impl.h:888-915
+ * ---------------------------------------------------------------------------------------- */
+void orc_approx_switch_crt_basis(const uint64_t* x, uint32_t sizeQ, uint32_t N, const uint64_t* q,
+                                 const uint64_t* QHatInvModq, const uint64_t* QHatInvModqPrecon,
+                                 const uint64_t* QHatModp, uint32_t sizeP, const uint64_t* p,
+                                 const uint64_t* mu128, uint64_t* out) {
+#pragma omp parallel for
+    for (uint32_t ri = 0; ri < N; ++ri) {
+        u128 sum[64];
+        for (uint32_t j = 0; j < sizeP; ++j)
+            sum[j] = 0;
+        for (uint32_t i = 0; i < sizeQ; ++i) {
+            uint64_t y = orc_mod_mul_fast_const(x[(size_t)i * N + ri], QHatInvModq[i], q[i], QHatInvModqPrecon[i]);
+            for (uint32_t j = 0; j < sizeP; ++j)
+                sum[j] += (u128)y * QHatModp[(size_t)i * sizeP + j];
+        }
+        for (uint32_t j = 0; j < sizeP; ++j)
+            out[(size_t)j * N + ri] =
+                orc_barrett128((uint64_t)sum[j], (uint64_t)(sum[j] >> 64), p[j], mu128[2 * j], mu128[2 * j + 1]);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a16: SwitchCRTBasis — dcrtpoly-impl.h:1008-1085.  The double accumulation order is part of
+ * the result: nu starts at 0.5, i ascending, one rounding per multiply and per add (no FMA:
+ * this file is compiled with -ffp-contract=off).
+ * ---------------------------------------------------------------------------------------- */
+void orc_switch_crt_basis(const uint64_t* x, uint32_t sizeQ, uint32_t N, const uint64_t* q,
+                          const uint64_t* QHatInvModq, const uint64_t* QHatInvModqPrecon,
+                          const uint64_t* QHatModp_pq, const uint64_t* alphaQModp, uint32_t sizeP,
+                          const uint64_t* p, const uint64_t* mu128, const double* qInv, uint64_t* out) {
+#pragma omp parallel for
+    for (uint32_t ri = 0; ri < N; ++ri) {
+        uint64_t y[64];
+        double nu = 0.5;
+        for (uint32_t i = 0; i < sizeQ; ++i) {
+            y[i] = orc_mod_mul_fast_const(x[(size_t)i * N + ri], QHatInvModq[i], q[i], QHatInvModqPrecon[i]);
+            nu += (double)y[i] * qInv[i];
+        }
+        size_t alpha           = (size_t)nu;
+        const uint64_t* aQModp = alphaQModp + alpha * sizeP;
+        for (uint32_t j = 0; j < sizeP; ++j) {
+            u128 cur = 0;
+            for (uint32_t i = 0; i < sizeQ; ++i)
+                cur += (u128)y[i] * QHatModp_pq[(size_t)j * sizeQ + i];
+            uint64_t v = orc_barrett128((uint64_t)cur, (uint64_t)(cur >> 64), p[j], mu128[2 * j], mu128[2 * j + 1]);
+            out[(size_t)j * N + ri] = orc_mod_sub_fast(v, aQModp[j], p[j]);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * HYBRID key switching tables — rns-cryptoparameters.cpp:80-350.
+ * The reference computes these with BigInteger products/quotients; every stored value is a
+ * residue of a product of moduli, so 64-bit modular products give the same numbers.
+ * ---------------------------------------------------------------------------------------- */
+struct orc_hybrid {
+    uint32_t N, sizeQ, sizeP, numPartQ, alpha;
+    orc_ctx* ctx; /* limbs [0,sizeQ) = Q, [sizeQ, sizeQ+sizeP) = P */
+    uint64_t *q, *p;
+    uint64_t *PInvModq, *PInvModqPrecon;       /* [sizeQ] */
+    uint64_t *PHatInvModp, *PHatInvModpPrecon; /* [sizeP] */
+    uint64_t* PHatModq;                        /* [sizeP][sizeQ] */
+    uint64_t* muQ128;                          /* [sizeQ][2] modqBarrettMu */
+};
+
+static uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+/* rns-cryptoparameters.cpp:128-176 */
+uint32_t orc_hybrid_select_p(uint32_t N, uint32_t sizeQ, const uint64_t* q, uint32_t numPartQ, uint32_t auxBits,
+                             uint64_t* p, uint64_t* psiP) {
+    uint32_t a = ceil_div(sizeQ, numPartQ);
+    /* maxBits = max bit length of the composite digits: exact via long double log2 is unsafe,
+     * so multiply out in arbitrary precision (little-endian 64-bit limbs). */
+    uint32_t maxBits = 0;
+    for (uint32_t j = 0; j < numPartQ; ++j) {
+        uint64_t big[80];
+        uint32_t len = 1;
+        big[0]       = 1;
+        for (uint32_t i = a * j; i < (j + 1) * a && i < sizeQ; ++i) {
+            uint64_t carry = 0;
+            for (uint32_t k = 0; k < len; ++k) {
+                u128 t = (u128)big[k] * q[i] + carry;
+                big[k] = (uint64_t)t;
+                carry  = (uint64_t)(t >> 64);
+            }
+            if (carry)
+                big[len++] = carry;
+        }
+        uint32_t bits = 64 * (len - 1) + orc_get_msb(big[len - 1]);
+        if (bits > maxBits)
+            maxBits = bits;
+    }
+    uint32_t sizeP     = ceil_div(maxBits, auxBits);
+    uint64_t primeStep = 2 * (uint64_t)N; /* CryptoParametersCKKSRNS::FindAuxPrimeStep, ckksrns-cryptoparameters.cpp:185-188 */
+    uint64_t pPrev     = orc_first_prime(auxBits, primeStep);
+    for (uint32_t i = 0; i < sizeP; ++i) {
+        int foundInQ;
+        do {
+            p[i]     = orc_previous_prime(pPrev, primeStep);
+            foundInQ = 0;
+            for (uint32_t j = 0; j < sizeQ; ++j)
+                if (p[i] == q[j])
+                    foundInQ = 1;
+            pPrev = p[i];
+        } while (foundInQ);
+        psiP[i] = orc_root_of_unity(2 * (uint64_t)N, p[i]);
+    }
+    return sizeP;
+}
+
+orc_hybrid* orc_hybrid_create(uint32_t N, uint32_t sizeQ, const uint64_t* q, const uint64_t* psiQ,
+                              uint32_t sizeP, const uint64_t* p, const uint64_t* psiP, uint32_t numPartQ) {
+    orc_hybrid* h = (orc_hybrid*)calloc(1, sizeof(orc_hybrid));
+    h->N          = N;
+    h->sizeQ      = sizeQ;
+    h->sizeP      = sizeP;
+    h->numPartQ   = numPartQ;
+    h->alpha      = ceil_div(sizeQ, numPartQ); /* :92 */
+    uint32_t L    = sizeQ + sizeP;
+    uint64_t* m   = (uint64_t*)malloc(sizeof(uint64_t) * L);
+    uint64_t* r   = (uint64_t*)malloc(sizeof(uint64_t) * L);
+    memcpy(m, q, sizeof(uint64_t) * sizeQ);
+    memcpy(m + sizeQ, p, sizeof(uint64_t) * sizeP);
+    memcpy(r, psiQ, sizeof(uint64_t) * sizeQ);
+    memcpy(r + sizeQ, psiP, sizeof(uint64_t) * sizeP);
+    h->ctx = orc_ctx_create(N, L, m, r);
+    h->q   = m;
+    h->p   = m + sizeQ;
+    free(r);
+
+    h->PInvModq          = (uint64_t*)malloc(sizeof(uint64_t) * sizeQ);
+    h->PInvModqPrecon    = (uint64_t*)malloc(sizeof(uint64_t) * sizeQ);
+    h->PHatInvModp       = (uint64_t*)malloc(sizeof(uint64_t) * sizeP);
+    h->PHatInvModpPrecon = (uint64_t*)malloc(sizeof(uint64_t) * sizeP);
+    h->PHatModq          = (uint64_t*)malloc(sizeof(uint64_t) * sizeP * sizeQ);
+    h->muQ128            = (uint64_t*)malloc(sizeof(uint64_t) * 2 * sizeQ);
+    /* [P^-1]_{q_i}  (:205-212) */
+    for (uint32_t i = 0; i < sizeQ; ++i) {
+        uint64_t Pmod = 1;
+        for (uint32_t j = 0; j < sizeP; ++j)
+            Pmod = orc_mulmod(Pmod, p[j] % q[i], q[i]);
+        h->PInvModq[i]       = orc_invmod(Pmod, q[i]);
+        h->PInvModqPrecon[i] = orc_prep_mod_mul_const(h->PInvModq[i], q[i]);
+        orc_barrett_mu128(q[i], h->muQ128 + 2 * i);
+    }
+    /* [(P/p_j)^-1]_{p_j}, [P/p_j]_{q_i}  (:214-230) */
+    for (uint32_t j = 0; j < sizeP; ++j) {
+        uint64_t hat = 1;
+        for (uint32_t k = 0; k < sizeP; ++k)
+            if (k != j)
+                hat = orc_mulmod(hat, p[k] % p[j], p[j]);
+        h->PHatInvModp[j]       = orc_invmod(hat, p[j]);
+        h->PHatInvModpPrecon[j] = orc_prep_mod_mul_const(h->PHatInvModp[j], p[j]);
+        for (uint32_t i = 0; i < sizeQ; ++i) {
+            uint64_t v = 1;
+            for (uint32_t k = 0; k < sizeP; ++k)
+                if (k != j)
+                    v = orc_mulmod(v, p[k] % q[i], q[i]);
+            h->PHatModq[(size_t)j * sizeQ + i] = v;
+        }
+    }
+    return h;
+}
+
+void orc_hybrid_destroy(orc_hybrid* h) {
+    if (!h)
+        return;
+    orc_ctx_destroy(h->ctx);
+    free(h->q);
+    free(h->PInvModq);
+    free(h->PInvModqPrecon);
+    free(h->PHatInvModp);
+    free(h->PHatInvModpPrecon);
+    free(h->PHatModq);
+    free(h->muQ128);
+    free(h);
+}
+uint32_t orc_hybrid_alpha(const orc_hybrid* h) { return h->alpha; }
+void orc_hybrid_get_PInvModq(const orc_hybrid* h, uint64_t* out) { memcpy(out, h->PInvModq, 8 * h->sizeQ); }
+void orc_hybrid_get_PHatInvModp(const orc_hybrid* h, uint64_t* out) { memcpy(out, h->PHatInvModp, 8 * h->sizeP); }
+void orc_hybrid_get_PHatModq(const orc_hybrid* h, uint64_t* out) {
+    memcpy(out, h->PHatModq, 8 * (size_t)h->sizeP * h->sizeQ);
+}
+
+/* digit geometry at level sizeQl (keyswitch-hybrid.cpp:329-349): */
+static uint32_t num_parts_at(const orc_hybrid* h, uint32_t sizeQl) {
+    uint32_t n = ceil_div(sizeQl, h->alpha);
+    return n > h->numPartQ ? h->numPartQ : n;
+}
+static uint32_t part_size_at(const orc_hybrid* h, uint32_t part, uint32_t sizeQl) {
+    uint32_t np = num_parts_at(h, sizeQl);
+    if (part == np - 1)
+        return sizeQl - h->alpha * part;
+    return h->alpha;
+}
+
+/* [ (Q_part^(l) / q_i)^-1 ]_{q_i} for the digit truncated to sizePartQl limbs (:297-318) */
+uint32_t orc_hybrid_get_PartQlHatInvModq(const orc_hybrid* h, uint32_t part, uint32_t sizeQl, uint64_t* out) {
+    uint32_t sz    = part_size_at(h, part, sizeQl);
+    uint32_t start = h->alpha * part;
+    for (uint32_t i = 0; i < sz; ++i) {
+        uint64_t qi  = h->q[start + i];
+        uint64_t hat = 1;
+        for (uint32_t k = 0; k < sz; ++k)
+            if (k != i)
+                hat = orc_mulmod(hat, h->q[start + k] % qi, qi);
+        out[i] = orc_invmod(hat, qi);
+    }
+    return sz;
+}
+
+/* complementary basis of digit `part` at level sizeQl (:253-283): all Q_l limbs outside the digit, then P */
+static uint32_t compl_basis(const orc_hybrid* h, uint32_t part, uint32_t sizeQl, uint32_t* limbIdx) {
+    uint32_t sz    = part_size_at(h, part, sizeQl);
+    uint32_t start = h->alpha * part;
+    uint32_t n     = 0;
+    for (uint32_t i = 0; i < sizeQl; ++i)
+        if (i < start || i >= start + sz)
+            limbIdx[n++] = i;
+    for (uint32_t j = 0; j < h->sizeP; ++j)
+        limbIdx[n++] = h->sizeQ + j;
+    return n;
+}
+
+/* [Q_part^(l)/q_i]_{c_j} over the complementary basis (:320-349) -> out[sizePartQl][sizeCompl] */
+uint32_t orc_hybrid_get_PartQlHatModp(const orc_hybrid* h, uint32_t part, uint32_t sizeQl, uint64_t* out,
+                                      uint64_t* complModuli) {
+    uint32_t idx[128];
+    uint32_t nc    = compl_basis(h, part, sizeQl, idx);
+    uint32_t sz    = part_size_at(h, part, sizeQl);
+    uint32_t start = h->alpha * part;
+    const uint64_t* mod = h->q; /* q then p contiguous */
+    for (uint32_t i = 0; i < sz; ++i)
+        for (uint32_t j = 0; j < nc; ++j) {
+            uint64_t cj = mod[idx[j]];
+            uint64_t v  = 1;
+            for (uint32_t k = 0; k < sz; ++k)
+                if (k != i)
+                    v = orc_mulmod(v, h->q[start + k] % cj, cj);
+            out[(size_t)i * nc + j] = v;
+        }
+    if (complModuli)
+        for (uint32_t j = 0; j < nc; ++j)
+            complModuli[j] = mod[idx[j]];
+    return nc;
+}
+
+/* keyswitch-hybrid.cpp:314-379 */
+uint32_t orc_hybrid_precompute_digits(const orc_hybrid* h, const uint64_t* c, uint32_t sizeQl, uint64_t* digits) {
+    const uint32_t N = h->N, sizeP = h->sizeP, sizeQlP = sizeQl + sizeP;
+    const uint32_t np = num_parts_at(h, sizeQl);
+    const uint64_t* mod = h->q;
+    for (uint32_t part = 0; part < np; ++part) {
+        uint32_t sz    = part_size_at(h, part, sizeQl);
+        uint32_t start = h->alpha * part;
+        uint32_t idx[128];
+        uint32_t nc = compl_basis(h, part, sizeQl, idx);
+        /* partsCt = digit limbs of c, to COEFFICIENT */
+        uint64_t* partsCt = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)sz * N);
+        memcpy(partsCt, c + (size_t)start * N, sizeof(uint64_t) * (size_t)sz * N);
+#pragma omp parallel for
+        for (uint32_t i = 0; i < sz; ++i)
+            ctx_inv(h->ctx, partsCt + (size_t)i * N, start + i);
+        uint64_t hatInv[64], hatInvPre[64], cm[128], mu[256];
+        uint64_t* hatModp = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)sz * nc);
+        orc_hybrid_get_PartQlHatInvModq(h, part, sizeQl, hatInv);
+        for (uint32_t i = 0; i < sz; ++i)
+            hatInvPre[i] = orc_prep_mod_mul_const(hatInv[i], h->q[start + i]);
+        orc_hybrid_get_PartQlHatModp(h, part, sizeQl, hatModp, cm);
+        for (uint32_t j = 0; j < nc; ++j)
+            orc_barrett_mu128(cm[j], mu + 2 * j);
+        uint64_t* compl_ = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)nc * N);
+        orc_approx_switch_crt_basis(partsCt, sz, N, h->q + start, hatInv, hatInvPre, hatModp, nc, cm, mu, compl_);
+#pragma omp parallel for
+        for (uint32_t j = 0; j < nc; ++j)
+            ctx_fwd(h->ctx, compl_ + (size_t)j * N, idx[j]);
+        /* assemble in basis Q_l ∪ P (:369-376) */
+        uint64_t* dst = digits + (size_t)part * sizeQlP * N;
+        for (uint32_t i = 0; i < start; ++i)
+            memcpy(dst + (size_t)i * N, compl_ + (size_t)i * N, 8 * (size_t)N);
+        for (uint32_t i = start; i < start + sz; ++i)
+            memcpy(dst + (size_t)i * N, c + (size_t)i * N, 8 * (size_t)N);
+        for (uint32_t i = start + sz; i < sizeQlP; ++i)
+            memcpy(dst + (size_t)i * N, compl_ + (size_t)(i - sz) * N, 8 * (size_t)N);
+        (void)mod;
+        free(partsCt);
+        free(hatModp);
+        free(compl_);
+    }
+    return np;
+}
+
+/* keyswitch-hybrid.cpp:402-435 */
+void orc_hybrid_inner_product(const orc_hybrid* h, const uint64_t* digits, uint32_t numPartQl, uint32_t sizeQl,
+                              const uint64_t* keyB, const uint64_t* keyA, uint64_t* out0, uint64_t* out1) {
+    const uint32_t N = h->N, sizeQlP = sizeQl + h->sizeP, sizeQP = h->sizeQ + h->sizeP;
+    const uint32_t delta = h->sizeQ - sizeQl;
+    memset(out0, 0, sizeof(uint64_t) * (size_t)sizeQlP * N);
+    memset(out1, 0, sizeof(uint64_t) * (size_t)sizeQlP * N);
+    for (uint32_t j = 0; j < numPartQl; ++j) {
+#pragma omp parallel for
+        for (uint32_t i = 0; i < sizeQlP; ++i) {
+            uint32_t idx = (i >= sizeQl) ? i + delta : i;
+            uint64_t qi  = h->q[idx]; /* q then p contiguous: idx in [0, sizeQ+sizeP) */
+            uint64_t mu  = orc_compute_mu(qi);
+            const uint64_t* cji = digits + ((size_t)j * sizeQlP + i) * N;
+            const uint64_t* bji = keyB + ((size_t)j * sizeQP + idx) * N;
+            const uint64_t* aji = keyA + ((size_t)j * sizeQP + idx) * N;
+            uint64_t* e0 = out0 + (size_t)i * N;
+            uint64_t* e1 = out1 + (size_t)i * N;
+            for (uint32_t r = 0; r < N; ++r) {
+                e0[r] = orc_mod_add_fast(e0[r], orc_mod_mul_fast(cji[r], bji[r], qi, mu), qi);
+                e1[r] = orc_mod_add_fast(e1[r], orc_mod_mul_fast(cji[r], aji[r], qi, mu), qi);
+            }
+        }
+    }
+}
+
+/* dcrtpoly-impl.h:966-1005 with t == 0 */
+void orc_hybrid_approx_mod_down(const orc_hybrid* h, const uint64_t* x, uint32_t sizeQl, uint64_t* out) {
+    const uint32_t N = h->N, sizeP = h->sizeP;
+    uint64_t* partP = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)sizeP * N);
+    memcpy(partP, x + (size_t)sizeQl * N, sizeof(uint64_t) * (size_t)sizeP * N);
+#pragma omp parallel for
+    for (uint32_t j = 0; j < sizeP; ++j)
+        ctx_inv(h->ctx, partP + (size_t)j * N, h->sizeQ + j);
+    /* PHatModq is [sizeP][sizeQ]; ApproxSwitchCRTBasis reads QHatModp[i][j] with i over P, j over Q_l:
+     * pass a [sizeP][sizeQl] slice copy */
+    uint64_t* hat = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)sizeP * sizeQl);
+    for (uint32_t j = 0; j < sizeP; ++j)
+        memcpy(hat + (size_t)j * sizeQl, h->PHatModq + (size_t)j * h->sizeQ, 8 * (size_t)sizeQl);
+    uint64_t* sw = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)sizeQl * N);
+    orc_approx_switch_crt_basis(partP, sizeP, N, h->p, h->PHatInvModp, h->PHatInvModpPrecon, hat, sizeQl, h->q,
+                                h->muQ128, sw);
+#pragma omp parallel for
+    for (uint32_t i = 0; i < sizeQl; ++i) {
+        uint64_t qi = h->q[i];
+        uint64_t* s = sw + (size_t)i * N;
+        ctx_fwd(h->ctx, s, i);
+        /* (m_vectors[i] - switched) * PInvModq[i]  — PolyImpl::Times(NativeInteger) -> ModMul Shoup
+         * (mubintvecnat.cpp:295-304) */
+        for (uint32_t r = 0; r < N; ++r) {
+            uint64_t d            = orc_mod_sub_fast(x[(size_t)i * N + r], s[r], qi);
+            out[(size_t)i * N + r] = orc_mod_mul_fast_const(d, h->PInvModq[i], qi, h->PInvModqPrecon[i]);
+        }
+    }
+    free(partP);
+    free(hat);
+    free(sw);
+}
+
+/* keyswitch-hybrid.cpp:308-312 + :381-400 */
+void orc_hybrid_key_switch(const orc_hybrid* h, const uint64_t* c, uint32_t sizeQl, const uint64_t* keyB,
+                           const uint64_t* keyA, uint64_t* out0, uint64_t* out1) {
+    const uint32_t N = h->N, sizeQlP = sizeQl + h->sizeP;
+    uint32_t np      = num_parts_at(h, sizeQl);
+    uint64_t* digits = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)np * sizeQlP * N);
+    uint64_t* e0     = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)sizeQlP * N);
+    uint64_t* e1     = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)sizeQlP * N);
+    orc_hybrid_precompute_digits(h, c, sizeQl, digits);
+    orc_hybrid_inner_product(h, digits, np, sizeQl, keyB, keyA, e0, e1);
+    orc_hybrid_approx_mod_down(h, e0, sizeQl, out0);
+    orc_hybrid_approx_mod_down(h, e1, sizeQl, out1);
+    free(digits);
+    free(e0);
+    free(e1);
+}
+
+/* base-leveledshe.cpp:607-644 (EvalMultCore) + :201-214 (relinearise and add) */
+void orc_ckks_eval_mult_relin(const orc_hybrid* h, const uint64_t* a0, const uint64_t* a1, const uint64_t* b0,
+                              const uint64_t* b1, uint32_t sizeQl, const uint64_t* keyB, const uint64_t* keyA,
+                              uint64_t* c0, uint64_t* c1) {
+    const uint32_t N = h->N;
+    size_t sz        = (size_t)sizeQl * N;
+    uint64_t* d2     = (uint64_t*)malloc(sizeof(uint64_t) * sz);
+    uint64_t* t      = (uint64_t*)malloc(sizeof(uint64_t) * sz);
+    uint64_t* k0     = (uint64_t*)malloc(sizeof(uint64_t) * sz);
+    uint64_t* k1     = (uint64_t*)malloc(sizeof(uint64_t) * sz);
+#pragma omp parallel for
+    for (uint32_t i = 0; i < sizeQl; ++i) {
+        uint64_t qi = h->q[i];
+        size_t o    = (size_t)i * N;
+        orc_vec_mul(c0 + o, a0 + o, b0 + o, N, qi); /* d0 = a0*b0 */
+        orc_vec_mul(c1 + o, a0 + o, b1 + o, N, qi); /* d1 = a0*b1 + a1*b0 */
+        orc_vec_mul(t + o, a1 + o, b0 + o, N, qi);
+        orc_vec_add(c1 + o, c1 + o, t + o, N, qi);
+        orc_vec_mul(d2 + o, a1 + o, b1 + o, N, qi); /* d2 = a1*b1 */
+    }
+    orc_hybrid_key_switch(h, d2, sizeQl, keyB, keyA, k0, k1);
+#pragma omp parallel for
+    for (uint32_t i = 0; i < sizeQl; ++i) {
+        uint64_t qi = h->q[i];
+        size_t o    = (size_t)i * N;
+        orc_vec_add(c0 + o, c0 + o, k0 + o, N, qi);
+        orc_vec_add(c1 + o, c1 + o, k1 + o, N, qi);
+    }
+    free(d2);
+    free(t);
+    free(k0);
+    free(k1);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a15: rescale
+ * ---------------------------------------------------------------------------------------- */
+/* ckksrns-cryptoparameters.cpp:60-81 for the level whose last limb is l = sizeQl-1:
+ * QlQlInvModqlDivqlModq[i] = ((Q^(l-1))^-1 mod q_l * Q^(l-1) / q_l) mod q_i ,  qlInvModq[i] = q_l^-1 mod q_i.
+ * With Q' = Q^(l-1) = prod_{k<l} q_k:  result = floor(Q' * inv / q_l), inv = Q'^-1 mod q_l.
+ * Q'*inv = 1 + m*q_l for an integer m, hence floor(Q'*inv/q_l) = m = (Q'*inv - 1)/q_l, and
+ * m mod q_i = (0*inv - 1) * q_l^-1 = -(q_l^-1) mod q_i  (Q' = 0 mod q_i for i < l). */
+void orc_rescale_tables(const orc_ctx* c, uint32_t sizeQl, uint64_t* QlQlInvModqlDivqlModq, uint64_t* qlInvModq) {
+    uint32_t l  = sizeQl - 1;
+    uint64_t ql = c->q[l];
+    for (uint32_t i = 0; i < l; ++i) {
+        uint64_t qi   = c->q[i];
+        uint64_t inv  = orc_invmod(ql % qi, qi);
+        qlInvModq[i]  = inv;
+        QlQlInvModqlDivqlModq[i] = (qi - inv) % qi;
+    }
+}
+
+/* dcrtpoly-impl.h:693-712, m_format == EVALUATION */
+void orc_drop_last_element_and_scale(const orc_ctx* c, const uint64_t* x, uint32_t sizeQl, uint64_t* out) {
+    const uint32_t N = c->N, l = sizeQl - 1;
+    uint64_t tabA[128], tabB[128];
+    orc_rescale_tables(c, sizeQl, tabA, tabB);
+    uint64_t* last = (uint64_t*)malloc(sizeof(uint64_t) * N);
+    memcpy(last, x + (size_t)l * N, sizeof(uint64_t) * N);
+    ctx_inv(c, last, l);
+#pragma omp parallel for
+    for (uint32_t i = 0; i < l; ++i) {
+        uint64_t qi   = c->q[i];
+        uint64_t* tmp = (uint64_t*)malloc(sizeof(uint64_t) * N);
+        memcpy(tmp, last, sizeof(uint64_t) * N);
+        orc_switch_modulus(tmp, N, c->q[l], qi);
+        orc_vec_mul_const(tmp, tmp, tabA[i], N, qi);
+        ctx_fwd(c, tmp, i);
+        orc_vec_mul_const(out + (size_t)i * N, x + (size_t)i * N, tabB[i], N, qi);
+        orc_vec_add(out + (size_t)i * N, out + (size_t)i * N, tmp, N, qi);
+        free(tmp);
+    }
+    free(last);
+}

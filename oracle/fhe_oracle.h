@@ -1,0 +1,155 @@
+/*
+ * fhe_oracle.h — TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C CPU restatement of the reference algorithms on the lbcrypto::DCRTPoly hot path
+ * (SURVEY.md §8a rows a1..a18).  It is the parity checker for the HIP library: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The product library
+ * (libfhe_hip.so) never links, imports or falls back to anything in oracle/.
+ *
+ * Parity status: PINNED — checked against the reference's own known-answer vectors
+ * (tests/golden/ fixtures, from /root/reference/src/core/unittest and src/pke/unittest) and against
+ * the reference itself compiled from its sources into oracle/_ref/ (tests/test_oracle_vs_ref.py).
+ *
+ * All reference citations are relative to /root/reference/.
+ * Data layout everywhere: a tower is uint64_t[nLimbs][N], limb-major, N contiguous.
+ */
+#ifndef FHE_ORACLE_H
+#define FHE_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------- a1/a2: scalar modular arithmetic ---------------- */
+uint64_t orc_mulmod(uint64_t a, uint64_t b, uint64_t q); /* exact a*b mod q (setup use) */
+uint64_t orc_powmod(uint64_t a, uint64_t e, uint64_t q);
+uint64_t orc_invmod(uint64_t a, uint64_t q);             /* q prime */
+uint32_t orc_get_msb(uint64_t x);                        /* nbtheory.h:169-186 (1-indexed bit length) */
+uint64_t orc_compute_mu(uint64_t q);                     /* ubintnat.h:642-647 */
+uint64_t orc_mod_mul_fast(uint64_t a, uint64_t b, uint64_t q, uint64_t mu);            /* :1348-1361 */
+uint64_t orc_prep_mod_mul_const(uint64_t b, uint64_t q);                               /* :1437-1444 */
+uint64_t orc_mod_mul_fast_const(uint64_t a, uint64_t b, uint64_t q, uint64_t bPrecon); /* :1464-1469 */
+uint64_t orc_mod_add_fast(uint64_t a, uint64_t b, uint64_t q);                         /* :737-743 */
+uint64_t orc_mod_sub_fast(uint64_t a, uint64_t b, uint64_t q);                         /* :911-921 */
+void     orc_barrett_mu128(uint64_t q, uint64_t mu[2]); /* floor(2^128/q): mu[0]=lo, mu[1]=hi */
+uint64_t orc_barrett128(uint64_t a_lo, uint64_t a_hi, uint64_t q, uint64_t mu_lo, uint64_t mu_hi);
+                                                        /* utilities-int.h:60-99 */
+
+/* ---------------- number theory (host-side parameter reproduction) ---------------- */
+int      orc_is_prime(uint64_t n);
+uint64_t orc_first_prime(uint32_t nBits, uint64_t m);    /* nbtheory-impl.h:329-347 */
+uint64_t orc_last_prime(uint32_t nBits, uint64_t m);     /* :349-373 */
+uint64_t orc_next_prime(uint64_t q, uint64_t m);         /* :375-383 */
+uint64_t orc_previous_prime(uint64_t q, uint64_t m);     /* :385-393 */
+uint64_t orc_root_of_unity(uint64_t m, uint64_t q);      /* :183-231 (minimum primitive m-th root) */
+uint32_t orc_reverse_bits(uint32_t x, uint32_t nbits);   /* nbtheory.h:135-157 */
+void     orc_precompute_auto_map(uint32_t n, uint32_t k, uint32_t* precomp); /* nbtheory2.cpp:264-275 */
+uint32_t orc_find_automorphism_index_2n_complex(int32_t i, uint32_t m);      /* nbtheory2.cpp:243-262 */
+/* ILDCRTParams(order, depth, bits) modulus chain: ildcrtparams.h:100-117 */
+void     orc_dcrt_params(uint32_t order, uint32_t nLimbs, uint32_t bits, uint64_t* q, uint64_t* psi);
+
+/* ---------------- a3/a4/a5: negacyclic NTT ---------------- */
+/* tables are uint64_t[N] each; nInv = N^-1 mod q.  transformnat-impl.h:714-756 */
+void orc_ntt_precompute(uint64_t q, uint64_t psi, uint32_t N, uint64_t* tbl, uint64_t* tblPrecon,
+                        uint64_t* tblInv, uint64_t* tblInvPrecon, uint64_t* nInv, uint64_t* nInvPrecon);
+/* in place, natural -> bit-reversed.  transformnat-impl.h:303-374 */
+void orc_ntt_fwd(uint64_t* x, uint32_t N, uint64_t q, const uint64_t* tbl, const uint64_t* tblPrecon);
+/* in place, bit-reversed -> natural, 1/N folded in.  transformnat-impl.h:512-625 */
+void orc_ntt_inv(uint64_t* x, uint32_t N, uint64_t q, const uint64_t* tblInv, const uint64_t* tblInvPrecon,
+                 uint64_t nInv, uint64_t nInvPrecon);
+
+/* A tower context = what DCRTPoly::Params + the static twiddle cache hold. */
+typedef struct orc_ctx orc_ctx;
+orc_ctx* orc_ctx_create(uint32_t N, uint32_t nLimbs, const uint64_t* q, const uint64_t* psi);
+void     orc_ctx_destroy(orc_ctx*);
+uint32_t orc_ctx_n(const orc_ctx*);
+uint32_t orc_ctx_limbs(const orc_ctx*);
+uint64_t orc_ctx_modulus(const orc_ctx*, uint32_t limb);
+/* a6: DCRTPoly::SwitchFormat over a batch of towers x[batch][nSel][N]; limbIdx selects context limbs.
+ * nThreads<=0 -> omp default (the reference's `num_threads(0)` behaviour, dcrtpoly-impl.h:1932-1940) */
+void orc_ntt_fwd_tower(const orc_ctx*, uint64_t* x, const uint32_t* limbIdx, uint32_t nSel, uint32_t batch, int nThreads);
+void orc_ntt_inv_tower(const orc_ctx*, uint64_t* x, const uint32_t* limbIdx, uint32_t nSel, uint32_t batch, int nThreads);
+
+/* ---------------- a7: element-wise vector ops (mubintvecnat.cpp:132-142,229-339) ---------------- */
+void orc_vec_add(uint64_t* out, const uint64_t* a, const uint64_t* b, size_t n, uint64_t q);
+void orc_vec_sub(uint64_t* out, const uint64_t* a, const uint64_t* b, size_t n, uint64_t q);
+void orc_vec_mul(uint64_t* out, const uint64_t* a, const uint64_t* b, size_t n, uint64_t q);
+void orc_vec_mul_const(uint64_t* out, const uint64_t* a, uint64_t c, size_t n, uint64_t q);
+void orc_vec_mult_acc(uint64_t* acc, const uint64_t* v, uint64_t c, size_t n, uint64_t q);
+void orc_vec_neg(uint64_t* out, const uint64_t* a, size_t n, uint64_t q);
+
+/* ---------------- a8: automorphism (poly-impl.h:310-376) ---------------- */
+void orc_automorph_eval(uint64_t* out, const uint64_t* in, uint32_t N, const uint32_t* precomp);
+void orc_automorph_eval_k(uint64_t* out, const uint64_t* in, uint32_t N, uint32_t k);
+void orc_automorph_coeff(uint64_t* out, const uint64_t* in, uint32_t N, uint32_t k, uint64_t q);
+
+/* ---------------- a9: centred modulus switch (mubintvecnat.cpp:109-122) ---------------- */
+void orc_switch_modulus(uint64_t* v, size_t n, uint64_t oldq, uint64_t newq);
+
+/* ---------------- a10: ApproxSwitchCRTBasis fast path (dcrtpoly-impl.h:888-915) ----------------
+ * x[sizeQ][N] (COEFF) -> out[sizeP][N].  QHatModp is [sizeQ][sizeP]; mu128 is [sizeP][2] (lo,hi). */
+void orc_approx_switch_crt_basis(const uint64_t* x, uint32_t sizeQ, uint32_t N, const uint64_t* q,
+                                 const uint64_t* QHatInvModq, const uint64_t* QHatInvModqPrecon,
+                                 const uint64_t* QHatModp, uint32_t sizeP, const uint64_t* p,
+                                 const uint64_t* mu128, uint64_t* out);
+
+/* ---------------- a16: exact SwitchCRTBasis (dcrtpoly-impl.h:1008-1085) ----------------
+ * QHatModp here is [sizeP][sizeQ] (the reference indexes QHatModp[j][i] in this function);
+ * alphaQModp is [sizeQ+1][sizeP]; qInv[i] = 1.0/q_i (double). */
+void orc_switch_crt_basis(const uint64_t* x, uint32_t sizeQ, uint32_t N, const uint64_t* q,
+                          const uint64_t* QHatInvModq, const uint64_t* QHatInvModqPrecon,
+                          const uint64_t* QHatModp_pq, const uint64_t* alphaQModp, uint32_t sizeP,
+                          const uint64_t* p, const uint64_t* mu128, const double* qInv, uint64_t* out);
+
+/* ---------------- HYBRID key-switch tables (rns-cryptoparameters.cpp:80-350) ---------------- */
+typedef struct orc_hybrid orc_hybrid;
+/* Q tower (sizeQ limbs) + P tower (sizeP limbs) given explicitly; numPartQ = dnum. */
+orc_hybrid* orc_hybrid_create(uint32_t N, uint32_t sizeQ, const uint64_t* q, const uint64_t* psiQ,
+                              uint32_t sizeP, const uint64_t* p, const uint64_t* psiP, uint32_t numPartQ);
+void        orc_hybrid_destroy(orc_hybrid*);
+uint32_t    orc_hybrid_alpha(const orc_hybrid*);
+/* choose the P basis the way PrecomputeCRTTables does (rns-cryptoparameters.cpp:128-176);
+ * returns sizeP, fills p/psiP (capacity >= 64). */
+uint32_t    orc_hybrid_select_p(uint32_t N, uint32_t sizeQ, const uint64_t* q, uint32_t numPartQ, uint32_t auxBits,
+                                uint64_t* p, uint64_t* psiP);
+/* table getters (all copied out as flat u64 arrays) */
+void orc_hybrid_get_PInvModq(const orc_hybrid*, uint64_t* out /*[sizeQ]*/);
+void orc_hybrid_get_PHatInvModp(const orc_hybrid*, uint64_t* out /*[sizeP]*/);
+void orc_hybrid_get_PHatModq(const orc_hybrid*, uint64_t* out /*[sizeP][sizeQ]*/);
+/* digit `part` at level sizeQl: PartQlHatInvModq[part][sizePartQl-1] -> out[sizePartQl] */
+uint32_t orc_hybrid_get_PartQlHatInvModq(const orc_hybrid*, uint32_t part, uint32_t sizeQl, uint64_t* out);
+/* PartQlHatModp[sizeQl-1][part] -> out[sizePartQl][sizeCompl]; returns sizeCompl; complModuli[sizeCompl] */
+uint32_t orc_hybrid_get_PartQlHatModp(const orc_hybrid*, uint32_t part, uint32_t sizeQl, uint64_t* out,
+                                      uint64_t* complModuli);
+
+/* a11..a13 composites on explicit arrays. Everything EVALUATION format in/out unless said. */
+/* EvalKeySwitchPrecomputeCore (keyswitch-hybrid.cpp:314-379): c[sizeQl][N] EVAL ->
+ * digits[numPartQl][sizeQl+sizeP][N] EVAL.  returns numPartQl. */
+uint32_t orc_hybrid_precompute_digits(const orc_hybrid*, const uint64_t* c, uint32_t sizeQl, uint64_t* digits);
+/* EvalFastKeySwitchCoreExt (:402-435): key a/b are [numPartQ][sizeQ+sizeP][N];
+ * out0/out1 [sizeQl+sizeP][N] */
+void orc_hybrid_inner_product(const orc_hybrid*, const uint64_t* digits, uint32_t numPartQl, uint32_t sizeQl,
+                              const uint64_t* keyB, const uint64_t* keyA, uint64_t* out0, uint64_t* out1);
+/* ApproxModDown (dcrtpoly-impl.h:966-1005), t=0 (CKKS): x[sizeQl+sizeP][N] EVAL -> out[sizeQl][N] EVAL */
+void orc_hybrid_approx_mod_down(const orc_hybrid*, const uint64_t* x, uint32_t sizeQl, uint64_t* out);
+/* KeySwitchCore (:308-312): full a13. out0/out1 [sizeQl][N] */
+void orc_hybrid_key_switch(const orc_hybrid*, const uint64_t* c, uint32_t sizeQl, const uint64_t* keyB,
+                           const uint64_t* keyA, uint64_t* out0, uint64_t* out1);
+/* a14 EvalMultCore (base-leveledshe.cpp:607-644) + relinearise (:201-214):
+ * ct1 = (a0,a1), ct2 = (b0,b1), each [sizeQl][N] EVAL -> out (c0,c1) */
+void orc_ckks_eval_mult_relin(const orc_hybrid*, const uint64_t* a0, const uint64_t* a1, const uint64_t* b0,
+                              const uint64_t* b1, uint32_t sizeQl, const uint64_t* keyB, const uint64_t* keyA,
+                              uint64_t* c0, uint64_t* c1);
+
+/* ---------------- a15: DropLastElementAndScale (dcrtpoly-impl.h:693-712), EVAL in/out ----------------
+ * x[sizeQl][N] -> out[sizeQl-1][N]; ctx limbs [0,sizeQl) are the tower. Tables are computed inside
+ * the way ckksrns-cryptoparameters.cpp:60-81 does. */
+void orc_drop_last_element_and_scale(const orc_ctx*, const uint64_t* x, uint32_t sizeQl, uint64_t* out);
+void orc_rescale_tables(const orc_ctx*, uint32_t sizeQl, uint64_t* QlQlInvModqlDivqlModq, uint64_t* qlInvModq);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,1 @@
+#include "cereal/cereal.hpp"

@@ -1,0 +1,414 @@
+// ref_shim.cpp — TEST INFRASTRUCTURE ONLY.
+//
+// A C-ABI window onto the REFERENCE ITSELF (lbcrypto::DCRTPoly / ChineseRemainderTransformFTT /
+// CryptoContext compiled unmodified from /root/reference into oracle/_ref/).  Used to
+//   (1) pin oracle/fhe_oracle.c against the real reference on random inputs,
+//   (2) generate tests/golden/* fixtures (tests/golden/make_golden.py),
+//   (3) serve as bench.py's cpu_baseline with kind "reference" (OpenMP, all host cores).
+// Our own code: it only CALLS the reference's public class surface; no reference source is copied.
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <random>
+#include <vector>
+
+#include "openfhe.h"
+#include "utils/utilities-int.h"
+#include <chrono>
+
+using namespace lbcrypto;
+
+namespace {
+using ParmType = DCRTPoly::Params;
+
+std::shared_ptr<ParmType> make_params(uint32_t N, uint32_t L, const uint64_t* q, const uint64_t* psi) {
+    std::vector<NativeInteger> m(L), r(L);
+    for (uint32_t i = 0; i < L; ++i) {
+        m[i] = NativeInteger(q[i]);
+        r[i] = NativeInteger(psi[i]);
+    }
+    return std::make_shared<ParmType>(2 * N, m, r);
+}
+
+DCRTPoly make_poly(const std::shared_ptr<ParmType>& params, const uint64_t* x, Format f) {
+    uint32_t N = params->GetRingDimension();
+    uint32_t L = params->GetParams().size();
+    DCRTPoly p(params, f, true);
+    for (uint32_t i = 0; i < L; ++i) {
+        NativePoly e(params->GetParams()[i], f, true);
+        for (uint32_t j = 0; j < N; ++j)
+            e[j] = NativeInteger(x[(size_t)i * N + j]);
+        p.SetElementAtIndex(i, std::move(e));
+    }
+    return p;
+}
+
+void export_poly(const DCRTPoly& p, uint64_t* out) {
+    uint32_t N = p.GetRingDimension();
+    uint32_t L = p.GetNumOfElements();
+    for (uint32_t i = 0; i < L; ++i) {
+        const auto& e = p.GetElementAtIndex(i);
+        for (uint32_t j = 0; j < N; ++j)
+            out[(size_t)i * N + j] = e[j].ConvertToInt<uint64_t>();
+    }
+}
+
+std::vector<NativeInteger> vecNI(const uint64_t* v, size_t n) {
+    std::vector<NativeInteger> r(n);
+    for (size_t i = 0; i < n; ++i)
+        r[i] = NativeInteger(v[i]);
+    return r;
+}
+std::vector<NativeInteger> precon(const std::vector<NativeInteger>& v, const uint64_t* mod) {
+    std::vector<NativeInteger> r(v.size());
+    for (size_t i = 0; i < v.size(); ++i)
+        r[i] = v[i].PrepModMulConst(NativeInteger(mod[i]));
+    return r;
+}
+std::vector<DoubleNativeInt> mu128(const uint64_t* mod, size_t n) {
+    std::vector<DoubleNativeInt> r(n);
+    for (size_t i = 0; i < n; ++i)
+        r[i] = (BigInteger(1).LShiftEq(128) / BigInteger(mod[i])).ConvertToInt<DoubleNativeInt>();
+    return r;
+}
+}  // namespace
+
+extern "C" {
+
+// ---- number theory ----
+uint64_t ref_last_prime(uint32_t bits, uint64_t m) { return LastPrime<NativeInteger>(bits, m).ConvertToInt<uint64_t>(); }
+uint64_t ref_first_prime(uint32_t bits, uint64_t m) { return FirstPrime<NativeInteger>(bits, m).ConvertToInt<uint64_t>(); }
+uint64_t ref_previous_prime(uint64_t q, uint64_t m) { return PreviousPrime<NativeInteger>(NativeInteger(q), m).ConvertToInt<uint64_t>(); }
+uint64_t ref_next_prime(uint64_t q, uint64_t m) { return NextPrime<NativeInteger>(NativeInteger(q), m).ConvertToInt<uint64_t>(); }
+uint64_t ref_root_of_unity(uint32_t m, uint64_t q) { return RootOfUnity<NativeInteger>(m, NativeInteger(q)).ConvertToInt<uint64_t>(); }
+void ref_dcrt_params(uint32_t order, uint32_t L, uint32_t bits, uint64_t* q, uint64_t* psi) {
+    ILDCRTParams<BigInteger> p(order, L, bits);
+    for (uint32_t i = 0; i < L; ++i) {
+        q[i]   = p.GetParams()[i]->GetModulus().ConvertToInt<uint64_t>();
+        psi[i] = p.GetParams()[i]->GetRootOfUnity().ConvertToInt<uint64_t>();
+    }
+}
+void ref_precompute_auto_map(uint32_t n, uint32_t k, uint32_t* out) {
+    std::vector<uint32_t> v(n);
+    PrecomputeAutoMap(n, k, &v);
+    std::memcpy(out, v.data(), sizeof(uint32_t) * n);
+}
+uint32_t ref_find_automorphism_index_2n_complex(int32_t i, uint32_t m) { return FindAutomorphismIndex2nComplex(i, m); }
+
+// ---- scalar ops ----
+uint64_t ref_mod_mul_fast_const(uint64_t a, uint64_t b, uint64_t q) {
+    NativeInteger B(b), Q(q);
+    return NativeInteger(a).ModMulFastConst(B, Q, B.PrepModMulConst(Q)).ConvertToInt<uint64_t>();
+}
+uint64_t ref_prep_mod_mul_const(uint64_t b, uint64_t q) { return NativeInteger(b).PrepModMulConst(NativeInteger(q)).ConvertToInt<uint64_t>(); }
+uint64_t ref_compute_mu(uint64_t q) { return NativeInteger(q).ComputeMu().ConvertToInt<uint64_t>(); }
+uint64_t ref_mod_mul_fast(uint64_t a, uint64_t b, uint64_t q) {
+    NativeInteger Q(q);
+    return NativeInteger(a).ModMulFast(NativeInteger(b), Q, Q.ComputeMu()).ConvertToInt<uint64_t>();
+}
+uint64_t ref_barrett128(uint64_t lo, uint64_t hi, uint64_t q) {
+    DoubleNativeInt a  = ((DoubleNativeInt)hi << 64) | lo;
+    DoubleNativeInt mu = (BigInteger(1).LShiftEq(128) / BigInteger(q)).ConvertToInt<DoubleNativeInt>();
+    return BarrettUint128ModUint64(a, q, mu);
+}
+
+// ---- single-limb NTT through ChineseRemainderTransformFTT (the FTT hook, math-hal.h:105-106) ----
+void ref_ntt(uint64_t q, uint64_t psi, uint32_t N, uint64_t* x, int inverse) {
+    NativeVector v(N, NativeInteger(q));
+    for (uint32_t i = 0; i < N; ++i)
+        v[i] = NativeInteger(x[i]);
+    if (inverse)
+        ChineseRemainderTransformFTT<NativeVector>().InverseTransformFromBitReverseInPlace(NativeInteger(psi), 2 * N, &v);
+    else
+        ChineseRemainderTransformFTT<NativeVector>().ForwardTransformToBitReverseInPlace(NativeInteger(psi), 2 * N, &v);
+    for (uint32_t i = 0; i < N; ++i)
+        x[i] = v[i].ConvertToInt<uint64_t>();
+}
+
+// ---- DCRTPoly session: keeps `batch` reference DCRTPoly objects alive so SwitchFormat / operator*=
+//      can be timed without conversion overhead (cpu_baseline kind "reference") ----
+struct RefTowers {
+    std::shared_ptr<ParmType> params;
+    std::vector<DCRTPoly> polys;
+};
+void* ref_towers_create(uint32_t N, uint32_t L, const uint64_t* q, const uint64_t* psi, const uint64_t* x,
+                        uint32_t batch, int evalFormat) {
+    auto* t   = new RefTowers;
+    t->params = make_params(N, L, q, psi);
+    for (uint32_t b = 0; b < batch; ++b)
+        t->polys.push_back(make_poly(t->params, x + (size_t)b * L * N, evalFormat ? Format::EVALUATION : Format::COEFFICIENT));
+    return t;
+}
+void ref_towers_destroy(void* h) { delete static_cast<RefTowers*>(h); }
+void ref_towers_switch_format(void* h) {  // DCRTPolyImpl::SwitchFormat, dcrtpoly-impl.h:1932-1940
+    for (auto& p : static_cast<RefTowers*>(h)->polys)
+        p.SwitchFormat();
+}
+void ref_towers_mul_eq(void* h, void* other) {  // operator*=  dcrtpoly-impl.h:395-408
+    auto& a = static_cast<RefTowers*>(h)->polys;
+    auto& b = static_cast<RefTowers*>(other)->polys;
+    for (size_t i = 0; i < a.size(); ++i)
+        a[i] *= b[i];
+}
+void ref_towers_add_eq(void* h, void* other) {
+    auto& a = static_cast<RefTowers*>(h)->polys;
+    auto& b = static_cast<RefTowers*>(other)->polys;
+    for (size_t i = 0; i < a.size(); ++i)
+        a[i] += b[i];
+}
+void ref_towers_sub_eq(void* h, void* other) {
+    auto& a = static_cast<RefTowers*>(h)->polys;
+    auto& b = static_cast<RefTowers*>(other)->polys;
+    for (size_t i = 0; i < a.size(); ++i)
+        a[i] -= b[i];
+}
+void ref_towers_export(void* h, uint64_t* out) {
+    auto* t    = static_cast<RefTowers*>(h);
+    uint32_t N = t->params->GetRingDimension(), L = t->params->GetParams().size();
+    for (size_t b = 0; b < t->polys.size(); ++b)
+        export_poly(t->polys[b], out + b * (size_t)L * N);
+}
+
+// ---- automorphism, modulus switch ----
+void ref_automorph(uint32_t N, uint32_t L, const uint64_t* q, const uint64_t* psi, const uint64_t* in, uint64_t* out,
+                   uint32_t k, int evalFormat, int usePrecomp) {
+    auto params = make_params(N, L, q, psi);
+    auto p      = make_poly(params, in, evalFormat ? Format::EVALUATION : Format::COEFFICIENT);
+    if (usePrecomp) {
+        std::vector<uint32_t> pre(N);
+        PrecomputeAutoMap(N, k, &pre);
+        export_poly(p.AutomorphismTransform(k, pre), out);
+    }
+    else {
+        export_poly(p.AutomorphismTransform(k), out);
+    }
+}
+void ref_switch_modulus(uint64_t* v, uint32_t n, uint64_t oldq, uint64_t newq) {
+    NativeVector x(n, NativeInteger(oldq));
+    for (uint32_t i = 0; i < n; ++i)
+        x[i] = NativeInteger(v[i]);
+    x.SwitchModulus(NativeInteger(newq));
+    for (uint32_t i = 0; i < n; ++i)
+        v[i] = x[i].ConvertToInt<uint64_t>();
+}
+
+// ---- basis conversions with caller-provided tables ----
+// QHatModp is [sizeQ][sizeP] (as ApproxSwitchCRTBasis indexes it)
+void ref_approx_switch_crt_basis(uint32_t N, uint32_t sizeQ, const uint64_t* q, const uint64_t* psiQ, const uint64_t* x,
+                                 const uint64_t* QHatInvModq, const uint64_t* QHatModp, uint32_t sizeP,
+                                 const uint64_t* p, const uint64_t* psiP, uint64_t* out) {
+    auto pq = make_params(N, sizeQ, q, psiQ);
+    auto pp = make_params(N, sizeP, p, psiP);
+    auto X  = make_poly(pq, x, Format::COEFFICIENT);
+    auto hi = vecNI(QHatInvModq, sizeQ);
+    std::vector<std::vector<NativeInteger>> hm(sizeQ);
+    for (uint32_t i = 0; i < sizeQ; ++i)
+        hm[i] = vecNI(QHatModp + (size_t)i * sizeP, sizeP);
+    auto r = X.ApproxSwitchCRTBasis(pq, pp, hi, precon(hi, q), hm, mu128(p, sizeP));
+    export_poly(r, out);
+}
+// QHatModp is [sizeP][sizeQ]; alphaQModp [sizeQ+1][sizeP]
+void ref_switch_crt_basis(uint32_t N, uint32_t sizeQ, const uint64_t* q, const uint64_t* psiQ, const uint64_t* x,
+                          const uint64_t* QHatInvModq, const uint64_t* QHatModp_pq, const uint64_t* alphaQModp,
+                          uint32_t sizeP, const uint64_t* p, const uint64_t* psiP, const double* qInv, uint64_t* out) {
+    auto pq = make_params(N, sizeQ, q, psiQ);
+    auto pp = make_params(N, sizeP, p, psiP);
+    auto X  = make_poly(pq, x, Format::COEFFICIENT);
+    auto hi = vecNI(QHatInvModq, sizeQ);
+    std::vector<std::vector<NativeInteger>> hm(sizeP), al(sizeQ + 1);
+    for (uint32_t j = 0; j < sizeP; ++j)
+        hm[j] = vecNI(QHatModp_pq + (size_t)j * sizeQ, sizeQ);
+    for (uint32_t a = 0; a <= sizeQ; ++a)
+        al[a] = vecNI(alphaQModp + (size_t)a * sizeP, sizeP);
+    std::vector<double> qi(qInv, qInv + sizeQ);
+    auto r = X.SwitchCRTBasis(pp, hi, precon(hi, q), hm, al, mu128(p, sizeP), qi);
+    export_poly(r, out);
+}
+// DropLastElementAndScale with caller tables (EVAL in/out)
+void ref_drop_last_element_and_scale(uint32_t N, uint32_t sizeQl, const uint64_t* q, const uint64_t* psi,
+                                     const uint64_t* x, const uint64_t* tabA, const uint64_t* tabB, uint64_t* out) {
+    auto pq = make_params(N, sizeQl, q, psi);
+    auto X  = make_poly(pq, x, Format::EVALUATION);
+    X.DropLastElementAndScale(vecNI(tabA, sizeQl - 1), vecNI(tabB, sizeQl - 1));
+    export_poly(X, out);
+}
+
+// ---- CKKS session: the reference's own context, keys, ciphertexts (config 3 shape) ----
+struct RefCkks {
+    CryptoContext<DCRTPoly> cc;
+    KeyPair<DCRTPoly> kp;
+    std::vector<Ciphertext<DCRTPoly>> cts;
+};
+
+void* ref_ckks_create(uint32_t ringDim, uint32_t multDepth, uint32_t scalingModSize, uint32_t firstModSize,
+                      uint32_t numLargeDigits, int scalTech) {
+    CCParams<CryptoContextCKKSRNS> parameters;
+    parameters.SetSecurityLevel(HEStd_NotSet);
+    parameters.SetRingDim(ringDim);
+    parameters.SetMultiplicativeDepth(multDepth);
+    parameters.SetScalingModSize(scalingModSize);
+    parameters.SetFirstModSize(firstModSize);
+    parameters.SetKeySwitchTechnique(HYBRID);
+    parameters.SetScalingTechnique(static_cast<ScalingTechnique>(scalTech));
+    if (numLargeDigits > 0)
+        parameters.SetNumLargeDigits(numLargeDigits);
+    auto* s = new RefCkks;
+    s->cc   = GenCryptoContext(parameters);
+    s->cc->Enable(PKE);
+    s->cc->Enable(KEYSWITCH);
+    s->cc->Enable(LEVELEDSHE);
+    s->kp = s->cc->KeyGen();
+    s->cc->EvalMultKeyGen(s->kp.secretKey);
+    return s;
+}
+void ref_ckks_destroy(void* h) {
+    auto* s = static_cast<RefCkks*>(h);
+    s->cc->ClearEvalMultKeys();
+    delete s;
+}
+// info[0]=N, [1]=sizeQ, [2]=sizeP, [3]=numPartQ, [4]=numPerPartQ(alpha)
+void ref_ckks_info(void* h, uint32_t* info) {
+    auto* s       = static_cast<RefCkks*>(h);
+    const auto cp = std::dynamic_pointer_cast<CryptoParametersRNS>(s->cc->GetCryptoParameters());
+    info[0]       = cp->GetElementParams()->GetRingDimension();
+    info[1]       = cp->GetElementParams()->GetParams().size();
+    info[2]       = cp->GetParamsP()->GetParams().size();
+    info[3]       = cp->GetNumPartQ();
+    info[4]       = cp->GetNumPerPartQ();
+}
+void ref_ckks_get_moduli(void* h, uint64_t* q, uint64_t* psiQ, uint64_t* p, uint64_t* psiP) {
+    auto* s       = static_cast<RefCkks*>(h);
+    const auto cp = std::dynamic_pointer_cast<CryptoParametersRNS>(s->cc->GetCryptoParameters());
+    const auto& Q = cp->GetElementParams()->GetParams();
+    const auto& P = cp->GetParamsP()->GetParams();
+    for (size_t i = 0; i < Q.size(); ++i) {
+        q[i]    = Q[i]->GetModulus().ConvertToInt<uint64_t>();
+        psiQ[i] = Q[i]->GetRootOfUnity().ConvertToInt<uint64_t>();
+    }
+    for (size_t i = 0; i < P.size(); ++i) {
+        p[i]    = P[i]->GetModulus().ConvertToInt<uint64_t>();
+        psiP[i] = P[i]->GetRootOfUnity().ConvertToInt<uint64_t>();
+    }
+}
+// relinearisation key: b/a vectors, each [numPartQ][sizeQ+sizeP][N]
+void ref_ckks_get_relin_key(void* h, uint64_t* keyB, uint64_t* keyA) {
+    auto* s        = static_cast<RefCkks*>(h);
+    const auto& ek = CryptoContextImpl<DCRTPoly>::GetEvalMultKeyVector(s->kp.secretKey->GetKeyTag())[0];
+    const auto& av = ek->GetAVector();
+    const auto& bv = ek->GetBVector();
+    size_t stride  = (size_t)av[0].GetNumOfElements() * av[0].GetRingDimension();
+    for (size_t j = 0; j < av.size(); ++j) {
+        export_poly(bv[j], keyB + j * stride);
+        export_poly(av[j], keyA + j * stride);
+    }
+}
+// PrecomputeCRTTables outputs for cross-checking the oracle's / product's table builders
+void ref_ckks_get_tables(void* h, uint64_t* PInvModq, uint64_t* PHatInvModp, uint64_t* PHatModq /*[sizeP][sizeQ]*/) {
+    auto* s       = static_cast<RefCkks*>(h);
+    const auto cp = std::dynamic_pointer_cast<CryptoParametersRNS>(s->cc->GetCryptoParameters());
+    size_t sizeQ = cp->GetElementParams()->GetParams().size(), sizeP = cp->GetParamsP()->GetParams().size();
+    for (size_t i = 0; i < sizeQ; ++i)
+        PInvModq[i] = cp->GetPInvModq()[i].ConvertToInt<uint64_t>();
+    for (size_t j = 0; j < sizeP; ++j) {
+        PHatInvModp[j] = cp->GetPHatInvModp()[j].ConvertToInt<uint64_t>();
+        for (size_t i = 0; i < sizeQ; ++i)
+            PHatModq[j * sizeQ + i] = cp->GetPHatModq()[j][i].ConvertToInt<uint64_t>();
+    }
+}
+// PartQlHatInvModq(part, sizePartQl-1) and PartQlHatModp(sizeQl-1, part) ([sizePartQl][sizeCompl]); returns sizeCompl
+uint32_t ref_ckks_get_part_tables(void* h, uint32_t part, uint32_t sizeQl, uint64_t* hatInv, uint64_t* hatModp,
+                                  uint64_t* complModuli) {
+    auto* s       = static_cast<RefCkks*>(h);
+    const auto cp = std::dynamic_pointer_cast<CryptoParametersRNS>(s->cc->GetCryptoParameters());
+    uint32_t alpha = cp->GetNumPerPartQ();
+    uint32_t numPartQl = (sizeQl + alpha - 1) / alpha;
+    if (numPartQl > cp->GetNumberOfQPartitions())
+        numPartQl = cp->GetNumberOfQPartitions();
+    uint32_t sizePartQl = (part == numPartQl - 1) ? sizeQl - alpha * part : alpha;
+    const auto& hi = cp->GetPartQlHatInvModq(part, sizePartQl - 1);
+    for (uint32_t i = 0; i < sizePartQl; ++i)
+        hatInv[i] = hi[i].ConvertToInt<uint64_t>();
+    const auto& hm    = cp->GetPartQlHatModp(sizeQl - 1, part);
+    const auto& compl_ = cp->GetParamsComplPartQ(sizeQl - 1, part)->GetParams();
+    uint32_t nc       = compl_.size();
+    for (uint32_t i = 0; i < sizePartQl; ++i)
+        for (uint32_t j = 0; j < nc; ++j)
+            hatModp[(size_t)i * nc + j] = hm[i][j].ConvertToInt<uint64_t>();
+    for (uint32_t j = 0; j < nc; ++j)
+        complModuli[j] = compl_[j]->GetModulus().ConvertToInt<uint64_t>();
+    return nc;
+}
+// rescale tables at the level with sizeQl limbs (ckksrns-cryptoparameters.cpp:60-81): index k = sizeQ - sizeQl
+void ref_ckks_get_rescale_tables(void* h, uint32_t sizeQl, uint64_t* tabA, uint64_t* tabB) {
+    auto* s       = static_cast<RefCkks*>(h);
+    const auto cp = std::dynamic_pointer_cast<CryptoParametersCKKSRNS>(s->cc->GetCryptoParameters());
+    size_t sizeQ  = cp->GetElementParams()->GetParams().size();
+    const auto& A = cp->GetQlQlInvModqlDivqlModq(sizeQ - sizeQl);
+    const auto& B = cp->GetqlInvModq(sizeQ - sizeQl);
+    for (size_t i = 0; i + 1 < sizeQl; ++i) {
+        tabA[i] = A[i].ConvertToInt<uint64_t>();
+        tabB[i] = B[i].ConvertToInt<uint64_t>();
+    }
+}
+// encrypt a deterministic message; returns ciphertext index in the session
+int ref_ckks_encrypt(void* h, uint32_t seed, uint32_t level) {
+    auto* s        = static_cast<RefCkks*>(h);
+    uint32_t slots = s->cc->GetRingDimension() / 2;
+    std::mt19937_64 gen(seed);
+    std::uniform_real_distribution<double> dist(-1.0, 1.0);
+    std::vector<double> v(slots);
+    for (auto& e : v)
+        e = dist(gen);
+    Plaintext pt = s->cc->MakeCKKSPackedPlaintext(v, 1, level);
+    s->cts.push_back(s->cc->Encrypt(s->kp.publicKey, pt));
+    return static_cast<int>(s->cts.size()) - 1;
+}
+// info[0]=#elements, [1]=sizeQl, [2]=noiseScaleDeg, [3]=level
+void ref_ct_info(void* h, int ct, uint32_t* info) {
+    auto& c = static_cast<RefCkks*>(h)->cts[ct];
+    info[0] = c->GetElements().size();
+    info[1] = c->GetElements()[0].GetNumOfElements();
+    info[2] = c->GetNoiseScaleDeg();
+    info[3] = c->GetLevel();
+}
+void ref_ct_export(void* h, int ct, uint32_t elem, uint64_t* out) {
+    export_poly(static_cast<RefCkks*>(h)->cts[ct]->GetElements()[elem], out);
+}
+int ref_ckks_eval_mult(void* h, int a, int b) {  // cryptocontext.h:1871-1879
+    auto* s = static_cast<RefCkks*>(h);
+    s->cts.push_back(s->cc->EvalMult(s->cts[a], s->cts[b]));
+    return static_cast<int>(s->cts.size()) - 1;
+}
+int ref_ckks_eval_mult_no_relin(void* h, int a, int b) {
+    auto* s = static_cast<RefCkks*>(h);
+    s->cts.push_back(s->cc->EvalMultNoRelin(s->cts[a], s->cts[b]));
+    return static_cast<int>(s->cts.size()) - 1;
+}
+int ref_ckks_rescale(void* h, int a) {
+    auto* s = static_cast<RefCkks*>(h);
+    s->cts.push_back(s->cc->Rescale(s->cts[a]));
+    return static_cast<int>(s->cts.size()) - 1;
+}
+// time `reps` EvalMult calls on (a,b); returns seconds per call (cpu_baseline kind "reference")
+double ref_ckks_time_eval_mult(void* h, int a, int b, int reps) {
+    auto* s = static_cast<RefCkks*>(h);
+    auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps; ++r) {
+        auto c = s->cc->EvalMult(s->cts[a], s->cts[b]);
+        (void)c;
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double>(t1 - t0).count() / reps;
+}
+void ref_ckks_decrypt(void* h, int ct, double* out, uint32_t n) {
+    auto* s = static_cast<RefCkks*>(h);
+    Plaintext pt;
+    s->cc->Decrypt(s->kp.secretKey, s->cts[ct], &pt);
+    pt->SetLength(n);
+    auto v = pt->GetRealPackedValue();
+    for (uint32_t i = 0; i < n && i < v.size(); ++i)
+        out[i] = v[i];
+}
+int ref_omp_threads() { return OpenFHEParallelControls.GetNumThreads(); }
+
+}  // extern "C"

@@ -1,0 +1,175 @@
+"""ctypes loaders for the three native libraries used by the tests.
+
+  oracle  = oracle/libfhe_oracle.so      (our C restatement; TEST infrastructure)
+  ref     = oracle/_ref/libref_shim.so   (the reference itself, compiled from /root/reference; optional)
+  hip     = the product C-ABI library (openfhe-development_amd/csrc/libfhe_hip.so)
+"""
+import ctypes as C
+import os
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "libfhe_oracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libref_shim.so")
+HIP_SO = os.path.join(ROOT, "openfhe-development_amd", "csrc", "libfhe_hip.so")
+
+u64 = C.c_uint64
+u32 = C.c_uint32
+i32 = C.c_int32
+vp = C.c_void_p
+P64 = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+P32 = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+PF64 = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+
+
+def _sig(lib, name, res, args):
+    f = getattr(lib, name)
+    f.restype = res
+    f.argtypes = args
+    return f
+
+
+_oracle = None
+
+
+def load_oracle():
+    global _oracle
+    if _oracle is not None:
+        return _oracle
+    if not os.path.exists(ORACLE_SO):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+    L = C.CDLL(ORACLE_SO)
+    S = lambda n, r, a: _sig(L, n, r, a)
+    S("orc_mulmod", u64, [u64, u64, u64])
+    S("orc_powmod", u64, [u64, u64, u64])
+    S("orc_invmod", u64, [u64, u64])
+    S("orc_get_msb", u32, [u64])
+    S("orc_compute_mu", u64, [u64])
+    S("orc_mod_mul_fast", u64, [u64, u64, u64, u64])
+    S("orc_prep_mod_mul_const", u64, [u64, u64])
+    S("orc_mod_mul_fast_const", u64, [u64, u64, u64, u64])
+    S("orc_mod_add_fast", u64, [u64, u64, u64])
+    S("orc_mod_sub_fast", u64, [u64, u64, u64])
+    S("orc_barrett_mu128", None, [u64, P64])
+    S("orc_barrett128", u64, [u64, u64, u64, u64, u64])
+    S("orc_is_prime", C.c_int, [u64])
+    S("orc_first_prime", u64, [u32, u64])
+    S("orc_last_prime", u64, [u32, u64])
+    S("orc_next_prime", u64, [u64, u64])
+    S("orc_previous_prime", u64, [u64, u64])
+    S("orc_root_of_unity", u64, [u64, u64])
+    S("orc_reverse_bits", u32, [u32, u32])
+    S("orc_precompute_auto_map", None, [u32, u32, P32])
+    S("orc_find_automorphism_index_2n_complex", u32, [i32, u32])
+    S("orc_dcrt_params", None, [u32, u32, u32, P64, P64])
+    S("orc_ntt_precompute", None, [u64, u64, u32, P64, P64, P64, P64, P64, P64])
+    S("orc_ntt_fwd", None, [P64, u32, u64, P64, P64])
+    S("orc_ntt_inv", None, [P64, u32, u64, P64, P64, u64, u64])
+    S("orc_ctx_create", vp, [u32, u32, P64, P64])
+    S("orc_ctx_destroy", None, [vp])
+    S("orc_ntt_fwd_tower", None, [vp, P64, vp, u32, u32, C.c_int])
+    S("orc_ntt_inv_tower", None, [vp, P64, vp, u32, u32, C.c_int])
+    for n in ("orc_vec_add", "orc_vec_sub", "orc_vec_mul"):
+        S(n, None, [P64, P64, P64, C.c_size_t, u64])
+    S("orc_vec_mul_const", None, [P64, P64, u64, C.c_size_t, u64])
+    S("orc_vec_mult_acc", None, [P64, P64, u64, C.c_size_t, u64])
+    S("orc_vec_neg", None, [P64, P64, C.c_size_t, u64])
+    S("orc_automorph_eval", None, [P64, P64, u32, P32])
+    S("orc_automorph_eval_k", None, [P64, P64, u32, u32])
+    S("orc_automorph_coeff", None, [P64, P64, u32, u32, u64])
+    S("orc_switch_modulus", None, [P64, C.c_size_t, u64, u64])
+    S("orc_approx_switch_crt_basis", None, [P64, u32, u32, P64, P64, P64, P64, u32, P64, P64, P64])
+    S("orc_switch_crt_basis", None, [P64, u32, u32, P64, P64, P64, P64, P64, u32, P64, P64, PF64, P64])
+    S("orc_hybrid_create", vp, [u32, u32, P64, P64, u32, P64, P64, u32])
+    S("orc_hybrid_destroy", None, [vp])
+    S("orc_hybrid_alpha", u32, [vp])
+    S("orc_hybrid_select_p", u32, [u32, u32, P64, u32, u32, P64, P64])
+    S("orc_hybrid_get_PInvModq", None, [vp, P64])
+    S("orc_hybrid_get_PHatInvModp", None, [vp, P64])
+    S("orc_hybrid_get_PHatModq", None, [vp, P64])
+    S("orc_hybrid_get_PartQlHatInvModq", u32, [vp, u32, u32, P64])
+    S("orc_hybrid_get_PartQlHatModp", u32, [vp, u32, u32, P64, P64])
+    S("orc_hybrid_precompute_digits", u32, [vp, P64, u32, P64])
+    S("orc_hybrid_inner_product", None, [vp, P64, u32, u32, P64, P64, P64, P64])
+    S("orc_hybrid_approx_mod_down", None, [vp, P64, u32, P64])
+    S("orc_hybrid_key_switch", None, [vp, P64, u32, P64, P64, P64, P64])
+    S("orc_ckks_eval_mult_relin", None, [vp, P64, P64, P64, P64, u32, P64, P64, P64, P64])
+    S("orc_drop_last_element_and_scale", None, [vp, P64, u32, P64])
+    S("orc_rescale_tables", None, [vp, u32, P64, P64])
+    _oracle = L
+    return L
+
+
+_ref = None
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def load_ref():
+    global _ref
+    if _ref is not None:
+        return _ref
+    L = C.CDLL(REF_SO)
+    S = lambda n, r, a: _sig(L, n, r, a)
+    S("ref_last_prime", u64, [u32, u64])
+    S("ref_first_prime", u64, [u32, u64])
+    S("ref_previous_prime", u64, [u64, u64])
+    S("ref_next_prime", u64, [u64, u64])
+    S("ref_root_of_unity", u64, [u32, u64])
+    S("ref_dcrt_params", None, [u32, u32, u32, P64, P64])
+    S("ref_precompute_auto_map", None, [u32, u32, P32])
+    S("ref_find_automorphism_index_2n_complex", u32, [i32, u32])
+    S("ref_mod_mul_fast_const", u64, [u64, u64, u64])
+    S("ref_prep_mod_mul_const", u64, [u64, u64])
+    S("ref_compute_mu", u64, [u64])
+    S("ref_mod_mul_fast", u64, [u64, u64, u64])
+    S("ref_barrett128", u64, [u64, u64, u64])
+    S("ref_ntt", None, [u64, u64, u32, P64, C.c_int])
+    S("ref_towers_create", vp, [u32, u32, P64, P64, P64, u32, C.c_int])
+    S("ref_towers_destroy", None, [vp])
+    S("ref_towers_switch_format", None, [vp])
+    S("ref_towers_mul_eq", None, [vp, vp])
+    S("ref_towers_add_eq", None, [vp, vp])
+    S("ref_towers_sub_eq", None, [vp, vp])
+    S("ref_towers_export", None, [vp, P64])
+    S("ref_automorph", None, [u32, u32, P64, P64, P64, P64, u32, C.c_int, C.c_int])
+    S("ref_switch_modulus", None, [P64, u32, u64, u64])
+    S("ref_approx_switch_crt_basis", None, [u32, u32, P64, P64, P64, P64, P64, u32, P64, P64, P64])
+    S("ref_switch_crt_basis", None, [u32, u32, P64, P64, P64, P64, P64, P64, u32, P64, P64, PF64, P64])
+    S("ref_drop_last_element_and_scale", None, [u32, u32, P64, P64, P64, P64, P64, P64])
+    S("ref_ckks_create", vp, [u32, u32, u32, u32, u32, C.c_int])
+    S("ref_ckks_destroy", None, [vp])
+    S("ref_ckks_info", None, [vp, P32])
+    S("ref_ckks_get_moduli", None, [vp, P64, P64, P64, P64])
+    S("ref_ckks_get_relin_key", None, [vp, P64, P64])
+    S("ref_ckks_get_tables", None, [vp, P64, P64, P64])
+    S("ref_ckks_get_part_tables", u32, [vp, u32, u32, P64, P64, P64])
+    S("ref_ckks_get_rescale_tables", None, [vp, u32, P64, P64])
+    S("ref_ckks_encrypt", C.c_int, [vp, u32, u32])
+    S("ref_ct_info", None, [vp, C.c_int, P32])
+    S("ref_ct_export", None, [vp, C.c_int, u32, P64])
+    S("ref_ckks_eval_mult", C.c_int, [vp, C.c_int, C.c_int])
+    S("ref_ckks_eval_mult_no_relin", C.c_int, [vp, C.c_int, C.c_int])
+    S("ref_ckks_rescale", C.c_int, [vp, C.c_int])
+    S("ref_ckks_time_eval_mult", C.c_double, [vp, C.c_int, C.c_int, C.c_int])
+    S("ref_ckks_decrypt", None, [vp, C.c_int, PF64, u32])
+    S("ref_omp_threads", C.c_int, [])
+    _ref = L
+    return L
+
+
+def rand_residues(rng, q, shape):
+    """uniform residues in [0,q) from a numpy Generator (q < 2^63)."""
+    return rng.integers(0, int(q), size=shape, dtype=np.uint64)
+
+
+def rand_tower(rng, qs, N, batch=None):
+    L = len(qs)
+    shape = (L, N) if batch is None else (batch, L, N)
+    out = np.empty(shape, dtype=np.uint64)
+    for i, q in enumerate(qs):
+        out[..., i, :] = rng.integers(0, int(q), size=out[..., i, :].shape, dtype=np.uint64)
+    return out
