@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X DCRTPoly backend.
+
+Metric (BASELINE.json): "NTT GB/s vs HBM roofline + CKKS EvalMultKeySwitch/sec, N=2^16 L=30, 1/2/4/8 GPU".
+One step = one pass of the hot path over one batch of synthetic input already resident in HBM:
+    forward NTT + inverse NTT of a batch of B = 1024 polynomials, N = 2^16, L = 30 60-bit RNS limbs
+    (BASELINE config 2: [1024][30][65536] uint64 = 16.1 GB per GPU, ILDCRTParams(2N, 30, 60) moduli).
+value = algorithmic GB/s = (4 * 8 * N * L * B bytes per step, i.e. each transform reads and writes the tower
+once) * n_gpus / step time.  Multi-GPU: the batch of independent polynomials is sharded, B per GPU (weak
+scaling), no collective on the data path; the barrier + max-over-ranks timing uses torch.distributed (RCCL).
+
+Extra fields on the same JSON line: `roofline` (dominant kernel, live hipEvent timing), `cpu_baseline`
+(reference compiled from its own sources, or the oracle port, timed on this host) and `evalmult` (CKKS
+EvalMult + HYBRID key switch throughput at config 3's shape: N=2^16, l=21, k=7, dnum=3).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from openfhe_amd import fhe_hip as fh  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--logn", type=int, default=16)
+    ap.add_argument("--limbs", type=int, default=30)
+    ap.add_argument("--batch", type=int, default=1024, help="polynomials per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-evalmult", action="store_true")
+    ap.add_argument("--evalmult-batch", type=int, default=64, help="ciphertexts per GPU in the EvalMult leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def fill_random_tower(ctx, q, batch, seed, seed_polys=8):
+    """[batch][L][N] uniform residues in HBM: `seed_polys` towers generated on the host, replicated on device."""
+    rng = np.random.default_rng(seed)
+    L, N = len(q), ctx.N
+    seed_polys = min(seed_polys, batch)
+    host = np.empty((seed_polys, L, N), np.uint64)
+    for i, qi in enumerate(q):
+        host[:, i, :] = rng.integers(0, int(qi), size=(seed_polys, N), dtype=np.uint64)
+    dev = ctx.malloc(batch * L * N * 8)
+    lib = ctx.lib
+    lib.check(lib.L.fhe_memcpy_h2d(ctx.h, dev, host.ctypes.data_as(C.c_void_p), host.nbytes, None))
+    ctx.sync()
+    done = seed_polys
+    stride = L * N * 8
+    while done < batch:
+        n = min(done, batch - done)
+        lib.check(lib.L.fhe_memcpy_d2d(ctx.h, C.c_void_p(dev.value + done * stride), dev, n * stride, None))
+        done += n
+    ctx.sync()
+    return dev
+
+
+def cpu_baseline(q, psi, logN, L, seconds):
+    """fwd+inv NTT of DCRTPoly-shaped towers on the host cores: the reference itself (oracle/_ref, OpenMP over
+    limbs as DCRTPolyImpl::SwitchFormat does) when its build travelled with the repo, else the oracle port."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import libs
+    N = 1 << logN
+    polys = 4
+    rng = np.random.default_rng(7)
+    x = np.empty((polys, L, N), np.uint64)
+    for i, qi in enumerate(q):
+        x[:, i, :] = rng.integers(0, int(qi), size=(polys, N), dtype=np.uint64)
+    cores = os.cpu_count() or 1
+    if libs.have_ref():
+        r = libs.load_ref()
+        h = r.ref_towers_create(N, L, q, psi, x, polys, 0)
+        r.ref_towers_switch_format(h)  # warm the twiddle cache
+        r.ref_towers_switch_format(h)
+        t0 = time.time()
+        reps = 0
+        while time.time() - t0 < seconds:
+            r.ref_towers_switch_format(h)  # COEFF -> EVAL
+            r.ref_towers_switch_format(h)  # EVAL -> COEFF
+            reps += 1
+        dt = time.time() - t0
+        threads = r.ref_omp_threads()
+        r.ref_towers_destroy(h)
+        kind = "reference"
+    else:
+        o = libs.load_oracle()
+        octx = o.orc_ctx_create(N, L, q, psi)
+        o.orc_ntt_fwd_tower(octx, x, None, L, polys, 0)
+        o.orc_ntt_inv_tower(octx, x, None, L, polys, 0)
+        t0 = time.time()
+        reps = 0
+        while time.time() - t0 < seconds:
+            o.orc_ntt_fwd_tower(octx, x, None, L, polys, 0)
+            o.orc_ntt_inv_tower(octx, x, None, L, polys, 0)
+            reps += 1
+        dt = time.time() - t0
+        threads = cores
+        o.orc_ctx_destroy(octx)
+        kind = "port"
+    bytes_done = 4.0 * 8 * N * L * polys * reps
+    return {"value": round(bytes_done / dt / 1e9, 3), "unit": "GB/s", "cores": int(threads), "kind": kind,
+            "sample": f"{reps} x fwd+inv NTT of {polys} towers (N=2^{logN}, L={L}) in {dt:.1f} s; "
+                      f"{dt / (reps * polys) * 1e3:.1f} ms per tower fwd+inv; host has {cores} logical cores"}
+
+
+def evalmult_leg(lib, device, logN, batch, steps, warmup, sync):
+    """CKKS EvalMult + HYBRID key switch at config 3's shape (depth 20: l=21 limbs, dnum=3 => alpha=7, k=7)."""
+    sizeQ, dnum = 21, 3
+    q, psiQ = lib.ckks_like_chain(logN, sizeQ, 60, 59)
+    p, psiP = lib.select_p(logN, q, dnum, 60)
+    allq = np.concatenate([q, p])
+    ctx = fh.Context(lib, logN, allq, np.concatenate([psiQ, psiP]), device=device)
+    plan = fh.KeySwitchPlan(ctx, sizeQ, len(p), dnum)
+    lib.check(lib.L.fhe_ks_key_alloc(plan.h, C.byref(key := C.c_void_p())))
+    plan.key = key
+    N = ctx.N
+    rng = np.random.default_rng(3)
+    # evaluation key: uniform residues (2 * dnum * (l+k) limbs), generated per limb on the host
+    words = lib.L.fhe_ks_key_words(key)
+    for which in (0, 1):
+        host = np.empty((dnum, len(allq), N), np.uint64)
+        for i, qi in enumerate(allq):
+            host[:, i, :] = rng.integers(0, int(qi), size=(dnum, N), dtype=np.uint64)
+        assert host.size == words
+        lib.check(lib.L.fhe_memcpy_h2d(ctx.h, lib.L.fhe_ks_key_devptr(key, which), host.ctypes.data_as(C.c_void_p),
+                                       host.nbytes, None))
+        ctx.sync()
+    ops = [fh.Tower(ctx, fill_random_tower(ctx, q, batch, 100 + i, seed_polys=2), batch, sizeQ) for i in range(4)]
+    c0, c1 = ops[0].like(), ops[0].like()
+    ws, wsb = plan.workspace(sizeQ, batch)
+
+    def step():
+        lib.check(lib.L.fhe_ckks_eval_mult(plan.h, key, ops[0].ptr, ops[1].ptr, ops[2].ptr, ops[3].ptr, sizeQ, batch,
+                                           c0.ptr, c1.ptr, ws, wsb, None))
+    for _ in range(warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    dt = (time.perf_counter() - t0) / steps
+    plan.close()
+    ctx.close()
+    return {"ops_per_s_per_gpu": round(batch / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "batch": batch,
+            "shape": f"N=2^{logN}, l={sizeQ}, k={len(p)}, dnum={dnum}, workspace {wsb / 2**30:.1f} GiB"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    torch = None
+    if world > 1 or a.gpus > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    elif not os.environ.get("FHE_BENCH_NO_TORCH"):
+        try:
+            import torch
+        except Exception:
+            torch = None
+    lib = fh.Lib()  # the HIP library or nothing
+    if lib.device_count() < 1:
+        raise fh.FheError("bench.py needs a HIP device; there is no CPU fallback")
+    device = local if world > 1 else 0
+
+    logN, L, B = a.logn, a.limbs, a.batch
+    N = 1 << logN
+    q, psi = lib.dcrt_chain(logN, L, 60)  # ILDCRTParams(2N, L, 60): LastPrime then PreviousPrime chain
+    ctx = fh.Context(lib, logN, q, psi, device=device)
+    x = fill_random_tower(ctx, q, B, seed=2 + rank)
+
+    def gpu_sync():
+        ctx.sync()
+        if torch is not None and torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def step():
+        lib.check(lib.L.fhe_ntt_fwd(ctx.h, x, None, L, B, None))
+        lib.check(lib.L.fhe_ntt_inv(ctx.h, x, None, L, B, None))
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    gpu_sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    gpu_sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / a.steps * 1e3
+    bytes_per_step = 4.0 * 8 * N * L * B  # fwd + inv, each: read once + write once
+    value = bytes_per_step * world / (ms_per_step * 1e-3) / 1e9
+
+    # ---- roofline of the dominant kernel (row pass of the forward transform), live hipEvent timing ----
+    roof = None
+    per_kernel = {}
+    if rank == 0:
+        ms = C.c_float()
+        names = {10: "fwd_column_pass", 11: "fwd_row_pass", 12: "inv_row_pass", 13: "inv_column_pass"}
+        if logN > 12:
+            for d, nm in names.items():
+                lib.check(lib.L.fhe_time_ntt(ctx.h, x, None, L, B, d, 5, None, C.byref(ms)))
+                per_kernel[nm + "_ms"] = round(ms.value, 4)
+            dom = max(per_kernel, key=per_kernel.get)
+            alg = 2.0 * 8 * N * L * B  # a pass kernel reads every word once and writes it once
+            ach = alg / (per_kernel[dom] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "ntt_pass_kernel/" + dom[:-3], "achieved": round(ach, 1),
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": alg, "per_kernel_ms": per_kernel}
+        else:
+            lib.check(lib.L.fhe_time_ntt(ctx.h, x, None, L, B, 0, 5, None, C.byref(ms)))
+            alg = 2.0 * 8 * N * L * B
+            ach = alg / (ms.value * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "ntt_pass_kernel(single pass)", "achieved": round(ach, 1),
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None}
+        # restore a valid tower for anything that follows (single-pass timing scrambles it): not needed further
+    ctx.free(x)
+
+    em = None
+    if not a.no_evalmult and logN == 16:
+        em = evalmult_leg(lib, device, logN, a.evalmult_batch, max(2, a.steps // 3), 1, gpu_sync)
+        if dist is not None:
+            tt = torch.tensor([em["ops_per_s_per_gpu"]], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+            em["ops_per_s_total"] = round(float(tt.item()), 1)
+        else:
+            em["ops_per_s_total"] = em["ops_per_s_per_gpu"]
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(q, psi, logN, L, a.cpu_seconds)
+
+    if rank == 0:
+        out = {
+            "metric": "NTT GB/s vs HBM roofline + CKKS EvalMultKeySwitch/sec, N=2^16 L=30, 1/2/4/8 GPU",
+            "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"batched fwd+inv negacyclic NTT, N=2^{logN}, L={L} x 60-bit limbs, "
+                                   f"{B} polynomials per GPU (BASELINE configs[1])",
+                       "global_batch": B * world, "bytes_per_step_per_gpu": bytes_per_step,
+                       "parallelism": f"batch-sharded x{world}, no data-path collective"},
+            "hbm_roofline_frac_fwd_inv": round(value / world / HBM_PEAK_GBPS, 4),
+            "roofline": roof, "cpu_baseline": cpu, "evalmult": em,
+        }
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,30 @@
+#!/bin/bash
+# Builds the product library (hipcc, gfx950) and the test-side native pieces.
+#   ./build.sh hip     -> openfhe-development_amd/csrc/libfhe_hip.so   (THE product; no CPU fallback exists)
+#   ./build.sh emu     -> tests/emu/libfhe_emu.so   (TEST ONLY: lane emulator build of the same sources)
+#   ./build.sh oracle  -> oracle/libfhe_oracle.so   (TEST ONLY: C restatement of the reference)
+#   ./build.sh ref     -> oracle/_ref/*.so          (TEST ONLY: the reference itself, needs /root/reference)
+#   ./build.sh all     -> hip + emu + oracle (+ ref when /root/reference exists)
+set -e
+ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+CSRC="$ROOT/openfhe-development_amd/csrc"
+what="${1:-all}"
+build_hip() {
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fopenmp -Wno-unused-result \
+        -x hip "$CSRC/fhe_hip.cpp" -o "$CSRC/libfhe_hip.so"
+}
+build_emu() {
+  g++ -std=c++17 -O2 -g -DFHE_EMU -fopenmp -fPIC -shared -ffp-contract=off -Wall -Wno-unknown-pragmas \
+      -I"$ROOT/tests/emu" -I"$CSRC" "$CSRC/fhe_hip.cpp" "$ROOT/tests/emu/emu_runtime.cpp" \
+      -o "$ROOT/tests/emu/libfhe_emu.so" -lpthread
+}
+build_oracle() { make -s -C "$ROOT/oracle" oracle; }
+build_ref() { make -s -j"$(nproc)" -C "$ROOT/oracle" ref; }
+case "$what" in
+  hip) build_hip ;;
+  emu) build_emu ;;
+  oracle) build_oracle ;;
+  ref) build_ref ;;
+  all) build_hip; build_emu; build_oracle; if [ -d /root/reference/src ]; then build_ref; fi ;;
+  *) echo "unknown target $what"; exit 2 ;;
+esac

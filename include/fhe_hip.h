@@ -1,0 +1,223 @@
+/*
+ * fhe_hip.h — C ABI of the MI355X (gfx950) RNS polynomial-arithmetic backend for OpenFHE's DCRTPoly
+ * hot path.  This is the drop-in boundary: a thin `lattice/hal/hip/` HAL shim implementing
+ * lbcrypto::DCRTPolyInterface and the standalone parity/benchmark harness both
+ * bind exactly these entry points.  The reference has no FFI of its own — its "operator API" is the C++
+ * class surface selected at compile time by src/core/include/lattice/hal/lat-backend.h:39-61 — so each
+ * entry point cites the reference member function(s) it replaces (paths relative to
+ * openfhe-development/).
+ *
+ * Conventions
+ *  - plain C types only; every call returns fhe_status (0 = OK), no exceptions cross the ABI;
+ *    fhe_last_error() returns the message of the last failure on the calling thread
+ *    (the C++ shim re-throws it with OPENFHE_THROW so callers see the reference's behaviour);
+ *  - a tower lives in DEVICE memory as uint64_t[batch][nLimbs][N], limb-major, N contiguous, every word
+ *    a canonical residue in [0, q_limb) (reference: std::vector<PolyImpl<NativeVector>>,
+ *    src/core/include/lattice/hal/default/dcrtpoly.h:395-397); `limbIdx[r]` maps tower row r to a limb
+ *    of the context (NULL = identity), which is how towers at lower levels, digits and the Q∪P
+ *    extension share one context;
+ *  - the caller owns all tower memory (fhe_malloc/fhe_free or any other device allocation, e.g. a
+ *    torch tensor's data_ptr); the library owns its context/plan tables behind opaque handles;
+ *  - all work is asynchronous on `stream` (a hipStream_t passed as void*, NULL = default stream);
+ *    fhe_stream_sync() or the caller's own hip sync makes results visible;
+ *  - there is NO CPU fallback: if no gfx950 device is usable every entry point fails with
+ *    FHE_ERR_DEVICE.
+ */
+#ifndef FHE_HIP_H
+#define FHE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int fhe_status;
+enum {
+    FHE_OK          = 0,
+    FHE_ERR_ARG     = 1, /* bad argument (the reference would OPENFHE_THROW) */
+    FHE_ERR_DEVICE  = 2, /* HIP runtime failure / no device */
+    FHE_ERR_ALLOC   = 3,
+    FHE_ERR_UNSUPPORTED = 4
+};
+
+typedef struct fhe_ctx fhe_ctx;          /* ring + modulus tower + device twiddle tables */
+typedef struct fhe_conv fhe_conv;        /* one CRT basis-conversion plan (tables on device) */
+typedef struct fhe_ks_plan fhe_ks_plan;  /* HYBRID key-switching plan for a (Q, P, dnum) */
+typedef struct fhe_ks_key fhe_ks_key;    /* an evaluation key resident on the device */
+
+const char* fhe_last_error(void);
+const char* fhe_version(void);
+/* number of usable devices (hipGetDeviceCount); 0 if none */
+int fhe_device_count(void);
+
+/* ---- context -------------------------------------------------------------------------------------
+ * Replaces ILDCRTParams + the lazily built static twiddle cache
+ * (src/core/include/lattice/hal/default/ildcrtparams.h:70-372,
+ *  ChineseRemainderTransformFTTNat::PreCompute, src/core/include/math/hal/intnat/transformnat-impl.h:714-756).
+ * q[i] prime < 2^60 with q[i] = 1 mod 2N, psi[i] a primitive 2N-th root of unity mod q[i] (the reference
+ * uses RootOfUnity(), the minimum one). Tables are built eagerly and are immutable afterwards.
+ * logN in [4, 17]; nLimbs <= 128. */
+fhe_status fhe_ctx_create(uint32_t logN, uint32_t nLimbs, const uint64_t* q, const uint64_t* psi, int device,
+                          fhe_ctx** out);
+void       fhe_ctx_destroy(fhe_ctx* ctx);
+uint32_t   fhe_ctx_logn(const fhe_ctx* ctx);
+uint32_t   fhe_ctx_limbs(const fhe_ctx* ctx);
+int        fhe_ctx_device(const fhe_ctx* ctx);
+
+/* ---- memory / streams ---------------------------------------------------------------------------- */
+fhe_status fhe_malloc(fhe_ctx* ctx, size_t bytes, void** devPtr);
+fhe_status fhe_free(fhe_ctx* ctx, void* devPtr);
+fhe_status fhe_memcpy_h2d(fhe_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream);
+fhe_status fhe_memcpy_d2h(fhe_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream);
+fhe_status fhe_memcpy_d2d(fhe_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream);
+fhe_status fhe_stream_sync(fhe_ctx* ctx, void* stream);
+
+/* ---- a4/a5/a6: NTT -------------------------------------------------------------------------------
+ * Replaces DCRTPolyImpl::SwitchFormat (dcrtpoly-impl.h:1932-1940) -> PolyImpl::SwitchFormat
+ * (poly-impl.h:420-440) -> ChineseRemainderTransformFTTNat::ForwardTransformToBitReverseInPlace /
+ * InverseTransformFromBitReverseInPlace (transformnat-impl.h:648-657, 678-690; loops :303-374, :512-625).
+ * In place on x[batch][nLimbs][N] (or out of place with xin != xout); forward = COEFFICIENT -> EVALUATION
+ * (natural -> bit-reversed order), inverse = EVALUATION -> COEFFICIENT (1/N folded in). */
+fhe_status fhe_ntt_fwd(fhe_ctx* ctx, uint64_t* x, const uint32_t* limbIdx, uint32_t nLimbs, uint32_t batch, void* stream);
+fhe_status fhe_ntt_inv(fhe_ctx* ctx, uint64_t* x, const uint32_t* limbIdx, uint32_t nLimbs, uint32_t batch, void* stream);
+fhe_status fhe_ntt_fwd_oop(fhe_ctx* ctx, const uint64_t* xin, uint64_t* xout, const uint32_t* limbIdx, uint32_t nLimbs,
+                           uint32_t batch, void* stream);
+fhe_status fhe_ntt_inv_oop(fhe_ctx* ctx, const uint64_t* xin, uint64_t* xout, const uint32_t* limbIdx, uint32_t nLimbs,
+                           uint32_t batch, void* stream);
+
+/* ---- a7: element-wise tower arithmetic -----------------------------------------------------------
+ * Replaces DCRTPolyImpl::operator+= / -= / *= , Plus/Minus/Times, Negate
+ * (dcrtpoly-impl.h:347-408, dcrtpoly.h:131-189) and NativeVectorT::ModAddEq/ModSubEq/ModMulEq
+ * (src/core/lib/math/hal/intnat/mubintvecnat.cpp:229-339). out may alias a or b. */
+fhe_status fhe_add(fhe_ctx* ctx, uint64_t* out, const uint64_t* a, const uint64_t* b, const uint32_t* limbIdx,
+                   uint32_t nLimbs, uint32_t batch, void* stream);
+fhe_status fhe_sub(fhe_ctx* ctx, uint64_t* out, const uint64_t* a, const uint64_t* b, const uint32_t* limbIdx,
+                   uint32_t nLimbs, uint32_t batch, void* stream);
+fhe_status fhe_mul(fhe_ctx* ctx, uint64_t* out, const uint64_t* a, const uint64_t* b, const uint32_t* limbIdx,
+                   uint32_t nLimbs, uint32_t batch, void* stream);
+fhe_status fhe_neg(fhe_ctx* ctx, uint64_t* out, const uint64_t* a, const uint32_t* limbIdx, uint32_t nLimbs,
+                   uint32_t batch, void* stream);
+/* Times(const std::vector<NativeInteger>&) / operator*=(NativeInteger) (dcrtpoly-impl.h:582-620):
+ * consts[r] (HOST array, one per tower row, < q) multiplies limb r of every tower in the batch */
+fhe_status fhe_mul_const(fhe_ctx* ctx, uint64_t* out, const uint64_t* a, const uint64_t* consts,
+                         const uint32_t* limbIdx, uint32_t nLimbs, uint32_t batch, void* stream);
+/* LeveledSHEBase::EvalMultCore (src/pke/lib/schemebase/base-leveledshe.cpp:607-644):
+ * d0 = a0*b0, d1 = a0*b1 + a1*b0, d2 = a1*b1 */
+fhe_status fhe_tensor(fhe_ctx* ctx, const uint64_t* a0, const uint64_t* a1, const uint64_t* b0, const uint64_t* b1,
+                      uint64_t* d0, uint64_t* d1, uint64_t* d2, const uint32_t* limbIdx, uint32_t nLimbs,
+                      uint32_t batch, void* stream);
+
+/* ---- a8: automorphism ----------------------------------------------------------------------------
+ * Replaces DCRTPolyImpl::AutomorphismTransform(k[, precomp]) (dcrtpoly-impl.h:314-333) ->
+ * PolyImpl::AutomorphismTransform (poly-impl.h:310-376; table PrecomputeAutoMap, nbtheory2.cpp:264-275).
+ * k odd. evalFormat != 0: EVALUATION gather; 0: COEFFICIENT signed permutation. out must not alias in. */
+fhe_status fhe_automorph(fhe_ctx* ctx, uint64_t* out, const uint64_t* in, uint32_t k, int evalFormat,
+                         const uint32_t* limbIdx, uint32_t nLimbs, uint32_t batch, void* stream);
+
+/* ---- a9: centred modulus switch -------------------------------------------------------------------
+ * Replaces PolyImpl::SwitchModulus / NativeVectorT::SwitchModulus (poly-impl.h:400-407,
+ * mubintvecnat.cpp:109-122): limb `srcPos` (context limb srcCtxLimb) of every tower src[batch][srcLimbs][N]
+ * is lifted, centred, into each of the nLimbs rows of out. */
+fhe_status fhe_switch_modulus(fhe_ctx* ctx, uint64_t* out, const uint32_t* limbIdx, uint32_t nLimbs,
+                              const uint64_t* src, uint32_t srcLimbs, uint32_t srcPos, uint32_t srcCtxLimb,
+                              uint32_t batch, void* stream);
+
+/* ---- a10/a16: CRT basis conversion ------------------------------------------------------------------
+ * fhe_conv_create builds the device tables for converting from the basis {srcLimbIdx} to {dstLimbIdx}
+ * (context limbs). The table VALUES are computed by the library the way CryptoParametersRNS /
+ * CryptoParametersBFVRNS do (src/pke/lib/schemerns/rns-cryptoparameters.cpp:199-349):
+ *   QHatInvModq[i] = [(Q/q_i)^-1]_{q_i},  QHatModp[i][j] = [Q/q_i]_{p_j},  mu_j = floor(2^128/p_j),
+ *   and for the exact form alphaQModp[a][j] = [a*Q]_{p_j}, qInv[i] = 1.0/q_i.
+ * fhe_approx_switch_basis replaces DCRTPolyImpl::ApproxSwitchCRTBasis (dcrtpoly-impl.h:888-932, fast path);
+ * fhe_switch_basis_exact replaces DCRTPolyImpl::SwitchCRTBasis (:1008-1085; the overflow count is
+ * accumulated in double in the reference's order).
+ * in  = [batch][inStride][N]  COEFFICIENT format, source limb i at row inFirst+i;
+ * out = [batch][outStride][N] COEFFICIENT format, target limb j at row outFirst+j. */
+fhe_status fhe_conv_create(fhe_ctx* ctx, const uint32_t* srcLimbIdx, uint32_t nSrc, const uint32_t* dstLimbIdx,
+                           uint32_t nDst, fhe_conv** out);
+void       fhe_conv_destroy(fhe_conv* conv);
+fhe_status fhe_approx_switch_basis(fhe_conv* conv, const uint64_t* in, uint32_t inStride, uint32_t inFirst,
+                                   uint64_t* out, uint32_t outStride, uint32_t outFirst, uint32_t batch, void* stream);
+fhe_status fhe_switch_basis_exact(fhe_conv* conv, const uint64_t* in, uint32_t inStride, uint32_t inFirst,
+                                  uint64_t* out, uint32_t outStride, uint32_t outFirst, uint32_t batch, void* stream);
+
+/* ---- a11..a14: HYBRID key switching -----------------------------------------------------------------
+ * The context must hold the Q limbs [0,sizeQ) followed by the P limbs [sizeQ, sizeQ+sizeP).
+ * fhe_ks_plan_create replaces the HYBRID part of CryptoParametersRNS::PrecomputeCRTTables
+ * (rns-cryptoparameters.cpp:80-350): digit partition (alpha = ceil(sizeQ/numPartQ)), complementary bases,
+ * PartQlHatInvModq / PartQlHatModp per level, PInvModq, PHatInvModp, PHatModq, Barrett constants.
+ * fhe_ks_key_upload copies an evaluation key (b and a vectors of EvalKeyRelin,
+ * src/pke/include/key/evalkeyrelin.h:141,171), each given as HOST uint64_t[numPartQ][sizeQ+sizeP][N] in
+ * EVALUATION format, to the device. With RCCL the caller broadcasts the device copy instead
+ * (fhe_ks_key_alloc + fhe_ks_key_devptr). */
+fhe_status fhe_ks_plan_create(fhe_ctx* ctx, uint32_t sizeQ, uint32_t sizeP, uint32_t numPartQ, fhe_ks_plan** out);
+void       fhe_ks_plan_destroy(fhe_ks_plan* plan);
+uint32_t   fhe_ks_plan_alpha(const fhe_ks_plan* plan);
+fhe_status fhe_ks_key_alloc(fhe_ks_plan* plan, fhe_ks_key** out);
+fhe_status fhe_ks_key_upload(fhe_ks_plan* plan, const uint64_t* keyB, const uint64_t* keyA, fhe_ks_key** out);
+void       fhe_ks_key_destroy(fhe_ks_key* key);
+/* device pointers of the b (which=0) / a (which=1) vectors: uint64_t[numPartQ][sizeQ+sizeP][N] */
+uint64_t*  fhe_ks_key_devptr(fhe_ks_key* key, int which);
+size_t     fhe_ks_key_words(const fhe_ks_key* key);
+
+/* workspace (device bytes) needed by the composite calls below for `batch` towers at level sizeQl */
+size_t     fhe_ks_workspace_bytes(const fhe_ks_plan* plan, uint32_t sizeQl, uint32_t batch);
+
+/* KeySwitchHYBRID::EvalKeySwitchPrecomputeCore + EvalFastKeySwitchCore
+ * (src/pke/lib/keyswitch/keyswitch-hybrid.cpp:314-400), i.e. KeySwitchCore (:308-312):
+ * c[batch][sizeQl][N] EVALUATION -> out0,out1[batch][sizeQl][N] EVALUATION. `ws` = device workspace. */
+fhe_status fhe_keyswitch_hybrid(fhe_ks_plan* plan, const fhe_ks_key* key, const uint64_t* c, uint32_t sizeQl,
+                                uint32_t batch, uint64_t* out0, uint64_t* out1, void* ws, size_t wsBytes,
+                                void* stream);
+/* cc->EvalMult(ct1, ct2) for 2-element ciphertexts: EvalMultCore + KeySwitchCore + add
+ * (src/pke/lib/schemebase/base-leveledshe.cpp:201-214, 607-644).  All towers [batch][sizeQl][N] EVALUATION.
+ * c0/c1 may alias a0/a1. */
+fhe_status fhe_ckks_eval_mult(fhe_ks_plan* plan, const fhe_ks_key* key, const uint64_t* a0, const uint64_t* a1,
+                              const uint64_t* b0, const uint64_t* b1, uint32_t sizeQl, uint32_t batch, uint64_t* c0,
+                              uint64_t* c1, void* ws, size_t wsBytes, void* stream);
+/* DCRTPolyImpl::ApproxModDown with t = 0 (dcrtpoly-impl.h:966-1005):
+ * x[batch][sizeQl+sizeP][N] EVALUATION -> out[batch][sizeQl][N] EVALUATION */
+fhe_status fhe_approx_mod_down(fhe_ks_plan* plan, const uint64_t* x, uint32_t sizeQl, uint32_t batch, uint64_t* out,
+                               void* ws, size_t wsBytes, void* stream);
+
+/* ---- a15: CKKS rescale ---------------------------------------------------------------------------
+ * Replaces DCRTPolyImpl::DropLastElementAndScale (dcrtpoly-impl.h:693-712) with the tables of
+ * CryptoParametersCKKSRNS (src/pke/lib/scheme/ckksrns/ckksrns-cryptoparameters.cpp:60-81) computed inside.
+ * The tower uses context limbs [0,sizeQl). x[batch][sizeQl][N] EVALUATION -> out[batch][sizeQl-1][N].
+ * ws: device workspace of fhe_rescale_workspace_bytes(). */
+size_t     fhe_rescale_workspace_bytes(const fhe_ctx* ctx, uint32_t sizeQl, uint32_t batch);
+fhe_status fhe_rescale(fhe_ctx* ctx, const uint64_t* x, uint32_t sizeQl, uint32_t batch, uint64_t* out, void* ws,
+                       size_t wsBytes, void* stream);
+
+/* ---- host-side parameter helpers (no device work) -------------------------------------------------
+ * Number theory the reference uses to pick moduli and roots, restated with 64-bit arithmetic so that a
+ * caller can reproduce the reference's (N, q_i, psi_i) without linking OpenFHE:
+ * FirstPrime/LastPrime/NextPrime/PreviousPrime (src/core/include/math/nbtheory-impl.h:329-393),
+ * RootOfUnity = the minimum primitive m-th root (:183-231), the ILDCRTParams(order, depth, bits) chain
+ * (src/core/include/lattice/hal/default/ildcrtparams.h:100-117) and the HYBRID auxiliary basis P of
+ * CryptoParametersRNS::PrecomputeCRTTables (src/pke/lib/schemerns/rns-cryptoparameters.cpp:128-176, with the
+ * CKKS prime step 2N, src/pke/lib/scheme/ckksrns/ckksrns-cryptoparameters.cpp:185-188). */
+uint64_t   fhe_param_first_prime(uint32_t bits, uint64_t m);
+uint64_t   fhe_param_last_prime(uint32_t bits, uint64_t m);
+uint64_t   fhe_param_next_prime(uint64_t q, uint64_t m);
+uint64_t   fhe_param_previous_prime(uint64_t q, uint64_t m);
+uint64_t   fhe_param_root_of_unity(uint64_t m, uint64_t q);
+fhe_status fhe_param_dcrt_chain(uint32_t order, uint32_t nLimbs, uint32_t bits, uint64_t* q, uint64_t* psi);
+/* returns sizeP (0 on error); p/psiP need capacity >= 64 */
+uint32_t   fhe_param_select_p(uint32_t logN, uint32_t sizeQ, const uint64_t* q, uint32_t numPartQ, uint32_t auxBits,
+                              uint64_t* p, uint64_t* psiP);
+
+/* ---- measurement helper ----------------------------------------------------------------------------
+ * Runs `iters` back-to-back launches of fwd (dir=0), inv (dir=1) or fwd+inv (dir=2) NTT on x — or of a single
+ * pass kernel of a two-pass ring: 10/11 = column/row pass of the forward, 12/13 = row/column pass of the
+ * inverse (timing only; the data is then not a transform) — and returns
+ * the average wall time per launch-set in milliseconds measured with hipEvents on `stream`
+ * (bench.py's roofline leg: torch.cuda.Event only sees torch's stream). */
+fhe_status fhe_time_ntt(fhe_ctx* ctx, uint64_t* x, const uint32_t* limbIdx, uint32_t nLimbs, uint32_t batch, int dir,
+                        int iters, void* stream, float* msPerIter);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

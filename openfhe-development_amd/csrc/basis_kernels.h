@@ -1,0 +1,158 @@
+// basis_kernels.h — CRT basis conversion and the HYBRID key-switch inner product.
+//
+// approx_switch_kernel replaces DCRTPolyImpl::ApproxSwitchCRTBasis (fast path,
+// src/core/include/lattice/hal/default/dcrtpoly-impl.h:888-915): per coefficient
+//   y_i   = x_i * [Qhat_i^-1]_{q_i}            (Shoup, ModMulFastConst)
+//   out_j = Barrett128( sum_i y_i * [Qhat_i]_{p_j} )   (128-bit accumulate, BarrettUint128ModUint64,
+//                                                      utils/utilities-int.h:60-99)
+// switch_exact_kernel adds the floating-point overflow count of SwitchCRTBasis (:1008-1085).
+// ks_inner_product_kernel replaces KeySwitchHYBRID::EvalFastKeySwitchCoreExt
+// (src/pke/lib/keyswitch/keyswitch-hybrid.cpp:402-435).
+//
+// Mapping: one coefficient per lane (consecutive lanes = consecutive coefficients => coalesced
+// reads/writes of every limb), all source limbs of that coefficient are reduced to y_i in registers,
+// output limbs are produced in chunks of OUT_CHUNK accumulators; the conversion constants are
+// wave-uniform and come through the scalar cache.
+#ifndef FHE_BASIS_KERNELS_H
+#define FHE_BASIS_KERNELS_H
+#include "modarith.h"
+#include "launch.h"
+#include "ntt_kernels.h"
+#include "elemwise_kernels.h"
+
+namespace fhe {
+
+
+struct ConvTables {           // device-resident, built once per (source basis, target basis)
+    const TwPair* hatInv;     // [nSrc]  [Qhat_i^-1]_{q_i} as Shoup pair
+    const uint64_t* hatMod;   // [nSrc][nDst]  [Qhat_i]_{p_j}
+    const uint64_t* srcQ;     // [nSrc]
+    const uint64_t* dstQ;     // [nDst]
+    const uint64_t* dstMu;    // [nDst][2]  floor(2^128/p_j) (lo,hi)
+    // exact variant only:
+    const double* srcQInv;    // [nSrc] 1.0/q_i
+    const uint64_t* alphaMod; // [nSrc+1][nDst]  [alpha*Q]_{p_j}
+};
+
+struct ConvArgs {
+    const uint64_t* in;   // [batch][inStride][N]; source limb i is row inFirst + i
+    uint64_t* out;        // [batch][outStride][N]; target limb j is row outFirst + j
+    ConvTables tb;
+    uint32_t logN, batch;
+    uint32_t nSrc, nDst;
+    uint32_t inStride, inFirst, outStride, outFirst;
+};
+
+template <int OUT_CHUNK, bool EXACT>
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) switch_basis_kernel(const ConvArgs g) {
+    const uint32_t N     = 1u << g.logN;
+    const uint64_t gid   = (uint64_t)FHE_BID * kThreads + FHE_TID;  // over batch*N coefficients
+    if (gid >= ((uint64_t)g.batch << g.logN))
+        return;
+    const uint32_t b  = (uint32_t)(gid >> g.logN);
+    const uint32_t ri = (uint32_t)gid & (N - 1u);
+    const uint64_t* in = g.in + (((uint64_t)b * g.inStride + g.inFirst) << g.logN) + ri;
+    uint64_t* out      = g.out + (((uint64_t)b * g.outStride + g.outFirst) << g.logN) + ri;
+
+    // overflow count of the exact variant: nu = 0.5 + sum_i y_i/q_i in double, i ascending, one rounding per
+    // multiply and per add (dcrtpoly-impl.h:1056-1063); compiled with -ffp-contract=off
+    uint32_t alpha = 0;
+    if (EXACT) {
+        double nu = 0.5;
+        for (uint32_t i = 0; i < g.nSrc; ++i) {
+            const TwPair h   = g.tb.hatInv[i];
+            const uint64_t y = mul_shoup(in[(uint64_t)i << g.logN], h.w, h.wp, g.tb.srcQ[i]);
+            nu += (double)y * g.tb.srcQInv[i];
+        }
+        alpha = (uint32_t)nu;
+    }
+
+    for (uint32_t j0 = 0; j0 < g.nDst; j0 += OUT_CHUNK) {
+        u128w acc[OUT_CHUNK];
+#pragma unroll
+        for (int jj = 0; jj < OUT_CHUNK; ++jj)
+            acc[jj] = u128w{0, 0};
+        for (uint32_t i = 0; i < g.nSrc; ++i) {
+            const TwPair h       = g.tb.hatInv[i];
+            const uint64_t y     = mul_shoup(in[(uint64_t)i << g.logN], h.w, h.wp, g.tb.srcQ[i]);
+            const uint64_t* hrow = g.tb.hatMod + (uint64_t)i * g.nDst + j0;
+#pragma unroll
+            for (int jj = 0; jj < OUT_CHUNK; ++jj)
+                if (j0 + jj < g.nDst)
+                    acc128(acc[jj], y, hrow[jj]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < OUT_CHUNK; ++jj) {
+            const uint32_t j = j0 + jj;
+            if (j < g.nDst) {
+                const uint64_t p = g.tb.dstQ[j];
+                uint64_t v       = barrett128(acc[jj], p, g.tb.dstMu[2 * j], g.tb.dstMu[2 * j + 1]);
+                if (EXACT)
+                    v = sub_mod(v, g.tb.alphaMod[(uint64_t)alpha * g.nDst + j], p);
+                out[(uint64_t)j << g.logN] = v;
+            }
+        }
+    }
+}
+
+// ---- HYBRID inner product ------------------------------------------------------------------------
+// For every ciphertext b, output limb i in [0, sizeQl+sizeP), coefficient r:
+//   out0 = sum_j digit_j[i] * keyB_j[idx(i)],  out1 = sum_j digit_j[i] * keyA_j[idx(i)],
+//   idx(i) = i < sizeQl ? i : i + (sizeQ - sizeQl)          (keyswitch-hybrid.cpp:425)
+// digit_j[i] is read from the ModUp output buffer of digit j, except for the digit's own limbs which are
+// taken straight from the (EVALUATION-format) input c — the reference copies them (:371-372), we do not.
+constexpr int kMaxDigits = 8;
+struct KsInnerArgs {
+    const uint64_t* c;                 // [batch][sizeQl][N] EVAL
+    const uint64_t* digits[kMaxDigits];  // digit j complement: [batch][nc_j][N] EVAL
+    const uint64_t* keyB;              // [numPartQ][sizeQ+sizeP][N]
+    const uint64_t* keyA;
+    uint64_t* out0;                    // [batch][sizeQl+sizeP][N]
+    uint64_t* out1;
+    const LimbConst* lc;               // [ctxLimbs]; ctx limbs: Q then P
+    const uint64_t* mu128;             // [ctxLimbs][2]
+    uint32_t logN, batch, sizeQl, sizeQ, sizeP, numDigits, alpha;
+    uint32_t nc[kMaxDigits];           // complement size of digit j = sizeQl - size_j + sizeP
+};
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ks_inner_product_kernel(const KsInnerArgs g) {
+    // one workgroup = 4096 consecutive coefficients of one (b, i) output row; batch-fastest so that the
+    // key rows (shared by the whole batch) stay in L2
+    const uint32_t t          = FHE_TID;
+    const uint32_t tilesPerRow = (1u << g.logN) >> kTileLog ? ((1u << g.logN) >> kTileLog) : 1u;
+    const uint32_t sizeQlP    = g.sizeQl + g.sizeP;
+    uint32_t blk              = FHE_BID;
+    const uint32_t b          = blk % g.batch;
+    blk /= g.batch;
+    const uint32_t tr = blk % tilesPerRow;
+    const uint32_t i  = blk / tilesPerRow;
+    if (i >= sizeQlP)
+        return;
+    const uint32_t idx  = i < g.sizeQl ? i : i + (g.sizeQ - g.sizeQl);
+    const LimbConst lc  = g.lc[idx];
+    const uint64_t mulo = g.mu128[2 * idx], muhi = g.mu128[2 * idx + 1];
+    const uint32_t N    = 1u << g.logN;
+    const uint32_t rEnd = ((tr + 1u) << kTileLog) < N ? ((tr + 1u) << kTileLog) : N;
+    for (uint32_t r = (tr << kTileLog) + t; r < rEnd; r += kThreads) {
+        u128w s0{0, 0}, s1{0, 0};
+        for (uint32_t j = 0; j < g.numDigits; ++j) {
+            const uint32_t start = j * g.alpha;
+            const uint32_t sz    = sizeQlP - g.nc[j];
+            uint64_t d;
+            if (i >= start && i < start + sz)
+                d = g.c[(((uint64_t)b * g.sizeQl + i) << g.logN) + r];
+            else {
+                const uint32_t pos = i < start ? i : i - sz;
+                d = g.digits[j][(((uint64_t)b * g.nc[j] + pos) << g.logN) + r];
+            }
+            const uint64_t koff = (((uint64_t)j * (g.sizeQ + g.sizeP) + idx) << g.logN) + r;
+            acc128(s0, d, g.keyB[koff]);
+            acc128(s1, d, g.keyA[koff]);
+        }
+        const uint64_t ooff = (((uint64_t)b * sizeQlP + i) << g.logN) + r;
+        g.out0[ooff]        = barrett128(s0, lc.q, mulo, muhi);
+        g.out1[ooff]        = barrett128(s1, lc.q, mulo, muhi);
+    }
+}
+
+}  // namespace fhe
+#endif

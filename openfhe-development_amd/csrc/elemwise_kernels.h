@@ -1,0 +1,244 @@
+// elemwise_kernels.h — per-coefficient tower operations (HBM-bound streams).
+//
+// Replaces the per-limb OpenMP loops of DCRTPolyImpl::operator+=, -=, *=, Times(vector<NativeInteger>),
+// Negate (src/core/include/lattice/hal/default/dcrtpoly-impl.h:347-408, 582-620; dcrtpoly.h:131-189)
+// and the NativeVectorT kernels they call (src/core/lib/math/hal/intnat/mubintvecnat.cpp:132-142,
+// 229-339), the EVALUATION/COEFFICIENT automorphisms (poly-impl.h:345-376), the centred modulus
+// switch (mubintvecnat.cpp:109-122) and the tensor product of LeveledSHEBase::EvalMultCore
+// (src/pke/lib/schemebase/base-leveledshe.cpp:607-644).
+//
+// Work decomposition: a workgroup owns 4096 consecutive words of the [rows][N] tower array (one
+// "tile", the same granule as the NTT), each lane moves 16-byte pairs, so every wave instruction is a
+// fully coalesced 1 KiB access.  For N >= 4096 a tile lies inside one limb and the modulus is uniform.
+#ifndef FHE_ELEMWISE_KERNELS_H
+#define FHE_ELEMWISE_KERNELS_H
+#include "modarith.h"
+#include "launch.h"
+#include "ntt_kernels.h"
+
+namespace fhe {
+
+struct LimbConst {  // per-context-limb constants for exact a*b mod q
+    uint64_t q;
+    uint64_t mu;   // floor(2^(2*msb+3)/q)    (ComputeMu, ubintnat.h:642-647)
+    uint32_t msb;  // bit length of q
+    uint32_t pad;
+};
+
+enum ElemOp : int {
+    OP_ADD = 0,        // out = a + b
+    OP_SUB = 1,        // out = a - b
+    OP_MUL = 2,        // out = a * b
+    OP_NEG = 3,        // out = -a
+    OP_MUL_CONST = 4,  // out = a * c[row]         (c as Shoup pair)
+    OP_SUB_MUL_CONST = 5,  // out = (a - b) * c[row]   (ApproxModDown tail, dcrtpoly-impl.h:1002)
+    OP_MUL_CONST_ADD = 6,  // out = a * c[row] + b     (DropLastElementAndScale tail, :707-708)
+    OP_MULT_ACC = 7,   // out = out + a * b        (inner-product accumulate)
+    OP_COPY = 8,
+};
+
+struct ElemArgs {
+    uint64_t* out;
+    const uint64_t* a;
+    const uint64_t* b;
+    const LimbConst* lc;   // [ctxLimbs]
+    const TwPair* consts;  // [nLimbs] per tower row-in-tower constant (Shoup pair), may be null
+    uint32_t logN, nLimbs, rows;
+    uint32_t aStride, aFirst;  // aStride != 0: operand a is a [batch][aStride][N] view, rows aFirst.. of each tower
+    uint32_t bStride, bFirst;  // same for b
+    LimbSel sel;
+};
+
+template <int OP>
+FHE_HD uint64_t elem_apply(uint64_t o, uint64_t a, uint64_t b, const LimbConst lc, const TwPair c) {
+    const uint64_t q = lc.q;
+    switch (OP) {
+        case OP_ADD:
+            return add_mod(a, b, q);
+        case OP_SUB:
+            return sub_mod(a, b, q);
+        case OP_MUL:
+            return mul_mod_barrett(a, b, q, lc.mu, (int)lc.msb);
+        case OP_NEG:
+            return a == 0 ? 0 : q - a;
+        case OP_MUL_CONST:
+            return mul_shoup(a, c.w, c.wp, q);
+        case OP_SUB_MUL_CONST:
+            return mul_shoup(sub_mod(a, b, q), c.w, c.wp, q);
+        case OP_MUL_CONST_ADD:
+            return add_mod(mul_shoup(a, c.w, c.wp, q), b, q);
+        case OP_MULT_ACC:
+            return add_mod(o, mul_mod_barrett(a, b, q, lc.mu, (int)lc.msb), q);
+        default:
+            return a;
+    }
+}
+
+template <int OP>
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) elemwise_kernel(const ElemArgs g) {
+    const uint32_t t          = FHE_TID;
+    const uint64_t base       = (uint64_t)FHE_BID << kTileLog;
+    const uint64_t totalWords = (uint64_t)g.rows << g.logN;
+    constexpr bool needB = (OP == OP_ADD || OP == OP_SUB || OP == OP_MUL || OP == OP_SUB_MUL_CONST ||
+                            OP == OP_MUL_CONST_ADD || OP == OP_MULT_ACC);
+    constexpr bool needC = (OP == OP_MUL_CONST || OP == OP_SUB_MUL_CONST || OP == OP_MUL_CONST_ADD);
+    constexpr bool needO = (OP == OP_MULT_ACC);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const uint64_t off = base + (((uint64_t)m * kThreads + t) << 1);
+        if (off >= totalWords)
+            continue;
+        const uint32_t row  = (uint32_t)(off >> g.logN);
+        const uint32_t rit  = row % g.nLimbs;
+        const LimbConst lc  = g.lc[g.sel.idx[rit]];
+        TwPair c            = {0, 0};
+        if (needC)
+            c = g.consts[rit];
+        const uint32_t tb   = row / g.nLimbs;
+        const uint64_t ri   = off & (((uint64_t)1 << g.logN) - 1u);
+        const uint64_t aoff = g.aStride ? ((((uint64_t)tb * g.aStride + g.aFirst + rit) << g.logN) + ri) : off;
+        uint64_t a0 = g.a[aoff], a1 = g.a[aoff + 1];
+        uint64_t b0 = 0, b1 = 0, o0 = 0, o1 = 0;
+        if (needB) {
+            const uint64_t boff = g.bStride ? ((((uint64_t)tb * g.bStride + g.bFirst + rit) << g.logN) + ri) : off;
+            b0 = g.b[boff];
+            b1 = g.b[boff + 1];
+        }
+        if (needO) {
+            o0 = g.out[off];
+            o1 = g.out[off + 1];
+        }
+        g.out[off]     = elem_apply<OP>(o0, a0, b0, lc, c);
+        g.out[off + 1] = elem_apply<OP>(o1, a1, b1, lc, c);
+    }
+}
+
+// ---- EvalMultCore tensor product: d0 = a0*b0, d1 = a0*b1 + a1*b0, d2 = a1*b1 ------------------------
+struct TensorArgs {
+    const uint64_t *a0, *a1, *b0, *b1;
+    uint64_t *d0, *d1, *d2;
+    const LimbConst* lc;
+    uint32_t logN, nLimbs, rows;
+    LimbSel sel;
+};
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) tensor_kernel(const TensorArgs g) {
+    const uint32_t t          = FHE_TID;
+    const uint64_t base       = (uint64_t)FHE_BID << kTileLog;
+    const uint64_t totalWords = (uint64_t)g.rows << g.logN;
+#pragma unroll 2
+    for (int m = 0; m < 16; ++m) {
+        const uint64_t off = base + (uint64_t)m * kThreads + t;
+        if (off >= totalWords)
+            continue;
+        const uint32_t row = (uint32_t)(off >> g.logN);
+        const LimbConst lc = g.lc[g.sel.idx[row % g.nLimbs]];
+        const uint64_t x0 = g.a0[off], x1 = g.a1[off], y0 = g.b0[off], y1 = g.b1[off];
+        const int msb = (int)lc.msb;
+        g.d0[off] = mul_mod_barrett(x0, y0, lc.q, lc.mu, msb);
+        g.d1[off] = add_mod(mul_mod_barrett(x0, y1, lc.q, lc.mu, msb), mul_mod_barrett(x1, y0, lc.q, lc.mu, msb), lc.q);
+        g.d2[off] = mul_mod_barrett(x1, y1, lc.q, lc.mu, msb);
+    }
+}
+
+// ---- automorphism -------------------------------------------------------------------------------
+// EVALUATION: out[j] = in[precomp[j]]  (poly-impl.h:366-376), precomp[bitrev(j)] = bitrev(((2j+1)k mod 2N)>>1)
+// computed on the fly (nbtheory2.cpp:264-275) so no table has to be shipped: for output index jr,
+// j = bitrev(jr), idx = (((2j+1)*k) mod 2N) >> 1, source = bitrev(idx).
+// COEFFICIENT: out[(j*k) mod N] = ((j*k)>>logN)&1 ? q - in[j] : in[j]   (poly-impl.h:359-362)
+struct AutoArgs {
+    uint64_t* out;
+    const uint64_t* in;
+    const uint64_t* q;  // [ctxLimbs]
+    uint32_t logN, nLimbs, rows, k, evalFormat;
+    LimbSel sel;
+};
+FHE_HD uint32_t bitrev32(uint32_t x, uint32_t nbits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brev(x) >> (32 - nbits);
+#else
+    uint32_t r = 0;
+    for (uint32_t i = 0; i < nbits; ++i)
+        r |= ((x >> i) & 1u) << (nbits - 1 - i);
+    return r;
+#endif
+}
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) automorph_kernel(const AutoArgs g) {
+    const uint32_t t          = FHE_TID;
+    const uint64_t base       = (uint64_t)FHE_BID << kTileLog;
+    const uint64_t totalWords = (uint64_t)g.rows << g.logN;
+    const uint32_t N = 1u << g.logN, mask = N - 1u;
+#pragma unroll 4
+    for (int m = 0; m < 16; ++m) {
+        const uint64_t off = base + (uint64_t)m * kThreads + t;
+        if (off >= totalWords)
+            continue;
+        const uint64_t rowBase = off & ~(uint64_t)mask;
+        const uint32_t jr      = (uint32_t)off & mask;
+        if (g.evalFormat) {
+            const uint32_t j   = bitrev32(jr, g.logN);
+            const uint32_t idx = (((2u * j + 1u) * g.k) & (2u * N - 1u)) >> 1;
+            g.out[off]         = g.in[rowBase + bitrev32(idx, g.logN)];
+        }
+        else {
+            // gather form of the scatter in the reference: out[jk mod N] = +-in[j]  <=>  j = jr * k^-1 mod 2N
+            // (k odd => invertible mod 2N); host passes kInv in g.k? no: keep scatter semantics exactly:
+            const uint32_t jk  = jr * g.k;  // this lane is SOURCE index jr
+            const uint32_t row = (uint32_t)(off >> g.logN);
+            const uint64_t q   = g.q[g.sel.idx[row % g.nLimbs]];
+            const uint64_t v   = g.in[off];
+            g.out[rowBase + (jk & mask)] = ((jk >> g.logN) & 1u) ? q - v : v;
+        }
+    }
+}
+
+// ---- centred modulus switch of ONE source limb into every limb of a tower (a9) ----------------------
+// out[b][i][r] = SwitchModulus(src[b][r] : qSrc -> q_i)  (mubintvecnat.cpp:109-122); used by
+// DropLastElementAndScale (dcrtpoly-impl.h:703-704) and ModRaise (dcrtpoly-impl.h:87-93).
+// Optionally fused with the per-limb constant multiply that follows it in the rescale (tmp *= const).
+struct SwitchModArgs {
+    uint64_t* out;        // [batch][nLimbs][N]
+    const uint64_t* src;  // [batch][srcStrideLimbs][N], limb srcLimbPos of each tower is the source
+    const uint64_t* q;    // [ctxLimbs]
+    const TwPair* consts; // [nLimbs] or null
+    uint32_t logN, nLimbs, rows, srcStrideLimbs, srcLimbPos, srcCtxLimb;
+    LimbSel sel;
+};
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) switch_modulus_kernel(const SwitchModArgs g) {
+    const uint32_t t          = FHE_TID;
+    const uint64_t base       = (uint64_t)FHE_BID << kTileLog;
+    const uint64_t totalWords = (uint64_t)g.rows << g.logN;
+    const uint32_t mask       = (1u << g.logN) - 1u;
+    const uint64_t qs         = g.q[g.srcCtxLimb];
+    const uint64_t halfQ      = qs >> 1;
+#pragma unroll 4
+    for (int m = 0; m < 16; ++m) {
+        const uint64_t off = base + (uint64_t)m * kThreads + t;
+        if (off >= totalWords)
+            continue;
+        const uint32_t row = (uint32_t)(off >> g.logN);
+        const uint32_t b = row / g.nLimbs, rit = row % g.nLimbs;
+        const uint64_t qn = g.q[g.sel.idx[rit]];
+        uint64_t v = g.src[(((uint64_t)b * g.srcStrideLimbs + g.srcLimbPos) << g.logN) + ((uint32_t)off & mask)];
+        if (qn > qs) {
+            v += (v > halfQ) ? (qn - qs) : 0;
+        }
+        else {
+            // ModSubEq semantics (ubintnat.h:889-899): operands reduced mod qn first
+            uint64_t bv = (v > halfQ) ? (qs - qn) : 0;
+            uint64_t av = v;
+            if (av >= qn)
+                av %= qn;
+            if (bv >= qn)
+                bv %= qn;
+            v = (av < bv) ? av + qn - bv : av - bv;
+        }
+        if (g.consts) {
+            const TwPair c = g.consts[rit];
+            v              = mul_shoup(v, c.w, c.wp, qn);
+        }
+        g.out[off] = v;
+    }
+}
+
+}  // namespace fhe
+#endif

@@ -1,0 +1,1178 @@
+// fhe_hip.cpp — implementation of the C ABI in include/fhe_hip.h (compiled by hipcc for gfx950).
+//
+// Host logic only: contexts (device twiddle tables), pass planning for the NTT, conversion / key-switch
+// plans (tables as CryptoParametersRNS::PrecomputeCRTTables builds them,
+// src/pke/lib/schemerns/rns-cryptoparameters.cpp:80-350) and the launch sequences that replace
+// KeySwitchHYBRID (src/pke/lib/keyswitch/keyswitch-hybrid.cpp:308-435), ApproxModDown
+// (src/core/include/lattice/hal/default/dcrtpoly-impl.h:966-1005) and DropLastElementAndScale (:693-712).
+// All arithmetic runs in the kernels of ntt_kernels.h / elemwise_kernels.h / basis_kernels.h.
+#include "../../include/fhe_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "basis_kernels.h"
+#include "elemwise_kernels.h"
+#include "host_math.h"
+#include "ntt_kernels.h"
+#include "rt.h"
+
+using namespace fhe;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_lastError;
+static fhe_status fail(fhe_status code, const std::string& msg) {
+    g_lastError = msg;
+    return code;
+}
+#define RT_CHECK(expr)                                                                  \
+    do {                                                                                \
+        const char* _e = (expr);                                                        \
+        if (_e)                                                                         \
+            return fail(FHE_ERR_DEVICE, std::string(#expr) + ": " + _e);                \
+    } while (0)
+#define ARG_CHECK(cond, msg)                  \
+    do {                                      \
+        if (!(cond))                          \
+            return fail(FHE_ERR_ARG, msg);    \
+    } while (0)
+
+extern "C" const char* fhe_last_error(void) { return g_lastError.c_str(); }
+extern "C" const char* fhe_version(void) {
+#ifdef FHE_EMU
+    return "fhe_hip 0.1 (TEST lane emulator build — not a product build)";
+#else
+    return "fhe_hip 0.1 (gfx950)";
+#endif
+}
+extern "C" int fhe_device_count(void) { return rt::device_count(); }
+
+// ------------------------------------------------------------------------------------------------
+// host math
+// ------------------------------------------------------------------------------------------------
+namespace fhe {
+namespace host {
+bool is_prime(uint64_t n) {
+    static const uint64_t w[] = {2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37};
+    if (n < 2)
+        return false;
+    for (uint64_t p : w) {
+        if (n == p)
+            return true;
+        if (n % p == 0)
+            return false;
+    }
+    uint64_t d = n - 1;
+    int s      = 0;
+    while (!(d & 1)) {
+        d >>= 1;
+        ++s;
+    }
+    for (uint64_t a : w) {
+        uint64_t x = powmod(a, d, n);
+        if (x == 1 || x == n - 1)
+            continue;
+        bool comp = true;
+        for (int r = 1; r < s && comp; ++r) {
+            x = mulmod(x, x, n);
+            if (x == n - 1)
+                comp = false;
+        }
+        if (comp)
+            return false;
+    }
+    return true;
+}
+bool is_primitive_root_2n(uint64_t psi, uint64_t twoN, uint64_t q) {
+    return psi != 0 && psi < q && powmod(psi, twoN / 2, q) == q - 1;
+}
+uint64_t first_prime(uint32_t bits, uint64_t m) {  // nbtheory-impl.h:329-347
+    uint64_t q = (uint64_t)1 << bits, r = q % m, c = q + 1 - r;
+    if (r > 0)
+        c += m;
+    while (!is_prime(c))
+        c += m;
+    return c;
+}
+uint64_t last_prime(uint32_t bits, uint64_t m) {  // nbtheory-impl.h:349-373
+    uint64_t q = (uint64_t)1 << bits, r = q % m, c = q + 1 - r;
+    if (r < 2)
+        c -= m;
+    while (!is_prime(c))
+        c -= m;
+    return c;
+}
+uint64_t previous_prime(uint64_t q, uint64_t m) {
+    uint64_t c = q - m;
+    while (!is_prime(c))
+        c -= m;
+    return c;
+}
+uint64_t next_prime(uint64_t q, uint64_t m) {
+    uint64_t c = q + m;
+    while (!is_prime(c))
+        c += m;
+    return c;
+}
+uint64_t min_root_of_unity(uint64_t m, uint64_t q) {  // nbtheory-impl.h:183-231
+    uint64_t e = (q - 1) / m, root = 0;
+    for (uint64_t g = 2; g < q; ++g) {
+        uint64_t r = powmod(g, e, q);
+        if (powmod(r, m / 2, q) == q - 1) {
+            root = r;
+            break;
+        }
+    }
+    uint64_t sq = mulmod(root, root, q), x = root, best = root;
+    for (uint64_t i = 1; i < m / 2; ++i) {
+        x = mulmod(x, sq, q);
+        if (x < best)
+            best = x;
+    }
+    return best;
+}
+uint64_t prod_mod(const std::vector<uint64_t>& mods, int skip, uint64_t mod) {
+    uint64_t v = 1 % mod;
+    for (int k = 0; k < (int)mods.size(); ++k)
+        if (k != skip)
+            v = mulmod(v, mods[k] % mod, mod);
+    return v;
+}
+}  // namespace host
+}  // namespace fhe
+
+// ------------------------------------------------------------------------------------------------
+// host-side parameter helpers
+// ------------------------------------------------------------------------------------------------
+extern "C" uint64_t fhe_param_first_prime(uint32_t bits, uint64_t m) { return host::first_prime(bits, m); }
+extern "C" uint64_t fhe_param_last_prime(uint32_t bits, uint64_t m) { return host::last_prime(bits, m); }
+extern "C" uint64_t fhe_param_next_prime(uint64_t q, uint64_t m) { return host::next_prime(q, m); }
+extern "C" uint64_t fhe_param_previous_prime(uint64_t q, uint64_t m) { return host::previous_prime(q, m); }
+extern "C" uint64_t fhe_param_root_of_unity(uint64_t m, uint64_t q) {
+    if (m == 0 || (m & (m - 1)) || (q - 1) % m != 0)
+        return 0;
+    return host::min_root_of_unity(m, q);
+}
+extern "C" fhe_status fhe_param_dcrt_chain(uint32_t order, uint32_t nLimbs, uint32_t bits, uint64_t* q, uint64_t* psi) {
+    ARG_CHECK(q && psi && nLimbs >= 1, "fhe_param_dcrt_chain: null argument");
+    ARG_CHECK(bits >= 4 && bits <= 60, "Invalid bits for ILDCRTParams");  // ildcrtparams.h:103-104 (MAX_MODULUS_SIZE 60)
+    ARG_CHECK(order >= 2 && (order & (order - 1)) == 0, "fhe_param_dcrt_chain: order must be a power of two");
+    uint64_t cur = host::last_prime(bits, order);
+    for (uint32_t i = 0; i < nLimbs; ++i) {
+        if (i)
+            cur = host::previous_prime(cur, order);
+        q[i]   = cur;
+        psi[i] = host::min_root_of_unity(order, cur);
+    }
+    return FHE_OK;
+}
+extern "C" uint32_t fhe_param_select_p(uint32_t logN, uint32_t sizeQ, const uint64_t* q, uint32_t numPartQ,
+                                       uint32_t auxBits, uint64_t* p, uint64_t* psiP) {
+    if (!q || !p || !psiP || numPartQ == 0 || sizeQ == 0 || auxBits < 4 || auxBits > 60)
+        return 0;
+    const uint32_t a = (sizeQ + numPartQ - 1) / numPartQ;
+    uint32_t maxBits = 0;
+    for (uint32_t j = 0; j < numPartQ; ++j) {  // bit length of each composite digit (exact, multi-word product)
+        std::vector<uint64_t> big(1, 1);
+        for (uint32_t i = a * j; i < (j + 1) * a && i < sizeQ; ++i) {
+            uint64_t carry = 0;
+            for (auto& w : big) {
+                host::u128 t = (host::u128)w * q[i] + carry;
+                w            = (uint64_t)t;
+                carry        = (uint64_t)(t >> 64);
+            }
+            if (carry)
+                big.push_back(carry);
+        }
+        maxBits = std::max(maxBits, (uint32_t)(64 * (big.size() - 1) + host::bitlen(big.back())));
+    }
+    const uint32_t sizeP = (maxBits + auxBits - 1) / auxBits;
+    if (sizeP > 64)
+        return 0;
+    const uint64_t step = 2ull << logN;
+    uint64_t prev       = host::first_prime(auxBits, step);
+    for (uint32_t i = 0; i < sizeP; ++i) {
+        bool inQ;
+        do {
+            p[i] = host::previous_prime(prev, step);
+            inQ  = false;
+            for (uint32_t j = 0; j < sizeQ; ++j)
+                inQ |= (p[i] == q[j]);
+            prev = p[i];
+        } while (inQ);
+        psiP[i] = host::min_root_of_unity(step, p[i]);
+    }
+    return sizeP;
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct fhe_ctx {
+    uint32_t logN = 0, N = 0, L = 0;
+    int device    = 0;
+    std::vector<uint64_t> q, psi;
+    // device tables
+    TwPair* d_tw      = nullptr;  // [L][N] forward
+    TwPair* d_twInv   = nullptr;  // [L][N] inverse
+    TwPair* d_fin     = nullptr;  // [L][2] {N^-1, TableInv[1]*N^-1}
+    uint64_t* d_q     = nullptr;  // [L]
+    LimbConst* d_lc   = nullptr;  // [L]
+    uint64_t* d_mu128 = nullptr;  // [L][2]
+    std::vector<void*> owned;     // every device allocation made for tables (freed in destroy)
+    // cached per-level rescale tables (ckksrns-cryptoparameters.cpp:60-81): sizeQl -> {A, B} device arrays
+    std::map<uint32_t, std::pair<TwPair*, TwPair*>> rescaleTabs;
+    // small ring of device slots for per-call constant vectors (fhe_mul_const)
+    TwPair* d_constRing = nullptr;
+    uint32_t constRingPos = 0;
+};
+static const uint32_t kConstRingSlots = 64;
+
+static fhe_status upload(fhe_ctx* c, const void* host, size_t bytes, void** dev) {
+    RT_CHECK(rt::dmalloc(dev, bytes));
+    c->owned.push_back(*dev);
+    RT_CHECK(rt::h2d(*dev, host, bytes, nullptr));
+    RT_CHECK(rt::sync(nullptr));
+    return FHE_OK;
+}
+
+extern "C" fhe_status fhe_ctx_create(uint32_t logN, uint32_t nLimbs, const uint64_t* q, const uint64_t* psi,
+                                     int device, fhe_ctx** out) {
+    ARG_CHECK(out != nullptr, "fhe_ctx_create: out is null");
+    ARG_CHECK(logN >= 4 && logN <= 17, "fhe_ctx_create: logN must be in [4,17]");
+    ARG_CHECK(nLimbs >= 1 && nLimbs <= (uint32_t)kMaxLimbs, "fhe_ctx_create: nLimbs must be in [1,128]");
+    ARG_CHECK(q && psi, "fhe_ctx_create: null modulus/root array");
+    if (rt::device_count() <= 0)
+        return fail(FHE_ERR_DEVICE, "fhe_ctx_create: no HIP device available (there is no CPU fallback)");
+    ARG_CHECK(device >= 0 && device < rt::device_count(), "fhe_ctx_create: bad device ordinal");
+    const uint32_t N = 1u << logN;
+    for (uint32_t i = 0; i < nLimbs; ++i) {
+        ARG_CHECK(q[i] > 2 && q[i] < ((uint64_t)1 << 60), "fhe_ctx_create: modulus must be < 2^60");
+        ARG_CHECK((q[i] - 1) % (2ull * N) == 0, "fhe_ctx_create: modulus must be 1 mod 2N");
+        ARG_CHECK(host::is_primitive_root_2n(psi[i], 2ull * N, q[i]),
+                  "fhe_ctx_create: psi is not a primitive 2N-th root of unity");
+    }
+    RT_CHECK(rt::set_device(device));
+    fhe_ctx* c = new fhe_ctx;
+    c->logN    = logN;
+    c->N       = N;
+    c->L       = nLimbs;
+    c->device  = device;
+    c->q.assign(q, q + nLimbs);
+    c->psi.assign(psi, psi + nLimbs);
+
+    // twiddle tables: Table[bitrev(i)] = psi^i, TableI[bitrev(i)] = psi^-i  (transformnat-impl.h:725-737)
+    std::vector<TwPair> tw((size_t)nLimbs * N), twInv((size_t)nLimbs * N), fin((size_t)nLimbs * 2);
+    std::vector<LimbConst> lc(nLimbs);
+    std::vector<uint64_t> mu(2 * (size_t)nLimbs);
+#pragma omp parallel for schedule(dynamic)
+    for (uint32_t l = 0; l < nLimbs; ++l) {
+        const uint64_t ql = q[l], ps = psi[l], psInv = host::invmod(ps, ql);
+        uint64_t x = 1, xi = 1;
+        TwPair* t  = tw.data() + (size_t)l * N;
+        TwPair* ti = twInv.data() + (size_t)l * N;
+        for (uint32_t i = 0; i < N; ++i) {
+            const uint32_t r = host::bitrev(i, logN);
+            t[r]             = TwPair{x, host::shoup(x, ql)};
+            ti[r]            = TwPair{xi, host::shoup(xi, ql)};
+            x                = host::mulmod(x, ps, ql);
+            xi               = host::mulmod(xi, psInv, ql);
+        }
+        const uint64_t nInv = host::invmod((uint64_t)N % ql, ql);
+        const uint64_t w1n  = host::mulmod(ti[1].w, nInv, ql);  // transformnat-impl.h:533-534
+        fin[2 * l]          = TwPair{nInv, host::shoup(nInv, ql)};
+        fin[2 * l + 1]      = TwPair{w1n, host::shoup(w1n, ql)};
+        lc[l]               = LimbConst{ql, host::barrett_mu(ql), host::bitlen(ql), 0};
+        host::mu128(ql, &mu[2 * l]);
+    }
+    fhe_status s;
+    if ((s = upload(c, tw.data(), tw.size() * sizeof(TwPair), (void**)&c->d_tw)) ||
+        (s = upload(c, twInv.data(), twInv.size() * sizeof(TwPair), (void**)&c->d_twInv)) ||
+        (s = upload(c, fin.data(), fin.size() * sizeof(TwPair), (void**)&c->d_fin)) ||
+        (s = upload(c, c->q.data(), nLimbs * sizeof(uint64_t), (void**)&c->d_q)) ||
+        (s = upload(c, lc.data(), nLimbs * sizeof(LimbConst), (void**)&c->d_lc)) ||
+        (s = upload(c, mu.data(), mu.size() * sizeof(uint64_t), (void**)&c->d_mu128))) {
+        fhe_ctx_destroy(c);
+        return s;
+    }
+    *out = c;
+    return FHE_OK;
+}
+
+extern "C" void fhe_ctx_destroy(fhe_ctx* c) {
+    if (!c)
+        return;
+    rt::set_device(c->device);
+    for (void* p : c->owned)
+        rt::dfree(p);
+    delete c;
+}
+extern "C" uint32_t fhe_ctx_logn(const fhe_ctx* c) { return c ? c->logN : 0; }
+extern "C" uint32_t fhe_ctx_limbs(const fhe_ctx* c) { return c ? c->L : 0; }
+extern "C" int fhe_ctx_device(const fhe_ctx* c) { return c ? c->device : -1; }
+
+// ------------------------------------------------------------------------------------------------
+// memory / streams
+// ------------------------------------------------------------------------------------------------
+extern "C" fhe_status fhe_malloc(fhe_ctx* c, size_t bytes, void** p) {
+    ARG_CHECK(c && p, "fhe_malloc: null argument");
+    RT_CHECK(rt::set_device(c->device));
+    if (const char* e = rt::dmalloc(p, bytes))
+        return fail(FHE_ERR_ALLOC, std::string("fhe_malloc: ") + e);
+    return FHE_OK;
+}
+extern "C" fhe_status fhe_free(fhe_ctx* c, void* p) {
+    ARG_CHECK(c, "fhe_free: null context");
+    RT_CHECK(rt::dfree(p));
+    return FHE_OK;
+}
+extern "C" fhe_status fhe_memcpy_h2d(fhe_ctx* c, void* d, const void* s, size_t n, void* st) {
+    ARG_CHECK(c && d && s, "fhe_memcpy_h2d: null argument");
+    RT_CHECK(rt::h2d(d, s, n, (rt::stream_t)st));
+    return FHE_OK;
+}
+extern "C" fhe_status fhe_memcpy_d2h(fhe_ctx* c, void* d, const void* s, size_t n, void* st) {
+    ARG_CHECK(c && d && s, "fhe_memcpy_d2h: null argument");
+    RT_CHECK(rt::d2h(d, s, n, (rt::stream_t)st));
+    return FHE_OK;
+}
+extern "C" fhe_status fhe_memcpy_d2d(fhe_ctx* c, void* d, const void* s, size_t n, void* st) {
+    ARG_CHECK(c && d && s, "fhe_memcpy_d2d: null argument");
+    RT_CHECK(rt::d2d(d, s, n, (rt::stream_t)st));
+    return FHE_OK;
+}
+extern "C" fhe_status fhe_stream_sync(fhe_ctx* c, void* st) {
+    ARG_CHECK(c, "fhe_stream_sync: null context");
+    RT_CHECK(rt::sync((rt::stream_t)st));
+    return FHE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+static fhe_status make_sel(const fhe_ctx* c, const uint32_t* limbIdx, uint32_t nLimbs, LimbSel* sel, const char* who) {
+    if (nLimbs < 1 || nLimbs > (uint32_t)kMaxLimbs)
+        return fail(FHE_ERR_ARG, std::string(who) + ": nLimbs out of range");
+    for (uint32_t i = 0; i < nLimbs; ++i) {
+        uint32_t l = limbIdx ? limbIdx[i] : i;
+        if (l >= c->L)
+            return fail(FHE_ERR_ARG, std::string(who) + ": limb index exceeds context size");
+        sel->idx[i] = (uint8_t)l;
+    }
+    for (uint32_t i = nLimbs; i < (uint32_t)kMaxLimbs; ++i)
+        sel->idx[i] = 0;
+    return FHE_OK;
+}
+static inline uint32_t tiles_for(const fhe_ctx* c, uint64_t rows) {
+    const uint64_t words = rows << c->logN;
+    return (uint32_t)((words + kTile - 1) >> kTileLog);
+}
+#define LAUNCH_CHECK() RT_CHECK(rt::last_launch_error())
+
+// ------------------------------------------------------------------------------------------------
+// NTT planning
+// ------------------------------------------------------------------------------------------------
+struct PassPlan {
+    bool layoutA;
+    uint32_t T;
+    uint32_t nSteps;
+    NttStep steps[6];
+};
+
+// stages of one pass act on the T bits of the in-tile point index p (bit T-1 first for the forward
+// transform, bit 0 first for the inverse); they are grouped into register-resident steps of <= 4 stages.
+static void plan_pass(bool inverse, bool layoutA, uint32_t logN, uint32_t T, PassPlan* pp) {
+    pp->layoutA     = layoutA;
+    pp->T           = T;
+    const int logC  = kTileLog - (int)T;
+    const int jsh   = layoutA ? (int)(logN - T) : 0;  // p bit b  <->  j bit b + jsh
+    const int ish   = layoutA ? logC : 0;             // p bit b  <->  tile-index bit b + ish
+    const int nst   = (int)(T + 3) / 4;
+    int sizes[4];
+    for (int i = 0; i < nst; ++i)
+        sizes[i] = (int)T / nst + (i < (int)T % nst ? 1 : 0);
+    NttStep real[4];
+    if (!inverse) {
+        int top = (int)T - 1;
+        for (int i = 0; i < nst; ++i) {
+            const int r = sizes[i], fp = std::max(top - 3, 0);
+            real[i] = NttStep{(int8_t)(fp + ish), (int8_t)(fp + jsh), (int8_t)(top - fp), (int8_t)(top - fp - r + 1)};
+            top -= r;
+        }
+    }
+    else {
+        int bot = 0;
+        for (int i = 0; i < nst; ++i) {
+            const int r = sizes[i], fp = std::min(bot, (int)T - 4);
+            real[i] = NttStep{(int8_t)(fp + ish), (int8_t)(fp + jsh), (int8_t)(bot - fp + r - 1), (int8_t)(bot - fp)};
+            bot += r;
+        }
+    }
+    // staging steps: a first/last step whose register field sits below tile-index bit 4 would touch HBM in
+    // < 128-byte pieces; route it through LDS with the fully coalesced mapping (field at bits 8..11) instead
+    uint32_t n = 0;
+    const NttStep stage{8, 0, -1, 0};
+    if (!layoutA && real[0].fI < 4)
+        pp->steps[n++] = stage;
+    for (int i = 0; i < nst; ++i)
+        pp->steps[n++] = real[i];
+    if (!layoutA && real[nst - 1].fI < 4)
+        pp->steps[n++] = stage;
+    pp->nSteps = n;
+}
+
+static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse, const uint64_t* xin, uint64_t* xout,
+                              const LimbSel& sel, uint32_t nLimbs, uint32_t batch, bool canonOut, void* stream,
+                              uint32_t inStride = 0, uint32_t inFirst = 0) {
+    NttPassArgs a;
+    a.inStride = inStride;
+    a.inFirst  = inFirst;
+    a.xin      = xin;
+    a.x        = xout;
+    a.tw       = inverse ? c->d_twInv : c->d_tw;
+    a.q        = c->d_q;
+    a.fin      = c->d_fin;
+    a.logN     = c->logN;
+    a.T        = pp.T;
+    a.nLimbs   = nLimbs;
+    a.rows     = batch * nLimbs;
+    a.batch    = batch;
+    a.nSteps   = pp.nSteps;
+    // canonicalise right after the last step that has butterfly stages (a trailing staging step only moves data)
+    a.canonStep = 0xffffffffu;
+    if (canonOut)
+        for (uint32_t i = 0; i < pp.nSteps; ++i)
+            if (pp.steps[i].bHi >= pp.steps[i].bLo)
+                a.canonStep = i;
+    for (uint32_t i = 0; i < 6; ++i)
+        a.steps[i] = i < pp.nSteps ? pp.steps[i] : NttStep{0, 0, -1, 0};
+    a.sel = sel;
+    const uint32_t grid        = tiles_for(c, a.rows);
+    const uint32_t tilesPerRow = c->N >= (uint32_t)kTile ? (c->N >> kTileLog) : 1u;
+    a.xcdSwizzle = (c->N >= (uint32_t)kTile && ((nLimbs * tilesPerRow) % 8u == 0)) ? 1u : 0u;
+    if (pp.layoutA) {
+        if (inverse)
+            FHE_LAUNCH((ntt_pass_kernel<true, true>), grid, stream, a);
+        else
+            FHE_LAUNCH((ntt_pass_kernel<true, false>), grid, stream, a);
+    }
+    else {
+        if (inverse)
+            FHE_LAUNCH((ntt_pass_kernel<false, true>), grid, stream, a);
+        else
+            FHE_LAUNCH((ntt_pass_kernel<false, false>), grid, stream, a);
+    }
+    LAUNCH_CHECK();
+    return FHE_OK;
+}
+
+// inStride != 0: xin is a [batch][inStride][N] view whose rows inFirst.. are transformed into the dense xout
+static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_t* xout, const uint32_t* limbIdx,
+                          uint32_t nLimbs, uint32_t batch, void* stream, uint32_t inStride = 0, uint32_t inFirst = 0) {
+    ARG_CHECK(c && xin && xout, "fhe_ntt: null argument");
+    ARG_CHECK(batch >= 1, "fhe_ntt: batch must be >= 1");
+    LimbSel sel;
+    if (fhe_status s = make_sel(c, limbIdx, nLimbs, &sel, "fhe_ntt"))
+        return s;
+    RT_CHECK(rt::set_device(c->device));
+    const uint32_t logN = c->logN;
+    if (logN <= (uint32_t)kTileLog) {
+        PassPlan p;
+        plan_pass(inverse, false, logN, logN, &p);
+        return launch_pass(c, p, inverse, xin, xout, sel, nLimbs, batch, true, stream, inStride, inFirst);
+    }
+    // two passes over HBM: a strided column pass of T1 stages (the coefficient index's top bits) and a
+    // contiguous row pass of T2 = logN - T1 stages.  T1 is kept minimal (>= 4) so that the column pass reads
+    // rows of 2^(12-T1) consecutive words (2 KiB at T1 = 4) and, at T1 = 4, needs no LDS at all.
+    const uint32_t T1 = std::max(4u, logN - (uint32_t)kTileLog), T2 = logN - T1;
+    PassPlan pa, pb;
+    plan_pass(inverse, true, logN, T1, &pa);
+    plan_pass(inverse, false, logN, T2, &pb);
+    if (!inverse) {
+        if (fhe_status s = launch_pass(c, pa, false, xin, xout, sel, nLimbs, batch, false, stream, inStride, inFirst))
+            return s;
+        return launch_pass(c, pb, false, xout, xout, sel, nLimbs, batch, true, stream);
+    }
+    if (fhe_status s = launch_pass(c, pb, true, xin, xout, sel, nLimbs, batch, false, stream, inStride, inFirst))
+        return s;
+    return launch_pass(c, pa, true, xout, xout, sel, nLimbs, batch, true, stream);
+}
+
+extern "C" fhe_status fhe_ntt_fwd(fhe_ctx* c, uint64_t* x, const uint32_t* li, uint32_t nl, uint32_t b, void* st) {
+    return ntt_run(c, false, x, x, li, nl, b, st);
+}
+extern "C" fhe_status fhe_ntt_inv(fhe_ctx* c, uint64_t* x, const uint32_t* li, uint32_t nl, uint32_t b, void* st) {
+    return ntt_run(c, true, x, x, li, nl, b, st);
+}
+extern "C" fhe_status fhe_ntt_fwd_oop(fhe_ctx* c, const uint64_t* xi, uint64_t* xo, const uint32_t* li, uint32_t nl,
+                                      uint32_t b, void* st) {
+    return ntt_run(c, false, xi, xo, li, nl, b, st);
+}
+extern "C" fhe_status fhe_ntt_inv_oop(fhe_ctx* c, const uint64_t* xi, uint64_t* xo, const uint32_t* li, uint32_t nl,
+                                      uint32_t b, void* st) {
+    return ntt_run(c, true, xi, xo, li, nl, b, st);
+}
+
+// dir: 0 fwd, 1 inv, 2 fwd then inv; 10/11 = only the column / row pass of the forward transform,
+// 12/13 = only the row / column pass of the inverse (two-pass rings; timing only, data is not meaningful)
+extern "C" fhe_status fhe_time_ntt(fhe_ctx* c, uint64_t* x, const uint32_t* li, uint32_t nl, uint32_t b, int dir,
+                                   int iters, void* st, float* ms) {
+    ARG_CHECK(c && x && ms && iters > 0, "fhe_time_ntt: bad argument");
+    LimbSel sel;
+    if (fhe_status s = make_sel(c, li, nl, &sel, "fhe_time_ntt"))
+        return s;
+    RT_CHECK(rt::set_device(c->device));
+    PassPlan pp;
+    if (dir >= 10) {
+        ARG_CHECK(c->logN > (uint32_t)kTileLog && dir <= 13, "fhe_time_ntt: single-pass timing needs a two-pass ring");
+        const uint32_t T1 = std::max(4u, c->logN - (uint32_t)kTileLog), T2 = c->logN - T1;
+        const bool inv = dir >= 12, colPass = (dir == 10 || dir == 13);
+        plan_pass(inv, colPass, c->logN, colPass ? T1 : T2, &pp);
+    }
+    rt::Timer tm;
+    RT_CHECK(tm.start((rt::stream_t)st));
+    for (int i = 0; i < iters; ++i) {
+        if (dir >= 10) {
+            if (fhe_status s = launch_pass(c, pp, dir >= 12, x, x, sel, nl, b, false, st))
+                return s;
+            continue;
+        }
+        if (dir == 0 || dir == 2)
+            if (fhe_status s = fhe_ntt_fwd(c, x, li, nl, b, st))
+                return s;
+        if (dir == 1 || dir == 2)
+            if (fhe_status s = fhe_ntt_inv(c, x, li, nl, b, st))
+                return s;
+    }
+    float total = 0;
+    RT_CHECK(tm.stop((rt::stream_t)st, &total));
+    *ms = total / iters;
+    return FHE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// element-wise
+// ------------------------------------------------------------------------------------------------
+template <int OP>
+static fhe_status elem_run(fhe_ctx* c, uint64_t* out, const uint64_t* a, const uint64_t* b, const TwPair* d_consts,
+                           const uint32_t* limbIdx, uint32_t nLimbs, uint32_t batch, void* stream, const char* who,
+                           uint32_t aStride = 0, uint32_t aFirst = 0, uint32_t bStride = 0, uint32_t bFirst = 0) {
+    ARG_CHECK(c && out && a, std::string(who) + ": null argument");
+    ARG_CHECK(batch >= 1, std::string(who) + ": batch must be >= 1");
+    ElemArgs g;
+    if (fhe_status s = make_sel(c, limbIdx, nLimbs, &g.sel, who))
+        return s;
+    RT_CHECK(rt::set_device(c->device));
+    g.out    = out;
+    g.a      = a;
+    g.b      = b;
+    g.lc     = c->d_lc;
+    g.consts = d_consts;
+    g.logN   = c->logN;
+    g.nLimbs = nLimbs;
+    g.rows   = batch * nLimbs;
+    g.aStride = aStride, g.aFirst = aFirst, g.bStride = bStride, g.bFirst = bFirst;
+    FHE_LAUNCH((elemwise_kernel<OP>), tiles_for(c, g.rows), stream, g);
+    LAUNCH_CHECK();
+    return FHE_OK;
+}
+extern "C" fhe_status fhe_add(fhe_ctx* c, uint64_t* o, const uint64_t* a, const uint64_t* b, const uint32_t* li,
+                              uint32_t nl, uint32_t bt, void* st) {
+    ARG_CHECK(b, "fhe_add: null argument");
+    return elem_run<OP_ADD>(c, o, a, b, nullptr, li, nl, bt, st, "fhe_add");
+}
+extern "C" fhe_status fhe_sub(fhe_ctx* c, uint64_t* o, const uint64_t* a, const uint64_t* b, const uint32_t* li,
+                              uint32_t nl, uint32_t bt, void* st) {
+    ARG_CHECK(b, "fhe_sub: null argument");
+    return elem_run<OP_SUB>(c, o, a, b, nullptr, li, nl, bt, st, "fhe_sub");
+}
+extern "C" fhe_status fhe_mul(fhe_ctx* c, uint64_t* o, const uint64_t* a, const uint64_t* b, const uint32_t* li,
+                              uint32_t nl, uint32_t bt, void* st) {
+    ARG_CHECK(b, "fhe_mul: null argument");
+    return elem_run<OP_MUL>(c, o, a, b, nullptr, li, nl, bt, st, "fhe_mul");
+}
+extern "C" fhe_status fhe_neg(fhe_ctx* c, uint64_t* o, const uint64_t* a, const uint32_t* li, uint32_t nl, uint32_t bt,
+                              void* st) {
+    return elem_run<OP_NEG>(c, o, a, nullptr, nullptr, li, nl, bt, st, "fhe_neg");
+}
+
+// per-call constant vectors (fhe_mul_const) go through a small ring of device slots; the upload is
+// synchronous on `stream`, so a slot is only reused after kConstRingSlots later calls have completed theirs
+static fhe_status consts_to_device(fhe_ctx* c, const uint64_t* consts, const uint32_t* limbIdx, uint32_t nLimbs,
+                                   void* stream, TwPair** d_out) {
+    std::vector<TwPair> h(nLimbs);
+    for (uint32_t i = 0; i < nLimbs; ++i) {
+        const uint64_t ql = c->q[limbIdx ? limbIdx[i] : i];
+        const uint64_t v  = consts[i] % ql;
+        h[i]              = TwPair{v, host::shoup(v, ql)};
+    }
+    if (!c->d_constRing) {
+        void* d = nullptr;
+        RT_CHECK(rt::dmalloc(&d, (size_t)kConstRingSlots * kMaxLimbs * sizeof(TwPair)));
+        c->owned.push_back(d);
+        c->d_constRing = (TwPair*)d;
+    }
+    TwPair* slot    = c->d_constRing + (size_t)(c->constRingPos % kConstRingSlots) * kMaxLimbs;
+    c->constRingPos = c->constRingPos + 1;
+    RT_CHECK(rt::h2d(slot, h.data(), nLimbs * sizeof(TwPair), (rt::stream_t)stream));
+    RT_CHECK(rt::sync((rt::stream_t)stream));  // h is a stack-lifetime staging buffer
+    *d_out = slot;
+    return FHE_OK;
+}
+extern "C" fhe_status fhe_mul_const(fhe_ctx* c, uint64_t* o, const uint64_t* a, const uint64_t* consts,
+                                    const uint32_t* li, uint32_t nl, uint32_t bt, void* st) {
+    ARG_CHECK(c && consts, "fhe_mul_const: null argument");
+    ARG_CHECK(nl >= 1 && nl <= (uint32_t)kMaxLimbs, "fhe_mul_const: nLimbs out of range");
+    for (uint32_t i = 0; i < nl; ++i)
+        ARG_CHECK((li ? li[i] : i) < c->L, "fhe_mul_const: limb index exceeds context size");
+    TwPair* d = nullptr;
+    if (fhe_status s = consts_to_device(c, consts, li, nl, st, &d))
+        return s;
+    return elem_run<OP_MUL_CONST>(c, o, a, nullptr, d, li, nl, bt, st, "fhe_mul_const");
+}
+
+extern "C" fhe_status fhe_tensor(fhe_ctx* c, const uint64_t* a0, const uint64_t* a1, const uint64_t* b0,
+                                 const uint64_t* b1, uint64_t* d0, uint64_t* d1, uint64_t* d2, const uint32_t* li,
+                                 uint32_t nl, uint32_t bt, void* st) {
+    ARG_CHECK(c && a0 && a1 && b0 && b1 && d0 && d1 && d2, "fhe_tensor: null argument");
+    ARG_CHECK(bt >= 1, "fhe_tensor: batch must be >= 1");
+    TensorArgs g;
+    if (fhe_status s = make_sel(c, li, nl, &g.sel, "fhe_tensor"))
+        return s;
+    RT_CHECK(rt::set_device(c->device));
+    g.a0 = a0, g.a1 = a1, g.b0 = b0, g.b1 = b1, g.d0 = d0, g.d1 = d1, g.d2 = d2;
+    g.lc     = c->d_lc;
+    g.logN   = c->logN;
+    g.nLimbs = nl;
+    g.rows   = bt * nl;
+    FHE_LAUNCH(tensor_kernel, tiles_for(c, g.rows), st, g);
+    LAUNCH_CHECK();
+    return FHE_OK;
+}
+
+extern "C" fhe_status fhe_automorph(fhe_ctx* c, uint64_t* out, const uint64_t* in, uint32_t k, int evalFormat,
+                                    const uint32_t* li, uint32_t nl, uint32_t bt, void* st) {
+    ARG_CHECK(c && out && in, "fhe_automorph: null argument");
+    ARG_CHECK(out != in, "fhe_automorph: out must not alias in");
+    ARG_CHECK(k % 2 == 1, "Automorphism index not odd");  // poly-impl.h:337-338
+    ARG_CHECK(bt >= 1, "fhe_automorph: batch must be >= 1");
+    AutoArgs g;
+    if (fhe_status s = make_sel(c, li, nl, &g.sel, "fhe_automorph"))
+        return s;
+    RT_CHECK(rt::set_device(c->device));
+    g.out = out, g.in = in, g.q = c->d_q;
+    g.logN = c->logN, g.nLimbs = nl, g.rows = bt * nl, g.k = k, g.evalFormat = evalFormat ? 1u : 0u;
+    FHE_LAUNCH(automorph_kernel, tiles_for(c, g.rows), st, g);
+    LAUNCH_CHECK();
+    return FHE_OK;
+}
+
+static fhe_status switch_modulus_run(fhe_ctx* c, uint64_t* out, const LimbSel& sel, uint32_t nl, const uint64_t* src,
+                                     uint32_t srcLimbs, uint32_t srcPos, uint32_t srcCtxLimb, const TwPair* d_consts,
+                                     uint32_t bt, void* st) {
+    SwitchModArgs g;
+    g.out = out, g.src = src, g.q = c->d_q, g.consts = d_consts;
+    g.logN = c->logN, g.nLimbs = nl, g.rows = bt * nl;
+    g.srcStrideLimbs = srcLimbs, g.srcLimbPos = srcPos, g.srcCtxLimb = srcCtxLimb;
+    g.sel = sel;
+    FHE_LAUNCH(switch_modulus_kernel, tiles_for(c, g.rows), st, g);
+    LAUNCH_CHECK();
+    return FHE_OK;
+}
+extern "C" fhe_status fhe_switch_modulus(fhe_ctx* c, uint64_t* out, const uint32_t* li, uint32_t nl, const uint64_t* src,
+                                         uint32_t srcLimbs, uint32_t srcPos, uint32_t srcCtxLimb, uint32_t bt,
+                                         void* st) {
+    ARG_CHECK(c && out && src, "fhe_switch_modulus: null argument");
+    ARG_CHECK(srcPos < srcLimbs && srcCtxLimb < c->L && bt >= 1, "fhe_switch_modulus: bad source limb");
+    LimbSel sel;
+    if (fhe_status s = make_sel(c, li, nl, &sel, "fhe_switch_modulus"))
+        return s;
+    RT_CHECK(rt::set_device(c->device));
+    return switch_modulus_run(c, out, sel, nl, src, srcLimbs, srcPos, srcCtxLimb, nullptr, bt, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// basis conversion plans
+// ------------------------------------------------------------------------------------------------
+struct fhe_conv {
+    fhe_ctx* ctx;
+    uint32_t nSrc, nDst;
+    ConvTables tb;
+    std::vector<void*> owned;
+};
+
+static fhe_status conv_upload(fhe_conv* cv, const void* h, size_t bytes, const void** d) {
+    void* p = nullptr;
+    RT_CHECK(rt::dmalloc(&p, bytes));
+    cv->owned.push_back(p);
+    RT_CHECK(rt::h2d(p, h, bytes, nullptr));
+    RT_CHECK(rt::sync(nullptr));
+    *d = p;
+    return FHE_OK;
+}
+
+// tables for converting from moduli src[] to dst[]   (rns-cryptoparameters.cpp:214-246, 297-349)
+static fhe_status conv_build(fhe_ctx* c, const std::vector<uint64_t>& src, const std::vector<uint64_t>& dst,
+                             fhe_conv** out) {
+    const uint32_t nSrc = (uint32_t)src.size(), nDst = (uint32_t)dst.size();
+    fhe_conv* cv = new fhe_conv;
+    cv->ctx      = c;
+    cv->nSrc     = nSrc;
+    cv->nDst     = nDst;
+    std::vector<TwPair> hatInv(nSrc);
+    std::vector<uint64_t> hatMod((size_t)nSrc * nDst), mu(2 * (size_t)nDst), alphaMod((size_t)(nSrc + 1) * nDst);
+    std::vector<double> qInv(nSrc);
+    for (uint32_t i = 0; i < nSrc; ++i) {
+        const uint64_t hat = host::prod_mod(src, (int)i, src[i]);
+        const uint64_t inv = host::invmod(hat, src[i]);
+        hatInv[i]          = TwPair{inv, host::shoup(inv, src[i])};
+        qInv[i]            = 1.0 / static_cast<double>(src[i]);
+        for (uint32_t j = 0; j < nDst; ++j)
+            hatMod[(size_t)i * nDst + j] = host::prod_mod(src, (int)i, dst[j]);
+    }
+    for (uint32_t j = 0; j < nDst; ++j) {
+        host::mu128(dst[j], &mu[2 * j]);
+        const uint64_t Qmod = host::prod_mod(src, -1, dst[j]);
+        for (uint32_t a = 0; a <= nSrc; ++a)
+            alphaMod[(size_t)a * nDst + j] = host::mulmod(a % dst[j], Qmod, dst[j]);
+    }
+    fhe_status s;
+    if ((s = conv_upload(cv, hatInv.data(), hatInv.size() * sizeof(TwPair), (const void**)&cv->tb.hatInv)) ||
+        (s = conv_upload(cv, hatMod.data(), hatMod.size() * 8, (const void**)&cv->tb.hatMod)) ||
+        (s = conv_upload(cv, src.data(), src.size() * 8, (const void**)&cv->tb.srcQ)) ||
+        (s = conv_upload(cv, dst.data(), dst.size() * 8, (const void**)&cv->tb.dstQ)) ||
+        (s = conv_upload(cv, mu.data(), mu.size() * 8, (const void**)&cv->tb.dstMu)) ||
+        (s = conv_upload(cv, qInv.data(), qInv.size() * sizeof(double), (const void**)&cv->tb.srcQInv)) ||
+        (s = conv_upload(cv, alphaMod.data(), alphaMod.size() * 8, (const void**)&cv->tb.alphaMod))) {
+        fhe_conv_destroy(cv);
+        return s;
+    }
+    *out = cv;
+    return FHE_OK;
+}
+
+extern "C" fhe_status fhe_conv_create(fhe_ctx* c, const uint32_t* srcIdx, uint32_t nSrc, const uint32_t* dstIdx,
+                                      uint32_t nDst, fhe_conv** out) {
+    ARG_CHECK(c && srcIdx && dstIdx && out, "fhe_conv_create: null argument");
+    ARG_CHECK(nSrc >= 1 && nSrc <= 64 && nDst >= 1 && nDst <= (uint32_t)kMaxLimbs, "fhe_conv_create: bad basis size");
+    std::vector<uint64_t> src(nSrc), dst(nDst);
+    for (uint32_t i = 0; i < nSrc; ++i) {
+        ARG_CHECK(srcIdx[i] < c->L, "fhe_conv_create: source limb exceeds context size");
+        src[i] = c->q[srcIdx[i]];
+    }
+    for (uint32_t j = 0; j < nDst; ++j) {
+        ARG_CHECK(dstIdx[j] < c->L, "fhe_conv_create: target limb exceeds context size");
+        dst[j] = c->q[dstIdx[j]];
+    }
+    RT_CHECK(rt::set_device(c->device));
+    return conv_build(c, src, dst, out);
+}
+extern "C" void fhe_conv_destroy(fhe_conv* cv) {
+    if (!cv)
+        return;
+    for (void* p : cv->owned)
+        rt::dfree(p);
+    delete cv;
+}
+
+template <bool EXACT>
+static fhe_status conv_run(fhe_conv* cv, const uint64_t* in, uint32_t inStride, uint32_t inFirst, uint64_t* out,
+                           uint32_t outStride, uint32_t outFirst, uint32_t batch, void* st) {
+    ARG_CHECK(cv && in && out, "fhe_switch_basis: null argument");
+    ARG_CHECK(batch >= 1 && inFirst + cv->nSrc <= inStride && outFirst + cv->nDst <= outStride,
+              "fhe_switch_basis: limb window exceeds tower stride");
+    RT_CHECK(rt::set_device(cv->ctx->device));
+    ConvArgs g;
+    g.in = in, g.out = out, g.tb = cv->tb;
+    g.logN = cv->ctx->logN, g.batch = batch, g.nSrc = cv->nSrc, g.nDst = cv->nDst;
+    g.inStride = inStride, g.inFirst = inFirst, g.outStride = outStride, g.outFirst = outFirst;
+    const uint64_t coeffs = (uint64_t)batch << g.logN;
+    const uint32_t grid   = (uint32_t)((coeffs + kThreads - 1) / kThreads);
+    if (cv->nDst <= 8)
+        FHE_LAUNCH((switch_basis_kernel<8, EXACT>), grid, st, g);
+    else if (cv->nDst <= 16)
+        FHE_LAUNCH((switch_basis_kernel<16, EXACT>), grid, st, g);
+    else
+        FHE_LAUNCH((switch_basis_kernel<24, EXACT>), grid, st, g);
+    LAUNCH_CHECK();
+    return FHE_OK;
+}
+extern "C" fhe_status fhe_approx_switch_basis(fhe_conv* cv, const uint64_t* in, uint32_t is, uint32_t ifst,
+                                              uint64_t* out, uint32_t os, uint32_t ofst, uint32_t b, void* st) {
+    return conv_run<false>(cv, in, is, ifst, out, os, ofst, b, st);
+}
+extern "C" fhe_status fhe_switch_basis_exact(fhe_conv* cv, const uint64_t* in, uint32_t is, uint32_t ifst,
+                                             uint64_t* out, uint32_t os, uint32_t ofst, uint32_t b, void* st) {
+    return conv_run<true>(cv, in, is, ifst, out, os, ofst, b, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// HYBRID key switching
+// ------------------------------------------------------------------------------------------------
+struct fhe_ks_plan {
+    fhe_ctx* ctx;
+    uint32_t sizeQ, sizeP, numPartQ, alpha;
+    // ModUp plans per (level sizeQl, digit): built lazily per level, cached
+    struct Level {
+        uint32_t sizeQl = 0, numParts = 0;
+        std::vector<fhe_conv*> up;              // digit -> complement conversion
+        std::vector<std::vector<uint32_t>> cidx;  // complement context-limb lists
+        std::vector<uint32_t> partSize;
+        fhe_conv* down = nullptr;               // P -> Q_l
+        TwPair* d_PInv = nullptr;               // [sizeQl] Shoup pairs of [P^-1]_{q_i}
+    };
+    std::vector<Level*> levels;  // index sizeQl
+    std::vector<void*> owned;
+};
+struct fhe_ks_key {
+    fhe_ks_plan* plan;
+    uint64_t *d_b = nullptr, *d_a = nullptr;
+    size_t words = 0;
+};
+
+extern "C" fhe_status fhe_ks_plan_create(fhe_ctx* c, uint32_t sizeQ, uint32_t sizeP, uint32_t numPartQ,
+                                         fhe_ks_plan** out) {
+    ARG_CHECK(c && out, "fhe_ks_plan_create: null argument");
+    ARG_CHECK(sizeQ >= 1 && sizeP >= 1 && sizeQ + sizeP <= c->L, "fhe_ks_plan_create: context must hold Q then P limbs");
+    ARG_CHECK(numPartQ >= 1, "numPartQ is zero");  // rns-cryptoparameters.cpp:82-83
+    const uint32_t a = (sizeQ + numPartQ - 1) / numPartQ;
+    // rns-cryptoparameters.cpp:87-91
+    ARG_CHECK(sizeQ > a * (numPartQ - 1),
+              "HYBRID key switching parameters: Can't appropriately distribute towers into digits");
+    ARG_CHECK(numPartQ <= (uint32_t)kMaxDigits, "fhe_ks_plan_create: at most 8 digits supported");
+    fhe_ks_plan* p = new fhe_ks_plan;
+    p->ctx = c, p->sizeQ = sizeQ, p->sizeP = sizeP, p->numPartQ = numPartQ, p->alpha = a;
+    p->levels.assign(sizeQ + 1, nullptr);
+    *out = p;
+    return FHE_OK;
+}
+extern "C" void fhe_ks_plan_destroy(fhe_ks_plan* p) {
+    if (!p)
+        return;
+    for (auto* lv : p->levels) {
+        if (!lv)
+            continue;
+        for (auto* cv : lv->up)
+            fhe_conv_destroy(cv);
+        fhe_conv_destroy(lv->down);
+        delete lv;
+    }
+    for (void* q : p->owned)
+        rt::dfree(q);
+    delete p;
+}
+extern "C" uint32_t fhe_ks_plan_alpha(const fhe_ks_plan* p) { return p ? p->alpha : 0; }
+
+static fhe_status ks_level(fhe_ks_plan* p, uint32_t sizeQl, fhe_ks_plan::Level** out) {
+    ARG_CHECK(sizeQl >= 1 && sizeQl <= p->sizeQ, "fhe_keyswitch: sizeQl out of range");
+    if (p->levels[sizeQl]) {
+        *out = p->levels[sizeQl];
+        return FHE_OK;
+    }
+    fhe_ctx* c = p->ctx;
+    auto* lv   = new fhe_ks_plan::Level;
+    lv->sizeQl = sizeQl;
+    // keyswitch-hybrid.cpp:329-333
+    lv->numParts = std::min((sizeQl + p->alpha - 1) / p->alpha, p->numPartQ);
+    for (uint32_t part = 0; part < lv->numParts; ++part) {
+        const uint32_t start = p->alpha * part;
+        const uint32_t sz    = (part == lv->numParts - 1) ? sizeQl - start : p->alpha;  // :341-352
+        std::vector<uint64_t> src, dst;
+        std::vector<uint32_t> cidx;
+        for (uint32_t i = 0; i < sz; ++i)
+            src.push_back(c->q[start + i]);
+        // complementary basis (rns-cryptoparameters.cpp:253-283): Q_l limbs outside the digit, then P
+        for (uint32_t i = 0; i < sizeQl; ++i)
+            if (i < start || i >= start + sz)
+                cidx.push_back(i);
+        for (uint32_t j = 0; j < p->sizeP; ++j)
+            cidx.push_back(p->sizeQ + j);
+        for (uint32_t i : cidx)
+            dst.push_back(c->q[i]);
+        fhe_conv* cv = nullptr;
+        if (fhe_status s = conv_build(c, src, dst, &cv)) {
+            delete lv;
+            return s;
+        }
+        lv->up.push_back(cv);
+        lv->cidx.push_back(cidx);
+        lv->partSize.push_back(sz);
+    }
+    {
+        std::vector<uint64_t> src, dst;
+        for (uint32_t j = 0; j < p->sizeP; ++j)
+            src.push_back(c->q[p->sizeQ + j]);
+        for (uint32_t i = 0; i < sizeQl; ++i)
+            dst.push_back(c->q[i]);
+        if (fhe_status s = conv_build(c, src, dst, &lv->down)) {
+            delete lv;
+            return s;
+        }
+        // [P^-1]_{q_i}  (rns-cryptoparameters.cpp:205-212)
+        std::vector<TwPair> pinv(sizeQl);
+        for (uint32_t i = 0; i < sizeQl; ++i) {
+            const uint64_t v = host::invmod(host::prod_mod(src, -1, c->q[i]), c->q[i]);
+            pinv[i]          = TwPair{v, host::shoup(v, c->q[i])};
+        }
+        void* d = nullptr;
+        RT_CHECK(rt::dmalloc(&d, pinv.size() * sizeof(TwPair)));
+        p->owned.push_back(d);
+        RT_CHECK(rt::h2d(d, pinv.data(), pinv.size() * sizeof(TwPair), nullptr));
+        RT_CHECK(rt::sync(nullptr));
+        lv->d_PInv = (TwPair*)d;
+    }
+    p->levels[sizeQl] = lv;
+    *out              = lv;
+    return FHE_OK;
+}
+
+extern "C" fhe_status fhe_ks_key_alloc(fhe_ks_plan* p, fhe_ks_key** out) {
+    ARG_CHECK(p && out, "fhe_ks_key_alloc: null argument");
+    RT_CHECK(rt::set_device(p->ctx->device));
+    fhe_ks_key* k = new fhe_ks_key;
+    k->plan       = p;
+    k->words      = (size_t)p->numPartQ * (p->sizeQ + p->sizeP) << p->ctx->logN;
+    if (rt::dmalloc((void**)&k->d_b, k->words * 8) || rt::dmalloc((void**)&k->d_a, k->words * 8)) {
+        fhe_ks_key_destroy(k);
+        return fail(FHE_ERR_ALLOC, "fhe_ks_key_alloc: device allocation failed");
+    }
+    *out = k;
+    return FHE_OK;
+}
+extern "C" fhe_status fhe_ks_key_upload(fhe_ks_plan* p, const uint64_t* keyB, const uint64_t* keyA, fhe_ks_key** out) {
+    ARG_CHECK(keyB && keyA, "fhe_ks_key_upload: null key");
+    fhe_ks_key* k = nullptr;
+    if (fhe_status s = fhe_ks_key_alloc(p, &k))
+        return s;
+    RT_CHECK(rt::h2d(k->d_b, keyB, k->words * 8, nullptr));
+    RT_CHECK(rt::h2d(k->d_a, keyA, k->words * 8, nullptr));
+    RT_CHECK(rt::sync(nullptr));
+    *out = k;
+    return FHE_OK;
+}
+extern "C" void fhe_ks_key_destroy(fhe_ks_key* k) {
+    if (!k)
+        return;
+    if (k->d_b)
+        rt::dfree(k->d_b);
+    if (k->d_a)
+        rt::dfree(k->d_a);
+    delete k;
+}
+extern "C" uint64_t* fhe_ks_key_devptr(fhe_ks_key* k, int which) { return k ? (which ? k->d_a : k->d_b) : nullptr; }
+extern "C" size_t fhe_ks_key_words(const fhe_ks_key* k) { return k ? k->words : 0; }
+
+// workspace layout (words), all sized for `batch` towers:
+//   coef   [batch][sizeQl][N]              INTT of the input
+//   dig_j  [batch][nc_j][N]  j < numParts  ModUp complements
+//   e0,e1  [batch][sizeQl+sizeP][N]        inner products
+//   md     [2*batch][sizeQl][N]            ModDown conversion output  (also used as [2*batch][sizeP][N] scratch: pcoef)
+//   pcoef  [2*batch][sizeP][N]
+//   d2     [batch][sizeQl][N], k0,k1 [batch][sizeQl][N]   (eval_mult only)
+struct KsLayout {
+    size_t coef, dig[kMaxDigits], e0, e1, md, pcoef, d2, k0, k1, total;
+};
+static KsLayout ks_layout(const fhe_ks_plan* p, uint32_t sizeQl, uint32_t batch) {
+    KsLayout w{};
+    const size_t N = (size_t)1 << p->ctx->logN;
+    const uint32_t numParts = std::min((sizeQl + p->alpha - 1) / p->alpha, p->numPartQ);
+    size_t off = 0;
+    w.coef = off, off += (size_t)batch * sizeQl * N;
+    for (uint32_t j = 0; j < numParts; ++j) {
+        const uint32_t start = p->alpha * j;
+        const uint32_t sz    = (j == numParts - 1) ? sizeQl - start : p->alpha;
+        w.dig[j] = off, off += (size_t)batch * (sizeQl - sz + p->sizeP) * N;
+    }
+    w.e0 = off, off += (size_t)batch * (sizeQl + p->sizeP) * N;
+    w.e1 = off, off += (size_t)batch * (sizeQl + p->sizeP) * N;
+    w.md = off, off += (size_t)2 * batch * sizeQl * N;
+    w.pcoef = off, off += (size_t)2 * batch * p->sizeP * N;
+    w.d2 = off, off += (size_t)batch * sizeQl * N;
+    w.k0 = off, off += (size_t)batch * sizeQl * N;
+    w.k1 = off, off += (size_t)batch * sizeQl * N;
+    w.total = off;
+    return w;
+}
+extern "C" size_t fhe_ks_workspace_bytes(const fhe_ks_plan* p, uint32_t sizeQl, uint32_t batch) {
+    if (!p || sizeQl < 1 || sizeQl > p->sizeQ || batch < 1)
+        return 0;
+    return ks_layout(p, sizeQl, batch).total * 8;
+}
+
+// ApproxModDown for nTow towers x[nTow][sizeQl+sizeP][N] -> out[nTow][sizeQl][N]   (dcrtpoly-impl.h:966-1005)
+// extra (may be null): added to the result (fuses the final `+= ks` of EvalMult, base-leveledshe.cpp:210-211)
+static fhe_status mod_down_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const uint64_t* x, uint32_t nTow, uint64_t* out,
+                               uint64_t* pcoef, uint64_t* md, void* st) {
+    fhe_ctx* c            = p->ctx;
+    const uint32_t sizeQl = lv->sizeQl, sizeP = p->sizeP, sizeQlP = sizeQl + sizeP;
+    // 1. P part to COEFFICIENT (:978-985): INTT of rows [sizeQl, sizeQl+sizeP) of every tower, written densely
+    std::vector<uint32_t> pIdx(sizeP);
+    for (uint32_t j = 0; j < sizeP; ++j)
+        pIdx[j] = p->sizeQ + j;
+    if (fhe_status s = ntt_run(c, true, x, pcoef, pIdx.data(), sizeP, nTow, st, sizeQlP, sizeQl))
+        return s;
+    // 2. P -> Q_l (:987-988)
+    if (fhe_status s = fhe_approx_switch_basis(lv->down, pcoef, sizeP, 0, md, sizeQl, 0, nTow, st))
+        return s;
+    // 3. back to EVALUATION (:1001)
+    if (fhe_status s = fhe_ntt_fwd(c, md, nullptr, sizeQl, nTow, st))
+        return s;
+    // 4. out_i = (x_i - md_i) * [P^-1]_{q_i} (:1002); x towers are sizeQlP rows apart
+    return elem_run<OP_SUB_MUL_CONST>(c, out, x, md, lv->d_PInv, nullptr, sizeQl, nTow, st, "fhe_approx_mod_down",
+                                      sizeQlP, 0);
+}
+
+static fhe_status keyswitch_run(fhe_ks_plan* p, const fhe_ks_key* key, const uint64_t* cin, uint32_t sizeQl,
+                                uint32_t batch, uint64_t* out0, uint64_t* out1, uint64_t* ws, const KsLayout& w,
+                                void* st) {
+    fhe_ctx* c = p->ctx;
+    fhe_ks_plan::Level* lv = nullptr;
+    if (fhe_status s = ks_level(p, sizeQl, &lv))
+        return s;
+    const uint32_t sizeP = p->sizeP, sizeQlP = sizeQl + sizeP;
+    // EvalKeySwitchPrecomputeCore (keyswitch-hybrid.cpp:314-379)
+    if (fhe_status s = fhe_ntt_inv_oop(c, cin, ws + w.coef, nullptr, sizeQl, batch, st))
+        return s;
+    KsInnerArgs g;
+    for (uint32_t j = 0; j < lv->numParts; ++j) {
+        const uint32_t nc = (uint32_t)lv->cidx[j].size();
+        uint64_t* dj      = ws + w.dig[j];
+        if (fhe_status s = fhe_approx_switch_basis(lv->up[j], ws + w.coef, sizeQl, p->alpha * j, dj, nc, 0, batch, st))
+            return s;
+        if (fhe_status s = fhe_ntt_fwd(c, dj, lv->cidx[j].data(), nc, batch, st))
+            return s;
+        g.digits[j] = dj;
+        g.nc[j]     = nc;
+    }
+    for (uint32_t j = lv->numParts; j < (uint32_t)kMaxDigits; ++j) {
+        g.digits[j] = nullptr;
+        g.nc[j]     = 0;
+    }
+    // EvalFastKeySwitchCoreExt (:402-435)
+    g.c = cin, g.keyB = key->d_b, g.keyA = key->d_a;
+    g.out0 = ws + w.e0, g.out1 = ws + w.e1;
+    g.lc = c->d_lc, g.mu128 = c->d_mu128;
+    g.logN = c->logN, g.batch = batch, g.sizeQl = sizeQl, g.sizeQ = p->sizeQ, g.sizeP = sizeP;
+    g.numDigits = lv->numParts, g.alpha = p->alpha;
+    const uint32_t tilesPerRow = c->N >= (uint32_t)kTile ? (c->N >> kTileLog) : 1u;
+    FHE_LAUNCH(ks_inner_product_kernel, (uint64_t)batch * tilesPerRow * sizeQlP, st, g);
+    LAUNCH_CHECK();
+    // 2 x ApproxModDown (:381-400): e0 and e1 are adjacent in the workspace -> one batch of 2*batch towers
+    //    (w.e1 == w.e0 + batch*sizeQlP*N by construction)
+    if (fhe_status s = mod_down_run(p, lv, ws + w.e0, batch, out0, ws + w.pcoef, ws + w.md, st))
+        return s;
+    return mod_down_run(p, lv, ws + w.e1, batch, out1, ws + w.pcoef, ws + w.md, st);
+}
+
+extern "C" fhe_status fhe_keyswitch_hybrid(fhe_ks_plan* p, const fhe_ks_key* key, const uint64_t* cin, uint32_t sizeQl,
+                                           uint32_t batch, uint64_t* out0, uint64_t* out1, void* ws, size_t wsBytes,
+                                           void* st) {
+    ARG_CHECK(p && key && cin && out0 && out1 && ws, "fhe_keyswitch_hybrid: null argument");
+    ARG_CHECK(key->plan == p, "fhe_keyswitch_hybrid: key belongs to another plan");
+    ARG_CHECK(sizeQl >= 1 && sizeQl <= p->sizeQ && batch >= 1, "fhe_keyswitch_hybrid: bad level or batch");
+    const KsLayout w = ks_layout(p, sizeQl, batch);
+    ARG_CHECK(wsBytes >= w.total * 8, "fhe_keyswitch_hybrid: workspace too small");
+    RT_CHECK(rt::set_device(p->ctx->device));
+    return keyswitch_run(p, key, cin, sizeQl, batch, out0, out1, (uint64_t*)ws, w, st);
+}
+
+extern "C" fhe_status fhe_ckks_eval_mult(fhe_ks_plan* p, const fhe_ks_key* key, const uint64_t* a0, const uint64_t* a1,
+                                         const uint64_t* b0, const uint64_t* b1, uint32_t sizeQl, uint32_t batch,
+                                         uint64_t* c0, uint64_t* c1, void* wsv, size_t wsBytes, void* st) {
+    ARG_CHECK(p && key && a0 && a1 && b0 && b1 && c0 && c1 && wsv, "fhe_ckks_eval_mult: null argument");
+    ARG_CHECK(key->plan == p, "fhe_ckks_eval_mult: key belongs to another plan");
+    ARG_CHECK(sizeQl >= 1 && sizeQl <= p->sizeQ && batch >= 1, "fhe_ckks_eval_mult: bad level or batch");
+    const KsLayout w = ks_layout(p, sizeQl, batch);
+    ARG_CHECK(wsBytes >= w.total * 8, "fhe_ckks_eval_mult: workspace too small");
+    fhe_ctx* c   = p->ctx;
+    uint64_t* ws = (uint64_t*)wsv;
+    RT_CHECK(rt::set_device(c->device));
+    // EvalMultCore (base-leveledshe.cpp:607-644)
+    if (fhe_status s = fhe_tensor(c, a0, a1, b0, b1, c0, c1, ws + w.d2, nullptr, sizeQl, batch, st))
+        return s;
+    // KeySwitchCore on d2 (:207)
+    if (fhe_status s = keyswitch_run(p, key, ws + w.d2, sizeQl, batch, ws + w.k0, ws + w.k1, ws, w, st))
+        return s;
+    // cv[0] += ab[0]; cv[1] += ab[1]  (:210-211)
+    if (fhe_status s = fhe_add(c, c0, c0, ws + w.k0, nullptr, sizeQl, batch, st))
+        return s;
+    return fhe_add(c, c1, c1, ws + w.k1, nullptr, sizeQl, batch, st);
+}
+
+extern "C" fhe_status fhe_approx_mod_down(fhe_ks_plan* p, const uint64_t* x, uint32_t sizeQl, uint32_t batch,
+                                          uint64_t* out, void* wsv, size_t wsBytes, void* st) {
+    ARG_CHECK(p && x && out && wsv, "fhe_approx_mod_down: null argument");
+    ARG_CHECK(sizeQl >= 1 && sizeQl <= p->sizeQ && batch >= 1, "fhe_approx_mod_down: bad level or batch");
+    const KsLayout w = ks_layout(p, sizeQl, batch);
+    ARG_CHECK(wsBytes >= w.total * 8, "fhe_approx_mod_down: workspace too small");
+    RT_CHECK(rt::set_device(p->ctx->device));
+    fhe_ks_plan::Level* lv = nullptr;
+    if (fhe_status s = ks_level(p, sizeQl, &lv))
+        return s;
+    uint64_t* ws = (uint64_t*)wsv;
+    return mod_down_run(p, lv, x, batch, out, ws + w.pcoef, ws + w.md, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// CKKS rescale
+// ------------------------------------------------------------------------------------------------
+extern "C" size_t fhe_rescale_workspace_bytes(const fhe_ctx* c, uint32_t sizeQl, uint32_t batch) {
+    if (!c || sizeQl < 2)
+        return 0;
+    // last[batch][1][N] + tmp[batch][sizeQl-1][N]
+    return ((size_t)batch * sizeQl << c->logN) * 8;
+}
+extern "C" fhe_status fhe_rescale(fhe_ctx* c, const uint64_t* x, uint32_t sizeQl, uint32_t batch, uint64_t* out,
+                                  void* wsv, size_t wsBytes, void* st) {
+    ARG_CHECK(c && x && out && wsv, "fhe_rescale: null argument");
+    ARG_CHECK(sizeQl >= 2 && sizeQl <= c->L, "Removing last element of DCRTPoly renders it invalid.");  // :672-673
+    ARG_CHECK(batch >= 1 && wsBytes >= fhe_rescale_workspace_bytes(c, sizeQl, batch), "fhe_rescale: workspace too small");
+    RT_CHECK(rt::set_device(c->device));
+    const uint32_t l = sizeQl - 1;
+    uint64_t* last   = (uint64_t*)wsv;                       // [batch][N]
+    uint64_t* tmp    = last + ((size_t)batch << c->logN);     // [batch][l][N]
+    // tables (ckksrns-cryptoparameters.cpp:60-81): qlInvModq[i] = q_l^-1 mod q_i,
+    // QlQlInvModqlDivqlModq[i] = floor(Q'*(Q'^-1 mod q_l)/q_l) mod q_i = -(q_l^-1) mod q_i   
+    auto it = c->rescaleTabs.find(sizeQl);
+    if (it == c->rescaleTabs.end()) {
+        std::vector<TwPair> hA(l), hB(l);
+        for (uint32_t i = 0; i < l; ++i) {
+            const uint64_t qi = c->q[i];
+            const uint64_t B  = host::invmod(c->q[l] % qi, qi);
+            const uint64_t A  = (qi - B) % qi;
+            hA[i]             = TwPair{A, host::shoup(A, qi)};
+            hB[i]             = TwPair{B, host::shoup(B, qi)};
+        }
+        void *dA = nullptr, *dB = nullptr;
+        RT_CHECK(rt::dmalloc(&dA, l * sizeof(TwPair)));
+        c->owned.push_back(dA);
+        RT_CHECK(rt::dmalloc(&dB, l * sizeof(TwPair)));
+        c->owned.push_back(dB);
+        RT_CHECK(rt::h2d(dA, hA.data(), l * sizeof(TwPair), nullptr));
+        RT_CHECK(rt::h2d(dB, hB.data(), l * sizeof(TwPair), nullptr));
+        RT_CHECK(rt::sync(nullptr));
+        it = c->rescaleTabs.emplace(sizeQl, std::make_pair((TwPair*)dA, (TwPair*)dB)).first;
+    }
+    TwPair *dA = it->second.first, *dB = it->second.second;
+    // lastPoly.SetFormat(COEFFICIENT)  (:696-697): INTT of the last limb of every tower, written densely
+    const uint32_t lastIdx = l;
+    if (fhe_status s = ntt_run(c, true, x, last, &lastIdx, 1, batch, st, sizeQl, l))
+        return s;
+    // tmp = SwitchModulus(last -> q_i) * QlQlInvModqlDivqlModq[i]   (:703-705)
+    LimbSel sel;
+    if (fhe_status s = make_sel(c, nullptr, l, &sel, "fhe_rescale"))
+        return s;
+    if (fhe_status s = switch_modulus_run(c, tmp, sel, l, last, 1, 0, l, dA, batch, st))
+        return s;
+    // tmp.SwitchFormat()  (:706-707)
+    if (fhe_status s = fhe_ntt_fwd(c, tmp, nullptr, l, batch, st))
+        return s;
+    // m_vectors[i] = m_vectors[i] * qlInvModq[i] + tmp  (:708-709); x towers are sizeQl rows apart
+    return elem_run<OP_MUL_CONST_ADD>(c, out, x, tmp, dB, nullptr, l, batch, st, "fhe_rescale", sizeQl, 0);
+}

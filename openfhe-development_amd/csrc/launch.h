@@ -1,0 +1,30 @@
+// launch.h — the few spellings that differ between the real gfx950 build (hipcc) and the test-only
+// lane emulator (tests/emu/, g++: one OS thread per lane, a barrier for s_barrier).
+// The product library is ALWAYS the hipcc build; FHE_EMU exists only so that kernel index logic can be
+// unit-tested on a machine without a GPU.  There is no CPU fallback in the product.
+#ifndef FHE_LAUNCH_H
+#define FHE_LAUNCH_H
+
+#ifdef FHE_EMU
+#include "emu_runtime.h"  // tests/emu/emu_runtime.h
+#define FHE_GLOBAL static
+#define FHE_LAUNCH_BOUNDS(n)
+#define FHE_TID (fhe_emu::tls.tid)
+#define FHE_BID (fhe_emu::tls.bid)
+#define FHE_NBLK (fhe_emu::tls.nblk)
+#define FHE_SYNC() fhe_emu::block_sync()
+#define FHE_SHARED_U64(name, n) uint64_t* name = reinterpret_cast<uint64_t*>(fhe_emu::block_shared(sizeof(uint64_t) * (n)))
+#define FHE_UNIFORM(x) (x)
+#else
+#include <hip/hip_runtime.h>
+#define FHE_GLOBAL __global__
+#define FHE_LAUNCH_BOUNDS(n) __launch_bounds__(n)
+#define FHE_TID (threadIdx.x)
+#define FHE_BID (blockIdx.x)
+#define FHE_NBLK (gridDim.x)
+#define FHE_SYNC() __syncthreads()
+#define FHE_SHARED_U64(name, n) __shared__ uint64_t name[n]
+#define FHE_UNIFORM(x) (__builtin_amdgcn_readfirstlane(x))
+#endif
+
+#endif

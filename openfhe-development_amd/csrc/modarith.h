@@ -1,0 +1,114 @@
+// modarith.h — 64-bit residue arithmetic for the DCRTPoly hot path on gfx950.
+//
+// Every value is a residue of a prime q < 2^60 held in one 64-bit word, one word per lane
+// (reference data model: NativeIntegerT<uint64_t>, src/core/include/math/hal/intnat/ubintnat.h).
+// Final results are always the canonical residue in [0,q), so they are bit-identical to the
+// reference's ModMulFastConst / ModMulFast / ModAddFast / ModSubFast outputs (ubintnat.h:737-757,
+// 911-930, 1348-1361, 1464-1469); intermediate values use lazy ranges [0,2q) / [0,4q), which the
+// 4 spare bits of a 60-bit modulus allow.
+//
+// The same header compiles for the device (hipcc) and for the host (g++, used by the host-side
+// table builders and by the test-only lane emulator under tests/emu/).
+#ifndef FHE_MODARITH_H
+#define FHE_MODARITH_H
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__HIP_DEVICE_COMPILE__)
+#include <hip/hip_runtime.h>
+#define FHE_HD __host__ __device__ __forceinline__
+#else
+#define FHE_HD inline
+#endif
+
+namespace fhe {
+
+FHE_HD uint64_t mulhi64(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (uint64_t)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+
+// x in [0, 2m) -> [0, m)
+FHE_HD uint64_t csub(uint64_t x, uint64_t m) {
+    return x >= m ? x - m : x;
+}
+
+// Shoup multiplication by a constant w with precomputed wp = floor(w * 2^64 / q)
+// (ubintnat.h:1437-1444).  LAZY form: any y < 2^64, result in [0, 2q), congruent to y*w.
+FHE_HD uint64_t mul_shoup_lazy(uint64_t y, uint64_t w, uint64_t wp, uint64_t q) {
+    uint64_t Q = mulhi64(y, wp);
+    return y * w - Q * q;
+}
+// canonical result in [0,q): same value as ModMulFastConst (ubintnat.h:1464-1469)
+FHE_HD uint64_t mul_shoup(uint64_t y, uint64_t w, uint64_t wp, uint64_t q) {
+    return csub(mul_shoup_lazy(y, w, wp, q), q);
+}
+
+FHE_HD uint64_t add_mod(uint64_t a, uint64_t b, uint64_t q) {  // ModAddFast, ubintnat.h:737-743
+    return csub(a + b, q);
+}
+FHE_HD uint64_t sub_mod(uint64_t a, uint64_t b, uint64_t q) {  // ModSubFast, ubintnat.h:911-921
+    return a >= b ? a - b : a + q - b;
+}
+
+// 128-bit value as two words
+struct u128w {
+    uint64_t lo, hi;
+};
+FHE_HD u128w mul128(uint64_t a, uint64_t b) {  // Mul128, utils/utilities-int.h:47-49
+    u128w r;
+    r.lo = a * b;
+    r.hi = mulhi64(a, b);
+    return r;
+}
+FHE_HD void acc128(u128w& s, uint64_t a, uint64_t b) {  // s += a*b
+    uint64_t lo = a * b;
+    uint64_t hi = mulhi64(a, b);
+    s.lo += lo;
+    s.hi += hi + (s.lo < lo);
+}
+
+// a (128-bit) mod q with mu = floor(2^128/q) given as (mu_lo, mu_hi).
+// Same quotient estimate as BarrettUint128ModUint64 (utils/utilities-int.h:60-99): the low word of
+// floor(a*mu / 2^128), then r = a_lo - quot*q and final corrective subtractions.
+FHE_HD uint64_t barrett128(u128w a, uint64_t q, uint64_t mu_lo, uint64_t mu_hi) {
+    uint64_t left_hi = mulhi64(a.lo, mu_lo);
+    uint64_t mid_lo  = a.lo * mu_hi;
+    uint64_t mid_hi  = mulhi64(a.lo, mu_hi);
+    uint64_t tmp1    = mid_lo + left_hi;
+    uint64_t tmp2    = mid_hi + (tmp1 < mid_lo);
+    uint64_t m2_lo   = a.hi * mu_lo;
+    uint64_t m2_hi   = mulhi64(a.hi, mu_lo);
+    uint64_t carry   = (uint64_t)(m2_lo + tmp1) < m2_lo;
+    uint64_t quot    = a.hi * mu_hi + tmp2 + m2_hi + carry;
+    uint64_t r       = a.lo - quot * q;
+    while (r >= q)
+        r -= q;
+    return r;
+}
+
+// exact a*b mod q for a,b < q < 2^60 via the 128-bit Barrett above (any exact product equals the
+// reference's ModMulFast result)
+FHE_HD uint64_t mul_mod(uint64_t a, uint64_t b, uint64_t q, uint64_t mu_lo, uint64_t mu_hi) {
+    return barrett128(mul128(a, b), q, mu_lo, mu_hi);
+}
+
+// Single-word Barrett for a*b with a,b < q < 2^62: mu64 = floor(2^(2*nb)/q) style is avoided; instead
+// use the reference's own generalized Barrett (ubintnat.h:1348-1361) with mu = floor(2^(2*msb+3)/q):
+//   t = (a*b) >> (msb-2);  est = (t*mu) >> (msb+5);  r = a*b - est*q;  r in [0, 2q)
+FHE_HD uint64_t mul_mod_barrett(uint64_t a, uint64_t b, uint64_t q, uint64_t mu, int msb) {
+    uint64_t lo = a * b, hi = mulhi64(a, b);
+    int n       = msb - 2;
+    uint64_t t  = (lo >> n) | (hi << (64 - n));  // low 64 bits of (prod >> n); msb>=3 so 0<n<64
+    // est = (t*mu) >> (n+7)   (128-bit product, shift n+7 in (7, 69))
+    uint64_t plo = t * mu, phi = mulhi64(t, mu);
+    int sh       = n + 7;
+    uint64_t est = sh < 64 ? ((plo >> sh) | (phi << (64 - sh))) : (phi >> (sh - 64));
+    uint64_t r   = lo - est * q;
+    return csub(r, q);
+}
+
+}  // namespace fhe
+#endif

@@ -1,0 +1,108 @@
+// rt.h — device runtime spellings (HIP in the product; heap + lane emulator under FHE_EMU for tests).
+#ifndef FHE_RT_H
+#define FHE_RT_H
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <string>
+
+#include "launch.h"
+
+#ifdef FHE_EMU
+#include <chrono>
+#include <cstdlib>
+namespace fhe {
+namespace rt {
+typedef void* stream_t;
+inline bool ok() { return true; }
+inline int device_count() { return 1; }
+inline const char* set_device(int) { return nullptr; }
+inline const char* dmalloc(void** p, size_t bytes) {
+    *p = std::malloc(bytes ? bytes : 1);
+    return *p ? nullptr : "malloc failed";
+}
+inline const char* dfree(void* p) {
+    std::free(p);
+    return nullptr;
+}
+inline const char* h2d(void* d, const void* s, size_t n, stream_t) {
+    std::memcpy(d, s, n);
+    return nullptr;
+}
+inline const char* d2h(void* d, const void* s, size_t n, stream_t) {
+    std::memcpy(d, s, n);
+    return nullptr;
+}
+inline const char* d2d(void* d, const void* s, size_t n, stream_t) {
+    std::memmove(d, s, n);
+    return nullptr;
+}
+inline const char* sync(stream_t) { return nullptr; }
+inline const char* last_launch_error() { return nullptr; }
+struct Timer {
+    std::chrono::steady_clock::time_point t0;
+    const char* start(stream_t) {
+        t0 = std::chrono::steady_clock::now();
+        return nullptr;
+    }
+    const char* stop(stream_t, float* ms) {
+        *ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return nullptr;
+    }
+};
+}  // namespace rt
+}  // namespace fhe
+#define FHE_LAUNCH(kernel, grid, stream, ...) \
+    fhe_emu::launch((uint32_t)(grid), fhe::kThreads, [=]() { kernel(__VA_ARGS__); })
+#else
+#include <hip/hip_runtime.h>
+namespace fhe {
+namespace rt {
+typedef hipStream_t stream_t;
+inline const char* err(hipError_t e) { return e == hipSuccess ? nullptr : hipGetErrorString(e); }
+inline int device_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+inline const char* set_device(int d) { return err(hipSetDevice(d)); }
+inline const char* dmalloc(void** p, size_t bytes) { return err(hipMalloc(p, bytes ? bytes : 1)); }
+inline const char* dfree(void* p) { return err(hipFree(p)); }
+inline const char* h2d(void* d, const void* s, size_t n, stream_t st) {
+    return err(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, st));
+}
+inline const char* d2h(void* d, const void* s, size_t n, stream_t st) {
+    return err(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, st));
+}
+inline const char* d2d(void* d, const void* s, size_t n, stream_t st) {
+    return err(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, st));
+}
+inline const char* sync(stream_t st) { return err(hipStreamSynchronize(st)); }
+inline const char* last_launch_error() { return err(hipGetLastError()); }
+struct Timer {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const char* start(stream_t st) {
+        if (auto e = err(hipEventCreate(&e0)))
+            return e;
+        if (auto e = err(hipEventCreate(&e1)))
+            return e;
+        return err(hipEventRecord(e0, st));
+    }
+    const char* stop(stream_t st, float* ms) {
+        if (auto e = err(hipEventRecord(e1, st)))
+            return e;
+        if (auto e = err(hipEventSynchronize(e1)))
+            return e;
+        auto e = err(hipEventElapsedTime(ms, e0, e1));
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+        return e;
+    }
+};
+}  // namespace rt
+}  // namespace fhe
+#define FHE_LAUNCH(kernel, grid, stream, ...) \
+    hipLaunchKernelGGL(kernel, dim3((uint32_t)(grid)), dim3(fhe::kThreads), 0, (hipStream_t)(stream), __VA_ARGS__)
+#endif
+#endif

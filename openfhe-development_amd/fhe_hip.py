@@ -1,0 +1,362 @@
+"""ctypes binding of the C ABI in include/fhe_hip.h (libfhe_hip.so, built for gfx950).
+
+This is plumbing for tests and bench.py: the product is the C-ABI library itself.  There is NO CPU
+fallback: constructing `Lib()` raises if the HIP library has not been built, and every call raises
+`FheError` with the library's message if the device is unusable.
+
+Host-side mirror of the reference surface: `Context` ~ ILDCRTParams + twiddle cache, `Tower` ~
+lbcrypto::DCRTPoly (src/core/include/lattice/hal/default/dcrtpoly.h:59-398) holding a batch of
+device-resident towers, with the reference's method names (SwitchFormat, Plus, Minus, Times,
+AutomorphismTransform, ApproxSwitchCRTBasis ...).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_SO = os.path.join(_HERE, "csrc", "libfhe_hip.so")
+
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+vp = C.c_void_p
+u32 = C.c_uint32
+EVALUATION, COEFFICIENT = 0, 1  # lbcrypto::Format (src/core/include/utils/inttypes.h:65)
+
+
+class FheError(RuntimeError):
+    pass
+
+
+def _np_u32(a):
+    if a is None:
+        return None, None
+    arr = np.ascontiguousarray(np.asarray(a, dtype=np.uint32))
+    return arr, arr.ctypes.data_as(u32p)
+
+
+class Lib:
+    """Loads libfhe_hip.so (or an explicitly given build, e.g. the test-only lane emulator)."""
+
+    def __init__(self, path=None):
+        path = path or DEFAULT_SO
+        if not os.path.exists(path):
+            raise FheError(
+                f"{path} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback.")
+        self.path = path
+        L = self.L = C.CDLL(path)
+
+        def S(name, res, args):
+            f = getattr(L, name)
+            f.restype, f.argtypes = res, args
+
+        S("fhe_last_error", C.c_char_p, [])
+        S("fhe_version", C.c_char_p, [])
+        S("fhe_device_count", C.c_int, [])
+        S("fhe_ctx_create", C.c_int, [u32, u32, u64p, u64p, C.c_int, C.POINTER(vp)])
+        S("fhe_ctx_destroy", None, [vp])
+        S("fhe_ctx_logn", u32, [vp])
+        S("fhe_ctx_limbs", u32, [vp])
+        S("fhe_ctx_device", C.c_int, [vp])
+        S("fhe_malloc", C.c_int, [vp, C.c_size_t, C.POINTER(vp)])
+        S("fhe_free", C.c_int, [vp, vp])
+        for n in ("fhe_memcpy_h2d", "fhe_memcpy_d2h", "fhe_memcpy_d2d"):
+            S(n, C.c_int, [vp, vp, vp, C.c_size_t, vp])
+        S("fhe_stream_sync", C.c_int, [vp, vp])
+        S("fhe_ntt_fwd", C.c_int, [vp, vp, u32p, u32, u32, vp])
+        S("fhe_ntt_inv", C.c_int, [vp, vp, u32p, u32, u32, vp])
+        S("fhe_ntt_fwd_oop", C.c_int, [vp, vp, vp, u32p, u32, u32, vp])
+        S("fhe_ntt_inv_oop", C.c_int, [vp, vp, vp, u32p, u32, u32, vp])
+        for n in ("fhe_add", "fhe_sub", "fhe_mul"):
+            S(n, C.c_int, [vp, vp, vp, vp, u32p, u32, u32, vp])
+        S("fhe_neg", C.c_int, [vp, vp, vp, u32p, u32, u32, vp])
+        S("fhe_mul_const", C.c_int, [vp, vp, vp, u64p, u32p, u32, u32, vp])
+        S("fhe_tensor", C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, u32p, u32, u32, vp])
+        S("fhe_automorph", C.c_int, [vp, vp, vp, u32, C.c_int, u32p, u32, u32, vp])
+        S("fhe_switch_modulus", C.c_int, [vp, vp, u32p, u32, vp, u32, u32, u32, u32, vp])
+        S("fhe_conv_create", C.c_int, [vp, u32p, u32, u32p, u32, C.POINTER(vp)])
+        S("fhe_conv_destroy", None, [vp])
+        S("fhe_approx_switch_basis", C.c_int, [vp, vp, u32, u32, vp, u32, u32, u32, vp])
+        S("fhe_switch_basis_exact", C.c_int, [vp, vp, u32, u32, vp, u32, u32, u32, vp])
+        S("fhe_ks_plan_create", C.c_int, [vp, u32, u32, u32, C.POINTER(vp)])
+        S("fhe_ks_plan_destroy", None, [vp])
+        S("fhe_ks_plan_alpha", u32, [vp])
+        S("fhe_ks_key_alloc", C.c_int, [vp, C.POINTER(vp)])
+        S("fhe_ks_key_upload", C.c_int, [vp, u64p, u64p, C.POINTER(vp)])
+        S("fhe_ks_key_destroy", None, [vp])
+        S("fhe_ks_key_devptr", vp, [vp, C.c_int])
+        S("fhe_ks_key_words", C.c_size_t, [vp])
+        S("fhe_ks_workspace_bytes", C.c_size_t, [vp, u32, u32])
+        S("fhe_keyswitch_hybrid", C.c_int, [vp, vp, vp, u32, u32, vp, vp, vp, C.c_size_t, vp])
+        S("fhe_ckks_eval_mult", C.c_int, [vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp, C.c_size_t, vp])
+        S("fhe_approx_mod_down", C.c_int, [vp, vp, u32, u32, vp, vp, C.c_size_t, vp])
+        S("fhe_rescale_workspace_bytes", C.c_size_t, [vp, u32, u32])
+        S("fhe_rescale", C.c_int, [vp, vp, u32, u32, vp, vp, C.c_size_t, vp])
+        u64 = C.c_uint64
+        S("fhe_param_first_prime", u64, [u32, u64])
+        S("fhe_param_last_prime", u64, [u32, u64])
+        S("fhe_param_next_prime", u64, [u64, u64])
+        S("fhe_param_previous_prime", u64, [u64, u64])
+        S("fhe_param_root_of_unity", u64, [u64, u64])
+        S("fhe_param_dcrt_chain", C.c_int, [u32, u32, u32, u64p, u64p])
+        S("fhe_param_select_p", u32, [u32, u32, u64p, u32, u32, u64p, u64p])
+        S("fhe_time_ntt", C.c_int, [vp, vp, u32p, u32, u32, C.c_int, C.c_int, vp, C.POINTER(C.c_float)])
+
+    def check(self, status):
+        if status != 0:
+            raise FheError(f"fhe status {status}: {self.L.fhe_last_error().decode()}")
+
+    def version(self):
+        return self.L.fhe_version().decode()
+
+    def device_count(self):
+        return self.L.fhe_device_count()
+
+    # ---- host-side parameter helpers (ILDCRTParams chain, HYBRID auxiliary basis) ----
+    def dcrt_chain(self, logN, n_limbs, bits):
+        q = np.zeros(n_limbs, np.uint64)
+        psi = np.zeros(n_limbs, np.uint64)
+        self.check(self.L.fhe_param_dcrt_chain(2 << logN, n_limbs, bits, q.ctypes.data_as(u64p), psi.ctypes.data_as(u64p)))
+        return q, psi
+
+    def ckks_like_chain(self, logN, sizeQ, first_bits=60, scale_bits=59):
+        """first modulus of first_bits, then sizeQ-1 descending primes of scale_bits (FIXEDMANUAL-like shape)"""
+        M = 2 << logN
+        q = [self.L.fhe_param_last_prime(first_bits, M)]
+        cur = self.L.fhe_param_last_prime(scale_bits, M)
+        while len(q) < sizeQ:
+            if cur not in q:
+                q.append(cur)
+            cur = self.L.fhe_param_previous_prime(cur, M)
+        q = np.array(q, np.uint64)
+        psi = np.array([self.L.fhe_param_root_of_unity(M, int(v)) for v in q], np.uint64)
+        return q, psi
+
+    def select_p(self, logN, q, numPartQ, aux_bits=60):
+        q = np.ascontiguousarray(q, dtype=np.uint64)
+        p = np.zeros(64, np.uint64)
+        psi = np.zeros(64, np.uint64)
+        n = self.L.fhe_param_select_p(logN, len(q), q.ctypes.data_as(u64p), numPartQ, aux_bits, p.ctypes.data_as(u64p),
+                                      psi.ctypes.data_as(u64p))
+        if n == 0:
+            raise FheError("fhe_param_select_p failed")
+        return p[:n].copy(), psi[:n].copy()
+
+
+class Context:
+    """Ring dimension N = 2^logN + modulus tower (q_i, psi_i) with device-resident twiddle tables."""
+
+    def __init__(self, lib, logN, q, psi, device=0):
+        self.lib, self.logN, self.N = lib, logN, 1 << logN
+        self.q = np.ascontiguousarray(np.asarray(q, dtype=np.uint64))
+        self.psi = np.ascontiguousarray(np.asarray(psi, dtype=np.uint64))
+        self.L = len(self.q)
+        h = vp()
+        lib.check(lib.L.fhe_ctx_create(logN, self.L, self.q.ctypes.data_as(u64p), self.psi.ctypes.data_as(u64p),
+                                       device, C.byref(h)))
+        self.h = h
+        self._allocs = []
+
+    def close(self):
+        if self.h:
+            for p in self._allocs:
+                self.lib.L.fhe_free(self.h, p)
+            self._allocs = []
+            self.lib.L.fhe_ctx_destroy(self.h)
+            self.h = None
+
+    # ---- raw device memory ----
+    def malloc(self, nbytes):
+        p = vp()
+        self.lib.check(self.lib.L.fhe_malloc(self.h, nbytes, C.byref(p)))
+        self._allocs.append(p)
+        return p
+
+    def free(self, p):
+        self._allocs = [a for a in self._allocs if a.value != p.value]
+        self.lib.check(self.lib.L.fhe_free(self.h, p))
+
+    def upload(self, arr, stream=None):
+        arr = np.ascontiguousarray(arr, dtype=np.uint64)
+        p = self.malloc(arr.nbytes)
+        self.lib.check(self.lib.L.fhe_memcpy_h2d(self.h, p, arr.ctypes.data_as(vp), arr.nbytes, stream))
+        self.sync(stream)
+        return p
+
+    def download(self, p, shape, stream=None):
+        out = np.empty(shape, dtype=np.uint64)
+        self.lib.check(self.lib.L.fhe_memcpy_d2h(self.h, out.ctypes.data_as(vp), p, out.nbytes, stream))
+        self.sync(stream)
+        return out
+
+    def sync(self, stream=None):
+        self.lib.check(self.lib.L.fhe_stream_sync(self.h, stream))
+
+    def tower(self, host, limb_idx=None, fmt=EVALUATION):
+        """host: uint64 [batch][nLimbs][N] (or [nLimbs][N])"""
+        host = np.asarray(host, dtype=np.uint64)
+        if host.ndim == 2:
+            host = host[None]
+        return Tower(self, self.upload(host), host.shape[0], host.shape[1], limb_idx, fmt)
+
+    def empty(self, batch, n_limbs, limb_idx=None, fmt=EVALUATION):
+        return Tower(self, self.malloc(batch * n_limbs * self.N * 8), batch, n_limbs, limb_idx, fmt)
+
+
+class Tower:
+    """A batch of device-resident RNS towers: the DCRTPoly data model, uint64[batch][nLimbs][N]."""
+
+    def __init__(self, ctx, ptr, batch, n_limbs, limb_idx=None, fmt=EVALUATION):
+        self.ctx, self.ptr, self.batch, self.n_limbs, self.fmt = ctx, ptr, batch, n_limbs, fmt
+        self.limb_idx = None if limb_idx is None else np.ascontiguousarray(np.asarray(limb_idx, dtype=np.uint32))
+
+    def _li(self):
+        return None if self.limb_idx is None else self.limb_idx.ctypes.data_as(u32p)
+
+    def to_host(self):
+        return self.ctx.download(self.ptr, (self.batch, self.n_limbs, self.ctx.N))
+
+    def like(self):
+        return self.ctx.empty(self.batch, self.n_limbs, self.limb_idx, self.fmt)
+
+    # DCRTPolyImpl::SwitchFormat (dcrtpoly-impl.h:1932-1940)
+    def SwitchFormat(self, stream=None):
+        L, c = self.ctx.lib, self.ctx
+        f = L.L.fhe_ntt_inv if self.fmt == EVALUATION else L.L.fhe_ntt_fwd
+        L.check(f(c.h, self.ptr, self._li(), self.n_limbs, self.batch, stream))
+        self.fmt = COEFFICIENT if self.fmt == EVALUATION else EVALUATION
+        return self
+
+    def SetFormat(self, fmt, stream=None):  # ilelement.h:447-450
+        if fmt != self.fmt:
+            self.SwitchFormat(stream)
+        return self
+
+    def _bin(self, fn, other, stream):
+        out = self.like()
+        self.ctx.lib.check(fn(self.ctx.h, out.ptr, self.ptr, other.ptr, self._li(), self.n_limbs, self.batch, stream))
+        return out
+
+    def Plus(self, other, stream=None):  # dcrtpoly.h:153-162
+        return self._bin(self.ctx.lib.L.fhe_add, other, stream)
+
+    def Minus(self, other, stream=None):  # dcrtpoly-impl.h:362-371
+        return self._bin(self.ctx.lib.L.fhe_sub, other, stream)
+
+    def Times(self, other, stream=None):  # dcrtpoly.h:174-189
+        if isinstance(other, Tower):
+            return self._bin(self.ctx.lib.L.fhe_mul, other, stream)
+        consts = np.ascontiguousarray(np.asarray(other, dtype=np.uint64))  # Times(vector<NativeInteger>) :582-601
+        out = self.like()
+        self.ctx.lib.check(self.ctx.lib.L.fhe_mul_const(self.ctx.h, out.ptr, self.ptr, consts.ctypes.data_as(u64p),
+                                                       self._li(), self.n_limbs, self.batch, stream))
+        return out
+
+    def Negate(self, stream=None):  # dcrtpoly-impl.h:347-354
+        out = self.like()
+        self.ctx.lib.check(self.ctx.lib.L.fhe_neg(self.ctx.h, out.ptr, self.ptr, self._li(), self.n_limbs, self.batch,
+                                                  stream))
+        return out
+
+    def AutomorphismTransform(self, k, stream=None):  # dcrtpoly-impl.h:314-333
+        out = self.like()
+        self.ctx.lib.check(self.ctx.lib.L.fhe_automorph(self.ctx.h, out.ptr, self.ptr, k,
+                                                        1 if self.fmt == EVALUATION else 0, self._li(), self.n_limbs,
+                                                        self.batch, stream))
+        return out
+
+
+class Conv:
+    """CRT basis conversion plan (ApproxSwitchCRTBasis / SwitchCRTBasis)."""
+
+    def __init__(self, ctx, src_idx, dst_idx):
+        self.ctx = ctx
+        self.src = np.ascontiguousarray(np.asarray(src_idx, dtype=np.uint32))
+        self.dst = np.ascontiguousarray(np.asarray(dst_idx, dtype=np.uint32))
+        h = vp()
+        ctx.lib.check(ctx.lib.L.fhe_conv_create(ctx.h, self.src.ctypes.data_as(u32p), len(self.src),
+                                                self.dst.ctypes.data_as(u32p), len(self.dst), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.L.fhe_conv_destroy(self.h)
+            self.h = None
+
+    def run(self, tin, exact=False, stream=None):
+        """tin: Tower [batch][nSrc][N] COEFFICIENT -> Tower [batch][nDst][N] COEFFICIENT"""
+        out = self.ctx.empty(tin.batch, len(self.dst), self.dst, COEFFICIENT)
+        f = self.ctx.lib.L.fhe_switch_basis_exact if exact else self.ctx.lib.L.fhe_approx_switch_basis
+        self.ctx.lib.check(f(self.h, tin.ptr, tin.n_limbs, 0, out.ptr, len(self.dst), 0, tin.batch, stream))
+        return out
+
+
+class KeySwitchPlan:
+    """HYBRID key switching for a context whose limbs are Q (sizeQ) followed by P (sizeP)."""
+
+    def __init__(self, ctx, sizeQ, sizeP, numPartQ):
+        self.ctx, self.sizeQ, self.sizeP, self.numPartQ = ctx, sizeQ, sizeP, numPartQ
+        h = vp()
+        ctx.lib.check(ctx.lib.L.fhe_ks_plan_create(ctx.h, sizeQ, sizeP, numPartQ, C.byref(h)))
+        self.h = h
+        self.key = None
+        self._ws = None
+        self._ws_bytes = 0
+
+    def close(self):
+        if self.key:
+            self.ctx.lib.L.fhe_ks_key_destroy(self.key)
+            self.key = None
+        if self.h:
+            self.ctx.lib.L.fhe_ks_plan_destroy(self.h)
+            self.h = None
+
+    def upload_key(self, keyB, keyA):
+        keyB = np.ascontiguousarray(keyB, dtype=np.uint64)
+        keyA = np.ascontiguousarray(keyA, dtype=np.uint64)
+        k = vp()
+        self.ctx.lib.check(self.ctx.lib.L.fhe_ks_key_upload(self.h, keyB.ctypes.data_as(u64p),
+                                                            keyA.ctypes.data_as(u64p), C.byref(k)))
+        self.key = k
+
+    def workspace(self, sizeQl, batch):
+        need = self.ctx.lib.L.fhe_ks_workspace_bytes(self.h, sizeQl, batch)
+        if need > self._ws_bytes:
+            if self._ws is not None:
+                self.ctx.free(self._ws)
+            self._ws = self.ctx.malloc(need)
+            self._ws_bytes = need
+        return self._ws, self._ws_bytes
+
+    def KeySwitchCore(self, c, stream=None):  # keyswitch-hybrid.cpp:308-312
+        ws, wsb = self.workspace(c.n_limbs, c.batch)
+        o0, o1 = c.like(), c.like()
+        self.ctx.lib.check(self.ctx.lib.L.fhe_keyswitch_hybrid(self.h, self.key, c.ptr, c.n_limbs, c.batch, o0.ptr,
+                                                               o1.ptr, ws, wsb, stream))
+        return o0, o1
+
+    def EvalMult(self, a0, a1, b0, b1, stream=None):  # base-leveledshe.cpp:201-214
+        ws, wsb = self.workspace(a0.n_limbs, a0.batch)
+        c0, c1 = a0.like(), a0.like()
+        self.ctx.lib.check(self.ctx.lib.L.fhe_ckks_eval_mult(self.h, self.key, a0.ptr, a1.ptr, b0.ptr, b1.ptr,
+                                                             a0.n_limbs, a0.batch, c0.ptr, c1.ptr, ws, wsb, stream))
+        return c0, c1
+
+    def ApproxModDown(self, x, sizeQl, stream=None):  # dcrtpoly-impl.h:966-1005
+        ws, wsb = self.workspace(sizeQl, x.batch)
+        out = self.ctx.empty(x.batch, sizeQl)
+        self.ctx.lib.check(self.ctx.lib.L.fhe_approx_mod_down(self.h, x.ptr, sizeQl, x.batch, out.ptr, ws, wsb, stream))
+        return out
+
+
+def rescale(ctx, x, stream=None):
+    """DCRTPoly::DropLastElementAndScale on a Tower over context limbs [0, sizeQl) (dcrtpoly-impl.h:693-712)."""
+    sizeQl = x.n_limbs
+    need = ctx.lib.L.fhe_rescale_workspace_bytes(ctx.h, sizeQl, x.batch)
+    ws = ctx.malloc(need)
+    out = ctx.empty(x.batch, sizeQl - 1)
+    ctx.lib.check(ctx.lib.L.fhe_rescale(ctx.h, x.ptr, sizeQl, x.batch, out.ptr, ws, need, stream))
+    ctx.sync(stream)
+    ctx.free(ws)
+    return out

@@ -1,0 +1,317 @@
+"""Parity of the HIP kernels (through the C ABI) against the oracle on identical seeded inputs.
+
+Every test runs twice: on the `emu` backend (TEST-ONLY lane emulator, CPU, small sizes) and, with
+`-m gpu`, on the real library on an MI355X.  Bit-exact equality is required everywhere (integer path);
+the only floating-point step (SwitchCRTBasis overflow count) is also required to be bit-exact because it
+replicates the reference's operation order.
+"""
+import numpy as np
+import pytest
+
+import libs
+from openfhe_amd import fhe_hip as fh
+
+
+def is_emu(lib):
+    return "emulator" in lib.version()
+
+
+def params(o, logN, L, bits=60):
+    q = np.zeros(L, np.uint64)
+    psi = np.zeros(L, np.uint64)
+    o.orc_dcrt_params(2 << logN, L, bits, q, psi)
+    return q, psi
+
+
+def ntt_sizes(lib):
+    small = [(4, 2, 3), (5, 1, 1), (7, 3, 2), (10, 2, 3), (11, 1, 5), (12, 2, 2), (13, 2, 1), (14, 1, 2)]
+    if is_emu(lib):
+        return small + [(16, 1, 1)]
+    return small + [(15, 3, 2), (16, 4, 3), (17, 2, 2)]
+
+
+def test_ntt_forward_inverse(backend, oracle):
+    o = oracle
+    rng = np.random.default_rng(11)
+    for logN, L, B in ntt_sizes(backend):
+        q, psi = params(o, logN, L)
+        N = 1 << logN
+        ctx = fh.Context(backend, logN, q, psi)
+        octx = o.orc_ctx_create(N, L, q, psi)
+        x = libs.rand_tower(rng, q, N, B)
+        # edge values: 0, q-1
+        x[0, :, 0] = 0
+        x[0, :, 1] = q - np.uint64(1)
+        want = x.copy()
+        o.orc_ntt_fwd_tower(octx, want, None, L, B, 0)
+        t = ctx.tower(x, fmt=fh.COEFFICIENT)
+        t.SwitchFormat()
+        got = t.to_host()
+        assert np.array_equal(got, want), f"forward NTT mismatch logN={logN}"
+        t.SwitchFormat()
+        assert np.array_equal(t.to_host(), x), f"round trip mismatch logN={logN}"
+        # inverse from an independent EVALUATION input
+        y = libs.rand_tower(rng, q, N, B)
+        wanti = y.copy()
+        o.orc_ntt_inv_tower(octx, wanti, None, L, B, 0)
+        t2 = ctx.tower(y, fmt=fh.EVALUATION)
+        t2.SwitchFormat()
+        assert np.array_equal(t2.to_host(), wanti), f"inverse NTT mismatch logN={logN}"
+        o.orc_ctx_destroy(octx)
+        ctx.close()
+
+
+def test_ntt_limb_selection_and_oop(backend, oracle):
+    """towers at a lower level / arbitrary limb subsets share one context through limbIdx"""
+    o = oracle
+    rng = np.random.default_rng(12)
+    logN, L = (12, 5) if is_emu(backend) else (13, 5)
+    N = 1 << logN
+    q, psi = params(o, logN, L)
+    ctx = fh.Context(backend, logN, q, psi)
+    octx = o.orc_ctx_create(N, L, q, psi)
+    sel = np.array([4, 1, 3], np.uint32)
+    x = libs.rand_tower(rng, q[sel], N, 2)
+    want = x.copy()
+    o.orc_ntt_fwd_tower(octx, want, sel.ctypes.data, 3, 2, 0)
+    t = ctx.tower(x, limb_idx=sel, fmt=fh.COEFFICIENT)
+    out = ctx.empty(2, 3, sel)
+    backend.check(backend.L.fhe_ntt_fwd_oop(ctx.h, t.ptr, out.ptr, sel.ctypes.data_as(fh.u32p), 3, 2, None))
+    assert np.array_equal(out.to_host(), want)
+    assert np.array_equal(t.to_host(), x), "out-of-place transform must not touch its input"
+    o.orc_ctx_destroy(octx)
+    ctx.close()
+
+
+def test_config1_cpu_reference_case(backend, oracle):
+    """BASELINE config 1: N=2^12, 2x60-bit limbs, fwd+inv round trip bit-exact, forward words vs oracle"""
+    o = oracle
+    q, psi = params(o, 12, 2)
+    assert list(q) == [1152921504606830593, 1152921504606748673]
+    rng = np.random.default_rng(1)
+    x = libs.rand_tower(rng, q, 4096, 1)
+    ctx = fh.Context(backend, 12, q, psi)
+    octx = o.orc_ctx_create(4096, 2, q, psi)
+    want = x.copy()
+    o.orc_ntt_fwd_tower(octx, want, None, 2, 1, 0)
+    t = ctx.tower(x, fmt=fh.COEFFICIENT).SwitchFormat()
+    assert np.array_equal(t.to_host(), want)
+    assert np.array_equal(t.SwitchFormat().to_host(), x)
+    o.orc_ctx_destroy(octx)
+    ctx.close()
+
+
+def test_elementwise(backend, oracle):
+    o = oracle
+    rng = np.random.default_rng(13)
+    for logN, L, B in [(6, 3, 2), (12, 2, 2), (13, 3, 1)]:
+        N = 1 << logN
+        q, psi = params(o, logN, L)
+        ctx = fh.Context(backend, logN, q, psi)
+        a = libs.rand_tower(rng, q, N, B)
+        b = libs.rand_tower(rng, q, N, B)
+        a[0, :, 0] = 0
+        b[0, :, 0] = q - np.uint64(1)
+        a[0, :, 1] = q - np.uint64(1)
+        b[0, :, 1] = q - np.uint64(1)
+        ta, tb = ctx.tower(a), ctx.tower(b)
+        for name, fn in (("Plus", o.orc_vec_add), ("Minus", o.orc_vec_sub), ("Times", o.orc_vec_mul)):
+            want = np.empty_like(a)
+            for bb in range(B):
+                for l in range(L):
+                    fn(want[bb, l], a[bb, l], b[bb, l], N, q[l])
+            got = getattr(ta, name)(tb).to_host()
+            assert np.array_equal(got, want), f"{name} mismatch logN={logN}"
+        consts = rng.integers(1, 1 << 59, size=L, dtype=np.uint64) % q
+        want = np.empty_like(a)
+        for bb in range(B):
+            for l in range(L):
+                o.orc_vec_mul_const(want[bb, l], a[bb, l], consts[l], N, q[l])
+        assert np.array_equal(ta.Times(consts).to_host(), want)
+        want = np.empty_like(a)
+        for bb in range(B):
+            for l in range(L):
+                o.orc_vec_neg(want[bb, l], a[bb, l], N, q[l])
+        assert np.array_equal(ta.Negate().to_host(), want)
+        ctx.close()
+
+
+def test_automorphism(backend, oracle):
+    o = oracle
+    rng = np.random.default_rng(14)
+    for logN, L, B in [(5, 2, 2), (12, 2, 1), (13, 2, 2)]:
+        N = 1 << logN
+        q, psi = params(o, logN, L)
+        ctx = fh.Context(backend, logN, q, psi)
+        x = libs.rand_tower(rng, q, N, B)
+        x[0, :, 3] = 0  # COEFF branch stores q - 0 = q unreduced, as the reference does
+        for k in (3, 5, 2 * N - 1, o.orc_find_automorphism_index_2n_complex(7, 2 * N)):
+            pre = np.zeros(N, np.uint32)
+            o.orc_precompute_auto_map(N, k, pre)
+            want = np.empty_like(x)
+            wantc = np.empty_like(x)
+            for bb in range(B):
+                for l in range(L):
+                    o.orc_automorph_eval(want[bb, l], x[bb, l], N, pre)
+                    o.orc_automorph_coeff(wantc[bb, l], x[bb, l], N, k, q[l])
+            assert np.array_equal(ctx.tower(x, fmt=fh.EVALUATION).AutomorphismTransform(k).to_host(), want)
+            assert np.array_equal(ctx.tower(x, fmt=fh.COEFFICIENT).AutomorphismTransform(k).to_host(), wantc)
+        ctx.close()
+
+
+def test_automorphism_even_index_rejected(backend, oracle):
+    q, psi = params(oracle, 5, 1)
+    ctx = fh.Context(backend, 5, q, psi)
+    t = ctx.tower(np.zeros((1, 1, 32), np.uint64))
+    with pytest.raises(fh.FheError, match="Automorphism index not odd"):  # poly-impl.h:337-338
+        t.AutomorphismTransform(4)
+    ctx.close()
+
+
+def test_context_argument_checks(backend, oracle):
+    q, psi = params(oracle, 6, 2)
+    with pytest.raises(fh.FheError):
+        fh.Context(backend, 6, q, psi + np.uint64(1))  # not a primitive root
+    with pytest.raises(fh.FheError):
+        fh.Context(backend, 3, q, psi)  # logN out of range
+    with pytest.raises(fh.FheError):
+        fh.Context(backend, 6, np.array([97, 193], np.uint64) * np.uint64(1 << 58), psi)
+
+
+def conv_tables(o, src, dst):
+    """host tables exactly as the oracle's hybrid code derives them: hatInv[i], hatMod[i][j], mu128[j]"""
+    nS, nD = len(src), len(dst)
+    hatInv = np.zeros(nS, np.uint64)
+    hatPre = np.zeros(nS, np.uint64)
+    hatMod = np.zeros((nS, nD), np.uint64)
+    mu = np.zeros((nD, 2), np.uint64)
+    for i in range(nS):
+        h = 1
+        for k in range(nS):
+            if k != i:
+                h = (h * int(src[k])) % int(src[i])
+        hatInv[i] = pow(h, -1, int(src[i]))
+        hatPre[i] = (int(hatInv[i]) << 64) // int(src[i])
+        for j in range(nD):
+            v = 1
+            for k in range(nS):
+                if k != i:
+                    v = (v * int(src[k])) % int(dst[j])
+            hatMod[i, j] = v
+    for j in range(nD):
+        m = (1 << 128) // int(dst[j])
+        mu[j] = (m & ((1 << 64) - 1), m >> 64)
+    return hatInv, hatPre, hatMod, mu
+
+
+def test_approx_and_exact_switch_crt_basis(backend, oracle):
+    o = oracle
+    rng = np.random.default_rng(15)
+    for logN, nS, nD, B in [(5, 2, 3, 2), (12, 3, 9, 1), (12, 7, 21, 1), (13, 4, 5, 2)]:
+        N = 1 << logN
+        q, psi = params(o, logN, nS + nD)
+        ctx = fh.Context(backend, logN, q, psi)
+        src_idx = np.arange(nS, dtype=np.uint32)
+        dst_idx = np.arange(nS, nS + nD, dtype=np.uint32)
+        src, dst = q[:nS], q[nS:]
+        hatInv, hatPre, hatMod, mu = conv_tables(o, src, dst)
+        x = libs.rand_tower(rng, src, N, B)
+        x[0, :, 0] = 0
+        x[0, :, 1] = src - np.uint64(1)
+        conv = fh.Conv(ctx, src_idx, dst_idx)
+        tin = ctx.tower(x, limb_idx=src_idx, fmt=fh.COEFFICIENT)
+        want = np.empty((B, nD, N), np.uint64)
+        for bb in range(B):
+            o.orc_approx_switch_crt_basis(x[bb], nS, N, src, hatInv, hatPre, hatMod, nD, dst, mu, want[bb])
+        assert np.array_equal(conv.run(tin).to_host(), want), "ApproxSwitchCRTBasis mismatch"
+        # exact variant: alphaQModp[a][j] = a*Q mod p_j, qInv = 1/q_i (double); QHatModp indexed [j][i]
+        Q = 1
+        for s in src:
+            Q *= int(s)
+        alpha = np.array([[(a * Q) % int(p) for p in dst] for a in range(nS + 1)], np.uint64)
+        qinv = np.array([1.0 / float(int(s)) for s in src], np.float64)
+        wante = np.empty((B, nD, N), np.uint64)
+        hm_pq = np.ascontiguousarray(hatMod.T)
+        for bb in range(B):
+            o.orc_switch_crt_basis(x[bb], nS, N, src, hatInv, hatPre, hm_pq, alpha, nD, dst, mu, qinv, wante[bb])
+        assert np.array_equal(conv.run(tin, exact=True).to_host(), wante), "SwitchCRTBasis mismatch"
+        conv.close()
+        ctx.close()
+
+
+def ckks_like_params(o, logN, sizeQ, dnum, first_bits=60, scale_bits=50, aux_bits=60):
+    """A CKKS-shaped tower without the reference's context: first modulus `first_bits`, the rest
+    `scale_bits`, auxiliary P chosen the way PrecomputeCRTTables does (oracle restatement)."""
+    M = 2 << logN
+    q = [o.orc_last_prime(first_bits, M)]
+    cur = o.orc_last_prime(scale_bits, M)
+    for _ in range(sizeQ - 1):
+        q.append(cur)
+        cur = o.orc_previous_prime(cur, M)
+    q = np.array(q, np.uint64)
+    psiQ = np.array([o.orc_root_of_unity(M, int(v)) for v in q], np.uint64)
+    p = np.zeros(64, np.uint64)
+    psiP = np.zeros(64, np.uint64)
+    sizeP = o.orc_hybrid_select_p(1 << logN, sizeQ, q, dnum, aux_bits, p, psiP)
+    return q, psiQ, p[:sizeP].copy(), psiP[:sizeP].copy()
+
+
+@pytest.mark.parametrize("logN,sizeQ,dnum,sizeQl,B", [(12, 6, 3, 6, 2), (12, 7, 2, 5, 1), (12, 5, 3, 2, 1), (13, 4, 2, 4, 1)])
+def test_hybrid_keyswitch_and_eval_mult(backend, oracle, logN, sizeQ, dnum, sizeQl, B):
+    o = oracle
+    if is_emu(backend) and logN > 12:
+        pytest.skip("emulator: keep the CPU suite short")
+    rng = np.random.default_rng(16)
+    N = 1 << logN
+    q, psiQ, p, psiP = ckks_like_params(o, logN, sizeQ, dnum)
+    sizeP = len(p)
+    hy = o.orc_hybrid_create(N, sizeQ, q, psiQ, sizeP, p, psiP, dnum)
+    allq = np.concatenate([q, p])
+    ctx = fh.Context(backend, logN, allq, np.concatenate([psiQ, psiP]))
+    plan = fh.KeySwitchPlan(ctx, sizeQ, sizeP, dnum)
+    keyB = libs.rand_tower(rng, allq, N, dnum)
+    keyA = libs.rand_tower(rng, allq, N, dnum)
+    plan.upload_key(keyB, keyA)
+    ql = q[:sizeQl]
+    a0, a1, b0, b1 = (libs.rand_tower(rng, ql, N, B) for _ in range(4))
+    # key switch alone
+    w0 = np.empty_like(a0)
+    w1 = np.empty_like(a0)
+    for bb in range(B):
+        o.orc_hybrid_key_switch(hy, a0[bb], sizeQl, keyB, keyA, w0[bb], w1[bb])
+    g0, g1 = plan.KeySwitchCore(ctx.tower(a0))
+    assert np.array_equal(g0.to_host(), w0) and np.array_equal(g1.to_host(), w1), "KeySwitchCore mismatch"
+    # EvalMult = tensor + key switch + add
+    c0 = np.empty_like(a0)
+    c1 = np.empty_like(a0)
+    for bb in range(B):
+        o.orc_ckks_eval_mult_relin(hy, a0[bb], a1[bb], b0[bb], b1[bb], sizeQl, keyB, keyA, c0[bb], c1[bb])
+    r0, r1 = plan.EvalMult(ctx.tower(a0), ctx.tower(a1), ctx.tower(b0), ctx.tower(b1))
+    assert np.array_equal(r0.to_host(), c0) and np.array_equal(r1.to_host(), c1), "EvalMult mismatch"
+    # ApproxModDown alone
+    x = libs.rand_tower(rng, np.concatenate([ql, p]), N, B)
+    wd = np.empty((B, sizeQl, N), np.uint64)
+    for bb in range(B):
+        o.orc_hybrid_approx_mod_down(hy, x[bb], sizeQl, wd[bb])
+    assert np.array_equal(plan.ApproxModDown(ctx.tower(x), sizeQl).to_host(), wd), "ApproxModDown mismatch"
+    plan.close()
+    ctx.close()
+    o.orc_hybrid_destroy(hy)
+
+
+def test_rescale(backend, oracle):
+    o = oracle
+    rng = np.random.default_rng(17)
+    for logN, sizeQl, B in [(6, 3, 2), (12, 4, 2), (13, 3, 1)]:
+        N = 1 << logN
+        q, psiQ, _, _ = ckks_like_params(o, logN, sizeQl + 1, 2)
+        ctx = fh.Context(backend, logN, q, psiQ)
+        octx = o.orc_ctx_create(N, len(q), q, psiQ)
+        x = libs.rand_tower(rng, q[:sizeQl], N, B)
+        want = np.empty((B, sizeQl - 1, N), np.uint64)
+        for bb in range(B):
+            o.orc_drop_last_element_and_scale(octx, x[bb], sizeQl, want[bb])
+        got = fh.rescale(ctx, ctx.tower(x)).to_host()
+        assert np.array_equal(got, want), f"DropLastElementAndScale mismatch logN={logN}"
+        o.orc_ctx_destroy(octx)
+        ctx.close()
