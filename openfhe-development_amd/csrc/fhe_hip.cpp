@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -211,6 +212,9 @@ extern "C" uint32_t fhe_param_select_p(uint32_t logN, uint32_t sizeQ, const uint
     return sizeP;
 }
 
+static uint32_t env_u32(const char* name, uint32_t dflt);
+static bool ntt_generic();
+
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
@@ -229,6 +233,7 @@ struct fhe_ctx {
     // cached per-level rescale tables (ckksrns-cryptoparameters.cpp:60-81): sizeQl -> {A, B} device arrays
     std::map<uint32_t, std::pair<TwPair*, TwPair*>> rescaleTabs;
     // small ring of device slots for per-call constant vectors (fhe_mul_const)
+    uint32_t persistentGrid = 1024;  // workgroups of the persistent NTT kernels (CUs x FHE_NTT_WG_PER_CU)
     TwPair* d_constRing = nullptr;
     uint32_t constRingPos = 0;
 };
@@ -266,6 +271,7 @@ extern "C" fhe_status fhe_ctx_create(uint32_t logN, uint32_t nLimbs, const uint6
     c->device  = device;
     c->q.assign(q, q + nLimbs);
     c->psi.assign(psi, psi + nLimbs);
+    c->persistentGrid = rt::cu_count(device) * env_u32("FHE_NTT_WG_PER_CU", 4);
 
     // twiddle tables: Table[bitrev(i)] = psi^i, TableI[bitrev(i)] = psi^-i  (transformnat-impl.h:725-737)
     std::vector<TwPair> tw((size_t)nLimbs * N), twInv((size_t)nLimbs * N), fin((size_t)nLimbs * 2);
@@ -381,6 +387,7 @@ static inline uint32_t tiles_for(const fhe_ctx* c, uint64_t rows) {
 struct PassPlan {
     bool layoutA;
     uint32_t T;
+    uint32_t outBound = 16;  // forward: bound (units of q) of the pass output under the lazy schedule
     uint32_t nSteps;
     NttStep steps[6];
 };
@@ -397,12 +404,12 @@ static void plan_pass(bool inverse, bool layoutA, uint32_t logN, uint32_t T, Pas
     int sizes[4];
     for (int i = 0; i < nst; ++i)
         sizes[i] = (int)T / nst + (i < (int)T % nst ? 1 : 0);
-    NttStep real[4];
+    NttStep real[4] = {};
     if (!inverse) {
         int top = (int)T - 1;
         for (int i = 0; i < nst; ++i) {
             const int r = sizes[i], fp = std::max(top - 3, 0);
-            real[i] = NttStep{(int8_t)(fp + ish), (int8_t)(fp + jsh), (int8_t)(top - fp), (int8_t)(top - fp - r + 1)};
+            real[i] = NttStep{(int8_t)(fp + ish), (int8_t)(fp + jsh), (int8_t)(top - fp), (int8_t)(top - fp - r + 1), 0, 0, 0, 0};
             top -= r;
         }
     }
@@ -410,14 +417,14 @@ static void plan_pass(bool inverse, bool layoutA, uint32_t logN, uint32_t T, Pas
         int bot = 0;
         for (int i = 0; i < nst; ++i) {
             const int r = sizes[i], fp = std::min(bot, (int)T - 4);
-            real[i] = NttStep{(int8_t)(fp + ish), (int8_t)(fp + jsh), (int8_t)(bot - fp + r - 1), (int8_t)(bot - fp)};
+            real[i] = NttStep{(int8_t)(fp + ish), (int8_t)(fp + jsh), (int8_t)(bot - fp + r - 1), (int8_t)(bot - fp), 0, 0, 0, 0};
             bot += r;
         }
     }
     // staging steps: a first/last step whose register field sits below tile-index bit 4 would touch HBM in
     // < 128-byte pieces; route it through LDS with the fully coalesced mapping (field at bits 8..11) instead
     uint32_t n = 0;
-    const NttStep stage{8, 0, -1, 0};
+    const NttStep stage{8, 0, -1, 0, 0, 0, 0, 0};
     if (!layoutA && real[0].fI < 4)
         pp->steps[n++] = stage;
     for (int i = 0; i < nst; ++i)
@@ -425,6 +432,36 @@ static void plan_pass(bool inverse, bool layoutA, uint32_t logN, uint32_t T, Pas
     if (!layoutA && real[nst - 1].fI < 4)
         pp->steps[n++] = stage;
     pp->nSteps = n;
+}
+
+// lazy-reduction schedule of a forward pass for the fast kernel: a butterfly adds at most 2q to the bound of
+// its operands and 16q < 2^64, so a step of r stages needs a correction only when bound + 2r would exceed 16.
+// `bound` (in units of q) is the bound of the pass input on entry and of its output on return.
+static void schedule_fwd(PassPlan& pp, uint32_t logN, uint32_t* bound) {
+    for (uint32_t i = 0; i < pp.nSteps; ++i) {
+        NttStep& st = pp.steps[i];
+        if (st.bHi < st.bLo)
+            continue;
+        const uint32_t r = (uint32_t)(st.bHi - st.bLo + 1);
+        if (*bound + 2 * r <= 16) {
+            st.mode = 0;
+            *bound += 2 * r;
+        }
+        else {
+            st.mode = 1;
+            *bound  = 8 + 2 * r;
+        }
+    }
+    (void)logN;
+}
+// twiddle index = 2^s + (j >> (Fj+4))...: lane-independent iff no lane-dependent bit of j lies above the field
+static void mark_uniform(PassPlan& pp, uint32_t logN) {
+    for (uint32_t i = 0; i < pp.nSteps; ++i) {
+        NttStep& st = pp.steps[i];
+        if (st.bHi < st.bLo)
+            continue;
+        st.uniformTw = pp.layoutA ? ((uint32_t)st.Fj + 4 == logN) : ((uint32_t)st.Fj + 4 >= (uint32_t)kTileLog);
+    }
 }
 
 static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse, const uint64_t* xin, uint64_t* xout,
@@ -446,16 +483,39 @@ static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse
     a.nSteps   = pp.nSteps;
     // canonicalise right after the last step that has butterfly stages (a trailing staging step only moves data)
     a.canonStep = 0xffffffffu;
+    a.canonLevels = 1;
+    while ((1u << a.canonLevels) < pp.outBound)
+        ++a.canonLevels;
     if (canonOut)
         for (uint32_t i = 0; i < pp.nSteps; ++i)
             if (pp.steps[i].bHi >= pp.steps[i].bLo)
                 a.canonStep = i;
     for (uint32_t i = 0; i < 6; ++i)
-        a.steps[i] = i < pp.nSteps ? pp.steps[i] : NttStep{0, 0, -1, 0};
+        a.steps[i] = i < pp.nSteps ? pp.steps[i] : NttStep{0, 0, -1, 0, 0, 0, 0, 0};
     a.sel = sel;
     const uint32_t grid        = tiles_for(c, a.rows);
     const uint32_t tilesPerRow = c->N >= (uint32_t)kTile ? (c->N >> kTileLog) : 1u;
     a.xcdSwizzle = (c->N >= (uint32_t)kTile && ((nLimbs * tilesPerRow) % 8u == 0)) ? 1u : 0u;
+    if (c->logN >= (uint32_t)kTileLog && !ntt_generic()) {
+        // fast path: persistent workgroups, a multiple of 8 so that the XCD a workgroup runs on (blockIdx % 8)
+        // stays the XCD of every tile it walks
+        uint32_t pgrid = std::min(grid, c->persistentGrid);
+        if (pgrid >= 8)
+            pgrid &= ~7u;
+#define FHE_FAST_CASE(LA, INV, NS) \
+    if (pp.layoutA == LA && inverse == INV && pp.nSteps == NS) { \
+        FHE_LAUNCH((ntt_pass_fast_kernel<LA, INV, NS>), pgrid, stream, a); \
+        launched = true; \
+    }
+        bool launched = false;
+        FHE_FAST_CASE(true, false, 1) FHE_FAST_CASE(true, false, 2) FHE_FAST_CASE(true, true, 1) FHE_FAST_CASE(true, true, 2)
+        FHE_FAST_CASE(false, false, 3) FHE_FAST_CASE(false, false, 4) FHE_FAST_CASE(false, true, 3) FHE_FAST_CASE(false, true, 4)
+#undef FHE_FAST_CASE
+        if (!launched)
+            return fail(FHE_ERR_UNSUPPORTED, "ntt: no fast kernel instance for this pass plan");
+        LAUNCH_CHECK();
+        return FHE_OK;
+    }
     if (pp.layoutA) {
         if (inverse)
             FHE_LAUNCH((ntt_pass_kernel<true, true>), grid, stream, a);
@@ -472,6 +532,31 @@ static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse
     return FHE_OK;
 }
 
+// tuning knobs (environment, read once): FHE_NTT_T1 = stages in the strided column pass of a two-pass ring
+// (default: as few as possible, >= 4), FHE_NTT_CHUNK = towers per chunk (default 0 = whole batch per pass)
+static uint32_t env_u32(const char* name, uint32_t dflt) {
+    const char* v = std::getenv(name);
+    return v ? (uint32_t)std::strtoul(v, nullptr, 10) : dflt;
+}
+static uint32_t ntt_t1(uint32_t logN) {
+    static const uint32_t forced = env_u32("FHE_NTT_T1", 0);
+    const uint32_t lo = std::max(4u, logN - (uint32_t)kTileLog), hi = std::min((uint32_t)kTileLog - 4u, logN - 4u);
+    if (forced >= lo && forced <= hi)
+        return forced;
+    return lo;
+}
+static bool ntt_generic() {
+    // the persistent/prefetching kernel (ntt_pass_fast_kernel) is experimental: at 207 VGPRs it runs 2 waves
+    // per SIMD and measured 20 % slower than the one-tile-per-workgroup kernel on MI355X (profiles/r01_*), so
+    // it is opt-in (FHE_NTT_FAST=1) until its register budget is fixed
+    static const uint32_t v = env_u32("FHE_NTT_FAST", 0);
+    return v == 0;
+}
+static uint32_t ntt_chunk() {
+    static const uint32_t v = env_u32("FHE_NTT_CHUNK", 0);
+    return v;
+}
+
 // inStride != 0: xin is a [batch][inStride][N] view whose rows inFirst.. are transformed into the dense xout
 static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_t* xout, const uint32_t* limbIdx,
                           uint32_t nLimbs, uint32_t batch, void* stream, uint32_t inStride = 0, uint32_t inFirst = 0) {
@@ -485,23 +570,43 @@ static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_
     if (logN <= (uint32_t)kTileLog) {
         PassPlan p;
         plan_pass(inverse, false, logN, logN, &p);
+        uint32_t bound = 1;
+        mark_uniform(p, logN);
+        if (!inverse)
+            schedule_fwd(p, logN, &bound);
+        p.outBound = bound;
         return launch_pass(c, p, inverse, xin, xout, sel, nLimbs, batch, true, stream, inStride, inFirst);
     }
     // two passes over HBM: a strided column pass of T1 stages (the coefficient index's top bits) and a
     // contiguous row pass of T2 = logN - T1 stages.  T1 is kept minimal (>= 4) so that the column pass reads
     // rows of 2^(12-T1) consecutive words (2 KiB at T1 = 4) and, at T1 = 4, needs no LDS at all.
-    const uint32_t T1 = std::max(4u, logN - (uint32_t)kTileLog), T2 = logN - T1;
+    const uint32_t T1 = ntt_t1(logN), T2 = logN - T1;
     PassPlan pa, pb;
     plan_pass(inverse, true, logN, T1, &pa);
     plan_pass(inverse, false, logN, T2, &pb);
+    mark_uniform(pa, logN);
+    mark_uniform(pb, logN);
     if (!inverse) {
-        if (fhe_status s = launch_pass(c, pa, false, xin, xout, sel, nLimbs, batch, false, stream, inStride, inFirst))
-            return s;
-        return launch_pass(c, pb, false, xout, xout, sel, nLimbs, batch, true, stream);
+        uint32_t bound = 1;
+        schedule_fwd(pa, logN, &bound);
+        schedule_fwd(pb, logN, &bound);
+        pb.outBound = bound;
     }
-    if (fhe_status s = launch_pass(c, pb, true, xin, xout, sel, nLimbs, batch, false, stream, inStride, inFirst))
-        return s;
-    return launch_pass(c, pa, true, xout, xout, sel, nLimbs, batch, true, stream);
+    // optional chunking (tuning knob FHE_NTT_CHUNK = towers per chunk): both passes of a chunk run back to
+    // back so that the intermediate tower can be served from the 256 MiB Infinity Cache instead of HBM
+    const uint32_t chunk = ntt_chunk() ? std::min(ntt_chunk(), batch) : batch;
+    for (uint32_t b0 = 0; b0 < batch; b0 += chunk) {
+        const uint32_t nb   = std::min(chunk, batch - b0);
+        const uint64_t* in  = xin + (inStride ? ((size_t)b0 * inStride << logN) : ((size_t)b0 * nLimbs << logN));
+        uint64_t* out       = xout + ((size_t)b0 * nLimbs << logN);
+        const PassPlan& p1  = inverse ? pb : pa;
+        const PassPlan& p2  = inverse ? pa : pb;
+        if (fhe_status s = launch_pass(c, p1, inverse, in, out, sel, nLimbs, nb, false, stream, inStride, inFirst))
+            return s;
+        if (fhe_status s = launch_pass(c, p2, inverse, out, out, sel, nLimbs, nb, true, stream))
+            return s;
+    }
+    return FHE_OK;
 }
 
 extern "C" fhe_status fhe_ntt_fwd(fhe_ctx* c, uint64_t* x, const uint32_t* li, uint32_t nl, uint32_t b, void* st) {
@@ -531,9 +636,15 @@ extern "C" fhe_status fhe_time_ntt(fhe_ctx* c, uint64_t* x, const uint32_t* li, 
     PassPlan pp;
     if (dir >= 10) {
         ARG_CHECK(c->logN > (uint32_t)kTileLog && dir <= 13, "fhe_time_ntt: single-pass timing needs a two-pass ring");
-        const uint32_t T1 = std::max(4u, c->logN - (uint32_t)kTileLog), T2 = c->logN - T1;
+        const uint32_t T1 = ntt_t1(c->logN), T2 = c->logN - T1;
         const bool inv = dir >= 12, colPass = (dir == 10 || dir == 13);
         plan_pass(inv, colPass, c->logN, colPass ? T1 : T2, &pp);
+        mark_uniform(pp, c->logN);
+        if (!inv) {
+            uint32_t bound = colPass ? 1u : 16u;
+            schedule_fwd(pp, c->logN, &bound);
+            pp.outBound = bound;
+        }
     }
     rt::Timer tm;
     RT_CHECK(tm.start((rt::stream_t)st));

@@ -9,6 +9,7 @@
 #include "emu_runtime.h"  // tests/emu/emu_runtime.h
 #define FHE_GLOBAL static
 #define FHE_LAUNCH_BOUNDS(n)
+#define FHE_LAUNCH_BOUNDS2(n, w)
 #define FHE_TID (fhe_emu::tls.tid)
 #define FHE_BID (fhe_emu::tls.bid)
 #define FHE_NBLK (fhe_emu::tls.nblk)
@@ -19,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #define FHE_GLOBAL __global__
 #define FHE_LAUNCH_BOUNDS(n) __launch_bounds__(n)
+#define FHE_LAUNCH_BOUNDS2(n, w) __launch_bounds__(n, w)
 #define FHE_TID (threadIdx.x)
 #define FHE_BID (blockIdx.x)
 #define FHE_NBLK (gridDim.x)

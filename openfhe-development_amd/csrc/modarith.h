@@ -35,11 +35,51 @@ FHE_HD uint64_t csub(uint64_t x, uint64_t m) {
     return x >= m ? x - m : x;
 }
 
+// 32x32+64 -> 64 multiply-add: the only integer multiplier CDNA4 has (v_mad_u64_u32, measured 5.1 cycles per
+// wave64 on a SIMD; v_mul_hi_u32 is slower at 7.7).  Spelled as inline asm on the device so that hipcc cannot
+// re-select v_mul_hi_u32 / v_mul_lo_u32 + v_add3 for parts of the chain.
+FHE_HD uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t d;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
+    return d;
+#else
+    return (uint64_t)a * b + c;
+#endif
+}
+FHE_HD uint64_t mul32x32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t d;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b) : "vcc");
+    return d;
+#else
+    return (uint64_t)a * b;
+#endif
+}
+
 // Shoup multiplication by a constant w with precomputed wp = floor(w * 2^64 / q)
 // (ubintnat.h:1437-1444).  LAZY form: any y < 2^64, result in [0, 2q), congruent to y*w.
+// Ten multiply-adds: Q = hi64(y*wp) (4), then lo64(y*w + Q*(-q)) (2 for the low word with 64-bit carry,
+// 4 for the cross terms accumulated into the high word).  nq = -q mod 2^64.
+FHE_HD uint64_t mul_shoup_lazy_nq(uint64_t y, uint64_t w, uint64_t wp, uint64_t nq) {
+    const uint32_t yl = (uint32_t)y, yh = (uint32_t)(y >> 32), pl = (uint32_t)wp, ph = (uint32_t)(wp >> 32);
+    const uint64_t p0 = mul32x32(yl, pl);
+    const uint64_t p1 = mad64(yh, pl, p0 >> 32);
+    const uint64_t p2 = mad64(yl, ph, (uint32_t)p1);
+    const uint64_t Q  = mad64(yh, ph, p1 >> 32) + (p2 >> 32);
+    const uint32_t Ql = (uint32_t)Q, Qh = (uint32_t)(Q >> 32), wl = (uint32_t)w, wh = (uint32_t)(w >> 32);
+    const uint32_t nql = (uint32_t)nq, nqh = (uint32_t)(nq >> 32);
+    uint64_t acc = mul32x32(yl, wl);
+    acc          = mad64(Ql, nql, acc);
+    uint64_t h   = acc >> 32;
+    h            = mad64(yl, wh, h);
+    h            = mad64(yh, wl, h);
+    h            = mad64(Ql, nqh, h);
+    h            = mad64(Qh, nql, h);
+    return (acc & 0xffffffffull) | (h << 32);
+}
 FHE_HD uint64_t mul_shoup_lazy(uint64_t y, uint64_t w, uint64_t wp, uint64_t q) {
-    uint64_t Q = mulhi64(y, wp);
-    return y * w - Q * q;
+    return mul_shoup_lazy_nq(y, w, wp, 0 - q);
 }
 // canonical result in [0,q): same value as ModMulFastConst (ubintnat.h:1464-1469)
 FHE_HD uint64_t mul_shoup(uint64_t y, uint64_t w, uint64_t wp, uint64_t q) {

@@ -48,6 +48,12 @@ struct NttStep {
     int8_t Fj;   // position of the same field inside the coefficient index j
     int8_t bHi;  // butterfly stages act on field bits bHi..bLo (bHi < bLo: data movement only)
     int8_t bLo;
+    // fast kernel only (forward transform): lazy-reduction schedule of this step
+    //   0: no correction (bounds still fit)      1: all 16 values are brought back below 8q before the step
+    uint8_t mode;
+    uint8_t levels;
+    uint8_t uniformTw;  // 1: the twiddle index of this step does not depend on the lane (scalar loads)
+    uint8_t pad;
 };
 
 struct NttPassArgs {
@@ -62,6 +68,7 @@ struct NttPassArgs {
     uint32_t rows;        // batch * nLimbs
     uint32_t batch;
     uint32_t nSteps;
+    uint32_t canonLevels; // fast forward kernel: outputs of the canon step are < 2^canonLevels * q
     uint32_t canonStep;   // index of the step after whose stages values are canonicalised to [0,q); >= nSteps: never
     uint32_t xcdSwizzle;  // 1: remap blockIdx so that an XCD keeps one (limb, tile) pair across the batch
     uint32_t inStride;    // 0: xin is dense like x; else towers of xin are inStride rows apart and the
@@ -78,24 +85,24 @@ FHE_HD uint32_t lds_sigma(uint32_t I) {
 
 // ---- butterflies -------------------------------------------------------------------------------
 // forward (Cooley-Tukey), lazy: inputs in [0,4q) -> outputs in [0,4q)
-FHE_HD void bfly_fwd(uint64_t& a, uint64_t& b, const TwPair w, uint64_t q, uint64_t twoq) {
+FHE_HD void bfly_fwd(uint64_t& a, uint64_t& b, const TwPair w, uint64_t nq, uint64_t twoq) {
     uint64_t X = csub(a, twoq);
-    uint64_t T = mul_shoup_lazy(b, w.w, w.wp, q);
+    uint64_t T = mul_shoup_lazy_nq(b, w.w, w.wp, nq);
     a          = X + T;
     b          = X - T + twoq;
 }
 // inverse (Gentleman-Sande), lazy: inputs in [0,2q) -> outputs in [0,2q)
-FHE_HD void bfly_inv(uint64_t& a, uint64_t& b, const TwPair w, uint64_t q, uint64_t twoq) {
+FHE_HD void bfly_inv(uint64_t& a, uint64_t& b, const TwPair w, uint64_t nq, uint64_t twoq) {
     uint64_t u = a, v = b;
     a          = csub(u + v, twoq);
-    b          = mul_shoup_lazy(u - v + twoq, w.w, w.wp, q);
+    b          = mul_shoup_lazy_nq(u - v + twoq, w.w, w.wp, nq);
 }
 // last inverse stage: lower output *N^-1, upper output *(w1*N^-1)  (transformnat-impl.h:598-624)
-FHE_HD void bfly_inv_last(uint64_t& a, uint64_t& b, const TwPair nInv, const TwPair w1nInv, uint64_t q,
+FHE_HD void bfly_inv_last(uint64_t& a, uint64_t& b, const TwPair nInv, const TwPair w1nInv, uint64_t nq,
                           uint64_t twoq) {
     uint64_t u = a, v = b;
-    a          = mul_shoup_lazy(u + v, nInv.w, nInv.wp, q);
-    b          = mul_shoup_lazy(u - v + twoq, w1nInv.w, w1nInv.wp, q);
+    a          = mul_shoup_lazy_nq(u + v, nInv.w, nInv.wp, nq);
+    b          = mul_shoup_lazy_nq(u - v + twoq, w1nInv.w, w1nInv.wp, nq);
 }
 
 // ---- the pass kernel ---------------------------------------------------------------------------
@@ -139,7 +146,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_pass_kernel(const NttPassArgs a)
     const uint64_t totalWords = (uint64_t)a.rows << logN;
 
     uint64_t r[16];
-    uint64_t q = 0, twoq = 0;
+    uint64_t q = 0, twoq = 0, nq = 0;
     const TwPair* tw = nullptr;
     uint32_t limb    = 0;
 
@@ -171,6 +178,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_pass_kernel(const NttPassArgs a)
             limb = a.sel.idx[(inRange ? row : 0u) % a.nLimbs];
             q    = a.q[limb];
             twoq = q << 1;
+            nq   = 0 - q;
             tw   = a.tw + ((uint64_t)limb << logN);
         }
         if (si == 0) {
@@ -206,7 +214,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_pass_kernel(const NttPassArgs a)
 #pragma unroll
                             for (int lo = 0; lo < (1 << b); ++lo) {
                                 const int k0 = (g << (b + 1)) | lo;
-                                bfly_fwd(r[k0], r[k0 | (1 << b)], w, q, twoq);
+                                bfly_fwd(r[k0], r[k0 | (1 << b)], w, nq, twoq);
                             }
                         }
                     }
@@ -222,7 +230,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_pass_kernel(const NttPassArgs a)
                             const TwPair nInv = a.fin[2 * limb], w1n = a.fin[2 * limb + 1];
 #pragma unroll
                             for (int lo = 0; lo < (1 << b); ++lo)  // b == 3 here, g == 0
-                                bfly_inv_last(r[lo], r[lo | (1 << b)], nInv, w1n, q, twoq);
+                                bfly_inv_last(r[lo], r[lo | (1 << b)], nInv, w1n, nq, twoq);
                         }
                         else {
 #pragma unroll
@@ -231,7 +239,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_pass_kernel(const NttPassArgs a)
 #pragma unroll
                                 for (int lo = 0; lo < (1 << b); ++lo) {
                                     const int k0 = (g << (b + 1)) | lo;
-                                    bfly_inv(r[k0], r[k0 | (1 << b)], w, q, twoq);
+                                    bfly_inv(r[k0], r[k0 | (1 << b)], w, nq, twoq);
                                 }
                             }
                         }
@@ -257,6 +265,256 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_pass_kernel(const NttPassArgs a)
             for (int k = 0; k < 16; ++k)
                 lds[sb ^ lds_sigma((uint32_t)k << fI)] = r[k];
             FHE_SYNC();
+        }
+    }
+}
+
+
+// ================================================================================================
+// Fast path for rings with N >= 4096 (every tile lies inside one limb): same tiling and step plan as
+// ntt_pass_kernel, plus
+//  * persistent workgroups: each workgroup walks a strided list of tiles and issues the HBM loads of its
+//    next tile before computing the current one, so the memory pipe and the integer pipe overlap inside a
+//    wave instead of relying on other waves being in a different phase;
+//  * a 10-multiply Shoup butterfly with the x+T sum folded into the multiply-add chain and no register
+//    shuffles for the low product (see bfly_fwd_fast);
+//  * forward transform: conditional subtractions only where the 64-bit headroom (16q) would otherwise
+//    overflow (NttStep::mode), instead of one per butterfly.
+// ================================================================================================
+
+// hi64(y * wp): 4 multiply-adds
+FHE_HD uint64_t mulhi64_mad(uint32_t yl, uint32_t yh, uint64_t wp) {
+    const uint32_t pl = (uint32_t)wp, ph = (uint32_t)(wp >> 32);
+    const uint64_t p0 = mul32x32(yl, pl);
+    const uint64_t p1 = mad64(yh, pl, p0 >> 32);
+    const uint64_t p2 = mad64(yl, ph, (uint32_t)p1);
+    return mad64(yh, ph, p1 >> 32) + (p2 >> 32);
+}
+// returns (x + y*w - floor(y*wp/2^64)*q) mod 2^64  ==  x + T,  T in [0,2q)
+FHE_HD uint64_t shoup_acc(uint64_t x, uint64_t y, const TwPair w, uint64_t nq) {
+    const uint32_t yl = (uint32_t)y, yh = (uint32_t)(y >> 32);
+    const uint64_t Q  = mulhi64_mad(yl, yh, w.wp);
+    const uint32_t Ql = (uint32_t)Q, Qh = (uint32_t)(Q >> 32), wl = (uint32_t)w.w, wh = (uint32_t)(w.w >> 32);
+    const uint32_t nql = (uint32_t)nq, nqh = (uint32_t)(nq >> 32);
+    uint64_t C = mul32x32(yl, wh);  // cross terms: only their low 32 bits matter
+    C          = mad64(yh, wl, C);
+    C          = mad64(Ql, nqh, C);
+    C          = mad64(Qh, nql, C);
+    uint64_t L = mad64(yl, wl, x);  // low product accumulated straight onto x
+    L          = mad64(Ql, nql, L);
+    const uint32_t hi = (uint32_t)(L >> 32) + (uint32_t)C;
+    return ((uint64_t)hi << 32) | (uint32_t)L;
+}
+// x in [0, 2m) -> [0, m) written as subtract-then-select (2 + 2 instructions)
+FHE_HD uint64_t csub2(uint64_t x, uint64_t m) {
+    const uint64_t d = x - m;
+    return x < m ? x : d;
+}
+FHE_HD void bfly_fwd_fast(uint64_t& a, uint64_t& b, const TwPair w, uint64_t nq, uint64_t twoq) {
+    const uint64_t X  = a;
+    const uint64_t an = shoup_acc(X, b, w, nq);  // X + T
+    b                 = (X << 1) + twoq - an;    // X - T + 2q
+    a                 = an;
+}
+FHE_HD void bfly_inv_fast(uint64_t& a, uint64_t& b, const TwPair w, uint64_t nq, uint64_t twoq) {
+    const uint64_t u = a, v = b;
+    a                = csub2(u + v, twoq);
+    b                = shoup_acc(0, u - v + twoq, w, nq);
+}
+
+// NSTEPS = number of entries of a.steps (compile time, so that the step loop unrolls and the position of the
+// next-tile prefetch is static).  Row-pass plans carry one data-movement ("staging") step: the last one for the
+// forward transform, the first one for the inverse.
+#ifndef FHE_NTT_MINWAVES
+#define FHE_NTT_MINWAVES 2
+#endif
+template <bool LAYOUT_A, bool INVERSE, int NSTEPS>
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS2(kThreads, FHE_NTT_MINWAVES) ntt_pass_fast_kernel(const NttPassArgs a) {
+    FHE_SHARED_U64(lds, kTile);
+    const uint32_t t    = FHE_TID;
+    const uint32_t logN = a.logN;
+    const uint32_t N    = 1u << logN;
+    const uint32_t T    = a.T;
+    const uint32_t tilesPerRow = N >> kTileLog;
+    const uint32_t nTiles      = a.rows * tilesPerRow;
+    const uint32_t logC = kTileLog - T;
+    const uint32_t S    = N >> T;
+    // the next tile's HBM loads are issued at the start of step PFS: as early as possible, but behind the first
+    // per-lane (vector) twiddle loads, because vmcnt retires in order.  Steps whose twiddles are lane-uniform
+    // fetch them through the scalar cache and do not interfere.
+    constexpr int PFS = !INVERSE ? 0 : (LAYOUT_A ? (NSTEPS == 1 ? 0 : 1) : 2);
+
+    auto locate = [&](uint32_t w, uint32_t& row, uint64_t& gbase, uint32_t& jbase) {
+        uint32_t tile = w;
+        if (a.xcdSwizzle) {
+            const uint32_t xcd = w & 7u, i = w >> 3;
+            const uint32_t b = i % a.batch, pairIdx = i / a.batch;
+            const uint32_t pair = pairIdx * 8u + xcd;
+            tile = (b * a.nLimbs + pair / tilesPerRow) * tilesPerRow + pair % tilesPerRow;
+        }
+        row = tile / tilesPerRow;
+        if (LAYOUT_A) {
+            jbase = (tile % tilesPerRow) << logC;
+            gbase = ((uint64_t)row << logN) + jbase;
+        }
+        else {
+            jbase = (tile % tilesPerRow) << kTileLog;
+            gbase = (uint64_t)tile << kTileLog;
+        }
+    };
+    auto lane_geom = [&](uint32_t fI, uint32_t& rel, uint64_t& kstride) {
+        const uint32_t Ib = ((t >> fI) << (fI + 4)) | (t & ((1u << fI) - 1u));
+        if (LAYOUT_A) {
+            const uint32_t p0 = Ib >> logC, c0 = Ib & ((1u << logC) - 1u);
+            rel     = p0 * S + c0;
+            kstride = (fI >= logC) ? ((uint64_t)S << (fI - logC)) : ((uint64_t)1 << fI);
+        }
+        else {
+            rel     = Ib;
+            kstride = (uint64_t)1 << fI;
+        }
+    };
+
+    uint32_t relIn, relOut;
+    uint64_t ksIn, ksOut;
+    lane_geom((uint32_t)a.steps[0].fI, relIn, ksIn);
+    lane_geom((uint32_t)a.steps[NSTEPS - 1].fI, relOut, ksOut);
+
+    uint64_t pf[16];
+    auto issue_loads = [&](uint32_t ww) {
+        uint32_t row, jb;
+        uint64_t gb;
+        locate(ww, row, gb, jb);
+        uint64_t ioff = gb + relIn;
+        if (a.inStride)
+            ioff = (((uint64_t)(row / a.nLimbs) * a.inStride + a.inFirst + row % a.nLimbs) << logN) + jb + relIn;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            pf[k] = a.xin[ioff + k * ksIn];
+    };
+    uint32_t w = FHE_BID;
+    if (w < nTiles)
+        issue_loads(w);
+
+    for (; w < nTiles; w += FHE_NBLK) {
+        uint32_t row, jbase;
+        uint64_t gbase;
+        locate(w, row, gbase, jbase);
+        const uint32_t limb = FHE_UNIFORM(a.sel.idx[row % a.nLimbs]);
+        const uint64_t q    = a.q[limb];
+        const uint64_t twoq = q << 1, nq = 0 - q;
+        const TwPair* tw    = a.tw + ((uint64_t)limb << logN);
+        const bool more     = w + FHE_NBLK < nTiles;
+
+        uint64_t r[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            r[k] = pf[k];
+
+#pragma unroll
+        for (int si = 0; si < NSTEPS; ++si) {
+            const NttStep st  = a.steps[si];
+            const uint32_t fI = (uint32_t)st.fI;
+            uint32_t rel;
+            uint64_t kstride;
+            lane_geom(fI, rel, kstride);
+            const uint32_t Ib = ((t >> fI) << (fI + 4)) | (t & ((1u << fI) - 1u));
+            if (si != 0) {
+                const uint32_t sb = lds_sigma(Ib);
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    r[k] = lds[sb ^ lds_sigma((uint32_t)k << fI)];
+                FHE_SYNC();
+            }
+            if (si == PFS && more)
+                issue_loads(w + FHE_NBLK);
+            if (st.bHi >= st.bLo) {
+                const uint32_t Fj = (uint32_t)st.Fj;
+                uint32_t jhigh    = (jbase + rel) >> (Fj + 4);
+                if (st.uniformTw)
+                    jhigh = FHE_UNIFORM(jhigh);
+                if (!INVERSE) {
+                    if (st.mode == 1) {  // keep the 64-bit headroom: everything back below 8q
+#pragma unroll
+                        for (int k = 0; k < 16; ++k)
+                            r[k] = csub2(r[k], twoq << 2);
+                    }
+#pragma unroll
+                    for (int b = 3; b >= 0; --b) {
+                        if (b <= st.bHi && b >= st.bLo) {
+                            const uint32_t s      = logN - 1u - (Fj + b);
+                            const uint32_t twbase = (1u << s) + (jhigh << (3 - b));
+#pragma unroll
+                            for (int g = 0; g < (8 >> b); ++g) {
+                                const TwPair wv = tw[twbase + g];
+#pragma unroll
+                                for (int lo = 0; lo < (1 << b); ++lo) {
+                                    const int k0 = (g << (b + 1)) | lo;
+                                    bfly_fwd_fast(r[k0], r[k0 | (1 << b)], wv, nq, twoq);
+                                }
+                            }
+                        }
+                    }
+                }
+                else {
+#pragma unroll
+                    for (int b = 0; b <= 3; ++b) {
+                        if (b <= st.bHi && b >= st.bLo) {
+                            const uint32_t s      = logN - 1u - (Fj + b);
+                            const uint32_t twbase = (1u << s) + (jhigh << (3 - b));
+                            if (s == 0) {
+                                const TwPair nInv = a.fin[2 * limb], w1n = a.fin[2 * limb + 1];
+#pragma unroll
+                                for (int lo = 0; lo < (1 << b); ++lo) {
+                                    const uint64_t u = r[lo], v = r[lo | (1 << b)];
+                                    r[lo]            = shoup_acc(0, u + v, nInv, nq);
+                                    r[lo | (1 << b)] = shoup_acc(0, u - v + twoq, w1n, nq);
+                                }
+                            }
+                            else {
+#pragma unroll
+                                for (int g = 0; g < (8 >> b); ++g) {
+                                    const TwPair wv = tw[twbase + g];
+#pragma unroll
+                                    for (int lo = 0; lo < (1 << b); ++lo) {
+                                        const int k0 = (g << (b + 1)) | lo;
+                                        bfly_inv_fast(r[k0], r[k0 | (1 << b)], wv, nq, twoq);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if ((uint32_t)si == a.canonStep) {
+                if (INVERSE) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        r[k] = csub2(r[k], q);
+                }
+                else {
+                    // forward outputs are below 2^canonLevels * q
+                    for (int lv = (int)a.canonLevels - 1; lv >= 0; --lv) {
+                        const uint64_t m = q << lv;
+#pragma unroll
+                        for (int k = 0; k < 16; ++k)
+                            r[k] = csub2(r[k], m);
+                    }
+                }
+            }
+            if (si + 1 == NSTEPS) {
+                const uint64_t ooff = gbase + relOut;
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    a.x[ooff + k * ksOut] = r[k];
+            }
+            else {
+                const uint32_t sb = lds_sigma(Ib);
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    lds[sb ^ lds_sigma((uint32_t)k << fI)] = r[k];
+                FHE_SYNC();
+            }
         }
     }
 }

@@ -16,6 +16,7 @@ namespace rt {
 typedef void* stream_t;
 inline bool ok() { return true; }
 inline int device_count() { return 1; }
+inline uint32_t cu_count(int) { return 3; }
 inline const char* set_device(int) { return nullptr; }
 inline const char* dmalloc(void** p, size_t bytes) {
     *p = std::malloc(bytes ? bytes : 1);
@@ -67,6 +68,12 @@ inline int device_count() {
     return n;
 }
 inline const char* set_device(int d) { return err(hipSetDevice(d)); }
+inline uint32_t cu_count(int d) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, d) != hipSuccess)
+        return 256;
+    return (uint32_t)p.multiProcessorCount;
+}
 inline const char* dmalloc(void** p, size_t bytes) { return err(hipMalloc(p, bytes ? bytes : 1)); }
 inline const char* dfree(void* p) { return err(hipFree(p)); }
 inline const char* h2d(void* d, const void* s, size_t n, stream_t st) {

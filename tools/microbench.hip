@@ -82,6 +82,34 @@ static float timeit(hipStream_t st, int reps, const std::function<void()>& f) {
 }
 #include <functional>
 
+template <int KIND>
+__global__ void alu_asm(uint64_t* out, uint64_t seed, int iters) {
+    uint32_t a[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = (uint32_t)seed * (threadIdx.x + 1 + i * 977); b[i] = a[i] ^ 0x5555u; }
+    uint64_t w64 = seed | 1;
+    uint32_t w = (uint32_t)seed | 1;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (KIND == 0) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(w));
+            else if (KIND == 1) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(b[i]));
+            else if (KIND == 2) { uint64_t x = ((uint64_t)b[i] << 32) | a[i]; asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(x) : "v"(w64)); a[i] = (uint32_t)x; b[i] = (uint32_t)(x >> 32); }
+            else if (KIND == 3) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(w) : );
+            else if (KIND == 4) asm volatile("v_sub_co_u32 %0, vcc, %0, %2\n v_subb_co_u32 %1, vcc, %1, %2, vcc" : "+v"(a[i]), "+v"(b[i]) : "v"(w) : "vcc");
+            else if (KIND == 5) { uint64_t x = ((uint64_t)b[i] << 32) | a[i]; asm volatile("v_cmp_ge_u64 vcc, %0, %1" : : "v"(x), "v"(w64) : "vcc"); }
+            else if (KIND == 6) { uint64_t d; asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(a[i]), "v"(w) : "vcc"); a[i] = (uint32_t)(d >> 32); }
+            else if (KIND == 7) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(w));
+            else if (KIND == 8) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(a[i]) : "v"(w));
+            else if (KIND == 9) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(w));
+        }
+    }
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s ^= a[i] ^ ((uint64_t)b[i] << 32);
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 int main(int argc, char** argv) {
     size_t gb = argc > 1 ? atol(argv[1]) : 4;
     hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
@@ -107,6 +135,30 @@ int main(int argc, char** argv) {
       printf(" \"alu_%s\": {\"Gops\": %.1f, \"cycles_per_wave_op_per_simd\": %.2f},\n", names[K], ops / ms / 1e6, \
              (double)p.multiProcessorCount * 4 * (p.clockRate * 1e3) * (ms * 1e-3) / (ops / 64)); }
     RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9)
+       const char* anames[] = {"v_add_u32", "v_mov_b32", "v_lshl_add_u64", "v_cndmask_b32", "v_sub_co+subb", "v_cmp_ge_u64",
+                            "v_mad_u64_u32", "v_mul_u32_u24", "v_mad_u32_u24", "v_add3_u32"};
+#define RUNA(K) { float ms = timeit(st, 3, [&] { hipLaunchKernelGGL(alu_asm<K>, dim3(blocks), dim3(256), 0, st, out, 0x1234567ull, iters); }); \
+      double ops = (double)blocks * 256 * iters * 8; \
+      printf(" \"asm_%s\": {\"Gops\": %.1f, \"cycles_per_wave_op_per_simd\": %.2f},\n", anames[K], ops / ms / 1e6, \
+             (double)p.multiProcessorCount * 4 * (p.clockRate * 1e3) * (ms * 1e-3) / (ops / 64)); }
+    RUNA(0) RUNA(1) RUNA(2) RUNA(3) RUNA(4) RUNA(5) RUNA(6) RUNA(7) RUNA(8) RUNA(9)
+    // cache residency: write S bytes then read them back (separately timed), and rewrite the same S bytes repeatedly
+    for (size_t mb : {16, 64, 128, 192, 512, 2048}) {
+        size_t sb = mb << 20, sn = sb / 16;
+        if (sb > bytes) break;
+        float wt = 0, rt = 0;
+        hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
+        for (int rep = 0; rep < 6; ++rep) {
+            CK(hipEventRecord(e0, st));
+            hipLaunchKernelGGL(write16, dim3(8192), dim3(256), 0, st, b, sn);
+            CK(hipEventRecord(e1, st));
+            hipLaunchKernelGGL(read16, dim3(8192), dim3(256), 0, st, b, a, sn);
+            CK(hipEventRecord(e2, st)); CK(hipEventSynchronize(e2));
+            float t1, t2; CK(hipEventElapsedTime(&t1, e0, e1)); CK(hipEventElapsedTime(&t2, e1, e2));
+            if (rep >= 2) { wt += t1; rt += t2; }
+        }
+        printf(" \"cache_%zuMB\": {\"write_then_read_GBps\": [%.0f, %.0f]},\n", mb, sb / (wt / 4) / 1e6, sb / (rt / 4) / 1e6);
+    }
     printf(" \"done\": true}\n");
     return 0;
 }
