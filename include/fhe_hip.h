@@ -156,6 +156,10 @@ void       fhe_ks_plan_destroy(fhe_ks_plan* plan);
 uint32_t   fhe_ks_plan_alpha(const fhe_ks_plan* plan);
 fhe_status fhe_ks_key_alloc(fhe_ks_plan* plan, fhe_ks_key** out);
 fhe_status fhe_ks_key_upload(fhe_ks_plan* plan, const uint64_t* keyB, const uint64_t* keyA, fhe_ks_key** out);
+/* adopt key vectors that already live in device memory (not owned: destroy leaves them alone). This is the
+ * multi-GPU path: rank 0 uploads, every rank receives the words with an RCCL broadcast into its own buffer
+ * (e.g. a torch tensor) and wraps it — the only collective of the whole design. */
+fhe_status fhe_ks_key_wrap(fhe_ks_plan* plan, uint64_t* devKeyB, uint64_t* devKeyA, fhe_ks_key** out);
 void       fhe_ks_key_destroy(fhe_ks_key* key);
 /* device pointers of the b (which=0) / a (which=1) vectors: uint64_t[numPartQ][sizeQ+sizeP][N] */
 uint64_t*  fhe_ks_key_devptr(fhe_ks_key* key, int which);

@@ -945,6 +945,7 @@ struct fhe_ks_key {
     fhe_ks_plan* plan;
     uint64_t *d_b = nullptr, *d_a = nullptr;
     size_t words = 0;
+    bool owned = true;
 };
 
 extern "C" fhe_status fhe_ks_plan_create(fhe_ctx* c, uint32_t sizeQ, uint32_t sizeP, uint32_t numPartQ,
@@ -1067,12 +1068,23 @@ extern "C" fhe_status fhe_ks_key_upload(fhe_ks_plan* p, const uint64_t* keyB, co
     *out = k;
     return FHE_OK;
 }
+extern "C" fhe_status fhe_ks_key_wrap(fhe_ks_plan* p, uint64_t* devB, uint64_t* devA, fhe_ks_key** out) {
+    ARG_CHECK(p && devB && devA && out, "fhe_ks_key_wrap: null argument");
+    fhe_ks_key* k = new fhe_ks_key;
+    k->plan       = p;
+    k->words      = (size_t)p->numPartQ * (p->sizeQ + p->sizeP) << p->ctx->logN;
+    k->d_b        = devB;
+    k->d_a        = devA;
+    k->owned      = false;
+    *out          = k;
+    return FHE_OK;
+}
 extern "C" void fhe_ks_key_destroy(fhe_ks_key* k) {
     if (!k)
         return;
-    if (k->d_b)
+    if (k->owned && k->d_b)
         rt::dfree(k->d_b);
-    if (k->d_a)
+    if (k->owned && k->d_a)
         rt::dfree(k->d_a);
     delete k;
 }

@@ -182,14 +182,26 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_pass_kernel(const NttPassArgs a)
             tw   = a.tw + ((uint64_t)limb << logN);
         }
         if (si == 0) {
-            uint64_t ioff = off0;
             if (a.inStride) {
-                const uint32_t rr = inRange ? row : 0u;
-                ioff = ((((uint64_t)(rr / a.nLimbs) * a.inStride + a.inFirst + rr % a.nLimbs)) << logN) + (off0 & (N - 1u));
-            }
+                // strided source view: map every element's dense row to its row in the [batch][inStride][N] view
+                // (with N < 4096 the 16 values of a lane can lie in different rows)
 #pragma unroll
-            for (int k = 0; k < 16; ++k)
-                r[k] = (LAYOUT_A || off0 + k * kstride < totalWords) ? a.xin[ioff + k * kstride] : 0;
+                for (int k = 0; k < 16; ++k) {
+                    const uint64_t d = off0 + k * kstride;
+                    if (LAYOUT_A || d < totalWords) {
+                        const uint32_t rr = (uint32_t)(d >> logN);
+                        r[k] = a.xin[((((uint64_t)(rr / a.nLimbs) * a.inStride + a.inFirst + rr % a.nLimbs)) << logN) +
+                                     (d & (N - 1u))];
+                    }
+                    else
+                        r[k] = 0;
+                }
+            }
+            else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    r[k] = (LAYOUT_A || off0 + k * kstride < totalWords) ? a.xin[off0 + k * kstride] : 0;
+            }
         }
         else {
             const uint32_t sb = lds_sigma(Ib);

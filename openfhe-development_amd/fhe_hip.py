@@ -84,6 +84,7 @@ class Lib:
         S("fhe_ks_plan_alpha", u32, [vp])
         S("fhe_ks_key_alloc", C.c_int, [vp, C.POINTER(vp)])
         S("fhe_ks_key_upload", C.c_int, [vp, u64p, u64p, C.POINTER(vp)])
+        S("fhe_ks_key_wrap", C.c_int, [vp, vp, vp, C.POINTER(vp)])
         S("fhe_ks_key_destroy", None, [vp])
         S("fhe_ks_key_devptr", vp, [vp, C.c_int])
         S("fhe_ks_key_words", C.c_size_t, [vp])
@@ -319,6 +320,16 @@ class KeySwitchPlan:
         self.ctx.lib.check(self.ctx.lib.L.fhe_ks_key_upload(self.h, keyB.ctypes.data_as(u64p),
                                                             keyA.ctypes.data_as(u64p), C.byref(k)))
         self.key = k
+
+    def wrap_key(self, dev_b, dev_a):
+        """adopt device-resident key vectors (e.g. torch tensors filled by an RCCL broadcast)"""
+        k = vp()
+        self.ctx.lib.check(self.ctx.lib.L.fhe_ks_key_wrap(self.h, vp(dev_b), vp(dev_a), C.byref(k)))
+        self.key = k
+
+    def key_words(self):
+        N = self.ctx.N
+        return self.numPartQ * (self.sizeQ + self.sizeP) * N
 
     def workspace(self, sizeQl, batch):
         need = self.ctx.lib.L.fhe_ks_workspace_bytes(self.h, sizeQl, batch)

@@ -1,0 +1,91 @@
+"""The N>1 path on CPU: world_size 2, gloo backend.  Each rank shards the ciphertext batch, receives the
+evaluation key through the broadcast (the design's only collective) and runs EvalMult + key switching on its
+slice; rank results are gathered and compared bit-for-bit with the oracle on the full batch.
+The ranks use the TEST-ONLY lane-emulator build (CPU tensors are its "device" memory); on GPUs the same code
+runs with backend nccl (= RCCL) and the HIP library."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+import numpy as np
+ROOT = sys.argv[1]; out = sys.argv[2]
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch, torch.distributed as dist
+from openfhe_amd import fhe_hip as fh
+from openfhe_amd import shard
+import libs
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+lib = fh.Lib(os.path.join(ROOT, "tests", "emu", "libfhe_emu.so"))
+o = libs.load_oracle()
+logN, sizeQ, dnum, B = 10, 4, 2, 5
+N = 1 << logN
+q, psiQ = lib.ckks_like_chain(logN, sizeQ, 60, 50)
+p, psiP = lib.select_p(logN, q, dnum)
+allq = np.concatenate([q, p])
+ctx = fh.Context(lib, logN, allq, np.concatenate([psiQ, psiP]))
+plan = fh.KeySwitchPlan(ctx, sizeQ, len(p), dnum)
+rng = np.random.default_rng(99)          # same seed on every rank: the full batch is known everywhere,
+keyB = libs.rand_tower(rng, allq, N, dnum)  # but only rank 0's key copy is used
+keyA = libs.rand_tower(rng, allq, N, dnum)
+ops = [libs.rand_tower(rng, q, N, B) for _ in range(4)]
+keep = shard.broadcast_key(plan, keyB if rank == 0 else None, keyA if rank == 0 else None, "cpu")
+lo, hi = shard.shard_range(B, rank, world)
+mine = [ctx.tower(x[lo:hi]) for x in ops]
+c0, c1 = plan.EvalMult(*mine)
+np.savez(out + f".{rank}.npz", lo=lo, hi=hi, c0=c0.to_host(), c1=c1.to_host())
+dist.barrier()
+if rank == 0:
+    hy = o.orc_hybrid_create(N, sizeQ, q, psiQ, len(p), p, psiP, dnum)
+    w0 = np.empty_like(ops[0]); w1 = np.empty_like(ops[0])
+    for b in range(B):
+        o.orc_ckks_eval_mult_relin(hy, ops[0][b], ops[1][b], ops[2][b], ops[3][b], sizeQ, keyB, keyA, w0[b], w1[b])
+    got0 = np.empty_like(w0); got1 = np.empty_like(w1); covered = np.zeros(B, bool)
+    for r in range(world):
+        z = np.load(out + f".{r}.npz")
+        got0[z["lo"]:z["hi"]] = z["c0"]; got1[z["lo"]:z["hi"]] = z["c1"]; covered[z["lo"]:z["hi"]] = True
+    assert covered.all(), "shards do not cover the batch"
+    assert np.array_equal(got0, w0) and np.array_equal(got1, w1), "sharded EvalMult differs from the oracle"
+    open(out + ".ok", "w").write("ok")
+dist.destroy_process_group()
+'''
+
+
+def test_shard_range_partitions():
+    from openfhe_amd import shard
+    for total in (0, 1, 5, 8, 1024, 1025):
+        for world in (1, 2, 3, 8):
+            spans = [shard.shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_sharded_eval_mult_with_key_broadcast(tmp_path, backend):
+    if "emulator" not in backend.version():
+        import pytest
+        pytest.skip("CPU (gloo) variant only; the GPU variant is bench.py --gpus N")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    worker = tmp_path / "worker.py"
+    worker.write_text(WORKER)
+    out = str(tmp_path / "res")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(worker), ROOT, out], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    assert os.path.exists(out + ".ok"), "\n".join(logs)

@@ -1,0 +1,162 @@
+"""The oracle against the REFERENCE ITSELF (oracle/_ref, compiled from /root/reference by oracle/Makefile) on
+fresh random inputs.  Skipped where the reference build is not available (e.g. a box without /root/reference
+and without a travelled oracle/_ref)."""
+import numpy as np
+import pytest
+
+import libs
+
+
+def test_scalar_ops(oracle, ref):
+    rng = np.random.default_rng(31)
+    for bits in (20, 40, 59, 60):
+        q = oracle.orc_last_prime(bits, 1 << 10)
+        assert q == ref.ref_last_prime(bits, 1 << 10)
+        assert oracle.orc_compute_mu(q) == ref.ref_compute_mu(q)
+        for _ in range(200):
+            a, b = (int(v) for v in rng.integers(0, q, size=2, dtype=np.uint64))
+            pre = oracle.orc_prep_mod_mul_const(b, q)
+            assert pre == ref.ref_prep_mod_mul_const(b, q)
+            assert oracle.orc_mod_mul_fast_const(a, b, q, pre) == ref.ref_mod_mul_fast_const(a, b, q) == a * b % q
+            assert oracle.orc_mod_mul_fast(a, b, q, oracle.orc_compute_mu(q)) == ref.ref_mod_mul_fast(a, b, q)
+            lo, hi = (int(v) for v in rng.integers(0, 1 << 63, size=2, dtype=np.uint64))
+            mu = np.zeros(2, np.uint64)
+            oracle.orc_barrett_mu128(q, mu)
+            assert oracle.orc_barrett128(lo, hi, q, int(mu[0]), int(mu[1])) == ref.ref_barrett128(lo, hi, q) \
+                == ((hi << 64) | lo) % q
+
+
+def test_primes_roots_automaps(oracle, ref):
+    for bits, m in ((28, 16), (50, 1 << 13), (60, 1 << 17)):
+        assert oracle.orc_first_prime(bits, m) == ref.ref_first_prime(bits, m)
+        q = oracle.orc_last_prime(bits, m)
+        assert oracle.orc_previous_prime(q, m) == ref.ref_previous_prime(q, m)
+        assert oracle.orc_next_prime(q - 2 * m if False else oracle.orc_previous_prime(q, m), m) == q
+        assert oracle.orc_root_of_unity(m, q) == ref.ref_root_of_unity(m, q)
+    for n, k in ((8, 3), (64, 5), (4096, 2 * 4096 - 1), (4096, 3125)):
+        a = np.zeros(n, np.uint32)
+        b = np.zeros(n, np.uint32)
+        oracle.orc_precompute_auto_map(n, k, a)
+        ref.ref_precompute_auto_map(n, k, b)
+        assert np.array_equal(a, b)
+    for i in (1, 7, -3, 100):
+        assert oracle.orc_find_automorphism_index_2n_complex(i, 1 << 13) == ref.ref_find_automorphism_index_2n_complex(i, 1 << 13)
+
+
+@pytest.mark.parametrize("logN,L", [(3, 2), (4, 1), (8, 2), (12, 2)])
+def test_tower_switch_format_and_arith(oracle, ref, logN, L):
+    o, r = oracle, ref
+    N = 1 << logN
+    rng = np.random.default_rng(32)
+    q = np.zeros(L, np.uint64)
+    psi = np.zeros(L, np.uint64)
+    o.orc_dcrt_params(2 * N, L, 60 if logN > 4 else 28, q, psi)
+    x = libs.rand_tower(rng, q, N, 2)
+    y = libs.rand_tower(rng, q, N, 2)
+    octx = o.orc_ctx_create(N, L, q, psi)
+    h = r.ref_towers_create(N, L, q, psi, x, 2, 0)
+    g = r.ref_towers_create(N, L, q, psi, y, 2, 1)
+    r.ref_towers_switch_format(h)  # COEFF -> EVAL
+    want = np.zeros_like(x)
+    r.ref_towers_export(h, want)
+    got = x.copy()
+    o.orc_ntt_fwd_tower(octx, got, None, L, 2, 0)
+    assert np.array_equal(got, want)
+    r.ref_towers_mul_eq(h, g)
+    r.ref_towers_export(h, want)
+    prod = np.zeros_like(x)
+    for b in range(2):
+        for l in range(L):
+            o.orc_vec_mul(prod[b, l], got[b, l], y[b, l], N, q[l])
+    assert np.array_equal(prod, want)
+    r.ref_towers_switch_format(h)  # EVAL -> COEFF
+    r.ref_towers_export(h, want)
+    o.orc_ntt_inv_tower(octx, prod, None, L, 2, 0)
+    assert np.array_equal(prod, want)
+    r.ref_towers_destroy(h)
+    r.ref_towers_destroy(g)
+    o.orc_ctx_destroy(octx)
+
+
+def test_automorphism_and_switch_modulus(oracle, ref):
+    o, r = oracle, ref
+    rng = np.random.default_rng(33)
+    N, L = 64, 2
+    q = np.zeros(L, np.uint64)
+    psi = np.zeros(L, np.uint64)
+    o.orc_dcrt_params(2 * N, L, 50, q, psi)
+    x = libs.rand_tower(rng, q, N)
+    x[:, 5] = 0
+    for k in (3, 5, 127):
+        for evalfmt in (1, 0):
+            want = np.zeros_like(x)
+            r.ref_automorph(N, L, q, psi, x, want, k, evalfmt, 0)
+            got = np.zeros_like(x)
+            for l in range(L):
+                if evalfmt:
+                    o.orc_automorph_eval_k(got[l], x[l], N, k)
+                else:
+                    o.orc_automorph_coeff(got[l], x[l], N, k, q[l])
+            assert np.array_equal(got, want)
+            if evalfmt:
+                r.ref_automorph(N, L, q, psi, x, want, k, 1, 1)  # precomputed-table overload
+                pre = np.zeros(N, np.uint32)
+                o.orc_precompute_auto_map(N, k, pre)
+                for l in range(L):
+                    o.orc_automorph_eval(got[l], x[l], N, pre)
+                assert np.array_equal(got, want)
+    for oldq, newq in ((int(q[0]), int(q[1])), (int(q[1]), int(q[0])), (int(q[0]), 65537), (65537, int(q[0]))):
+        v = rng.integers(0, oldq, size=257, dtype=np.uint64)
+        v[0], v[1], v[2] = 0, oldq - 1, oldq // 2
+        a, b = v.copy(), v.copy()
+        o.orc_switch_modulus(a, len(a), oldq, newq)
+        r.ref_switch_modulus(b, len(b), oldq, newq)
+        assert np.array_equal(a, b)
+
+
+def test_ckks_eval_mult_keyswitch_against_live_reference(oracle, ref):
+    """fresh context + keys from the reference's own KeyGen; the oracle must reproduce EvalMult limb values"""
+    o, r = oracle, ref
+    h = r.ref_ckks_create(1 << 10, 5, 45, 55, 3, 0)
+    info = np.zeros(5, np.uint32)
+    r.ref_ckks_info(h, info)
+    N, sizeQ, sizeP, numPartQ, alpha = map(int, info)
+    q, psiQ = np.zeros(sizeQ, np.uint64), np.zeros(sizeQ, np.uint64)
+    p, psiP = np.zeros(sizeP, np.uint64), np.zeros(sizeP, np.uint64)
+    r.ref_ckks_get_moduli(h, q, psiQ, p, psiP)
+    hy = o.orc_hybrid_create(N, sizeQ, q, psiQ, sizeP, p, psiP, numPartQ)
+    A, B, Cc = np.zeros(sizeQ, np.uint64), np.zeros(sizeP, np.uint64), np.zeros((sizeP, sizeQ), np.uint64)
+    r.ref_ckks_get_tables(h, A, B, Cc)
+    A2, B2, C2 = A.copy(), B.copy(), Cc.copy()
+    o.orc_hybrid_get_PInvModq(hy, A2)
+    o.orc_hybrid_get_PHatInvModp(hy, B2)
+    o.orc_hybrid_get_PHatModq(hy, C2)
+    assert np.array_equal(A, A2) and np.array_equal(B, B2) and np.array_equal(Cc, C2)
+    keyB = np.zeros((numPartQ, sizeQ + sizeP, N), np.uint64)
+    keyA = keyB.copy()
+    r.ref_ckks_get_relin_key(h, keyB, keyA)
+    c1, c2 = r.ref_ckks_encrypt(h, 5, 1), r.ref_ckks_encrypt(h, 6, 1)
+    ci = np.zeros(4, np.uint32)
+    r.ref_ct_info(h, c1, ci)
+    sizeQl = int(ci[1])
+
+    def ex(ct, e, L=sizeQl):
+        a = np.zeros((L, N), np.uint64)
+        r.ref_ct_export(h, ct, e, a)
+        return a
+    cm = r.ref_ckks_eval_mult(h, c1, c2)
+    o0, o1 = np.zeros((sizeQl, N), np.uint64), np.zeros((sizeQl, N), np.uint64)
+    o.orc_ckks_eval_mult_relin(hy, ex(c1, 0), ex(c1, 1), ex(c2, 0), ex(c2, 1), sizeQl, keyB, keyA, o0, o1)
+    assert np.array_equal(o0, ex(cm, 0)) and np.array_equal(o1, ex(cm, 1))
+    rs = r.ref_ckks_rescale(h, cm)
+    octx = o.orc_ctx_create(N, sizeQ, q, psiQ)
+    f = np.zeros((sizeQl - 1, N), np.uint64)
+    o.orc_drop_last_element_and_scale(octx, o0, sizeQl, f)
+    assert np.array_equal(f, ex(rs, 0, sizeQl - 1))
+    # sanity: the reference decrypts its own product to (approximately) the product of the messages
+    vals = np.zeros(4, np.float64)
+    r.ref_ckks_decrypt(h, cm, vals, 4)
+    assert np.all(np.isfinite(vals))
+    o.orc_ctx_destroy(octx)
+    o.orc_hybrid_destroy(hy)
+    r.ref_ckks_destroy(h)

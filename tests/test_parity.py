@@ -256,7 +256,7 @@ def ckks_like_params(o, logN, sizeQ, dnum, first_bits=60, scale_bits=50, aux_bit
     return q, psiQ, p[:sizeP].copy(), psiP[:sizeP].copy()
 
 
-@pytest.mark.parametrize("logN,sizeQ,dnum,sizeQl,B", [(12, 6, 3, 6, 2), (12, 7, 2, 5, 1), (12, 5, 3, 2, 1), (13, 4, 2, 4, 1)])
+@pytest.mark.parametrize("logN,sizeQ,dnum,sizeQl,B", [(10, 4, 2, 4, 3), (8, 5, 2, 3, 2), (12, 6, 3, 6, 2), (12, 7, 2, 5, 1), (12, 5, 3, 2, 1), (13, 4, 2, 4, 1)])
 def test_hybrid_keyswitch_and_eval_mult(backend, oracle, logN, sizeQ, dnum, sizeQl, B):
     o = oracle
     if is_emu(backend) and logN > 12:
@@ -302,7 +302,7 @@ def test_hybrid_keyswitch_and_eval_mult(backend, oracle, logN, sizeQ, dnum, size
 def test_rescale(backend, oracle):
     o = oracle
     rng = np.random.default_rng(17)
-    for logN, sizeQl, B in [(6, 3, 2), (12, 4, 2), (13, 3, 1)]:
+    for logN, sizeQl, B in [(6, 3, 2), (9, 5, 3), (12, 4, 2), (13, 3, 1)]:
         N = 1 << logN
         q, psiQ, _, _ = ckks_like_params(o, logN, sizeQl + 1, 2)
         ctx = fh.Context(backend, logN, q, psiQ)
