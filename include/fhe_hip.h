@@ -194,6 +194,48 @@ size_t     fhe_rescale_workspace_bytes(const fhe_ctx* ctx, uint32_t sizeQl, uint
 fhe_status fhe_rescale(fhe_ctx* ctx, const uint64_t* x, uint32_t sizeQl, uint32_t batch, uint64_t* out, void* ws,
                        size_t wsBytes, void* stream);
 
+/* ---- a17: ScaleAndRound family (BFV HPS) ----------------------------------------------------------------
+ * fhe_sr_plan_create keeps the caller's tables on the device. They are the reference's own
+ * (CryptoParametersBFVRNS getters, e.g. GettRSHatInvModsDivsModr / GettRSHatInvModsDivsFrac,
+ * src/pke/include/schemerns/rns-cryptoparameters.h:829-848): tab is [sizeO][sizeI+1] exactly as the reference
+ * indexes it, frac is [sizeI] (NULL selects ApproxScaleAndRound, which has no fractional part).
+ * fhe_scale_and_round replaces DCRTPolyImpl::ScaleAndRound (dcrtpoly-impl.h:1513-1628) / ApproxScaleAndRound
+ * (:1470-1510): x is [batch][sizeI+sizeO][N] COEFFICIENT; outputFirst != 0 means the output basis is the FIRST
+ * sizeO limbs of x (the reference decides this by comparing the first moduli, :1527-1534), else the LAST sizeO.
+ * out is [batch][sizeO][N].
+ * fhe_scale_and_round_p_over_q replaces ScaleAndRoundPOverQ (:1674-1689): x [batch][sizeQ+1][N] over the context
+ * limbs limbIdx[0..sizeQ] -> out [batch][sizeQ][N]. */
+typedef struct fhe_sr_plan fhe_sr_plan;
+fhe_status fhe_sr_plan_create(fhe_ctx* ctx, uint32_t sizeI, const uint32_t* outLimbIdx, uint32_t sizeO,
+                              const uint64_t* tab, const double* frac, fhe_sr_plan** out);
+void       fhe_sr_plan_destroy(fhe_sr_plan* plan);
+fhe_status fhe_scale_and_round(fhe_sr_plan* plan, const uint64_t* x, int outputFirst, uint64_t* out, uint32_t batch,
+                               void* stream);
+fhe_status fhe_scale_and_round_p_over_q(fhe_ctx* ctx, const uint64_t* x, const uint32_t* limbIdx, uint32_t sizeQ,
+                                        uint64_t* out, uint32_t batch, void* stream);
+
+/* ---- a18: BEHZ base conversions (BFV) ---------------------------------------------------------------------
+ * fhe_behz_create builds the tables of CryptoParametersBFVRNS's BEHZ block
+ * (src/pke/lib/scheme/bfvrns/bfvrns-cryptoparameters.cpp:673-850) for the basis Q (context limbs qLimbIdx) and
+ * Bsk = B ∪ {m_sk} (context limbs bskLimbIdx, numQ+1 of them, m_sk last), plaintext modulus t, m̃ = 2^16.
+ * fhe_param_behz_bsk returns the Bsk moduli/roots the reference would pick (:682-711) so that a caller can put them
+ * into the context; it returns numQ+1, or 0 if m_sk would need more than 60 bits.
+ * Towers are x[batch][numQ+numBsk][N].
+ *   fhe_behz_q_to_bsk  = FastBaseConvqToBskMontgomery (dcrtpoly-impl.h:1694-1786): Q rows in `evalFormat` on entry,
+ *                        all rows EVALUATION on return (ws: fhe_behz_workspace_bytes, only needed for EVALUATION input);
+ *   fhe_behz_floorq    = FastRNSFloorq (:1791-1840), COEFFICIENT, in place;
+ *   fhe_behz_conv_sk   = FastBaseConvSK (:1845-1929), COEFFICIENT, result out[batch][numQ][N]. */
+typedef struct fhe_behz fhe_behz;
+uint32_t   fhe_param_behz_bsk(uint32_t logN, uint32_t numQ, const uint64_t* q, uint64_t t, uint64_t* bsk, uint64_t* psiBsk);
+fhe_status fhe_behz_create(fhe_ctx* ctx, const uint32_t* qLimbIdx, uint32_t numQ, const uint32_t* bskLimbIdx, uint64_t t,
+                           fhe_behz** out);
+void       fhe_behz_destroy(fhe_behz* plan);
+size_t     fhe_behz_workspace_bytes(const fhe_behz* plan, uint32_t batch);
+fhe_status fhe_behz_q_to_bsk(fhe_behz* plan, uint64_t* x, int evalFormat, uint32_t batch, void* ws, size_t wsBytes,
+                             void* stream);
+fhe_status fhe_behz_floorq(fhe_behz* plan, uint64_t* x, uint32_t batch, void* stream);
+fhe_status fhe_behz_conv_sk(fhe_behz* plan, const uint64_t* x, uint64_t* out, uint32_t batch, void* stream);
+
 /* ---- host-side parameter helpers (no device work) -------------------------------------------------
  * Number theory the reference uses to pick moduli and roots, restated with 64-bit arithmetic so that a
  * caller can reproduce the reference's (N, q_i, psi_i) without linking OpenFHE:

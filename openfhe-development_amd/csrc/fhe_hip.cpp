@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "basis_kernels.h"
+#include "bfv_kernels.h"
 #include "elemwise_kernels.h"
 #include "host_math.h"
 #include "ntt_kernels.h"
@@ -214,6 +215,7 @@ extern "C" uint32_t fhe_param_select_p(uint32_t logN, uint32_t sizeQ, const uint
 
 static uint32_t env_u32(const char* name, uint32_t dflt);
 static bool ntt_generic();
+static uint32_t ntt_stagger();
 
 // ------------------------------------------------------------------------------------------------
 // context
@@ -466,9 +468,12 @@ static void mark_uniform(PassPlan& pp, uint32_t logN) {
 
 static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse, const uint64_t* xin, uint64_t* xout,
                               const LimbSel& sel, uint32_t nLimbs, uint32_t batch, bool canonOut, void* stream,
-                              uint32_t inStride = 0, uint32_t inFirst = 0) {
+                              uint32_t inStride = 0, uint32_t inFirst = 0, uint32_t outStride = 0, uint32_t outFirst = 0) {
     NttPassArgs a;
+    a.outStride = outStride;
+    a.outFirst  = outFirst;
     a.inStride = inStride;
+    a.stagger  = ntt_stagger();
     a.inFirst  = inFirst;
     a.xin      = xin;
     a.x        = xout;
@@ -496,7 +501,7 @@ static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse
     const uint32_t grid        = tiles_for(c, a.rows);
     const uint32_t tilesPerRow = c->N >= (uint32_t)kTile ? (c->N >> kTileLog) : 1u;
     a.xcdSwizzle = (c->N >= (uint32_t)kTile && ((nLimbs * tilesPerRow) % 8u == 0)) ? 1u : 0u;
-    if (c->logN >= (uint32_t)kTileLog && !ntt_generic()) {
+    if (c->logN >= (uint32_t)kTileLog && !ntt_generic() && outStride == 0) {
         // fast path: persistent workgroups, a multiple of 8 so that the XCD a workgroup runs on (blockIdx % 8)
         // stays the XCD of every tile it walks
         uint32_t pgrid = std::min(grid, c->persistentGrid);
@@ -552,14 +557,20 @@ static bool ntt_generic() {
     static const uint32_t v = env_u32("FHE_NTT_FAST", 0);
     return v == 0;
 }
+static uint32_t ntt_stagger() {
+    static const uint32_t v = env_u32("FHE_NTT_STAGGER", 0);
+    return v;
+}
 static uint32_t ntt_chunk() {
     static const uint32_t v = env_u32("FHE_NTT_CHUNK", 0);
     return v;
 }
 
 // inStride != 0: xin is a [batch][inStride][N] view whose rows inFirst.. are transformed into the dense xout
+// outStride != 0: xout is a [batch][outStride][N] view as well (rows outFirst..)
 static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_t* xout, const uint32_t* limbIdx,
-                          uint32_t nLimbs, uint32_t batch, void* stream, uint32_t inStride = 0, uint32_t inFirst = 0) {
+                          uint32_t nLimbs, uint32_t batch, void* stream, uint32_t inStride = 0, uint32_t inFirst = 0,
+                          uint32_t outStride = 0, uint32_t outFirst = 0) {
     ARG_CHECK(c && xin && xout, "fhe_ntt: null argument");
     ARG_CHECK(batch >= 1, "fhe_ntt: batch must be >= 1");
     LimbSel sel;
@@ -575,7 +586,7 @@ static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_
         if (!inverse)
             schedule_fwd(p, logN, &bound);
         p.outBound = bound;
-        return launch_pass(c, p, inverse, xin, xout, sel, nLimbs, batch, true, stream, inStride, inFirst);
+        return launch_pass(c, p, inverse, xin, xout, sel, nLimbs, batch, true, stream, inStride, inFirst, outStride, outFirst);
     }
     // two passes over HBM: a strided column pass of T1 stages (the coefficient index's top bits) and a
     // contiguous row pass of T2 = logN - T1 stages.  T1 is kept minimal (>= 4) so that the column pass reads
@@ -598,12 +609,12 @@ static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_
     for (uint32_t b0 = 0; b0 < batch; b0 += chunk) {
         const uint32_t nb   = std::min(chunk, batch - b0);
         const uint64_t* in  = xin + (inStride ? ((size_t)b0 * inStride << logN) : ((size_t)b0 * nLimbs << logN));
-        uint64_t* out       = xout + ((size_t)b0 * nLimbs << logN);
+        uint64_t* out       = xout + (outStride ? ((size_t)b0 * outStride << logN) : ((size_t)b0 * nLimbs << logN));
         const PassPlan& p1  = inverse ? pb : pa;
         const PassPlan& p2  = inverse ? pa : pb;
-        if (fhe_status s = launch_pass(c, p1, inverse, in, out, sel, nLimbs, nb, false, stream, inStride, inFirst))
+        if (fhe_status s = launch_pass(c, p1, inverse, in, out, sel, nLimbs, nb, false, stream, inStride, inFirst, outStride, outFirst))
             return s;
-        if (fhe_status s = launch_pass(c, p2, inverse, out, out, sel, nLimbs, nb, true, stream))
+        if (fhe_status s = launch_pass(c, p2, inverse, out, out, sel, nLimbs, nb, true, stream, outStride, outFirst, outStride, outFirst))
             return s;
     }
     return FHE_OK;
@@ -1298,4 +1309,331 @@ extern "C" fhe_status fhe_rescale(fhe_ctx* c, const uint64_t* x, uint32_t sizeQl
         return s;
     // m_vectors[i] = m_vectors[i] * qlInvModq[i] + tmp  (:708-709); x towers are sizeQl rows apart
     return elem_run<OP_MUL_CONST_ADD>(c, out, x, tmp, dB, nullptr, l, batch, st, "fhe_rescale", sizeQl, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// BFV side: ScaleAndRound family and BEHZ
+// ------------------------------------------------------------------------------------------------
+struct fhe_sr_plan {
+    fhe_ctx* ctx;
+    uint32_t sizeI, sizeO;
+    bool exact;
+    uint64_t *d_tab = nullptr, *d_o = nullptr, *d_mu = nullptr;
+    double* d_frac  = nullptr;
+    std::vector<void*> owned;
+};
+template <typename T>
+static fhe_status dev_copy(std::vector<void*>& owned, const T* h, size_t n, T** d) {
+    void* p = nullptr;
+    RT_CHECK(rt::dmalloc(&p, n * sizeof(T)));
+    owned.push_back(p);
+    RT_CHECK(rt::h2d(p, h, n * sizeof(T), nullptr));
+    RT_CHECK(rt::sync(nullptr));
+    *d = (T*)p;
+    return FHE_OK;
+}
+extern "C" fhe_status fhe_sr_plan_create(fhe_ctx* c, uint32_t sizeI, const uint32_t* outLimbIdx, uint32_t sizeO,
+                                         const uint64_t* tab, const double* frac, fhe_sr_plan** out) {
+    ARG_CHECK(c && outLimbIdx && tab && out, "fhe_sr_plan_create: null argument");
+    ARG_CHECK(sizeI >= 1 && sizeO >= 1 && sizeI <= 64 && sizeO <= 64, "fhe_sr_plan_create: bad basis size");
+    RT_CHECK(rt::set_device(c->device));
+    std::vector<uint64_t> o(sizeO), mu(2 * (size_t)sizeO);
+    for (uint32_t j = 0; j < sizeO; ++j) {
+        ARG_CHECK(outLimbIdx[j] < c->L, "fhe_sr_plan_create: limb index exceeds context size");
+        o[j] = c->q[outLimbIdx[j]];
+        host::mu128(o[j], &mu[2 * j]);
+    }
+    fhe_sr_plan* p = new fhe_sr_plan;
+    p->ctx = c, p->sizeI = sizeI, p->sizeO = sizeO, p->exact = frac != nullptr;
+    fhe_status s;
+    if ((s = dev_copy(p->owned, tab, (size_t)sizeO * (sizeI + 1), &p->d_tab)) || (s = dev_copy(p->owned, o.data(), o.size(), &p->d_o)) ||
+        (s = dev_copy(p->owned, mu.data(), mu.size(), &p->d_mu)) || (frac && (s = dev_copy(p->owned, frac, sizeI, &p->d_frac)))) {
+        fhe_sr_plan_destroy(p);
+        return s;
+    }
+    *out = p;
+    return FHE_OK;
+}
+extern "C" void fhe_sr_plan_destroy(fhe_sr_plan* p) {
+    if (!p)
+        return;
+    for (void* q : p->owned)
+        rt::dfree(q);
+    delete p;
+}
+extern "C" fhe_status fhe_scale_and_round(fhe_sr_plan* p, const uint64_t* x, int outputFirst, uint64_t* out, uint32_t batch,
+                                          void* st) {
+    ARG_CHECK(p && x && out && batch >= 1, "fhe_scale_and_round: bad argument");
+    RT_CHECK(rt::set_device(p->ctx->device));
+    ScaleRoundArgs g;
+    const uint32_t tot = p->sizeI + p->sizeO;
+    uint64_t* xm       = const_cast<uint64_t*>(x);
+    g.in  = TowerView{xm, tot, outputFirst ? p->sizeO : 0u};   // inputIndex  (:1527-1534)
+    g.own = TowerView{xm, tot, outputFirst ? 0u : p->sizeI};   // outputIndex
+    g.out = TowerView{out, p->sizeO, 0};
+    g.tab = p->d_tab, g.frac = p->d_frac, g.o = p->d_o, g.mu = p->d_mu;
+    g.logN = p->ctx->logN, g.batch = batch, g.sizeI = p->sizeI, g.sizeO = p->sizeO;
+    const uint32_t grid = (uint32_t)((((uint64_t)batch << g.logN) + kThreads - 1) / kThreads);
+    if (p->exact)
+        FHE_LAUNCH((scale_round_kernel<true>), grid, st, g);
+    else
+        FHE_LAUNCH((scale_round_kernel<false>), grid, st, g);
+    LAUNCH_CHECK();
+    return FHE_OK;
+}
+extern "C" fhe_status fhe_scale_and_round_p_over_q(fhe_ctx* c, const uint64_t* x, const uint32_t* limbIdx, uint32_t sizeQ,
+                                                   uint64_t* out, uint32_t batch, void* st) {
+    ARG_CHECK(c && x && limbIdx && out && batch >= 1 && sizeQ >= 1 && sizeQ < (uint32_t)kMaxLimbs,
+              "fhe_scale_and_round_p_over_q: bad argument");
+    for (uint32_t i = 0; i <= sizeQ; ++i)
+        ARG_CHECK(limbIdx[i] < c->L, "fhe_scale_and_round_p_over_q: limb index exceeds context size");
+    RT_CHECK(rt::set_device(c->device));
+    const uint64_t pLast = c->q[limbIdx[sizeQ]];
+    std::vector<uint64_t> q(sizeQ), pinv(sizeQ);
+    for (uint32_t i = 0; i < sizeQ; ++i) {
+        q[i]    = c->q[limbIdx[i]];
+        pinv[i] = host::invmod(pLast % q[i], q[i]);  // pInvModq
+    }
+    TwPair* dInv = nullptr;
+    if (fhe_status s = consts_to_device(c, pinv.data(), limbIdx, sizeQ, st, &dInv))
+        return s;
+    // moduli go through the same ring (as raw words in the .w field of a second slot)
+    std::vector<uint64_t> qraw(q);
+    TwPair* dQ = nullptr;
+    {
+        std::vector<TwPair> h(sizeQ);
+        for (uint32_t i = 0; i < sizeQ; ++i)
+            h[i] = TwPair{q[i], 0};
+        TwPair* slot    = c->d_constRing + (size_t)(c->constRingPos % kConstRingSlots) * kMaxLimbs;
+        c->constRingPos = c->constRingPos + 1;
+        RT_CHECK(rt::h2d(slot, h.data(), sizeQ * sizeof(TwPair), (rt::stream_t)st));
+        RT_CHECK(rt::sync((rt::stream_t)st));
+        dQ = slot;
+    }
+    POverQArgs g;
+    g.x = TowerView{const_cast<uint64_t*>(x), sizeQ + 1, 0}, g.out = TowerView{out, sizeQ, 0};
+    g.q = nullptr, g.pInv = dInv, g.pLast = pLast, g.logN = c->logN, g.batch = batch, g.sizeQ = sizeQ;
+    g.qPairs = dQ;
+    FHE_LAUNCH(p_over_q_kernel, (uint32_t)((((uint64_t)batch << g.logN) + kThreads - 1) / kThreads), st, g);
+    LAUNCH_CHECK();
+    return FHE_OK;
+}
+
+// ---- BEHZ ----
+struct fhe_behz {
+    fhe_ctx* ctx;
+    uint32_t numQ, numBsk;
+    std::vector<uint32_t> qIdx, bskIdx, allIdx;
+    BehzTables tb;
+    std::vector<void*> owned;
+};
+// Bsk = numQ primes below q.back() then m_sk  (bfvrns-cryptoparameters.cpp:682-711)
+extern "C" uint32_t fhe_param_behz_bsk(uint32_t logN, uint32_t numQ, const uint64_t* q, uint64_t t, uint64_t* bsk,
+                                       uint64_t* psiBsk) {
+    if (!q || !bsk || !psiBsk || numQ < 1 || numQ > (uint32_t)kMaxBfvLimbs - 1)
+        return 0;
+    const uint64_t M = 2ull << logN;
+    uint64_t cur     = q[numQ - 1];
+    for (uint32_t i = 0; i < numQ; ++i) {
+        cur    = host::previous_prime(cur, M);
+        bsk[i] = cur;
+    }
+    uint64_t msk = host::previous_prime(bsk[numQ - 1], M);
+    uint32_t sb  = host::bitlen(msk);
+    auto mulw = [](std::vector<uint64_t>& big, uint64_t m) {
+        uint64_t carry = 0;
+        for (auto& w : big) {
+            host::u128 tt = (host::u128)w * m + carry;
+            w             = (uint64_t)tt;
+            carry         = (uint64_t)(tt >> 64);
+        }
+        if (carry)
+            big.push_back(carry);
+    };
+    auto less = [](const std::vector<uint64_t>& a, const std::vector<uint64_t>& b) {
+        if (a.size() != b.size())
+            return a.size() < b.size();
+        for (size_t k = a.size(); k-- > 0;)
+            if (a[k] != b[k])
+                return a[k] < b[k];
+        return false;
+    };
+    std::vector<uint64_t> rhs(1, 1);
+    mulw(rhs, M);
+    mulw(rhs, t);
+    for (uint32_t i = 0; i < numQ; ++i)
+        mulw(rhs, q[i]);
+    for (;;) {
+        std::vector<uint64_t> lhs(1, 1);
+        for (uint32_t i = 0; i < numQ; ++i)
+            mulw(lhs, bsk[i]);
+        mulw(lhs, msk);
+        if (!less(lhs, rhs))
+            break;
+        if (++sb > 60)
+            return 0;  // the reference throws: requested bit length exceeds MAX_MODULUS_SIZE
+        msk = host::next_prime(host::first_prime(sb, M), M);
+    }
+    bsk[numQ] = msk;
+    for (uint32_t i = 0; i <= numQ; ++i)
+        psiBsk[i] = host::min_root_of_unity(M, bsk[i]);
+    return numQ + 1;
+}
+
+extern "C" fhe_status fhe_behz_create(fhe_ctx* c, const uint32_t* qLimbIdx, uint32_t numQ, const uint32_t* bskLimbIdx,
+                                      uint64_t t, fhe_behz** out) {
+    ARG_CHECK(c && qLimbIdx && bskLimbIdx && out, "fhe_behz_create: null argument");
+    ARG_CHECK(numQ >= 1 && numQ + 1 <= (uint32_t)kMaxBfvLimbs, "fhe_behz_create: at most 15 Q limbs supported");
+    const uint32_t numB = numQ, numBsk = numQ + 1;
+    std::vector<uint64_t> q(numQ), bsk(numBsk);
+    for (uint32_t i = 0; i < numQ; ++i) {
+        ARG_CHECK(qLimbIdx[i] < c->L, "fhe_behz_create: limb index exceeds context size");
+        q[i] = c->q[qLimbIdx[i]];
+    }
+    for (uint32_t j = 0; j < numBsk; ++j) {
+        ARG_CHECK(bskLimbIdx[j] < c->L, "fhe_behz_create: limb index exceeds context size");
+        bsk[j] = c->q[bskLimbIdx[j]];
+    }
+    RT_CHECK(rt::set_device(c->device));
+    const uint64_t mtilde = 1ull << 16, msk = bsk[numB];
+    std::vector<uint64_t> B(bsk.begin(), bsk.begin() + numB);
+    std::vector<uint64_t> muQ(2 * (size_t)numQ), muBsk(2 * (size_t)numBsk), QHatModbsk((size_t)numQ * numBsk), QHatModmt(numQ),
+        qInvModbsk((size_t)numQ * numBsk), BHatModmsk(numB), BHatModq((size_t)numB * numQ);
+    std::vector<TwPair> mtQHatInv(numQ), tQHatInv(numQ), BModq(numQ), QModbsk(numBsk), mtInvModbsk(numBsk), tQInvModbsk(numBsk),
+        BHatInv(numB);
+    auto pair = [](uint64_t v, uint64_t m) { return TwPair{v, host::shoup(v, m)}; };
+    for (uint32_t i = 0; i < numQ; ++i) {
+        const uint64_t qi = q[i], hatInv = host::invmod(host::prod_mod(q, (int)i, qi), qi);
+        tQHatInv[i]  = pair(host::mulmod(hatInv, t % qi, qi), qi);        // :722-733
+        mtQHatInv[i] = pair(host::mulmod(hatInv, mtilde % qi, qi), qi);   // :755-768
+        for (uint32_t j = 0; j < numBsk; ++j) {
+            QHatModbsk[(size_t)i * numBsk + j] = host::prod_mod(q, (int)i, bsk[j]);         // :735-747
+            qInvModbsk[(size_t)i * numBsk + j] = host::invmod(qi % bsk[j], bsk[j]);          // :749-755
+        }
+        uint64_t v = 1;
+        for (uint32_t k = 0; k < numQ; ++k)
+            if (k != i)
+                v = (v * (q[k] & (mtilde - 1))) & (mtilde - 1);
+        QHatModmt[i] = v;
+        BModq[i]     = pair(host::prod_mod(B, -1, qi), qi);                // :838-845
+        host::mu128(qi, &muQ[2 * i]);
+    }
+    uint64_t Qm = 1;
+    for (uint32_t k = 0; k < numQ; ++k)
+        Qm = (Qm * (q[k] & (mtilde - 1))) & (mtilde - 1);
+    uint64_t inv = 1;
+    for (int it = 0; it < 5; ++it)
+        inv = (inv * (2 - Qm * inv)) & (mtilde - 1);
+    for (uint32_t j = 0; j < numBsk; ++j) {
+        const uint64_t bj = bsk[j], Qb = host::prod_mod(q, -1, bj);
+        QModbsk[j]     = pair(Qb, bj);                                                        // :775-783
+        mtInvModbsk[j] = pair(host::invmod(mtilde % bj, bj), bj);                              // :785-793
+        tQInvModbsk[j] = pair(host::mulmod(host::invmod(Qb, bj), t % bj, bj), bj);             // :795-804
+        host::mu128(bj, &muBsk[2 * j]);
+    }
+    for (uint32_t i = 0; i < numB; ++i) {
+        BHatInv[i]    = pair(host::invmod(host::prod_mod(B, (int)i, B[i]), B[i]), B[i]);       // :806-817
+        BHatModmsk[i] = host::prod_mod(B, (int)i, msk);                                      // :829-834
+        for (uint32_t j = 0; j < numQ; ++j)
+            BHatModq[(size_t)i * numQ + j] = host::prod_mod(B, (int)i, q[j]);                 // :819-827
+    }
+    fhe_behz* h = new fhe_behz;
+    h->ctx = c, h->numQ = numQ, h->numBsk = numBsk;
+    h->qIdx.assign(qLimbIdx, qLimbIdx + numQ);
+    h->bskIdx.assign(bskLimbIdx, bskLimbIdx + numBsk);
+    h->allIdx = h->qIdx;
+    h->allIdx.insert(h->allIdx.end(), h->bskIdx.begin(), h->bskIdx.end());
+    BehzTables& tb = h->tb;
+    tb.numQ = numQ, tb.numBsk = numBsk;
+    tb.negQInvModmt = ((mtilde - 1) * inv) & (mtilde - 1);                                    // :770-773
+    tb.BInvModmsk   = pair(host::invmod(host::prod_mod(B, -1, msk), msk), msk);              // :836-837
+    tb.mskMu        = host::barrett_mu(msk);
+    tb.mskMsb       = host::bitlen(msk);
+    fhe_status s;
+    uint64_t *dq, *dbsk, *dmuQ, *dmuB, *d1, *d2, *d3, *d4, *d5;
+    TwPair *p1, *p2, *p3, *p4, *p5, *p6, *p7;
+    if ((s = dev_copy(h->owned, q.data(), q.size(), &dq)) || (s = dev_copy(h->owned, bsk.data(), bsk.size(), &dbsk)) ||
+        (s = dev_copy(h->owned, muQ.data(), muQ.size(), &dmuQ)) || (s = dev_copy(h->owned, muBsk.data(), muBsk.size(), &dmuB)) ||
+        (s = dev_copy(h->owned, QHatModbsk.data(), QHatModbsk.size(), &d1)) || (s = dev_copy(h->owned, QHatModmt.data(), QHatModmt.size(), &d2)) ||
+        (s = dev_copy(h->owned, qInvModbsk.data(), qInvModbsk.size(), &d3)) || (s = dev_copy(h->owned, BHatModmsk.data(), BHatModmsk.size(), &d4)) ||
+        (s = dev_copy(h->owned, BHatModq.data(), BHatModq.size(), &d5)) || (s = dev_copy(h->owned, mtQHatInv.data(), mtQHatInv.size(), &p1)) ||
+        (s = dev_copy(h->owned, tQHatInv.data(), tQHatInv.size(), &p2)) || (s = dev_copy(h->owned, BModq.data(), BModq.size(), &p3)) ||
+        (s = dev_copy(h->owned, QModbsk.data(), QModbsk.size(), &p4)) || (s = dev_copy(h->owned, mtInvModbsk.data(), mtInvModbsk.size(), &p5)) ||
+        (s = dev_copy(h->owned, tQInvModbsk.data(), tQInvModbsk.size(), &p6)) || (s = dev_copy(h->owned, BHatInv.data(), BHatInv.size(), &p7))) {
+        fhe_behz_destroy(h);
+        return s;
+    }
+    tb.q = dq, tb.bsk = dbsk, tb.muQ = dmuQ, tb.muBsk = dmuB, tb.QHatModbsk = d1, tb.QHatModmt = d2, tb.qInvModbsk = d3;
+    tb.BHatModmsk = d4, tb.BHatModq = d5, tb.mtQHatInv = p1, tb.tQHatInv = p2, tb.BModq = p3, tb.QModbsk = p4;
+    tb.mtInvModbsk = p5, tb.tQInvModbsk = p6, tb.BHatInv = p7;
+    *out = h;
+    return FHE_OK;
+}
+extern "C" void fhe_behz_destroy(fhe_behz* h) {
+    if (!h)
+        return;
+    for (void* p : h->owned)
+        rt::dfree(p);
+    delete h;
+}
+static uint32_t coeff_grid(const fhe_ctx* c, uint32_t batch) {
+    return (uint32_t)((((uint64_t)batch << c->logN) + kThreads - 1) / kThreads);
+}
+extern "C" size_t fhe_behz_workspace_bytes(const fhe_behz* h, uint32_t batch) {
+    return h ? ((size_t)batch * h->numQ << h->ctx->logN) * 8 : 0;
+}
+// DCRTPolyImpl::FastBaseConvqToBskMontgomery (dcrtpoly-impl.h:1694-1786): x is [batch][numQ+numBsk][N]; on entry its
+// first numQ rows hold the input in `evalFormat`; on return ALL rows are in EVALUATION format
+extern "C" fhe_status fhe_behz_q_to_bsk(fhe_behz* h, uint64_t* x, int evalFormat, uint32_t batch, void* ws, size_t wsBytes,
+                                        void* st) {
+    ARG_CHECK(h && x && batch >= 1, "fhe_behz_q_to_bsk: bad argument");
+    fhe_ctx* c = h->ctx;
+    RT_CHECK(rt::set_device(c->device));
+    const uint32_t tot = h->numQ + h->numBsk;
+    BehzArgs g;
+    g.tb = h->tb, g.logN = c->logN, g.batch = batch;
+    g.outBsk = TowerView{x, tot, h->numQ};
+    g.inBsk = g.outBsk, g.outQ = TowerView{x, tot, 0};
+    if (evalFormat) {
+        ARG_CHECK(ws && wsBytes >= fhe_behz_workspace_bytes(h, batch), "fhe_behz_q_to_bsk: workspace too small");
+        uint64_t* coef = (uint64_t*)ws;
+        if (fhe_status s = ntt_run(c, true, x, coef, h->qIdx.data(), h->numQ, batch, st, tot, 0))  // :1708-1712
+            return s;
+        g.inQ = TowerView{coef, h->numQ, 0};
+        FHE_LAUNCH(behz_q_to_bsk_kernel, coeff_grid(c, batch), st, g);
+        LAUNCH_CHECK();
+        // only the new Bsk limbs go to EVALUATION; the Q limbs keep their original NTT form (:1776-1780)
+        return ntt_run(c, false, x, x, h->bskIdx.data(), h->numBsk, batch, st, tot, h->numQ, tot, h->numQ);
+    }
+    g.inQ = TowerView{x, tot, 0};
+    FHE_LAUNCH(behz_q_to_bsk_kernel, coeff_grid(c, batch), st, g);
+    LAUNCH_CHECK();
+    return fhe_ntt_fwd(c, x, h->allIdx.data(), tot, batch, st);  // every limb to EVALUATION (:1774, :1781-1785)
+}
+// DCRTPolyImpl::FastRNSFloorq (:1791-1840), in place on x[batch][numQ+numBsk][N] COEFFICIENT
+extern "C" fhe_status fhe_behz_floorq(fhe_behz* h, uint64_t* x, uint32_t batch, void* st) {
+    ARG_CHECK(h && x && batch >= 1, "fhe_behz_floorq: bad argument");
+    RT_CHECK(rt::set_device(h->ctx->device));
+    const uint32_t tot = h->numQ + h->numBsk;
+    BehzArgs g;
+    g.tb = h->tb, g.logN = h->ctx->logN, g.batch = batch;
+    g.inQ = g.outQ = TowerView{x, tot, 0};
+    g.inBsk = g.outBsk = TowerView{x, tot, h->numQ};
+    FHE_LAUNCH(behz_floorq_kernel, coeff_grid(h->ctx, batch), st, g);
+    LAUNCH_CHECK();
+    return FHE_OK;
+}
+// DCRTPolyImpl::FastBaseConvSK (:1845-1929): x[batch][numQ+numBsk][N] COEFFICIENT -> out[batch][numQ][N]
+extern "C" fhe_status fhe_behz_conv_sk(fhe_behz* h, const uint64_t* x, uint64_t* out, uint32_t batch, void* st) {
+    ARG_CHECK(h && x && out && batch >= 1, "fhe_behz_conv_sk: bad argument");
+    RT_CHECK(rt::set_device(h->ctx->device));
+    const uint32_t tot = h->numQ + h->numBsk;
+    BehzArgs g;
+    g.tb = h->tb, g.logN = h->ctx->logN, g.batch = batch;
+    uint64_t* xm = const_cast<uint64_t*>(x);
+    g.inQ = TowerView{xm, tot, 0}, g.inBsk = TowerView{xm, tot, h->numQ};
+    g.outQ = TowerView{out, h->numQ, 0}, g.outBsk = g.inBsk;
+    FHE_LAUNCH(behz_conv_sk_kernel, coeff_grid(h->ctx, batch), st, g);
+    LAUNCH_CHECK();
+    return FHE_OK;
 }

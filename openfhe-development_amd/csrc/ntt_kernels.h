@@ -73,6 +73,9 @@ struct NttPassArgs {
     uint32_t xcdSwizzle;  // 1: remap blockIdx so that an XCD keeps one (limb, tile) pair across the batch
     uint32_t inStride;    // 0: xin is dense like x; else towers of xin are inStride rows apart and the
     uint32_t inFirst;     //    transformed rows start at row inFirst of each tower
+    uint32_t outStride;   // 0: x is dense; else x is a [batch][outStride][N] view, rows outFirst.. of each tower
+    uint32_t outFirst;    //    (applies to every access of a.x, i.e. stores and in-place reloads)
+    uint32_t stagger;     // tuning: first-wave workgroups with odd (blockIdx>>3) start `stagger` x 64 cycles late
     NttStep steps[6];
     LimbSel sel;
 };
@@ -120,6 +123,15 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_pass_kernel(const NttPassArgs a)
     // ---- which tile? ----
     uint32_t tile = FHE_BID;
     const uint32_t tilesPerRow = (N >= (uint32_t)kTile) ? (N >> kTileLog) : 1u;
+#if !defined(FHE_EMU)
+    // de-synchronise the first wave of workgroups: all of them start within ~100 cycles and run the same
+    // load -> compute -> store phases, so without an offset every CU alternates between an HBM-only and an
+    // ALU-only phase; half of the initially resident workgroups start late, successors inherit the offset
+    if (a.stagger && tile < 2048u && ((tile >> 3) & 1u)) {
+        for (uint32_t i = 0; i < a.stagger; i += 64)
+            __builtin_amdgcn_s_sleep(64);
+    }
+#endif
     if (a.xcdSwizzle) {
         // blockIdx = xcd + 8*i ; i = pairIdx*batch + b ; pair = pairIdx*8 + xcd ; pair = limb*tilesPerRow + tr
         const uint32_t xcd = tile & 7u, i = tile >> 3;
@@ -266,10 +278,22 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_pass_kernel(const NttPassArgs a)
                 r[k] = INVERSE ? csub(r[k], q) : csub(csub(r[k], twoq), q);
         }
         if (si + 1 == a.nSteps) {
+            if (a.outStride) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k)
-                if (LAYOUT_A || off0 + k * kstride < totalWords)
-                    a.x[off0 + k * kstride] = r[k];
+                for (int k = 0; k < 16; ++k) {
+                    const uint64_t d = off0 + k * kstride;
+                    if (LAYOUT_A || d < totalWords) {
+                        const uint32_t rr = (uint32_t)(d >> logN);
+                        a.x[((((uint64_t)(rr / a.nLimbs) * a.outStride + a.outFirst + rr % a.nLimbs)) << logN) + (d & (N - 1u))] = r[k];
+                    }
+                }
+            }
+            else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (LAYOUT_A || off0 + k * kstride < totalWords)
+                        a.x[off0 + k * kstride] = r[k];
+            }
         }
         else {
             const uint32_t sb = lds_sigma(Ib);

@@ -95,6 +95,18 @@ class Lib:
         S("fhe_rescale_workspace_bytes", C.c_size_t, [vp, u32, u32])
         S("fhe_rescale", C.c_int, [vp, vp, u32, u32, vp, vp, C.c_size_t, vp])
         u64 = C.c_uint64
+        f64p = C.POINTER(C.c_double)
+        S("fhe_sr_plan_create", C.c_int, [vp, u32, u32p, u32, u64p, f64p, C.POINTER(vp)])
+        S("fhe_sr_plan_destroy", None, [vp])
+        S("fhe_scale_and_round", C.c_int, [vp, vp, C.c_int, vp, u32, vp])
+        S("fhe_scale_and_round_p_over_q", C.c_int, [vp, vp, u32p, u32, vp, u32, vp])
+        S("fhe_param_behz_bsk", u32, [u32, u32, u64p, u64, u64p, u64p])
+        S("fhe_behz_create", C.c_int, [vp, u32p, u32, u32p, u64, C.POINTER(vp)])
+        S("fhe_behz_destroy", None, [vp])
+        S("fhe_behz_workspace_bytes", C.c_size_t, [vp, u32])
+        S("fhe_behz_q_to_bsk", C.c_int, [vp, vp, C.c_int, u32, vp, C.c_size_t, vp])
+        S("fhe_behz_floorq", C.c_int, [vp, vp, u32, vp])
+        S("fhe_behz_conv_sk", C.c_int, [vp, vp, vp, u32, vp])
         S("fhe_param_first_prime", u64, [u32, u64])
         S("fhe_param_last_prime", u64, [u32, u64])
         S("fhe_param_next_prime", u64, [u64, u64])
@@ -133,6 +145,15 @@ class Lib:
         q = np.array(q, np.uint64)
         psi = np.array([self.L.fhe_param_root_of_unity(M, int(v)) for v in q], np.uint64)
         return q, psi
+
+    def behz_bsk(self, logN, q, t):
+        q = np.ascontiguousarray(q, dtype=np.uint64)
+        bsk = np.zeros(len(q) + 1, np.uint64)
+        psi = np.zeros(len(q) + 1, np.uint64)
+        n = self.L.fhe_param_behz_bsk(logN, len(q), q.ctypes.data_as(u64p), t, bsk.ctypes.data_as(u64p), psi.ctypes.data_as(u64p))
+        if n == 0:
+            raise FheError("fhe_param_behz_bsk failed")
+        return bsk, psi
 
     def select_p(self, logN, q, numPartQ, aux_bits=60):
         q = np.ascontiguousarray(q, dtype=np.uint64)
@@ -371,3 +392,83 @@ def rescale(ctx, x, stream=None):
     ctx.sync(stream)
     ctx.free(ws)
     return out
+
+
+class ScaleAndRoundPlan:
+    """DCRTPoly::ScaleAndRound / ApproxScaleAndRound with the reference's tables (dcrtpoly-impl.h:1470-1628)."""
+
+    def __init__(self, ctx, sizeI, out_idx, tab, frac=None):
+        self.ctx, self.sizeI = ctx, sizeI
+        self.out_idx = np.ascontiguousarray(np.asarray(out_idx, dtype=np.uint32))
+        tab = np.ascontiguousarray(tab, dtype=np.uint64)
+        assert tab.shape == (len(self.out_idx), sizeI + 1)
+        fp = None
+        if frac is not None:
+            frac = np.ascontiguousarray(frac, dtype=np.float64)
+            fp = frac.ctypes.data_as(C.POINTER(C.c_double))
+        h = vp()
+        ctx.lib.check(ctx.lib.L.fhe_sr_plan_create(ctx.h, sizeI, self.out_idx.ctypes.data_as(u32p), len(self.out_idx),
+                                                   tab.ctypes.data_as(u64p), fp, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.L.fhe_sr_plan_destroy(self.h)
+            self.h = None
+
+    def run(self, x, output_first, stream=None):
+        out = self.ctx.empty(x.batch, len(self.out_idx), self.out_idx, COEFFICIENT)
+        self.ctx.lib.check(self.ctx.lib.L.fhe_scale_and_round(self.h, x.ptr, 1 if output_first else 0, out.ptr, x.batch, stream))
+        return out
+
+
+def scale_and_round_p_over_q(ctx, x, limb_idx, stream=None):
+    """DCRTPoly::ScaleAndRoundPOverQ (dcrtpoly-impl.h:1674-1689): x over limb_idx (sizeQ+1 limbs) -> sizeQ limbs"""
+    li = np.ascontiguousarray(np.asarray(limb_idx, dtype=np.uint32))
+    sizeQ = len(li) - 1
+    out = ctx.empty(x.batch, sizeQ, li[:sizeQ], COEFFICIENT)
+    ctx.lib.check(ctx.lib.L.fhe_scale_and_round_p_over_q(ctx.h, x.ptr, li.ctypes.data_as(u32p), sizeQ, out.ptr, x.batch, stream))
+    return out
+
+
+class Behz:
+    """BEHZ base conversions over a context that holds the Q limbs and the Bsk limbs."""
+
+    def __init__(self, ctx, q_idx, bsk_idx, t):
+        self.ctx = ctx
+        self.q_idx = np.ascontiguousarray(np.asarray(q_idx, dtype=np.uint32))
+        self.bsk_idx = np.ascontiguousarray(np.asarray(bsk_idx, dtype=np.uint32))
+        self.numQ, self.numBsk = len(self.q_idx), len(self.bsk_idx)
+        h = vp()
+        ctx.lib.check(ctx.lib.L.fhe_behz_create(ctx.h, self.q_idx.ctypes.data_as(u32p), self.numQ,
+                                                self.bsk_idx.ctypes.data_as(u32p), t, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.L.fhe_behz_destroy(self.h)
+            self.h = None
+
+    def FastBaseConvqToBskMontgomery(self, xq_host, eval_format, stream=None):
+        """xq_host: uint64 [batch][numQ][N]; returns the extended tower [batch][numQ+numBsk][N] (EVALUATION)"""
+        xq_host = np.asarray(xq_host, dtype=np.uint64)
+        B, N = xq_host.shape[0], self.ctx.N
+        full = np.zeros((B, self.numQ + self.numBsk, N), np.uint64)
+        full[:, :self.numQ] = xq_host
+        t = self.ctx.tower(full, limb_idx=np.concatenate([self.q_idx, self.bsk_idx]))
+        wsb = self.ctx.lib.L.fhe_behz_workspace_bytes(self.h, B)
+        ws = self.ctx.malloc(wsb)
+        self.ctx.lib.check(self.ctx.lib.L.fhe_behz_q_to_bsk(self.h, t.ptr, 1 if eval_format else 0, B, ws, wsb, stream))
+        self.ctx.sync(stream)
+        self.ctx.free(ws)
+        t.fmt = EVALUATION
+        return t
+
+    def FastRNSFloorq(self, t, stream=None):
+        self.ctx.lib.check(self.ctx.lib.L.fhe_behz_floorq(self.h, t.ptr, t.batch, stream))
+        return t
+
+    def FastBaseConvSK(self, t, stream=None):
+        out = self.ctx.empty(t.batch, self.numQ, self.q_idx, COEFFICIENT)
+        self.ctx.lib.check(self.ctx.lib.L.fhe_behz_conv_sk(self.h, t.ptr, out.ptr, t.batch, stream))
+        return out

@@ -1,0 +1,282 @@
+// dcrtpoly_hip.h — header-only C++ host side over the C ABI (include/fhe_hip.h).
+//
+// Mirrors the part of the reference class surface that lies on the hot path, with the reference's names,
+// argument meaning and error behaviour (errors are thrown as exceptions carrying the library's message, the way
+// OPENFHE_THROW does in src/core/include/utils/exception.h):
+//   lbcrypto::DCRTPolyImpl  (src/core/include/lattice/hal/default/dcrtpoly.h:59-398, dcrtpoly-impl.h)
+//   ILDCRTParams             (src/core/include/lattice/hal/default/ildcrtparams.h:70-372)
+//   KeySwitchHYBRID          (src/pke/lib/keyswitch/keyswitch-hybrid.cpp:308-435)
+// A tower object owns ONE device allocation uint64_t[batch][limbs][N]; `batch` > 1 is the extension over the
+// reference (a DCRTPoly is batch == 1): every method applies to all towers of the batch in one launch.
+// The drop-in `lattice/hal/hip/` shim described in INTEGRATION.md derives from DCRTPolyInterface and forwards to
+// exactly these calls.
+#ifndef FHE_HAL_DCRTPOLY_HIP_H
+#define FHE_HAL_DCRTPOLY_HIP_H
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/fhe_hip.h"
+
+namespace fhehip {
+
+enum Format { EVALUATION = 0, COEFFICIENT = 1 };  // lbcrypto::Format, utils/inttypes.h:65
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+inline void check(fhe_status s) {
+    if (s != FHE_OK)
+        throw Error(std::string(fhe_last_error()));
+}
+
+// ILDCRTParams + device twiddle tables (shared, immutable)
+class Params {
+public:
+    // ILDCRTParams(corder, moduli, rootsOfUnity)  ildcrtparams.h:130-145
+    Params(uint32_t cyclotomicOrder, const std::vector<uint64_t>& moduli, const std::vector<uint64_t>& roots, int device = 0)
+        : m_moduli(moduli), m_roots(roots) {
+        if (moduli.size() != roots.size())
+            throw Error("sizes of moduli and roots of unity do not match 1");
+        uint32_t logN = 0;
+        while ((2u << logN) < cyclotomicOrder)
+            ++logN;
+        check(fhe_ctx_create(logN, (uint32_t)moduli.size(), moduli.data(), roots.data(), device, &m_ctx));
+    }
+    // ILDCRTParams(corder, depth, bits)  ildcrtparams.h:100-117
+    static std::shared_ptr<Params> Generate(uint32_t cyclotomicOrder, uint32_t depth, uint32_t bits, int device = 0) {
+        std::vector<uint64_t> q(depth), psi(depth);
+        check(fhe_param_dcrt_chain(cyclotomicOrder, depth, bits, q.data(), psi.data()));
+        return std::make_shared<Params>(cyclotomicOrder, q, psi, device);
+    }
+    ~Params() { fhe_ctx_destroy(m_ctx); }
+    Params(const Params&)            = delete;
+    Params& operator=(const Params&) = delete;
+    uint32_t GetRingDimension() const { return 1u << fhe_ctx_logn(m_ctx); }
+    uint32_t GetCyclotomicOrder() const { return 2u << fhe_ctx_logn(m_ctx); }
+    const std::vector<uint64_t>& GetModuli() const { return m_moduli; }
+    const std::vector<uint64_t>& GetRoots() const { return m_roots; }
+    fhe_ctx* ctx() const { return m_ctx; }
+
+private:
+    fhe_ctx* m_ctx = nullptr;
+    std::vector<uint64_t> m_moduli, m_roots;
+};
+
+class DCRTPolyHip {
+public:
+    // towers over the context limbs limbIdx (empty = limbs [0, nLimbs))
+    DCRTPolyHip(std::shared_ptr<Params> params, uint32_t nLimbs, Format format, uint32_t batch = 1,
+                std::vector<uint32_t> limbIdx = {})
+        : m_params(std::move(params)), m_limbs(nLimbs), m_batch(batch), m_format(format), m_idx(std::move(limbIdx)) {
+        if (!m_idx.empty() && m_idx.size() != nLimbs)
+            throw Error("limb index list does not match the number of towers");
+        void* p = nullptr;
+        check(fhe_malloc(m_params->ctx(), bytes(), &p));
+        m_data = static_cast<uint64_t*>(p);
+    }
+    ~DCRTPolyHip() {
+        if (m_data)
+            fhe_free(m_params->ctx(), m_data);
+    }
+    DCRTPolyHip(DCRTPolyHip&& o) noexcept { *this = std::move(o); }
+    DCRTPolyHip& operator=(DCRTPolyHip&& o) noexcept {
+        if (this != &o) {
+            if (m_data)
+                fhe_free(m_params->ctx(), m_data);
+            m_params = std::move(o.m_params);
+            m_limbs = o.m_limbs, m_batch = o.m_batch, m_format = o.m_format, m_idx = std::move(o.m_idx);
+            m_data   = o.m_data;
+            o.m_data = nullptr;
+        }
+        return *this;
+    }
+    DCRTPolyHip(const DCRTPolyHip& o) : DCRTPolyHip(o.m_params, o.m_limbs, o.m_format, o.m_batch, o.m_idx) {
+        check(fhe_memcpy_d2d(m_params->ctx(), m_data, o.m_data, bytes(), nullptr));
+    }
+
+    // host <-> device (SetValues / GetValues of the limbs, poly.h:166-195)
+    void SetValues(const std::vector<uint64_t>& host, Format format) {
+        if (host.size() != words())
+            throw Error("SetValues: size mismatch");
+        check(fhe_memcpy_h2d(m_params->ctx(), m_data, host.data(), bytes(), nullptr));
+        check(fhe_stream_sync(m_params->ctx(), nullptr));
+        m_format = format;
+    }
+    std::vector<uint64_t> GetValues() const {
+        std::vector<uint64_t> h(words());
+        check(fhe_memcpy_d2h(m_params->ctx(), h.data(), m_data, bytes(), nullptr));
+        check(fhe_stream_sync(m_params->ctx(), nullptr));
+        return h;
+    }
+
+    Format GetFormat() const { return m_format; }
+    uint32_t GetNumOfElements() const { return m_limbs; }
+    uint32_t GetRingDimension() const { return m_params->GetRingDimension(); }
+    uint32_t GetBatch() const { return m_batch; }
+    const std::shared_ptr<Params>& GetParams() const { return m_params; }
+    uint64_t* data() { return m_data; }
+    const uint64_t* data() const { return m_data; }
+
+    // DCRTPolyImpl::SwitchFormat (dcrtpoly-impl.h:1932-1940), SetFormat (ilelement.h:447-450)
+    void SwitchFormat(void* stream = nullptr) {
+        if (m_format == COEFFICIENT)
+            check(fhe_ntt_fwd(m_params->ctx(), m_data, idx(), m_limbs, m_batch, stream));
+        else
+            check(fhe_ntt_inv(m_params->ctx(), m_data, idx(), m_limbs, m_batch, stream));
+        m_format = m_format == COEFFICIENT ? EVALUATION : COEFFICIENT;
+    }
+    void SetFormat(Format f, void* stream = nullptr) {
+        if (f != m_format)
+            SwitchFormat(stream);
+    }
+
+    // Plus / Minus / Times and the in-place operators (dcrtpoly.h:131-189, dcrtpoly-impl.h:362-408)
+    DCRTPolyHip Plus(const DCRTPolyHip& r) const { return bin(fhe_add, r); }
+    DCRTPolyHip Minus(const DCRTPolyHip& r) const { return bin(fhe_sub, r); }
+    DCRTPolyHip Times(const DCRTPolyHip& r) const { return bin(fhe_mul, r); }
+    DCRTPolyHip& operator+=(const DCRTPolyHip& r) { return binEq(fhe_add, r); }
+    DCRTPolyHip& operator-=(const DCRTPolyHip& r) { return binEq(fhe_sub, r); }
+    DCRTPolyHip& operator*=(const DCRTPolyHip& r) { return binEq(fhe_mul, r); }
+    // Times(const std::vector<NativeInteger>&)  dcrtpoly-impl.h:582-601
+    DCRTPolyHip Times(const std::vector<uint64_t>& perLimb) const {
+        if (perLimb.size() != m_limbs)
+            throw Error("tower size mismatch; cannot multiply");
+        DCRTPolyHip out(m_params, m_limbs, m_format, m_batch, m_idx);
+        check(fhe_mul_const(m_params->ctx(), out.m_data, m_data, perLimb.data(), idx(), m_limbs, m_batch, nullptr));
+        return out;
+    }
+    DCRTPolyHip Negate() const {  // dcrtpoly-impl.h:347-354
+        DCRTPolyHip out(m_params, m_limbs, m_format, m_batch, m_idx);
+        check(fhe_neg(m_params->ctx(), out.m_data, m_data, idx(), m_limbs, m_batch, nullptr));
+        return out;
+    }
+    // AutomorphismTransform(k)  dcrtpoly-impl.h:314-333 ("Automorphism index not odd" is thrown for even k)
+    DCRTPolyHip AutomorphismTransform(uint32_t k) const {
+        DCRTPolyHip out(m_params, m_limbs, m_format, m_batch, m_idx);
+        check(fhe_automorph(m_params->ctx(), out.m_data, m_data, k, m_format == EVALUATION, idx(), m_limbs, m_batch, nullptr));
+        return out;
+    }
+    // DropLastElementAndScale (CKKS rescale)  dcrtpoly-impl.h:693-712; tower must use context limbs [0, limbs)
+    void DropLastElementAndScale() {
+        if (!m_idx.empty())
+            throw Error("DropLastElementAndScale: tower must use the leading context limbs");
+        if (m_format != EVALUATION)
+            throw Error("DropLastElementAndScale: EVALUATION format expected");
+        DCRTPolyHip out(m_params, m_limbs - 1, m_format, m_batch);
+        size_t wsb = fhe_rescale_workspace_bytes(m_params->ctx(), m_limbs, m_batch);
+        void* ws   = nullptr;
+        check(fhe_malloc(m_params->ctx(), wsb, &ws));
+        fhe_status s = fhe_rescale(m_params->ctx(), m_data, m_limbs, m_batch, out.m_data, ws, wsb, nullptr);
+        fhe_stream_sync(m_params->ctx(), nullptr);
+        fhe_free(m_params->ctx(), ws);
+        check(s);
+        *this = std::move(out);
+    }
+    // ApproxSwitchCRTBasis / SwitchCRTBasis to the context limbs `target` (dcrtpoly-impl.h:888-932, 1008-1085)
+    DCRTPolyHip SwitchCRTBasis(const std::vector<uint32_t>& target, bool exact) const {
+        if (m_format != COEFFICIENT)
+            throw Error("SwitchCRTBasis: COEFFICIENT format expected");
+        std::vector<uint32_t> src = m_idx;
+        if (src.empty())
+            for (uint32_t i = 0; i < m_limbs; ++i)
+                src.push_back(i);
+        fhe_conv* cv = nullptr;
+        check(fhe_conv_create(m_params->ctx(), src.data(), m_limbs, target.data(), (uint32_t)target.size(), &cv));
+        DCRTPolyHip out(m_params, (uint32_t)target.size(), COEFFICIENT, m_batch, target);
+        fhe_status s = exact ? fhe_switch_basis_exact(cv, m_data, m_limbs, 0, out.m_data, (uint32_t)target.size(), 0, m_batch, nullptr)
+                             : fhe_approx_switch_basis(cv, m_data, m_limbs, 0, out.m_data, (uint32_t)target.size(), 0, m_batch, nullptr);
+        fhe_stream_sync(m_params->ctx(), nullptr);
+        fhe_conv_destroy(cv);
+        check(s);
+        return out;
+    }
+
+private:
+    typedef fhe_status (*BinFn)(fhe_ctx*, uint64_t*, const uint64_t*, const uint64_t*, const uint32_t*, uint32_t, uint32_t, void*);
+    void compatible(const DCRTPolyHip& r) const {
+        if (r.m_limbs != m_limbs || r.m_batch != m_batch)
+            throw Error("tower size mismatch");  // dcrtpoly.h:154-162
+        if (r.m_format != m_format)
+            throw Error("format mismatch");
+    }
+    DCRTPolyHip bin(BinFn f, const DCRTPolyHip& r) const {
+        compatible(r);
+        DCRTPolyHip out(m_params, m_limbs, m_format, m_batch, m_idx);
+        check(f(m_params->ctx(), out.m_data, m_data, r.m_data, idx(), m_limbs, m_batch, nullptr));
+        return out;
+    }
+    DCRTPolyHip& binEq(BinFn f, const DCRTPolyHip& r) {
+        compatible(r);
+        check(f(m_params->ctx(), m_data, m_data, r.m_data, idx(), m_limbs, m_batch, nullptr));
+        return *this;
+    }
+    const uint32_t* idx() const { return m_idx.empty() ? nullptr : m_idx.data(); }
+    size_t words() const { return (size_t)m_batch * m_limbs * m_params->GetRingDimension(); }
+    size_t bytes() const { return words() * sizeof(uint64_t); }
+
+    std::shared_ptr<Params> m_params;
+    uint32_t m_limbs = 0, m_batch = 0;
+    Format m_format  = EVALUATION;
+    std::vector<uint32_t> m_idx;
+    uint64_t* m_data = nullptr;
+};
+
+// KeySwitchHYBRID over a context holding Q then P limbs (keyswitch-hybrid.cpp:308-435)
+class KeySwitchHybrid {
+public:
+    KeySwitchHybrid(std::shared_ptr<Params> params, uint32_t sizeQ, uint32_t sizeP, uint32_t numPartQ)
+        : m_params(std::move(params)), m_sizeQ(sizeQ) {
+        check(fhe_ks_plan_create(m_params->ctx(), sizeQ, sizeP, numPartQ, &m_plan));
+    }
+    ~KeySwitchHybrid() {
+        fhe_ks_key_destroy(m_key);
+        if (m_ws)
+            fhe_free(m_params->ctx(), m_ws);
+        fhe_ks_plan_destroy(m_plan);
+    }
+    // EvalKeyRelin b/a vectors, host uint64[numPartQ][sizeQ+sizeP][N] (evalkeyrelin.h:141,171)
+    void SetEvalKey(const std::vector<uint64_t>& keyB, const std::vector<uint64_t>& keyA) {
+        fhe_ks_key_destroy(m_key);
+        m_key = nullptr;
+        check(fhe_ks_key_upload(m_plan, keyB.data(), keyA.data(), &m_key));
+    }
+    // KeySwitchCore(a, evalKey)
+    std::pair<DCRTPolyHip, DCRTPolyHip> KeySwitchCore(const DCRTPolyHip& a) {
+        DCRTPolyHip o0(m_params, a.GetNumOfElements(), EVALUATION, a.GetBatch()), o1(m_params, a.GetNumOfElements(), EVALUATION, a.GetBatch());
+        reserve(a.GetNumOfElements(), a.GetBatch());
+        check(fhe_keyswitch_hybrid(m_plan, m_key, a.data(), a.GetNumOfElements(), a.GetBatch(), o0.data(), o1.data(), m_ws, m_wsBytes, nullptr));
+        return {std::move(o0), std::move(o1)};
+    }
+    // LeveledSHEBase::EvalMult(ct1, ct2, evalKey) for 2-element ciphertexts (base-leveledshe.cpp:201-214)
+    std::pair<DCRTPolyHip, DCRTPolyHip> EvalMult(const DCRTPolyHip& a0, const DCRTPolyHip& a1, const DCRTPolyHip& b0, const DCRTPolyHip& b1) {
+        DCRTPolyHip c0(m_params, a0.GetNumOfElements(), EVALUATION, a0.GetBatch()), c1(m_params, a0.GetNumOfElements(), EVALUATION, a0.GetBatch());
+        reserve(a0.GetNumOfElements(), a0.GetBatch());
+        check(fhe_ckks_eval_mult(m_plan, m_key, a0.data(), a1.data(), b0.data(), b1.data(), a0.GetNumOfElements(), a0.GetBatch(),
+                                 c0.data(), c1.data(), m_ws, m_wsBytes, nullptr));
+        return {std::move(c0), std::move(c1)};
+    }
+
+private:
+    void reserve(uint32_t sizeQl, uint32_t batch) {
+        size_t need = fhe_ks_workspace_bytes(m_plan, sizeQl, batch);
+        if (need > m_wsBytes) {
+            if (m_ws)
+                fhe_free(m_params->ctx(), m_ws);
+            check(fhe_malloc(m_params->ctx(), need, &m_ws));
+            m_wsBytes = need;
+        }
+    }
+    std::shared_ptr<Params> m_params;
+    uint32_t m_sizeQ;
+    fhe_ks_plan* m_plan = nullptr;
+    fhe_ks_key* m_key   = nullptr;
+    void* m_ws          = nullptr;
+    size_t m_wsBytes    = 0;
+};
+
+}  // namespace fhehip
+#endif

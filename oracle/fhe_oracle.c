@@ -1029,3 +1029,331 @@ void orc_drop_last_element_and_scale(const orc_ctx* c, const uint64_t* x, uint32
     }
     free(last);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * a17: ScaleAndRound family.  Double-precision accumulation order is part of the result.
+ * ---------------------------------------------------------------------------------------- */
+/* dcrtpoly-impl.h:1513-1628 (HAVE_INT128 && NATIVEINT == 64 branch) */
+void orc_scale_and_round(const uint64_t* x, uint32_t sizeI, uint32_t sizeO, uint32_t N, int outputFirst,
+                         const uint64_t* tab, const double* frac, const uint64_t* o, const uint64_t* mu128,
+                         uint64_t* out) {
+    const uint32_t inputIndex  = outputFirst ? sizeO : 0;
+    const uint32_t outputIndex = outputFirst ? 0 : sizeI;
+#pragma omp parallel for
+    for (uint32_t ri = 0; ri < N; ++ri) {
+        double nu = 0.5;
+        for (uint32_t i = 0; i < sizeI; ++i)
+            nu += frac[i] * (double)x[(size_t)(i + inputIndex) * N + ri];
+        /* isConvertableToNativeInt: |nu| <= (double)Max64BitValue  (utils/utilities.h:122-126) */
+        const int small = fabs(nu) <= (double)UINT64_MAX;
+        for (uint32_t j = 0; j < sizeO; ++j) {
+            const uint64_t* tj = tab + (size_t)j * (sizeI + 1);
+            u128 cur = 0;
+            for (uint32_t i = 0; i < sizeI; ++i)
+                cur += (u128)x[(size_t)(i + inputIndex) * N + ri] * tj[i];
+            cur += (u128)x[(size_t)(outputIndex + j) * N + ri] * tj[sizeI];
+            const uint64_t oj = o[j];
+            uint64_t v = orc_barrett128((uint64_t)cur, (uint64_t)(cur >> 64), oj, mu128[2 * j], mu128[2 * j + 1]);
+            uint64_t a;
+            if (small) {
+                uint64_t alpha = (uint64_t)nu;
+                a = alpha >= oj ? alpha % oj : alpha;
+            }
+            else {
+                u128 alpha = (u128)nu;
+                a = orc_barrett128((uint64_t)alpha, (uint64_t)(alpha >> 64), oj, mu128[2 * j], mu128[2 * j + 1]);
+            }
+            out[(size_t)j * N + ri] = orc_mod_add_fast(v, a, oj);
+        }
+    }
+}
+
+/* dcrtpoly-impl.h:1470-1510 */
+void orc_approx_scale_and_round(const uint64_t* x, uint32_t sizeQ, uint32_t sizeP, uint32_t N, const uint64_t* tab,
+                                const uint64_t* p, const uint64_t* mu128, uint64_t* out) {
+#pragma omp parallel for
+    for (uint32_t ri = 0; ri < N; ++ri)
+        for (uint32_t j = 0; j < sizeP; ++j) {
+            const uint64_t* tj = tab + (size_t)j * (sizeQ + 1);
+            u128 cur = 0;
+            for (uint32_t i = 0; i < sizeQ; ++i)
+                cur += (u128)x[(size_t)i * N + ri] * tj[i];
+            cur += (u128)x[(size_t)(sizeQ + j) * N + ri] * tj[sizeQ];
+            out[(size_t)j * N + ri] =
+                orc_barrett128((uint64_t)cur, (uint64_t)(cur >> 64), p[j], mu128[2 * j], mu128[2 * j + 1]);
+        }
+}
+
+/* dcrtpoly-impl.h:1674-1689 */
+void orc_scale_and_round_p_over_q(const uint64_t* x, uint32_t sizeQ, uint32_t N, const uint64_t* q, uint64_t pLast,
+                                  const uint64_t* pInvModq, uint64_t* out) {
+    for (uint32_t i = 0; i < sizeQ; ++i) {
+        uint64_t* tmp = (uint64_t*)malloc(sizeof(uint64_t) * N);
+        memcpy(tmp, x + (size_t)sizeQ * N, sizeof(uint64_t) * N);
+        orc_switch_modulus(tmp, N, pLast, q[i]);
+        orc_vec_sub(out + (size_t)i * N, x + (size_t)i * N, tmp, N, q[i]);
+        orc_vec_mul_const(out + (size_t)i * N, out + (size_t)i * N, pInvModq[i], N, q[i]);
+        free(tmp);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a18: BEHZ.  Tables as bfvrns-cryptoparameters.cpp:673-850 builds them (residues of products => modular
+ * arithmetic; the one genuinely multi-precision step is the msk size check B*msk >= 2n*t*Q).
+ * ---------------------------------------------------------------------------------------- */
+struct orc_behz {
+    uint32_t N, numQ, numBsk;
+    uint64_t t, *q, *bsk, *psiBsk;
+    uint64_t *mtQHatInv, *mtQHatInvPre; /* [numQ]  [mtilde*(Q/q_i)^-1]_{q_i} */
+    uint64_t* QHatModbsk;               /* [numQ][numBsk] */
+    uint64_t* QHatModmt;                /* [numQ] */
+    uint64_t *QModbsk, *QModbskPre;     /* [numBsk] */
+    uint64_t negQInvModmt;
+    uint64_t *mtInvModbsk, *mtInvModbskPre; /* [numBsk] */
+    uint64_t *tQHatInv, *tQHatInvPre;       /* [numQ] */
+    uint64_t* qInvModbsk;                   /* [numQ][numBsk] */
+    uint64_t *tQInvModbsk, *tQInvModbskPre; /* [numBsk] */
+    uint64_t *BHatInv, *BHatInvPre;         /* [numB] */
+    uint64_t* BHatModmsk;                   /* [numB] */
+    uint64_t BInvModmsk, BInvModmskPre;
+    uint64_t* BHatModq;                     /* [numB][numQ] */
+    uint64_t *BModq, *BModqPre;             /* [numQ] */
+    uint64_t *muBsk, *muQ;                  /* [.][2] */
+};
+
+static uint32_t mp_mul_small(uint64_t* big, uint32_t len, uint64_t m) {
+    uint64_t carry = 0;
+    for (uint32_t k = 0; k < len; ++k) {
+        u128 t = (u128)big[k] * m + carry;
+        big[k] = (uint64_t)t;
+        carry  = (uint64_t)(t >> 64);
+    }
+    if (carry)
+        big[len++] = carry;
+    return len;
+}
+static int mp_less(const uint64_t* a, uint32_t la, const uint64_t* b, uint32_t lb) {
+    if (la != lb)
+        return la < lb;
+    for (int k = (int)la - 1; k >= 0; --k)
+        if (a[k] != b[k])
+            return a[k] < b[k];
+    return 0;
+}
+static uint64_t prod_mod_list(const uint64_t* m, uint32_t n, int skip, uint64_t mod) {
+    uint64_t v = 1 % mod;
+    for (uint32_t k = 0; k < n; ++k)
+        if ((int)k != skip)
+            v = orc_mulmod(v, m[k] % mod, mod);
+    return v;
+}
+
+orc_behz* orc_behz_create(uint32_t N, uint32_t numQ, const uint64_t* q, uint64_t t) {
+    orc_behz* h = (orc_behz*)calloc(1, sizeof(orc_behz));
+    const uint64_t M = 2 * (uint64_t)N, mtilde = (uint64_t)1 << 16;
+    const uint32_t numB = numQ, numBsk = numQ + 1;
+    h->N = N, h->numQ = numQ, h->numBsk = numBsk, h->t = t;
+    h->q      = (uint64_t*)malloc(8 * numQ);
+    h->bsk    = (uint64_t*)malloc(8 * numBsk);
+    h->psiBsk = (uint64_t*)malloc(8 * numBsk);
+    memcpy(h->q, q, 8 * numQ);
+    /* B = numQ primes below q.back(), then msk (:682-711) */
+    uint64_t cur = q[numQ - 1];
+    for (uint32_t i = 0; i < numB; ++i) {
+        cur          = orc_previous_prime(cur, M);
+        h->bsk[i]    = cur;
+        h->psiBsk[i] = orc_root_of_unity(M, cur);
+    }
+    uint64_t msk = orc_previous_prime(h->bsk[numB - 1], M);
+    uint32_t s   = orc_get_msb(msk);
+    {
+        uint64_t lhs[80], rhs[80];
+        uint32_t ll, lr = 1;
+        rhs[0] = 1;
+        lr     = mp_mul_small(rhs, lr, M);
+        lr     = mp_mul_small(rhs, lr, t);
+        for (uint32_t i = 0; i < numQ; ++i)
+            lr = mp_mul_small(rhs, lr, q[i]);
+        for (;;) {
+            ll     = 1;
+            lhs[0] = 1;
+            for (uint32_t i = 0; i < numB; ++i)
+                ll = mp_mul_small(lhs, ll, h->bsk[i]);
+            ll = mp_mul_small(lhs, ll, msk);
+            if (!mp_less(lhs, ll, rhs, lr))
+                break;
+            msk = orc_next_prime(orc_first_prime(++s, M), M);
+        }
+    }
+    h->bsk[numB]    = msk;
+    h->psiBsk[numB] = orc_root_of_unity(M, msk);
+
+    h->mtQHatInv      = (uint64_t*)malloc(8 * numQ);
+    h->mtQHatInvPre   = (uint64_t*)malloc(8 * numQ);
+    h->QHatModbsk     = (uint64_t*)malloc(8 * (size_t)numQ * numBsk);
+    h->QHatModmt      = (uint64_t*)malloc(8 * numQ);
+    h->QModbsk        = (uint64_t*)malloc(8 * numBsk);
+    h->QModbskPre     = (uint64_t*)malloc(8 * numBsk);
+    h->mtInvModbsk    = (uint64_t*)malloc(8 * numBsk);
+    h->mtInvModbskPre = (uint64_t*)malloc(8 * numBsk);
+    h->tQHatInv       = (uint64_t*)malloc(8 * numQ);
+    h->tQHatInvPre    = (uint64_t*)malloc(8 * numQ);
+    h->qInvModbsk     = (uint64_t*)malloc(8 * (size_t)numQ * numBsk);
+    h->tQInvModbsk    = (uint64_t*)malloc(8 * numBsk);
+    h->tQInvModbskPre = (uint64_t*)malloc(8 * numBsk);
+    h->BHatInv        = (uint64_t*)malloc(8 * numB);
+    h->BHatInvPre     = (uint64_t*)malloc(8 * numB);
+    h->BHatModmsk     = (uint64_t*)malloc(8 * numB);
+    h->BHatModq       = (uint64_t*)malloc(8 * (size_t)numB * numQ);
+    h->BModq          = (uint64_t*)malloc(8 * numQ);
+    h->BModqPre       = (uint64_t*)malloc(8 * numQ);
+    h->muBsk          = (uint64_t*)malloc(16 * numBsk);
+    h->muQ            = (uint64_t*)malloc(16 * numQ);
+    for (uint32_t i = 0; i < numQ; ++i) {
+        const uint64_t qi     = q[i];
+        const uint64_t hatInv = orc_invmod(prod_mod_list(q, numQ, (int)i, qi), qi);
+        h->tQHatInv[i]        = orc_mulmod(hatInv, t % qi, qi);                 /* :722-733 */
+        h->tQHatInvPre[i]     = orc_prep_mod_mul_const(h->tQHatInv[i], qi);
+        h->mtQHatInv[i]       = orc_mulmod(hatInv, mtilde % qi, qi);            /* :755-768 */
+        h->mtQHatInvPre[i]    = orc_prep_mod_mul_const(h->mtQHatInv[i], qi);
+        for (uint32_t j = 0; j < numBsk; ++j) {
+            h->QHatModbsk[(size_t)i * numBsk + j] = prod_mod_list(q, numQ, (int)i, h->bsk[j]); /* :735-747 */
+            h->qInvModbsk[(size_t)i * numBsk + j] = orc_invmod(qi % h->bsk[j], h->bsk[j]);      /* :749-755 */
+        }
+        /* Q/q_i mod 2^16: product of the other moduli mod 2^16 */
+        uint64_t v = 1;
+        for (uint32_t k = 0; k < numQ; ++k)
+            if (k != i)
+                v = (v * (q[k] & (mtilde - 1))) & (mtilde - 1);
+        h->QHatModmt[i] = v;
+        h->BModq[i]     = prod_mod_list(h->bsk, numB, -1, qi);                  /* :838-845 */
+        h->BModqPre[i]  = orc_prep_mod_mul_const(h->BModq[i], qi);
+        orc_barrett_mu128(qi, h->muQ + 2 * i);
+    }
+    {   /* [-Q^-1]_{mtilde} (:770-773): Q odd => invertible mod 2^16; Newton iteration */
+        uint64_t Qm = 1;
+        for (uint32_t k = 0; k < numQ; ++k)
+            Qm = (Qm * (q[k] & (mtilde - 1))) & (mtilde - 1);
+        uint64_t inv = 1;
+        for (int it = 0; it < 5; ++it)
+            inv = (inv * (2 - Qm * inv)) & (mtilde - 1);
+        h->negQInvModmt = ((mtilde - 1) * inv) & (mtilde - 1);
+    }
+    for (uint32_t j = 0; j < numBsk; ++j) {
+        const uint64_t bj    = h->bsk[j];
+        h->QModbsk[j]        = prod_mod_list(q, numQ, -1, bj);                   /* :775-783 */
+        h->QModbskPre[j]     = orc_prep_mod_mul_const(h->QModbsk[j], bj);
+        h->mtInvModbsk[j]    = orc_invmod(mtilde % bj, bj);                      /* :785-793 */
+        h->mtInvModbskPre[j] = orc_prep_mod_mul_const(h->mtInvModbsk[j], bj);
+        h->tQInvModbsk[j]    = orc_mulmod(orc_invmod(h->QModbsk[j], bj), t % bj, bj); /* :795-804 */
+        h->tQInvModbskPre[j] = orc_prep_mod_mul_const(h->tQInvModbsk[j], bj);
+        orc_barrett_mu128(bj, h->muBsk + 2 * j);
+    }
+    for (uint32_t i = 0; i < numB; ++i) {
+        const uint64_t bi = h->bsk[i];
+        h->BHatInv[i]     = orc_invmod(prod_mod_list(h->bsk, numB, (int)i, bi), bi);   /* :806-817 */
+        h->BHatInvPre[i]  = orc_prep_mod_mul_const(h->BHatInv[i], bi);
+        h->BHatModmsk[i]  = prod_mod_list(h->bsk, numB, (int)i, msk);                 /* :829-834 */
+        for (uint32_t j = 0; j < numQ; ++j)
+            h->BHatModq[(size_t)i * numQ + j] = prod_mod_list(h->bsk, numB, (int)i, q[j]); /* :819-827 */
+    }
+    h->BInvModmsk    = orc_invmod(prod_mod_list(h->bsk, numB, -1, msk), msk);         /* :836-837 */
+    h->BInvModmskPre = orc_prep_mod_mul_const(h->BInvModmsk, msk);
+    return h;
+}
+void orc_behz_destroy(orc_behz* h) {
+    if (!h)
+        return;
+    uint64_t* ptrs[] = {h->q, h->bsk, h->psiBsk, h->mtQHatInv, h->mtQHatInvPre, h->QHatModbsk, h->QHatModmt, h->QModbsk,
+                        h->QModbskPre, h->mtInvModbsk, h->mtInvModbskPre, h->tQHatInv, h->tQHatInvPre, h->qInvModbsk,
+                        h->tQInvModbsk, h->tQInvModbskPre, h->BHatInv, h->BHatInvPre, h->BHatModmsk, h->BHatModq,
+                        h->BModq, h->BModqPre, h->muBsk, h->muQ};
+    for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i)
+        free(ptrs[i]);
+    free(h);
+}
+uint32_t orc_behz_num_bsk(const orc_behz* h) { return h->numBsk; }
+void orc_behz_get_bsk(const orc_behz* h, uint64_t* bsk, uint64_t* psiBsk) {
+    memcpy(bsk, h->bsk, 8 * h->numBsk);
+    memcpy(psiBsk, h->psiBsk, 8 * h->numBsk);
+}
+
+/* dcrtpoly-impl.h:1731-1774 (coefficient-domain core of FastBaseConvqToBskMontgomery) */
+void orc_behz_q_to_bsk_montgomery(const orc_behz* h, const uint64_t* xq, uint64_t* outBsk) {
+    const uint32_t N = h->N, numQ = h->numQ, numBsk = h->numBsk;
+    const uint64_t mtilde = (uint64_t)1 << 16, half = mtilde >> 1, mask = mtilde - 1;
+#pragma omp parallel for
+    for (uint32_t k = 0; k < N; ++k) {
+        uint64_t y[64];
+        uint64_t rm = 0;
+        for (uint32_t i = 0; i < numQ; ++i) {
+            y[i] = orc_mod_mul_fast_const(xq[(size_t)i * N + k], h->mtQHatInv[i], h->q[i], h->mtQHatInvPre[i]);
+            rm += y[i] * h->QHatModmt[i];
+        }
+        rm &= mask;
+        rm *= h->negQInvModmt;
+        rm &= mask;
+        for (uint32_t j = 0; j < numBsk; ++j) {
+            const uint64_t bj = h->bsk[j];
+            u128 res          = 0;
+            for (uint32_t i = 0; i < numQ; ++i)
+                res += (u128)y[i] * h->QHatModbsk[(size_t)i * numBsk + j];
+            uint64_t v = orc_barrett128((uint64_t)res, (uint64_t)(res >> 64), bj, h->muBsk[2 * j], h->muBsk[2 * j + 1]);
+            uint64_t r = rm;
+            if (rm >= half)
+                r += bj - mtilde;
+            r = orc_mod_mul_fast_const(r, h->QModbsk[j], bj, h->QModbskPre[j]);
+            r = orc_mod_add_fast(r, v, bj);
+            outBsk[(size_t)j * N + k] = orc_mod_mul_fast_const(r, h->mtInvModbsk[j], bj, h->mtInvModbskPre[j]);
+        }
+    }
+}
+
+/* dcrtpoly-impl.h:1791-1840 */
+void orc_behz_fast_rns_floorq(const orc_behz* h, uint64_t* x) {
+    const uint32_t N = h->N, numQ = h->numQ, numBsk = h->numBsk;
+#pragma omp parallel for
+    for (uint32_t k = 0; k < N; ++k) {
+        for (uint32_t i = 0; i < numQ; ++i)
+            x[(size_t)i * N + k] = orc_mod_mul_fast_const(x[(size_t)i * N + k], h->tQHatInv[i], h->q[i], h->tQHatInvPre[i]);
+        for (uint32_t j = 0; j < numBsk; ++j) {
+            const uint64_t bj = h->bsk[j];
+            u128 aq           = 0;
+            for (uint32_t i = 0; i < numQ; ++i)
+                aq += (u128)x[(size_t)i * N + k] * h->qInvModbsk[(size_t)i * numBsk + j];
+            uint64_t s = orc_barrett128((uint64_t)aq, (uint64_t)(aq >> 64), bj, h->muBsk[2 * j], h->muBsk[2 * j + 1]);
+            uint64_t v = orc_mod_mul_fast_const(x[(size_t)(numQ + j) * N + k], h->tQInvModbsk[j], bj, h->tQInvModbskPre[j]);
+            x[(size_t)(numQ + j) * N + k] = orc_mod_sub_fast(v, s, bj);
+        }
+    }
+}
+
+/* dcrtpoly-impl.h:1845-1929 */
+void orc_behz_fast_base_conv_sk(const orc_behz* h, const uint64_t* x, uint64_t* outQ) {
+    const uint32_t N = h->N, numQ = h->numQ, numBsk = h->numBsk, numB = numBsk - 1;
+    const uint64_t msk = h->bsk[numB], mskHalf = msk >> 1;
+#pragma omp parallel for
+    for (uint32_t k = 0; k < N; ++k) {
+        uint64_t b[64];
+        uint64_t alpha = 0;
+        for (uint32_t i = 0; i < numB; ++i) {
+            b[i] = orc_mod_mul_fast_const(x[(size_t)(numQ + i) * N + k], h->BHatInv[i], h->bsk[i], h->BHatInvPre[i]);
+            /* ModMul / ModAddEq with full reduction of both operands (ubintnat.h generic versions) */
+            alpha = (alpha + orc_mulmod(b[i] % msk, h->BHatModmsk[i], msk)) % msk;
+        }
+        alpha = orc_mod_sub_fast(alpha, x[(size_t)(numQ + numB) * N + k], msk);
+        alpha = orc_mod_mul_fast_const(alpha, h->BInvModmsk, msk, h->BInvModmskPre);
+        for (uint32_t j = 0; j < numQ; ++j) {
+            const uint64_t qj = h->q[j];
+            u128 res          = 0;
+            for (uint32_t i = 0; i < numB; ++i)
+                res += (u128)b[i] * h->BHatModq[(size_t)i * numQ + j];
+            uint64_t v = orc_barrett128((uint64_t)res, (uint64_t)(res >> 64), qj, h->muQ[2 * j], h->muQ[2 * j + 1]);
+            uint64_t a = alpha;
+            if (a > mskHalf)
+                a = orc_mod_sub_fast(a, msk, qj);
+            a = orc_mod_mul_fast_const(a, h->BModq[j], qj, h->BModqPre[j]);
+            outQ[(size_t)j * N + k] = orc_mod_sub_fast(v, a, qj);
+        }
+    }
+}

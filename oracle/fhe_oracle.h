@@ -149,6 +149,30 @@ void orc_ckks_eval_mult_relin(const orc_hybrid*, const uint64_t* a0, const uint6
 void orc_drop_last_element_and_scale(const orc_ctx*, const uint64_t* x, uint32_t sizeQl, uint64_t* out);
 void orc_rescale_tables(const orc_ctx*, uint32_t sizeQl, uint64_t* QlQlInvModqlDivqlModq, uint64_t* qlInvModq);
 
+/* ---------------- a17: ScaleAndRound family (dcrtpoly-impl.h:1470-1689) ----------------
+ * x is a tower [sizeI+sizeO][N] (COEFF). tab is [sizeO][sizeI+1] as the reference indexes it (tab[j][i]);
+ * outputFirst != 0: the output basis is the FIRST sizeO limbs of x (inputIndex = sizeO), else the LAST sizeO limbs. */
+void orc_scale_and_round(const uint64_t* x, uint32_t sizeI, uint32_t sizeO, uint32_t N, int outputFirst,
+                         const uint64_t* tab, const double* frac, const uint64_t* o, const uint64_t* mu128,
+                         uint64_t* out);
+/* ApproxScaleAndRound (:1470-1510): x [sizeQ+sizeP][N] -> out [sizeP][N], tab [sizeP][sizeQ+1] */
+void orc_approx_scale_and_round(const uint64_t* x, uint32_t sizeQ, uint32_t sizeP, uint32_t N, const uint64_t* tab,
+                                const uint64_t* p, const uint64_t* mu128, uint64_t* out);
+/* ScaleAndRoundPOverQ (:1674-1689): x [sizeQ+1][N] (last limb modulus pLast) -> out [sizeQ][N] */
+void orc_scale_and_round_p_over_q(const uint64_t* x, uint32_t sizeQ, uint32_t N, const uint64_t* q, uint64_t pLast,
+                                  const uint64_t* pInvModq, uint64_t* out);
+
+/* ---------------- a18: BEHZ (dcrtpoly-impl.h:1694-1929; tables bfvrns-cryptoparameters.cpp:673-850) ---------------- */
+typedef struct orc_behz orc_behz;
+orc_behz* orc_behz_create(uint32_t N, uint32_t numQ, const uint64_t* q, uint64_t t);
+void      orc_behz_destroy(orc_behz*);
+uint32_t  orc_behz_num_bsk(const orc_behz*);                 /* numQ + 1 */
+void      orc_behz_get_bsk(const orc_behz*, uint64_t* bsk, uint64_t* psiBsk);
+/* coefficient-domain cores (the NTTs around them are orc_ntt_*): */
+void orc_behz_q_to_bsk_montgomery(const orc_behz*, const uint64_t* xq /*[numQ][N]*/, uint64_t* outBsk /*[numBsk][N]*/);
+void orc_behz_fast_rns_floorq(const orc_behz*, uint64_t* x /*[numQ+numBsk][N], in place*/);
+void orc_behz_fast_base_conv_sk(const orc_behz*, const uint64_t* x /*[numQ+numBsk][N]*/, uint64_t* outQ /*[numQ][N]*/);
+
 #ifdef __cplusplus
 }
 #endif

@@ -411,4 +411,108 @@ void ref_ckks_decrypt(void* h, int ct, double* out, uint32_t n) {
 }
 int ref_omp_threads() { return OpenFHEParallelControls.GetNumThreads(); }
 
+// ---- ScaleAndRound family with caller tables ----
+// x is [sizeI+sizeO][N] COEFF over `moduli` (in x's limb order); output basis = first sizeO limbs if outputFirst else last sizeO
+void ref_scale_and_round(uint32_t N, uint32_t sizeI, uint32_t sizeO, int outputFirst, const uint64_t* moduli,
+                         const uint64_t* roots, const uint64_t* x, const uint64_t* tab, const double* frac, uint64_t* out) {
+    auto pAll = make_params(N, sizeI + sizeO, moduli, roots);
+    uint32_t off = outputFirst ? 0 : sizeI;
+    auto pOut = make_params(N, sizeO, moduli + off, roots + off);
+    auto X    = make_poly(pAll, x, Format::COEFFICIENT);
+    std::vector<std::vector<NativeInteger>> t(sizeO);
+    for (uint32_t j = 0; j < sizeO; ++j)
+        t[j] = vecNI(tab + (size_t)j * (sizeI + 1), sizeI + 1);
+    std::vector<double> f(frac, frac + sizeI);
+    export_poly(X.ScaleAndRound(pOut, t, f, mu128(moduli + off, sizeO)), out);
+}
+void ref_approx_scale_and_round(uint32_t N, uint32_t sizeQ, uint32_t sizeP, const uint64_t* moduli, const uint64_t* roots,
+                                const uint64_t* x, const uint64_t* tab, uint64_t* out) {
+    auto pAll = make_params(N, sizeQ + sizeP, moduli, roots);
+    auto pP   = make_params(N, sizeP, moduli + sizeQ, roots + sizeQ);
+    auto X    = make_poly(pAll, x, Format::COEFFICIENT);
+    std::vector<std::vector<NativeInteger>> t(sizeP);
+    for (uint32_t j = 0; j < sizeP; ++j)
+        t[j] = vecNI(tab + (size_t)j * (sizeQ + 1), sizeQ + 1);
+    export_poly(X.ApproxScaleAndRound(pP, t, mu128(moduli + sizeQ, sizeP)), out);
+}
+void ref_scale_and_round_p_over_q(uint32_t N, uint32_t sizeQ, const uint64_t* moduli, const uint64_t* roots,
+                                  const uint64_t* x, const uint64_t* pInvModq, uint64_t* out) {
+    auto pAll = make_params(N, sizeQ + 1, moduli, roots);
+    auto pQ   = make_params(N, sizeQ, moduli, roots);
+    auto X    = make_poly(pAll, x, Format::COEFFICIENT);
+    X.ScaleAndRoundPOverQ(pQ, vecNI(pInvModq, sizeQ));
+    export_poly(X, out);
+}
+
+// ---- BFV / BEHZ session: the reference's own CryptoParametersBFVRNS tables ----
+struct RefBfv {
+    CryptoContext<DCRTPoly> cc;
+};
+void* ref_bfv_create(uint32_t ringDim, uint64_t t, uint32_t multDepth, uint32_t scalingModSize, int multTech) {
+    CCParams<CryptoContextBFVRNS> parameters;
+    parameters.SetSecurityLevel(HEStd_NotSet);
+    parameters.SetRingDim(ringDim);
+    parameters.SetPlaintextModulus(t);
+    parameters.SetMultiplicativeDepth(multDepth);
+    parameters.SetScalingModSize(scalingModSize);
+    parameters.SetMultiplicationTechnique(static_cast<MultiplicationTechnique>(multTech));
+    auto* s = new RefBfv;
+    s->cc   = GenCryptoContext(parameters);
+    s->cc->Enable(PKE);
+    s->cc->Enable(LEVELEDSHE);
+    return s;
+}
+void ref_bfv_destroy(void* h) { delete static_cast<RefBfv*>(h); }
+// info[0]=N, [1]=numQ, [2]=numBsk
+void ref_bfv_info(void* h, uint32_t* info) {
+    const auto cp = std::dynamic_pointer_cast<CryptoParametersBFVRNS>(static_cast<RefBfv*>(h)->cc->GetCryptoParameters());
+    info[0]       = cp->GetElementParams()->GetRingDimension();
+    info[1]       = cp->GetModuliQ().size();
+    info[2]       = cp->GetModuliBsk().size();
+}
+void ref_bfv_get_moduli(void* h, uint64_t* q, uint64_t* psiQ, uint64_t* bsk, uint64_t* psiBsk) {
+    const auto cp = std::dynamic_pointer_cast<CryptoParametersBFVRNS>(static_cast<RefBfv*>(h)->cc->GetCryptoParameters());
+    const auto& P = cp->GetParamsQBsk()->GetParams();
+    size_t numQ   = cp->GetModuliQ().size();
+    for (size_t i = 0; i < P.size(); ++i) {
+        uint64_t m = P[i]->GetModulus().ConvertToInt<uint64_t>(), r = P[i]->GetRootOfUnity().ConvertToInt<uint64_t>();
+        if (i < numQ) {
+            q[i]    = m;
+            psiQ[i] = r;
+        }
+        else {
+            bsk[i - numQ]    = m;
+            psiBsk[i - numQ] = r;
+        }
+    }
+}
+// x [numQ][N] in `evalFormat` -> out [numQ+numBsk][N] EVALUATION   (dcrtpoly-impl.h:1694-1786)
+void ref_bfv_behz_q_to_bsk(void* h, const uint64_t* x, int evalFormat, uint64_t* out) {
+    const auto cp = std::dynamic_pointer_cast<CryptoParametersBFVRNS>(static_cast<RefBfv*>(h)->cc->GetCryptoParameters());
+    auto a = make_poly(cp->GetElementParams(), x, evalFormat ? Format::EVALUATION : Format::COEFFICIENT);
+    a.FastBaseConvqToBskMontgomery(cp->GetParamsQBsk(), cp->GetModuliQ(), cp->GetModuliBsk(), cp->GetModbskBarrettMu(),
+                                   cp->GetmtildeQHatInvModq(), cp->GetmtildeQHatInvModqPrecon(), cp->GetQHatModbsk(),
+                                   cp->GetQHatModmtilde(), cp->GetQModbsk(), cp->GetQModbskPrecon(),
+                                   cp->GetNegQInvModmtilde(), cp->GetmtildeInvModbsk(), cp->GetmtildeInvModbskPrecon());
+    export_poly(a, out);
+}
+// x [numQ+numBsk][N] COEFFICIENT, in place   (dcrtpoly-impl.h:1791-1840)
+void ref_bfv_fast_rns_floorq(void* h, uint64_t* x) {
+    const auto cp = std::dynamic_pointer_cast<CryptoParametersBFVRNS>(static_cast<RefBfv*>(h)->cc->GetCryptoParameters());
+    auto a = make_poly(cp->GetParamsQBsk(), x, Format::COEFFICIENT);
+    a.FastRNSFloorq(cp->GetPlaintextModulus(), cp->GetModuliQ(), cp->GetModuliBsk(), cp->GetModbskBarrettMu(),
+                    cp->GettQHatInvModq(), cp->GettQHatInvModqPrecon(), cp->GetQHatModbsk(), cp->GetqInvModbsk(),
+                    cp->GettQInvModbsk(), cp->GettQInvModbskPrecon());
+    export_poly(a, x);
+}
+// x [numQ+numBsk][N] COEFFICIENT -> out [numQ][N]   (dcrtpoly-impl.h:1845-1929)
+void ref_bfv_fast_base_conv_sk(void* h, const uint64_t* x, uint64_t* out) {
+    const auto cp = std::dynamic_pointer_cast<CryptoParametersBFVRNS>(static_cast<RefBfv*>(h)->cc->GetCryptoParameters());
+    auto a = make_poly(cp->GetParamsQBsk(), x, Format::COEFFICIENT);
+    a.FastBaseConvSK(cp->GetElementParams(), cp->GetModqBarrettMu(), cp->GetModuliBsk(), cp->GetModbskBarrettMu(),
+                     cp->GetBHatInvModb(), cp->GetBHatInvModbPrecon(), cp->GetBHatModmsk(), cp->GetBInvModmsk(),
+                     cp->GetBInvModmskPrecon(), cp->GetBHatModq(), cp->GetBModq(), cp->GetBModqPrecon());
+    export_poly(a, out);
+}
+
 }  // extern "C"

@@ -97,6 +97,16 @@ def load_oracle():
     S("orc_ckks_eval_mult_relin", None, [vp, P64, P64, P64, P64, u32, P64, P64, P64, P64])
     S("orc_drop_last_element_and_scale", None, [vp, P64, u32, P64])
     S("orc_rescale_tables", None, [vp, u32, P64, P64])
+    S("orc_scale_and_round", None, [P64, u32, u32, u32, C.c_int, P64, PF64, P64, P64, P64])
+    S("orc_approx_scale_and_round", None, [P64, u32, u32, u32, P64, P64, P64, P64])
+    S("orc_scale_and_round_p_over_q", None, [P64, u32, u32, P64, u64, P64, P64])
+    S("orc_behz_create", vp, [u32, u32, P64, u64])
+    S("orc_behz_destroy", None, [vp])
+    S("orc_behz_num_bsk", u32, [vp])
+    S("orc_behz_get_bsk", None, [vp, P64, P64])
+    S("orc_behz_q_to_bsk_montgomery", None, [vp, P64, P64])
+    S("orc_behz_fast_rns_floorq", None, [vp, P64])
+    S("orc_behz_fast_base_conv_sk", None, [vp, P64, P64])
     _oracle = L
     return L
 
@@ -157,6 +167,16 @@ def load_ref():
     S("ref_ckks_time_eval_mult", C.c_double, [vp, C.c_int, C.c_int, C.c_int])
     S("ref_ckks_decrypt", None, [vp, C.c_int, PF64, u32])
     S("ref_omp_threads", C.c_int, [])
+    S("ref_scale_and_round", None, [u32, u32, u32, C.c_int, P64, P64, P64, P64, PF64, P64])
+    S("ref_approx_scale_and_round", None, [u32, u32, u32, P64, P64, P64, P64, P64])
+    S("ref_scale_and_round_p_over_q", None, [u32, u32, P64, P64, P64, P64, P64])
+    S("ref_bfv_create", vp, [u32, u64, u32, u32, C.c_int])
+    S("ref_bfv_destroy", None, [vp])
+    S("ref_bfv_info", None, [vp, P32])
+    S("ref_bfv_get_moduli", None, [vp, P64, P64, P64, P64])
+    S("ref_bfv_behz_q_to_bsk", None, [vp, P64, C.c_int, P64])
+    S("ref_bfv_fast_rns_floorq", None, [vp, P64])
+    S("ref_bfv_fast_base_conv_sk", None, [vp, P64, P64])
     _ref = L
     return L
 

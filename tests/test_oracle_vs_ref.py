@@ -160,3 +160,84 @@ def test_ckks_eval_mult_keyswitch_against_live_reference(oracle, ref):
     o.orc_ctx_destroy(octx)
     o.orc_hybrid_destroy(hy)
     r.ref_ckks_destroy(h)
+
+
+@pytest.mark.parametrize("ring,t,depth,sms", [(16, 65537, 2, 60), (64, 65537, 3, 55), (1024, 786433, 4, 60)])
+def test_behz_against_live_reference(oracle, ref, ring, t, depth, sms):
+    """the reference's own CryptoParametersBFVRNS tables + DCRTPoly BEHZ members vs the oracle's derived tables"""
+    o, r = oracle, ref
+    rng = np.random.default_rng(41)
+    h = r.ref_bfv_create(ring, t, depth, sms, 0)  # MultiplicationTechnique BEHZ = 0
+    info = np.zeros(3, np.uint32)
+    r.ref_bfv_info(h, info)
+    N, numQ, numBsk = map(int, info)
+    q, pq = np.zeros(numQ, np.uint64), np.zeros(numQ, np.uint64)
+    bsk, pb = np.zeros(numBsk, np.uint64), np.zeros(numBsk, np.uint64)
+    r.ref_bfv_get_moduli(h, q, pq, bsk, pb)
+    hb = o.orc_behz_create(N, numQ, q, t)
+    b2, p2 = np.zeros(numBsk, np.uint64), np.zeros(numBsk, np.uint64)
+    o.orc_behz_get_bsk(hb, b2, p2)
+    assert np.array_equal(b2, bsk) and np.array_equal(p2, pb)
+    x = libs.rand_tower(rng, q, N)
+    want = np.zeros((numQ + numBsk, N), np.uint64)
+    r.ref_bfv_behz_q_to_bsk(h, x, 0, want)
+    got = np.zeros((numBsk, N), np.uint64)
+    o.orc_behz_q_to_bsk_montgomery(hb, x, got)
+    cb = o.orc_ctx_create(N, numBsk, bsk, pb)
+    o.orc_ntt_fwd_tower(cb, got, None, numBsk, 1, 1)
+    assert np.array_equal(got, want[numQ:])
+    allm = np.concatenate([q, bsk])
+    y = libs.rand_tower(rng, allm, N)
+    y2 = y.copy()
+    r.ref_bfv_fast_rns_floorq(h, y)
+    o.orc_behz_fast_rns_floorq(hb, y2)
+    assert np.array_equal(y, y2)
+    z = libs.rand_tower(rng, allm, N)
+    w, w2 = np.zeros((numQ, N), np.uint64), np.zeros((numQ, N), np.uint64)
+    r.ref_bfv_fast_base_conv_sk(h, z, w)
+    o.orc_behz_fast_base_conv_sk(hb, z, w2)
+    assert np.array_equal(w, w2)
+    o.orc_ctx_destroy(cb)
+    o.orc_behz_destroy(hb)
+    r.ref_bfv_destroy(h)
+
+
+@pytest.mark.parametrize("sizeI,sizeO,outputFirst,fscale", [(3, 2, 1, 1.0), (4, 3, 0, 1.0), (3, 2, 1, 2.0 ** 70), (2, 3, 0, 32.0)])
+def test_scale_and_round_against_live_reference(oracle, ref, sizeI, sizeO, outputFirst, fscale):
+    o, r = oracle, ref
+    rng = np.random.default_rng(42)
+    N, L = 64, sizeI + sizeO
+    q, psi = np.zeros(L, np.uint64), np.zeros(L, np.uint64)
+    o.orc_dcrt_params(2 * N, L, 60, q, psi)
+    x = libs.rand_tower(rng, q, N)
+    off = 0 if outputFirst else sizeI
+    om = q[off:off + sizeO].copy()
+    tab = np.stack([rng.integers(0, int(m), size=sizeI + 1, dtype=np.uint64) for m in om])
+    frac = rng.random(sizeI) * fscale
+    mu = np.zeros((sizeO, 2), np.uint64)
+    for j in range(sizeO):
+        t = np.zeros(2, np.uint64)
+        o.orc_barrett_mu128(int(om[j]), t)
+        mu[j] = t
+    want, got = np.zeros((sizeO, N), np.uint64), np.zeros((sizeO, N), np.uint64)
+    r.ref_scale_and_round(N, sizeI, sizeO, outputFirst, q, psi, x, tab, frac, want)
+    o.orc_scale_and_round(x, sizeI, sizeO, N, outputFirst, tab, frac, om, mu, got)
+    assert np.array_equal(want, got)
+    if not outputFirst:
+        r.ref_approx_scale_and_round(N, sizeI, sizeO, q, psi, x, tab, want)
+        o.orc_approx_scale_and_round(x, sizeI, sizeO, N, tab, om, mu, got)
+        assert np.array_equal(want, got)
+
+
+def test_scale_and_round_p_over_q_against_live_reference(oracle, ref):
+    o, r = oracle, ref
+    rng = np.random.default_rng(43)
+    N, sizeQ = 64, 3
+    q, psi = np.zeros(sizeQ + 1, np.uint64), np.zeros(sizeQ + 1, np.uint64)
+    o.orc_dcrt_params(2 * N, sizeQ + 1, 50, q, psi)
+    x = libs.rand_tower(rng, q, N)
+    pinv = np.array([pow(int(q[sizeQ]), -1, int(q[i])) for i in range(sizeQ)], np.uint64)
+    want, got = np.zeros((sizeQ, N), np.uint64), np.zeros((sizeQ, N), np.uint64)
+    r.ref_scale_and_round_p_over_q(N, sizeQ, q, psi, x, pinv, want)
+    o.orc_scale_and_round_p_over_q(x, sizeQ, N, q[:sizeQ].copy(), int(q[sizeQ]), pinv, got)
+    assert np.array_equal(want, got)

@@ -1,0 +1,123 @@
+"""Parity of the BFV-side kernels (ScaleAndRound family, BEHZ trio) against the oracle; emulator on CPU,
+the HIP library with -m gpu.  Bit-exact, including ScaleAndRound's double-precision rounding term."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import libs
+from openfhe_amd import fhe_hip as fh
+from test_parity import params
+
+
+def mu128(o, mods):
+    out = np.zeros((len(mods), 2), np.uint64)
+    for j, m in enumerate(mods):
+        t = np.zeros(2, np.uint64)
+        o.orc_barrett_mu128(int(m), t)
+        out[j] = t
+    return out
+
+
+@pytest.mark.parametrize("logN,sizeI,sizeO,outputFirst,fscale,B",
+                         [(6, 3, 2, 1, 1.0, 2), (10, 4, 3, 0, 1.0, 1), (12, 3, 2, 1, 2.0 ** 70, 1), (12, 7, 8, 0, 1.0, 2)])
+def test_scale_and_round(backend, oracle, logN, sizeI, sizeO, outputFirst, fscale, B):
+    o = oracle
+    N, L = 1 << logN, sizeI + sizeO
+    rng = np.random.default_rng(21)
+    q, psi = params(o, logN, L)
+    ctx = fh.Context(backend, logN, q, psi)
+    off = 0 if outputFirst else sizeI
+    out_idx = np.arange(off, off + sizeO, dtype=np.uint32)
+    om = q[off:off + sizeO].copy()
+    tab = np.stack([rng.integers(0, int(m), size=sizeI + 1, dtype=np.uint64) for m in om])
+    frac = rng.random(sizeI) * fscale
+    x = libs.rand_tower(rng, q, N, B)
+    x[0, :, 0] = 0
+    x[0, :, 1] = q - np.uint64(1)
+    want = np.zeros((B, sizeO, N), np.uint64)
+    for b in range(B):
+        o.orc_scale_and_round(x[b], sizeI, sizeO, N, outputFirst, tab, frac, om, mu128(o, om), want[b])
+    plan = fh.ScaleAndRoundPlan(ctx, sizeI, out_idx, tab, frac)
+    assert np.array_equal(plan.run(ctx.tower(x, fmt=fh.COEFFICIENT), outputFirst).to_host(), want)
+    plan.close()
+    if not outputFirst:  # ApproxScaleAndRound: input basis first, output basis last, no fractional part
+        wanta = np.zeros((B, sizeO, N), np.uint64)
+        for b in range(B):
+            o.orc_approx_scale_and_round(x[b], sizeI, sizeO, N, tab, om, mu128(o, om), wanta[b])
+        plana = fh.ScaleAndRoundPlan(ctx, sizeI, out_idx, tab, None)
+        assert np.array_equal(plana.run(ctx.tower(x, fmt=fh.COEFFICIENT), 0).to_host(), wanta)
+        plana.close()
+    ctx.close()
+
+
+def test_scale_and_round_p_over_q(backend, oracle):
+    o = oracle
+    rng = np.random.default_rng(22)
+    for logN, sizeQ, bits, B in [(5, 2, 40, 2), (12, 4, 60, 1)]:
+        N = 1 << logN
+        q, psi = params(o, logN, sizeQ + 1, bits)
+        ctx = fh.Context(backend, logN, q, psi)
+        x = libs.rand_tower(rng, q, N, B)
+        pinv = np.array([pow(int(q[sizeQ]), -1, int(q[i])) for i in range(sizeQ)], np.uint64)
+        want = np.zeros((B, sizeQ, N), np.uint64)
+        for b in range(B):
+            o.orc_scale_and_round_p_over_q(x[b], sizeQ, N, q[:sizeQ].copy(), int(q[sizeQ]), pinv, want[b])
+        got = fh.scale_and_round_p_over_q(ctx, ctx.tower(x, fmt=fh.COEFFICIENT), np.arange(sizeQ + 1)).to_host()
+        assert np.array_equal(got, want)
+        ctx.close()
+
+
+def behz_setup(lib, o, logN, numQ, t, bits=60):
+    N = 1 << logN
+    q, psiQ = params(o, logN, numQ, bits)
+    hb = o.orc_behz_create(N, numQ, q, t)
+    nb = o.orc_behz_num_bsk(hb)
+    bsk, psiB = np.zeros(nb, np.uint64), np.zeros(nb, np.uint64)
+    o.orc_behz_get_bsk(hb, bsk, psiB)
+    b2, p2 = lib.behz_bsk(logN, q, t)  # product-side selection of the Bsk basis
+    assert np.array_equal(b2, bsk) and np.array_equal(p2, psiB)
+    ctx = fh.Context(lib, logN, np.concatenate([q, bsk]), np.concatenate([psiQ, psiB]))
+    plan = fh.Behz(ctx, np.arange(numQ), np.arange(numQ, numQ + nb), t)
+    return N, q, psiQ, bsk, psiB, hb, ctx, plan
+
+
+@pytest.mark.parametrize("logN,numQ,t,B", [(4, 2, 65537, 2), (10, 3, 65537, 2), (12, 6, 786433, 1)])
+def test_behz_trio(backend, oracle, logN, numQ, t, B):
+    o = oracle
+    rng = np.random.default_rng(23)
+    N, q, psiQ, bsk, psiB, hb, ctx, plan = behz_setup(backend, o, logN, numQ, t)
+    nb = len(bsk)
+    octxQ = o.orc_ctx_create(N, numQ, q, psiQ)
+    octxB = o.orc_ctx_create(N, nb, bsk, psiB)
+    x = libs.rand_tower(rng, q, N, B)
+    for eval_fmt in (False, True):
+        xc = x.copy()
+        if eval_fmt:  # oracle: to COEFFICIENT first (dcrtpoly-impl.h:1708-1712)
+            o.orc_ntt_inv_tower(octxQ, xc, None, numQ, B, 1)
+        want_b = np.zeros((B, nb, N), np.uint64)
+        for b in range(B):
+            o.orc_behz_q_to_bsk_montgomery(hb, xc[b], want_b[b])
+        o.orc_ntt_fwd_tower(octxB, want_b, None, nb, B, 1)
+        want_q = x.copy()
+        if not eval_fmt:
+            o.orc_ntt_fwd_tower(octxQ, want_q, None, numQ, B, 1)
+        got = plan.FastBaseConvqToBskMontgomery(x, eval_fmt).to_host()
+        assert np.array_equal(got[:, :numQ], want_q) and np.array_equal(got[:, numQ:], want_b), f"q->Bsk eval={eval_fmt}"
+    allm = np.concatenate([q, bsk])
+    y = libs.rand_tower(rng, allm, N, B)
+    wy = y.copy()
+    for b in range(B):
+        o.orc_behz_fast_rns_floorq(hb, wy[b])
+    ty = ctx.tower(y, limb_idx=np.arange(numQ + nb), fmt=fh.COEFFICIENT)
+    assert np.array_equal(plan.FastRNSFloorq(ty).to_host(), wy), "FastRNSFloorq"
+    z = libs.rand_tower(rng, allm, N, B)
+    wz = np.zeros((B, numQ, N), np.uint64)
+    for b in range(B):
+        o.orc_behz_fast_base_conv_sk(hb, z[b], wz[b])
+    tz = ctx.tower(z, limb_idx=np.arange(numQ + nb), fmt=fh.COEFFICIENT)
+    assert np.array_equal(plan.FastBaseConvSK(tz).to_host(), wz), "FastBaseConvSK"
+    plan.close()
+    ctx.close()
+    o.orc_behz_destroy(hb)
