@@ -21,7 +21,7 @@ def mu128(o, mods):
 
 
 @pytest.mark.parametrize("logN,sizeI,sizeO,outputFirst,fscale,B",
-                         [(6, 3, 2, 1, 1.0, 2), (10, 4, 3, 0, 1.0, 1), (12, 3, 2, 1, 2.0 ** 70, 1), (12, 7, 8, 0, 1.0, 2)])
+                         [(6, 3, 2, 1, 1.0, 2), (10, 4, 3, 0, 1.0, 1), (12, 3, 2, 1, 2.0 ** 60, 1), (12, 7, 8, 0, 1.0, 2)])
 def test_scale_and_round(backend, oracle, logN, sizeI, sizeO, outputFirst, fscale, B):
     o = oracle
     N, L = 1 << logN, sizeI + sizeO
