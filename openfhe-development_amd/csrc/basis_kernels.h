@@ -43,7 +43,10 @@ struct ConvArgs {
     uint32_t inStride, inFirst, outStride, outFirst;
 };
 
-template <int OUT_CHUNK, bool EXACT>
+// NSRC = compile-time upper bound of the number of source limbs (8 or 16): y_i live in registers, the output limbs
+// are produced one at a time with a column-wise multiply-accumulate (mac192), so the kernel needs few registers
+// (high occupancy) and computes every y_i once.
+template <int NSRC, bool EXACT>
 FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) switch_basis_kernel(const ConvArgs g) {
     const uint32_t N     = 1u << g.logN;
     const uint64_t gid   = (uint64_t)FHE_BID * kThreads + FHE_TID;  // over batch*N coefficients
@@ -54,44 +57,36 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) switch_basis_kernel(const ConvArgs g
     const uint64_t* in = g.in + (((uint64_t)b * g.inStride + g.inFirst) << g.logN) + ri;
     uint64_t* out      = g.out + (((uint64_t)b * g.outStride + g.outFirst) << g.logN) + ri;
 
+    uint64_t y[NSRC];
     // overflow count of the exact variant: nu = 0.5 + sum_i y_i/q_i in double, i ascending, one rounding per
     // multiply and per add (dcrtpoly-impl.h:1056-1063); compiled with -ffp-contract=off
-    uint32_t alpha = 0;
-    if (EXACT) {
-        double nu = 0.5;
-        for (uint32_t i = 0; i < g.nSrc; ++i) {
-            const TwPair h   = g.tb.hatInv[i];
-            const uint64_t y = mul_shoup(in[(uint64_t)i << g.logN], h.w, h.wp, g.tb.srcQ[i]);
-            nu += (double)y * g.tb.srcQInv[i];
+    double nu = 0.5;
+#pragma unroll
+    for (int i = 0; i < NSRC; ++i) {
+        y[i] = 0;
+        if (i < (int)g.nSrc) {
+            const TwPair h = g.tb.hatInv[i];
+            y[i]           = mul_shoup(in[(uint64_t)i << g.logN], h.w, h.wp, g.tb.srcQ[i]);
+            if (EXACT)
+                nu += (double)y[i] * g.tb.srcQInv[i];
         }
-        alpha = (uint32_t)nu;
     }
+    const uint32_t alpha = EXACT ? (uint32_t)nu : 0u;
 
-    for (uint32_t j0 = 0; j0 < g.nDst; j0 += OUT_CHUNK) {
-        u128w acc[OUT_CHUNK];
+    for (uint32_t j = 0; j < g.nDst; ++j) {
+        mac192 m;
+        mac192_clear(m);
 #pragma unroll
-        for (int jj = 0; jj < OUT_CHUNK; ++jj)
-            acc[jj] = u128w{0, 0};
-        for (uint32_t i = 0; i < g.nSrc; ++i) {
-            const TwPair h       = g.tb.hatInv[i];
-            const uint64_t y     = mul_shoup(in[(uint64_t)i << g.logN], h.w, h.wp, g.tb.srcQ[i]);
-            const uint64_t* hrow = g.tb.hatMod + (uint64_t)i * g.nDst + j0;
-#pragma unroll
-            for (int jj = 0; jj < OUT_CHUNK; ++jj)
-                if (j0 + jj < g.nDst)
-                    acc128(acc[jj], y, hrow[jj]);
-        }
-#pragma unroll
-        for (int jj = 0; jj < OUT_CHUNK; ++jj) {
-            const uint32_t j = j0 + jj;
-            if (j < g.nDst) {
-                const uint64_t p = g.tb.dstQ[j];
-                uint64_t v       = barrett128(acc[jj], p, g.tb.dstMu[2 * j], g.tb.dstMu[2 * j + 1]);
-                if (EXACT)
-                    v = sub_mod(v, g.tb.alphaMod[(uint64_t)alpha * g.nDst + j], p);
-                out[(uint64_t)j << g.logN] = v;
-            }
-        }
+        for (int i = 0; i < NSRC; ++i)
+            if (i < (int)g.nSrc)
+                mac192_add(m, y[i], g.tb.hatMod[(uint64_t)i * g.nDst + j]);
+        u128w acc;
+        mac192_fold(m, acc.lo, acc.hi);
+        const uint64_t p = g.tb.dstQ[j];
+        uint64_t v       = barrett128(acc, p, g.tb.dstMu[2 * j], g.tb.dstMu[2 * j + 1]);
+        if (EXACT)
+            v = sub_mod(v, g.tb.alphaMod[(uint64_t)alpha * g.nDst + j], p);
+        out[(uint64_t)j << g.logN] = v;
     }
 }
 
@@ -133,7 +128,9 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ks_inner_product_kernel(const KsInne
     const uint32_t N    = 1u << g.logN;
     const uint32_t rEnd = ((tr + 1u) << kTileLog) < N ? ((tr + 1u) << kTileLog) : N;
     for (uint32_t r = (tr << kTileLog) + t; r < rEnd; r += kThreads) {
-        u128w s0{0, 0}, s1{0, 0};
+        mac192 s0, s1;
+        mac192_clear(s0);
+        mac192_clear(s1);
         for (uint32_t j = 0; j < g.numDigits; ++j) {
             const uint32_t start = j * g.alpha;
             const uint32_t sz    = sizeQlP - g.nc[j];
@@ -145,12 +142,15 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ks_inner_product_kernel(const KsInne
                 d = g.digits[j][(((uint64_t)b * g.nc[j] + pos) << g.logN) + r];
             }
             const uint64_t koff = (((uint64_t)j * (g.sizeQ + g.sizeP) + idx) << g.logN) + r;
-            acc128(s0, d, g.keyB[koff]);
-            acc128(s1, d, g.keyA[koff]);
+            mac192_add(s0, d, g.keyB[koff]);
+            mac192_add(s1, d, g.keyA[koff]);
         }
         const uint64_t ooff = (((uint64_t)b * sizeQlP + i) << g.logN) + r;
-        g.out0[ooff]        = barrett128(s0, lc.q, mulo, muhi);
-        g.out1[ooff]        = barrett128(s1, lc.q, mulo, muhi);
+        u128w a0, a1;
+        mac192_fold(s0, a0.lo, a0.hi);
+        mac192_fold(s1, a1.lo, a1.hi);
+        g.out0[ooff] = barrett128(a0, lc.q, mulo, muhi);
+        g.out1[ooff] = barrett128(a1, lc.q, mulo, muhi);
     }
 }
 

@@ -35,6 +35,7 @@ enum ElemOp : int {
     OP_MUL_CONST_ADD = 6,  // out = a * c[row] + b     (DropLastElementAndScale tail, :707-708)
     OP_MULT_ACC = 7,   // out = out + a * b        (inner-product accumulate)
     OP_COPY = 8,
+    OP_SUB_MUL_CONST_ACC = 9,  // out = out + (a - b) * c[row]   (ApproxModDown tail fused with EvalMult's `+= ks`)
 };
 
 struct ElemArgs {
@@ -69,6 +70,8 @@ FHE_HD uint64_t elem_apply(uint64_t o, uint64_t a, uint64_t b, const LimbConst l
             return add_mod(mul_shoup(a, c.w, c.wp, q), b, q);
         case OP_MULT_ACC:
             return add_mod(o, mul_mod_barrett(a, b, q, lc.mu, (int)lc.msb), q);
+        case OP_SUB_MUL_CONST_ACC:
+            return add_mod(o, mul_shoup(sub_mod(a, b, q), c.w, c.wp, q), q);
         default:
             return a;
     }
@@ -80,9 +83,9 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) elemwise_kernel(const ElemArgs g) {
     const uint64_t base       = (uint64_t)FHE_BID << kTileLog;
     const uint64_t totalWords = (uint64_t)g.rows << g.logN;
     constexpr bool needB = (OP == OP_ADD || OP == OP_SUB || OP == OP_MUL || OP == OP_SUB_MUL_CONST ||
-                            OP == OP_MUL_CONST_ADD || OP == OP_MULT_ACC);
-    constexpr bool needC = (OP == OP_MUL_CONST || OP == OP_SUB_MUL_CONST || OP == OP_MUL_CONST_ADD);
-    constexpr bool needO = (OP == OP_MULT_ACC);
+                            OP == OP_MUL_CONST_ADD || OP == OP_MULT_ACC || OP == OP_SUB_MUL_CONST_ACC);
+    constexpr bool needC = (OP == OP_MUL_CONST || OP == OP_SUB_MUL_CONST || OP == OP_MUL_CONST_ADD || OP == OP_SUB_MUL_CONST_ACC);
+    constexpr bool needO = (OP == OP_MULT_ACC || OP == OP_SUB_MUL_CONST_ACC);
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         const uint64_t off = base + (((uint64_t)m * kThreads + t) << 1);

@@ -216,6 +216,7 @@ extern "C" uint32_t fhe_param_select_p(uint32_t logN, uint32_t sizeQ, const uint
 static uint32_t env_u32(const char* name, uint32_t dflt);
 static bool ntt_generic();
 static uint32_t ntt_stagger();
+static bool ntt_legacy();
 
 // ------------------------------------------------------------------------------------------------
 // context
@@ -521,6 +522,22 @@ static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse
         LAUNCH_CHECK();
         return FHE_OK;
     }
+    if (c->logN >= (uint32_t)kTileLog && !ntt_legacy()) {
+        if (pp.layoutA) {
+            if (inverse)
+                FHE_LAUNCH((ntt_pass_full_kernel<true, true>), grid, stream, a);
+            else
+                FHE_LAUNCH((ntt_pass_full_kernel<true, false>), grid, stream, a);
+        }
+        else {
+            if (inverse)
+                FHE_LAUNCH((ntt_pass_full_kernel<false, true>), grid, stream, a);
+            else
+                FHE_LAUNCH((ntt_pass_full_kernel<false, false>), grid, stream, a);
+        }
+        LAUNCH_CHECK();
+        return FHE_OK;
+    }
     if (pp.layoutA) {
         if (inverse)
             FHE_LAUNCH((ntt_pass_kernel<true, true>), grid, stream, a);
@@ -555,6 +572,13 @@ static bool ntt_generic() {
     // per SIMD and measured 20 % slower than the one-tile-per-workgroup kernel on MI355X (profiles/r01_*), so
     // it is opt-in (FHE_NTT_FAST=1) until its register budget is fixed
     static const uint32_t v = env_u32("FHE_NTT_FAST", 0);
+    return v == 0;
+}
+static bool ntt_legacy() {
+    // ntt_pass_full_kernel (lazy-reduction schedule + folded butterfly) is bit-exact but measured 3-5 % slower than
+    // the generic kernel on MI355X (profiles/r01_sweeps.md: hipcc adds ~13 v_mov per butterfly around the
+    // multiply-add chain), so the generic kernel stays the default; FHE_NTT_FULL=1 selects the other one
+    static const uint32_t v = env_u32("FHE_NTT_FULL", 0);
     return v == 0;
 }
 static uint32_t ntt_stagger() {
@@ -882,7 +906,7 @@ static fhe_status conv_build(fhe_ctx* c, const std::vector<uint64_t>& src, const
 extern "C" fhe_status fhe_conv_create(fhe_ctx* c, const uint32_t* srcIdx, uint32_t nSrc, const uint32_t* dstIdx,
                                       uint32_t nDst, fhe_conv** out) {
     ARG_CHECK(c && srcIdx && dstIdx && out, "fhe_conv_create: null argument");
-    ARG_CHECK(nSrc >= 1 && nSrc <= 64 && nDst >= 1 && nDst <= (uint32_t)kMaxLimbs, "fhe_conv_create: bad basis size");
+    ARG_CHECK(nSrc >= 1 && nSrc <= 32 && nDst >= 1 && nDst <= (uint32_t)kMaxLimbs, "fhe_conv_create: bad basis size");
     std::vector<uint64_t> src(nSrc), dst(nDst);
     for (uint32_t i = 0; i < nSrc; ++i) {
         ARG_CHECK(srcIdx[i] < c->L, "fhe_conv_create: source limb exceeds context size");
@@ -916,12 +940,12 @@ static fhe_status conv_run(fhe_conv* cv, const uint64_t* in, uint32_t inStride, 
     g.inStride = inStride, g.inFirst = inFirst, g.outStride = outStride, g.outFirst = outFirst;
     const uint64_t coeffs = (uint64_t)batch << g.logN;
     const uint32_t grid   = (uint32_t)((coeffs + kThreads - 1) / kThreads);
-    if (cv->nDst <= 8)
+    if (cv->nSrc <= 8)
         FHE_LAUNCH((switch_basis_kernel<8, EXACT>), grid, st, g);
-    else if (cv->nDst <= 16)
+    else if (cv->nSrc <= 16)
         FHE_LAUNCH((switch_basis_kernel<16, EXACT>), grid, st, g);
     else
-        FHE_LAUNCH((switch_basis_kernel<24, EXACT>), grid, st, g);
+        FHE_LAUNCH((switch_basis_kernel<32, EXACT>), grid, st, g);
     LAUNCH_CHECK();
     return FHE_OK;
 }
@@ -1139,32 +1163,46 @@ extern "C" size_t fhe_ks_workspace_bytes(const fhe_ks_plan* p, uint32_t sizeQl, 
     return ks_layout(p, sizeQl, batch).total * 8;
 }
 
-// ApproxModDown for nTow towers x[nTow][sizeQl+sizeP][N] -> out[nTow][sizeQl][N]   (dcrtpoly-impl.h:966-1005)
-// extra (may be null): added to the result (fuses the final `+= ks` of EvalMult, base-leveledshe.cpp:210-211)
-static fhe_status mod_down_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const uint64_t* x, uint32_t nTow, uint64_t* out,
-                               uint64_t* pcoef, uint64_t* md, void* st) {
+// ApproxModDown (dcrtpoly-impl.h:966-1005) in two parts so that the two accumulators of a key switch share the
+// INTT / conversion / NTT launches:
+//   mod_down_core: x[nTow][sizeQl+sizeP][N] -> md[nTow][sizeQl][N] = NTT(ApproxSwitchCRTBasis(INTT(P part)))
+//   mod_down_tail: out_i = (x_i - md_i) * [P^-1]_{q_i}     (or out_i += ... when `accumulate`)
+static fhe_status mod_down_core(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const uint64_t* x, uint32_t nTow, uint64_t* pcoef,
+                                uint64_t* md, void* st) {
     fhe_ctx* c            = p->ctx;
     const uint32_t sizeQl = lv->sizeQl, sizeP = p->sizeP, sizeQlP = sizeQl + sizeP;
-    // 1. P part to COEFFICIENT (:978-985): INTT of rows [sizeQl, sizeQl+sizeP) of every tower, written densely
     std::vector<uint32_t> pIdx(sizeP);
     for (uint32_t j = 0; j < sizeP; ++j)
         pIdx[j] = p->sizeQ + j;
+    // P part to COEFFICIENT (:978-985): INTT of rows [sizeQl, sizeQl+sizeP) of every tower, written densely
     if (fhe_status s = ntt_run(c, true, x, pcoef, pIdx.data(), sizeP, nTow, st, sizeQlP, sizeQl))
         return s;
-    // 2. P -> Q_l (:987-988)
+    // P -> Q_l (:987-988)
     if (fhe_status s = fhe_approx_switch_basis(lv->down, pcoef, sizeP, 0, md, sizeQl, 0, nTow, st))
         return s;
-    // 3. back to EVALUATION (:1001)
-    if (fhe_status s = fhe_ntt_fwd(c, md, nullptr, sizeQl, nTow, st))
+    // back to EVALUATION (:1001)
+    return fhe_ntt_fwd(c, md, nullptr, sizeQl, nTow, st);
+}
+static fhe_status mod_down_tail(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const uint64_t* x, const uint64_t* md, uint32_t nTow,
+                                uint64_t* out, bool accumulate, void* st) {
+    const uint32_t sizeQl = lv->sizeQl, sizeQlP = sizeQl + p->sizeP;
+    // (:1002); x towers are sizeQlP rows apart
+    if (accumulate)
+        return elem_run<OP_SUB_MUL_CONST_ACC>(p->ctx, out, x, md, lv->d_PInv, nullptr, sizeQl, nTow, st, "fhe_approx_mod_down",
+                                              sizeQlP, 0);
+    return elem_run<OP_SUB_MUL_CONST>(p->ctx, out, x, md, lv->d_PInv, nullptr, sizeQl, nTow, st, "fhe_approx_mod_down", sizeQlP, 0);
+}
+static fhe_status mod_down_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const uint64_t* x, uint32_t nTow, uint64_t* out,
+                               uint64_t* pcoef, uint64_t* md, void* st) {
+    if (fhe_status s = mod_down_core(p, lv, x, nTow, pcoef, md, st))
         return s;
-    // 4. out_i = (x_i - md_i) * [P^-1]_{q_i} (:1002); x towers are sizeQlP rows apart
-    return elem_run<OP_SUB_MUL_CONST>(c, out, x, md, lv->d_PInv, nullptr, sizeQl, nTow, st, "fhe_approx_mod_down",
-                                      sizeQlP, 0);
+    return mod_down_tail(p, lv, x, md, nTow, out, false, st);
 }
 
+// accumulate: out0/out1 += key-switch result (EvalMult's `cv[0] += ab[0]; cv[1] += ab[1]`, base-leveledshe.cpp:210-211)
 static fhe_status keyswitch_run(fhe_ks_plan* p, const fhe_ks_key* key, const uint64_t* cin, uint32_t sizeQl,
                                 uint32_t batch, uint64_t* out0, uint64_t* out1, uint64_t* ws, const KsLayout& w,
-                                void* st) {
+                                void* st, bool accumulate = false) {
     fhe_ctx* c = p->ctx;
     fhe_ks_plan::Level* lv = nullptr;
     if (fhe_status s = ks_level(p, sizeQl, &lv))
@@ -1197,11 +1235,13 @@ static fhe_status keyswitch_run(fhe_ks_plan* p, const fhe_ks_key* key, const uin
     const uint32_t tilesPerRow = c->N >= (uint32_t)kTile ? (c->N >> kTileLog) : 1u;
     FHE_LAUNCH(ks_inner_product_kernel, (uint64_t)batch * tilesPerRow * sizeQlP, st, g);
     LAUNCH_CHECK();
-    // 2 x ApproxModDown (:381-400): e0 and e1 are adjacent in the workspace -> one batch of 2*batch towers
-    //    (w.e1 == w.e0 + batch*sizeQlP*N by construction)
-    if (fhe_status s = mod_down_run(p, lv, ws + w.e0, batch, out0, ws + w.pcoef, ws + w.md, st))
+    // 2 x ApproxModDown (:381-400): e0 and e1 are adjacent in the workspace (w.e1 == w.e0 + batch*sizeQlP*N), so the
+    // INTT / conversion / NTT run once over 2*batch towers; only the element-wise tails are per accumulator
+    if (fhe_status s = mod_down_core(p, lv, ws + w.e0, 2 * batch, ws + w.pcoef, ws + w.md, st))
         return s;
-    return mod_down_run(p, lv, ws + w.e1, batch, out1, ws + w.pcoef, ws + w.md, st);
+    if (fhe_status s = mod_down_tail(p, lv, ws + w.e0, ws + w.md, batch, out0, accumulate, st))
+        return s;
+    return mod_down_tail(p, lv, ws + w.e1, ws + w.md + ((size_t)batch * sizeQl << c->logN), batch, out1, accumulate, st);
 }
 
 extern "C" fhe_status fhe_keyswitch_hybrid(fhe_ks_plan* p, const fhe_ks_key* key, const uint64_t* cin, uint32_t sizeQl,
@@ -1230,13 +1270,8 @@ extern "C" fhe_status fhe_ckks_eval_mult(fhe_ks_plan* p, const fhe_ks_key* key, 
     // EvalMultCore (base-leveledshe.cpp:607-644)
     if (fhe_status s = fhe_tensor(c, a0, a1, b0, b1, c0, c1, ws + w.d2, nullptr, sizeQl, batch, st))
         return s;
-    // KeySwitchCore on d2 (:207)
-    if (fhe_status s = keyswitch_run(p, key, ws + w.d2, sizeQl, batch, ws + w.k0, ws + w.k1, ws, w, st))
-        return s;
-    // cv[0] += ab[0]; cv[1] += ab[1]  (:210-211)
-    if (fhe_status s = fhe_add(c, c0, c0, ws + w.k0, nullptr, sizeQl, batch, st))
-        return s;
-    return fhe_add(c, c1, c1, ws + w.k1, nullptr, sizeQl, batch, st);
+    // KeySwitchCore on d2 (:207) with `cv[0] += ab[0]; cv[1] += ab[1]` (:210-211) fused into the ModDown tails
+    return keyswitch_run(p, key, ws + w.d2, sizeQl, batch, c0, c1, ws, w, st, true);
 }
 
 extern "C" fhe_status fhe_approx_mod_down(fhe_ks_plan* p, const uint64_t* x, uint32_t sizeQl, uint32_t batch,

@@ -39,7 +39,7 @@ FHE_HD uint64_t csub(uint64_t x, uint64_t m) {
 // wave64 on a SIMD; v_mul_hi_u32 is slower at 7.7).  Spelled as inline asm on the device so that hipcc cannot
 // re-select v_mul_hi_u32 / v_mul_lo_u32 + v_add3 for parts of the chain.
 FHE_HD uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FHE_NO_MAD_ASM)
     uint64_t d;
     asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
     return d;
@@ -48,7 +48,7 @@ FHE_HD uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) {
 #endif
 }
 FHE_HD uint64_t mul32x32(uint32_t a, uint32_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FHE_NO_MAD_ASM)
     uint64_t d;
     asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b) : "vcc");
     return d;
@@ -108,6 +108,42 @@ FHE_HD void acc128(u128w& s, uint64_t a, uint64_t b) {  // s += a*b
     uint64_t hi = mulhi64(a, b);
     s.lo += lo;
     s.hi += hi + (s.lo < lo);
+}
+
+// Column-wise 64x64 multiply-accumulate: three 64-bit column sums with explicit carry words, no shifts or
+// zero-extended operands in the inner loop (8 instructions per MAC: 4 v_mad_u64_u32 + 4 carry adds).
+//   value = c0 + (c1 << 32) + (c2 << 64) + carries: k0 counts 2^64 overflows of c0, k1 of c1, k2 of c2.
+struct mac192 {
+    uint64_t c0, c1, c2;
+    uint32_t k0, k1, k2;
+};
+FHE_HD void mac192_clear(mac192& m) {
+    m.c0 = m.c1 = m.c2 = 0;
+    m.k0 = m.k1 = m.k2 = 0;
+}
+FHE_HD void mac192_add(mac192& m, uint64_t a, uint64_t b) {
+    const uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
+    uint64_t t;
+    t = (uint64_t)al * bl + m.c0;
+    m.k0 += t < m.c0;
+    m.c0 = t;
+    t    = (uint64_t)al * bh + m.c1;
+    m.k1 += t < m.c1;
+    m.c1 = t;
+    t    = (uint64_t)ah * bl + m.c1;
+    m.k1 += t < m.c1;
+    m.c1 = t;
+    t    = (uint64_t)ah * bh + m.c2;
+    m.k2 += t < m.c2;
+    m.c2 = t;
+}
+// fold the columns into a 128-bit value (the true sum must be < 2^128)
+struct u128w;
+FHE_HD void mac192_fold(const mac192& m, uint64_t& lo, uint64_t& hi) {
+    // total = c0 + c1*2^32 + c2*2^64 + k0*2^64 + k1*2^96 + k2*2^128(=0 by assumption)
+    const uint64_t c1lo = m.c1 << 32, c1hi = (m.c1 >> 32) + ((uint64_t)m.k1 << 32);
+    lo = m.c0 + c1lo;
+    hi = m.c2 + c1hi + (uint64_t)m.k0 + (lo < c1lo);
 }
 
 // a (128-bit) mod q with mu = floor(2^128/q) given as (mu_lo, mu_hi).

@@ -361,6 +361,160 @@ FHE_HD void bfly_inv_fast(uint64_t& a, uint64_t& b, const TwPair w, uint64_t nq,
 // NSTEPS = number of entries of a.steps (compile time, so that the step loop unrolls and the position of the
 // next-tile prefetch is static).  Row-pass plans carry one data-movement ("staging") step: the last one for the
 // forward transform, the first one for the inverse.
+// ================================================================================================
+// Production kernel for rings with N >= 4096: one tile per workgroup like ntt_pass_kernel, but the tile
+// lies inside one limb (wave-uniform modulus and twiddle base, no range checks), butterflies use the
+// multiply-add chain with the x+T sum folded in (bfly_fwd_fast), and the forward transform follows the
+// lazy-reduction schedule of NttStep::mode / NttPassArgs::canonLevels instead of one conditional
+// subtraction per butterfly.
+// ================================================================================================
+template <bool LAYOUT_A, bool INVERSE>
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_pass_full_kernel(const NttPassArgs a) {
+    FHE_SHARED_U64(lds, kTile);
+    const uint32_t t    = FHE_TID;
+    const uint32_t logN = a.logN;
+    const uint32_t N    = 1u << logN;
+    const uint32_t T    = a.T;
+    const uint32_t tilesPerRow = N >> kTileLog;
+    uint32_t tile = FHE_BID;
+    if (a.xcdSwizzle) {
+        const uint32_t xcd = tile & 7u, i = tile >> 3;
+        const uint32_t b = i % a.batch, pairIdx = i / a.batch;
+        const uint32_t pair = pairIdx * 8u + xcd;
+        tile = (b * a.nLimbs + pair / tilesPerRow) * tilesPerRow + pair % tilesPerRow;
+    }
+    const uint32_t logC = kTileLog - T;
+    const uint32_t S    = N >> T;
+    const uint32_t row  = tile / tilesPerRow, tr = tile % tilesPerRow;
+    const uint32_t jbase = LAYOUT_A ? (tr << logC) : (tr << kTileLog);
+    // physical row of this tile in the source / destination views
+    const uint32_t tb = row / a.nLimbs, rit = row % a.nLimbs;
+    const uint64_t inRow  = a.inStride ? ((uint64_t)tb * a.inStride + a.inFirst + rit) : (uint64_t)row;
+    const uint64_t outRow = a.outStride ? ((uint64_t)tb * a.outStride + a.outFirst + rit) : (uint64_t)row;
+    const uint32_t limb = FHE_UNIFORM(a.sel.idx[rit]);
+    const uint64_t q    = a.q[limb];
+    const uint64_t twoq = q << 1, nq = 0 - q;
+    const TwPair* tw    = a.tw + ((uint64_t)limb << logN);
+
+    uint64_t r[16];
+    for (uint32_t si = 0; si < a.nSteps; ++si) {
+        const NttStep st  = a.steps[si];
+        const uint32_t fI = (uint32_t)st.fI;
+        const uint32_t Ib = ((t >> fI) << (fI + 4)) | (t & ((1u << fI) - 1u));
+        uint32_t jrel;
+        uint64_t kstride;
+        if (LAYOUT_A) {
+            const uint32_t p0 = Ib >> logC, c0 = Ib & ((1u << logC) - 1u);
+            jrel    = p0 * S + c0;
+            kstride = (fI >= logC) ? ((uint64_t)S << (fI - logC)) : ((uint64_t)1 << fI);
+        }
+        else {
+            jrel    = Ib;
+            kstride = (uint64_t)1 << fI;
+        }
+        const uint32_t j0 = jbase + jrel;
+        if (si == 0) {
+            const uint64_t* src = a.xin + (inRow << logN) + j0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                r[k] = src[k * kstride];
+        }
+        else {
+            const uint32_t sb = lds_sigma(Ib);
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                r[k] = lds[sb ^ lds_sigma((uint32_t)k << fI)];
+            FHE_SYNC();
+        }
+        if (st.bHi >= st.bLo) {
+            const uint32_t Fj = (uint32_t)st.Fj;
+            uint32_t jhigh    = j0 >> (Fj + 4);
+            if (st.uniformTw)
+                jhigh = FHE_UNIFORM(jhigh);
+            if (!INVERSE) {
+                if (st.mode == 1) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        r[k] = csub2(r[k], twoq << 2);
+                }
+#pragma unroll
+                for (int b = 3; b >= 0; --b) {
+                    if (b <= st.bHi && b >= st.bLo) {
+                        const uint32_t s      = logN - 1u - (Fj + b);
+                        const uint32_t twbase = (1u << s) + (jhigh << (3 - b));
+#pragma unroll
+                        for (int g = 0; g < (8 >> b); ++g) {
+                            const TwPair wv = tw[twbase + g];
+#pragma unroll
+                            for (int lo = 0; lo < (1 << b); ++lo) {
+                                const int k0 = (g << (b + 1)) | lo;
+                                bfly_fwd_fast(r[k0], r[k0 | (1 << b)], wv, nq, twoq);
+                            }
+                        }
+                    }
+                }
+            }
+            else {
+#pragma unroll
+                for (int b = 0; b <= 3; ++b) {
+                    if (b <= st.bHi && b >= st.bLo) {
+                        const uint32_t s      = logN - 1u - (Fj + b);
+                        const uint32_t twbase = (1u << s) + (jhigh << (3 - b));
+                        if (s == 0) {
+                            const TwPair nInv = a.fin[2 * limb], w1n = a.fin[2 * limb + 1];
+#pragma unroll
+                            for (int lo = 0; lo < (1 << b); ++lo) {
+                                const uint64_t u = r[lo], v = r[lo | (1 << b)];
+                                r[lo]            = shoup_acc(0, u + v, nInv, nq);
+                                r[lo | (1 << b)] = shoup_acc(0, u - v + twoq, w1n, nq);
+                            }
+                        }
+                        else {
+#pragma unroll
+                            for (int g = 0; g < (8 >> b); ++g) {
+                                const TwPair wv = tw[twbase + g];
+#pragma unroll
+                                for (int lo = 0; lo < (1 << b); ++lo) {
+                                    const int k0 = (g << (b + 1)) | lo;
+                                    bfly_inv_fast(r[k0], r[k0 | (1 << b)], wv, nq, twoq);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (si == a.canonStep) {
+            if (INVERSE) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    r[k] = csub2(r[k], q);
+            }
+            else {
+                for (int lv = (int)a.canonLevels - 1; lv >= 0; --lv) {
+                    const uint64_t m = q << lv;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        r[k] = csub2(r[k], m);
+                }
+            }
+        }
+        if (si + 1 == a.nSteps) {
+            uint64_t* dst = a.x + (outRow << logN) + j0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                dst[k * kstride] = r[k];
+        }
+        else {
+            const uint32_t sb = lds_sigma(Ib);
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                lds[sb ^ lds_sigma((uint32_t)k << fI)] = r[k];
+            FHE_SYNC();
+        }
+    }
+}
+
 #ifndef FHE_NTT_MINWAVES
 #define FHE_NTT_MINWAVES 2
 #endif

@@ -39,7 +39,7 @@ class Lib:
     """Loads libfhe_hip.so (or an explicitly given build, e.g. the test-only lane emulator)."""
 
     def __init__(self, path=None):
-        path = path or DEFAULT_SO
+        path = path or os.environ.get("FHE_HIP_LIB") or DEFAULT_SO
         if not os.path.exists(path):
             raise FheError(
                 f"{path} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
