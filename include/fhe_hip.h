@@ -180,6 +180,21 @@ fhe_status fhe_keyswitch_hybrid(fhe_ks_plan* plan, const fhe_ks_key* key, const 
 fhe_status fhe_ckks_eval_mult(fhe_ks_plan* plan, const fhe_ks_key* key, const uint64_t* a0, const uint64_t* a1,
                               const uint64_t* b0, const uint64_t* b1, uint32_t sizeQl, uint32_t batch, uint64_t* c0,
                               uint64_t* c1, void* ws, size_t wsBytes, void* stream);
+/* Hoisting (Halevi-Shoup): LeveledSHEBase::EvalFastRotationPrecompute = EvalKeySwitchPrecomputeCore(c1)
+ * (src/pke/lib/schemebase/base-leveledshe.cpp:425-430) once, then per rotation key EvalFastKeySwitchCore + add +
+ * automorphism (:432-463).  The digits stay in the workspace `ws` between the calls (same sizeQl / batch / ws).
+ * fhe_eval_automorphism = EvalAutomorphism (:381-422): out0 = Auto_k(c0 + ks0(c1)), out1 = Auto_k(ks1(c1)).
+ * `key` must be the evaluation key of automorphism index k (FindAutomorphismIndex2nComplex for CKKS rotations). */
+fhe_status fhe_ks_precompute(fhe_ks_plan* plan, const uint64_t* c1, uint32_t sizeQl, uint32_t batch, void* ws,
+                             size_t wsBytes, void* stream);
+fhe_status fhe_ks_fast_keyswitch(fhe_ks_plan* plan, const fhe_ks_key* key, const uint64_t* c1, uint32_t sizeQl,
+                                 uint32_t batch, uint64_t* out0, uint64_t* out1, void* ws, size_t wsBytes, void* stream);
+fhe_status fhe_eval_fast_rotation(fhe_ks_plan* plan, const fhe_ks_key* key, const uint64_t* c0, const uint64_t* c1,
+                                  uint32_t k, uint32_t sizeQl, uint32_t batch, uint64_t* out0, uint64_t* out1, void* ws,
+                                  size_t wsBytes, void* stream);
+fhe_status fhe_eval_automorphism(fhe_ks_plan* plan, const fhe_ks_key* key, const uint64_t* c0, const uint64_t* c1,
+                                 uint32_t k, uint32_t sizeQl, uint32_t batch, uint64_t* out0, uint64_t* out1, void* ws,
+                                 size_t wsBytes, void* stream);
 /* DCRTPolyImpl::ApproxModDown with t = 0 (dcrtpoly-impl.h:966-1005):
  * x[batch][sizeQl+sizeP][N] EVALUATION -> out[batch][sizeQl][N] EVALUATION */
 fhe_status fhe_approx_mod_down(fhe_ks_plan* plan, const uint64_t* x, uint32_t sizeQl, uint32_t batch, uint64_t* out,

@@ -1198,19 +1198,14 @@ static fhe_status mod_down_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const uin
     return mod_down_tail(p, lv, x, md, nTow, out, false, st);
 }
 
-// accumulate: out0/out1 += key-switch result (EvalMult's `cv[0] += ab[0]; cv[1] += ab[1]`, base-leveledshe.cpp:210-211)
-static fhe_status keyswitch_run(fhe_ks_plan* p, const fhe_ks_key* key, const uint64_t* cin, uint32_t sizeQl,
-                                uint32_t batch, uint64_t* out0, uint64_t* out1, uint64_t* ws, const KsLayout& w,
-                                void* st, bool accumulate = false) {
-    fhe_ctx* c = p->ctx;
-    fhe_ks_plan::Level* lv = nullptr;
-    if (fhe_status s = ks_level(p, sizeQl, &lv))
-        return s;
-    const uint32_t sizeP = p->sizeP, sizeQlP = sizeQl + sizeP;
-    // EvalKeySwitchPrecomputeCore (keyswitch-hybrid.cpp:314-379)
+// EvalKeySwitchPrecomputeCore (keyswitch-hybrid.cpp:314-379): digit decomposition + ModUp of every digit into the
+// workspace's digit buffers (the digit's own limbs are NOT copied: the inner product reads them from `cin`)
+static fhe_status ks_precompute_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const uint64_t* cin, uint32_t batch,
+                                    uint64_t* ws, const KsLayout& w, void* st) {
+    fhe_ctx* c            = p->ctx;
+    const uint32_t sizeQl = lv->sizeQl;
     if (fhe_status s = fhe_ntt_inv_oop(c, cin, ws + w.coef, nullptr, sizeQl, batch, st))
         return s;
-    KsInnerArgs g;
     for (uint32_t j = 0; j < lv->numParts; ++j) {
         const uint32_t nc = (uint32_t)lv->cidx[j].size();
         uint64_t* dj      = ws + w.dig[j];
@@ -1218,12 +1213,20 @@ static fhe_status keyswitch_run(fhe_ks_plan* p, const fhe_ks_key* key, const uin
             return s;
         if (fhe_status s = fhe_ntt_fwd(c, dj, lv->cidx[j].data(), nc, batch, st))
             return s;
-        g.digits[j] = dj;
-        g.nc[j]     = nc;
     }
-    for (uint32_t j = lv->numParts; j < (uint32_t)kMaxDigits; ++j) {
-        g.digits[j] = nullptr;
-        g.nc[j]     = 0;
+    return FHE_OK;
+}
+// EvalFastKeySwitchCore (keyswitch-hybrid.cpp:381-435) on digits already in the workspace.
+// accumulate: out0/out1 += result (EvalMult's `cv[0] += ab[0]; cv[1] += ab[1]`, base-leveledshe.cpp:210-211)
+static fhe_status ks_fast_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const fhe_ks_key* key, const uint64_t* cin,
+                              uint32_t batch, uint64_t* out0, uint64_t* out1, uint64_t* ws, const KsLayout& w, void* st,
+                              bool accumulate) {
+    fhe_ctx* c            = p->ctx;
+    const uint32_t sizeQl = lv->sizeQl, sizeP = p->sizeP, sizeQlP = sizeQl + sizeP;
+    KsInnerArgs g;
+    for (uint32_t j = 0; j < (uint32_t)kMaxDigits; ++j) {
+        g.digits[j] = j < lv->numParts ? ws + w.dig[j] : nullptr;
+        g.nc[j]     = j < lv->numParts ? (uint32_t)lv->cidx[j].size() : 0u;
     }
     // EvalFastKeySwitchCoreExt (:402-435)
     g.c = cin, g.keyB = key->d_b, g.keyA = key->d_a;
@@ -1241,6 +1244,16 @@ static fhe_status keyswitch_run(fhe_ks_plan* p, const fhe_ks_key* key, const uin
     if (fhe_status s = mod_down_tail(p, lv, ws + w.e0, ws + w.md, batch, out0, accumulate, st))
         return s;
     return mod_down_tail(p, lv, ws + w.e1, ws + w.md + ((size_t)batch * sizeQl << c->logN), batch, out1, accumulate, st);
+}
+static fhe_status keyswitch_run(fhe_ks_plan* p, const fhe_ks_key* key, const uint64_t* cin, uint32_t sizeQl,
+                                uint32_t batch, uint64_t* out0, uint64_t* out1, uint64_t* ws, const KsLayout& w,
+                                void* st, bool accumulate = false) {
+    fhe_ks_plan::Level* lv = nullptr;
+    if (fhe_status s = ks_level(p, sizeQl, &lv))
+        return s;
+    if (fhe_status s = ks_precompute_run(p, lv, cin, batch, ws, w, st))
+        return s;
+    return ks_fast_run(p, lv, key, cin, batch, out0, out1, ws, w, st, accumulate);
 }
 
 extern "C" fhe_status fhe_keyswitch_hybrid(fhe_ks_plan* p, const fhe_ks_key* key, const uint64_t* cin, uint32_t sizeQl,
@@ -1271,6 +1284,57 @@ extern "C" fhe_status fhe_ckks_eval_mult(fhe_ks_plan* p, const fhe_ks_key* key, 
         return s;
     // KeySwitchCore on d2 (:207) with `cv[0] += ab[0]; cv[1] += ab[1]` (:210-211) fused into the ModDown tails
     return keyswitch_run(p, key, ws + w.d2, sizeQl, batch, c0, c1, ws, w, st, true);
+}
+
+#define KS_COMMON_CHECKS(who)                                                                              \
+    ARG_CHECK(p && ws, who ": null argument");                                                             \
+    ARG_CHECK(sizeQl >= 1 && sizeQl <= p->sizeQ && batch >= 1, who ": bad level or batch");                \
+    const KsLayout w = ks_layout(p, sizeQl, batch);                                                        \
+    ARG_CHECK(wsBytes >= w.total * 8, who ": workspace too small");                                        \
+    RT_CHECK(rt::set_device(p->ctx->device));                                                              \
+    fhe_ks_plan::Level* lv = nullptr;                                                                      \
+    if (fhe_status s_ = ks_level(p, sizeQl, &lv))                                                          \
+        return s_;
+
+extern "C" fhe_status fhe_ks_precompute(fhe_ks_plan* p, const uint64_t* c1, uint32_t sizeQl, uint32_t batch, void* ws,
+                                        size_t wsBytes, void* st) {
+    KS_COMMON_CHECKS("fhe_ks_precompute")
+    ARG_CHECK(c1, "fhe_ks_precompute: null argument");
+    return ks_precompute_run(p, lv, c1, batch, (uint64_t*)ws, w, st);
+}
+extern "C" fhe_status fhe_ks_fast_keyswitch(fhe_ks_plan* p, const fhe_ks_key* key, const uint64_t* c1, uint32_t sizeQl,
+                                            uint32_t batch, uint64_t* out0, uint64_t* out1, void* ws, size_t wsBytes,
+                                            void* st) {
+    KS_COMMON_CHECKS("fhe_ks_fast_keyswitch")
+    ARG_CHECK(key && c1 && out0 && out1 && key->plan == p, "fhe_ks_fast_keyswitch: bad key or null argument");
+    return ks_fast_run(p, lv, key, c1, batch, out0, out1, (uint64_t*)ws, w, st, false);
+}
+// LeveledSHEBase::EvalFastRotation (base-leveledshe.cpp:432-463): ba = EvalFastKeySwitchCore(digits, key_k);
+// ba[0] += cv[0]; both elements through AutomorphismTransform(k)
+extern "C" fhe_status fhe_eval_fast_rotation(fhe_ks_plan* p, const fhe_ks_key* key, const uint64_t* c0, const uint64_t* c1,
+                                             uint32_t k, uint32_t sizeQl, uint32_t batch, uint64_t* out0, uint64_t* out1,
+                                             void* ws, size_t wsBytes, void* st) {
+    KS_COMMON_CHECKS("fhe_eval_fast_rotation")
+    ARG_CHECK(key && c0 && c1 && out0 && out1 && key->plan == p, "fhe_eval_fast_rotation: bad key or null argument");
+    ARG_CHECK(k % 2 == 1, "Automorphism index not odd");
+    uint64_t* wsp = (uint64_t*)ws;
+    fhe_ctx* c    = p->ctx;
+    if (fhe_status s = ks_fast_run(p, lv, key, c1, batch, wsp + w.k0, wsp + w.k1, wsp, w, st, false))
+        return s;
+    if (fhe_status s = fhe_add(c, wsp + w.k0, wsp + w.k0, c0, nullptr, sizeQl, batch, st))
+        return s;
+    if (fhe_status s = fhe_automorph(c, out0, wsp + w.k0, k, 1, nullptr, sizeQl, batch, st))
+        return s;
+    return fhe_automorph(c, out1, wsp + w.k1, k, 1, nullptr, sizeQl, batch, st);
+}
+// LeveledSHEBase::EvalAutomorphism (base-leveledshe.cpp:381-422) = KeySwitchInPlace + AutomorphismTransform on both
+// elements; identical result to precompute + fast rotation
+extern "C" fhe_status fhe_eval_automorphism(fhe_ks_plan* p, const fhe_ks_key* key, const uint64_t* c0, const uint64_t* c1,
+                                            uint32_t k, uint32_t sizeQl, uint32_t batch, uint64_t* out0, uint64_t* out1,
+                                            void* ws, size_t wsBytes, void* st) {
+    if (fhe_status s = fhe_ks_precompute(p, c1, sizeQl, batch, ws, wsBytes, st))
+        return s;
+    return fhe_eval_fast_rotation(p, key, c0, c1, k, sizeQl, batch, out0, out1, ws, wsBytes, st);
 }
 
 extern "C" fhe_status fhe_approx_mod_down(fhe_ks_plan* p, const uint64_t* x, uint32_t sizeQl, uint32_t batch,

@@ -91,6 +91,10 @@ class Lib:
         S("fhe_ks_workspace_bytes", C.c_size_t, [vp, u32, u32])
         S("fhe_keyswitch_hybrid", C.c_int, [vp, vp, vp, u32, u32, vp, vp, vp, C.c_size_t, vp])
         S("fhe_ckks_eval_mult", C.c_int, [vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp, C.c_size_t, vp])
+        S("fhe_ks_precompute", C.c_int, [vp, vp, u32, u32, vp, C.c_size_t, vp])
+        S("fhe_ks_fast_keyswitch", C.c_int, [vp, vp, vp, u32, u32, vp, vp, vp, C.c_size_t, vp])
+        S("fhe_eval_fast_rotation", C.c_int, [vp, vp, vp, vp, u32, u32, u32, vp, vp, vp, C.c_size_t, vp])
+        S("fhe_eval_automorphism", C.c_int, [vp, vp, vp, vp, u32, u32, u32, vp, vp, vp, C.c_size_t, vp])
         S("fhe_approx_mod_down", C.c_int, [vp, vp, u32, u32, vp, vp, C.c_size_t, vp])
         S("fhe_rescale_workspace_bytes", C.c_size_t, [vp, u32, u32])
         S("fhe_rescale", C.c_int, [vp, vp, u32, u32, vp, vp, C.c_size_t, vp])
@@ -374,6 +378,33 @@ class KeySwitchPlan:
         self.ctx.lib.check(self.ctx.lib.L.fhe_ckks_eval_mult(self.h, self.key, a0.ptr, a1.ptr, b0.ptr, b1.ptr,
                                                              a0.n_limbs, a0.batch, c0.ptr, c1.ptr, ws, wsb, stream))
         return c0, c1
+
+    def make_key(self, keyB, keyA):
+        """upload an additional evaluation key (e.g. a rotation key); returns the handle"""
+        keyB = np.ascontiguousarray(keyB, dtype=np.uint64)
+        keyA = np.ascontiguousarray(keyA, dtype=np.uint64)
+        k = vp()
+        self.ctx.lib.check(self.ctx.lib.L.fhe_ks_key_upload(self.h, keyB.ctypes.data_as(u64p), keyA.ctypes.data_as(u64p),
+                                                            C.byref(k)))
+        return k
+
+    def EvalFastRotationPrecompute(self, c1, stream=None):  # base-leveledshe.cpp:425-430
+        ws, wsb = self.workspace(c1.n_limbs, c1.batch)
+        self.ctx.lib.check(self.ctx.lib.L.fhe_ks_precompute(self.h, c1.ptr, c1.n_limbs, c1.batch, ws, wsb, stream))
+
+    def EvalFastRotation(self, key, c0, c1, k, stream=None):  # base-leveledshe.cpp:432-463 (digits already in ws)
+        ws, wsb = self.workspace(c0.n_limbs, c0.batch)
+        o0, o1 = c0.like(), c0.like()
+        self.ctx.lib.check(self.ctx.lib.L.fhe_eval_fast_rotation(self.h, key, c0.ptr, c1.ptr, k, c0.n_limbs, c0.batch,
+                                                                 o0.ptr, o1.ptr, ws, wsb, stream))
+        return o0, o1
+
+    def EvalAutomorphism(self, key, c0, c1, k, stream=None):  # base-leveledshe.cpp:381-422
+        ws, wsb = self.workspace(c0.n_limbs, c0.batch)
+        o0, o1 = c0.like(), c0.like()
+        self.ctx.lib.check(self.ctx.lib.L.fhe_eval_automorphism(self.h, key, c0.ptr, c1.ptr, k, c0.n_limbs, c0.batch,
+                                                                o0.ptr, o1.ptr, ws, wsb, stream))
+        return o0, o1
 
     def ApproxModDown(self, x, sizeQl, stream=None):  # dcrtpoly-impl.h:966-1005
         ws, wsb = self.workspace(sizeQl, x.batch)

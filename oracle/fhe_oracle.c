@@ -988,6 +988,27 @@ void orc_ckks_eval_mult_relin(const orc_hybrid* h, const uint64_t* a0, const uin
     free(k1);
 }
 
+/* base-leveledshe.cpp:381-422 / :432-463 */
+void orc_eval_automorphism(const orc_hybrid* h, const uint64_t* c0, const uint64_t* c1, uint32_t sizeQl, uint32_t k,
+                           const uint64_t* keyB, const uint64_t* keyA, uint64_t* out0, uint64_t* out1) {
+    const uint32_t N = h->N;
+    size_t sz        = (size_t)sizeQl * N;
+    uint64_t* k0     = (uint64_t*)malloc(sizeof(uint64_t) * sz);
+    uint64_t* k1     = (uint64_t*)malloc(sizeof(uint64_t) * sz);
+    uint32_t* pre    = (uint32_t*)malloc(sizeof(uint32_t) * N);
+    orc_hybrid_key_switch(h, c1, sizeQl, keyB, keyA, k0, k1);
+    orc_precompute_auto_map(N, k, pre);
+    for (uint32_t i = 0; i < sizeQl; ++i) {
+        size_t o = (size_t)i * N;
+        orc_vec_add(k0 + o, k0 + o, c0 + o, N, h->q[i]); /* ba[0] += cv[0] */
+        orc_automorph_eval(out0 + o, k0 + o, N, pre);
+        orc_automorph_eval(out1 + o, k1 + o, N, pre);
+    }
+    free(k0);
+    free(k1);
+    free(pre);
+}
+
 /* ------------------------------------------------------------------------------------------
  * a15: rescale
  * ---------------------------------------------------------------------------------------- */

@@ -143,6 +143,11 @@ void orc_ckks_eval_mult_relin(const orc_hybrid*, const uint64_t* a0, const uint6
                               const uint64_t* b1, uint32_t sizeQl, const uint64_t* keyB, const uint64_t* keyA,
                               uint64_t* c0, uint64_t* c1);
 
+/* LeveledSHEBase::EvalAutomorphism (base-leveledshe.cpp:381-422) == EvalFastRotation with freshly computed digits
+ * (:432-463): out0 = Auto_k(c0 + ks0(c1)), out1 = Auto_k(ks1(c1)), all EVALUATION, key = the automorphism key of k */
+void orc_eval_automorphism(const orc_hybrid*, const uint64_t* c0, const uint64_t* c1, uint32_t sizeQl, uint32_t k,
+                           const uint64_t* keyB, const uint64_t* keyA, uint64_t* out0, uint64_t* out1);
+
 /* ---------------- a15: DropLastElementAndScale (dcrtpoly-impl.h:693-712), EVAL in/out ----------------
  * x[sizeQl][N] -> out[sizeQl-1][N]; ctx limbs [0,sizeQl) are the tower. Tables are computed inside
  * the way ckksrns-cryptoparameters.cpp:60-81 does. */

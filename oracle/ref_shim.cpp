@@ -409,6 +409,38 @@ void ref_ckks_decrypt(void* h, int ct, double* out, uint32_t n) {
     for (uint32_t i = 0; i < n && i < v.size(); ++i)
         out[i] = v[i];
 }
+// rotations: EvalAtIndexKeyGen + key export + EvalRotate / hoisted EvalFastRotation
+void ref_ckks_rotate_keygen(void* h, const int32_t* indices, uint32_t n) {
+    auto* s = static_cast<RefCkks*>(h);
+    s->cc->EvalRotateKeyGen(s->kp.secretKey, std::vector<int32_t>(indices, indices + n));
+}
+// returns the automorphism index k of rotation `index`; fills the key vectors [numPartQ][sizeQ+sizeP][N]
+uint32_t ref_ckks_get_rot_key(void* h, int32_t index, uint64_t* keyB, uint64_t* keyA) {
+    auto* s     = static_cast<RefCkks*>(h);
+    uint32_t M  = s->cc->GetCyclotomicOrder();
+    uint32_t k  = FindAutomorphismIndex2nComplex(index, M);
+    auto& km    = CryptoContextImpl<DCRTPoly>::GetEvalAutomorphismKeyMap(s->kp.secretKey->GetKeyTag());
+    const auto& ek = km.at(k);
+    const auto& av = ek->GetAVector();
+    const auto& bv = ek->GetBVector();
+    size_t stride  = (size_t)av[0].GetNumOfElements() * av[0].GetRingDimension();
+    for (size_t j = 0; j < av.size(); ++j) {
+        export_poly(bv[j], keyB + j * stride);
+        export_poly(av[j], keyA + j * stride);
+    }
+    return k;
+}
+int ref_ckks_eval_rotate(void* h, int ct, int32_t index) {
+    auto* s = static_cast<RefCkks*>(h);
+    s->cts.push_back(s->cc->EvalRotate(s->cts[ct], index));
+    return static_cast<int>(s->cts.size()) - 1;
+}
+int ref_ckks_eval_fast_rotate(void* h, int ct, int32_t index) {  // hoisted: precompute digits once, then rotate
+    auto* s     = static_cast<RefCkks*>(h);
+    auto digits = s->cc->EvalFastRotationPrecompute(s->cts[ct]);
+    s->cts.push_back(s->cc->EvalFastRotation(s->cts[ct], index, s->cc->GetCyclotomicOrder(), digits));
+    return static_cast<int>(s->cts.size()) - 1;
+}
 int ref_omp_threads() { return OpenFHEParallelControls.GetNumThreads(); }
 
 // ---- ScaleAndRound family with caller tables ----

@@ -95,6 +95,7 @@ def load_oracle():
     S("orc_hybrid_approx_mod_down", None, [vp, P64, u32, P64])
     S("orc_hybrid_key_switch", None, [vp, P64, u32, P64, P64, P64, P64])
     S("orc_ckks_eval_mult_relin", None, [vp, P64, P64, P64, P64, u32, P64, P64, P64, P64])
+    S("orc_eval_automorphism", None, [vp, P64, P64, u32, u32, P64, P64, P64, P64])
     S("orc_drop_last_element_and_scale", None, [vp, P64, u32, P64])
     S("orc_rescale_tables", None, [vp, u32, P64, P64])
     S("orc_scale_and_round", None, [P64, u32, u32, u32, C.c_int, P64, PF64, P64, P64, P64])
@@ -167,6 +168,10 @@ def load_ref():
     S("ref_ckks_time_eval_mult", C.c_double, [vp, C.c_int, C.c_int, C.c_int])
     S("ref_ckks_decrypt", None, [vp, C.c_int, PF64, u32])
     S("ref_omp_threads", C.c_int, [])
+    S("ref_ckks_rotate_keygen", None, [vp, np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS"), u32])
+    S("ref_ckks_get_rot_key", u32, [vp, i32, P64, P64])
+    S("ref_ckks_eval_rotate", C.c_int, [vp, C.c_int, i32])
+    S("ref_ckks_eval_fast_rotate", C.c_int, [vp, C.c_int, i32])
     S("ref_scale_and_round", None, [u32, u32, u32, C.c_int, P64, P64, P64, P64, PF64, P64])
     S("ref_approx_scale_and_round", None, [u32, u32, u32, P64, P64, P64, P64, P64])
     S("ref_scale_and_round_p_over_q", None, [u32, u32, P64, P64, P64, P64, P64])

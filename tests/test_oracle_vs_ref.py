@@ -241,3 +241,41 @@ def test_scale_and_round_p_over_q_against_live_reference(oracle, ref):
     r.ref_scale_and_round_p_over_q(N, sizeQ, q, psi, x, pinv, want)
     o.orc_scale_and_round_p_over_q(x, sizeQ, N, q[:sizeQ].copy(), int(q[sizeQ]), pinv, got)
     assert np.array_equal(want, got)
+
+
+def test_rotations_against_live_reference(oracle, ref):
+    """EvalRotate and hoisted EvalFastRotation of the reference (its own rotation keys) vs the oracle"""
+    o, r = oracle, ref
+    h = r.ref_ckks_create(1 << 10, 4, 45, 55, 3, 0)
+    info = np.zeros(5, np.uint32)
+    r.ref_ckks_info(h, info)
+    N, sizeQ, sizeP, numPartQ, alpha = map(int, info)
+    q, psiQ = np.zeros(sizeQ, np.uint64), np.zeros(sizeQ, np.uint64)
+    p, psiP = np.zeros(sizeP, np.uint64), np.zeros(sizeP, np.uint64)
+    r.ref_ckks_get_moduli(h, q, psiQ, p, psiP)
+    hy = o.orc_hybrid_create(N, sizeQ, q, psiQ, sizeP, p, psiP, numPartQ)
+    idx = np.array([1, -3, 7], np.int32)
+    r.ref_ckks_rotate_keygen(h, idx, 3)
+    ct = r.ref_ckks_encrypt(h, 5, 1)
+    ci = np.zeros(4, np.uint32)
+    r.ref_ct_info(h, ct, ci)
+    sizeQl = int(ci[1])
+
+    def ex(c, e):
+        a = np.zeros((sizeQl, N), np.uint64)
+        r.ref_ct_export(h, c, e, a)
+        return a
+    c0, c1 = ex(ct, 0), ex(ct, 1)
+    for index in (1, -3, 7):
+        keyB = np.zeros((numPartQ, sizeQ + sizeP, N), np.uint64)
+        keyA = keyB.copy()
+        k = r.ref_ckks_get_rot_key(h, index, keyB, keyA)
+        assert k == o.orc_find_automorphism_index_2n_complex(index, 2 * N)
+        o0, o1 = np.zeros_like(c0), np.zeros_like(c0)
+        o.orc_eval_automorphism(hy, c0, c1, sizeQl, k, keyB, keyA, o0, o1)
+        rr = r.ref_ckks_eval_rotate(h, ct, index)
+        rf = r.ref_ckks_eval_fast_rotate(h, ct, index)
+        assert np.array_equal(o0, ex(rr, 0)) and np.array_equal(o1, ex(rr, 1))
+        assert np.array_equal(o0, ex(rf, 0)) and np.array_equal(o1, ex(rf, 1))
+    o.orc_hybrid_destroy(hy)
+    r.ref_ckks_destroy(h)

@@ -315,3 +315,40 @@ def test_rescale(backend, oracle):
         assert np.array_equal(got, want), f"DropLastElementAndScale mismatch logN={logN}"
         o.orc_ctx_destroy(octx)
         ctx.close()
+
+
+@pytest.mark.parametrize("logN,sizeQ,dnum,sizeQl,B", [(10, 4, 2, 3, 2), (12, 6, 3, 6, 1)])
+def test_hoisted_rotations(backend, oracle, logN, sizeQ, dnum, sizeQl, B):
+    """EvalAutomorphism and EvalFastRotation (one ModUp, several rotation keys) against the oracle"""
+    o = oracle
+    rng = np.random.default_rng(18)
+    N = 1 << logN
+    q, psiQ, p, psiP = ckks_like_params(o, logN, sizeQ, dnum)
+    sizeP = len(p)
+    hy = o.orc_hybrid_create(N, sizeQ, q, psiQ, sizeP, p, psiP, dnum)
+    allq = np.concatenate([q, p])
+    ctx = fh.Context(backend, logN, allq, np.concatenate([psiQ, psiP]))
+    plan = fh.KeySwitchPlan(ctx, sizeQ, sizeP, dnum)
+    ql = q[:sizeQl]
+    c0, c1 = libs.rand_tower(rng, ql, N, B), libs.rand_tower(rng, ql, N, B)
+    t0, t1 = ctx.tower(c0), ctx.tower(c1)
+    ks = [o.orc_find_automorphism_index_2n_complex(i, 2 * N) for i in (1, -2, 5)] + [2 * N - 1]  # + conjugation
+    keys = [(libs.rand_tower(rng, allq, N, dnum), libs.rand_tower(rng, allq, N, dnum)) for _ in ks]
+    handles = [plan.make_key(kb, ka) for kb, ka in keys]
+    want = []
+    for k, (kb, ka) in zip(ks, keys):
+        w0, w1 = np.empty_like(c0), np.empty_like(c0)
+        for b in range(B):
+            o.orc_eval_automorphism(hy, c0[b], c1[b], sizeQl, k, kb, ka, w0[b], w1[b])
+        want.append((w0, w1))
+    g0, g1 = plan.EvalAutomorphism(handles[0], t0, t1, ks[0])
+    assert np.array_equal(g0.to_host(), want[0][0]) and np.array_equal(g1.to_host(), want[0][1])
+    plan.EvalFastRotationPrecompute(t1)  # hoisted: digits computed once ...
+    for k, hnd, (w0, w1) in zip(ks, handles, want):  # ... reused for every rotation key
+        g0, g1 = plan.EvalFastRotation(hnd, t0, t1, k)
+        assert np.array_equal(g0.to_host(), w0) and np.array_equal(g1.to_host(), w1), f"rotation k={k}"
+    for hnd in handles:
+        backend.L.fhe_ks_key_destroy(hnd)
+    plan.close()
+    ctx.close()
+    o.orc_hybrid_destroy(hy)
