@@ -251,7 +251,7 @@ def main():
                     traffic = pmc["per_launch_bytes"][dom[:-3]]["total"]
             except Exception:
                 traffic = None
-            roof = {"bound": "hbm", "kernel": "ntt_pass_kernel/" + dom[:-3], "achieved": round(ach, 1),
+            roof = {"bound": "hbm", "kernel": "ntt_pass_full_kernel/" + dom[:-3], "achieved": round(ach, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
                     "traffic_source": "profiles/r01_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
                                       if traffic else None,

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""copies the judged summaries of the last tools/gpu_bench_r01.sh run from gpurun_out/ (scratch) into profiles/"""
+import collections, csv, glob, json, os, shutil, sys
+R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+os.makedirs("profiles", exist_ok=True)
+shutil.copy("gpurun_out/bench_r01.json", f"profiles/{R}_bench.json")
+shutil.copy("gpurun_out/bench_r01_em128.json", f"profiles/{R}_bench_evalmult128.json")
+shutil.copy(glob.glob("gpurun_out/prof_r01/*/*kernel_stats.csv")[0], f"profiles/{R}_rocprof_kernel_stats_bench.csv")
+names = {"<true, false>": "fwd_column_pass", "<false, false>": "fwd_row_pass", "<false, true>": "inv_row_pass",
+         "<true, true>": "inv_column_pass"}
+res = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(f"gpurun_out/pmc_r01_{c}/*/*counter_collection.csv")[0]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == c and "ntt_pass" in r["Kernel_Name"]:
+            key = [v for k, v in names.items() if k in r["Kernel_Name"]][0]
+            agg[key].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        res.setdefault(k, {})[c] = sum(v) / len(v)
+out = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --steps 2 "
+               "--warmup 1 --no-cpu-baseline --no-evalmult` (N=2^16, L=30, B=1024), tools/gpu_bench_r01.sh. Counter units are "
+               "KiB; FETCH_SIZE is doubled (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md §HBM).",
+       "workload": "logN16_L30_B1024", "per_launch_bytes": {}}
+for k, v in res.items():
+    out["per_launch_bytes"][k] = {"fetch_bytes": v["FETCH_SIZE"] * 2048, "write_bytes": v["WRITE_SIZE"] * 1024,
+                                  "total": v["FETCH_SIZE"] * 2048 + v["WRITE_SIZE"] * 1024,
+                                  "algorithmic": 2 * 8 * 65536 * 30 * 1024}
+json.dump(out, open(f"profiles/{R}_pmc_traffic.json", "w"), indent=1)
+b = json.load(open(f"profiles/{R}_bench.json"))
+print(json.dumps({k: b[k] for k in ("value", "ms_per_step", "hbm_roofline_frac_fwd_inv", "roofline", "cpu_baseline", "evalmult")}, indent=1))
