@@ -250,6 +250,14 @@ fhe_status fhe_behz_q_to_bsk(fhe_behz* plan, uint64_t* x, int evalFormat, uint32
                              void* stream);
 fhe_status fhe_behz_floorq(fhe_behz* plan, uint64_t* x, uint32_t batch, void* stream);
 fhe_status fhe_behz_conv_sk(fhe_behz* plan, const uint64_t* x, uint64_t* out, uint32_t batch, void* stream);
+/* LeveledSHEBFVRNS::EvalMult, BEHZ branch, no relinearisation (src/pke/lib/scheme/bfvrns/bfvrns-leveledshe.cpp:198-445;
+ * config 5 of BASELINE.json): the four input elements [batch][numQ][N] EVALUATION -> three product elements
+ * [batch][numQ][N], COEFFICIENT as the reference returns them, or EVALUATION when outEval != 0 (the SetFormat that
+ * LeveledSHEBase::EvalMult(ct,ct,key) applies before KeySwitchCore, base-leveledshe.cpp:204-205). */
+size_t     fhe_bfv_eval_mult_behz_workspace_bytes(const fhe_behz* plan, uint32_t batch);
+fhe_status fhe_bfv_eval_mult_behz(fhe_behz* plan, const uint64_t* a0, const uint64_t* a1, const uint64_t* b0,
+                                  const uint64_t* b1, uint64_t* d0, uint64_t* d1, uint64_t* d2, int outEval,
+                                  uint32_t batch, void* ws, size_t wsBytes, void* stream);
 
 /* ---- host-side parameter helpers (no device work) -------------------------------------------------
  * Number theory the reference uses to pick moduli and roots, restated with 64-bit arithmetic so that a

@@ -1735,3 +1735,51 @@ extern "C" fhe_status fhe_behz_conv_sk(fhe_behz* h, const uint64_t* x, uint64_t*
     LAUNCH_CHECK();
     return FHE_OK;
 }
+
+// LeveledSHEBFVRNS::EvalMult, BEHZ branch, without relinearisation (bfvrns-leveledshe.cpp:198-445):
+//   :302-325 FastBaseConvqToBskMontgomery + SetFormat(EVALUATION) on the four input elements,
+//   :327-372 tensor product over Q u Bsk,  :414-437 SetFormat(COEFFICIENT); FastRNSFloorq; FastBaseConvSK per product.
+// Inputs [batch][numQ][N] EVALUATION; outputs [batch][numQ][N], COEFFICIENT as the reference leaves them, or
+// EVALUATION when outEval != 0 (what LeveledSHEBase::EvalMult(ct,ct,key) does next, base-leveledshe.cpp:204-205).
+extern "C" size_t fhe_bfv_eval_mult_behz_workspace_bytes(const fhe_behz* h, uint32_t batch) {
+    if (!h)
+        return 0;
+    const size_t ext = ((size_t)batch * (h->numQ + h->numBsk)) << h->ctx->logN;
+    return (7 * ext) * 8 + fhe_behz_workspace_bytes(h, batch);
+}
+extern "C" fhe_status fhe_bfv_eval_mult_behz(fhe_behz* h, const uint64_t* a0, const uint64_t* a1, const uint64_t* b0,
+                                             const uint64_t* b1, uint64_t* d0, uint64_t* d1, uint64_t* d2, int outEval,
+                                             uint32_t batch, void* ws, size_t wsBytes, void* st) {
+    ARG_CHECK(h && a0 && a1 && b0 && b1 && d0 && d1 && d2 && ws && batch >= 1, "fhe_bfv_eval_mult_behz: bad argument");
+    ARG_CHECK(wsBytes >= fhe_bfv_eval_mult_behz_workspace_bytes(h, batch), "fhe_bfv_eval_mult_behz: workspace too small");
+    fhe_ctx* c = h->ctx;
+    RT_CHECK(rt::set_device(c->device));
+    const uint32_t tot = h->numQ + h->numBsk;
+    const size_t ext = ((size_t)batch * tot) << c->logN, rowB = (size_t)8 << c->logN;
+    uint64_t* w        = (uint64_t*)ws;
+    uint64_t* e[4]     = {w, w + ext, w + 2 * ext, w + 3 * ext};
+    uint64_t* p[3]     = {w + 4 * ext, w + 5 * ext, w + 6 * ext};
+    void* sub          = w + 7 * ext;
+    const size_t subB  = fhe_behz_workspace_bytes(h, batch);
+    const uint64_t* in[4] = {a0, a1, b0, b1};
+    for (int k = 0; k < 4; ++k) {
+        RT_CHECK(rt::d2d_2d(e[k], tot * rowB, in[k], h->numQ * rowB, h->numQ * rowB, batch, (rt::stream_t)st));
+        if (fhe_status s = fhe_behz_q_to_bsk(h, e[k], 1, batch, sub, subB, st))
+            return s;
+    }
+    if (fhe_status s = fhe_tensor(c, e[0], e[1], e[2], e[3], p[0], p[1], p[2], h->allIdx.data(), tot, batch, st))
+        return s;
+    uint64_t* out[3] = {d0, d1, d2};
+    for (int k = 0; k < 3; ++k) {
+        if (fhe_status s = fhe_ntt_inv(c, p[k], h->allIdx.data(), tot, batch, st))
+            return s;
+        if (fhe_status s = fhe_behz_floorq(h, p[k], batch, st))
+            return s;
+        if (fhe_status s = fhe_behz_conv_sk(h, p[k], out[k], batch, st))
+            return s;
+        if (outEval)
+            if (fhe_status s = fhe_ntt_fwd(c, out[k], h->qIdx.data(), h->numQ, batch, st))
+                return s;
+    }
+    return FHE_OK;
+}

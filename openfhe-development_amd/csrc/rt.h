@@ -38,6 +38,11 @@ inline const char* d2d(void* d, const void* s, size_t n, stream_t) {
     std::memmove(d, s, n);
     return nullptr;
 }
+inline const char* d2d_2d(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, stream_t) {
+    for (size_t r = 0; r < height; ++r)
+        std::memmove((char*)d + r * dpitch, (const char*)s + r * spitch, width);
+    return nullptr;
+}
 inline const char* sync(stream_t) { return nullptr; }
 inline const char* last_launch_error() { return nullptr; }
 struct Timer {
@@ -84,6 +89,10 @@ inline const char* d2h(void* d, const void* s, size_t n, stream_t st) {
 }
 inline const char* d2d(void* d, const void* s, size_t n, stream_t st) {
     return err(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, st));
+}
+inline const char* d2d_2d(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height,
+                          stream_t st) {
+    return err(hipMemcpy2DAsync(d, dpitch, s, spitch, width, height, hipMemcpyDeviceToDevice, st));
 }
 inline const char* sync(stream_t st) { return err(hipStreamSynchronize(st)); }
 inline const char* last_launch_error() { return err(hipGetLastError()); }

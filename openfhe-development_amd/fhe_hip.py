@@ -111,6 +111,8 @@ class Lib:
         S("fhe_behz_q_to_bsk", C.c_int, [vp, vp, C.c_int, u32, vp, C.c_size_t, vp])
         S("fhe_behz_floorq", C.c_int, [vp, vp, u32, vp])
         S("fhe_behz_conv_sk", C.c_int, [vp, vp, vp, u32, vp])
+        S("fhe_bfv_eval_mult_behz_workspace_bytes", C.c_size_t, [vp, u32])
+        S("fhe_bfv_eval_mult_behz", C.c_int, [vp] * 8 + [C.c_int, u32, vp, C.c_size_t, vp])
         S("fhe_param_first_prime", u64, [u32, u64])
         S("fhe_param_last_prime", u64, [u32, u64])
         S("fhe_param_next_prime", u64, [u64, u64])
@@ -503,3 +505,19 @@ class Behz:
         out = self.ctx.empty(t.batch, self.numQ, self.q_idx, COEFFICIENT)
         self.ctx.lib.check(self.ctx.lib.L.fhe_behz_conv_sk(self.h, t.ptr, out.ptr, t.batch, stream))
         return out
+
+    def EvalMultNoRelin(self, a0, a1, b0, b1, out_eval=False, stream=None):
+        """LeveledSHEBFVRNS::EvalMult (BEHZ) on device towers [batch][numQ][N] (EVALUATION); returns (d0, d1, d2)"""
+        B = a0.batch
+        fmt = EVALUATION if out_eval else COEFFICIENT
+        d = [self.ctx.empty(B, self.numQ, self.q_idx, fmt) for _ in range(3)]
+        L = self.ctx.lib.L
+        wsb = L.fhe_bfv_eval_mult_behz_workspace_bytes(self.h, B)
+        ws = self.ctx.malloc(wsb)
+        try:
+            self.ctx.lib.check(L.fhe_bfv_eval_mult_behz(self.h, a0.ptr, a1.ptr, b0.ptr, b1.ptr, d[0].ptr, d[1].ptr,
+                                                        d[2].ptr, 1 if out_eval else 0, B, ws, wsb, stream))
+            self.ctx.sync(stream)
+        finally:
+            self.ctx.free(ws)
+        return d

@@ -1378,3 +1378,51 @@ void orc_behz_fast_base_conv_sk(const orc_behz* h, const uint64_t* x, uint64_t* 
         }
     }
 }
+
+/* LeveledSHEBFVRNS::EvalMult, BEHZ branch (src/pke/lib/scheme/bfvrns/bfvrns-leveledshe.cpp:198-445):
+ *   :302-325  FastBaseConvqToBskMontgomery on every input element, then SetFormat(EVALUATION)
+ *   :327-372  tensor product over Q u Bsk (non-Karatsuba order: d0=a0*b0, d1=a0*b1 then += a1*b0, d2=a1*b1)
+ *   :414-437  per product element: SetFormat(COEFFICIENT); FastRNSFloorq; FastBaseConvSK
+ * ctxAll: limbs 0..numQ-1 = Q, numQ.. = Bsk.  Inputs [numQ][N] EVALUATION; outputs [numQ][N] COEFFICIENT. */
+void orc_bfv_eval_mult_behz(const orc_behz* h, const orc_ctx* ctxAll, const uint64_t* a0, const uint64_t* a1,
+                            const uint64_t* b0, const uint64_t* b1, uint64_t* d0, uint64_t* d1, uint64_t* d2) {
+    const uint32_t N = h->N, numQ = h->numQ, numBsk = h->numBsk, tot = numQ + numBsk;
+    const size_t qw = (size_t)numQ * N, aw = (size_t)tot * N;
+    uint32_t* idxBsk = (uint32_t*)malloc(4 * numBsk);
+    for (uint32_t j = 0; j < numBsk; ++j)
+        idxBsk[j] = numQ + j;
+    const uint64_t* in[4] = {a0, a1, b0, b1};
+    uint64_t* ext[4];
+    uint64_t* coef = (uint64_t*)malloc(8 * qw);
+    for (int e = 0; e < 4; ++e) {
+        ext[e] = (uint64_t*)malloc(8 * aw);
+        memcpy(coef, in[e], 8 * qw);
+        orc_ntt_inv_tower(ctxAll, coef, NULL, numQ, 1, 1);                 /* dcrtpoly-impl.h:1708-1712 */
+        orc_behz_q_to_bsk_montgomery(h, coef, ext[e] + qw);
+        orc_ntt_fwd_tower(ctxAll, ext[e] + qw, idxBsk, numBsk, 1, 1);
+        memcpy(ext[e], in[e], 8 * qw);                                     /* Q limbs keep their NTT form */
+    }
+    uint64_t* prod[3];
+    uint64_t* tmp = (uint64_t*)malloc(8 * (size_t)N);
+    for (int e = 0; e < 3; ++e)
+        prod[e] = (uint64_t*)malloc(8 * aw);
+    for (uint32_t l = 0; l < tot; ++l) {
+        const uint64_t m = orc_ctx_modulus(ctxAll, l);
+        const size_t o   = (size_t)l * N;
+        orc_vec_mul(prod[0] + o, ext[0] + o, ext[2] + o, N, m);
+        orc_vec_mul(prod[1] + o, ext[0] + o, ext[3] + o, N, m);
+        orc_vec_mul(tmp, ext[1] + o, ext[2] + o, N, m);
+        orc_vec_add(prod[1] + o, prod[1] + o, tmp, N, m);
+        orc_vec_mul(prod[2] + o, ext[1] + o, ext[3] + o, N, m);
+    }
+    uint64_t* out[3] = {d0, d1, d2};
+    for (int e = 0; e < 3; ++e) {
+        orc_ntt_inv_tower(ctxAll, prod[e], NULL, tot, 1, 1);
+        orc_behz_fast_rns_floorq(h, prod[e]);
+        orc_behz_fast_base_conv_sk(h, prod[e], out[e]);
+        free(prod[e]);
+    }
+    for (int e = 0; e < 4; ++e)
+        free(ext[e]);
+    free(tmp), free(coef), free(idxBsk);
+}

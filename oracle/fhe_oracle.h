@@ -177,6 +177,10 @@ void      orc_behz_get_bsk(const orc_behz*, uint64_t* bsk, uint64_t* psiBsk);
 void orc_behz_q_to_bsk_montgomery(const orc_behz*, const uint64_t* xq /*[numQ][N]*/, uint64_t* outBsk /*[numBsk][N]*/);
 void orc_behz_fast_rns_floorq(const orc_behz*, uint64_t* x /*[numQ+numBsk][N], in place*/);
 void orc_behz_fast_base_conv_sk(const orc_behz*, const uint64_t* x /*[numQ+numBsk][N]*/, uint64_t* outQ /*[numQ][N]*/);
+/* LeveledSHEBFVRNS::EvalMult, BEHZ branch (bfvrns-leveledshe.cpp:198-445) without relinearisation: ctxAll = Q then Bsk
+ * limbs; inputs [numQ][N] EVALUATION, outputs [numQ][N] COEFFICIENT (as the reference leaves them). */
+void orc_bfv_eval_mult_behz(const orc_behz*, const orc_ctx* ctxAll, const uint64_t* a0, const uint64_t* a1,
+                            const uint64_t* b0, const uint64_t* b1, uint64_t* d0, uint64_t* d1, uint64_t* d2);
 
 #ifdef __cplusplus
 }

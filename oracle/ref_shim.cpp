@@ -479,6 +479,8 @@ void ref_scale_and_round_p_over_q(uint32_t N, uint32_t sizeQ, const uint64_t* mo
 // ---- BFV / BEHZ session: the reference's own CryptoParametersBFVRNS tables ----
 struct RefBfv {
     CryptoContext<DCRTPoly> cc;
+    KeyPair<DCRTPoly> kp;
+    std::vector<Ciphertext<DCRTPoly>> cts;
 };
 void* ref_bfv_create(uint32_t ringDim, uint64_t t, uint32_t multDepth, uint32_t scalingModSize, int multTech) {
     CCParams<CryptoContextBFVRNS> parameters;
@@ -491,10 +493,51 @@ void* ref_bfv_create(uint32_t ringDim, uint64_t t, uint32_t multDepth, uint32_t 
     auto* s = new RefBfv;
     s->cc   = GenCryptoContext(parameters);
     s->cc->Enable(PKE);
+    s->cc->Enable(KEYSWITCH);
     s->cc->Enable(LEVELEDSHE);
     return s;
 }
 void ref_bfv_destroy(void* h) { delete static_cast<RefBfv*>(h); }
+// ciphertext session (config 5): keys, deterministic packed messages, EvalMultNoRelin through the scheme layer
+void ref_bfv_keygen(void* h) {
+    auto* s = static_cast<RefBfv*>(h);
+    s->kp   = s->cc->KeyGen();
+}
+int ref_bfv_encrypt(void* h, uint32_t seed) {
+    auto* s    = static_cast<RefBfv*>(h);
+    uint64_t t = s->cc->GetCryptoParameters()->GetPlaintextModulus();
+    std::mt19937_64 gen(seed);
+    std::vector<int64_t> v(s->cc->GetRingDimension());
+    for (auto& e : v)
+        e = static_cast<int64_t>(gen() % t) - static_cast<int64_t>(t / 2);
+    s->cts.push_back(s->cc->Encrypt(s->kp.publicKey, s->cc->MakePackedPlaintext(v)));
+    return static_cast<int>(s->cts.size()) - 1;
+}
+// info[0]=#elements, [1]=#limbs, [2]=format of element 0 (0 = EVALUATION, 1 = COEFFICIENT)
+void ref_bfv_ct_info(void* h, int ct, uint32_t* info) {
+    auto& c = static_cast<RefBfv*>(h)->cts[ct];
+    info[0] = c->GetElements().size();
+    info[1] = c->GetElements()[0].GetNumOfElements();
+    info[2] = c->GetElements()[0].GetFormat() == Format::EVALUATION ? 0 : 1;
+}
+void ref_bfv_ct_export(void* h, int ct, uint32_t elem, uint64_t* out) {
+    export_poly(static_cast<RefBfv*>(h)->cts[ct]->GetElements()[elem], out);
+}
+int ref_bfv_eval_mult_no_relin(void* h, int a, int b) {  // bfvrns-leveledshe.cpp:198-445
+    auto* s = static_cast<RefBfv*>(h);
+    s->cts.push_back(s->cc->EvalMultNoRelin(s->cts[a], s->cts[b]));
+    return static_cast<int>(s->cts.size()) - 1;
+}
+double ref_bfv_time_eval_mult_no_relin(void* h, int a, int b, int reps) {
+    auto* s = static_cast<RefBfv*>(h);
+    auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps; ++r) {
+        auto c = s->cc->EvalMultNoRelin(s->cts[a], s->cts[b]);
+        (void)c;
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double>(t1 - t0).count() / reps;
+}
 // info[0]=N, [1]=numQ, [2]=numBsk
 void ref_bfv_info(void* h, uint32_t* info) {
     const auto cp = std::dynamic_pointer_cast<CryptoParametersBFVRNS>(static_cast<RefBfv*>(h)->cc->GetCryptoParameters());

@@ -108,6 +108,7 @@ def load_oracle():
     S("orc_behz_q_to_bsk_montgomery", None, [vp, P64, P64])
     S("orc_behz_fast_rns_floorq", None, [vp, P64])
     S("orc_behz_fast_base_conv_sk", None, [vp, P64, P64])
+    S("orc_bfv_eval_mult_behz", None, [vp, vp] + [P64] * 7)
     _oracle = L
     return L
 
@@ -182,6 +183,12 @@ def load_ref():
     S("ref_bfv_behz_q_to_bsk", None, [vp, P64, C.c_int, P64])
     S("ref_bfv_fast_rns_floorq", None, [vp, P64])
     S("ref_bfv_fast_base_conv_sk", None, [vp, P64, P64])
+    S("ref_bfv_keygen", None, [vp])
+    S("ref_bfv_encrypt", C.c_int, [vp, u32])
+    S("ref_bfv_ct_info", None, [vp, C.c_int, P32])
+    S("ref_bfv_ct_export", None, [vp, C.c_int, u32, P64])
+    S("ref_bfv_eval_mult_no_relin", C.c_int, [vp, C.c_int, C.c_int])
+    S("ref_bfv_time_eval_mult_no_relin", C.c_double, [vp, C.c_int, C.c_int, C.c_int])
     _ref = L
     return L
 

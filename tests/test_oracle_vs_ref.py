@@ -202,6 +202,48 @@ def test_behz_against_live_reference(oracle, ref, ring, t, depth, sms):
     r.ref_bfv_destroy(h)
 
 
+def ref_bfv_session(r, ring, t, depth, sms):
+    """reference BFV/BEHZ context with two fresh ciphertexts and their EvalMultNoRelin product, exported as arrays"""
+    h = r.ref_bfv_create(ring, t, depth, sms, 0)
+    info = np.zeros(3, np.uint32)
+    r.ref_bfv_info(h, info)
+    N, numQ, numBsk = map(int, info)
+    q, pq = np.zeros(numQ, np.uint64), np.zeros(numQ, np.uint64)
+    bsk, pb = np.zeros(numBsk, np.uint64), np.zeros(numBsk, np.uint64)
+    r.ref_bfv_get_moduli(h, q, pq, bsk, pb)
+    r.ref_bfv_keygen(h)
+    a, b = r.ref_bfv_encrypt(h, 1), r.ref_bfv_encrypt(h, 2)
+    c = r.ref_bfv_eval_mult_no_relin(h, a, b)
+
+    def export(ct):
+        ci = np.zeros(3, np.uint32)
+        r.ref_bfv_ct_info(h, ct, ci)
+        out = np.zeros((int(ci[0]), int(ci[1]), N), np.uint64)
+        for e in range(int(ci[0])):
+            r.ref_bfv_ct_export(h, ct, e, out[e])
+        return out, int(ci[2])
+
+    (A, fa), (B, fb), (D, fd) = export(a), export(b), export(c)
+    assert (fa, fb, fd) == (0, 0, 1) and D.shape[0] == 3  # inputs EVALUATION, product COEFFICIENT with 3 elements
+    return h, N, q, pq, bsk, pb, A, B, D
+
+
+@pytest.mark.parametrize("ring,t,depth,sms", [(64, 65537, 2, 60), (1024, 786433, 3, 55)])
+def test_bfv_eval_mult_behz_against_live_reference(oracle, ref, ring, t, depth, sms):
+    """LeveledSHEBFVRNS::EvalMult (BEHZ) through the reference's scheme layer vs the oracle's composite"""
+    o, r = oracle, ref
+    h, N, q, pq, bsk, pb, A, B, D = ref_bfv_session(r, ring, t, depth, sms)
+    numQ = len(q)
+    hb = o.orc_behz_create(N, numQ, q, t)
+    call = o.orc_ctx_create(N, numQ + len(bsk), np.concatenate([q, bsk]), np.concatenate([pq, pb]))
+    got = np.zeros((3, numQ, N), np.uint64)
+    o.orc_bfv_eval_mult_behz(hb, call, A[0], A[1], B[0], B[1], got[0], got[1], got[2])
+    assert np.array_equal(got, D)
+    o.orc_ctx_destroy(call)
+    o.orc_behz_destroy(hb)
+    r.ref_bfv_destroy(h)
+
+
 @pytest.mark.parametrize("sizeI,sizeO,outputFirst,fscale", [(3, 2, 1, 1.0), (4, 3, 0, 1.0), (3, 2, 1, 2.0 ** 60), (2, 3, 0, 32.0)])
 def test_scale_and_round_against_live_reference(oracle, ref, sizeI, sizeO, outputFirst, fscale):
     o, r = oracle, ref

@@ -121,3 +121,53 @@ def test_behz_trio(backend, oracle, logN, numQ, t, B):
     plan.close()
     ctx.close()
     o.orc_behz_destroy(hb)
+
+
+@pytest.mark.parametrize("logN,numQ,t,B", [(4, 2, 65537, 2), (10, 3, 65537, 3), (12, 4, 786433, 1)])
+def test_bfv_eval_mult_behz(backend, oracle, logN, numQ, t, B):
+    """fhe_bfv_eval_mult_behz vs the oracle's composite (itself pinned to the reference's scheme-layer EvalMultNoRelin)"""
+    o = oracle
+    rng = np.random.default_rng(29)
+    N, q, psiQ, bsk, psiB, hb, ctx, plan = behz_setup(backend, o, logN, numQ, t)
+    call = o.orc_ctx_create(N, numQ + len(bsk), np.concatenate([q, bsk]), np.concatenate([psiQ, psiB]))
+    X = [libs.rand_tower(rng, q, N, B) for _ in range(4)]
+    want = np.zeros((3, B, numQ, N), np.uint64)
+    for b in range(B):
+        o.orc_bfv_eval_mult_behz(hb, call, X[0][b], X[1][b], X[2][b], X[3][b], want[0, b], want[1, b], want[2, b])
+    T = [ctx.tower(x, limb_idx=np.arange(numQ)) for x in X]
+    got = plan.EvalMultNoRelin(*T)
+    for k in range(3):
+        assert np.array_equal(got[k].to_host(), want[k]), f"product element {k}"
+    octxQ = o.orc_ctx_create(N, numQ, q, psiQ)
+    got = plan.EvalMultNoRelin(*T, out_eval=True)
+    for k in range(3):
+        w = want[k].copy()
+        o.orc_ntt_fwd_tower(octxQ, w, None, numQ, B, 1)
+        assert np.array_equal(got[k].to_host(), w), f"product element {k} (EVALUATION)"
+    plan.close()
+    ctx.close()
+    o.orc_ctx_destroy(call)
+    o.orc_ctx_destroy(octxQ)
+    o.orc_behz_destroy(hb)
+
+
+@pytest.mark.parametrize("ring", [64, 1024])
+def test_bfv_eval_mult_behz_reference_vectors(backend, ring):
+    """the product against ciphertexts produced by the reference's own scheme layer (tests/golden/ref_vectors_bfv.npz,
+    generated by tests/golden/make_golden_bfv.py running cc->EvalMultNoRelin): no oracle in the loop"""
+    import os
+    V = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_vectors_bfv.npz"))
+    k = f"bfv{ring}"
+    q, psiQ, bsk, psiB, t = V[k + "_q"], V[k + "_psiQ"], V[k + "_bsk"], V[k + "_psiBsk"], int(V[k + "_t"][0])
+    A, B, D = V[k + "_a"], V[k + "_b"], V[k + "_d"]
+    numQ, nb, logN = len(q), len(bsk), int(ring).bit_length() - 1
+    b2, p2 = backend.behz_bsk(logN, q, t)
+    assert np.array_equal(b2, bsk) and np.array_equal(p2, psiB)
+    ctx = fh.Context(backend, logN, np.concatenate([q, bsk]), np.concatenate([psiQ, psiB]))
+    plan = fh.Behz(ctx, np.arange(numQ), np.arange(numQ, numQ + nb), t)
+    T = [ctx.tower(x[None], limb_idx=np.arange(numQ)) for x in (A[0], A[1], B[0], B[1])]
+    got = plan.EvalMultNoRelin(*T)
+    for e in range(3):
+        assert np.array_equal(got[e].to_host()[0], D[e]), f"product element {e}"
+    plan.close()
+    ctx.close()
