@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-evalmult", action="store_true")
     ap.add_argument("--evalmult-batch", type=int, default=64, help="ciphertexts per GPU in the EvalMult leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--bfv", action="store_true", help="also time BFV EvalMult (BEHZ), BASELINE configs[4] shape")
+    ap.add_argument("--bfv-batch", type=int, default=64)
     return ap.parse_args()
 
 
@@ -172,6 +174,72 @@ def evalmult_leg(lib, device, logN, batch, steps, warmup, sync):
             "shape": f"N=2^{logN}, l={sizeQ}, k={len(p)}, dnum={dnum}, workspace {wsb / 2**30:.1f} GiB"}
 
 
+def bfv_leg(lib, device, batch, steps, warmup, sync, with_cpu):
+    """BFV EvalMult (BEHZ, no relinearisation) at BASELINE configs[4]'s shape: N=2^15, Q = 7 x 60-bit limbs and
+    Bsk = 8 limbs (log2(Q*Bsk) ~ 900).  Product: fhe_bfv_eval_mult_behz on `batch` ciphertext pairs; CPU: the reference's
+    own cc->EvalMultNoRelin (oracle/_ref) on one pair when its build travelled with the repo."""
+    logN, numQ, t = 15, 7, 65537
+    q, psiQ = lib.ckks_like_chain(logN, numQ, 60, 60)
+    bsk, psiB = lib.behz_bsk(logN, q, t)
+    ctx = fh.Context(lib, logN, np.concatenate([q, bsk]), np.concatenate([psiQ, psiB]), device=device)
+    plan = fh.Behz(ctx, np.arange(numQ), np.arange(numQ, numQ + len(bsk)), t)
+    ops = [fh.Tower(ctx, fill_random_tower(ctx, q, batch, 200 + i, seed_polys=2), batch, numQ) for i in range(4)]
+    d = [ops[0].like() for _ in range(3)]
+    wsb = lib.L.fhe_bfv_eval_mult_behz_workspace_bytes(plan.h, batch)
+    ws = ctx.malloc(wsb)
+
+    def step():
+        lib.check(lib.L.fhe_bfv_eval_mult_behz(plan.h, ops[0].ptr, ops[1].ptr, ops[2].ptr, ops[3].ptr, d[0].ptr,
+                                               d[1].ptr, d[2].ptr, 0, batch, ws, wsb, None))
+    for _ in range(warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    dt = (time.perf_counter() - t0) / steps
+    ctx.free(ws)
+    plan.close()
+    ctx.close()
+    cpu = None
+    if with_cpu:  # after the GPU leg: the reference's OpenMP team keeps spinning for a while and slows kernel launches
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import libs
+        if libs.have_ref():
+            r = libs.load_ref()
+            for depth in range(2, 12):  # the reference sizes Q from the depth: first context with >= numQ limbs
+                h = r.ref_bfv_create(1 << logN, t, depth, 60, 0)
+                info = np.zeros(3, np.uint32)
+                r.ref_bfv_info(h, info)
+                if int(info[1]) >= numQ:
+                    break
+                r.ref_bfv_destroy(h)
+            r.ref_bfv_keygen(h)
+            ca, cb = r.ref_bfv_encrypt(h, 1), r.ref_bfv_encrypt(h, 2)
+            gomp = C.CDLL("libgomp.so.1")
+            cores = os.cpu_count() or 1
+            best, best_t = None, None
+            for nt in sorted({cores, 128, 64, 32, 16, 8}):  # give the reference its best OpenMP team size
+                if nt > cores:
+                    continue
+                gomp.omp_set_num_threads(nt)
+                r.ref_bfv_time_eval_mult_no_relin(h, ca, cb, 1)
+                sec1 = r.ref_bfv_time_eval_mult_no_relin(h, ca, cb, 2)
+                if best is None or sec1 < best_t:
+                    best, best_t = nt, sec1
+            gomp.omp_set_num_threads(best)
+            reps = max(3, min(50, int(3.0 / best_t)))
+            sec = r.ref_bfv_time_eval_mult_no_relin(h, ca, cb, reps)
+            cpu = {"value": round(1.0 / sec, 2), "unit": "EvalMult/s", "cores": int(best), "kind": "reference",
+                   "sample": f"{reps} x cc->EvalMultNoRelin (BEHZ), N=2^{logN}, {int(info[1])} Q limbs (depth {depth}); "
+                             f"{sec * 1e3:.1f} ms each; best OpenMP team of {{8..{cores}}}; host has {cores} logical cores"}
+            r.ref_bfv_destroy(h)
+    return {"ops_per_s_per_gpu": round(batch / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "batch": batch,
+            "shape": f"N=2^{logN}, {numQ} Q limbs + {len(bsk)} Bsk limbs, t={t}, no relinearisation",
+            "cpu_baseline": cpu}
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -275,6 +343,11 @@ def main():
         else:
             em["ops_per_s_total"] = em["ops_per_s_per_gpu"]
 
+    bfv = None
+    if a.bfv:
+        bfv = bfv_leg(lib, device, a.bfv_batch, max(2, a.steps // 3), 1, gpu_sync,
+                      rank == 0 and world == 1 and not a.no_cpu_baseline)
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(q, psi, logN, L, a.cpu_seconds)
@@ -292,6 +365,8 @@ def main():
             "hbm_roofline_frac_fwd_inv": round(value / world / HBM_PEAK_GBPS, 4),
             "roofline": roof, "cpu_baseline": cpu, "evalmult": em,
         }
+        if bfv is not None:
+            out["bfv_evalmult"] = bfv
         print(json.dumps(out))
     ctx.close()
     if dist is not None:

@@ -24,13 +24,13 @@ namespace fhe {
 
 
 struct ConvTables {           // device-resident, built once per (source basis, target basis)
-    const TwPair* hatInv;     // [nSrc]  [Qhat_i^-1]_{q_i} as Shoup pair
-    const uint64_t* hatMod;   // [nSrc][nDst]  [Qhat_i]_{p_j}
-    const uint64_t* srcQ;     // [nSrc]
+    const TwPair* hatInv;     // [32]  [Qhat_i^-1]_{q_i} as Shoup pair (entries >= nSrc are padding)
+    const uint64_t* hatMod;   // [nDst][NSRC]  [Qhat_i]_{p_j}: one target's row contiguous, padded to the kernel's NSRC
+    const uint64_t* srcQ;     // [32]
     const uint64_t* dstQ;     // [nDst]
     const uint64_t* dstMu;    // [nDst][2]  floor(2^128/p_j) (lo,hi)
     // exact variant only:
-    const double* srcQInv;    // [nSrc] 1.0/q_i
+    const double* srcQInv;    // [32] 1.0/q_i
     const uint64_t* alphaMod; // [nSrc+1][nDst]  [alpha*Q]_{p_j}
 };
 
@@ -57,33 +57,49 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) switch_basis_kernel(const ConvArgs g
     const uint64_t* in = g.in + (((uint64_t)b * g.inStride + g.inFirst) << g.logN) + ri;
     uint64_t* out      = g.out + (((uint64_t)b * g.outStride + g.outFirst) << g.logN) + ri;
 
+    // Every table is padded to NSRC entries on the host, and the source residues are read with a clamped row index,
+    // so that all loads of a phase are unconditional: the compiler issues them back to back (one wide s_load per
+    // table row, NSRC global loads in flight) instead of one load + wait per uniform branch.
+    uint64_t xin[NSRC];
+#pragma unroll
+    for (int i = 0; i < NSRC; ++i) {
+        const uint32_t row = (uint32_t)i < g.nSrc ? (uint32_t)i : g.nSrc - 1u;
+        xin[i]             = in[(uint64_t)row << g.logN];
+    }
     uint64_t y[NSRC];
     // overflow count of the exact variant: nu = 0.5 + sum_i y_i/q_i in double, i ascending, one rounding per
     // multiply and per add (dcrtpoly-impl.h:1056-1063); compiled with -ffp-contract=off
     double nu = 0.5;
+    const uint64_t* hp = reinterpret_cast<const uint64_t*>(g.tb.hatInv);
 #pragma unroll
     for (int i = 0; i < NSRC; ++i) {
+        const uint64_t w = FHE_ULOAD64(hp, 2 * i), wp = FHE_ULOAD64(hp, 2 * i + 1), qi = FHE_ULOAD64(g.tb.srcQ, i);
+        const double qinv = EXACT ? FHE_ULOADF64(g.tb.srcQInv, i) : 0.0;
         y[i] = 0;
         if (i < (int)g.nSrc) {
-            const TwPair h = g.tb.hatInv[i];
-            y[i]           = mul_shoup(in[(uint64_t)i << g.logN], h.w, h.wp, g.tb.srcQ[i]);
+            y[i] = mul_shoup(xin[i], w, wp, qi);
             if (EXACT)
-                nu += (double)y[i] * g.tb.srcQInv[i];
+                nu += (double)y[i] * qinv;
         }
     }
     const uint32_t alpha = EXACT ? (uint32_t)nu : 0u;
 
     for (uint32_t j = 0; j < g.nDst; ++j) {
+        uint64_t h[NSRC];
+#pragma unroll
+        for (int i = 0; i < NSRC; ++i)
+            h[i] = FHE_ULOAD64(g.tb.hatMod, (uint64_t)j * NSRC + i);
+        const uint64_t p = FHE_ULOAD64(g.tb.dstQ, j);
+        const uint64_t mulo = FHE_ULOAD64(g.tb.dstMu, 2 * j), muhi = FHE_ULOAD64(g.tb.dstMu, 2 * j + 1);
         mac192 m;
         mac192_clear(m);
 #pragma unroll
         for (int i = 0; i < NSRC; ++i)
             if (i < (int)g.nSrc)
-                mac192_add(m, y[i], g.tb.hatMod[(uint64_t)i * g.nDst + j]);
+                mac192_add(m, y[i], h[i]);
         u128w acc;
         mac192_fold(m, acc.lo, acc.hi);
-        const uint64_t p = g.tb.dstQ[j];
-        uint64_t v       = barrett128(acc, p, g.tb.dstMu[2 * j], g.tb.dstMu[2 * j + 1]);
+        uint64_t v = barrett128(acc, p, mulo, muhi);
         if (EXACT)
             v = sub_mod(v, g.tb.alphaMod[(uint64_t)alpha * g.nDst + j], p);
         out[(uint64_t)j << g.logN] = v;

@@ -49,7 +49,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) scale_round_kernel(const ScaleRoundA
     double nu = 0.5;
     if (EXACT) {
         for (uint32_t i = 0; i < g.sizeI; ++i)
-            nu += g.frac[i] * (double)(*tv_at(g.in, b, i, g.logN, ri));  // :1543-1548, i ascending
+            nu += FHE_ULOADF64(g.frac, i) * (double)(*tv_at(g.in, b, i, g.logN, ri));  // :1543-1548, i ascending
     }
     // isConvertableToNativeInt(nu): |nu| <= (double)(2^64-1) == 2^64   (utils/utilities.h:122-126)
     const bool small = EXACT && (nu <= 18446744073709551616.0);
@@ -66,9 +66,9 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) scale_round_kernel(const ScaleRoundA
         const uint64_t* tj = g.tab + (uint64_t)j * (g.sizeI + 1);
         u128w acc{0, 0};
         for (uint32_t i = 0; i < g.sizeI; ++i)
-            acc128(acc, *tv_at(g.in, b, i, g.logN, ri), tj[i]);
-        acc128(acc, *tv_at(g.own, b, j, g.logN, ri), tj[g.sizeI]);
-        const uint64_t oj = g.o[j], mlo = g.mu[2 * j], mhi = g.mu[2 * j + 1];
+            acc128(acc, *tv_at(g.in, b, i, g.logN, ri), FHE_ULOAD64(tj, i));
+        acc128(acc, *tv_at(g.own, b, j, g.logN, ri), FHE_ULOAD64(tj, g.sizeI));
+        const uint64_t oj = FHE_ULOAD64(g.o, j), mlo = FHE_ULOAD64(g.mu, 2 * j), mhi = FHE_ULOAD64(g.mu, 2 * j + 1);
         uint64_t v = barrett128(acc, oj, mlo, mhi);
         if (EXACT) {
             uint64_t a;
@@ -117,20 +117,23 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) p_over_q_kernel(const POverQArgs g) 
 }
 
 // ---- BEHZ --------------------------------------------------------------------------------------------
+// Every vector table is padded to kMaxBfvLimbs entries and every matrix is stored [target][kMaxBfvLimbs] (one target's
+// row contiguous), so that the kernels read them unconditionally through the scalar cache (FHE_ULOAD64) and issue the
+// residue loads of a coefficient back to back (clamped row index) before any arithmetic.
 struct BehzTables {           // bfvrns-cryptoparameters.cpp:673-850; all device resident
-    const uint64_t *q, *bsk;                 // [numQ], [numBsk]
-    const uint64_t *muQ, *muBsk;             // [.][2]
-    const TwPair* mtQHatInv;                 // [numQ]   [mtilde (Q/q_i)^-1]_{q_i}
-    const uint64_t* QHatModbsk;              // [numQ][numBsk]
-    const uint64_t* QHatModmt;               // [numQ]
-    const TwPair *QModbsk, *mtInvModbsk;     // [numBsk]
-    const TwPair* tQHatInv;                  // [numQ]
-    const uint64_t* qInvModbsk;              // [numQ][numBsk]
-    const TwPair* tQInvModbsk;               // [numBsk]
-    const TwPair* BHatInv;                   // [numB]
-    const uint64_t* BHatModmsk;              // [numB]
-    const uint64_t* BHatModq;                // [numB][numQ]
-    const TwPair* BModq;                     // [numQ]
+    const uint64_t *q, *bsk;                 // [16] (padding = 1)
+    const uint64_t *muQ, *muBsk;             // [16][2]
+    const TwPair* mtQHatInv;                 // [16]   [mtilde (Q/q_i)^-1]_{q_i}
+    const uint64_t* QHatModbsk;              // [numBsk][16]   [Q/q_i]_{bsk_j}
+    const uint64_t* QHatModmt;               // [16]
+    const TwPair *QModbsk, *mtInvModbsk;     // [16]
+    const TwPair* tQHatInv;                  // [16]
+    const uint64_t* qInvModbsk;              // [numBsk][16]   [q_i^-1]_{bsk_j}
+    const TwPair* tQInvModbsk;               // [16]
+    const TwPair* BHatInv;                   // [16]
+    const uint64_t* BHatModmsk;              // [16]
+    const uint64_t* BHatModq;                // [numQ][16]     [B/b_i]_{q_j}
+    const TwPair* BModq;                     // [16]
     TwPair BInvModmsk;
     uint64_t negQInvModmt;
     uint64_t mskMu;                          // ComputeMu(msk)
@@ -143,6 +146,33 @@ struct BehzArgs {
     BehzTables tb;
     uint32_t logN, batch;
 };
+FHE_HD TwPair uload_pair(const TwPair* p, uint32_t i) {
+    const uint64_t* w = reinterpret_cast<const uint64_t*>(p);
+    return TwPair{FHE_ULOAD64(w, 2 * i), FHE_ULOAD64(w, 2 * i + 1)};
+}
+// residues of one coefficient: rows 0..n-1 of the view, all loads issued before use (row index clamped)
+FHE_HD void load_rows(uint64_t (&x)[kMaxBfvLimbs], const TowerView v, uint32_t b, uint32_t n, uint32_t logN, uint32_t ri) {
+#pragma unroll
+    for (int i = 0; i < kMaxBfvLimbs; ++i)
+        x[i] = *tv_at(v, b, (uint32_t)i < n ? (uint32_t)i : n - 1u, logN, ri);
+}
+// sum_i y_i * row[i] mod m for the first n entries of a [.][kMaxBfvLimbs] table row (128-bit sum, then Barrett)
+FHE_HD uint64_t dot_row_mod(const uint64_t (&y)[kMaxBfvLimbs], const uint64_t* row, uint32_t n, uint64_t m, uint64_t mulo,
+                            uint64_t muhi) {
+    uint64_t h[kMaxBfvLimbs];
+#pragma unroll
+    for (int i = 0; i < kMaxBfvLimbs; ++i)
+        h[i] = FHE_ULOAD64(row, i);
+    mac192 acc;
+    mac192_clear(acc);
+#pragma unroll
+    for (int i = 0; i < kMaxBfvLimbs; ++i)
+        if (i < (int)n)
+            mac192_add(acc, y[i], h[i]);
+    u128w a;
+    mac192_fold(acc, a.lo, a.hi);
+    return barrett128(a, m, mulo, muhi);
+}
 
 // core of FastBaseConvqToBskMontgomery: inQ (COEFF) -> outBsk (COEFF)
 FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) behz_q_to_bsk_kernel(const BehzArgs g) {
@@ -152,30 +182,28 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) behz_q_to_bsk_kernel(const BehzArgs 
     const uint32_t b = (uint32_t)(gid >> g.logN), ri = (uint32_t)gid & ((1u << g.logN) - 1u);
     const uint64_t mtilde = (uint64_t)1 << 16, half = mtilde >> 1, mask = mtilde - 1;
     uint64_t y[kMaxBfvLimbs];
+    load_rows(y, g.inQ, b, g.tb.numQ, g.logN, ri);
     uint64_t rm = 0;
 #pragma unroll
     for (int i = 0; i < kMaxBfvLimbs; ++i) {
+        const TwPair c    = uload_pair(g.tb.mtQHatInv, i);
+        const uint64_t qi = FHE_ULOAD64(g.tb.q, i), hm = FHE_ULOAD64(g.tb.QHatModmt, i);
         if (i < (int)g.tb.numQ) {
-            const TwPair c = g.tb.mtQHatInv[i];
-            y[i]           = mul_shoup(*tv_at(g.inQ, b, i, g.logN, ri), c.w, c.wp, g.tb.q[i]);
-            rm += y[i] * g.tb.QHatModmt[i];  // plain 64-bit wrap-around, :1741
+            y[i] = mul_shoup(y[i], c.w, c.wp, qi);
+            rm += y[i] * hm;  // plain 64-bit wrap-around, :1741
         }
     }
     rm &= mask;
     rm *= g.tb.negQInvModmt;
     rm &= mask;
     for (uint32_t j = 0; j < g.tb.numBsk; ++j) {
-        const uint64_t bj = g.tb.bsk[j];
-        u128w acc{0, 0};
-#pragma unroll
-        for (int i = 0; i < kMaxBfvLimbs; ++i)
-            if (i < (int)g.tb.numQ)
-                acc128(acc, y[i], g.tb.QHatModbsk[(uint64_t)i * g.tb.numBsk + j]);
-        const uint64_t v = barrett128(acc, bj, g.tb.muBsk[2 * j], g.tb.muBsk[2 * j + 1]);
+        const uint64_t bj = FHE_ULOAD64(g.tb.bsk, j);
+        const TwPair cq = uload_pair(g.tb.QModbsk, j), cm = uload_pair(g.tb.mtInvModbsk, j);
+        const uint64_t v = dot_row_mod(y, g.tb.QHatModbsk + (uint64_t)j * kMaxBfvLimbs, g.tb.numQ, bj,
+                                       FHE_ULOAD64(g.tb.muBsk, 2 * j), FHE_ULOAD64(g.tb.muBsk, 2 * j + 1));
         uint64_t r       = rm;
         if (rm >= half)
             r += bj - mtilde;  // centred remainder, :1767-1768
-        const TwPair cq = g.tb.QModbsk[j], cm = g.tb.mtInvModbsk[j];
         r = mul_shoup(r, cq.w, cq.wp, bj);
         r = add_mod(r, v, bj);
         *tv_at(g.outBsk, b, j, g.logN, ri) = mul_shoup(r, cm.w, cm.wp, bj);
@@ -188,26 +216,28 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) behz_floorq_kernel(const BehzArgs g)
     if (gid >= ((uint64_t)g.batch << g.logN))
         return;
     const uint32_t b = (uint32_t)(gid >> g.logN), ri = (uint32_t)gid & ((1u << g.logN) - 1u);
-    uint64_t y[kMaxBfvLimbs];
+    uint64_t y[kMaxBfvLimbs], xb[kMaxBfvLimbs];
+    load_rows(y, g.inQ, b, g.tb.numQ, g.logN, ri);
+    load_rows(xb, g.inBsk, b, g.tb.numBsk, g.logN, ri);
 #pragma unroll
     for (int i = 0; i < kMaxBfvLimbs; ++i) {
+        const TwPair c    = uload_pair(g.tb.tQHatInv, i);
+        const uint64_t qi = FHE_ULOAD64(g.tb.q, i);
         if (i < (int)g.tb.numQ) {
-            const TwPair c = g.tb.tQHatInv[i];
-            y[i]           = mul_shoup(*tv_at(g.inQ, b, i, g.logN, ri), c.w, c.wp, g.tb.q[i]);
+            y[i] = mul_shoup(y[i], c.w, c.wp, qi);
             *tv_at(g.outQ, b, i, g.logN, ri) = y[i];  // the reference updates the Q limbs in place (:1810-1816)
         }
     }
-    for (uint32_t j = 0; j < g.tb.numBsk; ++j) {
-        const uint64_t bj = g.tb.bsk[j];
-        u128w acc{0, 0};
 #pragma unroll
-        for (int i = 0; i < kMaxBfvLimbs; ++i)
-            if (i < (int)g.tb.numQ)
-                acc128(acc, y[i], g.tb.qInvModbsk[(uint64_t)i * g.tb.numBsk + j]);
-        const uint64_t s = barrett128(acc, bj, g.tb.muBsk[2 * j], g.tb.muBsk[2 * j + 1]);
-        const TwPair c   = g.tb.tQInvModbsk[j];
-        const uint64_t v = mul_shoup(*tv_at(g.inBsk, b, j, g.logN, ri), c.w, c.wp, bj);
-        *tv_at(g.outBsk, b, j, g.logN, ri) = sub_mod(v, s, bj);
+    for (int j = 0; j < kMaxBfvLimbs; ++j) {
+        if (j < (int)g.tb.numBsk) {
+            const uint64_t bj = FHE_ULOAD64(g.tb.bsk, j);
+            const TwPair c    = uload_pair(g.tb.tQInvModbsk, j);
+            const uint64_t s  = dot_row_mod(y, g.tb.qInvModbsk + (uint64_t)j * kMaxBfvLimbs, g.tb.numQ, bj,
+                                            FHE_ULOAD64(g.tb.muBsk, 2 * j), FHE_ULOAD64(g.tb.muBsk, 2 * j + 1));
+            const uint64_t v  = mul_shoup(xb[j], c.w, c.wp, bj);
+            *tv_at(g.outBsk, b, j, g.logN, ri) = sub_mod(v, s, bj);
+        }
     }
 }
 
@@ -218,34 +248,33 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) behz_conv_sk_kernel(const BehzArgs g
         return;
     const uint32_t b = (uint32_t)(gid >> g.logN), ri = (uint32_t)gid & ((1u << g.logN) - 1u);
     const uint32_t numB = g.tb.numBsk - 1;
-    const uint64_t msk = g.tb.bsk[numB], mskHalf = msk >> 1;
+    const uint64_t msk = FHE_ULOAD64(g.tb.bsk, numB), mskHalf = msk >> 1;
     uint64_t y[kMaxBfvLimbs];
+    load_rows(y, g.inBsk, b, numB, g.logN, ri);
+    const uint64_t xsk = *tv_at(g.inBsk, b, numB, g.logN, ri);
     uint64_t alpha = 0;
 #pragma unroll
     for (int i = 0; i < kMaxBfvLimbs; ++i) {
+        const TwPair c    = uload_pair(g.tb.BHatInv, i);
+        const uint64_t bi = FHE_ULOAD64(g.tb.bsk, i), hm = FHE_ULOAD64(g.tb.BHatModmsk, i);
         if (i < (int)numB) {
-            const TwPair c = g.tb.BHatInv[i];
-            y[i]           = mul_shoup(*tv_at(g.inBsk, b, i, g.logN, ri), c.w, c.wp, g.tb.bsk[i]);
+            y[i] = mul_shoup(y[i], c.w, c.wp, bi);
             // alpha += y_i * [B/b_i]_{msk} mod msk with fully reducing ModMul/ModAddEq (:1878-1881)
             const uint64_t yi = y[i] >= msk ? y[i] % msk : y[i];
-            alpha = add_mod(alpha, mul_mod_barrett(yi, g.tb.BHatModmsk[i], msk, g.tb.mskMu, (int)g.tb.mskMsb), msk);
+            alpha = add_mod(alpha, mul_mod_barrett(yi, hm, msk, g.tb.mskMu, (int)g.tb.mskMsb), msk);
         }
     }
-    alpha = sub_mod(alpha, *tv_at(g.inBsk, b, numB, g.logN, ri), msk);
+    alpha = sub_mod(alpha, xsk, msk);
     alpha = mul_shoup(alpha, g.tb.BInvModmsk.w, g.tb.BInvModmsk.wp, msk);
     for (uint32_t j = 0; j < g.tb.numQ; ++j) {
-        const uint64_t qj = g.tb.q[j];
-        u128w acc{0, 0};
-#pragma unroll
-        for (int i = 0; i < kMaxBfvLimbs; ++i)
-            if (i < (int)numB)
-                acc128(acc, y[i], g.tb.BHatModq[(uint64_t)i * g.tb.numQ + j]);
-        const uint64_t v = barrett128(acc, qj, g.tb.muQ[2 * j], g.tb.muQ[2 * j + 1]);
-        uint64_t a       = alpha;
+        const uint64_t qj = FHE_ULOAD64(g.tb.q, j);
+        const TwPair c    = uload_pair(g.tb.BModq, j);
+        const uint64_t v  = dot_row_mod(y, g.tb.BHatModq + (uint64_t)j * kMaxBfvLimbs, numB, qj,
+                                        FHE_ULOAD64(g.tb.muQ, 2 * j), FHE_ULOAD64(g.tb.muQ, 2 * j + 1));
+        uint64_t a        = alpha;
         if (a > mskHalf)
             a = (a < msk) ? a + qj - msk : a - msk;  // ModSubFast(alpha, msk, q_j) with 64-bit wrap (:1917-1918)
-        const TwPair c = g.tb.BModq[j];
-        a              = mul_shoup(a, c.w, c.wp, qj);
+        a = mul_shoup(a, c.w, c.wp, qj);
         *tv_at(g.outQ, b, j, g.logN, ri) = sub_mod(v, a, qj);
     }
 }

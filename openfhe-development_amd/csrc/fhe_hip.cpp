@@ -21,6 +21,7 @@
 #include "elemwise_kernels.h"
 #include "host_math.h"
 #include "ntt_kernels.h"
+#include "ntt_static.h"
 #include "rt.h"
 
 using namespace fhe;
@@ -467,6 +468,11 @@ static void mark_uniform(PassPlan& pp, uint32_t logN) {
     }
 }
 
+static bool ntt_static();
+static bool ntt_lds2();
+static bool ntt_generic();
+static bool ntt_legacy();
+static uint32_t ntt_stagger();
 static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse, const uint64_t* xin, uint64_t* xout,
                               const LimbSel& sel, uint32_t nLimbs, uint32_t batch, bool canonOut, void* stream,
                               uint32_t inStride = 0, uint32_t inFirst = 0, uint32_t outStride = 0, uint32_t outFirst = 0) {
@@ -521,6 +527,38 @@ static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse
             return fail(FHE_ERR_UNSUPPORTED, "ntt: no fast kernel instance for this pass plan");
         LAUNCH_CHECK();
         return FHE_OK;
+    }
+    if (c->logN >= (uint32_t)kTileLog && !ntt_legacy() && ntt_static()) {
+        // compile-time pass plans (ntt_static.h): in-place pinned-register butterflies, immediate-offset LDS exchange
+        // forward: bound class of the pass input; inverse: does this pass end the transform (ntt_static.h)
+        const bool twoPass = c->logN > (uint32_t)kTileLog;
+        const int mode = inverse ? ((pp.layoutA || !twoPass) ? 1 : 0) : ((!pp.layoutA && twoPass) ? 9 : 1);
+        bool launched = false;
+#define FHE_STATIC_CASE(LA, INV, TT, MODE) \
+    if (!launched && pp.layoutA == LA && inverse == INV && pp.T == TT && mode == MODE) { \
+        FHE_LAUNCH((ntt_static_kernel<LA, INV, TT, MODE, false>), grid, stream, a); \
+        launched = true; \
+    }
+        if (ntt_lds2() && !pp.layoutA && pp.T == 12 && twoPass) {  // tuning knob: double-buffered exchange (row pass only)
+            if (inverse)
+                FHE_LAUNCH((ntt_static_kernel<false, true, 12, 0, true>), grid, stream, a);
+            else
+                FHE_LAUNCH((ntt_static_kernel<false, false, 12, 9, true>), grid, stream, a);
+            launched = true;
+        }
+        // column passes of logN = 13..16 (T1 = 4) and 17 (T1 = 5); row passes T2 = logN - T1; the single pass of logN = 12
+        FHE_STATIC_CASE(true, false, 4, 1) FHE_STATIC_CASE(true, true, 4, 1)
+        FHE_STATIC_CASE(true, false, 5, 1) FHE_STATIC_CASE(true, true, 5, 1)
+        FHE_STATIC_CASE(false, false, 12, 9) FHE_STATIC_CASE(false, true, 12, 0)
+        FHE_STATIC_CASE(false, false, 11, 9) FHE_STATIC_CASE(false, true, 11, 0)
+        FHE_STATIC_CASE(false, false, 10, 9) FHE_STATIC_CASE(false, true, 10, 0)
+        FHE_STATIC_CASE(false, false, 9, 9) FHE_STATIC_CASE(false, true, 9, 0)
+        FHE_STATIC_CASE(false, false, 12, 1) FHE_STATIC_CASE(false, true, 12, 1)
+#undef FHE_STATIC_CASE
+        if (launched) {
+            LAUNCH_CHECK();
+            return FHE_OK;
+        }
     }
     if (c->logN >= (uint32_t)kTileLog && !ntt_legacy()) {
         if (pp.layoutA) {
@@ -578,6 +616,15 @@ static bool ntt_legacy() {
     // FHE_NTT_LEGACY=1 runs the generic (small-ring) kernel for every N; default for N >= 4096 is
     // ntt_pass_full_kernel (hand-scheduled butterflies, lazy-reduction schedule), measured 5 % faster on MI355X
     static const uint32_t v = env_u32("FHE_NTT_LEGACY", 0);
+    return v != 0;
+}
+static bool ntt_static() {
+    // FHE_NTT_STATIC=0 falls back to the run-time-plan kernel (ntt_pass_full_kernel) for every pass shape
+    static const uint32_t v = env_u32("FHE_NTT_STATIC", 1);
+    return v != 0;
+}
+static bool ntt_lds2() {
+    static const uint32_t v = env_u32("FHE_NTT_LDS2", 0);
     return v != 0;
 }
 static uint32_t ntt_stagger() {
@@ -862,6 +909,7 @@ static fhe_status conv_upload(fhe_conv* cv, const void* h, size_t bytes, const v
     return FHE_OK;
 }
 
+static uint32_t conv_nsrc_pad(uint32_t nSrc) { return nSrc <= 8 ? 8u : nSrc <= 16 ? 16u : 32u; }
 // tables for converting from moduli src[] to dst[]   (rns-cryptoparameters.cpp:214-246, 297-349)
 static fhe_status conv_build(fhe_ctx* c, const std::vector<uint64_t>& src, const std::vector<uint64_t>& dst,
                              fhe_conv** out) {
@@ -870,16 +918,21 @@ static fhe_status conv_build(fhe_ctx* c, const std::vector<uint64_t>& src, const
     cv->ctx      = c;
     cv->nSrc     = nSrc;
     cv->nDst     = nDst;
-    std::vector<TwPair> hatInv(nSrc);
-    std::vector<uint64_t> hatMod((size_t)nSrc * nDst), mu(2 * (size_t)nDst), alphaMod((size_t)(nSrc + 1) * nDst);
-    std::vector<double> qInv(nSrc);
+    // table rows are padded to the NSRC of the kernel instantiation conv_run picks, so that the kernel's table
+    // reads are unconditional (basis_kernels.h)
+    const uint32_t pad = conv_nsrc_pad(nSrc);
+    std::vector<TwPair> hatInv(32, TwPair{0, 0});
+    std::vector<uint64_t> hatMod((size_t)pad * nDst, 0), mu(2 * (size_t)nDst), alphaMod((size_t)(nSrc + 1) * nDst);
+    std::vector<uint64_t> srcPad(32, 1);
+    std::vector<double> qInv(32, 0.0);
     for (uint32_t i = 0; i < nSrc; ++i) {
         const uint64_t hat = host::prod_mod(src, (int)i, src[i]);
         const uint64_t inv = host::invmod(hat, src[i]);
         hatInv[i]          = TwPair{inv, host::shoup(inv, src[i])};
         qInv[i]            = 1.0 / static_cast<double>(src[i]);
+        srcPad[i]          = src[i];
         for (uint32_t j = 0; j < nDst; ++j)
-            hatMod[(size_t)i * nDst + j] = host::prod_mod(src, (int)i, dst[j]);
+            hatMod[(size_t)j * pad + i] = host::prod_mod(src, (int)i, dst[j]);
     }
     for (uint32_t j = 0; j < nDst; ++j) {
         host::mu128(dst[j], &mu[2 * j]);
@@ -890,7 +943,7 @@ static fhe_status conv_build(fhe_ctx* c, const std::vector<uint64_t>& src, const
     fhe_status s;
     if ((s = conv_upload(cv, hatInv.data(), hatInv.size() * sizeof(TwPair), (const void**)&cv->tb.hatInv)) ||
         (s = conv_upload(cv, hatMod.data(), hatMod.size() * 8, (const void**)&cv->tb.hatMod)) ||
-        (s = conv_upload(cv, src.data(), src.size() * 8, (const void**)&cv->tb.srcQ)) ||
+        (s = conv_upload(cv, srcPad.data(), srcPad.size() * 8, (const void**)&cv->tb.srcQ)) ||
         (s = conv_upload(cv, dst.data(), dst.size() * 8, (const void**)&cv->tb.dstQ)) ||
         (s = conv_upload(cv, mu.data(), mu.size() * 8, (const void**)&cv->tb.dstMu)) ||
         (s = conv_upload(cv, qInv.data(), qInv.size() * sizeof(double), (const void**)&cv->tb.srcQInv)) ||
@@ -939,9 +992,10 @@ static fhe_status conv_run(fhe_conv* cv, const uint64_t* in, uint32_t inStride, 
     g.inStride = inStride, g.inFirst = inFirst, g.outStride = outStride, g.outFirst = outFirst;
     const uint64_t coeffs = (uint64_t)batch << g.logN;
     const uint32_t grid   = (uint32_t)((coeffs + kThreads - 1) / kThreads);
-    if (cv->nSrc <= 8)
+    const uint32_t pad = conv_nsrc_pad(cv->nSrc);
+    if (pad == 8)
         FHE_LAUNCH((switch_basis_kernel<8, EXACT>), grid, st, g);
-    else if (cv->nSrc <= 16)
+    else if (pad == 16)
         FHE_LAUNCH((switch_basis_kernel<16, EXACT>), grid, st, g);
     else
         FHE_LAUNCH((switch_basis_kernel<32, EXACT>), grid, st, g);
@@ -1595,18 +1649,22 @@ extern "C" fhe_status fhe_behz_create(fhe_ctx* c, const uint32_t* qLimbIdx, uint
     RT_CHECK(rt::set_device(c->device));
     const uint64_t mtilde = 1ull << 16, msk = bsk[numB];
     std::vector<uint64_t> B(bsk.begin(), bsk.begin() + numB);
-    std::vector<uint64_t> muQ(2 * (size_t)numQ), muBsk(2 * (size_t)numBsk), QHatModbsk((size_t)numQ * numBsk), QHatModmt(numQ),
-        qInvModbsk((size_t)numQ * numBsk), BHatModmsk(numB), BHatModq((size_t)numB * numQ);
-    std::vector<TwPair> mtQHatInv(numQ), tQHatInv(numQ), BModq(numQ), QModbsk(numBsk), mtInvModbsk(numBsk), tQInvModbsk(numBsk),
-        BHatInv(numB);
+    // vectors padded to kMaxBfvLimbs, matrices stored [target][kMaxBfvLimbs]: see bfv_kernels.h
+    constexpr size_t W = kMaxBfvLimbs;
+    std::vector<uint64_t> muQ(2 * W, 0), muBsk(2 * W, 0), QHatModbsk(W * numBsk, 0), QHatModmt(W, 0), qInvModbsk(W * numBsk, 0),
+        BHatModmsk(W, 0), BHatModq(W * numQ, 0), qPad(W, 1), bskPad(W, 1);
+    std::vector<TwPair> mtQHatInv(W, TwPair{0, 0}), tQHatInv(W, TwPair{0, 0}), BModq(W, TwPair{0, 0}), QModbsk(W, TwPair{0, 0}),
+        mtInvModbsk(W, TwPair{0, 0}), tQInvModbsk(W, TwPair{0, 0}), BHatInv(W, TwPair{0, 0});
+    std::copy(q.begin(), q.end(), qPad.begin());
+    std::copy(bsk.begin(), bsk.end(), bskPad.begin());
     auto pair = [](uint64_t v, uint64_t m) { return TwPair{v, host::shoup(v, m)}; };
     for (uint32_t i = 0; i < numQ; ++i) {
         const uint64_t qi = q[i], hatInv = host::invmod(host::prod_mod(q, (int)i, qi), qi);
         tQHatInv[i]  = pair(host::mulmod(hatInv, t % qi, qi), qi);        // :722-733
         mtQHatInv[i] = pair(host::mulmod(hatInv, mtilde % qi, qi), qi);   // :755-768
         for (uint32_t j = 0; j < numBsk; ++j) {
-            QHatModbsk[(size_t)i * numBsk + j] = host::prod_mod(q, (int)i, bsk[j]);         // :735-747
-            qInvModbsk[(size_t)i * numBsk + j] = host::invmod(qi % bsk[j], bsk[j]);          // :749-755
+            QHatModbsk[(size_t)j * W + i] = host::prod_mod(q, (int)i, bsk[j]);         // :735-747
+            qInvModbsk[(size_t)j * W + i] = host::invmod(qi % bsk[j], bsk[j]);          // :749-755
         }
         uint64_t v = 1;
         for (uint32_t k = 0; k < numQ; ++k)
@@ -1633,7 +1691,7 @@ extern "C" fhe_status fhe_behz_create(fhe_ctx* c, const uint32_t* qLimbIdx, uint
         BHatInv[i]    = pair(host::invmod(host::prod_mod(B, (int)i, B[i]), B[i]), B[i]);       // :806-817
         BHatModmsk[i] = host::prod_mod(B, (int)i, msk);                                      // :829-834
         for (uint32_t j = 0; j < numQ; ++j)
-            BHatModq[(size_t)i * numQ + j] = host::prod_mod(B, (int)i, q[j]);                 // :819-827
+            BHatModq[(size_t)j * W + i] = host::prod_mod(B, (int)i, q[j]);                 // :819-827
     }
     fhe_behz* h = new fhe_behz;
     h->ctx = c, h->numQ = numQ, h->numBsk = numBsk;
@@ -1650,7 +1708,7 @@ extern "C" fhe_status fhe_behz_create(fhe_ctx* c, const uint32_t* qLimbIdx, uint
     fhe_status s;
     uint64_t *dq, *dbsk, *dmuQ, *dmuB, *d1, *d2, *d3, *d4, *d5;
     TwPair *p1, *p2, *p3, *p4, *p5, *p6, *p7;
-    if ((s = dev_copy(h->owned, q.data(), q.size(), &dq)) || (s = dev_copy(h->owned, bsk.data(), bsk.size(), &dbsk)) ||
+    if ((s = dev_copy(h->owned, qPad.data(), qPad.size(), &dq)) || (s = dev_copy(h->owned, bskPad.data(), bskPad.size(), &dbsk)) ||
         (s = dev_copy(h->owned, muQ.data(), muQ.size(), &dmuQ)) || (s = dev_copy(h->owned, muBsk.data(), muBsk.size(), &dmuB)) ||
         (s = dev_copy(h->owned, QHatModbsk.data(), QHatModbsk.size(), &d1)) || (s = dev_copy(h->owned, QHatModmt.data(), QHatModmt.size(), &d2)) ||
         (s = dev_copy(h->owned, qInvModbsk.data(), qInvModbsk.size(), &d3)) || (s = dev_copy(h->owned, BHatModmsk.data(), BHatModmsk.size(), &d4)) ||

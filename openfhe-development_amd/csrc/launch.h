@@ -16,6 +16,8 @@
 #define FHE_SYNC() fhe_emu::block_sync()
 #define FHE_SHARED_U64(name, n) uint64_t* name = reinterpret_cast<uint64_t*>(fhe_emu::block_shared(sizeof(uint64_t) * (n)))
 #define FHE_UNIFORM(x) (x)
+#define FHE_ULOAD64(p, i) ((p)[i])
+#define FHE_ULOADF64(p, i) ((p)[i])
 #else
 #include <hip/hip_runtime.h>
 #define FHE_GLOBAL __global__
@@ -27,6 +29,11 @@
 #define FHE_SYNC() __syncthreads()
 #define FHE_SHARED_U64(name, n) __shared__ uint64_t name[n]
 #define FHE_UNIFORM(x) (__builtin_amdgcn_readfirstlane(x))
+// Read-only, wave-uniform table word.  Reading it through the constant address space tells the compiler that the
+// table cannot alias the kernel's own stores, so the access becomes an s_load (scalar cache, wide, hoistable)
+// instead of a per-lane global_load that is waited for on the spot.
+#define FHE_ULOAD64(p, i) (((const __attribute__((address_space(4))) uint64_t*)(p))[i])
+#define FHE_ULOADF64(p, i) (((const __attribute__((address_space(4))) double*)(p))[i])
 #endif
 
 #endif

@@ -160,9 +160,10 @@ FHE_HD uint64_t barrett128(u128w a, uint64_t q, uint64_t mu_lo, uint64_t mu_hi) 
     uint64_t carry   = (uint64_t)(m2_lo + tmp1) < m2_lo;
     uint64_t quot    = a.hi * mu_hi + tmp2 + m2_hi + carry;
     uint64_t r       = a.lo - quot * q;
-    while (r >= q)
-        r -= q;
-    return r;
+    // quot is the exact floor(a*mu/2^128) with mu = floor(2^128/q), so floor(a/q) - quot is 0 or 1 (a < 2^128) and
+    // r < 2q; the reference's `while (r >= q) r -= q` therefore runs at most once.  Two conditional subtractions keep a
+    // margin and avoid a divergent loop.
+    return csub(csub(r, q), q);
 }
 
 // exact a*b mod q for a,b < q < 2^60 via the 128-bit Barrett above (any exact product equals the

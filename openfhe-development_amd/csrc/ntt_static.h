@@ -1,0 +1,362 @@
+// ntt_static.h — production NTT pass kernels for rings with N >= 4096: the step plan of a pass is a compile-time
+// constant (template parameters), so that
+//  * every loop over steps / stages is straight-line code,
+//  * the LDS exchange uses `base + immediate` addresses: the tile index I is stored at word I + (I >> 4) (one pad word
+//    per 16), which is additive over the disjoint bit fields of (lane part, register part) and conflict-free for
+//    ds_read_b64 / ds_write_b64 at every field position; two buffers alternate, one barrier per exchange,
+//  * the 16 residues of a lane stay in v[32:63] and the butterflies / conditional subtractions run in place on them
+//    (ntt_bfly_pinned.h, generated and simulated by tools/gen_ntt_asm.py),
+//  * wave-uniform twiddles and all limb constants are scalar operands.
+// Same transform, tables, stage order and lazy-reduction bounds as ntt_pass_full_kernel (ntt_kernels.h), which remains
+// the fallback for pass shapes that are not instantiated here; reference: transformnat-impl.h:303-374, 512-625.
+#ifndef FHE_NTT_STATIC_H
+#define FHE_NTT_STATIC_H
+#include "ntt_kernels.h"
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FHE_NO_BFLY_ASM)
+#include "ntt_bfly_pinned.h"
+#define FHE_PINNED_ASM 1
+#endif
+
+namespace fhe {
+
+#ifndef FHE_PINNED_ASM
+struct BflyConst {
+    uint32_t nql, nqh;
+    uint64_t twoq, ntwoq;
+};
+struct BflyZero {
+    uint32_t z0, z1;
+};
+#endif
+
+// compile-time plan of one pass: the same grouping of the T stages into register-resident steps as plan_pass()
+template <bool LA, bool INV, int T>
+struct SPlan {
+    static constexpr int logC = kTileLog - T;
+    static constexpr int nst  = (T + 3) / 4;
+    static constexpr int ish  = LA ? logC : 0;
+    static constexpr int size(int i) { return T / nst + (i < T % nst ? 1 : 0); }
+    static constexpr int before(int i) {
+        int s = 0;
+        for (int j = 0; j < i; ++j)
+            s += size(j);
+        return s;
+    }
+    static constexpr int fp(int i) {
+        if (!INV) {
+            const int top = T - 1 - before(i);
+            return top - 3 > 0 ? top - 3 : 0;
+        }
+        const int bot = before(i);
+        return bot < T - 4 ? bot : T - 4;
+    }
+    static constexpr int bHi(int i) { return !INV ? (T - 1 - before(i)) - fp(i) : before(i) - fp(i) + size(i) - 1; }
+    static constexpr int bLo(int i) { return !INV ? bHi(i) - size(i) + 1 : before(i) - fp(i); }
+    static constexpr int fI(int i) { return fp(i) + ish; }
+    static constexpr bool stageFirst = !LA && fI(0) < 4;        // coalesced staging through LDS before the first step
+    static constexpr bool stageLast  = !LA && fI(nst - 1) < 4;  // ... and after the last one
+    // forward lazy-reduction schedule (schedule_fwd): bound of the values, in units of q, before step i
+    static constexpr int boundBefore(int i, int bin) {
+        int b = bin;
+        for (int j = 0; j < i; ++j)
+            b = (b + 2 * size(j) <= 16) ? b + 2 * size(j) : 8 + 2 * size(j);
+        return b;
+    }
+    static constexpr bool sweep(int i, int bin) { return boundBefore(i, bin) + 2 * size(i) > 16; }
+    static constexpr int outBound(int bin) { return boundBefore(nst, bin); }
+};
+
+constexpr int kLdsPadWords = kTile + (kTile >> 4);
+FHE_HD constexpr uint32_t lds_pad(uint32_t I) {
+    return I + (I >> 4);
+}
+
+template <bool INV, bool UNI, int B>
+FHE_HD void run_stage(uint64_t (&r)[16], const TwPair (&w)[8], const BflyConst c, const BflyZero z) {
+#ifdef FHE_PINNED_ASM
+    if constexpr (!INV) {
+        if constexpr (UNI) {
+            if constexpr (B == 0) stage_fwd_s_b0(r, w, c, z);
+            if constexpr (B == 1) stage_fwd_s_b1(r, w, c, z);
+            if constexpr (B == 2) stage_fwd_s_b2(r, w, c, z);
+            if constexpr (B == 3) stage_fwd_s_b3(r, w, c, z);
+        }
+        else {
+            if constexpr (B == 0) stage_fwd_v_b0(r, w, c, z);
+            if constexpr (B == 1) stage_fwd_v_b1(r, w, c, z);
+            if constexpr (B == 2) stage_fwd_v_b2(r, w, c, z);
+            if constexpr (B == 3) stage_fwd_v_b3(r, w, c, z);
+        }
+    }
+    else {
+        if constexpr (UNI) {
+            if constexpr (B == 0) stage_inv_s_b0(r, w, c, z);
+            if constexpr (B == 1) stage_inv_s_b1(r, w, c, z);
+            if constexpr (B == 2) stage_inv_s_b2(r, w, c, z);
+            if constexpr (B == 3) stage_inv_s_b3(r, w, c, z);
+        }
+        else {
+            if constexpr (B == 0) stage_inv_v_b0(r, w, c, z);
+            if constexpr (B == 1) stage_inv_v_b1(r, w, c, z);
+            if constexpr (B == 2) stage_inv_v_b2(r, w, c, z);
+            if constexpr (B == 3) stage_inv_v_b3(r, w, c, z);
+        }
+    }
+#else
+    (void)z;
+    const uint64_t nq = ((uint64_t)c.nqh << 32) | c.nql;
+    for (int g = 0; g < (8 >> B); ++g)
+        for (int lo = 0; lo < (1 << B); ++lo) {
+            const int k0 = (g << (B + 1)) | lo;
+            if (INV)
+                bfly_inv_fast(r[k0], r[k0 | (1 << B)], w[g], nq, c.twoq);
+            else
+                bfly_fwd_fast(r[k0], r[k0 | (1 << B)], w[g], nq, c.twoq);
+        }
+#endif
+}
+
+// last inverse stage (s == 0, always field bit 3): lower output * N^-1, upper output * (w1 * N^-1)
+FHE_HD void run_last_inv_stage(uint64_t (&r)[16], const TwPair nInv, const TwPair w1n, const BflyConst c, const BflyZero z) {
+#pragma unroll
+    for (int lo = 0; lo < 8; ++lo) {
+        const uint64_t u = r[lo], v = r[lo | 8];
+        r[lo]            = u + v;
+        r[lo | 8]        = u - v + c.twoq;
+    }
+#ifdef FHE_PINNED_ASM
+    mul2_s_0(r, nInv, w1n, c, z);
+    mul2_s_1(r, nInv, w1n, c, z);
+    mul2_s_2(r, nInv, w1n, c, z);
+    mul2_s_3(r, nInv, w1n, c, z);
+    mul2_s_4(r, nInv, w1n, c, z);
+    mul2_s_5(r, nInv, w1n, c, z);
+    mul2_s_6(r, nInv, w1n, c, z);
+    mul2_s_7(r, nInv, w1n, c, z);
+#else
+    (void)z;
+    const uint64_t nq = ((uint64_t)c.nqh << 32) | c.nql;
+    for (int lo = 0; lo < 8; ++lo) {
+        r[lo]     = shoup_acc(0, r[lo], nInv, nq);
+        r[lo | 8] = shoup_acc(0, r[lo | 8], w1n, nq);
+    }
+#endif
+}
+
+// conditional subtraction of m on the 8 residues whose index has bit B clear (the `a` inputs of a stage on bit B)
+template <int B>
+FHE_HD void run_csub8_a(uint64_t (&r)[16], uint64_t m) {
+#ifdef FHE_PINNED_ASM
+    if constexpr (B == 0) csub8_a0(r, m);
+    if constexpr (B == 1) csub8_a1(r, m);
+    if constexpr (B == 2) csub8_a2(r, m);
+    if constexpr (B == 3) csub8_a3(r, m);
+#else
+    for (int k = 0; k < 16; ++k)
+        if (!((k >> B) & 1))
+            r[k] = csub2(r[k], m);
+#endif
+}
+FHE_HD void run_csub16(uint64_t (&r)[16], uint64_t m) {
+#ifdef FHE_PINNED_ASM
+    csub16(r, m);
+#else
+    for (int k = 0; k < 16; ++k)
+        r[k] = csub2(r[k], m);
+#endif
+}
+
+// one register-resident step I of the plan: its stages, highest field bit first (forward) / lowest first (inverse)
+template <bool LA, bool INV, int T, int I, int B, bool ENDS>
+FHE_HD void run_step_stage(uint64_t (&r)[16], const TwPair* tw, uint32_t j0, uint32_t logN, const TwPair* fin,
+                           const BflyConst c, const BflyZero z) {
+    using P = SPlan<LA, INV, T>;
+    if constexpr (B <= P::bHi(I) && B >= P::bLo(I)) {
+        // twiddle index = 2^s + (j >> (Fj + 4)) * 2^(3-B) + g,  s = logN - 1 - (Fj + B),  Fj = fp + (LA ? logN - T : 0)
+        constexpr int fp   = P::fp(I);
+        constexpr bool uni = LA ? (fp + 4 == T) : (fp + 4 >= kTileLog);
+        const uint32_t Fj  = (uint32_t)fp + (LA ? logN - (uint32_t)T : 0u);
+        const uint32_t s   = logN - 1u - (Fj + (uint32_t)B);
+        // the transform's last inverse stage (s == 0) is the top stage of the pass that ends the transform
+        if constexpr (INV && ENDS && I == P::nst - 1 && B == P::bHi(I)) {
+            static_assert(B == 3, "the last inverse stage sits at field bit 3");
+            const uint64_t* fp64 = reinterpret_cast<const uint64_t*>(fin);
+            run_last_inv_stage(r, TwPair{FHE_ULOAD64(fp64, 0), FHE_ULOAD64(fp64, 1)},
+                               TwPair{FHE_ULOAD64(fp64, 2), FHE_ULOAD64(fp64, 3)}, c, z);
+            return;
+        }
+        uint32_t jhigh = j0 >> (Fj + 4u);
+        if constexpr (uni)
+            jhigh = FHE_UNIFORM(jhigh);
+        const TwPair* base = tw + ((size_t)1 << s);
+        const uint32_t off = jhigh << (3 - B);
+        TwPair w[8];
+#pragma unroll
+        for (int g = 0; g < (8 >> B); ++g) {
+            if constexpr (uni) {
+                const uint64_t* p = reinterpret_cast<const uint64_t*>(base + off + g);
+                w[g]              = TwPair{FHE_ULOAD64(p, 0), FHE_ULOAD64(p, 1)};
+            }
+            else
+                w[g] = base[off + g];
+        }
+        run_stage<INV, uni, B>(r, w, c, z);
+    }
+}
+
+template <bool LA, bool INV, int T, int I, bool ENDS>
+FHE_HD void run_step(uint64_t (&r)[16], const TwPair* tw, uint32_t j0, uint32_t logN, const TwPair* fin, const BflyConst c,
+                     const BflyZero z) {
+    if constexpr (!INV) {
+        run_step_stage<LA, INV, T, I, 3, ENDS>(r, tw, j0, logN, fin, c, z);
+        run_step_stage<LA, INV, T, I, 2, ENDS>(r, tw, j0, logN, fin, c, z);
+        run_step_stage<LA, INV, T, I, 1, ENDS>(r, tw, j0, logN, fin, c, z);
+        run_step_stage<LA, INV, T, I, 0, ENDS>(r, tw, j0, logN, fin, c, z);
+    }
+    else {
+        run_step_stage<LA, INV, T, I, 0, ENDS>(r, tw, j0, logN, fin, c, z);
+        run_step_stage<LA, INV, T, I, 1, ENDS>(r, tw, j0, logN, fin, c, z);
+        run_step_stage<LA, INV, T, I, 2, ENDS>(r, tw, j0, logN, fin, c, z);
+        run_step_stage<LA, INV, T, I, 3, ENDS>(r, tw, j0, logN, fin, c, z);
+    }
+}
+
+// lane geometry of a step whose register field sits at tile-index bit fI: tile index of register 0 and the
+// coefficient index / stride of the lane's 16 values
+template <bool LA, int T, int FI>
+FHE_HD void lane_geom_s(uint32_t t, uint32_t S, uint32_t& Ib, uint32_t& jrel, uint64_t& kstride) {
+    constexpr int logC = kTileLog - T;
+    Ib = ((t >> FI) << (FI + 4)) | (t & ((1u << FI) - 1u));
+    if (LA) {
+        const uint32_t p0 = Ib >> logC, c0 = Ib & ((1u << logC) - 1u);
+        jrel    = p0 * S + c0;
+        kstride = (FI >= logC) ? ((uint64_t)S << (FI >= logC ? FI - logC : 0)) : ((uint64_t)1 << FI);
+    }
+    else {
+        jrel    = Ib;
+        kstride = (uint64_t)1 << FI;
+    }
+}
+
+// MODE, forward: bound of the pass input in units of q — 1 = canonical, 9 = the lazy output of a column pass (anything
+// in (8,16]: the first step then starts with the sweep below 8q).  MODE, inverse: 1 = this pass ends the transform
+// (its top stage is the transform's last stage, with N^-1 folded in), 0 = it does not.
+// DB: two LDS buffers alternate (one barrier per exchange, 68 KiB, 2 workgroups per CU) instead of one buffer with a
+// barrier on either side of the exchange (34 KiB, 4 workgroups per CU).
+template <bool LA, bool INV, int T, int MODE, bool DB>
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_static_kernel(const NttPassArgs a) {
+    using P = SPlan<LA, INV, T>;
+    FHE_SHARED_U64(lds, (DB ? 2 : 1) * kLdsPadWords);
+    const uint32_t t    = FHE_TID;
+    const uint32_t logN = a.logN;
+    const uint32_t N    = 1u << logN;
+    const uint32_t tilesPerRow = N >> kTileLog;
+    uint32_t tile = FHE_BID;
+    if (a.xcdSwizzle) {
+        const uint32_t xcd = tile & 7u, i = tile >> 3;
+        const uint32_t b = i % a.batch, pairIdx = i / a.batch;
+        const uint32_t pair = pairIdx * 8u + xcd;
+        tile = (b * a.nLimbs + pair / tilesPerRow) * tilesPerRow + pair % tilesPerRow;
+    }
+    constexpr int logC = kTileLog - T;
+    const uint32_t S    = N >> T;
+    const uint32_t row  = tile / tilesPerRow, tr = tile % tilesPerRow;
+    const uint32_t jbase = LA ? (tr << logC) : (tr << kTileLog);
+    const uint32_t tb = row / a.nLimbs, rit = row % a.nLimbs;
+    const uint64_t inRow  = a.inStride ? ((uint64_t)tb * a.inStride + a.inFirst + rit) : (uint64_t)row;
+    const uint64_t outRow = a.outStride ? ((uint64_t)tb * a.outStride + a.outFirst + rit) : (uint64_t)row;
+    const uint32_t limb = FHE_UNIFORM(a.sel.idx[rit]);
+    const uint64_t q    = FHE_ULOAD64(a.q, limb);
+    const uint64_t twoq = q << 1, nq = 0 - q;
+    const TwPair* tw    = a.tw + ((uint64_t)limb << logN);
+    const TwPair* fin   = a.fin + 2 * (size_t)limb;
+    const BflyConst c{(uint32_t)nq, (uint32_t)(nq >> 32), twoq, 0 - twoq};
+    BflyZero z{0, 0};
+#ifdef FHE_PINNED_ASM
+    asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0" : "={v65}"(z.z0), "={v81}"(z.z1));
+#endif
+    const bool canonOut = a.canonStep != 0xffffffffu;
+    const uint64_t* src = a.xin + (inRow << logN) + jbase;
+    uint64_t* dst       = a.x + (outRow << logN) + jbase;
+
+    uint64_t r[16];
+    uint32_t Ib, jrel;
+    uint64_t ks;
+    int buf = 0;  // LDS buffer of the next exchange
+
+    // ---- first load ----
+    if constexpr (P::stageFirst) {
+        lane_geom_s<LA, T, 8>(t, S, Ib, jrel, ks);
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            r[k] = src[jrel + k * ks];
+        uint64_t* L = lds + buf * kLdsPadWords + lds_pad(Ib);
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            L[lds_pad((uint32_t)k << 8)] = r[k];
+        FHE_SYNC();
+    }
+
+#define FHE_STATIC_STEP(I)                                                                                        \
+    if constexpr (I < P::nst) {                                                                                   \
+        constexpr int fI = P::fI(I);                                                                              \
+        lane_geom_s<LA, T, fI>(t, S, Ib, jrel, ks);                                                               \
+        if constexpr (I == 0 && !P::stageFirst) {                                                                 \
+            _Pragma("unroll") for (int k = 0; k < 16; ++k) r[k] = src[jrel + k * ks];                             \
+        }                                                                                                         \
+        else {                                                                                                    \
+            const uint64_t* L = lds + buf * kLdsPadWords + lds_pad(Ib);                                           \
+            _Pragma("unroll") for (int k = 0; k < 16; ++k) r[k] = L[lds_pad((uint32_t)k << fI)];                  \
+            if constexpr (DB)                                                                                     \
+                buf ^= 1;                                                                                         \
+        }                                                                                                         \
+        /* lazy reduction: a forward butterfly's outputs are bounded by its `a` input + 2q whatever the `b` input  \
+           (< 2^64) is, so only the 8 `a` inputs of the step's first stage go back below 8q */                      \
+        if constexpr (!INV && P::sweep(I, MODE))                                                                 \
+            run_csub8_a<P::bHi(I)>(r, twoq << 2);                                                                 \
+        run_step<LA, INV, T, I, (INV && MODE == 1)>(r, tw, jbase + jrel, logN, fin, c, z);                         \
+        if constexpr (I == P::nst - 1) {                                                                          \
+            if (canonOut) {                                                                                       \
+                if constexpr (INV)                                                                                \
+                    run_csub16(r, q);                                                                             \
+                else {                                                                                            \
+                    constexpr int ob = P::outBound(MODE);                                                         \
+                    if constexpr (ob > 8) run_csub16(r, q << 3);                                                  \
+                    if constexpr (ob > 4) run_csub16(r, q << 2);                                                  \
+                    if constexpr (ob > 2) run_csub16(r, q << 1);                                                  \
+                    run_csub16(r, q);                                                                             \
+                }                                                                                                 \
+            }                                                                                                     \
+        }                                                                                                         \
+        if constexpr (I == P::nst - 1 && !P::stageLast) {                                                         \
+            _Pragma("unroll") for (int k = 0; k < 16; ++k) dst[jrel + k * ks] = r[k];                             \
+        }                                                                                                         \
+        else {                                                                                                    \
+            if constexpr (!DB && (I > 0 || P::stageFirst))                                                        \
+                FHE_SYNC(); /* every lane has finished reading the buffer */                                      \
+            uint64_t* L = lds + buf * kLdsPadWords + lds_pad(Ib);                                                 \
+            _Pragma("unroll") for (int k = 0; k < 16; ++k) L[lds_pad((uint32_t)k << fI)] = r[k];                  \
+            FHE_SYNC();                                                                                           \
+        }                                                                                                         \
+    }
+    FHE_STATIC_STEP(0)
+    FHE_STATIC_STEP(1)
+    FHE_STATIC_STEP(2)
+#undef FHE_STATIC_STEP
+
+    // ---- last store ----
+    if constexpr (P::stageLast) {
+        lane_geom_s<LA, T, 8>(t, S, Ib, jrel, ks);
+        const uint64_t* L = lds + buf * kLdsPadWords + lds_pad(Ib);
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            r[k] = L[lds_pad((uint32_t)k << 8)];
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            dst[jrel + k * ks] = r[k];
+    }
+}
+
+}  // namespace fhe
+#endif

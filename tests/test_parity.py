@@ -26,7 +26,7 @@ def params(o, logN, L, bits=60):
 def ntt_sizes(lib):
     small = [(4, 2, 3), (5, 1, 1), (7, 3, 2), (10, 2, 3), (11, 1, 5), (12, 2, 2), (13, 2, 1), (14, 1, 2)]
     if is_emu(lib):
-        return small + [(16, 1, 1)]
+        return small + [(15, 1, 1), (16, 1, 1), (17, 1, 1)]
     return small + [(15, 3, 2), (16, 4, 3), (17, 2, 2)]
 
 

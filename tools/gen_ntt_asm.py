@@ -1,0 +1,446 @@
+#!/usr/bin/env python3
+"""Generates openfhe-development_amd/csrc/ntt_bfly_pinned.h: hand-scheduled gfx950 butterflies that work IN PLACE on
+the 16 residues of a lane, which are pinned to v[32:63] (residue k = v[32+2k : 33+2k]).
+
+Why generated: gfx950 needs 64-bit VGPR operands in even-aligned pairs and inline asm cannot name the halves of a
+compiler-allocated pair, so in-place code must name physical registers; one asm text per register pair is needed,
+and two independent butterflies are interleaved per asm block so that the 2 wait states between a VALU carry
+write and its reader are filled with useful work.  The generator also SIMULATES every emitted block on random
+64-bit inputs against the butterfly arithmetic it replaces (python big ints) before writing the header.
+
+Usage:  python tools/gen_ntt_asm.py        (rewrites the header; exits non-zero if a simulated block is wrong)
+"""
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "openfhe-development_amd", "csrc", "ntt_bfly_pinned.h")
+M32, M64 = (1 << 32) - 1, (1 << 64) - 1
+DATA0 = 32  # residue k lives in v[DATA0+2k : DATA0+2k+1]
+DEAD = "s[40:41]"  # carry-outs nobody reads
+
+
+def R(k):
+    return DATA0 + 2 * k
+
+
+class T:
+    """temporaries of one butterfly slot (slot 0 / slot 1 run interleaved)"""
+
+    def __init__(self, slot):
+        b = 64 + 16 * slot
+        self.Z = b        # v[Z:Z+1]: mul_hi result, Z+1 holds 0 (pinned input)
+        self.L = b + 2    # Bm, later L
+        self.C = b + 4    # C'
+        self.H = b + 6    # {C'.hi, carry}
+        self.Q = b + 8
+        self.X = b + 10   # cross terms
+        self.Y = b + 12   # inverse: y = u - v + 2q
+        self.D = b + 14   # inverse: s - 2q
+        self.c0 = f"s[{42 + 4 * slot}:{43 + 4 * slot}]"
+        self.c1 = f"s[{44 + 4 * slot}:{45 + 4 * slot}]"
+        self.slot = slot
+
+
+def p(r):
+    return f"v[{r}:{r + 1}]"
+
+
+def v(r):
+    return f"v{r}"
+
+
+# instruction = (text, reads_sgpr_set, writes_sgpr_set, simfn)
+def ins(text, rd=(), wr=(), sim=None):
+    return {"t": text, "rd": set(rd), "wr": set(wr), "sim": sim}
+
+
+# ---- simulator helpers ------------------------------------------------------------------------------
+class St:
+    def __init__(self):
+        self.v = {}
+        self.s = {}
+        self.ops = {}
+
+    def g(self, name):  # 32-bit source: register "vN" or operand "%[x]"
+        if name.startswith("%["):
+            return self.ops[name[2:-1]] & M32
+        if name.startswith("v"):
+            return self.v[int(name[1:])]
+        return int(name)
+
+    def g64(self, name):
+        if name.startswith("%["):
+            return self.ops[name[2:-1]] & M64
+        if name.startswith("v["):
+            lo = int(name[2:name.index(":")])
+            return self.v[lo] | (self.v[lo + 1] << 32)
+        return int(name)
+
+    def set64(self, name, val):
+        lo = int(name[2:name.index(":")])
+        self.v[lo], self.v[lo + 1] = val & M32, (val >> 32) & M32
+
+
+def mad(d, sd, a, b, c):
+    def sim(S):
+        r = S.g(a) * S.g(b) + S.g64(c)
+        S.set64(d, r & M64)
+        S.s[sd] = r >> 64
+    return ins(f"v_mad_u64_u32 {d}, {sd}, {a}, {b}, {c}", wr=[sd], sim=sim)
+
+
+def mulhi(d, a, b):
+    def sim(S):
+        S.v[int(d[1:])] = (S.g(a) * S.g(b)) >> 32
+    return ins(f"v_mul_hi_u32 {d}, {a}, {b}", sim=sim)
+
+
+def mov(d, a):
+    def sim(S):
+        S.v[int(d[1:])] = S.g(a)
+    return ins(f"v_mov_b32 {d}, {a}", sim=sim)
+
+
+def cnd01(d, sc):
+    def sim(S):
+        S.v[int(d[1:])] = 1 if S.s[sc] else 0
+    return ins(f"v_cndmask_b32_e64 {d}, 0, 1, {sc}", rd=[sc], sim=sim)
+
+
+def cnd(d, a, b, sc):  # d = sc ? b : a
+    def sim(S):
+        S.v[int(d[1:])] = S.g(b) if S.s[sc] else S.g(a)
+    return ins(f"v_cndmask_b32_e64 {d}, {a}, {b}, {sc}", rd=[sc], sim=sim)
+
+
+def lshladd(d, a, sh, c):
+    def sim(S):
+        S.set64(d, ((S.g64(a) << sh) + S.g64(c)) & M64)
+    return ins(f"v_lshl_add_u64 {d}, {a}, {sh}, {c}", sim=sim)
+
+
+def add32(d, a, b):
+    def sim(S):
+        S.v[int(d[1:])] = (S.g(a) + S.g(b)) & M32
+    return ins(f"v_add_u32 {d}, {a}, {b}", sim=sim)
+
+
+def subco(d, sd, a, b):
+    def sim(S):
+        r = S.g(a) - S.g(b)
+        S.v[int(d[1:])] = r & M32
+        S.s[sd] = 1 if r < 0 else 0
+    return ins(f"v_sub_co_u32_e64 {d}, {sd}, {a}, {b}", wr=[sd], sim=sim)
+
+
+def subbco(d, sd, a, b, sc):
+    def sim(S):
+        r = S.g(a) - S.g(b) - S.s[sc]
+        S.v[int(d[1:])] = r & M32
+        S.s[sd] = 1 if r < 0 else 0
+    return ins(f"v_subb_co_u32_e64 {d}, {sd}, {a}, {b}, {sc}", rd=[sc], wr=[sd], sim=sim)
+
+
+def cmplt64(sd, a, b):
+    def sim(S):
+        S.s[sd] = 1 if S.g64(a) < S.g64(b) else 0
+    return ins(f"v_cmp_lt_u64_e64 {sd}, {a}, {b}", wr=[sd], sim=sim)
+
+
+# ---- instruction streams -----------------------------------------------------------------------------
+def shoup_tail(t, yl, yh, w, dst, addend):
+    """dst(pair) = lo64(y*w + Q*nq) + addend, Q = hi64(y*w'); y = (yl, yh) registers; w = operand suffix"""
+    wl, wh, pl, ph = (f"%[{n}{w}]" for n in ("wl", "wh", "pl", "ph"))
+    return [
+        mulhi(v(t.Z), yl, pl),
+        mad(p(t.X), DEAD, yl, wh, "0"),
+        mad(p(t.L), DEAD, yh, pl, p(t.Z)),
+        mad(p(t.C), t.c0, yl, ph, p(t.L)),
+        mad(p(t.X), DEAD, yh, wl, p(t.X)),
+        mov(v(t.H), v(t.C + 1)),
+        cnd01(v(t.H + 1), t.c0),
+        mad(p(t.Q), DEAD, yh, ph, p(t.H)),
+        mad(p(t.L), DEAD, yl, wl, addend),
+    ], [
+        mad(p(t.X), DEAD, v(t.Q), "%[nqh]", p(t.X)),
+        mad(p(t.X), DEAD, v(t.Q + 1), "%[nql]", p(t.X)),
+        add32(v(t.L + 1), v(t.L + 1), v(t.X)),
+        mad(dst, DEAD, v(t.Q), "%[nql]", p(t.L)),
+    ]
+
+
+def fwd_stream(t, A, B, w):
+    """a' = a + T, b' = a - T + 2q with T = shoup(b, w) in [0,2q); a = v[A:A+1], b = v[B:B+1]"""
+    head, tail = shoup_tail(t, v(B), v(B + 1), w, p(A), p(A))
+    return head + [lshladd(p(B), p(A), 1, "%[twoq]")] + tail + [
+        subco(v(B), t.c0, v(B), v(A)),
+        subbco(v(B + 1), t.c0, v(B + 1), v(A + 1), t.c0),
+    ]
+
+
+def inv_stream(t, A, B, w):
+    """a' = (u+v) mod 2q, b' = shoup(u - v + 2q, w); u = v[A:A+1], v = v[B:B+1]"""
+    pre = [
+        lshladd(p(t.Y), p(A), 0, "%[twoq]"),
+        lshladd(p(A), p(A), 0, p(B)),
+        subco(v(t.Y), t.c0, v(t.Y), v(B)),
+        lshladd(p(t.D), p(A), 0, "%[ntwoq]"),
+        cmplt64(t.c1, p(A), "%[twoq]"),
+        subbco(v(t.Y + 1), t.c0, v(t.Y + 1), v(B + 1), t.c0),
+    ]
+    head, tail = shoup_tail(t, v(t.Y), v(t.Y + 1), w, p(B), "0")
+    sel = [cnd(v(A), v(t.D), v(A), t.c1), cnd(v(A + 1), v(t.D + 1), v(A + 1), t.c1)]
+    return pre + head[:2] + sel + head[2:] + tail
+
+
+def mul_stream(t, A, w):
+    """x = shoup(x, w) in place (last inverse stage: the caller forms u+v / u-v+2q first); x is only overwritten by
+    the last instruction, after every read of its halves"""
+    head, tail = shoup_tail(t, v(A), v(A + 1), w, p(A), "0")
+    return head + tail
+
+
+CSUB_TMP = (68, 70, 72, 74)  # pairs used by the 4 interleaved conditional subtractions
+
+
+def csub_stream(i, A):
+    """x = x < m ? x : x - m   (m, -m as scalar pairs); chain i of 4"""
+    D, c = CSUB_TMP[i], f"s[{42 + 2 * i}:{43 + 2 * i}]"
+    return [
+        lshladd(p(D), p(A), 0, "%[negm]"),
+        cmplt64(c, p(A), "%[m]"),
+        cnd(v(A), v(D), v(A), c),
+        cnd(v(A + 1), v(D + 1), v(A + 1), c),
+    ]
+
+
+def schedule(streams):
+    """merge instruction streams round-robin; an SGPR written by a VALU instruction is not read by the next two
+    issued instructions (gfx950 needs 2 wait states there)"""
+    out, pos, recent = [], [0] * len(streams), []  # recent: sgpr write sets of the last 2 emitted
+    nxt = 0
+    while any(pos[i] < len(s) for i, s in enumerate(streams)):
+        done = False
+        for k in range(len(streams)):
+            i = (nxt + k) % len(streams)
+            if pos[i] >= len(streams[i]):
+                continue
+            c = streams[i][pos[i]]
+            if any(c["rd"] & w for w in recent[-2:]):
+                continue
+            out.append(c)
+            recent.append(c["wr"])
+            pos[i] += 1
+            nxt = (i + 1) % len(streams)
+            done = True
+            break
+        if not done:
+            out.append(ins("s_nop 0", sim=lambda S: None))
+            recent.append(set())
+    return out
+
+
+# ---- simulation against the arithmetic being replaced ------------------------------------------------
+def shoup_ref(y, w, wp, q):
+    Q = (y * wp) >> 64
+    return (y * w - Q * q) & M64
+
+
+def run(block, S):
+    for c in block:
+        c["sim"](S)
+
+
+def check_blocks():
+    rnd = random.Random(7)
+    for it in range(4000):
+        q = rnd.getrandbits(60) | (1 << 59) | 1
+        w = [rnd.randrange(q), rnd.randrange(q)]
+        wp = [(x << 64) // q for x in w]
+        S = St()
+        S.ops = {"nql": (-q) & M32, "nqh": ((-q) & M64) >> 32, "twoq": 2 * q, "ntwoq": (-2 * q) & M64}
+        for i in (0, 1):
+            S.ops.update({f"wl{i}": w[i] & M32, f"wh{i}": w[i] >> 32, f"pl{i}": wp[i] & M32, f"ph{i}": wp[i] >> 32})
+        t0, t1 = T(0), T(1)
+        S.v[t0.Z + 1] = S.v[t1.Z + 1] = 0
+        # forward pair: lazy inputs a < 14q, b < 2^64
+        a = [rnd.randrange(14 * q), rnd.randrange(14 * q)]
+        b = [rnd.getrandbits(64), rnd.randrange(16 * q)]
+        for i, (k0, k1) in enumerate(((0, 8), (5, 13))):
+            S.set64(p(R(k0)), a[i]), S.set64(p(R(k1)), b[i])
+        run(schedule([fwd_stream(t0, R(0), R(8), 0), fwd_stream(t1, R(5), R(13), 1)]), S)
+        for i, (k0, k1) in enumerate(((0, 8), (5, 13))):
+            Tm = shoup_ref(b[i], w[i], wp[i], q)
+            assert Tm < 2 * q
+            assert S.g64(p(R(k0))) == (a[i] + Tm) & M64, "fwd a"
+            assert S.g64(p(R(k1))) == (a[i] - Tm + 2 * q) & M64, "fwd b"
+        # inverse pair: inputs < 2q
+        u = [rnd.randrange(2 * q), rnd.randrange(2 * q)]
+        vv = [rnd.randrange(2 * q), rnd.randrange(2 * q)]
+        for i, (k0, k1) in enumerate(((2, 3), (14, 6))):
+            S.set64(p(R(k0)), u[i]), S.set64(p(R(k1)), vv[i])
+        run(schedule([inv_stream(t0, R(2), R(3), 0), inv_stream(t1, R(14), R(6), 1)]), S)
+        for i, (k0, k1) in enumerate(((2, 3), (14, 6))):
+            s = u[i] + vv[i]
+            assert S.g64(p(R(k0))) == (s if s < 2 * q else s - 2 * q), "inv a"
+            assert S.g64(p(R(k1))) == shoup_ref(u[i] - vv[i] + 2 * q, w[i], wp[i], q), "inv b"
+        # in-place multiply pair, any 64-bit input
+        x = [rnd.getrandbits(64), rnd.randrange(4 * q)]
+        S.set64(p(R(1)), x[0]), S.set64(p(R(9)), x[1])
+        run(schedule([mul_stream(t0, R(1), 0), mul_stream(t1, R(9), 1)]), S)
+        assert S.g64(p(R(1))) == shoup_ref(x[0], w[0], wp[0], q) and S.g64(p(R(9))) == shoup_ref(x[1], w[1], wp[1], q)
+        # conditional subtraction, 4 residues per block
+        m = q << rnd.randrange(0, 4)
+        S.ops.update({"m": m, "negm": (-m) & M64})
+        xs = [rnd.randrange(2 * m) for _ in range(4)]
+        for i, x0 in enumerate(xs):
+            S.set64(p(R(4 + i)), x0)
+        run(schedule([csub_stream(i, R(4 + i)) for i in range(4)]), S)
+        for i, x0 in enumerate(xs):
+            assert S.g64(p(R(4 + i))) == (x0 if x0 < m else x0 - m), "csub"
+    return True
+
+
+# ---- emission ----------------------------------------------------------------------------------------
+def clobbers(nslots):
+    regs = []
+    for s in range(nslots):
+        t = T(s)
+        regs += [f"v{r}" for r in range(t.Z, t.Z + 16) if r != t.Z + 1]
+        regs += [f"s{r}" for r in range(42 + 4 * s, 46 + 4 * s)]
+    return regs + ["s40", "s41"]
+
+
+def asm_block(block, outs, ins_, nslots):
+    text = "\n".join(f'        "{c["t"]}\\n\\t"' for c in block)
+    o = ", ".join(outs)
+    i = ", ".join(ins_)
+    regs = clobbers(nslots) if nslots else [f"v{r}" for r in range(68, 76)] + [f"s{r}" for r in range(42, 50)]
+    c = ", ".join(f'"{r}"' for r in regs)
+    return f"    asm volatile(\n{text}\n        : {o}\n        : {i}\n        : {c});\n"
+
+
+def pin(k, var):
+    return f'"+{{v[{R(k)}:{R(k) + 1}]}}"({var})'
+
+
+def tw_in(i, cls):
+    return [f'[wl{i}] "{cls}"(w{i}l)', f'[wh{i}] "{cls}"(w{i}h)', f'[pl{i}] "{cls}"(p{i}l)', f'[ph{i}] "{cls}"(p{i}h)']
+
+
+ZERO_IN = ['"{v65}"(z.z0)', '"{v81}"(z.z1)']
+CONST_IN = ['[nql] "s"(c.nql)', '[nqh] "s"(c.nqh)', '[twoq] "s"(c.twoq)', '[ntwoq] "s"(c.ntwoq)']
+
+
+def emit_pair_fn(name, kind, ka, kb, cls):
+    """two butterflies (r[ka[0]], r[ka[1]]) with twiddle 0 and (r[kb[0]], r[kb[1]]) with twiddle 1"""
+    mk = fwd_stream if kind == "fwd" else inv_stream
+    block = schedule([mk(T(0), R(ka[0]), R(ka[1]), 0), mk(T(1), R(kb[0]), R(kb[1]), 1)])
+    args = "uint64_t (&r)[16], const TwPair wa, const TwPair wb, const BflyConst c, const BflyZero z"
+    body = "".join(f"    const uint32_t w{i}l = (uint32_t)w{n}.w, w{i}h = (uint32_t)(w{n}.w >> 32), p{i}l = (uint32_t)w{n}.wp, "
+                   f"p{i}h = (uint32_t)(w{n}.wp >> 32);\n" for i, n in ((0, "a"), (1, "b")))
+    outs = [pin(k, f"r[{k}]") for k in (ka[0], ka[1], kb[0], kb[1])]
+    return (f"__device__ __forceinline__ void {name}({args}) {{\n{body}"
+            + asm_block(block, outs, tw_in(0, cls) + tw_in(1, cls) + CONST_IN + ZERO_IN, 2) + "}\n")
+
+
+def emit_mul_fn(name, ka, kb, cls):
+    block = schedule([mul_stream(T(0), R(ka), 0), mul_stream(T(1), R(kb), 1)])
+    args = "uint64_t (&r)[16], const TwPair wa, const TwPair wb, const BflyConst c, const BflyZero z"
+    body = "".join(f"    const uint32_t w{i}l = (uint32_t)w{n}.w, w{i}h = (uint32_t)(w{n}.w >> 32), p{i}l = (uint32_t)w{n}.wp, "
+                   f"p{i}h = (uint32_t)(w{n}.wp >> 32);\n" for i, n in ((0, "a"), (1, "b")))
+    outs = [pin(ka, f"r[{ka}]"), pin(kb, f"r[{kb}]")]
+    return (f"__device__ __forceinline__ void {name}({args}) {{\n{body}"
+            + asm_block(block, outs, tw_in(0, cls) + tw_in(1, cls) + CONST_IN[:2] + ZERO_IN, 2) + "}\n")
+
+
+def emit_csub_fn(name, ks):
+    block = schedule([csub_stream(i, R(k)) for i, k in enumerate(ks)])
+    outs = [pin(k, f"r[{k}]") for k in ks]
+    return (f"__device__ __forceinline__ void {name}(uint64_t (&r)[16], uint64_t m, uint64_t negm) {{\n"
+            + asm_block(block, outs, ['[m] "s"(m)', '[negm] "s"(negm)'], 0) + "}\n")
+
+
+def stage_pairs(b):
+    """butterflies of stage b on the 16 registers, as (k0, k1, twiddle group g)"""
+    out = []
+    for g in range(8 >> b):
+        for lo in range(1 << b):
+            k0 = (g << (b + 1)) | lo
+            out.append((k0, k0 | (1 << b), g))
+    return out
+
+
+def main():
+    check_blocks()
+    H = []
+    H.append("""// GENERATED by tools/gen_ntt_asm.py — do not edit; edit the generator and re-run it.
+// In-place gfx950 butterflies on the 16 residues of a lane pinned to v[32:63] (residue k = v[32+2k:33+2k]).
+// Arithmetic = bfly_fwd_fast / bfly_inv_fast of ntt_kernels.h (Shoup multiply of the reference's
+// ModMulFastConst, transformnat-impl.h:303-374 / 512-625, with lazy ranges); every block below was simulated against
+// that arithmetic by the generator before it was written.  Two butterflies are interleaved per asm block so that
+// the two wait states gfx950 needs between a VALU carry write and its reader are filled with the other butterfly.
+#ifndef FHE_NTT_BFLY_PINNED_H
+#define FHE_NTT_BFLY_PINNED_H
+#if defined(__HIP_DEVICE_COMPILE__)
+namespace fhe {
+struct BflyConst {  // wave-uniform (SGPR) constants of the limb
+    uint32_t nql, nqh;      // 2^64 - q
+    uint64_t twoq, ntwoq;   // 2q, 2^64 - 2q
+};
+struct BflyZero {   // two VGPRs holding 0 (high halves of the zero-extended mul_hi results)
+    uint32_t z0, z1;
+};
+""")
+    for kind in ("fwd", "inv"):
+        for b in range(4):
+            prs = stage_pairs(b)
+            for cls, tag in (("v", "v"), ("s", "s")):
+                fn = []
+                for i in range(0, 8, 2):
+                    (a0, a1, ga), (b0, b1, gb) = prs[i], prs[i + 1]
+                    name = f"bfly2_{kind}_{tag}_b{b}_{i // 2}"
+                    H.append(emit_pair_fn(name, kind, (a0, a1), (b0, b1), cls))
+                    fn.append(f"    {name}(r, w[{ga}], w[{gb}], c, z);\n")
+                H.append(f"// stage b = {b}: twiddle g serves the butterflies whose index has (k >> {b + 1}) == g\n"
+                         f"__device__ __forceinline__ void stage_{kind}_{tag}_b{b}(uint64_t (&r)[16], const TwPair (&w)[8], "
+                         f"const BflyConst c, const BflyZero z) {{\n" + "".join(fn) + "}\n")
+    # last inverse stage (s == 0): residues lo and lo|8 multiplied by N^-1 and w1*N^-1
+    for i in range(8):
+        H.append(emit_mul_fn(f"mul2_s_{i}", i, i | 8, "s"))
+    for i in range(4):
+        H.append(emit_csub_fn(f"csub4_{i}", [4 * i + j for j in range(4)]))
+    H.append("""__device__ __forceinline__ void csub16(uint64_t (&r)[16], uint64_t m) {
+    const uint64_t negm = 0 - m;
+    csub4_0(r, m, negm);
+    csub4_1(r, m, negm);
+    csub4_2(r, m, negm);
+    csub4_3(r, m, negm);
+}
+""")
+    # the 8 residues that are the `a` inputs of a stage on field bit b (index bit b clear): only those bound the
+    # outputs of a forward butterfly, so the lazy-reduction sweep before a step touches just them
+    for b in range(4):
+        ks = [k for k in range(16) if not (k >> b) & 1]
+        H.append(emit_csub_fn(f"csub4_a{b}_0", ks[:4]))
+        H.append(emit_csub_fn(f"csub4_a{b}_1", ks[4:]))
+        H.append(f"""__device__ __forceinline__ void csub8_a{b}(uint64_t (&r)[16], uint64_t m) {{
+    const uint64_t negm = 0 - m;
+    csub4_a{b}_0(r, m, negm);
+    csub4_a{b}_1(r, m, negm);
+}}
+""")
+    H.append("""}  // namespace fhe
+#endif
+#endif
+""")
+    open(OUT, "w").write("".join(H))
+    n = sum(1 for c in schedule([fwd_stream(T(0), R(0), R(1), 0), fwd_stream(T(1), R(2), R(3), 1)]) if not c["t"].startswith("s_nop"))
+    ni = sum(1 for c in schedule([inv_stream(T(0), R(0), R(1), 0), inv_stream(T(1), R(2), R(3), 1)]) if not c["t"].startswith("s_nop"))
+    print(f"wrote {OUT}: forward pair {n} VALU, inverse pair {ni} VALU; all blocks simulated OK")
+
+
+if __name__ == "__main__":
+    sys.exit(main())
