@@ -215,7 +215,6 @@ extern "C" uint32_t fhe_param_select_p(uint32_t logN, uint32_t sizeQ, const uint
 }
 
 static uint32_t env_u32(const char* name, uint32_t dflt);
-static bool ntt_generic();
 static uint32_t ntt_stagger();
 static bool ntt_legacy();
 
@@ -230,6 +229,8 @@ struct fhe_ctx {
     TwPair* d_tw      = nullptr;  // [L][N] forward
     TwPair* d_twInv   = nullptr;  // [L][N] inverse
     TwPair* d_fin     = nullptr;  // [L][2] {N^-1, TableInv[1]*N^-1}
+    TwPair* d_twRow   = nullptr;  // [L][N/4096][15][256] lane-major twiddles of the row pass's bit-0 step (N >= 4096), forward
+    TwPair* d_twRowInv = nullptr; // ... inverse
     uint64_t* d_q     = nullptr;  // [L]
     LimbConst* d_lc   = nullptr;  // [L]
     uint64_t* d_mu128 = nullptr;  // [L][2]
@@ -279,6 +280,9 @@ extern "C" fhe_status fhe_ctx_create(uint32_t logN, uint32_t nLimbs, const uint6
 
     // twiddle tables: Table[bitrev(i)] = psi^i, TableI[bitrev(i)] = psi^-i  (transformnat-impl.h:725-737)
     std::vector<TwPair> tw((size_t)nLimbs * N), twInv((size_t)nLimbs * N), fin((size_t)nLimbs * 2);
+    const bool rowTables   = logN >= (uint32_t)kTileLog;
+    const size_t rowPerLimb = rowTables ? (size_t)(N >> kTileLog) * kRowTwSlots * kThreads : 0;
+    std::vector<TwPair> twRow(rowPerLimb * nLimbs), twRowInv(rowPerLimb * nLimbs);
     std::vector<LimbConst> lc(nLimbs);
     std::vector<uint64_t> mu(2 * (size_t)nLimbs);
 #pragma omp parallel for schedule(dynamic)
@@ -294,6 +298,20 @@ extern "C" fhe_status fhe_ctx_create(uint32_t logN, uint32_t nLimbs, const uint6
             x                = host::mulmod(x, ps, ql);
             xi               = host::mulmod(xi, psInv, ql);
         }
+        // lane-major copy for the step whose register field is tile bit 0 (ntt_static.h, TwSrc): lane t of tile tr holds
+        // coefficients j0 = tr*4096 + 16t .. +15; stage b, twiddle g: index 2^(logN-1-b) + ((j0 >> 4) << (3-b)) + g
+        for (size_t tr = 0; rowTables && tr < (N >> kTileLog); ++tr)
+            for (uint32_t b = 0; b < 4; ++b)
+                for (uint32_t g = 0; g < (8u >> b); ++g) {
+                    const size_t slot = (size_t)(1u << (3 - b)) - 1 + g;
+                    TwPair* d  = twRow.data() + (size_t)l * rowPerLimb + (tr * kRowTwSlots + slot) * kThreads;
+                    TwPair* di = twRowInv.data() + (size_t)l * rowPerLimb + (tr * kRowTwSlots + slot) * kThreads;
+                    for (uint32_t lane = 0; lane < (uint32_t)kThreads; ++lane) {
+                        const size_t idx = ((size_t)1 << (logN - 1 - b)) + (((tr << 8) + lane) << (3 - b)) + g;
+                        d[lane]  = t[idx];
+                        di[lane] = ti[idx];
+                    }
+                }
         const uint64_t nInv = host::invmod((uint64_t)N % ql, ql);
         const uint64_t w1n  = host::mulmod(ti[1].w, nInv, ql);  // transformnat-impl.h:533-534
         fin[2 * l]          = TwPair{nInv, host::shoup(nInv, ql)};
@@ -305,6 +323,8 @@ extern "C" fhe_status fhe_ctx_create(uint32_t logN, uint32_t nLimbs, const uint6
     if ((s = upload(c, tw.data(), tw.size() * sizeof(TwPair), (void**)&c->d_tw)) ||
         (s = upload(c, twInv.data(), twInv.size() * sizeof(TwPair), (void**)&c->d_twInv)) ||
         (s = upload(c, fin.data(), fin.size() * sizeof(TwPair), (void**)&c->d_fin)) ||
+        (rowTables && (s = upload(c, twRow.data(), twRow.size() * sizeof(TwPair), (void**)&c->d_twRow))) ||
+        (rowTables && (s = upload(c, twRowInv.data(), twRowInv.size() * sizeof(TwPair), (void**)&c->d_twRowInv))) ||
         (s = upload(c, c->q.data(), nLimbs * sizeof(uint64_t), (void**)&c->d_q)) ||
         (s = upload(c, lc.data(), nLimbs * sizeof(LimbConst), (void**)&c->d_lc)) ||
         (s = upload(c, mu.data(), mu.size() * sizeof(uint64_t), (void**)&c->d_mu128))) {
@@ -391,7 +411,8 @@ static inline uint32_t tiles_for(const fhe_ctx* c, uint64_t rows) {
 struct PassPlan {
     bool layoutA;
     uint32_t T;
-    uint32_t outBound = 16;  // forward: bound (units of q) of the pass output under the lazy schedule
+    uint32_t inBound  = 1;   // forward: bound (units of q) of the pass input ...
+    uint32_t outBound = 16;  // ... and of the pass output under the lazy schedule
     uint32_t nSteps;
     NttStep steps[6];
 };
@@ -442,6 +463,7 @@ static void plan_pass(bool inverse, bool layoutA, uint32_t logN, uint32_t T, Pas
 // its operands and 16q < 2^64, so a step of r stages needs a correction only when bound + 2r would exceed 16.
 // `bound` (in units of q) is the bound of the pass input on entry and of its output on return.
 static void schedule_fwd(PassPlan& pp, uint32_t logN, uint32_t* bound) {
+    pp.inBound = *bound;
     for (uint32_t i = 0; i < pp.nSteps; ++i) {
         NttStep& st = pp.steps[i];
         if (st.bHi < st.bLo)
@@ -470,13 +492,12 @@ static void mark_uniform(PassPlan& pp, uint32_t logN) {
 
 static bool ntt_static();
 static bool ntt_lds2();
-static bool ntt_generic();
+static bool ntt_rowtw();
 static bool ntt_legacy();
 static uint32_t ntt_stagger();
-static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse, const uint64_t* xin, uint64_t* xout,
-                              const LimbSel& sel, uint32_t nLimbs, uint32_t batch, bool canonOut, void* stream,
-                              uint32_t inStride = 0, uint32_t inFirst = 0, uint32_t outStride = 0, uint32_t outFirst = 0) {
-    NttPassArgs a;
+static uint32_t fill_pass_args(const fhe_ctx* c, const PassPlan& pp, bool inverse, const uint64_t* xin, uint64_t* xout,
+                               const LimbSel& sel, uint32_t nLimbs, uint32_t batch, bool canonOut, uint32_t inStride,
+                               uint32_t inFirst, uint32_t outStride, uint32_t outFirst, NttPassArgs& a) {
     a.outStride = outStride;
     a.outFirst  = outFirst;
     a.inStride = inStride;
@@ -485,6 +506,7 @@ static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse
     a.xin      = xin;
     a.x        = xout;
     a.tw       = inverse ? c->d_twInv : c->d_tw;
+    a.twRow    = ntt_rowtw() ? (inverse ? c->d_twRowInv : c->d_twRow) : nullptr;
     a.q        = c->d_q;
     a.fin      = c->d_fin;
     a.logN     = c->logN;
@@ -508,31 +530,26 @@ static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse
     const uint32_t grid        = tiles_for(c, a.rows);
     const uint32_t tilesPerRow = c->N >= (uint32_t)kTile ? (c->N >> kTileLog) : 1u;
     a.xcdSwizzle = (c->N >= (uint32_t)kTile && ((nLimbs * tilesPerRow) % 8u == 0)) ? 1u : 0u;
-    if (c->logN >= (uint32_t)kTileLog && !ntt_generic() && outStride == 0) {
-        // fast path: persistent workgroups, a multiple of 8 so that the XCD a workgroup runs on (blockIdx % 8)
-        // stays the XCD of every tile it walks
-        uint32_t pgrid = std::min(grid, c->persistentGrid);
-        if (pgrid >= 8)
-            pgrid &= ~7u;
-#define FHE_FAST_CASE(LA, INV, NS) \
-    if (pp.layoutA == LA && inverse == INV && pp.nSteps == NS) { \
-        FHE_LAUNCH((ntt_pass_fast_kernel<LA, INV, NS>), pgrid, stream, a); \
-        launched = true; \
-    }
-        bool launched = false;
-        FHE_FAST_CASE(true, false, 1) FHE_FAST_CASE(true, false, 2) FHE_FAST_CASE(true, true, 1) FHE_FAST_CASE(true, true, 2)
-        FHE_FAST_CASE(false, false, 3) FHE_FAST_CASE(false, false, 4) FHE_FAST_CASE(false, true, 3) FHE_FAST_CASE(false, true, 4)
-#undef FHE_FAST_CASE
-        if (!launched)
-            return fail(FHE_ERR_UNSUPPORTED, "ntt: no fast kernel instance for this pass plan");
-        LAUNCH_CHECK();
-        return FHE_OK;
-    }
+    return grid;
+}
+// forward: bound class of a static pass's input; inverse: does the pass end the transform (ntt_static.h MODE)
+static int static_mode(const fhe_ctx* c, const PassPlan& pp, bool inverse) {
+    const bool twoPass = c->logN > (uint32_t)kTileLog;
+    // (forward classes: 1 = canonical input, 9 = at most 9q, 16 = anything below 16q; a 4-stage first step sweeps
+    // for every class above 1, so T = 12 has one instance for both)
+    const int fclass = pp.inBound <= 1 ? 1 : (pp.inBound <= 9 || pp.T == 12) ? 9 : 16;
+    return inverse ? ((pp.layoutA || !twoPass) ? 1 : 0) : fclass;
+}
+static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse, const uint64_t* xin, uint64_t* xout,
+                              const LimbSel& sel, uint32_t nLimbs, uint32_t batch, bool canonOut, void* stream,
+                              uint32_t inStride = 0, uint32_t inFirst = 0, uint32_t outStride = 0, uint32_t outFirst = 0) {
+    NttPassArgs a;
+    const uint32_t grid = fill_pass_args(c, pp, inverse, xin, xout, sel, nLimbs, batch, canonOut, inStride, inFirst, outStride,
+                                         outFirst, a);
     if (c->logN >= (uint32_t)kTileLog && !ntt_legacy() && ntt_static()) {
         // compile-time pass plans (ntt_static.h): in-place pinned-register butterflies, immediate-offset LDS exchange
-        // forward: bound class of the pass input; inverse: does this pass end the transform (ntt_static.h)
         const bool twoPass = c->logN > (uint32_t)kTileLog;
-        const int mode = inverse ? ((pp.layoutA || !twoPass) ? 1 : 0) : ((!pp.layoutA && twoPass) ? 9 : 1);
+        const int mode     = static_mode(c, pp, inverse);
         bool launched = false;
 #define FHE_STATIC_CASE(LA, INV, TT, MODE) \
     if (!launched && pp.layoutA == LA && inverse == INV && pp.T == TT && mode == MODE) { \
@@ -554,6 +571,12 @@ static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse
         FHE_STATIC_CASE(false, false, 10, 9) FHE_STATIC_CASE(false, true, 10, 0)
         FHE_STATIC_CASE(false, false, 9, 9) FHE_STATIC_CASE(false, true, 9, 0)
         FHE_STATIC_CASE(false, false, 12, 1) FHE_STATIC_CASE(false, true, 12, 1)
+        // other splits of a two-pass ring (FHE_NTT_T1): more stages in the HBM-bound column pass, fewer in the row pass
+        FHE_STATIC_CASE(true, false, 6, 1) FHE_STATIC_CASE(true, true, 6, 1)
+        FHE_STATIC_CASE(true, false, 7, 1) FHE_STATIC_CASE(true, true, 7, 1)
+        FHE_STATIC_CASE(true, false, 8, 1) FHE_STATIC_CASE(true, true, 8, 1)
+        FHE_STATIC_CASE(false, false, 8, 16) FHE_STATIC_CASE(false, true, 8, 0)
+        FHE_STATIC_CASE(false, false, 11, 16) FHE_STATIC_CASE(false, false, 10, 16) FHE_STATIC_CASE(false, false, 9, 16)
 #undef FHE_STATIC_CASE
         if (launched) {
             LAUNCH_CHECK();
@@ -605,13 +628,6 @@ static uint32_t ntt_t1(uint32_t logN) {
         return forced;
     return lo;
 }
-static bool ntt_generic() {
-    // the persistent/prefetching kernel (ntt_pass_fast_kernel) is experimental: at 207 VGPRs it runs 2 waves
-    // per SIMD and measured 20 % slower than the one-tile-per-workgroup kernel on MI355X (profiles/r01_*), so
-    // it is opt-in (FHE_NTT_FAST=1) until its register budget is fixed
-    static const uint32_t v = env_u32("FHE_NTT_FAST", 0);
-    return v == 0;
-}
 static bool ntt_legacy() {
     // FHE_NTT_LEGACY=1 runs the generic (small-ring) kernel for every N; default for N >= 4096 is
     // ntt_pass_full_kernel (hand-scheduled butterflies, lazy-reduction schedule), measured 5 % faster on MI355X
@@ -623,16 +639,17 @@ static bool ntt_static() {
     static const uint32_t v = env_u32("FHE_NTT_STATIC", 1);
     return v != 0;
 }
+static bool ntt_rowtw() {
+    // FHE_NTT_ROWTW=0: the row pass reads the standard twiddle table in its bit-0 step as well
+    static const uint32_t v = env_u32("FHE_NTT_ROWTW", 1);
+    return v != 0;
+}
 static bool ntt_lds2() {
     static const uint32_t v = env_u32("FHE_NTT_LDS2", 0);
     return v != 0;
 }
 static uint32_t ntt_stagger() {
     static const uint32_t v = env_u32("FHE_NTT_STAGGER", 0);
-    return v;
-}
-static uint32_t ntt_chunk() {
-    static const uint32_t v = env_u32("FHE_NTT_CHUNK", 0);
     return v;
 }
 
@@ -673,21 +690,16 @@ static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_
         schedule_fwd(pb, logN, &bound);
         pb.outBound = bound;
     }
-    // optional chunking (tuning knob FHE_NTT_CHUNK = towers per chunk): both passes of a chunk run back to
-    // back so that the intermediate tower can be served from the 256 MiB Infinity Cache instead of HBM
-    const uint32_t chunk = ntt_chunk() ? std::min(ntt_chunk(), batch) : batch;
-    for (uint32_t b0 = 0; b0 < batch; b0 += chunk) {
-        const uint32_t nb   = std::min(chunk, batch - b0);
-        const uint64_t* in  = xin + (inStride ? ((size_t)b0 * inStride << logN) : ((size_t)b0 * nLimbs << logN));
-        uint64_t* out       = xout + (outStride ? ((size_t)b0 * outStride << logN) : ((size_t)b0 * nLimbs << logN));
-        const PassPlan& p1  = inverse ? pb : pa;
-        const PassPlan& p2  = inverse ? pa : pb;
-        if (fhe_status s = launch_pass(c, p1, inverse, in, out, sel, nLimbs, nb, false, stream, inStride, inFirst, outStride, outFirst))
-            return s;
-        if (fhe_status s = launch_pass(c, p2, inverse, out, out, sel, nLimbs, nb, true, stream, outStride, outFirst, outStride, outFirst))
-            return s;
-    }
-    return FHE_OK;
+    const PassPlan& p1 = inverse ? pb : pa;
+    const PassPlan& p2 = inverse ? pa : pb;
+    // Both passes of the whole batch back to back on the caller's stream.  Two ways of overlapping the HBM-bound column
+    // pass of one part of the batch with the integer-bound row pass of another were measured and rejected
+    // (profiles/r01_sweeps.md): two streams (the hardware does not co-schedule two grids that each fill the chip) and
+    // one grid whose workgroups alternate between the two roles (the waiting column workgroups take half of the four
+    // resident slots of a CU away from the row workgroups: 33.2 ms instead of 30.4 ms per forward+inverse step).
+    if (fhe_status s = launch_pass(c, p1, inverse, xin, xout, sel, nLimbs, batch, false, stream, inStride, inFirst, outStride, outFirst))
+        return s;
+    return launch_pass(c, p2, inverse, xout, xout, sel, nLimbs, batch, true, stream, outStride, outFirst, outStride, outFirst);
 }
 
 extern "C" fhe_status fhe_ntt_fwd(fhe_ctx* c, uint64_t* x, const uint32_t* li, uint32_t nl, uint32_t b, void* st) {

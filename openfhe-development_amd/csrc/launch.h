@@ -8,6 +8,7 @@
 #ifdef FHE_EMU
 #include "emu_runtime.h"  // tests/emu/emu_runtime.h
 #define FHE_GLOBAL static
+#define FHE_DEV static inline
 #define FHE_LAUNCH_BOUNDS(n)
 #define FHE_LAUNCH_BOUNDS2(n, w)
 #define FHE_TID (fhe_emu::tls.tid)
@@ -21,6 +22,7 @@
 #else
 #include <hip/hip_runtime.h>
 #define FHE_GLOBAL __global__
+#define FHE_DEV __device__ __forceinline__
 #define FHE_LAUNCH_BOUNDS(n) __launch_bounds__(n)
 #define FHE_LAUNCH_BOUNDS2(n, w) __launch_bounds__(n, w)
 #define FHE_TID (threadIdx.x)

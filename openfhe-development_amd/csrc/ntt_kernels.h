@@ -60,6 +60,7 @@ struct NttPassArgs {
     const uint64_t* xin;  // source of the pass's first load ([batch][inStride][N] view, see inStride)
     uint64_t* x;          // [rows][N] destination (and source when xin == x)
     const TwPair* tw;     // [ctxLimbs][N], forward or inverse table
+    const TwPair* twRow;  // [ctxLimbs][N/4096][15][256] lane-major copy for the row pass's last/first step (ntt_static.h), or null
     const uint64_t* q;    // [ctxLimbs]
     const TwPair* fin;    // inverse only: [ctxLimbs][2] = {N^-1, Table_inv[1]*N^-1}
     uint32_t logN;

@@ -67,6 +67,18 @@ struct SPlan {
     static constexpr int outBound(int bin) { return boundBefore(nst, bin); }
 };
 
+#ifdef FHE_ABL_NOLDS  // timing experiment: the LDS exchange moves nothing (results are wrong)
+#define FHE_LDS_ST(slot, val) ((void)(slot))
+#define FHE_LDS_LD(dst, slot) ((void)(slot))
+#else
+#define FHE_LDS_ST(slot, val) ((slot) = (val))
+#define FHE_LDS_LD(dst, slot) ((dst) = (slot))
+#endif
+#ifdef FHE_ABL_NOSYNC  // timing experiment: no workgroup barriers (results are wrong)
+#define FHE_SSYNC() ((void)0)
+#else
+#define FHE_SSYNC() FHE_SYNC()
+#endif
 constexpr int kLdsPadWords = kTile + (kTile >> 4);
 FHE_HD constexpr uint32_t lds_pad(uint32_t I) {
     return I + (I >> 4);
@@ -167,59 +179,106 @@ FHE_HD void run_csub16(uint64_t (&r)[16], uint64_t m) {
 #endif
 }
 
-// one register-resident step I of the plan: its stages, highest field bit first (forward) / lowest first (inverse)
-template <bool LA, bool INV, int T, int I, int B, bool ENDS>
-FHE_HD void run_step_stage(uint64_t (&r)[16], const TwPair* tw, uint32_t j0, uint32_t logN, const TwPair* fin,
-                           const BflyConst c, const BflyZero z) {
+// Twiddles of one step.  `rowLane` (row passes only, may be null) points at this lane's entry of the lane-major copy
+// of the twiddles of the step whose register field sits at tile bit 0: there a lane's 15 twiddles are distinct from
+// every other lane's, and in the standard table (index 2^s + (j >> 4) * 2^(3-b) + g) neighbouring lanes are 2^(3-b)
+// entries apart — one 16-byte piece per cache line and instruction.  The copy stores, per tile, slot (2^(3-b) - 1 + g)
+// of all 256 lanes contiguously, so each load instruction of a wave reads 1 KiB of consecutive memory.
+struct TwSrc {
+    const TwPair* tw;       // standard table of the limb (Table[bitrev(i)] = psi^i)
+    const TwPair* rowLane;  // lane-major copy: slot s of this lane at rowLane[s * kThreads]
+    const TwPair* fin;      // inverse: {N^-1, Table_inv[1] * N^-1}
+};
+constexpr int kRowTwSlots = 15;
+
+template <bool LA, bool INV, int T, int I, int B>
+struct StageInfo {
     using P = SPlan<LA, INV, T>;
-    if constexpr (B <= P::bHi(I) && B >= P::bLo(I)) {
-        // twiddle index = 2^s + (j >> (Fj + 4)) * 2^(3-B) + g,  s = logN - 1 - (Fj + B),  Fj = fp + (LA ? logN - T : 0)
-        constexpr int fp   = P::fp(I);
-        constexpr bool uni = LA ? (fp + 4 == T) : (fp + 4 >= kTileLog);
-        const uint32_t Fj  = (uint32_t)fp + (LA ? logN - (uint32_t)T : 0u);
-        const uint32_t s   = logN - 1u - (Fj + (uint32_t)B);
+    static constexpr bool active = B <= P::bHi(I) && B >= P::bLo(I);
+    static constexpr int fp      = P::fp(I);
+    static constexpr bool uni    = LA ? (fp + 4 == T) : (fp + 4 >= kTileLog);
+};
+
+// issue the loads of stage B's twiddles (8 >> B of them)
+template <bool LA, bool INV, int T, int I, int B, bool ENDS>
+FHE_HD void load_stage_tw(TwPair (&w)[8], const TwSrc ts, uint32_t j0, uint32_t logN) {
+    using S = StageInfo<LA, INV, T, I, B>;
+    using P = SPlan<LA, INV, T>;
+    if constexpr (S::active) {
         // the transform's last inverse stage (s == 0) is the top stage of the pass that ends the transform
         if constexpr (INV && ENDS && I == P::nst - 1 && B == P::bHi(I)) {
             static_assert(B == 3, "the last inverse stage sits at field bit 3");
-            const uint64_t* fp64 = reinterpret_cast<const uint64_t*>(fin);
-            run_last_inv_stage(r, TwPair{FHE_ULOAD64(fp64, 0), FHE_ULOAD64(fp64, 1)},
-                               TwPair{FHE_ULOAD64(fp64, 2), FHE_ULOAD64(fp64, 3)}, c, z);
+            const uint64_t* fp64 = reinterpret_cast<const uint64_t*>(ts.fin);
+            w[0] = TwPair{FHE_ULOAD64(fp64, 0), FHE_ULOAD64(fp64, 1)};
+            w[1] = TwPair{FHE_ULOAD64(fp64, 2), FHE_ULOAD64(fp64, 3)};
+        }
+        else {
+#ifdef FHE_ABL_NOBFLY  // timing experiment: no twiddle loads, no butterflies (results are wrong)
             return;
-        }
-        uint32_t jhigh = j0 >> (Fj + 4u);
-        if constexpr (uni)
-            jhigh = FHE_UNIFORM(jhigh);
-        const TwPair* base = tw + ((size_t)1 << s);
-        const uint32_t off = jhigh << (3 - B);
-        TwPair w[8];
+#endif
+            // twiddle index = 2^s + (j >> (Fj + 4)) * 2^(3-B) + g,  s = logN - 1 - (Fj + B),  Fj = fp + (LA ? logN - T : 0)
+            const uint32_t Fj = (uint32_t)S::fp + (LA ? logN - (uint32_t)T : 0u);
+            const uint32_t s  = logN - 1u - (Fj + (uint32_t)B);
+            uint32_t jhigh    = j0 >> (Fj + 4u);
+            if constexpr (S::uni)
+                jhigh = FHE_UNIFORM(jhigh);
+            const TwPair* base = ts.tw + ((size_t)1 << s);
+            const uint32_t off = jhigh << (3 - B);
 #pragma unroll
-        for (int g = 0; g < (8 >> B); ++g) {
-            if constexpr (uni) {
-                const uint64_t* p = reinterpret_cast<const uint64_t*>(base + off + g);
-                w[g]              = TwPair{FHE_ULOAD64(p, 0), FHE_ULOAD64(p, 1)};
+            for (int g = 0; g < (8 >> B); ++g) {
+#ifdef FHE_ABL_NOTW  // timing experiment: every butterfly uses the limb's first twiddle (results are wrong)
+                const uint64_t* p0 = reinterpret_cast<const uint64_t*>(ts.tw + 1);
+                w[g]               = TwPair{FHE_ULOAD64(p0, 0) + (S::uni ? 0 : (j0 & 1)), FHE_ULOAD64(p0, 1)};
+                continue;
+#endif
+                if constexpr (S::uni) {
+                    const uint64_t* p = reinterpret_cast<const uint64_t*>(base + off + g);
+                    w[g]              = TwPair{FHE_ULOAD64(p, 0), FHE_ULOAD64(p, 1)};
+                }
+                else if constexpr (!LA && S::fp == 0) {
+                    if (ts.rowLane)
+                        w[g] = ts.rowLane[(size_t)((1 << (3 - B)) - 1 + g) * kThreads];
+                    else
+                        w[g] = base[off + g];
+                }
+                else
+                    w[g] = base[off + g];
             }
-            else
-                w[g] = base[off + g];
         }
-        run_stage<INV, uni, B>(r, w, c, z);
     }
 }
 
+template <bool LA, bool INV, int T, int I, int B, bool ENDS>
+FHE_HD void exec_stage(uint64_t (&r)[16], const TwPair (&w)[8], const BflyConst c, const BflyZero z) {
+    using S = StageInfo<LA, INV, T, I, B>;
+    using P = SPlan<LA, INV, T>;
+    if constexpr (S::active) {
+        if constexpr (INV && ENDS && I == P::nst - 1 && B == P::bHi(I))
+            run_last_inv_stage(r, w[0], w[1], c, z);
+        else {
+#ifdef FHE_ABL_NOBFLY
+            return;
+#endif
+            run_stage<INV, S::uni, B>(r, w, c, z);
+        }
+    }
+}
+
+// one register-resident step I of the plan: its stages, highest field bit first (forward) / lowest first (inverse);
+// the twiddle loads of a stage are issued before the butterflies of the previous stage (the asm blocks are
+// scheduling barriers, so the order written here is the order executed)
 template <bool LA, bool INV, int T, int I, bool ENDS>
-FHE_HD void run_step(uint64_t (&r)[16], const TwPair* tw, uint32_t j0, uint32_t logN, const TwPair* fin, const BflyConst c,
-                     const BflyZero z) {
-    if constexpr (!INV) {
-        run_step_stage<LA, INV, T, I, 3, ENDS>(r, tw, j0, logN, fin, c, z);
-        run_step_stage<LA, INV, T, I, 2, ENDS>(r, tw, j0, logN, fin, c, z);
-        run_step_stage<LA, INV, T, I, 1, ENDS>(r, tw, j0, logN, fin, c, z);
-        run_step_stage<LA, INV, T, I, 0, ENDS>(r, tw, j0, logN, fin, c, z);
-    }
-    else {
-        run_step_stage<LA, INV, T, I, 0, ENDS>(r, tw, j0, logN, fin, c, z);
-        run_step_stage<LA, INV, T, I, 1, ENDS>(r, tw, j0, logN, fin, c, z);
-        run_step_stage<LA, INV, T, I, 2, ENDS>(r, tw, j0, logN, fin, c, z);
-        run_step_stage<LA, INV, T, I, 3, ENDS>(r, tw, j0, logN, fin, c, z);
-    }
+FHE_HD void run_step(uint64_t (&r)[16], const TwSrc ts, uint32_t j0, uint32_t logN, const BflyConst c, const BflyZero z) {
+    TwPair w0[8], w1[8], w2[8], w3[8];
+    constexpr int B0 = INV ? 0 : 3, B1 = INV ? 1 : 2, B2 = INV ? 2 : 1, B3 = INV ? 3 : 0;
+    load_stage_tw<LA, INV, T, I, B0, ENDS>(w0, ts, j0, logN);
+    load_stage_tw<LA, INV, T, I, B1, ENDS>(w1, ts, j0, logN);
+    exec_stage<LA, INV, T, I, B0, ENDS>(r, w0, c, z);
+    load_stage_tw<LA, INV, T, I, B2, ENDS>(w2, ts, j0, logN);
+    exec_stage<LA, INV, T, I, B1, ENDS>(r, w1, c, z);
+    load_stage_tw<LA, INV, T, I, B3, ENDS>(w3, ts, j0, logN);
+    exec_stage<LA, INV, T, I, B2, ENDS>(r, w2, c, z);
+    exec_stage<LA, INV, T, I, B3, ENDS>(r, w3, c, z);
 }
 
 // lane geometry of a step whose register field sits at tile-index bit fI: tile index of register 0 and the
@@ -239,20 +298,19 @@ FHE_HD void lane_geom_s(uint32_t t, uint32_t S, uint32_t& Ib, uint32_t& jrel, ui
     }
 }
 
-// MODE, forward: bound of the pass input in units of q — 1 = canonical, 9 = the lazy output of a column pass (anything
-// in (8,16]: the first step then starts with the sweep below 8q).  MODE, inverse: 1 = this pass ends the transform
+// MODE, forward: an upper bound of the pass input in units of q — 1 = canonical, 9 = the lazy output of a 4-stage
+// column pass, 16 = anything below 16q (the lazy-reduction schedule is derived from it).  MODE, inverse: 1 = this pass ends the transform
 // (its top stage is the transform's last stage, with N^-1 folded in), 0 = it does not.
 // DB: two LDS buffers alternate (one barrier per exchange, 68 KiB, 2 workgroups per CU) instead of one buffer with a
 // barrier on either side of the exchange (34 KiB, 4 workgroups per CU).
 template <bool LA, bool INV, int T, int MODE, bool DB>
-FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_static_kernel(const NttPassArgs a) {
+FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) {
     using P = SPlan<LA, INV, T>;
-    FHE_SHARED_U64(lds, (DB ? 2 : 1) * kLdsPadWords);
     const uint32_t t    = FHE_TID;
     const uint32_t logN = a.logN;
     const uint32_t N    = 1u << logN;
     const uint32_t tilesPerRow = N >> kTileLog;
-    uint32_t tile = FHE_BID;
+    uint32_t tile = bid;
     if (a.xcdSwizzle) {
         const uint32_t xcd = tile & 7u, i = tile >> 3;
         const uint32_t b = i % a.batch, pairIdx = i / a.batch;
@@ -269,8 +327,12 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_static_kernel(const NttPassArgs 
     const uint32_t limb = FHE_UNIFORM(a.sel.idx[rit]);
     const uint64_t q    = FHE_ULOAD64(a.q, limb);
     const uint64_t twoq = q << 1, nq = 0 - q;
-    const TwPair* tw    = a.tw + ((uint64_t)limb << logN);
-    const TwPair* fin   = a.fin + 2 * (size_t)limb;
+    TwSrc ts;
+    ts.tw      = a.tw + ((uint64_t)limb << logN);
+    ts.fin     = a.fin + 2 * (size_t)limb;
+    ts.rowLane = nullptr;
+    if (!LA && a.twRow)  // [limb][tile of the ring][slot][lane]
+        ts.rowLane = a.twRow + ((size_t)limb * tilesPerRow + tr) * (kRowTwSlots * kThreads) + t;
     const BflyConst c{(uint32_t)nq, (uint32_t)(nq >> 32), twoq, 0 - twoq};
     BflyZero z{0, 0};
 #ifdef FHE_PINNED_ASM
@@ -294,8 +356,8 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_static_kernel(const NttPassArgs 
         uint64_t* L = lds + buf * kLdsPadWords + lds_pad(Ib);
 #pragma unroll
         for (int k = 0; k < 16; ++k)
-            L[lds_pad((uint32_t)k << 8)] = r[k];
-        FHE_SYNC();
+            FHE_LDS_ST(L[lds_pad((uint32_t)k << 8)], r[k]);
+        FHE_SSYNC();
     }
 
 #define FHE_STATIC_STEP(I)                                                                                        \
@@ -307,7 +369,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_static_kernel(const NttPassArgs 
         }                                                                                                         \
         else {                                                                                                    \
             const uint64_t* L = lds + buf * kLdsPadWords + lds_pad(Ib);                                           \
-            _Pragma("unroll") for (int k = 0; k < 16; ++k) r[k] = L[lds_pad((uint32_t)k << fI)];                  \
+            _Pragma("unroll") for (int k = 0; k < 16; ++k) FHE_LDS_LD(r[k], L[lds_pad((uint32_t)k << fI)]);                  \
             if constexpr (DB)                                                                                     \
                 buf ^= 1;                                                                                         \
         }                                                                                                         \
@@ -315,7 +377,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_static_kernel(const NttPassArgs 
            (< 2^64) is, so only the 8 `a` inputs of the step's first stage go back below 8q */                      \
         if constexpr (!INV && P::sweep(I, MODE))                                                                 \
             run_csub8_a<P::bHi(I)>(r, twoq << 2);                                                                 \
-        run_step<LA, INV, T, I, (INV && MODE == 1)>(r, tw, jbase + jrel, logN, fin, c, z);                         \
+        run_step<LA, INV, T, I, (INV && MODE == 1)>(r, ts, jbase + jrel, logN, c, z);                              \
         if constexpr (I == P::nst - 1) {                                                                          \
             if (canonOut) {                                                                                       \
                 if constexpr (INV)                                                                                \
@@ -334,10 +396,10 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_static_kernel(const NttPassArgs 
         }                                                                                                         \
         else {                                                                                                    \
             if constexpr (!DB && (I > 0 || P::stageFirst))                                                        \
-                FHE_SYNC(); /* every lane has finished reading the buffer */                                      \
+                FHE_SSYNC(); /* every lane has finished reading the buffer */                                      \
             uint64_t* L = lds + buf * kLdsPadWords + lds_pad(Ib);                                                 \
-            _Pragma("unroll") for (int k = 0; k < 16; ++k) L[lds_pad((uint32_t)k << fI)] = r[k];                  \
-            FHE_SYNC();                                                                                           \
+            _Pragma("unroll") for (int k = 0; k < 16; ++k) FHE_LDS_ST(L[lds_pad((uint32_t)k << fI)], r[k]);                  \
+            FHE_SSYNC();                                                                                           \
         }                                                                                                         \
     }
     FHE_STATIC_STEP(0)
@@ -351,11 +413,21 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_static_kernel(const NttPassArgs 
         const uint64_t* L = lds + buf * kLdsPadWords + lds_pad(Ib);
 #pragma unroll
         for (int k = 0; k < 16; ++k)
-            r[k] = L[lds_pad((uint32_t)k << 8)];
+            FHE_LDS_LD(r[k], L[lds_pad((uint32_t)k << 8)]);
 #pragma unroll
         for (int k = 0; k < 16; ++k)
             dst[jrel + k * ks] = r[k];
     }
+}
+
+template <bool LA, bool INV, int T, int MODE, bool DB>
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_static_kernel(const NttPassArgs a) {
+    // a single-step pass without staging (the 4-stage column pass) never touches LDS: do not reserve any, so that
+    // more workgroups fit on a CU
+    using P = SPlan<LA, INV, T>;
+    constexpr bool needsLds = P::nst > 1 || P::stageFirst || P::stageLast;
+    FHE_SHARED_U64(lds, needsLds ? (DB ? 2 : 1) * kLdsPadWords : 1);
+    ntt_static_body<LA, INV, T, MODE, DB>(a, FHE_BID, lds);
 }
 
 }  // namespace fhe
