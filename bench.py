@@ -319,7 +319,7 @@ def main():
                     traffic = pmc["per_launch_bytes"][dom[:-3]]["total"]
             except Exception:
                 traffic = None
-            roof = {"bound": "hbm", "kernel": "ntt_pass_full_kernel/" + dom[:-3], "achieved": round(ach, 1),
+            roof = {"bound": "hbm", "kernel": "ntt_static_kernel/" + dom[:-3], "achieved": round(ach, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
                     "traffic_source": "profiles/r01_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
                                       if traffic else None,
@@ -328,7 +328,7 @@ def main():
             lib.check(lib.L.fhe_time_ntt(ctx.h, x, None, L, B, 0, 5, None, C.byref(ms)))
             alg = 2.0 * 8 * N * L * B
             ach = alg / (ms.value * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "ntt_pass_kernel(single pass)", "achieved": round(ach, 1),
+            roof = {"bound": "hbm", "kernel": "ntt_static_kernel(single pass)", "achieved": round(ach, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None}
         # restore a valid tower for anything that follows (single-pass timing scrambles it): not needed further
     ctx.free(x)

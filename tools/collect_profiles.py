@@ -1,19 +1,24 @@
 #!/usr/bin/env python3
 """copies the judged summaries of the last tools/gpu_bench_r01.sh run from gpurun_out/ (scratch) into profiles/"""
 import collections, csv, glob, json, os, shutil, sys
+
+
+def newest(pattern):  # gpurun_out accumulates the runs of a round: take the latest file
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
 R = sys.argv[1] if len(sys.argv) > 1 else "r01"
 os.makedirs("profiles", exist_ok=True)
 shutil.copy("gpurun_out/bench_r01.json", f"profiles/{R}_bench.json")
 shutil.copy("gpurun_out/bench_r01_em128.json", f"profiles/{R}_bench_evalmult128.json")
-shutil.copy(glob.glob("gpurun_out/prof_r01/*/*kernel_stats.csv")[0], f"profiles/{R}_rocprof_kernel_stats_bench.csv")
-names = {"<true, false>": "fwd_column_pass", "<false, false>": "fwd_row_pass", "<false, true>": "inv_row_pass",
-         "<true, true>": "inv_column_pass"}
+shutil.copy(newest("gpurun_out/prof_r01/*/*kernel_stats.csv"), f"profiles/{R}_rocprof_kernel_stats_bench.csv")
+names = {"<true, false,": "fwd_column_pass", "<false, false,": "fwd_row_pass", "<false, true,": "inv_row_pass",
+         "<true, true,": "inv_column_pass"}
 res = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob(f"gpurun_out/pmc_r01_{c}/*/*counter_collection.csv")[0]
+    f = newest(f"gpurun_out/pmc_r01_{c}/*/*counter_collection.csv")
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == c and "ntt_pass" in r["Kernel_Name"]:
+        if r["Counter_Name"] == c and "ntt_static_kernel" in r["Kernel_Name"]:
             key = [v for k, v in names.items() if k in r["Kernel_Name"]][0]
             agg[key].append(float(r["Counter_Value"]))
     for k, v in agg.items():

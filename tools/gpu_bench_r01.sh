@@ -4,7 +4,7 @@ mkdir -p gpurun_out
 export FHE_BENCH_NO_TORCH=1
 echo "== gpu tests"; timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -2
 echo "== bench (default flags)"; timeout 900 python bench.py 2>&1 | tail -1 | tee gpurun_out/bench_r01.json | cut -c1-400
-echo "== bench evalmult batch 128"; timeout 900 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --evalmult-batch 128 2>&1 | tail -1 > gpurun_out/bench_r01_em128.json; python -c "import json;d=json.load(open('gpurun_out/bench_r01_em128.json'));print(d['evalmult'])"
+echo "== bench evalmult batch 128"; timeout 900 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --evalmult-batch 128 --bfv 2>&1 | tail -1 > gpurun_out/bench_r01_em128.json; python -c "import json;d=json.load(open('gpurun_out/bench_r01_em128.json'));print(d['evalmult']);print(d.get('bfv_evalmult'))"
 cd /tmp && export TMPDIR=/tmp
 echo "== rocprof kernel stats (same command as the bench line)"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r01 -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_r01.log 2>&1
