@@ -188,8 +188,40 @@ struct TwSrc {
     const TwPair* tw;       // standard table of the limb (Table[bitrev(i)] = psi^i)
     const TwPair* rowLane;  // lane-major copy: slot s of this lane at rowLane[s * kThreads]
     const TwPair* fin;      // inverse: {N^-1, Table_inv[1] * N^-1}
+    const TwPair* shared;   // LDS copy of the twiddles of the row pass's "shared" step (below), or null
+    uint32_t sharedLane;    // this lane's group index in that step: t >> fp
 };
 constexpr int kRowTwSlots = 15;
+
+// "Shared" step of a row pass: register field at tile bits fp..fp+3 with 4 <= fp < 8.  Its twiddles depend on the
+// lane only through t >> fp (2^(8-fp) <= 16 groups), and for one stage b the tile needs ONE contiguous run of
+// groups * (8 >> b) table entries starting at 2^s + (tileBase >> (fp+4)) * 2^(3-b).  The workgroup copies the runs of
+// the step's stages into LDS with one 16-byte load per lane at kernel start (<= 240 entries); the lanes then read
+// their (up to 15) twiddles as ds_read_b128 instead of 15 global loads of which 16+ lanes fetch the same address.
+template <int T, bool INV>
+struct SharedStep {
+    using P = SPlan<false, INV, T>;
+    static constexpr int find() {
+        for (int i = 0; i < P::nst; ++i)
+            if (P::fp(i) >= 4 && P::fp(i) + 4 < kTileLog)
+                return i;
+        return -1;
+    }
+    static constexpr int I      = find();
+    static constexpr bool any   = I >= 0;
+    static constexpr int fp     = any ? P::fp(any ? I : 0) : 4;
+    static constexpr int groups = 1 << (8 - fp);
+    static constexpr bool active(int b) { return any && b <= P::bHi(any ? I : 0) && b >= P::bLo(any ? I : 0); }
+    static constexpr int count(int b) { return active(b) ? groups * (8 >> b) : 0; }
+    static constexpr int offset(int b) {  // LDS entry offset of stage b's run
+        int o = 0;
+        for (int k = 0; k < b; ++k)
+            o += count(k);
+        return o;
+    }
+    static constexpr int total = count(0) + count(1) + count(2) + count(3);
+};
+constexpr int kSharedTwWords = 2 * 256;  // LDS words reserved for the shared step's twiddles (<= 240 TwPairs)
 
 template <bool LA, bool INV, int T, int I, int B>
 struct StageInfo {
@@ -240,6 +272,10 @@ FHE_HD void load_stage_tw(TwPair (&w)[8], const TwSrc ts, uint32_t j0, uint32_t 
                         w[g] = ts.rowLane[(size_t)((1 << (3 - B)) - 1 + g) * kThreads];
                     else
                         w[g] = base[off + g];
+                }
+                else if constexpr (!LA && SharedStep<T, INV>::any && SharedStep<T, INV>::I == I) {
+                    using SS = SharedStep<T, INV>;
+                    w[g]     = ts.shared[SS::offset(B) + ts.sharedLane * (8 >> B) + g];  // LDS (ds_read_b128)
                 }
                 else
                     w[g] = base[off + g];
@@ -333,6 +369,32 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
     ts.rowLane = nullptr;
     if (!LA && a.twRow)  // [limb][tile of the ring][slot][lane]
         ts.rowLane = a.twRow + ((size_t)limb * tilesPerRow + tr) * (kRowTwSlots * kThreads) + t;
+    // twiddles of the shared step: one 16-byte global load per lane now, written to LDS behind the data loads
+    TwPair* sharedLds = reinterpret_cast<TwPair*>(lds + (DB ? 2 : 1) * kLdsPadWords);
+    ts.shared         = sharedLds;
+    ts.sharedLane     = 0;
+    uint64_t sharedW = 0, sharedWp = 0;  // (two scalars: a conditionally assigned 16-byte struct lands in scratch)
+    using SS = SharedStep<LA ? 12 : T, INV>;
+    constexpr bool useShared = !LA && SS::any;
+    if constexpr (useShared) {
+        ts.sharedLane = t >> SS::fp;
+        if (t < (uint32_t)SS::total) {
+            // entry t belongs to the run of stage b with offset(b) <= t < offset(b) + count(b)
+            uint32_t b = 0, ob = 0;
+            if (SS::count(1) && t >= (uint32_t)SS::offset(1))
+                b = 1, ob = (uint32_t)SS::offset(1);
+            if (SS::count(2) && t >= (uint32_t)SS::offset(2))
+                b = 2, ob = (uint32_t)SS::offset(2);
+            if (SS::count(3) && t >= (uint32_t)SS::offset(3))
+                b = 3, ob = (uint32_t)SS::offset(3);
+            if (!SS::count(0) && b == 0)  // the step has no stage 0: its first run belongs to the lowest active stage
+                b = SS::count(1) ? 1 : SS::count(2) ? 2 : 3;
+            const uint32_t s_b = logN - 1u - ((uint32_t)SS::fp + b);
+            const size_t idx   = ((size_t)1 << s_b) + ((size_t)(jbase >> (SS::fp + 4)) << (3u - b)) + (t - ob);
+            const TwPair v     = ts.tw[idx];
+            sharedW = v.w, sharedWp = v.wp;
+        }
+    }
     const BflyConst c{(uint32_t)nq, (uint32_t)(nq >> 32), twoq, 0 - twoq};
     BflyZero z{0, 0};
 #ifdef FHE_PINNED_ASM
@@ -347,12 +409,22 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
     uint64_t ks;
     int buf = 0;  // LDS buffer of the next exchange
 
+#define FHE_SHARED_TW_TO_LDS()                                             \
+    if constexpr (useShared) {                                             \
+        if (t < (uint32_t)SS::total)                                       \
+            sharedLds[t] = TwPair{sharedW, sharedWp};                      \
+        /* the shared step must sit behind at least one barrier */          \
+        if constexpr (SS::I == 0 && !P::stageFirst)                        \
+            FHE_SSYNC();                                                   \
+    }
+
     // ---- first load ----
     if constexpr (P::stageFirst) {
         lane_geom_s<LA, T, 8>(t, S, Ib, jrel, ks);
 #pragma unroll
         for (int k = 0; k < 16; ++k)
             r[k] = src[jrel + k * ks];
+        FHE_SHARED_TW_TO_LDS()
         uint64_t* L = lds + buf * kLdsPadWords + lds_pad(Ib);
 #pragma unroll
         for (int k = 0; k < 16; ++k)
@@ -366,6 +438,7 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
         lane_geom_s<LA, T, fI>(t, S, Ib, jrel, ks);                                                               \
         if constexpr (I == 0 && !P::stageFirst) {                                                                 \
             _Pragma("unroll") for (int k = 0; k < 16; ++k) r[k] = src[jrel + k * ks];                             \
+            FHE_SHARED_TW_TO_LDS()                                                                                \
         }                                                                                                         \
         else {                                                                                                    \
             const uint64_t* L = lds + buf * kLdsPadWords + lds_pad(Ib);                                           \
@@ -406,6 +479,7 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
     FHE_STATIC_STEP(1)
     FHE_STATIC_STEP(2)
 #undef FHE_STATIC_STEP
+#undef FHE_SHARED_TW_TO_LDS
 
     // ---- last store ----
     if constexpr (P::stageLast) {
@@ -426,7 +500,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_static_kernel(const NttPassArgs 
     // more workgroups fit on a CU
     using P = SPlan<LA, INV, T>;
     constexpr bool needsLds = P::nst > 1 || P::stageFirst || P::stageLast;
-    FHE_SHARED_U64(lds, needsLds ? (DB ? 2 : 1) * kLdsPadWords : 1);
+    FHE_SHARED_U64(lds, needsLds ? (DB ? 2 : 1) * kLdsPadWords + kSharedTwWords : 1);
     ntt_static_body<LA, INV, T, MODE, DB>(a, FHE_BID, lds);
 }
 
