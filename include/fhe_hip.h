@@ -208,6 +208,11 @@ fhe_status fhe_approx_mod_down(fhe_ks_plan* plan, const uint64_t* x, uint32_t si
 size_t     fhe_rescale_workspace_bytes(const fhe_ctx* ctx, uint32_t sizeQl, uint32_t batch);
 fhe_status fhe_rescale(fhe_ctx* ctx, const uint64_t* x, uint32_t sizeQl, uint32_t batch, uint64_t* out, void* ws,
                        size_t wsBytes, void* stream);
+/* DCRTPolyImpl::ModReduce (dcrtpoly-impl.h:736-755) — BGV modulus switching by the last limb with plaintext modulus t
+ * (tables negtInvModq / qlInvModq / tModqPrecon of CryptoParametersBGVRNS are derived inside): x [batch][sizeQl][N] in
+ * `evalFormat`, out [batch][sizeQl-1][N] in the same format; ws as for fhe_rescale. */
+fhe_status fhe_mod_reduce(fhe_ctx* ctx, const uint64_t* x, uint32_t sizeQl, uint64_t t, int evalFormat, uint32_t batch,
+                          uint64_t* out, void* ws, size_t wsBytes, void* stream);
 
 /* ---- a17: ScaleAndRound family (BFV HPS) ----------------------------------------------------------------
  * fhe_sr_plan_create keeps the caller's tables on the device. They are the reference's own

@@ -96,7 +96,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) switch_basis_kernel(const ConvArgs g
 #pragma unroll
         for (int i = 0; i < NSRC; ++i)
             if (i < (int)g.nSrc)
-                mac192_add(m, y[i], h[i]);
+                mac192_add_uniform(m, y[i], h[i]);
         u128w acc;
         mac192_fold(m, acc.lo, acc.hi);
         uint64_t v = barrett128(acc, p, mulo, muhi);

@@ -168,7 +168,7 @@ FHE_HD uint64_t dot_row_mod(const uint64_t (&y)[kMaxBfvLimbs], const uint64_t* r
 #pragma unroll
     for (int i = 0; i < kMaxBfvLimbs; ++i)
         if (i < (int)n)
-            mac192_add(acc, y[i], h[i]);
+            mac192_add_uniform(acc, y[i], h[i]);
     u128w a;
     mac192_fold(acc, a.lo, a.hi);
     return barrett128(a, m, mulo, muhi);

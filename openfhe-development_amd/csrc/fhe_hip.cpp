@@ -237,6 +237,8 @@ struct fhe_ctx {
     std::vector<void*> owned;     // every device allocation made for tables (freed in destroy)
     // cached per-level rescale tables (ckksrns-cryptoparameters.cpp:60-81): sizeQl -> {A, B} device arrays
     std::map<uint32_t, std::pair<TwPair*, TwPair*>> rescaleTabs;
+    // cached ModReduce tables per (sizeQl, t): [0..l) = A_i, [l..2l) = B_i, [2l] = negtInvModq   (fhe_mod_reduce)
+    std::map<std::pair<uint32_t, uint64_t>, TwPair*> modReduceTabs;
     // small ring of device slots for per-call constant vectors (fhe_mul_const)
     uint32_t persistentGrid = 1024;  // workgroups of the persistent NTT kernels (CUs x FHE_NTT_WG_PER_CU)
     TwPair* d_constRing = nullptr;
@@ -1473,6 +1475,62 @@ extern "C" fhe_status fhe_rescale(fhe_ctx* c, const uint64_t* x, uint32_t sizeQl
         return s;
     // m_vectors[i] = m_vectors[i] * qlInvModq[i] + tmp  (:708-709); x towers are sizeQl rows apart
     return elem_run<OP_MUL_CONST_ADD>(c, out, x, tmp, dB, nullptr, l, batch, st, "fhe_rescale", sizeQl, 0);
+}
+
+// DCRTPolyImpl::ModReduce (dcrtpoly-impl.h:736-755), the BGV modulus switch by the last limb with plaintext modulus t:
+//   delta = [last limb]_COEFF * (-t^-1 mod q_l);  x_i = (x_i + t * SwitchModulus(delta -> q_i)) * q_l^-1,  i < l.
+// Launched as x_i * B_i + NTT(SwitchModulus(delta) * A_i) with B_i = q_l^-1 and A_i = t * q_l^-1 mod q_i: the NTT is
+// linear, every step yields canonical residues, so the words equal the reference's.  Same workspace as fhe_rescale.
+extern "C" fhe_status fhe_mod_reduce(fhe_ctx* c, const uint64_t* x, uint32_t sizeQl, uint64_t t, int evalFormat,
+                                     uint32_t batch, uint64_t* out, void* wsv, size_t wsBytes, void* st) {
+    ARG_CHECK(c && x && out && wsv, "fhe_mod_reduce: null argument");
+    ARG_CHECK(sizeQl >= 2 && sizeQl <= c->L, "Removing last element of DCRTPoly renders it invalid.");  // :672-673
+    ARG_CHECK(batch >= 1 && wsBytes >= fhe_rescale_workspace_bytes(c, sizeQl, batch), "fhe_mod_reduce: workspace too small");
+    RT_CHECK(rt::set_device(c->device));
+    const uint32_t l  = sizeQl - 1;
+    const uint64_t ql = c->q[l];
+    ARG_CHECK(t >= 2 && t % ql != 0, "fhe_mod_reduce: t must be invertible modulo the dropped limb");
+    uint64_t* last = (uint64_t*)wsv;                    // [batch][N]
+    uint64_t* tmp  = last + ((size_t)batch << c->logN);  // [batch][l][N]
+    auto it = c->modReduceTabs.find({sizeQl, t});
+    if (it == c->modReduceTabs.end()) {
+        std::vector<TwPair> h(2 * (size_t)l + 1);
+        for (uint32_t i = 0; i < l; ++i) {
+            const uint64_t qi = c->q[i];
+            const uint64_t B  = host::invmod(ql % qi, qi);      // qlInvModq
+            const uint64_t A  = host::mulmod(t % qi, B, qi);
+            h[i]              = TwPair{A, host::shoup(A, qi)};
+            h[l + i]          = TwPair{B, host::shoup(B, qi)};
+        }
+        const uint64_t negtInv = (ql - host::invmod(t % ql, ql)) % ql;  // negtInvModq
+        h[2 * (size_t)l]       = TwPair{negtInv, host::shoup(negtInv, ql)};
+        void* d = nullptr;
+        RT_CHECK(rt::dmalloc(&d, h.size() * sizeof(TwPair)));
+        c->owned.push_back(d);
+        RT_CHECK(rt::h2d(d, h.data(), h.size() * sizeof(TwPair), nullptr));
+        RT_CHECK(rt::sync(nullptr));
+        it = c->modReduceTabs.emplace(std::make_pair(sizeQl, t), (TwPair*)d).first;
+    }
+    TwPair *dA = it->second, *dB = dA + l, *dN = dA + 2 * (size_t)l;
+    const uint32_t lastIdx = l;
+    if (evalFormat) {  // delta.SetFormat(COEFFICIENT)  :741
+        if (fhe_status s = ntt_run(c, true, x, last, &lastIdx, 1, batch, st, sizeQl, l))
+            return s;
+    }
+    else
+        RT_CHECK(rt::d2d_2d(last, (size_t)8 << c->logN, x + ((size_t)l << c->logN), ((size_t)sizeQl * 8) << c->logN,
+                            (size_t)8 << c->logN, batch, (rt::stream_t)st));
+    if (fhe_status s = elem_run<OP_MUL_CONST>(c, last, last, nullptr, dN, &lastIdx, 1, batch, st, "fhe_mod_reduce"))  // :742
+        return s;
+    LimbSel sel;
+    if (fhe_status s = make_sel(c, nullptr, l, &sel, "fhe_mod_reduce"))
+        return s;
+    if (fhe_status s = switch_modulus_run(c, tmp, sel, l, last, 1, 0, l, dA, batch, st))  // :749, :752 (t folded into A_i)
+        return s;
+    if (evalFormat)  // :750-751
+        if (fhe_status s = fhe_ntt_fwd(c, tmp, nullptr, l, batch, st))
+            return s;
+    return elem_run<OP_MUL_CONST_ADD>(c, out, x, tmp, dB, nullptr, l, batch, st, "fhe_mod_reduce", sizeQl, 0);  // :752-753
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -137,6 +137,30 @@ FHE_HD void mac192_add(mac192& m, uint64_t a, uint64_t b) {
     m.k2 += t < m.c2;
     m.c2 = t;
 }
+// mac192_add with a wave-uniform multiplier b (a table word in SGPRs): on gfx950 the carries come straight from the
+// multiply-adds' carry-outs (7 VALU instructions; hipcc's version of the C++ above is 13: multiply, 64-bit add,
+// compare, add-with-carry per column).  Two instructions separate every carry write from its reader.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FHE_NO_MAD_ASM)
+__device__ __forceinline__ void mac192_add_uniform(mac192& m, uint64_t a, uint64_t b) {
+    const uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
+    asm volatile(
+        "v_mad_u64_u32 %[c0], s[42:43], %[al], %[bl], %[c0]\n\t"
+        "v_mad_u64_u32 %[c1], s[44:45], %[al], %[bh], %[c1]\n\t"
+        "v_mad_u64_u32 %[c2], s[40:41], %[ah], %[bh], %[c2]\n\t"
+        "v_addc_co_u32_e64 %[k0], s[40:41], %[k0], 0, s[42:43]\n\t"
+        "v_mad_u64_u32 %[c1], s[46:47], %[ah], %[bl], %[c1]\n\t"
+        "v_addc_co_u32_e64 %[k1], s[40:41], %[k1], 0, s[44:45]\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e64 %[k1], s[40:41], %[k1], 0, s[46:47]\n\t"
+        : [c0] "+v"(m.c0), [c1] "+v"(m.c1), [c2] "+v"(m.c2), [k0] "+v"(m.k0), [k1] "+v"(m.k1)
+        : [al] "v"(al), [ah] "v"(ah), [bl] "s"(bl), [bh] "s"(bh)
+        : "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47");
+}
+#else
+FHE_HD void mac192_add_uniform(mac192& m, uint64_t a, uint64_t b) {
+    mac192_add(m, a, b);
+}
+#endif
 // fold the columns into a 128-bit value (the true sum must be < 2^128)
 struct u128w;
 FHE_HD void mac192_fold(const mac192& m, uint64_t& lo, uint64_t& hi) {

@@ -21,6 +21,7 @@ u64p = C.POINTER(C.c_uint64)
 u32p = C.POINTER(C.c_uint32)
 vp = C.c_void_p
 u32 = C.c_uint32
+u64 = C.c_uint64
 EVALUATION, COEFFICIENT = 0, 1  # lbcrypto::Format (src/core/include/utils/inttypes.h:65)
 
 
@@ -98,7 +99,7 @@ class Lib:
         S("fhe_approx_mod_down", C.c_int, [vp, vp, u32, u32, vp, vp, C.c_size_t, vp])
         S("fhe_rescale_workspace_bytes", C.c_size_t, [vp, u32, u32])
         S("fhe_rescale", C.c_int, [vp, vp, u32, u32, vp, vp, C.c_size_t, vp])
-        u64 = C.c_uint64
+        S("fhe_mod_reduce", C.c_int, [vp, vp, u32, u64, C.c_int, u32, vp, vp, C.c_size_t, vp])
         f64p = C.POINTER(C.c_double)
         S("fhe_sr_plan_create", C.c_int, [vp, u32, u32p, u32, u64p, f64p, C.POINTER(vp)])
         S("fhe_sr_plan_destroy", None, [vp])
@@ -422,6 +423,19 @@ def rescale(ctx, x, stream=None):
     ws = ctx.malloc(need)
     out = ctx.empty(x.batch, sizeQl - 1)
     ctx.lib.check(ctx.lib.L.fhe_rescale(ctx.h, x.ptr, sizeQl, x.batch, out.ptr, ws, need, stream))
+    ctx.sync(stream)
+    ctx.free(ws)
+    return out
+
+
+def mod_reduce(ctx, x, t, stream=None):
+    """DCRTPoly::ModReduce (BGV modulus switch by the last limb, dcrtpoly-impl.h:736-755) on a Tower over limbs [0, sizeQl)."""
+    sizeQl = x.n_limbs
+    need = ctx.lib.L.fhe_rescale_workspace_bytes(ctx.h, sizeQl, x.batch)
+    ws = ctx.malloc(need)
+    out = ctx.empty(x.batch, sizeQl - 1, None, x.fmt)
+    ctx.lib.check(ctx.lib.L.fhe_mod_reduce(ctx.h, x.ptr, sizeQl, t, 1 if x.fmt == EVALUATION else 0, x.batch, out.ptr, ws,
+                                           need, stream))
     ctx.sync(stream)
     ctx.free(ws)
     return out

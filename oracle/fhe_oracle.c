@@ -1051,6 +1051,35 @@ void orc_drop_last_element_and_scale(const orc_ctx* c, const uint64_t* x, uint32
     free(last);
 }
 
+/* DCRTPolyImpl::ModReduce (dcrtpoly-impl.h:736-755), BGV modulus switching by the last limb with plaintext modulus t:
+ * delta = [last]_{COEFF} * (-t^-1 mod q_l); per remaining limb: x_i = (x_i + t * SwitchModulus(delta -> q_i)) * q_l^-1.
+ * Tables as CryptoParametersBGVRNS builds them (bgvrns-cryptoparameters.cpp: negtInvModq, qlInvModq, tModqPrecon). */
+void orc_mod_reduce(const orc_ctx* c, const uint64_t* x, uint32_t sizeQl, uint64_t t, int evalFormat, uint64_t* out) {
+    const uint32_t N = c->N, l = sizeQl - 1;
+    const uint64_t ql = c->q[l];
+    const uint64_t negtInv = (ql - orc_invmod(t % ql, ql)) % ql;
+    uint64_t* delta = (uint64_t*)malloc(sizeof(uint64_t) * N);
+    memcpy(delta, x + (size_t)l * N, sizeof(uint64_t) * N);
+    if (evalFormat)
+        ctx_inv(c, delta, l);                        /* delta.SetFormat(COEFFICIENT)  :741 */
+    orc_vec_mul_const(delta, delta, negtInv, N, ql); /* delta *= negtInvModq          :742 */
+#pragma omp parallel for
+    for (uint32_t i = 0; i < l; ++i) {
+        const uint64_t qi   = c->q[i];
+        const uint64_t qlInv = orc_invmod(ql % qi, qi);
+        uint64_t* tmp = (uint64_t*)malloc(sizeof(uint64_t) * N);
+        memcpy(tmp, delta, sizeof(uint64_t) * N);
+        orc_switch_modulus(tmp, N, ql, qi);          /* :749 */
+        if (evalFormat)
+            ctx_fwd(c, tmp, i);                      /* :750-751 */
+        orc_vec_mul_const(tmp, tmp, t % qi, N, qi);  /* tmp *= t                      :752 */
+        orc_vec_add(out + (size_t)i * N, x + (size_t)i * N, tmp, N, qi);
+        orc_vec_mul_const(out + (size_t)i * N, out + (size_t)i * N, qlInv, N, qi); /* :753 */
+        free(tmp);
+    }
+    free(delta);
+}
+
 /* ------------------------------------------------------------------------------------------
  * a17: ScaleAndRound family.  Double-precision accumulation order is part of the result.
  * ---------------------------------------------------------------------------------------- */

@@ -152,6 +152,8 @@ void orc_eval_automorphism(const orc_hybrid*, const uint64_t* c0, const uint64_t
  * x[sizeQl][N] -> out[sizeQl-1][N]; ctx limbs [0,sizeQl) are the tower. Tables are computed inside
  * the way ckksrns-cryptoparameters.cpp:60-81 does. */
 void orc_drop_last_element_and_scale(const orc_ctx*, const uint64_t* x, uint32_t sizeQl, uint64_t* out);
+/* DCRTPolyImpl::ModReduce (dcrtpoly-impl.h:736-755): BGV modulus switch by the last limb; x [sizeQl][N], out [sizeQl-1][N] */
+void orc_mod_reduce(const orc_ctx*, const uint64_t* x, uint32_t sizeQl, uint64_t t, int evalFormat, uint64_t* out);
 void orc_rescale_tables(const orc_ctx*, uint32_t sizeQl, uint64_t* QlQlInvModqlDivqlModq, uint64_t* qlInvModq);
 
 /* ---------------- a17: ScaleAndRound family (dcrtpoly-impl.h:1470-1689) ----------------

@@ -233,6 +233,24 @@ void ref_drop_last_element_and_scale(uint32_t N, uint32_t sizeQl, const uint64_t
     export_poly(X, out);
 }
 
+// DCRTPoly::ModReduce with the tables CryptoParametersBGVRNS::PrecomputeCRTTables derives (bgvrns-cryptoparameters.cpp)
+void ref_mod_reduce(uint32_t N, uint32_t sizeQl, const uint64_t* q, const uint64_t* psi, const uint64_t* x, uint64_t t,
+                    int evalFormat, uint64_t* out) {
+    auto pq = make_params(N, sizeQl, q, psi);
+    auto X  = make_poly(pq, x, evalFormat ? Format::EVALUATION : Format::COEFFICIENT);
+    const NativeInteger T(t), ql(q[sizeQl - 1]);
+    std::vector<NativeInteger> tModqPrecon(sizeQl - 1), qlInvModq(sizeQl - 1), qlInvModqPrecon(sizeQl - 1);
+    for (uint32_t i = 0; i + 1 < sizeQl; ++i) {
+        const NativeInteger qi(q[i]);
+        tModqPrecon[i]     = T.PrepModMulConst(qi);
+        qlInvModq[i]       = ql.ModInverse(qi);
+        qlInvModqPrecon[i] = qlInvModq[i].PrepModMulConst(qi);
+    }
+    const NativeInteger negtInvModq = ql - T.ModInverse(ql);
+    X.ModReduce(T, tModqPrecon, negtInvModq, negtInvModq.PrepModMulConst(ql), qlInvModq, qlInvModqPrecon);
+    export_poly(X, out);
+}
+
 // ---- CKKS session: the reference's own context, keys, ciphertexts (config 3 shape) ----
 struct RefCkks {
     CryptoContext<DCRTPoly> cc;

@@ -101,6 +101,7 @@ def load_oracle():
     S("orc_scale_and_round", None, [P64, u32, u32, u32, C.c_int, P64, PF64, P64, P64, P64])
     S("orc_approx_scale_and_round", None, [P64, u32, u32, u32, P64, P64, P64, P64])
     S("orc_scale_and_round_p_over_q", None, [P64, u32, u32, P64, u64, P64, P64])
+    S("orc_mod_reduce", None, [vp, P64, u32, u64, C.c_int, P64])
     S("orc_behz_create", vp, [u32, u32, P64, u64])
     S("orc_behz_destroy", None, [vp])
     S("orc_behz_num_bsk", u32, [vp])
@@ -176,6 +177,7 @@ def load_ref():
     S("ref_scale_and_round", None, [u32, u32, u32, C.c_int, P64, P64, P64, P64, PF64, P64])
     S("ref_approx_scale_and_round", None, [u32, u32, u32, P64, P64, P64, P64, P64])
     S("ref_scale_and_round_p_over_q", None, [u32, u32, P64, P64, P64, P64, P64])
+    S("ref_mod_reduce", None, [u32, u32, P64, P64, P64, u64, C.c_int, P64])
     S("ref_bfv_create", vp, [u32, u64, u32, u32, C.c_int])
     S("ref_bfv_destroy", None, [vp])
     S("ref_bfv_info", None, [vp, P32])

@@ -202,6 +202,24 @@ def test_behz_against_live_reference(oracle, ref, ring, t, depth, sms):
     r.ref_bfv_destroy(h)
 
 
+@pytest.mark.parametrize("logN,sizeQl,t,ev", [(4, 3, 65537, 1), (6, 4, 786433, 0), (10, 3, 2, 1)])
+def test_mod_reduce_against_live_reference(oracle, ref, logN, sizeQl, t, ev):
+    """DCRTPoly::ModReduce (BGV modulus switch) of the reference vs the oracle"""
+    o, r = oracle, ref
+    rng = np.random.default_rng(77)
+    N = 1 << logN
+    q, psi = np.zeros(sizeQl, np.uint64), np.zeros(sizeQl, np.uint64)
+    o.orc_dcrt_params(2 * N, sizeQl, 55, q, psi)
+    x = libs.rand_tower(rng, q, N)
+    want = np.zeros((sizeQl - 1, N), np.uint64)
+    r.ref_mod_reduce(N, sizeQl, q, psi, x, t, ev, want)
+    octx = o.orc_ctx_create(N, sizeQl, q, psi)
+    got = np.zeros((sizeQl - 1, N), np.uint64)
+    o.orc_mod_reduce(octx, x, sizeQl, t, ev, got)
+    assert np.array_equal(got, want)
+    o.orc_ctx_destroy(octx)
+
+
 def ref_bfv_session(r, ring, t, depth, sms):
     """reference BFV/BEHZ context with two fresh ciphertexts and their EvalMultNoRelin product, exported as arrays"""
     h = r.ref_bfv_create(ring, t, depth, sms, 0)

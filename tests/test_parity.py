@@ -317,6 +317,25 @@ def test_rescale(backend, oracle):
         ctx.close()
 
 
+@pytest.mark.parametrize("logN,sizeQl,t,B,ev", [(4, 3, 65537, 2, 1), (10, 4, 786433, 2, 1), (12, 3, 65537, 1, 0), (13, 3, 2, 1, 1)])
+def test_mod_reduce(backend, oracle, logN, sizeQl, t, B, ev):
+    """fhe_mod_reduce (DCRTPoly::ModReduce, BGV modulus switching) vs the oracle"""
+    o = oracle
+    rng = np.random.default_rng(31)
+    N = 1 << logN
+    q, psi = params(o, logN, sizeQl)
+    ctx = fh.Context(backend, logN, q, psi)
+    octx = o.orc_ctx_create(N, sizeQl, q, psi)
+    x = libs.rand_tower(rng, q, N, B)
+    want = np.zeros((B, sizeQl - 1, N), np.uint64)
+    for b in range(B):
+        o.orc_mod_reduce(octx, x[b], sizeQl, t, ev, want[b])
+    got = fh.mod_reduce(ctx, ctx.tower(x, fmt=fh.EVALUATION if ev else fh.COEFFICIENT), t)
+    assert np.array_equal(got.to_host(), want)
+    o.orc_ctx_destroy(octx)
+    ctx.close()
+
+
 @pytest.mark.parametrize("logN,sizeQ,dnum,sizeQl,B", [(10, 4, 2, 3, 2), (12, 6, 3, 6, 1)])
 def test_hoisted_rotations(backend, oracle, logN, sizeQ, dnum, sizeQl, B):
     """EvalAutomorphism and EvalFastRotation (one ModUp, several rotation keys) against the oracle"""
