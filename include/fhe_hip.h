@@ -141,6 +141,23 @@ fhe_status fhe_approx_switch_basis(fhe_conv* conv, const uint64_t* in, uint32_t 
                                    uint64_t* out, uint32_t outStride, uint32_t outFirst, uint32_t batch, void* stream);
 fhe_status fhe_switch_basis_exact(fhe_conv* conv, const uint64_t* in, uint32_t inStride, uint32_t inFirst,
                                   uint64_t* out, uint32_t outStride, uint32_t outFirst, uint32_t batch, void* stream);
+/* Plan with the CALLER's tables, laid out as the reference passes them to ApproxSwitchCRTBasis / SwitchCRTBasis
+ * (dcrtpoly-impl.h:888-932, 1008-1085): QHatInvModq[nSrc], QHatModp[nSrc][nDst]; for the exact variant additionally
+ * alphaQModp[nSrc+1][nDst] and qInv[nSrc] (doubles), else both NULL.  Needed where the tables are not the plain CRT
+ * ones, e.g. FastExpandCRTBasisPloverQ's mPlQHatInvModq / qInvModp. */
+fhe_status fhe_conv_create_custom(fhe_ctx* ctx, const uint32_t* srcLimbIdx, uint32_t nSrc, const uint32_t* dstLimbIdx,
+                                  uint32_t nDst, const uint64_t* hatInv, const uint64_t* hatMod, const uint64_t* alphaMod,
+                                  const double* qInv, fhe_conv** out);
+/* DCRTPolyImpl::ExpandCRTBasis / ExpandCRTBasisReverseOrder (dcrtpoly-impl.h:1088-1148): x [batch][nSrc][N] over the plan's
+ * source basis Q in format inEval -> out [batch][nSrc+nDst][N] over Q u P in resultEval (reverseOrder: P rows first).
+ * ws (fhe_expand_crt_basis_workspace_bytes) is only needed for EVALUATION input. */
+size_t     fhe_expand_crt_basis_workspace_bytes(const fhe_conv* plan, uint32_t batch);
+fhe_status fhe_expand_crt_basis(fhe_conv* plan, const uint64_t* x, int inEval, uint64_t* out, int resultEval,
+                                int reverseOrder, uint32_t batch, void* ws, size_t wsBytes, void* stream);
+/* DCRTPolyImpl::FastExpandCRTBasisPloverQ (dcrtpoly-impl.h:1151-1164), COEFFICIENT format: toPl = custom-table plan
+ * Q -> Pl (mPlQHatInvModq, qInvModp), toQl = plan Pl -> Ql; x [batch][nQ][N] -> out [batch][nQl+nPl][N] = [Ql | Pl]. */
+fhe_status fhe_fast_expand_crt_basis_p_over_q(fhe_conv* toPl, fhe_conv* toQl, const uint64_t* x, uint64_t* out,
+                                              uint32_t batch, void* stream);
 
 /* ---- a11..a14: HYBRID key switching -----------------------------------------------------------------
  * The context must hold the Q limbs [0,sizeQ) followed by the P limbs [sizeQ, sizeQ+sizeP).

@@ -909,6 +909,7 @@ extern "C" fhe_status fhe_switch_modulus(fhe_ctx* c, uint64_t* out, const uint32
 struct fhe_conv {
     fhe_ctx* ctx;
     uint32_t nSrc, nDst;
+    std::vector<uint32_t> srcIdx, dstIdx;  // context limbs of the two bases (empty for internal plans)
     ConvTables tb;
     std::vector<void*> owned;
 };
@@ -924,36 +925,36 @@ static fhe_status conv_upload(fhe_conv* cv, const void* h, size_t bytes, const v
 }
 
 static uint32_t conv_nsrc_pad(uint32_t nSrc) { return nSrc <= 8 ? 8u : nSrc <= 16 ? 16u : 32u; }
-// tables for converting from moduli src[] to dst[]   (rns-cryptoparameters.cpp:214-246, 297-349)
-static fhe_status conv_build(fhe_ctx* c, const std::vector<uint64_t>& src, const std::vector<uint64_t>& dst,
-                             fhe_conv** out) {
+// device plan from explicit tables: hatInv[i] (multiplier of source residue i, mod src_i), hatMod[i*nDst + j] (weight of
+// y_i in target j, mod dst_j), alphaMod[a*nDst + j] / qInv[i] for the exact variant (may be null: approximate only).
+// Table rows are padded to the NSRC of the kernel instantiation conv_run picks, so that the kernel's table reads are
+// unconditional (basis_kernels.h).
+static fhe_status conv_from_tables(fhe_ctx* c, const std::vector<uint64_t>& src, const std::vector<uint64_t>& dst,
+                                   const uint64_t* hatInvIn, const uint64_t* hatModIn, const uint64_t* alphaIn,
+                                   const double* qInvIn, fhe_conv** out) {
     const uint32_t nSrc = (uint32_t)src.size(), nDst = (uint32_t)dst.size();
     fhe_conv* cv = new fhe_conv;
     cv->ctx      = c;
     cv->nSrc     = nSrc;
     cv->nDst     = nDst;
-    // table rows are padded to the NSRC of the kernel instantiation conv_run picks, so that the kernel's table
-    // reads are unconditional (basis_kernels.h)
     const uint32_t pad = conv_nsrc_pad(nSrc);
     std::vector<TwPair> hatInv(32, TwPair{0, 0});
-    std::vector<uint64_t> hatMod((size_t)pad * nDst, 0), mu(2 * (size_t)nDst), alphaMod((size_t)(nSrc + 1) * nDst);
+    std::vector<uint64_t> hatMod((size_t)pad * nDst, 0), mu(2 * (size_t)nDst), alphaMod((size_t)(nSrc + 1) * nDst, 0);
     std::vector<uint64_t> srcPad(32, 1);
     std::vector<double> qInv(32, 0.0);
     for (uint32_t i = 0; i < nSrc; ++i) {
-        const uint64_t hat = host::prod_mod(src, (int)i, src[i]);
-        const uint64_t inv = host::invmod(hat, src[i]);
+        const uint64_t inv = hatInvIn[i] % src[i];
         hatInv[i]          = TwPair{inv, host::shoup(inv, src[i])};
-        qInv[i]            = 1.0 / static_cast<double>(src[i]);
+        qInv[i]            = qInvIn ? qInvIn[i] : 1.0 / static_cast<double>(src[i]);
         srcPad[i]          = src[i];
         for (uint32_t j = 0; j < nDst; ++j)
-            hatMod[(size_t)j * pad + i] = host::prod_mod(src, (int)i, dst[j]);
+            hatMod[(size_t)j * pad + i] = hatModIn[(size_t)i * nDst + j] % dst[j];
     }
-    for (uint32_t j = 0; j < nDst; ++j) {
+    for (uint32_t j = 0; j < nDst; ++j)
         host::mu128(dst[j], &mu[2 * j]);
-        const uint64_t Qmod = host::prod_mod(src, -1, dst[j]);
-        for (uint32_t a = 0; a <= nSrc; ++a)
-            alphaMod[(size_t)a * nDst + j] = host::mulmod(a % dst[j], Qmod, dst[j]);
-    }
+    if (alphaIn)
+        for (size_t k = 0; k < alphaMod.size(); ++k)
+            alphaMod[k] = alphaIn[k] % dst[k % nDst];
     fhe_status s;
     if ((s = conv_upload(cv, hatInv.data(), hatInv.size() * sizeof(TwPair), (const void**)&cv->tb.hatInv)) ||
         (s = conv_upload(cv, hatMod.data(), hatMod.size() * 8, (const void**)&cv->tb.hatMod)) ||
@@ -967,6 +968,32 @@ static fhe_status conv_build(fhe_ctx* c, const std::vector<uint64_t>& src, const
     }
     *out = cv;
     return FHE_OK;
+}
+// tables for converting from moduli src[] to dst[]   (rns-cryptoparameters.cpp:214-246, 297-349); srcScale[i] (mod
+// src_i) and dstScale[j] (mod dst_j), when given, are folded into the two constant sets: the plan then computes
+// dstScale_j * SwitchBasis(srcScale_i * x_i) — exact as residues, used for the BGV t factors of ApproxModDown
+static fhe_status conv_build(fhe_ctx* c, const std::vector<uint64_t>& src, const std::vector<uint64_t>& dst, fhe_conv** out,
+                             const uint64_t* srcScale = nullptr, const uint64_t* dstScale = nullptr) {
+    const uint32_t nSrc = (uint32_t)src.size(), nDst = (uint32_t)dst.size();
+    std::vector<uint64_t> hatInv(nSrc), hatMod((size_t)nSrc * nDst), alphaMod((size_t)(nSrc + 1) * nDst);
+    for (uint32_t i = 0; i < nSrc; ++i) {
+        const uint64_t hat = host::prod_mod(src, (int)i, src[i]);
+        hatInv[i]          = host::invmod(hat, src[i]);
+        if (srcScale)
+            hatInv[i] = host::mulmod(hatInv[i], srcScale[i] % src[i], src[i]);
+        for (uint32_t j = 0; j < nDst; ++j) {
+            uint64_t v = host::prod_mod(src, (int)i, dst[j]);
+            if (dstScale)
+                v = host::mulmod(v, dstScale[j] % dst[j], dst[j]);
+            hatMod[(size_t)i * nDst + j] = v;
+        }
+    }
+    for (uint32_t j = 0; j < nDst; ++j) {
+        const uint64_t Qmod = host::prod_mod(src, -1, dst[j]);
+        for (uint32_t a = 0; a <= nSrc; ++a)
+            alphaMod[(size_t)a * nDst + j] = host::mulmod(a % dst[j], Qmod, dst[j]);
+    }
+    return conv_from_tables(c, src, dst, hatInv.data(), hatMod.data(), alphaMod.data(), nullptr, out);
 }
 
 extern "C" fhe_status fhe_conv_create(fhe_ctx* c, const uint32_t* srcIdx, uint32_t nSrc, const uint32_t* dstIdx,
@@ -983,7 +1010,37 @@ extern "C" fhe_status fhe_conv_create(fhe_ctx* c, const uint32_t* srcIdx, uint32
         dst[j] = c->q[dstIdx[j]];
     }
     RT_CHECK(rt::set_device(c->device));
-    return conv_build(c, src, dst, out);
+    if (fhe_status s = conv_build(c, src, dst, out))
+        return s;
+    (*out)->srcIdx.assign(srcIdx, srcIdx + nSrc);
+    (*out)->dstIdx.assign(dstIdx, dstIdx + nDst);
+    return FHE_OK;
+}
+// conversion plan with the CALLER's tables, laid out as the reference passes them to ApproxSwitchCRTBasis /
+// SwitchCRTBasis (dcrtpoly-impl.h:888-932, 1008-1085): QHatInvModq[nSrc], QHatModp[nSrc][nDst]; for the exact variant
+// alphaQModp[nSrc+1][nDst] and qInv[nSrc] (doubles), else null.  Needed where the tables are not the plain CRT ones,
+// e.g. FastExpandCRTBasisPloverQ's mPlQHatInvModq / qInvModp (bfvrns-cryptoparameters.cpp).
+extern "C" fhe_status fhe_conv_create_custom(fhe_ctx* c, const uint32_t* srcIdx, uint32_t nSrc, const uint32_t* dstIdx,
+                                             uint32_t nDst, const uint64_t* hatInv, const uint64_t* hatMod,
+                                             const uint64_t* alphaMod, const double* qInv, fhe_conv** out) {
+    ARG_CHECK(c && srcIdx && dstIdx && hatInv && hatMod && out, "fhe_conv_create_custom: null argument");
+    ARG_CHECK(nSrc >= 1 && nSrc <= 32 && nDst >= 1 && nDst <= (uint32_t)kMaxLimbs, "fhe_conv_create_custom: bad basis size");
+    ARG_CHECK((alphaMod == nullptr) == (qInv == nullptr), "fhe_conv_create_custom: alphaMod and qInv go together");
+    std::vector<uint64_t> src(nSrc), dst(nDst);
+    for (uint32_t i = 0; i < nSrc; ++i) {
+        ARG_CHECK(srcIdx[i] < c->L, "fhe_conv_create_custom: source limb exceeds context size");
+        src[i] = c->q[srcIdx[i]];
+    }
+    for (uint32_t j = 0; j < nDst; ++j) {
+        ARG_CHECK(dstIdx[j] < c->L, "fhe_conv_create_custom: target limb exceeds context size");
+        dst[j] = c->q[dstIdx[j]];
+    }
+    RT_CHECK(rt::set_device(c->device));
+    if (fhe_status s = conv_from_tables(c, src, dst, hatInv, hatMod, alphaMod, qInv, out))
+        return s;
+    (*out)->srcIdx.assign(srcIdx, srcIdx + nSrc);
+    (*out)->dstIdx.assign(dstIdx, dstIdx + nDst);
+    return FHE_OK;
 }
 extern "C" void fhe_conv_destroy(fhe_conv* cv) {
     if (!cv)
@@ -1023,6 +1080,54 @@ extern "C" fhe_status fhe_approx_switch_basis(fhe_conv* cv, const uint64_t* in, 
 extern "C" fhe_status fhe_switch_basis_exact(fhe_conv* cv, const uint64_t* in, uint32_t is, uint32_t ifst,
                                              uint64_t* out, uint32_t os, uint32_t ofst, uint32_t b, void* st) {
     return conv_run<true>(cv, in, is, ifst, out, os, ofst, b, st);
+}
+
+// DCRTPolyImpl::ExpandCRTBasis / ExpandCRTBasisReverseOrder (dcrtpoly-impl.h:1088-1148): x over the plan's source basis Q
+// (format inEval) -> out over Q u P in resultEval, P = SwitchCRTBasis of the coefficient form; reverse: P rows first.
+extern "C" size_t fhe_expand_crt_basis_workspace_bytes(const fhe_conv* cv, uint32_t batch) {
+    return cv ? (((size_t)batch * cv->nSrc) << cv->ctx->logN) * 8 : 0;
+}
+extern "C" fhe_status fhe_expand_crt_basis(fhe_conv* cv, const uint64_t* x, int inEval, uint64_t* out, int resultEval,
+                                           int reverseOrder, uint32_t batch, void* ws, size_t wsBytes, void* st) {
+    ARG_CHECK(cv && x && out && batch >= 1, "fhe_expand_crt_basis: bad argument");
+    ARG_CHECK(!cv->srcIdx.empty(), "fhe_expand_crt_basis: the plan must come from fhe_conv_create[_custom]");
+    fhe_ctx* c = cv->ctx;
+    RT_CHECK(rt::set_device(c->device));
+    const uint32_t nQ = cv->nSrc, nP = cv->nDst, tot = nQ + nP;
+    const uint32_t qFirst = reverseOrder ? nP : 0, pFirst = reverseOrder ? 0 : nQ;
+    const size_t rowB = (size_t)8 << c->logN;
+    const uint64_t* coef = x;  // coefficient form of the Q part
+    if (inEval) {              // :1096-1099
+        ARG_CHECK(ws && wsBytes >= fhe_expand_crt_basis_workspace_bytes(cv, batch), "fhe_expand_crt_basis: workspace too small");
+        if (fhe_status s = ntt_run(c, true, x, (uint64_t*)ws, cv->srcIdx.data(), nQ, batch, st))
+            return s;
+        coef = (const uint64_t*)ws;
+    }
+    if (fhe_status s = conv_run<true>(cv, coef, nQ, 0, out, tot, pFirst, batch, st))  // :1101-1102
+        return s;
+    // Q rows of the result: the stored EVALUATION copy when it can be reused (:1104-1105), else the coefficient form
+    const uint64_t* qsrc = (resultEval && inEval) ? x : coef;
+    uint64_t* qdst       = out + ((size_t)qFirst << c->logN);
+    RT_CHECK(rt::d2d_2d(qdst, tot * rowB, qsrc, nQ * rowB, nQ * rowB, batch, (rt::stream_t)st));
+    if (resultEval) {  // :1112-1114
+        if (!inEval)
+            if (fhe_status s = ntt_run(c, false, out, out, cv->srcIdx.data(), nQ, batch, st, tot, qFirst, tot, qFirst))
+                return s;
+        return ntt_run(c, false, out, out, cv->dstIdx.data(), nP, batch, st, tot, pFirst, tot, pFirst);
+    }
+    return FHE_OK;
+}
+// DCRTPolyImpl::FastExpandCRTBasisPloverQ (dcrtpoly-impl.h:1151-1164), COEFFICIENT format: partPl =
+// ApproxSwitchCRTBasis(x; toPl) with the caller's mPlQHatInvModq / qInvModp tables (fhe_conv_create_custom), partQl =
+// SwitchCRTBasis(partPl; toQl); out = [Ql rows | Pl rows].
+extern "C" fhe_status fhe_fast_expand_crt_basis_p_over_q(fhe_conv* toPl, fhe_conv* toQl, const uint64_t* x, uint64_t* out,
+                                                         uint32_t batch, void* st) {
+    ARG_CHECK(toPl && toQl && x && out && batch >= 1, "fhe_fast_expand_crt_basis_p_over_q: bad argument");
+    ARG_CHECK(toQl->nSrc == toPl->nDst, "fhe_fast_expand_crt_basis_p_over_q: the second plan must start from the first plan's target basis");
+    const uint32_t nQl = toQl->nDst, nPl = toPl->nDst, tot = nQl + nPl;
+    if (fhe_status s = conv_run<false>(toPl, x, toPl->nSrc, 0, out, tot, nQl, batch, st))
+        return s;
+    return conv_run<true>(toQl, out, tot, nQl, out, tot, 0, batch, st);
 }
 
 // ------------------------------------------------------------------------------------------------

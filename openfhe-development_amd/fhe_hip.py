@@ -80,6 +80,10 @@ class Lib:
         S("fhe_conv_destroy", None, [vp])
         S("fhe_approx_switch_basis", C.c_int, [vp, vp, u32, u32, vp, u32, u32, u32, vp])
         S("fhe_switch_basis_exact", C.c_int, [vp, vp, u32, u32, vp, u32, u32, u32, vp])
+        S("fhe_conv_create_custom", C.c_int, [vp, u32p, u32, u32p, u32, u64p, u64p, u64p, C.POINTER(C.c_double), C.POINTER(vp)])
+        S("fhe_expand_crt_basis_workspace_bytes", C.c_size_t, [vp, u32])
+        S("fhe_expand_crt_basis", C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, u32, vp, C.c_size_t, vp])
+        S("fhe_fast_expand_crt_basis_p_over_q", C.c_int, [vp, vp, vp, vp, u32, vp])
         S("fhe_ks_plan_create", C.c_int, [vp, u32, u32, u32, C.POINTER(vp)])
         S("fhe_ks_plan_destroy", None, [vp])
         S("fhe_ks_plan_alpha", u32, [vp])
@@ -299,13 +303,29 @@ class Tower:
 class Conv:
     """CRT basis conversion plan (ApproxSwitchCRTBasis / SwitchCRTBasis)."""
 
-    def __init__(self, ctx, src_idx, dst_idx):
+    def __init__(self, ctx, src_idx, dst_idx, hat_inv=None, hat_mod=None, alpha_mod=None, q_inv=None):
+        """default: the plain CRT tables of (src basis, dst basis); with hat_inv[nSrc] / hat_mod[nSrc][nDst]
+        (+ alpha_mod[nSrc+1][nDst], q_inv[nSrc] for the exact variant) the caller's tables (fhe_conv_create_custom)"""
         self.ctx = ctx
         self.src = np.ascontiguousarray(np.asarray(src_idx, dtype=np.uint32))
         self.dst = np.ascontiguousarray(np.asarray(dst_idx, dtype=np.uint32))
         h = vp()
-        ctx.lib.check(ctx.lib.L.fhe_conv_create(ctx.h, self.src.ctypes.data_as(u32p), len(self.src),
-                                                self.dst.ctypes.data_as(u32p), len(self.dst), C.byref(h)))
+        if hat_inv is None:
+            ctx.lib.check(ctx.lib.L.fhe_conv_create(ctx.h, self.src.ctypes.data_as(u32p), len(self.src),
+                                                    self.dst.ctypes.data_as(u32p), len(self.dst), C.byref(h)))
+        else:
+            hi = np.ascontiguousarray(hat_inv, dtype=np.uint64)
+            hm = np.ascontiguousarray(hat_mod, dtype=np.uint64)
+            assert hm.shape == (len(self.src), len(self.dst))
+            al = qi = None
+            if alpha_mod is not None:
+                al_a = np.ascontiguousarray(alpha_mod, dtype=np.uint64)
+                qi_a = np.ascontiguousarray(q_inv, dtype=np.float64)
+                al, qi = al_a.ctypes.data_as(u64p), qi_a.ctypes.data_as(C.POINTER(C.c_double))
+            ctx.lib.check(ctx.lib.L.fhe_conv_create_custom(ctx.h, self.src.ctypes.data_as(u32p), len(self.src),
+                                                           self.dst.ctypes.data_as(u32p), len(self.dst),
+                                                           hi.ctypes.data_as(u64p), hm.ctypes.data_as(u64p), al, qi,
+                                                           C.byref(h)))
         self.h = h
 
     def close(self):
@@ -318,6 +338,29 @@ class Conv:
         out = self.ctx.empty(tin.batch, len(self.dst), self.dst, COEFFICIENT)
         f = self.ctx.lib.L.fhe_switch_basis_exact if exact else self.ctx.lib.L.fhe_approx_switch_basis
         self.ctx.lib.check(f(self.h, tin.ptr, tin.n_limbs, 0, out.ptr, len(self.dst), 0, tin.batch, stream))
+        return out
+
+    def ExpandCRTBasis(self, tin, result_format, reverse=False, stream=None):
+        """DCRTPoly::ExpandCRTBasis[ReverseOrder] (dcrtpoly-impl.h:1088-1148): tower over the source basis -> Q u P"""
+        idx = np.concatenate([self.dst, self.src]) if reverse else np.concatenate([self.src, self.dst])
+        out = self.ctx.empty(tin.batch, len(idx), idx, result_format)
+        L = self.ctx.lib.L
+        wsb = L.fhe_expand_crt_basis_workspace_bytes(self.h, tin.batch)
+        ws = self.ctx.malloc(wsb)
+        try:
+            self.ctx.lib.check(L.fhe_expand_crt_basis(self.h, tin.ptr, 1 if tin.fmt == EVALUATION else 0, out.ptr,
+                                                      1 if result_format == EVALUATION else 0, 1 if reverse else 0,
+                                                      tin.batch, ws, wsb, stream))
+            self.ctx.sync(stream)
+        finally:
+            self.ctx.free(ws)
+        return out
+
+    def FastExpandCRTBasisPloverQ(self, to_ql, tin, stream=None):
+        """self = custom-table plan Q -> Pl, to_ql = plan Pl -> Ql (dcrtpoly-impl.h:1151-1164); COEFFICIENT towers"""
+        idx = np.concatenate([to_ql.dst, self.dst])
+        out = self.ctx.empty(tin.batch, len(idx), idx, COEFFICIENT)
+        self.ctx.lib.check(self.ctx.lib.L.fhe_fast_expand_crt_basis_p_over_q(self.h, to_ql.h, tin.ptr, out.ptr, tin.batch, stream))
         return out
 
 

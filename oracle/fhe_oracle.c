@@ -1455,3 +1455,50 @@ void orc_bfv_eval_mult_behz(const orc_behz* h, const orc_ctx* ctxAll, const uint
         free(ext[e]);
     free(tmp), free(coef), free(idxBsk);
 }
+
+/* DCRTPolyImpl::ExpandCRTBasis / ExpandCRTBasisReverseOrder (dcrtpoly-impl.h:1088-1148).  ctxQP: limbs 0..nQ-1 = Q,
+ * nQ.. = P.  x [nQ][N] in `inEval`; out [(nQ+nP)][N] in `resultEval`, Q rows first (reverse: P rows first).  Tables as
+ * for orc_switch_crt_basis. */
+void orc_expand_crt_basis(const orc_ctx* ctxQP, uint32_t nQ, uint32_t nP, const uint64_t* x, int inEval,
+                          const uint64_t* QHatInvModq, const uint64_t* QHatInvModqPrecon, const uint64_t* QHatModp_pq,
+                          const uint64_t* alphaQModp, const uint64_t* muP128, const double* qInv, int resultEval,
+                          int reverse, uint64_t* out) {
+    const uint32_t N = ctxQP->N;
+    const size_t qw = (size_t)nQ * N, pw = (size_t)nP * N;
+    uint64_t* coef = (uint64_t*)malloc(8 * qw);
+    memcpy(coef, x, 8 * qw);
+    if (inEval)
+        for (uint32_t i = 0; i < nQ; ++i)
+            ctx_inv(ctxQP, coef + (size_t)i * N, i);
+    uint64_t* partP = (uint64_t*)malloc(8 * pw);
+    orc_switch_crt_basis(coef, nQ, N, ctxQP->q, QHatInvModq, QHatInvModqPrecon, QHatModp_pq, alphaQModp, nP, ctxQP->q + nQ,
+                         muP128, qInv, partP);
+    uint64_t* qpart = reverse ? out + pw : out;
+    uint64_t* ppart = reverse ? out : out + qw;
+    memcpy(qpart, (resultEval && inEval) ? x : coef, 8 * qw); /* :1104-1105 */
+    memcpy(ppart, partP, 8 * pw);
+    if (resultEval) {
+        if (!inEval)
+            for (uint32_t i = 0; i < nQ; ++i)
+                ctx_fwd(ctxQP, qpart + (size_t)i * N, i);
+        for (uint32_t j = 0; j < nP; ++j)
+            ctx_fwd(ctxQP, ppart + (size_t)j * N, nQ + j);
+    }
+    free(coef);
+    free(partP);
+}
+
+/* DCRTPolyImpl::FastExpandCRTBasisPloverQ (dcrtpoly-impl.h:1151-1164), COEFFICIENT: x [nQ][N] over Q ->
+ * out [(nQl+nPl)][N] = [Ql | Pl]; tables named as in CRTBasisExtensionPrecomputations. */
+void orc_fast_expand_crt_basis_p_over_q(const uint64_t* x, uint32_t nQ, uint32_t N, const uint64_t* q,
+                                        const uint64_t* mPlQHatInvModq, const uint64_t* mPlQHatInvModqPrecon,
+                                        const uint64_t* qInvModp /*[nQ][nPl]*/, uint32_t nPl, const uint64_t* pl,
+                                        const uint64_t* muPl128, const uint64_t* PlHatInvModp, const uint64_t* PlHatInvModpPrecon,
+                                        const uint64_t* PlHatModq_qp /*[nQl][nPl]*/, const uint64_t* alphaPlModq /*[nPl+1][nQl]*/,
+                                        uint32_t nQl, const uint64_t* ql, const uint64_t* muQl128, const double* pInv,
+                                        uint64_t* out) {
+    uint64_t* partPl = out + (size_t)nQl * N;
+    orc_approx_switch_crt_basis(x, nQ, N, q, mPlQHatInvModq, mPlQHatInvModqPrecon, qInvModp, nPl, pl, muPl128, partPl);
+    orc_switch_crt_basis(partPl, nPl, N, pl, PlHatInvModp, PlHatInvModpPrecon, PlHatModq_qp, alphaPlModq, nQl, ql, muQl128,
+                         pInv, out);
+}

@@ -104,6 +104,17 @@ void orc_switch_crt_basis(const uint64_t* x, uint32_t sizeQ, uint32_t N, const u
                           const uint64_t* p, const uint64_t* mu128, const double* qInv, uint64_t* out);
 
 /* ---------------- HYBRID key-switch tables (rns-cryptoparameters.cpp:80-350) ---------------- */
+/* DCRTPolyImpl::ExpandCRTBasis[ReverseOrder] (dcrtpoly-impl.h:1088-1148) and FastExpandCRTBasisPloverQ (:1151-1164) */
+void orc_expand_crt_basis(const orc_ctx* ctxQP, uint32_t nQ, uint32_t nP, const uint64_t* x, int inEval,
+                          const uint64_t* QHatInvModq, const uint64_t* QHatInvModqPrecon, const uint64_t* QHatModp_pq,
+                          const uint64_t* alphaQModp, const uint64_t* muP128, const double* qInv, int resultEval,
+                          int reverse, uint64_t* out);
+void orc_fast_expand_crt_basis_p_over_q(const uint64_t* x, uint32_t nQ, uint32_t N, const uint64_t* q,
+                                        const uint64_t* mPlQHatInvModq, const uint64_t* mPlQHatInvModqPrecon,
+                                        const uint64_t* qInvModp, uint32_t nPl, const uint64_t* pl, const uint64_t* muPl128,
+                                        const uint64_t* PlHatInvModp, const uint64_t* PlHatInvModpPrecon,
+                                        const uint64_t* PlHatModq_qp, const uint64_t* alphaPlModq, uint32_t nQl,
+                                        const uint64_t* ql, const uint64_t* muQl128, const double* pInv, uint64_t* out);
 typedef struct orc_hybrid orc_hybrid;
 /* Q tower (sizeQ limbs) + P tower (sizeP limbs) given explicitly; numPartQ = dnum. */
 orc_hybrid* orc_hybrid_create(uint32_t N, uint32_t sizeQ, const uint64_t* q, const uint64_t* psiQ,

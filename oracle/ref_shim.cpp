@@ -224,6 +224,68 @@ void ref_switch_crt_basis(uint32_t N, uint32_t sizeQ, const uint64_t* q, const u
     auto r = X.SwitchCRTBasis(pp, hi, precon(hi, q), hm, al, mu128(p, sizeP), qi);
     export_poly(r, out);
 }
+// ExpandCRTBasis / ExpandCRTBasisReverseOrder with caller tables (same layouts as ref_switch_crt_basis); out [(nQ+nP)][N]
+void ref_expand_crt_basis(uint32_t N, uint32_t sizeQ, const uint64_t* q, const uint64_t* psiQ, const uint64_t* x, int inEval,
+                          const uint64_t* QHatInvModq, const uint64_t* QHatModp_pq, const uint64_t* alphaQModp, uint32_t sizeP,
+                          const uint64_t* p, const uint64_t* psiP, const double* qInv, int resultEval, int reverse,
+                          uint64_t* out) {
+    auto pq = make_params(N, sizeQ, q, psiQ);
+    auto pp = make_params(N, sizeP, p, psiP);
+    std::vector<uint64_t> all(sizeQ + sizeP), allPsi(sizeQ + sizeP);
+    for (uint32_t i = 0; i < sizeQ + sizeP; ++i) {
+        const bool fromQ = reverse ? i >= sizeP : i < sizeQ;
+        const uint32_t k = reverse ? (fromQ ? i - sizeP : i) : (fromQ ? i : i - sizeQ);
+        all[i]    = fromQ ? q[k] : p[k];
+        allPsi[i] = fromQ ? psiQ[k] : psiP[k];
+    }
+    auto pqp = make_params(N, sizeQ + sizeP, all.data(), allPsi.data());
+    auto X   = make_poly(pq, x, inEval ? Format::EVALUATION : Format::COEFFICIENT);
+    auto hi  = vecNI(QHatInvModq, sizeQ);
+    std::vector<std::vector<NativeInteger>> hm(sizeP), al(sizeQ + 1);
+    for (uint32_t j = 0; j < sizeP; ++j)
+        hm[j] = vecNI(QHatModp_pq + (size_t)j * sizeQ, sizeQ);
+    for (uint32_t a = 0; a <= sizeQ; ++a)
+        al[a] = vecNI(alphaQModp + (size_t)a * sizeP, sizeP);
+    std::vector<double> qi(qInv, qInv + sizeQ);
+    const Format rf = resultEval ? Format::EVALUATION : Format::COEFFICIENT;
+    if (reverse)
+        X.ExpandCRTBasisReverseOrder(pqp, pp, hi, precon(hi, q), hm, al, mu128(p, sizeP), qi, rf);
+    else
+        X.ExpandCRTBasis(pqp, pp, hi, precon(hi, q), hm, al, mu128(p, sizeP), qi, rf);
+    export_poly(X, out);
+}
+// FastExpandCRTBasisPloverQ (COEFFICIENT): qInvModp [sizeQ][sizePl]; PlHatModq_qp [sizeQl][sizePl]; alphaPlModq
+// [sizePl+1][sizeQl]; out [(sizeQl+sizePl)][N]
+void ref_fast_expand_crt_basis_p_over_q(uint32_t N, uint32_t sizeQ, const uint64_t* q, const uint64_t* psiQ, const uint64_t* x,
+                                        const uint64_t* mPlQHatInvModq, const uint64_t* qInvModp, uint32_t sizePl,
+                                        const uint64_t* pl, const uint64_t* psiPl, const uint64_t* PlHatInvModp,
+                                        const uint64_t* PlHatModq_qp, const uint64_t* alphaPlModq, uint32_t sizeQl,
+                                        const uint64_t* ql, const uint64_t* psiQl, const double* pInv, uint64_t* out) {
+    auto pq  = make_params(N, sizeQ, q, psiQ);
+    auto ppl = make_params(N, sizePl, pl, psiPl);
+    auto pql = make_params(N, sizeQl, ql, psiQl);
+    std::vector<uint64_t> all(sizeQl + sizePl), allPsi(sizeQl + sizePl);
+    for (uint32_t i = 0; i < sizeQl + sizePl; ++i) {
+        all[i]    = i < sizeQl ? ql[i] : pl[i - sizeQl];
+        allPsi[i] = i < sizeQl ? psiQl[i] : psiPl[i - sizeQl];
+    }
+    auto pqlpl = make_params(N, sizeQl + sizePl, all.data(), allPsi.data());
+    auto X     = make_poly(pq, x, Format::COEFFICIENT);
+    auto m1    = vecNI(mPlQHatInvModq, sizeQ);
+    std::vector<std::vector<NativeInteger>> qinvp(sizeQ), hm(sizeQl), al(sizePl + 1);
+    for (uint32_t i = 0; i < sizeQ; ++i)
+        qinvp[i] = vecNI(qInvModp + (size_t)i * sizePl, sizePl);
+    for (uint32_t i = 0; i < sizeQl; ++i)
+        hm[i] = vecNI(PlHatModq_qp + (size_t)i * sizePl, sizePl);
+    for (uint32_t a = 0; a <= sizePl; ++a)
+        al[a] = vecNI(alphaPlModq + (size_t)a * sizeQl, sizeQl);
+    auto hi2 = vecNI(PlHatInvModp, sizePl);
+    std::vector<double> pi(pInv, pInv + sizePl);
+    DCRTPoly::CRTBasisExtensionPrecomputations pre(pqlpl, ppl, pql, m1, precon(m1, q), qinvp, mu128(pl, sizePl), hi2,
+                                                   precon(hi2, pl), hm, al, mu128(ql, sizeQl), pi);
+    X.FastExpandCRTBasisPloverQ(pre);
+    export_poly(X, out);
+}
 // DropLastElementAndScale with caller tables (EVAL in/out)
 void ref_drop_last_element_and_scale(uint32_t N, uint32_t sizeQl, const uint64_t* q, const uint64_t* psi,
                                      const uint64_t* x, const uint64_t* tabA, const uint64_t* tabB, uint64_t* out) {

@@ -102,6 +102,9 @@ def load_oracle():
     S("orc_approx_scale_and_round", None, [P64, u32, u32, u32, P64, P64, P64, P64])
     S("orc_scale_and_round_p_over_q", None, [P64, u32, u32, P64, u64, P64, P64])
     S("orc_mod_reduce", None, [vp, P64, u32, u64, C.c_int, P64])
+    S("orc_expand_crt_basis", None, [vp, u32, u32, P64, C.c_int, P64, P64, P64, P64, P64, PF64, C.c_int, C.c_int, P64])
+    S("orc_fast_expand_crt_basis_p_over_q", None, [P64, u32, u32, P64, P64, P64, P64, u32, P64, P64, P64, P64, P64, P64, u32,
+                                                   P64, P64, PF64, P64])
     S("orc_behz_create", vp, [u32, u32, P64, u64])
     S("orc_behz_destroy", None, [vp])
     S("orc_behz_num_bsk", u32, [vp])
@@ -178,6 +181,9 @@ def load_ref():
     S("ref_approx_scale_and_round", None, [u32, u32, u32, P64, P64, P64, P64, P64])
     S("ref_scale_and_round_p_over_q", None, [u32, u32, P64, P64, P64, P64, P64])
     S("ref_mod_reduce", None, [u32, u32, P64, P64, P64, u64, C.c_int, P64])
+    S("ref_expand_crt_basis", None, [u32, u32, P64, P64, P64, C.c_int, P64, P64, P64, u32, P64, P64, PF64, C.c_int, C.c_int, P64])
+    S("ref_fast_expand_crt_basis_p_over_q", None, [u32, u32, P64, P64, P64, P64, P64, u32, P64, P64, P64, P64, P64, u32, P64,
+                                                   P64, PF64, P64])
     S("ref_bfv_create", vp, [u32, u64, u32, u32, C.c_int])
     S("ref_bfv_destroy", None, [vp])
     S("ref_bfv_info", None, [vp, P32])
@@ -207,3 +213,34 @@ def rand_tower(rng, qs, N, batch=None):
     for i, q in enumerate(qs):
         out[..., i, :] = rng.integers(0, int(q), size=out[..., i, :].shape, dtype=np.uint64)
     return out
+
+
+def crt_tables(src, dst):
+    """plain CRT conversion tables src -> dst with python integers (rns-cryptoparameters.cpp:214-246, 297-349):
+    hatInv[i], hatPre[i] (Shoup), hatMod[i][j], alpha[a][j] = a*Q mod dst_j, qInv[i] (double), mu128[j]"""
+    src_i, dst_i = [int(v) for v in src], [int(v) for v in dst]
+    Q = 1
+    for v in src_i:
+        Q *= v
+    hatInv = np.array([pow((Q // s) % s, -1, s) for s in src_i], np.uint64)
+    hatPre = np.array([(int(h) << 64) // s for h, s in zip(hatInv, src_i)], np.uint64)
+    hatMod = np.array([[(Q // s) % d for d in dst_i] for s in src_i], np.uint64)
+    alpha = np.array([[(a * Q) % d for d in dst_i] for a in range(len(src_i) + 1)], np.uint64)
+    qInv = np.array([1.0 / float(s) for s in src_i], np.float64)
+    mu = np.array([[((1 << 128) // d) & ((1 << 64) - 1), ((1 << 128) // d) >> 64] for d in dst_i], np.uint64)
+    return hatInv, hatPre, hatMod, alpha, qInv, mu
+
+
+def p_over_q_tables(q, pl):
+    """FastExpandCRTBasisPloverQ's first conversion (bfvrns-cryptoparameters.cpp:507-528): mPlQHatInvModq[i] =
+    -(Pl * (Q/q_i)^-1) mod q_i, its Shoup precon, qInvModp[i][j] = q_i^-1 mod p_j"""
+    q_i, p_i = [int(v) for v in q], [int(v) for v in pl]
+    Q, P = 1, 1
+    for v in q_i:
+        Q *= v
+    for v in p_i:
+        P *= v
+    m = np.array([(-(P * pow((Q // s) % s, -1, s))) % s for s in q_i], np.uint64)
+    mpre = np.array([(int(h) << 64) // s for h, s in zip(m, q_i)], np.uint64)
+    qinvp = np.array([[pow(s % d, -1, d) for d in p_i] for s in q_i], np.uint64)
+    return m, mpre, qinvp

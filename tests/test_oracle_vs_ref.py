@@ -220,6 +220,49 @@ def test_mod_reduce_against_live_reference(oracle, ref, logN, sizeQl, t, ev):
     o.orc_ctx_destroy(octx)
 
 
+@pytest.mark.parametrize("logN,nQ,nP,inEval,resEval,rev", [(4, 2, 3, 1, 1, 0), (5, 3, 3, 0, 1, 1), (6, 3, 4, 1, 0, 0), (4, 2, 2, 0, 0, 1)])
+def test_expand_crt_basis_against_live_reference(oracle, ref, logN, nQ, nP, inEval, resEval, rev):
+    """DCRTPoly::ExpandCRTBasis / ExpandCRTBasisReverseOrder of the reference vs the oracle composite"""
+    o, r = oracle, ref
+    rng = np.random.default_rng(91)
+    N = 1 << logN
+    allq, allpsi = np.zeros(nQ + nP, np.uint64), np.zeros(nQ + nP, np.uint64)
+    o.orc_dcrt_params(2 * N, nQ + nP, 58, allq, allpsi)
+    q, p, psiQ, psiP = allq[:nQ].copy(), allq[nQ:].copy(), allpsi[:nQ].copy(), allpsi[nQ:].copy()
+    hatInv, hatPre, hatMod, alpha, qInv, mu = libs.crt_tables(q, p)
+    hm_pq = np.ascontiguousarray(hatMod.T)
+    x = libs.rand_tower(rng, q, N)
+    want = np.zeros((nQ + nP, N), np.uint64)
+    r.ref_expand_crt_basis(N, nQ, q, psiQ, x, inEval, hatInv, hm_pq, alpha, nP, p, psiP, qInv, resEval, rev, want)
+    octx = o.orc_ctx_create(N, nQ + nP, allq, allpsi)
+    got = np.zeros((nQ + nP, N), np.uint64)
+    o.orc_expand_crt_basis(octx, nQ, nP, x, inEval, hatInv, hatPre, hm_pq, alpha, mu, qInv, resEval, rev, got)
+    assert np.array_equal(got, want)
+    o.orc_ctx_destroy(octx)
+
+
+@pytest.mark.parametrize("logN,nQ,nP", [(4, 2, 3), (6, 3, 3), (5, 4, 5)])
+def test_fast_expand_crt_basis_p_over_q_against_live_reference(oracle, ref, logN, nQ, nP):
+    """DCRTPoly::FastExpandCRTBasisPloverQ with the BFV HPSPOVERQ tables vs the oracle composite"""
+    o, r = oracle, ref
+    rng = np.random.default_rng(92)
+    N = 1 << logN
+    allq, allpsi = np.zeros(nQ + nP, np.uint64), np.zeros(nQ + nP, np.uint64)
+    o.orc_dcrt_params(2 * N, nQ + nP, 58, allq, allpsi)
+    q, pl, psiQ, psiP = allq[:nQ].copy(), allq[nQ:].copy(), allpsi[:nQ].copy(), allpsi[nQ:].copy()
+    m, mpre, qinvp = libs.p_over_q_tables(q, pl)
+    hatInv2, hatPre2, hatMod2, alpha2, pInv, muQ = libs.crt_tables(pl, q)  # Pl -> Ql (= Q)
+    _, _, _, _, _, muP = libs.crt_tables(q, pl)
+    hm2_qp = np.ascontiguousarray(hatMod2.T)
+    x = libs.rand_tower(rng, q, N)
+    want = np.zeros((nQ + nP, N), np.uint64)
+    r.ref_fast_expand_crt_basis_p_over_q(N, nQ, q, psiQ, x, m, qinvp, nP, pl, psiP, hatInv2, hm2_qp, alpha2, nQ, q, psiQ, pInv, want)
+    got = np.zeros((nQ + nP, N), np.uint64)
+    o.orc_fast_expand_crt_basis_p_over_q(x, nQ, N, q, m, mpre, qinvp, nP, pl, muP, hatInv2, hatPre2, hm2_qp, alpha2, nQ, q, muQ,
+                                         pInv, got)
+    assert np.array_equal(got, want)
+
+
 def ref_bfv_session(r, ring, t, depth, sms):
     """reference BFV/BEHZ context with two fresh ciphertexts and their EvalMultNoRelin product, exported as arrays"""
     h = r.ref_bfv_create(ring, t, depth, sms, 0)

@@ -171,3 +171,56 @@ def test_bfv_eval_mult_behz_reference_vectors(backend, ring):
         assert np.array_equal(got[e].to_host()[0], D[e]), f"product element {e}"
     plan.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("logN,nQ,nP,B,inEval,resEval,rev", [(4, 2, 3, 2, 1, 1, 0), (10, 3, 3, 2, 0, 1, 1), (12, 4, 5, 1, 1, 0, 0),
+                                                           (12, 3, 4, 1, 0, 0, 1), (13, 2, 3, 1, 1, 1, 1)])
+def test_expand_crt_basis(backend, oracle, logN, nQ, nP, B, inEval, resEval, rev):
+    """fhe_expand_crt_basis (ExpandCRTBasis / ExpandCRTBasisReverseOrder, the BFV HPS basis extension) vs the oracle"""
+    o = oracle
+    rng = np.random.default_rng(37)
+    N = 1 << logN
+    allq, allpsi = params(o, logN, nQ + nP, 58)
+    q, p = allq[:nQ], allq[nQ:]
+    hatInv, hatPre, hatMod, alpha, qInv, mu = libs.crt_tables(q, p)
+    hm_pq = np.ascontiguousarray(hatMod.T)
+    ctx = fh.Context(backend, logN, allq, allpsi)
+    octx = o.orc_ctx_create(N, nQ + nP, allq, allpsi)
+    x = libs.rand_tower(rng, q, N, B)
+    want = np.zeros((B, nQ + nP, N), np.uint64)
+    for b in range(B):
+        o.orc_expand_crt_basis(octx, nQ, nP, x[b], inEval, hatInv, hatPre, hm_pq, alpha, mu, qInv, resEval, rev, want[b])
+    conv = fh.Conv(ctx, np.arange(nQ), np.arange(nQ, nQ + nP))
+    tin = ctx.tower(x, limb_idx=np.arange(nQ), fmt=fh.EVALUATION if inEval else fh.COEFFICIENT)
+    got = conv.ExpandCRTBasis(tin, fh.EVALUATION if resEval else fh.COEFFICIENT, reverse=bool(rev))
+    assert np.array_equal(got.to_host(), want)
+    conv.close()
+    ctx.close()
+    o.orc_ctx_destroy(octx)
+
+
+@pytest.mark.parametrize("logN,nQ,nP,B", [(4, 2, 3, 2), (10, 3, 3, 2), (12, 4, 5, 1)])
+def test_fast_expand_crt_basis_p_over_q(backend, oracle, logN, nQ, nP, B):
+    """fhe_fast_expand_crt_basis_p_over_q with the HPSPOVERQ tables (custom-table plan + exact plan) vs the oracle"""
+    o = oracle
+    rng = np.random.default_rng(38)
+    N = 1 << logN
+    allq, allpsi = params(o, logN, nQ + nP, 58)
+    q, pl = allq[:nQ], allq[nQ:]
+    m, mpre, qinvp = libs.p_over_q_tables(q, pl)
+    hatInv2, hatPre2, hatMod2, alpha2, pInv, muQ = libs.crt_tables(pl, q)
+    _, _, _, _, _, muP = libs.crt_tables(q, pl)
+    hm2_qp = np.ascontiguousarray(hatMod2.T)
+    x = libs.rand_tower(rng, q, N, B)
+    want = np.zeros((B, nQ + nP, N), np.uint64)
+    for b in range(B):
+        o.orc_fast_expand_crt_basis_p_over_q(x[b], nQ, N, q, m, mpre, qinvp, nP, pl, muP, hatInv2, hatPre2, hm2_qp, alpha2, nQ, q,
+                                             muQ, pInv, want[b])
+    ctx = fh.Context(backend, logN, allq, allpsi)
+    to_pl = fh.Conv(ctx, np.arange(nQ), np.arange(nQ, nQ + nP), hat_inv=m, hat_mod=qinvp)
+    to_ql = fh.Conv(ctx, np.arange(nQ, nQ + nP), np.arange(nQ))
+    tin = ctx.tower(x, limb_idx=np.arange(nQ), fmt=fh.COEFFICIENT)
+    got = to_pl.FastExpandCRTBasisPloverQ(to_ql, tin)
+    assert np.array_equal(got.to_host(), want)
+    to_pl.close(), to_ql.close()
+    ctx.close()
