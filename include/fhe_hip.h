@@ -216,6 +216,10 @@ fhe_status fhe_eval_automorphism(fhe_ks_plan* plan, const fhe_ks_key* key, const
  * x[batch][sizeQl+sizeP][N] EVALUATION -> out[batch][sizeQl][N] EVALUATION */
 fhe_status fhe_approx_mod_down(fhe_ks_plan* plan, const uint64_t* x, uint32_t sizeQl, uint32_t batch, uint64_t* out,
                                void* ws, size_t wsBytes, void* stream);
+/* ApproxModDown with the BGV factors t^-1 (mod p_j) before and t (mod q_i) after the conversion (dcrtpoly-impl.h:966-1005
+ * with t > 0; tables tInvModp / tModqPrecon of CryptoParametersBGVRNS are derived inside).  Same layout and workspace. */
+fhe_status fhe_approx_mod_down_bgv(fhe_ks_plan* plan, const uint64_t* x, uint32_t sizeQl, uint64_t t, uint32_t batch,
+                                   uint64_t* out, void* ws, size_t wsBytes, void* stream);
 
 /* ---- a15: CKKS rescale ---------------------------------------------------------------------------
  * Replaces DCRTPolyImpl::DropLastElementAndScale (dcrtpoly-impl.h:693-712) with the tables of

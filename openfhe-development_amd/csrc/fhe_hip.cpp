@@ -1143,6 +1143,7 @@ struct fhe_ks_plan {
         std::vector<std::vector<uint32_t>> cidx;  // complement context-limb lists
         std::vector<uint32_t> partSize;
         fhe_conv* down = nullptr;               // P -> Q_l
+        std::map<uint64_t, fhe_conv*> downT;    // BGV: P -> Q_l with t^-1 (mod p_j) and t (mod q_i) folded in, per t
         TwPair* d_PInv = nullptr;               // [sizeQl] Shoup pairs of [P^-1]_{q_i}
     };
     std::vector<Level*> levels;  // index sizeQl
@@ -1180,6 +1181,8 @@ extern "C" void fhe_ks_plan_destroy(fhe_ks_plan* p) {
         for (auto* cv : lv->up)
             fhe_conv_destroy(cv);
         fhe_conv_destroy(lv->down);
+        for (auto& kv : lv->downT)
+            fhe_conv_destroy(kv.second);
         delete lv;
     }
     for (void* q : p->owned)
@@ -1340,7 +1343,7 @@ extern "C" size_t fhe_ks_workspace_bytes(const fhe_ks_plan* p, uint32_t sizeQl, 
 //   mod_down_core: x[nTow][sizeQl+sizeP][N] -> md[nTow][sizeQl][N] = NTT(ApproxSwitchCRTBasis(INTT(P part)))
 //   mod_down_tail: out_i = (x_i - md_i) * [P^-1]_{q_i}     (or out_i += ... when `accumulate`)
 static fhe_status mod_down_core(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const uint64_t* x, uint32_t nTow, uint64_t* pcoef,
-                                uint64_t* md, void* st) {
+                                uint64_t* md, void* st, fhe_conv* down = nullptr) {
     fhe_ctx* c            = p->ctx;
     const uint32_t sizeQl = lv->sizeQl, sizeP = p->sizeP, sizeQlP = sizeQl + sizeP;
     std::vector<uint32_t> pIdx(sizeP);
@@ -1350,7 +1353,7 @@ static fhe_status mod_down_core(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const ui
     if (fhe_status s = ntt_run(c, true, x, pcoef, pIdx.data(), sizeP, nTow, st, sizeQlP, sizeQl))
         return s;
     // P -> Q_l (:987-988)
-    if (fhe_status s = fhe_approx_switch_basis(lv->down, pcoef, sizeP, 0, md, sizeQl, 0, nTow, st))
+    if (fhe_status s = fhe_approx_switch_basis(down ? down : lv->down, pcoef, sizeP, 0, md, sizeQl, 0, nTow, st))
         return s;
     // back to EVALUATION (:1001)
     return fhe_ntt_fwd(c, md, nullptr, sizeQl, nTow, st);
@@ -1522,6 +1525,45 @@ extern "C" fhe_status fhe_approx_mod_down(fhe_ks_plan* p, const uint64_t* x, uin
         return s;
     uint64_t* ws = (uint64_t*)wsv;
     return mod_down_run(p, lv, x, batch, out, ws + w.pcoef, ws + w.md, st);
+}
+
+// ApproxModDown with the BGV plaintext-modulus factors (dcrtpoly-impl.h:966-1005 with t > 0): the P part is multiplied
+// by t^-1 mod p_j before the conversion (:981-983) and the converted part by t mod q_i after it (:996-998).  Both
+// are constant multiplications of canonical residues, so they are folded into the conversion's two constant sets
+// (y_j = x_j * [t^-1 * Phat_j^-1]_{p_j};  out_i = sum_j y_j * [t * Phat_j]_{q_i}): same words, no extra pass.
+extern "C" fhe_status fhe_approx_mod_down_bgv(fhe_ks_plan* p, const uint64_t* x, uint32_t sizeQl, uint64_t t, uint32_t batch,
+                                              uint64_t* out, void* wsv, size_t wsBytes, void* st) {
+    ARG_CHECK(p && x && out && wsv, "fhe_approx_mod_down_bgv: null argument");
+    ARG_CHECK(sizeQl >= 1 && sizeQl <= p->sizeQ && batch >= 1, "fhe_approx_mod_down_bgv: bad level or batch");
+    ARG_CHECK(t >= 2, "fhe_approx_mod_down_bgv: t must be at least 2");
+    const KsLayout w = ks_layout(p, sizeQl, batch);
+    ARG_CHECK(wsBytes >= w.total * 8, "fhe_approx_mod_down_bgv: workspace too small");
+    fhe_ctx* c = p->ctx;
+    RT_CHECK(rt::set_device(c->device));
+    fhe_ks_plan::Level* lv = nullptr;
+    if (fhe_status s = ks_level(p, sizeQl, &lv))
+        return s;
+    auto it = lv->downT.find(t);
+    if (it == lv->downT.end()) {
+        std::vector<uint64_t> src(p->sizeP), dst(sizeQl), sScale(p->sizeP), dScale(sizeQl);
+        for (uint32_t j = 0; j < p->sizeP; ++j) {
+            src[j] = c->q[p->sizeQ + j];
+            ARG_CHECK(t % src[j] != 0, "fhe_approx_mod_down_bgv: t must be invertible modulo every p_j");
+            sScale[j] = host::invmod(t % src[j], src[j]);  // tInvModp (bgvrns-cryptoparameters.cpp:77-81)
+        }
+        for (uint32_t i = 0; i < sizeQl; ++i) {
+            dst[i]    = c->q[i];
+            dScale[i] = t % dst[i];
+        }
+        fhe_conv* cv = nullptr;
+        if (fhe_status s = conv_build(c, src, dst, &cv, sScale.data(), dScale.data()))
+            return s;
+        it = lv->downT.emplace(t, cv).first;
+    }
+    uint64_t* ws = (uint64_t*)wsv;
+    if (fhe_status s = mod_down_core(p, lv, x, batch, ws + w.pcoef, ws + w.md, st, it->second))
+        return s;
+    return mod_down_tail(p, lv, x, ws + w.md, batch, out, false, st);
 }
 
 // ------------------------------------------------------------------------------------------------

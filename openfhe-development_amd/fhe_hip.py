@@ -101,6 +101,7 @@ class Lib:
         S("fhe_eval_fast_rotation", C.c_int, [vp, vp, vp, vp, u32, u32, u32, vp, vp, vp, C.c_size_t, vp])
         S("fhe_eval_automorphism", C.c_int, [vp, vp, vp, vp, u32, u32, u32, vp, vp, vp, C.c_size_t, vp])
         S("fhe_approx_mod_down", C.c_int, [vp, vp, u32, u32, vp, vp, C.c_size_t, vp])
+        S("fhe_approx_mod_down_bgv", C.c_int, [vp, vp, u32, u64, u32, vp, vp, C.c_size_t, vp])
         S("fhe_rescale_workspace_bytes", C.c_size_t, [vp, u32, u32])
         S("fhe_rescale", C.c_int, [vp, vp, u32, u32, vp, vp, C.c_size_t, vp])
         S("fhe_mod_reduce", C.c_int, [vp, vp, u32, u64, C.c_int, u32, vp, vp, C.c_size_t, vp])
@@ -452,10 +453,14 @@ class KeySwitchPlan:
                                                                 o0.ptr, o1.ptr, ws, wsb, stream))
         return o0, o1
 
-    def ApproxModDown(self, x, sizeQl, stream=None):  # dcrtpoly-impl.h:966-1005
+    def ApproxModDown(self, x, sizeQl, t=0, stream=None):  # dcrtpoly-impl.h:966-1005 (t > 0: the BGV form)
         ws, wsb = self.workspace(sizeQl, x.batch)
         out = self.ctx.empty(x.batch, sizeQl)
-        self.ctx.lib.check(self.ctx.lib.L.fhe_approx_mod_down(self.h, x.ptr, sizeQl, x.batch, out.ptr, ws, wsb, stream))
+        L = self.ctx.lib.L
+        if t:
+            self.ctx.lib.check(L.fhe_approx_mod_down_bgv(self.h, x.ptr, sizeQl, t, x.batch, out.ptr, ws, wsb, stream))
+        else:
+            self.ctx.lib.check(L.fhe_approx_mod_down(self.h, x.ptr, sizeQl, x.batch, out.ptr, ws, wsb, stream))
         return out
 
 

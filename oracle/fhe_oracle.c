@@ -937,6 +937,38 @@ void orc_hybrid_approx_mod_down(const orc_hybrid* h, const uint64_t* x, uint32_t
     free(sw);
 }
 
+/* ApproxModDown with the BGV factors (dcrtpoly-impl.h:966-1005, t > 0): partP[j] *= t^-1 mod p_j (:981-983),
+ * switched[i] *= t before its NTT (:996-999) */
+void orc_hybrid_approx_mod_down_t(const orc_hybrid* h, const uint64_t* x, uint32_t sizeQl, uint64_t t, uint64_t* out) {
+    const uint32_t N = h->N, sizeP = h->sizeP;
+    uint64_t* partP = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)sizeP * N);
+    memcpy(partP, x + (size_t)sizeQl * N, sizeof(uint64_t) * (size_t)sizeP * N);
+    for (uint32_t j = 0; j < sizeP; ++j) {
+        const uint64_t pj = h->p[j];
+        ctx_inv(h->ctx, partP + (size_t)j * N, h->sizeQ + j);
+        orc_vec_mul_const(partP + (size_t)j * N, partP + (size_t)j * N, orc_invmod(t % pj, pj), N, pj);
+    }
+    uint64_t* hat = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)sizeP * sizeQl);
+    for (uint32_t j = 0; j < sizeP; ++j)
+        memcpy(hat + (size_t)j * sizeQl, h->PHatModq + (size_t)j * h->sizeQ, 8 * (size_t)sizeQl);
+    uint64_t* sw = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)sizeQl * N);
+    orc_approx_switch_crt_basis(partP, sizeP, N, h->p, h->PHatInvModp, h->PHatInvModpPrecon, hat, sizeQl, h->q,
+                                h->muQ128, sw);
+    for (uint32_t i = 0; i < sizeQl; ++i) {
+        uint64_t qi = h->q[i];
+        uint64_t* s = sw + (size_t)i * N;
+        orc_vec_mul_const(s, s, t % qi, N, qi);
+        ctx_fwd(h->ctx, s, i);
+        for (uint32_t r = 0; r < N; ++r) {
+            uint64_t d             = orc_mod_sub_fast(x[(size_t)i * N + r], s[r], qi);
+            out[(size_t)i * N + r] = orc_mod_mul_fast_const(d, h->PInvModq[i], qi, h->PInvModqPrecon[i]);
+        }
+    }
+    free(partP);
+    free(hat);
+    free(sw);
+}
+
 /* keyswitch-hybrid.cpp:308-312 + :381-400 */
 void orc_hybrid_key_switch(const orc_hybrid* h, const uint64_t* c, uint32_t sizeQl, const uint64_t* keyB,
                            const uint64_t* keyA, uint64_t* out0, uint64_t* out1) {

@@ -145,6 +145,8 @@ void orc_hybrid_inner_product(const orc_hybrid*, const uint64_t* digits, uint32_
                               const uint64_t* keyB, const uint64_t* keyA, uint64_t* out0, uint64_t* out1);
 /* ApproxModDown (dcrtpoly-impl.h:966-1005), t=0 (CKKS): x[sizeQl+sizeP][N] EVAL -> out[sizeQl][N] EVAL */
 void orc_hybrid_approx_mod_down(const orc_hybrid*, const uint64_t* x, uint32_t sizeQl, uint64_t* out);
+/* same with the BGV factors t^-1 mod p_j / t mod q_i (dcrtpoly-impl.h:981-983, 996-998) */
+void orc_hybrid_approx_mod_down_t(const orc_hybrid*, const uint64_t* x, uint32_t sizeQl, uint64_t t, uint64_t* out);
 /* KeySwitchCore (:308-312): full a13. out0/out1 [sizeQl][N] */
 void orc_hybrid_key_switch(const orc_hybrid*, const uint64_t* c, uint32_t sizeQl, const uint64_t* keyB,
                            const uint64_t* keyA, uint64_t* out0, uint64_t* out1);

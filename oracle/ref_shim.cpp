@@ -286,6 +286,39 @@ void ref_fast_expand_crt_basis_p_over_q(uint32_t N, uint32_t sizeQ, const uint64
     X.FastExpandCRTBasisPloverQ(pre);
     export_poly(X, out);
 }
+// ApproxModDown with caller tables; x [(sizeQl+sizeP)][N] EVALUATION; PHatModq [sizeP][sizeQl]; t = 0: CKKS/BFV form,
+// t > 0: BGV form with tInvModp / tModqPrecon as CryptoParametersBGVRNS builds them
+void ref_approx_mod_down(uint32_t N, uint32_t sizeQl, const uint64_t* q, const uint64_t* psiQ, uint32_t sizeP, const uint64_t* p,
+                         const uint64_t* psiP, const uint64_t* x, const uint64_t* PInvModq, const uint64_t* PHatInvModp,
+                         const uint64_t* PHatModq, uint64_t t, uint64_t* out) {
+    std::vector<uint64_t> all(sizeQl + sizeP), allPsi(sizeQl + sizeP);
+    for (uint32_t i = 0; i < sizeQl + sizeP; ++i) {
+        all[i]    = i < sizeQl ? q[i] : p[i - sizeQl];
+        allPsi[i] = i < sizeQl ? psiQ[i] : psiP[i - sizeQl];
+    }
+    auto pqp = make_params(N, sizeQl + sizeP, all.data(), allPsi.data());
+    auto pq  = make_params(N, sizeQl, q, psiQ);
+    auto pp  = make_params(N, sizeP, p, psiP);
+    auto X   = make_poly(pqp, x, Format::EVALUATION);
+    auto pinv = vecNI(PInvModq, sizeQl);
+    auto phi  = vecNI(PHatInvModp, sizeP);
+    std::vector<std::vector<NativeInteger>> phm(sizeP);
+    for (uint32_t j = 0; j < sizeP; ++j)
+        phm[j] = vecNI(PHatModq + (size_t)j * sizeQl, sizeQl);
+    std::vector<NativeInteger> tInvModp, tInvModpPrecon, tModqPrecon;
+    const NativeInteger T(t);
+    if (t > 0) {
+        for (uint32_t j = 0; j < sizeP; ++j) {
+            tInvModp.push_back(T.ModInverse(NativeInteger(p[j])));
+            tInvModpPrecon.push_back(tInvModp[j].PrepModMulConst(NativeInteger(p[j])));
+        }
+        for (uint32_t i = 0; i < sizeQl; ++i)
+            tModqPrecon.push_back(T.PrepModMulConst(NativeInteger(q[i])));
+    }
+    auto r = X.ApproxModDown(pq, pp, pinv, precon(pinv, q), phi, precon(phi, p), phm, mu128(q, sizeQl), tInvModp,
+                             tInvModpPrecon, T, tModqPrecon);
+    export_poly(r, out);
+}
 // DropLastElementAndScale with caller tables (EVAL in/out)
 void ref_drop_last_element_and_scale(uint32_t N, uint32_t sizeQl, const uint64_t* q, const uint64_t* psi,
                                      const uint64_t* x, const uint64_t* tabA, const uint64_t* tabB, uint64_t* out) {

@@ -263,6 +263,36 @@ def test_fast_expand_crt_basis_p_over_q_against_live_reference(oracle, ref, logN
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("logN,sizeQ,sizeQl,dnum,t", [(4, 3, 3, 1, 0), (5, 4, 3, 2, 65537), (6, 4, 4, 2, 2), (4, 2, 2, 1, 786433)])
+def test_approx_mod_down_against_live_reference(oracle, ref, logN, sizeQ, sizeQl, dnum, t):
+    """DCRTPoly::ApproxModDown of the reference (CKKS/BFV form t = 0 and BGV form t > 0) vs the oracle"""
+    o, r = oracle, ref
+    rng = np.random.default_rng(93)
+    N = 1 << logN
+    q, psiQ = np.zeros(sizeQ, np.uint64), np.zeros(sizeQ, np.uint64)
+    o.orc_dcrt_params(2 * N, sizeQ, 50, q, psiQ)
+    p, psiP = np.zeros(64, np.uint64), np.zeros(64, np.uint64)
+    sizeP = o.orc_hybrid_select_p(N, sizeQ, q, dnum, 60, p, psiP)
+    p, psiP = p[:sizeP].copy(), psiP[:sizeP].copy()
+    hy = o.orc_hybrid_create(N, sizeQ, q, psiQ, sizeP, p, psiP, dnum)
+    ql, psiQl = q[:sizeQl].copy(), psiQ[:sizeQl].copy()
+    hatInv, _, hatMod, _, _, _ = libs.crt_tables(p, ql)  # PHatInvModp[j], PHatModq[j][i]
+    P = 1
+    for v in p:
+        P *= int(v)
+    pinv = np.array([pow(P % int(v), -1, int(v)) for v in ql], np.uint64)
+    x = libs.rand_tower(rng, np.concatenate([ql, p]), N)
+    want = np.zeros((sizeQl, N), np.uint64)
+    r.ref_approx_mod_down(N, sizeQl, ql, psiQl, sizeP, p, psiP, x, pinv, hatInv, hatMod, t, want)
+    got = np.zeros((sizeQl, N), np.uint64)
+    if t:
+        o.orc_hybrid_approx_mod_down_t(hy, x, sizeQl, t, got)
+    else:
+        o.orc_hybrid_approx_mod_down(hy, x, sizeQl, got)
+    assert np.array_equal(got, want)
+    o.orc_hybrid_destroy(hy)
+
+
 def ref_bfv_session(r, ring, t, depth, sms):
     """reference BFV/BEHZ context with two fresh ciphertexts and their EvalMultNoRelin product, exported as arrays"""
     h = r.ref_bfv_create(ring, t, depth, sms, 0)

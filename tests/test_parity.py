@@ -294,6 +294,11 @@ def test_hybrid_keyswitch_and_eval_mult(backend, oracle, logN, sizeQ, dnum, size
     for bb in range(B):
         o.orc_hybrid_approx_mod_down(hy, x[bb], sizeQl, wd[bb])
     assert np.array_equal(plan.ApproxModDown(ctx.tower(x), sizeQl).to_host(), wd), "ApproxModDown mismatch"
+    # ... and its BGV form (t^-1 mod p_j before, t mod q_i after the conversion)
+    for t in (65537, 2):
+        for bb in range(B):
+            o.orc_hybrid_approx_mod_down_t(hy, x[bb], sizeQl, t, wd[bb])
+        assert np.array_equal(plan.ApproxModDown(ctx.tower(x), sizeQl, t=t).to_host(), wd), f"ApproxModDown (BGV, t={t}) mismatch"
     plan.close()
     ctx.close()
     o.orc_hybrid_destroy(hy)
