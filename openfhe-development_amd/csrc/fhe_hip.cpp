@@ -215,7 +215,6 @@ extern "C" uint32_t fhe_param_select_p(uint32_t logN, uint32_t sizeQ, const uint
 }
 
 static uint32_t env_u32(const char* name, uint32_t dflt);
-static uint32_t ntt_stagger();
 static bool ntt_legacy();
 
 // ------------------------------------------------------------------------------------------------
@@ -240,7 +239,6 @@ struct fhe_ctx {
     // cached ModReduce tables per (sizeQl, t): [0..l) = A_i, [l..2l) = B_i, [2l] = negtInvModq   (fhe_mod_reduce)
     std::map<std::pair<uint32_t, uint64_t>, TwPair*> modReduceTabs;
     // small ring of device slots for per-call constant vectors (fhe_mul_const)
-    uint32_t persistentGrid = 1024;  // workgroups of the persistent NTT kernels (CUs x FHE_NTT_WG_PER_CU)
     TwPair* d_constRing = nullptr;
     uint32_t constRingPos = 0;
 };
@@ -278,7 +276,6 @@ extern "C" fhe_status fhe_ctx_create(uint32_t logN, uint32_t nLimbs, const uint6
     c->device  = device;
     c->q.assign(q, q + nLimbs);
     c->psi.assign(psi, psi + nLimbs);
-    c->persistentGrid = rt::cu_count(device) * env_u32("FHE_NTT_WG_PER_CU", 4);
 
     // twiddle tables: Table[bitrev(i)] = psi^i, TableI[bitrev(i)] = psi^-i  (transformnat-impl.h:725-737)
     std::vector<TwPair> tw((size_t)nLimbs * N), twInv((size_t)nLimbs * N), fin((size_t)nLimbs * 2);
@@ -496,14 +493,12 @@ static bool ntt_static();
 static bool ntt_lds2();
 static bool ntt_rowtw();
 static bool ntt_legacy();
-static uint32_t ntt_stagger();
 static uint32_t fill_pass_args(const fhe_ctx* c, const PassPlan& pp, bool inverse, const uint64_t* xin, uint64_t* xout,
                                const LimbSel& sel, uint32_t nLimbs, uint32_t batch, bool canonOut, uint32_t inStride,
                                uint32_t inFirst, uint32_t outStride, uint32_t outFirst, NttPassArgs& a) {
     a.outStride = outStride;
     a.outFirst  = outFirst;
     a.inStride = inStride;
-    a.stagger  = ntt_stagger();
     a.inFirst  = inFirst;
     a.xin      = xin;
     a.x        = xout;
@@ -649,10 +644,6 @@ static bool ntt_rowtw() {
 static bool ntt_lds2() {
     static const uint32_t v = env_u32("FHE_NTT_LDS2", 0);
     return v != 0;
-}
-static uint32_t ntt_stagger() {
-    static const uint32_t v = env_u32("FHE_NTT_STAGGER", 0);
-    return v;
 }
 
 // inStride != 0: xin is a [batch][inStride][N] view whose rows inFirst.. are transformed into the dense xout

@@ -76,7 +76,6 @@ struct NttPassArgs {
     uint32_t inFirst;     //    transformed rows start at row inFirst of each tower
     uint32_t outStride;   // 0: x is dense; else x is a [batch][outStride][N] view, rows outFirst.. of each tower
     uint32_t outFirst;    //    (applies to every access of a.x, i.e. stores and in-place reloads)
-    uint32_t stagger;     // tuning: first-wave workgroups with odd (blockIdx>>3) start `stagger` x 64 cycles late
     NttStep steps[6];
     LimbSel sel;
 };
@@ -124,15 +123,6 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_pass_kernel(const NttPassArgs a)
     // ---- which tile? ----
     uint32_t tile = FHE_BID;
     const uint32_t tilesPerRow = (N >= (uint32_t)kTile) ? (N >> kTileLog) : 1u;
-#if !defined(FHE_EMU)
-    // de-synchronise the first wave of workgroups: all of them start within ~100 cycles and run the same
-    // load -> compute -> store phases, so without an offset every CU alternates between an HBM-only and an
-    // ALU-only phase; half of the initially resident workgroups start late, successors inherit the offset
-    if (a.stagger && tile < 2048u && ((tile >> 3) & 1u)) {
-        for (uint32_t i = 0; i < a.stagger; i += 64)
-            __builtin_amdgcn_s_sleep(64);
-    }
-#endif
     if (a.xcdSwizzle) {
         // blockIdx = xcd + 8*i ; i = pairIdx*batch + b ; pair = pairIdx*8 + xcd ; pair = limb*tilesPerRow + tr
         const uint32_t xcd = tile & 7u, i = tile >> 3;
@@ -308,13 +298,8 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_pass_kernel(const NttPassArgs a)
 
 
 // ================================================================================================
-// Fast path for rings with N >= 4096 (every tile lies inside one limb): same tiling and step plan as
-// ntt_pass_kernel, plus
-//  * persistent workgroups: each workgroup walks a strided list of tiles and issues the HBM loads of its
-//    next tile before computing the current one, so the memory pipe and the integer pipe overlap inside a
-//    wave instead of relying on other waves being in a different phase;
-//  * a 10-multiply Shoup butterfly with the x+T sum folded into the multiply-add chain and no register
-//    shuffles for the low product (see bfly_fwd_fast);
+// Arithmetic shared by the kernels for rings with N >= 4096 (ntt_pass_full_kernel below, ntt_static.h):
+//  * a 10-multiply Shoup butterfly with the x+T sum folded into the multiply-add chain (bfly_fwd_fast),
 //  * forward transform: conditional subtractions only where the 64-bit headroom (16q) would otherwise
 //    overflow (NttStep::mode), instead of one per butterfly.
 // ================================================================================================
@@ -596,200 +581,6 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_pass_full_kernel(const NttPassAr
             for (int k = 0; k < 16; ++k)
                 lds[sb ^ lds_sigma((uint32_t)k << fI)] = r[k];
             FHE_SYNC();
-        }
-    }
-}
-
-#ifndef FHE_NTT_MINWAVES
-#define FHE_NTT_MINWAVES 2
-#endif
-template <bool LAYOUT_A, bool INVERSE, int NSTEPS>
-FHE_GLOBAL void FHE_LAUNCH_BOUNDS2(kThreads, FHE_NTT_MINWAVES) ntt_pass_fast_kernel(const NttPassArgs a) {
-    FHE_SHARED_U64(lds, kTile);
-    const uint32_t t    = FHE_TID;
-    const uint32_t logN = a.logN;
-    const uint32_t N    = 1u << logN;
-    const uint32_t T    = a.T;
-    const uint32_t tilesPerRow = N >> kTileLog;
-    const uint32_t nTiles      = a.rows * tilesPerRow;
-    const uint32_t logC = kTileLog - T;
-    const uint32_t S    = N >> T;
-    // the next tile's HBM loads are issued at the start of step PFS: as early as possible, but behind the first
-    // per-lane (vector) twiddle loads, because vmcnt retires in order.  Steps whose twiddles are lane-uniform
-    // fetch them through the scalar cache and do not interfere.
-    constexpr int PFS = !INVERSE ? 0 : (LAYOUT_A ? (NSTEPS == 1 ? 0 : 1) : 2);
-
-    auto locate = [&](uint32_t w, uint32_t& row, uint64_t& gbase, uint32_t& jbase) {
-        uint32_t tile = w;
-        if (a.xcdSwizzle) {
-            const uint32_t xcd = w & 7u, i = w >> 3;
-            const uint32_t b = i % a.batch, pairIdx = i / a.batch;
-            const uint32_t pair = pairIdx * 8u + xcd;
-            tile = (b * a.nLimbs + pair / tilesPerRow) * tilesPerRow + pair % tilesPerRow;
-        }
-        row = tile / tilesPerRow;
-        if (LAYOUT_A) {
-            jbase = (tile % tilesPerRow) << logC;
-            gbase = ((uint64_t)row << logN) + jbase;
-        }
-        else {
-            jbase = (tile % tilesPerRow) << kTileLog;
-            gbase = (uint64_t)tile << kTileLog;
-        }
-    };
-    auto lane_geom = [&](uint32_t fI, uint32_t& rel, uint64_t& kstride) {
-        const uint32_t Ib = ((t >> fI) << (fI + 4)) | (t & ((1u << fI) - 1u));
-        if (LAYOUT_A) {
-            const uint32_t p0 = Ib >> logC, c0 = Ib & ((1u << logC) - 1u);
-            rel     = p0 * S + c0;
-            kstride = (fI >= logC) ? ((uint64_t)S << (fI - logC)) : ((uint64_t)1 << fI);
-        }
-        else {
-            rel     = Ib;
-            kstride = (uint64_t)1 << fI;
-        }
-    };
-
-    uint32_t relIn, relOut;
-    uint64_t ksIn, ksOut;
-    lane_geom((uint32_t)a.steps[0].fI, relIn, ksIn);
-    lane_geom((uint32_t)a.steps[NSTEPS - 1].fI, relOut, ksOut);
-
-    uint64_t pf[16];
-    auto issue_loads = [&](uint32_t ww) {
-        uint32_t row, jb;
-        uint64_t gb;
-        locate(ww, row, gb, jb);
-        uint64_t ioff = gb + relIn;
-        if (a.inStride)
-            ioff = (((uint64_t)(row / a.nLimbs) * a.inStride + a.inFirst + row % a.nLimbs) << logN) + jb + relIn;
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-            pf[k] = a.xin[ioff + k * ksIn];
-    };
-    uint32_t w = FHE_BID;
-    if (w < nTiles)
-        issue_loads(w);
-
-    for (; w < nTiles; w += FHE_NBLK) {
-        uint32_t row, jbase;
-        uint64_t gbase;
-        locate(w, row, gbase, jbase);
-        const uint32_t limb = FHE_UNIFORM(a.sel.idx[row % a.nLimbs]);
-        const uint64_t q    = a.q[limb];
-        const uint64_t twoq = q << 1, nq = 0 - q;
-        const TwPair* tw    = a.tw + ((uint64_t)limb << logN);
-        const bool more     = w + FHE_NBLK < nTiles;
-
-        uint64_t r[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-            r[k] = pf[k];
-
-#pragma unroll
-        for (int si = 0; si < NSTEPS; ++si) {
-            const NttStep st  = a.steps[si];
-            const uint32_t fI = (uint32_t)st.fI;
-            uint32_t rel;
-            uint64_t kstride;
-            lane_geom(fI, rel, kstride);
-            const uint32_t Ib = ((t >> fI) << (fI + 4)) | (t & ((1u << fI) - 1u));
-            if (si != 0) {
-                const uint32_t sb = lds_sigma(Ib);
-#pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    r[k] = lds[sb ^ lds_sigma((uint32_t)k << fI)];
-                FHE_SYNC();
-            }
-            if (si == PFS && more)
-                issue_loads(w + FHE_NBLK);
-            if (st.bHi >= st.bLo) {
-                const uint32_t Fj = (uint32_t)st.Fj;
-                uint32_t jhigh    = (jbase + rel) >> (Fj + 4);
-                if (st.uniformTw)
-                    jhigh = FHE_UNIFORM(jhigh);
-                if (!INVERSE) {
-                    if (st.mode == 1) {  // keep the 64-bit headroom: everything back below 8q
-#pragma unroll
-                        for (int k = 0; k < 16; ++k)
-                            r[k] = csub2(r[k], twoq << 2);
-                    }
-#pragma unroll
-                    for (int b = 3; b >= 0; --b) {
-                        if (b <= st.bHi && b >= st.bLo) {
-                            const uint32_t s      = logN - 1u - (Fj + b);
-                            const uint32_t twbase = (1u << s) + (jhigh << (3 - b));
-#pragma unroll
-                            for (int g = 0; g < (8 >> b); ++g) {
-                                const TwPair wv = tw[twbase + g];
-#pragma unroll
-                                for (int lo = 0; lo < (1 << b); ++lo) {
-                                    const int k0 = (g << (b + 1)) | lo;
-                                    bfly_fwd_fast(r[k0], r[k0 | (1 << b)], wv, nq, twoq);
-                                }
-                            }
-                        }
-                    }
-                }
-                else {
-#pragma unroll
-                    for (int b = 0; b <= 3; ++b) {
-                        if (b <= st.bHi && b >= st.bLo) {
-                            const uint32_t s      = logN - 1u - (Fj + b);
-                            const uint32_t twbase = (1u << s) + (jhigh << (3 - b));
-                            if (s == 0) {
-                                const TwPair nInv = a.fin[2 * limb], w1n = a.fin[2 * limb + 1];
-#pragma unroll
-                                for (int lo = 0; lo < (1 << b); ++lo) {
-                                    const uint64_t u = r[lo], v = r[lo | (1 << b)];
-                                    r[lo]            = shoup_acc(0, u + v, nInv, nq);
-                                    r[lo | (1 << b)] = shoup_acc(0, u - v + twoq, w1n, nq);
-                                }
-                            }
-                            else {
-#pragma unroll
-                                for (int g = 0; g < (8 >> b); ++g) {
-                                    const TwPair wv = tw[twbase + g];
-#pragma unroll
-                                    for (int lo = 0; lo < (1 << b); ++lo) {
-                                        const int k0 = (g << (b + 1)) | lo;
-                                        bfly_inv_fast(r[k0], r[k0 | (1 << b)], wv, nq, twoq);
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-            if ((uint32_t)si == a.canonStep) {
-                if (INVERSE) {
-#pragma unroll
-                    for (int k = 0; k < 16; ++k)
-                        r[k] = csub2(r[k], q);
-                }
-                else {
-                    // forward outputs are below 2^canonLevels * q
-                    for (int lv = (int)a.canonLevels - 1; lv >= 0; --lv) {
-                        const uint64_t m = q << lv;
-#pragma unroll
-                        for (int k = 0; k < 16; ++k)
-                            r[k] = csub2(r[k], m);
-                    }
-                }
-            }
-            if (si + 1 == NSTEPS) {
-                const uint64_t ooff = gbase + relOut;
-#pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    a.x[ooff + k * ksOut] = r[k];
-            }
-            else {
-                const uint32_t sb = lds_sigma(Ib);
-#pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    lds[sb ^ lds_sigma((uint32_t)k << fI)] = r[k];
-                FHE_SYNC();
-            }
         }
     }
 }
