@@ -212,6 +212,23 @@ fhe_status fhe_eval_fast_rotation(fhe_ks_plan* plan, const fhe_ks_key* key, cons
 fhe_status fhe_eval_automorphism(fhe_ks_plan* plan, const fhe_ks_key* key, const uint64_t* c0, const uint64_t* c1,
                                  uint32_t k, uint32_t sizeQl, uint32_t batch, uint64_t* out0, uint64_t* out1, void* ws,
                                  size_t wsBytes, void* stream);
+/* Double hoisting (ckksrns-fhe.cpp:1830-2000) works in the extended basis Q_l u P and mods down once:
+ *   fhe_ks_ext                 = KeySwitchHYBRID::KeySwitchExt for one element (keyswitch-hybrid.cpp:217-243):
+ *                                out [batch][sizeQl+sizeP][N], Q_l rows = c * [P]_{q_i}, P rows = 0;
+ *   fhe_ks_fast_keyswitch_ext  = EvalFastKeySwitchCoreExt (:402-435) on the digits fhe_ks_precompute left in ws;
+ *   fhe_eval_fast_rotation_ext = LeveledSHECKKSRNS::EvalFastRotationExt (ckksrns-leveledshe.cpp:534-582);
+ *   fhe_ks_down                = KeySwitchHYBRID::KeySwitchDown (:245-278), ApproxModDown of both elements.
+ * Extended towers are [batch][sizeQl+sizeP][N] over context limbs {0..sizeQl-1, sizeQ..sizeQ+sizeP-1}; the generic
+ * element-wise entry points (fhe_add / fhe_mul / fhe_automorph with that limb list) cover EvalAddExt / EvalMultExt. */
+fhe_status fhe_ks_ext(fhe_ks_plan* plan, const uint64_t* c, uint32_t sizeQl, uint32_t batch, uint64_t* outExt, void* stream);
+fhe_status fhe_ks_fast_keyswitch_ext(fhe_ks_plan* plan, const fhe_ks_key* key, const uint64_t* c1, uint32_t sizeQl,
+                                     uint32_t batch, uint64_t* out0Ext, uint64_t* out1Ext, void* ws, size_t wsBytes,
+                                     void* stream);
+fhe_status fhe_eval_fast_rotation_ext(fhe_ks_plan* plan, const fhe_ks_key* key, const uint64_t* c0, const uint64_t* c1,
+                                      uint32_t k, int addFirst, uint32_t sizeQl, uint32_t batch, uint64_t* out0Ext,
+                                      uint64_t* out1Ext, void* ws, size_t wsBytes, void* stream);
+fhe_status fhe_ks_down(fhe_ks_plan* plan, const uint64_t* x0Ext, const uint64_t* x1Ext, uint32_t sizeQl, uint32_t batch,
+                       uint64_t* out0, uint64_t* out1, void* ws, size_t wsBytes, void* stream);
 /* DCRTPolyImpl::ApproxModDown with t = 0 (dcrtpoly-impl.h:966-1005):
  * x[batch][sizeQl+sizeP][N] EVALUATION -> out[batch][sizeQl][N] EVALUATION */
 fhe_status fhe_approx_mod_down(fhe_ks_plan* plan, const uint64_t* x, uint32_t sizeQl, uint32_t batch, uint64_t* out,

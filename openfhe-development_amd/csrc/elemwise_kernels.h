@@ -47,6 +47,7 @@ struct ElemArgs {
     uint32_t logN, nLimbs, rows;
     uint32_t aStride, aFirst;  // aStride != 0: operand a is a [batch][aStride][N] view, rows aFirst.. of each tower
     uint32_t bStride, bFirst;  // same for b
+    uint32_t oStride, oFirst;  // same for out
     LimbSel sel;
 };
 
@@ -107,12 +108,13 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) elemwise_kernel(const ElemArgs g) {
             b0 = g.b[boff];
             b1 = g.b[boff + 1];
         }
+        const uint64_t ooff = g.oStride ? ((((uint64_t)tb * g.oStride + g.oFirst + rit) << g.logN) + ri) : off;
         if (needO) {
-            o0 = g.out[off];
-            o1 = g.out[off + 1];
+            o0 = g.out[ooff];
+            o1 = g.out[ooff + 1];
         }
-        g.out[off]     = elem_apply<OP>(o0, a0, b0, lc, c);
-        g.out[off + 1] = elem_apply<OP>(o1, a1, b1, lc, c);
+        g.out[ooff]     = elem_apply<OP>(o0, a0, b0, lc, c);
+        g.out[ooff + 1] = elem_apply<OP>(o1, a1, b1, lc, c);
     }
 }
 

@@ -759,7 +759,8 @@ extern "C" fhe_status fhe_time_ntt(fhe_ctx* c, uint64_t* x, const uint32_t* li, 
 template <int OP>
 static fhe_status elem_run(fhe_ctx* c, uint64_t* out, const uint64_t* a, const uint64_t* b, const TwPair* d_consts,
                            const uint32_t* limbIdx, uint32_t nLimbs, uint32_t batch, void* stream, const char* who,
-                           uint32_t aStride = 0, uint32_t aFirst = 0, uint32_t bStride = 0, uint32_t bFirst = 0) {
+                           uint32_t aStride = 0, uint32_t aFirst = 0, uint32_t bStride = 0, uint32_t bFirst = 0,
+                           uint32_t oStride = 0, uint32_t oFirst = 0) {
     ARG_CHECK(c && out && a, std::string(who) + ": null argument");
     ARG_CHECK(batch >= 1, std::string(who) + ": batch must be >= 1");
     ElemArgs g;
@@ -775,6 +776,7 @@ static fhe_status elem_run(fhe_ctx* c, uint64_t* out, const uint64_t* a, const u
     g.nLimbs = nLimbs;
     g.rows   = batch * nLimbs;
     g.aStride = aStride, g.aFirst = aFirst, g.bStride = bStride, g.bFirst = bFirst;
+    g.oStride = oStride, g.oFirst = oFirst;
     FHE_LAUNCH((elemwise_kernel<OP>), tiles_for(c, g.rows), stream, g);
     LAUNCH_CHECK();
     return FHE_OK;
@@ -1136,6 +1138,7 @@ struct fhe_ks_plan {
         fhe_conv* down = nullptr;               // P -> Q_l
         std::map<uint64_t, fhe_conv*> downT;    // BGV: P -> Q_l with t^-1 (mod p_j) and t (mod q_i) folded in, per t
         TwPair* d_PInv = nullptr;               // [sizeQl] Shoup pairs of [P^-1]_{q_i}
+        TwPair* d_PModq = nullptr;              // [sizeQl] Shoup pairs of [P]_{q_i} (built on first use)
     };
     std::vector<Level*> levels;  // index sizeQl
     std::vector<void*> owned;
@@ -1385,9 +1388,10 @@ static fhe_status ks_precompute_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, cons
 }
 // EvalFastKeySwitchCore (keyswitch-hybrid.cpp:381-435) on digits already in the workspace.
 // accumulate: out0/out1 += result (EvalMult's `cv[0] += ab[0]; cv[1] += ab[1]`, base-leveledshe.cpp:210-211)
-static fhe_status ks_fast_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const fhe_ks_key* key, const uint64_t* cin,
-                              uint32_t batch, uint64_t* out0, uint64_t* out1, uint64_t* ws, const KsLayout& w, void* st,
-                              bool accumulate) {
+// EvalFastKeySwitchCoreExt (keyswitch-hybrid.cpp:402-435): inner product of the digits in the workspace with the key, both
+// halves, result [batch][sizeQl+sizeP][N] in the extended basis
+static fhe_status ks_inner_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const fhe_ks_key* key, const uint64_t* cin,
+                               uint32_t batch, uint64_t* e0, uint64_t* e1, uint64_t* ws, const KsLayout& w, void* st) {
     fhe_ctx* c            = p->ctx;
     const uint32_t sizeQl = lv->sizeQl, sizeP = p->sizeP, sizeQlP = sizeQl + sizeP;
     KsInnerArgs g;
@@ -1395,15 +1399,23 @@ static fhe_status ks_fast_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const fhe_
         g.digits[j] = j < lv->numParts ? ws + w.dig[j] : nullptr;
         g.nc[j]     = j < lv->numParts ? (uint32_t)lv->cidx[j].size() : 0u;
     }
-    // EvalFastKeySwitchCoreExt (:402-435)
     g.c = cin, g.keyB = key->d_b, g.keyA = key->d_a;
-    g.out0 = ws + w.e0, g.out1 = ws + w.e1;
+    g.out0 = e0, g.out1 = e1;
     g.lc = c->d_lc, g.mu128 = c->d_mu128;
     g.logN = c->logN, g.batch = batch, g.sizeQl = sizeQl, g.sizeQ = p->sizeQ, g.sizeP = sizeP;
     g.numDigits = lv->numParts, g.alpha = p->alpha;
     const uint32_t tilesPerRow = c->N >= (uint32_t)kTile ? (c->N >> kTileLog) : 1u;
     FHE_LAUNCH(ks_inner_product_kernel, (uint64_t)batch * tilesPerRow * sizeQlP, st, g);
     LAUNCH_CHECK();
+    return FHE_OK;
+}
+static fhe_status ks_fast_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const fhe_ks_key* key, const uint64_t* cin,
+                              uint32_t batch, uint64_t* out0, uint64_t* out1, uint64_t* ws, const KsLayout& w, void* st,
+                              bool accumulate) {
+    fhe_ctx* c            = p->ctx;
+    const uint32_t sizeQl = lv->sizeQl;
+    if (fhe_status s = ks_inner_run(p, lv, key, cin, batch, ws + w.e0, ws + w.e1, ws, w, st))
+        return s;
     // 2 x ApproxModDown (:381-400): e0 and e1 are adjacent in the workspace (w.e1 == w.e0 + batch*sizeQlP*N), so the
     // INTT / conversion / NTT run once over 2*batch towers; only the element-wise tails are per accumulator
     if (fhe_status s = mod_down_core(p, lv, ws + w.e0, 2 * batch, ws + w.pcoef, ws + w.md, st))
@@ -1502,6 +1514,101 @@ extern "C" fhe_status fhe_eval_automorphism(fhe_ks_plan* p, const fhe_ks_key* ke
     if (fhe_status s = fhe_ks_precompute(p, c1, sizeQl, batch, ws, wsBytes, st))
         return s;
     return fhe_eval_fast_rotation(p, key, c0, c1, k, sizeQl, batch, out0, out1, ws, wsBytes, st);
+}
+
+// ---- double hoisting: work in the extended basis Q_l u P, one ModDown at the end (ckksrns-fhe.cpp:1830-2000) ----
+static fhe_status ext_limbs(const fhe_ks_plan* p, uint32_t sizeQl, std::vector<uint32_t>& idx) {
+    idx.resize(sizeQl + p->sizeP);
+    for (uint32_t i = 0; i < sizeQl; ++i)
+        idx[i] = i;
+    for (uint32_t j = 0; j < p->sizeP; ++j)
+        idx[sizeQl + j] = p->sizeQ + j;
+    return FHE_OK;
+}
+// [P]_{q_i} as Shoup pairs for limbs [0, sizeQl)  (PModq, rns-cryptoparameters.cpp:200-203), cached per level
+static fhe_status ks_pmodq(fhe_ks_plan* p, fhe_ks_plan::Level* lv, TwPair** d) {
+    if (!lv->d_PModq) {
+        fhe_ctx* c = p->ctx;
+        std::vector<uint64_t> pm(p->sizeP);
+        for (uint32_t j = 0; j < p->sizeP; ++j)
+            pm[j] = c->q[p->sizeQ + j];
+        std::vector<TwPair> h(lv->sizeQl);
+        for (uint32_t i = 0; i < lv->sizeQl; ++i) {
+            const uint64_t v = host::prod_mod(pm, -1, c->q[i]);
+            h[i]             = TwPair{v, host::shoup(v, c->q[i])};
+        }
+        void* dp = nullptr;
+        RT_CHECK(rt::dmalloc(&dp, h.size() * sizeof(TwPair)));
+        p->owned.push_back(dp);
+        RT_CHECK(rt::h2d(dp, h.data(), h.size() * sizeof(TwPair), nullptr));
+        RT_CHECK(rt::sync(nullptr));
+        lv->d_PModq = (TwPair*)dp;
+    }
+    *d = lv->d_PModq;
+    return FHE_OK;
+}
+// KeySwitchHYBRID::KeySwitchExt for one element (keyswitch-hybrid.cpp:217-243): out [batch][sizeQl+sizeP][N], Q_l rows =
+// c * [P]_{q_i}, P rows = 0
+extern "C" fhe_status fhe_ks_ext(fhe_ks_plan* p, const uint64_t* cin, uint32_t sizeQl, uint32_t batch, uint64_t* out, void* st) {
+    ARG_CHECK(p && cin && out, "fhe_ks_ext: null argument");
+    ARG_CHECK(sizeQl >= 1 && sizeQl <= p->sizeQ && batch >= 1, "fhe_ks_ext: bad level or batch");
+    fhe_ctx* c = p->ctx;
+    RT_CHECK(rt::set_device(c->device));
+    fhe_ks_plan::Level* lv = nullptr;
+    if (fhe_status s = ks_level(p, sizeQl, &lv))
+        return s;
+    TwPair* dP = nullptr;
+    if (fhe_status s = ks_pmodq(p, lv, &dP))
+        return s;
+    const uint32_t sizeQlP = sizeQl + p->sizeP;
+    const size_t rowB      = (size_t)8 << c->logN;
+    RT_CHECK(rt::dzero_2d(out + ((size_t)sizeQl << c->logN), sizeQlP * rowB, p->sizeP * rowB, batch, (rt::stream_t)st));
+    return elem_run<OP_MUL_CONST>(c, out, cin, nullptr, dP, nullptr, sizeQl, batch, st, "fhe_ks_ext", 0, 0, 0, 0, sizeQlP, 0);
+}
+// EvalFastKeySwitchCoreExt on digits already in the workspace (fhe_ks_precompute): out0/out1 [batch][sizeQl+sizeP][N]
+extern "C" fhe_status fhe_ks_fast_keyswitch_ext(fhe_ks_plan* p, const fhe_ks_key* key, const uint64_t* c1, uint32_t sizeQl,
+                                                uint32_t batch, uint64_t* out0, uint64_t* out1, void* ws, size_t wsBytes,
+                                                void* st) {
+    KS_COMMON_CHECKS("fhe_ks_fast_keyswitch_ext")
+    ARG_CHECK(key && c1 && out0 && out1 && key->plan == p, "fhe_ks_fast_keyswitch_ext: bad key or null argument");
+    return ks_inner_run(p, lv, key, c1, batch, out0, out1, (uint64_t*)ws, w, st);
+}
+// LeveledSHECKKSRNS::EvalFastRotationExt (ckksrns-leveledshe.cpp:534-582): EvalFastKeySwitchCoreExt, optionally
+// + c0 * [P]_{q_i} on the first element's Q_l limbs, then the automorphism on both extended elements
+extern "C" fhe_status fhe_eval_fast_rotation_ext(fhe_ks_plan* p, const fhe_ks_key* key, const uint64_t* c0, const uint64_t* c1,
+                                                 uint32_t k, int addFirst, uint32_t sizeQl, uint32_t batch, uint64_t* out0,
+                                                 uint64_t* out1, void* ws, size_t wsBytes, void* st) {
+    KS_COMMON_CHECKS("fhe_eval_fast_rotation_ext")
+    ARG_CHECK(key && c0 && c1 && out0 && out1 && key->plan == p, "fhe_eval_fast_rotation_ext: bad key or null argument");
+    ARG_CHECK(k % 2 == 1, "Automorphism index not odd");
+    fhe_ctx* c    = p->ctx;
+    uint64_t* wsp = (uint64_t*)ws;
+    const uint32_t sizeQlP = sizeQl + p->sizeP;
+    if (fhe_status s = ks_inner_run(p, lv, key, c1, batch, wsp + w.e0, wsp + w.e1, wsp, w, st))
+        return s;
+    if (addFirst) {  // cTilda[0] += psiC0  (:561-570): e0 rows [0, sizeQl) += c0 * PModq
+        TwPair* dP = nullptr;
+        if (fhe_status s = ks_pmodq(p, lv, &dP))
+            return s;
+        if (fhe_status s = elem_run<OP_MUL_CONST_ADD>(c, wsp + w.e0, c0, wsp + w.e0, dP, nullptr, sizeQl, batch, st,
+                                                      "fhe_eval_fast_rotation_ext", 0, 0, sizeQlP, 0, sizeQlP, 0))
+            return s;
+    }
+    std::vector<uint32_t> idx;
+    ext_limbs(p, sizeQl, idx);
+    if (fhe_status s = fhe_automorph(c, out0, wsp + w.e0, k, 1, idx.data(), sizeQlP, batch, st))
+        return s;
+    return fhe_automorph(c, out1, wsp + w.e1, k, 1, idx.data(), sizeQlP, batch, st);
+}
+// KeySwitchHYBRID::KeySwitchDown (keyswitch-hybrid.cpp:245-278): ApproxModDown of both extended elements
+extern "C" fhe_status fhe_ks_down(fhe_ks_plan* p, const uint64_t* x0, const uint64_t* x1, uint32_t sizeQl, uint32_t batch,
+                                  uint64_t* out0, uint64_t* out1, void* ws, size_t wsBytes, void* st) {
+    KS_COMMON_CHECKS("fhe_ks_down")
+    ARG_CHECK(x0 && x1 && out0 && out1, "fhe_ks_down: null argument");
+    uint64_t* wsp = (uint64_t*)ws;
+    if (fhe_status s = mod_down_run(p, lv, x0, batch, out0, wsp + w.pcoef, wsp + w.md, st))
+        return s;
+    return mod_down_run(p, lv, x1, batch, out1, wsp + w.pcoef, wsp + w.md, st);
 }
 
 extern "C" fhe_status fhe_approx_mod_down(fhe_ks_plan* p, const uint64_t* x, uint32_t sizeQl, uint32_t batch,

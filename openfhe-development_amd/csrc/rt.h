@@ -43,6 +43,11 @@ inline const char* d2d_2d(void* d, size_t dpitch, const void* s, size_t spitch, 
         std::memmove((char*)d + r * dpitch, (const char*)s + r * spitch, width);
     return nullptr;
 }
+inline const char* dzero_2d(void* d, size_t pitch, size_t width, size_t height, stream_t) {
+    for (size_t r = 0; r < height; ++r)
+        std::memset((char*)d + r * pitch, 0, width);
+    return nullptr;
+}
 inline const char* sync(stream_t) { return nullptr; }
 inline const char* last_launch_error() { return nullptr; }
 struct Timer {
@@ -93,6 +98,9 @@ inline const char* d2d(void* d, const void* s, size_t n, stream_t st) {
 inline const char* d2d_2d(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height,
                           stream_t st) {
     return err(hipMemcpy2DAsync(d, dpitch, s, spitch, width, height, hipMemcpyDeviceToDevice, st));
+}
+inline const char* dzero_2d(void* d, size_t pitch, size_t width, size_t height, stream_t st) {
+    return err(hipMemset2DAsync(d, pitch, 0, width, height, st));
 }
 inline const char* sync(stream_t st) { return err(hipStreamSynchronize(st)); }
 inline const char* last_launch_error() { return err(hipGetLastError()); }

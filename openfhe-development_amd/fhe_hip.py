@@ -100,6 +100,10 @@ class Lib:
         S("fhe_ks_fast_keyswitch", C.c_int, [vp, vp, vp, u32, u32, vp, vp, vp, C.c_size_t, vp])
         S("fhe_eval_fast_rotation", C.c_int, [vp, vp, vp, vp, u32, u32, u32, vp, vp, vp, C.c_size_t, vp])
         S("fhe_eval_automorphism", C.c_int, [vp, vp, vp, vp, u32, u32, u32, vp, vp, vp, C.c_size_t, vp])
+        S("fhe_ks_ext", C.c_int, [vp, vp, u32, u32, vp, vp])
+        S("fhe_ks_fast_keyswitch_ext", C.c_int, [vp, vp, vp, u32, u32, vp, vp, vp, C.c_size_t, vp])
+        S("fhe_eval_fast_rotation_ext", C.c_int, [vp, vp, vp, vp, u32, C.c_int, u32, u32, vp, vp, vp, C.c_size_t, vp])
+        S("fhe_ks_down", C.c_int, [vp, vp, vp, u32, u32, vp, vp, vp, C.c_size_t, vp])
         S("fhe_approx_mod_down", C.c_int, [vp, vp, u32, u32, vp, vp, C.c_size_t, vp])
         S("fhe_approx_mod_down_bgv", C.c_int, [vp, vp, u32, u64, u32, vp, vp, C.c_size_t, vp])
         S("fhe_rescale_workspace_bytes", C.c_size_t, [vp, u32, u32])
@@ -444,6 +448,29 @@ class KeySwitchPlan:
         o0, o1 = c0.like(), c0.like()
         self.ctx.lib.check(self.ctx.lib.L.fhe_eval_fast_rotation(self.h, key, c0.ptr, c1.ptr, k, c0.n_limbs, c0.batch,
                                                                  o0.ptr, o1.ptr, ws, wsb, stream))
+        return o0, o1
+
+    def ext_limbs(self, sizeQl):
+        """context limbs of the extended basis Q_l u P"""
+        return np.concatenate([np.arange(sizeQl), np.arange(self.sizeQ, self.sizeQ + self.sizeP)]).astype(np.uint32)
+
+    def KeySwitchExt(self, c, stream=None):  # keyswitch-hybrid.cpp:217-243, one element
+        out = self.ctx.empty(c.batch, c.n_limbs + self.sizeP, self.ext_limbs(c.n_limbs))
+        self.ctx.lib.check(self.ctx.lib.L.fhe_ks_ext(self.h, c.ptr, c.n_limbs, c.batch, out.ptr, stream))
+        return out
+
+    def EvalFastRotationExt(self, key, c0, c1, k, add_first, stream=None):  # ckksrns-leveledshe.cpp:534-582 (digits in ws)
+        ws, wsb = self.workspace(c0.n_limbs, c0.batch)
+        idx = self.ext_limbs(c0.n_limbs)
+        o0, o1 = (self.ctx.empty(c0.batch, len(idx), idx) for _ in range(2))
+        self.ctx.lib.check(self.ctx.lib.L.fhe_eval_fast_rotation_ext(self.h, key, c0.ptr, c1.ptr, k, 1 if add_first else 0,
+                                                                     c0.n_limbs, c0.batch, o0.ptr, o1.ptr, ws, wsb, stream))
+        return o0, o1
+
+    def KeySwitchDown(self, x0, x1, sizeQl, stream=None):  # keyswitch-hybrid.cpp:245-278
+        ws, wsb = self.workspace(sizeQl, x0.batch)
+        o0, o1 = self.ctx.empty(x0.batch, sizeQl), self.ctx.empty(x0.batch, sizeQl)
+        self.ctx.lib.check(self.ctx.lib.L.fhe_ks_down(self.h, x0.ptr, x1.ptr, sizeQl, x0.batch, o0.ptr, o1.ptr, ws, wsb, stream))
         return o0, o1
 
     def EvalAutomorphism(self, key, c0, c1, k, stream=None):  # base-leveledshe.cpp:381-422

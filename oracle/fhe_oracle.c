@@ -1041,6 +1041,37 @@ void orc_eval_automorphism(const orc_hybrid* h, const uint64_t* c0, const uint64
     free(pre);
 }
 
+/* LeveledSHECKKSRNS::EvalFastRotationExt (ckksrns-leveledshe.cpp:534-582): cTilda = EvalFastKeySwitchCoreExt(digits of c1,
+ * key) in the extended basis Q_l u P; addFirst: cTilda[0] += c0 * [P]_{q_i} on the Q_l limbs (KeySwitchExt,
+ * keyswitch-hybrid.cpp:217-243); both elements through the automorphism.  out0/out1 [(sizeQl+sizeP)][N]. */
+void orc_eval_fast_rotation_ext(const orc_hybrid* h, const uint64_t* c0, const uint64_t* c1, uint32_t sizeQl, uint32_t k,
+                                int addFirst, const uint64_t* keyB, const uint64_t* keyA, uint64_t* out0, uint64_t* out1) {
+    const uint32_t N = h->N, sizeQlP = sizeQl + h->sizeP;
+    const uint32_t np = num_parts_at(h, sizeQl);
+    uint64_t* digits  = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)np * sizeQlP * N);
+    uint64_t* e0      = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)sizeQlP * N);
+    uint64_t* e1      = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)sizeQlP * N);
+    uint64_t* tmp     = (uint64_t*)malloc(sizeof(uint64_t) * N);
+    uint32_t* pre     = (uint32_t*)malloc(sizeof(uint32_t) * N);
+    orc_hybrid_precompute_digits(h, c1, sizeQl, digits);
+    orc_hybrid_inner_product(h, digits, np, sizeQl, keyB, keyA, e0, e1);
+    if (addFirst)
+        for (uint32_t i = 0; i < sizeQl; ++i) {
+            const uint64_t qi = h->q[i];
+            uint64_t PModq    = 1; /* rns-cryptoparameters.cpp:200-203 */
+            for (uint32_t j = 0; j < h->sizeP; ++j)
+                PModq = orc_mulmod(PModq, h->p[j] % qi, qi);
+            orc_vec_mul_const(tmp, c0 + (size_t)i * N, PModq, N, qi); /* TimesNoCheck(PModq) */
+            orc_vec_add(e0 + (size_t)i * N, e0 + (size_t)i * N, tmp, N, qi);
+        }
+    orc_precompute_auto_map(N, k, pre);
+    for (uint32_t i = 0; i < sizeQlP; ++i) {
+        orc_automorph_eval(out0 + (size_t)i * N, e0 + (size_t)i * N, N, pre);
+        orc_automorph_eval(out1 + (size_t)i * N, e1 + (size_t)i * N, N, pre);
+    }
+    free(digits), free(e0), free(e1), free(tmp), free(pre);
+}
+
 /* ------------------------------------------------------------------------------------------
  * a15: rescale
  * ---------------------------------------------------------------------------------------- */

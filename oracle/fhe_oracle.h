@@ -158,6 +158,9 @@ void orc_ckks_eval_mult_relin(const orc_hybrid*, const uint64_t* a0, const uint6
 
 /* LeveledSHEBase::EvalAutomorphism (base-leveledshe.cpp:381-422) == EvalFastRotation with freshly computed digits
  * (:432-463): out0 = Auto_k(c0 + ks0(c1)), out1 = Auto_k(ks1(c1)), all EVALUATION, key = the automorphism key of k */
+/* EvalFastRotationExt (ckksrns-leveledshe.cpp:534-582): result stays in the extended basis, out [(sizeQl+sizeP)][N] */
+void orc_eval_fast_rotation_ext(const orc_hybrid*, const uint64_t* c0, const uint64_t* c1, uint32_t sizeQl, uint32_t k,
+                                int addFirst, const uint64_t* keyB, const uint64_t* keyA, uint64_t* out0, uint64_t* out1);
 void orc_eval_automorphism(const orc_hybrid*, const uint64_t* c0, const uint64_t* c1, uint32_t sizeQl, uint32_t k,
                            const uint64_t* keyB, const uint64_t* keyA, uint64_t* out0, uint64_t* out1);
 

@@ -554,6 +554,18 @@ int ref_ckks_eval_fast_rotate(void* h, int ct, int32_t index) {  // hoisted: pre
     s->cts.push_back(s->cc->EvalFastRotation(s->cts[ct], index, s->cc->GetCyclotomicOrder(), digits));
     return static_cast<int>(s->cts.size()) - 1;
 }
+// double hoisting building blocks: EvalFastRotationExt (result in Q_l u P) and KeySwitchDown
+int ref_ckks_eval_fast_rotate_ext(void* h, int ct, int32_t index, int addFirst) {
+    auto* s     = static_cast<RefCkks*>(h);
+    auto digits = s->cc->EvalFastRotationPrecompute(s->cts[ct]);
+    s->cts.push_back(s->cc->EvalFastRotationExt(s->cts[ct], index, digits, addFirst != 0));
+    return static_cast<int>(s->cts.size()) - 1;
+}
+int ref_ckks_key_switch_down(void* h, int ctExt) {
+    auto* s = static_cast<RefCkks*>(h);
+    s->cts.push_back(s->cc->KeySwitchDown(s->cts[ctExt]));
+    return static_cast<int>(s->cts.size()) - 1;
+}
 int ref_omp_threads() { return OpenFHEParallelControls.GetNumThreads(); }
 
 // ---- ScaleAndRound family with caller tables ----

@@ -102,6 +102,7 @@ def load_oracle():
     S("orc_approx_scale_and_round", None, [P64, u32, u32, u32, P64, P64, P64, P64])
     S("orc_scale_and_round_p_over_q", None, [P64, u32, u32, P64, u64, P64, P64])
     S("orc_mod_reduce", None, [vp, P64, u32, u64, C.c_int, P64])
+    S("orc_eval_fast_rotation_ext", None, [vp, P64, P64, u32, u32, C.c_int, P64, P64, P64, P64])
     S("orc_hybrid_approx_mod_down_t", None, [vp, P64, u32, u64, P64])
     S("orc_expand_crt_basis", None, [vp, u32, u32, P64, C.c_int, P64, P64, P64, P64, P64, PF64, C.c_int, C.c_int, P64])
     S("orc_fast_expand_crt_basis_p_over_q", None, [P64, u32, u32, P64, P64, P64, P64, u32, P64, P64, P64, P64, P64, P64, u32,
@@ -182,6 +183,8 @@ def load_ref():
     S("ref_approx_scale_and_round", None, [u32, u32, u32, P64, P64, P64, P64, P64])
     S("ref_scale_and_round_p_over_q", None, [u32, u32, P64, P64, P64, P64, P64])
     S("ref_mod_reduce", None, [u32, u32, P64, P64, P64, u64, C.c_int, P64])
+    S("ref_ckks_eval_fast_rotate_ext", C.c_int, [vp, C.c_int, i32, C.c_int])
+    S("ref_ckks_key_switch_down", C.c_int, [vp, C.c_int])
     S("ref_approx_mod_down", None, [u32, u32, P64, P64, u32, P64, P64, P64, P64, P64, P64, u64, P64])
     S("ref_expand_crt_basis", None, [u32, u32, P64, P64, P64, C.c_int, P64, P64, P64, u32, P64, P64, PF64, C.c_int, C.c_int, P64])
     S("ref_fast_expand_crt_basis_p_over_q", None, [u32, u32, P64, P64, P64, P64, P64, u32, P64, P64, P64, P64, P64, u32, P64,

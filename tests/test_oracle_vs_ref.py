@@ -410,5 +410,21 @@ def test_rotations_against_live_reference(oracle, ref):
         rf = r.ref_ckks_eval_fast_rotate(h, ct, index)
         assert np.array_equal(o0, ex(rr, 0)) and np.array_equal(o1, ex(rr, 1))
         assert np.array_equal(o0, ex(rf, 0)) and np.array_equal(o1, ex(rf, 1))
+        # double hoisting: EvalFastRotationExt keeps the extended basis, KeySwitchDown ends it
+        for add_first in (1, 0):
+            re = r.ref_ckks_eval_fast_rotate_ext(h, ct, index, add_first)
+            cie = np.zeros(4, np.uint32)
+            r.ref_ct_info(h, re, cie)
+            assert int(cie[1]) == sizeQl + sizeP
+            w0, w1 = np.zeros((sizeQl + sizeP, N), np.uint64), np.zeros((sizeQl + sizeP, N), np.uint64)
+            r.ref_ct_export(h, re, 0, w0), r.ref_ct_export(h, re, 1, w1)
+            e0, e1 = np.zeros_like(w0), np.zeros_like(w0)
+            o.orc_eval_fast_rotation_ext(hy, c0, c1, sizeQl, k, add_first, keyB, keyA, e0, e1)
+            assert np.array_equal(e0, w0) and np.array_equal(e1, w1), "EvalFastRotationExt"
+            rd = r.ref_ckks_key_switch_down(h, re)
+            d0, d1 = np.zeros_like(c0), np.zeros_like(c0)
+            o.orc_hybrid_approx_mod_down(hy, e0, sizeQl, d0)
+            o.orc_hybrid_approx_mod_down(hy, e1, sizeQl, d1)
+            assert np.array_equal(d0, ex(rd, 0)) and np.array_equal(d1, ex(rd, 1)), "KeySwitchDown"
     o.orc_hybrid_destroy(hy)
     r.ref_ckks_destroy(h)

@@ -371,6 +371,42 @@ def test_hoisted_rotations(backend, oracle, logN, sizeQ, dnum, sizeQl, B):
     for k, hnd, (w0, w1) in zip(ks, handles, want):  # ... reused for every rotation key
         g0, g1 = plan.EvalFastRotation(hnd, t0, t1, k)
         assert np.array_equal(g0.to_host(), w0) and np.array_equal(g1.to_host(), w1), f"rotation k={k}"
+    # double hoisting: rotations that stay in the extended basis, summed there, one KeySwitchDown at the end
+    acc0 = acc1 = None
+    wacc0 = np.zeros((B, sizeQl + sizeP, N), np.uint64)
+    wacc1 = np.zeros_like(wacc0)
+    extq = np.concatenate([ql, p])
+    for j, (k, hnd, (kb, ka)) in enumerate(zip(ks, handles, keys)):
+        add_first = j % 2 == 0
+        e0, e1 = plan.EvalFastRotationExt(hnd, t0, t1, k, add_first)
+        w0, w1 = np.empty_like(wacc0), np.empty_like(wacc0)
+        for b in range(B):
+            o.orc_eval_fast_rotation_ext(hy, c0[b], c1[b], sizeQl, k, 1 if add_first else 0, kb, ka, w0[b], w1[b])
+        assert np.array_equal(e0.to_host(), w0) and np.array_equal(e1.to_host(), w1), f"EvalFastRotationExt k={k}"
+        for i, m in enumerate(extq):  # EvalAddExt: limb-wise modular add in the extended basis
+            wacc0[:, i] = (wacc0[:, i] + w0[:, i]) % m
+            wacc1[:, i] = (wacc1[:, i] + w1[:, i]) % m
+        if acc0 is None:
+            acc0, acc1 = e0, e1
+        else:
+            idx = plan.ext_limbs(sizeQl)
+            for acc, e in ((acc0, e0), (acc1, e1)):
+                backend.check(backend.L.fhe_add(ctx.h, acc.ptr, acc.ptr, e.ptr, idx.ctypes.data_as(fh.u32p), len(idx), B, None))
+    assert np.array_equal(acc0.to_host(), wacc0) and np.array_equal(acc1.to_host(), wacc1), "EvalAddExt"
+    d0, d1 = plan.KeySwitchDown(acc0, acc1, sizeQl)
+    wd0, wd1 = np.empty((B, sizeQl, N), np.uint64), np.empty((B, sizeQl, N), np.uint64)
+    for b in range(B):
+        o.orc_hybrid_approx_mod_down(hy, wacc0[b], sizeQl, wd0[b])
+        o.orc_hybrid_approx_mod_down(hy, wacc1[b], sizeQl, wd1[b])
+    assert np.array_equal(d0.to_host(), wd0) and np.array_equal(d1.to_host(), wd1), "KeySwitchDown"
+    # KeySwitchExt: c * [P]_{q_i} on the Q_l limbs, zeros on the P limbs
+    ext = plan.KeySwitchExt(t0).to_host()
+    P = 1
+    for v in p:
+        P *= int(v)
+    for i, m in enumerate(ql):
+        assert np.array_equal(ext[:, i], (c0[:, i].astype(object) * (P % int(m)) % int(m)).astype(np.uint64)), "KeySwitchExt"
+    assert not ext[:, sizeQl:].any()
     for hnd in handles:
         backend.L.fhe_ks_key_destroy(hnd)
     plan.close()
