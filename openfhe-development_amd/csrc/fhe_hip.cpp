@@ -490,9 +490,18 @@ static void mark_uniform(PassPlan& pp, uint32_t logN) {
 }
 
 static bool ntt_static();
+static uint32_t ntt_t1(uint32_t logN);
+static int static_mode(const fhe_ctx* c, const struct PassPlan& pp, bool inverse);
 static bool ntt_lds2();
 static bool ntt_rowtw();
 static bool ntt_legacy();
+// fused epilogue of a forward transform's last pass (NttPassArgs::epi*)
+struct NttEpilogue {
+    uint32_t mode = 0, split = 0, aStride = 0, aFirst = 0;
+    const uint64_t* A = nullptr;
+    const TwPair* C   = nullptr;
+    uint64_t *out0 = nullptr, *out1 = nullptr;
+};
 static uint32_t fill_pass_args(const fhe_ctx* c, const PassPlan& pp, bool inverse, const uint64_t* xin, uint64_t* xout,
                                const LimbSel& sel, uint32_t nLimbs, uint32_t batch, bool canonOut, uint32_t inStride,
                                uint32_t inFirst, uint32_t outStride, uint32_t outFirst, NttPassArgs& a) {
@@ -527,6 +536,8 @@ static uint32_t fill_pass_args(const fhe_ctx* c, const PassPlan& pp, bool invers
     const uint32_t grid        = tiles_for(c, a.rows);
     const uint32_t tilesPerRow = c->N >= (uint32_t)kTile ? (c->N >> kTileLog) : 1u;
     a.xcdSwizzle = (c->N >= (uint32_t)kTile && ((nLimbs * tilesPerRow) % 8u == 0)) ? 1u : 0u;
+    a.epiMode = 0, a.epiSplit = 0, a.epiAStride = 0, a.epiAFirst = 0;
+    a.epiA = nullptr, a.epiC = nullptr, a.epiOut0 = a.epiOut1 = nullptr;
     return grid;
 }
 // forward: bound class of a static pass's input; inverse: does the pass end the transform (ntt_static.h MODE)
@@ -539,10 +550,29 @@ static int static_mode(const fhe_ctx* c, const PassPlan& pp, bool inverse) {
 }
 static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse, const uint64_t* xin, uint64_t* xout,
                               const LimbSel& sel, uint32_t nLimbs, uint32_t batch, bool canonOut, void* stream,
-                              uint32_t inStride = 0, uint32_t inFirst = 0, uint32_t outStride = 0, uint32_t outFirst = 0) {
+                              uint32_t inStride = 0, uint32_t inFirst = 0, uint32_t outStride = 0, uint32_t outFirst = 0,
+                              const NttEpilogue* epi = nullptr) {
     NttPassArgs a;
     const uint32_t grid = fill_pass_args(c, pp, inverse, xin, xout, sel, nLimbs, batch, canonOut, inStride, inFirst, outStride,
                                          outFirst, a);
+    if (epi && epi->mode) {
+        // only the static forward row / single pass kernels carry the epilogue (ntt_epilogue_supported)
+        a.epiMode = epi->mode, a.epiSplit = epi->split, a.epiAStride = epi->aStride, a.epiAFirst = epi->aFirst;
+        a.epiA = epi->A, a.epiC = epi->C, a.epiOut0 = epi->out0, a.epiOut1 = epi->out1;
+        const int mode = static_mode(c, pp, inverse);
+        bool launched  = false;
+#define FHE_EPI_CASE(TT, MODE) \
+    if (!launched && !pp.layoutA && !inverse && pp.T == TT && mode == MODE) { \
+        FHE_LAUNCH((ntt_static_kernel<false, false, TT, MODE, false, true>), grid, stream, a); \
+        launched = true; \
+    }
+        FHE_EPI_CASE(12, 9) FHE_EPI_CASE(11, 9) FHE_EPI_CASE(10, 9) FHE_EPI_CASE(9, 9) FHE_EPI_CASE(12, 1)
+#undef FHE_EPI_CASE
+        if (!launched)
+            return fail(FHE_ERR_UNSUPPORTED, "ntt: no epilogue kernel for this pass shape");
+        LAUNCH_CHECK();
+        return FHE_OK;
+    }
     if (c->logN >= (uint32_t)kTileLog && !ntt_legacy() && ntt_static()) {
         // compile-time pass plans (ntt_static.h): in-place pinned-register butterflies, immediate-offset LDS exchange
         const bool twoPass = c->logN > (uint32_t)kTileLog;
@@ -648,9 +678,15 @@ static bool ntt_lds2() {
 
 // inStride != 0: xin is a [batch][inStride][N] view whose rows inFirst.. are transformed into the dense xout
 // outStride != 0: xout is a [batch][outStride][N] view as well (rows outFirst..)
+// does a forward transform of this ring end in a kernel that can carry the fused epilogue?
+static bool ntt_epilogue_supported(const fhe_ctx* c) {
+    if (c->logN < (uint32_t)kTileLog || c->logN > 16u || ntt_legacy() || !ntt_static())
+        return false;
+    return c->logN == (uint32_t)kTileLog || ntt_t1(c->logN) == 4u;  // row passes T2 = 9..12 after a 4-stage column pass
+}
 static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_t* xout, const uint32_t* limbIdx,
                           uint32_t nLimbs, uint32_t batch, void* stream, uint32_t inStride = 0, uint32_t inFirst = 0,
-                          uint32_t outStride = 0, uint32_t outFirst = 0) {
+                          uint32_t outStride = 0, uint32_t outFirst = 0, const NttEpilogue* epi = nullptr) {
     ARG_CHECK(c && xin && xout, "fhe_ntt: null argument");
     ARG_CHECK(batch >= 1, "fhe_ntt: batch must be >= 1");
     LimbSel sel;
@@ -666,7 +702,7 @@ static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_
         if (!inverse)
             schedule_fwd(p, logN, &bound);
         p.outBound = bound;
-        return launch_pass(c, p, inverse, xin, xout, sel, nLimbs, batch, true, stream, inStride, inFirst, outStride, outFirst);
+        return launch_pass(c, p, inverse, xin, xout, sel, nLimbs, batch, true, stream, inStride, inFirst, outStride, outFirst, epi);
     }
     // two passes over HBM: a strided column pass of T1 stages (the coefficient index's top bits) and a
     // contiguous row pass of T2 = logN - T1 stages.  T1 is kept minimal (>= 4) so that the column pass reads
@@ -692,7 +728,7 @@ static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_
     // resident slots of a CU away from the row workgroups: 33.2 ms instead of 30.4 ms per forward+inverse step).
     if (fhe_status s = launch_pass(c, p1, inverse, xin, xout, sel, nLimbs, batch, false, stream, inStride, inFirst, outStride, outFirst))
         return s;
-    return launch_pass(c, p2, inverse, xout, xout, sel, nLimbs, batch, true, stream, outStride, outFirst, outStride, outFirst);
+    return launch_pass(c, p2, inverse, xout, xout, sel, nLimbs, batch, true, stream, outStride, outFirst, outStride, outFirst, epi);
 }
 
 extern "C" fhe_status fhe_ntt_fwd(fhe_ctx* c, uint64_t* x, const uint32_t* li, uint32_t nl, uint32_t b, void* st) {
@@ -1337,7 +1373,7 @@ extern "C" size_t fhe_ks_workspace_bytes(const fhe_ks_plan* p, uint32_t sizeQl, 
 //   mod_down_core: x[nTow][sizeQl+sizeP][N] -> md[nTow][sizeQl][N] = NTT(ApproxSwitchCRTBasis(INTT(P part)))
 //   mod_down_tail: out_i = (x_i - md_i) * [P^-1]_{q_i}     (or out_i += ... when `accumulate`)
 static fhe_status mod_down_core(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const uint64_t* x, uint32_t nTow, uint64_t* pcoef,
-                                uint64_t* md, void* st, fhe_conv* down = nullptr) {
+                                uint64_t* md, void* st, fhe_conv* down = nullptr, const NttEpilogue* epi = nullptr) {
     fhe_ctx* c            = p->ctx;
     const uint32_t sizeQl = lv->sizeQl, sizeP = p->sizeP, sizeQlP = sizeQl + sizeP;
     std::vector<uint32_t> pIdx(sizeP);
@@ -1349,8 +1385,8 @@ static fhe_status mod_down_core(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const ui
     // P -> Q_l (:987-988)
     if (fhe_status s = fhe_approx_switch_basis(down ? down : lv->down, pcoef, sizeP, 0, md, sizeQl, 0, nTow, st))
         return s;
-    // back to EVALUATION (:1001)
-    return fhe_ntt_fwd(c, md, nullptr, sizeQl, nTow, st);
+    // back to EVALUATION (:1001); with an epilogue the last pass also applies (:1002) and stores the final result
+    return ntt_run(c, false, md, md, nullptr, sizeQl, nTow, st, 0, 0, 0, 0, epi);
 }
 static fhe_status mod_down_tail(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const uint64_t* x, const uint64_t* md, uint32_t nTow,
                                 uint64_t* out, bool accumulate, void* st) {
@@ -1418,6 +1454,14 @@ static fhe_status ks_fast_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const fhe_
         return s;
     // 2 x ApproxModDown (:381-400): e0 and e1 are adjacent in the workspace (w.e1 == w.e0 + batch*sizeQlP*N), so the
     // INTT / conversion / NTT run once over 2*batch towers; only the element-wise tails are per accumulator
+    if (ntt_epilogue_supported(c)) {
+        // (x_i - switched_i) * [P^-1]_{q_i} (+= into out for EvalMult) applied by the last NTT pass itself: the switched
+        // tower is never written to HBM in EVALUATION form and the two tail kernels disappear
+        NttEpilogue epi;
+        epi.mode = accumulate ? 2u : 1u, epi.split = batch, epi.aStride = sizeQl + p->sizeP, epi.aFirst = 0;
+        epi.A = ws + w.e0, epi.C = lv->d_PInv, epi.out0 = out0, epi.out1 = out1;
+        return mod_down_core(p, lv, ws + w.e0, 2 * batch, ws + w.pcoef, ws + w.md, st, nullptr, &epi);
+    }
     if (fhe_status s = mod_down_core(p, lv, ws + w.e0, 2 * batch, ws + w.pcoef, ws + w.md, st))
         return s;
     if (fhe_status s = mod_down_tail(p, lv, ws + w.e0, ws + w.md, batch, out0, accumulate, st))

@@ -78,6 +78,15 @@ struct NttPassArgs {
     uint32_t outFirst;    //    (applies to every access of a.x, i.e. stores and in-place reloads)
     NttStep steps[6];
     LimbSel sel;
+    // Optional epilogue of the pass that stores the transform's result (static forward kernels only): instead of the
+    // plain store, out = (A - r) * C [+ out]  — ApproxModDown's last line (dcrtpoly-impl.h:1002) fused with EvalMult's
+    // `+=` (base-leveledshe.cpp:210-211), so that the converted tower never goes to HBM.  epiMode 0: off,
+    // 1: out = (A - r) * C, 2: out += (A - r) * C.  Towers [0, epiSplit) go to epiOut0, the rest to epiOut1 (dense
+    // [towers][nLimbs][N]); A is a [towers][epiAStride][N] view (rows epiAFirst..), C one Shoup pair per tower row.
+    uint32_t epiMode, epiSplit, epiAStride, epiAFirst;
+    const uint64_t* epiA;
+    const TwPair* epiC;
+    uint64_t *epiOut0, *epiOut1;
 };
 
 // LDS word index swizzle: conflict-free ds_read_b64/ds_write_b64 for every register-field position

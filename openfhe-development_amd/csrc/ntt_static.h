@@ -170,6 +170,25 @@ FHE_HD void run_csub8_a(uint64_t (&r)[16], uint64_t m) {
             r[k] = csub2(r[k], m);
 #endif
 }
+// residues I and I|8 times the Shoup pair `cw`, lazily reduced to [0,2q)
+template <int I>
+FHE_HD void epi_mul2(uint64_t (&r)[16], const TwPair cw, const BflyConst c, const BflyZero z) {
+#ifdef FHE_PINNED_ASM
+    if constexpr (I == 0) mul2_s_0(r, cw, cw, c, z);
+    if constexpr (I == 1) mul2_s_1(r, cw, cw, c, z);
+    if constexpr (I == 2) mul2_s_2(r, cw, cw, c, z);
+    if constexpr (I == 3) mul2_s_3(r, cw, cw, c, z);
+    if constexpr (I == 4) mul2_s_4(r, cw, cw, c, z);
+    if constexpr (I == 5) mul2_s_5(r, cw, cw, c, z);
+    if constexpr (I == 6) mul2_s_6(r, cw, cw, c, z);
+    if constexpr (I == 7) mul2_s_7(r, cw, cw, c, z);
+#else
+    (void)z;
+    const uint64_t nq = ((uint64_t)c.nqh << 32) | c.nql;
+    r[I]     = shoup_acc(0, r[I], cw, nq);
+    r[I | 8] = shoup_acc(0, r[I | 8], cw, nq);
+#endif
+}
 FHE_HD void run_csub16(uint64_t (&r)[16], uint64_t m) {
 #ifdef FHE_PINNED_ASM
     csub16(r, m);
@@ -339,7 +358,7 @@ FHE_HD void lane_geom_s(uint32_t t, uint32_t S, uint32_t& Ib, uint32_t& jrel, ui
 // (its top stage is the transform's last stage, with N^-1 folded in), 0 = it does not.
 // DB: two LDS buffers alternate (one barrier per exchange, 68 KiB, 2 workgroups per CU) instead of one buffer with a
 // barrier on either side of the exchange (34 KiB, 4 workgroups per CU).
-template <bool LA, bool INV, int T, int MODE, bool DB>
+template <bool LA, bool INV, int T, int MODE, bool DB, bool EPI = false>
 FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) {
     using P = SPlan<LA, INV, T>;
     const uint32_t t    = FHE_TID;
@@ -408,6 +427,49 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
     uint32_t Ib, jrel;
     uint64_t ks;
     int buf = 0;  // LDS buffer of the next exchange
+    // final store of the pass, with the optional fused epilogue (NttPassArgs::epiMode)
+    auto store_result = [&](uint64_t (&v)[16], uint32_t jr, uint64_t kstr) {
+        if constexpr (!EPI) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                dst[jr + k * kstr] = v[k];
+        }
+        else {
+            const uint64_t* cw = reinterpret_cast<const uint64_t*>(a.epiC + rit);
+            const uint64_t cW = FHE_ULOAD64(cw, 0), cWp = FHE_ULOAD64(cw, 1);
+            const uint64_t* A  = a.epiA + ((((uint64_t)tb * a.epiAStride + a.epiAFirst + rit)) << logN) + jbase;
+            const bool second  = tb >= a.epiSplit;
+            uint64_t* O        = (second ? a.epiOut1 : a.epiOut0) +
+                          ((((uint64_t)(second ? tb - a.epiSplit : tb) * a.nLimbs + rit)) << logN) + jbase;
+            const bool acc = a.epiMode == 2u;
+            const TwPair cpair{cW, cWp};
+            // groups of 4 residues {2g, 2g+1, 2g+8, 2g+9} keep the extra live registers small; the multiplication
+            // by C runs in place on the pinned residues (ntt_bfly_pinned.h, mul2_s_*)
+#define FHE_EPI_GROUP(G)                                                                          \
+    {                                                                                             \
+        constexpr int ks4[4] = {2 * G, 2 * G + 1, 2 * G + 8, 2 * G + 9};                          \
+        uint64_t av[4], ov[4] = {0, 0, 0, 0};                                                     \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) av[k] = A[jr + ks4[k] * kstr];              \
+        if (acc) {                                                                                \
+            _Pragma("unroll") for (int k = 0; k < 4; ++k) ov[k] = O[jr + ks4[k] * kstr];          \
+        }                                                                                         \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) v[ks4[k]] = sub_mod(av[k], v[ks4[k]], q);   \
+        epi_mul2<2 * G>(v, cpair, c, z);                                                          \
+        epi_mul2<2 * G + 1>(v, cpair, c, z);                                                      \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                           \
+            uint64_t x = csub2(v[ks4[k]], q);                                                     \
+            if (acc)                                                                              \
+                x = add_mod(ov[k], x, q);                                                         \
+            O[jr + ks4[k] * kstr] = x;                                                            \
+        }                                                                                         \
+    }
+            FHE_EPI_GROUP(0)
+            FHE_EPI_GROUP(1)
+            FHE_EPI_GROUP(2)
+            FHE_EPI_GROUP(3)
+#undef FHE_EPI_GROUP
+        }
+    };
 
 #define FHE_SHARED_TW_TO_LDS()                                             \
     if constexpr (useShared) {                                             \
@@ -465,7 +527,7 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
             }                                                                                                     \
         }                                                                                                         \
         if constexpr (I == P::nst - 1 && !P::stageLast) {                                                         \
-            _Pragma("unroll") for (int k = 0; k < 16; ++k) dst[jrel + k * ks] = r[k];                             \
+            store_result(r, jrel, ks);                                                                            \
         }                                                                                                         \
         else {                                                                                                    \
             if constexpr (!DB && (I > 0 || P::stageFirst))                                                        \
@@ -488,20 +550,18 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
 #pragma unroll
         for (int k = 0; k < 16; ++k)
             FHE_LDS_LD(r[k], L[lds_pad((uint32_t)k << 8)]);
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-            dst[jrel + k * ks] = r[k];
+        store_result(r, jrel, ks);
     }
 }
 
-template <bool LA, bool INV, int T, int MODE, bool DB>
+template <bool LA, bool INV, int T, int MODE, bool DB, bool EPI = false>
 FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_static_kernel(const NttPassArgs a) {
     // a single-step pass without staging (the 4-stage column pass) never touches LDS: do not reserve any, so that
     // more workgroups fit on a CU
     using P = SPlan<LA, INV, T>;
     constexpr bool needsLds = P::nst > 1 || P::stageFirst || P::stageLast;
     FHE_SHARED_U64(lds, needsLds ? (DB ? 2 : 1) * kLdsPadWords + kSharedTwWords : 1);
-    ntt_static_body<LA, INV, T, MODE, DB>(a, FHE_BID, lds);
+    ntt_static_body<LA, INV, T, MODE, DB, EPI>(a, FHE_BID, lds);
 }
 
 }  // namespace fhe
