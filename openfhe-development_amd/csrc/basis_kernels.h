@@ -19,6 +19,7 @@
 #include "launch.h"
 #include "ntt_kernels.h"
 #include "elemwise_kernels.h"
+#include "ntt_static.h"  // FHE_PINNED_ASM, reduce192_uniform (generated gfx950 code)
 
 namespace fhe {
 
@@ -29,6 +30,7 @@ struct ConvTables {           // device-resident, built once per (source basis, 
     const uint64_t* srcQ;     // [32]
     const uint64_t* dstQ;     // [nDst]
     const uint64_t* dstMu;    // [nDst][2]  floor(2^128/p_j) (lo,hi)
+    const uint64_t* dstRed;   // [nDst][4]  {p_j, 2^64 mod p_j, its Shoup precon, floor(2^64/p_j)} for reduce192_uniform
     // exact variant only:
     const double* srcQInv;    // [32] 1.0/q_i
     const uint64_t* alphaMod; // [nSrc+1][nDst]  [alpha*Q]_{p_j}
@@ -66,6 +68,10 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) switch_basis_kernel(const ConvArgs g
         const uint32_t row = (uint32_t)i < g.nSrc ? (uint32_t)i : g.nSrc - 1u;
         xin[i]             = in[(uint64_t)row << g.logN];
     }
+#ifdef FHE_PINNED_ASM
+    BflyZero z{0, 0};
+    asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0" : "={v65}"(z.z0), "={v81}"(z.z1));
+#endif
     uint64_t y[NSRC];
     // overflow count of the exact variant: nu = 0.5 + sum_i y_i/q_i in double, i ascending, one rounding per
     // multiply and per add (dcrtpoly-impl.h:1056-1063); compiled with -ffp-contract=off
@@ -97,9 +103,17 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) switch_basis_kernel(const ConvArgs g
         for (int i = 0; i < NSRC; ++i)
             if (i < (int)g.nSrc)
                 mac192_add_uniform(m, y[i], h[i]);
+#ifdef FHE_PINNED_ASM
+        // any exact reduction equals BarrettUint128ModUint64; this one is hi*[2^64]_p + lo with Shoup (generated asm)
+        (void)mulo, (void)muhi;
+        const uint64_t* rc = g.tb.dstRed + 4 * (uint64_t)j;
+        const Reduce192Const kc{p, FHE_ULOAD64(rc, 1), FHE_ULOAD64(rc, 2), FHE_ULOAD64(rc, 3)};
+        uint64_t v = reduce192_uniform(m.c0, m.c1, m.c2, m.k0, m.k1, kc, z);
+#else
         u128w acc;
         mac192_fold(m, acc.lo, acc.hi);
         uint64_t v = barrett128(acc, p, mulo, muhi);
+#endif
         if (EXACT)
             v = sub_mod(v, g.tb.alphaMod[(uint64_t)alpha * g.nDst + j], p);
         out[(uint64_t)j << g.logN] = v;

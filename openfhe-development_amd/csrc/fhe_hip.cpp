@@ -979,8 +979,15 @@ static fhe_status conv_from_tables(fhe_ctx* c, const std::vector<uint64_t>& src,
         for (uint32_t j = 0; j < nDst; ++j)
             hatMod[(size_t)j * pad + i] = hatModIn[(size_t)i * nDst + j] % dst[j];
     }
-    for (uint32_t j = 0; j < nDst; ++j)
+    std::vector<uint64_t> red(4 * (size_t)nDst);
+    for (uint32_t j = 0; j < nDst; ++j) {
         host::mu128(dst[j], &mu[2 * j]);
+        const uint64_t R = (uint64_t)((((unsigned __int128)1) << 64) % dst[j]);
+        red[4 * j]       = dst[j];
+        red[4 * j + 1]   = R;
+        red[4 * j + 2]   = host::shoup(R, dst[j]);
+        red[4 * j + 3]   = (uint64_t)((((unsigned __int128)1) << 64) / dst[j]);
+    }
     if (alphaIn)
         for (size_t k = 0; k < alphaMod.size(); ++k)
             alphaMod[k] = alphaIn[k] % dst[k % nDst];
@@ -990,6 +997,7 @@ static fhe_status conv_from_tables(fhe_ctx* c, const std::vector<uint64_t>& src,
         (s = conv_upload(cv, srcPad.data(), srcPad.size() * 8, (const void**)&cv->tb.srcQ)) ||
         (s = conv_upload(cv, dst.data(), dst.size() * 8, (const void**)&cv->tb.dstQ)) ||
         (s = conv_upload(cv, mu.data(), mu.size() * 8, (const void**)&cv->tb.dstMu)) ||
+        (s = conv_upload(cv, red.data(), red.size() * 8, (const void**)&cv->tb.dstRed)) ||
         (s = conv_upload(cv, qInv.data(), qInv.size() * sizeof(double), (const void**)&cv->tb.srcQInv)) ||
         (s = conv_upload(cv, alphaMod.data(), alphaMod.size() * 8, (const void**)&cv->tb.alphaMod))) {
         fhe_conv_destroy(cv);

@@ -143,6 +143,28 @@ def subbco(d, sd, a, b, sc):
     return ins(f"v_subb_co_u32_e64 {d}, {sd}, {a}, {b}, {sc}", rd=[sc], wr=[sd], sim=sim)
 
 
+def addco(d, sd, a, b):
+    def sim(S):
+        r = S.g(a) + S.g(b)
+        S.v[int(d[1:])] = r & M32
+        S.s[sd] = r >> 32
+    return ins(f"v_add_co_u32_e64 {d}, {sd}, {a}, {b}", wr=[sd], sim=sim)
+
+
+def addcco(d, sd, a, b, sc):
+    def sim(S):
+        r = S.g(a) + S.g(b) + S.s[sc]
+        S.v[int(d[1:])] = r & M32
+        S.s[sd] = r >> 32
+    return ins(f"v_addc_co_u32_e64 {d}, {sd}, {a}, {b}, {sc}", rd=[sc], wr=[sd], sim=sim)
+
+
+def mov64(d, a):
+    def sim(S):
+        S.set64(d, S.g64(a))
+    return ins(f"v_mov_b64 {d}, {a}", sim=sim)
+
+
 def cmplt64(sd, a, b):
     def sim(S):
         S.s[sd] = 1 if S.g64(a) < S.g64(b) else 0
@@ -214,6 +236,70 @@ def csub_stream(i, A):
         cnd(v(A), v(D), v(A), c),
         cnd(v(A + 1), v(D + 1), v(A + 1), c),
     ]
+
+
+def reduce192_stream():
+    """(c0 + c1*2^32 + c2*2^64 + k0*2^64 + k1*2^96) mod p for a sum < 2^128, canonical:  hi*R + lo with R = 2^64 mod p
+    (Shoup), lo reduced with mu64 = floor(2^64/p), two conditional subtractions.  Operands: c0l..c2h, k0, k1 (VGPR
+    words), scalars Rl,Rh,Rpl,Rph (R and its Shoup precon), mul,muh (mu64), nql,nqh (2^64-p), p, twop, np, ntwop."""
+    t = T(0)
+    A1, A2, A3 = 76, 78, 79  # a1 | a2, a3 (t.Y = 76..77, t.D = 78..79)
+    LO = 76                  # pair {c0l copy, a1}: v76 = c0l, v77 = a1
+    A1 = 77
+    c0, c1 = t.c0, t.c1
+    fold = [
+        mov(v(LO), "%[c0l]"),
+        addco(v(A1), c0, "%[c0h]", "%[c1l]"),
+        addco(v(A2), c1, "%[c2l]", "%[k0]"),
+        addcco(v(A2), c0, v(A2), "%[c1h]", c0),
+        addcco(v(A3), c1, "%[c2h]", "%[k1]", c1),
+        addcco(v(A3), c0, v(A3), "0", c0),
+    ]
+    # t = shoup(hi, R): temps Z,L,C,H,Q,X of slot 0; result pair -> t.L... use dst = p(t.C) after C is dead? keep separate: slot-1 regs
+    u = T(1)
+    hw = {"wl": "%[Rl]", "wh": "%[Rh]", "pl": "%[Rpl]", "ph": "%[Rph]"}
+    yl, yh = v(A2), v(A3)
+    sh = [
+        mulhi(v(t.Z), yl, hw["pl"]),
+        mad(p(t.X), DEAD, yl, hw["wh"], "0"),
+        mad(p(t.L), DEAD, yh, hw["pl"], p(t.Z)),
+        mad(p(t.C), c1, yl, hw["ph"], p(t.L)),
+        mad(p(t.X), DEAD, yh, hw["wl"], p(t.X)),
+        mov(v(t.H), v(t.C + 1)),
+        cnd01(v(t.H + 1), c1),
+        mad(p(t.Q), DEAD, yh, hw["ph"], p(t.H)),
+        mad(p(t.L), DEAD, yl, hw["wl"], "0"),
+        mad(p(t.X), DEAD, v(t.Q), "%[nqh]", p(t.X)),
+        mad(p(t.X), DEAD, v(t.Q + 1), "%[nql]", p(t.X)),
+        add32(v(t.L + 1), v(t.L + 1), v(t.X)),
+        mad(p(u.L), DEAD, v(t.Q), "%[nql]", p(t.L)),  # t in u.L, [0,2p)
+    ]
+    # r = lo - hi64(lo*mu64)*p   (lo = v[76:77])
+    lo = [
+        mulhi(v(u.Z), v(LO), "%[mul]"),
+        mad(p(u.C), DEAD, v(A1), "%[mul]", p(u.Z)),
+        mad(p(u.H), u.c0, v(LO), "%[muh]", p(u.C)),
+        mov(v(u.Q), v(u.H + 1)),
+        cnd01(v(u.Q + 1), u.c0),
+        mad(p(u.X), DEAD, v(A1), "%[muh]", p(u.Q)),       # Q = u.X
+        mad(p(u.C), DEAD, v(u.X), "%[nql]", p(LO)),       # L = Ql*nql + lo
+        mad(p(u.H), DEAD, v(u.X), "%[nqh]", "0"),
+        mad(p(u.H), DEAD, v(u.X + 1), "%[nql]", p(u.H)),
+        add32(v(u.C + 1), v(u.C + 1), v(u.H)),             # r in u.C, [0,2p)
+    ]
+    fin = [
+        lshladd(p(u.L), p(u.L), 0, p(u.C)),                # s = t + r < 4p
+        lshladd(p(u.Y), p(u.L), 0, "%[ntwop]"),
+        cmplt64(u.c1, p(u.L), "%[twop]"),
+        cnd(v(u.L), v(u.Y), v(u.L), u.c1),
+        cnd(v(u.L + 1), v(u.Y + 1), v(u.L + 1), u.c1),
+        lshladd(p(u.Y), p(u.L), 0, "%[np]"),
+        cmplt64(u.c1, p(u.L), "%[p]"),
+        cnd(v(u.L), v(u.Y), v(u.L), u.c1),
+        cnd(v(u.L + 1), v(u.Y + 1), v(u.L + 1), u.c1),
+        mov64("%[out]", p(u.L)),
+    ]
+    return fold, sh, lo, fin
 
 
 def schedule(streams):
@@ -300,6 +386,44 @@ def check_blocks():
         run(schedule([csub_stream(i, R(4 + i)) for i in range(4)]), S)
         for i, x0 in enumerate(xs):
             assert S.g64(p(R(4 + i))) == (x0 if x0 < m else x0 - m), "csub"
+    # 192-bit column sums -> canonical residue
+    for it in range(4000):
+        bits = rnd.choice([28, 45, 59, 60])
+        pm = rnd.getrandbits(bits) | (1 << (bits - 1)) | 1
+        n = rnd.randrange(1, 17)
+        c0 = c1 = c2 = 0
+        for _ in range(n):
+            a, b = rnd.randrange(pm) if rnd.random() < 0.9 else pm - 1, rnd.randrange(pm) if rnd.random() < 0.9 else pm - 1
+            c0 += (a & M32) * (b & M32)
+            c1 += (a & M32) * (b >> 32) + (a >> 32) * (b & M32)
+            c2 += (a >> 32) * (b >> 32)
+        total = c0 + (c1 << 32) + (c2 << 64)
+        assert total < 1 << 128
+        k0, c0 = c0 >> 64, c0 & M64
+        k1, c1 = c1 >> 64, c1 & M64
+        assert c2 < 1 << 64
+        Rm = (1 << 64) % pm
+        Rp = (Rm << 64) // pm
+        mu = (1 << 64) // pm
+        if mu > M64:
+            mu = M64
+        S = St()
+        S.v[T(0).Z + 1] = S.v[T(1).Z + 1] = 0
+        S.ops = {"c0l": c0 & M32, "c0h": c0 >> 32, "c1l": c1 & M32, "c1h": c1 >> 32, "c2l": c2 & M32, "c2h": c2 >> 32,
+                 "k0": k0, "k1": k1, "Rl": Rm & M32, "Rh": Rm >> 32, "Rpl": Rp & M32, "Rph": Rp >> 32, "mul": mu & M32,
+                 "muh": mu >> 32, "nql": (-pm) & M32, "nqh": ((-pm) & M64) >> 32, "p": pm, "twop": 2 * pm,
+                 "np": (-pm) & M64, "ntwop": (-2 * pm) & M64}
+        fold, sh, lo, fin = reduce192_stream()
+        outreg = {}
+
+        def run_out(block):
+            for c in block:
+                if c["t"].startswith("v_mov_b64 %[out]"):
+                    outreg["v"] = S.g64(p(T(1).L))
+                else:
+                    c["sim"](S)
+        run_out(schedule([fold]) + schedule([sh, lo]) + schedule([fin]))
+        assert outreg["v"] == total % pm, "reduce192"
     return True
 
 
@@ -412,6 +536,32 @@ struct BflyZero {   // two VGPRs holding 0 (high halves of the zero-extended mul
         H.append(emit_mul_fn(f"mul2_s_{i}", i, i | 8, "s"))
     for i in range(4):
         H.append(emit_csub_fn(f"csub4_{i}", [4 * i + j for j in range(4)]))
+    fold, sh, lo, fin = reduce192_stream()
+    block = schedule([fold]) + schedule([sh, lo]) + schedule([fin])
+    regs = [f"v{r}" for r in range(64, 96) if r not in (65, 81)] + [f"s{r}" for r in range(40, 50)]
+    text = "\n".join(f'        "{c["t"]}\\n\\t"' for c in block)
+    H.append("""// Column sums of mac192 (value < 2^128) -> canonical residue mod p, p and its constants wave-uniform:
+// value = hi*2^64 + lo  ==  hi*R + lo (mod p), R = 2^64 mod p as a Shoup pair; lo is reduced with mu64 = floor(2^64/p).
+// Any exact reduction equals the reference's BarrettUint128ModUint64 (utilities-int.h:60-99).
+struct Reduce192Const {
+    uint64_t p, R, Rp, mu64;
+};
+__device__ __forceinline__ uint64_t reduce192_uniform(uint64_t c0, uint64_t c1, uint64_t c2, uint32_t k0, uint32_t k1,
+                                                      const Reduce192Const k, const BflyZero z) {
+    uint64_t out;
+    const uint64_t nq = 0 - k.p, twop = k.p << 1, ntwop = 0 - twop;
+    asm volatile(
+""" + text + """
+        : [out] "=v"(out)
+        : [c0l] "v"((uint32_t)c0), [c0h] "v"((uint32_t)(c0 >> 32)), [c1l] "v"((uint32_t)c1), [c1h] "v"((uint32_t)(c1 >> 32)),
+          [c2l] "v"((uint32_t)c2), [c2h] "v"((uint32_t)(c2 >> 32)), [k0] "v"(k0), [k1] "v"(k1),
+          [Rl] "s"((uint32_t)k.R), [Rh] "s"((uint32_t)(k.R >> 32)), [Rpl] "s"((uint32_t)k.Rp), [Rph] "s"((uint32_t)(k.Rp >> 32)),
+          [mul] "s"((uint32_t)k.mu64), [muh] "s"((uint32_t)(k.mu64 >> 32)), [nql] "s"((uint32_t)nq), [nqh] "s"((uint32_t)(nq >> 32)),
+          [p] "s"(k.p), [twop] "s"(twop), [np] "s"(nq), [ntwop] "s"(ntwop), "{v65}"(z.z0), "{v81}"(z.z1)
+        : """ + ", ".join(f'"{r}"' for r in regs) + """);
+    return out;
+}
+""")
     H.append("""__device__ __forceinline__ void csub16(uint64_t (&r)[16], uint64_t m) {
     const uint64_t negm = 0 - m;
     csub4_0(r, m, negm);
