@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--no-evalmult", action="store_true")
     ap.add_argument("--evalmult-batch", type=int, default=64, help="ciphertexts per GPU in the EvalMult leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--bfv", action="store_true", help="also time BFV EvalMult (BEHZ), BASELINE configs[4] shape")
+    ap.add_argument("--no-bfv", action="store_true", help="skip the BFV EvalMult (BEHZ) leg (BASELINE configs[4] shape)")
     ap.add_argument("--bfv-batch", type=int, default=64)
     return ap.parse_args()
 
@@ -335,7 +335,7 @@ def main():
 
     em = None
     if not a.no_evalmult and logN == 16:
-        em = evalmult_leg(lib, device, logN, a.evalmult_batch, max(2, a.steps // 3), 1, gpu_sync)
+        em = evalmult_leg(lib, device, logN, a.evalmult_batch, max(4, a.steps // 2), 2, gpu_sync)
         if dist is not None:
             tt = torch.tensor([em["ops_per_s_per_gpu"]], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.SUM)
@@ -344,8 +344,8 @@ def main():
             em["ops_per_s_total"] = em["ops_per_s_per_gpu"]
 
     bfv = None
-    if a.bfv:
-        bfv = bfv_leg(lib, device, a.bfv_batch, max(2, a.steps // 3), 1, gpu_sync,
+    if not a.no_bfv and logN == 16:
+        bfv = bfv_leg(lib, device, a.bfv_batch, max(10, a.steps), 3, gpu_sync,
                       rank == 0 and world == 1 and not a.no_cpu_baseline)
 
     cpu = None

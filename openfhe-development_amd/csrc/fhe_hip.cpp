@@ -284,7 +284,9 @@ extern "C" fhe_status fhe_ctx_create(uint32_t logN, uint32_t nLimbs, const uint6
     std::vector<TwPair> twRow(rowPerLimb * nLimbs), twRowInv(rowPerLimb * nLimbs);
     std::vector<LimbConst> lc(nLimbs);
     std::vector<uint64_t> mu(2 * (size_t)nLimbs);
-#pragma omp parallel for schedule(dynamic)
+    // one thread per limb at most: a team of every host core would keep spinning after the region (libgomp's default
+    // wait policy) and slow down the caller's kernel launches for a while
+#pragma omp parallel for schedule(dynamic) num_threads(std::max(1, std::min<int>((int)nLimbs, 32)))
     for (uint32_t l = 0; l < nLimbs; ++l) {
         const uint64_t ql = q[l], ps = psi[l], psInv = host::invmod(ps, ql);
         uint64_t x = 1, xi = 1;

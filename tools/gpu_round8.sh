@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 export FHE_BENCH_NO_TORCH=1
 echo "== gpu tests"; timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
-echo "== bench static"; timeout 900 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --bfv 2>&1 | tail -1 > gpurun_out/bench_r8.json; python -c "
+echo "== bench static"; timeout 900 python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_r8.json; python -c "
 import json;d=json.load(open('gpurun_out/bench_r8.json'));print(d['value'],d['ms_per_step'],d['roofline']);print(d['evalmult']);print(d.get('bfv_evalmult'))"
 echo "== bench run-time plan (FHE_NTT_STATIC=0)"; FHE_NTT_STATIC=0 timeout 900 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-evalmult 2>&1 | tail -1 | python -c "
 import json,sys;d=json.loads(sys.stdin.readline());print(d['value'],d['ms_per_step'],d['roofline'])"
