@@ -272,6 +272,19 @@ fhe_status fhe_scale_and_round(fhe_sr_plan* plan, const uint64_t* x, int outputF
 fhe_status fhe_scale_and_round_p_over_q(fhe_ctx* ctx, const uint64_t* x, const uint32_t* limbIdx, uint32_t sizeQ,
                                         uint64_t* out, uint32_t batch, void* stream);
 
+/* ScaleAndRound -> NativePoly modulo t, the BFV decryption step (dcrtpoly-impl.h:1190-1467): x [batch][sizeQ][N]
+ * COEFFICIENT over the context limbs limbIdx (NULL: 0..sizeQ-1) -> out [batch][N] residues mod t.  Tables are the
+ * reference's tQHatInvModqDivqModt, tQHatInvModqBDivqModt, tQHatInvModqDivqFrac, tQHatInvModqDivqBFrac (the two "B"
+ * tables may be NULL when max(q_i) and sizeQ keep the reference on its unsplit branches); which of the reference's eight
+ * branches runs is decided from (max q_i, t, sizeQ) exactly as there.  fhe_scale_and_round_behz_decrypt is the BEHZ
+ * overload (:1631-1671) with tgammaQHatModq / negInvqModtgamma, gamma = 2^26. */
+fhe_status fhe_scale_and_round_native(fhe_ctx* ctx, const uint64_t* x, const uint32_t* limbIdx, uint32_t sizeQ, uint64_t t,
+                                      const uint64_t* tabModt, const uint64_t* tabBModt, const double* frac,
+                                      const double* bfrac, uint32_t batch, uint64_t* out, void* stream);
+fhe_status fhe_scale_and_round_behz_decrypt(fhe_ctx* ctx, const uint64_t* x, const uint32_t* limbIdx, uint32_t sizeQ,
+                                            uint64_t tgamma, const uint64_t* tgammaQHatModq,
+                                            const uint64_t* negInvqModtgamma, uint32_t batch, uint64_t* out, void* stream);
+
 /* ---- a18: BEHZ base conversions (BFV) ---------------------------------------------------------------------
  * fhe_behz_create builds the tables of CryptoParametersBFVRNS's BEHZ block
  * (src/pke/lib/scheme/bfvrns/bfvrns-cryptoparameters.cpp:673-850) for the basis Q (context limbs qLimbIdx) and

@@ -82,6 +82,78 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) scale_round_kernel(const ScaleRoundA
     }
 }
 
+// ---- ScaleAndRound -> NativePoly mod t (decryption, dcrtpoly-impl.h:1190-1467) and the BEHZ overload (:1631-1671) ----
+struct ScaleRoundNativeArgs {
+    TowerView in;            // sizeQ rows, COEFFICIENT
+    uint64_t* out;           // [batch][N] residues mod t
+    const uint64_t* q;       // [sizeQ] moduli of the rows (BEHZ overload)
+    const TwPair* tabModt;   // [sizeQ] (value, Shoup precon mod t)   | BEHZ: tgammaQHatModq (precon mod q_i)
+    const TwPair* tabBModt;  // [sizeQ] the "B" table                  | BEHZ: negInvqModtgamma (precon mod t*gamma)
+    const double* frac;      // [sizeQ]
+    const double* bfrac;     // [sizeQ]
+    uint64_t t;              // BEHZ: t * gamma
+    uint32_t logN, batch, sizeQ, qMSBHf;
+    uint32_t pow2, split, nomod;  // the reference's branch conditions, evaluated on the host (:1198-1218 ff)
+};
+// the reference's ModMulFastConst (ubintnat.h:1464-1469): operand may exceed the modulus
+FHE_HD uint64_t mod_mul_fast_const(uint64_t a, uint64_t b, uint64_t m, uint64_t bInv) {
+    const uint64_t qq = mulhi64(a, bInv) + 1;
+    const int64_t y   = (int64_t)(a * b - qq * m);
+    return y >= 0 ? (uint64_t)y : (uint64_t)y + m;
+}
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) scale_round_native_kernel(const ScaleRoundNativeArgs g) {
+    const uint64_t gid = (uint64_t)FHE_BID * kThreads + FHE_TID;
+    if (gid >= ((uint64_t)g.batch << g.logN))
+        return;
+    const uint32_t b = (uint32_t)(gid >> g.logN), ri = (uint32_t)gid & ((1u << g.logN) - 1u);
+    const uint64_t t = g.t;
+    double floatSum  = g.pow2 ? 0.5 : 0.0;
+    uint64_t intSum  = 0;
+    for (uint32_t i = 0; i < g.sizeQ; ++i) {
+        const uint64_t v = *tv_at(g.in, b, i, g.logN, ri);
+        const TwPair ta  = g.tabModt[i];
+        if (!g.split) {
+            floatSum += (double)v * FHE_ULOADF64(g.frac, i);
+            intSum += g.nomod ? v * ta.w : mod_mul_fast_const(v, ta.w, t, ta.wp);
+        }
+        else {
+            const TwPair tbm = g.tabBModt[i];
+            const uint64_t hi = v >> g.qMSBHf, lo = v - (hi << g.qMSBHf);
+            floatSum += (double)lo * FHE_ULOADF64(g.frac, i);
+            floatSum += (double)hi * FHE_ULOADF64(g.bfrac, i);
+            intSum += g.nomod ? lo * ta.w : mod_mul_fast_const(lo, ta.w, t, ta.wp);
+            intSum += g.nomod ? hi * tbm.w : mod_mul_fast_const(hi, tbm.w, t, tbm.wp);
+        }
+    }
+    uint64_t r;
+    if (g.pow2) {
+        intSum += (uint64_t)floatSum;
+        r = intSum & (t - 1);
+    }
+    else {
+        const double td = (double)t, tInv = 1. / td;
+        floatSum += (double)intSum;
+        floatSum -= td * (double)(uint64_t)(floatSum * tInv);
+        r = (uint64_t)(floatSum + 0.5);
+    }
+    g.out[((uint64_t)b << g.logN) + ri] = r;
+}
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) scale_round_behz_decrypt_kernel(const ScaleRoundNativeArgs g) {
+    const uint64_t gid = (uint64_t)FHE_BID * kThreads + FHE_TID;
+    if (gid >= ((uint64_t)g.batch << g.logN))
+        return;
+    const uint32_t b = (uint32_t)(gid >> g.logN), ri = (uint32_t)gid & ((1u << g.logN) - 1u);
+    const uint64_t tgamma = g.t, gammaMinus1 = (1u << 26) - 1;
+    uint64_t s = 0;
+    for (uint32_t i = 0; i < g.sizeQ; ++i) {
+        const TwPair ta = g.tabModt[i], tb2 = g.tabBModt[i];
+        const uint64_t a = mod_mul_fast_const(*tv_at(g.in, b, i, g.logN, ri), ta.w, g.q[i], ta.wp);
+        s                = add_mod(s, mod_mul_fast_const(a, tb2.w, tgamma, tb2.wp), tgamma);
+    }
+    s += s & gammaMinus1;
+    g.out[((uint64_t)b << g.logN) + ri] = s >> 26;
+}
+
 // ---- ScaleAndRoundPOverQ ----------------------------------------------------------------------------
 struct POverQArgs {
     TowerView x;    // [sizeQ+1] rows, the last one modulo pLast

@@ -1940,6 +1940,110 @@ extern "C" fhe_status fhe_scale_and_round_p_over_q(fhe_ctx* c, const uint64_t* x
     return FHE_OK;
 }
 
+// DCRTPolyImpl::ScaleAndRound -> NativePoly mod t (dcrtpoly-impl.h:1190-1467, BFV HPS decryption) with the caller's
+// tables tQHatInvModqDivqModt / tQHatInvModqBDivqModt / tQHatInvModqDivqFrac / tQHatInvModqDivqBFrac; the branch the
+// reference takes depends only on (max q_i, t, sizeQ) and is selected here with its own conditions.
+static uint32_t msb64(uint64_t v) {
+    uint32_t n = 0;
+    while (v)
+        ++n, v >>= 1;
+    return n;
+}
+static fhe_status native_tables(fhe_ctx* c, uint32_t sizeQ, const uint64_t* a, const uint64_t* b, const uint64_t* modA,
+                                const uint64_t* modB, std::vector<TwPair>& h) {
+    h.assign(2 * (size_t)sizeQ, TwPair{0, 0});
+    for (uint32_t i = 0; i < sizeQ; ++i) {
+        h[i] = TwPair{a[i], host::shoup(a[i], modA[i])};  // PrepModMulConst: table values are residues of their modulus
+        if (b)
+            h[sizeQ + i] = TwPair{b[i], host::shoup(b[i], modB[i])};
+    }
+    (void)c;
+    return FHE_OK;
+}
+extern "C" fhe_status fhe_scale_and_round_native(fhe_ctx* c, const uint64_t* x, const uint32_t* limbIdx, uint32_t sizeQ,
+                                                 uint64_t t, const uint64_t* tabModt, const uint64_t* tabBModt,
+                                                 const double* frac, const double* bfrac, uint32_t batch, uint64_t* out,
+                                                 void* st) {
+    ARG_CHECK(c && x && tabModt && frac && out && batch >= 1, "fhe_scale_and_round_native: bad argument");
+    ARG_CHECK(sizeQ >= 1 && sizeQ <= (uint32_t)kMaxLimbs && t >= 2, "fhe_scale_and_round_native: bad basis size or t");
+    RT_CHECK(rt::set_device(c->device));
+    uint64_t qmax = 0;
+    for (uint32_t i = 0; i < sizeQ; ++i) {
+        const uint32_t l = limbIdx ? limbIdx[i] : i;
+        ARG_CHECK(l < c->L, "fhe_scale_and_round_native: limb index exceeds context size");
+        qmax = std::max(qmax, c->q[l]);
+    }
+    ScaleRoundNativeArgs g;
+    const uint32_t qMSB = msb64(qmax), tMSB = msb64(t), sizeQMSB = msb64(sizeQ);
+    g.qMSBHf = qMSB >> 1;
+    g.pow2   = (t & (t - 1)) == 0 ? 1u : 0u;
+    g.split  = (qMSB + sizeQMSB < 52) ? 0u : 1u;
+    if (!g.split)
+        g.nomod = g.pow2 ? (qMSB + sizeQMSB + tMSB < 63) : (qMSB + tMSB + sizeQMSB < 52);
+    else
+        g.nomod = g.pow2 ? (g.qMSBHf + tMSB + sizeQMSB < 62) : (g.qMSBHf + tMSB + sizeQMSB < 52);
+    ARG_CHECK(!g.split || (tabBModt && bfrac), "fhe_scale_and_round_native: this (q, t, sizeQ) needs the B tables");
+    std::vector<uint64_t> tv(sizeQ, t);
+    std::vector<TwPair> h;
+    native_tables(c, sizeQ, tabModt, g.split ? tabBModt : nullptr, tv.data(), tv.data(), h);
+    std::vector<double> fr(2 * (size_t)sizeQ, 0.0);
+    for (uint32_t i = 0; i < sizeQ; ++i) {
+        fr[i] = frac[i];
+        if (g.split)
+            fr[sizeQ + i] = bfrac[i];
+    }
+    void *dT = nullptr, *dF = nullptr;
+    RT_CHECK(rt::dmalloc(&dT, h.size() * sizeof(TwPair)));
+    RT_CHECK(rt::dmalloc(&dF, fr.size() * sizeof(double)));
+    RT_CHECK(rt::h2d(dT, h.data(), h.size() * sizeof(TwPair), (rt::stream_t)st));
+    RT_CHECK(rt::h2d(dF, fr.data(), fr.size() * sizeof(double), (rt::stream_t)st));
+    g.in = TowerView{const_cast<uint64_t*>(x), sizeQ, 0};
+    g.out = out, g.q = nullptr;
+    g.tabModt = (TwPair*)dT, g.tabBModt = (TwPair*)dT + sizeQ;
+    g.frac = (double*)dF, g.bfrac = (double*)dF + sizeQ;
+    g.t = t, g.logN = c->logN, g.batch = batch, g.sizeQ = sizeQ;
+    FHE_LAUNCH(scale_round_native_kernel, (uint32_t)((((uint64_t)batch << g.logN) + kThreads - 1) / kThreads), st, g);
+    const char* le = rt::last_launch_error();
+    RT_CHECK(rt::sync((rt::stream_t)st));  // decryption is a once-per-result call: tables live for this call only
+    rt::dfree(dT), rt::dfree(dF);
+    RT_CHECK(le);
+    return FHE_OK;
+}
+// DCRTPolyImpl::ScaleAndRound, BEHZ decryption overload (dcrtpoly-impl.h:1631-1671): tables tgammaQHatModq (mod q_i) and
+// negInvqModtgamma (mod t*gamma, gamma = 2^26)
+extern "C" fhe_status fhe_scale_and_round_behz_decrypt(fhe_ctx* c, const uint64_t* x, const uint32_t* limbIdx, uint32_t sizeQ,
+                                                       uint64_t tgamma, const uint64_t* tgammaQHatModq,
+                                                       const uint64_t* negInvqModtgamma, uint32_t batch, uint64_t* out,
+                                                       void* st) {
+    ARG_CHECK(c && x && tgammaQHatModq && negInvqModtgamma && out && batch >= 1, "fhe_scale_and_round_behz_decrypt: bad argument");
+    ARG_CHECK(sizeQ >= 1 && sizeQ <= (uint32_t)kMaxLimbs && tgamma >= 2, "fhe_scale_and_round_behz_decrypt: bad basis size or t*gamma");
+    RT_CHECK(rt::set_device(c->device));
+    std::vector<uint64_t> qv(sizeQ), tg(sizeQ, tgamma);
+    for (uint32_t i = 0; i < sizeQ; ++i) {
+        const uint32_t l = limbIdx ? limbIdx[i] : i;
+        ARG_CHECK(l < c->L, "fhe_scale_and_round_behz_decrypt: limb index exceeds context size");
+        qv[i] = c->q[l];
+    }
+    std::vector<TwPair> h;
+    native_tables(c, sizeQ, tgammaQHatModq, negInvqModtgamma, qv.data(), tg.data(), h);
+    void *dT = nullptr, *dQ = nullptr;
+    RT_CHECK(rt::dmalloc(&dT, h.size() * sizeof(TwPair)));
+    RT_CHECK(rt::dmalloc(&dQ, qv.size() * 8));
+    RT_CHECK(rt::h2d(dT, h.data(), h.size() * sizeof(TwPair), (rt::stream_t)st));
+    RT_CHECK(rt::h2d(dQ, qv.data(), qv.size() * 8, (rt::stream_t)st));
+    ScaleRoundNativeArgs g{};
+    g.in = TowerView{const_cast<uint64_t*>(x), sizeQ, 0};
+    g.out = out, g.q = (uint64_t*)dQ;
+    g.tabModt = (TwPair*)dT, g.tabBModt = (TwPair*)dT + sizeQ;
+    g.t = tgamma, g.logN = c->logN, g.batch = batch, g.sizeQ = sizeQ;
+    FHE_LAUNCH(scale_round_behz_decrypt_kernel, (uint32_t)((((uint64_t)batch << g.logN) + kThreads - 1) / kThreads), st, g);
+    const char* le = rt::last_launch_error();
+    RT_CHECK(rt::sync((rt::stream_t)st));
+    rt::dfree(dT), rt::dfree(dQ);
+    RT_CHECK(le);
+    return FHE_OK;
+}
+
 // ---- BEHZ ----
 struct fhe_behz {
     fhe_ctx* ctx;

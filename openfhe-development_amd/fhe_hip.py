@@ -114,6 +114,8 @@ class Lib:
         S("fhe_sr_plan_destroy", None, [vp])
         S("fhe_scale_and_round", C.c_int, [vp, vp, C.c_int, vp, u32, vp])
         S("fhe_scale_and_round_p_over_q", C.c_int, [vp, vp, u32p, u32, vp, u32, vp])
+        S("fhe_scale_and_round_native", C.c_int, [vp, vp, u32p, u32, u64, u64p, u64p, f64p, f64p, u32, vp, vp])
+        S("fhe_scale_and_round_behz_decrypt", C.c_int, [vp, vp, u32p, u32, u64, u64p, u64p, u32, vp, vp])
         S("fhe_param_behz_bsk", u32, [u32, u32, u64p, u64, u64p, u64p])
         S("fhe_behz_create", C.c_int, [vp, u32p, u32, u32p, u64, C.POINTER(vp)])
         S("fhe_behz_destroy", None, [vp])
@@ -514,6 +516,41 @@ def mod_reduce(ctx, x, t, stream=None):
     ctx.sync(stream)
     ctx.free(ws)
     return out
+
+
+def scale_and_round_native(ctx, x, t, tab_modt, frac, tab_bmodt=None, bfrac=None, stream=None):
+    """DCRTPoly::ScaleAndRound -> NativePoly mod t (BFV decryption, dcrtpoly-impl.h:1190-1467); returns uint64 [batch][N]"""
+    ta = np.ascontiguousarray(tab_modt, dtype=np.uint64)
+    fr = np.ascontiguousarray(frac, dtype=np.float64)
+    tb = np.ascontiguousarray(tab_bmodt, dtype=np.uint64) if tab_bmodt is not None else None
+    bf = np.ascontiguousarray(bfrac, dtype=np.float64) if bfrac is not None else None
+    out = ctx.malloc(x.batch * ctx.N * 8)
+    li = x.limb_idx.ctypes.data_as(u32p) if x.limb_idx is not None else None
+    f64p = C.POINTER(C.c_double)
+    ctx.lib.check(ctx.lib.L.fhe_scale_and_round_native(ctx.h, x.ptr, li, x.n_limbs, t, ta.ctypes.data_as(u64p),
+                                                       tb.ctypes.data_as(u64p) if tb is not None else None,
+                                                       fr.ctypes.data_as(f64p), bf.ctypes.data_as(f64p) if bf is not None else None,
+                                                       x.batch, out, stream))
+    host = np.empty((x.batch, ctx.N), np.uint64)
+    ctx.lib.check(ctx.lib.L.fhe_memcpy_d2h(ctx.h, host.ctypes.data_as(vp), out, host.nbytes, stream))
+    ctx.sync(stream)
+    ctx.free(out)
+    return host
+
+
+def scale_and_round_behz_decrypt(ctx, x, tgamma, tgamma_qhat_modq, neg_invq_mod_tgamma, stream=None):
+    """DCRTPoly::ScaleAndRound, BEHZ decryption overload (dcrtpoly-impl.h:1631-1671); returns uint64 [batch][N]"""
+    ta = np.ascontiguousarray(tgamma_qhat_modq, dtype=np.uint64)
+    tb = np.ascontiguousarray(neg_invq_mod_tgamma, dtype=np.uint64)
+    out = ctx.malloc(x.batch * ctx.N * 8)
+    li = x.limb_idx.ctypes.data_as(u32p) if x.limb_idx is not None else None
+    ctx.lib.check(ctx.lib.L.fhe_scale_and_round_behz_decrypt(ctx.h, x.ptr, li, x.n_limbs, tgamma, ta.ctypes.data_as(u64p),
+                                                             tb.ctypes.data_as(u64p), x.batch, out, stream))
+    host = np.empty((x.batch, ctx.N), np.uint64)
+    ctx.lib.check(ctx.lib.L.fhe_memcpy_d2h(ctx.h, host.ctypes.data_as(vp), out, host.nbytes, stream))
+    ctx.sync(stream)
+    ctx.free(out)
+    return host
 
 
 class ScaleAndRoundPlan:

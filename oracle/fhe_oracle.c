@@ -1210,6 +1210,86 @@ void orc_scale_and_round_p_over_q(const uint64_t* x, uint32_t sizeQ, uint32_t N,
     }
 }
 
+/* DCRTPolyImpl::ScaleAndRound -> NativePoly mod t (dcrtpoly-impl.h:1190-1467; BFV HPS decryption).  The eight branches
+ * differ in three switches: t a power of two (final `& (t-1)` vs the double-precision reduction :1375-1377), the
+ * hi/lo split of every residue at bit qMSB/2 when qMSB + sizeQMSB >= 52 (:1247ff), and plain wrap-around products
+ * vs ModMulFastConst modulo t.  Double-precision sums in the reference's order (i ascending; lo term, then hi term). */
+static uint32_t msb64(uint64_t v) {
+    uint32_t n = 0;
+    while (v) {
+        ++n;
+        v >>= 1;
+    }
+    return n;
+}
+void orc_scale_and_round_native(const uint64_t* x, uint32_t sizeQ, uint32_t N, const uint64_t* q, uint64_t t,
+                                const uint64_t* tabModt, const uint64_t* tabBModt, const double* frac, const double* bfrac,
+                                uint64_t* out) {
+    uint64_t qmax = q[0];
+    for (uint32_t i = 1; i < sizeQ; ++i)
+        if (q[i] > qmax)
+            qmax = q[i];
+    const uint32_t qMSB = msb64(qmax), tMSB = msb64(t), sizeQMSB = msb64(sizeQ), qMSBHf = qMSB >> 1;
+    const int pow2  = (t & (t - 1)) == 0;
+    const int split = !(qMSB + sizeQMSB < 52);
+    int nomod;
+    if (!split)
+        nomod = pow2 ? (qMSB + sizeQMSB + tMSB < 63) : (qMSB + tMSB + sizeQMSB < 52);
+    else
+        nomod = pow2 ? (qMSBHf + tMSB + sizeQMSB < 62) : (qMSBHf + tMSB + sizeQMSB < 52);
+    uint64_t pre[128], preB[128];
+    for (uint32_t i = 0; i < sizeQ; ++i) {
+        pre[i]  = orc_prep_mod_mul_const(tabModt[i], t);
+        preB[i] = tabBModt ? orc_prep_mod_mul_const(tabBModt[i], t) : 0;
+    }
+    const double td = (double)t, tInv = 1. / td;
+    for (uint32_t ri = 0; ri < N; ++ri) {
+        double floatSum = pow2 ? 0.5 : 0.0;
+        uint64_t intSum = 0;
+        for (uint32_t i = 0; i < sizeQ; ++i) {
+            const uint64_t v = x[(size_t)i * N + ri];
+            if (!split) {
+                floatSum += (double)v * frac[i];
+                intSum += nomod ? v * tabModt[i] : orc_mod_mul_fast_const(v, tabModt[i], t, pre[i]);
+            }
+            else {
+                const uint64_t hi = v >> qMSBHf, lo = v - (hi << qMSBHf);
+                floatSum += (double)lo * frac[i];
+                floatSum += (double)hi * bfrac[i];
+                intSum += nomod ? lo * tabModt[i] : orc_mod_mul_fast_const(lo, tabModt[i], t, pre[i]);
+                intSum += nomod ? hi * tabBModt[i] : orc_mod_mul_fast_const(hi, tabBModt[i], t, preB[i]);
+            }
+        }
+        if (pow2) {
+            intSum += (uint64_t)floatSum;
+            out[ri] = intSum & (t - 1);
+        }
+        else {
+            floatSum += (double)intSum;
+            floatSum -= td * (double)(uint64_t)(floatSum * tInv);
+            out[ri] = (uint64_t)(floatSum + 0.5);
+        }
+    }
+}
+
+/* DCRTPolyImpl::ScaleAndRound, BEHZ decryption overload (dcrtpoly-impl.h:1631-1671), gamma = 2^26 */
+void orc_scale_and_round_behz_decrypt(const uint64_t* x, uint32_t sizeQ, uint32_t N, const uint64_t* q, uint64_t tgamma,
+                                      const uint64_t* tgammaQHatModq, const uint64_t* negInvqModtgamma, uint64_t* out) {
+    const uint64_t gammaMinus1 = (1u << 26) - 1;
+    for (uint32_t k = 0; k < N; ++k) {
+        uint64_t s = 0;
+        for (uint32_t i = 0; i < sizeQ; ++i) {
+            const uint64_t a = orc_mod_mul_fast_const(x[(size_t)i * N + k], tgammaQHatModq[i], q[i],
+                                                      orc_prep_mod_mul_const(tgammaQHatModq[i], q[i]));
+            const uint64_t b = orc_mod_mul_fast_const(a, negInvqModtgamma[i], tgamma,
+                                                      orc_prep_mod_mul_const(negInvqModtgamma[i], tgamma));
+            s = orc_mod_add_fast(s, b, tgamma);
+        }
+        s += s & gammaMinus1;
+        out[k] = s >> 26;
+    }
+}
+
 /* ------------------------------------------------------------------------------------------
  * a18: BEHZ.  Tables as bfvrns-cryptoparameters.cpp:673-850 builds them (residues of products => modular
  * arithmetic; the one genuinely multi-precision step is the msk size check B*msk >= 2n*t*Q).

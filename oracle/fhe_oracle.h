@@ -186,6 +186,13 @@ void orc_scale_and_round_p_over_q(const uint64_t* x, uint32_t sizeQ, uint32_t N,
                                   const uint64_t* pInvModq, uint64_t* out);
 
 /* ---------------- a18: BEHZ (dcrtpoly-impl.h:1694-1929; tables bfvrns-cryptoparameters.cpp:673-850) ---------------- */
+/* ScaleAndRound -> NativePoly mod t (dcrtpoly-impl.h:1190-1467) and its BEHZ-decryption overload (:1631-1671);
+ * x [sizeQ][N] COEFFICIENT, out [N]; tabBModt / bfrac may be NULL when the split branch cannot be taken */
+void orc_scale_and_round_native(const uint64_t* x, uint32_t sizeQ, uint32_t N, const uint64_t* q, uint64_t t,
+                                const uint64_t* tabModt, const uint64_t* tabBModt, const double* frac, const double* bfrac,
+                                uint64_t* out);
+void orc_scale_and_round_behz_decrypt(const uint64_t* x, uint32_t sizeQ, uint32_t N, const uint64_t* q, uint64_t tgamma,
+                                      const uint64_t* tgammaQHatModq, const uint64_t* negInvqModtgamma, uint64_t* out);
 typedef struct orc_behz orc_behz;
 orc_behz* orc_behz_create(uint32_t N, uint32_t numQ, const uint64_t* q, uint64_t t);
 void      orc_behz_destroy(orc_behz*);

@@ -601,6 +601,39 @@ void ref_scale_and_round_p_over_q(uint32_t N, uint32_t sizeQ, const uint64_t* mo
     export_poly(X, out);
 }
 
+// ScaleAndRound -> NativePoly mod t (decryption) with caller tables; out [N]
+void ref_scale_and_round_native(uint32_t N, uint32_t sizeQ, const uint64_t* q, const uint64_t* psi, const uint64_t* x, uint64_t t,
+                                const uint64_t* tabModt, const uint64_t* tabBModt, const double* frac, const double* bfrac,
+                                uint64_t* out) {
+    auto pq = make_params(N, sizeQ, q, psi);
+    auto X  = make_poly(pq, x, Format::COEFFICIENT);
+    const NativeInteger T(t);
+    auto a = vecNI(tabModt, sizeQ), b = vecNI(tabBModt, sizeQ);
+    std::vector<NativeInteger> ap(sizeQ), bp(sizeQ);
+    for (uint32_t i = 0; i < sizeQ; ++i) {
+        ap[i] = a[i].PrepModMulConst(T);
+        bp[i] = b[i].PrepModMulConst(T);
+    }
+    std::vector<double> f(frac, frac + sizeQ), bf(bfrac, bfrac + sizeQ);
+    auto r = X.ScaleAndRound(T, a, ap, b, bp, f, bf);
+    for (uint32_t k = 0; k < N; ++k)
+        out[k] = r[k].ConvertToInt<uint64_t>();
+}
+void ref_scale_and_round_behz_decrypt(uint32_t N, uint32_t sizeQ, const uint64_t* q, const uint64_t* psi, const uint64_t* x,
+                                      uint64_t t, uint64_t tgamma, const uint64_t* tgammaQHatModq,
+                                      const uint64_t* negInvqModtgamma, uint64_t* out) {
+    auto pq = make_params(N, sizeQ, q, psi);
+    auto X  = make_poly(pq, x, Format::COEFFICIENT);
+    const NativeInteger TG(tgamma);
+    auto a = vecNI(tgammaQHatModq, sizeQ), b = vecNI(negInvqModtgamma, sizeQ);
+    std::vector<NativeInteger> bp(sizeQ);
+    for (uint32_t i = 0; i < sizeQ; ++i)
+        bp[i] = b[i].PrepModMulConst(TG);
+    auto r = X.ScaleAndRound(vecNI(q, sizeQ), NativeInteger(t), TG, a, precon(a, q), b, bp);
+    for (uint32_t k = 0; k < N; ++k)
+        out[k] = r[k].ConvertToInt<uint64_t>();
+}
+
 // ---- BFV / BEHZ session: the reference's own CryptoParametersBFVRNS tables ----
 struct RefBfv {
     CryptoContext<DCRTPoly> cc;

@@ -102,6 +102,8 @@ def load_oracle():
     S("orc_approx_scale_and_round", None, [P64, u32, u32, u32, P64, P64, P64, P64])
     S("orc_scale_and_round_p_over_q", None, [P64, u32, u32, P64, u64, P64, P64])
     S("orc_mod_reduce", None, [vp, P64, u32, u64, C.c_int, P64])
+    S("orc_scale_and_round_native", None, [P64, u32, u32, P64, u64, P64, P64, PF64, PF64, P64])
+    S("orc_scale_and_round_behz_decrypt", None, [P64, u32, u32, P64, u64, P64, P64, P64])
     S("orc_eval_fast_rotation_ext", None, [vp, P64, P64, u32, u32, C.c_int, P64, P64, P64, P64])
     S("orc_hybrid_approx_mod_down_t", None, [vp, P64, u32, u64, P64])
     S("orc_expand_crt_basis", None, [vp, u32, u32, P64, C.c_int, P64, P64, P64, P64, P64, PF64, C.c_int, C.c_int, P64])
@@ -183,6 +185,8 @@ def load_ref():
     S("ref_approx_scale_and_round", None, [u32, u32, u32, P64, P64, P64, P64, P64])
     S("ref_scale_and_round_p_over_q", None, [u32, u32, P64, P64, P64, P64, P64])
     S("ref_mod_reduce", None, [u32, u32, P64, P64, P64, u64, C.c_int, P64])
+    S("ref_scale_and_round_native", None, [u32, u32, P64, P64, P64, u64, P64, P64, PF64, PF64, P64])
+    S("ref_scale_and_round_behz_decrypt", None, [u32, u32, P64, P64, P64, u64, u64, P64, P64, P64])
     S("ref_ckks_eval_fast_rotate_ext", C.c_int, [vp, C.c_int, i32, C.c_int])
     S("ref_ckks_key_switch_down", C.c_int, [vp, C.c_int])
     S("ref_approx_mod_down", None, [u32, u32, P64, P64, u32, P64, P64, P64, P64, P64, P64, u64, P64])
@@ -249,3 +253,38 @@ def p_over_q_tables(q, pl):
     mpre = np.array([(int(h) << 64) // s for h, s in zip(m, q_i)], np.uint64)
     qinvp = np.array([[pow(s % d, -1, d) for d in p_i] for s in q_i], np.uint64)
     return m, mpre, qinvp
+
+
+def decrypt_tables(q, t):
+    """tables of the BFV HPS decryption ScaleAndRound (bfvrns-cryptoparameters.cpp): with v_i = t*[(Q/q_i)^-1]_{q_i},
+    tQHatInvModqDivqModt[i] = floor(v_i/q_i) mod t, Frac[i] = frac(v_i/q_i); the B tables use v_i*2^(qMSB/2)"""
+    from fractions import Fraction
+    q_i = [int(v) for v in q]
+    Q = 1
+    for v in q_i:
+        Q *= v
+    qmsb = max(q_i).bit_length()
+    Bv = 1 << (qmsb >> 1)
+    a, b, fr, bf = [], [], [], []
+    for s in q_i:
+        inv = pow((Q // s) % s, -1, s)
+        v = t * inv
+        a.append((v // s) % t)
+        fr.append(float(Fraction(v % s, s)))
+        vb = (v * Bv) % (s * t)  # only floor(vb/s) mod t and frac(vb/s) matter
+        b.append((vb // s) % t)
+        bf.append(float(Fraction(vb % s, s)))
+    return (np.array(a, np.uint64), np.array(b, np.uint64), np.array(fr, np.float64), np.array(bf, np.float64))
+
+
+def behz_decrypt_tables(q, t):
+    """tgammaQHatModq[i] = [t*gamma*(Q/q_i)^-1... ]: the reference multiplies x_i by [t*gamma*(Q/q_i)^-1]_{q_i} and then
+    by [-q_i^-1]_{t*gamma} (bfvrns-cryptoparameters.cpp, BEHZ decryption block), gamma = 2^26"""
+    q_i = [int(v) for v in q]
+    Q = 1
+    for v in q_i:
+        Q *= v
+    tg = t << 26
+    a = np.array([(tg % s) * pow((Q // s) % s, -1, s) % s for s in q_i], np.uint64)
+    b = np.array([(-pow(s % tg, -1, tg)) % tg for s in q_i], np.uint64)
+    return tg, a, b

@@ -293,6 +293,42 @@ def test_approx_mod_down_against_live_reference(oracle, ref, logN, sizeQ, sizeQl
     o.orc_hybrid_destroy(hy)
 
 
+@pytest.mark.parametrize("logN,sizeQ,bits,t", [(4, 2, 28, 65537), (4, 2, 28, 1 << 16), (5, 3, 45, 65537), (5, 3, 45, 1 << 20),
+                                                (4, 3, 60, 65537), (4, 4, 60, 1 << 30), (4, 2, 50, 786433), (4, 3, 55, 1 << 3),
+                                                (4, 2, 30, (1 << 34) - 41), (4, 3, 59, (1 << 34) - 41)])
+def test_scale_and_round_native_against_live_reference(oracle, ref, logN, sizeQ, bits, t):
+    """DCRTPoly::ScaleAndRound -> NativePoly (BFV decryption, all branch families: t power of two or not, split or not,
+    with or without modular products) of the reference vs the oracle"""
+    o, r = oracle, ref
+    rng = np.random.default_rng(101)
+    N = 1 << logN
+    q, psi = np.zeros(sizeQ, np.uint64), np.zeros(sizeQ, np.uint64)
+    o.orc_dcrt_params(2 * N, sizeQ, bits, q, psi)
+    a, b, fr, bf = libs.decrypt_tables(q, t)
+    x = libs.rand_tower(rng, q, N)
+    x[:, 0] = q - np.uint64(1)
+    x[:, 1] = 0
+    want, got = np.zeros(N, np.uint64), np.zeros(N, np.uint64)
+    r.ref_scale_and_round_native(N, sizeQ, q, psi, x, t, a, b, fr, bf, want)
+    o.orc_scale_and_round_native(x, sizeQ, N, q, t, a, b, fr, bf, got)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("logN,sizeQ,bits,t", [(4, 2, 45, 65537), (5, 3, 60, 786433), (4, 4, 55, 2)])
+def test_scale_and_round_behz_decrypt_against_live_reference(oracle, ref, logN, sizeQ, bits, t):
+    o, r = oracle, ref
+    rng = np.random.default_rng(102)
+    N = 1 << logN
+    q, psi = np.zeros(sizeQ, np.uint64), np.zeros(sizeQ, np.uint64)
+    o.orc_dcrt_params(2 * N, sizeQ, bits, q, psi)
+    tg, a, b = libs.behz_decrypt_tables(q, t)
+    x = libs.rand_tower(rng, q, N)
+    want, got = np.zeros(N, np.uint64), np.zeros(N, np.uint64)
+    r.ref_scale_and_round_behz_decrypt(N, sizeQ, q, psi, x, t, tg, a, b, want)
+    o.orc_scale_and_round_behz_decrypt(x, sizeQ, N, q, tg, a, b, got)
+    assert np.array_equal(got, want)
+
+
 def ref_bfv_session(r, ring, t, depth, sms):
     """reference BFV/BEHZ context with two fresh ciphertexts and their EvalMultNoRelin product, exported as arrays"""
     h = r.ref_bfv_create(ring, t, depth, sms, 0)

@@ -224,3 +224,40 @@ def test_fast_expand_crt_basis_p_over_q(backend, oracle, logN, nQ, nP, B):
     assert np.array_equal(got.to_host(), want)
     to_pl.close(), to_ql.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("logN,sizeQ,bits,t,B", [(4, 2, 28, 65537, 2), (10, 3, 45, 1 << 20, 2), (12, 3, 60, 65537, 1), (12, 4, 60, 1 << 30, 1),
+                                                  (10, 2, 50, 786433, 2), (12, 3, 59, (1 << 34) - 41, 1), (4, 2, 30, (1 << 34) - 41, 2)])
+def test_scale_and_round_native(backend, oracle, logN, sizeQ, bits, t, B):
+    """fhe_scale_and_round_native (decryption ScaleAndRound -> residues mod t) vs the oracle, every branch family"""
+    o = oracle
+    rng = np.random.default_rng(41)
+    N = 1 << logN
+    q, psi = params(o, logN, sizeQ, bits)
+    a, b, fr, bf = libs.decrypt_tables(q, t)
+    x = libs.rand_tower(rng, q, N, B)
+    x[0, :, 0] = q - np.uint64(1)
+    want = np.zeros((B, N), np.uint64)
+    for bb in range(B):
+        o.orc_scale_and_round_native(x[bb], sizeQ, N, q, t, a, b, fr, bf, want[bb])
+    ctx = fh.Context(backend, logN, q, psi)
+    got = fh.scale_and_round_native(ctx, ctx.tower(x, fmt=fh.COEFFICIENT), t, a, fr, b, bf)
+    assert np.array_equal(got, want)
+    ctx.close()
+
+
+@pytest.mark.parametrize("logN,sizeQ,bits,t,B", [(4, 2, 45, 65537, 2), (12, 3, 60, 786433, 1)])
+def test_scale_and_round_behz_decrypt(backend, oracle, logN, sizeQ, bits, t, B):
+    o = oracle
+    rng = np.random.default_rng(42)
+    N = 1 << logN
+    q, psi = params(o, logN, sizeQ, bits)
+    tg, a, b = libs.behz_decrypt_tables(q, t)
+    x = libs.rand_tower(rng, q, N, B)
+    want = np.zeros((B, N), np.uint64)
+    for bb in range(B):
+        o.orc_scale_and_round_behz_decrypt(x[bb], sizeQ, N, q, tg, a, b, want[bb])
+    ctx = fh.Context(backend, logN, q, psi)
+    got = fh.scale_and_round_behz_decrypt(ctx, ctx.tower(x, fmt=fh.COEFFICIENT), tg, a, b)
+    assert np.array_equal(got, want)
+    ctx.close()
