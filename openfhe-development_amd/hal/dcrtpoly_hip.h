@@ -176,6 +176,42 @@ public:
         check(s);
         *this = std::move(out);
     }
+    // ModReduce (BGV modulus switch by the last limb, plaintext modulus t)  dcrtpoly-impl.h:736-755
+    void ModReduce(uint64_t t) {
+        if (!m_idx.empty())
+            throw Error("ModReduce: tower must use the leading context limbs");
+        DCRTPolyHip out(m_params, m_limbs - 1, m_format, m_batch);
+        size_t wsb = fhe_rescale_workspace_bytes(m_params->ctx(), m_limbs, m_batch);
+        void* ws   = nullptr;
+        check(fhe_malloc(m_params->ctx(), wsb, &ws));
+        fhe_status s = fhe_mod_reduce(m_params->ctx(), m_data, m_limbs, t, m_format == EVALUATION, m_batch, out.m_data, ws, wsb, nullptr);
+        fhe_stream_sync(m_params->ctx(), nullptr);
+        fhe_free(m_params->ctx(), ws);
+        check(s);
+        *this = std::move(out);
+    }
+    // ExpandCRTBasis / ExpandCRTBasisReverseOrder to this basis + the context limbs `extra` (dcrtpoly-impl.h:1088-1148)
+    DCRTPolyHip ExpandCRTBasis(const std::vector<uint32_t>& extra, Format resultFormat, bool reverseOrder = false) const {
+        std::vector<uint32_t> src = m_idx;
+        if (src.empty())
+            for (uint32_t i = 0; i < m_limbs; ++i)
+                src.push_back(i);
+        fhe_conv* cv = nullptr;
+        check(fhe_conv_create(m_params->ctx(), src.data(), m_limbs, extra.data(), (uint32_t)extra.size(), &cv));
+        std::vector<uint32_t> all = reverseOrder ? extra : src;
+        all.insert(all.end(), reverseOrder ? src.begin() : extra.begin(), reverseOrder ? src.end() : extra.end());
+        DCRTPolyHip out(m_params, (uint32_t)all.size(), resultFormat, m_batch, all);
+        size_t wsb = fhe_expand_crt_basis_workspace_bytes(cv, m_batch);
+        void* ws   = nullptr;
+        check(fhe_malloc(m_params->ctx(), wsb, &ws));
+        fhe_status s = fhe_expand_crt_basis(cv, m_data, m_format == EVALUATION, out.m_data, resultFormat == EVALUATION,
+                                            reverseOrder, m_batch, ws, wsb, nullptr);
+        fhe_stream_sync(m_params->ctx(), nullptr);
+        fhe_free(m_params->ctx(), ws);
+        fhe_conv_destroy(cv);
+        check(s);
+        return out;
+    }
     // ApproxSwitchCRTBasis / SwitchCRTBasis to the context limbs `target` (dcrtpoly-impl.h:888-932, 1008-1085)
     DCRTPolyHip SwitchCRTBasis(const std::vector<uint32_t>& target, bool exact) const {
         if (m_format != COEFFICIENT)

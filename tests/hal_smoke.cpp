@@ -66,6 +66,25 @@ int main() {
     // rescale drops a tower
     A.DropLastElementAndScale();
     if (A.GetNumOfElements() != L - 1) return 7;
+    // ExpandCRTBasis: Q = {limb 0} -> {0, 1}; the Q rows keep their values, the extension is the exact CRT lift
+    {
+        DCRTPolyHip Q1(params, 1, COEFFICIENT, B, std::vector<uint32_t>{0});
+        std::vector<uint64_t> small((size_t)B * N);
+        for (size_t i = 0; i < small.size(); ++i)
+            small[i] = (i * 2654435761ull) % 1000003ull;  // < q_0/2: the lift to q_1 is the same integer
+        Q1.SetValues(small, COEFFICIENT);
+        DCRTPolyHip E = Q1.ExpandCRTBasis({1}, COEFFICIENT);
+        if (E.GetNumOfElements() != 2) return 8;
+        auto ev = E.GetValues();
+        for (uint32_t t = 0; t < B; ++t)
+            for (uint32_t k = 0; k < N; ++k)
+                if (ev[((size_t)t * 2 + 0) * N + k] != small[(size_t)t * N + k] ||
+                    ev[((size_t)t * 2 + 1) * N + k] != small[(size_t)t * N + k])
+                    return 9;
+    }
+    // ModReduce drops a tower as well
+    Bp.ModReduce(65537);
+    if (Bp.GetNumOfElements() != L - 1) return 10;
     std::puts("hal_smoke OK");
     return 0;
 }
