@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-evalmult", action="store_true")
     ap.add_argument("--evalmult-batch", type=int, default=64, help="ciphertexts per GPU in the EvalMult leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-hadamard", action="store_true", help="skip the Hadamard-product leg")
     ap.add_argument("--no-bfv", action="store_true", help="skip the BFV EvalMult (BEHZ) leg (BASELINE configs[4] shape)")
     ap.add_argument("--bfv-batch", type=int, default=64)
     return ap.parse_args()
@@ -299,6 +300,49 @@ def main():
     bytes_per_step = 4.0 * 8 * N * L * B  # fwd + inv, each: read once + write once
     value = bytes_per_step * world / (ms_per_step * 1e-3) / 1e9
 
+    # ---- size-independent parity at the full workload: every step is NTT followed by INTT, so the resident batch must
+    # still be the generated one; sample towers (first / middle / last) and compare them word for word with the host copy
+    def roundtrip_check():
+        rng = np.random.default_rng(2 + rank)
+        seed_polys = min(8, B)
+        host = np.empty((seed_polys, L, N), np.uint64)
+        for i, qi in enumerate(q):
+            host[:, i, :] = rng.integers(0, int(qi), size=(seed_polys, N), dtype=np.uint64)
+        got = np.empty((L, N), np.uint64)
+        for tw in sorted({0, B // 2, B - 1}):
+            lib.check(lib.L.fhe_memcpy_d2h(ctx.h, got.ctypes.data_as(C.c_void_p), C.c_void_p(x.value + tw * L * N * 8),
+                                           got.nbytes, None))
+            ctx.sync()
+            # fill_random_tower doubles the filled prefix (8, 16, 32, ... towers): tower t is a copy of tower t mod 8
+            if not np.array_equal(got, host[tw % seed_polys]):
+                return f"MISMATCH at tower {tw}"
+        return "fwd+inv round trip bit-exact on towers {0, B/2, B-1} after all steps"
+    roundtrip = roundtrip_check()
+
+    # ---- Hadamard product a o b over the same batch shape: 3 streams, HBM-bound ----
+    hadamard = None
+    if not a.no_hadamard:
+        y = fill_random_tower(ctx, q, B, seed=50 + rank)
+        z = ctx.malloc(B * L * N * 8)
+
+        def hstep():
+            lib.check(lib.L.fhe_mul(ctx.h, z, x, y, None, L, B, None))
+        for _ in range(2):
+            hstep()
+        gpu_sync()
+        t1 = time.perf_counter()
+        hs = max(5, a.steps)
+        for _ in range(hs):
+            hstep()
+        gpu_sync()
+        hdt = (time.perf_counter() - t1) / hs
+        hbytes = 3.0 * 8 * N * L * B
+        hadamard = {"GB_per_s_per_gpu": round(hbytes / hdt / 1e9, 1), "ms": round(hdt * 1e3, 3),
+                    "hbm_roofline_frac": round(hbytes / hdt / 1e9 / HBM_PEAK_GBPS, 4),
+                    "bytes": hbytes, "note": "out = a*b mod q_i per limb (generalized Barrett), read 2 + write 1 streams"}
+        ctx.free(y)
+        ctx.free(z)
+
     # ---- roofline of the dominant kernel (row pass of the forward transform), live hipEvent timing ----
     roof = None
     per_kernel = {}
@@ -364,6 +408,7 @@ def main():
                        "parallelism": f"batch-sharded x{world}, no data-path collective"},
             "hbm_roofline_frac_fwd_inv": round(value / world / HBM_PEAK_GBPS, 4),
             "roofline": roof, "cpu_baseline": cpu, "evalmult": em,
+            "hadamard": hadamard, "parity_at_full_size": roundtrip,
         }
         if bfv is not None:
             out["bfv_evalmult"] = bfv
