@@ -340,6 +340,25 @@ def main():
         hadamard = {"GB_per_s_per_gpu": round(hbytes / hdt / 1e9, 1), "ms": round(hdt * 1e3, 3),
                     "hbm_roofline_frac": round(hbytes / hdt / 1e9 / HBM_PEAK_GBPS, 4),
                     "bytes": hbytes, "note": "out = a*b mod q_i per limb (generalized Barrett), read 2 + write 1 streams"}
+        # fused use: c = INTT(NTT(a) o NTT(b)), a, b, c in COEFFICIENT form (negacyclic polynomial product per limb)
+        def pstep():
+            lib.check(lib.L.fhe_ntt_fwd(ctx.h, x, None, L, B, None))
+            lib.check(lib.L.fhe_ntt_fwd(ctx.h, y, None, L, B, None))
+            lib.check(lib.L.fhe_mul(ctx.h, z, x, y, None, L, B, None))
+            lib.check(lib.L.fhe_ntt_inv(ctx.h, z, None, L, B, None))
+            lib.check(lib.L.fhe_ntt_inv(ctx.h, x, None, L, B, None))  # restore the operands for the next step
+            lib.check(lib.L.fhe_ntt_inv(ctx.h, y, None, L, B, None))
+        pstep()
+        gpu_sync()
+        t2 = time.perf_counter()
+        ps = max(3, a.steps // 3)
+        for _ in range(ps):
+            pstep()
+        gpu_sync()
+        pdt = (time.perf_counter() - t2) / ps
+        hadamard["polymul"] = {"ms_per_batch_incl_operand_restore": round(pdt * 1e3, 3),
+                               "note": "2 NTT + Hadamard + INTT (+ 2 INTT restoring a, b): limb-wise negacyclic products of "
+                                       f"{B} towers; {round(B * L / pdt / 1e3, 1)} k limb-products/s"}
         ctx.free(y)
         ctx.free(z)
 
