@@ -132,7 +132,7 @@ def cpu_baseline(q, psi, logN, L, seconds):
                       f"{dt / (reps * polys) * 1e3:.1f} ms per tower fwd+inv; host has {cores} logical cores"}
 
 
-def evalmult_leg(lib, device, logN, batch, steps, warmup, sync):
+def evalmult_leg(lib, device, logN, batch, steps, warmup, sync, dist=None):
     """CKKS EvalMult + HYBRID key switch at config 3's shape (depth 20: l=21 limbs, dnum=3 => alpha=7, k=7)."""
     sizeQ, dnum = 21, 3
     q, psiQ = lib.ckks_like_chain(logN, sizeQ, 60, 59)
@@ -140,20 +140,40 @@ def evalmult_leg(lib, device, logN, batch, steps, warmup, sync):
     allq = np.concatenate([q, p])
     ctx = fh.Context(lib, logN, allq, np.concatenate([psiQ, psiP]), device=device)
     plan = fh.KeySwitchPlan(ctx, sizeQ, len(p), dnum)
-    lib.check(lib.L.fhe_ks_key_alloc(plan.h, C.byref(key := C.c_void_p())))
-    plan.key = key
     N = ctx.N
     rng = np.random.default_rng(3)
-    # evaluation key: uniform residues (2 * dnum * (l+k) limbs), generated per limb on the host
-    words = lib.L.fhe_ks_key_words(key)
-    for which in (0, 1):
+
+    def host_key():  # evaluation key half: uniform residues ([dnum][l+k][N]), generated per limb on the host
         host = np.empty((dnum, len(allq), N), np.uint64)
         for i, qi in enumerate(allq):
             host[:, i, :] = rng.integers(0, int(qi), size=(dnum, N), dtype=np.uint64)
-        assert host.size == words
-        lib.check(lib.L.fhe_memcpy_h2d(ctx.h, lib.L.fhe_ks_key_devptr(key, which), host.ctypes.data_as(C.c_void_p),
-                                       host.nbytes, None))
-        ctx.sync()
+        return host
+    key_dist, keep = "local (single process)", None
+    if dist is not None:
+        # the evaluation key exists on rank 0 and reaches every GPU with ONE broadcast over RCCL/xGMI; it is
+        # the only collective of the whole path
+        try:
+            import torch
+            from openfhe_amd import shard
+            kb = ka = None
+            if dist.get_rank() == 0:
+                kb, ka = host_key(), host_key()
+            keep = shard.broadcast_key(plan, kb, ka, torch.device("cuda", device))
+            torch.cuda.synchronize()
+            key_dist = f"rccl broadcast from rank 0 to {dist.get_world_size()} rank(s), {2 * plan.key_words() * 8 / 2**20:.0f} MiB"
+        except Exception as e:  # keep the benchmark alive; the line says what happened
+            key_dist, keep = f"local (broadcast failed: {type(e).__name__}: {e})", None
+            plan.key = None
+    if plan.key is None:
+        lib.check(lib.L.fhe_ks_key_alloc(plan.h, C.byref(key := C.c_void_p())))
+        plan.key = key
+        assert lib.L.fhe_ks_key_words(key) == dnum * len(allq) * N
+        for which in (0, 1):
+            host = host_key()
+            lib.check(lib.L.fhe_memcpy_h2d(ctx.h, lib.L.fhe_ks_key_devptr(key, which), host.ctypes.data_as(C.c_void_p),
+                                           host.nbytes, None))
+            ctx.sync()
+    key = plan.key
     ops = [fh.Tower(ctx, fill_random_tower(ctx, q, batch, 100 + i, seed_polys=2), batch, sizeQ) for i in range(4)]
     c0, c1 = ops[0].like(), ops[0].like()
     ws, wsb = plan.workspace(sizeQ, batch)
@@ -171,8 +191,10 @@ def evalmult_leg(lib, device, logN, batch, steps, warmup, sync):
     dt = (time.perf_counter() - t0) / steps
     plan.close()
     ctx.close()
+    del keep
     return {"ops_per_s_per_gpu": round(batch / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "batch": batch,
-            "shape": f"N=2^{logN}, l={sizeQ}, k={len(p)}, dnum={dnum}, workspace {wsb / 2**30:.1f} GiB"}
+            "shape": f"N=2^{logN}, l={sizeQ}, k={len(p)}, dnum={dnum}, workspace {wsb / 2**30:.1f} GiB",
+            "eval_key": key_dist}
 
 
 def bfv_leg(lib, device, batch, steps, warmup, sync, with_cpu):
@@ -248,7 +270,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     torch = None
-    if world > 1 or a.gpus > 1:
+    if world > 1 or a.gpus > 1 or os.environ.get("FHE_BENCH_FORCE_DIST"):
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local)
@@ -398,7 +420,7 @@ def main():
 
     em = None
     if not a.no_evalmult and logN == 16:
-        em = evalmult_leg(lib, device, logN, a.evalmult_batch, max(4, a.steps // 2), 2, gpu_sync)
+        em = evalmult_leg(lib, device, logN, a.evalmult_batch, max(4, a.steps // 2), 2, gpu_sync, dist)
         if dist is not None:
             tt = torch.tensor([em["ops_per_s_per_gpu"]], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.SUM)
