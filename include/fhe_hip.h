@@ -72,6 +72,16 @@ fhe_status fhe_memcpy_h2d(fhe_ctx* ctx, void* dst, const void* src, size_t bytes
 fhe_status fhe_memcpy_d2h(fhe_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream);
 fhe_status fhe_memcpy_d2d(fhe_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream);
 fhe_status fhe_stream_sync(fhe_ctx* ctx, void* stream);
+/* Streams and graphs.  Every entry point only enqueues work on the caller's stream, so a sequence of calls (an EvalMult, a
+ * BFV EvalMult, a rotation ... 20-60 kernel launches) can be recorded ONCE into a HIP graph and replayed with a single
+ * launch: fhe_graph_begin(stream) ... calls on that stream ... fhe_graph_end(stream, &graph); fhe_graph_launch(graph,
+ * stream).  Run the sequence once before capturing (tables are built on first use; building is not capturable). */
+fhe_status fhe_stream_create(fhe_ctx* ctx, void** stream);
+fhe_status fhe_stream_destroy(fhe_ctx* ctx, void* stream);
+fhe_status fhe_graph_begin(fhe_ctx* ctx, void* stream);
+fhe_status fhe_graph_end(fhe_ctx* ctx, void* stream, void** graph);
+fhe_status fhe_graph_launch(fhe_ctx* ctx, void* graph, void* stream);
+void       fhe_graph_destroy(void* graph);
 
 /* ---- a4/a5/a6: NTT -------------------------------------------------------------------------------
  * Replaces DCRTPolyImpl::SwitchFormat (dcrtpoly-impl.h:1932-1940) -> PolyImpl::SwitchFormat

@@ -384,6 +384,46 @@ extern "C" fhe_status fhe_stream_sync(fhe_ctx* c, void* st) {
     return FHE_OK;
 }
 
+// Streams and graphs.  Composite calls (EvalMult, key switch, BFV EvalMult ...) are sequences of 20-60 kernel launches of
+// 50-1000 us each; on a busy host the launch path, not the GPU, sets their pace.  Every entry point only enqueues work on
+// the caller's stream (tables are built on first use, so run the sequence once before capturing), hence a caller can
+// record a sequence into a HIP graph once and replay it with a single launch.
+extern "C" fhe_status fhe_stream_create(fhe_ctx* c, void** stream) {
+    ARG_CHECK(c && stream, "fhe_stream_create: null argument");
+    RT_CHECK(rt::set_device(c->device));
+    rt::stream_t s;
+    RT_CHECK(rt::stream_create(&s));
+    *stream = (void*)s;
+    return FHE_OK;
+}
+extern "C" fhe_status fhe_stream_destroy(fhe_ctx* c, void* stream) {
+    ARG_CHECK(c, "fhe_stream_destroy: null context");
+    RT_CHECK(rt::stream_destroy((rt::stream_t)stream));
+    return FHE_OK;
+}
+extern "C" fhe_status fhe_graph_begin(fhe_ctx* c, void* stream) {
+    ARG_CHECK(c && stream, "fhe_graph_begin: capture needs a stream created with fhe_stream_create");
+    RT_CHECK(rt::set_device(c->device));
+    RT_CHECK(rt::capture_begin((rt::stream_t)stream));
+    return FHE_OK;
+}
+extern "C" fhe_status fhe_graph_end(fhe_ctx* c, void* stream, void** graph) {
+    ARG_CHECK(c && stream && graph, "fhe_graph_end: null argument");
+    rt::graph_t g;
+    RT_CHECK(rt::capture_end((rt::stream_t)stream, &g));
+    *graph = (void*)g;
+    return FHE_OK;
+}
+extern "C" fhe_status fhe_graph_launch(fhe_ctx* c, void* graph, void* stream) {
+    ARG_CHECK(c && graph, "fhe_graph_launch: null argument");
+    RT_CHECK(rt::graph_launch((rt::graph_t)graph, (rt::stream_t)stream));
+    return FHE_OK;
+}
+extern "C" void fhe_graph_destroy(void* graph) {
+    if (graph)
+        rt::graph_destroy((rt::graph_t)graph);
+}
+
 // ------------------------------------------------------------------------------------------------
 // helpers
 // ------------------------------------------------------------------------------------------------

@@ -48,6 +48,16 @@ inline const char* dzero_2d(void* d, size_t pitch, size_t width, size_t height, 
         std::memset((char*)d + r * pitch, 0, width);
     return nullptr;
 }
+typedef void* graph_t;
+inline const char* stream_create(stream_t* s) {
+    *s = nullptr;
+    return nullptr;
+}
+inline const char* stream_destroy(stream_t) { return nullptr; }
+inline const char* capture_begin(stream_t) { return "stream capture needs the HIP build"; }
+inline const char* capture_end(stream_t, graph_t*) { return "stream capture needs the HIP build"; }
+inline const char* graph_launch(graph_t, stream_t) { return "stream capture needs the HIP build"; }
+inline const char* graph_destroy(graph_t) { return nullptr; }
 inline const char* sync(stream_t) { return nullptr; }
 inline const char* last_launch_error() { return nullptr; }
 struct Timer {
@@ -102,6 +112,20 @@ inline const char* d2d_2d(void* d, size_t dpitch, const void* s, size_t spitch, 
 inline const char* dzero_2d(void* d, size_t pitch, size_t width, size_t height, stream_t st) {
     return err(hipMemset2DAsync(d, pitch, 0, width, height, st));
 }
+typedef hipGraphExec_t graph_t;
+inline const char* stream_create(stream_t* s) { return err(hipStreamCreateWithFlags(s, hipStreamNonBlocking)); }
+inline const char* stream_destroy(stream_t s) { return err(hipStreamDestroy(s)); }
+inline const char* capture_begin(stream_t s) { return err(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal)); }
+inline const char* capture_end(stream_t s, graph_t* out) {
+    hipGraph_t g = nullptr;
+    if (auto e = err(hipStreamEndCapture(s, &g)))
+        return e;
+    auto e = err(hipGraphInstantiate(out, g, nullptr, nullptr, 0));
+    hipGraphDestroy(g);
+    return e;
+}
+inline const char* graph_launch(graph_t g, stream_t s) { return err(hipGraphLaunch(g, s)); }
+inline const char* graph_destroy(graph_t g) { return err(hipGraphExecDestroy(g)); }
 inline const char* sync(stream_t st) { return err(hipStreamSynchronize(st)); }
 inline const char* last_launch_error() { return err(hipGetLastError()); }
 struct Timer {

@@ -65,6 +65,12 @@ class Lib:
         for n in ("fhe_memcpy_h2d", "fhe_memcpy_d2h", "fhe_memcpy_d2d"):
             S(n, C.c_int, [vp, vp, vp, C.c_size_t, vp])
         S("fhe_stream_sync", C.c_int, [vp, vp])
+        S("fhe_stream_create", C.c_int, [vp, C.POINTER(vp)])
+        S("fhe_stream_destroy", C.c_int, [vp, vp])
+        S("fhe_graph_begin", C.c_int, [vp, vp])
+        S("fhe_graph_end", C.c_int, [vp, vp, C.POINTER(vp)])
+        S("fhe_graph_launch", C.c_int, [vp, vp, vp])
+        S("fhe_graph_destroy", None, [vp])
         S("fhe_ntt_fwd", C.c_int, [vp, vp, u32p, u32, u32, vp])
         S("fhe_ntt_inv", C.c_int, [vp, vp, u32p, u32, u32, vp])
         S("fhe_ntt_fwd_oop", C.c_int, [vp, vp, vp, u32p, u32, u32, vp])

@@ -5,6 +5,8 @@ Every test runs twice: on the `emu` backend (TEST-ONLY lane emulator, CPU, small
 the only floating-point step (SwitchCRTBasis overflow count) is also required to be bit-exact because it
 replicates the reference's operation order.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -409,6 +411,59 @@ def test_hoisted_rotations(backend, oracle, logN, sizeQ, dnum, sizeQl, B):
     assert not ext[:, sizeQl:].any()
     for hnd in handles:
         backend.L.fhe_ks_key_destroy(hnd)
+    plan.close()
+    ctx.close()
+    o.orc_hybrid_destroy(hy)
+
+
+@pytest.mark.gpu
+def test_graph_capture_replays_eval_mult(oracle):
+    """a captured EvalMult + key switch (fhe_graph_begin/end) replays bit-exactly, also on fresh inputs"""
+    lib = fh.Lib()
+    if lib.device_count() < 1:
+        pytest.skip("needs a HIP device")
+    o = oracle
+    rng = np.random.default_rng(55)
+    logN, sizeQ, dnum, B = 12, 5, 2, 2
+    N = 1 << logN
+    q, psiQ, p, psiP = ckks_like_params(o, logN, sizeQ, dnum)
+    sizeP = len(p)
+    hy = o.orc_hybrid_create(N, sizeQ, q, psiQ, sizeP, p, psiP, dnum)
+    allq = np.concatenate([q, p])
+    ctx = fh.Context(lib, logN, allq, np.concatenate([psiQ, psiP]))
+    plan = fh.KeySwitchPlan(ctx, sizeQ, sizeP, dnum)
+    keyB, keyA = libs.rand_tower(rng, allq, N, dnum), libs.rand_tower(rng, allq, N, dnum)
+    plan.upload_key(keyB, keyA)
+    ops = [libs.rand_tower(rng, q, N, B) for _ in range(4)]
+    T = [ctx.tower(x) for x in ops]
+    c0, c1 = T[0].like(), T[0].like()
+    ws, wsb = plan.workspace(sizeQ, B)
+    st = C.c_void_p()
+    lib.check(lib.L.fhe_stream_create(ctx.h, C.byref(st)))
+
+    def call():
+        lib.check(lib.L.fhe_ckks_eval_mult(plan.h, plan.key, T[0].ptr, T[1].ptr, T[2].ptr, T[3].ptr, sizeQ, B, c0.ptr, c1.ptr,
+                                           ws, wsb, st))
+    call()  # builds the level's tables
+    lib.check(lib.L.fhe_stream_sync(ctx.h, st))
+    g = C.c_void_p()
+    lib.check(lib.L.fhe_graph_begin(ctx.h, st))
+    call()
+    lib.check(lib.L.fhe_graph_end(ctx.h, st, C.byref(g)))
+    for trial in range(2):
+        if trial:  # new operands in the same buffers: the graph must pick them up
+            for t, x in zip(T, ops):
+                x[:] = libs.rand_tower(rng, q, N, B)
+                lib.check(lib.L.fhe_memcpy_h2d(ctx.h, t.ptr, x.ctypes.data_as(C.c_void_p), x.nbytes, None))
+            ctx.sync()
+        lib.check(lib.L.fhe_graph_launch(ctx.h, g, st))
+        lib.check(lib.L.fhe_stream_sync(ctx.h, st))
+        for b in range(B):
+            w0, w1 = np.empty((sizeQ, N), np.uint64), np.empty((sizeQ, N), np.uint64)
+            o.orc_ckks_eval_mult_relin(hy, ops[0][b], ops[1][b], ops[2][b], ops[3][b], sizeQ, keyB, keyA, w0, w1)
+            assert np.array_equal(c0.to_host()[b], w0) and np.array_equal(c1.to_host()[b], w1), f"graph replay {trial}"
+    lib.L.fhe_graph_destroy(g)
+    lib.check(lib.L.fhe_stream_destroy(ctx.h, st))
     plan.close()
     ctx.close()
     o.orc_hybrid_destroy(hy)

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 echo "== rocprof kernel stats (same command as the bench line)"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r01 -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_r01.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_r01_$c -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-evalmult --no-bfv > $GRAFT_REPO_ROOT/gpurun_out/pmc_r01_$c.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_r01_$c -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-evalmult --no-bfv --no-hadamard > $GRAFT_REPO_ROOT/gpurun_out/pmc_r01_$c.log 2>&1
 done
 cd $GRAFT_REPO_ROOT
 f=$(find gpurun_out/prof_r01 -name "*kernel_stats.csv" | head -1); head -14 $f | cut -c1-170
