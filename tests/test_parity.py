@@ -209,7 +209,7 @@ def conv_tables(o, src, dst):
 def test_approx_and_exact_switch_crt_basis(backend, oracle):
     o = oracle
     rng = np.random.default_rng(15)
-    for logN, nS, nD, B in [(5, 2, 3, 2), (12, 3, 9, 1), (12, 7, 21, 1), (13, 4, 5, 2)]:
+    for logN, nS, nD, B in [(5, 2, 3, 2), (12, 3, 9, 1), (12, 7, 21, 1), (13, 4, 5, 2), (10, 12, 3, 1), (10, 20, 2, 1)]:
         N = 1 << logN
         q, psi = params(o, logN, nS + nD)
         ctx = fh.Context(backend, logN, q, psi)
