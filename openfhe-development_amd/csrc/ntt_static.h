@@ -84,9 +84,40 @@ FHE_HD constexpr uint32_t lds_pad(uint32_t I) {
     return I + (I >> 4);
 }
 
-template <bool INV, bool UNI, int B>
-FHE_HD void run_stage(uint64_t (&r)[16], const TwPair (&w)[8], const BflyConst c, const BflyZero z) {
+// Inverse stages are LAZY in the sum output (a' = u + v is not reduced): the bound of a residue doubles along its chain
+// of sum outputs and returns to 2q with every product output, the constant K of u - v + K is the pair's bound, a
+// pair that reached 16q is brought back to 8q first, and the step ends with the few conditional subtractions that bring
+// every residue below 2q again (16 instead of 32 subtractions per 4-stage step; tools/gen_ntt_asm.py, inv_lazy_plan).
+// `bnd` carries the bounds (units of q) through the stages of a step in the C++ build; the generated gfx950 code has
+// them folded into its constants.
+FHE_HD void inv_lazy_stage_cpp(int B, uint64_t (&r)[16], const TwPair (&w)[8], const BflyConst c, uint32_t (&bnd)[16]) {
+    const uint64_t nq = ((uint64_t)c.nqh << 32) | c.nql, q = c.twoq >> 1;
+    for (int g = 0; g < (8 >> B); ++g)
+        for (int lo = 0; lo < (1 << B); ++lo) {
+            const int k0 = (g << (B + 1)) | lo, k1 = k0 | (1 << B);
+            if (bnd[k0] >= 16u) {
+                r[k0] = csub2(r[k0], q << 3), r[k1] = csub2(r[k1], q << 3);
+                bnd[k0] = bnd[k1] = 8;
+            }
+            const uint64_t u = r[k0], v = r[k1];
+            r[k0]   = u + v;
+            r[k1]   = shoup_acc(0, u - v + (uint64_t)bnd[k0] * q, w[g], nq);
+            bnd[k0] = 2 * bnd[k0], bnd[k1] = 2;
+        }
+}
+FHE_HD void inv_lazy_end_cpp(uint64_t (&r)[16], const BflyConst c, uint32_t (&bnd)[16]) {
+    const uint64_t q = c.twoq >> 1;
+    for (int k = 0; k < 16; ++k)
+        while (bnd[k] > 2u) {
+            bnd[k] >>= 1;
+            r[k] = csub2(r[k], (uint64_t)bnd[k] * q);
+        }
+}
+
+template <bool INV, bool UNI, int B, int BLO>
+FHE_HD void run_stage(uint64_t (&r)[16], const TwPair (&w)[8], const BflyConst c, const BflyZero z, uint32_t (&bnd)[16]) {
 #ifdef FHE_PINNED_ASM
+    (void)bnd;
     if constexpr (!INV) {
         if constexpr (UNI) {
             if constexpr (B == 0) stage_fwd_s_b0(r, w, c, z);
@@ -102,42 +133,63 @@ FHE_HD void run_stage(uint64_t (&r)[16], const TwPair (&w)[8], const BflyConst c
         }
     }
     else {
+#define FHE_INVL(TAG, BB, LO) if constexpr (B == BB && BLO == LO) stage_invl_##TAG##_b##BB##_lo##LO(r, w, c, z);
         if constexpr (UNI) {
-            if constexpr (B == 0) stage_inv_s_b0(r, w, c, z);
-            if constexpr (B == 1) stage_inv_s_b1(r, w, c, z);
-            if constexpr (B == 2) stage_inv_s_b2(r, w, c, z);
-            if constexpr (B == 3) stage_inv_s_b3(r, w, c, z);
+            FHE_INVL(s, 0, 0) FHE_INVL(s, 1, 0) FHE_INVL(s, 2, 0) FHE_INVL(s, 3, 0) FHE_INVL(s, 1, 1) FHE_INVL(s, 2, 1)
+            FHE_INVL(s, 3, 1) FHE_INVL(s, 2, 2) FHE_INVL(s, 3, 2) FHE_INVL(s, 3, 3)
         }
         else {
-            if constexpr (B == 0) stage_inv_v_b0(r, w, c, z);
-            if constexpr (B == 1) stage_inv_v_b1(r, w, c, z);
-            if constexpr (B == 2) stage_inv_v_b2(r, w, c, z);
-            if constexpr (B == 3) stage_inv_v_b3(r, w, c, z);
+            FHE_INVL(v, 0, 0) FHE_INVL(v, 1, 0) FHE_INVL(v, 2, 0) FHE_INVL(v, 3, 0) FHE_INVL(v, 1, 1) FHE_INVL(v, 2, 1)
+            FHE_INVL(v, 3, 1) FHE_INVL(v, 2, 2) FHE_INVL(v, 3, 2) FHE_INVL(v, 3, 3)
         }
+#undef FHE_INVL
     }
 #else
     (void)z;
+    if (INV) {
+        inv_lazy_stage_cpp(B, r, w, c, bnd);
+        return;
+    }
     const uint64_t nq = ((uint64_t)c.nqh << 32) | c.nql;
     for (int g = 0; g < (8 >> B); ++g)
         for (int lo = 0; lo < (1 << B); ++lo) {
             const int k0 = (g << (B + 1)) | lo;
-            if (INV)
-                bfly_inv_fast(r[k0], r[k0 | (1 << B)], w[g], nq, c.twoq);
-            else
-                bfly_fwd_fast(r[k0], r[k0 | (1 << B)], w[g], nq, c.twoq);
+            bfly_fwd_fast(r[k0], r[k0 | (1 << B)], w[g], nq, c.twoq);
         }
 #endif
 }
+// end of a lazy inverse step: every residue back below 2q
+template <int BLO, int BHI>
+FHE_HD void run_inv_lazy_end(uint64_t (&r)[16], const BflyConst c, uint32_t (&bnd)[16]) {
+#ifdef FHE_PINNED_ASM
+    (void)bnd;
+#define FHE_INVE(LO, HI) if constexpr (BLO == LO && BHI == HI) inv_lazy_end_lo##LO##_hi##HI(r, c);
+    FHE_INVE(0, 0) FHE_INVE(0, 1) FHE_INVE(0, 2) FHE_INVE(0, 3) FHE_INVE(1, 1) FHE_INVE(1, 2) FHE_INVE(1, 3) FHE_INVE(2, 2)
+    FHE_INVE(2, 3) FHE_INVE(3, 3)
+#undef FHE_INVE
+#else
+    inv_lazy_end_cpp(r, c, bnd);
+#endif
+}
 
-// last inverse stage (s == 0, always field bit 3): lower output * N^-1, upper output * (w1 * N^-1)
-FHE_HD void run_last_inv_stage(uint64_t (&r)[16], const TwPair nInv, const TwPair w1n, const BflyConst c, const BflyZero z) {
+// last inverse stage (s == 0, always field bit 3): lower output * N^-1, upper output * (w1 * N^-1).  Its inputs carry the
+// lazy bounds of the step (see run_stage): the pair's K and the 16q -> 8q correction follow the same plan.
+template <int BLO>
+FHE_HD void run_last_inv_stage(uint64_t (&r)[16], const TwPair nInv, const TwPair w1n, const BflyConst c, const BflyZero z,
+                               uint32_t (&bnd)[16]) {
+    const uint64_t q = c.twoq >> 1;
+#ifdef FHE_PINNED_ASM
+    (void)bnd;
+    if constexpr (BLO == 0) inv_lazy_pre_b3_lo0(r, c);
+    if constexpr (BLO == 1) inv_lazy_pre_b3_lo1(r, c);
+    if constexpr (BLO == 2) inv_lazy_pre_b3_lo2(r, c);
+    if constexpr (BLO == 3) inv_lazy_pre_b3_lo3(r, c);
 #pragma unroll
     for (int lo = 0; lo < 8; ++lo) {
         const uint64_t u = r[lo], v = r[lo | 8];
         r[lo]            = u + v;
-        r[lo | 8]        = u - v + c.twoq;
+        r[lo | 8]        = u - v + (uint64_t)kInvLazyK[BLO][3][lo] * q;
     }
-#ifdef FHE_PINNED_ASM
     mul2_s_0(r, nInv, w1n, c, z);
     mul2_s_1(r, nInv, w1n, c, z);
     mul2_s_2(r, nInv, w1n, c, z);
@@ -150,8 +202,14 @@ FHE_HD void run_last_inv_stage(uint64_t (&r)[16], const TwPair nInv, const TwPai
     (void)z;
     const uint64_t nq = ((uint64_t)c.nqh << 32) | c.nql;
     for (int lo = 0; lo < 8; ++lo) {
-        r[lo]     = shoup_acc(0, r[lo], nInv, nq);
-        r[lo | 8] = shoup_acc(0, r[lo | 8], w1n, nq);
+        if (bnd[lo] >= 16u) {
+            r[lo] = csub2(r[lo], q << 3), r[lo | 8] = csub2(r[lo | 8], q << 3);
+            bnd[lo] = bnd[lo | 8] = 8;
+        }
+        const uint64_t u = r[lo], v = r[lo | 8];
+        r[lo]     = shoup_acc(0, u + v, nInv, nq);
+        r[lo | 8] = shoup_acc(0, u - v + (uint64_t)bnd[lo] * q, w1n, nq);
+        bnd[lo] = bnd[lo | 8] = 2;
     }
 #endif
 }
@@ -304,17 +362,20 @@ FHE_HD void load_stage_tw(TwPair (&w)[8], const TwSrc ts, uint32_t j0, uint32_t 
 }
 
 template <bool LA, bool INV, int T, int I, int B, bool ENDS>
-FHE_HD void exec_stage(uint64_t (&r)[16], const TwPair (&w)[8], const BflyConst c, const BflyZero z) {
+FHE_HD void exec_stage(uint64_t (&r)[16], const TwPair (&w)[8], const BflyConst c, const BflyZero z, uint32_t (&bnd)[16]) {
     using S = StageInfo<LA, INV, T, I, B>;
     using P = SPlan<LA, INV, T>;
     if constexpr (S::active) {
         if constexpr (INV && ENDS && I == P::nst - 1 && B == P::bHi(I))
-            run_last_inv_stage(r, w[0], w[1], c, z);
+            run_last_inv_stage<P::bLo(I)>(r, w[0], w[1], c, z, bnd);
         else {
 #ifdef FHE_ABL_NOBFLY
             return;
 #endif
-            run_stage<INV, S::uni, B>(r, w, c, z);
+            run_stage<INV, S::uni, B, P::bLo(I)>(r, w, c, z, bnd);
+            // a lazy inverse step ends with the reductions back below 2q (after its last stage)
+            if constexpr (INV && B == P::bHi(I))
+                run_inv_lazy_end<P::bLo(I), P::bHi(I)>(r, c, bnd);
         }
     }
 }
@@ -325,15 +386,18 @@ FHE_HD void exec_stage(uint64_t (&r)[16], const TwPair (&w)[8], const BflyConst 
 template <bool LA, bool INV, int T, int I, bool ENDS>
 FHE_HD void run_step(uint64_t (&r)[16], const TwSrc ts, uint32_t j0, uint32_t logN, const BflyConst c, const BflyZero z) {
     TwPair w0[8], w1[8], w2[8], w3[8];
+    uint32_t bnd[16];  // lazy bounds of an inverse step (C++ build only; every step starts below 2q)
+    for (int k = 0; k < 16; ++k)
+        bnd[k] = 2;
     constexpr int B0 = INV ? 0 : 3, B1 = INV ? 1 : 2, B2 = INV ? 2 : 1, B3 = INV ? 3 : 0;
     load_stage_tw<LA, INV, T, I, B0, ENDS>(w0, ts, j0, logN);
     load_stage_tw<LA, INV, T, I, B1, ENDS>(w1, ts, j0, logN);
-    exec_stage<LA, INV, T, I, B0, ENDS>(r, w0, c, z);
+    exec_stage<LA, INV, T, I, B0, ENDS>(r, w0, c, z, bnd);
     load_stage_tw<LA, INV, T, I, B2, ENDS>(w2, ts, j0, logN);
-    exec_stage<LA, INV, T, I, B1, ENDS>(r, w1, c, z);
+    exec_stage<LA, INV, T, I, B1, ENDS>(r, w1, c, z, bnd);
     load_stage_tw<LA, INV, T, I, B3, ENDS>(w3, ts, j0, logN);
-    exec_stage<LA, INV, T, I, B2, ENDS>(r, w2, c, z);
-    exec_stage<LA, INV, T, I, B3, ENDS>(r, w3, c, z);
+    exec_stage<LA, INV, T, I, B2, ENDS>(r, w2, c, z, bnd);
+    exec_stage<LA, INV, T, I, B3, ENDS>(r, w3, c, z, bnd);
 }
 
 // lane geometry of a step whose register field sits at tile-index bit fI: tile index of register 0 and the

@@ -217,6 +217,78 @@ def inv_stream(t, A, B, w):
     return pre + head[:2] + sel + head[2:] + tail
 
 
+def inv_lazy_stream(t, A, B, w, kop):
+    """Gentleman-Sande butterfly without the reduction of the sum: a' = u + v, b' = shoup(u - v + K, w) with K = the
+    bound of v (a multiple of 2q given as the scalar operand `kop`); the caller tracks the bounds (inv_lazy_plan)"""
+    pre = [
+        lshladd(p(t.Y), p(A), 0, kop),
+        lshladd(p(A), p(A), 0, p(B)),
+        subco(v(t.Y), t.c0, v(t.Y), v(B)),
+        subbco(v(t.Y + 1), t.c0, v(t.Y + 1), v(B + 1), t.c0),
+    ]
+    head, tail = shoup_tail(t, v(t.Y), v(t.Y + 1), w, p(B), "0")
+    return pre + head + tail
+
+
+def inv_lazy_plan(bLo, bHi, ends=False):
+    """Bounds (units of q) of the 16 residues through the inverse stages bLo..bHi when the sum output is not reduced:
+    inputs < 2q; a' = u + v doubles the bound, b' = shoup(.) is < 2q again.  A pair whose bound reached 16q is brought
+    back to 8q first (u + v and u - v + K must stay below 2^64 > 16q).  Returns
+      pre[b]  = [(k, m)]: residue k gets csub(m*q) before stage b,
+      K[b]    = [m per butterfly, in stage_pairs order]: K = m*q,
+      end     = [(k, m), ...] in order: csub(m*q) bringing every residue below 2q after the last stage.
+    ends: the last stage is the transform's final multiplication stage (outputs < 2q, no end reductions)."""
+    bound = [2] * 16
+    pre, K = {}, {}
+    for b in range(bLo, bHi + 1):
+        pre[b], K[b] = [], []
+        for (k0, k1, _g) in stage_pairs(b):
+            assert bound[k0] == bound[k1]
+            if bound[k0] >= 16:
+                pre[b] += [(k0, 8), (k1, 8)]
+                bound[k0] = bound[k1] = 8
+            K[b].append(bound[k0])
+            if ends and b == bHi:
+                bound[k0] = bound[k1] = 2
+            else:
+                bound[k0], bound[k1] = 2 * bound[k0], 2
+    end = []
+    lvl = 8
+    while lvl >= 2:
+        for k in range(16):
+            if bound[k] > lvl:
+                end.append((k, lvl))
+                bound[k] = lvl
+        lvl //= 2
+    assert all(b == 2 for b in bound)
+    return pre, K, end
+
+
+def csub_blocks(items):
+    """[(k, m)] in execution order -> blocks of <= 4 conditional subtractions; a block never holds the same residue twice
+    (the levels of one residue are sequential) and keeps the order between levels"""
+    blocks, cur = [], []
+    for k, m in items:
+        if len(cur) == 4 or any(k == k2 for k2, _ in cur):
+            blocks.append(cur)
+            cur = []
+        cur.append((k, m))
+    if cur:
+        blocks.append(cur)
+    return blocks
+
+
+def csub_chain_stream(i, A, mop, nop):
+    """x = x < m ? x : x - m with explicit operand names for m and -m; chain i of up to 4"""
+    D, c = CSUB_TMP[i], f"s[{42 + 2 * i}:{43 + 2 * i}]"
+    return [
+        lshladd(p(D), p(A), 0, nop),
+        cmplt64(c, p(A), mop),
+        cnd(v(A), v(D), v(A), c),
+        cnd(v(A + 1), v(D + 1), v(A + 1), c),
+    ]
+
+
 def mul_stream(t, A, w):
     """x = shoup(x, w) in place (last inverse stage: the caller forms u+v / u-v+2q first); x is only overwritten by
     the last instruction, after every read of its halves"""
@@ -386,6 +458,55 @@ def check_blocks():
         run(schedule([csub_stream(i, R(4 + i)) for i in range(4)]), S)
         for i, x0 in enumerate(xs):
             assert S.g64(p(R(4 + i))) == (x0 if x0 < m else x0 - m), "csub"
+    # lazy inverse steps: every (bLo, bHi), with and without the final multiplication stage
+    for bLo in range(4):
+        for bHi in range(bLo, 4):
+            for ends in ((False, True) if bHi == 3 else (False,)):
+                pre, K, end = inv_lazy_plan(bLo, bHi, ends)
+                for it in range(40):
+                    q = rnd.getrandbits(60) | (1 << 59) | 1
+                    S = St()
+                    S.v[T(0).Z + 1] = S.v[T(1).Z + 1] = 0
+                    S.ops = {"nql": (-q) & M32, "nqh": ((-q) & M64) >> 32}
+                    for m in (2, 4, 8):
+                        S.ops[f"k{m}"], S.ops[f"n{m}"] = m * q, (-m * q) & M64
+                    x = [rnd.randrange(2 * q) if it else 2 * q - 1 for _ in range(16)]
+                    ref = [v_ % q for v_ in x]
+                    for k in range(16):
+                        S.set64(p(R(k)), x[k])
+                    for b in range(bLo, bHi + 1):
+                        for grp in csub_blocks(pre[b]):
+                            run(schedule([csub_chain_stream(i, R(k), f"%[k{m}]", f"%[n{m}]") for i, (k, m) in enumerate(grp)]), S)
+                        prs = stage_pairs(b)
+                        for j in range(0, 8, 2):
+                            tw = [rnd.randrange(q), rnd.randrange(q)]
+                            for i in (0, 1):
+                                wp_ = (tw[i] << 64) // q
+                                S.ops.update({f"wl{i}": tw[i] & M32, f"wh{i}": tw[i] >> 32, f"pl{i}": wp_ & M32, f"ph{i}": wp_ >> 32})
+                            (a0, a1, _), (b0, b1, _) = prs[j], prs[j + 1]
+                            if ends and b == bHi:  # final stage: sums / differences formed by the caller, then multiplied
+                                for (u_, v_), m in (((a0, a1), K[b][j]), ((b0, b1), K[b][j + 1])):
+                                    uu, vv = S.g64(p(R(u_))), S.g64(p(R(v_)))
+                                    assert uu + vv < 1 << 64 and uu - vv + m * q < 1 << 64
+                                    S.set64(p(R(u_)), uu + vv), S.set64(p(R(v_)), uu - vv + m * q)
+                                run(schedule([mul_stream(T(0), R(a0), 0), mul_stream(T(1), R(b0), 1)]), S)
+                                run(schedule([mul_stream(T(0), R(a1), 0), mul_stream(T(1), R(b1), 1)]), S)
+                                for (u_, v_), w_ in (((a0, a1), tw[0]), ((b0, b1), tw[1])):
+                                    ru, rv = ref[u_], ref[v_]
+                                    ref[u_], ref[v_] = (ru + rv) * w_ % q, (ru - rv) * w_ % q
+                            else:
+                                for (u_, v_) in ((a0, a1), (b0, b1)):
+                                    assert S.g64(p(R(u_))) + S.g64(p(R(v_))) < 1 << 64
+                                run(schedule([inv_lazy_stream(T(0), R(a0), R(a1), 0, f"%[k{K[b][j]}]"),
+                                              inv_lazy_stream(T(1), R(b0), R(b1), 1, f"%[k{K[b][j + 1]}]")]), S)
+                                for (u_, v_), w_ in (((a0, a1), tw[0]), ((b0, b1), tw[1])):
+                                    ru, rv = ref[u_], ref[v_]
+                                    ref[u_], ref[v_] = (ru + rv) % q, (ru - rv) * w_ % q
+                    for grp in csub_blocks(end):
+                        run(schedule([csub_chain_stream(i, R(k), f"%[k{m}]", f"%[n{m}]") for i, (k, m) in enumerate(grp)]), S)
+                    for k in range(16):
+                        got = S.g64(p(R(k)))
+                        assert got < 2 * q and got % q == ref[k], ("lazy inverse step", bLo, bHi, ends, k)
     # 192-bit column sums -> canonical residue
     for it in range(4000):
         bits = rnd.choice([28, 45, 59, 60])
@@ -470,6 +591,31 @@ def emit_pair_fn(name, kind, ka, kb, cls):
             + asm_block(block, outs, tw_in(0, cls) + tw_in(1, cls) + CONST_IN + ZERO_IN, 2) + "}\n")
 
 
+LAZY_CONST_IN = ['[nql] "s"(c.nql)', '[nqh] "s"(c.nqh)', '[k2] "s"(c.twoq)', '[k4] "s"(c.twoq << 1)', '[k8] "s"(c.twoq << 2)']
+LAZY_RED_IN = ['[k2] "s"(c.twoq)', '[k4] "s"(c.twoq << 1)', '[k8] "s"(c.twoq << 2)', '[n2] "s"(0 - c.twoq)',
+               '[n4] "s"(0 - (c.twoq << 1))', '[n8] "s"(0 - (c.twoq << 2))']
+
+
+def emit_lazy_pair_fn(name, ka, kb, cls, Ka, Kb):
+    block = schedule([inv_lazy_stream(T(0), R(ka[0]), R(ka[1]), 0, f"%[k{Ka}]"),
+                      inv_lazy_stream(T(1), R(kb[0]), R(kb[1]), 1, f"%[k{Kb}]")])
+    args = "uint64_t (&r)[16], const TwPair wa, const TwPair wb, const BflyConst c, const BflyZero z"
+    body = "".join(f"    const uint32_t w{i}l = (uint32_t)w{n}.w, w{i}h = (uint32_t)(w{n}.w >> 32), p{i}l = (uint32_t)w{n}.wp, "
+                   f"p{i}h = (uint32_t)(w{n}.wp >> 32);\n" for i, n in ((0, "a"), (1, "b")))
+    outs = [pin(k, f"r[{k}]") for k in (ka[0], ka[1], kb[0], kb[1])]
+    return (f"__device__ __forceinline__ void {name}({args}) {{\n{body}"
+            + asm_block(block, outs, tw_in(0, cls) + tw_in(1, cls) + LAZY_CONST_IN + ZERO_IN, 2) + "}\n")
+
+
+def emit_reduce_fn(name, items):
+    """conditional subtractions [(k, m)] (threshold m*q) as blocks of <= 4"""
+    body = ""
+    for grp in csub_blocks(items):
+        block = schedule([csub_chain_stream(i, R(k), f"%[k{m}]", f"%[n{m}]") for i, (k, m) in enumerate(grp)])
+        body += asm_block(block, [pin(k, f"r[{k}]") for k, _ in grp], LAZY_RED_IN, 0)
+    return f"__device__ __forceinline__ void {name}(uint64_t (&r)[16], const BflyConst c) {{\n(void)c;\n{body}}}\n"
+
+
 def emit_mul_fn(name, ka, kb, cls):
     block = schedule([mul_stream(T(0), R(ka), 0), mul_stream(T(1), R(kb), 1)])
     args = "uint64_t (&r)[16], const TwPair wa, const TwPair wb, const BflyConst c, const BflyZero z"
@@ -531,6 +677,30 @@ struct BflyZero {   // two VGPRs holding 0 (high halves of the zero-extended mul
                 H.append(f"// stage b = {b}: twiddle g serves the butterflies whose index has (k >> {b + 1}) == g\n"
                          f"__device__ __forceinline__ void stage_{kind}_{tag}_b{b}(uint64_t (&r)[16], const TwPair (&w)[8], "
                          f"const BflyConst c, const BflyZero z) {{\n" + "".join(fn) + "}\n")
+    # lazy inverse stages: the sum output is not reduced; bounds follow inv_lazy_plan(bLo, .)
+    ktab = [[[0] * 8 for _ in range(4)] for _ in range(4)]
+    for bLo in range(4):
+        for b in range(bLo, 4):
+            pre, K, _ = inv_lazy_plan(bLo, b)
+            ktab[bLo][b] = K[b]
+            H.append(emit_reduce_fn(f"inv_lazy_pre_b{b}_lo{bLo}", pre[b]))
+            prs = stage_pairs(b)
+            for cls, tag in (("v", "v"), ("s", "s")):
+                fn = []
+                for i in range(0, 8, 2):
+                    (a0, a1, ga), (b0, b1, gb) = prs[i], prs[i + 1]
+                    name = f"bfly2_invl_{tag}_b{b}_lo{bLo}_{i // 2}"
+                    H.append(emit_lazy_pair_fn(name, (a0, a1), (b0, b1), cls, K[b][i], K[b][i + 1]))
+                    fn.append(f"    {name}(r, w[{ga}], w[{gb}], c, z);\n")
+                H.append(f"__device__ __forceinline__ void stage_invl_{tag}_b{b}_lo{bLo}(uint64_t (&r)[16], const TwPair (&w)[8], "
+                         f"const BflyConst c, const BflyZero z) {{\n    inv_lazy_pre_b{b}_lo{bLo}(r, c);\n" + "".join(fn) + "}\n")
+        for bHi in range(bLo, 4):
+            _, _, end = inv_lazy_plan(bLo, bHi)
+            H.append(emit_reduce_fn(f"inv_lazy_end_lo{bLo}_hi{bHi}", end))
+    H.append("// K multiplier (units of q) of butterfly `pair` of stage b when the step starts at stage bLo: [bLo][b][pair]\n"
+             "__device__ constexpr unsigned char kInvLazyK[4][4][8] = {"
+             + ", ".join("{" + ", ".join("{" + ", ".join(str(x) for x in ktab[lo][b]) + "}" for b in range(4)) + "}" for lo in range(4))
+             + "};\n")
     # last inverse stage (s == 0): residues lo and lo|8 multiplied by N^-1 and w1*N^-1
     for i in range(8):
         H.append(emit_mul_fn(f"mul2_s_{i}", i, i | 8, "s"))
