@@ -728,7 +728,8 @@ static bool ntt_epilogue_supported(const fhe_ctx* c) {
 }
 static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_t* xout, const uint32_t* limbIdx,
                           uint32_t nLimbs, uint32_t batch, void* stream, uint32_t inStride = 0, uint32_t inFirst = 0,
-                          uint32_t outStride = 0, uint32_t outFirst = 0, const NttEpilogue* epi = nullptr) {
+                          uint32_t outStride = 0, uint32_t outFirst = 0, const NttEpilogue* epi = nullptr,
+                          bool canonOut = true) {
     ARG_CHECK(c && xin && xout, "fhe_ntt: null argument");
     ARG_CHECK(batch >= 1, "fhe_ntt: batch must be >= 1");
     LimbSel sel;
@@ -744,7 +745,7 @@ static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_
         if (!inverse)
             schedule_fwd(p, logN, &bound);
         p.outBound = bound;
-        return launch_pass(c, p, inverse, xin, xout, sel, nLimbs, batch, true, stream, inStride, inFirst, outStride, outFirst, epi);
+        return launch_pass(c, p, inverse, xin, xout, sel, nLimbs, batch, canonOut, stream, inStride, inFirst, outStride, outFirst, epi);
     }
     // two passes over HBM: a strided column pass of T1 stages (the coefficient index's top bits) and a
     // contiguous row pass of T2 = logN - T1 stages.  T1 is kept minimal (>= 4) so that the column pass reads
@@ -770,7 +771,7 @@ static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_
     // resident slots of a CU away from the row workgroups: 33.2 ms instead of 30.4 ms per forward+inverse step).
     if (fhe_status s = launch_pass(c, p1, inverse, xin, xout, sel, nLimbs, batch, false, stream, inStride, inFirst, outStride, outFirst))
         return s;
-    return launch_pass(c, p2, inverse, xout, xout, sel, nLimbs, batch, true, stream, outStride, outFirst, outStride, outFirst, epi);
+    return launch_pass(c, p2, inverse, xout, xout, sel, nLimbs, batch, canonOut, stream, outStride, outFirst, outStride, outFirst, epi);
 }
 
 extern "C" fhe_status fhe_ntt_fwd(fhe_ctx* c, uint64_t* x, const uint32_t* li, uint32_t nl, uint32_t b, void* st) {
@@ -1467,7 +1468,9 @@ static fhe_status ks_precompute_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, cons
         uint64_t* dj      = ws + w.dig[j];
         if (fhe_status s = fhe_approx_switch_basis(lv->up[j], ws + w.coef, sizeQl, p->alpha * j, dj, nc, 0, batch, st))
             return s;
-        if (fhe_status s = fhe_ntt_fwd(c, dj, lv->cidx[j].data(), nc, batch, st))
+        // the digits are only read by the inner product, whose 128-bit accumulation takes any 64-bit operand: the
+        // transform's outputs stay in the lazy range (< 16q), the 4-level canonicalisation is skipped
+        if (fhe_status s = ntt_run(c, false, dj, dj, lv->cidx[j].data(), nc, batch, st, 0, 0, 0, 0, nullptr, false))
             return s;
     }
     return FHE_OK;

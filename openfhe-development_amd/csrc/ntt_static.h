@@ -517,7 +517,7 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
         if (acc) {                                                                                \
             _Pragma("unroll") for (int k = 0; k < 4; ++k) ov[k] = O[jr + ks4[k] * kstr];          \
         }                                                                                         \
-        _Pragma("unroll") for (int k = 0; k < 4; ++k) v[ks4[k]] = sub_mod(av[k], v[ks4[k]], q);   \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) v[ks4[k]] = av[k] + (q << 3) - v[ks4[k]];   \
         epi_mul2<2 * G>(v, cpair, c, z);                                                          \
         epi_mul2<2 * G + 1>(v, cpair, c, z);                                                      \
         _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                           \
@@ -584,9 +584,11 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
                 else {                                                                                            \
                     constexpr int ob = P::outBound(MODE);                                                         \
                     if constexpr (ob > 8) run_csub16(r, q << 3);                                                  \
-                    if constexpr (ob > 4) run_csub16(r, q << 2);                                                  \
-                    if constexpr (ob > 2) run_csub16(r, q << 1);                                                  \
-                    run_csub16(r, q);                                                                             \
+                    if constexpr (!EPI) { /* the epilogue takes values below 8q (A + 8q - r, then a Shoup product) */ \
+                        if constexpr (ob > 4) run_csub16(r, q << 2);                                              \
+                        if constexpr (ob > 2) run_csub16(r, q << 1);                                              \
+                        run_csub16(r, q);                                                                         \
+                    }                                                                                             \
                 }                                                                                                 \
             }                                                                                                     \
         }                                                                                                         \
