@@ -756,7 +756,14 @@ __device__ __forceinline__ uint64_t reduce192_uniform(uint64_t c0, uint64_t c1, 
 #endif
 #endif
 """)
-    open(OUT, "w").write("".join(H))
+    text = "".join(H)
+    if "--check" in sys.argv:  # tests: the committed header must be what this generator (and its simulation) produces
+        if open(OUT).read() != text:
+            print("ntt_bfly_pinned.h is stale: run python tools/gen_ntt_asm.py")
+            return 1
+        print("ntt_bfly_pinned.h is up to date; all blocks simulated OK")
+        return 0
+    open(OUT, "w").write(text)
     n = sum(1 for c in schedule([fwd_stream(T(0), R(0), R(1), 0), fwd_stream(T(1), R(2), R(3), 1)]) if not c["t"].startswith("s_nop"))
     ni = sum(1 for c in schedule([inv_stream(T(0), R(0), R(1), 0), inv_stream(T(1), R(2), R(3), 1)]) if not c["t"].startswith("s_nop"))
     print(f"wrote {OUT}: forward pair {n} VALU, inverse pair {ni} VALU; all blocks simulated OK")
