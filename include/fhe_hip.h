@@ -324,6 +324,13 @@ size_t     fhe_bfv_eval_mult_behz_workspace_bytes(const fhe_behz* plan, uint32_t
 fhe_status fhe_bfv_eval_mult_behz(fhe_behz* plan, const uint64_t* a0, const uint64_t* a1, const uint64_t* b0,
                                   const uint64_t* b1, uint64_t* d0, uint64_t* d1, uint64_t* d2, int outEval,
                                   uint32_t batch, void* ws, size_t wsBytes, void* stream);
+/* The same with relinearisation — LeveledSHEBase::EvalMult(ct, ct, key) on BFV/BEHZ ciphertexts (base-leveledshe.cpp:201-214):
+ * EvalMultNoRelin, SetFormat(EVALUATION), KeySwitchCore on the third element, c0 += ks0, c1 += ks1.  The context holds Q
+ * as its leading limbs (the key-switch plan's Q), P, and the Bsk limbs; outputs [batch][numQ][N] EVALUATION. */
+size_t     fhe_bfv_eval_mult_relin_workspace_bytes(const fhe_behz* plan, const fhe_ks_plan* ks, uint32_t batch);
+fhe_status fhe_bfv_eval_mult_relin_behz(fhe_behz* plan, fhe_ks_plan* ks, const fhe_ks_key* key, const uint64_t* a0,
+                                        const uint64_t* a1, const uint64_t* b0, const uint64_t* b1, uint64_t* c0, uint64_t* c1,
+                                        uint32_t batch, void* ws, size_t wsBytes, void* stream);
 
 /* ---- host-side parameter helpers (no device work) -------------------------------------------------
  * Number theory the reference uses to pick moduli and roots, restated with 64-bit arithmetic so that a

@@ -2357,3 +2357,31 @@ extern "C" fhe_status fhe_bfv_eval_mult_behz(fhe_behz* h, const uint64_t* a0, co
     }
     return FHE_OK;
 }
+
+// LeveledSHEBase::EvalMult(ct, ct, key) for BFV/BEHZ (base-leveledshe.cpp:201-214 over bfvrns-leveledshe.cpp:198-445):
+// EvalMultNoRelin (three elements, COEFFICIENT) -> SetFormat(EVALUATION) -> KeySwitchCore on the third element ->
+// c0 += ks0, c1 += ks1.  The context holds Q (limbs 0..sizeQ-1, the key-switch plan's Q), P and the Bsk limbs.
+extern "C" size_t fhe_bfv_eval_mult_relin_workspace_bytes(const fhe_behz* bz, const fhe_ks_plan* p, uint32_t batch) {
+    if (!bz || !p)
+        return 0;
+    return fhe_bfv_eval_mult_behz_workspace_bytes(bz, batch) + fhe_ks_workspace_bytes(p, p->sizeQ, batch) +
+           (((size_t)batch * p->sizeQ) << p->ctx->logN) * 8;
+}
+extern "C" fhe_status fhe_bfv_eval_mult_relin_behz(fhe_behz* bz, fhe_ks_plan* p, const fhe_ks_key* key, const uint64_t* a0,
+                                                   const uint64_t* a1, const uint64_t* b0, const uint64_t* b1, uint64_t* c0,
+                                                   uint64_t* c1, uint32_t batch, void* wsv, size_t wsBytes, void* st) {
+    ARG_CHECK(bz && p && key && a0 && a1 && b0 && b1 && c0 && c1 && wsv && batch >= 1, "fhe_bfv_eval_mult_relin_behz: bad argument");
+    ARG_CHECK(key->plan == p && bz->ctx == p->ctx, "fhe_bfv_eval_mult_relin_behz: plans / key do not belong together");
+    ARG_CHECK(bz->numQ == p->sizeQ, "fhe_bfv_eval_mult_relin_behz: the BEHZ basis Q must be the key-switch plan's Q");
+    for (uint32_t i = 0; i < bz->numQ; ++i)
+        ARG_CHECK(bz->qIdx[i] == i, "fhe_bfv_eval_mult_relin_behz: Q must be the context's leading limbs");
+    ARG_CHECK(wsBytes >= fhe_bfv_eval_mult_relin_workspace_bytes(bz, p, batch), "fhe_bfv_eval_mult_relin_behz: workspace too small");
+    const size_t nrB = fhe_bfv_eval_mult_behz_workspace_bytes(bz, batch), ksB = fhe_ks_workspace_bytes(p, p->sizeQ, batch);
+    char* w      = (char*)wsv;
+    uint64_t* d2 = (uint64_t*)(w + nrB + ksB);
+    if (fhe_status s = fhe_bfv_eval_mult_behz(bz, a0, a1, b0, b1, c0, c1, d2, 1, batch, w, nrB, st))
+        return s;
+    const KsLayout lay = ks_layout(p, p->sizeQ, batch);
+    return keyswitch_run(p, key, d2, p->sizeQ, batch, c0, c1, (uint64_t*)(w + nrB), lay, st, true);
+}
+

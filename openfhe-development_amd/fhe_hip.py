@@ -131,6 +131,8 @@ class Lib:
         S("fhe_behz_conv_sk", C.c_int, [vp, vp, vp, u32, vp])
         S("fhe_bfv_eval_mult_behz_workspace_bytes", C.c_size_t, [vp, u32])
         S("fhe_bfv_eval_mult_behz", C.c_int, [vp] * 8 + [C.c_int, u32, vp, C.c_size_t, vp])
+        S("fhe_bfv_eval_mult_relin_workspace_bytes", C.c_size_t, [vp, vp, u32])
+        S("fhe_bfv_eval_mult_relin_behz", C.c_int, [vp] * 9 + [u32, vp, C.c_size_t, vp])
         S("fhe_param_first_prime", u64, [u32, u64])
         S("fhe_param_last_prime", u64, [u32, u64])
         S("fhe_param_next_prime", u64, [u64, u64])
@@ -637,6 +639,22 @@ class Behz:
         out = self.ctx.empty(t.batch, self.numQ, self.q_idx, COEFFICIENT)
         self.ctx.lib.check(self.ctx.lib.L.fhe_behz_conv_sk(self.h, t.ptr, out.ptr, t.batch, stream))
         return out
+
+    def EvalMult(self, ks_plan, a0, a1, b0, b1, stream=None):
+        """LeveledSHEBase::EvalMult(ct, ct, key) on BFV/BEHZ ciphertexts: EvalMultNoRelin + relinearisation with the
+        key-switch plan's evaluation key; returns (c0, c1), EVALUATION"""
+        B = a0.batch
+        c0, c1 = (self.ctx.empty(B, self.numQ, self.q_idx, EVALUATION) for _ in range(2))
+        L = self.ctx.lib.L
+        wsb = L.fhe_bfv_eval_mult_relin_workspace_bytes(self.h, ks_plan.h, B)
+        ws = self.ctx.malloc(wsb)
+        try:
+            self.ctx.lib.check(L.fhe_bfv_eval_mult_relin_behz(self.h, ks_plan.h, ks_plan.key, a0.ptr, a1.ptr, b0.ptr, b1.ptr,
+                                                              c0.ptr, c1.ptr, B, ws, wsb, stream))
+            self.ctx.sync(stream)
+        finally:
+            self.ctx.free(ws)
+        return c0, c1
 
     def EvalMultNoRelin(self, a0, a1, b0, b1, out_eval=False, stream=None):
         """LeveledSHEBFVRNS::EvalMult (BEHZ) on device towers [batch][numQ][N] (EVALUATION); returns (d0, d1, d2)"""

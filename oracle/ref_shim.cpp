@@ -655,7 +655,63 @@ void* ref_bfv_create(uint32_t ringDim, uint64_t t, uint32_t multDepth, uint32_t 
     s->cc->Enable(LEVELEDSHE);
     return s;
 }
-void ref_bfv_destroy(void* h) { delete static_cast<RefBfv*>(h); }
+// BFV with HYBRID key switching (relinearisation path of config 5)
+void* ref_bfv_create_hybrid(uint32_t ringDim, uint64_t t, uint32_t multDepth, uint32_t scalingModSize, uint32_t numLargeDigits) {
+    CCParams<CryptoContextBFVRNS> parameters;
+    parameters.SetSecurityLevel(HEStd_NotSet);
+    parameters.SetRingDim(ringDim);
+    parameters.SetPlaintextModulus(t);
+    parameters.SetMultiplicativeDepth(multDepth);
+    parameters.SetScalingModSize(scalingModSize);
+    parameters.SetMultiplicationTechnique(BEHZ);
+    parameters.SetKeySwitchTechnique(HYBRID);
+    if (numLargeDigits > 0)
+        parameters.SetNumLargeDigits(numLargeDigits);
+    auto* s = new RefBfv;
+    s->cc   = GenCryptoContext(parameters);
+    s->cc->Enable(PKE);
+    s->cc->Enable(KEYSWITCH);
+    s->cc->Enable(LEVELEDSHE);
+    s->kp = s->cc->KeyGen();
+    s->cc->EvalMultKeyGen(s->kp.secretKey);
+    return s;
+}
+// info[0]=sizeP, [1]=numPartQ, [2]=numPerPartQ
+void ref_bfv_hybrid_info(void* h, uint32_t* info) {
+    const auto cp = std::dynamic_pointer_cast<CryptoParametersRNS>(static_cast<RefBfv*>(h)->cc->GetCryptoParameters());
+    info[0]       = cp->GetParamsP()->GetParams().size();
+    info[1]       = cp->GetNumPartQ();
+    info[2]       = cp->GetNumPerPartQ();
+}
+void ref_bfv_get_p(void* h, uint64_t* p, uint64_t* psiP) {
+    const auto cp = std::dynamic_pointer_cast<CryptoParametersRNS>(static_cast<RefBfv*>(h)->cc->GetCryptoParameters());
+    const auto& P = cp->GetParamsP()->GetParams();
+    for (size_t i = 0; i < P.size(); ++i) {
+        p[i]    = P[i]->GetModulus().ConvertToInt<uint64_t>();
+        psiP[i] = P[i]->GetRootOfUnity().ConvertToInt<uint64_t>();
+    }
+}
+void ref_bfv_get_relin_key(void* h, uint64_t* keyB, uint64_t* keyA) {
+    auto* s        = static_cast<RefBfv*>(h);
+    const auto& ek = CryptoContextImpl<DCRTPoly>::GetEvalMultKeyVector(s->kp.secretKey->GetKeyTag())[0];
+    const auto& av = ek->GetAVector();
+    const auto& bv = ek->GetBVector();
+    size_t stride  = (size_t)av[0].GetNumOfElements() * av[0].GetRingDimension();
+    for (size_t j = 0; j < av.size(); ++j) {
+        export_poly(bv[j], keyB + j * stride);
+        export_poly(av[j], keyA + j * stride);
+    }
+}
+int ref_bfv_eval_mult(void* h, int a, int b) {  // cc->EvalMult: EvalMultNoRelin + SetFormat + KeySwitchCore + adds
+    auto* s = static_cast<RefBfv*>(h);
+    s->cts.push_back(s->cc->EvalMult(s->cts[a], s->cts[b]));
+    return static_cast<int>(s->cts.size()) - 1;
+}
+void ref_bfv_destroy(void* h) {
+    auto* s = static_cast<RefBfv*>(h);
+    s->cc->ClearEvalMultKeys();
+    delete s;
+}
 // ciphertext session (config 5): keys, deterministic packed messages, EvalMultNoRelin through the scheme layer
 void ref_bfv_keygen(void* h) {
     auto* s = static_cast<RefBfv*>(h);

@@ -12,7 +12,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import libs  # noqa: E402
-from test_oracle_vs_ref import ref_bfv_session  # noqa: E402
+from test_oracle_vs_ref import ref_bfv_relin_session, ref_bfv_session  # noqa: E402
 
 r = libs.load_ref()
 out = {}
@@ -22,5 +22,9 @@ for ring, t, depth, sms in ((64, 65537, 2, 60), (1024, 786433, 3, 55)):
     out.update({k + "_t": np.array([t], np.uint64), k + "_q": q, k + "_psiQ": pq, k + "_bsk": bsk, k + "_psiBsk": pb,
                 k + "_a": A, k + "_b": B, k + "_d": D})
     r.ref_bfv_destroy(h)
+# cc->EvalMult (EvalMultNoRelin + HYBRID relinearisation) at N = 64: moduli of Q, Bsk and P, the key, inputs, result
+h, S = ref_bfv_relin_session(r, 64, 65537, 2, 60, 2)
+out.update({"bfvrelin64_" + k: (np.array([v], np.uint64) if np.isscalar(v) else v) for k, v in S.items()})
+r.ref_bfv_destroy(h)
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_vectors_bfv.npz"), **out)
 print("wrote tests/golden/ref_vectors_bfv.npz with", len(out), "arrays")

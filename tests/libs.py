@@ -200,6 +200,11 @@ def load_ref():
     S("ref_bfv_behz_q_to_bsk", None, [vp, P64, C.c_int, P64])
     S("ref_bfv_fast_rns_floorq", None, [vp, P64])
     S("ref_bfv_fast_base_conv_sk", None, [vp, P64, P64])
+    S("ref_bfv_create_hybrid", vp, [u32, u64, u32, u32, u32])
+    S("ref_bfv_hybrid_info", None, [vp, P32])
+    S("ref_bfv_get_p", None, [vp, P64, P64])
+    S("ref_bfv_get_relin_key", None, [vp, P64, P64])
+    S("ref_bfv_eval_mult", C.c_int, [vp, C.c_int, C.c_int])
     S("ref_bfv_keygen", None, [vp])
     S("ref_bfv_encrypt", C.c_int, [vp, u32])
     S("ref_bfv_ct_info", None, [vp, C.c_int, P32])

@@ -355,6 +355,68 @@ def ref_bfv_session(r, ring, t, depth, sms):
     return h, N, q, pq, bsk, pb, A, B, D
 
 
+def ref_bfv_relin_session(r, ring, t, depth, sms, dnum):
+    """reference BFV/BEHZ context with HYBRID relinearisation: moduli, key, two ciphertexts and cc->EvalMult of them"""
+    h = r.ref_bfv_create_hybrid(ring, t, depth, sms, dnum)
+    info = np.zeros(3, np.uint32)
+    r.ref_bfv_info(h, info)
+    N, numQ, numBsk = map(int, info)
+    hi = np.zeros(3, np.uint32)
+    r.ref_bfv_hybrid_info(h, hi)
+    sizeP, numPartQ = int(hi[0]), int(hi[1])
+    q, pq = np.zeros(numQ, np.uint64), np.zeros(numQ, np.uint64)
+    bsk, pb = np.zeros(numBsk, np.uint64), np.zeros(numBsk, np.uint64)
+    r.ref_bfv_get_moduli(h, q, pq, bsk, pb)
+    p, pp = np.zeros(sizeP, np.uint64), np.zeros(sizeP, np.uint64)
+    r.ref_bfv_get_p(h, p, pp)
+    keyB = np.zeros((numPartQ, numQ + sizeP, N), np.uint64)
+    keyA = keyB.copy()
+    r.ref_bfv_get_relin_key(h, keyB, keyA)
+    a, b = r.ref_bfv_encrypt(h, 1), r.ref_bfv_encrypt(h, 2)
+    c = r.ref_bfv_eval_mult(h, a, b)
+
+    def export(ct):
+        ci = np.zeros(3, np.uint32)
+        r.ref_bfv_ct_info(h, ct, ci)
+        out = np.zeros((int(ci[0]), int(ci[1]), N), np.uint64)
+        for e in range(int(ci[0])):
+            r.ref_bfv_ct_export(h, ct, e, out[e])
+        return out, int(ci[2])
+    (A, fa), (B, fb), (Cc, fc) = export(a), export(b), export(c)
+    assert (fa, fb, fc) == (0, 0, 0) and Cc.shape[0] == 2
+    return h, dict(N=N, t=t, q=q, psiQ=pq, bsk=bsk, psiBsk=pb, p=p, psiP=pp, numPartQ=numPartQ, keyB=keyB, keyA=keyA, a=A, b=B, c=Cc)
+
+
+def oracle_bfv_eval_mult_relin(o, S):
+    """oracle composition: EvalMultNoRelin (BEHZ) -> NTT -> HYBRID key switch of the third element -> adds"""
+    N, q, numQ = S["N"], S["q"], len(S["q"])
+    hb = o.orc_behz_create(N, numQ, q, S["t"])
+    call = o.orc_ctx_create(N, numQ + len(S["bsk"]), np.concatenate([q, S["bsk"]]), np.concatenate([S["psiQ"], S["psiBsk"]]))
+    d = np.zeros((3, numQ, N), np.uint64)
+    A, B = S["a"], S["b"]
+    o.orc_bfv_eval_mult_behz(hb, call, np.ascontiguousarray(A[0]), np.ascontiguousarray(A[1]), np.ascontiguousarray(B[0]),
+                             np.ascontiguousarray(B[1]), d[0], d[1], d[2])
+    cq = o.orc_ctx_create(N, numQ, q, S["psiQ"])
+    o.orc_ntt_fwd_tower(cq, d, None, numQ, 3, 1)
+    hy = o.orc_hybrid_create(N, numQ, q, S["psiQ"], len(S["p"]), S["p"], S["psiP"], S["numPartQ"])
+    k0, k1 = np.zeros((numQ, N), np.uint64), np.zeros((numQ, N), np.uint64)
+    o.orc_hybrid_key_switch(hy, d[2], numQ, S["keyB"], S["keyA"], k0, k1)
+    out = np.zeros((2, numQ, N), np.uint64)
+    for i in range(numQ):
+        o.orc_vec_add(out[0, i], d[0, i], k0[i], N, int(q[i]))
+        o.orc_vec_add(out[1, i], d[1, i], k1[i], N, int(q[i]))
+    o.orc_hybrid_destroy(hy), o.orc_ctx_destroy(cq), o.orc_ctx_destroy(call), o.orc_behz_destroy(hb)
+    return out
+
+
+@pytest.mark.parametrize("ring,t,depth,sms,dnum", [(64, 65537, 2, 60, 2), (1024, 786433, 3, 55, 3)])
+def test_bfv_eval_mult_with_relinearisation_against_live_reference(oracle, ref, ring, t, depth, sms, dnum):
+    """cc->EvalMult on BFV/BEHZ ciphertexts with a HYBRID relinearisation key (config 5 end to end) vs the oracle"""
+    h, S = ref_bfv_relin_session(ref, ring, t, depth, sms, dnum)
+    assert np.array_equal(oracle_bfv_eval_mult_relin(oracle, S), S["c"])
+    ref.ref_bfv_destroy(h)
+
+
 @pytest.mark.parametrize("ring,t,depth,sms", [(64, 65537, 2, 60), (1024, 786433, 3, 55)])
 def test_bfv_eval_mult_behz_against_live_reference(oracle, ref, ring, t, depth, sms):
     """LeveledSHEBFVRNS::EvalMult (BEHZ) through the reference's scheme layer vs the oracle's composite"""

@@ -261,3 +261,27 @@ def test_scale_and_round_behz_decrypt(backend, oracle, logN, sizeQ, bits, t, B):
     got = fh.scale_and_round_behz_decrypt(ctx, ctx.tower(x, fmt=fh.COEFFICIENT), tg, a, b)
     assert np.array_equal(got, want)
     ctx.close()
+
+
+def test_bfv_eval_mult_with_relinearisation_reference_vectors(backend):
+    """fhe_bfv_eval_mult_relin_behz against the reference's own cc->EvalMult on BFV/BEHZ ciphertexts with its own HYBRID
+    relinearisation key (tests/golden/ref_vectors_bfv.npz): config 5 end to end, no oracle in the loop"""
+    import os
+    V = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_vectors_bfv.npz"))
+    g = lambda k: V["bfvrelin64_" + k]
+    N, t, numPartQ = int(g("N")[0]), int(g("t")[0]), int(g("numPartQ")[0])
+    q, bsk, p = g("q"), g("bsk"), g("p")
+    numQ, sizeP, nb, logN = len(q), len(p), len(bsk), N.bit_length() - 1
+    allq = np.concatenate([q, p, bsk])
+    allpsi = np.concatenate([g("psiQ"), g("psiP"), g("psiBsk")])
+    ctx = fh.Context(backend, logN, allq, allpsi)
+    ks = fh.KeySwitchPlan(ctx, numQ, sizeP, numPartQ)
+    ks.upload_key(g("keyB"), g("keyA"))
+    behz = fh.Behz(ctx, np.arange(numQ), np.arange(numQ + sizeP, numQ + sizeP + nb), t)
+    A, B, Cw = g("a"), g("b"), g("c")
+    T = [ctx.tower(x[None], limb_idx=np.arange(numQ)) for x in (A[0], A[1], B[0], B[1])]
+    c0, c1 = behz.EvalMult(ks, *T)
+    assert np.array_equal(c0.to_host()[0], Cw[0]) and np.array_equal(c1.to_host()[0], Cw[1])
+    behz.close()
+    ks.close()
+    ctx.close()
