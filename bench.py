@@ -253,6 +253,48 @@ def bfv_leg(lib, device, batch, steps, warmup, sync, with_cpu):
     ctx.free(ws)
     plan.close()
     ctx.close()
+    # ... and with relinearisation (cc->EvalMult): context = Q, P (HYBRID, dnum 3), Bsk; uniform random evaluation key
+    dnum = 3
+    p, psiP = lib.select_p(logN, q, dnum, 60)
+    ctx = fh.Context(lib, logN, np.concatenate([q, p, bsk]), np.concatenate([psiQ, psiP, psiB]), device=device)
+    ks = fh.KeySwitchPlan(ctx, numQ, len(p), dnum)
+    rng = np.random.default_rng(5)
+    allqp = np.concatenate([q, p])
+
+    def host_key():
+        host = np.empty((dnum, len(allqp), ctx.N), np.uint64)
+        for i, qi in enumerate(allqp):
+            host[:, i, :] = rng.integers(0, int(qi), size=(dnum, ctx.N), dtype=np.uint64)
+        return host
+    ks.upload_key(host_key(), host_key())
+    plan = fh.Behz(ctx, np.arange(numQ), np.arange(numQ + len(p), numQ + len(p) + len(bsk)), t)
+    ops = [fh.Tower(ctx, fill_random_tower(ctx, q, batch, 300 + i, seed_polys=2), batch, numQ) for i in range(4)]
+    c0, c1 = ops[0].like(), ops[0].like()
+    wsb = lib.L.fhe_bfv_eval_mult_relin_workspace_bytes(plan.h, ks.h, batch)
+    ws = ctx.malloc(wsb)
+    st = C.c_void_p()
+    lib.check(lib.L.fhe_stream_create(ctx.h, C.byref(st)))
+
+    def call2():
+        lib.check(lib.L.fhe_bfv_eval_mult_relin_behz(plan.h, ks.h, ks.key, ops[0].ptr, ops[1].ptr, ops[2].ptr, ops[3].ptr,
+                                                     c0.ptr, c1.ptr, batch, ws, wsb, st))
+    step2, mode2, graph2 = timed_sequence(lib, ctx, st, call2)
+    for _ in range(warmup):
+        step2()
+    lib.check(lib.L.fhe_stream_sync(ctx.h, st))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step2()
+    lib.check(lib.L.fhe_stream_sync(ctx.h, st))
+    dt2 = (time.perf_counter() - t0) / steps
+    lib.L.fhe_graph_destroy(graph2)
+    lib.check(lib.L.fhe_stream_destroy(ctx.h, st))
+    ctx.free(ws)
+    plan.close()
+    ks.close()
+    ctx.close()
+    relin = {"ops_per_s_per_gpu": round(batch / dt2, 1), "ms_per_batch": round(dt2 * 1e3, 3),
+             "shape": f"+ HYBRID relinearisation, dnum={dnum}, {len(p)} P limbs", "launch": mode2, "cpu_baseline": None}
     cpu = None
     if with_cpu:  # after the GPU leg: the reference's OpenMP team keeps spinning for a while and slows kernel launches
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -286,7 +328,16 @@ def bfv_leg(lib, device, batch, steps, warmup, sync, with_cpu):
                    "sample": f"{reps} x cc->EvalMultNoRelin (BEHZ), N=2^{logN}, {int(info[1])} Q limbs (depth {depth}); "
                              f"{sec * 1e3:.1f} ms each; best OpenMP team of {{8..{cores}}}; host has {cores} logical cores"}
             r.ref_bfv_destroy(h)
-    return {"ops_per_s_per_gpu": round(batch / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "batch": batch,
+            # the same with relinearisation: cc->EvalMult on a HYBRID context of the same depth
+            h2 = r.ref_bfv_create_hybrid(1 << logN, t, depth, 60, dnum)
+            ca, cb = r.ref_bfv_encrypt(h2, 1), r.ref_bfv_encrypt(h2, 2)
+            r.ref_bfv_time_eval_mult(h2, ca, cb, 1)
+            reps2 = max(3, min(30, int(3.0 / max(best_t, 1e-3))))
+            sec2 = r.ref_bfv_time_eval_mult(h2, ca, cb, reps2)
+            relin["cpu_baseline"] = {"value": round(1.0 / sec2, 2), "unit": "EvalMult/s", "cores": int(best), "kind": "reference",
+                                     "sample": f"{reps2} x cc->EvalMult (BEHZ + HYBRID relinearisation), N=2^{logN}; {sec2 * 1e3:.1f} ms each"}
+            r.ref_bfv_destroy(h2)
+    return {"with_relinearisation": relin, "ops_per_s_per_gpu": round(batch / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "batch": batch,
             "shape": f"N=2^{logN}, {numQ} Q limbs + {len(bsk)} Bsk limbs, t={t}, no relinearisation", "launch": mode,
             "cpu_baseline": cpu}
 
@@ -448,7 +499,7 @@ def main():
 
     em = None
     if not a.no_evalmult and logN == 16:
-        em = evalmult_leg(lib, device, logN, a.evalmult_batch, max(4, a.steps // 2), 2, gpu_sync, dist)
+        em = evalmult_leg(lib, device, logN, a.evalmult_batch, max(20, a.steps * 2), 6, gpu_sync, dist)
         if dist is not None:
             tt = torch.tensor([em["ops_per_s_per_gpu"]], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.SUM)
@@ -458,7 +509,7 @@ def main():
 
     bfv = None
     if not a.no_bfv and logN == 16:
-        bfv = bfv_leg(lib, device, a.bfv_batch, max(10, a.steps), 3, gpu_sync,
+        bfv = bfv_leg(lib, device, a.bfv_batch, max(30, a.steps * 3), 6, gpu_sync,
                       rank == 0 and world == 1 and not a.no_cpu_baseline)
 
     cpu = None

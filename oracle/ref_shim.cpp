@@ -707,6 +707,16 @@ int ref_bfv_eval_mult(void* h, int a, int b) {  // cc->EvalMult: EvalMultNoRelin
     s->cts.push_back(s->cc->EvalMult(s->cts[a], s->cts[b]));
     return static_cast<int>(s->cts.size()) - 1;
 }
+double ref_bfv_time_eval_mult(void* h, int a, int b, int reps) {  // with relinearisation
+    auto* s = static_cast<RefBfv*>(h);
+    auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps; ++r) {
+        auto c = s->cc->EvalMult(s->cts[a], s->cts[b]);
+        (void)c;
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double>(t1 - t0).count() / reps;
+}
 void ref_bfv_destroy(void* h) {
     auto* s = static_cast<RefBfv*>(h);
     s->cc->ClearEvalMultKeys();

@@ -205,6 +205,7 @@ def load_ref():
     S("ref_bfv_get_p", None, [vp, P64, P64])
     S("ref_bfv_get_relin_key", None, [vp, P64, P64])
     S("ref_bfv_eval_mult", C.c_int, [vp, C.c_int, C.c_int])
+    S("ref_bfv_time_eval_mult", C.c_double, [vp, C.c_int, C.c_int, C.c_int])
     S("ref_bfv_keygen", None, [vp])
     S("ref_bfv_encrypt", C.c_int, [vp, u32])
     S("ref_bfv_ct_info", None, [vp, C.c_int, P32])
