@@ -239,6 +239,23 @@ fhe_status fhe_eval_fast_rotation_ext(fhe_ks_plan* plan, const fhe_ks_key* key, 
                                       uint64_t* out1Ext, void* ws, size_t wsBytes, void* stream);
 fhe_status fhe_ks_down(fhe_ks_plan* plan, const uint64_t* x0Ext, const uint64_t* x1Ext, uint32_t sizeQl, uint32_t batch,
                        uint64_t* out0, uint64_t* out1, void* ws, size_t wsBytes, void* stream);
+/* Baby-step/giant-step plaintext-matrix x ciphertext product with double hoisting: FHECKKSRNS::EvalLinearTransform
+ * (src/pke/lib/scheme/ckksrns/ckksrns-fhe.cpp:1832-1882) and one level of EvalCoeffsToSlots / EvalSlotsToCoeffs
+ * (:1884-2198), the linear-transform loops of CKKS bootstrapping.
+ *   rot_j   = inK[j] ? EvalFastRotationExt(ct, inK[j], digits(ct), true) : KeySwitchExt(ct, true)        j < nIn
+ *   inner_i = sum_j rot_j * diag[i*nIn + j]            (EvalMultExt / EvalAddExtInPlace; NULL = term absent)
+ *   outK[i] == 0: first += KeySwitchDownFirstElement(inner_i); outer[1] += inner_i[1]
+ *   else        : d = KeySwitchDown(inner_i); first += Automorphism(d[0]); outer += EvalFastRotationExt(d, outK[i], digits(d), false)
+ *   (out0, out1) = KeySwitchDown(outer), out0 += first
+ * inK / outK are automorphism indices (FindAutomorphismIndex2nComplex of the rotation), 0 = no rotation; inKeys[j] /
+ * outKeys[i] the matching evaluation keys (ignored where the index is 0).  diag: HOST array of nOut*nIn DEVICE pointers to
+ * plaintext rows [sizeQl+sizeP][N] in EVALUATION format over limbs {0..sizeQl-1, sizeQ..sizeQ+sizeP-1}
+ * (EvalLinearTransformPrecompute's aux plaintexts), shared by the whole batch.  c0,c1,out0,out1: [batch][sizeQl][N]. */
+size_t fhe_ckks_bsgs_workspace_bytes(const fhe_ks_plan* plan, uint32_t sizeQl, uint32_t batch, uint32_t nIn);
+fhe_status fhe_ckks_bsgs_transform(fhe_ks_plan* plan, const uint64_t* c0, const uint64_t* c1, uint32_t sizeQl, uint32_t batch,
+                                   uint32_t nIn, const uint32_t* inK, const fhe_ks_key* const* inKeys, uint32_t nOut,
+                                   const uint32_t* outK, const fhe_ks_key* const* outKeys, const uint64_t* const* diag,
+                                   uint64_t* out0, uint64_t* out1, void* ws, size_t wsBytes, void* stream);
 /* DCRTPolyImpl::ApproxModDown with t = 0 (dcrtpoly-impl.h:966-1005):
  * x[batch][sizeQl+sizeP][N] EVALUATION -> out[batch][sizeQl][N] EVALUATION */
 fhe_status fhe_approx_mod_down(fhe_ks_plan* plan, const uint64_t* x, uint32_t sizeQl, uint32_t batch, uint64_t* out,

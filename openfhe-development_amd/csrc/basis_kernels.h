@@ -186,5 +186,58 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ks_inner_product_kernel(const KsInne
     }
 }
 
+// ---- baby-step/giant-step inner sum (double hoisting) ---------------------------------------------
+// inner[e][b][i][r] = sum_j rot_j[e][b][i][r] * diag_j[i][r]  over the extended basis Q_l u P: the EvalMultExt /
+// EvalAddExtInPlace chain of FHECKKSRNS::EvalLinearTransform (ckksrns-fhe.cpp:1855-1859, 2723-2740) as ONE pass:
+// every rotated ciphertext and every plaintext diagonal is read once, the sum is kept in a 192-bit accumulator and
+// reduced once (an exact reduction of the exact sum equals the reference's chain of ModMul / ModAdd results).
+constexpr int kMaxBsgsIn = 32;
+struct BsgsInnerArgs {
+    const uint64_t* rot;               // [nIn][2][batch][sizeQl+sizeP][N] EVAL, canonical
+    const uint64_t* diag[kMaxBsgsIn];  // diagonal of inner rotation j: [sizeQl+sizeP][N] EVAL, shared by the batch; null = absent
+    uint64_t* out;                     // [2][batch][sizeQl+sizeP][N]
+    const LimbConst* lc;               // [ctxLimbs]; ctx limbs: Q then P
+    const uint64_t* mu128;             // [ctxLimbs][2]
+    uint32_t logN, batch, sizeQl, sizeQ, sizeP, nIn, accumulate;
+};
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) bsgs_inner_kernel(const BsgsInnerArgs g) {
+    // one workgroup = 4096 consecutive coefficients of one (e, i, b) row; batch-fastest: the diagonal's row stays in L2
+    const uint32_t t           = FHE_TID;
+    const uint32_t N           = 1u << g.logN;
+    const uint32_t tilesPerRow = (N >> kTileLog) ? (N >> kTileLog) : 1u;
+    const uint32_t sizeQlP     = g.sizeQl + g.sizeP;
+    uint32_t blk               = FHE_BID;
+    const uint32_t b           = blk % g.batch;
+    blk /= g.batch;
+    const uint32_t tr = blk % tilesPerRow;
+    blk /= tilesPerRow;
+    const uint32_t i = blk % sizeQlP;
+    const uint32_t e = blk / sizeQlP;
+    if (e >= 2u)
+        return;
+    const uint32_t idx  = i < g.sizeQl ? i : i + (g.sizeQ - g.sizeQl);
+    const LimbConst lc  = g.lc[idx];
+    const uint64_t mulo = g.mu128[2 * idx], muhi = g.mu128[2 * idx + 1];
+    const uint64_t rotStride = ((uint64_t)2 * g.batch * sizeQlP) << g.logN;  // words between rot_j and rot_{j+1}
+    const uint64_t rowOff    = (((uint64_t)e * g.batch + b) * sizeQlP + i) << g.logN;
+    const uint32_t rEnd      = ((tr + 1u) << kTileLog) < N ? ((tr + 1u) << kTileLog) : N;
+    for (uint32_t r = (tr << kTileLog) + t; r < rEnd; r += kThreads) {
+        mac192 s;
+        mac192_clear(s);
+        for (uint32_t j = 0; j < g.nIn; ++j) {
+            const uint64_t* dj = g.diag[j];
+            if (!dj)
+                continue;
+            mac192_add(s, g.rot[(uint64_t)j * rotStride + rowOff + r], dj[((uint64_t)i << g.logN) + r]);
+        }
+        u128w a;
+        mac192_fold(s, a.lo, a.hi);
+        uint64_t v = barrett128(a, lc.q, mulo, muhi);
+        if (g.accumulate)
+            v = add_mod(g.out[rowOff + r], v, lc.q);
+        g.out[rowOff + r] = v;
+    }
+}
+
 }  // namespace fhe
 #endif

@@ -155,6 +155,7 @@ struct AutoArgs {
     const uint64_t* in;
     const uint64_t* q;  // [ctxLimbs]
     uint32_t logN, nLimbs, rows, k, evalFormat;
+    uint32_t accumulate;  // EVALUATION only: out += Automorphism(in)  (`first += ...AutomorphismTransform(...)`, ckksrns-fhe.cpp:1873)
     LimbSel sel;
 };
 FHE_HD uint32_t bitrev32(uint32_t x, uint32_t nbits) {
@@ -182,7 +183,10 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) automorph_kernel(const AutoArgs g) {
         if (g.evalFormat) {
             const uint32_t j   = bitrev32(jr, g.logN);
             const uint32_t idx = (((2u * j + 1u) * g.k) & (2u * N - 1u)) >> 1;
-            g.out[off]         = g.in[rowBase + bitrev32(idx, g.logN)];
+            uint64_t v         = g.in[rowBase + bitrev32(idx, g.logN)];
+            if (g.accumulate)
+                v = add_mod(g.out[off], v, g.q[g.sel.idx[(uint32_t)(off >> g.logN) % g.nLimbs]]);
+            g.out[off] = v;
         }
         else {
             // gather form of the scatter in the reference: out[jk mod N] = +-in[j]  <=>  j = jr * k^-1 mod 2N

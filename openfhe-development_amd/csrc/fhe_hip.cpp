@@ -946,6 +946,19 @@ extern "C" fhe_status fhe_automorph(fhe_ctx* c, uint64_t* out, const uint64_t* i
     RT_CHECK(rt::set_device(c->device));
     g.out = out, g.in = in, g.q = c->d_q;
     g.logN = c->logN, g.nLimbs = nl, g.rows = bt * nl, g.k = k, g.evalFormat = evalFormat ? 1u : 0u;
+    g.accumulate = 0;
+    FHE_LAUNCH(automorph_kernel, tiles_for(c, g.rows), st, g);
+    LAUNCH_CHECK();
+    return FHE_OK;
+}
+// out (+)= Automorphism_k(in) in EVALUATION format
+static fhe_status automorph_eval_run(fhe_ctx* c, uint64_t* out, const uint64_t* in, uint32_t k, const uint32_t* li, uint32_t nl,
+                                     uint32_t bt, bool accumulate, void* st) {
+    AutoArgs g;
+    if (fhe_status s = make_sel(c, li, nl, &g.sel, "automorphism"))
+        return s;
+    g.out = out, g.in = in, g.q = c->d_q;
+    g.logN = c->logN, g.nLimbs = nl, g.rows = bt * nl, g.k = k, g.evalFormat = 1u, g.accumulate = accumulate ? 1u : 0u;
     FHE_LAUNCH(automorph_kernel, tiles_for(c, g.rows), st, g);
     LAUNCH_CHECK();
     return FHE_OK;
@@ -1706,6 +1719,183 @@ extern "C" fhe_status fhe_ks_down(fhe_ks_plan* p, const uint64_t* x0, const uint
     if (fhe_status s = mod_down_run(p, lv, x0, batch, out0, wsp + w.pcoef, wsp + w.md, st))
         return s;
     return mod_down_run(p, lv, x1, batch, out1, wsp + w.pcoef, wsp + w.md, st);
+}
+
+// ---- BSGS plaintext-matrix product with double hoisting ----
+// FHECKKSRNS::EvalLinearTransform (ckksrns-fhe.cpp:1832-1882) and one level of EvalCoeffsToSlots / EvalSlotsToCoeffs
+// (:1884-2198): inner rotations hoisted on one digit decomposition and kept in the extended basis, one fused
+// multiply-accumulate pass per outer step, one KeySwitchDown per outer step and one at the end.
+// workspace = [key-switch layout][rot: nIn x 2 x batch ext towers][inner: 2 x batch ext][outer: 2 x batch ext]
+//             [d: 2 x batch Q_l towers][first: batch Q_l towers]
+struct BsgsLayout {
+    KsLayout ks;
+    size_t rot, inner, outer, d, first, total;
+};
+static BsgsLayout bsgs_layout(const fhe_ks_plan* p, uint32_t sizeQl, uint32_t batch, uint32_t nIn) {
+    BsgsLayout b{};
+    b.ks             = ks_layout(p, sizeQl, batch);
+    const size_t N   = (size_t)1 << p->ctx->logN;
+    const size_t ext = (size_t)batch * (sizeQl + p->sizeP) * N, low = (size_t)batch * sizeQl * N;
+    size_t off       = b.ks.total;
+    b.rot = off, off += (size_t)nIn * 2 * ext;
+    b.inner = off, off += 2 * ext;
+    b.outer = off, off += 2 * ext;
+    b.d = off, off += 2 * low;
+    b.first = off, off += low;
+    b.total = off;
+    return b;
+}
+extern "C" size_t fhe_ckks_bsgs_workspace_bytes(const fhe_ks_plan* p, uint32_t sizeQl, uint32_t batch, uint32_t nIn) {
+    if (!p || sizeQl < 1 || sizeQl > p->sizeQ || batch < 1 || nIn < 1)
+        return 0;
+    return bsgs_layout(p, sizeQl, batch, nIn).total * 8;
+}
+// KeySwitchDown of two adjacent extended towers x[2*batch] -> out0, out1 (keyswitch-hybrid.cpp:245-278)
+static fhe_status mod_down_pair(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const uint64_t* x, uint32_t batch, uint64_t* out0,
+                                uint64_t* out1, uint64_t* pcoef, uint64_t* md, void* st) {
+    fhe_ctx* c = p->ctx;
+    if (ntt_epilogue_supported(c)) {
+        NttEpilogue epi;
+        epi.mode = 1u, epi.split = batch, epi.aStride = lv->sizeQl + p->sizeP, epi.aFirst = 0;
+        epi.A = x, epi.C = lv->d_PInv, epi.out0 = out0, epi.out1 = out1;
+        return mod_down_core(p, lv, x, 2 * batch, pcoef, md, st, nullptr, &epi);
+    }
+    if (fhe_status s = mod_down_core(p, lv, x, 2 * batch, pcoef, md, st))
+        return s;
+    if (fhe_status s = mod_down_tail(p, lv, x, md, batch, out0, false, st))
+        return s;
+    const size_t ext = ((size_t)batch * (lv->sizeQl + p->sizeP)) << c->logN, low = ((size_t)batch * lv->sizeQl) << c->logN;
+    return mod_down_tail(p, lv, x + ext, md + low, batch, out1, false, st);
+}
+extern "C" fhe_status fhe_ckks_bsgs_transform(fhe_ks_plan* p, const uint64_t* c0, const uint64_t* c1, uint32_t sizeQl,
+                                              uint32_t batch, uint32_t nIn, const uint32_t* inK,
+                                              const fhe_ks_key* const* inKeys, uint32_t nOut, const uint32_t* outK,
+                                              const fhe_ks_key* const* outKeys, const uint64_t* const* diag, uint64_t* out0,
+                                              uint64_t* out1, void* wsv, size_t wsBytes, void* st) {
+    ARG_CHECK(p && c0 && c1 && inK && outK && diag && out0 && out1 && wsv, "fhe_ckks_bsgs_transform: null argument");
+    ARG_CHECK(sizeQl >= 1 && sizeQl <= p->sizeQ && batch >= 1, "fhe_ckks_bsgs_transform: bad level or batch");
+    ARG_CHECK(nIn >= 1 && nOut >= 1, "fhe_ckks_bsgs_transform: needs at least one inner and one outer step");
+    const BsgsLayout L = bsgs_layout(p, sizeQl, batch, nIn);
+    ARG_CHECK(wsBytes >= L.total * 8, "fhe_ckks_bsgs_transform: workspace too small");
+    for (uint32_t j = 0; j < nIn; ++j) {
+        ARG_CHECK(inK[j] == 0 || inK[j] % 2 == 1, "Automorphism index not odd");
+        ARG_CHECK(inK[j] == 0 || (inKeys && inKeys[j] && inKeys[j]->plan == p), "fhe_ckks_bsgs_transform: missing inner rotation key");
+    }
+    for (uint32_t i = 0; i < nOut; ++i) {
+        ARG_CHECK(outK[i] == 0 || outK[i] % 2 == 1, "Automorphism index not odd");
+        ARG_CHECK(outK[i] == 0 || (outKeys && outKeys[i] && outKeys[i]->plan == p), "fhe_ckks_bsgs_transform: missing outer rotation key");
+    }
+    fhe_ctx* c = p->ctx;
+    RT_CHECK(rt::set_device(c->device));
+    fhe_ks_plan::Level* lv = nullptr;
+    if (fhe_status s = ks_level(p, sizeQl, &lv))
+        return s;
+    const KsLayout& w      = L.ks;
+    uint64_t* ws           = (uint64_t*)wsv;
+    const uint32_t sizeQlP = sizeQl + p->sizeP;
+    const size_t ext = ((size_t)batch * sizeQlP) << c->logN, low = ((size_t)batch * sizeQl) << c->logN;
+    uint64_t *rot = ws + L.rot, *inner = ws + L.inner, *outer = ws + L.outer, *d = ws + L.d, *first = ws + L.first;
+    std::vector<uint32_t> extIdx;
+    ext_limbs(p, sizeQl, extIdx);
+    TwPair* dP = nullptr;
+    if (fhe_status s = ks_pmodq(p, lv, &dP))
+        return s;
+
+    // inner (baby-step) rotations: one digit decomposition of c1 serves all of them (EvalFastRotationPrecompute, :1842)
+    bool digitsReady = false;
+    for (uint32_t j = 0; j < nIn; ++j) {
+        uint64_t* rj = rot + (size_t)j * 2 * ext;
+        if (inK[j] == 0) {  // KeySwitchExt(ct, true)
+            if (fhe_status s = fhe_ks_ext(p, c0, sizeQl, batch, rj, st))
+                return s;
+            if (fhe_status s = fhe_ks_ext(p, c1, sizeQl, batch, rj + ext, st))
+                return s;
+            continue;
+        }
+        if (!digitsReady) {
+            if (fhe_status s = ks_precompute_run(p, lv, c1, batch, ws, w, st))
+                return s;
+            digitsReady = true;
+        }
+        // EvalFastRotationExt(ct, index, digits, addFirst = true): e0, e1 are adjacent in the key-switch workspace
+        if (fhe_status s = ks_inner_run(p, lv, inKeys[j], c1, batch, ws + w.e0, ws + w.e1, ws, w, st))
+            return s;
+        if (fhe_status s = elem_run<OP_MUL_CONST_ADD>(c, ws + w.e0, c0, ws + w.e0, dP, nullptr, sizeQl, batch, st,
+                                                      "fhe_ckks_bsgs_transform", 0, 0, sizeQlP, 0, sizeQlP, 0))
+            return s;
+        if (fhe_status s = automorph_eval_run(c, rj, ws + w.e0, inK[j], extIdx.data(), sizeQlP, 2 * batch, false, st))
+            return s;
+    }
+
+    bool firstSet = false, outer0Set = false, outer1Set = false;
+    for (uint32_t i = 0; i < nOut; ++i) {
+        // inner_i = sum_j rot_j * diag[i][j]
+        bool any = false;
+        for (uint32_t j0 = 0; j0 < nIn; j0 += kMaxBsgsIn) {
+            BsgsInnerArgs g;
+            const uint32_t n = std::min<uint32_t>(kMaxBsgsIn, nIn - j0);
+            bool chunkAny    = false;
+            for (uint32_t j = 0; j < (uint32_t)kMaxBsgsIn; ++j) {
+                g.diag[j] = j < n ? diag[(size_t)i * nIn + j0 + j] : nullptr;
+                chunkAny |= g.diag[j] != nullptr;
+            }
+            if (!chunkAny && (any || j0 + n < nIn))
+                continue;  // nothing to add (an all-absent outer step still produces a zero `inner` in its last chunk)
+            g.rot = rot + (size_t)j0 * 2 * ext, g.out = inner, g.lc = c->d_lc, g.mu128 = c->d_mu128;
+            g.logN = c->logN, g.batch = batch, g.sizeQl = sizeQl, g.sizeQ = p->sizeQ, g.sizeP = p->sizeP, g.nIn = n;
+            g.accumulate = any ? 1u : 0u;
+            const uint32_t tilesPerRow = c->N >= (uint32_t)kTile ? (c->N >> kTileLog) : 1u;
+            FHE_LAUNCH(bsgs_inner_kernel, (uint64_t)2 * batch * tilesPerRow * sizeQlP, st, g);
+            LAUNCH_CHECK();
+            any = true;
+        }
+        if (outK[i] == 0) {
+            // first += KeySwitchDownFirstElement(inner); outer[1] += inner[1]  (:1861-1866, 1976-1979)
+            if (fhe_status s = mod_down_run(p, lv, inner, batch, firstSet ? d : first, ws + w.pcoef, ws + w.md, st))
+                return s;
+            if (firstSet)
+                if (fhe_status s = elem_run<OP_ADD>(c, first, first, d, nullptr, nullptr, sizeQl, batch, st, "fhe_ckks_bsgs_transform"))
+                    return s;
+            firstSet = true;
+            if (outer1Set) {
+                if (fhe_status s = elem_run<OP_ADD>(c, outer + ext, outer + ext, inner + ext, nullptr, extIdx.data(), sizeQlP, batch,
+                                                    st, "fhe_ckks_bsgs_transform"))
+                    return s;
+            }
+            else
+                RT_CHECK(rt::d2d(outer + ext, inner + ext, ext * 8, (rt::stream_t)st));
+            outer1Set = true;
+            continue;
+        }
+        // inner = KeySwitchDown(inner); first += Automorphism(inner[0]); outer += EvalFastRotationExt(inner, index,
+        // digits(inner), addFirst = false)  (:1868-1876)
+        if (fhe_status s = mod_down_pair(p, lv, inner, batch, d, d + low, ws + w.pcoef, ws + w.md, st))
+            return s;
+        if (fhe_status s = automorph_eval_run(c, first, d, outK[i], nullptr, sizeQl, batch, firstSet, st))
+            return s;
+        firstSet = true;
+        if (fhe_status s = ks_precompute_run(p, lv, d + low, batch, ws, w, st))
+            return s;
+        if (fhe_status s = ks_inner_run(p, lv, outKeys[i], d + low, batch, ws + w.e0, ws + w.e1, ws, w, st))
+            return s;
+        if (outer0Set == outer1Set) {
+            if (fhe_status s = automorph_eval_run(c, outer, ws + w.e0, outK[i], extIdx.data(), sizeQlP, 2 * batch, outer0Set, st))
+                return s;
+        }
+        else {
+            if (fhe_status s = automorph_eval_run(c, outer, ws + w.e0, outK[i], extIdx.data(), sizeQlP, batch, outer0Set, st))
+                return s;
+            if (fhe_status s = automorph_eval_run(c, outer + ext, ws + w.e1, outK[i], extIdx.data(), sizeQlP, batch, outer1Set, st))
+                return s;
+        }
+        outer0Set = outer1Set = true;
+    }
+    if (!outer0Set)
+        RT_CHECK(rt::dzero_2d(outer, ext * 8, ext * 8, 1, (rt::stream_t)st));
+    // result = KeySwitchDown(outer); result[0] += first  (:1879-1880)
+    if (fhe_status s = mod_down_pair(p, lv, outer, batch, out0, out1, ws + w.pcoef, ws + w.md, st))
+        return s;
+    return elem_run<OP_ADD>(c, out0, out0, first, nullptr, nullptr, sizeQl, batch, st, "fhe_ckks_bsgs_transform");
 }
 
 extern "C" fhe_status fhe_approx_mod_down(fhe_ks_plan* p, const uint64_t* x, uint32_t sizeQl, uint32_t batch,

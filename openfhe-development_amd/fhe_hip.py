@@ -110,6 +110,8 @@ class Lib:
         S("fhe_ks_fast_keyswitch_ext", C.c_int, [vp, vp, vp, u32, u32, vp, vp, vp, C.c_size_t, vp])
         S("fhe_eval_fast_rotation_ext", C.c_int, [vp, vp, vp, vp, u32, C.c_int, u32, u32, vp, vp, vp, C.c_size_t, vp])
         S("fhe_ks_down", C.c_int, [vp, vp, vp, u32, u32, vp, vp, vp, C.c_size_t, vp])
+        S("fhe_ckks_bsgs_workspace_bytes", C.c_size_t, [vp, u32, u32, u32])
+        S("fhe_ckks_bsgs_transform", C.c_int, [vp, vp, vp, u32, u32, u32, vp, vp, u32, vp, vp, vp, vp, vp, vp, C.c_size_t, vp])
         S("fhe_approx_mod_down", C.c_int, [vp, vp, u32, u32, vp, vp, C.c_size_t, vp])
         S("fhe_approx_mod_down_bgv", C.c_int, [vp, vp, u32, u64, u32, vp, vp, C.c_size_t, vp])
         S("fhe_rescale_workspace_bytes", C.c_size_t, [vp, u32, u32])
@@ -482,6 +484,43 @@ class KeySwitchPlan:
         o0, o1 = self.ctx.empty(x0.batch, sizeQl), self.ctx.empty(x0.batch, sizeQl)
         self.ctx.lib.check(self.ctx.lib.L.fhe_ks_down(self.h, x0.ptr, x1.ptr, sizeQl, x0.batch, o0.ptr, o1.ptr, ws, wsb, stream))
         return o0, o1
+
+    def BsgsTransform(self, c0, c1, in_rot, out_rot, diag, ws=None, out=None, stream=None):
+        """fhe_ckks_bsgs_transform: in_rot / out_rot = lists of (automorphism index, key handle) or None for "no rotation";
+        diag[i][j] = device pointer of the plaintext rows of outer step i, inner rotation j (None = absent).
+        ws = (pointer, bytes) of a caller-owned workspace (needed for graph capture), else allocated per call."""
+        L = self.ctx.lib.L
+        nIn, nOut = len(in_rot), len(out_rot)
+
+        def split(rots):
+            ks = (C.c_uint32 * len(rots))(*[0 if r is None else int(r[0]) for r in rots])
+            hs = (vp * len(rots))(*[None if r is None else r[1] for r in rots])
+            return ks, hs
+        inK, inH = split(in_rot)
+        outK, outH = split(out_rot)
+        dp = (vp * (nIn * nOut))(*[diag[i][j] for i in range(nOut) for j in range(nIn)])
+        own = ws is None
+        if own:
+            wsb = L.fhe_ckks_bsgs_workspace_bytes(self.h, c0.n_limbs, c0.batch, nIn)
+            ws = (self.ctx.malloc(wsb), wsb)
+        o0, o1 = out if out is not None else (c0.like(), c0.like())
+        self.ctx.lib.check(L.fhe_ckks_bsgs_transform(self.h, c0.ptr, c1.ptr, c0.n_limbs, c0.batch, nIn, inK, inH, nOut, outK,
+                                                     outH, dp, o0.ptr, o1.ptr, ws[0], ws[1], stream))
+        if own:
+            self.ctx.sync(stream)
+            self.ctx.free(ws[0])
+        return o0, o1
+
+    def EvalLinearTransform(self, A, c0, c1, bStep, rot_keys, stream=None):
+        """FHECKKSRNS::EvalLinearTransform (ckksrns-fhe.cpp:1832-1882).  A = device pointers of the `slots` encoded diagonals
+        (EvalLinearTransformPrecompute), rot_keys[index] = (automorphism index, key handle) for the baby steps 1..bStep-1
+        and the giant steps bStep*j."""
+        slots = len(A)
+        gStep = -(-slots // bStep)
+        in_rot = [None] + [rot_keys[i] for i in range(1, bStep)]
+        out_rot = [None] + [rot_keys[bStep * j] for j in range(1, gStep)]
+        diag = [[A[bStep * j + i] if bStep * j + i < slots else None for i in range(bStep)] for j in range(gStep)]
+        return self.BsgsTransform(c0, c1, in_rot, out_rot, diag, stream=stream)
 
     def EvalAutomorphism(self, key, c0, c1, k, stream=None):  # base-leveledshe.cpp:381-422
         ws, wsb = self.workspace(c0.n_limbs, c0.batch)

@@ -1072,6 +1072,88 @@ void orc_eval_fast_rotation_ext(const orc_hybrid* h, const uint64_t* c0, const u
     free(digits), free(e0), free(e1), free(tmp), free(pre);
 }
 
+/* Baby-step/giant-step plaintext-matrix x ciphertext product with double hoisting: FHECKKSRNS::EvalLinearTransform
+ * (ckksrns-fhe.cpp:1832-1882) and one level of EvalCoeffsToSlots / EvalSlotsToCoeffs (:1884-2198) share this shape.
+ *   rot_j   = inK[j]  ? EvalFastRotationExt(ct, inK[j], digits(ct), addFirst = true) : KeySwitchExt(ct, true)      (:1845-1847, 1855)
+ *   inner_i = sum_j rot_j * diag[i*nIn + j]       (EvalMultExt / EvalAddExtInPlace, :2723-2740; NULL diag = term absent)
+ *   outK[i] == 0:  first += ApproxModDown(inner_i[0]);  outer[1] += inner_i[1]                               (:1861-1866, 1976-1979)
+ *   else        :  d = KeySwitchDown(inner_i); first += Automorphism_k(d[0]);
+ *                  outer += EvalFastRotationExt(d, k, digits(d), addFirst = false)                            (:1868-1876)
+ *   result  = KeySwitchDown(outer); result[0] += first                                                        (:1879-1880)
+ * Everything in EVALUATION format; c0,c1,out0,out1 [sizeQl][N]; diag rows [(sizeQl+sizeP)][N]; keys [numPartQ][sizeQ+sizeP][N]. */
+void orc_ckks_bsgs_transform(const orc_hybrid* h, const uint64_t* c0, const uint64_t* c1, uint32_t sizeQl, uint32_t nIn,
+                             const uint32_t* inK, const uint64_t* const* inKeyB, const uint64_t* const* inKeyA, uint32_t nOut,
+                             const uint32_t* outK, const uint64_t* const* outKeyB, const uint64_t* const* outKeyA,
+                             const uint64_t* const* diag, uint64_t* out0, uint64_t* out1) {
+    const uint32_t N = h->N, sizeQlP = sizeQl + h->sizeP;
+    const size_t ext = (size_t)sizeQlP * N, low = (size_t)sizeQl * N;
+    uint64_t* rot    = (uint64_t*)calloc((size_t)nIn * 2 * ext, sizeof(uint64_t));
+    uint64_t* inner  = (uint64_t*)malloc(sizeof(uint64_t) * 2 * ext);
+    uint64_t* outer  = (uint64_t*)calloc(2 * ext, sizeof(uint64_t));
+    uint64_t* tmpE   = (uint64_t*)malloc(sizeof(uint64_t) * 2 * ext);
+    uint64_t* first  = (uint64_t*)calloc(low, sizeof(uint64_t));
+    uint64_t* d      = (uint64_t*)malloc(sizeof(uint64_t) * 2 * low);
+    uint64_t* tmp    = (uint64_t*)malloc(sizeof(uint64_t) * N);
+    uint32_t* pre    = (uint32_t*)malloc(sizeof(uint32_t) * N);
+    for (uint32_t j = 0; j < nIn; ++j) {
+        uint64_t *r0 = rot + (size_t)j * 2 * ext, *r1 = r0 + ext;
+        if (inK[j])
+            orc_eval_fast_rotation_ext(h, c0, c1, sizeQl, inK[j], 1, inKeyB[j], inKeyA[j], r0, r1);
+        else /* KeySwitchExt(ct, true), keyswitch-hybrid.cpp:217-243: c * [P]_{q_i} on the Q_l limbs, zeros on the P limbs */
+            for (uint32_t i = 0; i < sizeQl; ++i) {
+                const uint64_t qi = h->q[i];
+                uint64_t PModq    = 1;
+                for (uint32_t t = 0; t < h->sizeP; ++t)
+                    PModq = orc_mulmod(PModq, h->p[t] % qi, qi);
+                orc_vec_mul_const(r0 + (size_t)i * N, c0 + (size_t)i * N, PModq, N, qi);
+                orc_vec_mul_const(r1 + (size_t)i * N, c1 + (size_t)i * N, PModq, N, qi);
+            }
+    }
+    for (uint32_t i = 0; i < nOut; ++i) {
+        memset(inner, 0, sizeof(uint64_t) * 2 * ext);
+        for (uint32_t j = 0; j < nIn; ++j) {
+            const uint64_t* a = diag[(size_t)i * nIn + j];
+            if (!a)
+                continue;
+            for (uint32_t e = 0; e < 2; ++e)
+                for (uint32_t l = 0; l < sizeQlP; ++l) {
+                    const uint64_t m = l < sizeQl ? h->q[l] : h->p[l - sizeQl];
+                    orc_vec_mul(tmp, rot + ((size_t)j * 2 + e) * ext + (size_t)l * N, a + (size_t)l * N, N, m);
+                    orc_vec_add(inner + e * ext + (size_t)l * N, inner + e * ext + (size_t)l * N, tmp, N, m);
+                }
+        }
+        if (!outK[i]) {
+            orc_hybrid_approx_mod_down(h, inner, sizeQl, d); /* KeySwitchDownFirstElement */
+            for (uint32_t l = 0; l < sizeQl; ++l)
+                orc_vec_add(first + (size_t)l * N, first + (size_t)l * N, d + (size_t)l * N, N, h->q[l]);
+            for (uint32_t l = 0; l < sizeQlP; ++l) {
+                const uint64_t m = l < sizeQl ? h->q[l] : h->p[l - sizeQl];
+                orc_vec_add(outer + ext + (size_t)l * N, outer + ext + (size_t)l * N, inner + ext + (size_t)l * N, N, m);
+            }
+        }
+        else {
+            orc_hybrid_approx_mod_down(h, inner, sizeQl, d);
+            orc_hybrid_approx_mod_down(h, inner + ext, sizeQl, d + low);
+            orc_precompute_auto_map(N, outK[i], pre);
+            for (uint32_t l = 0; l < sizeQl; ++l) {
+                orc_automorph_eval(tmp, d + (size_t)l * N, N, pre);
+                orc_vec_add(first + (size_t)l * N, first + (size_t)l * N, tmp, N, h->q[l]);
+            }
+            orc_eval_fast_rotation_ext(h, d, d + low, sizeQl, outK[i], 0, outKeyB[i], outKeyA[i], tmpE, tmpE + ext);
+            for (uint32_t e = 0; e < 2; ++e)
+                for (uint32_t l = 0; l < sizeQlP; ++l) {
+                    const uint64_t m = l < sizeQl ? h->q[l] : h->p[l - sizeQl];
+                    orc_vec_add(outer + e * ext + (size_t)l * N, outer + e * ext + (size_t)l * N, tmpE + e * ext + (size_t)l * N, N, m);
+                }
+        }
+    }
+    orc_hybrid_approx_mod_down(h, outer, sizeQl, out0);
+    orc_hybrid_approx_mod_down(h, outer + ext, sizeQl, out1);
+    for (uint32_t l = 0; l < sizeQl; ++l)
+        orc_vec_add(out0 + (size_t)l * N, out0 + (size_t)l * N, first + (size_t)l * N, N, h->q[l]);
+    free(rot), free(inner), free(outer), free(tmpE), free(first), free(d), free(tmp), free(pre);
+}
+
 /* ------------------------------------------------------------------------------------------
  * a15: rescale
  * ---------------------------------------------------------------------------------------- */

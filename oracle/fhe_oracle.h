@@ -161,6 +161,13 @@ void orc_ckks_eval_mult_relin(const orc_hybrid*, const uint64_t* a0, const uint6
 /* EvalFastRotationExt (ckksrns-leveledshe.cpp:534-582): result stays in the extended basis, out [(sizeQl+sizeP)][N] */
 void orc_eval_fast_rotation_ext(const orc_hybrid*, const uint64_t* c0, const uint64_t* c1, uint32_t sizeQl, uint32_t k,
                                 int addFirst, const uint64_t* keyB, const uint64_t* keyA, uint64_t* out0, uint64_t* out1);
+/* BSGS plaintext-matrix product with double hoisting (FHECKKSRNS::EvalLinearTransform, ckksrns-fhe.cpp:1832-1882; one level
+ * of EvalCoeffsToSlots / EvalSlotsToCoeffs, :1884-2198).  inK[j] / outK[i] = automorphism index, 0 = no rotation;
+ * diag[i*nIn+j] = plaintext rows [(sizeQl+sizeP)][N] EVALUATION or NULL (term absent). */
+void orc_ckks_bsgs_transform(const orc_hybrid*, const uint64_t* c0, const uint64_t* c1, uint32_t sizeQl, uint32_t nIn,
+                             const uint32_t* inK, const uint64_t* const* inKeyB, const uint64_t* const* inKeyA, uint32_t nOut,
+                             const uint32_t* outK, const uint64_t* const* outKeyB, const uint64_t* const* outKeyA,
+                             const uint64_t* const* diag, uint64_t* out0, uint64_t* out1);
 void orc_eval_automorphism(const orc_hybrid*, const uint64_t* c0, const uint64_t* c1, uint32_t sizeQl, uint32_t k,
                            const uint64_t* keyB, const uint64_t* keyA, uint64_t* out0, uint64_t* out1);
 

@@ -566,6 +566,72 @@ int ref_ckks_key_switch_down(void* h, int ctExt) {
     s->cts.push_back(s->cc->KeySwitchDown(s->cts[ctExt]));
     return static_cast<int>(s->cts.size()) - 1;
 }
+
+// ---- BSGS linear transform with double hoisting: the reference's own FHECKKSRNS::EvalLinearTransform ----
+// (the FHE object is a protected member of SchemeBase: reached through a derived accessor, not modified)
+namespace {
+struct SchemeFheAccess : SchemeBase<DCRTPoly> {
+    static std::shared_ptr<FHEBase<DCRTPoly>> get(const SchemeBase<DCRTPoly>& s) { return s.*(&SchemeFheAccess::m_FHE); }
+};
+std::shared_ptr<FHECKKSRNS> fhe_of(const CryptoContext<DCRTPoly>& cc) {
+    return std::dynamic_pointer_cast<FHECKKSRNS>(SchemeFheAccess::get(*cc->GetScheme()));
+}
+struct RefLt {
+    std::vector<ReadOnlyPlaintext> A;
+    uint32_t slots, bStep;
+};
+}  // namespace
+// bootstrapping parameters only (no plaintext precomputation): level budget {1,1}, baby step = dim1 = bStep
+void* ref_ckks_lt_create(void* h, uint32_t slots, uint32_t bStep, const double* m /*[slots][slots] (re, im)*/, uint32_t L) {
+    auto* s = static_cast<RefCkks*>(h);
+    s->cc->Enable(ADVANCEDSHE);
+    s->cc->Enable(FHE);
+    s->cc->EvalBootstrapSetup({1, 1}, {bStep, bStep}, slots, 0, false);
+    std::vector<std::vector<std::complex<double>>> M(slots, std::vector<std::complex<double>>(slots));
+    for (uint32_t i = 0; i < slots; ++i)
+        for (uint32_t j = 0; j < slots; ++j)
+            M[i][j] = {m[2 * ((size_t)i * slots + j)], m[2 * ((size_t)i * slots + j) + 1]};
+    auto* lt  = new RefLt;
+    lt->slots = slots, lt->bStep = bStep;
+    lt->A     = fhe_of(s->cc)->EvalLinearTransformPrecompute(*s->cc, M, 1.0, L);
+    return lt;
+}
+void ref_ckks_lt_destroy(void* l) { delete static_cast<RefLt*>(l); }
+// diagonal i as [sizeQl+sizeP][N] EVALUATION residues; returns its number of limbs
+uint32_t ref_ckks_lt_get_diag(void* l, uint32_t i, uint64_t* out) {
+    auto* lt = static_cast<RefLt*>(l);
+    auto pt  = lt->A[i]->GetElement<DCRTPoly>();
+    pt.SetFormat(Format::EVALUATION);
+    if (out)
+        export_poly(pt, out);
+    return pt.GetNumOfElements();
+}
+int ref_ckks_eval_linear_transform(void* h, void* l, int ct) {
+    auto* s  = static_cast<RefCkks*>(h);
+    auto* lt = static_cast<RefLt*>(l);
+    ConstCiphertext<DCRTPoly> c = s->cts[ct];
+    s->cts.push_back(fhe_of(s->cc)->EvalLinearTransform(lt->A, c));
+    return static_cast<int>(s->cts.size()) - 1;
+}
+// an encryption with `slots` packed values (sparse packing when slots < N/2)
+int ref_ckks_encrypt_slots(void* h, const double* vals /*[slots] (re, im)*/, uint32_t level, uint32_t slots) {
+    auto* s = static_cast<RefCkks*>(h);
+    std::vector<std::complex<double>> v(slots);
+    for (uint32_t i = 0; i < slots; ++i)
+        v[i] = {vals[2 * i], vals[2 * i + 1]};
+    auto pt = s->cc->MakeCKKSPackedPlaintext(v, 1, level, nullptr, slots);
+    s->cts.push_back(s->cc->Encrypt(s->kp.publicKey, pt));
+    return static_cast<int>(s->cts.size()) - 1;
+}
+void ref_ckks_decrypt_complex(void* h, int ct, double* out, uint32_t n) {
+    auto* s = static_cast<RefCkks*>(h);
+    Plaintext pt;
+    s->cc->Decrypt(s->kp.secretKey, s->cts[ct], &pt);
+    pt->SetLength(n);
+    auto v = pt->GetCKKSPackedValue();
+    for (uint32_t i = 0; i < n && i < v.size(); ++i)
+        out[2 * i] = v[i].real(), out[2 * i + 1] = v[i].imag();
+}
 int ref_omp_threads() { return OpenFHEParallelControls.GetNumThreads(); }
 
 // ---- ScaleAndRound family with caller tables ----

@@ -105,6 +105,8 @@ def load_oracle():
     S("orc_scale_and_round_native", None, [P64, u32, u32, P64, u64, P64, P64, PF64, PF64, P64])
     S("orc_scale_and_round_behz_decrypt", None, [P64, u32, u32, P64, u64, P64, P64, P64])
     S("orc_eval_fast_rotation_ext", None, [vp, P64, P64, u32, u32, C.c_int, P64, P64, P64, P64])
+    PV = C.POINTER(C.c_void_p)
+    S("orc_ckks_bsgs_transform", None, [vp, P64, P64, u32, u32, P32, PV, PV, u32, P32, PV, PV, PV, P64, P64])
     S("orc_hybrid_approx_mod_down_t", None, [vp, P64, u32, u64, P64])
     S("orc_expand_crt_basis", None, [vp, u32, u32, P64, C.c_int, P64, P64, P64, P64, P64, PF64, C.c_int, C.c_int, P64])
     S("orc_fast_expand_crt_basis_p_over_q", None, [P64, u32, u32, P64, P64, P64, P64, u32, P64, P64, P64, P64, P64, P64, u32,
@@ -189,6 +191,12 @@ def load_ref():
     S("ref_scale_and_round_behz_decrypt", None, [u32, u32, P64, P64, P64, u64, u64, P64, P64, P64])
     S("ref_ckks_eval_fast_rotate_ext", C.c_int, [vp, C.c_int, i32, C.c_int])
     S("ref_ckks_key_switch_down", C.c_int, [vp, C.c_int])
+    S("ref_ckks_lt_create", vp, [vp, u32, u32, PF64, u32])
+    S("ref_ckks_lt_destroy", None, [vp])
+    S("ref_ckks_lt_get_diag", u32, [vp, u32, C.c_void_p])
+    S("ref_ckks_eval_linear_transform", C.c_int, [vp, vp, C.c_int])
+    S("ref_ckks_encrypt_slots", C.c_int, [vp, PF64, u32, u32])
+    S("ref_ckks_decrypt_complex", None, [vp, C.c_int, PF64, u32])
     S("ref_approx_mod_down", None, [u32, u32, P64, P64, u32, P64, P64, P64, P64, P64, P64, u64, P64])
     S("ref_expand_crt_basis", None, [u32, u32, P64, P64, P64, C.c_int, P64, P64, P64, u32, P64, P64, PF64, C.c_int, C.c_int, P64])
     S("ref_fast_expand_crt_basis_p_over_q", None, [u32, u32, P64, P64, P64, P64, P64, u32, P64, P64, P64, P64, P64, u32, P64,
@@ -294,3 +302,11 @@ def behz_decrypt_tables(q, t):
     a = np.array([(tg % s) * pow((Q // s) % s, -1, s) % s for s in q_i], np.uint64)
     b = np.array([(-pow(s % tg, -1, tg)) % tg for s in q_i], np.uint64)
     return tg, a, b
+
+
+def ptr_array(arrays):
+    """C array of data pointers (NULL for None) for the `const uint64_t* const*` arguments; keeps nothing alive itself"""
+    a = (C.c_void_p * max(1, len(arrays)))()
+    for i, x in enumerate(arrays):
+        a[i] = None if x is None else x.ctypes.data
+    return a

@@ -526,3 +526,77 @@ def test_rotations_against_live_reference(oracle, ref):
             assert np.array_equal(d0, ex(rd, 0)) and np.array_equal(d1, ex(rd, 1)), "KeySwitchDown"
     o.orc_hybrid_destroy(hy)
     r.ref_ckks_destroy(h)
+
+
+def ref_linear_transform_session(r, o, ring, depth, sms, fms, dnum, slots, bStep, level=1, seed=11):
+    """The reference's own EvalLinearTransform (BSGS with double hoisting) on its own keys and plaintext diagonals.
+    Returns everything the oracle / the product need: moduli, ciphertext, diagonals, rotation keys, and the result."""
+    h = r.ref_ckks_create(ring, depth, sms, fms, dnum, 0)
+    info = np.zeros(5, np.uint32)
+    r.ref_ckks_info(h, info)
+    N, sizeQ, sizeP, numPartQ, alpha = map(int, info)
+    q, psiQ = np.zeros(sizeQ, np.uint64), np.zeros(sizeQ, np.uint64)
+    p, psiP = np.zeros(sizeP, np.uint64), np.zeros(sizeP, np.uint64)
+    r.ref_ckks_get_moduli(h, q, psiQ, p, psiP)
+    gStep = -(-slots // bStep)
+    rots = sorted(set(range(1, bStep)) | {bStep * j for j in range(1, gStep)})
+    idx = np.array(rots, np.int32)
+    r.ref_ckks_rotate_keygen(h, idx, len(idx))
+    rng = np.random.default_rng(seed)
+    vals, M = np.zeros((slots, 2)), np.zeros((slots, slots, 2))
+    vals[:, 0], M[:, :, 0] = rng.uniform(-1, 1, slots), rng.uniform(-1, 1, (slots, slots))  # real data: the default CKKS mode
+    ct = r.ref_ckks_encrypt_slots(h, vals, level, slots)
+    ci = np.zeros(4, np.uint32)
+    r.ref_ct_info(h, ct, ci)
+    sizeQl = int(ci[1])
+    lt = r.ref_ckks_lt_create(h, slots, bStep, M, sizeQl - 1)  # L: plaintexts get L + 1 Q limbs (the ciphertext's) + P
+    assert r.ref_ckks_lt_get_diag(lt, 0, None) == sizeQl + sizeP
+    diag = np.zeros((slots, sizeQl + sizeP, N), np.uint64)
+    for i in range(slots):
+        r.ref_ckks_lt_get_diag(lt, i, diag[i].ctypes.data)
+
+    def ex(c, e):
+        a = np.zeros((sizeQl, N), np.uint64)
+        r.ref_ct_export(h, c, e, a)
+        return a
+    keys = {}
+    for index in rots:
+        keyB = np.zeros((numPartQ, sizeQ + sizeP, N), np.uint64)
+        keyA = keyB.copy()
+        k = r.ref_ckks_get_rot_key(h, index, keyB, keyA)
+        keys[index] = (k, keyB, keyA)
+    res = r.ref_ckks_eval_linear_transform(h, lt, ct)
+    S = dict(N=N, q=q, psiQ=psiQ, p=p, psiP=psiP, numPartQ=numPartQ, sizeQl=sizeQl, slots=slots, bStep=bStep, gStep=gStep,
+             c=np.stack([ex(ct, 0), ex(ct, 1)]), diag=diag, values=vals[:, 0].copy(), matrix=M[:, :, 0].copy(), keys=keys, out=np.stack([ex(res, 0), ex(res, 1)]))
+    return h, lt, ct, res, S
+
+
+def bsgs_arguments(S):
+    """orc_ckks_bsgs_transform / fhe_ckks_bsgs_transform arguments of EvalLinearTransform: inner rotations 0..bStep-1,
+    outer rotations bStep*j, diagonal bStep*j+i (absent beyond `slots`)"""
+    bStep, gStep, slots, keys = S["bStep"], S["gStep"], S["slots"], S["keys"]
+    inK = np.array([0] + [keys[i][0] for i in range(1, bStep)], np.uint32)
+    outK = np.array([0] + [keys[bStep * j][0] for j in range(1, gStep)], np.uint32)
+    inB = [None] + [keys[i][1] for i in range(1, bStep)]
+    inA = [None] + [keys[i][2] for i in range(1, bStep)]
+    outB = [None] + [keys[bStep * j][1] for j in range(1, gStep)]
+    outA = [None] + [keys[bStep * j][2] for j in range(1, gStep)]
+    diag = [S["diag"][bStep * j + i] if bStep * j + i < slots else None for j in range(gStep) for i in range(bStep)]
+    return inK, inB, inA, outK, outB, outA, diag
+
+
+@pytest.mark.parametrize("ring,depth,dnum,slots,bStep", [(1 << 9, 3, 2, 16, 4), (1 << 10, 4, 3, 8, 4), (1 << 9, 3, 2, 16, 5)])
+def test_linear_transform_against_live_reference(oracle, ref, ring, depth, dnum, slots, bStep):
+    """FHECKKSRNS::EvalLinearTransform of the reference (BSGS + double hoisting, its own keys and encoded diagonals) vs the
+    oracle's composition of EvalFastRotationExt / EvalMultExt / KeySwitchDown"""
+    o, r = oracle, ref
+    h, lt, ct, res, S = ref_linear_transform_session(r, o, ring, depth, 45, 55, dnum, slots, bStep)
+    hy = o.orc_hybrid_create(S["N"], len(S["q"]), S["q"], S["psiQ"], len(S["p"]), S["p"], S["psiP"], S["numPartQ"])
+    inK, inB, inA, outK, outB, outA, diag = bsgs_arguments(S)
+    out = np.zeros_like(S["c"])
+    o.orc_ckks_bsgs_transform(hy, S["c"][0], S["c"][1], S["sizeQl"], len(inK), inK, libs.ptr_array(inB), libs.ptr_array(inA),
+                              len(outK), outK, libs.ptr_array(outB), libs.ptr_array(outA), libs.ptr_array(diag), out[0], out[1])
+    assert np.array_equal(out, S["out"])
+    o.orc_hybrid_destroy(hy)
+    r.ref_ckks_lt_destroy(lt)
+    r.ref_ckks_destroy(h)
