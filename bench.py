@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-hadamard", action="store_true", help="skip the Hadamard-product leg")
     ap.add_argument("--no-bfv", action="store_true", help="skip the BFV EvalMult (BEHZ) leg (BASELINE configs[4] shape)")
     ap.add_argument("--bfv-batch", type=int, default=64)
+    ap.add_argument("--no-lt", action="store_true", help="skip the BSGS linear-transform leg (bootstrapping's inner loop)")
     return ap.parse_args()
 
 
@@ -217,6 +218,106 @@ def evalmult_leg(lib, device, logN, batch, steps, warmup, sync, dist=None):
     return {"ops_per_s_per_gpu": round(batch / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "batch": batch,
             "shape": f"N=2^{logN}, l={sizeQ}, k={len(p)}, dnum={dnum}, workspace {wsb / 2**30:.1f} GiB",
             "eval_key": key_dist, "launch": mode}
+
+
+def linear_transform_leg(lib, device, batches, steps, warmup, with_cpu):
+    """FHECKKSRNS::EvalLinearTransform (BSGS with double hoisting, the linear-transform loop of CKKS bootstrapping, BASELINE
+    configs[3]'s inner loop) at config 3's ring and level: N=2^16, l=21 limbs, dnum=3, 64 diagonals as 8 baby x 8 giant steps.
+    One HIP graph replay per transform; the CPU figure is the reference's own EvalLinearTransform (oracle/_ref)."""
+    logN, sizeQ, dnum, slots, bStep = 16, 21, 3, 64, 8
+    gStep = slots // bStep
+    q, psiQ = lib.ckks_like_chain(logN, sizeQ, 60, 59)
+    p, psiP = lib.select_p(logN, q, dnum, 60)
+    allq = np.concatenate([q, p])
+    ctx = fh.Context(lib, logN, np.concatenate([q, p]), np.concatenate([psiQ, psiP]), device=device)
+    plan = fh.KeySwitchPlan(ctx, sizeQ, len(p), dnum)
+    N = ctx.N
+    rng = np.random.default_rng(9)
+
+    def rows(mods, lead):
+        host = np.empty((lead, len(mods), N), np.uint64)
+        for i, m in enumerate(mods):
+            host[:, i, :] = rng.integers(0, int(m), size=(lead, N), dtype=np.uint64)
+        return host
+    # distinct device buffers for every key and diagonal (so that nothing is served from the Infinity Cache by accident);
+    # their content is uniform random either way, two host images are enough
+    kimg = [rows(allq, dnum) for _ in range(2)]
+    keys = {}
+    for n, index in enumerate(list(range(1, bStep)) + [bStep * j for j in range(1, gStep)]):
+        keys[index] = (lib.find_automorphism_index(index, 2 * N), plan.make_key(kimg[n % 2], kimg[(n + 1) % 2]))
+    dimg = [rows(allq, 1)[0] for _ in range(2)]
+    A = [ctx.upload(dimg[i % 2]) for i in range(slots)]
+    in_rot = [None] + [keys[i] for i in range(1, bStep)]
+    out_rot = [None] + [keys[bStep * j] for j in range(1, gStep)]
+    diag = [[A[bStep * j + i] for i in range(bStep)] for j in range(gStep)]
+    res = {"shape": f"N=2^{logN}, l={sizeQ}, k={len(p)}, dnum={dnum}, {slots} diagonals = {bStep} baby x {gStep} giant steps, "
+                    f"{bStep - 1}+{gStep - 1} rotation keys", "per_batch": {}}
+    st = C.c_void_p()
+    lib.check(lib.L.fhe_stream_create(ctx.h, C.byref(st)))
+    for batch in batches:
+        c0 = fh.Tower(ctx, fill_random_tower(ctx, q, batch, 400, seed_polys=2), batch, sizeQ)
+        c1 = fh.Tower(ctx, fill_random_tower(ctx, q, batch, 401, seed_polys=2), batch, sizeQ)
+        out = (c0.like(), c0.like())
+        wsb = lib.L.fhe_ckks_bsgs_workspace_bytes(plan.h, sizeQ, batch, bStep, gStep)
+        ws = (ctx.malloc(wsb), wsb)
+
+        def call():
+            plan.BsgsTransform(c0, c1, in_rot, out_rot, diag, ws=ws, out=out, stream=st)
+        step, mode, graph = timed_sequence(lib, ctx, st, call)
+        t0 = time.perf_counter()
+        n = 0
+        while n < warmup or time.perf_counter() - t0 < 0.4:  # a step is a few ms: warm up by time, so that the clocks have ramped
+            step()
+            lib.check(lib.L.fhe_stream_sync(ctx.h, st))
+            n += 1
+        reps = max(steps, int(0.5 / max((time.perf_counter() - t0) / n, 1e-4)))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            step()
+        lib.check(lib.L.fhe_stream_sync(ctx.h, st))
+        dt = (time.perf_counter() - t0) / reps
+        lib.L.fhe_graph_destroy(graph)
+        res["per_batch"][str(batch)] = {"transforms_per_s_per_gpu": round(batch / dt, 2), "ms_per_batch": round(dt * 1e3, 3),
+                                        "workspace_GiB": round(wsb / 2**30, 2), "launch": mode}
+        for t in (c0, c1) + out:
+            ctx.free(t.ptr)
+        ctx.free(ws[0])
+    lib.check(lib.L.fhe_stream_destroy(ctx.h, st))
+    plan.close()
+    ctx.close()
+    res["transforms_per_s_per_gpu"] = max(v["transforms_per_s_per_gpu"] for v in res["per_batch"].values())
+    res["cpu_baseline"] = None
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import libs
+        if libs.have_ref():
+            r = libs.load_ref()
+            gomp = C.CDLL("libgomp.so.1")
+            cores = os.cpu_count() or 1
+            h = r.ref_ckks_create(1 << logN, sizeQ - 1, 59, 60, dnum, 0)
+            idx = np.array(sorted(keys), np.int32)
+            r.ref_ckks_rotate_keygen(h, idx, len(idx))
+            vals, M = np.zeros((slots, 2)), np.zeros((slots, slots, 2))
+            vals[:, 0], M[:, :, 0] = rng.uniform(-1, 1, slots), rng.uniform(-1, 1, (slots, slots))
+            ct = r.ref_ckks_encrypt_slots(h, vals, 0, slots)
+            lt = r.ref_ckks_lt_create(h, slots, bStep, M, 0)
+            best, best_t = None, None
+            for nt in sorted({cores, 64, 32, 16, 8}):  # give the reference its best OpenMP team size
+                if nt > cores:
+                    continue
+                gomp.omp_set_num_threads(nt)
+                sec1 = r.ref_ckks_time_linear_transform(h, lt, ct, 1)
+                if best is None or sec1 < best_t:
+                    best, best_t = nt, sec1
+            gomp.omp_set_num_threads(best)
+            reps = max(2, min(10, int(6.0 / best_t)))
+            sec = r.ref_ckks_time_linear_transform(h, lt, ct, reps)
+            res["cpu_baseline"] = {"value": round(1.0 / sec, 3), "unit": "transforms/s", "cores": int(best), "kind": "reference",
+                                   "sample": f"{reps} x FHECKKSRNS::EvalLinearTransform, N=2^{logN}, {sizeQ} Q limbs, {slots} diagonals, "
+                                             f"bStep={bStep}; {sec * 1e3:.0f} ms each; best OpenMP team of {{8..{cores}}}"}
+            r.ref_ckks_lt_destroy(lt)
+            r.ref_ckks_destroy(h)
+    return res
 
 
 def bfv_leg(lib, device, batch, steps, warmup, sync, with_cpu):
@@ -512,6 +613,10 @@ def main():
         bfv = bfv_leg(lib, device, a.bfv_batch, max(30, a.steps * 3), 6, gpu_sync,
                       rank == 0 and world == 1 and not a.no_cpu_baseline)
 
+    ltr = None
+    if not a.no_lt and logN == 16 and world == 1:
+        ltr = linear_transform_leg(lib, device, (1, 8), max(10, a.steps), 3, rank == 0 and not a.no_cpu_baseline)
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(q, psi, logN, L, a.cpu_seconds)
@@ -532,6 +637,8 @@ def main():
         }
         if bfv is not None:
             out["bfv_evalmult"] = bfv
+        if ltr is not None:
+            out["linear_transform"] = ltr
         print(json.dumps(out))
     ctx.close()
     if dist is not None:

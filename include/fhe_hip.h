@@ -250,8 +250,10 @@ fhe_status fhe_ks_down(fhe_ks_plan* plan, const uint64_t* x0Ext, const uint64_t*
  * inK / outK are automorphism indices (FindAutomorphismIndex2nComplex of the rotation), 0 = no rotation; inKeys[j] /
  * outKeys[i] the matching evaluation keys (ignored where the index is 0).  diag: HOST array of nOut*nIn DEVICE pointers to
  * plaintext rows [sizeQl+sizeP][N] in EVALUATION format over limbs {0..sizeQl-1, sizeQ..sizeQ+sizeP-1}
- * (EvalLinearTransformPrecompute's aux plaintexts), shared by the whole batch.  c0,c1,out0,out1: [batch][sizeQl][N]. */
-size_t fhe_ckks_bsgs_workspace_bytes(const fhe_ks_plan* plan, uint32_t sizeQl, uint32_t batch, uint32_t nIn);
+ * (EvalLinearTransformPrecompute's aux plaintexts), shared by the whole batch.  c0,c1,out0,out1: [batch][sizeQl][N].
+ * Every stage runs once over all outer steps (their accumulations are exact modular sums, so the order is free); the
+ * first call with a new set of diagonals uploads their pointer table (not capturable), later calls are pure launches. */
+size_t fhe_ckks_bsgs_workspace_bytes(const fhe_ks_plan* plan, uint32_t sizeQl, uint32_t batch, uint32_t nIn, uint32_t nOut);
 fhe_status fhe_ckks_bsgs_transform(fhe_ks_plan* plan, const uint64_t* c0, const uint64_t* c1, uint32_t sizeQl, uint32_t batch,
                                    uint32_t nIn, const uint32_t* inK, const fhe_ks_key* const* inKeys, uint32_t nOut,
                                    const uint32_t* outK, const fhe_ks_key* const* outKeys, const uint64_t* const* diag,
@@ -366,6 +368,9 @@ fhe_status fhe_param_dcrt_chain(uint32_t order, uint32_t nLimbs, uint32_t bits, 
 /* returns sizeP (0 on error); p/psiP need capacity >= 64 */
 uint32_t   fhe_param_select_p(uint32_t logN, uint32_t sizeQ, const uint64_t* q, uint32_t numPartQ, uint32_t auxBits,
                               uint64_t* p, uint64_t* psiP);
+/* FindAutomorphismIndex2nComplex (src/core/lib/math/nbtheory2.cpp:243-262): automorphism index 5^index mod m of a CKKS
+ * rotation by `index` slots (m = 2N, a power of two); 0 on error */
+uint32_t   fhe_param_find_automorphism_index_2n_complex(int32_t index, uint32_t m);
 
 /* ---- measurement helper ----------------------------------------------------------------------------
  * Runs `iters` back-to-back launches of fwd (dir=0), inv (dir=1) or fwd+inv (dir=2) NTT on x — or of a single

@@ -140,16 +140,17 @@ struct KsInnerArgs {
     uint32_t nc[kMaxDigits];           // complement size of digit j = sizeQl - size_j + sizeP
 };
 FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ks_inner_product_kernel(const KsInnerArgs g) {
-    // one workgroup = 4096 consecutive coefficients of one (b, i) output row; batch-fastest so that the
-    // key rows (shared by the whole batch) stay in L2
+    // one workgroup = 4096 consecutive coefficients of one (b, i) output row.  The key rows of a (limb, tile) group are
+    // shared by the whole batch: workgroups go round-robin over the 8 XCDs, so the group's `batch` workgroups take
+    // consecutive slots of ONE XCD and the key tile is fetched into one L2 once (not once per XCD)
     const uint32_t t          = FHE_TID;
     const uint32_t tilesPerRow = (1u << g.logN) >> kTileLog ? ((1u << g.logN) >> kTileLog) : 1u;
     const uint32_t sizeQlP    = g.sizeQl + g.sizeP;
-    uint32_t blk              = FHE_BID;
-    const uint32_t b          = blk % g.batch;
-    blk /= g.batch;
-    const uint32_t tr = blk % tilesPerRow;
-    const uint32_t i  = blk / tilesPerRow;
+    const uint32_t xcd = FHE_BID & 7u, slot = FHE_BID >> 3;
+    const uint32_t b   = slot % g.batch;
+    const uint32_t grp = (slot / g.batch) * 8u + xcd;
+    const uint32_t tr = grp % tilesPerRow;
+    const uint32_t i  = grp / tilesPerRow;
     if (i >= sizeQlP)
         return;
     const uint32_t idx  = i < g.sizeQl ? i : i + (g.sizeQ - g.sizeQl);
@@ -160,7 +161,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ks_inner_product_kernel(const KsInne
     const uint32_t N    = 1u << g.logN;
     const uint32_t rEnd = ((tr + 1u) << kTileLog) < N ? ((tr + 1u) << kTileLog) : N;
     for (uint32_t r = (tr << kTileLog) + t; r < rEnd; r += kThreads) {
-        mac192 s0, s1;
+        mac192 s0, s1;  // (the digits are lazy, up to 16q < 2^64: the 60-bit shortcuts of sum8 do not apply here)
         mac192_clear(s0);
         mac192_clear(s1);
         for (uint32_t j = 0; j < g.numDigits; ++j) {
@@ -186,56 +187,102 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ks_inner_product_kernel(const KsInne
     }
 }
 
-// ---- baby-step/giant-step inner sum (double hoisting) ---------------------------------------------
-// inner[e][b][i][r] = sum_j rot_j[e][b][i][r] * diag_j[i][r]  over the extended basis Q_l u P: the EvalMultExt /
-// EvalAddExtInPlace chain of FHECKKSRNS::EvalLinearTransform (ckksrns-fhe.cpp:1855-1859, 2723-2740) as ONE pass:
-// every rotated ciphertext and every plaintext diagonal is read once, the sum is kept in a 192-bit accumulator and
-// reduced once (an exact reduction of the exact sum equals the reference's chain of ModMul / ModAdd results).
-constexpr int kMaxBsgsIn = 32;
+// ---- baby-step/giant-step inner sums (double hoisting) --------------------------------------------
+// inner_i[e][b][l][r] = sum_j rot_j[e][b][l][r] * diag_{i,j}[l][r]  over the extended basis Q_l u P, for ALL outer steps i
+// in one pass: the EvalMultExt / EvalAddExtInPlace chains of FHECKKSRNS::EvalLinearTransform (ckksrns-fhe.cpp:1855-1859,
+// 2723-2740).  A lane keeps the nIn rotated residues of its coefficient in registers and walks the outer steps, so every
+// rotated ciphertext is read once (not once per outer step); each sum is kept in a 192-bit accumulator and reduced once
+// (an exact reduction of the exact sum equals the reference's chain of ModMul / ModAdd results).
+// Workgroup order is XCD-aware: the 2*batch workgroups that need the same plaintext rows (one limb tile, every element
+// and ciphertext of the batch) get consecutive slots on ONE XCD, so the diagonals are fetched once per XCD L2.
+constexpr int kMaxBsgsIn = 16;  // inner rotations per launch (more are accumulated by further launches)
 struct BsgsInnerArgs {
-    const uint64_t* rot;               // [nIn][2][batch][sizeQl+sizeP][N] EVAL, canonical
-    const uint64_t* diag[kMaxBsgsIn];  // diagonal of inner rotation j: [sizeQl+sizeP][N] EVAL, shared by the batch; null = absent
-    uint64_t* out;                     // [2][batch][sizeQl+sizeP][N]
-    const LimbConst* lc;               // [ctxLimbs]; ctx limbs: Q then P
-    const uint64_t* mu128;             // [ctxLimbs][2]
-    uint32_t logN, batch, sizeQl, sizeQ, sizeP, nIn, accumulate;
+    const uint64_t* rot;          // [nIn][2][batch][sizeQl+sizeP][N] EVAL, canonical (already offset to the chunk's first rotation)
+    const uint64_t* const* diag;  // DEVICE table [nOut][nInPad]: plaintext rows [sizeQl+sizeP][N] EVAL; absent terms and the
+                                  // padding up to a multiple of the kernel's NIN point at rows of zeros
+    uint64_t* out;                // [2][nOut][batch][sizeQl+sizeP][N]
+    const LimbConst* lc;          // [ctxLimbs]; ctx limbs: Q then P
+    const uint64_t* mu128;        // [ctxLimbs][2]
+    uint32_t logN, batch, sizeQl, sizeQ, sizeP, nIn, nInPad, j0, nOut, accumulate;
 };
+// CPL = coefficients per lane (adjacent: CPL = 2 gives 16-byte accesses); the plaintext residues of outer step i+1 are
+// loaded before the sums of step i are computed (software pipelining: the loads of a wave overlap its own arithmetic).
+template <int NIN, int CPL>
 FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) bsgs_inner_kernel(const BsgsInnerArgs g) {
-    // one workgroup = 4096 consecutive coefficients of one (e, i, b) row; batch-fastest: the diagonal's row stays in L2
     const uint32_t t           = FHE_TID;
     const uint32_t N           = 1u << g.logN;
     const uint32_t tilesPerRow = (N >> kTileLog) ? (N >> kTileLog) : 1u;
     const uint32_t sizeQlP     = g.sizeQl + g.sizeP;
-    uint32_t blk               = FHE_BID;
-    const uint32_t b           = blk % g.batch;
-    blk /= g.batch;
-    const uint32_t tr = blk % tilesPerRow;
-    blk /= tilesPerRow;
-    const uint32_t i = blk % sizeQlP;
-    const uint32_t e = blk / sizeQlP;
-    if (e >= 2u)
+    const uint32_t nGroups     = sizeQlP * tilesPerRow, per = 2u * g.batch;
+    const uint32_t xcd = FHE_BID & 7u, slot = FHE_BID >> 3;
+    const uint32_t grp = (slot / per) * 8u + xcd, local = slot % per;
+    if (grp >= nGroups)
         return;
-    const uint32_t idx  = i < g.sizeQl ? i : i + (g.sizeQ - g.sizeQl);
+    const uint32_t e = local / g.batch, b = local % g.batch;
+    const uint32_t l = grp / tilesPerRow, tr = grp % tilesPerRow;
+    const uint32_t idx  = l < g.sizeQl ? l : l + (g.sizeQ - g.sizeQl);
     const LimbConst lc  = g.lc[idx];
     const uint64_t mulo = g.mu128[2 * idx], muhi = g.mu128[2 * idx + 1];
     const uint64_t rotStride = ((uint64_t)2 * g.batch * sizeQlP) << g.logN;  // words between rot_j and rot_{j+1}
-    const uint64_t rowOff    = (((uint64_t)e * g.batch + b) * sizeQlP + i) << g.logN;
+    const uint64_t rotOff    = (((uint64_t)e * g.batch + b) * sizeQlP + l) << g.logN;
+    const uint64_t outStride = ((uint64_t)g.batch * sizeQlP) << g.logN;      // words between inner_i and inner_{i+1}
+    const uint64_t outOff    = ((((uint64_t)e * g.nOut) * g.batch + b) * sizeQlP + l) << g.logN;
     const uint32_t rEnd      = ((tr + 1u) << kTileLog) < N ? ((tr + 1u) << kTileLog) : N;
-    for (uint32_t r = (tr << kTileLog) + t; r < rEnd; r += kThreads) {
-        mac192 s;
-        mac192_clear(s);
-        for (uint32_t j = 0; j < g.nIn; ++j) {
-            const uint64_t* dj = g.diag[j];
-            if (!dj)
-                continue;
-            mac192_add(s, g.rot[(uint64_t)j * rotStride + rowOff + r], dj[((uint64_t)i << g.logN) + r]);
+    for (uint32_t r = (tr << kTileLog) + CPL * t; r < rEnd; r += CPL * kThreads) {
+        // all loads unconditional (absent terms point at a row of zeros, missing rotations re-read the last one and meet
+        // a zero row too): the compiler issues the NIN loads of a phase back to back
+        uint64_t x[NIN][CPL], y[NIN][CPL], yn[NIN][CPL];
+#pragma unroll
+        for (int j = 0; j < NIN; ++j) {
+            const uint32_t jj  = (uint32_t)j < g.nIn ? (uint32_t)j : g.nIn - 1u;
+            const uint64_t* xp = g.rot + ((uint64_t)jj * rotStride + rotOff) + r;  // uniform base + 32-bit lane offset
+#pragma unroll
+            for (int u = 0; u < CPL; ++u)
+                x[j][u] = xp[u];
         }
-        u128w a;
-        mac192_fold(s, a.lo, a.hi);
-        uint64_t v = barrett128(a, lc.q, mulo, muhi);
-        if (g.accumulate)
-            v = add_mod(g.out[rowOff + r], v, lc.q);
-        g.out[rowOff + r] = v;
+        const uint32_t lr = (l << g.logN) + r;  // word offset inside a plaintext: below 2^23
+        {
+            const uint64_t* const* drow = g.diag + g.j0;
+#pragma unroll
+            for (int j = 0; j < NIN; ++j)
+#pragma unroll
+                for (int u = 0; u < CPL; ++u)
+                    y[j][u] = (drow[j] + lr)[u];
+        }
+        for (uint32_t i = 0; i < g.nOut; ++i) {
+            {  // next outer step's plaintext residues (the last step re-reads its own: no branch around the loads)
+                const uint32_t in = i + 1u < g.nOut ? i + 1u : i;
+                const uint64_t* const* drow = g.diag + (uint64_t)in * g.nInPad + g.j0;
+#pragma unroll
+                for (int j = 0; j < NIN; ++j)
+#pragma unroll
+                    for (int u = 0; u < CPL; ++u)
+                        yn[j][u] = (drow[j] + lr)[u];
+            }
+            uint64_t v[CPL] = {};
+#pragma unroll
+            for (int j0 = 0; j0 < NIN; j0 += 8) {  // one exact reduction per 8 terms (sum8)
+#pragma unroll
+                for (int u = 0; u < CPL; ++u) {
+                    sum8 s;
+                    sum8_clear(s);
+#pragma unroll
+                    for (int j = j0; j < j0 + 8 && j < NIN; ++j)
+                        sum8_add(s, x[j][u], y[j][u]);
+                    const uint64_t rj = sum8_reduce(s, lc.q, lc.msb, mulo, muhi);
+                    v[u]              = j0 ? add_mod(v[u], rj, lc.q) : rj;
+                }
+            }
+            uint64_t* op = g.out + (outOff + (uint64_t)i * outStride) + r;
+#pragma unroll
+            for (int u = 0; u < CPL; ++u)
+                op[u] = g.accumulate ? add_mod(op[u], v[u], lc.q) : v[u];
+#pragma unroll
+            for (int j = 0; j < NIN; ++j)
+#pragma unroll
+                for (int u = 0; u < CPL; ++u)
+                    y[j][u] = yn[j][u];
+        }
     }
 }
 

@@ -200,6 +200,41 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) automorph_kernel(const AutoArgs g) {
     }
 }
 
+// out (+)= sum_s Automorphism_{k_s}(in_s), EVALUATION format: the `first += ...AutomorphismTransform(...)` and
+// `EvalAddExtInPlace(result, EvalFastRotationExt(...))` accumulations of the BSGS linear transform
+// (ckksrns-fhe.cpp:1868-1876) over all outer steps in one pass (modular addition is exact, so the order is free).
+// k_s = 1 is the identity (an outer step without rotation).
+constexpr int kMaxAutoSum = 32;
+struct AutoSumArgs {
+    uint64_t* out;
+    const uint64_t* in[kMaxAutoSum];
+    uint32_t k[kMaxAutoSum];
+    const uint64_t* q;  // [ctxLimbs]
+    uint32_t logN, nLimbs, rows, nSrc, accumulate;
+    LimbSel sel;
+};
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) automorph_sum_kernel(const AutoSumArgs g) {
+    const uint32_t t          = FHE_TID;
+    const uint64_t base       = (uint64_t)FHE_BID << kTileLog;
+    const uint64_t totalWords = (uint64_t)g.rows << g.logN;
+    const uint32_t N = 1u << g.logN, mask = N - 1u;
+#pragma unroll 2
+    for (int m = 0; m < 16; ++m) {
+        const uint64_t off = base + (uint64_t)m * kThreads + t;
+        if (off >= totalWords)
+            continue;
+        const uint64_t rowBase = off & ~(uint64_t)mask;
+        const uint32_t j       = bitrev32((uint32_t)off & mask, g.logN);
+        const uint64_t q       = g.q[g.sel.idx[(uint32_t)(off >> g.logN) % g.nLimbs]];
+        uint64_t v             = g.accumulate ? g.out[off] : 0;
+        for (uint32_t s = 0; s < g.nSrc; ++s) {
+            const uint32_t idx = (((2u * j + 1u) * g.k[s]) & (2u * N - 1u)) >> 1;
+            v                  = add_mod(v, g.in[s][rowBase + bitrev32(idx, g.logN)], q);
+        }
+        g.out[off] = v;
+    }
+}
+
 // ---- centred modulus switch of ONE source limb into every limb of a tower (a9) ----------------------
 // out[b][i][r] = SwitchModulus(src[b][r] : qSrc -> q_i)  (mubintvecnat.cpp:109-122); used by
 // DropLastElementAndScale (dcrtpoly-impl.h:703-704) and ModRaise (dcrtpoly-impl.h:87-93).

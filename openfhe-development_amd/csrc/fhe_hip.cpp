@@ -175,6 +175,26 @@ extern "C" fhe_status fhe_param_dcrt_chain(uint32_t order, uint32_t nLimbs, uint
     }
     return FHE_OK;
 }
+extern "C" uint32_t fhe_param_find_automorphism_index_2n_complex(int32_t index, uint32_t m) {
+    if (m < 4 || (m & (m - 1)))
+        return 0;  // "m should be a power of two."
+    if (index == 0)
+        return 1;
+    if (index == (int32_t)m - 1)
+        return (uint32_t)index;
+    const uint64_t mask = m - 1;
+    uint64_t g0         = 5;
+    if (index < 0) {  // 5^-1 mod 2^k by Hensel lifting (every step doubles the number of correct bits)
+        uint64_t inv = 1;
+        for (int it = 0; it < 6; ++it)
+            inv = (inv * (2 - 5 * inv)) & mask;
+        g0 = inv;
+    }
+    uint64_t g = g0;
+    for (uint32_t j = 1, n = (uint32_t)(index < 0 ? -(int64_t)index : index); j < n; ++j)
+        g = (g * g0) & mask;
+    return (uint32_t)g;
+}
 extern "C" uint32_t fhe_param_select_p(uint32_t logN, uint32_t sizeQ, const uint64_t* q, uint32_t numPartQ,
                                        uint32_t auxBits, uint64_t* p, uint64_t* psiP) {
     if (!q || !p || !psiP || numPartQ == 0 || sizeQ == 0 || auxBits < 4 || auxBits > 60)
@@ -1242,6 +1262,8 @@ struct fhe_ks_plan {
     };
     std::vector<Level*> levels;  // index sizeQl
     std::vector<void*> owned;
+    std::map<std::vector<uint64_t>, void*> bsgsTables;  // device copies of the diagonal pointer tables, by content
+    uint64_t* d_zeroRows = nullptr;                     // [sizeQ+sizeP][N] zeros: the "absent diagonal" of the BSGS transform
 };
 struct fhe_ks_key {
     fhe_ks_plan* plan;
@@ -1492,22 +1514,24 @@ static fhe_status ks_precompute_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, cons
 // accumulate: out0/out1 += result (EvalMult's `cv[0] += ab[0]; cv[1] += ab[1]`, base-leveledshe.cpp:210-211)
 // EvalFastKeySwitchCoreExt (keyswitch-hybrid.cpp:402-435): inner product of the digits in the workspace with the key, both
 // halves, result [batch][sizeQl+sizeP][N] in the extended basis
+// towOff: the `batch` towers start at tower towOff of `cin` and of every digit buffer (a slice of a larger precompute)
 static fhe_status ks_inner_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const fhe_ks_key* key, const uint64_t* cin,
-                               uint32_t batch, uint64_t* e0, uint64_t* e1, uint64_t* ws, const KsLayout& w, void* st) {
+                               uint32_t batch, uint64_t* e0, uint64_t* e1, uint64_t* ws, const KsLayout& w, void* st,
+                               uint32_t towOff = 0) {
     fhe_ctx* c            = p->ctx;
     const uint32_t sizeQl = lv->sizeQl, sizeP = p->sizeP, sizeQlP = sizeQl + sizeP;
     KsInnerArgs g;
     for (uint32_t j = 0; j < (uint32_t)kMaxDigits; ++j) {
-        g.digits[j] = j < lv->numParts ? ws + w.dig[j] : nullptr;
         g.nc[j]     = j < lv->numParts ? (uint32_t)lv->cidx[j].size() : 0u;
+        g.digits[j] = j < lv->numParts ? ws + w.dig[j] + (((size_t)towOff * g.nc[j]) << c->logN) : nullptr;
     }
-    g.c = cin, g.keyB = key->d_b, g.keyA = key->d_a;
+    g.c = cin + (((size_t)towOff * sizeQl) << c->logN), g.keyB = key->d_b, g.keyA = key->d_a;
     g.out0 = e0, g.out1 = e1;
     g.lc = c->d_lc, g.mu128 = c->d_mu128;
     g.logN = c->logN, g.batch = batch, g.sizeQl = sizeQl, g.sizeQ = p->sizeQ, g.sizeP = sizeP;
     g.numDigits = lv->numParts, g.alpha = p->alpha;
     const uint32_t tilesPerRow = c->N >= (uint32_t)kTile ? (c->N >> kTileLog) : 1u;
-    FHE_LAUNCH(ks_inner_product_kernel, (uint64_t)batch * tilesPerRow * sizeQlP, st, g);
+    FHE_LAUNCH(ks_inner_product_kernel, (((uint64_t)tilesPerRow * sizeQlP + 7) / 8) * 8 * batch, st, g);
     LAUNCH_CHECK();
     return FHE_OK;
 }
@@ -1723,49 +1747,78 @@ extern "C" fhe_status fhe_ks_down(fhe_ks_plan* p, const uint64_t* x0, const uint
 
 // ---- BSGS plaintext-matrix product with double hoisting ----
 // FHECKKSRNS::EvalLinearTransform (ckksrns-fhe.cpp:1832-1882) and one level of EvalCoeffsToSlots / EvalSlotsToCoeffs
-// (:1884-2198): inner rotations hoisted on one digit decomposition and kept in the extended basis, one fused
-// multiply-accumulate pass per outer step, one KeySwitchDown per outer step and one at the end.
-// workspace = [key-switch layout][rot: nIn x 2 x batch ext towers][inner: 2 x batch ext][outer: 2 x batch ext]
-//             [d: 2 x batch Q_l towers][first: batch Q_l towers]
+// (:1884-2198).  The reference walks the outer (giant) steps one after the other; here every stage runs ONCE over all
+// outer steps (the accumulations `first += ...` and `outer += ...` are exact modular sums, so their order is free):
+//   1. rot_j      inner rotations on one digit decomposition of c1, kept in the extended basis      (nIn launch groups)
+//   2. inner_i    all outer steps' multiply-accumulate sums in one pass over the rotated ciphertexts (1 kernel)
+//   3. d_i        KeySwitchDown of every inner_i as one batch of 2*nOut*batch towers                (INTT, conversion, NTT)
+//   4. first      sum_i Automorphism_{k_i}(d_i[0])                                                   (1 kernel)
+//   5. digits     ModUp of every rotated step's d_i[1] as one batch                                  (INTT, conversions, NTTs)
+//   6. e_i        inner product with the outer step's own key                                        (1 kernel per rotated step)
+//   7. outer      sum_i Automorphism_{k_i}(e_i)  (+ inner_i[1] of the unrotated steps)               (2 kernels)
+//   8. result     KeySwitchDown(outer), result[0] += first
+// workspace = [key-switch layout for batch*nOut towers][rot: nIn x 2 x batch ext][inner: 2 x nOut x batch ext]
+//             [d: 2 x nOut x batch Q_l][outer: 2 x batch ext][first: batch Q_l]
 struct BsgsLayout {
-    KsLayout ks;
-    size_t rot, inner, outer, d, first, total;
+    size_t ksTotal, rot, inner, d, outer, first, total;
 };
-static BsgsLayout bsgs_layout(const fhe_ks_plan* p, uint32_t sizeQl, uint32_t batch, uint32_t nIn) {
+static BsgsLayout bsgs_layout(const fhe_ks_plan* p, uint32_t sizeQl, uint32_t batch, uint32_t nIn, uint32_t nOut) {
     BsgsLayout b{};
-    b.ks             = ks_layout(p, sizeQl, batch);
+    b.ksTotal        = ks_layout(p, sizeQl, batch * nOut).total;
     const size_t N   = (size_t)1 << p->ctx->logN;
     const size_t ext = (size_t)batch * (sizeQl + p->sizeP) * N, low = (size_t)batch * sizeQl * N;
-    size_t off       = b.ks.total;
+    size_t off       = b.ksTotal;
     b.rot = off, off += (size_t)nIn * 2 * ext;
-    b.inner = off, off += 2 * ext;
+    b.inner = off, off += (size_t)nOut * 2 * ext;
+    b.d = off, off += (size_t)nOut * 2 * low;
     b.outer = off, off += 2 * ext;
-    b.d = off, off += 2 * low;
     b.first = off, off += low;
     b.total = off;
     return b;
 }
-extern "C" size_t fhe_ckks_bsgs_workspace_bytes(const fhe_ks_plan* p, uint32_t sizeQl, uint32_t batch, uint32_t nIn) {
-    if (!p || sizeQl < 1 || sizeQl > p->sizeQ || batch < 1 || nIn < 1)
+extern "C" size_t fhe_ckks_bsgs_workspace_bytes(const fhe_ks_plan* p, uint32_t sizeQl, uint32_t batch, uint32_t nIn,
+                                                uint32_t nOut) {
+    if (!p || sizeQl < 1 || sizeQl > p->sizeQ || batch < 1 || nIn < 1 || nOut < 1)
         return 0;
-    return bsgs_layout(p, sizeQl, batch, nIn).total * 8;
+    return bsgs_layout(p, sizeQl, batch, nIn, nOut).total * 8;
 }
-// KeySwitchDown of two adjacent extended towers x[2*batch] -> out0, out1 (keyswitch-hybrid.cpp:245-278)
-static fhe_status mod_down_pair(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const uint64_t* x, uint32_t batch, uint64_t* out0,
-                                uint64_t* out1, uint64_t* pcoef, uint64_t* md, void* st) {
+// KeySwitchDown of two adjacent extended towers x[2*batch] -> out0, out1 (keyswitch-hybrid.cpp:245-278); out1 == nullptr:
+// all nTow towers go to out0 (one batch of ApproxModDown calls)
+static fhe_status mod_down_many(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const uint64_t* x, uint32_t nTow, uint32_t split,
+                                uint64_t* out0, uint64_t* out1, uint64_t* pcoef, uint64_t* md, void* st) {
     fhe_ctx* c = p->ctx;
     if (ntt_epilogue_supported(c)) {
         NttEpilogue epi;
-        epi.mode = 1u, epi.split = batch, epi.aStride = lv->sizeQl + p->sizeP, epi.aFirst = 0;
-        epi.A = x, epi.C = lv->d_PInv, epi.out0 = out0, epi.out1 = out1;
-        return mod_down_core(p, lv, x, 2 * batch, pcoef, md, st, nullptr, &epi);
+        epi.mode = 1u, epi.split = split, epi.aStride = lv->sizeQl + p->sizeP, epi.aFirst = 0;
+        epi.A = x, epi.C = lv->d_PInv, epi.out0 = out0, epi.out1 = out1 ? out1 : out0;
+        return mod_down_core(p, lv, x, nTow, pcoef, md, st, nullptr, &epi);
     }
-    if (fhe_status s = mod_down_core(p, lv, x, 2 * batch, pcoef, md, st))
+    if (fhe_status s = mod_down_core(p, lv, x, nTow, pcoef, md, st))
         return s;
-    if (fhe_status s = mod_down_tail(p, lv, x, md, batch, out0, false, st))
+    if (fhe_status s = mod_down_tail(p, lv, x, md, split, out0, false, st))
         return s;
-    const size_t ext = ((size_t)batch * (lv->sizeQl + p->sizeP)) << c->logN, low = ((size_t)batch * lv->sizeQl) << c->logN;
-    return mod_down_tail(p, lv, x + ext, md + low, batch, out1, false, st);
+    if (split == nTow)
+        return FHE_OK;
+    const size_t ext = ((size_t)split * (lv->sizeQl + p->sizeP)) << c->logN, low = ((size_t)split * lv->sizeQl) << c->logN;
+    return mod_down_tail(p, lv, x + ext, md + low, nTow - split, out1, false, st);
+}
+// out (+)= sum_s Automorphism_{k_s}(in_s) over towers of `nl` limbs
+static fhe_status automorph_sum_run(fhe_ctx* c, uint64_t* out, const std::vector<const uint64_t*>& in, const std::vector<uint32_t>& k,
+                                    const uint32_t* li, uint32_t nl, uint32_t bt, void* st) {
+    for (size_t s0 = 0; s0 < in.size(); s0 += kMaxAutoSum) {
+        AutoSumArgs g;
+        if (fhe_status s = make_sel(c, li, nl, &g.sel, "automorphism"))
+            return s;
+        g.nSrc = (uint32_t)std::min<size_t>(kMaxAutoSum, in.size() - s0);
+        for (uint32_t s = 0; s < (uint32_t)kMaxAutoSum; ++s) {
+            g.in[s] = s < g.nSrc ? in[s0 + s] : nullptr;
+            g.k[s]  = s < g.nSrc ? k[s0 + s] : 1u;
+        }
+        g.out = out, g.q = c->d_q, g.logN = c->logN, g.nLimbs = nl, g.rows = bt * nl, g.accumulate = s0 ? 1u : 0u;
+        FHE_LAUNCH(automorph_sum_kernel, tiles_for(c, g.rows), st, g);
+        LAUNCH_CHECK();
+    }
+    return FHE_OK;
 }
 extern "C" fhe_status fhe_ckks_bsgs_transform(fhe_ks_plan* p, const uint64_t* c0, const uint64_t* c1, uint32_t sizeQl,
                                               uint32_t batch, uint32_t nIn, const uint32_t* inK,
@@ -1775,7 +1828,7 @@ extern "C" fhe_status fhe_ckks_bsgs_transform(fhe_ks_plan* p, const uint64_t* c0
     ARG_CHECK(p && c0 && c1 && inK && outK && diag && out0 && out1 && wsv, "fhe_ckks_bsgs_transform: null argument");
     ARG_CHECK(sizeQl >= 1 && sizeQl <= p->sizeQ && batch >= 1, "fhe_ckks_bsgs_transform: bad level or batch");
     ARG_CHECK(nIn >= 1 && nOut >= 1, "fhe_ckks_bsgs_transform: needs at least one inner and one outer step");
-    const BsgsLayout L = bsgs_layout(p, sizeQl, batch, nIn);
+    const BsgsLayout L = bsgs_layout(p, sizeQl, batch, nIn, nOut);
     ARG_CHECK(wsBytes >= L.total * 8, "fhe_ckks_bsgs_transform: workspace too small");
     for (uint32_t j = 0; j < nIn; ++j) {
         ARG_CHECK(inK[j] == 0 || inK[j] % 2 == 1, "Automorphism index not odd");
@@ -1790,7 +1843,6 @@ extern "C" fhe_status fhe_ckks_bsgs_transform(fhe_ks_plan* p, const uint64_t* c0
     fhe_ks_plan::Level* lv = nullptr;
     if (fhe_status s = ks_level(p, sizeQl, &lv))
         return s;
-    const KsLayout& w      = L.ks;
     uint64_t* ws           = (uint64_t*)wsv;
     const uint32_t sizeQlP = sizeQl + p->sizeP;
     const size_t ext = ((size_t)batch * sizeQlP) << c->logN, low = ((size_t)batch * sizeQl) << c->logN;
@@ -1800,9 +1852,47 @@ extern "C" fhe_status fhe_ckks_bsgs_transform(fhe_ks_plan* p, const uint64_t* c0
     TwPair* dP = nullptr;
     if (fhe_status s = ks_pmodq(p, lv, &dP))
         return s;
+    // outer steps without a rotation first, the rotated ones behind them (slices of one batch from stage 3 on)
+    std::vector<uint32_t> perm;
+    for (uint32_t i = 0; i < nOut; ++i)
+        if (outK[i] == 0)
+            perm.push_back(i);
+    const uint32_t nZ = (uint32_t)perm.size(), nR = nOut - nZ;
+    for (uint32_t i = 0; i < nOut; ++i)
+        if (outK[i] != 0)
+            perm.push_back(i);
+    // the diagonals' pointer table on the device: outer steps permuted, rows padded to the kernel's unroll width, absent
+    // terms and padding pointing at rows of zeros (cached by content: the same transform is applied many times)
+    const uint32_t ninK   = nIn <= 4 ? 4u : nIn <= 8 ? 8u : (uint32_t)kMaxBsgsIn;  // kernel instance (NIN)
+    const uint32_t nInPad = (nIn + ninK - 1) / ninK * ninK;
+    if (!p->d_zeroRows) {
+        void* dz = nullptr;
+        const size_t bytes = ((size_t)(p->sizeQ + p->sizeP) << c->logN) * 8;
+        RT_CHECK(rt::dmalloc(&dz, bytes));
+        p->owned.push_back(dz);
+        RT_CHECK(rt::dzero_2d(dz, bytes, bytes, 1, nullptr));
+        RT_CHECK(rt::sync(nullptr));
+        p->d_zeroRows = (uint64_t*)dz;
+    }
+    std::vector<uint64_t> tab((size_t)nOut * nInPad, (uint64_t)(uintptr_t)p->d_zeroRows);
+    for (uint32_t i = 0; i < nOut; ++i)
+        for (uint32_t j = 0; j < nIn; ++j)
+            if (diag[(size_t)perm[i] * nIn + j])
+                tab[(size_t)i * nInPad + j] = (uint64_t)(uintptr_t)diag[(size_t)perm[i] * nIn + j];
+    auto it = p->bsgsTables.find(tab);
+    if (it == p->bsgsTables.end()) {
+        void* dp = nullptr;
+        RT_CHECK(rt::dmalloc(&dp, tab.size() * 8));
+        p->owned.push_back(dp);
+        RT_CHECK(rt::h2d(dp, tab.data(), tab.size() * 8, nullptr));
+        RT_CHECK(rt::sync(nullptr));
+        it = p->bsgsTables.emplace(tab, dp).first;
+    }
+    const uint64_t* const* dTab = (const uint64_t* const*)it->second;
 
-    // inner (baby-step) rotations: one digit decomposition of c1 serves all of them (EvalFastRotationPrecompute, :1842)
-    bool digitsReady = false;
+    // 1. inner (baby-step) rotations: one digit decomposition of c1 serves all of them (EvalFastRotationPrecompute, :1842)
+    const KsLayout wB = ks_layout(p, sizeQl, batch);
+    bool digitsReady  = false;
     for (uint32_t j = 0; j < nIn; ++j) {
         uint64_t* rj = rot + (size_t)j * 2 * ext;
         if (inK[j] == 0) {  // KeySwitchExt(ct, true)
@@ -1813,87 +1903,83 @@ extern "C" fhe_status fhe_ckks_bsgs_transform(fhe_ks_plan* p, const uint64_t* c0
             continue;
         }
         if (!digitsReady) {
-            if (fhe_status s = ks_precompute_run(p, lv, c1, batch, ws, w, st))
+            if (fhe_status s = ks_precompute_run(p, lv, c1, batch, ws, wB, st))
                 return s;
             digitsReady = true;
         }
         // EvalFastRotationExt(ct, index, digits, addFirst = true): e0, e1 are adjacent in the key-switch workspace
-        if (fhe_status s = ks_inner_run(p, lv, inKeys[j], c1, batch, ws + w.e0, ws + w.e1, ws, w, st))
+        if (fhe_status s = ks_inner_run(p, lv, inKeys[j], c1, batch, ws + wB.e0, ws + wB.e1, ws, wB, st))
             return s;
-        if (fhe_status s = elem_run<OP_MUL_CONST_ADD>(c, ws + w.e0, c0, ws + w.e0, dP, nullptr, sizeQl, batch, st,
+        if (fhe_status s = elem_run<OP_MUL_CONST_ADD>(c, ws + wB.e0, c0, ws + wB.e0, dP, nullptr, sizeQl, batch, st,
                                                       "fhe_ckks_bsgs_transform", 0, 0, sizeQlP, 0, sizeQlP, 0))
             return s;
-        if (fhe_status s = automorph_eval_run(c, rj, ws + w.e0, inK[j], extIdx.data(), sizeQlP, 2 * batch, false, st))
+        if (fhe_status s = automorph_eval_run(c, rj, ws + wB.e0, inK[j], extIdx.data(), sizeQlP, 2 * batch, false, st))
             return s;
     }
-
-    bool firstSet = false, outer0Set = false, outer1Set = false;
-    for (uint32_t i = 0; i < nOut; ++i) {
-        // inner_i = sum_j rot_j * diag[i][j]
-        bool any = false;
-        for (uint32_t j0 = 0; j0 < nIn; j0 += kMaxBsgsIn) {
-            BsgsInnerArgs g;
-            const uint32_t n = std::min<uint32_t>(kMaxBsgsIn, nIn - j0);
-            bool chunkAny    = false;
-            for (uint32_t j = 0; j < (uint32_t)kMaxBsgsIn; ++j) {
-                g.diag[j] = j < n ? diag[(size_t)i * nIn + j0 + j] : nullptr;
-                chunkAny |= g.diag[j] != nullptr;
-            }
-            if (!chunkAny && (any || j0 + n < nIn))
-                continue;  // nothing to add (an all-absent outer step still produces a zero `inner` in its last chunk)
-            g.rot = rot + (size_t)j0 * 2 * ext, g.out = inner, g.lc = c->d_lc, g.mu128 = c->d_mu128;
-            g.logN = c->logN, g.batch = batch, g.sizeQl = sizeQl, g.sizeQ = p->sizeQ, g.sizeP = p->sizeP, g.nIn = n;
-            g.accumulate = any ? 1u : 0u;
-            const uint32_t tilesPerRow = c->N >= (uint32_t)kTile ? (c->N >> kTileLog) : 1u;
-            FHE_LAUNCH(bsgs_inner_kernel, (uint64_t)2 * batch * tilesPerRow * sizeQlP, st, g);
-            LAUNCH_CHECK();
-            any = true;
-        }
-        if (outK[i] == 0) {
-            // first += KeySwitchDownFirstElement(inner); outer[1] += inner[1]  (:1861-1866, 1976-1979)
-            if (fhe_status s = mod_down_run(p, lv, inner, batch, firstSet ? d : first, ws + w.pcoef, ws + w.md, st))
-                return s;
-            if (firstSet)
-                if (fhe_status s = elem_run<OP_ADD>(c, first, first, d, nullptr, nullptr, sizeQl, batch, st, "fhe_ckks_bsgs_transform"))
-                    return s;
-            firstSet = true;
-            if (outer1Set) {
-                if (fhe_status s = elem_run<OP_ADD>(c, outer + ext, outer + ext, inner + ext, nullptr, extIdx.data(), sizeQlP, batch,
-                                                    st, "fhe_ckks_bsgs_transform"))
-                    return s;
-            }
-            else
-                RT_CHECK(rt::d2d(outer + ext, inner + ext, ext * 8, (rt::stream_t)st));
-            outer1Set = true;
-            continue;
-        }
-        // inner = KeySwitchDown(inner); first += Automorphism(inner[0]); outer += EvalFastRotationExt(inner, index,
-        // digits(inner), addFirst = false)  (:1868-1876)
-        if (fhe_status s = mod_down_pair(p, lv, inner, batch, d, d + low, ws + w.pcoef, ws + w.md, st))
-            return s;
-        if (fhe_status s = automorph_eval_run(c, first, d, outK[i], nullptr, sizeQl, batch, firstSet, st))
-            return s;
-        firstSet = true;
-        if (fhe_status s = ks_precompute_run(p, lv, d + low, batch, ws, w, st))
-            return s;
-        if (fhe_status s = ks_inner_run(p, lv, outKeys[i], d + low, batch, ws + w.e0, ws + w.e1, ws, w, st))
-            return s;
-        if (outer0Set == outer1Set) {
-            if (fhe_status s = automorph_eval_run(c, outer, ws + w.e0, outK[i], extIdx.data(), sizeQlP, 2 * batch, outer0Set, st))
-                return s;
-        }
-        else {
-            if (fhe_status s = automorph_eval_run(c, outer, ws + w.e0, outK[i], extIdx.data(), sizeQlP, batch, outer0Set, st))
-                return s;
-            if (fhe_status s = automorph_eval_run(c, outer + ext, ws + w.e1, outK[i], extIdx.data(), sizeQlP, batch, outer1Set, st))
-                return s;
-        }
-        outer0Set = outer1Set = true;
+    // 2. inner_i = sum_j rot_j * diag[i][j] for every outer step: inner is [2][nOut][batch] extended towers
+    for (uint32_t j0 = 0; j0 < nIn; j0 += ninK) {
+        BsgsInnerArgs g;
+        g.nIn = std::min<uint32_t>(ninK, nIn - j0), g.nInPad = nInPad, g.j0 = j0, g.nOut = nOut;
+        g.rot = rot + (size_t)j0 * 2 * ext, g.diag = dTab, g.out = inner, g.lc = c->d_lc, g.mu128 = c->d_mu128;
+        g.logN = c->logN, g.batch = batch, g.sizeQl = sizeQl, g.sizeQ = p->sizeQ, g.sizeP = p->sizeP;
+        g.accumulate = j0 ? 1u : 0u;
+        const uint32_t tilesPerRow = c->N >= (uint32_t)kTile ? (c->N >> kTileLog) : 1u;
+        const uint64_t nGroups = (uint64_t)sizeQlP * tilesPerRow, grid = ((nGroups + 7) / 8) * 8 * 2 * batch;
+        static const uint32_t cpl = env_u32("FHE_BSGS_CPL", 2);  // coefficients per lane of the 4- and 8-term instances
+        if (ninK == 4 && cpl == 2 && c->N >= 2)
+            FHE_LAUNCH((bsgs_inner_kernel<4, 2>), grid, st, g);
+        else if (ninK == 4)
+            FHE_LAUNCH((bsgs_inner_kernel<4, 1>), grid, st, g);
+        else if (ninK == 8 && cpl == 2 && c->N >= 2)
+            FHE_LAUNCH((bsgs_inner_kernel<8, 2>), grid, st, g);
+        else if (ninK == 8)
+            FHE_LAUNCH((bsgs_inner_kernel<8, 1>), grid, st, g);
+        else
+            FHE_LAUNCH((bsgs_inner_kernel<16, 1>), grid, st, g);
+        LAUNCH_CHECK();
     }
-    if (!outer0Set)
+    // 3. KeySwitchDown of every inner_i (KeySwitchDownFirstElement for the unrotated steps: their second element is only
+    //    needed in the extended basis): element-0 towers of all steps, and element-1 towers when any step is rotated
+    const KsLayout wM   = ks_layout(p, sizeQl, batch * nOut);
+    const uint32_t nTow = (nR ? 2u : 1u) * nOut * batch;
+    if (fhe_status s = mod_down_many(p, lv, inner, nTow, nTow, d, nullptr, ws + wM.pcoef, ws + wM.md, st))
+        return s;
+    // 4. first = sum_i Automorphism_{k_i}(d_i[0])      (:1861, 1873, 1976)
+    {
+        std::vector<const uint64_t*> src(nOut);
+        std::vector<uint32_t> ks(nOut);
+        for (uint32_t i = 0; i < nOut; ++i)
+            src[i] = d + (size_t)i * low, ks[i] = outK[perm[i]] ? outK[perm[i]] : 1u;
+        if (fhe_status s = automorph_sum_run(c, first, src, ks, nullptr, sizeQl, batch, st))
+            return s;
+    }
+    // 5.-7. outer = sum over the rotated steps of EvalFastRotationExt(d_i, k_i, digits(d_i[1]), addFirst = false)
+    //       (+ inner_i[1] of the unrotated steps in the second element)           (:1875-1876, 1863-1866, 1977-1979)
+    std::vector<const uint64_t*> src0, src1;
+    std::vector<uint32_t> k0, k1;
+    for (uint32_t i = 0; i < nZ; ++i)
+        src1.push_back(inner + (size_t)(nOut + i) * ext), k1.push_back(1u);
+    if (nR) {
+        const KsLayout wR  = ks_layout(p, sizeQl, batch * nR);
+        const uint64_t* dR = d + (size_t)(nOut + nZ) * low;  // second elements of the rotated steps: nR*batch towers
+        if (fhe_status s = ks_precompute_run(p, lv, dR, batch * nR, ws, wR, st))
+            return s;
+        for (uint32_t i = 0; i < nR; ++i) {
+            uint64_t *e0 = ws + wR.e0 + (size_t)i * ext, *e1 = ws + wR.e1 + (size_t)i * ext;
+            if (fhe_status s = ks_inner_run(p, lv, outKeys[perm[nZ + i]], dR, batch, e0, e1, ws, wR, st, i * batch))
+                return s;
+            src0.push_back(e0), src1.push_back(e1);
+            k0.push_back(outK[perm[nZ + i]]), k1.push_back(outK[perm[nZ + i]]);
+        }
+        if (fhe_status s = automorph_sum_run(c, outer, src0, k0, extIdx.data(), sizeQlP, batch, st))
+            return s;
+    }
+    else
         RT_CHECK(rt::dzero_2d(outer, ext * 8, ext * 8, 1, (rt::stream_t)st));
-    // result = KeySwitchDown(outer); result[0] += first  (:1879-1880)
-    if (fhe_status s = mod_down_pair(p, lv, outer, batch, out0, out1, ws + w.pcoef, ws + w.md, st))
+    if (fhe_status s = automorph_sum_run(c, outer + ext, src1, k1, extIdx.data(), sizeQlP, batch, st))
+        return s;
+    // 8. result = KeySwitchDown(outer); result[0] += first  (:1879-1880)
+    if (fhe_status s = mod_down_many(p, lv, outer, 2 * batch, batch, out0, out1, ws + wB.pcoef, ws + wB.md, st))
         return s;
     return elem_run<OP_ADD>(c, out0, out0, first, nullptr, nullptr, sizeQl, batch, st, "fhe_ckks_bsgs_transform");
 }

@@ -170,6 +170,44 @@ FHE_HD void mac192_fold(const mac192& m, uint64_t& lo, uint64_t& hi) {
     hi = m.c2 + c1hi + (uint64_t)m.k0 + (lo < c1lo);
 }
 
+// ---- sums of at most 8 products of residues below 2^60 (the reference's MAX_MODULUS_SIZE; fhe_ctx_create enforces it) ----
+// With x = xh*2^32 + xl, y = yh*2^32 + yl: xl*yh, xh*yl < 2^60 and xh*yh < 2^56, so the 16 middle products and the 8 high
+// products of a chunk accumulate in plain 64-bit words; only the low column needs a carry count (7 instructions per term).
+struct sum8 {
+    uint64_t c0, c1, c2;
+    uint32_t k0;
+};
+FHE_HD void sum8_clear(sum8& s) {
+    s.c0 = s.c1 = s.c2 = 0;
+    s.k0 = 0;
+}
+FHE_HD void sum8_add(sum8& s, uint64_t x, uint64_t y) {
+    const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32), yl = (uint32_t)y, yh = (uint32_t)(y >> 32);
+    const uint64_t lo = (uint64_t)xl * yl + s.c0;
+    s.k0 += lo < s.c0;
+    s.c0 = lo;
+    s.c1 += (uint64_t)xl * yh;
+    s.c1 += (uint64_t)xh * yl;
+    s.c2 += (uint64_t)xh * yh;
+}
+// The exact residue of the sum S (<= 8 products of residues of q, so S < 8*q^2 < 2^(2k+3), k = bit length of q <= 60):
+//   s    = floor(S / 2^(k-1)) < 2^(k+4) <= 2^64,   mu' = floor(2^(k+63) / q) = floor(mu128 / 2^(65-k)) < 2^64
+//   qhat = floor(s * mu' / 2^64):  S/q - 3 < qhat <= S/q   (one unit each from the two floors inside and the one outside)
+//   r    = S - qhat*q in [0, 3q), 3q < 2^62: the low words suffice; two conditional subtractions make it canonical.
+// Any exact reduction equals the reference's ModMul / ModAdd chain (mubintvecnat.cpp:229-339) and its
+// BarrettUint128ModUint64 (utils/utilities-int.h:60-99).
+FHE_HD uint64_t sum8_reduce(const sum8& s, uint64_t q, uint32_t k, uint64_t mu_lo, uint64_t mu_hi) {
+    const uint64_t m = s.c1 << 32, lo = s.c0 + m;
+    const uint64_t hi = s.c2 + (s.c1 >> 32) + s.k0 + (lo < m);
+    const uint32_t sh = 65u - k;  // 5..61 (k = 60..4)
+    const uint64_t mu = (mu_lo >> sh) | (mu_hi << (64u - sh));
+    const uint64_t sv = (lo >> (k - 1u)) | (hi << sh);
+    uint64_t r        = lo - mulhi64(sv, mu) * q;
+    r -= r >= q ? q : 0;
+    r -= r >= q ? q : 0;
+    return r;
+}
+
 // a (128-bit) mod q with mu = floor(2^128/q) given as (mu_lo, mu_hi).
 // Same quotient estimate as BarrettUint128ModUint64 (utils/utilities-int.h:60-99): the low word of
 // floor(a*mu / 2^128), then r = a_lo - quot*q and final corrective subtractions.

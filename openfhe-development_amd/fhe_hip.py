@@ -110,7 +110,7 @@ class Lib:
         S("fhe_ks_fast_keyswitch_ext", C.c_int, [vp, vp, vp, u32, u32, vp, vp, vp, C.c_size_t, vp])
         S("fhe_eval_fast_rotation_ext", C.c_int, [vp, vp, vp, vp, u32, C.c_int, u32, u32, vp, vp, vp, C.c_size_t, vp])
         S("fhe_ks_down", C.c_int, [vp, vp, vp, u32, u32, vp, vp, vp, C.c_size_t, vp])
-        S("fhe_ckks_bsgs_workspace_bytes", C.c_size_t, [vp, u32, u32, u32])
+        S("fhe_ckks_bsgs_workspace_bytes", C.c_size_t, [vp, u32, u32, u32, u32])
         S("fhe_ckks_bsgs_transform", C.c_int, [vp, vp, vp, u32, u32, u32, vp, vp, u32, vp, vp, vp, vp, vp, vp, C.c_size_t, vp])
         S("fhe_approx_mod_down", C.c_int, [vp, vp, u32, u32, vp, vp, C.c_size_t, vp])
         S("fhe_approx_mod_down_bgv", C.c_int, [vp, vp, u32, u64, u32, vp, vp, C.c_size_t, vp])
@@ -142,6 +142,7 @@ class Lib:
         S("fhe_param_root_of_unity", u64, [u64, u64])
         S("fhe_param_dcrt_chain", C.c_int, [u32, u32, u32, u64p, u64p])
         S("fhe_param_select_p", u32, [u32, u32, u64p, u32, u32, u64p, u64p])
+        S("fhe_param_find_automorphism_index_2n_complex", u32, [C.c_int32, u32])
         S("fhe_time_ntt", C.c_int, [vp, vp, u32p, u32, u32, C.c_int, C.c_int, vp, C.POINTER(C.c_float)])
 
     def check(self, status):
@@ -182,6 +183,13 @@ class Lib:
         if n == 0:
             raise FheError("fhe_param_behz_bsk failed")
         return bsk, psi
+
+    def find_automorphism_index(self, index, m):
+        """FindAutomorphismIndex2nComplex (nbtheory2.cpp:243-262)"""
+        k = self.L.fhe_param_find_automorphism_index_2n_complex(index, m)
+        if k == 0:
+            raise FheError("m should be a power of two.")
+        return k
 
     def select_p(self, logN, q, numPartQ, aux_bits=60):
         q = np.ascontiguousarray(q, dtype=np.uint64)
@@ -501,7 +509,7 @@ class KeySwitchPlan:
         dp = (vp * (nIn * nOut))(*[diag[i][j] for i in range(nOut) for j in range(nIn)])
         own = ws is None
         if own:
-            wsb = L.fhe_ckks_bsgs_workspace_bytes(self.h, c0.n_limbs, c0.batch, nIn)
+            wsb = L.fhe_ckks_bsgs_workspace_bytes(self.h, c0.n_limbs, c0.batch, nIn, nOut)
             ws = (self.ctx.malloc(wsb), wsb)
         o0, o1 = out if out is not None else (c0.like(), c0.like())
         self.ctx.lib.check(L.fhe_ckks_bsgs_transform(self.h, c0.ptr, c1.ptr, c0.n_limbs, c0.batch, nIn, inK, inH, nOut, outK,

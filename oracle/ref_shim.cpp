@@ -613,6 +613,18 @@ int ref_ckks_eval_linear_transform(void* h, void* l, int ct) {
     s->cts.push_back(fhe_of(s->cc)->EvalLinearTransform(lt->A, c));
     return static_cast<int>(s->cts.size()) - 1;
 }
+double ref_ckks_time_linear_transform(void* h, void* l, int ct, int reps) {
+    auto* s  = static_cast<RefCkks*>(h);
+    auto* lt = static_cast<RefLt*>(l);
+    ConstCiphertext<DCRTPoly> c = s->cts[ct];
+    auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps; ++r) {
+        auto out = fhe_of(s->cc)->EvalLinearTransform(lt->A, c);
+        (void)out;
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double>(t1 - t0).count() / reps;
+}
 // an encryption with `slots` packed values (sparse packing when slots < N/2)
 int ref_ckks_encrypt_slots(void* h, const double* vals /*[slots] (re, im)*/, uint32_t level, uint32_t slots) {
     auto* s = static_cast<RefCkks*>(h);

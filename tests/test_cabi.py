@@ -73,3 +73,8 @@ def test_host_parameter_helpers_match_oracle(oracle):
     P, PP = np.zeros(64, np.uint64), np.zeros(64, np.uint64)
     n = oracle.orc_hybrid_select_p(4096, 7, q, 3, 60, P, PP)
     assert n == len(p) and np.array_equal(P[:n], p) and np.array_equal(PP[:n], pp)
+    for m in (8, 1 << 13, 1 << 17):  # FindAutomorphismIndex2nComplex (the oracle's is pinned on the reference's)
+        for index in (0, 1, -1, 2, 7, -13, 100, m - 1):
+            assert L.find_automorphism_index(index, m) == oracle.orc_find_automorphism_index_2n_complex(index, m)
+    with pytest.raises(fh.FheError, match="power of two"):
+        L.find_automorphism_index(3, 24)
