@@ -644,6 +644,60 @@ void ref_ckks_decrypt_complex(void* h, int ct, double* out, uint32_t n) {
     for (uint32_t i = 0; i < n && i < v.size(); ++i)
         out[2 * i] = v[i].real(), out[2 * i + 1] = v[i].imag();
 }
+
+// ---- EvalCoeffsToSlots (the multi-level, FFT-like linear transform of bootstrapping) on the reference itself ----
+namespace {
+struct RefC2S {
+    std::vector<std::vector<ReadOnlyPlaintext>> A;
+    ckks_boot_params p;
+};
+}  // namespace
+// level budget `budget` for encoding; plaintexts via EvalCoeffsToSlotsPrecompute with the roots-of-unity tables that
+// EvalBootstrapSetup builds for it (ckksrns-fhe.cpp:144-166); L as in that function (Q limbs left after the transform)
+void* ref_ckks_c2s_create(void* h, uint32_t slots, uint32_t budget, uint32_t L) {
+    auto* s = static_cast<RefCkks*>(h);
+    s->cc->Enable(ADVANCEDSHE);
+    s->cc->Enable(FHE);
+    s->cc->EvalBootstrapSetup({budget, budget}, {0, 0}, slots, 0, false);
+    const uint32_t m = 4 * slots;
+    std::vector<uint32_t> rotGroup(slots);
+    uint32_t fivePows = 1;
+    for (uint32_t i = 0; i < slots; ++i) {
+        rotGroup[i] = fivePows;
+        fivePows    = (fivePows * 5) & (m - 1);
+    }
+    std::vector<std::complex<double>> ksiPows(m + 1);
+    for (uint32_t j = 0; j < m; ++j)
+        ksiPows[j] = {std::cos(2 * M_PI * j / m), std::sin(2 * M_PI * j / m)};
+    ksiPows[m] = ksiPows[0];
+    auto* c = new RefC2S;
+    c->A    = fhe_of(s->cc)->EvalCoeffsToSlotsPrecompute(*s->cc, ksiPows, rotGroup, false, 1.0, L, false);
+    c->p    = GetCollapsedFFTParams(slots, budget, 0);
+    return c;
+}
+void ref_ckks_c2s_destroy(void* c) { delete static_cast<RefC2S*>(c); }
+void ref_ckks_c2s_params(void* c, uint32_t* out /*[9]*/) {
+    const auto& p = static_cast<RefC2S*>(c)->p;
+    const uint32_t v[9] = {p.lvlb, p.layersCollapse, p.remCollapse, p.numRotations, p.b, p.g, p.numRotationsRem, p.bRem, p.gRem};
+    std::copy(v, v + 9, out);
+}
+// plaintext A[s][idx] as [limbs][N] EVALUATION residues; returns its number of limbs, 0 if the slot is empty
+uint32_t ref_ckks_c2s_get_diag(void* c, uint32_t s, uint32_t idx, uint64_t* out) {
+    auto& A = static_cast<RefC2S*>(c)->A;
+    if (s >= A.size() || idx >= A[s].size() || !A[s][idx])
+        return 0;
+    auto pt = A[s][idx]->GetElement<DCRTPoly>();
+    pt.SetFormat(Format::EVALUATION);
+    if (out)
+        export_poly(pt, out);
+    return pt.GetNumOfElements();
+}
+int ref_ckks_eval_coeffs_to_slots(void* h, void* c, int ct) {
+    auto* s = static_cast<RefCkks*>(h);
+    ConstCiphertext<DCRTPoly> x = s->cts[ct];
+    s->cts.push_back(fhe_of(s->cc)->EvalCoeffsToSlots(static_cast<RefC2S*>(c)->A, x));
+    return static_cast<int>(s->cts.size()) - 1;
+}
 int ref_omp_threads() { return OpenFHEParallelControls.GetNumThreads(); }
 
 // ---- ScaleAndRound family with caller tables ----

@@ -196,6 +196,11 @@ def load_ref():
     S("ref_ckks_lt_get_diag", u32, [vp, u32, C.c_void_p])
     S("ref_ckks_eval_linear_transform", C.c_int, [vp, vp, C.c_int])
     S("ref_ckks_time_linear_transform", C.c_double, [vp, vp, C.c_int, C.c_int])
+    S("ref_ckks_c2s_create", vp, [vp, u32, u32, u32])
+    S("ref_ckks_c2s_destroy", None, [vp])
+    S("ref_ckks_c2s_params", None, [vp, P32])
+    S("ref_ckks_c2s_get_diag", u32, [vp, u32, u32, C.c_void_p])
+    S("ref_ckks_eval_coeffs_to_slots", C.c_int, [vp, vp, C.c_int])
     S("ref_ckks_encrypt_slots", C.c_int, [vp, PF64, u32, u32])
     S("ref_ckks_decrypt_complex", None, [vp, C.c_int, PF64, u32])
     S("ref_approx_mod_down", None, [u32, u32, P64, P64, u32, P64, P64, P64, P64, P64, P64, u64, P64])

@@ -600,3 +600,122 @@ def test_linear_transform_against_live_reference(oracle, ref, ring, depth, dnum,
     o.orc_hybrid_destroy(hy)
     r.ref_ckks_lt_destroy(lt)
     r.ref_ckks_destroy(h)
+
+
+def c2s_levels(P, slots, N):
+    """Rotation plan of FHECKKSRNS::EvalCoeffsToSlots (ckksrns-fhe.cpp:1884-1925), level by level in evaluation order:
+    [(s, inner rotation indices, outer rotation indices, {(i, j): index into A[s]} )]"""
+    lvlb, layers, rem, numRot, b, g, numRotRem, bRem, gRem = P
+    M4 = N // 2
+    flagRem = 1 if rem else 0
+    stop = 0 if rem else -1
+    out = []
+    offset = (numRot + 1) // 2 - 1
+    for s in range(lvlb - 1, stop, -1):
+        scale = 1 << ((s - flagRem) * layers + rem)
+        rot_out = [(scale * g * i) % M4 for i in range(b)]
+        rot_in = [(scale * (j - offset)) % slots for j in range(g)]
+        terms = {(i, j): g * i + j for i in range(b) for j in range(g) if g * i + j != numRot}
+        out.append((s, rot_in, rot_out, terms))
+    if flagRem:
+        offset = (numRotRem + 1) // 2 - 1
+        rot_out = [(gRem * i) % M4 for i in range(bRem)]
+        rot_in = [(j - offset) % slots for j in range(gRem)]
+        terms = {(i, j): gRem * i + j for i in range(bRem) for j in range(gRem) if gRem * i + j != numRotRem}
+        out.append((0, rot_in, rot_out, terms))
+    return out
+
+
+def ref_coeffs_to_slots_session(r, ring, depth, dnum, budget, level=0, seed=21):
+    """The reference's own EvalCoeffsToSlots (fully packed) with its own keys and plaintexts; everything exported."""
+    h = r.ref_ckks_create(ring, depth, 45, 55, dnum, 0)
+    info = np.zeros(5, np.uint32)
+    r.ref_ckks_info(h, info)
+    N, sizeQ, sizeP, numPartQ, alpha = map(int, info)
+    slots = N // 2
+    q, psiQ = np.zeros(sizeQ, np.uint64), np.zeros(sizeQ, np.uint64)
+    p, psiP = np.zeros(sizeP, np.uint64), np.zeros(sizeP, np.uint64)
+    r.ref_ckks_get_moduli(h, q, psiQ, p, psiP)
+    rng = np.random.default_rng(seed)
+    vals = np.zeros((slots, 2))
+    vals[:, 0] = rng.uniform(-1, 1, slots)
+    ct = r.ref_ckks_encrypt_slots(h, vals, level, slots)
+    ci = np.zeros(4, np.uint32)
+    r.ref_ct_info(h, ct, ci)
+    sizeQl = int(ci[1])
+    c2s = r.ref_ckks_c2s_create(h, slots, budget, sizeQl - budget)  # L + lvlb limbs at the first level = the ciphertext's
+    P = np.zeros(9, np.uint32)
+    r.ref_ckks_c2s_params(c2s, P)
+    levels = c2s_levels([int(v) for v in P], slots, N)
+    rots = sorted({x for _, ri, ro, _ in levels for x in ri + ro if x})
+    idx = np.array(rots, np.int32)
+    r.ref_ckks_rotate_keygen(h, idx, len(idx))
+    keys = {}
+    for index in rots:
+        keyB = np.zeros((numPartQ, sizeQ + sizeP, N), np.uint64)
+        keyA = keyB.copy()
+        keys[index] = (r.ref_ckks_get_rot_key(h, index, keyB, keyA), keyB, keyA)
+    diags = []
+    for n, (s, ri, ro, terms) in enumerate(levels):
+        limbs = sizeQl - n + sizeP
+        d = {}
+        for (i, j), a in terms.items():
+            rows = np.zeros((limbs, N), np.uint64)
+            assert r.ref_ckks_c2s_get_diag(c2s, s, a, rows.ctypes.data) == limbs
+            d[(i, j)] = rows
+        diags.append(d)
+    res = r.ref_ckks_eval_coeffs_to_slots(h, c2s, ct)
+    r.ref_ct_info(h, res, ci)
+    outQl = int(ci[1])
+    assert outQl == sizeQl - (len(levels) - 1)
+
+    def ex(c, e, nl):
+        a = np.zeros((nl, N), np.uint64)
+        r.ref_ct_export(h, c, e, a)
+        return a
+    S = dict(N=N, q=q, psiQ=psiQ, p=p, psiP=psiP, numPartQ=numPartQ, sizeQl=sizeQl, levels=levels, keys=keys, diags=diags,
+             c=np.stack([ex(ct, 0, sizeQl), ex(ct, 1, sizeQl)]), out=np.stack([ex(res, 0, outQl), ex(res, 1, outQl)]))
+    r.ref_ckks_c2s_destroy(c2s)
+    return h, S
+
+
+def c2s_level_arguments(S, n):
+    """orc_ckks_bsgs_transform / fhe_ckks_bsgs_transform arguments of level n of the session"""
+    s, rot_in, rot_out, terms = S["levels"][n]
+    keys = S["keys"]
+
+    def side(rots):
+        return (np.array([keys[x][0] if x else 0 for x in rots], np.uint32), [keys[x][1] if x else None for x in rots],
+                [keys[x][2] if x else None for x in rots])
+    inK, inB, inA = side(rot_in)
+    outK, outB, outA = side(rot_out)
+    diag = [S["diags"][n].get((i, j)) for i in range(len(rot_out)) for j in range(len(rot_in))]
+    return inK, inB, inA, outK, outB, outA, diag
+
+
+@pytest.mark.parametrize("ring,depth,dnum,budget", [(64, 4, 2, 2), (128, 5, 3, 3), (32, 3, 2, 1)])
+def test_coeffs_to_slots_against_live_reference(oracle, ref, ring, depth, dnum, budget):
+    """FHECKKSRNS::EvalCoeffsToSlots (collapsed-FFT levels, each a BSGS transform with double hoisting, a rescale between
+    them) run by the reference vs the oracle: one orc_ckks_bsgs_transform per level + DropLastElementAndScale"""
+    o, r = oracle, ref
+    h, S = ref_coeffs_to_slots_session(r, ring, depth, dnum, budget)
+    N, q = S["N"], S["q"]
+    hy = o.orc_hybrid_create(N, len(q), q, S["psiQ"], len(S["p"]), S["p"], S["psiP"], S["numPartQ"])
+    octx = o.orc_ctx_create(N, len(q), q, S["psiQ"])
+    c, sizeQl = S["c"], S["sizeQl"]
+    for n in range(len(S["levels"])):
+        if n:  # ModReduceInternalInPlace between the levels (ckksrns-fhe.cpp:1936-1937)
+            nxt = np.zeros((2, sizeQl - 1, N), np.uint64)
+            for e in range(2):
+                o.orc_drop_last_element_and_scale(octx, np.ascontiguousarray(c[e]), sizeQl, nxt[e])
+            c, sizeQl = nxt, sizeQl - 1
+        inK, inB, inA, outK, outB, outA, diag = c2s_level_arguments(S, n)
+        out = np.zeros_like(c)
+        o.orc_ckks_bsgs_transform(hy, np.ascontiguousarray(c[0]), np.ascontiguousarray(c[1]), sizeQl, len(inK), inK,
+                                  libs.ptr_array(inB), libs.ptr_array(inA), len(outK), outK, libs.ptr_array(outB),
+                                  libs.ptr_array(outA), libs.ptr_array(diag), out[0], out[1])
+        c = out
+    assert np.array_equal(c, S["out"])
+    o.orc_ctx_destroy(octx)
+    o.orc_hybrid_destroy(hy)
+    r.ref_ckks_destroy(h)
