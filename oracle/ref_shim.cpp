@@ -654,7 +654,15 @@ struct RefC2S {
 }  // namespace
 // level budget `budget` for encoding; plaintexts via EvalCoeffsToSlotsPrecompute with the roots-of-unity tables that
 // EvalBootstrapSetup builds for it (ckksrns-fhe.cpp:144-166); L as in that function (Q limbs left after the transform)
+static void* ref_ckks_fft_create(void* h, uint32_t slots, uint32_t budget, uint32_t L, bool decode);
 void* ref_ckks_c2s_create(void* h, uint32_t slots, uint32_t budget, uint32_t L) {
+    return ref_ckks_fft_create(h, slots, budget, L, false);
+}
+// the decoding direction: EvalSlotsToCoeffsPrecompute / EvalSlotsToCoeffs (ckksrns-fhe.cpp:1670-1830, 2041-2198)
+void* ref_ckks_s2c_create(void* h, uint32_t slots, uint32_t budget, uint32_t L) {
+    return ref_ckks_fft_create(h, slots, budget, L, true);
+}
+static void* ref_ckks_fft_create(void* h, uint32_t slots, uint32_t budget, uint32_t L, bool decode) {
     auto* s = static_cast<RefCkks*>(h);
     s->cc->Enable(ADVANCEDSHE);
     s->cc->Enable(FHE);
@@ -671,7 +679,8 @@ void* ref_ckks_c2s_create(void* h, uint32_t slots, uint32_t budget, uint32_t L) 
         ksiPows[j] = {std::cos(2 * M_PI * j / m), std::sin(2 * M_PI * j / m)};
     ksiPows[m] = ksiPows[0];
     auto* c = new RefC2S;
-    c->A    = fhe_of(s->cc)->EvalCoeffsToSlotsPrecompute(*s->cc, ksiPows, rotGroup, false, 1.0, L, false);
+    c->A    = decode ? fhe_of(s->cc)->EvalSlotsToCoeffsPrecompute(*s->cc, ksiPows, rotGroup, false, 1.0, L, false) :
+                       fhe_of(s->cc)->EvalCoeffsToSlotsPrecompute(*s->cc, ksiPows, rotGroup, false, 1.0, L, false);
     c->p    = GetCollapsedFFTParams(slots, budget, 0);
     return c;
 }
@@ -691,6 +700,12 @@ uint32_t ref_ckks_c2s_get_diag(void* c, uint32_t s, uint32_t idx, uint64_t* out)
     if (out)
         export_poly(pt, out);
     return pt.GetNumOfElements();
+}
+int ref_ckks_eval_slots_to_coeffs(void* h, void* c, int ct) {
+    auto* s = static_cast<RefCkks*>(h);
+    ConstCiphertext<DCRTPoly> x = s->cts[ct];
+    s->cts.push_back(fhe_of(s->cc)->EvalSlotsToCoeffs(static_cast<RefC2S*>(c)->A, x));
+    return static_cast<int>(s->cts.size()) - 1;
 }
 int ref_ckks_eval_coeffs_to_slots(void* h, void* c, int ct) {
     auto* s = static_cast<RefCkks*>(h);

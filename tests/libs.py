@@ -197,6 +197,8 @@ def load_ref():
     S("ref_ckks_eval_linear_transform", C.c_int, [vp, vp, C.c_int])
     S("ref_ckks_time_linear_transform", C.c_double, [vp, vp, C.c_int, C.c_int])
     S("ref_ckks_c2s_create", vp, [vp, u32, u32, u32])
+    S("ref_ckks_s2c_create", vp, [vp, u32, u32, u32])
+    S("ref_ckks_eval_slots_to_coeffs", C.c_int, [vp, vp, C.c_int])
     S("ref_ckks_c2s_destroy", None, [vp])
     S("ref_ckks_c2s_params", None, [vp, P32])
     S("ref_ckks_c2s_get_diag", u32, [vp, u32, u32, C.c_void_p])

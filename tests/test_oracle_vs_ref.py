@@ -626,8 +626,32 @@ def c2s_levels(P, slots, N):
     return out
 
 
-def ref_coeffs_to_slots_session(r, ring, depth, dnum, budget, level=0, seed=21):
-    """The reference's own EvalCoeffsToSlots (fully packed) with its own keys and plaintexts; everything exported."""
+def s2c_levels(P, slots, N):
+    """Rotation plan of FHECKKSRNS::EvalSlotsToCoeffs (ckksrns-fhe.cpp:2041-2080): levels ascending, the remainder last"""
+    lvlb, layers, rem, numRot, b, g, numRotRem, bRem, gRem = P
+    M4 = N // 2
+    flagRem = 1 if rem else 0
+    smax = lvlb - flagRem
+    offset = (numRot + 1) // 2 - 1
+    out = []
+    for s in range(smax):
+        scale = 1 << (s * layers)
+        rot_in = [((j - offset) * scale) % M4 for j in range(g)]
+        rot_out = [(g * i * scale) % M4 for i in range(b)]
+        out.append((s, rot_in, rot_out, {(i, j): g * i + j for i in range(b) for j in range(g) if g * i + j != numRot}))
+    if flagRem:
+        scale = 1 << (smax * layers)
+        offset = (numRotRem + 1) // 2 - 1
+        rot_in = [((j - offset) * scale) % M4 for j in range(gRem)]
+        rot_out = [(gRem * i * scale) % M4 for i in range(bRem)]
+        out.append((smax, rot_in, rot_out,
+                    {(i, j): gRem * i + j for i in range(bRem) for j in range(gRem) if gRem * i + j != numRotRem}))
+    return out
+
+
+def ref_coeffs_to_slots_session(r, ring, depth, dnum, budget, level=0, seed=21, decode=False):
+    """The reference's own EvalCoeffsToSlots (or, decode=True, EvalSlotsToCoeffs), fully packed, with its own keys and
+    plaintexts; everything exported."""
     h = r.ref_ckks_create(ring, depth, 45, 55, dnum, 0)
     info = np.zeros(5, np.uint32)
     r.ref_ckks_info(h, info)
@@ -643,10 +667,11 @@ def ref_coeffs_to_slots_session(r, ring, depth, dnum, budget, level=0, seed=21):
     ci = np.zeros(4, np.uint32)
     r.ref_ct_info(h, ct, ci)
     sizeQl = int(ci[1])
-    c2s = r.ref_ckks_c2s_create(h, slots, budget, sizeQl - budget)  # L + lvlb limbs at the first level = the ciphertext's
+    create = r.ref_ckks_s2c_create if decode else r.ref_ckks_c2s_create
+    c2s = create(h, slots, budget, sizeQl - budget)  # L + lvlb limbs at the first level = the ciphertext's
     P = np.zeros(9, np.uint32)
     r.ref_ckks_c2s_params(c2s, P)
-    levels = c2s_levels([int(v) for v in P], slots, N)
+    levels = (s2c_levels if decode else c2s_levels)([int(v) for v in P], slots, N)
     rots = sorted({x for _, ri, ro, _ in levels for x in ri + ro if x})
     idx = np.array(rots, np.int32)
     r.ref_ckks_rotate_keygen(h, idx, len(idx))
@@ -664,7 +689,7 @@ def ref_coeffs_to_slots_session(r, ring, depth, dnum, budget, level=0, seed=21):
             assert r.ref_ckks_c2s_get_diag(c2s, s, a, rows.ctypes.data) == limbs
             d[(i, j)] = rows
         diags.append(d)
-    res = r.ref_ckks_eval_coeffs_to_slots(h, c2s, ct)
+    res = (r.ref_ckks_eval_slots_to_coeffs if decode else r.ref_ckks_eval_coeffs_to_slots)(h, c2s, ct)
     r.ref_ct_info(h, res, ci)
     outQl = int(ci[1])
     assert outQl == sizeQl - (len(levels) - 1)
@@ -693,12 +718,14 @@ def c2s_level_arguments(S, n):
     return inK, inB, inA, outK, outB, outA, diag
 
 
-@pytest.mark.parametrize("ring,depth,dnum,budget", [(64, 4, 2, 2), (128, 5, 3, 3), (32, 3, 2, 1)])
-def test_coeffs_to_slots_against_live_reference(oracle, ref, ring, depth, dnum, budget):
-    """FHECKKSRNS::EvalCoeffsToSlots (collapsed-FFT levels, each a BSGS transform with double hoisting, a rescale between
-    them) run by the reference vs the oracle: one orc_ckks_bsgs_transform per level + DropLastElementAndScale"""
+@pytest.mark.parametrize("ring,depth,dnum,budget,decode", [(64, 4, 2, 2, False), (128, 5, 3, 3, False), (32, 3, 2, 1, False),
+                                                           (64, 4, 2, 2, True), (128, 5, 3, 3, True)])
+def test_coeffs_to_slots_against_live_reference(oracle, ref, ring, depth, dnum, budget, decode):
+    """FHECKKSRNS::EvalCoeffsToSlots / EvalSlotsToCoeffs (collapsed-FFT levels, each a BSGS transform with double hoisting,
+    a rescale between them) run by the reference vs the oracle: one orc_ckks_bsgs_transform per level +
+    DropLastElementAndScale"""
     o, r = oracle, ref
-    h, S = ref_coeffs_to_slots_session(r, ring, depth, dnum, budget)
+    h, S = ref_coeffs_to_slots_session(r, ring, depth, dnum, budget, decode=decode)
     N, q = S["N"], S["q"]
     hy = o.orc_hybrid_create(N, len(q), q, S["psiQ"], len(S["p"]), S["p"], S["psiP"], S["numPartQ"])
     octx = o.orc_ctx_create(N, len(q), q, S["psiQ"])
