@@ -13,6 +13,7 @@
 #ifndef FHE_HAL_DCRTPOLY_HIP_H
 #define FHE_HAL_DCRTPOLY_HIP_H
 #include <cstdint>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -269,6 +270,10 @@ public:
         check(fhe_ks_plan_create(m_params->ctx(), sizeQ, sizeP, numPartQ, &m_plan));
     }
     ~KeySwitchHybrid() {
+        for (auto& kv : m_rot)
+            fhe_ks_key_destroy(kv.second.second);
+        for (void* d : m_diag)
+            fhe_free(m_params->ctx(), d);
         fhe_ks_key_destroy(m_key);
         if (m_ws)
             fhe_free(m_params->ctx(), m_ws);
@@ -296,6 +301,61 @@ public:
         return {std::move(c0), std::move(c1)};
     }
 
+    // ---- BSGS linear transform with double hoisting (FHECKKSRNS::EvalLinearTransform, ckksrns-fhe.cpp:1832-1882) ----
+    // rotation key of `index` slots (EvalRotateKeyGen's key for FindAutomorphismIndex2nComplex(index, 2N))
+    void SetRotationKey(int32_t index, const std::vector<uint64_t>& keyB, const std::vector<uint64_t>& keyA) {
+        const uint32_t k = fhe_param_find_automorphism_index_2n_complex(index, 2u * m_params->GetRingDimension());
+        if (k == 0)
+            throw Error("m should be a power of two.");
+        fhe_ks_key* h = nullptr;
+        check(fhe_ks_key_upload(m_plan, keyB.data(), keyA.data(), &h));
+        auto it = m_rot.find(index);
+        if (it != m_rot.end())
+            fhe_ks_key_destroy(it->second.second);
+        m_rot[index] = {k, h};
+    }
+    // an encoded diagonal (EvalLinearTransformPrecompute's aux plaintext): host rows [sizeQl+sizeP][N], EVALUATION
+    // format over the limbs {0..sizeQl-1, sizeQ..sizeQ+sizeP-1}; stays on the device until the object dies
+    const uint64_t* UploadDiagonal(const std::vector<uint64_t>& rows) {
+        void* d = nullptr;
+        check(fhe_malloc(m_params->ctx(), rows.size() * sizeof(uint64_t), &d));
+        m_diag.push_back(d);
+        check(fhe_memcpy_h2d(m_params->ctx(), d, rows.data(), rows.size() * sizeof(uint64_t), nullptr));
+        return static_cast<const uint64_t*>(d);
+    }
+    // A[i] = diagonal i (nullptr = absent); baby step bStep, giant steps ceil(|A| / bStep)
+    std::pair<DCRTPolyHip, DCRTPolyHip> EvalLinearTransform(const std::vector<const uint64_t*>& A, uint32_t bStep,
+                                                             const DCRTPolyHip& c0, const DCRTPolyHip& c1) {
+        const uint32_t slots = (uint32_t)A.size(), gStep = (slots + bStep - 1) / bStep;
+        std::vector<uint32_t> inK(bStep, 0), outK(gStep, 0);
+        std::vector<const fhe_ks_key*> inKeys(bStep, nullptr), outKeys(gStep, nullptr);
+        auto key = [&](int32_t index, uint32_t& k, const fhe_ks_key*& h) {
+            auto it = m_rot.find(index);
+            if (it == m_rot.end())
+                throw Error("EvalLinearTransform: no rotation key for index " + std::to_string(index));
+            k = it->second.first, h = it->second.second;
+        };
+        for (uint32_t j = 1; j < bStep; ++j)
+            key((int32_t)j, inK[j], inKeys[j]);
+        for (uint32_t i = 1; i < gStep; ++i)
+            key((int32_t)(bStep * i), outK[i], outKeys[i]);
+        std::vector<const uint64_t*> diag((size_t)gStep * bStep, nullptr);
+        for (uint32_t i = 0; i < slots; ++i)
+            diag[i] = A[i];
+        const uint32_t sizeQl = c0.GetNumOfElements(), batch = c0.GetBatch();
+        DCRTPolyHip o0(m_params, sizeQl, EVALUATION, batch), o1(m_params, sizeQl, EVALUATION, batch);
+        const size_t need = fhe_ckks_bsgs_workspace_bytes(m_plan, sizeQl, batch, bStep, gStep);
+        void* ws          = nullptr;
+        check(fhe_malloc(m_params->ctx(), need, &ws));
+        const fhe_status st = fhe_ckks_bsgs_transform(m_plan, c0.data(), c1.data(), sizeQl, batch, bStep, inK.data(), inKeys.data(),
+                                                      gStep, outK.data(), outKeys.data(), diag.data(), o0.data(), o1.data(), ws,
+                                                      need, nullptr);
+        fhe_stream_sync(m_params->ctx(), nullptr);
+        fhe_free(m_params->ctx(), ws);
+        check(st);
+        return {std::move(o0), std::move(o1)};
+    }
+
 private:
     void reserve(uint32_t sizeQl, uint32_t batch) {
         size_t need = fhe_ks_workspace_bytes(m_plan, sizeQl, batch);
@@ -310,6 +370,8 @@ private:
     uint32_t m_sizeQ;
     fhe_ks_plan* m_plan = nullptr;
     fhe_ks_key* m_key   = nullptr;
+    std::map<int32_t, std::pair<uint32_t, fhe_ks_key*>> m_rot;  // rotation index -> (automorphism index, key)
+    std::vector<void*> m_diag;
     void* m_ws          = nullptr;
     size_t m_wsBytes    = 0;
 };

@@ -85,6 +85,39 @@ int main() {
     // ModReduce drops a tower as well
     Bp.ModReduce(65537);
     if (Bp.GetNumOfElements() != L - 1) return 10;
+    // EvalLinearTransform with a single unrotated diagonal: KeySwitchExt multiplies by P, the plaintext's P rows meet zeros and
+    // KeySwitchDown divides by P again, so the result is exactly the Hadamard product with the diagonal's Q rows
+    {
+        const uint32_t sizeQ = 3, sizeP = 2;
+        auto qp = Params::Generate(m, sizeQ + sizeP, 50);
+        KeySwitchHybrid ks(qp, sizeQ, sizeP, 3);
+        std::vector<uint64_t> c((size_t)B * sizeQ * N), d((size_t)(sizeQ + sizeP) * N);
+        for (uint32_t t = 0; t < B; ++t)
+            for (uint32_t l = 0; l < sizeQ; ++l)
+                for (uint32_t i = 0; i < N; ++i)
+                    c[((size_t)t * sizeQ + l) * N + i] = gen() % qp->GetModuli()[l];
+        for (uint32_t l = 0; l < sizeQ + sizeP; ++l)
+            for (uint32_t i = 0; i < N; ++i)
+                d[(size_t)l * N + i] = gen() % qp->GetModuli()[l];
+        DCRTPolyHip c0(qp, sizeQ, EVALUATION, B), c1(qp, sizeQ, EVALUATION, B);
+        c0.SetValues(c, EVALUATION);
+        c1.SetValues(c, EVALUATION);
+        auto r = ks.EvalLinearTransform({ks.UploadDiagonal(d)}, 1, c0, c1);
+        auto r0 = r.first.GetValues(), r1 = r.second.GetValues();
+        for (uint32_t t = 0; t < B; ++t)
+            for (uint32_t l = 0; l < sizeQ; ++l)
+                for (uint32_t i = 0; i < N; ++i) {
+                    const size_t at = ((size_t)t * sizeQ + l) * N + i;
+                    const uint64_t want = mulmod(c[at], d[(size_t)l * N + i], qp->GetModuli()[l]);
+                    if (r0[at] != want || r1[at] != want) return 11;
+                }
+        try {  // a second baby step needs the key of rotation 1
+            ks.EvalLinearTransform({ks.UploadDiagonal(d), ks.UploadDiagonal(d)}, 2, c0, c1);
+            return 12;
+        } catch (const Error& e) {
+            if (std::string(e.what()).find("no rotation key") == std::string::npos) return 13;
+        }
+    }
     std::puts("hal_smoke OK");
     return 0;
 }
