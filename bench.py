@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=1024, help="polynomials per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-evalmult", action="store_true")
-    ap.add_argument("--evalmult-batch", type=int, default=64, help="ciphertexts per GPU in the EvalMult leg")
+    ap.add_argument("--evalmult-batch", type=int, default=256, help="ciphertexts per GPU in the EvalMult leg (BASELINE configs[2]: 256)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-hadamard", action="store_true", help="skip the Hadamard-product leg")
     ap.add_argument("--no-bfv", action="store_true", help="skip the BFV EvalMult (BEHZ) leg (BASELINE configs[4] shape)")
@@ -222,9 +222,9 @@ def evalmult_leg(lib, device, logN, batch, steps, warmup, sync, dist=None):
 
 def linear_transform_leg(lib, device, batches, steps, warmup, with_cpu):
     """FHECKKSRNS::EvalLinearTransform (BSGS with double hoisting, the linear-transform loop of CKKS bootstrapping, BASELINE
-    configs[3]'s inner loop) at config 3's ring and level: N=2^16, l=21 limbs, dnum=3, 64 diagonals as 8 baby x 8 giant steps.
+    configs[3]'s inner loop) at config 4's ring: N=2^17, l=21 limbs, dnum=3, 64 diagonals as 8 baby x 8 giant steps.
     One HIP graph replay per transform; the CPU figure is the reference's own EvalLinearTransform (oracle/_ref)."""
-    logN, sizeQ, dnum, slots, bStep = 16, 21, 3, 64, 8
+    logN, sizeQ, dnum, slots, bStep = 17, 21, 3, 64, 8
     gStep = slots // bStep
     q, psiQ = lib.ckks_like_chain(logN, sizeQ, 60, 59)
     p, psiP = lib.select_p(logN, q, dnum, 60)

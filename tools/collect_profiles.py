@@ -9,8 +9,8 @@ def newest(pattern):  # gpurun_out accumulates the runs of a round: take the lat
 R = sys.argv[1] if len(sys.argv) > 1 else "r01"
 os.makedirs("profiles", exist_ok=True)
 shutil.copy("gpurun_out/bench_r01.json", f"profiles/{R}_bench.json")
-shutil.copy("gpurun_out/bench_r01_em128.json", f"profiles/{R}_bench_evalmult128.json")
 shutil.copy(newest("gpurun_out/prof_r01/*/*kernel_stats.csv"), f"profiles/{R}_rocprof_kernel_stats_bench.csv")
+shutil.copy(newest("gpurun_out/prof_r01_ntt/*/*kernel_stats.csv"), f"profiles/{R}_rocprof_kernel_stats_ntt_leg.csv")
 names = {"<true, false,": "fwd_column_pass", "<false, false,": "fwd_row_pass", "<false, true,": "inv_row_pass",
          "<true, true,": "inv_column_pass"}
 res = {}
