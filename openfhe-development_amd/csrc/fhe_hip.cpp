@@ -1303,6 +1303,8 @@ extern "C" void fhe_ks_plan_destroy(fhe_ks_plan* p) {
     }
     for (void* q : p->owned)
         rt::dfree(q);
+    for (auto& kv : p->bsgsTables)
+        rt::dfree(kv.second);
     delete p;
 }
 extern "C" uint32_t fhe_ks_plan_alpha(const fhe_ks_plan* p) { return p ? p->alpha : 0; }
@@ -1881,9 +1883,15 @@ extern "C" fhe_status fhe_ckks_bsgs_transform(fhe_ks_plan* p, const uint64_t* c0
                 tab[(size_t)i * nInPad + j] = (uint64_t)(uintptr_t)diag[(size_t)perm[i] * nIn + j];
     auto it = p->bsgsTables.find(tab);
     if (it == p->bsgsTables.end()) {
+        if (p->bsgsTables.size() >= 64) {  // a caller that keeps re-allocating its diagonals: drop the stale tables
+            RT_CHECK(rt::sync((rt::stream_t)st));
+            RT_CHECK(rt::sync(nullptr));
+            for (auto& kv : p->bsgsTables)
+                rt::dfree(kv.second);
+            p->bsgsTables.clear();
+        }
         void* dp = nullptr;
         RT_CHECK(rt::dmalloc(&dp, tab.size() * 8));
-        p->owned.push_back(dp);
         RT_CHECK(rt::h2d(dp, tab.data(), tab.size() * 8, nullptr));
         RT_CHECK(rt::sync(nullptr));
         it = p->bsgsTables.emplace(tab, dp).first;
