@@ -48,7 +48,9 @@ struct ConvArgs {
 // NSRC = compile-time upper bound of the number of source limbs (8 or 16): y_i live in registers, the output limbs
 // are produced one at a time with a column-wise multiply-accumulate (mac192), so the kernel needs few registers
 // (high occupancy) and computes every y_i once.
-template <int NSRC, bool EXACT>
+// SUM8: the column sums as chunks of <= 8 products with one 64-bit Barrett reduction each (sum8, modarith.h) instead of the
+// 192-bit accumulator with the generated reduction
+template <int NSRC, bool EXACT, bool SUM8 = false>
 FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) switch_basis_kernel(const ConvArgs g) {
     const uint32_t N     = 1u << g.logN;
     const uint64_t gid   = (uint64_t)FHE_BID * kThreads + FHE_TID;  // over batch*N coefficients
@@ -97,6 +99,26 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) switch_basis_kernel(const ConvArgs g
             h[i] = FHE_ULOAD64(g.tb.hatMod, (uint64_t)j * NSRC + i);
         const uint64_t p = FHE_ULOAD64(g.tb.dstQ, j);
         const uint64_t mulo = FHE_ULOAD64(g.tb.dstMu, 2 * j), muhi = FHE_ULOAD64(g.tb.dstMu, 2 * j + 1);
+        if (SUM8) {
+            const uint32_t k = 64u - (uint32_t)__builtin_clzll(p);
+            uint64_t v       = 0;
+#pragma unroll
+            for (int c0 = 0; c0 < NSRC; c0 += 8) {
+                if (c0 && c0 >= (int)g.nSrc)
+                    break;
+                sum8 s8;
+                sum8_clear(s8);
+#pragma unroll
+                for (int i = c0; i < c0 + 8 && i < NSRC; ++i)
+                    sum8_add(s8, y[i], h[i]);  // y[i] = 0 beyond nSrc
+                const uint64_t rj = sum8_reduce(s8, p, k, mulo, muhi);
+                v                 = c0 ? add_mod(v, rj, p) : rj;
+            }
+            if (EXACT)
+                v = sub_mod(v, g.tb.alphaMod[(uint64_t)alpha * g.nDst + j], p);
+            out[(uint64_t)j << g.logN] = v;
+            continue;
+        }
         mac192 m;
         mac192_clear(m);
 #pragma unroll

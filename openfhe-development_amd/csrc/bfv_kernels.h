@@ -235,15 +235,23 @@ FHE_HD uint64_t dot_row_mod(const uint64_t (&y)[kMaxBfvLimbs], const uint64_t* r
 #pragma unroll
     for (int i = 0; i < kMaxBfvLimbs; ++i)
         h[i] = FHE_ULOAD64(row, i);
-    mac192 acc;
-    mac192_clear(acc);
+    // chunks of <= 8 products (y_i < 2^60, table entries < m) with one 64-bit Barrett reduction each (sum8, modarith.h)
+    const uint32_t k = 64u - (uint32_t)__builtin_clzll(m);
+    uint64_t v       = 0;
 #pragma unroll
-    for (int i = 0; i < kMaxBfvLimbs; ++i)
-        if (i < (int)n)
-            mac192_add_uniform(acc, y[i], h[i]);
-    u128w a;
-    mac192_fold(acc, a.lo, a.hi);
-    return barrett128(a, m, mulo, muhi);
+    for (int c0 = 0; c0 < kMaxBfvLimbs; c0 += 8) {
+        if (c0 && c0 >= (int)n)
+            break;
+        sum8 s;
+        sum8_clear(s);
+#pragma unroll
+        for (int i = c0; i < c0 + 8 && i < kMaxBfvLimbs; ++i)
+            if (i < (int)n)
+                sum8_add(s, y[i], h[i]);
+        const uint64_t r = sum8_reduce(s, m, k, mulo, muhi);
+        v                = c0 ? add_mod(v, r, m) : r;
+    }
+    return v;
 }
 
 // core of FastBaseConvqToBskMontgomery: inQ (COEFF) -> outBsk (COEFF)

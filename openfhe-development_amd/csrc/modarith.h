@@ -190,8 +190,9 @@ FHE_HD void sum8_add(sum8& s, uint64_t x, uint64_t y) {
     s.c1 += (uint64_t)xh * yl;
     s.c2 += (uint64_t)xh * yh;
 }
-// The exact residue of the sum S (<= 8 products of residues of q, so S < 8*q^2 < 2^(2k+3), k = bit length of q <= 60):
-//   s    = floor(S / 2^(k-1)) < 2^(k+4) <= 2^64,   mu' = floor(2^(k+63) / q) = floor(mu128 / 2^(65-k)) < 2^64
+// The exact residue mod q (k = bit length of q <= 60) of a sum S of <= 8 products a_i*b_i with a_i < 2^60 and b_i < q
+// (so S < 2^(k+63); in particular <= 8 products of residues of q):
+//   s    = floor(S / 2^(k-1)) < 2^64,   mu' = floor(2^(k+63) / q) = floor(mu128 / 2^(65-k)) < 2^64
 //   qhat = floor(s * mu' / 2^64):  S/q - 3 < qhat <= S/q   (one unit each from the two floors inside and the one outside)
 //   r    = S - qhat*q in [0, 3q), 3q < 2^62: the low words suffice; two conditional subtractions make it canonical.
 // Any exact reduction equals the reference's ModMul / ModAdd chain (mubintvecnat.cpp:229-339) and its
