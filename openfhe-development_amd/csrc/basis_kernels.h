@@ -178,14 +178,18 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ks_inner_product_kernel(const KsInne
     const uint32_t idx  = i < g.sizeQl ? i : i + (g.sizeQ - g.sizeQl);
     const LimbConst lc  = g.lc[idx];
     const uint64_t mulo = g.mu128[2 * idx], muhi = g.mu128[2 * idx + 1];
-    // (the generated MAC / reduction of the conversion kernel were tried here and lost: 1.61 ms instead of 1.14 ms per
-    // launch at config 3's shape — this kernel is HBM-bound and the pinned temporaries cost it occupancy)
+    // The ModUp digits arrive in the NTT's lazy range (< 16q, ks_precompute_run): four conditional subtractions make them
+    // residues, after which the <= kMaxDigits = 8 products per sum fit the 64-bit column sums with one 64-bit Barrett
+    // reduction (sum8, modarith.h) -- half the instructions of a 192-bit accumulator + 128-bit Barrett per output, which
+    // is what makes this kernel HBM-bound.  (The generated MAC / reduction of the conversion kernel were tried here and
+    // lost: 1.61 ms instead of 1.14 ms per launch at config 3's shape, the pinned temporaries cost occupancy.)
     const uint32_t N    = 1u << g.logN;
     const uint32_t rEnd = ((tr + 1u) << kTileLog) < N ? ((tr + 1u) << kTileLog) : N;
+    const uint64_t q = lc.q;
     for (uint32_t r = (tr << kTileLog) + t; r < rEnd; r += kThreads) {
-        mac192 s0, s1;  // (the digits are lazy, up to 16q < 2^64: the 60-bit shortcuts of sum8 do not apply here)
-        mac192_clear(s0);
-        mac192_clear(s1);
+        sum8 s0, s1;
+        sum8_clear(s0);
+        sum8_clear(s1);
         for (uint32_t j = 0; j < g.numDigits; ++j) {
             const uint32_t start = j * g.alpha;
             const uint32_t sz    = sizeQlP - g.nc[j];
@@ -196,16 +200,17 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ks_inner_product_kernel(const KsInne
                 const uint32_t pos = i < start ? i : i - sz;
                 d = g.digits[j][(((uint64_t)b * g.nc[j] + pos) << g.logN) + r];
             }
+            d = csub(d, q << 3);
+            d = csub(d, q << 2);
+            d = csub(d, q << 1);
+            d = csub(d, q);
             const uint64_t koff = (((uint64_t)j * (g.sizeQ + g.sizeP) + idx) << g.logN) + r;
-            mac192_add(s0, d, g.keyB[koff]);
-            mac192_add(s1, d, g.keyA[koff]);
+            sum8_add(s0, d, g.keyB[koff]);
+            sum8_add(s1, d, g.keyA[koff]);
         }
         const uint64_t ooff = (((uint64_t)b * sizeQlP + i) << g.logN) + r;
-        u128w a0, a1;
-        mac192_fold(s0, a0.lo, a0.hi);
-        mac192_fold(s1, a1.lo, a1.hi);
-        g.out0[ooff] = barrett128(a0, lc.q, mulo, muhi);
-        g.out1[ooff] = barrett128(a1, lc.q, mulo, muhi);
+        g.out0[ooff] = sum8_reduce(s0, q, lc.msb, mulo, muhi);
+        g.out1[ooff] = sum8_reduce(s1, q, lc.msb, mulo, muhi);
     }
 }
 
