@@ -37,3 +37,44 @@ def broadcast_key(plan, keyB_host, keyA_host, device, src=0):
         tens.append(t)
     plan.wrap_key(tens[0].data_ptr(), tens[1].data_ptr())
     return tens
+
+
+def broadcast_rotation_keys(plan, host_keys, device, src=0):
+    """Replicates a SET of evaluation keys (the rotation keys of a linear transform / of bootstrapping) with ONE
+    broadcast: rank `src` packs them as int64[nKeys][2][words]; every rank wraps the slices of its copy as key handles.
+    host_keys: list of (keyB, keyA) on rank `src` (only its length matters on the other ranks).
+    Returns (handles, tensor); keep the tensor alive as long as the handles are used, destroy the handles with
+    fhe_ks_key_destroy."""
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+
+    words, n = plan.key_words(), len(host_keys)
+    t = torch.empty((n, 2, words), dtype=torch.int64, device=device)
+    if dist.get_rank() == src:
+        for i, (kb, ka) in enumerate(host_keys):
+            for h, arr in enumerate((kb, ka)):
+                flat = np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1)
+                assert flat.size == words
+                t[i, h].copy_(torch.from_numpy(flat.view(np.int64)))
+    dist.broadcast(t, src=src)
+    L, handles = plan.ctx.lib.L, []
+    for i in range(n):
+        k = C.c_void_p()
+        plan.ctx.lib.check(L.fhe_ks_key_wrap(plan.h, C.c_void_p(t[i, 0].data_ptr()), C.c_void_p(t[i, 1].data_ptr()), C.byref(k)))
+        handles.append(k)
+    return handles, t
+
+
+def broadcast_rows(host_rows, shape, device, src=0):
+    """Replicates read-only tables of residues (e.g. the encoded diagonals of a linear transform, uint64 `shape`) from
+    rank `src` with one broadcast; returns the rank-local int64 tensor (its data_ptr() + offsets are device pointers)."""
+    import torch
+    import torch.distributed as dist
+
+    t = torch.empty(shape, dtype=torch.int64, device=device)
+    if dist.get_rank() == src:
+        t.copy_(torch.from_numpy(np.ascontiguousarray(host_rows, dtype=np.uint64).view(np.int64).reshape(shape)))
+    dist.broadcast(t, src=src)
+    return t

@@ -89,3 +89,80 @@ def test_two_rank_sharded_eval_mult_with_key_broadcast(tmp_path, backend):
     logs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
     assert os.path.exists(out + ".ok"), "\n".join(logs)
+
+
+WORKER_LT = r"""
+import os, sys
+import numpy as np
+ROOT = sys.argv[1]; out = sys.argv[2]
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch, torch.distributed as dist
+from openfhe_amd import fhe_hip as fh
+from openfhe_amd import shard
+import libs
+from test_parity_lt import run_oracle
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+lib = fh.Lib(os.path.join(ROOT, "tests", "emu", "libfhe_emu.so"))
+o = libs.load_oracle()
+logN, sizeQ, dnum, B, bStep, gStep = 8, 3, 3, 3, 2, 2
+N = 1 << logN
+q, psiQ = lib.ckks_like_chain(logN, sizeQ, 60, 50)
+p, psiP = lib.select_p(logN, q, dnum)
+allq = np.concatenate([q, p])
+ctx = fh.Context(lib, logN, allq, np.concatenate([psiQ, psiP]))
+plan = fh.KeySwitchPlan(ctx, sizeQ, len(p), dnum)
+rng = np.random.default_rng(7)   # same seed everywhere: rank 0's copies are the ones that travel
+rots = [1, bStep]                # baby step 1, giant step bStep
+keys = [(libs.rand_tower(rng, allq, N, dnum), libs.rand_tower(rng, allq, N, dnum)) for _ in rots]
+diag = np.stack([libs.rand_tower(rng, allq, N) for _ in range(bStep * gStep)])
+c0, c1 = libs.rand_tower(rng, q, N, B), libs.rand_tower(rng, q, N, B)
+handles, keep_k = shard.broadcast_rotation_keys(plan, keys if rank == 0 else [None] * len(rots), "cpu")
+dt = shard.broadcast_rows(diag if rank == 0 else None, diag.shape, "cpu")
+ks = [lib.find_automorphism_index(r, 2 * N) for r in rots]
+row = diag[0].size * 8
+dptr = [[dt.data_ptr() + (i * bStep + j) * row for j in range(bStep)] for i in range(gStep)]
+lo, hi = shard.shard_range(B, rank, world)
+g0, g1 = plan.BsgsTransform(ctx.tower(c0[lo:hi]), ctx.tower(c1[lo:hi]), [None, (ks[0], handles[0])], [None, (ks[1], handles[1])], dptr)
+np.savez(out + f".{rank}.npz", lo=lo, hi=hi, c0=g0.to_host(), c1=g1.to_host())
+dist.barrier()
+if rank == 0:
+    hy = o.orc_hybrid_create(N, sizeQ, q, psiQ, len(p), p, psiP, dnum)
+    want = run_oracle(o, hy, c0, c1, sizeQ, [None, (ks[0],) + keys[0]], [None, (ks[1],) + keys[1]],
+                      [[diag[i * bStep + j] for j in range(bStep)] for i in range(gStep)])
+    got = np.empty_like(want); covered = np.zeros(B, bool)
+    for r in range(world):
+        z = np.load(out + f".{r}.npz")
+        got[0, z["lo"]:z["hi"]] = z["c0"]; got[1, z["lo"]:z["hi"]] = z["c1"]; covered[z["lo"]:z["hi"]] = True
+    assert covered.all() and np.array_equal(got, want), "sharded linear transform differs from the oracle"
+    open(out + ".ok", "w").write("ok")
+dist.destroy_process_group()
+"""
+
+
+def run_two_ranks(tmp_path, source):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    worker = tmp_path / "worker.py"
+    worker.write_text(source)
+    out = str(tmp_path / "res")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(worker), ROOT, out], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    assert os.path.exists(out + ".ok"), "\n".join(logs)
+
+
+def test_two_rank_sharded_linear_transform_with_key_and_diagonal_broadcast(tmp_path, backend):
+    """config 4's shape of parallelism: ciphertexts sharded over the ranks, the rotation keys and the encoded diagonals
+    replicated with one broadcast each, no collective on the data path"""
+    if "emulator" not in backend.version():
+        import pytest
+        pytest.skip("CPU (gloo) variant only")
+    run_two_ranks(tmp_path, WORKER_LT)
