@@ -266,7 +266,7 @@ private:
 class KeySwitchHybrid {
 public:
     KeySwitchHybrid(std::shared_ptr<Params> params, uint32_t sizeQ, uint32_t sizeP, uint32_t numPartQ)
-        : m_params(std::move(params)), m_sizeQ(sizeQ) {
+        : m_params(std::move(params)), m_sizeQ(sizeQ), m_sizeP(sizeP) {
         check(fhe_ks_plan_create(m_params->ctx(), sizeQ, sizeP, numPartQ, &m_plan));
     }
     ~KeySwitchHybrid() {
@@ -300,6 +300,60 @@ public:
                                  c0.data(), c1.data(), m_ws, m_wsBytes, nullptr));
         return {std::move(c0), std::move(c1)};
     }
+
+    // DCRTPolyImpl::ApproxModDown with the context's P (dcrtpoly-impl.h:966-1005; t > 0: the BGV form): x over Q_l u P
+    DCRTPolyHip ApproxModDown(const DCRTPolyHip& x, uint32_t sizeQl, uint64_t t = 0) {
+        DCRTPolyHip out(m_params, sizeQl, EVALUATION, x.GetBatch());
+        reserve(sizeQl, x.GetBatch());
+        check(t ? fhe_approx_mod_down_bgv(m_plan, x.data(), sizeQl, t, x.GetBatch(), out.data(), m_ws, m_wsBytes, nullptr)
+                : fhe_approx_mod_down(m_plan, x.data(), sizeQl, x.GetBatch(), out.data(), m_ws, m_wsBytes, nullptr));
+        return out;
+    }
+    // KeySwitchHYBRID::KeySwitchExt for one element (keyswitch-hybrid.cpp:217-243): c * [P] on the Q_l limbs, zeros on P
+    DCRTPolyHip KeySwitchExt(const DCRTPolyHip& c) {
+        DCRTPolyHip out(m_params, c.GetNumOfElements() + m_sizeP, EVALUATION, c.GetBatch(), extLimbs(c.GetNumOfElements()));
+        check(fhe_ks_ext(m_plan, c.data(), c.GetNumOfElements(), c.GetBatch(), out.data(), nullptr));
+        return out;
+    }
+    // KeySwitchHYBRID::KeySwitchDown (keyswitch-hybrid.cpp:245-278)
+    std::pair<DCRTPolyHip, DCRTPolyHip> KeySwitchDown(const DCRTPolyHip& x0, const DCRTPolyHip& x1) {
+        const uint32_t sizeQl = x0.GetNumOfElements() - m_sizeP;
+        DCRTPolyHip o0(m_params, sizeQl, EVALUATION, x0.GetBatch()), o1(m_params, sizeQl, EVALUATION, x0.GetBatch());
+        reserve(sizeQl, x0.GetBatch());
+        check(fhe_ks_down(m_plan, x0.data(), x1.data(), sizeQl, x0.GetBatch(), o0.data(), o1.data(), m_ws, m_wsBytes, nullptr));
+        return {std::move(o0), std::move(o1)};
+    }
+    // LeveledSHEBase::EvalAutomorphism / EvalRotate (base-leveledshe.cpp:381-422) with the key set by SetRotationKey
+    std::pair<DCRTPolyHip, DCRTPolyHip> EvalRotate(const DCRTPolyHip& c0, const DCRTPolyHip& c1, int32_t index) {
+        auto it = m_rot.find(index);
+        if (it == m_rot.end())
+            throw Error("EvalRotate: no rotation key for index " + std::to_string(index));
+        const uint32_t sizeQl = c0.GetNumOfElements(), batch = c0.GetBatch();
+        DCRTPolyHip o0(m_params, sizeQl, EVALUATION, batch), o1(m_params, sizeQl, EVALUATION, batch);
+        reserve(sizeQl, batch);
+        check(fhe_eval_automorphism(m_plan, it->second.second, c0.data(), c1.data(), it->second.first, sizeQl, batch, o0.data(),
+                                    o1.data(), m_ws, m_wsBytes, nullptr));
+        return {std::move(o0), std::move(o1)};
+    }
+    // hoisted rotations: EvalFastRotationPrecompute once (base-leveledshe.cpp:425-430), then EvalFastRotation per index
+    // (:432-463); the digits live in this object's workspace until the next call that uses it
+    void EvalFastRotationPrecompute(const DCRTPolyHip& c1) {
+        reserve(c1.GetNumOfElements(), c1.GetBatch());
+        check(fhe_ks_precompute(m_plan, c1.data(), c1.GetNumOfElements(), c1.GetBatch(), m_ws, m_wsBytes, nullptr));
+    }
+    std::pair<DCRTPolyHip, DCRTPolyHip> EvalFastRotation(const DCRTPolyHip& c0, const DCRTPolyHip& c1, int32_t index) {
+        auto it = m_rot.find(index);
+        if (it == m_rot.end())
+            throw Error("EvalFastRotation: no rotation key for index " + std::to_string(index));
+        const uint32_t sizeQl = c0.GetNumOfElements(), batch = c0.GetBatch();
+        DCRTPolyHip o0(m_params, sizeQl, EVALUATION, batch), o1(m_params, sizeQl, EVALUATION, batch);
+        check(fhe_eval_fast_rotation(m_plan, it->second.second, c0.data(), c1.data(), it->second.first, sizeQl, batch, o0.data(),
+                                     o1.data(), m_ws, m_wsBytes, nullptr));
+        return {std::move(o0), std::move(o1)};
+    }
+    uint32_t AutomorphismIndex(int32_t index) const { return m_rot.at(index).first; }
+    fhe_ks_plan* plan() const { return m_plan; }
+    const fhe_ks_key* key() const { return m_key; }
 
     // ---- BSGS linear transform with double hoisting (FHECKKSRNS::EvalLinearTransform, ckksrns-fhe.cpp:1832-1882) ----
     // rotation key of `index` slots (EvalRotateKeyGen's key for FindAutomorphismIndex2nComplex(index, 2N))
@@ -366,14 +420,84 @@ private:
             m_wsBytes = need;
         }
     }
+    std::vector<uint32_t> extLimbs(uint32_t sizeQl) const {  // context limbs of Q_l u P
+        std::vector<uint32_t> v;
+        for (uint32_t i = 0; i < sizeQl; ++i)
+            v.push_back(i);
+        for (uint32_t j = 0; j < m_sizeP; ++j)
+            v.push_back(m_sizeQ + j);
+        return v;
+    }
     std::shared_ptr<Params> m_params;
-    uint32_t m_sizeQ;
+    uint32_t m_sizeQ, m_sizeP;
     fhe_ks_plan* m_plan = nullptr;
     fhe_ks_key* m_key   = nullptr;
     std::map<int32_t, std::pair<uint32_t, fhe_ks_key*>> m_rot;  // rotation index -> (automorphism index, key)
     std::vector<void*> m_diag;
     void* m_ws          = nullptr;
     size_t m_wsBytes    = 0;
+};
+
+// BFV multiplication in the BEHZ RNS variant (CryptoParametersBFVRNS's BEHZ tables, bfvrns-cryptoparameters.cpp:673-850;
+// DCRTPolyImpl::FastBaseConvqToBskMontgomery / FastRNSFloorq / FastBaseConvSK, dcrtpoly-impl.h:1694-1929;
+// LeveledSHEBFVRNS::EvalMult, bfvrns-leveledshe.cpp:198-445).  The context holds Q (qLimbs) and Bsk (bskLimbs, m_sk last).
+class BfvBehz {
+public:
+    // the Bsk moduli / roots the reference picks for (N, Q, t) (bfvrns-cryptoparameters.cpp:682-711)
+    static void SelectBsk(uint32_t cyclotomicOrder, const std::vector<uint64_t>& q, uint64_t t, std::vector<uint64_t>& bsk,
+                          std::vector<uint64_t>& psi) {
+        uint32_t logN = 0;
+        while ((2u << logN) < cyclotomicOrder)
+            ++logN;
+        bsk.assign(q.size() + 1, 0), psi.assign(q.size() + 1, 0);
+        if (fhe_param_behz_bsk(logN, (uint32_t)q.size(), q.data(), t, bsk.data(), psi.data()) != q.size() + 1)
+            throw Error("BEHZ: no auxiliary basis for these parameters");
+    }
+    BfvBehz(std::shared_ptr<Params> params, const std::vector<uint32_t>& qLimbs, const std::vector<uint32_t>& bskLimbs, uint64_t t)
+        : m_params(std::move(params)), m_numQ((uint32_t)qLimbs.size()) {
+        if (bskLimbs.size() != qLimbs.size() + 1)
+            throw Error("BEHZ: Bsk must hold one limb more than Q");
+        check(fhe_behz_create(m_params->ctx(), qLimbs.data(), m_numQ, bskLimbs.data(), t, &m_plan));
+    }
+    ~BfvBehz() { fhe_behz_destroy(m_plan); }
+    BfvBehz(const BfvBehz&)            = delete;
+    BfvBehz& operator=(const BfvBehz&) = delete;
+    // EvalMultNoRelin: (a0, a1) x (b0, b1) -> (d0, d1, d2), inputs EVALUATION over Q, outputs COEFFICIENT like the reference's
+    std::vector<DCRTPolyHip> EvalMultNoRelin(const DCRTPolyHip& a0, const DCRTPolyHip& a1, const DCRTPolyHip& b0, const DCRTPolyHip& b1) {
+        const uint32_t batch = a0.GetBatch();
+        std::vector<DCRTPolyHip> d;
+        for (int i = 0; i < 3; ++i)
+            d.emplace_back(m_params, m_numQ, COEFFICIENT, batch);
+        const size_t need = fhe_bfv_eval_mult_behz_workspace_bytes(m_plan, batch);
+        void* ws          = nullptr;
+        check(fhe_malloc(m_params->ctx(), need, &ws));
+        const fhe_status st = fhe_bfv_eval_mult_behz(m_plan, a0.data(), a1.data(), b0.data(), b1.data(), d[0].data(), d[1].data(),
+                                                     d[2].data(), 0, batch, ws, need, nullptr);
+        fhe_stream_sync(m_params->ctx(), nullptr);
+        fhe_free(m_params->ctx(), ws);
+        check(st);
+        return d;
+    }
+    // cc->EvalMult: EvalMultNoRelin + HYBRID relinearisation with `ks`'s evaluation key (base-leveledshe.cpp:201-214)
+    std::pair<DCRTPolyHip, DCRTPolyHip> EvalMult(KeySwitchHybrid& ks, const DCRTPolyHip& a0, const DCRTPolyHip& a1,
+                                                 const DCRTPolyHip& b0, const DCRTPolyHip& b1) {
+        const uint32_t batch = a0.GetBatch();
+        DCRTPolyHip c0(m_params, m_numQ, EVALUATION, batch), c1(m_params, m_numQ, EVALUATION, batch);
+        const size_t need = fhe_bfv_eval_mult_relin_workspace_bytes(m_plan, ks.plan(), batch);
+        void* ws          = nullptr;
+        check(fhe_malloc(m_params->ctx(), need, &ws));
+        const fhe_status st = fhe_bfv_eval_mult_relin_behz(m_plan, ks.plan(), ks.key(), a0.data(), a1.data(), b0.data(), b1.data(),
+                                                           c0.data(), c1.data(), batch, ws, need, nullptr);
+        fhe_stream_sync(m_params->ctx(), nullptr);
+        fhe_free(m_params->ctx(), ws);
+        check(st);
+        return {std::move(c0), std::move(c1)};
+    }
+
+private:
+    std::shared_ptr<Params> m_params;
+    uint32_t m_numQ;
+    fhe_behz* m_plan = nullptr;
 };
 
 }  // namespace fhehip

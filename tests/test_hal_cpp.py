@@ -8,13 +8,17 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(libdir, libname, tmp_path):
-    exe = str(tmp_path / "hal_smoke")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "hal_smoke.cpp"), "-o", exe,
-                           f"-L{libdir}", f"-l{libname}", f"-Wl,-rpath,{libdir}", "-lpthread"])
+def _run(libdir, libname, tmp_path, prog="hal_smoke", with_oracle=False):
+    exe = str(tmp_path / prog)
+    cmd = ["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", prog + ".cpp"), "-o", exe, f"-L{libdir}", f"-l{libname}",
+           f"-Wl,-rpath,{libdir}", "-lpthread"]
+    if with_oracle:  # the checker: oracle/libfhe_oracle.so (test infrastructure, see oracle/fhe_oracle.h)
+        odir = os.path.join(ROOT, "oracle")
+        cmd += [f"-L{odir}", "-lfhe_oracle", f"-Wl,-rpath,{odir}"]
+    subprocess.check_call(cmd)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, f"hal_smoke failed with code {out.returncode}: {out.stdout} {out.stderr}"
-    assert "hal_smoke OK" in out.stdout
+    assert out.returncode == 0, f"{prog} failed with code {out.returncode}: {out.stdout} {out.stderr}"
+    assert f"{prog} OK" in out.stdout
 
 
 def test_hal_cpp_on_emulator(backend, tmp_path):
@@ -26,3 +30,16 @@ def test_hal_cpp_on_emulator(backend, tmp_path):
 @pytest.mark.gpu
 def test_hal_cpp_on_gpu(hip, tmp_path):
     _run(os.path.join(ROOT, "openfhe-development_amd", "csrc"), "fhe_hip", tmp_path)
+
+
+def test_hal_cpp_parity_with_oracle_on_emulator(backend, oracle, tmp_path):
+    """KeySwitchHybrid (KeySwitchCore, EvalMult, rotations, KeySwitchExt / Down, ApproxModDown) and BfvBehz::EvalMultNoRelin
+    through the C++ mirror, compared word for word with the oracle"""
+    if "emulator" not in backend.version():
+        pytest.skip("emulator variant")
+    _run(os.path.join(ROOT, "tests", "emu"), "fhe_emu", tmp_path, "hal_parity", with_oracle=True)
+
+
+@pytest.mark.gpu
+def test_hal_cpp_parity_with_oracle_on_gpu(hip, oracle, tmp_path):
+    _run(os.path.join(ROOT, "openfhe-development_amd", "csrc"), "fhe_hip", tmp_path, "hal_parity", with_oracle=True)
