@@ -742,9 +742,14 @@ static bool ntt_lds2() {
 // outStride != 0: xout is a [batch][outStride][N] view as well (rows outFirst..)
 // does a forward transform of this ring end in a kernel that can carry the fused epilogue?
 static bool ntt_epilogue_supported(const fhe_ctx* c) {
-    if (c->logN < (uint32_t)kTileLog || c->logN > 16u || ntt_legacy() || !ntt_static())
+    if (c->logN < (uint32_t)kTileLog || ntt_legacy() || !ntt_static())
         return false;
-    return c->logN == (uint32_t)kTileLog || ntt_t1(c->logN) == 4u;  // row passes T2 = 9..12 after a 4-stage column pass
+    if (c->logN == (uint32_t)kTileLog)
+        return true;  // the single pass
+    // the epilogue instances of launch_pass: row passes of 9..12 stages whose input class is 9 (static_mode): any 12-stage
+    // row pass (logN = 16 after 4 column stages, 17 after 5, ...), shorter ones only after a 4-stage column pass
+    const uint32_t t1 = ntt_t1(c->logN), t2 = c->logN - t1;
+    return t2 == 12u || (t1 == 4u && t2 >= 9u && t2 <= 12u);
 }
 static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_t* xout, const uint32_t* limbIdx,
                           uint32_t nLimbs, uint32_t batch, void* stream, uint32_t inStride = 0, uint32_t inFirst = 0,

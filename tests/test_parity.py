@@ -6,6 +6,7 @@ the only floating-point step (SwitchCRTBasis overflow count) is also required to
 replicates the reference's operation order.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -258,11 +259,12 @@ def ckks_like_params(o, logN, sizeQ, dnum, first_bits=60, scale_bits=50, aux_bit
     return q, psiQ, p[:sizeP].copy(), psiP[:sizeP].copy()
 
 
-@pytest.mark.parametrize("logN,sizeQ,dnum,sizeQl,B", [(10, 4, 2, 4, 3), (8, 5, 2, 3, 2), (12, 6, 3, 6, 2), (12, 7, 2, 5, 1), (12, 5, 3, 2, 1), (13, 4, 2, 4, 1)])
+@pytest.mark.parametrize("logN,sizeQ,dnum,sizeQl,B", [(10, 4, 2, 4, 3), (8, 5, 2, 3, 2), (12, 6, 3, 6, 2), (12, 7, 2, 5, 1), (12, 5, 3, 2, 1), (13, 4, 2, 4, 1),
+                                                      (16, 2, 2, 2, 1), (17, 2, 2, 2, 1)])  # 12-stage row passes: BASELINE configs[2] / [3] rings
 def test_hybrid_keyswitch_and_eval_mult(backend, oracle, logN, sizeQ, dnum, sizeQl, B):
     o = oracle
-    if is_emu(backend) and logN > 12:
-        pytest.skip("emulator: keep the CPU suite short")
+    if is_emu(backend) and logN > 12 and not os.environ.get("FHE_TEST_BIG_EMU"):
+        pytest.skip("emulator: keep the CPU suite short (FHE_TEST_BIG_EMU=1 runs these too)")
     rng = np.random.default_rng(16)
     N = 1 << logN
     q, psiQ, p, psiP = ckks_like_params(o, logN, sizeQ, dnum)
