@@ -95,10 +95,15 @@ def cpu_baseline(q, psi, logN, L, seconds):
             if nt > cores:
                 continue
             gomp.omp_set_num_threads(nt)
-            t1 = time.time()
+            r.ref_towers_switch_format(h)  # let the new team start up
             r.ref_towers_switch_format(h)
-            r.ref_towers_switch_format(h)
-            dt1 = time.time() - t1
+            dt1 = None
+            for _ in range(3):  # best of three: a probe disturbed by another process must not pick a bad team
+                t1 = time.time()
+                r.ref_towers_switch_format(h)
+                r.ref_towers_switch_format(h)
+                d = time.time() - t1
+                dt1 = d if dt1 is None else min(dt1, d)
             if best is None or dt1 < best_t:
                 best, best_t = nt, dt1
         gomp.omp_set_num_threads(best)
