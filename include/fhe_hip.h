@@ -372,6 +372,11 @@ uint32_t   fhe_param_select_p(uint32_t logN, uint32_t sizeQ, const uint64_t* q, 
  * rotation by `index` slots (m = 2N, a power of two); 0 on error */
 uint32_t   fhe_param_find_automorphism_index_2n_complex(int32_t index, uint32_t m);
 
+/* ---- diagnostics -----------------------------------------------------------------------------------
+ * number of forward column passes launched with the experimental conversion prologue (FHE_KS_FUSE_CONV=1: the ModUp /
+ * ModDown basis conversions of a key switch computed inside the NTT's HBM-bound column pass; default off) */
+uint64_t   fhe_debug_fused_conv_launches(void);
+
 /* ---- measurement helper ----------------------------------------------------------------------------
  * Runs `iters` back-to-back launches of fwd (dir=0), inv (dir=1) or fwd+inv (dir=2) NTT on x — or of a single
  * pass kernel of a two-pass ring: 10/11 = column/row pass of the forward, 12/13 = row/column pass of the

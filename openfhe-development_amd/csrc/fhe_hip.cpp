@@ -248,6 +248,7 @@ struct fhe_ctx {
     TwPair* d_tw      = nullptr;  // [L][N] forward
     TwPair* d_twInv   = nullptr;  // [L][N] inverse
     TwPair* d_fin     = nullptr;  // [L][2] {N^-1, TableInv[1]*N^-1}
+    std::vector<TwPair> h_fin;    // host copy (the key-switch plans derive tables with extra per-limb factors from it)
     TwPair* d_twRow   = nullptr;  // [L][N/4096][15][256] lane-major twiddles of the row pass's bit-0 step (N >= 4096), forward
     TwPair* d_twRowInv = nullptr; // ... inverse
     uint64_t* d_q     = nullptr;  // [L]
@@ -340,6 +341,7 @@ extern "C" fhe_status fhe_ctx_create(uint32_t logN, uint32_t nLimbs, const uint6
         lc[l]               = LimbConst{ql, host::barrett_mu(ql), host::bitlen(ql), 0};
         host::mu128(ql, &mu[2 * l]);
     }
+    c->h_fin = fin;
     fhe_status s;
     if ((s = upload(c, tw.data(), tw.size() * sizeof(TwPair), (void**)&c->d_tw)) ||
         (s = upload(c, twInv.data(), twInv.size() * sizeof(TwPair), (void**)&c->d_twInv)) ||
@@ -564,6 +566,15 @@ struct NttEpilogue {
     const TwPair* C   = nullptr;
     uint64_t *out0 = nullptr, *out1 = nullptr;
 };
+// experimental (FHE_KS_FUSE_CONV): conversion prologue of a forward transform's column pass (NttPassArgs::pro*), and the
+// final constants of an inverse transform replaced by ones that carry a per-limb factor (NttPassArgs::fin)
+static uint64_t g_fusedConvLaunches = 0;  // diagnostics: column passes launched with the conversion prologue
+extern "C" uint64_t fhe_debug_fused_conv_launches(void) { return g_fusedConvLaunches; }
+struct NttPrologue {
+    uint32_t nSrc = 0, stride = 0, first = 0;
+    const uint64_t* y = nullptr;
+    const uint64_t* h = nullptr;  // [nLimbs][8]
+};
 static uint32_t fill_pass_args(const fhe_ctx* c, const PassPlan& pp, bool inverse, const uint64_t* xin, uint64_t* xout,
                                const LimbSel& sel, uint32_t nLimbs, uint32_t batch, bool canonOut, uint32_t inStride,
                                uint32_t inFirst, uint32_t outStride, uint32_t outFirst, NttPassArgs& a) {
@@ -600,6 +611,8 @@ static uint32_t fill_pass_args(const fhe_ctx* c, const PassPlan& pp, bool invers
     a.xcdSwizzle = (c->N >= (uint32_t)kTile && ((nLimbs * tilesPerRow) % 8u == 0)) ? 1u : 0u;
     a.epiMode = 0, a.epiSplit = 0, a.epiAStride = 0, a.epiAFirst = 0;
     a.epiA = nullptr, a.epiC = nullptr, a.epiOut0 = a.epiOut1 = nullptr;
+    a.proNSrc = 0, a.proStride = 0, a.proFirst = 0;
+    a.proY = nullptr, a.proH = nullptr, a.mu128 = c->d_mu128;
     return grid;
 }
 // forward: bound class of a static pass's input; inverse: does the pass end the transform (ntt_static.h MODE)
@@ -613,10 +626,27 @@ static int static_mode(const fhe_ctx* c, const PassPlan& pp, bool inverse) {
 static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse, const uint64_t* xin, uint64_t* xout,
                               const LimbSel& sel, uint32_t nLimbs, uint32_t batch, bool canonOut, void* stream,
                               uint32_t inStride = 0, uint32_t inFirst = 0, uint32_t outStride = 0, uint32_t outFirst = 0,
-                              const NttEpilogue* epi = nullptr) {
+                              const NttEpilogue* epi = nullptr, const NttPrologue* pro = nullptr, const TwPair* fin = nullptr) {
     NttPassArgs a;
     const uint32_t grid = fill_pass_args(c, pp, inverse, xin, xout, sel, nLimbs, batch, canonOut, inStride, inFirst, outStride,
                                          outFirst, a);
+    if (fin)
+        a.fin = fin;
+    if (pro && pro->nSrc) {
+        // only the static forward column passes of 4 / 5 stages carry the prologue (ntt_prologue_supported)
+        a.proNSrc = pro->nSrc, a.proStride = pro->stride, a.proFirst = pro->first, a.proY = pro->y, a.proH = pro->h;
+        ++g_fusedConvLaunches;
+        const uint32_t tilesPerRow = c->N >> kTileLog;
+        a.xcdSwizzle = ((batch * tilesPerRow) % 8u == 0) ? 2u : 0u;
+        if (pp.layoutA && !inverse && pp.T == 4)
+            FHE_LAUNCH((ntt_static_kernel<true, false, 4, 1, false, false, true>), grid, stream, a);
+        else if (pp.layoutA && !inverse && pp.T == 5)
+            FHE_LAUNCH((ntt_static_kernel<true, false, 5, 1, false, false, true>), grid, stream, a);
+        else
+            return fail(FHE_ERR_UNSUPPORTED, "ntt: no prologue kernel for this pass shape");
+        LAUNCH_CHECK();
+        return FHE_OK;
+    }
     if (epi && epi->mode) {
         // only the static forward row / single pass kernels carry the epilogue (ntt_epilogue_supported)
         a.epiMode = epi->mode, a.epiSplit = epi->split, a.epiAStride = epi->aStride, a.epiAFirst = epi->aFirst;
@@ -751,10 +781,18 @@ static bool ntt_epilogue_supported(const fhe_ctx* c) {
     const uint32_t t1 = ntt_t1(c->logN), t2 = c->logN - t1;
     return t2 == 12u || (t1 == 4u && t2 >= 9u && t2 <= 12u);
 }
+// experimental: conversions of a key switch computed inside the forward transforms' column passes (default off)
+static bool ntt_prologue_supported(const fhe_ctx* c) {
+    static const bool on = env_u32("FHE_KS_FUSE_CONV", 0) != 0;
+    if (!on || c->logN <= (uint32_t)kTileLog || ntt_legacy() || !ntt_static())
+        return false;
+    const uint32_t t1 = ntt_t1(c->logN);
+    return t1 == 4u || t1 == 5u;
+}
 static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_t* xout, const uint32_t* limbIdx,
                           uint32_t nLimbs, uint32_t batch, void* stream, uint32_t inStride = 0, uint32_t inFirst = 0,
                           uint32_t outStride = 0, uint32_t outFirst = 0, const NttEpilogue* epi = nullptr,
-                          bool canonOut = true) {
+                          bool canonOut = true, const NttPrologue* pro = nullptr, const TwPair* fin = nullptr) {
     ARG_CHECK(c && xin && xout, "fhe_ntt: null argument");
     ARG_CHECK(batch >= 1, "fhe_ntt: batch must be >= 1");
     LimbSel sel;
@@ -770,7 +808,10 @@ static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_
         if (!inverse)
             schedule_fwd(p, logN, &bound);
         p.outBound = bound;
-        return launch_pass(c, p, inverse, xin, xout, sel, nLimbs, batch, canonOut, stream, inStride, inFirst, outStride, outFirst, epi);
+        if (pro && pro->nSrc)
+            return fail(FHE_ERR_UNSUPPORTED, "ntt: the conversion prologue needs a two-pass ring");
+        return launch_pass(c, p, inverse, xin, xout, sel, nLimbs, batch, canonOut, stream, inStride, inFirst, outStride, outFirst, epi,
+                           nullptr, fin);
     }
     // two passes over HBM: a strided column pass of T1 stages (the coefficient index's top bits) and a
     // contiguous row pass of T2 = logN - T1 stages.  T1 is kept minimal (>= 4) so that the column pass reads
@@ -794,9 +835,12 @@ static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_
     // (profiles/r01_sweeps.md): two streams (the hardware does not co-schedule two grids that each fill the chip) and
     // one grid whose workgroups alternate between the two roles (the waiting column workgroups take half of the four
     // resident slots of a CU away from the row workgroups: 33.2 ms instead of 30.4 ms per forward+inverse step).
-    if (fhe_status s = launch_pass(c, p1, inverse, xin, xout, sel, nLimbs, batch, false, stream, inStride, inFirst, outStride, outFirst))
+    // (the prologue belongs to the forward transform's first pass, the final constants to the inverse transform's last)
+    if (fhe_status s = launch_pass(c, p1, inverse, xin, xout, sel, nLimbs, batch, false, stream, inStride, inFirst, outStride, outFirst,
+                                   nullptr, inverse ? nullptr : pro, nullptr))
         return s;
-    return launch_pass(c, p2, inverse, xout, xout, sel, nLimbs, batch, canonOut, stream, outStride, outFirst, outStride, outFirst, epi);
+    return launch_pass(c, p2, inverse, xout, xout, sel, nLimbs, batch, canonOut, stream, outStride, outFirst, outStride, outFirst, epi,
+                       nullptr, inverse ? fin : nullptr);
 }
 
 extern "C" fhe_status fhe_ntt_fwd(fhe_ctx* c, uint64_t* x, const uint32_t* li, uint32_t nl, uint32_t b, void* st) {
@@ -1271,6 +1315,8 @@ struct fhe_ks_plan {
         std::map<uint64_t, fhe_conv*> downT;    // BGV: P -> Q_l with t^-1 (mod p_j) and t (mod q_i) folded in, per t
         TwPair* d_PInv = nullptr;               // [sizeQl] Shoup pairs of [P^-1]_{q_i}
         TwPair* d_PModq = nullptr;              // [sizeQl] Shoup pairs of [P]_{q_i} (built on first use)
+        TwPair* d_finY  = nullptr;              // [ctxLimbs][2]: inverse-NTT final constants times [Qhat_i^-1]_{q_i} of the limb's
+                                                // digit (Q limbs) / of the P basis (P limbs): FHE_KS_FUSE_CONV, built on first use
     };
     std::vector<Level*> levels;  // index sizeQl
     std::vector<void*> owned;
@@ -1472,6 +1518,52 @@ extern "C" size_t fhe_ks_workspace_bytes(const fhe_ks_plan* p, uint32_t sizeQl, 
 // INTT / conversion / NTT launches:
 //   mod_down_core: x[nTow][sizeQl+sizeP][N] -> md[nTow][sizeQl][N] = NTT(ApproxSwitchCRTBasis(INTT(P part)))
 //   mod_down_tail: out_i = (x_i - md_i) * [P^-1]_{q_i}     (or out_i += ... when `accumulate`)
+// experimental (FHE_KS_FUSE_CONV): the ModUp / ModDown conversions run inside the column pass of the forward transform
+// that follows them.  The inverse transform in front leaves y_i = x_i * [Qhat_i^-1]_{q_i} (the factor rides on its final
+// constants: the same residue as ModMulFastConst, dcrtpoly-impl.h:898-903), the column pass of every target limb sums
+// y_i * [Qhat_i]_{p_j} over the <= 8 source limbs (:905-912).
+static bool ks_fused_conv(const fhe_ks_plan* p, const fhe_ks_plan::Level* lv) {
+    if (!ntt_prologue_supported(p->ctx) || p->sizeP > 8u)
+        return false;
+    for (uint32_t sz : lv->partSize)
+        if (sz > 8u)
+            return false;
+    return true;
+}
+static fhe_status ks_fin_y(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const TwPair** out) {
+    if (!lv->d_finY) {
+        fhe_ctx* c = p->ctx;
+        std::vector<TwPair> t = c->h_fin;
+        auto fold = [&](uint32_t limb, uint64_t f) {
+            const uint64_t ql = c->q[limb];
+            for (int e = 0; e < 2; ++e) {
+                const uint64_t v = host::mulmod(t[2 * limb + e].w, f, ql);
+                t[2 * limb + e]  = TwPair{v, host::shoup(v, ql)};
+            }
+        };
+        for (uint32_t part = 0; part < lv->numParts; ++part) {
+            std::vector<uint64_t> src;
+            for (uint32_t i = 0; i < lv->partSize[part]; ++i)
+                src.push_back(c->q[p->alpha * part + i]);
+            for (uint32_t i = 0; i < lv->partSize[part]; ++i)
+                fold(p->alpha * part + i, host::invmod(host::prod_mod(src, (int)i, src[i]), src[i]));
+        }
+        std::vector<uint64_t> pm;
+        for (uint32_t j = 0; j < p->sizeP; ++j)
+            pm.push_back(c->q[p->sizeQ + j]);
+        for (uint32_t j = 0; j < p->sizeP; ++j)
+            fold(p->sizeQ + j, host::invmod(host::prod_mod(pm, (int)j, pm[j]), pm[j]));
+        void* d = nullptr;
+        RT_CHECK(rt::dmalloc(&d, t.size() * sizeof(TwPair)));
+        p->owned.push_back(d);
+        RT_CHECK(rt::h2d(d, t.data(), t.size() * sizeof(TwPair), nullptr));
+        RT_CHECK(rt::sync(nullptr));
+        lv->d_finY = (TwPair*)d;
+    }
+    *out = lv->d_finY;
+    return FHE_OK;
+}
+
 static fhe_status mod_down_core(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const uint64_t* x, uint32_t nTow, uint64_t* pcoef,
                                 uint64_t* md, void* st, fhe_conv* down = nullptr, const NttEpilogue* epi = nullptr) {
     fhe_ctx* c            = p->ctx;
@@ -1479,6 +1571,18 @@ static fhe_status mod_down_core(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const ui
     std::vector<uint32_t> pIdx(sizeP);
     for (uint32_t j = 0; j < sizeP; ++j)
         pIdx[j] = p->sizeQ + j;
+    if (!down && ks_fused_conv(p, lv)) {
+        const TwPair* finY = nullptr;
+        if (fhe_status s = ks_fin_y(p, lv, &finY))
+            return s;
+        // INTT of the P part with [Phat_j^-1]_{p_j} on its final constants, then the forward transform over Q_l whose
+        // column pass computes the converted residues itself (and whose row pass carries the epilogue as before)
+        if (fhe_status s = ntt_run(c, true, x, pcoef, pIdx.data(), sizeP, nTow, st, sizeQlP, sizeQl, 0, 0, nullptr, true, nullptr, finY))
+            return s;
+        NttPrologue pro;
+        pro.nSrc = sizeP, pro.stride = sizeP, pro.first = 0, pro.y = pcoef, pro.h = lv->down->tb.hatMod;
+        return ntt_run(c, false, md, md, nullptr, sizeQl, nTow, st, 0, 0, 0, 0, epi, true, &pro);
+    }
     // P part to COEFFICIENT (:978-985): INTT of rows [sizeQl, sizeQl+sizeP) of every tower, written densely
     if (fhe_status s = ntt_run(c, true, x, pcoef, pIdx.data(), sizeP, nTow, st, sizeQlP, sizeQl))
         return s;
@@ -1510,6 +1614,22 @@ static fhe_status ks_precompute_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, cons
                                     uint64_t* ws, const KsLayout& w, void* st) {
     fhe_ctx* c            = p->ctx;
     const uint32_t sizeQl = lv->sizeQl;
+    if (ks_fused_conv(p, lv)) {
+        const TwPair* finY = nullptr;
+        if (fhe_status s = ks_fin_y(p, lv, &finY))
+            return s;
+        if (fhe_status s = ntt_run(c, true, cin, ws + w.coef, nullptr, sizeQl, batch, st, 0, 0, 0, 0, nullptr, true, nullptr, finY))
+            return s;
+        for (uint32_t j = 0; j < lv->numParts; ++j) {
+            NttPrologue pro;
+            pro.nSrc = lv->partSize[j], pro.stride = sizeQl, pro.first = p->alpha * j, pro.y = ws + w.coef, pro.h = lv->up[j]->tb.hatMod;
+            uint64_t* dj = ws + w.dig[j];
+            if (fhe_status s = ntt_run(c, false, dj, dj, lv->cidx[j].data(), (uint32_t)lv->cidx[j].size(), batch, st, 0, 0, 0, 0,
+                                       nullptr, false, &pro))
+                return s;
+        }
+        return FHE_OK;
+    }
     if (fhe_status s = fhe_ntt_inv_oop(c, cin, ws + w.coef, nullptr, sizeQl, batch, st))
         return s;
     for (uint32_t j = 0; j < lv->numParts; ++j) {

@@ -87,6 +87,15 @@ struct NttPassArgs {
     const uint64_t* epiA;
     const TwPair* epiC;
     uint64_t *epiOut0, *epiOut1;
+    // Optional prologue of a forward column pass (static kernels, experimental: FHE_KS_FUSE_CONV): the pass does not read
+    // its input but computes it as the CRT basis conversion  r = sum_i y_i * proH[row][i] mod q_row  from the proNSrc <= 8
+    // rows proFirst.. of the [batch][proStride][N] view proY (y_i = x_i * [Qhat_i^-1]_{q_i}, left there by an inverse
+    // transform whose final constant carries that factor): ApproxSwitchCRTBasis (dcrtpoly-impl.h:888-915) inside the
+    // HBM-bound pass instead of in a kernel of its own.  proH: [nLimbs][8] (ConvTables::hatMod), mu128: [ctxLimbs][2].
+    uint32_t proNSrc, proStride, proFirst;
+    const uint64_t* proY;
+    const uint64_t* proH;
+    const uint64_t* mu128;
 };
 
 // LDS word index swizzle: conflict-free ds_read_b64/ds_write_b64 for every register-field position

@@ -422,15 +422,21 @@ FHE_HD void lane_geom_s(uint32_t t, uint32_t S, uint32_t& Ib, uint32_t& jrel, ui
 // (its top stage is the transform's last stage, with N^-1 folded in), 0 = it does not.
 // DB: two LDS buffers alternate (one barrier per exchange, 68 KiB, 2 workgroups per CU) instead of one buffer with a
 // barrier on either side of the exchange (34 KiB, 4 workgroups per CU).
-template <bool LA, bool INV, int T, int MODE, bool DB, bool EPI = false>
+template <bool LA, bool INV, int T, int MODE, bool DB, bool EPI = false, bool PRO = false>
 FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) {
+    static_assert(!PRO || (LA && !INV && !EPI), "the conversion prologue belongs to a forward column pass");
     using P = SPlan<LA, INV, T>;
     const uint32_t t    = FHE_TID;
     const uint32_t logN = a.logN;
     const uint32_t N    = 1u << logN;
     const uint32_t tilesPerRow = N >> kTileLog;
     uint32_t tile = bid;
-    if (a.xcdSwizzle) {
+    if (PRO && a.xcdSwizzle == 2u) {  // prologue: the nLimbs workgroups that convert the same source tile take one XCD's slots
+        const uint32_t xcd = tile & 7u, i = tile >> 3;
+        const uint32_t l = i % a.nLimbs, grp = (i / a.nLimbs) * 8u + xcd;  // grp runs over batch x tilesPerRow
+        tile = ((grp / tilesPerRow) * a.nLimbs + l) * tilesPerRow + grp % tilesPerRow;
+    }
+    else if (a.xcdSwizzle) {
         const uint32_t xcd = tile & 7u, i = tile >> 3;
         const uint32_t b = i % a.batch, pairIdx = i / a.batch;
         const uint32_t pair = pairIdx * 8u + xcd;
@@ -535,6 +541,35 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
         }
     };
 
+    // first load of the pass: the tower's residues, or (PRO) their conversion from the source limbs
+    auto load_input = [&](uint64_t (&v)[16], uint32_t jr, uint64_t kstr) {
+        if constexpr (!PRO) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                v[k] = src[jr + k * kstr];
+        }
+        else {
+            uint64_t h[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                h[i] = FHE_ULOAD64(a.proH, (uint64_t)rit * 8u + i);  // zero beyond proNSrc
+            const uint64_t mulo = FHE_ULOAD64(a.mu128, 2 * (uint64_t)limb), muhi = FHE_ULOAD64(a.mu128, 2 * (uint64_t)limb + 1);
+            const uint32_t kq   = 64u - (uint32_t)__builtin_clzll(q);
+            const uint64_t* yb  = a.proY + (((uint64_t)tb * a.proStride + a.proFirst) << logN) + jbase;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                sum8 sacc;
+                sum8_clear(sacc);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t rowi = (uint32_t)i < a.proNSrc ? (uint32_t)i : a.proNSrc - 1u;  // unconditional loads
+                    sum8_add(sacc, yb[((uint64_t)rowi << logN) + jr + k * kstr], h[i]);
+                }
+                v[k] = sum8_reduce(sacc, q, kq, mulo, muhi);
+            }
+        }
+    };
+
 #define FHE_SHARED_TW_TO_LDS()                                             \
     if constexpr (useShared) {                                             \
         if (t < (uint32_t)SS::total)                                       \
@@ -547,9 +582,7 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
     // ---- first load ----
     if constexpr (P::stageFirst) {
         lane_geom_s<LA, T, 8>(t, S, Ib, jrel, ks);
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-            r[k] = src[jrel + k * ks];
+        load_input(r, jrel, ks);
         FHE_SHARED_TW_TO_LDS()
         uint64_t* L = lds + buf * kLdsPadWords + lds_pad(Ib);
 #pragma unroll
@@ -563,7 +596,7 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
         constexpr int fI = P::fI(I);                                                                              \
         lane_geom_s<LA, T, fI>(t, S, Ib, jrel, ks);                                                               \
         if constexpr (I == 0 && !P::stageFirst) {                                                                 \
-            _Pragma("unroll") for (int k = 0; k < 16; ++k) r[k] = src[jrel + k * ks];                             \
+            load_input(r, jrel, ks);                                                                              \
             FHE_SHARED_TW_TO_LDS()                                                                                \
         }                                                                                                         \
         else {                                                                                                    \
@@ -620,14 +653,14 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
     }
 }
 
-template <bool LA, bool INV, int T, int MODE, bool DB, bool EPI = false>
+template <bool LA, bool INV, int T, int MODE, bool DB, bool EPI = false, bool PRO = false>
 FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_static_kernel(const NttPassArgs a) {
     // a single-step pass without staging (the 4-stage column pass) never touches LDS: do not reserve any, so that
     // more workgroups fit on a CU
     using P = SPlan<LA, INV, T>;
     constexpr bool needsLds = P::nst > 1 || P::stageFirst || P::stageLast;
     FHE_SHARED_U64(lds, needsLds ? (DB ? 2 : 1) * kLdsPadWords + kSharedTwWords : 1);
-    ntt_static_body<LA, INV, T, MODE, DB, EPI>(a, FHE_BID, lds);
+    ntt_static_body<LA, INV, T, MODE, DB, EPI, PRO>(a, FHE_BID, lds);
 }
 
 }  // namespace fhe

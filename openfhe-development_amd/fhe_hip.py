@@ -143,6 +143,7 @@ class Lib:
         S("fhe_param_dcrt_chain", C.c_int, [u32, u32, u32, u64p, u64p])
         S("fhe_param_select_p", u32, [u32, u32, u64p, u32, u32, u64p, u64p])
         S("fhe_param_find_automorphism_index_2n_complex", u32, [C.c_int32, u32])
+        S("fhe_debug_fused_conv_launches", C.c_uint64, [])
         S("fhe_time_ntt", C.c_int, [vp, vp, u32p, u32, u32, C.c_int, C.c_int, vp, C.POINTER(C.c_float)])
 
     def check(self, status):

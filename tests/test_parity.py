@@ -469,3 +469,17 @@ def test_graph_capture_replays_eval_mult(oracle):
     plan.close()
     ctx.close()
     o.orc_hybrid_destroy(hy)
+
+
+def test_fused_conversion_path_on_emulator(backend):
+    """experimental FHE_KS_FUSE_CONV=1 (ModUp / ModDown conversions inside the NTT column passes; default off, not yet
+    measured on the GPU): bit-exact against the oracle on two-pass rings, and the fused launches are really taken"""
+    import subprocess
+    import sys
+    if not is_emu(backend):
+        pytest.skip("emulator variant")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FHE_KS_FUSE_CONV="1", PYTHONPATH=os.pathsep.join([root, os.path.join(root, "tests")]))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "fused_conv_check.py"),
+                          os.path.join(root, "tests", "emu", "libfhe_emu.so")], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "fused_conv_check OK" in out.stdout, out.stdout + out.stderr
