@@ -48,9 +48,10 @@ struct ConvArgs {
 // NSRC = compile-time upper bound of the number of source limbs (8 or 16): y_i live in registers, the output limbs
 // are produced one at a time with a column-wise multiply-accumulate (mac192), so the kernel needs few registers
 // (high occupancy) and computes every y_i once.
-// SUM8: the column sums as chunks of <= 8 products with one 64-bit Barrett reduction each (sum8, modarith.h) instead of the
-// 192-bit accumulator with the generated reduction
-template <int NSRC, bool EXACT, bool SUM8 = false>
+// SUM8 = 1: the column sums as chunks of <= 8 products with one 64-bit Barrett reduction each (sum8, modarith.h) instead of
+// the 192-bit accumulator with the generated reduction (0); 2: the same with both factors split at 30 bits, which needs
+// no carry bookkeeping at all (sum8s; experimental, FHE_CONV_SUM8=2)
+template <int NSRC, bool EXACT, int SUM8 = 0>
 FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) switch_basis_kernel(const ConvArgs g) {
     const uint32_t N     = 1u << g.logN;
     const uint64_t gid   = (uint64_t)FHE_BID * kThreads + FHE_TID;  // over batch*N coefficients
@@ -99,7 +100,31 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) switch_basis_kernel(const ConvArgs g
             h[i] = FHE_ULOAD64(g.tb.hatMod, (uint64_t)j * NSRC + i);
         const uint64_t p = FHE_ULOAD64(g.tb.dstQ, j);
         const uint64_t mulo = FHE_ULOAD64(g.tb.dstMu, 2 * j), muhi = FHE_ULOAD64(g.tb.dstMu, 2 * j + 1);
-        if (SUM8) {
+        if (SUM8 == 2) {
+            const uint32_t k = 64u - (uint32_t)__builtin_clzll(p);
+            uint64_t v       = 0;
+#pragma unroll
+            for (int c0 = 0; c0 < NSRC; c0 += 8) {
+                if (c0 && c0 >= (int)g.nSrc)
+                    break;
+                sum8s s8;
+                sum8s_clear(s8);
+#pragma unroll
+                for (int i = c0; i < c0 + 8 && i < NSRC; ++i) {
+                    uint32_t y0, y1, h0, h1;
+                    split30(y[i], y0, y1);  // (loop-invariant over j: hoisted by the compiler; y[i] = 0 beyond nSrc)
+                    split30(h[i], h0, h1);  // wave-uniform: scalar unit
+                    sum8s_add(s8, y0, y1, h0, h1);
+                }
+                const uint64_t rj = sum8s_reduce(s8, p, k, mulo, muhi);
+                v                 = c0 ? add_mod(v, rj, p) : rj;
+            }
+            if (EXACT)
+                v = sub_mod(v, g.tb.alphaMod[(uint64_t)alpha * g.nDst + j], p);
+            out[(uint64_t)j << g.logN] = v;
+            continue;
+        }
+        if (SUM8 == 1) {
             const uint32_t k = 64u - (uint32_t)__builtin_clzll(p);
             uint64_t v       = 0;
 #pragma unroll

@@ -1226,19 +1226,21 @@ static fhe_status conv_run(fhe_conv* cv, const uint64_t* in, uint32_t inStride, 
     const uint64_t coeffs = (uint64_t)batch << g.logN;
     const uint32_t grid   = (uint32_t)((coeffs + kThreads - 1) / kThreads);
     const uint32_t pad = conv_nsrc_pad(cv->nSrc);
-    static const bool sum8 = env_u32("FHE_CONV_SUM8", 1) != 0;
-    if (pad == 8 && sum8)
-        FHE_LAUNCH((switch_basis_kernel<8, EXACT, true>), grid, st, g);
+    static const uint32_t sum8 = env_u32("FHE_CONV_SUM8", 1);  // 0: 192-bit accumulator, 1: sum8 (default), 2: 30-bit split (experimental)
+    if (pad == 8 && sum8 == 2)
+        FHE_LAUNCH((switch_basis_kernel<8, EXACT, 2>), grid, st, g);
+    else if (pad == 8 && sum8)
+        FHE_LAUNCH((switch_basis_kernel<8, EXACT, 1>), grid, st, g);
     else if (pad == 8)
-        FHE_LAUNCH((switch_basis_kernel<8, EXACT>), grid, st, g);
+        FHE_LAUNCH((switch_basis_kernel<8, EXACT, 0>), grid, st, g);
     else if (pad == 16 && sum8)
-        FHE_LAUNCH((switch_basis_kernel<16, EXACT, true>), grid, st, g);
+        FHE_LAUNCH((switch_basis_kernel<16, EXACT, 1>), grid, st, g);
     else if (pad == 16)
-        FHE_LAUNCH((switch_basis_kernel<16, EXACT>), grid, st, g);
+        FHE_LAUNCH((switch_basis_kernel<16, EXACT, 0>), grid, st, g);
     else if (sum8)
-        FHE_LAUNCH((switch_basis_kernel<32, EXACT, true>), grid, st, g);
+        FHE_LAUNCH((switch_basis_kernel<32, EXACT, 1>), grid, st, g);
     else
-        FHE_LAUNCH((switch_basis_kernel<32, EXACT>), grid, st, g);
+        FHE_LAUNCH((switch_basis_kernel<32, EXACT, 0>), grid, st, g);
     LAUNCH_CHECK();
     return FHE_OK;
 }

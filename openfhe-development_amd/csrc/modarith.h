@@ -209,6 +209,36 @@ FHE_HD uint64_t sum8_reduce(const sum8& s, uint64_t q, uint32_t k, uint64_t mu_l
     return r;
 }
 
+// The same sums with both factors split at 30 bits (x = x1*2^30 + x0 for x < 2^60): every partial product is below 2^60,
+// so <= 8 terms accumulate in three plain 64-bit columns with NO carry bookkeeping at all (4 multiply-adds per term);
+// S = c0 + c1*2^30 + c2*2^60 is assembled once.  A wave-uniform factor is split once per table entry, a per-lane factor
+// once per loaded residue.  (experimental: FHE_CONV_SUM8=2; not yet measured on the GPU)
+struct sum8s {
+    uint64_t c0, c1, c2;
+};
+FHE_HD void sum8s_clear(sum8s& s) { s.c0 = s.c1 = s.c2 = 0; }
+FHE_HD void split30(uint64_t x, uint32_t& x0, uint32_t& x1) {
+    x0 = (uint32_t)x & 0x3fffffffu;
+    x1 = (uint32_t)(x >> 30);
+}
+FHE_HD void sum8s_add(sum8s& s, uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1) {
+    s.c0 += (uint64_t)x0 * y0;
+    s.c1 += (uint64_t)x0 * y1;
+    s.c1 += (uint64_t)x1 * y0;
+    s.c2 += (uint64_t)x1 * y1;
+}
+FHE_HD uint64_t sum8s_reduce(const sum8s& s, uint64_t q, uint32_t k, uint64_t mu_lo, uint64_t mu_hi) {
+    const uint64_t t1 = s.c1 << 30, l1 = s.c0 + t1, t2 = s.c2 << 60, lo = l1 + t2;
+    const uint64_t hi = (s.c1 >> 34) + (s.c2 >> 4) + (l1 < t1) + (lo < t2);
+    const uint32_t sh = 65u - k;
+    const uint64_t mu = (mu_lo >> sh) | (mu_hi << (64u - sh));
+    const uint64_t sv = (lo >> (k - 1u)) | (hi << sh);
+    uint64_t r        = lo - mulhi64(sv, mu) * q;
+    r -= r >= q ? q : 0;
+    r -= r >= q ? q : 0;
+    return r;
+}
+
 // a (128-bit) mod q with mu = floor(2^128/q) given as (mu_lo, mu_hi).
 // Same quotient estimate as BarrettUint128ModUint64 (utils/utilities-int.h:60-99): the low word of
 // floor(a*mu / 2^128), then r = a_lo - quot*q and final corrective subtractions.

@@ -23,6 +23,8 @@ int main() {
             const int n = 1 + (int)(gen() % 8);
             fhe::sum8 s;
             fhe::sum8_clear(s);
+            fhe::sum8s s30;
+            fhe::sum8s_clear(s30);
             u128 S = 0;
             for (int i = 0; i < n; ++i) {
                 uint64_t a = gen() >> 4, b = gen() % q;  // a < 2^60, b < q
@@ -31,9 +33,19 @@ int main() {
                 if (rep % 7 == 1)
                     a = gen() % q;  // a product of two residues
                 fhe::sum8_add(s, a, b);
+                uint32_t a0, a1, b0, b1;
+                fhe::split30(a, a0, a1);
+                fhe::split30(b, b0, b1);
+                fhe::sum8s_add(s30, a0, a1, b0, b1);
                 S += (u128)a * b;
             }
             const uint64_t got = fhe::sum8_reduce(s, q, k, mulo, muhi), want = (uint64_t)(S % q);
+            const uint64_t got30 = fhe::sum8s_reduce(s30, q, k, mulo, muhi);
+            if (got30 != want) {
+                std::printf("sum8s mismatch: k=%u q=%llu n=%d got=%llu want=%llu\n", k, (unsigned long long)q, n,
+                            (unsigned long long)got30, (unsigned long long)want);
+                return 2;
+            }
             if (got != want) {
                 std::printf("sum8 mismatch: k=%u q=%llu n=%d got=%llu want=%llu\n", k, (unsigned long long)q, n,
                             (unsigned long long)got, (unsigned long long)want);

@@ -483,3 +483,20 @@ def test_fused_conversion_path_on_emulator(backend):
     out = subprocess.run([sys.executable, os.path.join(root, "tests", "fused_conv_check.py"),
                           os.path.join(root, "tests", "emu", "libfhe_emu.so")], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "fused_conv_check OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("variant", ["0", "2"])
+def test_conversion_kernel_variants_on_emulator(backend, variant):
+    """the non-default column-sum variants of the basis-conversion kernel (FHE_CONV_SUM8 is read once per process: 0 = 192-bit
+    accumulator + generated reduction, 2 = 30-bit split without carries, experimental) against the oracle, through the
+    regular conversion / key-switch parity tests in a child process"""
+    import subprocess
+    import sys
+    if not is_emu(backend):
+        pytest.skip("emulator variant")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FHE_CONV_SUM8=variant)
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_parity.py"), "-q", "-x", "-m", "not gpu",
+                          "-k", "test_approx_and_exact_switch_crt_basis or (test_hybrid_keyswitch_and_eval_mult and 12-6)"],
+                         env=env, capture_output=True, text=True, timeout=1200, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
