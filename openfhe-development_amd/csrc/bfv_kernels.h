@@ -229,6 +229,7 @@ FHE_HD void load_rows(uint64_t (&x)[kMaxBfvLimbs], const TowerView v, uint32_t b
         x[i] = *tv_at(v, b, (uint32_t)i < n ? (uint32_t)i : n - 1u, logN, ri);
 }
 // sum_i y_i * row[i] mod m for the first n entries of a [.][kMaxBfvLimbs] table row (128-bit sum, then Barrett)
+template <bool SPLIT30 = false>
 FHE_HD uint64_t dot_row_mod(const uint64_t (&y)[kMaxBfvLimbs], const uint64_t* row, uint32_t n, uint64_t m, uint64_t mulo,
                             uint64_t muhi) {
     uint64_t h[kMaxBfvLimbs];
@@ -242,19 +243,36 @@ FHE_HD uint64_t dot_row_mod(const uint64_t (&y)[kMaxBfvLimbs], const uint64_t* r
     for (int c0 = 0; c0 < kMaxBfvLimbs; c0 += 8) {
         if (c0 && c0 >= (int)n)
             break;
-        sum8 s;
-        sum8_clear(s);
+        uint64_t r;
+        if (SPLIT30) {  // experimental (FHE_CONV_SUM8=2): both factors split at 30 bits, no carry bookkeeping (sum8s)
+            sum8s s;
+            sum8s_clear(s);
 #pragma unroll
-        for (int i = c0; i < c0 + 8 && i < kMaxBfvLimbs; ++i)
-            if (i < (int)n)
-                sum8_add(s, y[i], h[i]);
-        const uint64_t r = sum8_reduce(s, m, k, mulo, muhi);
-        v                = c0 ? add_mod(v, r, m) : r;
+            for (int i = c0; i < c0 + 8 && i < kMaxBfvLimbs; ++i)
+                if (i < (int)n) {
+                    uint32_t y0, y1, h0, h1;
+                    split30(y[i], y0, y1);
+                    split30(h[i], h0, h1);
+                    sum8s_add(s, y0, y1, h0, h1);
+                }
+            r = sum8s_reduce(s, m, k, mulo, muhi);
+        }
+        else {
+            sum8 s;
+            sum8_clear(s);
+#pragma unroll
+            for (int i = c0; i < c0 + 8 && i < kMaxBfvLimbs; ++i)
+                if (i < (int)n)
+                    sum8_add(s, y[i], h[i]);
+            r = sum8_reduce(s, m, k, mulo, muhi);
+        }
+        v = c0 ? add_mod(v, r, m) : r;
     }
     return v;
 }
 
 // core of FastBaseConvqToBskMontgomery: inQ (COEFF) -> outBsk (COEFF)
+template <bool SPLIT30 = false>
 FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) behz_q_to_bsk_kernel(const BehzArgs g) {
     const uint64_t gid = (uint64_t)FHE_BID * kThreads + FHE_TID;
     if (gid >= ((uint64_t)g.batch << g.logN))
@@ -279,7 +297,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) behz_q_to_bsk_kernel(const BehzArgs 
     for (uint32_t j = 0; j < g.tb.numBsk; ++j) {
         const uint64_t bj = FHE_ULOAD64(g.tb.bsk, j);
         const TwPair cq = uload_pair(g.tb.QModbsk, j), cm = uload_pair(g.tb.mtInvModbsk, j);
-        const uint64_t v = dot_row_mod(y, g.tb.QHatModbsk + (uint64_t)j * kMaxBfvLimbs, g.tb.numQ, bj,
+        const uint64_t v = dot_row_mod<SPLIT30>(y, g.tb.QHatModbsk + (uint64_t)j * kMaxBfvLimbs, g.tb.numQ, bj,
                                        FHE_ULOAD64(g.tb.muBsk, 2 * j), FHE_ULOAD64(g.tb.muBsk, 2 * j + 1));
         uint64_t r       = rm;
         if (rm >= half)
@@ -291,6 +309,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) behz_q_to_bsk_kernel(const BehzArgs 
 }
 
 // FastRNSFloorq, in place on the Q and Bsk limbs (COEFF)
+template <bool SPLIT30 = false>
 FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) behz_floorq_kernel(const BehzArgs g) {
     const uint64_t gid = (uint64_t)FHE_BID * kThreads + FHE_TID;
     if (gid >= ((uint64_t)g.batch << g.logN))
@@ -313,7 +332,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) behz_floorq_kernel(const BehzArgs g)
         if (j < (int)g.tb.numBsk) {
             const uint64_t bj = FHE_ULOAD64(g.tb.bsk, j);
             const TwPair c    = uload_pair(g.tb.tQInvModbsk, j);
-            const uint64_t s  = dot_row_mod(y, g.tb.qInvModbsk + (uint64_t)j * kMaxBfvLimbs, g.tb.numQ, bj,
+            const uint64_t s  = dot_row_mod<SPLIT30>(y, g.tb.qInvModbsk + (uint64_t)j * kMaxBfvLimbs, g.tb.numQ, bj,
                                             FHE_ULOAD64(g.tb.muBsk, 2 * j), FHE_ULOAD64(g.tb.muBsk, 2 * j + 1));
             const uint64_t v  = mul_shoup(xb[j], c.w, c.wp, bj);
             *tv_at(g.outBsk, b, j, g.logN, ri) = sub_mod(v, s, bj);
@@ -322,6 +341,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) behz_floorq_kernel(const BehzArgs g)
 }
 
 // FastBaseConvSK: inBsk (COEFF) -> outQ (COEFF)
+template <bool SPLIT30 = false>
 FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) behz_conv_sk_kernel(const BehzArgs g) {
     const uint64_t gid = (uint64_t)FHE_BID * kThreads + FHE_TID;
     if (gid >= ((uint64_t)g.batch << g.logN))
@@ -349,7 +369,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) behz_conv_sk_kernel(const BehzArgs g
     for (uint32_t j = 0; j < g.tb.numQ; ++j) {
         const uint64_t qj = FHE_ULOAD64(g.tb.q, j);
         const TwPair c    = uload_pair(g.tb.BModq, j);
-        const uint64_t v  = dot_row_mod(y, g.tb.BHatModq + (uint64_t)j * kMaxBfvLimbs, numB, qj,
+        const uint64_t v  = dot_row_mod<SPLIT30>(y, g.tb.BHatModq + (uint64_t)j * kMaxBfvLimbs, numB, qj,
                                         FHE_ULOAD64(g.tb.muQ, 2 * j), FHE_ULOAD64(g.tb.muQ, 2 * j + 1));
         uint64_t a        = alpha;
         if (a > mskHalf)

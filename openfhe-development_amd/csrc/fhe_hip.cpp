@@ -2666,6 +2666,10 @@ extern "C" void fhe_behz_destroy(fhe_behz* h) {
         rt::dfree(p);
     delete h;
 }
+static bool behz_split30() {  // experimental: the BEHZ dot products with 30-bit split factors (same knob as the conversion kernel)
+    static const bool on = env_u32("FHE_CONV_SUM8", 1) == 2u;
+    return on;
+}
 static uint32_t coeff_grid(const fhe_ctx* c, uint32_t batch) {
     return (uint32_t)((((uint64_t)batch << c->logN) + kThreads - 1) / kThreads);
 }
@@ -2690,13 +2694,19 @@ extern "C" fhe_status fhe_behz_q_to_bsk(fhe_behz* h, uint64_t* x, int evalFormat
         if (fhe_status s = ntt_run(c, true, x, coef, h->qIdx.data(), h->numQ, batch, st, tot, 0))  // :1708-1712
             return s;
         g.inQ = TowerView{coef, h->numQ, 0};
-        FHE_LAUNCH(behz_q_to_bsk_kernel, coeff_grid(c, batch), st, g);
+        if (behz_split30())
+            FHE_LAUNCH((behz_q_to_bsk_kernel<true>), coeff_grid(c, batch), st, g);
+        else
+            FHE_LAUNCH((behz_q_to_bsk_kernel<false>), coeff_grid(c, batch), st, g);
         LAUNCH_CHECK();
         // only the new Bsk limbs go to EVALUATION; the Q limbs keep their original NTT form (:1776-1780)
         return ntt_run(c, false, x, x, h->bskIdx.data(), h->numBsk, batch, st, tot, h->numQ, tot, h->numQ);
     }
     g.inQ = TowerView{x, tot, 0};
-    FHE_LAUNCH(behz_q_to_bsk_kernel, coeff_grid(c, batch), st, g);
+    if (behz_split30())
+        FHE_LAUNCH((behz_q_to_bsk_kernel<true>), coeff_grid(c, batch), st, g);
+    else
+        FHE_LAUNCH((behz_q_to_bsk_kernel<false>), coeff_grid(c, batch), st, g);
     LAUNCH_CHECK();
     return fhe_ntt_fwd(c, x, h->allIdx.data(), tot, batch, st);  // every limb to EVALUATION (:1774, :1781-1785)
 }
@@ -2709,7 +2719,10 @@ extern "C" fhe_status fhe_behz_floorq(fhe_behz* h, uint64_t* x, uint32_t batch, 
     g.tb = h->tb, g.logN = h->ctx->logN, g.batch = batch;
     g.inQ = g.outQ = TowerView{x, tot, 0};
     g.inBsk = g.outBsk = TowerView{x, tot, h->numQ};
-    FHE_LAUNCH(behz_floorq_kernel, coeff_grid(h->ctx, batch), st, g);
+    if (behz_split30())
+        FHE_LAUNCH((behz_floorq_kernel<true>), coeff_grid(h->ctx, batch), st, g);
+    else
+        FHE_LAUNCH((behz_floorq_kernel<false>), coeff_grid(h->ctx, batch), st, g);
     LAUNCH_CHECK();
     return FHE_OK;
 }
@@ -2723,7 +2736,10 @@ extern "C" fhe_status fhe_behz_conv_sk(fhe_behz* h, const uint64_t* x, uint64_t*
     uint64_t* xm = const_cast<uint64_t*>(x);
     g.inQ = TowerView{xm, tot, 0}, g.inBsk = TowerView{xm, tot, h->numQ};
     g.outQ = TowerView{out, h->numQ, 0}, g.outBsk = g.inBsk;
-    FHE_LAUNCH(behz_conv_sk_kernel, coeff_grid(h->ctx, batch), st, g);
+    if (behz_split30())
+        FHE_LAUNCH((behz_conv_sk_kernel<true>), coeff_grid(h->ctx, batch), st, g);
+    else
+        FHE_LAUNCH((behz_conv_sk_kernel<false>), coeff_grid(h->ctx, batch), st, g);
     LAUNCH_CHECK();
     return FHE_OK;
 }
