@@ -500,3 +500,7 @@ def test_conversion_kernel_variants_on_emulator(backend, variant):
                           "-k", "test_approx_and_exact_switch_crt_basis or (test_hybrid_keyswitch_and_eval_mult and 12-6)"],
                          env=env, capture_output=True, text=True, timeout=1200, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    if variant == "2":  # the same knob switches the BEHZ dot products of the BFV multiplication
+        out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_parity_bfv.py"), "-q", "-x", "-m",
+                              "not gpu", "-k", "behz or eval_mult"], env=env, capture_output=True, text=True, timeout=1200, cwd=root)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
