@@ -556,16 +556,22 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
             const uint64_t mulo = FHE_ULOAD64(a.mu128, 2 * (uint64_t)limb), muhi = FHE_ULOAD64(a.mu128, 2 * (uint64_t)limb + 1);
             const uint32_t kq   = 64u - (uint32_t)__builtin_clzll(q);
             const uint64_t* yb  = a.proY + (((uint64_t)tb * a.proStride + a.proFirst) << logN) + jbase;
+            uint32_t h0[8], h1[8];  // factors split at 30 bits: no carry bookkeeping in the sums (sum8s, modarith.h)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                split30(h[i], h0[i], h1[i]);
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                sum8 sacc;
-                sum8_clear(sacc);
+                sum8s sacc;
+                sum8s_clear(sacc);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const uint32_t rowi = (uint32_t)i < a.proNSrc ? (uint32_t)i : a.proNSrc - 1u;  // unconditional loads
-                    sum8_add(sacc, yb[((uint64_t)rowi << logN) + jr + k * kstr], h[i]);
+                    uint32_t y0, y1;
+                    split30(yb[((uint64_t)rowi << logN) + jr + k * kstr], y0, y1);
+                    sum8s_add(sacc, y0, y1, h0[i], h1[i]);
                 }
-                v[k] = sum8_reduce(sacc, q, kq, mulo, muhi);
+                v[k] = sum8s_reduce(sacc, q, kq, mulo, muhi);
             }
         }
     };
