@@ -541,14 +541,9 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
         }
     };
 
-    // first load of the pass: the tower's residues, or (PRO) their conversion from the source limbs
-    auto load_input = [&](uint64_t (&v)[16], uint32_t jr, uint64_t kstr) {
-        if constexpr (!PRO) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                v[k] = src[jr + k * kstr];
-        }
-        else {
+    // (PRO) first load of the pass: instead of the tower's residues, their conversion from the source limbs
+    auto load_converted = [&](uint64_t (&v)[16], uint32_t jr, uint64_t kstr) {
+        if constexpr (PRO) {
             uint64_t h[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i)
@@ -588,7 +583,13 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
     // ---- first load ----
     if constexpr (P::stageFirst) {
         lane_geom_s<LA, T, 8>(t, S, Ib, jrel, ks);
-        load_input(r, jrel, ks);
+        if constexpr (PRO)
+            load_converted(r, jrel, ks);
+        else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                r[k] = src[jrel + k * ks];
+        }
         FHE_SHARED_TW_TO_LDS()
         uint64_t* L = lds + buf * kLdsPadWords + lds_pad(Ib);
 #pragma unroll
@@ -602,7 +603,11 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
         constexpr int fI = P::fI(I);                                                                              \
         lane_geom_s<LA, T, fI>(t, S, Ib, jrel, ks);                                                               \
         if constexpr (I == 0 && !P::stageFirst) {                                                                 \
-            load_input(r, jrel, ks);                                                                              \
+            if constexpr (PRO)                                                                                    \
+                load_converted(r, jrel, ks);                                                                      \
+            else {                                                                                                \
+                _Pragma("unroll") for (int k = 0; k < 16; ++k) r[k] = src[jrel + k * ks];                         \
+            }                                                                                                     \
             FHE_SHARED_TW_TO_LDS()                                                                                \
         }                                                                                                         \
         else {                                                                                                    \
