@@ -109,14 +109,25 @@ fhe_status fhe_mul(fhe_ctx* ctx, uint64_t* out, const uint64_t* a, const uint64_
 fhe_status fhe_neg(fhe_ctx* ctx, uint64_t* out, const uint64_t* a, const uint32_t* limbIdx, uint32_t nLimbs,
                    uint32_t batch, void* stream);
 /* Times(const std::vector<NativeInteger>&) / operator*=(NativeInteger) (dcrtpoly-impl.h:582-620):
- * consts[r] (HOST array, one per tower row, < q) multiplies limb r of every tower in the batch */
+ * consts[r] (HOST array, one per tower row) multiplies limb r of every tower in the batch.  The constants travel by value
+ * in the kernel arguments: the call is asynchronous like every other one and can be captured into a graph; the host
+ * array may be released as soon as the call returns. */
 fhe_status fhe_mul_const(fhe_ctx* ctx, uint64_t* out, const uint64_t* a, const uint64_t* consts,
                          const uint32_t* limbIdx, uint32_t nLimbs, uint32_t batch, void* stream);
+/* NativeVectorT::MultAccEqNoCheck per limb (src/core/lib/math/hal/intnat/mubintvecnat.cpp:132-142; PolyImpl wrapper
+ * poly.h:323): acc[r] += v[r] * consts[r]  (constant reduced mod q first, Shoup product, ModAddFast) */
+fhe_status fhe_mult_acc(fhe_ctx* ctx, uint64_t* acc, const uint64_t* v, const uint64_t* consts,
+                        const uint32_t* limbIdx, uint32_t nLimbs, uint32_t batch, void* stream);
 /* LeveledSHEBase::EvalMultCore (src/pke/lib/schemebase/base-leveledshe.cpp:607-644):
  * d0 = a0*b0, d1 = a0*b1 + a1*b0, d2 = a1*b1 */
 fhe_status fhe_tensor(fhe_ctx* ctx, const uint64_t* a0, const uint64_t* a1, const uint64_t* b0, const uint64_t* b1,
                       uint64_t* d0, uint64_t* d1, uint64_t* d2, const uint32_t* limbIdx, uint32_t nLimbs,
                       uint32_t batch, void* stream);
+
+/* LeveledSHEBase::EvalSquareCore for 2-element ciphertexts (base-leveledshe.cpp:646-664):
+ * d0 = a0*a0, d1 = a0*a1 + a0*a1, d2 = a1*a1 */
+fhe_status fhe_tensor_square(fhe_ctx* ctx, const uint64_t* a0, const uint64_t* a1, uint64_t* d0, uint64_t* d1, uint64_t* d2,
+                             const uint32_t* limbIdx, uint32_t nLimbs, uint32_t batch, void* stream);
 
 /* ---- a8: automorphism ----------------------------------------------------------------------------
  * Replaces DCRTPolyImpl::AutomorphismTransform(k[, precomp]) (dcrtpoly-impl.h:314-333) ->
@@ -132,6 +143,9 @@ fhe_status fhe_automorph(fhe_ctx* ctx, uint64_t* out, const uint64_t* in, uint32
 fhe_status fhe_switch_modulus(fhe_ctx* ctx, uint64_t* out, const uint32_t* limbIdx, uint32_t nLimbs,
                               const uint64_t* src, uint32_t srcLimbs, uint32_t srcPos, uint32_t srcCtxLimb,
                               uint32_t batch, void* stream);
+/* With srcLimbs = 1 this is also the "ModRaise" constructor DCRTPolyImpl(const PolyType&, params) (dcrtpoly-impl.h:87-93,
+ * used by FHECKKSRNS::EvalBootstrap, ckksrns-fhe.cpp:592-601): one COEFFICIENT polynomial modulo q_0 lifted, centred, into
+ * every limb of a tower. */
 
 /* ---- a10/a16: CRT basis conversion ------------------------------------------------------------------
  * fhe_conv_create builds the device tables for converting from the basis {srcLimbIdx} to {dstLimbIdx}
@@ -164,6 +178,16 @@ fhe_status fhe_conv_create_custom(fhe_ctx* ctx, const uint32_t* srcLimbIdx, uint
 size_t     fhe_expand_crt_basis_workspace_bytes(const fhe_conv* plan, uint32_t batch);
 fhe_status fhe_expand_crt_basis(fhe_conv* plan, const uint64_t* x, int inEval, uint64_t* out, int resultEval,
                                 int reverseOrder, uint32_t batch, void* ws, size_t wsBytes, void* stream);
+/* DCRTPolyImpl::ApproxModUp (dcrtpoly-impl.h:935-963): x [batch][nSrc][N] over the plan's source basis Q in format inEval ->
+ * out [batch][nSrc+nDst][N] over Q u P in EVALUATION (the P part is ApproxSwitchCRTBasis of the coefficient form; the
+ * EVALUATION copy of the Q limbs is reused when the input has one).  ws as for fhe_expand_crt_basis. */
+fhe_status fhe_mod_up(fhe_conv* plan, const uint64_t* x, int inEval, uint64_t* out, uint32_t batch, void* ws, size_t wsBytes,
+                      void* stream);
+/* DCRTPolyImpl::ExpandCRTBasisQlHat (dcrtpoly-impl.h:1167-1187): limbs [0, sizeQl) of x [batch][sizeQl][N] times
+ * QlHatModq[i] (HOST constants), limbs [sizeQl, sizeQ) zero -> out [batch][sizeQ][N] over context limbs limbIdx[0..sizeQ)
+ * (NULL = identity); the format is unchanged. */
+fhe_status fhe_expand_crt_basis_ql_hat(fhe_ctx* ctx, const uint64_t* x, uint32_t sizeQl, const uint64_t* QlHatModq,
+                                       const uint32_t* limbIdx, uint32_t sizeQ, uint32_t batch, uint64_t* out, void* stream);
 /* DCRTPolyImpl::FastExpandCRTBasisPloverQ (dcrtpoly-impl.h:1151-1164), COEFFICIENT format: toPl = custom-table plan
  * Q -> Pl (mPlQHatInvModq, qInvModp), toQl = plan Pl -> Ql; x [batch][nQ][N] -> out [batch][nQl+nPl][N] = [Ql | Pl]. */
 fhe_status fhe_fast_expand_crt_basis_p_over_q(fhe_conv* toPl, fhe_conv* toQl, const uint64_t* x, uint64_t* out,
@@ -371,11 +395,6 @@ uint32_t   fhe_param_select_p(uint32_t logN, uint32_t sizeQ, const uint64_t* q, 
 /* FindAutomorphismIndex2nComplex (src/core/lib/math/nbtheory2.cpp:243-262): automorphism index 5^index mod m of a CKKS
  * rotation by `index` slots (m = 2N, a power of two); 0 on error */
 uint32_t   fhe_param_find_automorphism_index_2n_complex(int32_t index, uint32_t m);
-
-/* ---- diagnostics -----------------------------------------------------------------------------------
- * number of forward column passes launched with the experimental conversion prologue (FHE_KS_FUSE_CONV=1: the ModUp /
- * ModDown basis conversions of a key switch computed inside the NTT's HBM-bound column pass; default off) */
-uint64_t   fhe_debug_fused_conv_launches(void);
 
 /* ---- measurement helper ----------------------------------------------------------------------------
  * Runs `iters` back-to-back launches of fwd (dir=0), inv (dir=1) or fwd+inv (dir=2) NTT on x — or of a single

@@ -45,13 +45,13 @@ struct ConvArgs {
     uint32_t inStride, inFirst, outStride, outFirst;
 };
 
-// NSRC = compile-time upper bound of the number of source limbs (8 or 16): y_i live in registers, the output limbs
-// are produced one at a time with a column-wise multiply-accumulate (mac192), so the kernel needs few registers
-// (high occupancy) and computes every y_i once.
-// SUM8 = 1: the column sums as chunks of <= 8 products with one 64-bit Barrett reduction each (sum8, modarith.h) instead of
-// the 192-bit accumulator with the generated reduction (0); 2: the same with both factors split at 30 bits, which needs
-// no carry bookkeeping at all (sum8s; experimental, FHE_CONV_SUM8=2)
-template <int NSRC, bool EXACT, int SUM8 = 0>
+// NSRC = compile-time upper bound of the number of source limbs (8, 16 or 32): y_i live in registers, the output limbs
+// are produced one at a time as column sums over chunks of <= 8 products with one 64-bit Barrett reduction each, so the
+// kernel needs few registers (high occupancy) and computes every y_i once.
+// SUM8 = 2 (default since round 2: EvalMult +2.8 %, BFV +1 % on MI355X, profiles/r02_sweeps.md): both factors split at 30
+// bits, no carry bookkeeping at all (sum8s, modarith.h); SUM8 = 1 (FHE_CONV_SUM8=1): plain 64-bit columns whose low one
+// counts its carries (sum8).  Both are exact; any exact reduction equals BarrettUint128ModUint64 (utilities-int.h:60-99).
+template <int NSRC, bool EXACT, int SUM8 = 2>
 FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) switch_basis_kernel(const ConvArgs g) {
     const uint32_t N     = 1u << g.logN;
     const uint64_t gid   = (uint64_t)FHE_BID * kThreads + FHE_TID;  // over batch*N coefficients
@@ -71,10 +71,6 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) switch_basis_kernel(const ConvArgs g
         const uint32_t row = (uint32_t)i < g.nSrc ? (uint32_t)i : g.nSrc - 1u;
         xin[i]             = in[(uint64_t)row << g.logN];
     }
-#ifdef FHE_PINNED_ASM
-    BflyZero z{0, 0};
-    asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0" : "={v65}"(z.z0), "={v81}"(z.z1));
-#endif
     uint64_t y[NSRC];
     // overflow count of the exact variant: nu = 0.5 + sum_i y_i/q_i in double, i ascending, one rounding per
     // multiply and per add (dcrtpoly-impl.h:1056-1063); compiled with -ffp-contract=off
@@ -124,7 +120,8 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) switch_basis_kernel(const ConvArgs g
             out[(uint64_t)j << g.logN] = v;
             continue;
         }
-        if (SUM8 == 1) {
+        {
+            static_assert(SUM8 == 1 || SUM8 == 2, "SUM8 selects one of the two column-sum forms");
             const uint32_t k = 64u - (uint32_t)__builtin_clzll(p);
             uint64_t v       = 0;
 #pragma unroll
@@ -142,28 +139,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) switch_basis_kernel(const ConvArgs g
             if (EXACT)
                 v = sub_mod(v, g.tb.alphaMod[(uint64_t)alpha * g.nDst + j], p);
             out[(uint64_t)j << g.logN] = v;
-            continue;
         }
-        mac192 m;
-        mac192_clear(m);
-#pragma unroll
-        for (int i = 0; i < NSRC; ++i)
-            if (i < (int)g.nSrc)
-                mac192_add_uniform(m, y[i], h[i]);
-#ifdef FHE_PINNED_ASM
-        // any exact reduction equals BarrettUint128ModUint64; this one is hi*[2^64]_p + lo with Shoup (generated asm)
-        (void)mulo, (void)muhi;
-        const uint64_t* rc = g.tb.dstRed + 4 * (uint64_t)j;
-        const Reduce192Const kc{p, FHE_ULOAD64(rc, 1), FHE_ULOAD64(rc, 2), FHE_ULOAD64(rc, 3)};
-        uint64_t v = reduce192_uniform(m.c0, m.c1, m.c2, m.k0, m.k1, kc, z);
-#else
-        u128w acc;
-        mac192_fold(m, acc.lo, acc.hi);
-        uint64_t v = barrett128(acc, p, mulo, muhi);
-#endif
-        if (EXACT)
-            v = sub_mod(v, g.tb.alphaMod[(uint64_t)alpha * g.nDst + j], p);
-        out[(uint64_t)j << g.logN] = v;
     }
 }
 

@@ -155,12 +155,12 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) scale_round_behz_decrypt_kernel(cons
 }
 
 // ---- ScaleAndRoundPOverQ ----------------------------------------------------------------------------
+constexpr int kMaxPOverQ = 64;
 struct POverQArgs {
     TowerView x;    // [sizeQ+1] rows, the last one modulo pLast
     TowerView out;  // [sizeQ]
-    const uint64_t* q;       // unused (kept for ABI stability of the struct)
-    const TwPair* qPairs;    // [sizeQ] moduli in .w
-    const TwPair* pInv;      // [sizeQ] [p^-1]_{q_i}
+    uint64_t q[kMaxPOverQ];    // moduli, by value in the kernel arguments (no device staging: the call stays asynchronous)
+    TwPair pInv[kMaxPOverQ];   // [p^-1]_{q_i}
     uint64_t pLast;
     uint32_t logN, batch, sizeQ;
 };
@@ -171,7 +171,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) p_over_q_kernel(const POverQArgs g) 
     const uint32_t b = (uint32_t)(gid >> g.logN), ri = (uint32_t)gid & ((1u << g.logN) - 1u);
     const uint64_t last = *tv_at(g.x, b, g.sizeQ, g.logN, ri), halfP = g.pLast >> 1;
     for (uint32_t i = 0; i < g.sizeQ; ++i) {
-        const uint64_t qn = g.qPairs[i].w;
+        const uint64_t qn = g.q[i];
         uint64_t v        = last;  // SwitchModulus(pLast -> q_i), mubintvecnat.cpp:109-122
         if (qn > g.pLast)
             v += (v > halfP) ? (qn - g.pLast) : 0;

@@ -78,8 +78,14 @@ FHE_HD uint64_t elem_apply(uint64_t o, uint64_t a, uint64_t b, const LimbConst l
     }
 }
 
-template <int OP>
-FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) elemwise_kernel(const ElemArgs g) {
+// per-call constant vector passed BY VALUE in the kernel arguments (fhe_mul_const / fhe_mult_acc: the caller's host
+// constants need no device staging buffer, so the call stays asynchronous and capturable into a HIP graph)
+struct ConstVec {
+    TwPair c[kMaxLimbs];
+};
+
+template <int OP, typename ConstAt>
+FHE_DEV void elemwise_body(const ElemArgs& g, ConstAt constAt) {
     const uint32_t t          = FHE_TID;
     const uint64_t base       = (uint64_t)FHE_BID << kTileLog;
     const uint64_t totalWords = (uint64_t)g.rows << g.logN;
@@ -97,7 +103,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) elemwise_kernel(const ElemArgs g) {
         const LimbConst lc  = g.lc[g.sel.idx[rit]];
         TwPair c            = {0, 0};
         if (needC)
-            c = g.consts[rit];
+            c = constAt(rit);
         const uint32_t tb   = row / g.nLimbs;
         const uint64_t ri   = off & (((uint64_t)1 << g.logN) - 1u);
         const uint64_t aoff = g.aStride ? ((((uint64_t)tb * g.aStride + g.aFirst + rit) << g.logN) + ri) : off;
@@ -116,6 +122,14 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) elemwise_kernel(const ElemArgs g) {
         g.out[ooff]     = elem_apply<OP>(o0, a0, b0, lc, c);
         g.out[ooff + 1] = elem_apply<OP>(o1, a1, b1, lc, c);
     }
+}
+template <int OP>
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) elemwise_kernel(const ElemArgs g) {
+    elemwise_body<OP>(g, [&](uint32_t rit) { return g.consts[rit]; });
+}
+template <int OP>
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) elemwise_cv_kernel(const ElemArgs g, const ConstVec cv) {
+    elemwise_body<OP>(g, [&](uint32_t rit) { return cv.c[rit]; });
 }
 
 // ---- EvalMultCore tensor product: d0 = a0*b0, d1 = a0*b1 + a1*b0, d2 = a1*b1 ------------------------
@@ -142,6 +156,35 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) tensor_kernel(const TensorArgs g) {
         g.d0[off] = mul_mod_barrett(x0, y0, lc.q, lc.mu, msb);
         g.d1[off] = add_mod(mul_mod_barrett(x0, y1, lc.q, lc.mu, msb), mul_mod_barrett(x1, y0, lc.q, lc.mu, msb), lc.q);
         g.d2[off] = mul_mod_barrett(x1, y1, lc.q, lc.mu, msb);
+    }
+}
+
+// LeveledSHEBase::EvalSquareCore for a 2-element ciphertext (base-leveledshe.cpp:646-664):
+// d0 = a0*a0, d1 = a0*a1 then d1 += d1, d2 = a1*a1
+struct TensorSqArgs {
+    const uint64_t *a0, *a1;
+    uint64_t *d0, *d1, *d2;
+    const LimbConst* lc;
+    uint32_t logN, nLimbs, rows;
+    LimbSel sel;
+};
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) tensor_square_kernel(const TensorSqArgs g) {
+    const uint32_t t          = FHE_TID;
+    const uint64_t base       = (uint64_t)FHE_BID << kTileLog;
+    const uint64_t totalWords = (uint64_t)g.rows << g.logN;
+#pragma unroll 2
+    for (int m = 0; m < 16; ++m) {
+        const uint64_t off = base + (uint64_t)m * kThreads + t;
+        if (off >= totalWords)
+            continue;
+        const uint32_t row = (uint32_t)(off >> g.logN);
+        const LimbConst lc = g.lc[g.sel.idx[row % g.nLimbs]];
+        const uint64_t x0 = g.a0[off], x1 = g.a1[off];
+        const int msb = (int)lc.msb;
+        const uint64_t m01 = mul_mod_barrett(x0, x1, lc.q, lc.mu, msb);
+        g.d0[off] = mul_mod_barrett(x0, x0, lc.q, lc.mu, msb);
+        g.d1[off] = add_mod(m01, m01, lc.q);
+        g.d2[off] = mul_mod_barrett(x1, x1, lc.q, lc.mu, msb);
     }
 }
 

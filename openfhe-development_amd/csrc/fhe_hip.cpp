@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -235,7 +236,6 @@ extern "C" uint32_t fhe_param_select_p(uint32_t logN, uint32_t sizeQ, const uint
 }
 
 static uint32_t env_u32(const char* name, uint32_t dflt);
-static bool ntt_legacy();
 
 // ------------------------------------------------------------------------------------------------
 // context
@@ -259,11 +259,8 @@ struct fhe_ctx {
     std::map<uint32_t, std::pair<TwPair*, TwPair*>> rescaleTabs;
     // cached ModReduce tables per (sizeQl, t): [0..l) = A_i, [l..2l) = B_i, [2l] = negtInvModq   (fhe_mod_reduce)
     std::map<std::pair<uint32_t, uint64_t>, TwPair*> modReduceTabs;
-    // small ring of device slots for per-call constant vectors (fhe_mul_const)
-    TwPair* d_constRing = nullptr;
-    uint32_t constRingPos = 0;
+    std::mutex cacheMutex;        // guards the lazily filled caches above (callers may be OpenMP threads)
 };
-static const uint32_t kConstRingSlots = 64;
 
 static fhe_status upload(fhe_ctx* c, const void* host, size_t bytes, void** dev) {
     RT_CHECK(rt::dmalloc(dev, bytes));
@@ -553,27 +550,14 @@ static void mark_uniform(PassPlan& pp, uint32_t logN) {
     }
 }
 
-static bool ntt_static();
 static uint32_t ntt_t1(uint32_t logN);
 static int static_mode(const fhe_ctx* c, const struct PassPlan& pp, bool inverse);
-static bool ntt_lds2();
-static bool ntt_rowtw();
-static bool ntt_legacy();
 // fused epilogue of a forward transform's last pass (NttPassArgs::epi*)
 struct NttEpilogue {
     uint32_t mode = 0, split = 0, aStride = 0, aFirst = 0;
     const uint64_t* A = nullptr;
     const TwPair* C   = nullptr;
     uint64_t *out0 = nullptr, *out1 = nullptr;
-};
-// experimental (FHE_KS_FUSE_CONV): conversion prologue of a forward transform's column pass (NttPassArgs::pro*), and the
-// final constants of an inverse transform replaced by ones that carry a per-limb factor (NttPassArgs::fin)
-static uint64_t g_fusedConvLaunches = 0;  // diagnostics: column passes launched with the conversion prologue
-extern "C" uint64_t fhe_debug_fused_conv_launches(void) { return g_fusedConvLaunches; }
-struct NttPrologue {
-    uint32_t nSrc = 0, stride = 0, first = 0;
-    const uint64_t* y = nullptr;
-    const uint64_t* h = nullptr;  // [nLimbs][8]
 };
 static uint32_t fill_pass_args(const fhe_ctx* c, const PassPlan& pp, bool inverse, const uint64_t* xin, uint64_t* xout,
                                const LimbSel& sel, uint32_t nLimbs, uint32_t batch, bool canonOut, uint32_t inStride,
@@ -585,7 +569,7 @@ static uint32_t fill_pass_args(const fhe_ctx* c, const PassPlan& pp, bool invers
     a.xin      = xin;
     a.x        = xout;
     a.tw       = inverse ? c->d_twInv : c->d_tw;
-    a.twRow    = ntt_rowtw() ? (inverse ? c->d_twRowInv : c->d_twRow) : nullptr;
+    a.twRow    = inverse ? c->d_twRowInv : c->d_twRow;
     a.q        = c->d_q;
     a.fin      = c->d_fin;
     a.logN     = c->logN;
@@ -611,8 +595,6 @@ static uint32_t fill_pass_args(const fhe_ctx* c, const PassPlan& pp, bool invers
     a.xcdSwizzle = (c->N >= (uint32_t)kTile && ((nLimbs * tilesPerRow) % 8u == 0)) ? 1u : 0u;
     a.epiMode = 0, a.epiSplit = 0, a.epiAStride = 0, a.epiAFirst = 0;
     a.epiA = nullptr, a.epiC = nullptr, a.epiOut0 = a.epiOut1 = nullptr;
-    a.proNSrc = 0, a.proStride = 0, a.proFirst = 0;
-    a.proY = nullptr, a.proH = nullptr, a.mu128 = c->d_mu128;
     return grid;
 }
 // forward: bound class of a static pass's input; inverse: does the pass end the transform (ntt_static.h MODE)
@@ -626,27 +608,10 @@ static int static_mode(const fhe_ctx* c, const PassPlan& pp, bool inverse) {
 static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse, const uint64_t* xin, uint64_t* xout,
                               const LimbSel& sel, uint32_t nLimbs, uint32_t batch, bool canonOut, void* stream,
                               uint32_t inStride = 0, uint32_t inFirst = 0, uint32_t outStride = 0, uint32_t outFirst = 0,
-                              const NttEpilogue* epi = nullptr, const NttPrologue* pro = nullptr, const TwPair* fin = nullptr) {
+                              const NttEpilogue* epi = nullptr) {
     NttPassArgs a;
     const uint32_t grid = fill_pass_args(c, pp, inverse, xin, xout, sel, nLimbs, batch, canonOut, inStride, inFirst, outStride,
                                          outFirst, a);
-    if (fin)
-        a.fin = fin;
-    if (pro && pro->nSrc) {
-        // only the static forward column passes of 4 / 5 stages carry the prologue (ntt_prologue_supported)
-        a.proNSrc = pro->nSrc, a.proStride = pro->stride, a.proFirst = pro->first, a.proY = pro->y, a.proH = pro->h;
-        ++g_fusedConvLaunches;
-        const uint32_t tilesPerRow = c->N >> kTileLog;
-        a.xcdSwizzle = ((batch * tilesPerRow) % 8u == 0) ? 2u : 0u;
-        if (pp.layoutA && !inverse && pp.T == 4)
-            FHE_LAUNCH((ntt_static_kernel<true, false, 4, 1, false, false, true>), grid, stream, a);
-        else if (pp.layoutA && !inverse && pp.T == 5)
-            FHE_LAUNCH((ntt_static_kernel<true, false, 5, 1, false, false, true>), grid, stream, a);
-        else
-            return fail(FHE_ERR_UNSUPPORTED, "ntt: no prologue kernel for this pass shape");
-        LAUNCH_CHECK();
-        return FHE_OK;
-    }
     if (epi && epi->mode) {
         // only the static forward row / single pass kernels carry the epilogue (ntt_epilogue_supported)
         a.epiMode = epi->mode, a.epiSplit = epi->split, a.epiAStride = epi->aStride, a.epiAFirst = epi->aFirst;
@@ -655,7 +620,7 @@ static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse
         bool launched  = false;
 #define FHE_EPI_CASE(TT, MODE) \
     if (!launched && !pp.layoutA && !inverse && pp.T == TT && mode == MODE) { \
-        FHE_LAUNCH((ntt_static_kernel<false, false, TT, MODE, false, true>), grid, stream, a); \
+        FHE_LAUNCH((ntt_static_kernel<false, false, TT, MODE, true>), grid, stream, a); \
         launched = true; \
     }
         FHE_EPI_CASE(12, 9) FHE_EPI_CASE(11, 9) FHE_EPI_CASE(10, 9) FHE_EPI_CASE(9, 9) FHE_EPI_CASE(12, 1)
@@ -665,23 +630,15 @@ static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse
         LAUNCH_CHECK();
         return FHE_OK;
     }
-    if (c->logN >= (uint32_t)kTileLog && !ntt_legacy() && ntt_static()) {
+    if (c->logN >= (uint32_t)kTileLog) {
         // compile-time pass plans (ntt_static.h): in-place pinned-register butterflies, immediate-offset LDS exchange
-        const bool twoPass = c->logN > (uint32_t)kTileLog;
-        const int mode     = static_mode(c, pp, inverse);
-        bool launched = false;
+        const int mode = static_mode(c, pp, inverse);
+        bool launched  = false;
 #define FHE_STATIC_CASE(LA, INV, TT, MODE) \
     if (!launched && pp.layoutA == LA && inverse == INV && pp.T == TT && mode == MODE) { \
-        FHE_LAUNCH((ntt_static_kernel<LA, INV, TT, MODE, false>), grid, stream, a); \
+        FHE_LAUNCH((ntt_static_kernel<LA, INV, TT, MODE>), grid, stream, a); \
         launched = true; \
     }
-        if (ntt_lds2() && !pp.layoutA && pp.T == 12 && twoPass) {  // tuning knob: double-buffered exchange (row pass only)
-            if (inverse)
-                FHE_LAUNCH((ntt_static_kernel<false, true, 12, 0, true>), grid, stream, a);
-            else
-                FHE_LAUNCH((ntt_static_kernel<false, false, 12, 9, true>), grid, stream, a);
-            launched = true;
-        }
         // column passes of logN = 13..16 (T1 = 4) and 17 (T1 = 5); row passes T2 = logN - T1; the single pass of logN = 12
         FHE_STATIC_CASE(true, false, 4, 1) FHE_STATIC_CASE(true, true, 4, 1)
         FHE_STATIC_CASE(true, false, 5, 1) FHE_STATIC_CASE(true, true, 5, 1)
@@ -690,34 +647,13 @@ static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse
         FHE_STATIC_CASE(false, false, 10, 9) FHE_STATIC_CASE(false, true, 10, 0)
         FHE_STATIC_CASE(false, false, 9, 9) FHE_STATIC_CASE(false, true, 9, 0)
         FHE_STATIC_CASE(false, false, 12, 1) FHE_STATIC_CASE(false, true, 12, 1)
-        // other splits of a two-pass ring (FHE_NTT_T1): more stages in the HBM-bound column pass, fewer in the row pass
-        FHE_STATIC_CASE(true, false, 6, 1) FHE_STATIC_CASE(true, true, 6, 1)
-        FHE_STATIC_CASE(true, false, 7, 1) FHE_STATIC_CASE(true, true, 7, 1)
-        FHE_STATIC_CASE(true, false, 8, 1) FHE_STATIC_CASE(true, true, 8, 1)
-        FHE_STATIC_CASE(false, false, 8, 16) FHE_STATIC_CASE(false, true, 8, 0)
-        FHE_STATIC_CASE(false, false, 11, 16) FHE_STATIC_CASE(false, false, 10, 16) FHE_STATIC_CASE(false, false, 9, 16)
 #undef FHE_STATIC_CASE
-        if (launched) {
-            LAUNCH_CHECK();
-            return FHE_OK;
-        }
-    }
-    if (c->logN >= (uint32_t)kTileLog && !ntt_legacy()) {
-        if (pp.layoutA) {
-            if (inverse)
-                FHE_LAUNCH((ntt_pass_full_kernel<true, true>), grid, stream, a);
-            else
-                FHE_LAUNCH((ntt_pass_full_kernel<true, false>), grid, stream, a);
-        }
-        else {
-            if (inverse)
-                FHE_LAUNCH((ntt_pass_full_kernel<false, true>), grid, stream, a);
-            else
-                FHE_LAUNCH((ntt_pass_full_kernel<false, false>), grid, stream, a);
-        }
+        if (!launched)
+            return fail(FHE_ERR_UNSUPPORTED, "ntt: no kernel instance for this pass shape");
         LAUNCH_CHECK();
         return FHE_OK;
     }
+    // rings below one tile (N < 4096): the generic small-ring kernel, several limbs per workgroup
     if (pp.layoutA) {
         if (inverse)
             FHE_LAUNCH((ntt_pass_kernel<true, true>), grid, stream, a);
@@ -734,45 +670,20 @@ static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse
     return FHE_OK;
 }
 
-// tuning knobs (environment, read once): FHE_NTT_T1 = stages in the strided column pass of a two-pass ring
-// (default: as few as possible, >= 4), FHE_NTT_CHUNK = towers per chunk (default 0 = whole batch per pass)
 static uint32_t env_u32(const char* name, uint32_t dflt) {
     const char* v = std::getenv(name);
     return v ? (uint32_t)std::strtoul(v, nullptr, 10) : dflt;
 }
-static uint32_t ntt_t1(uint32_t logN) {
-    static const uint32_t forced = env_u32("FHE_NTT_T1", 0);
-    const uint32_t lo = std::max(4u, logN - (uint32_t)kTileLog), hi = std::min((uint32_t)kTileLog - 4u, logN - 4u);
-    if (forced >= lo && forced <= hi)
-        return forced;
-    return lo;
-}
-static bool ntt_legacy() {
-    // FHE_NTT_LEGACY=1 runs the generic (small-ring) kernel for every N; default for N >= 4096 is
-    // ntt_pass_full_kernel (hand-scheduled butterflies, lazy-reduction schedule), measured 5 % faster on MI355X
-    static const uint32_t v = env_u32("FHE_NTT_LEGACY", 0);
-    return v != 0;
-}
-static bool ntt_static() {
-    // FHE_NTT_STATIC=0 falls back to the run-time-plan kernel (ntt_pass_full_kernel) for every pass shape
-    static const uint32_t v = env_u32("FHE_NTT_STATIC", 1);
-    return v != 0;
-}
-static bool ntt_rowtw() {
-    // FHE_NTT_ROWTW=0: the row pass reads the standard twiddle table in its bit-0 step as well
-    static const uint32_t v = env_u32("FHE_NTT_ROWTW", 1);
-    return v != 0;
-}
-static bool ntt_lds2() {
-    static const uint32_t v = env_u32("FHE_NTT_LDS2", 0);
-    return v != 0;
-}
+// stages of the strided column pass of a two-pass ring: as few as possible (>= 4), so that the column pass reads rows of
+// 2^(12-T1) consecutive words and, at T1 = 4, is a pure register radix-16 step; the other splits were measured slower
+// (profiles/r01_sweeps.md) and their kernel instances are gone
+static uint32_t ntt_t1(uint32_t logN) { return std::max(4u, logN - (uint32_t)kTileLog); }
 
 // inStride != 0: xin is a [batch][inStride][N] view whose rows inFirst.. are transformed into the dense xout
 // outStride != 0: xout is a [batch][outStride][N] view as well (rows outFirst..)
 // does a forward transform of this ring end in a kernel that can carry the fused epilogue?
 static bool ntt_epilogue_supported(const fhe_ctx* c) {
-    if (c->logN < (uint32_t)kTileLog || ntt_legacy() || !ntt_static())
+    if (c->logN < (uint32_t)kTileLog)
         return false;
     if (c->logN == (uint32_t)kTileLog)
         return true;  // the single pass
@@ -781,18 +692,10 @@ static bool ntt_epilogue_supported(const fhe_ctx* c) {
     const uint32_t t1 = ntt_t1(c->logN), t2 = c->logN - t1;
     return t2 == 12u || (t1 == 4u && t2 >= 9u && t2 <= 12u);
 }
-// experimental: conversions of a key switch computed inside the forward transforms' column passes (default off)
-static bool ntt_prologue_supported(const fhe_ctx* c) {
-    static const bool on = env_u32("FHE_KS_FUSE_CONV", 0) != 0;
-    if (!on || c->logN <= (uint32_t)kTileLog || ntt_legacy() || !ntt_static())
-        return false;
-    const uint32_t t1 = ntt_t1(c->logN);
-    return t1 == 4u || t1 == 5u;
-}
 static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_t* xout, const uint32_t* limbIdx,
                           uint32_t nLimbs, uint32_t batch, void* stream, uint32_t inStride = 0, uint32_t inFirst = 0,
                           uint32_t outStride = 0, uint32_t outFirst = 0, const NttEpilogue* epi = nullptr,
-                          bool canonOut = true, const NttPrologue* pro = nullptr, const TwPair* fin = nullptr) {
+                          bool canonOut = true) {
     ARG_CHECK(c && xin && xout, "fhe_ntt: null argument");
     ARG_CHECK(batch >= 1, "fhe_ntt: batch must be >= 1");
     LimbSel sel;
@@ -808,10 +711,7 @@ static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_
         if (!inverse)
             schedule_fwd(p, logN, &bound);
         p.outBound = bound;
-        if (pro && pro->nSrc)
-            return fail(FHE_ERR_UNSUPPORTED, "ntt: the conversion prologue needs a two-pass ring");
-        return launch_pass(c, p, inverse, xin, xout, sel, nLimbs, batch, canonOut, stream, inStride, inFirst, outStride, outFirst, epi,
-                           nullptr, fin);
+        return launch_pass(c, p, inverse, xin, xout, sel, nLimbs, batch, canonOut, stream, inStride, inFirst, outStride, outFirst, epi);
     }
     // two passes over HBM: a strided column pass of T1 stages (the coefficient index's top bits) and a
     // contiguous row pass of T2 = logN - T1 stages.  T1 is kept minimal (>= 4) so that the column pass reads
@@ -835,12 +735,9 @@ static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_
     // (profiles/r01_sweeps.md): two streams (the hardware does not co-schedule two grids that each fill the chip) and
     // one grid whose workgroups alternate between the two roles (the waiting column workgroups take half of the four
     // resident slots of a CU away from the row workgroups: 33.2 ms instead of 30.4 ms per forward+inverse step).
-    // (the prologue belongs to the forward transform's first pass, the final constants to the inverse transform's last)
-    if (fhe_status s = launch_pass(c, p1, inverse, xin, xout, sel, nLimbs, batch, false, stream, inStride, inFirst, outStride, outFirst,
-                                   nullptr, inverse ? nullptr : pro, nullptr))
+    if (fhe_status s = launch_pass(c, p1, inverse, xin, xout, sel, nLimbs, batch, false, stream, inStride, inFirst, outStride, outFirst))
         return s;
-    return launch_pass(c, p2, inverse, xout, xout, sel, nLimbs, batch, canonOut, stream, outStride, outFirst, outStride, outFirst, epi,
-                       nullptr, inverse ? fin : nullptr);
+    return launch_pass(c, p2, inverse, xout, xout, sel, nLimbs, batch, canonOut, stream, outStride, outFirst, outStride, outFirst, epi);
 }
 
 extern "C" fhe_status fhe_ntt_fwd(fhe_ctx* c, uint64_t* x, const uint32_t* li, uint32_t nl, uint32_t b, void* st) {
@@ -949,39 +846,73 @@ extern "C" fhe_status fhe_neg(fhe_ctx* c, uint64_t* o, const uint64_t* a, const 
     return elem_run<OP_NEG>(c, o, a, nullptr, nullptr, li, nl, bt, st, "fhe_neg");
 }
 
-// per-call constant vectors (fhe_mul_const) go through a small ring of device slots; the upload is
-// synchronous on `stream`, so a slot is only reused after kConstRingSlots later calls have completed theirs
-static fhe_status consts_to_device(fhe_ctx* c, const uint64_t* consts, const uint32_t* limbIdx, uint32_t nLimbs,
-                                   void* stream, TwPair** d_out) {
-    std::vector<TwPair> h(nLimbs);
+// per-call constant vectors (Times(vector<NativeInteger>), MultAccEqNoCheck ...): the host constants become Shoup pairs
+// and travel BY VALUE in the kernel arguments — no staging buffer, no synchronisation, capturable into a HIP graph
+static fhe_status make_const_vec(const fhe_ctx* c, const uint64_t* consts, const uint32_t* limbIdx, uint32_t nLimbs,
+                                 ConstVec* cv, const char* who) {
+    ARG_CHECK(c && consts, std::string(who) + ": null argument");
+    ARG_CHECK(nLimbs >= 1 && nLimbs <= (uint32_t)kMaxLimbs, std::string(who) + ": nLimbs out of range");
+    for (uint32_t i = 0; i < (uint32_t)kMaxLimbs; ++i)
+        cv->c[i] = TwPair{0, 0};
     for (uint32_t i = 0; i < nLimbs; ++i) {
-        const uint64_t ql = c->q[limbIdx ? limbIdx[i] : i];
-        const uint64_t v  = consts[i] % ql;
-        h[i]              = TwPair{v, host::shoup(v, ql)};
+        const uint32_t l = limbIdx ? limbIdx[i] : i;
+        ARG_CHECK(l < c->L, std::string(who) + ": limb index exceeds context size");
+        const uint64_t ql = c->q[l], v = consts[i] % ql;
+        cv->c[i]          = TwPair{v, host::shoup(v, ql)};
     }
-    if (!c->d_constRing) {
-        void* d = nullptr;
-        RT_CHECK(rt::dmalloc(&d, (size_t)kConstRingSlots * kMaxLimbs * sizeof(TwPair)));
-        c->owned.push_back(d);
-        c->d_constRing = (TwPair*)d;
-    }
-    TwPair* slot    = c->d_constRing + (size_t)(c->constRingPos % kConstRingSlots) * kMaxLimbs;
-    c->constRingPos = c->constRingPos + 1;
-    RT_CHECK(rt::h2d(slot, h.data(), nLimbs * sizeof(TwPair), (rt::stream_t)stream));
-    RT_CHECK(rt::sync((rt::stream_t)stream));  // h is a stack-lifetime staging buffer
-    *d_out = slot;
+    return FHE_OK;
+}
+template <int OP>
+static fhe_status elem_cv_run(fhe_ctx* c, uint64_t* out, const uint64_t* a, const uint64_t* b, const ConstVec& cv,
+                              const uint32_t* limbIdx, uint32_t nLimbs, uint32_t batch, void* stream, const char* who,
+                              uint32_t oStride = 0, uint32_t oFirst = 0) {
+    ARG_CHECK(c && out && a, std::string(who) + ": null argument");
+    ARG_CHECK(batch >= 1, std::string(who) + ": batch must be >= 1");
+    ElemArgs g;
+    if (fhe_status s = make_sel(c, limbIdx, nLimbs, &g.sel, who))
+        return s;
+    RT_CHECK(rt::set_device(c->device));
+    g.out = out, g.a = a, g.b = b, g.lc = c->d_lc, g.consts = nullptr;
+    g.logN = c->logN, g.nLimbs = nLimbs, g.rows = batch * nLimbs;
+    g.aStride = g.aFirst = g.bStride = g.bFirst = 0;
+    g.oStride = oStride, g.oFirst = oFirst;
+    FHE_LAUNCH((elemwise_cv_kernel<OP>), tiles_for(c, g.rows), stream, g, cv);
+    LAUNCH_CHECK();
     return FHE_OK;
 }
 extern "C" fhe_status fhe_mul_const(fhe_ctx* c, uint64_t* o, const uint64_t* a, const uint64_t* consts,
                                     const uint32_t* li, uint32_t nl, uint32_t bt, void* st) {
-    ARG_CHECK(c && consts, "fhe_mul_const: null argument");
-    ARG_CHECK(nl >= 1 && nl <= (uint32_t)kMaxLimbs, "fhe_mul_const: nLimbs out of range");
-    for (uint32_t i = 0; i < nl; ++i)
-        ARG_CHECK((li ? li[i] : i) < c->L, "fhe_mul_const: limb index exceeds context size");
-    TwPair* d = nullptr;
-    if (fhe_status s = consts_to_device(c, consts, li, nl, st, &d))
+    ConstVec cv;
+    if (fhe_status s = make_const_vec(c, consts, li, nl, &cv, "fhe_mul_const"))
         return s;
-    return elem_run<OP_MUL_CONST>(c, o, a, nullptr, d, li, nl, bt, st, "fhe_mul_const");
+    return elem_cv_run<OP_MUL_CONST>(c, o, a, nullptr, cv, li, nl, bt, st, "fhe_mul_const");
+}
+// NativeVectorT::MultAccEqNoCheck per limb (mubintvecnat.cpp:132-142): acc[r] += v[r] * I[r]  (I reduced first, Shoup
+// product, ModAddFastEq)
+extern "C" fhe_status fhe_mult_acc(fhe_ctx* c, uint64_t* acc, const uint64_t* v, const uint64_t* consts,
+                                   const uint32_t* li, uint32_t nl, uint32_t bt, void* st) {
+    ConstVec cv;
+    if (fhe_status s = make_const_vec(c, consts, li, nl, &cv, "fhe_mult_acc"))
+        return s;
+    return elem_cv_run<OP_MUL_CONST_ADD>(c, acc, v, acc, cv, li, nl, bt, st, "fhe_mult_acc");
+}
+// DCRTPolyImpl::ExpandCRTBasisQlHat (dcrtpoly-impl.h:1167-1187): limbs [0, sizeQl) times QlHatModq[i], limbs [sizeQl, sizeQ)
+// zero; x [batch][sizeQl][N] -> out [batch][sizeQ][N] over context limbs limbIdx[0..sizeQ) (format unchanged)
+extern "C" fhe_status fhe_expand_crt_basis_ql_hat(fhe_ctx* c, const uint64_t* x, uint32_t sizeQl, const uint64_t* QlHatModq,
+                                                  const uint32_t* li, uint32_t sizeQ, uint32_t bt, uint64_t* out, void* st) {
+    ARG_CHECK(c && x && out && QlHatModq, "fhe_expand_crt_basis_ql_hat: null argument");
+    ARG_CHECK(sizeQl >= 1 && sizeQl <= sizeQ && sizeQ <= (uint32_t)kMaxLimbs && bt >= 1, "fhe_expand_crt_basis_ql_hat: bad sizes");
+    ARG_CHECK(out != x || sizeQl == sizeQ, "fhe_expand_crt_basis_ql_hat: in-place only when no limb is appended");
+    ConstVec cv;
+    if (fhe_status s = make_const_vec(c, QlHatModq, li, sizeQl, &cv, "fhe_expand_crt_basis_ql_hat"))
+        return s;
+    for (uint32_t i = sizeQl; i < sizeQ; ++i)
+        ARG_CHECK((li ? li[i] : i) < c->L, "fhe_expand_crt_basis_ql_hat: limb index exceeds context size");
+    RT_CHECK(rt::set_device(c->device));
+    const size_t rowB = (size_t)8 << c->logN;
+    if (sizeQ > sizeQl)
+        RT_CHECK(rt::dzero_2d(out + ((size_t)sizeQl << c->logN), sizeQ * rowB, (sizeQ - sizeQl) * rowB, bt, (rt::stream_t)st));
+    return elem_cv_run<OP_MUL_CONST>(c, out, x, nullptr, cv, li, sizeQl, bt, st, "fhe_expand_crt_basis_ql_hat", sizeQ, 0);
 }
 
 extern "C" fhe_status fhe_tensor(fhe_ctx* c, const uint64_t* a0, const uint64_t* a1, const uint64_t* b0,
@@ -999,6 +930,22 @@ extern "C" fhe_status fhe_tensor(fhe_ctx* c, const uint64_t* a0, const uint64_t*
     g.nLimbs = nl;
     g.rows   = bt * nl;
     FHE_LAUNCH(tensor_kernel, tiles_for(c, g.rows), st, g);
+    LAUNCH_CHECK();
+    return FHE_OK;
+}
+
+// LeveledSHEBase::EvalSquareCore for 2-element ciphertexts (base-leveledshe.cpp:646-664)
+extern "C" fhe_status fhe_tensor_square(fhe_ctx* c, const uint64_t* a0, const uint64_t* a1, uint64_t* d0, uint64_t* d1,
+                                        uint64_t* d2, const uint32_t* li, uint32_t nl, uint32_t bt, void* st) {
+    ARG_CHECK(c && a0 && a1 && d0 && d1 && d2, "fhe_tensor_square: null argument");
+    ARG_CHECK(bt >= 1, "fhe_tensor_square: batch must be >= 1");
+    TensorSqArgs g;
+    if (fhe_status s = make_sel(c, li, nl, &g.sel, "fhe_tensor_square"))
+        return s;
+    RT_CHECK(rt::set_device(c->device));
+    g.a0 = a0, g.a1 = a1, g.d0 = d0, g.d1 = d1, g.d2 = d2;
+    g.lc = c->d_lc, g.logN = c->logN, g.nLimbs = nl, g.rows = bt * nl;
+    FHE_LAUNCH(tensor_square_kernel, tiles_for(c, g.rows), st, g);
     LAUNCH_CHECK();
     return FHE_OK;
 }
@@ -1087,6 +1034,8 @@ static fhe_status conv_from_tables(fhe_ctx* c, const std::vector<uint64_t>& src,
                                    const uint64_t* hatInvIn, const uint64_t* hatModIn, const uint64_t* alphaIn,
                                    const double* qInvIn, fhe_conv** out) {
     const uint32_t nSrc = (uint32_t)src.size(), nDst = (uint32_t)dst.size();
+    if (nSrc < 1 || nSrc > 32u || nDst < 1 || nDst > (uint32_t)kMaxLimbs)  // table layout and kernel instances end at NSRC = 32
+        return fail(FHE_ERR_UNSUPPORTED, "basis conversion: at most 32 source and 128 target limbs supported");
     fhe_conv* cv = new fhe_conv;
     cv->ctx      = c;
     cv->nSrc     = nSrc;
@@ -1226,21 +1175,20 @@ static fhe_status conv_run(fhe_conv* cv, const uint64_t* in, uint32_t inStride, 
     const uint64_t coeffs = (uint64_t)batch << g.logN;
     const uint32_t grid   = (uint32_t)((coeffs + kThreads - 1) / kThreads);
     const uint32_t pad = conv_nsrc_pad(cv->nSrc);
-    static const uint32_t sum8 = env_u32("FHE_CONV_SUM8", 1);  // 0: 192-bit accumulator, 1: sum8 (default), 2: 30-bit split (experimental)
-    if (pad == 8 && sum8 == 2)
+    // column-sum form of the kernel: 2 = factors split at 30 bits (default), FHE_CONV_SUM8=1 = carry-counted 64-bit columns
+    static const bool split30 = env_u32("FHE_CONV_SUM8", 2) != 1u;
+    if (pad == 8 && split30)
         FHE_LAUNCH((switch_basis_kernel<8, EXACT, 2>), grid, st, g);
-    else if (pad == 8 && sum8)
-        FHE_LAUNCH((switch_basis_kernel<8, EXACT, 1>), grid, st, g);
     else if (pad == 8)
-        FHE_LAUNCH((switch_basis_kernel<8, EXACT, 0>), grid, st, g);
-    else if (pad == 16 && sum8)
-        FHE_LAUNCH((switch_basis_kernel<16, EXACT, 1>), grid, st, g);
+        FHE_LAUNCH((switch_basis_kernel<8, EXACT, 1>), grid, st, g);
+    else if (pad == 16 && split30)
+        FHE_LAUNCH((switch_basis_kernel<16, EXACT, 2>), grid, st, g);
     else if (pad == 16)
-        FHE_LAUNCH((switch_basis_kernel<16, EXACT, 0>), grid, st, g);
-    else if (sum8)
-        FHE_LAUNCH((switch_basis_kernel<32, EXACT, 1>), grid, st, g);
+        FHE_LAUNCH((switch_basis_kernel<16, EXACT, 1>), grid, st, g);
+    else if (split30)
+        FHE_LAUNCH((switch_basis_kernel<32, EXACT, 2>), grid, st, g);
     else
-        FHE_LAUNCH((switch_basis_kernel<32, EXACT, 0>), grid, st, g);
+        FHE_LAUNCH((switch_basis_kernel<32, EXACT, 1>), grid, st, g);
     LAUNCH_CHECK();
     return FHE_OK;
 }
@@ -1258,8 +1206,8 @@ extern "C" fhe_status fhe_switch_basis_exact(fhe_conv* cv, const uint64_t* in, u
 extern "C" size_t fhe_expand_crt_basis_workspace_bytes(const fhe_conv* cv, uint32_t batch) {
     return cv ? (((size_t)batch * cv->nSrc) << cv->ctx->logN) * 8 : 0;
 }
-extern "C" fhe_status fhe_expand_crt_basis(fhe_conv* cv, const uint64_t* x, int inEval, uint64_t* out, int resultEval,
-                                           int reverseOrder, uint32_t batch, void* ws, size_t wsBytes, void* st) {
+static fhe_status expand_run(fhe_conv* cv, const uint64_t* x, int inEval, uint64_t* out, int resultEval, int reverseOrder,
+                             uint32_t batch, void* ws, size_t wsBytes, void* st, bool exact) {
     ARG_CHECK(cv && x && out && batch >= 1, "fhe_expand_crt_basis: bad argument");
     ARG_CHECK(!cv->srcIdx.empty(), "fhe_expand_crt_basis: the plan must come from fhe_conv_create[_custom]");
     fhe_ctx* c = cv->ctx;
@@ -1274,7 +1222,8 @@ extern "C" fhe_status fhe_expand_crt_basis(fhe_conv* cv, const uint64_t* x, int 
             return s;
         coef = (const uint64_t*)ws;
     }
-    if (fhe_status s = conv_run<true>(cv, coef, nQ, 0, out, tot, pFirst, batch, st))  // :1101-1102
+    if (fhe_status s = exact ? conv_run<true>(cv, coef, nQ, 0, out, tot, pFirst, batch, st)  // :1101-1102
+                             : conv_run<false>(cv, coef, nQ, 0, out, tot, pFirst, batch, st))  // ApproxModUp :948
         return s;
     // Q rows of the result: the stored EVALUATION copy when it can be reused (:1104-1105), else the coefficient form
     const uint64_t* qsrc = (resultEval && inEval) ? x : coef;
@@ -1287,6 +1236,17 @@ extern "C" fhe_status fhe_expand_crt_basis(fhe_conv* cv, const uint64_t* x, int 
         return ntt_run(c, false, out, out, cv->dstIdx.data(), nP, batch, st, tot, pFirst, tot, pFirst);
     }
     return FHE_OK;
+}
+extern "C" fhe_status fhe_expand_crt_basis(fhe_conv* cv, const uint64_t* x, int inEval, uint64_t* out, int resultEval,
+                                           int reverseOrder, uint32_t batch, void* ws, size_t wsBytes, void* st) {
+    return expand_run(cv, x, inEval, out, resultEval, reverseOrder, batch, ws, wsBytes, st, true);
+}
+// DCRTPolyImpl::ApproxModUp (dcrtpoly-impl.h:935-963): x over the plan's source basis Q (format inEval) -> out over Q u P in
+// EVALUATION: the EVALUATION copy of the Q limbs is kept when there is one (:943-946, 950-951), P = ApproxSwitchCRTBasis of the
+// coefficient form (:948), every limb to EVALUATION (:958-960).  Workspace as fhe_expand_crt_basis (EVALUATION input only).
+extern "C" fhe_status fhe_mod_up(fhe_conv* cv, const uint64_t* x, int inEval, uint64_t* out, uint32_t batch, void* ws,
+                                 size_t wsBytes, void* st) {
+    return expand_run(cv, x, inEval, out, 1, 0, batch, ws, wsBytes, st, false);
 }
 // DCRTPolyImpl::FastExpandCRTBasisPloverQ (dcrtpoly-impl.h:1151-1164), COEFFICIENT format: partPl =
 // ApproxSwitchCRTBasis(x; toPl) with the caller's mPlQHatInvModq / qInvModp tables (fhe_conv_create_custom), partQl =
@@ -1317,13 +1277,12 @@ struct fhe_ks_plan {
         std::map<uint64_t, fhe_conv*> downT;    // BGV: P -> Q_l with t^-1 (mod p_j) and t (mod q_i) folded in, per t
         TwPair* d_PInv = nullptr;               // [sizeQl] Shoup pairs of [P^-1]_{q_i}
         TwPair* d_PModq = nullptr;              // [sizeQl] Shoup pairs of [P]_{q_i} (built on first use)
-        TwPair* d_finY  = nullptr;              // [ctxLimbs][2]: inverse-NTT final constants times [Qhat_i^-1]_{q_i} of the limb's
-                                                // digit (Q limbs) / of the P basis (P limbs): FHE_KS_FUSE_CONV, built on first use
     };
     std::vector<Level*> levels;  // index sizeQl
     std::vector<void*> owned;
     std::map<std::vector<uint64_t>, void*> bsgsTables;  // device copies of the diagonal pointer tables, by content
     uint64_t* d_zeroRows = nullptr;                     // [sizeQ+sizeP][N] zeros: the "absent diagonal" of the BSGS transform
+    std::mutex cacheMutex;                              // guards the lazily built levels / tables (callers may be OpenMP threads)
 };
 struct fhe_ks_key {
     fhe_ks_plan* plan;
@@ -1342,25 +1301,30 @@ extern "C" fhe_status fhe_ks_plan_create(fhe_ctx* c, uint32_t sizeQ, uint32_t si
     ARG_CHECK(sizeQ > a * (numPartQ - 1),
               "HYBRID key switching parameters: Can't appropriately distribute towers into digits");
     ARG_CHECK(numPartQ <= (uint32_t)kMaxDigits, "fhe_ks_plan_create: at most 8 digits supported");
+    // the conversion kernels take at most 32 source limbs (switch_basis_kernel<NSRC <= 32>): digits (ModUp) and P (ModDown)
+    if (a > 32u || sizeP > 32u)
+        return fail(FHE_ERR_UNSUPPORTED, "fhe_ks_plan_create: digit size ceil(sizeQ/numPartQ) and sizeP must be <= 32");
     fhe_ks_plan* p = new fhe_ks_plan;
     p->ctx = c, p->sizeQ = sizeQ, p->sizeP = sizeP, p->numPartQ = numPartQ, p->alpha = a;
     p->levels.assign(sizeQ + 1, nullptr);
     *out = p;
     return FHE_OK;
 }
+static void ks_level_free(fhe_ks_plan::Level* lv) {
+    if (!lv)
+        return;
+    for (auto* cv : lv->up)
+        fhe_conv_destroy(cv);
+    fhe_conv_destroy(lv->down);
+    for (auto& kv : lv->downT)
+        fhe_conv_destroy(kv.second);
+    delete lv;
+}
 extern "C" void fhe_ks_plan_destroy(fhe_ks_plan* p) {
     if (!p)
         return;
-    for (auto* lv : p->levels) {
-        if (!lv)
-            continue;
-        for (auto* cv : lv->up)
-            fhe_conv_destroy(cv);
-        fhe_conv_destroy(lv->down);
-        for (auto& kv : lv->downT)
-            fhe_conv_destroy(kv.second);
-        delete lv;
-    }
+    for (auto* lv : p->levels)
+        ks_level_free(lv);
     for (void* q : p->owned)
         rt::dfree(q);
     for (auto& kv : p->bsgsTables)
@@ -1371,6 +1335,7 @@ extern "C" uint32_t fhe_ks_plan_alpha(const fhe_ks_plan* p) { return p ? p->alph
 
 static fhe_status ks_level(fhe_ks_plan* p, uint32_t sizeQl, fhe_ks_plan::Level** out) {
     ARG_CHECK(sizeQl >= 1 && sizeQl <= p->sizeQ, "fhe_keyswitch: sizeQl out of range");
+    std::lock_guard<std::mutex> lock(p->cacheMutex);
     if (p->levels[sizeQl]) {
         *out = p->levels[sizeQl];
         return FHE_OK;
@@ -1397,7 +1362,7 @@ static fhe_status ks_level(fhe_ks_plan* p, uint32_t sizeQl, fhe_ks_plan::Level**
             dst.push_back(c->q[i]);
         fhe_conv* cv = nullptr;
         if (fhe_status s = conv_build(c, src, dst, &cv)) {
-            delete lv;
+            ks_level_free(lv);
             return s;
         }
         lv->up.push_back(cv);
@@ -1411,7 +1376,7 @@ static fhe_status ks_level(fhe_ks_plan* p, uint32_t sizeQl, fhe_ks_plan::Level**
         for (uint32_t i = 0; i < sizeQl; ++i)
             dst.push_back(c->q[i]);
         if (fhe_status s = conv_build(c, src, dst, &lv->down)) {
-            delete lv;
+            ks_level_free(lv);
             return s;
         }
         // [P^-1]_{q_i}  (rns-cryptoparameters.cpp:205-212)
@@ -1420,11 +1385,18 @@ static fhe_status ks_level(fhe_ks_plan* p, uint32_t sizeQl, fhe_ks_plan::Level**
             const uint64_t v = host::invmod(host::prod_mod(src, -1, c->q[i]), c->q[i]);
             pinv[i]          = TwPair{v, host::shoup(v, c->q[i])};
         }
-        void* d = nullptr;
-        RT_CHECK(rt::dmalloc(&d, pinv.size() * sizeof(TwPair)));
-        p->owned.push_back(d);
-        RT_CHECK(rt::h2d(d, pinv.data(), pinv.size() * sizeof(TwPair), nullptr));
-        RT_CHECK(rt::sync(nullptr));
+        void* d       = nullptr;
+        const char* e = rt::dmalloc(&d, pinv.size() * sizeof(TwPair));
+        if (!e) {
+            p->owned.push_back(d);
+            e = rt::h2d(d, pinv.data(), pinv.size() * sizeof(TwPair), nullptr);
+        }
+        if (!e)
+            e = rt::sync(nullptr);
+        if (e) {
+            ks_level_free(lv);
+            return fail(FHE_ERR_DEVICE, std::string("fhe_keyswitch: building the level tables: ") + e);
+        }
         lv->d_PInv = (TwPair*)d;
     }
     p->levels[sizeQl] = lv;
@@ -1520,52 +1492,6 @@ extern "C" size_t fhe_ks_workspace_bytes(const fhe_ks_plan* p, uint32_t sizeQl, 
 // INTT / conversion / NTT launches:
 //   mod_down_core: x[nTow][sizeQl+sizeP][N] -> md[nTow][sizeQl][N] = NTT(ApproxSwitchCRTBasis(INTT(P part)))
 //   mod_down_tail: out_i = (x_i - md_i) * [P^-1]_{q_i}     (or out_i += ... when `accumulate`)
-// experimental (FHE_KS_FUSE_CONV): the ModUp / ModDown conversions run inside the column pass of the forward transform
-// that follows them.  The inverse transform in front leaves y_i = x_i * [Qhat_i^-1]_{q_i} (the factor rides on its final
-// constants: the same residue as ModMulFastConst, dcrtpoly-impl.h:898-903), the column pass of every target limb sums
-// y_i * [Qhat_i]_{p_j} over the <= 8 source limbs (:905-912).
-static bool ks_fused_conv(const fhe_ks_plan* p, const fhe_ks_plan::Level* lv) {
-    if (!ntt_prologue_supported(p->ctx) || p->sizeP > 8u)
-        return false;
-    for (uint32_t sz : lv->partSize)
-        if (sz > 8u)
-            return false;
-    return true;
-}
-static fhe_status ks_fin_y(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const TwPair** out) {
-    if (!lv->d_finY) {
-        fhe_ctx* c = p->ctx;
-        std::vector<TwPair> t = c->h_fin;
-        auto fold = [&](uint32_t limb, uint64_t f) {
-            const uint64_t ql = c->q[limb];
-            for (int e = 0; e < 2; ++e) {
-                const uint64_t v = host::mulmod(t[2 * limb + e].w, f, ql);
-                t[2 * limb + e]  = TwPair{v, host::shoup(v, ql)};
-            }
-        };
-        for (uint32_t part = 0; part < lv->numParts; ++part) {
-            std::vector<uint64_t> src;
-            for (uint32_t i = 0; i < lv->partSize[part]; ++i)
-                src.push_back(c->q[p->alpha * part + i]);
-            for (uint32_t i = 0; i < lv->partSize[part]; ++i)
-                fold(p->alpha * part + i, host::invmod(host::prod_mod(src, (int)i, src[i]), src[i]));
-        }
-        std::vector<uint64_t> pm;
-        for (uint32_t j = 0; j < p->sizeP; ++j)
-            pm.push_back(c->q[p->sizeQ + j]);
-        for (uint32_t j = 0; j < p->sizeP; ++j)
-            fold(p->sizeQ + j, host::invmod(host::prod_mod(pm, (int)j, pm[j]), pm[j]));
-        void* d = nullptr;
-        RT_CHECK(rt::dmalloc(&d, t.size() * sizeof(TwPair)));
-        p->owned.push_back(d);
-        RT_CHECK(rt::h2d(d, t.data(), t.size() * sizeof(TwPair), nullptr));
-        RT_CHECK(rt::sync(nullptr));
-        lv->d_finY = (TwPair*)d;
-    }
-    *out = lv->d_finY;
-    return FHE_OK;
-}
-
 static fhe_status mod_down_core(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const uint64_t* x, uint32_t nTow, uint64_t* pcoef,
                                 uint64_t* md, void* st, fhe_conv* down = nullptr, const NttEpilogue* epi = nullptr) {
     fhe_ctx* c            = p->ctx;
@@ -1573,18 +1499,6 @@ static fhe_status mod_down_core(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const ui
     std::vector<uint32_t> pIdx(sizeP);
     for (uint32_t j = 0; j < sizeP; ++j)
         pIdx[j] = p->sizeQ + j;
-    if (!down && ks_fused_conv(p, lv)) {
-        const TwPair* finY = nullptr;
-        if (fhe_status s = ks_fin_y(p, lv, &finY))
-            return s;
-        // INTT of the P part with [Phat_j^-1]_{p_j} on its final constants, then the forward transform over Q_l whose
-        // column pass computes the converted residues itself (and whose row pass carries the epilogue as before)
-        if (fhe_status s = ntt_run(c, true, x, pcoef, pIdx.data(), sizeP, nTow, st, sizeQlP, sizeQl, 0, 0, nullptr, true, nullptr, finY))
-            return s;
-        NttPrologue pro;
-        pro.nSrc = sizeP, pro.stride = sizeP, pro.first = 0, pro.y = pcoef, pro.h = lv->down->tb.hatMod;
-        return ntt_run(c, false, md, md, nullptr, sizeQl, nTow, st, 0, 0, 0, 0, epi, true, &pro);
-    }
     // P part to COEFFICIENT (:978-985): INTT of rows [sizeQl, sizeQl+sizeP) of every tower, written densely
     if (fhe_status s = ntt_run(c, true, x, pcoef, pIdx.data(), sizeP, nTow, st, sizeQlP, sizeQl))
         return s;
@@ -1616,22 +1530,6 @@ static fhe_status ks_precompute_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, cons
                                     uint64_t* ws, const KsLayout& w, void* st) {
     fhe_ctx* c            = p->ctx;
     const uint32_t sizeQl = lv->sizeQl;
-    if (ks_fused_conv(p, lv)) {
-        const TwPair* finY = nullptr;
-        if (fhe_status s = ks_fin_y(p, lv, &finY))
-            return s;
-        if (fhe_status s = ntt_run(c, true, cin, ws + w.coef, nullptr, sizeQl, batch, st, 0, 0, 0, 0, nullptr, true, nullptr, finY))
-            return s;
-        for (uint32_t j = 0; j < lv->numParts; ++j) {
-            NttPrologue pro;
-            pro.nSrc = lv->partSize[j], pro.stride = sizeQl, pro.first = p->alpha * j, pro.y = ws + w.coef, pro.h = lv->up[j]->tb.hatMod;
-            uint64_t* dj = ws + w.dig[j];
-            if (fhe_status s = ntt_run(c, false, dj, dj, lv->cidx[j].data(), (uint32_t)lv->cidx[j].size(), batch, st, 0, 0, 0, 0,
-                                       nullptr, false, &pro))
-                return s;
-        }
-        return FHE_OK;
-    }
     if (fhe_status s = fhe_ntt_inv_oop(c, cin, ws + w.coef, nullptr, sizeQl, batch, st))
         return s;
     for (uint32_t j = 0; j < lv->numParts; ++j) {
@@ -1797,6 +1695,7 @@ static fhe_status ext_limbs(const fhe_ks_plan* p, uint32_t sizeQl, std::vector<u
 }
 // [P]_{q_i} as Shoup pairs for limbs [0, sizeQl)  (PModq, rns-cryptoparameters.cpp:200-203), cached per level
 static fhe_status ks_pmodq(fhe_ks_plan* p, fhe_ks_plan::Level* lv, TwPair** d) {
+    std::lock_guard<std::mutex> lock(p->cacheMutex);
     if (!lv->d_PModq) {
         fhe_ctx* c = p->ctx;
         std::vector<uint64_t> pm(p->sizeP);
@@ -2001,6 +1900,7 @@ extern "C" fhe_status fhe_ckks_bsgs_transform(fhe_ks_plan* p, const uint64_t* c0
     // terms and padding pointing at rows of zeros (cached by content: the same transform is applied many times)
     const uint32_t ninK   = nIn <= 4 ? 4u : nIn <= 8 ? 8u : (uint32_t)kMaxBsgsIn;  // kernel instance (NIN)
     const uint32_t nInPad = (nIn + ninK - 1) / ninK * ninK;
+    std::unique_lock<std::mutex> bsgsLock(p->cacheMutex);
     if (!p->d_zeroRows) {
         void* dz = nullptr;
         const size_t bytes = ((size_t)(p->sizeQ + p->sizeP) << c->logN) * 8;
@@ -2018,8 +1918,7 @@ extern "C" fhe_status fhe_ckks_bsgs_transform(fhe_ks_plan* p, const uint64_t* c0
     auto it = p->bsgsTables.find(tab);
     if (it == p->bsgsTables.end()) {
         if (p->bsgsTables.size() >= 64) {  // a caller that keeps re-allocating its diagonals: drop the stale tables
-            RT_CHECK(rt::sync((rt::stream_t)st));
-            RT_CHECK(rt::sync(nullptr));
+            RT_CHECK(rt::device_sync());   // (a launch on ANY stream may still read one of them)
             for (auto& kv : p->bsgsTables)
                 rt::dfree(kv.second);
             p->bsgsTables.clear();
@@ -2031,6 +1930,7 @@ extern "C" fhe_status fhe_ckks_bsgs_transform(fhe_ks_plan* p, const uint64_t* c0
         it = p->bsgsTables.emplace(tab, dp).first;
     }
     const uint64_t* const* dTab = (const uint64_t* const*)it->second;
+    bsgsLock.unlock();
 
     // 1. inner (baby-step) rotations: one digit decomposition of c1 serves all of them (EvalFastRotationPrecompute, :1842)
     const KsLayout wB = ks_layout(p, sizeQl, batch);
@@ -2156,6 +2056,7 @@ extern "C" fhe_status fhe_approx_mod_down_bgv(fhe_ks_plan* p, const uint64_t* x,
     fhe_ks_plan::Level* lv = nullptr;
     if (fhe_status s = ks_level(p, sizeQl, &lv))
         return s;
+    std::unique_lock<std::mutex> lock(p->cacheMutex);
     auto it = lv->downT.find(t);
     if (it == lv->downT.end()) {
         std::vector<uint64_t> src(p->sizeP), dst(sizeQl), sScale(p->sizeP), dScale(sizeQl);
@@ -2173,8 +2074,10 @@ extern "C" fhe_status fhe_approx_mod_down_bgv(fhe_ks_plan* p, const uint64_t* x,
             return s;
         it = lv->downT.emplace(t, cv).first;
     }
+    fhe_conv* downT = it->second;
+    lock.unlock();
     uint64_t* ws = (uint64_t*)wsv;
-    if (fhe_status s = mod_down_core(p, lv, x, batch, ws + w.pcoef, ws + w.md, st, it->second))
+    if (fhe_status s = mod_down_core(p, lv, x, batch, ws + w.pcoef, ws + w.md, st, downT))
         return s;
     return mod_down_tail(p, lv, x, ws + w.md, batch, out, false, st);
 }
@@ -2199,6 +2102,7 @@ extern "C" fhe_status fhe_rescale(fhe_ctx* c, const uint64_t* x, uint32_t sizeQl
     uint64_t* tmp    = last + ((size_t)batch << c->logN);     // [batch][l][N]
     // tables (ckksrns-cryptoparameters.cpp:60-81): qlInvModq[i] = q_l^-1 mod q_i,
     // QlQlInvModqlDivqlModq[i] = floor(Q'*(Q'^-1 mod q_l)/q_l) mod q_i = -(q_l^-1) mod q_i   
+    std::unique_lock<std::mutex> lock(c->cacheMutex);
     auto it = c->rescaleTabs.find(sizeQl);
     if (it == c->rescaleTabs.end()) {
         std::vector<TwPair> hA(l), hB(l);
@@ -2220,6 +2124,7 @@ extern "C" fhe_status fhe_rescale(fhe_ctx* c, const uint64_t* x, uint32_t sizeQl
         it = c->rescaleTabs.emplace(sizeQl, std::make_pair((TwPair*)dA, (TwPair*)dB)).first;
     }
     TwPair *dA = it->second.first, *dB = it->second.second;
+    lock.unlock();
     // lastPoly.SetFormat(COEFFICIENT)  (:696-697): INTT of the last limb of every tower, written densely
     const uint32_t lastIdx = l;
     if (fhe_status s = ntt_run(c, true, x, last, &lastIdx, 1, batch, st, sizeQl, l))
@@ -2252,6 +2157,7 @@ extern "C" fhe_status fhe_mod_reduce(fhe_ctx* c, const uint64_t* x, uint32_t siz
     ARG_CHECK(t >= 2 && t % ql != 0, "fhe_mod_reduce: t must be invertible modulo the dropped limb");
     uint64_t* last = (uint64_t*)wsv;                    // [batch][N]
     uint64_t* tmp  = last + ((size_t)batch << c->logN);  // [batch][l][N]
+    std::unique_lock<std::mutex> lock(c->cacheMutex);
     auto it = c->modReduceTabs.find({sizeQl, t});
     if (it == c->modReduceTabs.end()) {
         std::vector<TwPair> h(2 * (size_t)l + 1);
@@ -2272,6 +2178,7 @@ extern "C" fhe_status fhe_mod_reduce(fhe_ctx* c, const uint64_t* x, uint32_t siz
         it = c->modReduceTabs.emplace(std::make_pair(sizeQl, t), (TwPair*)d).first;
     }
     TwPair *dA = it->second, *dB = dA + l, *dN = dA + 2 * (size_t)l;
+    lock.unlock();
     const uint32_t lastIdx = l;
     if (evalFormat) {  // delta.SetFormat(COEFFICIENT)  :741
         if (fhe_status s = ntt_run(c, true, x, last, &lastIdx, 1, batch, st, sizeQl, l))
@@ -2370,32 +2277,18 @@ extern "C" fhe_status fhe_scale_and_round_p_over_q(fhe_ctx* c, const uint64_t* x
     for (uint32_t i = 0; i <= sizeQ; ++i)
         ARG_CHECK(limbIdx[i] < c->L, "fhe_scale_and_round_p_over_q: limb index exceeds context size");
     RT_CHECK(rt::set_device(c->device));
+    ARG_CHECK(sizeQ <= (uint32_t)kMaxPOverQ, "fhe_scale_and_round_p_over_q: at most 64 limbs supported");
     const uint64_t pLast = c->q[limbIdx[sizeQ]];
-    std::vector<uint64_t> q(sizeQ), pinv(sizeQ);
-    for (uint32_t i = 0; i < sizeQ; ++i) {
-        q[i]    = c->q[limbIdx[i]];
-        pinv[i] = host::invmod(pLast % q[i], q[i]);  // pInvModq
-    }
-    TwPair* dInv = nullptr;
-    if (fhe_status s = consts_to_device(c, pinv.data(), limbIdx, sizeQ, st, &dInv))
-        return s;
-    // moduli go through the same ring (as raw words in the .w field of a second slot)
-    std::vector<uint64_t> qraw(q);
-    TwPair* dQ = nullptr;
-    {
-        std::vector<TwPair> h(sizeQ);
-        for (uint32_t i = 0; i < sizeQ; ++i)
-            h[i] = TwPair{q[i], 0};
-        TwPair* slot    = c->d_constRing + (size_t)(c->constRingPos % kConstRingSlots) * kMaxLimbs;
-        c->constRingPos = c->constRingPos + 1;
-        RT_CHECK(rt::h2d(slot, h.data(), sizeQ * sizeof(TwPair), (rt::stream_t)st));
-        RT_CHECK(rt::sync((rt::stream_t)st));
-        dQ = slot;
-    }
     POverQArgs g;
+    for (uint32_t i = 0; i < (uint32_t)kMaxPOverQ; ++i)
+        g.q[i] = 1, g.pInv[i] = TwPair{0, 0};
+    for (uint32_t i = 0; i < sizeQ; ++i) {
+        const uint64_t qi = c->q[limbIdx[i]], inv = host::invmod(pLast % qi, qi);  // pInvModq
+        g.q[i]    = qi;
+        g.pInv[i] = TwPair{inv, host::shoup(inv, qi)};
+    }
     g.x = TowerView{const_cast<uint64_t*>(x), sizeQ + 1, 0}, g.out = TowerView{out, sizeQ, 0};
-    g.q = nullptr, g.pInv = dInv, g.pLast = pLast, g.logN = c->logN, g.batch = batch, g.sizeQ = sizeQ;
-    g.qPairs = dQ;
+    g.pLast = pLast, g.logN = c->logN, g.batch = batch, g.sizeQ = sizeQ;
     FHE_LAUNCH(p_over_q_kernel, (uint32_t)((((uint64_t)batch << g.logN) + kThreads - 1) / kThreads), st, g);
     LAUNCH_CHECK();
     return FHE_OK;
@@ -2666,8 +2559,8 @@ extern "C" void fhe_behz_destroy(fhe_behz* h) {
         rt::dfree(p);
     delete h;
 }
-static bool behz_split30() {  // experimental: the BEHZ dot products with 30-bit split factors (same knob as the conversion kernel)
-    static const bool on = env_u32("FHE_CONV_SUM8", 1) == 2u;
+static bool behz_split30() {  // the BEHZ dot products with 30-bit split factors (default; same knob as the conversion kernel)
+    static const bool on = env_u32("FHE_CONV_SUM8", 2) != 1u;
     return on;
 }
 static uint32_t coeff_grid(const fhe_ctx* c, uint32_t batch) {

@@ -87,15 +87,6 @@ struct NttPassArgs {
     const uint64_t* epiA;
     const TwPair* epiC;
     uint64_t *epiOut0, *epiOut1;
-    // Optional prologue of a forward column pass (static kernels, experimental: FHE_KS_FUSE_CONV): the pass does not read
-    // its input but computes it as the CRT basis conversion  r = sum_i y_i * proH[row][i] mod q_row  from the proNSrc <= 8
-    // rows proFirst.. of the [batch][proStride][N] view proY (y_i = x_i * [Qhat_i^-1]_{q_i}, left there by an inverse
-    // transform whose final constant carries that factor): ApproxSwitchCRTBasis (dcrtpoly-impl.h:888-915) inside the
-    // HBM-bound pass instead of in a kernel of its own.  proH: [nLimbs][8] (ConvTables::hatMod), mu128: [ctxLimbs][2].
-    uint32_t proNSrc, proStride, proFirst;
-    const uint64_t* proY;
-    const uint64_t* proH;
-    const uint64_t* mu128;
 };
 
 // LDS word index swizzle: conflict-free ds_read_b64/ds_write_b64 for every register-field position
@@ -350,257 +341,13 @@ FHE_HD uint64_t csub2(uint64_t x, uint64_t m) {
     const uint64_t d = x - m;
     return x < m ? x : d;
 }
-// Hand-scheduled butterflies for gfx950 (device build only; the C++ bodies below are the same arithmetic and are
-// what the host/emulator build runs).  gfx950 requires 64-bit VGPR operands to be even-aligned register pairs, so
-// "high word of a product as a 64-bit addend" costs a move into an even register whose odd neighbour holds 0 (or
-// the carry) — hipcc spends 9-13 v_mov per butterfly on this; with temporaries pinned to v[100:111] the chain
-// needs two:
-//   hi64(y*w'):  A.hi = mul_hi(yl,pl);  B = yh*pl + A.hi;  C = yl*ph + B (carry -> vcc);  Q = yh*ph + {C.hi, carry}
-//   x + T     :  L = yl*wl + x;  L += Ql*nql;  X = yl*wh + yh*wl + Ql*nqh + Qh*nql (low word only);  L.hi += X.lo
-//   x - T + 2q:  (x << 1) + 2q - (x + T)
-// 18 VALU instructions, 10 of them v_mad_u64_u32 / v_mul_hi_u32.  Carry-outs nobody reads go to s[40:41].
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(FHE_NO_BFLY_ASM)
-#define FHE_BFLY_CLOBBERS "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "vcc", "s40", "s41"
-__device__ __forceinline__ void bfly_fwd_fast(uint64_t& a, uint64_t& b, const TwPair w, uint64_t nq, uint64_t twoq) {
-    const uint32_t yl = (uint32_t)b, yh = (uint32_t)(b >> 32);
-    const uint32_t wl = (uint32_t)w.w, wh = (uint32_t)(w.w >> 32), pl = (uint32_t)w.wp, ph = (uint32_t)(w.wp >> 32);
-    const uint32_t nql = (uint32_t)nq, nqh = (uint32_t)(nq >> 32);
-    asm volatile(
-        "v_mov_b32 v101, 0\n\t"
-        "v_mul_hi_u32 v100, %2, %6\n\t"
-        "v_mad_u64_u32 v[110:111], s[40:41], %2, %5, 0\n\t"
-        "v_mad_u64_u32 v[102:103], s[40:41], %3, %6, v[100:101]\n\t"
-        "v_mad_u64_u32 v[104:105], vcc, %2, %7, v[102:103]\n\t"
-        "v_mad_u64_u32 v[110:111], s[40:41], %3, %4, v[110:111]\n\t"
-        "v_mov_b32 v106, v105\n\t"
-        "v_cndmask_b32_e64 v107, 0, 1, vcc\n\t"
-        "v_mad_u64_u32 v[108:109], s[40:41], %3, %7, v[106:107]\n\t"
-        "v_mad_u64_u32 v[102:103], s[40:41], %2, %4, %0\n\t"
-        "v_lshl_add_u64 v[104:105], %0, 1, %10\n\t"
-        "v_mad_u64_u32 v[110:111], s[40:41], v108, %9, v[110:111]\n\t"
-        "v_mad_u64_u32 v[110:111], s[40:41], v109, %8, v[110:111]\n\t"
-        "v_mad_u64_u32 v[102:103], s[40:41], v108, %8, v[102:103]\n\t"
-        "v_add_u32 v103, v103, v110\n\t"
-        "v_sub_co_u32 v104, vcc, v104, v102\n\t"
-        "v_mov_b64 %0, v[102:103]\n\t"
-        "s_nop 0\n\t"
-        "v_subb_co_u32 v105, vcc, v105, v103, vcc\n\t"
-        "v_mov_b64 %1, v[104:105]\n\t"
-        : "+v"(a), "+v"(b)
-        : "v"(yl), "v"(yh), "v"(wl), "v"(wh), "v"(pl), "v"(ph), "v"(nql), "v"(nqh), "v"(twoq)
-        : FHE_BFLY_CLOBBERS);
-}
-// inverse (Gentleman-Sande): a' = (u + v) mod 2q,  b' = (u - v + 2q) * w  (lazy, < 2q)
-__device__ __forceinline__ void bfly_inv_fast(uint64_t& a, uint64_t& b, const TwPair w, uint64_t nq, uint64_t twoq) {
-    const uint32_t vl = (uint32_t)b, vh = (uint32_t)(b >> 32);
-    const uint32_t wl = (uint32_t)w.w, wh = (uint32_t)(w.w >> 32), pl = (uint32_t)w.wp, ph = (uint32_t)(w.wp >> 32);
-    const uint32_t nql = (uint32_t)nq, nqh = (uint32_t)(nq >> 32);
-    const uint32_t tql = (uint32_t)twoq, tqh = (uint32_t)(twoq >> 32);
-    asm volatile(
-        // y = u - v + 2q -> v[108:109] ; s = u + v -> v[104:105]
-        "v_lshl_add_u64 v[108:109], %0, 0, %10\n\t"
-        "v_lshl_add_u64 v[104:105], %0, 0, %1\n\t"
-        "v_sub_co_u32 v108, vcc, v108, %2\n\t"
-        "v_mov_b32 v101, 0\n\t"
-        "s_nop 0\n\t"
-        "v_subb_co_u32 v109, vcc, v109, %3, vcc\n\t"
-        // a' = s >= 2q ? s - 2q : s
-        "v_sub_co_u32 v106, vcc, v104, %11\n\t"
-        "v_mul_hi_u32 v100, v108, %6\n\t"
-        "v_mad_u64_u32 v[110:111], s[40:41], v108, %5, 0\n\t"
-        "v_subb_co_u32 v107, vcc, v105, %12, vcc\n\t"
-        "v_mad_u64_u32 v[102:103], s[40:41], v109, %6, v[100:101]\n\t"
-        "v_mad_u64_u32 v[110:111], s[40:41], v109, %4, v[110:111]\n\t"
-        "v_cndmask_b32_e32 v104, v106, v104, vcc\n\t"
-        "v_cndmask_b32_e32 v105, v107, v105, vcc\n\t"
-        "v_mov_b64 %0, v[104:105]\n\t"
-        // b' = shoup(y): hi64(y*w') then lo64(y*w + Q*nq)
-        "v_mad_u64_u32 v[104:105], vcc, v108, %7, v[102:103]\n\t"
-        "v_mad_u64_u32 v[102:103], s[40:41], v108, %4, 0\n\t"
-        "v_mov_b32 v106, v105\n\t"
-        "v_cndmask_b32_e64 v107, 0, 1, vcc\n\t"
-        "v_mad_u64_u32 v[104:105], s[40:41], v109, %7, v[106:107]\n\t"
-        "v_mad_u64_u32 v[110:111], s[40:41], v104, %9, v[110:111]\n\t"
-        "v_mad_u64_u32 v[110:111], s[40:41], v105, %8, v[110:111]\n\t"
-        "v_mad_u64_u32 v[102:103], s[40:41], v104, %8, v[102:103]\n\t"
-        "v_add_u32 v103, v103, v110\n\t"
-        "v_mov_b64 %1, v[102:103]\n\t"
-        : "+v"(a), "+v"(b)
-        : "v"(vl), "v"(vh), "v"(wl), "v"(wh), "v"(pl), "v"(ph), "v"(nql), "v"(nqh), "v"(twoq), "v"(tql), "v"(tqh)
-        : FHE_BFLY_CLOBBERS);
-}
-#else
+// forward butterfly of the static kernels' plain C++ path (host / emulator build, and the device build under
+// FHE_NO_BFLY_ASM); the product kernels run the generated in-place gfx950 code of ntt_bfly_pinned.h instead
 FHE_HD void bfly_fwd_fast(uint64_t& a, uint64_t& b, const TwPair w, uint64_t nq, uint64_t twoq) {
     const uint64_t X  = a;
     const uint64_t an = shoup_acc(X, b, w, nq);  // X + T
     b                 = (X << 1) + twoq - an;    // X - T + 2q
     a                 = an;
-}
-FHE_HD void bfly_inv_fast(uint64_t& a, uint64_t& b, const TwPair w, uint64_t nq, uint64_t twoq) {
-    const uint64_t u = a, v = b;
-    a                = csub2(u + v, twoq);
-    b                = shoup_acc(0, u - v + twoq, w, nq);
-}
-#endif
-
-// ================================================================================================
-// Production kernel for rings with N >= 4096: one tile per workgroup like ntt_pass_kernel, but the tile
-// lies inside one limb (wave-uniform modulus and twiddle base, no range checks), butterflies use the
-// multiply-add chain with the x+T sum folded in (bfly_fwd_fast), and the forward transform follows the
-// lazy-reduction schedule of NttStep::mode / NttPassArgs::canonLevels instead of one conditional
-// subtraction per butterfly.
-// ================================================================================================
-template <bool LAYOUT_A, bool INVERSE>
-FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_pass_full_kernel(const NttPassArgs a) {
-    FHE_SHARED_U64(lds, kTile);
-    const uint32_t t    = FHE_TID;
-    const uint32_t logN = a.logN;
-    const uint32_t N    = 1u << logN;
-    const uint32_t T    = a.T;
-    const uint32_t tilesPerRow = N >> kTileLog;
-    uint32_t tile = FHE_BID;
-    if (a.xcdSwizzle) {
-        const uint32_t xcd = tile & 7u, i = tile >> 3;
-        const uint32_t b = i % a.batch, pairIdx = i / a.batch;
-        const uint32_t pair = pairIdx * 8u + xcd;
-        tile = (b * a.nLimbs + pair / tilesPerRow) * tilesPerRow + pair % tilesPerRow;
-    }
-    const uint32_t logC = kTileLog - T;
-    const uint32_t S    = N >> T;
-    const uint32_t row  = tile / tilesPerRow, tr = tile % tilesPerRow;
-    const uint32_t jbase = LAYOUT_A ? (tr << logC) : (tr << kTileLog);
-    // physical row of this tile in the source / destination views
-    const uint32_t tb = row / a.nLimbs, rit = row % a.nLimbs;
-    const uint64_t inRow  = a.inStride ? ((uint64_t)tb * a.inStride + a.inFirst + rit) : (uint64_t)row;
-    const uint64_t outRow = a.outStride ? ((uint64_t)tb * a.outStride + a.outFirst + rit) : (uint64_t)row;
-    const uint32_t limb = FHE_UNIFORM(a.sel.idx[rit]);
-    const uint64_t q    = a.q[limb];
-    const uint64_t twoq = q << 1, nq = 0 - q;
-    const TwPair* tw    = a.tw + ((uint64_t)limb << logN);
-
-    uint64_t r[16];
-    for (uint32_t si = 0; si < a.nSteps; ++si) {
-        const NttStep st  = a.steps[si];
-        const uint32_t fI = (uint32_t)st.fI;
-        const uint32_t Ib = ((t >> fI) << (fI + 4)) | (t & ((1u << fI) - 1u));
-        uint32_t jrel;
-        uint64_t kstride;
-        if (LAYOUT_A) {
-            const uint32_t p0 = Ib >> logC, c0 = Ib & ((1u << logC) - 1u);
-            jrel    = p0 * S + c0;
-            kstride = (fI >= logC) ? ((uint64_t)S << (fI - logC)) : ((uint64_t)1 << fI);
-        }
-        else {
-            jrel    = Ib;
-            kstride = (uint64_t)1 << fI;
-        }
-        const uint32_t j0 = jbase + jrel;
-        if (si == 0) {
-            const uint64_t* src = a.xin + (inRow << logN) + j0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                r[k] = src[k * kstride];
-        }
-        else {
-            const uint32_t sb = lds_sigma(Ib);
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                r[k] = lds[sb ^ lds_sigma((uint32_t)k << fI)];
-            FHE_SYNC();
-        }
-        if (st.bHi >= st.bLo) {
-            const uint32_t Fj = (uint32_t)st.Fj;
-            uint32_t jhigh    = j0 >> (Fj + 4);
-            if (st.uniformTw)
-                jhigh = FHE_UNIFORM(jhigh);
-            if (!INVERSE) {
-                if (st.mode == 1) {
-#pragma unroll
-                    for (int k = 0; k < 16; ++k)
-                        r[k] = csub2(r[k], twoq << 2);
-                }
-#pragma unroll
-                for (int b = 3; b >= 0; --b) {
-                    if (b <= st.bHi && b >= st.bLo) {
-                        const uint32_t s      = logN - 1u - (Fj + b);
-                        const uint32_t twbase = (1u << s) + (jhigh << (3 - b));
-                        TwPair wv[8];  // all twiddles of the stage in flight before the first butterfly
-#pragma unroll
-                        for (int g = 0; g < (8 >> b); ++g)
-                            wv[g] = tw[twbase + g];
-#pragma unroll
-                        for (int g = 0; g < (8 >> b); ++g) {
-#pragma unroll
-                            for (int lo = 0; lo < (1 << b); ++lo) {
-                                const int k0 = (g << (b + 1)) | lo;
-                                bfly_fwd_fast(r[k0], r[k0 | (1 << b)], wv[g], nq, twoq);
-                            }
-                        }
-                    }
-                }
-            }
-            else {
-#pragma unroll
-                for (int b = 0; b <= 3; ++b) {
-                    if (b <= st.bHi && b >= st.bLo) {
-                        const uint32_t s      = logN - 1u - (Fj + b);
-                        const uint32_t twbase = (1u << s) + (jhigh << (3 - b));
-                        if (s == 0) {
-                            const TwPair nInv = a.fin[2 * limb], w1n = a.fin[2 * limb + 1];
-#pragma unroll
-                            for (int lo = 0; lo < (1 << b); ++lo) {
-                                const uint64_t u = r[lo], v = r[lo | (1 << b)];
-                                r[lo]            = shoup_acc(0, u + v, nInv, nq);
-                                r[lo | (1 << b)] = shoup_acc(0, u - v + twoq, w1n, nq);
-                            }
-                        }
-                        else {
-                            TwPair wv[8];
-#pragma unroll
-                            for (int g = 0; g < (8 >> b); ++g)
-                                wv[g] = tw[twbase + g];
-#pragma unroll
-                            for (int g = 0; g < (8 >> b); ++g) {
-#pragma unroll
-                                for (int lo = 0; lo < (1 << b); ++lo) {
-                                    const int k0 = (g << (b + 1)) | lo;
-                                    bfly_inv_fast(r[k0], r[k0 | (1 << b)], wv[g], nq, twoq);
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        if (si == a.canonStep) {
-            if (INVERSE) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    r[k] = csub2(r[k], q);
-            }
-            else {
-                for (int lv = (int)a.canonLevels - 1; lv >= 0; --lv) {
-                    const uint64_t m = q << lv;
-#pragma unroll
-                    for (int k = 0; k < 16; ++k)
-                        r[k] = csub2(r[k], m);
-                }
-            }
-        }
-        if (si + 1 == a.nSteps) {
-            uint64_t* dst = a.x + (outRow << logN) + j0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                dst[k * kstride] = r[k];
-        }
-        else {
-            const uint32_t sb = lds_sigma(Ib);
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                lds[sb ^ lds_sigma((uint32_t)k << fI)] = r[k];
-            FHE_SYNC();
-        }
-    }
 }
 
 }  // namespace fhe

@@ -420,23 +420,17 @@ FHE_HD void lane_geom_s(uint32_t t, uint32_t S, uint32_t& Ib, uint32_t& jrel, ui
 // MODE, forward: an upper bound of the pass input in units of q — 1 = canonical, 9 = the lazy output of a 4-stage
 // column pass, 16 = anything below 16q (the lazy-reduction schedule is derived from it).  MODE, inverse: 1 = this pass ends the transform
 // (its top stage is the transform's last stage, with N^-1 folded in), 0 = it does not.
-// DB: two LDS buffers alternate (one barrier per exchange, 68 KiB, 2 workgroups per CU) instead of one buffer with a
-// barrier on either side of the exchange (34 KiB, 4 workgroups per CU).
-template <bool LA, bool INV, int T, int MODE, bool DB, bool EPI = false, bool PRO = false>
+// One LDS buffer with a barrier on either side of an exchange (34 KiB, 4 workgroups per CU); the double-buffered form
+// (68 KiB, 2 workgroups per CU) was measured slower (profiles/r01_sweeps.md).
+template <bool LA, bool INV, int T, int MODE, bool EPI = false>
 FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) {
-    static_assert(!PRO || (LA && !INV && !EPI), "the conversion prologue belongs to a forward column pass");
     using P = SPlan<LA, INV, T>;
     const uint32_t t    = FHE_TID;
     const uint32_t logN = a.logN;
     const uint32_t N    = 1u << logN;
     const uint32_t tilesPerRow = N >> kTileLog;
     uint32_t tile = bid;
-    if (PRO && a.xcdSwizzle == 2u) {  // prologue: the nLimbs workgroups that convert the same source tile take one XCD's slots
-        const uint32_t xcd = tile & 7u, i = tile >> 3;
-        const uint32_t l = i % a.nLimbs, grp = (i / a.nLimbs) * 8u + xcd;  // grp runs over batch x tilesPerRow
-        tile = ((grp / tilesPerRow) * a.nLimbs + l) * tilesPerRow + grp % tilesPerRow;
-    }
-    else if (a.xcdSwizzle) {
+    if (a.xcdSwizzle) {
         const uint32_t xcd = tile & 7u, i = tile >> 3;
         const uint32_t b = i % a.batch, pairIdx = i / a.batch;
         const uint32_t pair = pairIdx * 8u + xcd;
@@ -459,7 +453,7 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
     if (!LA && a.twRow)  // [limb][tile of the ring][slot][lane]
         ts.rowLane = a.twRow + ((size_t)limb * tilesPerRow + tr) * (kRowTwSlots * kThreads) + t;
     // twiddles of the shared step: one 16-byte global load per lane now, written to LDS behind the data loads
-    TwPair* sharedLds = reinterpret_cast<TwPair*>(lds + (DB ? 2 : 1) * kLdsPadWords);
+    TwPair* sharedLds = reinterpret_cast<TwPair*>(lds + kLdsPadWords);
     ts.shared         = sharedLds;
     ts.sharedLane     = 0;
     uint64_t sharedW = 0, sharedWp = 0;  // (two scalars: a conditionally assigned 16-byte struct lands in scratch)
@@ -496,7 +490,6 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
     uint64_t r[16];
     uint32_t Ib, jrel;
     uint64_t ks;
-    int buf = 0;  // LDS buffer of the next exchange
     // final store of the pass, with the optional fused epilogue (NttPassArgs::epiMode)
     auto store_result = [&](uint64_t (&v)[16], uint32_t jr, uint64_t kstr) {
         if constexpr (!EPI) {
@@ -541,36 +534,6 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
         }
     };
 
-    // (PRO) first load of the pass: instead of the tower's residues, their conversion from the source limbs
-    auto load_converted = [&](uint64_t (&v)[16], uint32_t jr, uint64_t kstr) {
-        if constexpr (PRO) {
-            uint64_t h[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                h[i] = FHE_ULOAD64(a.proH, (uint64_t)rit * 8u + i);  // zero beyond proNSrc
-            const uint64_t mulo = FHE_ULOAD64(a.mu128, 2 * (uint64_t)limb), muhi = FHE_ULOAD64(a.mu128, 2 * (uint64_t)limb + 1);
-            const uint32_t kq   = 64u - (uint32_t)__builtin_clzll(q);
-            const uint64_t* yb  = a.proY + (((uint64_t)tb * a.proStride + a.proFirst) << logN) + jbase;
-            uint32_t h0[8], h1[8];  // factors split at 30 bits: no carry bookkeeping in the sums (sum8s, modarith.h)
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                split30(h[i], h0[i], h1[i]);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                sum8s sacc;
-                sum8s_clear(sacc);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const uint32_t rowi = (uint32_t)i < a.proNSrc ? (uint32_t)i : a.proNSrc - 1u;  // unconditional loads
-                    uint32_t y0, y1;
-                    split30(yb[((uint64_t)rowi << logN) + jr + k * kstr], y0, y1);
-                    sum8s_add(sacc, y0, y1, h0[i], h1[i]);
-                }
-                v[k] = sum8s_reduce(sacc, q, kq, mulo, muhi);
-            }
-        }
-    };
-
 #define FHE_SHARED_TW_TO_LDS()                                             \
     if constexpr (useShared) {                                             \
         if (t < (uint32_t)SS::total)                                       \
@@ -583,15 +546,11 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
     // ---- first load ----
     if constexpr (P::stageFirst) {
         lane_geom_s<LA, T, 8>(t, S, Ib, jrel, ks);
-        if constexpr (PRO)
-            load_converted(r, jrel, ks);
-        else {
 #pragma unroll
-            for (int k = 0; k < 16; ++k)
-                r[k] = src[jrel + k * ks];
-        }
+        for (int k = 0; k < 16; ++k)
+            r[k] = src[jrel + k * ks];
         FHE_SHARED_TW_TO_LDS()
-        uint64_t* L = lds + buf * kLdsPadWords + lds_pad(Ib);
+        uint64_t* L = lds + lds_pad(Ib);
 #pragma unroll
         for (int k = 0; k < 16; ++k)
             FHE_LDS_ST(L[lds_pad((uint32_t)k << 8)], r[k]);
@@ -603,18 +562,12 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
         constexpr int fI = P::fI(I);                                                                              \
         lane_geom_s<LA, T, fI>(t, S, Ib, jrel, ks);                                                               \
         if constexpr (I == 0 && !P::stageFirst) {                                                                 \
-            if constexpr (PRO)                                                                                    \
-                load_converted(r, jrel, ks);                                                                      \
-            else {                                                                                                \
-                _Pragma("unroll") for (int k = 0; k < 16; ++k) r[k] = src[jrel + k * ks];                         \
-            }                                                                                                     \
+            _Pragma("unroll") for (int k = 0; k < 16; ++k) r[k] = src[jrel + k * ks];                             \
             FHE_SHARED_TW_TO_LDS()                                                                                \
         }                                                                                                         \
         else {                                                                                                    \
-            const uint64_t* L = lds + buf * kLdsPadWords + lds_pad(Ib);                                           \
+            const uint64_t* L = lds + lds_pad(Ib);                                           \
             _Pragma("unroll") for (int k = 0; k < 16; ++k) FHE_LDS_LD(r[k], L[lds_pad((uint32_t)k << fI)]);                  \
-            if constexpr (DB)                                                                                     \
-                buf ^= 1;                                                                                         \
         }                                                                                                         \
         /* lazy reduction: a forward butterfly's outputs are bounded by its `a` input + 2q whatever the `b` input  \
            (< 2^64) is, so only the 8 `a` inputs of the step's first stage go back below 8q */                      \
@@ -640,9 +593,9 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
             store_result(r, jrel, ks);                                                                            \
         }                                                                                                         \
         else {                                                                                                    \
-            if constexpr (!DB && (I > 0 || P::stageFirst))                                                        \
+            if constexpr (I > 0 || P::stageFirst)                                                                 \
                 FHE_SSYNC(); /* every lane has finished reading the buffer */                                      \
-            uint64_t* L = lds + buf * kLdsPadWords + lds_pad(Ib);                                                 \
+            uint64_t* L = lds + lds_pad(Ib);                                                 \
             _Pragma("unroll") for (int k = 0; k < 16; ++k) FHE_LDS_ST(L[lds_pad((uint32_t)k << fI)], r[k]);                  \
             FHE_SSYNC();                                                                                           \
         }                                                                                                         \
@@ -656,7 +609,7 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
     // ---- last store ----
     if constexpr (P::stageLast) {
         lane_geom_s<LA, T, 8>(t, S, Ib, jrel, ks);
-        const uint64_t* L = lds + buf * kLdsPadWords + lds_pad(Ib);
+        const uint64_t* L = lds + lds_pad(Ib);
 #pragma unroll
         for (int k = 0; k < 16; ++k)
             FHE_LDS_LD(r[k], L[lds_pad((uint32_t)k << 8)]);
@@ -664,14 +617,14 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
     }
 }
 
-template <bool LA, bool INV, int T, int MODE, bool DB, bool EPI = false, bool PRO = false>
+template <bool LA, bool INV, int T, int MODE, bool EPI = false>
 FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_static_kernel(const NttPassArgs a) {
     // a single-step pass without staging (the 4-stage column pass) never touches LDS: do not reserve any, so that
     // more workgroups fit on a CU
     using P = SPlan<LA, INV, T>;
     constexpr bool needsLds = P::nst > 1 || P::stageFirst || P::stageLast;
-    FHE_SHARED_U64(lds, needsLds ? (DB ? 2 : 1) * kLdsPadWords + kSharedTwWords : 1);
-    ntt_static_body<LA, INV, T, MODE, DB, EPI, PRO>(a, FHE_BID, lds);
+    FHE_SHARED_U64(lds, needsLds ? kLdsPadWords + kSharedTwWords : 1);
+    ntt_static_body<LA, INV, T, MODE, EPI>(a, FHE_BID, lds);
 }
 
 }  // namespace fhe

@@ -59,6 +59,7 @@ inline const char* capture_end(stream_t, graph_t*) { return "stream capture need
 inline const char* graph_launch(graph_t, stream_t) { return "stream capture needs the HIP build"; }
 inline const char* graph_destroy(graph_t) { return nullptr; }
 inline const char* sync(stream_t) { return nullptr; }
+inline const char* device_sync() { return nullptr; }
 inline const char* last_launch_error() { return nullptr; }
 struct Timer {
     std::chrono::steady_clock::time_point t0;
@@ -127,6 +128,7 @@ inline const char* capture_end(stream_t s, graph_t* out) {
 inline const char* graph_launch(graph_t g, stream_t s) { return err(hipGraphLaunch(g, s)); }
 inline const char* graph_destroy(graph_t g) { return err(hipGraphExecDestroy(g)); }
 inline const char* sync(stream_t st) { return err(hipStreamSynchronize(st)); }
+inline const char* device_sync() { return err(hipDeviceSynchronize()); }
 inline const char* last_launch_error() { return err(hipGetLastError()); }
 struct Timer {
     hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -79,6 +79,10 @@ class Lib:
             S(n, C.c_int, [vp, vp, vp, vp, u32p, u32, u32, vp])
         S("fhe_neg", C.c_int, [vp, vp, vp, u32p, u32, u32, vp])
         S("fhe_mul_const", C.c_int, [vp, vp, vp, u64p, u32p, u32, u32, vp])
+        S("fhe_mult_acc", C.c_int, [vp, vp, vp, u64p, u32p, u32, u32, vp])
+        S("fhe_tensor_square", C.c_int, [vp, vp, vp, vp, vp, vp, u32p, u32, u32, vp])
+        S("fhe_mod_up", C.c_int, [vp, vp, C.c_int, vp, u32, vp, C.c_size_t, vp])
+        S("fhe_expand_crt_basis_ql_hat", C.c_int, [vp, vp, u32, u64p, u32p, u32, u32, vp, vp])
         S("fhe_tensor", C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, u32p, u32, u32, vp])
         S("fhe_automorph", C.c_int, [vp, vp, vp, u32, C.c_int, u32p, u32, u32, vp])
         S("fhe_switch_modulus", C.c_int, [vp, vp, u32p, u32, vp, u32, u32, u32, u32, vp])
@@ -143,7 +147,6 @@ class Lib:
         S("fhe_param_dcrt_chain", C.c_int, [u32, u32, u32, u64p, u64p])
         S("fhe_param_select_p", u32, [u32, u32, u64p, u32, u32, u64p, u64p])
         S("fhe_param_find_automorphism_index_2n_complex", u32, [C.c_int32, u32])
-        S("fhe_debug_fused_conv_launches", C.c_uint64, [])
         S("fhe_time_ntt", C.c_int, [vp, vp, u32p, u32, u32, C.c_int, C.c_int, vp, C.POINTER(C.c_float)])
 
     def check(self, status):
@@ -215,13 +218,13 @@ class Context:
         lib.check(lib.L.fhe_ctx_create(logN, self.L, self.q.ctypes.data_as(u64p), self.psi.ctypes.data_as(u64p),
                                        device, C.byref(h)))
         self.h = h
-        self._allocs = []
+        self._allocs = {}  # pointer value -> handle
 
     def close(self):
         if self.h:
-            for p in self._allocs:
+            for p in self._allocs.values():
                 self.lib.L.fhe_free(self.h, p)
-            self._allocs = []
+            self._allocs = {}
             self.lib.L.fhe_ctx_destroy(self.h)
             self.h = None
 
@@ -229,12 +232,12 @@ class Context:
     def malloc(self, nbytes):
         p = vp()
         self.lib.check(self.lib.L.fhe_malloc(self.h, nbytes, C.byref(p)))
-        self._allocs.append(p)
+        self._allocs[p.value] = p
         return p
 
     def free(self, p):
-        self._allocs = [a for a in self._allocs if a.value != p.value]
-        self.lib.check(self.lib.L.fhe_free(self.h, p))
+        if self._allocs.pop(p.value, None) is not None:
+            self.lib.check(self.lib.L.fhe_free(self.h, p))
 
     def upload(self, arr, stream=None):
         arr = np.ascontiguousarray(arr, dtype=np.uint64)
@@ -257,17 +260,18 @@ class Context:
         host = np.asarray(host, dtype=np.uint64)
         if host.ndim == 2:
             host = host[None]
-        return Tower(self, self.upload(host), host.shape[0], host.shape[1], limb_idx, fmt)
+        return Tower(self, self.upload(host), host.shape[0], host.shape[1], limb_idx, fmt, owned=True)
 
     def empty(self, batch, n_limbs, limb_idx=None, fmt=EVALUATION):
-        return Tower(self, self.malloc(batch * n_limbs * self.N * 8), batch, n_limbs, limb_idx, fmt)
+        return Tower(self, self.malloc(batch * n_limbs * self.N * 8), batch, n_limbs, limb_idx, fmt, owned=True)
 
 
 class Tower:
     """A batch of device-resident RNS towers: the DCRTPoly data model, uint64[batch][nLimbs][N]."""
 
-    def __init__(self, ctx, ptr, batch, n_limbs, limb_idx=None, fmt=EVALUATION):
+    def __init__(self, ctx, ptr, batch, n_limbs, limb_idx=None, fmt=EVALUATION, owned=False):
         self.ctx, self.ptr, self.batch, self.n_limbs, self.fmt = ctx, ptr, batch, n_limbs, fmt
+        self._owned = owned  # allocated by Context.tower()/empty(): freed with the object
         self.limb_idx = None if limb_idx is None else np.ascontiguousarray(np.asarray(limb_idx, dtype=np.uint32))
 
     def _li(self):
@@ -278,6 +282,25 @@ class Tower:
 
     def like(self):
         return self.ctx.empty(self.batch, self.n_limbs, self.limb_idx, self.fmt)
+
+    def free(self):
+        """release the device buffer now (a Tower that is simply dropped is released by the garbage collector)"""
+        if self.ptr is not None and self.ctx.h:
+            self.ctx.free(self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_owned", False):
+                self.free()
+        except Exception:
+            pass
+
+    def MultAccEqNoCheck(self, v, consts, stream=None):  # poly.h:323 / mubintvecnat.cpp:132-142, per limb
+        consts = np.ascontiguousarray(np.asarray(consts, dtype=np.uint64))
+        self.ctx.lib.check(self.ctx.lib.L.fhe_mult_acc(self.ctx.h, self.ptr, v.ptr, consts.ctypes.data_as(u64p), self._li(),
+                                                      self.n_limbs, self.batch, stream))
+        return self
 
     # DCRTPolyImpl::SwitchFormat (dcrtpoly-impl.h:1932-1940)
     def SwitchFormat(self, stream=None):
@@ -377,6 +400,20 @@ class Conv:
             self.ctx.lib.check(L.fhe_expand_crt_basis(self.h, tin.ptr, 1 if tin.fmt == EVALUATION else 0, out.ptr,
                                                       1 if result_format == EVALUATION else 0, 1 if reverse else 0,
                                                       tin.batch, ws, wsb, stream))
+            self.ctx.sync(stream)
+        finally:
+            self.ctx.free(ws)
+        return out
+
+    def ApproxModUp(self, tin, stream=None):
+        """DCRTPoly::ApproxModUp (dcrtpoly-impl.h:935-963): tower over the source basis (either format) -> Q u P, EVALUATION"""
+        idx = np.concatenate([self.src, self.dst])
+        out = self.ctx.empty(tin.batch, len(idx), idx, EVALUATION)
+        L = self.ctx.lib.L
+        wsb = L.fhe_expand_crt_basis_workspace_bytes(self.h, tin.batch)
+        ws = self.ctx.malloc(wsb)
+        try:
+            self.ctx.lib.check(L.fhe_mod_up(self.h, tin.ptr, 1 if tin.fmt == EVALUATION else 0, out.ptr, tin.batch, ws, wsb, stream))
             self.ctx.sync(stream)
         finally:
             self.ctx.free(ws)

@@ -1713,6 +1713,62 @@ void orc_expand_crt_basis(const orc_ctx* ctxQP, uint32_t nQ, uint32_t nP, const 
     free(partP);
 }
 
+/* DCRTPolyImpl::ApproxModUp (dcrtpoly-impl.h:935-963).  ctxQP: limbs 0..nQ-1 = Q, nQ.. = P.  x [nQ][N] in `inEval`;
+ * out [(nQ+nP)][N] EVALUATION: the stored EVALUATION copy of the Q limbs is moved back (:943-951), the P part is
+ * ApproxSwitchCRTBasis of the coefficient form (:948), every limb goes to EVALUATION (:958-960).  QHatModp [nQ][nP]. */
+void orc_approx_mod_up(const orc_ctx* ctxQP, uint32_t nQ, uint32_t nP, const uint64_t* x, int inEval,
+                       const uint64_t* QHatInvModq, const uint64_t* QHatInvModqPrecon, const uint64_t* QHatModp,
+                       const uint64_t* muP128, uint64_t* out) {
+    const uint32_t N = ctxQP->N;
+    const size_t qw = (size_t)nQ * N;
+    uint64_t* coef = (uint64_t*)malloc(8 * qw);
+    memcpy(coef, x, 8 * qw);
+    if (inEval)
+        for (uint32_t i = 0; i < nQ; ++i)
+            ctx_inv(ctxQP, coef + (size_t)i * N, i);
+    orc_approx_switch_crt_basis(coef, nQ, N, ctxQP->q, QHatInvModq, QHatInvModqPrecon, QHatModp, nP, ctxQP->q + nQ, muP128,
+                                out + qw);
+    memcpy(out, inEval ? x : coef, 8 * qw);
+    for (uint32_t i = 0; i < nQ + nP; ++i)
+        if (!(inEval && i < nQ)) /* SetFormat(EVALUATION) is a no-op on limbs that already are */
+            ctx_fwd(ctxQP, out + (size_t)i * N, i);
+    free(coef);
+}
+
+/* DCRTPolyImpl::ExpandCRTBasisQlHat (dcrtpoly-impl.h:1167-1187): x [sizeQl][N] -> out [sizeQ][N], limbs below sizeQl times
+ * QlHatModq[i] (ModMulFastConst), the appended limbs zero */
+void orc_expand_crt_basis_ql_hat(const uint64_t* x, uint32_t sizeQl, uint32_t N, const uint64_t* q, const uint64_t* QlHatModq,
+                                 uint32_t sizeQ, uint64_t* out) {
+    for (uint32_t i = 0; i < sizeQl; ++i) {
+        const uint64_t pre = orc_prep_mod_mul_const(QlHatModq[i], q[i]);
+        for (uint32_t r = 0; r < N; ++r)
+            out[(size_t)i * N + r] = orc_mod_mul_fast_const(x[(size_t)i * N + r], QlHatModq[i], q[i], pre);
+    }
+    memset(out + (size_t)sizeQl * N, 0, 8 * (size_t)(sizeQ - sizeQl) * N);
+}
+
+/* LeveledSHEBase::EvalSquareCore for a 2-element ciphertext (base-leveledshe.cpp:646-664): towers [nLimbs][N] over q[] */
+void orc_eval_square_core(const uint64_t* a0, const uint64_t* a1, uint32_t nLimbs, uint32_t N, const uint64_t* q, uint64_t* d0,
+                          uint64_t* d1, uint64_t* d2) {
+    for (uint32_t i = 0; i < nLimbs; ++i) {
+        const size_t o = (size_t)i * N;
+        orc_vec_mul(d0 + o, a0 + o, a0 + o, N, q[i]); /* cv[0] * cv[0] */
+        orc_vec_mul(d1 + o, a0 + o, a1 + o, N, q[i]); /* cv[0] * cv[1] */
+        orc_vec_add(d1 + o, d1 + o, d1 + o, N, q[i]); /* cvr.back() += cvr.back() */
+        orc_vec_mul(d2 + o, a1 + o, a1 + o, N, q[i]); /* cv[1] * cv[1] */
+    }
+}
+
+/* the "ModRaise" constructor DCRTPolyImpl(const PolyType&, params) (dcrtpoly-impl.h:87-93): x [N] modulo q[0] ->
+ * out [nLimbs][N], limb 0 a copy, every other limb SwitchModulus(q[0] -> q[i]) */
+void orc_mod_raise(const uint64_t* x, uint32_t N, const uint64_t* q, uint32_t nLimbs, uint64_t* out) {
+    for (uint32_t i = 0; i < nLimbs; ++i) {
+        memcpy(out + (size_t)i * N, x, 8 * (size_t)N);
+        if (i)
+            orc_switch_modulus(out + (size_t)i * N, N, q[0], q[i]);
+    }
+}
+
 /* DCRTPolyImpl::FastExpandCRTBasisPloverQ (dcrtpoly-impl.h:1151-1164), COEFFICIENT: x [nQ][N] over Q ->
  * out [(nQl+nPl)][N] = [Ql | Pl]; tables named as in CRTBasisExtensionPrecomputations. */
 void orc_fast_expand_crt_basis_p_over_q(const uint64_t* x, uint32_t nQ, uint32_t N, const uint64_t* q,

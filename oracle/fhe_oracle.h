@@ -115,6 +115,18 @@ void orc_fast_expand_crt_basis_p_over_q(const uint64_t* x, uint32_t nQ, uint32_t
                                         const uint64_t* PlHatInvModp, const uint64_t* PlHatInvModpPrecon,
                                         const uint64_t* PlHatModq_qp, const uint64_t* alphaPlModq, uint32_t nQl,
                                         const uint64_t* ql, const uint64_t* muQl128, const double* pInv, uint64_t* out);
+/* DCRTPolyImpl::ApproxModUp (dcrtpoly-impl.h:935-963); QHatModp [nQ][nP]; out [(nQ+nP)][N] EVALUATION */
+void orc_approx_mod_up(const orc_ctx* ctxQP, uint32_t nQ, uint32_t nP, const uint64_t* x, int inEval,
+                       const uint64_t* QHatInvModq, const uint64_t* QHatInvModqPrecon, const uint64_t* QHatModp,
+                       const uint64_t* muP128, uint64_t* out);
+/* DCRTPolyImpl::ExpandCRTBasisQlHat (dcrtpoly-impl.h:1167-1187) */
+void orc_expand_crt_basis_ql_hat(const uint64_t* x, uint32_t sizeQl, uint32_t N, const uint64_t* q, const uint64_t* QlHatModq,
+                                 uint32_t sizeQ, uint64_t* out);
+/* LeveledSHEBase::EvalSquareCore, 2-element ciphertext (base-leveledshe.cpp:646-664) */
+void orc_eval_square_core(const uint64_t* a0, const uint64_t* a1, uint32_t nLimbs, uint32_t N, const uint64_t* q, uint64_t* d0,
+                          uint64_t* d1, uint64_t* d2);
+/* ModRaise constructor DCRTPolyImpl(const PolyType&, params) (dcrtpoly-impl.h:87-93) */
+void orc_mod_raise(const uint64_t* x, uint32_t N, const uint64_t* q, uint32_t nLimbs, uint64_t* out);
 typedef struct orc_hybrid orc_hybrid;
 /* Q tower (sizeQ limbs) + P tower (sizeP limbs) given explicitly; numPartQ = dnum. */
 orc_hybrid* orc_hybrid_create(uint32_t N, uint32_t sizeQ, const uint64_t* q, const uint64_t* psiQ,

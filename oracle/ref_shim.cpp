@@ -254,6 +254,56 @@ void ref_expand_crt_basis(uint32_t N, uint32_t sizeQ, const uint64_t* q, const u
         X.ExpandCRTBasis(pqp, pp, hi, precon(hi, q), hm, al, mu128(p, sizeP), qi, rf);
     export_poly(X, out);
 }
+// DCRTPolyImpl::ApproxModUp (dcrtpoly-impl.h:935-963) with caller tables; QHatModp [sizeQ][sizeP]; out [(sizeQ+sizeP)][N] EVALUATION
+void ref_approx_mod_up(uint32_t N, uint32_t sizeQ, const uint64_t* q, const uint64_t* psiQ, const uint64_t* x, int inEval,
+                       const uint64_t* QHatInvModq, const uint64_t* QHatModp, uint32_t sizeP, const uint64_t* p,
+                       const uint64_t* psiP, uint64_t* out) {
+    auto pq = make_params(N, sizeQ, q, psiQ);
+    auto pp = make_params(N, sizeP, p, psiP);
+    std::vector<uint64_t> all(q, q + sizeQ), allPsi(psiQ, psiQ + sizeQ);
+    all.insert(all.end(), p, p + sizeP);
+    allPsi.insert(allPsi.end(), psiP, psiP + sizeP);
+    auto pqp = make_params(N, sizeQ + sizeP, all.data(), allPsi.data());
+    auto X   = make_poly(pq, x, inEval ? Format::EVALUATION : Format::COEFFICIENT);
+    auto hi  = vecNI(QHatInvModq, sizeQ);
+    std::vector<std::vector<NativeInteger>> hm(sizeQ);
+    for (uint32_t i = 0; i < sizeQ; ++i)
+        hm[i] = vecNI(QHatModp + (size_t)i * sizeP, sizeP);
+    X.ApproxModUp(pq, pp, pqp, hi, precon(hi, q), hm, mu128(p, sizeP));
+    export_poly(X, out);
+}
+// DCRTPolyImpl::ExpandCRTBasisQlHat (dcrtpoly-impl.h:1167-1187): x [sizeQl][N] -> out [sizeQ][N]
+void ref_expand_crt_basis_ql_hat(uint32_t N, uint32_t sizeQ, const uint64_t* q, const uint64_t* psi, const uint64_t* x,
+                                 uint32_t sizeQl, int evalFormat, const uint64_t* QlHatModq, uint64_t* out) {
+    auto pq  = make_params(N, sizeQ, q, psi);
+    auto pql = make_params(N, sizeQl, q, psi);
+    auto X   = make_poly(pql, x, evalFormat ? Format::EVALUATION : Format::COEFFICIENT);
+    auto h   = vecNI(QlHatModq, sizeQl);
+    X.ExpandCRTBasisQlHat(pq, h, precon(h, q), sizeQ);
+    export_poly(X, out);
+}
+// PolyImpl::MultAccEqNoCheck per limb (poly.h:323 -> mubintvecnat.cpp:132-142): acc[i] += v[i] * consts[i]
+void ref_mult_acc(uint32_t N, uint32_t L, const uint64_t* q, const uint64_t* psi, uint64_t* acc, const uint64_t* v,
+                  const uint64_t* consts) {
+    auto pq = make_params(N, L, q, psi);
+    auto A  = make_poly(pq, acc, Format::EVALUATION);
+    auto V  = make_poly(pq, v, Format::EVALUATION);
+    for (uint32_t i = 0; i < L; ++i) {
+        NativePoly e = A.GetElementAtIndex(i);
+        e.MultAccEqNoCheck(V.GetElementAtIndex(i), NativeInteger(consts[i]));
+        A.SetElementAtIndex(i, std::move(e));
+    }
+    export_poly(A, acc);
+}
+// the "ModRaise" constructor DCRTPolyImpl(const PolyType&, params) (dcrtpoly-impl.h:87-93): x [N] modulo q[0], COEFFICIENT
+void ref_mod_raise(uint32_t N, uint32_t L, const uint64_t* q, const uint64_t* psi, const uint64_t* x, uint64_t* out) {
+    auto pq = make_params(N, L, q, psi);
+    NativePoly e(pq->GetParams()[0], Format::COEFFICIENT, true);
+    for (uint32_t j = 0; j < N; ++j)
+        e[j] = NativeInteger(x[j]);
+    DCRTPoly X(e, pq);
+    export_poly(X, out);
+}
 // FastExpandCRTBasisPloverQ (COEFFICIENT): qInvModp [sizeQ][sizePl]; PlHatModq_qp [sizeQl][sizePl]; alphaPlModq
 // [sizePl+1][sizeQl]; out [(sizeQl+sizePl)][N]
 void ref_fast_expand_crt_basis_p_over_q(uint32_t N, uint32_t sizeQ, const uint64_t* q, const uint64_t* psiQ, const uint64_t* x,
@@ -496,6 +546,11 @@ int ref_ckks_eval_mult_no_relin(void* h, int a, int b) {
     auto* s = static_cast<RefCkks*>(h);
     s->cts.push_back(s->cc->EvalMultNoRelin(s->cts[a], s->cts[b]));
     return static_cast<int>(s->cts.size()) - 1;
+}
+int ref_ckks_eval_square_no_relin(void* h, int a) {  // EvalSquareCore through LeveledSHEBase::EvalSquare (base-leveledshe.cpp:646-700)
+    auto* c = static_cast<RefCkks*>(h);
+    c->cts.push_back(c->cc->GetScheme()->EvalSquare(c->cts[a]));
+    return (int)c->cts.size() - 1;
 }
 int ref_ckks_rescale(void* h, int a) {
     auto* s = static_cast<RefCkks*>(h);

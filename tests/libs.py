@@ -119,6 +119,10 @@ def load_oracle():
     S("orc_behz_fast_rns_floorq", None, [vp, P64])
     S("orc_behz_fast_base_conv_sk", None, [vp, P64, P64])
     S("orc_bfv_eval_mult_behz", None, [vp, vp] + [P64] * 7)
+    S("orc_approx_mod_up", None, [vp, u32, u32, P64, C.c_int, P64, P64, P64, P64, P64])
+    S("orc_expand_crt_basis_ql_hat", None, [P64, u32, u32, P64, P64, u32, P64])
+    S("orc_eval_square_core", None, [P64, P64, u32, u32, P64, P64, P64, P64])
+    S("orc_mod_raise", None, [P64, u32, P64, u32, P64])
     _oracle = L
     return L
 
@@ -209,6 +213,11 @@ def load_ref():
     S("ref_expand_crt_basis", None, [u32, u32, P64, P64, P64, C.c_int, P64, P64, P64, u32, P64, P64, PF64, C.c_int, C.c_int, P64])
     S("ref_fast_expand_crt_basis_p_over_q", None, [u32, u32, P64, P64, P64, P64, P64, u32, P64, P64, P64, P64, P64, u32, P64,
                                                    P64, PF64, P64])
+    S("ref_approx_mod_up", None, [u32, u32, P64, P64, P64, C.c_int, P64, P64, u32, P64, P64, P64])
+    S("ref_expand_crt_basis_ql_hat", None, [u32, u32, P64, P64, P64, u32, C.c_int, P64, P64])
+    S("ref_mult_acc", None, [u32, u32, P64, P64, P64, P64, P64])
+    S("ref_mod_raise", None, [u32, u32, P64, P64, P64, P64])
+    S("ref_ckks_eval_square_no_relin", C.c_int, [vp, C.c_int])
     S("ref_bfv_create", vp, [u32, u64, u32, u32, C.c_int])
     S("ref_bfv_destroy", None, [vp])
     S("ref_bfv_info", None, [vp, P32])

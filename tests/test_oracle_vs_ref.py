@@ -746,3 +746,95 @@ def test_coeffs_to_slots_against_live_reference(oracle, ref, ring, depth, dnum, 
     o.orc_ctx_destroy(octx)
     o.orc_hybrid_destroy(hy)
     r.ref_ckks_destroy(h)
+
+
+# ---- round 2: the members that had no entry point (ApproxModUp, ExpandCRTBasisQlHat, MultAccEqNoCheck, EvalSquareCore,
+# ---- the ModRaise constructor) ----
+@pytest.mark.parametrize("logN,nQ,nP,inEval", [(4, 2, 3, 1), (5, 3, 2, 0), (6, 4, 4, 1), (4, 1, 2, 0)])
+def test_approx_mod_up_against_live_reference(oracle, ref, logN, nQ, nP, inEval):
+    """DCRTPolyImpl::ApproxModUp (dcrtpoly-impl.h:935-963) of the reference vs the oracle composite"""
+    o, r = oracle, ref
+    rng = np.random.default_rng(191)
+    N = 1 << logN
+    allq, allpsi = np.zeros(nQ + nP, np.uint64), np.zeros(nQ + nP, np.uint64)
+    o.orc_dcrt_params(2 * N, nQ + nP, 57, allq, allpsi)
+    q, p, psiQ, psiP = allq[:nQ].copy(), allq[nQ:].copy(), allpsi[:nQ].copy(), allpsi[nQ:].copy()
+    hatInv, hatPre, hatMod, _, _, mu = libs.crt_tables(q, p)
+    x = libs.rand_tower(rng, q, N)
+    want = np.zeros((nQ + nP, N), np.uint64)
+    r.ref_approx_mod_up(N, nQ, q, psiQ, x, inEval, hatInv, hatMod, nP, p, psiP, want)
+    octx = o.orc_ctx_create(N, nQ + nP, allq, allpsi)
+    got = np.zeros((nQ + nP, N), np.uint64)
+    o.orc_approx_mod_up(octx, nQ, nP, x, inEval, hatInv, hatPre, hatMod, mu, got)
+    assert np.array_equal(got, want)
+    o.orc_ctx_destroy(octx)
+
+
+@pytest.mark.parametrize("logN,sizeQ,sizeQl,ev", [(4, 3, 2, 1), (5, 4, 4, 0), (6, 5, 1, 1)])
+def test_expand_crt_basis_ql_hat_against_live_reference(oracle, ref, logN, sizeQ, sizeQl, ev):
+    """DCRTPolyImpl::ExpandCRTBasisQlHat (dcrtpoly-impl.h:1167-1187)"""
+    o, r = oracle, ref
+    rng = np.random.default_rng(192)
+    N = 1 << logN
+    q, psi = np.zeros(sizeQ, np.uint64), np.zeros(sizeQ, np.uint64)
+    o.orc_dcrt_params(2 * N, sizeQ, 55, q, psi)
+    x = libs.rand_tower(rng, q[:sizeQl], N)
+    h = libs.rand_tower(rng, q[:sizeQl], 1)[:, 0].copy()
+    want, got = np.zeros((sizeQ, N), np.uint64), np.ones((sizeQ, N), np.uint64)
+    r.ref_expand_crt_basis_ql_hat(N, sizeQ, q, psi, x, sizeQl, ev, h, want)
+    o.orc_expand_crt_basis_ql_hat(x, sizeQl, N, q, h, sizeQ, got)
+    assert np.array_equal(got, want)
+
+
+def test_mult_acc_and_mod_raise_against_live_reference(oracle, ref):
+    """PolyImpl::MultAccEqNoCheck (mubintvecnat.cpp:132-142) and the ModRaise constructor (dcrtpoly-impl.h:87-93)"""
+    o, r = oracle, ref
+    rng = np.random.default_rng(193)
+    for logN, L in [(4, 3), (7, 2)]:
+        N = 1 << logN
+        q, psi = np.zeros(L, np.uint64), np.zeros(L, np.uint64)
+        o.orc_dcrt_params(2 * N, L, 59, q, psi)
+        acc, v = libs.rand_tower(rng, q, N), libs.rand_tower(rng, q, N)
+        consts = np.array([int(rng.integers(0, 1 << 62)) for _ in range(L)], np.uint64)  # also constants >= q (ModEq first)
+        want = acc.copy()
+        r.ref_mult_acc(N, L, q, psi, want, v, consts)
+        got = acc.copy()
+        for i in range(L):
+            o.orc_vec_mult_acc(got[i], v[i], consts[i], N, q[i])
+        assert np.array_equal(got, want)
+        # ModRaise: descending and ascending moduli relative to q_0
+        for qs, ps in ((q, psi), (q[::-1].copy(), psi[::-1].copy())):
+            x = libs.rand_tower(rng, qs[:1], N)[0]
+            x[:3] = (0, qs[0] >> np.uint64(1), qs[0] - np.uint64(1))
+            want, got = np.zeros((L, N), np.uint64), np.zeros((L, N), np.uint64)
+            r.ref_mod_raise(N, L, qs, ps, x, want)
+            o.orc_mod_raise(x, N, qs, L, got)
+            assert np.array_equal(got, want)
+
+
+def test_eval_square_core_against_live_reference(oracle, ref):
+    """LeveledSHEBase::EvalSquareCore through cc->EvalSquare without relinearisation (FIXEDMANUAL: no level adjustment)"""
+    o, r = oracle, ref
+    h = r.ref_ckks_create(1 << 8, 2, 50, 60, 2, 0)  # scalTech 0 = FIXEDMANUAL
+    info = np.zeros(5, np.uint32)
+    r.ref_ckks_info(h, info)
+    N, sizeQ, sizeP = int(info[0]), int(info[1]), int(info[2])
+    q, psiQ, p, psiP = (np.zeros(n, np.uint64) for n in (sizeQ, sizeQ, sizeP, sizeP))
+    r.ref_ckks_get_moduli(h, q, psiQ, p, psiP)
+    ct = r.ref_ckks_encrypt(h, 5, 0)
+    sq = r.ref_ckks_eval_square_no_relin(h, ct)
+    ci = np.zeros(4, np.uint32)
+    r.ref_ct_info(h, sq, ci)
+    assert int(ci[0]) == 3
+    L = int(ci[1])
+    a = [np.zeros((L, N), np.uint64) for _ in range(2)]
+    for e in range(2):
+        r.ref_ct_export(h, ct, e, a[e])
+    want = [np.zeros((L, N), np.uint64) for _ in range(3)]
+    for e in range(3):
+        r.ref_ct_export(h, sq, e, want[e])
+    got = [np.zeros((L, N), np.uint64) for _ in range(3)]
+    o.orc_eval_square_core(a[0], a[1], L, N, q, got[0], got[1], got[2])
+    for e in range(3):
+        assert np.array_equal(got[e], want[e]), f"EvalSquareCore element {e}"
+    r.ref_ckks_destroy(h)

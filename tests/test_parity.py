@@ -139,6 +139,122 @@ def test_elementwise(backend, oracle):
         ctx.close()
 
 
+def test_mult_acc_square_ql_hat_async_consts(backend, oracle):
+    """fhe_mult_acc (MultAccEqNoCheck), fhe_tensor_square (EvalSquareCore), fhe_expand_crt_basis_ql_hat (ExpandCRTBasisQlHat);
+    the host constants of fhe_mul_const / fhe_mult_acc travel in the kernel arguments: the host array may change right after
+    the call returns (no staging buffer, no synchronisation inside the call)"""
+    o = oracle
+    rng = np.random.default_rng(131)
+    for logN, L, B in [(5, 3, 2), (12, 4, 2), (13, 2, 1)]:
+        N = 1 << logN
+        q, psi = params(o, logN, L)
+        ctx = fh.Context(backend, logN, q, psi)
+        a, v = libs.rand_tower(rng, q, N, B), libs.rand_tower(rng, q, N, B)
+        consts = np.array([int(rng.integers(0, 1 << 62)) for _ in range(L)], np.uint64)  # some >= q: reduced first
+        want = a.copy()
+        for bb in range(B):
+            for l in range(L):
+                o.orc_vec_mult_acc(want[bb, l], v[bb, l], consts[l], N, q[l])
+        ta, tv = ctx.tower(a), ctx.tower(v)
+        c2 = consts.copy()
+        ta.MultAccEqNoCheck(tv, c2)
+        c2[:] = 0  # the call has returned: its constants are already in the launch
+        assert np.array_equal(ta.to_host(), want), f"MultAccEqNoCheck logN={logN}"
+        # many constant multiplications in flight on one stream (the former 64-slot ring would have wrapped)
+        outs, wants = [], []
+        tv0 = ctx.tower(v)
+        for it in range(80):
+            cs = np.array([int(rng.integers(1, int(m))) for m in q], np.uint64)
+            if it % 16 == 0:
+                w = np.empty_like(v)
+                for bb in range(B):
+                    for l in range(L):
+                        o.orc_vec_mul_const(w[bb, l], v[bb, l], cs[l], N, q[l])
+                wants.append(w)
+                outs.append(tv0.Times(cs))
+            else:
+                tv0.Times(cs).free()
+        for t, w in zip(outs, wants):
+            assert np.array_equal(t.to_host(), w)
+        # EvalSquareCore
+        d = [ta.like() for _ in range(3)]
+        backend.check(backend.L.fhe_tensor_square(ctx.h, tv.ptr, tv0.ptr, d[0].ptr, d[1].ptr, d[2].ptr, None, L, B, None))
+        w = [np.empty_like(v) for _ in range(3)]
+        for bb in range(B):
+            o.orc_eval_square_core(v[bb], v[bb], L, N, q, w[0][bb], w[1][bb], w[2][bb])
+        for e in range(3):
+            assert np.array_equal(d[e].to_host(), w[e]), f"EvalSquareCore element {e}"
+        # ExpandCRTBasisQlHat: the first sizeQl limbs scaled, the rest zero
+        for sizeQl in sorted({1, L - 1, L} - {0}):
+            x = libs.rand_tower(rng, q[:sizeQl], N, B)
+            h = np.array([int(rng.integers(1, int(m))) for m in q[:sizeQl]], np.uint64)
+            tx, out = ctx.tower(x), ctx.empty(B, L)
+            backend.check(backend.L.fhe_expand_crt_basis_ql_hat(ctx.h, tx.ptr, sizeQl, h.ctypes.data_as(fh.u64p), None, L, B,
+                                                                out.ptr, None))
+            w = np.ones((B, L, N), np.uint64)
+            for bb in range(B):
+                o.orc_expand_crt_basis_ql_hat(x[bb], sizeQl, N, q, h, L, w[bb])
+            assert np.array_equal(out.to_host(), w), f"ExpandCRTBasisQlHat sizeQl={sizeQl}"
+        ctx.close()
+
+
+def test_switch_modulus_and_mod_raise(backend, oracle):
+    """fhe_switch_modulus (NativeVectorT::SwitchModulus, a9) directly: one source limb of a tower lifted, centred, into
+    every row of the output — in both directions (target modulus above and below the source) — and the ModRaise
+    constructor DCRTPolyImpl(const PolyType&, params) (dcrtpoly-impl.h:87-93) as its srcLimbs = 1 case"""
+    o = oracle
+    rng = np.random.default_rng(132)
+    for logN, L, B in [(4, 4, 2), (12, 3, 2), (13, 5, 1)]:
+        N = 1 << logN
+        q, psi = ckks_like_params(o, logN, L, 2, first_bits=60, scale_bits=45)[:2]  # q_0 (60 bits) above the others
+        ctx = fh.Context(backend, logN, q, psi)
+        for srcPos in (0, L - 1):  # 0: every target below the source; L-1: every other target above it
+            x = libs.rand_tower(rng, q, N, B)
+            x[0, srcPos, :4] = (0, 1, q[srcPos] >> np.uint64(1), q[srcPos] - np.uint64(1))
+            x[0, srcPos, 4] = (q[srcPos] >> np.uint64(1)) + np.uint64(1)
+            tx, out = ctx.tower(x), ctx.empty(B, L)
+            backend.check(backend.L.fhe_switch_modulus(ctx.h, out.ptr, None, L, tx.ptr, L, srcPos, srcPos, B, None))
+            want = np.empty((B, L, N), np.uint64)
+            for bb in range(B):
+                for l in range(L):
+                    want[bb, l] = x[bb, srcPos]
+                    o.orc_switch_modulus(want[bb, l], N, q[srcPos], q[l])
+            assert np.array_equal(out.to_host(), want), f"SwitchModulus logN={logN} srcPos={srcPos}"
+        # ModRaise: a single polynomial modulo q_0 into a full tower
+        x0 = libs.rand_tower(rng, q[:1], N, B)
+        tx, out = ctx.tower(x0), ctx.empty(B, L)
+        backend.check(backend.L.fhe_switch_modulus(ctx.h, out.ptr, None, L, tx.ptr, 1, 0, 0, B, None))
+        want = np.empty((B, L, N), np.uint64)
+        for bb in range(B):
+            o.orc_mod_raise(x0[bb, 0], N, q, L, want[bb])
+        assert np.array_equal(out.to_host(), want), "ModRaise"
+        ctx.close()
+
+
+@pytest.mark.parametrize("logN,nQ,nP,B", [(5, 2, 3, 2), (12, 3, 5, 1), (12, 7, 7, 1), (13, 4, 4, 2), (10, 12, 3, 1)])
+def test_approx_mod_up(backend, oracle, logN, nQ, nP, B):
+    """fhe_mod_up = DCRTPolyImpl::ApproxModUp (dcrtpoly-impl.h:935-963), from both formats"""
+    o = oracle
+    rng = np.random.default_rng(133)
+    N = 1 << logN
+    q, psi = params(o, logN, nQ + nP)
+    ctx = fh.Context(backend, logN, q, psi)
+    octx = o.orc_ctx_create(N, nQ + nP, q, psi)
+    src, dst = q[:nQ], q[nQ:]
+    hatInv, hatPre, hatMod, _, _, mu = libs.crt_tables(src, dst)
+    conv = fh.Conv(ctx, np.arange(nQ), np.arange(nQ, nQ + nP))
+    for fmt, inEval in ((fh.EVALUATION, 1), (fh.COEFFICIENT, 0)):
+        x = libs.rand_tower(rng, src, N, B)
+        want = np.empty((B, nQ + nP, N), np.uint64)
+        for bb in range(B):
+            o.orc_approx_mod_up(octx, nQ, nP, x[bb], inEval, hatInv, hatPre, hatMod, mu, want[bb])
+        got = conv.ApproxModUp(ctx.tower(x, limb_idx=np.arange(nQ), fmt=fmt))
+        assert np.array_equal(got.to_host(), want), f"ApproxModUp inEval={inEval}"
+    conv.close()
+    o.orc_ctx_destroy(octx)
+    ctx.close()
+
+
 def test_automorphism(backend, oracle):
     o = oracle
     rng = np.random.default_rng(14)
@@ -471,25 +587,11 @@ def test_graph_capture_replays_eval_mult(oracle):
     o.orc_hybrid_destroy(hy)
 
 
-def test_fused_conversion_path_on_emulator(backend):
-    """experimental FHE_KS_FUSE_CONV=1 (ModUp / ModDown conversions inside the NTT column passes; default off, not yet
-    measured on the GPU): bit-exact against the oracle on two-pass rings, and the fused launches are really taken"""
-    import subprocess
-    import sys
-    if not is_emu(backend):
-        pytest.skip("emulator variant")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FHE_KS_FUSE_CONV="1", PYTHONPATH=os.pathsep.join([root, os.path.join(root, "tests")]))
-    out = subprocess.run([sys.executable, os.path.join(root, "tests", "fused_conv_check.py"),
-                          os.path.join(root, "tests", "emu", "libfhe_emu.so")], env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0 and "fused_conv_check OK" in out.stdout, out.stdout + out.stderr
-
-
-@pytest.mark.parametrize("variant", ["0", "2"])
+@pytest.mark.parametrize("variant", ["1"])
 def test_conversion_kernel_variants_on_emulator(backend, variant):
-    """the non-default column-sum variants of the basis-conversion kernel (FHE_CONV_SUM8 is read once per process: 0 = 192-bit
-    accumulator + generated reduction, 2 = 30-bit split without carries, experimental) against the oracle, through the
-    regular conversion / key-switch parity tests in a child process"""
+    """the non-default column-sum variant of the basis-conversion / BEHZ kernels (FHE_CONV_SUM8 is read once per process:
+    1 = carry-counted 64-bit columns; the default 2 = 30-bit split without carries runs in every other test) against the
+    oracle, through the regular conversion / key-switch / BFV parity tests in a child process"""
     import subprocess
     import sys
     if not is_emu(backend):
@@ -500,7 +602,24 @@ def test_conversion_kernel_variants_on_emulator(backend, variant):
                           "-k", "test_approx_and_exact_switch_crt_basis or (test_hybrid_keyswitch_and_eval_mult and 12-6)"],
                          env=env, capture_output=True, text=True, timeout=1200, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    if variant == "2":  # the same knob switches the BEHZ dot products of the BFV multiplication
+    if variant == "1":  # the same knob switches the BEHZ dot products of the BFV multiplication
         out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_parity_bfv.py"), "-q", "-x", "-m",
                               "not gpu", "-k", "behz or eval_mult"], env=env, capture_output=True, text=True, timeout=1200, cwd=root)
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_oversized_digits_are_refused_not_miscomputed(backend, oracle):
+    """the conversion kernels end at 32 source limbs: a HYBRID plan whose digit (or P basis) is larger must be refused with
+    FHE_ERR_UNSUPPORTED instead of overflowing its tables (round-1 advisor finding)"""
+    o = oracle
+    logN = 4
+    q, psi = params(o, logN, 40, bits=40)
+    ctx = fh.Context(backend, logN, q, psi)
+    h = C.c_void_p()
+    st = backend.L.fhe_ks_plan_create(ctx.h, 34, 6, 1, C.byref(h))  # alpha = 34 > 32
+    assert st == 4 and b"<= 32" in backend.L.fhe_last_error()
+    st = backend.L.fhe_ks_plan_create(ctx.h, 6, 34, 2, C.byref(h))  # sizeP = 34 > 32
+    assert st == 4
+    plan = fh.KeySwitchPlan(ctx, 34, 6, 2)  # alpha = 17: fine
+    plan.close()
+    ctx.close()
