@@ -45,7 +45,54 @@ def parse():
     ap.add_argument("--no-bfv", action="store_true", help="skip the BFV EvalMult (BEHZ) leg (BASELINE configs[4] shape)")
     ap.add_argument("--bfv-batch", type=int, default=64)
     ap.add_argument("--no-lt", action="store_true", help="skip the BSGS linear-transform leg (bootstrapping's inner loop)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparisons of the legs' results")
+    ap.add_argument("--evalmult-logn", type=int, default=16, help="ring of the EvalMult leg (config 3: 16)")
+    ap.add_argument("--evalmult-limbs", type=int, default=21, help="Q limbs of the EvalMult leg (config 3: 21)")
     return ap.parse_args()
+
+
+def source_sha():
+    """identity of the kernel sources the resident library was built from: PMC records carry it, so that a record made with
+    other kernels is never quoted as this run's traffic"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "openfhe-development_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_oracle():
+    """the parity CHECKER (oracle/libfhe_oracle.so): used after the timed regions only, never inside them"""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import libs
+        return libs.load_oracle()
+    except Exception:
+        return None
+
+
+def sample_towers(batch):
+    return sorted({0, batch // 2, batch - 1})
+
+
+def download_tower(lib, ctx, dev, tw, n_limbs):
+    out = np.empty((n_limbs, ctx.N), np.uint64)
+    lib.check(lib.L.fhe_memcpy_d2h(ctx.h, out.ctypes.data_as(C.c_void_p), C.c_void_p(dev.value + tw * out.nbytes), out.nbytes, None))
+    ctx.sync()
+    return out
+
+
+def host_seed_towers(q, N, batch, seed, seed_polys):
+    """the host image fill_random_tower() replicated: tower t of the device batch is seed tower t % seed_polys"""
+    rng = np.random.default_rng(seed)
+    seed_polys = min(seed_polys, batch)
+    host = np.empty((seed_polys, len(q), N), np.uint64)
+    for i, qi in enumerate(q):
+        host[:, i, :] = rng.integers(0, int(qi), size=(seed_polys, N), dtype=np.uint64)
+    return host
 
 
 def fill_random_tower(ctx, q, batch, seed, seed_polys=8):
@@ -154,9 +201,9 @@ def timed_sequence(lib, ctx, st, call):
         return call, f"direct calls ({e})", None
 
 
-def evalmult_leg(lib, device, logN, batch, steps, warmup, sync, dist=None):
+def evalmult_leg(lib, device, logN, batch, steps, warmup, sync, dist=None, sizeQ=21, parity=True, tdev=None):
     """CKKS EvalMult + HYBRID key switch at config 3's shape (depth 20: l=21 limbs, dnum=3 => alpha=7, k=7)."""
-    sizeQ, dnum = 21, 3
+    dnum = 3
     q, psiQ = lib.ckks_like_chain(logN, sizeQ, 60, 59)
     p, psiP = lib.select_p(logN, q, dnum, 60)
     allq = np.concatenate([q, p])
@@ -171,6 +218,7 @@ def evalmult_leg(lib, device, logN, batch, steps, warmup, sync, dist=None):
             host[:, i, :] = rng.integers(0, int(qi), size=(dnum, N), dtype=np.uint64)
         return host
     key_dist, keep = "local (single process)", None
+    hostKeys = None  # (keyB, keyA) images when this rank generated the key itself (needed by the parity check)
     if dist is not None:
         # the evaluation key exists on rank 0 and reaches every GPU with ONE broadcast over RCCL/xGMI; it is
         # the only collective of the whole path
@@ -180,9 +228,12 @@ def evalmult_leg(lib, device, logN, batch, steps, warmup, sync, dist=None):
             kb = ka = None
             if dist.get_rank() == 0:
                 kb, ka = host_key(), host_key()
-            keep = shard.broadcast_key(plan, kb, ka, torch.device("cuda", device))
-            torch.cuda.synchronize()
-            key_dist = f"rccl broadcast from rank 0 to {dist.get_world_size()} rank(s), {2 * plan.key_words() * 8 / 2**20:.0f} MiB"
+            hostKeys = (kb, ka) if kb is not None else None
+            keep = shard.broadcast_key(plan, kb, ka, tdev if tdev is not None else torch.device("cuda", device))
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            key_dist = (f"{'rccl' if dist.get_backend() == 'nccl' else dist.get_backend()} broadcast from rank 0 to "
+                        f"{dist.get_world_size()} rank(s), {2 * plan.key_words() * 8 / 2**20:.1f} MiB")
         except Exception as e:  # keep the benchmark alive; the line says what happened
             key_dist, keep = f"local (broadcast failed: {type(e).__name__}: {e})", None
             plan.key = None
@@ -190,11 +241,14 @@ def evalmult_leg(lib, device, logN, batch, steps, warmup, sync, dist=None):
         lib.check(lib.L.fhe_ks_key_alloc(plan.h, C.byref(key := C.c_void_p())))
         plan.key = key
         assert lib.L.fhe_ks_key_words(key) == dnum * len(allq) * N
+        hk = []
         for which in (0, 1):
             host = host_key()
+            hk.append(host)
             lib.check(lib.L.fhe_memcpy_h2d(ctx.h, lib.L.fhe_ks_key_devptr(key, which), host.ctypes.data_as(C.c_void_p),
                                            host.nbytes, None))
             ctx.sync()
+        hostKeys = tuple(hk)
     key = plan.key
     ops = [fh.Tower(ctx, fill_random_tower(ctx, q, batch, 100 + i, seed_polys=2), batch, sizeQ) for i in range(4)]
     c0, c1 = ops[0].like(), ops[0].like()
@@ -215,17 +269,58 @@ def evalmult_leg(lib, device, logN, batch, steps, warmup, sync, dist=None):
         step()
     lib.check(lib.L.fhe_stream_sync(ctx.h, st))
     dt = (time.perf_counter() - t0) / steps
+    # ---- parity of the TIMED launch's result: towers {0, B/2, B-1} of both output elements against the oracle on the same
+    # inputs (tower t of every operand is seed tower t % 2; the key is this leg's host image)
+    par = "skipped"
+    o = load_oracle() if parity else None
+    if parity and o is None:
+        par = "oracle library not available"
+    elif parity and hostKeys is None:
+        par = "skipped on this rank (the key was generated on rank 0)"
+    elif parity:
+        seeds = [host_seed_towers(q, N, batch, 100 + i, 2) for i in range(4)]
+        hy = o.orc_hybrid_create(N, sizeQ, q, psiQ, len(p), p, psiP, dnum)
+        want = {}
+        par = "bit-exact vs oracle on towers " + str(sample_towers(batch)) + " of both elements (orc_ckks_eval_mult_relin)"
+        for tw in sample_towers(batch):
+            sp = tw % seeds[0].shape[0]
+            if sp not in want:
+                w0, w1 = np.empty((sizeQ, N), np.uint64), np.empty((sizeQ, N), np.uint64)
+                o.orc_ckks_eval_mult_relin(hy, seeds[0][sp], seeds[1][sp], seeds[2][sp], seeds[3][sp], sizeQ, hostKeys[0], hostKeys[1], w0, w1)
+                want[sp] = (w0, w1)
+            if not (np.array_equal(download_tower(lib, ctx, c0.ptr, tw, sizeQ), want[sp][0]) and
+                    np.array_equal(download_tower(lib, ctx, c1.ptr, tw, sizeQ), want[sp][1])):
+                par = f"MISMATCH vs oracle at tower {tw}"
+                break
+        o.orc_hybrid_destroy(hy)
     lib.L.fhe_graph_destroy(graph)
     lib.check(lib.L.fhe_stream_destroy(ctx.h, st))
     plan.close()
     ctx.close()
     del keep
+    # algorithmic HBM bytes of one EvalMult + key switch: every limb-NTT reads and writes its limb once
+    # (l INTT + beta*(l+k-alpha') forward in ModUp + 2k INTT + 2l forward in the two ModDowns), the tensor product moves 7l
+    # limbs, a ModUp conversion reads a digit and writes its complement, the inner product reads beta*(l+k) digit limbs and
+    # writes 2(l+k) (the key is shared by the batch), a ModDown conversion reads k and writes l limbs per element and its
+    # epilogue reads the extended element and the accumulator and writes the result (3l per element)
+    k_, l_ = len(p), sizeQ
+    alpha = -(-l_ // dnum)
+    beta = -(-l_ // alpha)
+    compl = sum(l_ + k_ - min(alpha, l_ - alpha * j) for j in range(beta))
+    ntt_limbs = l_ + compl + 2 * k_ + 2 * l_
+    limb_moves = 2 * ntt_limbs + 7 * l_ + (l_ + compl) + (beta * (l_ + k_) + 2 * (l_ + k_)) + 2 * (k_ + l_) + 2 * 3 * l_
+    alg = 8.0 * N * limb_moves
+    ach = alg * batch / dt / 1e9
     return {"ops_per_s_per_gpu": round(batch / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "batch": batch,
             "shape": f"N=2^{logN}, l={sizeQ}, k={len(p)}, dnum={dnum}, workspace {wsb / 2**30:.1f} GiB",
-            "eval_key": key_dist, "launch": mode}
+            "eval_key": key_dist, "launch": mode, "parity": par,
+            "roofline": {"bound": "hbm", "algorithmic_bytes_per_op": alg, "limb_ntts_per_op": ntt_limbs,
+                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                         "dominant_kernel": "ntt_static_kernel (forward row pass with the ModDown epilogue / digit transforms); "
+                                            "shares in profiles/r02_rocprof_kernel_stats_evalmult256.csv"}}
 
 
-def linear_transform_leg(lib, device, batches, steps, warmup, with_cpu):
+def linear_transform_leg(lib, device, batches, steps, warmup, with_cpu, parity=True):
     """FHECKKSRNS::EvalLinearTransform (BSGS with double hoisting, the linear-transform loop of CKKS bootstrapping, BASELINE
     configs[3]'s inner loop) at config 4's ring: N=2^17, l=21 limbs, dnum=3, 64 diagonals as 8 baby x 8 giant steps.
     One HIP graph replay per transform; the CPU figure is the reference's own EvalLinearTransform (oracle/_ref)."""
@@ -247,9 +342,10 @@ def linear_transform_leg(lib, device, batches, steps, warmup, with_cpu):
     # distinct device buffers for every key and diagonal (so that nothing is served from the Infinity Cache by accident);
     # their content is uniform random either way, two host images are enough
     kimg = [rows(allq, dnum) for _ in range(2)]
-    keys = {}
+    keys, keyImg = {}, {}
     for n, index in enumerate(list(range(1, bStep)) + [bStep * j for j in range(1, gStep)]):
         keys[index] = (lib.find_automorphism_index(index, 2 * N), plan.make_key(kimg[n % 2], kimg[(n + 1) % 2]))
+        keyImg[index] = (kimg[n % 2], kimg[(n + 1) % 2])
     dimg = [rows(allq, 1)[0] for _ in range(2)]
     A = [ctx.upload(dimg[i % 2]) for i in range(slots)]
     in_rot = [None] + [keys[i] for i in range(1, bStep)]
@@ -284,6 +380,29 @@ def linear_transform_leg(lib, device, batches, steps, warmup, with_cpu):
         lib.L.fhe_graph_destroy(graph)
         res["per_batch"][str(batch)] = {"transforms_per_s_per_gpu": round(batch / dt, 2), "ms_per_batch": round(dt * 1e3, 3),
                                         "workspace_GiB": round(wsb / 2**30, 2), "launch": mode}
+        if parity and batch == batches[0]:  # the timed replay's result against the oracle's sequential EvalLinearTransform
+            o = load_oracle()
+            if o is None:
+                res["parity"] = "oracle library not available"
+            else:
+                import libs
+                hy = o.orc_hybrid_create(N, sizeQ, q, psiQ, len(p), p, psiP, dnum)
+                s0, s1 = host_seed_towers(q, N, batch, 400, 2), host_seed_towers(q, N, batch, 401, 2)
+                inI = [None] + list(range(1, bStep))
+                outI = [None] + [bStep * j for j in range(1, gStep)]
+                inK = np.array([0 if i is None else keys[i][0] for i in inI], np.uint32)
+                outK = np.array([0 if i is None else keys[i][0] for i in outI], np.uint32)
+                pa = libs.ptr_array
+                flat = [dimg[(bStep * j + i) % 2] for j in range(gStep) for i in range(bStep)]
+                w0, w1 = np.zeros((sizeQ, N), np.uint64), np.zeros((sizeQ, N), np.uint64)
+                o.orc_ckks_bsgs_transform(hy, s0[0], s1[0], sizeQ, bStep, inK, pa([None if i is None else keyImg[i][0] for i in inI]),
+                                          pa([None if i is None else keyImg[i][1] for i in inI]), gStep, outK,
+                                          pa([None if i is None else keyImg[i][0] for i in outI]),
+                                          pa([None if i is None else keyImg[i][1] for i in outI]), pa(flat), w0, w1)
+                ok = (np.array_equal(download_tower(lib, ctx, out[0].ptr, 0, sizeQ), w0) and
+                      np.array_equal(download_tower(lib, ctx, out[1].ptr, 0, sizeQ), w1))
+                res["parity"] = ("bit-exact vs oracle (orc_ckks_bsgs_transform, both elements, batch %d)" % batch) if ok else "MISMATCH vs oracle"
+                o.orc_hybrid_destroy(hy)
         for t in (c0, c1) + out:
             ctx.free(t.ptr)
         ctx.free(ws[0])
@@ -325,7 +444,7 @@ def linear_transform_leg(lib, device, batches, steps, warmup, with_cpu):
     return res
 
 
-def bfv_leg(lib, device, batch, steps, warmup, sync, with_cpu):
+def bfv_leg(lib, device, batch, steps, warmup, sync, with_cpu, parity=True):
     """BFV EvalMult (BEHZ, no relinearisation) at BASELINE configs[4]'s shape: N=2^15, Q = 7 x 60-bit limbs and
     Bsk = 8 limbs (log2(Q*Bsk) ~ 900).  Product: fhe_bfv_eval_mult_behz on `batch` ciphertext pairs; CPU: the reference's
     own cc->EvalMultNoRelin (oracle/_ref) on one pair when its build travelled with the repo."""
@@ -354,6 +473,28 @@ def bfv_leg(lib, device, batch, steps, warmup, sync, with_cpu):
         step()
     lib.check(lib.L.fhe_stream_sync(ctx.h, st))
     dt = (time.perf_counter() - t0) / steps
+    par = "skipped"
+    o = load_oracle() if parity else None
+    hb = None
+    if parity and o is None:
+        par = "oracle library not available"
+    elif parity:
+        N = ctx.N
+        hb = o.orc_behz_create(N, numQ, q, t)
+        call = o.orc_ctx_create(N, numQ + len(bsk), np.concatenate([q, bsk]), np.concatenate([psiQ, psiB]))
+        seeds = [host_seed_towers(q, N, batch, 200 + i, 2) for i in range(4)]
+        par = "bit-exact vs oracle on towers " + str(sample_towers(batch)) + " of the three product elements (orc_bfv_eval_mult_behz)"
+        wantNR = {}
+        for tw in sample_towers(batch):
+            sp = tw % 2
+            if sp not in wantNR:
+                w = [np.zeros((numQ, N), np.uint64) for _ in range(3)]
+                o.orc_bfv_eval_mult_behz(hb, call, seeds[0][sp], seeds[1][sp], seeds[2][sp], seeds[3][sp], w[0], w[1], w[2])
+                wantNR[sp] = w
+            if not all(np.array_equal(download_tower(lib, ctx, d[k].ptr, tw, numQ), wantNR[sp][k]) for k in range(3)):
+                par = f"MISMATCH vs oracle at tower {tw}"
+                break
+        o.orc_ctx_destroy(call)
     lib.L.fhe_graph_destroy(graph)
     lib.check(lib.L.fhe_stream_destroy(ctx.h, st))
     ctx.free(ws)
@@ -372,7 +513,8 @@ def bfv_leg(lib, device, batch, steps, warmup, sync, with_cpu):
         for i, qi in enumerate(allqp):
             host[:, i, :] = rng.integers(0, int(qi), size=(dnum, ctx.N), dtype=np.uint64)
         return host
-    ks.upload_key(host_key(), host_key())
+    hkB, hkA = host_key(), host_key()
+    ks.upload_key(hkB, hkA)
     plan = fh.Behz(ctx, np.arange(numQ), np.arange(numQ + len(p), numQ + len(p) + len(bsk)), t)
     ops = [fh.Tower(ctx, fill_random_tower(ctx, q, batch, 300 + i, seed_polys=2), batch, numQ) for i in range(4)]
     c0, c1 = ops[0].like(), ops[0].like()
@@ -393,6 +535,38 @@ def bfv_leg(lib, device, batch, steps, warmup, sync, with_cpu):
         step2()
     lib.check(lib.L.fhe_stream_sync(ctx.h, st))
     dt2 = (time.perf_counter() - t0) / steps
+    par2 = "skipped"
+    if parity and o is not None:
+        # cc->EvalMult = EvalMultNoRelin, SetFormat(EVALUATION), KeySwitchCore on the third element, adds (base-leveledshe.cpp:201-214)
+        N = ctx.N
+        hy = o.orc_hybrid_create(N, numQ, q, psiQ, len(p), p, psiP, dnum)
+        call = o.orc_ctx_create(N, numQ + len(bsk), np.concatenate([q, bsk]), np.concatenate([psiQ, psiB]))
+        octxQ = o.orc_ctx_create(N, numQ, q, psiQ)
+        seeds = [host_seed_towers(q, N, batch, 300 + i, 2) for i in range(4)]
+        par2 = "bit-exact vs oracle on towers " + str(sample_towers(batch)) + " of both elements (BEHZ product + orc_hybrid_key_switch)"
+        wantR = {}
+        for tw in sample_towers(batch):
+            sp = tw % 2
+            if sp not in wantR:
+                w = [np.zeros((numQ, N), np.uint64) for _ in range(3)]
+                o.orc_bfv_eval_mult_behz(hb, call, seeds[0][sp], seeds[1][sp], seeds[2][sp], seeds[3][sp], w[0], w[1], w[2])
+                for k in range(3):
+                    o.orc_ntt_fwd_tower(octxQ, w[k], None, numQ, 1, 0)
+                k0, k1 = np.empty((numQ, N), np.uint64), np.empty((numQ, N), np.uint64)
+                o.orc_hybrid_key_switch(hy, w[2], numQ, hkB, hkA, k0, k1)
+                for l in range(numQ):
+                    o.orc_vec_add(w[0][l], w[0][l], k0[l], N, q[l])
+                    o.orc_vec_add(w[1][l], w[1][l], k1[l], N, q[l])
+                wantR[sp] = w
+            if not (np.array_equal(download_tower(lib, ctx, c0.ptr, tw, numQ), wantR[sp][0]) and
+                    np.array_equal(download_tower(lib, ctx, c1.ptr, tw, numQ), wantR[sp][1])):
+                par2 = f"MISMATCH vs oracle at tower {tw}"
+                break
+        for h in (call, octxQ):
+            o.orc_ctx_destroy(h)
+        o.orc_hybrid_destroy(hy)
+    if hb is not None:
+        o.orc_behz_destroy(hb)
     lib.L.fhe_graph_destroy(graph2)
     lib.check(lib.L.fhe_stream_destroy(ctx.h, st))
     ctx.free(ws)
@@ -400,7 +574,8 @@ def bfv_leg(lib, device, batch, steps, warmup, sync, with_cpu):
     ks.close()
     ctx.close()
     relin = {"ops_per_s_per_gpu": round(batch / dt2, 1), "ms_per_batch": round(dt2 * 1e3, 3),
-             "shape": f"+ HYBRID relinearisation, dnum={dnum}, {len(p)} P limbs", "launch": mode2, "cpu_baseline": None}
+             "shape": f"+ HYBRID relinearisation, dnum={dnum}, {len(p)} P limbs", "launch": mode2, "parity": par2,
+             "cpu_baseline": None}
     cpu = None
     if with_cpu:  # after the GPU leg: the reference's OpenMP team keeps spinning for a while and slows kernel launches
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -445,21 +620,48 @@ def bfv_leg(lib, device, batch, steps, warmup, sync, with_cpu):
             r.ref_bfv_destroy(h2)
     return {"with_relinearisation": relin, "ops_per_s_per_gpu": round(batch / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "batch": batch,
             "shape": f"N=2^{logN}, {numQ} Q limbs + {len(bsk)} Bsk limbs, t={t}, no relinearisation", "launch": mode,
-            "cpu_baseline": cpu}
+            "parity": par, "cpu_baseline": cpu}
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` invoked like the N=1 run: start one rank per GPU ourselves (the driver's own
+        # `python -m torch.distributed.run ... bench.py --gpus N` sets WORLD_SIZE and comes straight through)
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     torch = None
+    # FHE_BENCH_BACKEND=gloo: the CPU rehearsal of the multi-rank path (with FHE_HIP_LIB pointing at the test-only lane
+    # emulator build and small --logn/--batch); the product path is "nccl" = RCCL over xGMI
+    backend = os.environ.get("FHE_BENCH_BACKEND", "nccl")
+    tdev = None
     if world > 1 or a.gpus > 1 or os.environ.get("FHE_BENCH_FORCE_DIST"):
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            tdev = torch.device("cuda", local)
+            dist.init_process_group("nccl", device_id=tdev)
+        else:
+            tdev = torch.device("cpu")
+            dist.init_process_group(backend)
     elif not os.environ.get("FHE_BENCH_NO_TORCH"):
         try:
             import torch
@@ -468,7 +670,7 @@ def main():
     lib = fh.Lib()  # the HIP library or nothing
     if lib.device_count() < 1:
         raise fh.FheError("bench.py needs a HIP device; there is no CPU fallback")
-    device = local if world > 1 else 0
+    device = local if (world > 1 and backend == "nccl") else 0
 
     logN, L, B = a.logn, a.limbs, a.batch
     N = 1 << logN
@@ -499,32 +701,51 @@ def main():
     gpu_sync()
     barrier()
     dt = time.perf_counter() - t0
+    per_rank_ms = [round(dt / a.steps * 1e3, 4)]
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=tdev)
+        gathered = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(gathered, tt)
+        per_rank_ms = [round(float(g.item()) / a.steps * 1e3, 4) for g in gathered]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt / a.steps * 1e3
     bytes_per_step = 4.0 * 8 * N * L * B  # fwd + inv, each: read once + write once
     value = bytes_per_step * world / (ms_per_step * 1e-3) / 1e9
 
-    # ---- size-independent parity at the full workload: every step is NTT followed by INTT, so the resident batch must
-    # still be the generated one; sample towers (first / middle / last) and compare them word for word with the host copy
-    def roundtrip_check():
-        rng = np.random.default_rng(2 + rank)
+    # ---- parity at the full workload.  Every timed step is NTT followed by INTT, so the resident batch must still be the
+    # generated one (round trip); and ONE more forward transform of the resident 16 GB batch is compared word for word with
+    # the oracle's forward transform of the same towers (first / middle / last: tower t is seed tower t % 8), so that a
+    # wrong-but-invertible transform cannot pass.  The inverse transform that follows restores the batch.
+    def full_size_parity():
         seed_polys = min(8, B)
-        host = np.empty((seed_polys, L, N), np.uint64)
-        for i, qi in enumerate(q):
-            host[:, i, :] = rng.integers(0, int(qi), size=(seed_polys, N), dtype=np.uint64)
-        got = np.empty((L, N), np.uint64)
-        for tw in sorted({0, B // 2, B - 1}):
-            lib.check(lib.L.fhe_memcpy_d2h(ctx.h, got.ctypes.data_as(C.c_void_p), C.c_void_p(x.value + tw * L * N * 8),
-                                           got.nbytes, None))
-            ctx.sync()
-            # fill_random_tower doubles the filled prefix (8, 16, 32, ... towers): tower t is a copy of tower t mod 8
-            if not np.array_equal(got, host[tw % seed_polys]):
-                return f"MISMATCH at tower {tw}"
-        return "fwd+inv round trip bit-exact on towers {0, B/2, B-1} after all steps"
-    roundtrip = roundtrip_check()
+        host = host_seed_towers(q, N, B, 2 + rank, 8)
+        for tw in sample_towers(B):
+            if not np.array_equal(download_tower(lib, ctx, x, tw, L), host[tw % seed_polys]):
+                return f"MISMATCH (round trip) at tower {tw}"
+        if a.no_parity:
+            return "fwd+inv round trip bit-exact on towers {0, B/2, B-1} after all steps (oracle comparison skipped)"
+        o = load_oracle()
+        if o is None:
+            return "fwd+inv round trip bit-exact on towers {0, B/2, B-1}; oracle library not available"
+        octx = o.orc_ctx_create(N, L, q, psi)
+        lib.check(lib.L.fhe_ntt_fwd(ctx.h, x, None, L, B, None))
+        res = "forward NTT words of towers {0, B/2, B-1} of the resident batch == oracle (orc_ntt_fwd_tower), and fwd+inv round trip bit-exact after all steps"
+        done = {}
+        for tw in sample_towers(B):
+            sp = tw % seed_polys
+            if sp not in done:
+                w = host[sp].copy()
+                o.orc_ntt_fwd_tower(octx, w, None, L, 1, 0)
+                done[sp] = w
+            if not np.array_equal(download_tower(lib, ctx, x, tw, L), done[sp]):
+                res = f"MISMATCH vs oracle (forward NTT) at tower {tw}"
+                break
+        lib.check(lib.L.fhe_ntt_inv(ctx.h, x, None, L, B, None))
+        ctx.sync()
+        o.orc_ctx_destroy(octx)
+        return res
+    roundtrip = full_size_parity()
 
     # ---- Hadamard product a o b over the same batch shape: 3 streams, HBM-bound ----
     hadamard = None
@@ -582,17 +803,22 @@ def main():
             dom = max(per_kernel, key=per_kernel.get)
             alg = 2.0 * 8 * N * L * B  # a pass kernel reads every word once and writes it once
             ach = alg / (per_kernel[dom] * 1e-3) / 1e9
-            traffic = None  # HBM bytes per launch from the committed rocprofv3 PMC passes of this exact workload
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                if pmc.get("workload") == f"logN{logN}_L{L}_B{B}":
-                    traffic = pmc["per_launch_bytes"][dom[:-3]]["total"]
-            except Exception:
-                traffic = None
+            # HBM bytes per launch from the committed rocprofv3 PMC passes of this exact workload — quoted only when the record
+            # was made with the kernels this run executes (same kernel-source identity), else null
+            traffic, tsrc = None, None
+            for rec in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", rec)))
+                    if pmc.get("workload") == f"logN{logN}_L{L}_B{B}" and pmc.get("kernel_source_sha") == source_sha():
+                        traffic = pmc["per_launch_bytes"][dom[:-3]]["total"]
+                        tsrc = f"profiles/{rec} (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes, same kernel sources)"
+                        break
+                    tsrc = f"profiles/{rec} was recorded with other kernel sources: not quoted"
+                except Exception:
+                    continue
             roof = {"bound": "hbm", "kernel": "ntt_static_kernel/" + dom[:-3], "achieved": round(ach, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                    "traffic_source": "profiles/r01_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
-                                      if traffic else None,
+                    "traffic_source": tsrc, "kernel_source_sha": source_sha(),
                     "algorithmic_bytes_per_launch": alg, "per_kernel_ms": per_kernel}
         else:
             lib.check(lib.L.fhe_time_ntt(ctx.h, x, None, L, B, 0, 5, None, C.byref(ms)))
@@ -604,23 +830,49 @@ def main():
     ctx.free(x)
 
     em = None
-    if not a.no_evalmult and logN == 16:
-        em = evalmult_leg(lib, device, logN, a.evalmult_batch, max(20, a.steps * 2), 6, gpu_sync, dist)
+    if not a.no_evalmult:
+        em = evalmult_leg(lib, device, a.evalmult_logn, a.evalmult_batch, max(20, a.steps * 2), 6, gpu_sync, dist,
+                          sizeQ=a.evalmult_limbs, parity=not a.no_parity, tdev=tdev)
         if dist is not None:
-            tt = torch.tensor([em["ops_per_s_per_gpu"]], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([em["ops_per_s_per_gpu"]], dtype=torch.float64, device=tdev)
             dist.all_reduce(tt, op=dist.ReduceOp.SUM)
             em["ops_per_s_total"] = round(float(tt.item()), 1)
         else:
             em["ops_per_s_total"] = em["ops_per_s_per_gpu"]
 
+    # ---- multi-rank only: replication of a bootstrapping-sized rotation-key set: rank 0 holds the keys, every
+    # rank ends up with a full copy through scatter + all-gather (each xGMI link carries 1/N of the set per step instead of
+    # a link-bound ring broadcast of the whole set)
+    keyrep = None
+    if dist is not None and not os.environ.get("FHE_BENCH_NO_KEYREP"):
+        from openfhe_amd import shard
+        nkeys = int(os.environ.get("FHE_BENCH_KEYREP_KEYS", "14"))
+        words = 3 * (a.evalmult_limbs + 7) * (1 << a.evalmult_logn)  # one key half: [dnum][l+k][N]
+        try:
+            src_t = torch.zeros((nkeys, 2, words), dtype=torch.int64, device=tdev) if rank == 0 else None  # resident on rank 0
+            dist.barrier()
+            t0 = time.perf_counter()
+            full = shard.allgather_words(src_t, (nkeys, 2, words), tdev)
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            dist.barrier()
+            sec = time.perf_counter() - t0
+            gb = nkeys * 2 * words * 8 / 1e9
+            keyrep = {"keys": nkeys, "GB": round(gb, 3), "seconds": round(sec, 4), "GB_per_s": round(gb / sec, 1),
+                      "how": f"rank 0 -> {world} rank(s): scatter of 1/{world} slices + all-gather ({backend})"}
+            del full
+        except Exception as e:
+            keyrep = {"error": f"{type(e).__name__}: {e}"}
+
     bfv = None
     if not a.no_bfv and logN == 16:
         bfv = bfv_leg(lib, device, a.bfv_batch, max(30, a.steps * 3), 6, gpu_sync,
-                      rank == 0 and world == 1 and not a.no_cpu_baseline)
+                      rank == 0 and world == 1 and not a.no_cpu_baseline, parity=not a.no_parity)
 
     ltr = None
     if not a.no_lt and logN == 16 and world == 1:
-        ltr = linear_transform_leg(lib, device, (1, 8), max(10, a.steps), 3, rank == 0 and not a.no_cpu_baseline)
+        ltr = linear_transform_leg(lib, device, (1, 8), max(10, a.steps), 3, rank == 0 and not a.no_cpu_baseline,
+                                   parity=not a.no_parity)
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -638,8 +890,10 @@ def main():
                        "parallelism": f"batch-sharded x{world}, no data-path collective"},
             "hbm_roofline_frac_fwd_inv": round(value / world / HBM_PEAK_GBPS, 4),
             "roofline": roof, "cpu_baseline": cpu, "evalmult": em,
-            "hadamard": hadamard, "parity_at_full_size": roundtrip,
+            "hadamard": hadamard, "parity_at_full_size": roundtrip, "ms_per_step_per_rank": per_rank_ms,
         }
+        if keyrep is not None:
+            out["rotation_key_replication"] = keyrep
         if bfv is not None:
             out["bfv_evalmult"] = bfv
         if ltr is not None:

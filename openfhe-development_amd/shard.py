@@ -78,3 +78,63 @@ def broadcast_rows(host_rows, shape, device, src=0):
         t.copy_(torch.from_numpy(np.ascontiguousarray(host_rows, dtype=np.uint64).view(np.int64).reshape(shape)))
     dist.broadcast(t, src=src)
     return t
+
+
+def allgather_words(host_words, shape, device, src=0):
+    """Replicates a large read-only table of 64-bit words (a bootstrapping rotation-key set: ~13 GB at N = 2^17, SURVEY.md
+    8e) from rank `src` to every rank as scatter + all-gather: `src` sends each rank ONE 1/world slice, then every rank
+    gathers the other slices from its peers — every xGMI link carries 1/world of the table per step, where a ring
+    broadcast pushes the whole table through every link of the ring.  `host_words`: uint64 array of `shape` on rank
+    `src` (or an int64 tensor already on `device`; ignored elsewhere).  Returns the rank-local int64 tensor of `shape`
+    (its data_ptr() + offsets are device pointers; keep it alive while they are in use)."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    total = int(np.prod(shape))
+    per = -(-total // world)  # slice length, the last slice is padded
+    full = torch.empty(per * world, dtype=torch.int64, device=device)
+    mine = torch.empty(per, dtype=torch.int64, device=device)
+    chunks = None
+    if rank == src:
+        if isinstance(host_words, torch.Tensor):
+            flat = host_words.reshape(-1)
+        else:
+            flat = torch.from_numpy(np.ascontiguousarray(host_words, dtype=np.uint64).reshape(-1).view(np.int64))
+        if flat.numel() == per * world and flat.device == torch.device(device):
+            staged = flat
+        else:
+            staged = torch.zeros(per * world, dtype=torch.int64, device=device)
+            staged[:total].copy_(flat)
+        chunks = list(staged.split(per))
+    dist.scatter(mine, chunks, src=src)
+    try:
+        dist.all_gather_into_tensor(full, mine)
+    except Exception:  # backends without the flat form
+        parts = [torch.empty(per, dtype=torch.int64, device=device) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        full = torch.cat(parts)
+    return full[:total].view(*shape)
+
+
+def allgather_rotation_keys(plan, host_keys, device, src=0):
+    """`broadcast_rotation_keys` with the scatter + all-gather replication of `allgather_words`: host_keys = list of
+    (keyB, keyA) on rank `src` (only its length matters elsewhere).  Returns (handles, tensor)."""
+    import ctypes as C
+
+    import torch.distributed as dist
+
+    words, n = plan.key_words(), len(host_keys)
+    packed = None
+    if dist.get_rank() == src:
+        packed = np.empty((n, 2, words), np.uint64)
+        for i, (kb, ka) in enumerate(host_keys):
+            packed[i, 0] = np.ascontiguousarray(kb, dtype=np.uint64).reshape(-1)
+            packed[i, 1] = np.ascontiguousarray(ka, dtype=np.uint64).reshape(-1)
+    t = allgather_words(packed, (n, 2, words), device, src)
+    L, handles = plan.ctx.lib.L, []
+    for i in range(n):
+        k = C.c_void_p()
+        plan.ctx.lib.check(L.fhe_ks_key_wrap(plan.h, C.c_void_p(t[i, 0].data_ptr()), C.c_void_p(t[i, 1].data_ptr()), C.byref(k)))
+        handles.append(k)
+    return handles, t

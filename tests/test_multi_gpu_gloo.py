@@ -166,3 +166,66 @@ def test_two_rank_sharded_linear_transform_with_key_and_diagonal_broadcast(tmp_p
         import pytest
         pytest.skip("CPU (gloo) variant only")
     run_two_ranks(tmp_path, WORKER_LT)
+
+
+def test_bench_self_launches_two_ranks_on_gloo(backend):
+    """`python bench.py --gpus 2`, invoked exactly like the N=1 run (no torchrun), starts its own ranks; rehearsed on CPU with
+    the gloo backend and the test-only emulator build at small sizes (FHE_BENCH_BACKEND / FHE_HIP_LIB).  The JSON line must
+    carry n_gpus = 2, per-rank times, the key broadcast to 2 ranks, the scatter + all-gather replication record and the
+    per-leg parity fields."""
+    import json
+    if "emulator" not in backend.version():
+        import pytest
+        pytest.skip("CPU (gloo) variant only; on GPUs the same command runs with RCCL")
+    env = dict(os.environ, FHE_BENCH_BACKEND="gloo", FHE_HIP_LIB=os.path.join(ROOT, "tests", "emu", "libfhe_emu.so"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--logn", "12", "--limbs", "2",
+           "--batch", "4", "--evalmult-logn", "10", "--evalmult-limbs", "5", "--evalmult-batch", "3", "--no-bfv", "--no-lt",
+           "--no-hadamard", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and len(d["ms_per_step_per_rank"]) == 2 and d["scaling"] == "weak"
+    assert "2 rank(s)" in d["evalmult"]["eval_key"] and d["evalmult"]["ops_per_s_total"] >= d["evalmult"]["ops_per_s_per_gpu"]
+    assert d["evalmult"]["parity"].startswith("bit-exact vs oracle")
+    assert d["parity_at_full_size"].startswith("forward NTT words")
+    assert "scatter" in d["rotation_key_replication"]["how"] and d["rotation_key_replication"]["keys"] == 14
+
+
+def test_allgather_replication_matches_broadcast(tmp_path, backend):
+    """shard.allgather_words (scatter + all-gather) delivers the same words to every rank as the one-shot broadcast, also when
+    the table does not divide by the world size"""
+    if "emulator" not in backend.version():
+        import pytest
+        pytest.skip("CPU (gloo) variant only")
+    worker = tmp_path / "w.py"
+    worker.write_text(r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from openfhe_amd import shard
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+for shape in [(3, 2, 1031), (7,), (2, 4096)]:
+    want = (np.arange(int(np.prod(shape)), dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)).reshape(shape)
+    got = shard.allgather_words(want if rank == 0 else None, shape, "cpu")
+    assert np.array_equal(got.numpy().view(np.uint64), want), (rank, shape)
+    ref = shard.broadcast_rows(want if rank == 0 else None, shape, "cpu")
+    assert torch.equal(ref, got)
+dist.barrier()
+if rank == 0:
+    open(sys.argv[2], "w").write("ok")
+dist.destroy_process_group()
+''')
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ok = tmp_path / "ok"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(worker), ROOT, str(ok)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and ok.exists(), out.stdout[-2000:] + out.stderr[-3000:]

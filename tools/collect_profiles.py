@@ -1,21 +1,35 @@
 #!/usr/bin/env python3
-"""copies the judged summaries of the last tools/gpu_bench_r01.sh run from gpurun_out/ (scratch) into profiles/"""
-import collections, csv, glob, json, os, shutil, sys
+"""copies the judged summaries of the last `tools/gpu_record.sh <tag>` run from gpurun_out/ (scratch) into profiles/"""
+import collections, csv, glob, hashlib, json, os, shutil, sys
 
 
 def newest(pattern):  # gpurun_out accumulates the runs of a round: take the latest file
     return max(glob.glob(pattern), key=os.path.getmtime)
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+def source_sha():  # the same identity bench.py computes: the kernel sources the measured library was built from
+    h = hashlib.sha256()
+    d = os.path.join("openfhe-development_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+R = sys.argv[1] if len(sys.argv) > 1 else "r02"
 os.makedirs("profiles", exist_ok=True)
-shutil.copy("gpurun_out/bench_r01.json", f"profiles/{R}_bench.json")
-shutil.copy(newest("gpurun_out/prof_r01/*/*kernel_stats.csv"), f"profiles/{R}_rocprof_kernel_stats_bench.csv")
-shutil.copy(newest("gpurun_out/prof_r01_ntt/*/*kernel_stats.csv"), f"profiles/{R}_rocprof_kernel_stats_ntt_leg.csv")
+shutil.copy(f"gpurun_out/bench_{R}.json", f"profiles/{R}_bench.json")
+shutil.copy(newest(f"gpurun_out/prof_{R}/*/*kernel_stats.csv"), f"profiles/{R}_rocprof_kernel_stats_bench.csv")
+shutil.copy(newest(f"gpurun_out/prof_{R}_ntt/*/*kernel_stats.csv"), f"profiles/{R}_rocprof_kernel_stats_ntt_leg.csv")
+try:
+    shutil.copy(newest(f"gpurun_out/prof_{R}_evalmult/*/*kernel_stats.csv"), f"profiles/{R}_rocprof_kernel_stats_evalmult256.csv")
+except ValueError:
+    pass
 names = {"<true, false,": "fwd_column_pass", "<false, false,": "fwd_row_pass", "<false, true,": "inv_row_pass",
          "<true, true,": "inv_column_pass"}
 res = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = newest(f"gpurun_out/pmc_r01_{c}/*/*counter_collection.csv")
+    f = newest(f"gpurun_out/pmc_{R}_{c}/*/*counter_collection.csv")
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == c and "ntt_static_kernel" in r["Kernel_Name"]:
@@ -24,9 +38,11 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for k, v in agg.items():
         res.setdefault(k, {})[c] = sum(v) / len(v)
 out = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --steps 2 "
-               "--warmup 1 --no-cpu-baseline --no-evalmult` (N=2^16, L=30, B=1024), tools/gpu_bench_r01.sh. Counter units are "
+               "--warmup 1 --no-cpu-baseline --no-evalmult` (N=2^16, L=30, B=1024), tools/gpu_record.sh. Counter units are "
                "KiB; FETCH_SIZE is doubled (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md §HBM).",
-       "workload": "logN16_L30_B1024", "per_launch_bytes": {}}
+       "workload": "logN16_L30_B1024", "per_launch_bytes": {},
+       # identity of the kernel sources ON THE GPU BOX in that run (bench.py recorded it in its own line)
+       "kernel_source_sha": (json.load(open(f"profiles/{R}_bench.json")).get("roofline") or {}).get("kernel_source_sha") or source_sha()}
 for k, v in res.items():
     out["per_launch_bytes"][k] = {"fetch_bytes": v["FETCH_SIZE"] * 2048, "write_bytes": v["WRITE_SIZE"] * 1024,
                                   "total": v["FETCH_SIZE"] * 2048 + v["WRITE_SIZE"] * 1024,
