@@ -19,7 +19,10 @@ def source_sha():  # the same identity bench.py computes: the kernel sources the
 R = sys.argv[1] if len(sys.argv) > 1 else "r02"
 os.makedirs("profiles", exist_ok=True)
 shutil.copy(f"gpurun_out/bench_{R}.json", f"profiles/{R}_bench.json")
-shutil.copy(newest(f"gpurun_out/prof_{R}/*/*kernel_stats.csv"), f"profiles/{R}_rocprof_kernel_stats_bench.csv")
+try:
+    shutil.copy(newest(f"gpurun_out/prof_{R}/*/*kernel_stats.csv"), f"profiles/{R}_rocprof_kernel_stats_bench.csv")
+except ValueError:  # (rocprofv3 itself crashed on the whole-bench command in one session: the per-leg profiles remain)
+    pass
 shutil.copy(newest(f"gpurun_out/prof_{R}_ntt/*/*kernel_stats.csv"), f"profiles/{R}_rocprof_kernel_stats_ntt_leg.csv")
 try:
     shutil.copy(newest(f"gpurun_out/prof_{R}_evalmult/*/*kernel_stats.csv"), f"profiles/{R}_rocprof_kernel_stats_evalmult256.csv")
