@@ -662,7 +662,7 @@ struct FusedSync {
     uint32_t phaseMask;  // 3 = fused; 1 / 2 = one phase only, no synchronisation (lane emulator: workgroups run one by one)
     uint32_t forceSlow;  // test knob: treat every group as spread over XCDs
 };
-constexpr uint32_t kFusedMaxSpins = 1u << 19;
+constexpr uint32_t kFusedMaxSpins = 1u << 18;  // x (poll + s_sleep) ~ a few 100 ms; a raised *err ends every other wait early
 
 // returns false if the wait expired
 FHE_DEV bool fused_arrive_and_wait(const FusedSync& sy, uint32_t v, uint32_t G, uint64_t* lds) {
@@ -682,6 +682,8 @@ FHE_DEV bool fused_arrive_and_wait(const FusedSync& sy, uint32_t v, uint32_t G, 
                 st = (((uint32_t)(c >> field) & 63u) == G && !sy.forceSlow) ? 0u : 1u;
                 break;
             }
+            if ((spins & 255u) == 255u && __hip_atomic_load(sy.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                break;
             __builtin_amdgcn_s_sleep(2);
         }
         if (st == 1u) {
@@ -696,6 +698,8 @@ FHE_DEV bool fused_arrive_and_wait(const FusedSync& sy, uint32_t v, uint32_t G, 
                     st = 1;
                     break;
                 }
+                if ((spins & 255u) == 255u && __hip_atomic_load(sy.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                    break;
                 __builtin_amdgcn_s_sleep(2);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
