@@ -260,14 +260,7 @@ struct fhe_ctx {
     // cached ModReduce tables per (sizeQl, t): [0..l) = A_i, [l..2l) = B_i, [2l] = negtInvModq   (fhe_mod_reduce)
     std::map<std::pair<uint32_t, uint64_t>, TwPair*> modReduceTabs;
     std::mutex cacheMutex;        // guards the lazily filled caches above (callers may be OpenMP threads)
-    // arrival words of the fused (single-HBM-round-trip) transform: a ring of slots, one per launch, each [2][slotRows]
-    uint64_t* d_fusedCnt  = nullptr;
-    uint32_t* d_fusedErr  = nullptr;
-    size_t fusedSlotRows  = 0;
-    uint32_t fusedNext    = 0;
-    bool fusedLaunched    = false;  // a fused launch happened since the error word was last read
 };
-static const uint32_t kFusedSlots = 16;
 
 static fhe_status upload(fhe_ctx* c, const void* host, size_t bytes, void** dev) {
     RT_CHECK(rt::dmalloc(dev, bytes));
@@ -368,8 +361,6 @@ extern "C" void fhe_ctx_destroy(fhe_ctx* c) {
     rt::set_device(c->device);
     for (void* p : c->owned)
         rt::dfree(p);
-    if (c->d_fusedCnt)
-        rt::dfree(c->d_fusedCnt);
     delete c;
 }
 extern "C" uint32_t fhe_ctx_logn(const fhe_ctx* c) { return c ? c->logN : 0; }
@@ -409,15 +400,6 @@ extern "C" fhe_status fhe_memcpy_d2d(fhe_ctx* c, void* d, const void* s, size_t 
 extern "C" fhe_status fhe_stream_sync(fhe_ctx* c, void* st) {
     ARG_CHECK(c, "fhe_stream_sync: null context");
     RT_CHECK(rt::sync((rt::stream_t)st));
-    if (c->fusedLaunched && c->d_fusedErr) {  // did a fused transform abandon a tile (bounded inter-workgroup wait expired)?
-        uint32_t e = 0;
-        c->fusedLaunched = false;
-        RT_CHECK(rt::d2h(&e, c->d_fusedErr, sizeof(e), (rt::stream_t)st));
-        RT_CHECK(rt::sync((rt::stream_t)st));
-        if (e)
-            return fail(FHE_ERR_DEVICE, "fused NTT: a workgroup's bounded wait for its group expired; results are incomplete "
-                                        "(FHE_NTT_FUSED=0 selects the two-launch transform)");
-    }
     return FHE_OK;
 }
 
@@ -710,94 +692,6 @@ static bool ntt_epilogue_supported(const fhe_ctx* c) {
     const uint32_t t1 = ntt_t1(c->logN), t2 = c->logN - t1;
     return t2 == 12u || (t1 == 4u && t2 >= 9u && t2 <= 12u);
 }
-// ---- fused two-pass transform (ntt_fused_kernel, ntt_static.h): both passes in one launch, the tower between them stays in
-// the XCD's L2.  FHE_NTT_FUSED=0 restores the two launches; FHE_NTT_FUSED=2 forces the agent-scope (cross-XCD) hand-off of
-// every group (test knob).
-static uint32_t ntt_fused_mode() {
-    static const uint32_t v = env_u32("FHE_NTT_FUSED", 1);
-    return v;
-}
-static bool ntt_fused_enabled(const fhe_ctx* c) {
-    return ntt_fused_mode() != 0 && c->logN > (uint32_t)kTileLog;
-}
-static fhe_status fused_slot(fhe_ctx* c, uint32_t rows, uint64_t** cnt, void* stream) {
-    std::lock_guard<std::mutex> lock(c->cacheMutex);
-    if (!c->d_fusedErr) {
-        void* d = nullptr;
-        RT_CHECK(rt::dmalloc(&d, 64));
-        c->owned.push_back(d);
-        RT_CHECK(rt::dzero_2d(d, 64, 64, 1, nullptr));
-        RT_CHECK(rt::sync(nullptr));
-        c->d_fusedErr = (uint32_t*)d;
-    }
-    if (rows > c->fusedSlotRows) {
-        RT_CHECK(rt::device_sync());  // no launch may still use the smaller ring
-        if (c->d_fusedCnt)
-            rt::dfree(c->d_fusedCnt);
-        c->d_fusedCnt   = nullptr;
-        const size_t nr = ((size_t)rows + 1023) & ~(size_t)1023;
-        void* d         = nullptr;
-        RT_CHECK(rt::dmalloc(&d, (size_t)kFusedSlots * 2 * nr * 8));
-        c->d_fusedCnt    = (uint64_t*)d;
-        c->fusedSlotRows = nr;
-    }
-    *cnt = c->d_fusedCnt + (size_t)(c->fusedNext++ % kFusedSlots) * 2 * c->fusedSlotRows;
-    c->fusedLaunched = true;
-    // (arrival words of both rounds: zeroed on the caller's stream right before the launch; capturable)
-    RT_CHECK(rt::dzero_2d(*cnt, 2 * c->fusedSlotRows * 8, ((size_t)c->fusedSlotRows + rows) * 8, 1, (rt::stream_t)stream));
-    return FHE_OK;
-}
-static fhe_status launch_fused(fhe_ctx* c, const PassPlan& p1, const PassPlan& p2, bool inverse, const uint64_t* xin, uint64_t* xout,
-                               const LimbSel& sel, uint32_t nLimbs, uint32_t batch, bool canonOut, void* stream, uint32_t inStride,
-                               uint32_t inFirst, uint32_t outStride, uint32_t outFirst, const NttEpilogue* epi) {
-    const uint32_t logN = c->logN, T1 = ntt_t1(logN), T2 = logN - T1;
-    const bool wantEpi = epi && epi->mode;
-    if (!((T1 == 4u && T2 >= 9u && T2 <= 12u) || (T1 == 5u && T2 == 12u)) || (wantEpi && (inverse || !ntt_epilogue_supported(c))))
-        return FHE_ERR_UNSUPPORTED;
-    NttPassArgs a1, a2;
-    fill_pass_args(c, p1, inverse, xin, xout, sel, nLimbs, batch, false, inStride, inFirst, outStride, outFirst, a1);
-    fill_pass_args(c, p2, inverse, xout, xout, sel, nLimbs, batch, canonOut, outStride, outFirst, outStride, outFirst, a2);
-    a1.xcdSwizzle = a2.xcdSwizzle = 0;  // the fused kernel maps block ids to tiles itself
-    if (wantEpi) {
-        a2.epiMode = epi->mode, a2.epiSplit = epi->split, a2.epiAStride = epi->aStride, a2.epiAFirst = epi->aFirst;
-        a2.epiA = epi->A, a2.epiC = epi->C, a2.epiOut0 = epi->out0, a2.epiOut1 = epi->out1;
-    }
-    const uint32_t rows = batch * nLimbs, G = c->N >> kTileLog;
-    FusedSync sy;
-    sy.rows = rows, sy.batch = batch, sy.nLimbs = nLimbs, sy.phaseMask = 3u, sy.forceSlow = ntt_fused_mode() == 2u ? 1u : 0u;
-    if (fhe_status s = fused_slot(c, rows, &sy.cnt, stream))
-        return s;
-    sy.cnt2 = sy.cnt + c->fusedSlotRows;
-    sy.err  = c->d_fusedErr;
-    const uint32_t grid = ((rows + 7u) / 8u) * 8u * G;
-    bool launched       = false;
-#ifdef FHE_EMU
-#define FHE_FUSED_LAUNCH(...)                                         \
-    sy.phaseMask = 1u;                                                \
-    FHE_LAUNCH((ntt_fused_kernel<__VA_ARGS__>), grid, stream, a1, a2, sy); \
-    sy.phaseMask = 2u;                                                \
-    FHE_LAUNCH((ntt_fused_kernel<__VA_ARGS__>), grid, stream, a1, a2, sy);
-#else
-#define FHE_FUSED_LAUNCH(...) FHE_LAUNCH((ntt_fused_kernel<__VA_ARGS__>), grid, stream, a1, a2, sy);
-#endif
-#define FHE_FUSED_CASE(INV, TT1, TT2, EPIF)                                                    \
-    if (!launched && inverse == INV && T1 == TT1 && T2 == TT2 && wantEpi == EPIF) {          \
-        FHE_FUSED_LAUNCH(INV, TT1, TT2, 9, EPIF)                                               \
-        launched = true;                                                                      \
-    }
-    FHE_FUSED_CASE(false, 4, 12, false) FHE_FUSED_CASE(true, 4, 12, false) FHE_FUSED_CASE(false, 4, 12, true)
-    FHE_FUSED_CASE(false, 5, 12, false) FHE_FUSED_CASE(true, 5, 12, false) FHE_FUSED_CASE(false, 5, 12, true)
-    FHE_FUSED_CASE(false, 4, 11, false) FHE_FUSED_CASE(true, 4, 11, false) FHE_FUSED_CASE(false, 4, 11, true)
-    FHE_FUSED_CASE(false, 4, 10, false) FHE_FUSED_CASE(true, 4, 10, false) FHE_FUSED_CASE(false, 4, 10, true)
-    FHE_FUSED_CASE(false, 4, 9, false) FHE_FUSED_CASE(true, 4, 9, false) FHE_FUSED_CASE(false, 4, 9, true)
-#undef FHE_FUSED_CASE
-#undef FHE_FUSED_LAUNCH
-    if (!launched)
-        return FHE_ERR_UNSUPPORTED;
-    LAUNCH_CHECK();
-    return FHE_OK;
-}
-
 static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_t* xout, const uint32_t* limbIdx,
                           uint32_t nLimbs, uint32_t batch, void* stream, uint32_t inStride = 0, uint32_t inFirst = 0,
                           uint32_t outStride = 0, uint32_t outFirst = 0, const NttEpilogue* epi = nullptr,
@@ -836,12 +730,9 @@ static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_
     }
     const PassPlan& p1 = inverse ? pb : pa;
     const PassPlan& p2 = inverse ? pa : pb;
-    if (ntt_fused_enabled(c)) {
-        fhe_status fs = launch_fused(c, p1, p2, inverse, xin, xout, sel, nLimbs, batch, canonOut, stream, inStride, inFirst, outStride,
-                                     outFirst, epi);
-        if (fs != FHE_ERR_UNSUPPORTED)
-            return fs;
-    }
+    // Both passes of the whole batch back to back on the caller's stream.  Fusing them into one launch with the tower kept in
+    // the XCD's L2 between the phases was built and measured in round 2 (profiles/r02_sweeps.md, session 3): bit-exact, 31 %
+    // slower, no L2 retention at 4 workgroups per CU and write-through stores — removed.
     // Both passes of the whole batch back to back on the caller's stream.  Two ways of overlapping the HBM-bound column
     // pass of one part of the batch with the integer-bound row pass of another were measured and rejected
     // (profiles/r01_sweeps.md): two streams (the hardware does not co-schedule two grids that each fill the chip) and

@@ -422,18 +422,7 @@ FHE_HD void lane_geom_s(uint32_t t, uint32_t S, uint32_t& Ib, uint32_t& jrel, ui
 // (its top stage is the transform's last stage, with N^-1 folded in), 0 = it does not.
 // One LDS buffer with a barrier on either side of an exchange (34 KiB, 4 workgroups per CU); the double-buffered form
 // (68 KiB, 2 workgroups per CU) was measured slower (profiles/r01_sweeps.md).
-// first load of a pass.  COH: the words were written by OTHER workgroups of this launch (fused kernel below): read them
-// past this CU's vector L1 (`global_load ... sc1`, served by the XCD's L2) — a CU's L1 is never refreshed by other CUs' stores
-template <bool COH>
-FHE_DEV uint64_t ld_first(const uint64_t* p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (COH)
-        return __hip_atomic_load(const_cast<uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-    return *p;
-}
-
-template <bool LA, bool INV, int T, int MODE, bool EPI = false, bool COH = false>
+template <bool LA, bool INV, int T, int MODE, bool EPI = false>
 FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) {
     using P = SPlan<LA, INV, T>;
     const uint32_t t    = FHE_TID;
@@ -559,7 +548,7 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
         lane_geom_s<LA, T, 8>(t, S, Ib, jrel, ks);
 #pragma unroll
         for (int k = 0; k < 16; ++k)
-            r[k] = ld_first<COH>(src + jrel + k * ks);
+            r[k] = src[jrel + k * ks];
         FHE_SHARED_TW_TO_LDS()
         uint64_t* L = lds + lds_pad(Ib);
 #pragma unroll
@@ -573,7 +562,7 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
         constexpr int fI = P::fI(I);                                                                              \
         lane_geom_s<LA, T, fI>(t, S, Ib, jrel, ks);                                                               \
         if constexpr (I == 0 && !P::stageFirst) {                                                                 \
-            _Pragma("unroll") for (int k = 0; k < 16; ++k) r[k] = ld_first<COH>(src + jrel + k * ks);             \
+            _Pragma("unroll") for (int k = 0; k < 16; ++k) r[k] = src[jrel + k * ks];                             \
             FHE_SHARED_TW_TO_LDS()                                                                                \
         }                                                                                                         \
         else {                                                                                                    \
@@ -638,114 +627,6 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_static_kernel(const NttPassArgs 
     ntt_static_body<LA, INV, T, MODE, EPI>(a, FHE_BID, lds);
 }
 
-
-// ---- single-HBM-round-trip transform of a two-pass ring --------------------------------------------------------------
-// One launch runs BOTH passes.  The G = N/4096 workgroups that own the tiles of one limb-polynomial (512 KiB at N = 2^16)
-// form a group; block ids bid = 8*i + x put the members of a group on consecutive slots of ONE XCD (observed placement:
-// block b runs on XCD b % 8), so that the tower between the passes stays in that XCD's 4 MiB L2 instead of travelling to
-// HBM and back:
-//   phase 1   the member's tile of the first pass (forward: the strided column step; inverse: the row pass), plain stores
-//             (a plain store leaves its line in the XCD's L2);
-//   arrive    every wave drains its stores, one lane adds to the group's arrival word;
-//   wait      one lane polls the word (bounded) until all G members have arrived;
-//   phase 2   the member's tile of the second pass, first loads past the L1 (ld_first<true>: served by the L2).
-// Correctness never depends on the placement: the arrival word also counts the members per XCD (HW_REG_XCC_ID); a group
-// that turns out to be spread over XCDs takes a second, agent-scope round (release fence = L2 write-back, second arrival
-// word, acquire fence) before phase 2.  A wait that exceeds its bound raises *err and abandons the tile (the host reports
-// it at the next synchronisation) instead of hanging the device.  Groups of one XCD share their limb across consecutive
-// towers (virtual group index batch-fastest), so the limb's twiddles stay in that L2 as well.
-struct FusedSync {
-    uint64_t* cnt;       // [rows] arrival words, zeroed before the launch: bits 0..7 = arrivals, bits 8+6x.. = arrivals on XCD x
-    uint64_t* cnt2;      // [rows] second-round arrivals (groups spread over XCDs only)
-    uint32_t* err;       // raised when a bounded wait expires
-    uint32_t rows, batch, nLimbs;
-    uint32_t phaseMask;  // 3 = fused; 1 / 2 = one phase only, no synchronisation (lane emulator: workgroups run one by one)
-    uint32_t forceSlow;  // test knob: treat every group as spread over XCDs
-};
-constexpr uint32_t kFusedMaxSpins = 1u << 18;  // x (poll + s_sleep) ~ a few 100 ms; a raised *err ends every other wait early
-
-// returns false if the wait expired
-FHE_DEV bool fused_arrive_and_wait(const FusedSync& sy, uint32_t v, uint32_t G, uint64_t* lds) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached the L2
-    __syncthreads();
-    uint32_t* state = reinterpret_cast<uint32_t*>(lds);  // (the exchange buffer is idle between the passes)
-    if (threadIdx.x == 0) {
-        const uint32_t xcc   = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;  // HW_REG_XCC_ID[3:0]
-        const uint32_t field = 8u + 6u * xcc;
-        __hip_atomic_fetch_add(sy.cnt + v, 1ull + (1ull << field), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint64_t c     = 0;
-        uint32_t spins = 0, st = 2;
-        for (; spins < kFusedMaxSpins; ++spins) {
-            c = __hip_atomic_load(sy.cnt + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((uint32_t)(c & 0xffu) >= G) {
-                st = (((uint32_t)(c >> field) & 63u) == G && !sy.forceSlow) ? 0u : 1u;
-                break;
-            }
-            if ((spins & 255u) == 255u && __hip_atomic_load(sy.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                break;
-            __builtin_amdgcn_s_sleep(2);
-        }
-        if (st == 1u) {
-            // the group is spread over XCDs: publish through memory (cdna guide G16: release fence -> drained -> arrival
-            // word; poll; acquire fence)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(sy.cnt2 + v, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            st = 2;
-            for (spins = 0; spins < kFusedMaxSpins; ++spins) {
-                if (__hip_atomic_load(sy.cnt2 + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= G) {
-                    st = 1;
-                    break;
-                }
-                if ((spins & 255u) == 255u && __hip_atomic_load(sy.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                    break;
-                __builtin_amdgcn_s_sleep(2);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        if (st == 2u)
-            __hip_atomic_store(sy.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *state = st;
-    }
-    __syncthreads();
-    const uint32_t st = *state;
-    __syncthreads();  // the word is read by everyone before the second pass reuses the buffer
-    return st != 2u;
-#else
-    (void)sy, (void)v, (void)G, (void)lds;
-    return true;
-#endif
-}
-
-// MODE2: forward = input class of the row pass (9 after a 4/5-stage column pass); EPI: the row pass carries the epilogue
-template <bool INV, int T1, int T2, int MODE2, bool EPI = false>
-FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_fused_kernel(const NttPassArgs a1, const NttPassArgs a2, const FusedSync sy) {
-    FHE_SHARED_U64(lds, kLdsPadWords + kSharedTwWords);
-    const uint32_t bid  = FHE_BID;
-    const uint32_t logG = a1.logN - (uint32_t)kTileLog, G = 1u << logG;
-    const uint32_t xcd = bid & 7u, i = bid >> 3;
-    const uint32_t w = i & (G - 1u), v = (i >> logG) * 8u + xcd;  // member, virtual group index
-    if (v >= sy.rows)
-        return;  // (whole groups: nobody waits for them)
-    const uint32_t rit = v / sy.batch, tb = v % sy.batch;  // batch-fastest: neighbouring groups share the limb
-    const uint32_t tile = (tb * sy.nLimbs + rit) * G + w;
-    if (sy.phaseMask & 1u) {
-        if constexpr (INV)
-            ntt_static_body<false, true, T2, 0>(a1, tile, lds);
-        else
-            ntt_static_body<true, false, T1, 1>(a1, tile, lds);
-    }
-    if (sy.phaseMask == 3u)
-        if (!fused_arrive_and_wait(sy, v, G, lds))
-            return;
-    if (sy.phaseMask & 2u) {
-        if constexpr (INV)
-            ntt_static_body<true, true, T1, 1, false, true>(a2, tile, lds);
-        else
-            ntt_static_body<false, false, T2, MODE2, EPI, true>(a2, tile, lds);
-    }
-}
 
 }  // namespace fhe
 #endif
