@@ -4,7 +4,9 @@
 #   ./build.sh emu     -> tests/emu/libfhe_emu.so   (TEST ONLY: lane emulator build of the same sources)
 #   ./build.sh oracle  -> oracle/libfhe_oracle.so   (TEST ONLY: C restatement of the reference)
 #   ./build.sh ref     -> oracle/_ref/*.so          (TEST ONLY: the reference itself, needs /root/reference)
-#   ./build.sh all     -> hip + emu + oracle (+ ref when /root/reference exists)
+#   ./build.sh hal     -> openfhe-development_amd/hal/_build/*.so: the reference's sources compiled against the HIP backend
+#                         of lbcrypto::DCRTPoly (lattice/hal/hip/), + the test programs of tests/hal (needs /root/reference)
+#   ./build.sh all     -> hip + emu + oracle (+ ref + hal when /root/reference exists)
 set -e
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 CSRC="$ROOT/openfhe-development_amd/csrc"
@@ -20,11 +22,13 @@ build_emu() {
 }
 build_oracle() { make -s -C "$ROOT/oracle" oracle; }
 build_ref() { make -s -j"$(nproc)" -C "$ROOT/oracle" ref; }
+build_hal() { make -s -j"$(nproc)" -C "$ROOT/openfhe-development_amd/hal" && make -s -j3 -C "$ROOT/tests/hal"; }
 case "$what" in
   hip) build_hip ;;
   emu) build_emu ;;
   oracle) build_oracle ;;
   ref) build_ref ;;
-  all) build_hip; build_emu; build_oracle; if [ -d /root/reference/src ]; then build_ref; fi ;;
+  hal) build_ref; build_hal ;;
+  all) build_hip; build_emu; build_oracle; if [ -d /root/reference/src ]; then build_ref; build_hal; fi ;;
   *) echo "unknown target $what"; exit 2 ;;
 esac

@@ -1,0 +1,267 @@
+// hip-runtime.cpp — runtime of the HIP backend of lbcrypto::DCRTPoly (see lattice/hal/hip/hip-runtime.h).
+// Compiled into libOPENFHEcore when OpenFHE is built with this repo's lattice/lat-hal.h in front of the reference's.
+//
+// The device library is loaded at first use with dlopen: $FHE_HIP_LIB, else the path compiled in as FHE_HIP_DEFAULT_LIB
+// (libfhe_hip.so of this repo).  If it cannot be loaded or no device is visible, Available() is false and DCRTPolyHipImpl
+// behaves exactly like the default backend (every member runs on its host mirror) unless FHE_HAL_REQUIRE_DEVICE=1 asks for
+// a loud failure instead.
+#include "lattice/hal/hip/hip-runtime.h"
+
+#include <dlfcn.h>
+
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+
+#include "utils/exception.h"
+
+namespace lbcrypto {
+namespace hiprt {
+
+namespace {
+struct Runtime {
+    Api api{};
+    bool live = false;
+    std::string why;
+    // allocator
+    std::mutex poolMutex;
+    std::map<size_t, std::vector<uint64_t*>> freeLists;  // bucket (words) -> free buffers
+    fhe_ctx* anyCtx = nullptr;                           // fhe_malloc wants a context handle (device selection only)
+    // contexts
+    struct Universe {
+        uint32_t logN = 0;
+        fhe_ctx* ctx  = nullptr;
+        std::vector<uint64_t> q, psi;
+        std::unordered_map<uint64_t, uint32_t> limbOf;  // modulus -> context limb
+    };
+    std::mutex ctxMutex;
+    std::map<uint32_t, Universe> universes;  // by ring dimension
+    // conversion plans
+    std::mutex convMutex;
+    std::map<std::vector<uint64_t>, fhe_conv*> convs;  // key = {ctx, nSrc, nDst, idx..., table words...}
+    std::atomic<uint64_t> deviceOps{0}, hostFallbacks{0}, h2dBytes{0}, d2hBytes{0};
+};
+
+template <typename F>
+bool sym(void* h, const char* name, F* out) {
+    *out = reinterpret_cast<F>(dlsym(h, name));
+    return *out != nullptr;
+}
+
+Runtime* build() {
+    auto* r         = new Runtime;
+    const char* env = std::getenv("FHE_HIP_LIB");
+#ifdef FHE_HIP_DEFAULT_LIB
+    const std::string path = env ? env : FHE_HIP_DEFAULT_LIB;
+#else
+    const std::string path = env ? env : "libfhe_hip.so";
+#endif
+    void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!h) {
+        r->why = std::string("cannot load ") + path + ": " + dlerror();
+    }
+    else {
+        Api& a  = r->api;
+        bool ok = sym(h, "fhe_last_error", &a.last_error) && sym(h, "fhe_device_count", &a.device_count) &&
+                  sym(h, "fhe_ctx_create", &a.ctx_create) && sym(h, "fhe_malloc", &a.malloc_) && sym(h, "fhe_free", &a.free_) &&
+                  sym(h, "fhe_memcpy_h2d", &a.h2d) && sym(h, "fhe_memcpy_d2h", &a.d2h) && sym(h, "fhe_memcpy_d2d", &a.d2d) &&
+                  sym(h, "fhe_stream_sync", &a.sync) && sym(h, "fhe_ntt_fwd", &a.ntt_fwd) && sym(h, "fhe_ntt_inv", &a.ntt_inv) &&
+                  sym(h, "fhe_ntt_inv_oop", &a.ntt_inv_oop) && sym(h, "fhe_add", &a.add) && sym(h, "fhe_sub", &a.sub) &&
+                  sym(h, "fhe_mul", &a.mul) && sym(h, "fhe_neg", &a.neg) && sym(h, "fhe_mul_const", &a.mul_const) &&
+                  sym(h, "fhe_mult_acc", &a.mult_acc) && sym(h, "fhe_automorph", &a.automorph) &&
+                  sym(h, "fhe_switch_modulus", &a.switch_modulus) && sym(h, "fhe_conv_create_custom", &a.conv_create_custom) &&
+                  sym(h, "fhe_approx_switch_basis", &a.approx_switch_basis) &&
+                  sym(h, "fhe_switch_basis_exact", &a.switch_basis_exact);
+        if (!ok)
+            r->why = path + " does not export the C ABI of include/fhe_hip.h";
+        else if (a.device_count() < 1)
+            r->why = path + ": no HIP device visible";
+        else
+            r->live = true;
+    }
+    if (!r->live && std::getenv("FHE_HAL_REQUIRE_DEVICE"))
+        OPENFHE_THROW("HIP backend of DCRTPoly: " + r->why);
+    return r;
+}
+Runtime& rt() {
+    static Runtime* r = build();  // (never destroyed: device buffers of static objects may outlive main)
+    return *r;
+}
+uint32_t log2u(uint32_t n) {
+    uint32_t l = 0;
+    while ((1u << l) < n)
+        ++l;
+    return l;
+}
+}  // namespace
+
+bool Available() { return rt().live; }
+const Api& api() { return rt().api; }
+void Check(fhe_status s, const char* what) {
+    if (s != FHE_OK)
+        OPENFHE_THROW(std::string(what) + ": " + rt().api.last_error());
+}
+void CountDevice() { rt().deviceOps.fetch_add(1, std::memory_order_relaxed); }
+void CountHost() { rt().hostFallbacks.fetch_add(1, std::memory_order_relaxed); }
+void CountH2D(size_t b) { rt().h2dBytes.fetch_add(b, std::memory_order_relaxed); }
+void CountD2H(size_t b) { rt().d2hBytes.fetch_add(b, std::memory_order_relaxed); }
+
+// ---- allocator ----
+static size_t bucket_of(size_t words) {
+    size_t b = 1024;
+    while (b < words)
+        b <<= 1;
+    if (b > (1u << 20) && words <= b - (b >> 2))  // above 8 MiB: 3/4 steps, so that odd tower heights do not waste 2x
+        b -= b >> 2;
+    return b;
+}
+DevBuf::~DevBuf() {
+    if (!p)
+        return;
+    Runtime& r = rt();
+    std::lock_guard<std::mutex> lk(r.poolMutex);
+    r.freeLists[bucket_of(words)].push_back(p);
+}
+Buf Alloc(size_t words) {
+    Runtime& r      = rt();
+    const size_t bk = bucket_of(words);
+    auto b          = std::make_shared<DevBuf>();
+    b->words        = words;
+    {
+        std::lock_guard<std::mutex> lk(r.poolMutex);
+        auto& fl = r.freeLists[bk];
+        if (!fl.empty()) {
+            b->p = fl.back();
+            fl.pop_back();
+            return b;
+        }
+    }
+    void* d = nullptr;
+    fhe_status s = r.api.malloc_(r.anyCtx, bk * 8, &d);
+    if (s != FHE_OK) {  // memory pressure: give the cached buffers back to the device and retry once
+        std::lock_guard<std::mutex> lk(r.poolMutex);
+        for (auto& kv : r.freeLists) {
+            for (uint64_t* q : kv.second)
+                r.api.free_(r.anyCtx, q);
+            kv.second.clear();
+        }
+        s = r.api.malloc_(r.anyCtx, bk * 8, &d);
+    }
+    Check(s, "HIP backend: device allocation");
+    b->p = static_cast<uint64_t*>(d);
+    return b;
+}
+
+// ---- contexts ----
+bool Resolve(uint32_t ringDim, const std::vector<LimbSet>& sets, Resolved* out) {
+    Runtime& r = rt();
+    if (!r.live || ringDim < 16 || ringDim > (1u << 17) || (ringDim & (ringDim - 1)))
+        return false;
+    const uint64_t twoN = 2ull * ringDim;
+    for (const auto& s : sets)
+        for (uint32_t i = 0; i < s.n; ++i)
+            if (s.q[i] < 3 || s.q[i] >= (1ull << 60) || (s.q[i] - 1) % twoN != 0 || s.psi[i] == 0)
+                return false;
+    std::lock_guard<std::mutex> lk(r.ctxMutex);
+    auto& u = r.universes[ringDim];
+    std::vector<uint64_t> q = u.q, psi = u.psi;
+    bool grew = false;
+    for (const auto& s : sets)
+        for (uint32_t i = 0; i < s.n; ++i) {
+            bool known = false;
+            for (size_t k = 0; k < q.size() && !known; ++k)
+                known = q[k] == s.q[i];
+            if (!known) {
+                q.push_back(s.q[i]);
+                psi.push_back(s.psi[i]);
+                grew = true;
+            }
+        }
+    if (q.size() > 128) {
+        // more distinct moduli than one device context holds (many CryptoContexts in one process): start over with the
+        // moduli of this call; towers already on the device are plain words and resolve again at their next operation
+        q.clear(), psi.clear();
+        for (const auto& s : sets)
+            for (uint32_t i = 0; i < s.n; ++i) {
+                bool known = false;
+                for (size_t k = 0; k < q.size() && !known; ++k)
+                    known = q[k] == s.q[i];
+                if (!known)
+                    q.push_back(s.q[i]), psi.push_back(s.psi[i]);
+            }
+        if (q.size() > 128)
+            return false;
+        grew = true;
+    }
+    if (grew || !u.ctx) {
+        fhe_ctx* c = nullptr;
+        if (r.api.ctx_create(log2u(ringDim), (uint32_t)q.size(), q.data(), psi.data(), 0, &c) != FHE_OK)
+            return false;  // (e.g. a root that is not primitive: leave the operation to the host mirror)
+        // the previous context stays alive: operations of other threads may still be using its tables
+        u.ctx = c, u.q = q, u.psi = psi, u.logN = log2u(ringDim);
+        u.limbOf.clear();
+        for (uint32_t k = 0; k < q.size(); ++k)
+            u.limbOf[q[k]] = k;
+        if (!r.anyCtx)
+            r.anyCtx = c;
+    }
+    out->ctx = u.ctx;
+    out->idx.assign(sets.size(), {});
+    for (size_t si = 0; si < sets.size(); ++si) {
+        out->idx[si].resize(sets[si].n);
+        for (uint32_t i = 0; i < sets[si].n; ++i) {
+            const uint32_t l = u.limbOf[sets[si].q[i]];
+            if (u.psi[l] != sets[si].psi[i])
+                return false;  // same modulus with another root of unity: another transform, not ours
+            out->idx[si][i] = l;
+        }
+    }
+    return true;
+}
+
+// ---- conversion plans ----
+fhe_conv* ConvPlan(fhe_ctx* ctx, const std::vector<uint32_t>& srcIdx, const std::vector<uint32_t>& dstIdx, const uint64_t* hatInv,
+                   const uint64_t* hatMod, const uint64_t* alphaMod, const double* qInv) {
+    Runtime& r        = rt();
+    const size_t nSrc = srcIdx.size(), nDst = dstIdx.size();
+    std::vector<uint64_t> key;
+    key.reserve(4 + nSrc + nDst + nSrc + nSrc * nDst + (alphaMod ? (nSrc + 1) * nDst + nSrc : 0));
+    key.push_back(reinterpret_cast<uintptr_t>(ctx));
+    key.push_back(nSrc);
+    key.push_back(nDst);
+    key.push_back(alphaMod ? 1 : 0);
+    key.insert(key.end(), srcIdx.begin(), srcIdx.end());
+    key.insert(key.end(), dstIdx.begin(), dstIdx.end());
+    key.insert(key.end(), hatInv, hatInv + nSrc);
+    key.insert(key.end(), hatMod, hatMod + nSrc * nDst);
+    if (alphaMod) {
+        key.insert(key.end(), alphaMod, alphaMod + (nSrc + 1) * nDst);
+        for (size_t i = 0; i < nSrc; ++i) {
+            uint64_t w;
+            std::memcpy(&w, qInv + i, 8);
+            key.push_back(w);
+        }
+    }
+    std::lock_guard<std::mutex> lk(r.convMutex);
+    auto it = r.convs.find(key);
+    if (it != r.convs.end())
+        return it->second;
+    fhe_conv* cv = nullptr;
+    Check(r.api.conv_create_custom(ctx, srcIdx.data(), (uint32_t)nSrc, dstIdx.data(), (uint32_t)nDst, hatInv, hatMod, alphaMod, qInv, &cv),
+          "HIP backend: basis-conversion plan");
+    r.convs.emplace(std::move(key), cv);
+    return cv;
+}
+
+}  // namespace hiprt
+}  // namespace lbcrypto
+
+extern "C" void fhe_hal_stats(uint64_t out[4]) {
+    auto& r = lbcrypto::hiprt::rt();
+    out[0] = r.deviceOps, out[1] = r.hostFallbacks, out[2] = r.h2dBytes, out[3] = r.d2hBytes;
+}
+extern "C" int fhe_hal_available(void) { return lbcrypto::hiprt::Available() ? 1 : 0; }

@@ -1,0 +1,966 @@
+// dcrtpoly-hip.h — lbcrypto::DCRTPolyHipImpl: the DCRTPolyInterface implementation of the MI355X (HIP) backend.
+//
+// Contract: src/core/include/lattice/hal/dcrtpoly-interface.h:83-1604 (DCRTPolyInterface<Derived, BigVec, NativeVec, PolyImpl>),
+// selected by lattice/hal/hip/lat-backend-hip.h in place of lattice/hal/lat-backend.h:39-61; the default implementation it
+// stands in for is lattice/hal/default/dcrtpoly.h:59-398.  pke / binfhe sources are unchanged.
+//
+// Data model.  A tower lives EITHER in device memory as uint64_t[nLimbs][N] (one allocation, the layout of include/fhe_hip.h)
+// OR in a host mirror, an object of the reference's own DCRTPolyImpl (a std::vector<PolyImpl<NativeVector>>), or in both:
+//   * the hot members run as kernels of libfhe_hip.so on the device copy: SwitchFormat, + - * (tower x tower), Negate,
+//     Times(vector<NativeInteger>) / TimesNoCheck / *= NativeInteger, AutomorphismTransform, ApproxSwitchCRTBasis,
+//     ApproxModUp, ApproxModDown, SwitchCRTBasis, DropLastElementAndScale, DropLastElement(s), CloneTowers, and the
+//     "ModRaise" constructor from one NativePoly; their results stay on the device;
+//   * GetAllElements() / GetElementAtIndex() / operator[] hand out the host mirror, which is filled from the device on
+//     demand (lazily, once); mutable access and every member not listed above run on the mirror with the reference's own
+//     code (DCRTPolyImpl is a member, not a copy of its source) and drop the device copy;
+//   * the (params, format) pair always lives in the mirror object, also while its limbs are empty.
+// The table arguments of the CRT members are the reference's own (CryptoParametersRNS getters): conversion plans are
+// built from them with fhe_conv_create_custom and cached by content.  Everything that the device library cannot take
+// (ring outside 2^4..2^17, a modulus >= 2^60 or != 1 mod 2N, a missing root of unity, BGV's t > 0 in ApproxModDown ...)
+// falls back to the mirror, so behaviour — including the exceptions thrown — is the default backend's.
+// Without a usable device (hiprt::Available() == false) the class IS the default backend with one indirection.
+#ifndef LBCRYPTO_INC_LATTICE_HAL_HIP_DCRTPOLY_HIP_H
+#define LBCRYPTO_INC_LATTICE_HAL_HIP_DCRTPOLY_HIP_H
+
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "lattice/hal/dcrtpoly-interface.h"
+#include "lattice/hal/default/dcrtpoly.h"
+#include "lattice/hal/hip/hip-runtime.h"
+
+namespace lbcrypto {
+
+template <typename VecType>
+class DCRTPolyHipImpl final : public DCRTPolyInterface<DCRTPolyHipImpl<VecType>, VecType, NativeVector, PolyImpl> {
+public:
+    using Vector                = VecType;
+    using Integer               = typename VecType::Integer;
+    using Params                = ILDCRTParams<Integer>;
+    using PolyType              = PolyImpl<NativeVector>;
+    using PolyLargeType         = PolyImpl<VecType>;
+    using DCRTPolyType          = DCRTPolyHipImpl<VecType>;
+    using HostType              = DCRTPolyImpl<VecType>;  // the reference's default implementation = the host mirror
+    using DCRTPolyInterfaceType = DCRTPolyInterface<DCRTPolyHipImpl<VecType>, VecType, NativeVector, PolyImpl>;
+    using Precomputations       = typename DCRTPolyInterfaceType::CRTBasisExtensionPrecomputations;
+    using DggType               = typename DCRTPolyInterfaceType::DggType;
+    using DugType               = typename DCRTPolyInterfaceType::DugType;
+    using TugType               = typename DCRTPolyInterfaceType::TugType;
+    using BugType               = typename DCRTPolyInterfaceType::BugType;
+
+    static_assert(sizeof(NativeInteger) == sizeof(uint64_t), "a NativeVector is a flat array of 64-bit residues");
+
+    // ---------------------------------------------------------------------------------------------------------------
+    // construction / assignment (dcrtpoly.h:75-132): values are produced on the host; they move to the device when the
+    // first device member touches the object
+    // ---------------------------------------------------------------------------------------------------------------
+    DCRTPolyHipImpl() = default;
+    DCRTPolyHipImpl(const DCRTPolyType& e) noexcept {
+        CopyFrom(e);
+    }
+    DCRTPolyType& operator=(const DCRTPolyType& rhs) noexcept override {
+        if (this != &rhs)
+            CopyFrom(rhs);
+        return *this;
+    }
+    DCRTPolyHipImpl(DCRTPolyType&& e) noexcept
+        : m_h{std::move(e.m_h)}, m_d{std::move(e.m_d)}, m_hostValid{e.m_hostValid} {}
+    DCRTPolyType& operator=(DCRTPolyType&& rhs) noexcept override {
+        m_h         = std::move(rhs.m_h);
+        m_d         = std::move(rhs.m_d);
+        m_hostValid = rhs.m_hostValid;
+        return *this;
+    }
+    explicit DCRTPolyHipImpl(HostType&& h) noexcept : m_h{std::move(h)} {}
+    explicit DCRTPolyHipImpl(const HostType& h) : m_h{h} {}
+
+    DCRTPolyHipImpl(const PolyLargeType& e, const std::shared_ptr<Params>& params) noexcept : m_h{e, params} {}
+    DCRTPolyType& operator=(const PolyLargeType& rhs) noexcept {
+        Hm() = rhs;
+        return *this;
+    }
+    // the "ModRaise" constructor (dcrtpoly-impl.h:87-93): one polynomial modulo q_0 lifted, centred, into every limb
+    DCRTPolyHipImpl(const PolyType& e, const std::shared_ptr<Params>& params) noexcept {
+        if (!ModRaiseOnDevice(e, params))
+            m_h = HostType(e, params);
+    }
+    DCRTPolyType& operator=(const PolyType& rhs) noexcept {
+        Hm() = rhs;
+        return *this;
+    }
+    explicit DCRTPolyHipImpl(const std::vector<PolyType>& elements) : m_h{elements} {}
+    DCRTPolyHipImpl(const std::shared_ptr<Params>& params, Format format = Format::EVALUATION,
+                    bool initializeElementToZero = false) noexcept
+        : m_h{params, format, initializeElementToZero} {}
+    DCRTPolyHipImpl(const DggType& dgg, const std::shared_ptr<Params>& p, Format f = Format::EVALUATION) : m_h{dgg, p, f} {}
+    DCRTPolyHipImpl(const BugType& bug, const std::shared_ptr<Params>& p, Format f = Format::EVALUATION) : m_h{bug, p, f} {}
+    DCRTPolyHipImpl(const TugType& tug, const std::shared_ptr<Params>& p, Format f = Format::EVALUATION, uint32_t h = 0)
+        : m_h{tug, p, f, h} {}
+    DCRTPolyHipImpl(DugType& dug, const std::shared_ptr<Params>& p, Format f = Format::EVALUATION) : m_h{dug, p, f} {}
+
+    DCRTPolyType& operator=(std::initializer_list<uint64_t> rhs) noexcept override {
+        Hm() = rhs;
+        return *this;
+    }
+    DCRTPolyType& operator=(uint64_t val) noexcept {
+        Hm() = val;
+        return *this;
+    }
+    DCRTPolyType& operator=(const std::vector<int64_t>& rhs) noexcept {
+        Hm() = rhs;
+        return *this;
+    }
+    DCRTPolyType& operator=(const std::vector<int32_t>& rhs) noexcept {
+        Hm() = rhs;
+        return *this;
+    }
+    DCRTPolyType& operator=(std::initializer_list<std::string> rhs) noexcept {
+        Hm() = rhs;
+        return *this;
+    }
+
+    DCRTPolyType CloneWithNoise(const DiscreteGaussianGeneratorImpl<VecType>& dgg, Format format) const override {
+        return Wrap(Hc().CloneWithNoise(dgg, format));
+    }
+    // dcrtpoly-impl.h:207-214
+    DCRTPolyType CloneTowers(uint32_t startTower, uint32_t endTower) const {
+        if (m_d && !m_hostValid && endTower < NumLimbs() && startTower <= endTower) {
+            const auto& P = m_h.GetParams();
+            auto params   = std::make_shared<Params>(P->GetCyclotomicOrder(), P->GetParamPartition(startTower, endTower));
+            const size_t N = P->GetRingDimension(), n = endTower - startTower + 1;
+            auto d         = hiprt::Alloc(n * N);
+            hiprt::Check(hiprt::api().d2d(AnyCtx(P), d->p, m_d->p + (size_t)startTower * N, n * N * 8, nullptr), "CloneTowers");
+            hiprt::CountDevice();
+            return FromDevice(params, m_h.GetFormat(), std::move(d));
+        }
+        return Wrap(Hc().CloneTowers(startTower, endTower));
+    }
+
+    bool operator==(const DCRTPolyType& rhs) const override {
+        return Hc() == rhs.Hc();
+    }
+
+    // ---------------------------------------------------------------------------------------------------------------
+    // tower arithmetic (dcrtpoly.h:131-189, dcrtpoly-impl.h:347-408, 582-620)
+    // ---------------------------------------------------------------------------------------------------------------
+    DCRTPolyType& operator+=(const DCRTPolyType& rhs) override {
+        if (!BinaryInPlace(rhs, hiprt::api().add, false))
+            Hm() += rhs.Hc();
+        return *this;
+    }
+    DCRTPolyType& operator+=(const Integer& rhs) override {
+        Hm() += rhs;
+        return *this;
+    }
+    DCRTPolyType& operator+=(const NativeInteger& rhs) override {
+        Hm() += rhs;
+        return *this;
+    }
+    DCRTPolyType& operator-=(const DCRTPolyType& rhs) override {
+        if (!BinaryInPlace(rhs, hiprt::api().sub, false))
+            Hm() -= rhs.Hc();
+        return *this;
+    }
+    DCRTPolyType& operator-=(const Integer& rhs) override {
+        Hm() -= rhs;
+        return *this;
+    }
+    DCRTPolyType& operator-=(const NativeInteger& rhs) override {
+        Hm() -= rhs;
+        return *this;
+    }
+    DCRTPolyType& operator*=(const DCRTPolyType& rhs) override {
+        if (!BinaryInPlace(rhs, hiprt::api().mul, false))
+            Hm() *= rhs.Hc();
+        return *this;
+    }
+    DCRTPolyType& operator*=(const Integer& rhs) override {
+        Hm() *= rhs;
+        return *this;
+    }
+    DCRTPolyType& operator*=(const NativeInteger& rhs) override {
+        std::vector<NativeInteger> c(NumLimbs(), rhs);
+        if (!TimesConstInPlace(c))
+            Hm() *= rhs;
+        return *this;
+    }
+
+    DCRTPolyType Negate() const override {
+        hiprt::Resolved r;
+        if (OnDevice(&r)) {
+            auto d = hiprt::Alloc(Words());
+            hiprt::Check(hiprt::api().neg(r.ctx, d->p, m_d->p, r.idx[0].data(), NumLimbs(), 1, nullptr), "Negate");
+            hiprt::CountDevice();
+            return FromDevice(m_h.GetParams(), m_h.GetFormat(), std::move(d));
+        }
+        return Wrap(Hc().Negate());
+    }
+    DCRTPolyType operator-() const override {
+        return DCRTPolyType(m_h.GetParams(), m_h.GetFormat(), true) -= *this;
+    }
+
+    std::vector<DCRTPolyType> BaseDecompose(usint baseBits, bool evalModeAnswer) const override {
+        return WrapAll(Hc().BaseDecompose(baseBits, evalModeAnswer));
+    }
+    std::vector<DCRTPolyType> PowersOfBase(usint baseBits) const override {
+        return WrapAll(Hc().PowersOfBase(baseBits));
+    }
+    std::vector<DCRTPolyType> CRTDecompose(uint32_t baseBits) const {
+        return WrapAll(Hc().CRTDecompose(baseBits));
+    }
+
+    // dcrtpoly-impl.h:314-333 -> poly-impl.h:310-376 (EVALUATION: gather through PrecomputeAutoMap, COEFFICIENT: signed permutation)
+    DCRTPolyType AutomorphismTransform(uint32_t i) const override {
+        hiprt::Resolved r;
+        if ((i & 1u) && OnDevice(&r)) {
+            auto d = hiprt::Alloc(Words());
+            hiprt::Check(hiprt::api().automorph(r.ctx, d->p, m_d->p, i, m_h.GetFormat() == Format::EVALUATION ? 1 : 0,
+                                                r.idx[0].data(), NumLimbs(), 1, nullptr),
+                         "AutomorphismTransform");
+            hiprt::CountDevice();
+            return FromDevice(m_h.GetParams(), m_h.GetFormat(), std::move(d));
+        }
+        return Wrap(Hc().AutomorphismTransform(i));
+    }
+    DCRTPolyType AutomorphismTransform(uint32_t i, const std::vector<uint32_t>& vec) const override {
+        // `vec` is PrecomputeAutoMap(N, i) in every caller (nbtheory2.cpp:264-275); the kernel computes that map on the fly.
+        // The whole table is compared once per (N, i) would cost more than the transform; its ends and middle are checked.
+        const uint32_t N = m_h.GetParams()->GetRingDimension();
+        if (m_h.GetFormat() == Format::EVALUATION && vec.size() == N && AutoMapLooksRight(N, i, vec))
+            return AutomorphismTransform(i);
+        return Wrap(Hc().AutomorphismTransform(i, vec));
+    }
+
+    DCRTPolyType Plus(const Integer& rhs) const override {
+        return Wrap(Hc().Plus(rhs));
+    }
+    DCRTPolyType Plus(const std::vector<Integer>& rhs) const {
+        return Wrap(Hc().Plus(rhs));
+    }
+    DCRTPolyType Plus(const DCRTPolyType& rhs) const override {
+        DCRTPolyType out;
+        if (Binary(rhs, hiprt::api().add, false, &out))
+            return out;
+        return Wrap(Hc().Plus(rhs.Hc()));
+    }
+    DCRTPolyType Minus(const DCRTPolyType& rhs) const override {
+        DCRTPolyType out;
+        if (Binary(rhs, hiprt::api().sub, false, &out))
+            return out;
+        return Wrap(Hc().Minus(rhs.Hc()));
+    }
+    DCRTPolyType Minus(const Integer& rhs) const override {
+        return Wrap(Hc().Minus(rhs));
+    }
+    DCRTPolyType Minus(const std::vector<Integer>& rhs) const {
+        return Wrap(Hc().Minus(rhs));
+    }
+    DCRTPolyType Times(const DCRTPolyType& rhs) const override {
+        DCRTPolyType out;
+        if (Binary(rhs, hiprt::api().mul, true, &out))
+            return out;
+        return Wrap(Hc().Times(rhs.Hc()));
+    }
+    DCRTPolyType Times(const Integer& rhs) const override {
+        return Wrap(Hc().Times(rhs));
+    }
+    DCRTPolyType Times(const std::vector<Integer>& rhs) const {
+        return Wrap(Hc().Times(rhs));
+    }
+    DCRTPolyType Times(NativeInteger::SignedNativeInt rhs) const override {
+        return Wrap(Hc().Times(rhs));
+    }
+#if NATIVEINT != 64
+    DCRTPolyType Times(int64_t rhs) const {
+        return Times(static_cast<NativeInteger::SignedNativeInt>(rhs));
+    }
+#endif
+    // dcrtpoly-impl.h:582-601
+    DCRTPolyType Times(const std::vector<NativeInteger>& rhs) const {
+        if (rhs.size() == NumLimbs()) {
+            DCRTPolyType out(*this);
+            if (out.TimesConstInPlace(rhs))
+                return out;
+        }
+        return Wrap(Hc().Times(rhs));
+    }
+    DCRTPolyType TimesNoCheck(const std::vector<NativeInteger>& rhs) const {
+        if (rhs.size() >= NumLimbs()) {
+            DCRTPolyType out(*this);
+            if (out.TimesConstInPlace(rhs))
+                return out;
+        }
+        return Wrap(Hc().TimesNoCheck(rhs));
+    }
+
+    DCRTPolyType MultiplicativeInverse() const override {
+        return Wrap(Hc().MultiplicativeInverse());
+    }
+    bool InverseExists() const override {
+        return Hc().InverseExists();
+    }
+    bool IsEmpty() const override {
+        return (m_d && !m_hostValid) ? false : m_h.IsEmpty();
+    }
+
+    void SetValuesToZero() override {
+        Hm().SetValuesToZero();
+    }
+    void AddILElementOne() override {
+        Hm().AddILElementOne();
+    }
+    // dcrtpoly-impl.h:669-689: the device copy keeps its leading limbs, the mirror object keeps the metadata in step
+    void DropLastElement() override {
+        std::lock_guard<std::mutex> lk(m_lock.m);
+        m_h.DropLastElement();
+    }
+    void DropLastElements(size_t i) override {
+        std::lock_guard<std::mutex> lk(m_lock.m);
+        m_h.DropLastElements(i);
+    }
+    // dcrtpoly-impl.h:693-712 (CKKS rescale)
+    void DropLastElementAndScale(const std::vector<NativeInteger>& QlQlInvModqlDivqlModq,
+                                 const std::vector<NativeInteger>& qlInvModq) override {
+        if (!RescaleOnDevice(QlQlInvModqlDivqlModq, qlInvModq))
+            Hm().DropLastElementAndScale(QlQlInvModqlDivqlModq, qlInvModq);
+    }
+    void ModReduce(const NativeInteger& t, const std::vector<NativeInteger>& tModqPrecon, const NativeInteger& negtInvModq,
+                   const NativeInteger& negtInvModqPrecon, const std::vector<NativeInteger>& qlInvModq,
+                   const std::vector<NativeInteger>& qlInvModqPrecon) override {
+        Hm().ModReduce(t, tModqPrecon, negtInvModq, negtInvModqPrecon, qlInvModq, qlInvModqPrecon);
+    }
+
+    PolyLargeType CRTInterpolate() const override {
+        return Hc().CRTInterpolate();
+    }
+    PolyType DecryptionCRTInterpolate(PlaintextModulus ptm) const override {
+        return Hc().DecryptionCRTInterpolate(ptm);
+    }
+    PolyType ToNativePoly() const override {
+        return Hc().ToNativePoly();
+    }
+    PolyLargeType CRTInterpolateIndex(usint i) const override {
+        return Hc().CRTInterpolateIndex(i);
+    }
+    Integer GetWorkingModulus() const override {
+        return m_h.GetWorkingModulus();
+    }
+    void SetValuesModSwitch(const DCRTPolyType& element, const NativeInteger& modulus) override {
+        Hm().SetValuesModSwitch(element.Hc(), modulus);
+    }
+    std::shared_ptr<Params> GetExtendedCRTBasis(const std::shared_ptr<Params>& paramsP) const override {
+        return m_h.GetExtendedCRTBasis(paramsP);
+    }
+    void TimesQovert(const std::shared_ptr<Params>& paramsQ, const std::vector<NativeInteger>& tInvModq, const NativeInteger& t,
+                     const NativeInteger& NegQModt, const NativeInteger& NegQModtPrecon) override {
+        Hm().TimesQovert(paramsQ, tInvModq, t, NegQModt, NegQModtPrecon);
+    }
+
+    // ---------------------------------------------------------------------------------------------------------------
+    // CRT basis conversions (dcrtpoly-impl.h:888-1085)
+    // ---------------------------------------------------------------------------------------------------------------
+    DCRTPolyType ApproxSwitchCRTBasis(const std::shared_ptr<Params>& paramsQ, const std::shared_ptr<Params>& paramsP,
+                                      const std::vector<NativeInteger>& QHatInvModq,
+                                      const std::vector<NativeInteger>& QHatInvModqPrecon,
+                                      const std::vector<std::vector<NativeInteger>>& QHatModp,
+                                      const std::vector<DoubleNativeInt>& modpBarrettMu) const override {
+        DCRTPolyType out;
+        if (SwitchBasisOnDevice(paramsQ, paramsP, QHatInvModq, QHatModp, nullptr, nullptr, &out))
+            return out;
+        return Wrap(Hc().ApproxSwitchCRTBasis(paramsQ, paramsP, QHatInvModq, QHatInvModqPrecon, QHatModp, modpBarrettMu));
+    }
+    void ApproxModUp(const std::shared_ptr<Params>& paramsQ, const std::shared_ptr<Params>& paramsP,
+                     const std::shared_ptr<Params>& paramsQP, const std::vector<NativeInteger>& QHatInvModq,
+                     const std::vector<NativeInteger>& QHatInvModqPrecon,
+                     const std::vector<std::vector<NativeInteger>>& QHatModp,
+                     const std::vector<DoubleNativeInt>& modpBarrettMu) override {
+        if (!ModUpOnDevice(paramsQ, paramsP, paramsQP, QHatInvModq, QHatModp))
+            Hm().ApproxModUp(paramsQ, paramsP, paramsQP, QHatInvModq, QHatInvModqPrecon, QHatModp, modpBarrettMu);
+    }
+    DCRTPolyType ApproxModDown(const std::shared_ptr<Params>& paramsQ, const std::shared_ptr<Params>& paramsP,
+                               const std::vector<NativeInteger>& PInvModq, const std::vector<NativeInteger>& PInvModqPrecon,
+                               const std::vector<NativeInteger>& PHatInvModp,
+                               const std::vector<NativeInteger>& PHatInvModpPrecon,
+                               const std::vector<std::vector<NativeInteger>>& PHatModq,
+                               const std::vector<DoubleNativeInt>& modqBarrettMu, const std::vector<NativeInteger>& tInvModp,
+                               const std::vector<NativeInteger>& tInvModpPrecon, const NativeInteger& t,
+                               const std::vector<NativeInteger>& tModqPrecon) const override {
+        DCRTPolyType out;
+        if (t == NativeInteger(0) && ModDownOnDevice(paramsQ, paramsP, PInvModq, PHatInvModp, PHatModq, &out))
+            return out;
+        return Wrap(Hc().ApproxModDown(paramsQ, paramsP, PInvModq, PInvModqPrecon, PHatInvModp, PHatInvModpPrecon, PHatModq,
+                                       modqBarrettMu, tInvModp, tInvModpPrecon, t, tModqPrecon));
+    }
+    DCRTPolyType SwitchCRTBasis(const std::shared_ptr<Params>& paramsP, const std::vector<NativeInteger>& QHatInvModq,
+                                const std::vector<NativeInteger>& QHatInvModqPrecon,
+                                const std::vector<std::vector<NativeInteger>>& QHatModp,
+                                const std::vector<std::vector<NativeInteger>>& alphaQModp,
+                                const std::vector<DoubleNativeInt>& modpBarrettMu,
+                                const std::vector<double>& qInv) const override {
+        DCRTPolyType out;
+        // (:1008-1085 index QHatModp as [j][i]: transposed with respect to ApproxSwitchCRTBasis)
+        if (SwitchBasisOnDevice(m_h.GetParams(), paramsP, QHatInvModq, QHatModp, &alphaQModp, &qInv, &out, /*transposed=*/true))
+            return out;
+        return Wrap(Hc().SwitchCRTBasis(paramsP, QHatInvModq, QHatInvModqPrecon, QHatModp, alphaQModp, modpBarrettMu, qInv));
+    }
+    void ExpandCRTBasis(const std::shared_ptr<Params>& paramsQP, const std::shared_ptr<Params>& paramsP,
+                        const std::vector<NativeInteger>& QHatInvModq, const std::vector<NativeInteger>& QHatInvModqPrecon,
+                        const std::vector<std::vector<NativeInteger>>& QHatModp,
+                        const std::vector<std::vector<NativeInteger>>& alphaQModp,
+                        const std::vector<DoubleNativeInt>& modpBarrettMu, const std::vector<double>& qInv,
+                        Format resultFormat) override {
+        Hm().ExpandCRTBasis(paramsQP, paramsP, QHatInvModq, QHatInvModqPrecon, QHatModp, alphaQModp, modpBarrettMu, qInv,
+                            resultFormat);
+    }
+    void ExpandCRTBasisReverseOrder(const std::shared_ptr<Params>& paramsQP, const std::shared_ptr<Params>& paramsP,
+                                    const std::vector<NativeInteger>& QHatInvModq,
+                                    const std::vector<NativeInteger>& QHatInvModqPrecon,
+                                    const std::vector<std::vector<NativeInteger>>& QHatModp,
+                                    const std::vector<std::vector<NativeInteger>>& alphaQModp,
+                                    const std::vector<DoubleNativeInt>& modpBarrettMu, const std::vector<double>& qInv,
+                                    Format resultFormat) override {
+        Hm().ExpandCRTBasisReverseOrder(paramsQP, paramsP, QHatInvModq, QHatInvModqPrecon, QHatModp, alphaQModp, modpBarrettMu,
+                                        qInv, resultFormat);
+    }
+    void FastExpandCRTBasisPloverQ(const Precomputations& pre) override {
+        // (the struct is the interface's nested type; the mirror's is the same layout under its own name)
+        typename HostType::Precomputations hp{pre.paramsQlPl,        pre.paramsPl,           pre.paramsQl,
+                                              pre.mPlQHatInvModq,    pre.mPlQHatInvModqPrecon, pre.qInvModp,
+                                              pre.modpBarrettMu,     pre.PlHatInvModp,       pre.PlHatInvModpPrecon,
+                                              pre.PlHatModq,         pre.alphaPlModq,        pre.modqBarrettMu,
+                                              pre.pInv};
+        Hm().FastExpandCRTBasisPloverQ(hp);
+    }
+    void ExpandCRTBasisQlHat(const std::shared_ptr<Params>& paramsQ, const std::vector<NativeInteger>& QlHatModq,
+                             const std::vector<NativeInteger>& QlHatModqPrecon, const usint sizeQ) override {
+        Hm().ExpandCRTBasisQlHat(paramsQ, QlHatModq, QlHatModqPrecon, sizeQ);
+    }
+
+    PolyType ScaleAndRound(const NativeInteger& t, const std::vector<NativeInteger>& tQHatInvModqDivqModt,
+                           const std::vector<NativeInteger>& tQHatInvModqDivqModtPrecon,
+                           const std::vector<NativeInteger>& tQHatInvModqBDivqModt,
+                           const std::vector<NativeInteger>& tQHatInvModqBDivqModtPrecon,
+                           const std::vector<double>& tQHatInvModqDivqFrac,
+                           const std::vector<double>& tQHatInvModqBDivqFrac) const override {
+        return Hc().ScaleAndRound(t, tQHatInvModqDivqModt, tQHatInvModqDivqModtPrecon, tQHatInvModqBDivqModt,
+                                  tQHatInvModqBDivqModtPrecon, tQHatInvModqDivqFrac, tQHatInvModqBDivqFrac);
+    }
+    DCRTPolyType ApproxScaleAndRound(const std::shared_ptr<Params>& paramsP,
+                                     const std::vector<std::vector<NativeInteger>>& tPSHatInvModsDivsModp,
+                                     const std::vector<DoubleNativeInt>& modpBarretMu) const override {
+        return Wrap(Hc().ApproxScaleAndRound(paramsP, tPSHatInvModsDivsModp, modpBarretMu));
+    }
+    DCRTPolyType ScaleAndRound(const std::shared_ptr<Params>& paramsOutput,
+                               const std::vector<std::vector<NativeInteger>>& tOSHatInvModsDivsModo,
+                               const std::vector<double>& tOSHatInvModsDivsFrac,
+                               const std::vector<DoubleNativeInt>& modoBarretMu) const override {
+        return Wrap(Hc().ScaleAndRound(paramsOutput, tOSHatInvModsDivsModo, tOSHatInvModsDivsFrac, modoBarretMu));
+    }
+    PolyType ScaleAndRound(const std::vector<NativeInteger>& moduliQ, const NativeInteger& t, const NativeInteger& tgamma,
+                           const std::vector<NativeInteger>& tgammaQHatModq,
+                           const std::vector<NativeInteger>& tgammaQHatModqPrecon,
+                           const std::vector<NativeInteger>& negInvqModtgamma,
+                           const std::vector<NativeInteger>& negInvqModtgammaPrecon) const override {
+        return Hc().ScaleAndRound(moduliQ, t, tgamma, tgammaQHatModq, tgammaQHatModqPrecon, negInvqModtgamma,
+                                  negInvqModtgammaPrecon);
+    }
+    void ScaleAndRoundPOverQ(const std::shared_ptr<Params>& paramsQ, const std::vector<NativeInteger>& pInvModq) override {
+        Hm().ScaleAndRoundPOverQ(paramsQ, pInvModq);
+    }
+    void FastBaseConvqToBskMontgomery(
+        const std::shared_ptr<Params>& paramsQBsk, const std::vector<NativeInteger>& moduliQ,
+        const std::vector<NativeInteger>& moduliBsk, const std::vector<DoubleNativeInt>& modbskBarrettMu,
+        const std::vector<NativeInteger>& mtildeQHatInvModq, const std::vector<NativeInteger>& mtildeQHatInvModqPrecon,
+        const std::vector<std::vector<NativeInteger>>& QHatModbsk, const std::vector<uint64_t>& QHatModmtilde,
+        const std::vector<NativeInteger>& QModbsk, const std::vector<NativeInteger>& QModbskPrecon,
+        const uint64_t& negQInvModmtilde, const std::vector<NativeInteger>& mtildeInvModbsk,
+        const std::vector<NativeInteger>& mtildeInvModbskPrecon) override {
+        Hm().FastBaseConvqToBskMontgomery(paramsQBsk, moduliQ, moduliBsk, modbskBarrettMu, mtildeQHatInvModq, mtildeQHatInvModqPrecon,
+                                          QHatModbsk, QHatModmtilde, QModbsk, QModbskPrecon, negQInvModmtilde, mtildeInvModbsk,
+                                          mtildeInvModbskPrecon);
+    }
+    void FastRNSFloorq(const NativeInteger& t, const std::vector<NativeInteger>& moduliQ,
+                       const std::vector<NativeInteger>& moduliBsk, const std::vector<DoubleNativeInt>& modbskBarrettMu,
+                       const std::vector<NativeInteger>& tQHatInvModq, const std::vector<NativeInteger>& tQHatInvModqPrecon,
+                       const std::vector<std::vector<NativeInteger>>& QHatModbsk,
+                       const std::vector<std::vector<NativeInteger>>& qInvModbsk, const std::vector<NativeInteger>& tQInvModbsk,
+                       const std::vector<NativeInteger>& tQInvModbskPrecon) override {
+        Hm().FastRNSFloorq(t, moduliQ, moduliBsk, modbskBarrettMu, tQHatInvModq, tQHatInvModqPrecon, QHatModbsk, qInvModbsk,
+                           tQInvModbsk, tQInvModbskPrecon);
+    }
+    void FastBaseConvSK(const std::shared_ptr<Params>& paramsQ, const std::vector<DoubleNativeInt>& modqBarrettMu,
+                        const std::vector<NativeInteger>& moduliBsk, const std::vector<DoubleNativeInt>& modbskBarrettMu,
+                        const std::vector<NativeInteger>& BHatInvModb, const std::vector<NativeInteger>& BHatInvModbPrecon,
+                        const std::vector<NativeInteger>& BHatModmsk, const NativeInteger& BInvModmsk,
+                        const NativeInteger& BInvModmskPrecon, const std::vector<std::vector<NativeInteger>>& BHatModq,
+                        const std::vector<NativeInteger>& BModq, const std::vector<NativeInteger>& BModqPrecon) override {
+        Hm().FastBaseConvSK(paramsQ, modqBarrettMu, moduliBsk, modbskBarrettMu, BHatInvModb, BHatInvModbPrecon, BHatModmsk,
+                            BInvModmsk, BInvModmskPrecon, BHatModq, BModq, BModqPrecon);
+    }
+
+    // dcrtpoly-impl.h:1932-1940 -> ChineseRemainderTransformFTT (transformnat-impl.h:303-374, 512-625)
+    void SwitchFormat(uint32_t thread_limit = 0) override {
+        hiprt::Resolved r;
+        if (OnDevice(&r)) {
+            const bool toCoeff = m_h.GetFormat() == Format::EVALUATION;
+            auto f             = toCoeff ? hiprt::api().ntt_inv : hiprt::api().ntt_fwd;
+            hiprt::Check(f(r.ctx, m_d->p, r.idx[0].data(), NumLimbs(), 1, nullptr), "SwitchFormat");
+            hiprt::CountDevice();
+            DeviceIsNewer(toCoeff ? Format::COEFFICIENT : Format::EVALUATION);
+            return;
+        }
+        Hm().SwitchFormat(thread_limit);
+    }
+    void SwitchModulusAtIndex(size_t index, const Integer& modulus, const Integer& rootOfUnity) override {
+        Hm().SwitchModulusAtIndex(index, modulus, rootOfUnity);
+    }
+
+    template <class Archive>
+    void save(Archive& ar, std::uint32_t const version) const {
+        Hc().save(ar, version);
+    }
+    template <class Archive>
+    void load(Archive& ar, std::uint32_t const version) {
+        m_d.reset();
+        m_hostValid = true;
+        m_h.load(ar, version);
+    }
+    static const std::string GetElementName() {
+        return "DCRTPolyImpl";
+    }
+    std::string SerializedObjectName() const override {
+        return "DCRTPoly";
+    }
+    static uint32_t SerializedVersion() {
+        return 1;
+    }
+
+    inline Format GetFormat() const final {
+        return m_h.GetFormat();
+    }
+    void OverrideFormat(const Format f) final {
+        m_h.OverrideFormat(f);
+    }
+    inline const std::shared_ptr<Params>& GetParams() const {
+        return m_h.GetParams();
+    }
+    // the limbs as host objects: filled from the device on demand (const) / the device copy is dropped (mutable access)
+    const std::vector<PolyType>& GetAllElements() const {
+        return Hc().GetAllElements();
+    }
+    std::vector<PolyType>& GetAllElements() {
+        return Hm().GetAllElements();
+    }
+    void SetElementAtIndex(usint index, const PolyType& element) {
+        Hm().SetElementAtIndex(index, element);
+    }
+    void SetElementAtIndex(usint index, PolyType&& element) {
+        Hm().SetElementAtIndex(index, std::move(element));
+    }
+
+    // the host mirror (synchronised), for code that wants the default implementation's object
+    const HostType& Host() const {
+        return Hc();
+    }
+    // true while the authoritative copy of the words is the device buffer
+    bool IsDeviceResident() const {
+        return m_d && !m_hostValid;
+    }
+
+private:
+    struct Lock {  // a mutex that does not travel with copies
+        std::mutex m;
+        Lock() = default;
+        Lock(const Lock&) {}
+        Lock& operator=(const Lock&) {
+            return *this;
+        }
+    };
+
+    mutable HostType m_h;           // metadata always; words valid iff m_hostValid
+    mutable hiprt::Buf m_d;         // device words [nLimbs][N] (may hold more rows than nLimbs after DropLastElement)
+    mutable bool m_hostValid{true};
+    mutable Lock m_lock;
+
+    uint32_t NumLimbs() const {
+        return (uint32_t)m_h.GetAllElements().size();
+    }
+    size_t Words() const {
+        return (size_t)NumLimbs() * m_h.GetParams()->GetRingDimension();
+    }
+    static DCRTPolyType Wrap(HostType&& h) {
+        hiprt::CountHost();
+        return DCRTPolyType(std::move(h));
+    }
+    static std::vector<DCRTPolyType> WrapAll(std::vector<HostType>&& v) {
+        std::vector<DCRTPolyType> r;
+        r.reserve(v.size());
+        for (auto& h : v)
+            r.emplace_back(std::move(h));
+        return r;
+    }
+    static DCRTPolyType FromDevice(const std::shared_ptr<Params>& p, Format f, hiprt::Buf d) {
+        DCRTPolyType r;
+        r.m_h         = HostType(p, f, false);
+        r.m_d         = std::move(d);
+        r.m_hostValid = false;
+        return r;
+    }
+    static void LimbsOf(const std::shared_ptr<Params>& p, std::vector<uint64_t>& q, std::vector<uint64_t>& psi) {
+        const auto& v = p->GetParams();
+        q.resize(v.size());
+        psi.resize(v.size());
+        for (size_t i = 0; i < v.size(); ++i) {
+            q[i]   = v[i]->GetModulus().template ConvertToInt<uint64_t>();
+            psi[i] = v[i]->GetRootOfUnity().template ConvertToInt<uint64_t>();
+        }
+    }
+    // resolves the context limbs of several parameter sets at once (one lock, one context generation)
+    static bool ResolveSets(uint32_t N, const std::vector<std::shared_ptr<Params>>& sets, hiprt::Resolved* r) {
+        if (!hiprt::Available())
+            return false;
+        std::vector<std::vector<uint64_t>> q(sets.size()), psi(sets.size());
+        std::vector<hiprt::LimbSet> ls(sets.size());
+        for (size_t i = 0; i < sets.size(); ++i) {
+            LimbsOf(sets[i], q[i], psi[i]);
+            ls[i] = hiprt::LimbSet{q[i].data(), psi[i].data(), (uint32_t)q[i].size()};
+        }
+        return hiprt::Resolve(N, ls, r);
+    }
+
+    // ---- the two copies ---------------------------------------------------------------------------------------------
+    void CopyFrom(const DCRTPolyType& e) {
+        std::lock_guard<std::mutex> lk(e.m_lock.m);
+        m_h         = e.m_h;
+        m_hostValid = e.m_hostValid;
+        m_d.reset();
+        if (e.m_d && !e.m_hostValid) {  // device-resident source: device-to-device copy of its limbs
+            const size_t w = (size_t)e.m_h.GetAllElements().size() * e.m_h.GetParams()->GetRingDimension();
+            m_d            = hiprt::Alloc(w);
+            hiprt::Check(hiprt::api().d2d(AnyCtx(e.m_h.GetParams()), m_d->p, e.m_d->p, w * 8, nullptr), "DCRTPoly copy");
+        }
+    }
+    static fhe_ctx* AnyCtx(const std::shared_ptr<Params>& p) {
+        hiprt::Resolved r;
+        ResolveSets(p->GetRingDimension(), {p}, &r);
+        return r.ctx;
+    }
+    // host words valid (fills the mirror from the device if needed)
+    void SyncHost() const {
+        std::lock_guard<std::mutex> lk(m_lock.m);
+        if (m_hostValid)
+            return;
+        const auto P     = m_h.GetParams();
+        const Format f   = m_h.GetFormat();
+        const uint32_t L = (uint32_t)m_h.GetAllElements().size();
+        const size_t N   = P->GetRingDimension();
+        HostType h(P, f, false);
+        if (L < P->GetParams().size())  // (cannot happen: DropLastElement re-derives the params)
+            h.DropLastElements(P->GetParams().size() - L);
+        std::vector<uint64_t> stage((size_t)L * N);
+        fhe_ctx* c = AnyCtx(P);
+        hiprt::Check(hiprt::api().d2h(c, stage.data(), m_d->p, stage.size() * 8, nullptr), "DCRTPoly device -> host");
+        hiprt::Check(hiprt::api().sync(c, nullptr), "DCRTPoly device -> host");
+        hiprt::CountD2H(stage.size() * 8);
+        for (uint32_t i = 0; i < L; ++i) {
+            NativeVector v(N, P->GetParams()[i]->GetModulus());
+            std::memcpy(&v[0], stage.data() + (size_t)i * N, N * 8);
+            PolyType poly(P->GetParams()[i], f, false);
+            poly.SetValues(std::move(v), f);
+            h.SetElementAtIndex(i, std::move(poly));
+        }
+        m_h         = std::move(h);
+        m_hostValid = true;
+    }
+    const HostType& Hc() const {
+        SyncHost();
+        return m_h;
+    }
+    HostType& Hm() {  // mutable host access: the device copy is stale afterwards
+        SyncHost();
+        m_d.reset();
+        hiprt::CountHost();
+        return m_h;
+    }
+    // device words valid (uploads the mirror if needed); r.idx[0] = context limbs of this tower
+    bool OnDevice(hiprt::Resolved* r) const {
+        const auto& P = m_h.GetParams();
+        if (!P || NumLimbs() == 0 || NumLimbs() != P->GetParams().size())
+            return false;
+        if (!ResolveSets(P->GetRingDimension(), {P}, r))
+            return false;
+        return Upload(r->ctx);
+    }
+    bool Upload(fhe_ctx* c) const {
+        std::lock_guard<std::mutex> lk(m_lock.m);
+        if (m_d)
+            return true;
+        const uint32_t L = NumLimbs();
+        const size_t N   = m_h.GetParams()->GetRingDimension();
+        for (const auto& e : m_h.GetAllElements())
+            if (e.IsEmpty() || e.GetLength() != N)
+                return false;  // an unfilled tower: leave it (and its exceptions) to the host code
+        auto d = hiprt::Alloc((size_t)L * N);
+        for (uint32_t i = 0; i < L; ++i)
+            hiprt::Check(hiprt::api().h2d(c, d->p + (size_t)i * N, &m_h.GetAllElements()[i].GetValues()[0], N * 8, nullptr),
+                         "DCRTPoly host -> device");
+        hiprt::Check(hiprt::api().sync(c, nullptr), "DCRTPoly host -> device");
+        hiprt::CountH2D((size_t)L * N * 8);
+        m_d = std::move(d);
+        return true;
+    }
+    // after a kernel wrote the device copy in place: the mirror keeps (params, format) only
+    void DeviceIsNewer(Format f) {
+        std::lock_guard<std::mutex> lk(m_lock.m);
+        auto P      = m_h.GetParams();
+        m_h         = HostType(P, f, false);
+        m_hostValid = false;
+    }
+
+    // ---- device members ---------------------------------------------------------------------------------------------
+    using BinFn = decltype(hiprt::Api::add);
+    // both towers over the same limbs in the same format (Times: EVALUATION): everything else goes to the host code
+    bool Compatible(const DCRTPolyType& rhs, bool evalOnly) const {
+        const auto &A = m_h.GetParams(), &B = rhs.m_h.GetParams();
+        if (!A || !B || A->GetRingDimension() != B->GetRingDimension() || m_h.GetFormat() != rhs.m_h.GetFormat())
+            return false;
+        if (evalOnly && m_h.GetFormat() != Format::EVALUATION)
+            return false;
+        const auto &a = A->GetParams(), &b = B->GetParams();
+        if (a.size() != b.size() || a.size() != NumLimbs() || b.size() != rhs.NumLimbs())
+            return false;
+        for (size_t i = 0; i < a.size(); ++i)
+            if (a[i]->GetModulus() != b[i]->GetModulus())
+                return false;
+        return true;
+    }
+    bool Binary(const DCRTPolyType& rhs, BinFn fn, bool evalOnly, DCRTPolyType* out) const {
+        hiprt::Resolved r;
+        if (!Compatible(rhs, evalOnly) || !OnDevice(&r) || !rhs.Upload(r.ctx))
+            return false;
+        auto d = hiprt::Alloc(Words());
+        hiprt::Check(fn(r.ctx, d->p, m_d->p, rhs.m_d->p, r.idx[0].data(), NumLimbs(), 1, nullptr), "DCRTPoly arithmetic");
+        hiprt::CountDevice();
+        *out = FromDevice(m_h.GetParams(), m_h.GetFormat(), std::move(d));
+        return true;
+    }
+    bool BinaryInPlace(const DCRTPolyType& rhs, BinFn fn, bool evalOnly) {
+        hiprt::Resolved r;
+        if (!Compatible(rhs, evalOnly) || !OnDevice(&r) || !rhs.Upload(r.ctx))
+            return false;
+        hiprt::Check(fn(r.ctx, m_d->p, m_d->p, rhs.m_d->p, r.idx[0].data(), NumLimbs(), 1, nullptr), "DCRTPoly arithmetic");
+        hiprt::CountDevice();
+        DeviceIsNewer(m_h.GetFormat());
+        return true;
+    }
+    bool TimesConstInPlace(const std::vector<NativeInteger>& c) {
+        hiprt::Resolved r;
+        if (c.size() < NumLimbs() || !OnDevice(&r))
+            return false;
+        std::vector<uint64_t> k(NumLimbs());
+        for (uint32_t i = 0; i < NumLimbs(); ++i)
+            k[i] = c[i].ConvertToInt<uint64_t>();
+        hiprt::Check(hiprt::api().mul_const(r.ctx, m_d->p, m_d->p, k.data(), r.idx[0].data(), NumLimbs(), 1, nullptr),
+                     "DCRTPoly Times(constants)");
+        hiprt::CountDevice();
+        DeviceIsNewer(m_h.GetFormat());
+        return true;
+    }
+    static bool AutoMapLooksRight(uint32_t N, uint32_t k, const std::vector<uint32_t>& vec) {
+        uint32_t logN = 0;
+        while ((1u << logN) < N)
+            ++logN;
+        auto rev = [logN](uint32_t x) {
+            uint32_t y = 0;
+            for (uint32_t b = 0; b < logN; ++b)
+                y |= ((x >> b) & 1u) << (logN - 1 - b);
+            return y;
+        };
+        const uint32_t probes[5] = {0, 1, N / 2, N - 2, N - 1};
+        for (uint32_t j : probes) {  // precomp[bitrev(j)] = bitrev(((2j+1)k mod 2N) >> 1)   (nbtheory2.cpp:264-275)
+            if (j >= N)
+                continue;
+            const uint32_t idx = (uint32_t)((((uint64_t)2 * j + 1) * k) & (2 * (uint64_t)N - 1)) >> 1;
+            if (vec[rev(j)] != rev(idx))
+                return false;
+        }
+        return (k & 1u) != 0;
+    }
+    static void Flatten(const std::vector<std::vector<NativeInteger>>& m, size_t rows, size_t cols, bool transposed,
+                        std::vector<uint64_t>& out) {
+        out.resize(rows * cols);
+        for (size_t i = 0; i < rows; ++i)
+            for (size_t j = 0; j < cols; ++j)
+                out[i * cols + j] = (transposed ? m[j][i] : m[i][j]).ConvertToInt<uint64_t>();
+    }
+    // ApproxSwitchCRTBasis (alpha == nullptr) / SwitchCRTBasis on the device; this tower over paramsQ -> *out over paramsP
+    bool SwitchBasisOnDevice(const std::shared_ptr<Params>& paramsQ, const std::shared_ptr<Params>& paramsP,
+                             const std::vector<NativeInteger>& QHatInvModq, const std::vector<std::vector<NativeInteger>>& QHatModp,
+                             const std::vector<std::vector<NativeInteger>>* alpha, const std::vector<double>* qInv,
+                             DCRTPolyType* out, bool transposed = false) const {
+        const uint32_t sizeQ = NumLimbs(), sizeP = (uint32_t)paramsP->GetParams().size();
+        if (sizeQ == 0 || sizeQ > 32 || sizeP == 0 || sizeQ != paramsQ->GetParams().size() || QHatInvModq.size() < sizeQ)
+            return false;
+        if ((transposed ? QHatModp.size() < sizeP : QHatModp.size() < sizeQ))
+            return false;
+        hiprt::Resolved r;
+        const auto& mine = m_h.GetParams();
+        if (!ResolveSets(mine->GetRingDimension(), {mine, paramsP}, &r) || !Upload(r.ctx))
+            return false;
+        std::vector<uint64_t> hi(sizeQ), hm, al;
+        for (uint32_t i = 0; i < sizeQ; ++i)
+            hi[i] = QHatInvModq[i].ConvertToInt<uint64_t>();
+        Flatten(QHatModp, sizeQ, sizeP, transposed, hm);
+        if (alpha)
+            Flatten(*alpha, sizeQ + 1, sizeP, false, al);
+        fhe_conv* cv = hiprt::ConvPlan(r.ctx, r.idx[0], r.idx[1], hi.data(), hm.data(), alpha ? al.data() : nullptr,
+                                       alpha ? qInv->data() : nullptr);
+        const size_t N = mine->GetRingDimension();
+        auto d         = hiprt::Alloc((size_t)sizeP * N);
+        auto fn        = alpha ? hiprt::api().switch_basis_exact : hiprt::api().approx_switch_basis;
+        hiprt::Check(fn(cv, m_d->p, sizeQ, 0, d->p, sizeP, 0, 1, nullptr), "SwitchCRTBasis");
+        hiprt::CountDevice();
+        *out = FromDevice(paramsP, m_h.GetFormat(), std::move(d));
+        return true;
+    }
+    // ApproxModUp (dcrtpoly-impl.h:935-963): this (Q) -> Q u P in EVALUATION
+    bool ModUpOnDevice(const std::shared_ptr<Params>& paramsQ, const std::shared_ptr<Params>& paramsP,
+                       const std::shared_ptr<Params>& paramsQP, const std::vector<NativeInteger>& QHatInvModq,
+                       const std::vector<std::vector<NativeInteger>>& QHatModp) {
+        const uint32_t sizeQ = NumLimbs(), sizeP = (uint32_t)paramsP->GetParams().size();
+        if (paramsQP->GetParams().size() != sizeQ + sizeP)
+            return false;
+        const bool wasEval = m_h.GetFormat() == Format::EVALUATION;
+        DCRTPolyType coeff(*this);
+        if (wasEval)
+            coeff.SwitchFormat();
+        DCRTPolyType partP;
+        if (!coeff.SwitchBasisOnDevice(paramsQ, paramsP, QHatInvModq, QHatModp, nullptr, nullptr, &partP) || !partP.IsDeviceResident())
+            return false;
+        hiprt::Resolved r;
+        if (!ResolveSets(paramsQP->GetRingDimension(), {paramsQP, paramsP, m_h.GetParams()}, &r))
+            return false;
+        DCRTPolyType& qpart = wasEval ? *this : coeff;  // the EVALUATION copy of the Q limbs is kept when there is one
+        if (!qpart.Upload(r.ctx))
+            return false;
+        const size_t N = paramsQP->GetRingDimension();
+        auto d         = hiprt::Alloc((size_t)(sizeQ + sizeP) * N);
+        hiprt::Check(hiprt::api().d2d(r.ctx, d->p, qpart.m_d->p, (size_t)sizeQ * N * 8, nullptr), "ApproxModUp");
+        hiprt::Check(hiprt::api().d2d(r.ctx, d->p + (size_t)sizeQ * N, partP.m_d->p, (size_t)sizeP * N * 8, nullptr), "ApproxModUp");
+        if (!wasEval)
+            hiprt::Check(hiprt::api().ntt_fwd(r.ctx, d->p, r.idx[2].data(), sizeQ, 1, nullptr), "ApproxModUp");
+        hiprt::Check(hiprt::api().ntt_fwd(r.ctx, d->p + (size_t)sizeQ * N, r.idx[1].data(), sizeP, 1, nullptr), "ApproxModUp");
+        hiprt::CountDevice();
+        *this = FromDevice(paramsQP, Format::EVALUATION, std::move(d));
+        return true;
+    }
+    // ApproxModDown with t = 0 (dcrtpoly-impl.h:966-1005): this over Q_l u P -> *out over Q_l, EVALUATION
+    bool ModDownOnDevice(const std::shared_ptr<Params>& paramsQ, const std::shared_ptr<Params>& paramsP,
+                         const std::vector<NativeInteger>& PInvModq, const std::vector<NativeInteger>& PHatInvModp,
+                         const std::vector<std::vector<NativeInteger>>& PHatModq, DCRTPolyType* out) const {
+        const uint32_t sizeP = (uint32_t)paramsP->GetParams().size(), L = NumLimbs();
+        if (L <= sizeP || sizeP > 32 || m_h.GetFormat() != Format::EVALUATION)
+            return false;
+        const uint32_t sizeQ = L - sizeP;
+        if (sizeQ > paramsQ->GetParams().size() || PInvModq.size() < sizeQ || PHatInvModp.size() < sizeP || PHatModq.size() < sizeP)
+            return false;
+        // the Q limbs of this tower are the first sizeQ limbs of paramsQ (:991-994 drops the others)
+        const auto& mine = m_h.GetParams();
+        for (uint32_t i = 0; i < sizeQ; ++i)
+            if (mine->GetParams()[i]->GetModulus() != paramsQ->GetParams()[i]->GetModulus())
+                return false;
+        hiprt::Resolved r;
+        if (!ResolveSets(mine->GetRingDimension(), {mine, paramsP}, &r) || !Upload(r.ctx))
+            return false;
+        std::vector<uint32_t> idxQ(r.idx[0].begin(), r.idx[0].begin() + sizeQ);
+        const size_t N = mine->GetRingDimension();
+        // P part to COEFFICIENT (:978-985)
+        auto pcoef = hiprt::Alloc((size_t)sizeP * N);
+        hiprt::Check(hiprt::api().ntt_inv_oop(r.ctx, m_d->p + (size_t)sizeQ * N, pcoef->p, r.idx[1].data(), sizeP, 1, nullptr), "ApproxModDown");
+        // P -> Q_l (:987-988), with the reference's PHatInvModp / PHatModq tables
+        std::vector<uint64_t> hi(sizeP), hm((size_t)sizeP * sizeQ);
+        for (uint32_t j = 0; j < sizeP; ++j) {
+            hi[j] = PHatInvModp[j].ConvertToInt<uint64_t>();
+            for (uint32_t i = 0; i < sizeQ; ++i)
+                hm[(size_t)j * sizeQ + i] = PHatModq[j][i].ConvertToInt<uint64_t>();
+        }
+        fhe_conv* cv = hiprt::ConvPlan(r.ctx, r.idx[1], idxQ, hi.data(), hm.data(), nullptr, nullptr);
+        auto sw      = hiprt::Alloc((size_t)sizeQ * N);
+        hiprt::Check(hiprt::api().approx_switch_basis(cv, pcoef->p, sizeP, 0, sw->p, sizeQ, 0, 1, nullptr), "ApproxModDown");
+        hiprt::Check(hiprt::api().ntt_fwd(r.ctx, sw->p, idxQ.data(), sizeQ, 1, nullptr), "ApproxModDown");  // :1001
+        // (x_i - switched_i) * [P^-1]_{q_i}   (:1002)
+        std::vector<uint64_t> pinv(sizeQ);
+        for (uint32_t i = 0; i < sizeQ; ++i)
+            pinv[i] = PInvModq[i].ConvertToInt<uint64_t>();
+        hiprt::Check(hiprt::api().sub(r.ctx, sw->p, m_d->p, sw->p, idxQ.data(), sizeQ, 1, nullptr), "ApproxModDown");
+        hiprt::Check(hiprt::api().mul_const(r.ctx, sw->p, sw->p, pinv.data(), idxQ.data(), sizeQ, 1, nullptr), "ApproxModDown");
+        hiprt::CountDevice();
+        // the result's params: paramsQ, shortened to sizeQ limbs like `ans.DropLastElements(diffQ)` does (:991-994)
+        DCRTPolyType ans = FromDevice(paramsQ, Format::EVALUATION, std::move(sw));
+        const uint32_t diffQ = (uint32_t)paramsQ->GetParams().size() - sizeQ;
+        if (diffQ > 0)
+            ans.DropLastElements(diffQ);
+        *out = std::move(ans);
+        return true;
+    }
+    // DropLastElementAndScale, EVALUATION format (dcrtpoly-impl.h:693-712)
+    bool RescaleOnDevice(const std::vector<NativeInteger>& QlQlInvModqlDivqlModq, const std::vector<NativeInteger>& qlInvModq) {
+        const uint32_t L = NumLimbs();
+        if (L < 2 || m_h.GetFormat() != Format::EVALUATION || QlQlInvModqlDivqlModq.size() < L - 1 || qlInvModq.size() < L - 1)
+            return false;
+        hiprt::Resolved r;
+        if (!OnDevice(&r))
+            return false;
+        const size_t N     = m_h.GetParams()->GetRingDimension();
+        const uint32_t l   = L - 1;
+        const uint32_t lastLimb = r.idx[0][l];
+        std::vector<uint32_t> idx(r.idx[0].begin(), r.idx[0].begin() + l);
+        std::vector<uint64_t> a(l), b(l);
+        for (uint32_t i = 0; i < l; ++i) {
+            a[i] = QlQlInvModqlDivqlModq[i].ConvertToInt<uint64_t>();
+            b[i] = qlInvModq[i].ConvertToInt<uint64_t>();
+        }
+        const auto& A = hiprt::api();
+        auto last     = hiprt::Alloc(N);
+        auto tmp      = hiprt::Alloc((size_t)l * N);
+        hiprt::Check(A.ntt_inv_oop(r.ctx, m_d->p + (size_t)l * N, last->p, &lastLimb, 1, 1, nullptr), "DropLastElementAndScale");  // :696-697
+        hiprt::Check(A.switch_modulus(r.ctx, tmp->p, idx.data(), l, last->p, 1, 0, lastLimb, 1, nullptr), "DropLastElementAndScale");  // :703-704
+        hiprt::Check(A.mul_const(r.ctx, tmp->p, tmp->p, a.data(), idx.data(), l, 1, nullptr), "DropLastElementAndScale");            // :705
+        hiprt::Check(A.ntt_fwd(r.ctx, tmp->p, idx.data(), l, 1, nullptr), "DropLastElementAndScale");                                 // :706-707
+        hiprt::Check(A.mul_const(r.ctx, m_d->p, m_d->p, b.data(), idx.data(), l, 1, nullptr), "DropLastElementAndScale");             // :708
+        hiprt::Check(A.add(r.ctx, m_d->p, m_d->p, tmp->p, idx.data(), l, 1, nullptr), "DropLastElementAndScale");                     // :709
+        hiprt::CountDevice();
+        DeviceIsNewer(Format::EVALUATION);
+        DropLastElement();  // :698 (metadata; the device copy keeps its leading limbs)
+        return true;
+    }
+    bool ModRaiseOnDevice(const PolyType& e, const std::shared_ptr<Params>& params) {
+        if (!hiprt::Available() || e.IsEmpty() || e.GetFormat() != Format::COEFFICIENT || params->GetParams().empty() ||
+            e.GetModulus() != params->GetParams()[0]->GetModulus() || e.GetLength() != params->GetRingDimension())
+            return false;
+        hiprt::Resolved r;
+        if (!ResolveSets(params->GetRingDimension(), {params}, &r))
+            return false;
+        const size_t N   = params->GetRingDimension();
+        const uint32_t L = (uint32_t)params->GetParams().size();
+        auto src         = hiprt::Alloc(N);
+        auto d           = hiprt::Alloc((size_t)L * N);
+        hiprt::Check(hiprt::api().h2d(r.ctx, src->p, &e.GetValues()[0], N * 8, nullptr), "ModRaise");
+        hiprt::Check(hiprt::api().switch_modulus(r.ctx, d->p, r.idx[0].data(), L, src->p, 1, 0, r.idx[0][0], 1, nullptr), "ModRaise");
+        hiprt::Check(hiprt::api().sync(r.ctx, nullptr), "ModRaise");
+        hiprt::CountH2D(N * 8);
+        hiprt::CountDevice();
+        m_h         = HostType(params, Format::COEFFICIENT, false);
+        m_d         = std::move(d);
+        m_hostValid = false;
+        return true;
+    }
+};
+
+}  // namespace lbcrypto
+
+#endif

@@ -1,0 +1,98 @@
+// hip-runtime.h — the non-template part of the HIP backend of lbcrypto::DCRTPoly: binding of the C ABI (include/fhe_hip.h,
+// libfhe_hip.so loaded with dlopen), the registry that maps (ring dimension, modulus) to a limb of a device context, a
+// caching device allocator and the cache of basis-conversion plans built from the reference's own CRT tables.
+// Implemented in openfhe-development_amd/hal/hip-runtime.cpp (one translation unit added to libOPENFHEcore).
+#ifndef LBCRYPTO_INC_LATTICE_HAL_HIP_RUNTIME_H
+#define LBCRYPTO_INC_LATTICE_HAL_HIP_RUNTIME_H
+
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <vector>
+
+#include "fhe_hip.h"  // the C ABI (repo root include/)
+
+namespace lbcrypto {
+namespace hiprt {
+
+// entry points of the C ABI the shim uses (resolved once with dlsym)
+struct Api {
+    decltype(&fhe_last_error) last_error;
+    decltype(&fhe_device_count) device_count;
+    decltype(&fhe_ctx_create) ctx_create;
+    decltype(&fhe_malloc) malloc_;
+    decltype(&fhe_free) free_;
+    decltype(&fhe_memcpy_h2d) h2d;
+    decltype(&fhe_memcpy_d2h) d2h;
+    decltype(&fhe_memcpy_d2d) d2d;
+    decltype(&fhe_stream_sync) sync;
+    decltype(&fhe_ntt_fwd) ntt_fwd;
+    decltype(&fhe_ntt_inv) ntt_inv;
+    decltype(&fhe_ntt_inv_oop) ntt_inv_oop;
+    decltype(&fhe_add) add;
+    decltype(&fhe_sub) sub;
+    decltype(&fhe_mul) mul;
+    decltype(&fhe_neg) neg;
+    decltype(&fhe_mul_const) mul_const;
+    decltype(&fhe_mult_acc) mult_acc;
+    decltype(&fhe_automorph) automorph;
+    decltype(&fhe_switch_modulus) switch_modulus;
+    decltype(&fhe_conv_create_custom) conv_create_custom;
+    decltype(&fhe_approx_switch_basis) approx_switch_basis;
+    decltype(&fhe_switch_basis_exact) switch_basis_exact;
+};
+
+// true when the library is loaded and a device is usable; otherwise every DCRTPoly member runs on its host mirror
+bool Available();
+const Api& api();
+// throws (OPENFHE_THROW) with the library's message when a call failed
+void Check(fhe_status s, const char* what);
+
+// ---- device memory: size-bucketed free lists over fhe_malloc (hipMalloc / hipFree are far too slow per operation) ----
+struct DevBuf {
+    uint64_t* p  = nullptr;
+    size_t words = 0;
+    ~DevBuf();
+};
+using Buf = std::shared_ptr<DevBuf>;
+Buf Alloc(size_t words);
+
+// ---- contexts: one device context per ring dimension holding every modulus seen so far ----
+struct LimbSet {  // the moduli / roots of one tower (an ILDCRTParams), in tower order
+    const uint64_t* q;
+    const uint64_t* psi;
+    uint32_t n;
+};
+struct Resolved {
+    fhe_ctx* ctx = nullptr;
+    std::vector<std::vector<uint32_t>> idx;  // context limbs of every requested set
+};
+// registers the moduli of all sets (growing the context when new ones appear) and returns their context limbs; false when
+// the ring or a modulus is outside the device library's domain (N not 2^4..2^17, q >= 2^60, q != 1 mod 2N, > 128 limbs)
+bool Resolve(uint32_t ringDim, const std::vector<LimbSet>& sets, Resolved* out);
+
+// ---- basis-conversion plans from the caller's (= the reference's CryptoParameters') tables, cached by content ----
+// hatInv[nSrc], hatMod[nSrc][nDst] row-major; alphaMod[(nSrc+1)][nDst] + qInv[nSrc] for the exact variant or both null
+fhe_conv* ConvPlan(fhe_ctx* ctx, const std::vector<uint32_t>& srcIdx, const std::vector<uint32_t>& dstIdx, const uint64_t* hatInv,
+                   const uint64_t* hatMod, const uint64_t* alphaMod, const double* qInv);
+
+// ---- counters (tests assert that the device path really ran) ----
+struct Stats {
+    uint64_t deviceOps, hostFallbacks, h2dBytes, d2hBytes;
+};
+void CountDevice();
+void CountHost();
+void CountH2D(size_t bytes);
+void CountD2H(size_t bytes);
+
+}  // namespace hiprt
+}  // namespace lbcrypto
+
+extern "C" {
+// {device operations, host fallbacks, bytes host->device, bytes device->host} since process start
+void fhe_hal_stats(uint64_t out[4]);
+// 1 when the HIP backend is live (library loaded, device present), 0 when every operation runs on the host mirror
+int fhe_hal_available(void);
+}
+
+#endif

@@ -1,0 +1,149 @@
+// TEST PROGRAM — the reference's own CryptoContext API (openfhe.h), compiled twice from this one source:
+//   * against the stock libraries of oracle/_ref (default DCRTPoly backend), and
+//   * against openfhe-development_amd/hal/_build (the same reference sources built with the HIP backend of DCRTPoly).
+// Both runs use the deterministic test PRNG, so every key and ciphertext is the same: the program dumps the limbs of every
+// ciphertext it produces; tests/test_hal_shim.py compares the two dumps byte for byte and checks the decryptions.
+//
+//   shim_ckks <out.bin> <prng.so> <mode> [logN]      mode: leveled | bootstrap
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "openfhe.h"
+#include "math/distributiongenerator.h"
+
+using namespace lbcrypto;
+
+extern "C" void fhe_hal_stats(uint64_t out[4]) __attribute__((weak));
+extern "C" int fhe_hal_available(void) __attribute__((weak));
+
+static std::ofstream g_out;
+static void dump(const char* name, const Ciphertext<DCRTPoly>& ct) {
+    const auto& els = ct->GetElements();
+    uint64_t hdr[2] = {els.size(), 0};
+    g_out.write(reinterpret_cast<const char*>(hdr), 16);
+    for (const auto& e : els) {
+        const auto& limbs = e.GetAllElements();
+        uint64_t h2[3]    = {limbs.size(), e.GetRingDimension(), static_cast<uint64_t>(e.GetFormat())};
+        g_out.write(reinterpret_cast<const char*>(h2), 24);
+        for (const auto& l : limbs) {
+            uint64_t q = l.GetModulus().ConvertToInt<uint64_t>();
+            g_out.write(reinterpret_cast<const char*>(&q), 8);
+            for (uint32_t j = 0; j < l.GetLength(); ++j) {
+                uint64_t v = l[j].ConvertToInt<uint64_t>();
+                g_out.write(reinterpret_cast<const char*>(&v), 8);
+            }
+        }
+    }
+    std::cout << "dumped " << name << ": " << els.size() << " elements x " << els[0].GetNumOfElements() << " limbs" << std::endl;
+}
+static void show(const char* name, CryptoContext<DCRTPoly>& cc, const PrivateKey<DCRTPoly>& sk, const Ciphertext<DCRTPoly>& ct,
+                 size_t n) {
+    Plaintext pt;
+    cc->Decrypt(sk, ct, &pt);
+    pt->SetLength(n);
+    auto v = pt->GetRealPackedValue();
+    std::cout << "value " << name << ":";
+    for (size_t i = 0; i < n; ++i)
+        std::printf(" %.6f", v[i]);
+    std::cout << std::endl;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 4) {
+        std::cerr << "usage: shim_ckks out.bin prng.so leveled|bootstrap [logN]" << std::endl;
+        return 2;
+    }
+    g_out.open(argv[1], std::ios::binary);
+    PseudoRandomNumberGenerator::InitPRNGEngine(argv[2]);
+    const std::string mode = argv[3];
+    const uint32_t logN    = argc > 4 ? std::atoi(argv[4]) : 11;
+
+    if (mode == "leveled") {
+        CCParams<CryptoContextCKKSRNS> p;
+        p.SetSecurityLevel(HEStd_NotSet);
+        p.SetRingDim(1u << logN);
+        p.SetMultiplicativeDepth(4);
+        p.SetScalingModSize(50);
+        p.SetFirstModSize(60);
+        p.SetKeySwitchTechnique(HYBRID);
+        p.SetNumLargeDigits(2);
+        p.SetScalingTechnique(FIXEDMANUAL);
+        auto cc = GenCryptoContext(p);
+        cc->Enable(PKE);
+        cc->Enable(KEYSWITCH);
+        cc->Enable(LEVELEDSHE);
+        auto kp = cc->KeyGen();
+        cc->EvalMultKeyGen(kp.secretKey);
+        cc->EvalRotateKeyGen(kp.secretKey, {1, -2});
+        std::vector<double> x = {0.25, 0.5, 0.75, 1.0, 2.0, 3.0, 0.4, 0.5}, y = {1.0, 2.0, 0.5, 0.25, -1.0, 0.125, 0.3, -0.5};
+        auto cx = cc->Encrypt(kp.publicKey, cc->MakeCKKSPackedPlaintext(x));
+        auto cy = cc->Encrypt(kp.publicKey, cc->MakeCKKSPackedPlaintext(y));
+        dump("x", cx);
+        dump("y", cy);
+        auto m = cc->EvalMult(cx, cy);  // EvalMultCore + HYBRID KeySwitchCore (base-leveledshe.cpp:201-214)
+        dump("x*y", m);
+        auto r = cc->Rescale(m);  // DropLastElementAndScale
+        dump("rescale", r);
+        auto rot = cc->EvalRotate(r, 1);  // EvalAutomorphism: key switch + AutomorphismTransform
+        dump("rotate1", rot);
+        auto rot2 = cc->EvalRotate(rot, -2);
+        dump("rotate-2", rot2);
+        auto s = cc->EvalAdd(rot2, r);
+        auto sq = cc->Rescale(cc->EvalMult(s, s));  // a second multiplication one level down
+        dump("square", sq);
+        auto d = cc->Rescale(cc->EvalMult(sq, 0.5));  // plaintext-constant path, a third level
+        dump("final", d);
+        show("x*y", cc, kp.secretKey, r, 8);
+        show("rot", cc, kp.secretKey, rot2, 8);
+        show("final", cc, kp.secretKey, d, 8);
+    }
+    else {  // CKKS bootstrapping (ckksrns-fhe.cpp:429-760): ModRaise, CoeffsToSlots, Chebyshev sine, SlotsToCoeffs
+        CCParams<CryptoContextCKKSRNS> p;
+        SecretKeyDist skd = SPARSE_TERNARY;
+        p.SetSecretKeyDist(skd);
+        p.SetSecurityLevel(HEStd_NotSet);
+        p.SetRingDim(1u << logN);
+        p.SetScalingTechnique(FLEXIBLEAUTO);
+        p.SetScalingModSize(59);
+        p.SetFirstModSize(60);
+        p.SetNumLargeDigits(3);
+        p.SetKeySwitchTechnique(HYBRID);
+        std::vector<uint32_t> levelBudget = {2, 2};
+        const uint32_t levelsAfter        = 2;
+        const usint depth                 = levelsAfter + FHECKKSRNS::GetBootstrapDepth(levelBudget, skd);
+        p.SetMultiplicativeDepth(depth);
+        auto cc = GenCryptoContext(p);
+        cc->Enable(PKE);
+        cc->Enable(KEYSWITCH);
+        cc->Enable(LEVELEDSHE);
+        cc->Enable(ADVANCEDSHE);
+        cc->Enable(FHE);
+        const usint slots = 8;
+        cc->EvalBootstrapSetup(levelBudget, {0, 0}, slots);
+        auto kp = cc->KeyGen();
+        cc->EvalMultKeyGen(kp.secretKey);
+        cc->EvalBootstrapKeyGen(kp.secretKey, slots);
+        std::vector<double> x = {0.25, 0.5, 0.75, 1.0, 2.0, 3.0, 4.0, 5.0};
+        auto pt = cc->MakeCKKSPackedPlaintext(x, 1, depth - 1, nullptr, slots);
+        auto c  = cc->Encrypt(kp.publicKey, pt);
+        dump("in", c);
+        auto b = cc->EvalBootstrap(c);
+        dump("bootstrapped", b);
+        std::cout << "levels remaining " << depth - b->GetLevel() - (b->GetNoiseScaleDeg() - 1) << std::endl;
+        show("bootstrapped", cc, kp.secretKey, b, slots);
+    }
+    g_out.close();
+    if (fhe_hal_stats) {
+        uint64_t st[4];
+        fhe_hal_stats(st);
+        std::cout << "hal: available " << (fhe_hal_available ? fhe_hal_available() : -1) << " deviceOps " << st[0] << " hostOps " << st[1]
+                  << " h2dBytes " << st[2] << " d2hBytes " << st[3] << std::endl;
+    }
+    else
+        std::cout << "hal: stock backend" << std::endl;
+    return 0;
+}

@@ -1,0 +1,91 @@
+"""The HAL shim: the reference's UNMODIFIED sources compiled against lbcrypto::DCRTPolyHipImpl
+(openfhe-development_amd/hal/lattice/hal/hip/), driven through the reference's own CryptoContext API.
+
+One test program (tests/hal/shim_ckks.cpp) is compiled twice — against the stock libraries of oracle/_ref (default DCRTPoly
+backend) and against openfhe-development_amd/hal/_build (HIP backend) — and run with a deterministic test PRNG, so that both
+processes draw the same keys and randomness.  Every ciphertext either run produces (fresh encryptions, EvalMult + HYBRID key
+switch, Rescale, EvalRotate, a second multiplication one level down, a plaintext-constant multiplication; and the input /
+output of FHECKKSRNS::EvalBootstrap) is dumped limb by limb; the dumps must be IDENTICAL byte for byte, the decryptions must
+be right, and the shim run must report device operations (fhe_hal_stats)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+B = os.path.join(ROOT, "tests", "hal", "_build")
+PROGS = [os.path.join(B, n) for n in ("shim_ckks_stock", "shim_ckks_hip", "libdetprng.so")]
+
+
+def ensure_built():
+    if all(os.path.exists(p) for p in PROGS):
+        return
+    if os.path.isdir("/root/reference/src"):
+        subprocess.check_call([os.path.join(ROOT, "build.sh"), "hal"])
+    else:
+        pytest.skip("tests/hal/_build not present and /root/reference not mounted")
+
+
+def run(prog, out, mode, logN, device_lib=None):
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    if device_lib:
+        env["FHE_HIP_LIB"] = device_lib
+        env["FHE_HAL_REQUIRE_DEVICE"] = "1"  # the shim must not silently degrade to its host mirror
+    r = subprocess.run([prog, out, PROGS[2], mode, str(logN)], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+def values(stdout, name):
+    m = re.search(r"value " + re.escape(name) + r":(.*)", stdout)
+    return [float(v) for v in m.group(1).split()]
+
+
+def check(tmp_path, mode, logN, device_lib, expect):
+    ensure_built()
+    so, sh = str(tmp_path / "stock.bin"), str(tmp_path / "hip.bin")
+    out_stock = run(PROGS[0], so, mode, logN)
+    out_hip = run(PROGS[1], sh, mode, logN, device_lib)
+    assert "hal: stock backend" in out_stock
+    m = re.search(r"hal: available (\d+) deviceOps (\d+) hostOps (\d+)", out_hip)
+    assert m and int(m.group(1)) == 1 and int(m.group(2)) > 0, out_hip[-500:]
+    a, b = open(so, "rb").read(), open(sh, "rb").read()
+    assert len(a) > 1000 and a == b, "the HIP backend's ciphertext limbs differ from the default backend's"
+    for name, want in expect.items():
+        for run_out in (out_stock, out_hip):
+            got = values(run_out, name)
+            assert len(got) == len(want) and all(abs(g - w) < 1e-3 for g, w in zip(got, want)), (name, got, want)
+    return int(m.group(2))
+
+
+X = [0.25, 0.5, 0.75, 1.0, 2.0, 3.0, 0.4, 0.5]
+Y = [1.0, 2.0, 0.5, 0.25, -1.0, 0.125, 0.3, -0.5]
+XY = [a * b for a, b in zip(X, Y)]
+ROT = XY[-1:] + XY[:-1]  # rotate by 1 then by -2: one slot to the right (the vector is padded with zeros beyond 8 slots)
+ROT = [0.0] + XY[:7]
+FINAL = [0.5 * (r + s) ** 2 for r, s in zip(ROT, XY)]
+LEVELED = {"x*y": XY, "rot": ROT, "final": FINAL}
+BOOT = {"bootstrapped": [0.25, 0.5, 0.75, 1.0, 2.0, 3.0, 4.0, 5.0]}
+EMU = os.path.join(ROOT, "tests", "emu", "libfhe_emu.so")
+HIP = os.path.join(ROOT, "openfhe-development_amd", "csrc", "libfhe_hip.so")
+
+
+def test_shim_leveled_ckks_matches_default_backend_on_emulator(tmp_path):
+    check(tmp_path, "leveled", 11, EMU, LEVELED)
+
+
+def test_shim_bootstrap_matches_default_backend_on_emulator(tmp_path):
+    check(tmp_path, "bootstrap", 10, EMU, BOOT)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("logN", [12, 14])
+def test_shim_leveled_ckks_matches_default_backend_on_gpu(tmp_path, logN):
+    check(tmp_path, "leveled", logN, HIP, LEVELED)
+
+
+@pytest.mark.gpu
+def test_shim_bootstrap_matches_default_backend_on_gpu(tmp_path):
+    ops = check(tmp_path, "bootstrap", 13, HIP, BOOT)
+    assert ops > 500  # ModRaise, the CoeffsToSlots / SlotsToCoeffs transforms and the Chebyshev evaluation ran on the device
