@@ -768,25 +768,64 @@ def main():
         hadamard = {"GB_per_s_per_gpu": round(hbytes / hdt / 1e9, 1), "ms": round(hdt * 1e3, 3),
                     "hbm_roofline_frac": round(hbytes / hdt / 1e9 / HBM_PEAK_GBPS, 4),
                     "bytes": hbytes, "note": "out = a*b mod q_i per limb (generalized Barrett), read 2 + write 1 streams"}
-        # fused use: c = INTT(NTT(a) o NTT(b)), a, b, c in COEFFICIENT form (negacyclic polynomial product per limb)
-        def pstep():
-            lib.check(lib.L.fhe_ntt_fwd(ctx.h, x, None, L, B, None))
-            lib.check(lib.L.fhe_ntt_fwd(ctx.h, y, None, L, B, None))
-            lib.check(lib.L.fhe_mul(ctx.h, z, x, y, None, L, B, None))
+        # negacyclic polynomial product c = a * b, a, b, c in COEFFICIENT form (SURVEY 8(d) "fused fwd o mul o inv"):
+        # fhe_poly_mul (column passes + two fused row kernels) against the same product as four separate calls
+        wsb = lib.L.fhe_poly_mul_workspace_bytes(ctx.h, L, B)
+        wsp = ctx.malloc(wsb)
+        wa, wb = wsp, C.c_void_p(wsp.value + wsb // 2)
+
+        def pfused():
+            lib.check(lib.L.fhe_poly_mul(ctx.h, x, y, z, None, L, B, wsp, wsb, None))
+
+        def pplain():
+            lib.check(lib.L.fhe_ntt_fwd_oop(ctx.h, x, wa, None, L, B, None))
+            lib.check(lib.L.fhe_ntt_fwd_oop(ctx.h, y, wb, None, L, B, None))
+            lib.check(lib.L.fhe_mul(ctx.h, z, wa, wb, None, L, B, None))
             lib.check(lib.L.fhe_ntt_inv(ctx.h, z, None, L, B, None))
-            lib.check(lib.L.fhe_ntt_inv(ctx.h, x, None, L, B, None))  # restore the operands for the next step
-            lib.check(lib.L.fhe_ntt_inv(ctx.h, y, None, L, B, None))
-        pstep()
-        gpu_sync()
-        t2 = time.perf_counter()
-        ps = max(3, a.steps // 3)
-        for _ in range(ps):
-            pstep()
-        gpu_sync()
-        pdt = (time.perf_counter() - t2) / ps
-        hadamard["polymul"] = {"ms_per_batch_incl_operand_restore": round(pdt * 1e3, 3),
-                               "note": "2 NTT + Hadamard + INTT (+ 2 INTT restoring a, b): limb-wise negacyclic products of "
-                                       f"{B} towers; {round(B * L / pdt / 1e3, 1)} k limb-products/s"}
+        times = {}
+        for nm, fn in (("fused", pfused), ("separate", pplain), ("fused", pfused)):
+            fn()
+            gpu_sync()
+            t2 = time.perf_counter()
+            ps = max(3, a.steps // 2)
+            for _ in range(ps):
+                fn()
+            gpu_sync()
+            times[nm] = min(times.get(nm, 1e9), (time.perf_counter() - t2) / ps)
+        pbytes = 5.0 * 8 * N * L * B  # read a, b; write c; + one workspace round trip counted as algorithmic
+        ppar = "skipped"
+        if not a.no_parity:
+            o = load_oracle()
+            if o is None:
+                ppar = "oracle library not available"
+            else:
+                pfused()
+                gpu_sync()
+                octx = o.orc_ctx_create(N, L, q, psi)
+                hx, hy = host_seed_towers(q, N, B, 2 + rank, 8), host_seed_towers(q, N, B, 50 + rank, 8)
+                ppar = "bit-exact vs oracle (INTT(NTT(a) o NTT(b))) on towers " + str(sample_towers(B))
+                done = {}
+                for tw in sample_towers(B):
+                    sp = tw % hx.shape[0]
+                    if sp not in done:
+                        u, v = hx[sp].copy(), hy[sp].copy()
+                        o.orc_ntt_fwd_tower(octx, u, None, L, 1, 0)
+                        o.orc_ntt_fwd_tower(octx, v, None, L, 1, 0)
+                        w = np.empty_like(u)
+                        for l in range(L):
+                            o.orc_vec_mul(w[l], u[l], v[l], N, q[l])
+                        o.orc_ntt_inv_tower(octx, w, None, L, 1, 0)
+                        done[sp] = w
+                    if not np.array_equal(download_tower(lib, ctx, z, tw, L), done[sp]):
+                        ppar = f"MISMATCH vs oracle at tower {tw}"
+                        break
+                o.orc_ctx_destroy(octx)
+        hadamard["polymul_fused"] = {"ms_per_batch": round(times["fused"] * 1e3, 3), "ms_per_batch_four_separate_calls": round(times["separate"] * 1e3, 3),
+                                     "GB_per_s_algorithmic": round(pbytes / times["fused"] / 1e9, 1), "algorithmic_bytes": pbytes,
+                                     "k_limb_products_per_s": round(B * L / times["fused"] / 1e3, 1), "parity": ppar,
+                                     "note": "fhe_poly_mul: 2 forward column passes, forward row pass of a, [forward row pass of b + "
+                                             "Hadamard product + inverse row pass] in one kernel, inverse column pass"}
+        ctx.free(wsp)
         ctx.free(y)
         ctx.free(z)
 

@@ -96,6 +96,15 @@ fhe_status fhe_ntt_fwd_oop(fhe_ctx* ctx, const uint64_t* xin, uint64_t* xout, co
 fhe_status fhe_ntt_inv_oop(fhe_ctx* ctx, const uint64_t* xin, uint64_t* xout, const uint32_t* limbIdx, uint32_t nLimbs,
                            uint32_t batch, void* stream);
 
+/* Negacyclic polynomial product of COEFFICIENT-format towers, c = a * b in Z_q[x]/(x^N + 1) per limb: what the reference
+ * spells a.SetFormat(EVALUATION); b.SetFormat(EVALUATION); c = a * b; c.SetFormat(COEFFICIENT)
+ * (dcrtpoly-impl.h:1932-1940 with transformnat-impl.h:303-374, 512-625; dcrtpoly.h:174-189).  a and b are not modified; out may
+ * not alias them.  Two-pass rings run fused kernels (the forward row pass of b, the Hadamard product and the inverse row
+ * pass are one kernel: SURVEY.md 8(d) "fused fwd o mul o inv").  ws: 2 towers of device workspace. */
+size_t     fhe_poly_mul_workspace_bytes(const fhe_ctx* ctx, uint32_t nLimbs, uint32_t batch);
+fhe_status fhe_poly_mul(fhe_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, const uint32_t* limbIdx,
+                        uint32_t nLimbs, uint32_t batch, void* ws, size_t wsBytes, void* stream);
+
 /* ---- a7: element-wise tower arithmetic -----------------------------------------------------------
  * Replaces DCRTPolyImpl::operator+= / -= / *= , Plus/Minus/Times, Negate
  * (dcrtpoly-impl.h:347-408, dcrtpoly.h:131-189) and NativeVectorT::ModAddEq/ModSubEq/ModMulEq

@@ -758,6 +758,81 @@ extern "C" fhe_status fhe_ntt_inv_oop(fhe_ctx* c, const uint64_t* xi, uint64_t* 
     return ntt_run(c, true, xi, xo, li, nl, b, st);
 }
 
+// ---- negacyclic polynomial product of COEFFICIENT-format towers: c = INTT(NTT(a) o NTT(b)) per limb ----
+// What a caller of the reference writes as a.SetFormat(EVALUATION); b.SetFormat(EVALUATION); c = a * b; c.SetFormat(COEFFICIENT)
+// (dcrtpoly-impl.h:1932-1940, dcrtpoly.h:174-189): three transforms and a Hadamard product.  Two-pass rings whose row pass has a
+// static 9..12-stage instance run the fused kernels of ntt_static.h (poly_mul_row_*); every other ring runs the plain sequence.
+extern "C" size_t fhe_poly_mul_workspace_bytes(const fhe_ctx* c, uint32_t nLimbs, uint32_t batch) {
+    return c ? (((size_t)2 * batch * nLimbs) << c->logN) * 8 : 0;
+}
+static bool poly_mul_fused_supported(const fhe_ctx* c) {
+    if (c->logN <= (uint32_t)kTileLog)
+        return false;
+    const uint32_t t1 = ntt_t1(c->logN), t2 = c->logN - t1;
+    return (t1 == 4u && t2 >= 9u && t2 <= 12u) || (t1 == 5u && t2 == 12u);
+}
+extern "C" fhe_status fhe_poly_mul(fhe_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* out, const uint32_t* limbIdx,
+                                   uint32_t nLimbs, uint32_t batch, void* wsv, size_t wsBytes, void* stream) {
+    ARG_CHECK(c && a && b && out && wsv, "fhe_poly_mul: null argument");
+    ARG_CHECK(batch >= 1, "fhe_poly_mul: batch must be >= 1");
+    ARG_CHECK(wsBytes >= fhe_poly_mul_workspace_bytes(c, nLimbs, batch), "fhe_poly_mul: workspace too small");
+    LimbSel sel;
+    if (fhe_status s = make_sel(c, limbIdx, nLimbs, &sel, "fhe_poly_mul"))
+        return s;
+    RT_CHECK(rt::set_device(c->device));
+    uint64_t* wa = (uint64_t*)wsv;
+    uint64_t* wb = wa + (((size_t)batch * nLimbs) << c->logN);
+    if (!poly_mul_fused_supported(c)) {
+        if (fhe_status s = ntt_run(c, false, a, wa, limbIdx, nLimbs, batch, stream))
+            return s;
+        if (fhe_status s = ntt_run(c, false, b, wb, limbIdx, nLimbs, batch, stream))
+            return s;
+        if (fhe_status s = fhe_mul(c, out, wa, wb, limbIdx, nLimbs, batch, stream))
+            return s;
+        return ntt_run(c, true, out, out, limbIdx, nLimbs, batch, stream);
+    }
+    const uint32_t logN = c->logN, T1 = ntt_t1(logN), T2 = logN - T1;
+    PassPlan fa, fb, ib, ia;  // forward column / row, inverse row / column
+    plan_pass(false, true, logN, T1, &fa);
+    plan_pass(false, false, logN, T2, &fb);
+    plan_pass(true, false, logN, T2, &ib);
+    plan_pass(true, true, logN, T1, &ia);
+    for (PassPlan* p : {&fa, &fb, &ib, &ia})
+        mark_uniform(*p, logN);
+    uint32_t bound = 1;
+    schedule_fwd(fa, logN, &bound);
+    schedule_fwd(fb, logN, &bound);
+    fb.outBound = bound;
+    // column passes of a and b, out of place into the workspace
+    if (fhe_status s = launch_pass(c, fa, false, a, wa, sel, nLimbs, batch, false, stream))
+        return s;
+    if (fhe_status s = launch_pass(c, fa, false, b, wb, sel, nLimbs, batch, false, stream))
+        return s;
+    PolyMulArgs g;
+    const uint32_t grid = fill_pass_args(c, fb, false, wa, wa, sel, nLimbs, batch, true, 0, 0, 0, 0, g.fwd);
+    g.fwd.xcdSwizzle = 0;  // block id = tile: the workspace tile of a block is addressed by its id
+    g.inv = g.fwd;
+    g.aEval = wa;
+    g.lc = c->d_lc;
+#define FHE_PM_A(TT) \
+    if (T2 == TT)    \
+        FHE_LAUNCH((poly_mul_row_a_kernel<TT>), grid, stream, g);
+    FHE_PM_A(12) FHE_PM_A(11) FHE_PM_A(10) FHE_PM_A(9)
+#undef FHE_PM_A
+    LAUNCH_CHECK();
+    fill_pass_args(c, fb, false, wb, wb, sel, nLimbs, batch, true, 0, 0, 0, 0, g.fwd);
+    fill_pass_args(c, ib, true, out, out, sel, nLimbs, batch, false, 0, 0, 0, 0, g.inv);
+    g.fwd.xcdSwizzle = g.inv.xcdSwizzle = 0;
+#define FHE_PM_B(TT) \
+    if (T2 == TT)    \
+        FHE_LAUNCH((poly_mul_row_b_kernel<TT>), grid, stream, g);
+    FHE_PM_B(12) FHE_PM_B(11) FHE_PM_B(10) FHE_PM_B(9)
+#undef FHE_PM_B
+    LAUNCH_CHECK();
+    // inverse column pass: ends the transform (N^-1 folded in, canonical residues)
+    return launch_pass(c, ia, true, out, out, sel, nLimbs, batch, true, stream);
+}
+
 // dir: 0 fwd, 1 inv, 2 fwd then inv; 10/11 = only the column / row pass of the forward transform,
 // 12/13 = only the row / column pass of the inverse (two-pass rings; timing only, data is not meaningful)
 extern "C" fhe_status fhe_time_ntt(fhe_ctx* c, uint64_t* x, const uint32_t* li, uint32_t nl, uint32_t b, int dir,
@@ -775,7 +850,7 @@ extern "C" fhe_status fhe_time_ntt(fhe_ctx* c, uint64_t* x, const uint32_t* li, 
         plan_pass(inv, colPass, c->logN, colPass ? T1 : T2, &pp);
         mark_uniform(pp, c->logN);
         if (!inv) {
-            uint32_t bound = colPass ? 1u : 16u;
+            uint32_t bound = colPass ? 1u : 1u + 2u * T1;  // the row pass sees what the column pass leaves
             schedule_fwd(pp, c->logN, &bound);
             pp.outBound = bound;
         }

@@ -422,9 +422,14 @@ FHE_HD void lane_geom_s(uint32_t t, uint32_t S, uint32_t& Ib, uint32_t& jrel, ui
 // (its top stage is the transform's last stage, with N^-1 folded in), 0 = it does not.
 // One LDS buffer with a barrier on either side of an exchange (34 KiB, 4 workgroups per CU); the double-buffered form
 // (68 KiB, 2 workgroups per CU) was measured slower (profiles/r01_sweeps.md).
-template <bool LA, bool INV, int T, int MODE, bool EPI = false>
-FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) {
+// RAWOUT: the pass ends with its residues in the registers of the last step's lane layout (no staging exchange, no store);
+// RAWIN: the pass starts from residues already in the registers of its first step's lane layout (no load, no staging).
+// Both exist for the fused polynomial product (poly_mul kernels below): a forward row pass whose last step and an inverse
+// row pass whose first step both act on tile bit 0 hold the same 16 consecutive residues per lane.
+template <bool LA, bool INV, int T, int MODE, bool EPI = false, bool RAWIN = false, bool RAWOUT = false>
+FHE_DEV void ntt_static_core(const NttPassArgs& a, uint32_t bid, uint64_t* lds, uint64_t (&r)[16]) {
     using P = SPlan<LA, INV, T>;
+    static_assert(!(RAWIN || RAWOUT) || !LA, "register hand-over exists for row passes only");
     const uint32_t t    = FHE_TID;
     const uint32_t logN = a.logN;
     const uint32_t N    = 1u << logN;
@@ -487,7 +492,6 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
     const uint64_t* src = a.xin + (inRow << logN) + jbase;
     uint64_t* dst       = a.x + (outRow << logN) + jbase;
 
-    uint64_t r[16];
     uint32_t Ib, jrel;
     uint64_t ks;
     // final store of the pass, with the optional fused epilogue (NttPassArgs::epiMode)
@@ -544,7 +548,16 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
     }
 
     // ---- first load ----
-    if constexpr (P::stageFirst) {
+    if constexpr (RAWIN) {
+        FHE_SSYNC();  // every wave has left the previous pass's exchange buffer and shared twiddles
+        if constexpr (useShared) {
+            if (t < (uint32_t)SS::total)
+                sharedLds[t] = TwPair{sharedW, sharedWp};
+            if constexpr (SS::I == 0)
+                FHE_SSYNC();
+        }
+    }
+    else if constexpr (P::stageFirst) {
         lane_geom_s<LA, T, 8>(t, S, Ib, jrel, ks);
 #pragma unroll
         for (int k = 0; k < 16; ++k)
@@ -561,7 +574,10 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
     if constexpr (I < P::nst) {                                                                                   \
         constexpr int fI = P::fI(I);                                                                              \
         lane_geom_s<LA, T, fI>(t, S, Ib, jrel, ks);                                                               \
-        if constexpr (I == 0 && !P::stageFirst) {                                                                 \
+        if constexpr (I == 0 && RAWIN) {                                                                          \
+            /* residues already in r[] in this step's layout */                                                   \
+        }                                                                                                         \
+        else if constexpr (I == 0 && !P::stageFirst) {                                                            \
             _Pragma("unroll") for (int k = 0; k < 16; ++k) r[k] = src[jrel + k * ks];                             \
             FHE_SHARED_TW_TO_LDS()                                                                                \
         }                                                                                                         \
@@ -589,11 +605,14 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
                 }                                                                                                 \
             }                                                                                                     \
         }                                                                                                         \
-        if constexpr (I == P::nst - 1 && !P::stageLast) {                                                         \
+        if constexpr (I == P::nst - 1 && RAWOUT) {                                                                \
+            /* the caller takes the residues from r[] */                                                          \
+        }                                                                                                         \
+        else if constexpr (I == P::nst - 1 && !P::stageLast) {                                                    \
             store_result(r, jrel, ks);                                                                            \
         }                                                                                                         \
         else {                                                                                                    \
-            if constexpr (I > 0 || P::stageFirst)                                                                 \
+            if constexpr (I > 0 || P::stageFirst || RAWIN)                                                        \
                 FHE_SSYNC(); /* every lane has finished reading the buffer */                                      \
             uint64_t* L = lds + lds_pad(Ib);                                                 \
             _Pragma("unroll") for (int k = 0; k < 16; ++k) FHE_LDS_ST(L[lds_pad((uint32_t)k << fI)], r[k]);                  \
@@ -607,7 +626,7 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
 #undef FHE_SHARED_TW_TO_LDS
 
     // ---- last store ----
-    if constexpr (P::stageLast) {
+    if constexpr (P::stageLast && !RAWOUT) {
         lane_geom_s<LA, T, 8>(t, S, Ib, jrel, ks);
         const uint64_t* L = lds + lds_pad(Ib);
 #pragma unroll
@@ -615,6 +634,12 @@ FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) 
             FHE_LDS_LD(r[k], L[lds_pad((uint32_t)k << 8)]);
         store_result(r, jrel, ks);
     }
+}
+
+template <bool LA, bool INV, int T, int MODE, bool EPI = false>
+FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) {
+    uint64_t r[16];
+    ntt_static_core<LA, INV, T, MODE, EPI>(a, bid, lds, r);
 }
 
 template <bool LA, bool INV, int T, int MODE, bool EPI = false>
@@ -627,6 +652,64 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_static_kernel(const NttPassArgs 
     ntt_static_body<LA, INV, T, MODE, EPI>(a, FHE_BID, lds);
 }
 
+
+// ---- fused negacyclic polynomial product  c = a * b  (a, b, c in COEFFICIENT form; SURVEY.md 8(d) "fused fwd o mul o inv") -----
+// Per limb the reference computes INTT(NTT(a) o NTT(b)) with three transforms and a Hadamard product, each a round trip
+// through memory.  Here the contiguous (row) passes are fused around the product:
+//   column pass of a and of b (two launches of the plain column kernel, out of place into the workspace)
+//   poly_mul_row_a_kernel   forward row pass of a; the tile's transform is stored in the last step's lane layout
+//                           (word k*256 + t of the tile = register k of lane t): a private order, fully coalesced
+//   poly_mul_row_b_kernel   forward row pass of b, canonical residues in registers; product with a's transform (same lane
+//                           layout: NTT(a)[i] * NTT(b)[i] for the same i); inverse row pass straight from the registers;
+//                           the forward pass's last exchange and store, the Hadamard kernel and the inverse pass's first
+//                           load and exchange never happen
+//   inverse column pass of c (plain kernel)
+// A forward row pass ends and an inverse row pass begins on tile bit 0, i.e. with the same 16 consecutive residues per lane,
+// which is what makes the register hand-over possible (transformnat-impl.h:352-373 is the forward transform's last, unit-
+// stride stage, :541-567 the inverse's first).
+struct PolyMulArgs {
+    NttPassArgs fwd;       // forward row pass (of a: in place on the workspace; of b: input = the workspace, x unused)
+    NttPassArgs inv;       // inverse row pass into c (poly_mul_row_b_kernel only)
+    uint64_t* aEval;       // workspace of a: [rows][N], tiles in lane layout after poly_mul_row_a_kernel
+    const LimbConst* lc;   // [ctxLimbs] Barrett constants of the product
+};
+template <int T>
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) poly_mul_row_a_kernel(const PolyMulArgs g) {
+    FHE_SHARED_U64(lds, kLdsPadWords + kSharedTwWords);
+    uint64_t r[16];
+    ntt_static_core<false, false, T, 9, false, false, true>(g.fwd, FHE_BID, lds, r);  // canonical (fwd.canonStep set)
+    uint64_t* dst = g.aEval + ((uint64_t)FHE_BID << kTileLog) + FHE_TID;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        dst[(uint32_t)k * kThreads] = r[k];
+}
+template <int T>
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS2(kThreads, 4) poly_mul_row_b_kernel(const PolyMulArgs g) {  // 4 waves per SIMD: <= 128 VGPRs
+    FHE_SHARED_U64(lds, kLdsPadWords + kSharedTwWords);
+    uint64_t r[16];
+    ntt_static_core<false, false, T, 9, false, false, true>(g.fwd, FHE_BID, lds, r);
+    {
+        const uint32_t tilesPerRow = 1u << (g.fwd.logN - (uint32_t)kTileLog);
+        const uint32_t row         = FHE_BID / tilesPerRow;
+        const LimbConst lc         = g.lc[FHE_UNIFORM(g.fwd.sel.idx[row % g.fwd.nLimbs])];
+        const uint64_t* av         = g.aEval + ((uint64_t)FHE_BID << kTileLog) + FHE_TID;
+        // groups of 4 keep the extra live registers small (the kernel must stay within 128 VGPRs: 4 waves per SIMD)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            uint64_t x[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                x[k] = av[(uint32_t)(4 * g4 + k) * kThreads];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                r[4 * g4 + k] = mul_mod_barrett(x[k], r[4 * g4 + k], lc.q, lc.mu, (int)lc.msb);
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" ::: "memory");  // (keeps the next group's loads behind this group's products)
+#endif
+        }
+    }
+    ntt_static_core<false, true, T, 0, false, true, false>(g.inv, FHE_BID, lds, r);
+}
 
 }  // namespace fhe
 #endif

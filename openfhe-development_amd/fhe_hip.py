@@ -80,6 +80,8 @@ class Lib:
         S("fhe_neg", C.c_int, [vp, vp, vp, u32p, u32, u32, vp])
         S("fhe_mul_const", C.c_int, [vp, vp, vp, u64p, u32p, u32, u32, vp])
         S("fhe_mult_acc", C.c_int, [vp, vp, vp, u64p, u32p, u32, u32, vp])
+        S("fhe_poly_mul_workspace_bytes", C.c_size_t, [vp, u32, u32])
+        S("fhe_poly_mul", C.c_int, [vp, vp, vp, vp, u32p, u32, u32, vp, C.c_size_t, vp])
         S("fhe_tensor_square", C.c_int, [vp, vp, vp, vp, vp, vp, u32p, u32, u32, vp])
         S("fhe_mod_up", C.c_int, [vp, vp, C.c_int, vp, u32, vp, C.c_size_t, vp])
         S("fhe_expand_crt_basis_ql_hat", C.c_int, [vp, vp, u32, u64p, u32p, u32, u32, vp, vp])
@@ -333,6 +335,19 @@ class Tower:
         out = self.like()
         self.ctx.lib.check(self.ctx.lib.L.fhe_mul_const(self.ctx.h, out.ptr, self.ptr, consts.ctypes.data_as(u64p),
                                                        self._li(), self.n_limbs, self.batch, stream))
+        return out
+
+    def PolyMul(self, other, stream=None):
+        """negacyclic product of two COEFFICIENT towers (fhe_poly_mul): INTT(NTT(a) o NTT(b)) per limb"""
+        L = self.ctx.lib.L
+        out = self.like()
+        wsb = L.fhe_poly_mul_workspace_bytes(self.ctx.h, self.n_limbs, self.batch)
+        ws = self.ctx.malloc(wsb)
+        try:
+            self.ctx.lib.check(L.fhe_poly_mul(self.ctx.h, self.ptr, other.ptr, out.ptr, self._li(), self.n_limbs, self.batch, ws, wsb, stream))
+            self.ctx.sync(stream)
+        finally:
+            self.ctx.free(ws)
         return out
 
     def Negate(self, stream=None):  # dcrtpoly-impl.h:347-354

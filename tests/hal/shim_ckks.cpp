@@ -5,6 +5,7 @@
 // ciphertext it produces; tests/test_hal_shim.py compares the two dumps byte for byte and checks the decryptions.
 //
 //   shim_ckks <out.bin> <prng.so> <mode> [logN]      mode: leveled | bootstrap
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -100,6 +101,64 @@ int main(int argc, char** argv) {
         show("x*y", cc, kp.secretKey, r, 8);
         show("rot", cc, kp.secretKey, rot2, 8);
         show("final", cc, kp.secretKey, d, 8);
+    }
+    else if (mode == "bootkeys" || mode == "boottime") {
+        // BASELINE configs[3]: benchmark/src/ckks-bootstrapping.cpp:70 {2^17, 2^16 slots, 59, 60, auto digits, 5 levels after,
+        // {4,4}, SPARSE_TERNARY, FLEXIBLEAUTO} (ring overridable).  bootkeys: size of the rotation-key set; boottime: + one timed EvalBootstrap
+        CCParams<CryptoContextCKKSRNS> p;
+        SecretKeyDist skd = SPARSE_TERNARY;
+        p.SetSecretKeyDist(skd);
+        p.SetSecurityLevel(HEStd_NotSet);
+        p.SetRingDim(1u << logN);
+        p.SetScalingTechnique(FLEXIBLEAUTO);
+        p.SetScalingModSize(59);
+        p.SetFirstModSize(60);
+        p.SetKeySwitchTechnique(HYBRID);
+        std::vector<uint32_t> levelBudget = {4, 4};
+        const usint depth = 5 + FHECKKSRNS::GetBootstrapDepth(levelBudget, skd);
+        p.SetMultiplicativeDepth(depth);
+        auto cc = GenCryptoContext(p);
+        cc->Enable(PKE);
+        cc->Enable(KEYSWITCH);
+        cc->Enable(LEVELEDSHE);
+        cc->Enable(ADVANCEDSHE);
+        cc->Enable(FHE);
+        const usint slots = argc > 5 ? std::atoi(argv[5]) : (1u << (logN - 1));
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<double>(b - a).count();
+        };
+        auto t0 = now();
+        cc->EvalBootstrapSetup(levelBudget, {0, 0}, slots, 0, mode == "boottime");
+        std::cout << "setup seconds " << secs(t0, now()) << std::endl;
+        auto kp = cc->KeyGen();
+        cc->EvalMultKeyGen(kp.secretKey);
+        t0 = now();
+        cc->EvalBootstrapKeyGen(kp.secretKey, slots);
+        std::cout << "keygen seconds " << secs(t0, now()) << std::endl;
+        const auto cp  = std::dynamic_pointer_cast<CryptoParametersRNS>(cc->GetCryptoParameters());
+        const auto& km = cc->GetEvalAutomorphismKeyMap(kp.secretKey->GetKeyTag());
+        size_t bytes = 0;
+        for (const auto& kv : km)
+            for (const auto* vec : {&kv.second->GetAVector(), &kv.second->GetBVector()})
+                for (const auto& e : *vec)
+                    bytes += (size_t)e.GetNumOfElements() * e.GetRingDimension() * 8;
+        std::cout << "config4 ring 2^" << logN << " slots " << slots << " depth " << depth << " sizeQ " << cp->GetElementParams()->GetParams().size()
+                  << " sizeP " << cp->GetParamsP()->GetParams().size() << " dnum " << cp->GetNumPartQ() << " rotation keys " << km.size()
+                  << " key set GB " << bytes / 1e9 << std::endl;
+        if (mode == "boottime") {
+            std::vector<double> x = {0.25, 0.5, 0.75, 1.0, 2.0, 3.0, 4.0, 5.0};
+            auto pt = cc->MakeCKKSPackedPlaintext(x, 1, depth - 1, nullptr, slots);
+            auto c  = cc->Encrypt(kp.publicKey, pt);
+            auto b  = cc->EvalBootstrap(c);  // warm-up (tables, plans)
+            const int reps = argc > 6 ? std::atoi(argv[6]) : 1;
+            t0 = now();
+            for (int i = 0; i < reps; ++i)
+                b = cc->EvalBootstrap(c);
+            std::cout << "bootstrap seconds " << secs(t0, now()) / reps << " (" << reps << " reps)" << std::endl;
+            dump("bootstrapped", b);
+            show("bootstrapped", cc, kp.secretKey, b, 8);
+        }
     }
     else {  // CKKS bootstrapping (ckksrns-fhe.cpp:429-760): ModRaise, CoeffsToSlots, Chebyshev sine, SlotsToCoeffs
         CCParams<CryptoContextCKKSRNS> p;

@@ -623,3 +623,34 @@ def test_oversized_digits_are_refused_not_miscomputed(backend, oracle):
     plan = fh.KeySwitchPlan(ctx, 34, 6, 2)  # alpha = 17: fine
     plan.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("logN,L,B", [(5, 2, 2), (12, 2, 2), (13, 3, 2), (14, 2, 1), (15, 1, 2), (16, 2, 1), (17, 1, 1)])
+def test_poly_mul(backend, oracle, logN, L, B):
+    """fhe_poly_mul (c = a * b in Z_q[x]/(x^N + 1), COEFFICIENT in and out) against the oracle's INTT(NTT(a) o NTT(b)); two-pass
+    rings take the fused row kernels (forward row pass of b, Hadamard product and inverse row pass in one kernel)"""
+    o = oracle
+    if is_emu(backend) and logN > 14 and not os.environ.get("FHE_TEST_BIG_EMU"):
+        pytest.skip("emulator: keep the CPU suite short (FHE_TEST_BIG_EMU=1 runs these too)")
+    rng = np.random.default_rng(77)
+    N = 1 << logN
+    q, psi = params(o, logN, L)
+    ctx = fh.Context(backend, logN, q, psi)
+    octx = o.orc_ctx_create(N, L, q, psi)
+    a, b = libs.rand_tower(rng, q, N, B), libs.rand_tower(rng, q, N, B)
+    a[0, :, :2] = 0
+    b[0, :, 1] = q - np.uint64(1)
+    wa, wb = a.copy(), b.copy()
+    o.orc_ntt_fwd_tower(octx, wa, None, L, B, 0)
+    o.orc_ntt_fwd_tower(octx, wb, None, L, B, 0)
+    want = np.empty_like(a)
+    for bb in range(B):
+        for l in range(L):
+            o.orc_vec_mul(want[bb, l], wa[bb, l], wb[bb, l], N, q[l])
+    o.orc_ntt_inv_tower(octx, want, None, L, B, 0)
+    ta, tb = ctx.tower(a, fmt=fh.COEFFICIENT), ctx.tower(b, fmt=fh.COEFFICIENT)
+    got = ta.PolyMul(tb)
+    assert np.array_equal(got.to_host(), want), f"polynomial product logN={logN}"
+    assert np.array_equal(ta.to_host(), a) and np.array_equal(tb.to_host(), b), "operands must not change"
+    o.orc_ctx_destroy(octx)
+    ctx.close()
