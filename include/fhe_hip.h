@@ -117,6 +117,10 @@ fhe_status fhe_mul(fhe_ctx* ctx, uint64_t* out, const uint64_t* a, const uint64_
                    uint32_t nLimbs, uint32_t batch, void* stream);
 fhe_status fhe_neg(fhe_ctx* ctx, uint64_t* out, const uint64_t* a, const uint32_t* limbIdx, uint32_t nLimbs,
                    uint32_t batch, void* stream);
+/* acc += a * b per limb: the accumulation step of KeySwitchHYBRID::EvalFastKeySwitchCoreExt
+ * (src/pke/lib/keyswitch/keyswitch-hybrid.cpp:419-430) on whole towers; exact, so the order of accumulation is free */
+fhe_status fhe_mul_add(fhe_ctx* ctx, uint64_t* acc, const uint64_t* a, const uint64_t* b, const uint32_t* limbIdx,
+                       uint32_t nLimbs, uint32_t batch, void* stream);
 /* Times(const std::vector<NativeInteger>&) / operator*=(NativeInteger) (dcrtpoly-impl.h:582-620):
  * consts[r] (HOST array, one per tower row) multiplies limb r of every tower in the batch.  The constants travel by value
  * in the kernel arguments: the call is asynchronous like every other one and can be captured into a graph; the host

@@ -919,6 +919,13 @@ extern "C" fhe_status fhe_mul(fhe_ctx* c, uint64_t* o, const uint64_t* a, const 
     ARG_CHECK(b, "fhe_mul: null argument");
     return elem_run<OP_MUL>(c, o, a, b, nullptr, li, nl, bt, st, "fhe_mul");
 }
+// acc += a * b per limb (exact): the accumulation of KeySwitchHYBRID::EvalFastKeySwitchCoreExt, keyswitch-hybrid.cpp:419-430
+// (`elements[k].SetElementAtIndex(i, elements[k].GetElementAtIndex(i) + cji * bji)`), on whole towers
+extern "C" fhe_status fhe_mul_add(fhe_ctx* c, uint64_t* acc, const uint64_t* a, const uint64_t* b, const uint32_t* li,
+                                  uint32_t nl, uint32_t bt, void* st) {
+    ARG_CHECK(b, "fhe_mul_add: null argument");
+    return elem_run<OP_MULT_ACC>(c, acc, a, b, nullptr, li, nl, bt, st, "fhe_mul_add");
+}
 extern "C" fhe_status fhe_neg(fhe_ctx* c, uint64_t* o, const uint64_t* a, const uint32_t* li, uint32_t nl, uint32_t bt,
                               void* st) {
     return elem_run<OP_NEG>(c, o, a, nullptr, nullptr, li, nl, bt, st, "fhe_neg");

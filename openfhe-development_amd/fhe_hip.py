@@ -75,7 +75,7 @@ class Lib:
         S("fhe_ntt_inv", C.c_int, [vp, vp, u32p, u32, u32, vp])
         S("fhe_ntt_fwd_oop", C.c_int, [vp, vp, vp, u32p, u32, u32, vp])
         S("fhe_ntt_inv_oop", C.c_int, [vp, vp, vp, u32p, u32, u32, vp])
-        for n in ("fhe_add", "fhe_sub", "fhe_mul"):
+        for n in ("fhe_add", "fhe_sub", "fhe_mul", "fhe_mul_add"):
             S(n, C.c_int, [vp, vp, vp, vp, u32p, u32, u32, vp])
         S("fhe_neg", C.c_int, [vp, vp, vp, u32p, u32, u32, vp])
         S("fhe_mul_const", C.c_int, [vp, vp, vp, u64p, u32p, u32, u32, vp])

@@ -7,9 +7,14 @@
 // a loud failure instead.
 #include "lattice/hal/hip/hip-runtime.h"
 
+#include <cxxabi.h>
 #include <dlfcn.h>
+#include <execinfo.h>
 
+#include <algorithm>
 #include <atomic>
+#include <cstdio>
+#include <vector>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -71,7 +76,7 @@ Runtime* build() {
                   sym(h, "fhe_memcpy_h2d", &a.h2d) && sym(h, "fhe_memcpy_d2h", &a.d2h) && sym(h, "fhe_memcpy_d2d", &a.d2d) &&
                   sym(h, "fhe_stream_sync", &a.sync) && sym(h, "fhe_ntt_fwd", &a.ntt_fwd) && sym(h, "fhe_ntt_inv", &a.ntt_inv) &&
                   sym(h, "fhe_ntt_inv_oop", &a.ntt_inv_oop) && sym(h, "fhe_add", &a.add) && sym(h, "fhe_sub", &a.sub) &&
-                  sym(h, "fhe_mul", &a.mul) && sym(h, "fhe_neg", &a.neg) && sym(h, "fhe_mul_const", &a.mul_const) &&
+                  sym(h, "fhe_mul", &a.mul) && sym(h, "fhe_neg", &a.neg) && sym(h, "fhe_mul_add", &a.mul_add) && sym(h, "fhe_mul_const", &a.mul_const) &&
                   sym(h, "fhe_mult_acc", &a.mult_acc) && sym(h, "fhe_automorph", &a.automorph) &&
                   sym(h, "fhe_switch_modulus", &a.switch_modulus) && sym(h, "fhe_conv_create_custom", &a.conv_create_custom) &&
                   sym(h, "fhe_approx_switch_basis", &a.approx_switch_basis) &&
@@ -106,7 +111,41 @@ void Check(fhe_status s, const char* what) {
         OPENFHE_THROW(std::string(what) + ": " + rt().api.last_error());
 }
 void CountDevice() { rt().deviceOps.fetch_add(1, std::memory_order_relaxed); }
-void CountHost() { rt().hostFallbacks.fetch_add(1, std::memory_order_relaxed); }
+void CountHost() {
+    rt().hostFallbacks.fetch_add(1, std::memory_order_relaxed);
+    // FHE_HAL_TRACE=1: which callers send work to the host mirror (a tuning aid: call sites by frequency at exit)
+    static const bool trace = std::getenv("FHE_HAL_TRACE") != nullptr;
+    if (trace) {
+        static std::mutex mu;
+        static std::map<std::string, uint64_t>* sites = nullptr;
+        void* bt[6];
+        const int n = backtrace(bt, 6);
+        std::string key;
+        for (int i = 2; i < n; ++i) {
+            Dl_info info;
+            if (dladdr(bt[i], &info) && info.dli_sname) {
+                int st = 0;
+                char* dm = abi::__cxa_demangle(info.dli_sname, nullptr, nullptr, &st);
+                std::string nm = dm ? dm : info.dli_sname;
+                free(dm);
+                key += nm.substr(0, nm.find('(')).substr(0, 70) + " <- ";
+            }
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        if (!sites) {
+            sites = new std::map<std::string, uint64_t>;
+            std::atexit([] {
+                std::vector<std::pair<uint64_t, std::string>> v;
+                for (auto& kv : *sites)
+                    v.emplace_back(kv.second, kv.first);
+                std::sort(v.rbegin(), v.rend());
+                for (size_t i = 0; i < v.size() && i < 25; ++i)
+                    fprintf(stderr, "hal host site %8lu  %s\n", (unsigned long)v[i].first, v[i].second.c_str());
+            });
+        }
+        ++(*sites)[key];
+    }
+}
 void CountH2D(size_t b) { rt().h2dBytes.fetch_add(b, std::memory_order_relaxed); }
 void CountD2H(size_t b) { rt().d2hBytes.fetch_add(b, std::memory_order_relaxed); }
 

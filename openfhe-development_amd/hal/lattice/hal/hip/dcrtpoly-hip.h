@@ -22,6 +22,7 @@
 #ifndef LBCRYPTO_INC_LATTICE_HAL_HIP_DCRTPOLY_HIP_H
 #define LBCRYPTO_INC_LATTICE_HAL_HIP_DCRTPOLY_HIP_H
 
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -178,8 +179,10 @@ public:
             Hm() *= rhs.Hc();
         return *this;
     }
-    DCRTPolyType& operator*=(const Integer& rhs) override {
-        Hm() *= rhs;
+    DCRTPolyType& operator*=(const Integer& rhs) override {  // dcrtpoly-impl.h:604-611: NativeInteger val{rhs}, every limb *= val
+        std::vector<NativeInteger> c(NumLimbs(), NativeInteger{rhs});
+        if (!TimesConstInPlace(c))
+            Hm() *= rhs;
         return *this;
     }
     DCRTPolyType& operator*=(const NativeInteger& rhs) override {
@@ -265,10 +268,22 @@ public:
             return out;
         return Wrap(Hc().Times(rhs.Hc()));
     }
-    DCRTPolyType Times(const Integer& rhs) const override {
+    DCRTPolyType Times(const Integer& rhs) const override {  // dcrtpoly-impl.h:551-559
+        DCRTPolyType out(*this);
+        std::vector<NativeInteger> c(NumLimbs(), NativeInteger{rhs});
+        if (out.TimesConstInPlace(c))
+            return out;
         return Wrap(Hc().Times(rhs));
     }
-    DCRTPolyType Times(const std::vector<Integer>& rhs) const {
+    DCRTPolyType Times(const std::vector<Integer>& rhs) const {  // dcrtpoly-impl.h:572-580: limb i times NativeInteger(rhs[i])
+        if (rhs.size() >= NumLimbs()) {
+            std::vector<NativeInteger> c(NumLimbs());
+            for (uint32_t i = 0; i < NumLimbs(); ++i)
+                c[i] = NativeInteger(rhs[i]);
+            DCRTPolyType out(*this);
+            if (out.TimesConstInPlace(c))
+                return out;
+        }
         return Wrap(Hc().Times(rhs));
     }
     DCRTPolyType Times(NativeInteger::SignedNativeInt rhs) const override {
@@ -562,6 +577,75 @@ public:
         Hm().SetElementAtIndex(index, std::move(element));
     }
 
+    // ---- row-level helpers for the backend's own overrides of pke's limb loops (keyswitch/keyswitch-hybrid.h in this directory) --
+    // A piece = rows [first, first + n) of `src` (nullptr: n rows of zeros).  The pieces, laid out one after the other, become
+    // the limbs of a new tower over `params` in format `f` — what pke writes as a loop of
+    // `result.SetElementAtIndex(i, src.GetElementAtIndex(j))` (keyswitch-hybrid.cpp:356-376, :228-237).
+    struct RowPiece {
+        const DCRTPolyType* src;
+        uint32_t first, n;
+    };
+    static DCRTPolyType AssembleRows(const std::shared_ptr<Params>& params, Format f, const std::vector<RowPiece>& pieces) {
+        const size_t N   = params->GetRingDimension();
+        uint32_t total   = 0;
+        bool deviceOk    = hiprt::Available();
+        for (const auto& pc : pieces) {
+            total += pc.n;
+            if (pc.src && (pc.first + pc.n > pc.src->NumLimbs()))
+                OPENFHE_THROW("AssembleRows: row range outside the source tower");
+        }
+        if (total != params->GetParams().size())
+            OPENFHE_THROW("AssembleRows: pieces do not cover the parameter set");
+        hiprt::Resolved r;
+        deviceOk = deviceOk && ResolveSets(params->GetRingDimension(), {params}, &r);
+        for (const auto& pc : pieces)
+            if (deviceOk && pc.src)
+                deviceOk = pc.src->Upload(r.ctx);
+        if (deviceOk) {
+            auto d      = hiprt::Alloc((size_t)total * N);
+            uint32_t at = 0;
+            for (const auto& pc : pieces) {
+                if (pc.src)
+                    hiprt::Check(hiprt::api().d2d(r.ctx, d->p + (size_t)at * N, pc.src->m_d->p + (size_t)pc.first * N, (size_t)pc.n * N * 8, nullptr),
+                                 "AssembleRows");
+                else if (pc.n)
+                    ZeroRows(r.ctx, d->p + (size_t)at * N, (size_t)pc.n * N);
+                at += pc.n;
+            }
+            hiprt::CountDevice();
+            return FromDevice(params, f, std::move(d));
+        }
+        DCRTPolyType out(params, f, true);  // host: the reference's own loop
+        uint32_t at = 0;
+        for (const auto& pc : pieces) {
+            for (uint32_t i = 0; i < pc.n; ++i, ++at)
+                if (pc.src)
+                    out.m_h.SetElementAtIndex(at, pc.src->Hc().GetElementAtIndex(pc.first + i));
+        }
+        hiprt::CountHost();
+        return out;
+    }
+    // this[outFirst + i] += a[aFirst + i] * b[bFirst + i], i < n, EVALUATION — the accumulation of EvalFastKeySwitchCoreExt
+    // (keyswitch-hybrid.cpp:419-430) on whole row ranges
+    void MultAccRows(uint32_t outFirst, const DCRTPolyType& a, uint32_t aFirst, const DCRTPolyType& b, uint32_t bFirst, uint32_t n) {
+        if (outFirst + n > NumLimbs() || aFirst + n > a.NumLimbs() || bFirst + n > b.NumLimbs())
+            OPENFHE_THROW("MultAccRows: row range outside a tower");
+        hiprt::Resolved r;
+        if (OnDevice(&r) && a.Upload(r.ctx) && b.Upload(r.ctx)) {
+            const size_t N = m_h.GetParams()->GetRingDimension();
+            hiprt::Check(hiprt::api().mul_add(r.ctx, m_d->p + (size_t)outFirst * N, a.m_d->p + (size_t)aFirst * N, b.m_d->p + (size_t)bFirst * N,
+                                              r.idx[0].data() + outFirst, n, 1, nullptr),
+                         "MultAccRows");
+            hiprt::CountDevice();
+            DeviceIsNewer(m_h.GetFormat());
+            return;
+        }
+        HostType& h = Hm();
+        for (uint32_t i = 0; i < n; ++i)
+            h.SetElementAtIndex(outFirst + i, h.GetElementAtIndex(outFirst + i) +
+                                                  a.Hc().GetElementAtIndex(aFirst + i) * b.Hc().GetElementAtIndex(bFirst + i));
+    }
+
     // the host mirror (synchronised), for code that wants the default implementation's object
     const HostType& Host() const {
         return Hc();
@@ -648,6 +732,20 @@ private:
         hiprt::Resolved r;
         ResolveSets(p->GetRingDimension(), {p}, &r);
         return r.ctx;
+    }
+    static void ZeroRows(fhe_ctx* c, uint64_t* p, size_t words) {
+        // (the C ABI has no memset: a zero tower is uploaded once per size and copied on the device)
+        static std::mutex mu;
+        static hiprt::Buf zeros;
+        std::lock_guard<std::mutex> lk(mu);
+        if (!zeros || zeros->words < words) {
+            std::vector<uint64_t> z(words, 0);
+            auto b = hiprt::Alloc(words);
+            hiprt::Check(hiprt::api().h2d(c, b->p, z.data(), words * 8, nullptr), "zero rows");
+            hiprt::Check(hiprt::api().sync(c, nullptr), "zero rows");
+            zeros = std::move(b);
+        }
+        hiprt::Check(hiprt::api().d2d(c, p, zeros->p, words * 8, nullptr), "zero rows");
     }
     // host words valid (fills the mirror from the device if needed)
     void SyncHost() const {
@@ -802,8 +900,10 @@ private:
                              const std::vector<NativeInteger>& QHatInvModq, const std::vector<std::vector<NativeInteger>>& QHatModp,
                              const std::vector<std::vector<NativeInteger>>* alpha, const std::vector<double>* qInv,
                              DCRTPolyType* out, bool transposed = false) const {
-        const uint32_t sizeQ = NumLimbs(), sizeP = (uint32_t)paramsP->GetParams().size();
-        if (sizeQ == 0 || sizeQ > 32 || sizeP == 0 || sizeQ != paramsQ->GetParams().size() || QHatInvModq.size() < sizeQ)
+        // (:892: sizeQ = min(limbs of this tower, limbs of paramsQ) — the last digit of a lower level is shorter than its params)
+        const uint32_t sizeQ = std::min<uint32_t>(NumLimbs(), (uint32_t)paramsQ->GetParams().size());
+        const uint32_t sizeP = (uint32_t)paramsP->GetParams().size();
+        if (sizeQ == 0 || sizeQ > 32 || sizeP == 0 || sizeQ != NumLimbs() || QHatInvModq.size() < sizeQ)
             return false;
         if ((transposed ? QHatModp.size() < sizeP : QHatModp.size() < sizeQ))
             return false;

@@ -33,6 +33,7 @@ struct Api {
     decltype(&fhe_sub) sub;
     decltype(&fhe_mul) mul;
     decltype(&fhe_neg) neg;
+    decltype(&fhe_mul_add) mul_add;
     decltype(&fhe_mul_const) mul_const;
     decltype(&fhe_mult_acc) mult_acc;
     decltype(&fhe_automorph) automorph;

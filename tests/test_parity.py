@@ -136,6 +136,16 @@ def test_elementwise(backend, oracle):
             for l in range(L):
                 o.orc_vec_neg(want[bb, l], a[bb, l], N, q[l])
         assert np.array_equal(ta.Negate().to_host(), want)
+        # fhe_mul_add: acc += a * b (the key-switch inner product's accumulation, keyswitch-hybrid.cpp:419-430)
+        acc = libs.rand_tower(rng, q, N, B)
+        want = np.empty_like(a)
+        for bb in range(B):
+            for l in range(L):
+                o.orc_vec_mul(want[bb, l], a[bb, l], b[bb, l], N, q[l])
+                o.orc_vec_add(want[bb, l], want[bb, l], acc[bb, l], N, q[l])
+        tacc = ctx.tower(acc)
+        backend.check(backend.L.fhe_mul_add(ctx.h, tacc.ptr, ta.ptr, tb.ptr, None, L, B, None))
+        assert np.array_equal(tacc.to_host(), want)
         ctx.close()
 
 
