@@ -105,6 +105,17 @@ size_t     fhe_poly_mul_workspace_bytes(const fhe_ctx* ctx, uint32_t nLimbs, uin
 fhe_status fhe_poly_mul(fhe_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, const uint32_t* limbIdx,
                         uint32_t nLimbs, uint32_t batch, void* ws, size_t wsBytes, void* stream);
 
+/* DCRTPolyImpl::Plus(const std::vector<Integer>&) (dcrtpoly-impl.h:520-527): limb i plus the constant consts[i] (reduced mod
+ * q_i first) — PolyImpl::Plus(Integer) (poly-impl.h:211-218) adds it to every word in EVALUATION and to coefficient 0 only in
+ * COEFFICIENT (coeff0Only != 0).  This is what LeveledSHECKKSRNS::EvalAddInPlace(ciphertext, double)
+ * (ckksrns-leveledshe.cpp:60-68) does to element 0.  out may alias a; constants travel by value (asynchronous). */
+fhe_status fhe_add_const(fhe_ctx* ctx, uint64_t* out, const uint64_t* a, const uint64_t* consts, const uint32_t* limbIdx,
+                         uint32_t nLimbs, uint32_t batch, int coeff0Only, void* stream);
+/* DCRTPolyImpl::Minus(const std::vector<Integer>&) (dcrtpoly-impl.h:541-548 -> poly-impl.h:221-225: ModSub on every word, in
+ * both formats); EvalSubInPlace(ciphertext, double) (ckksrns-leveledshe.cpp:112-120) */
+fhe_status fhe_sub_const(fhe_ctx* ctx, uint64_t* out, const uint64_t* a, const uint64_t* consts, const uint32_t* limbIdx,
+                         uint32_t nLimbs, uint32_t batch, void* stream);
+
 /* ---- a7: element-wise tower arithmetic -----------------------------------------------------------
  * Replaces DCRTPolyImpl::operator+= / -= / *= , Plus/Minus/Times, Negate
  * (dcrtpoly-impl.h:347-408, dcrtpoly.h:131-189) and NativeVectorT::ModAddEq/ModSubEq/ModMulEq

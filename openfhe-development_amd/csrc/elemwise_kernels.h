@@ -36,6 +36,8 @@ enum ElemOp : int {
     OP_MULT_ACC = 7,   // out = out + a * b        (inner-product accumulate)
     OP_COPY = 8,
     OP_SUB_MUL_CONST_ACC = 9,  // out = out + (a - b) * c[row]   (ApproxModDown tail fused with EvalMult's `+= ks`)
+    OP_ADD_CONST = 10,     // out = a + c[row]         (PolyImpl::Plus(Integer) in EVALUATION / Minus(Integer) with c = q - c)
+    OP_ADD_CONST_AT0 = 11, // out = a + c[row] at coefficient 0 only (PolyImpl::Plus(Integer) in COEFFICIENT, poly-impl.h:213-214)
 };
 
 struct ElemArgs {
@@ -73,6 +75,9 @@ FHE_HD uint64_t elem_apply(uint64_t o, uint64_t a, uint64_t b, const LimbConst l
             return add_mod(o, mul_mod_barrett(a, b, q, lc.mu, (int)lc.msb), q);
         case OP_SUB_MUL_CONST_ACC:
             return add_mod(o, mul_shoup(sub_mod(a, b, q), c.w, c.wp, q), q);
+        case OP_ADD_CONST:
+        case OP_ADD_CONST_AT0:
+            return add_mod(a, c.w, q);
         default:
             return a;
     }
@@ -91,7 +96,8 @@ FHE_DEV void elemwise_body(const ElemArgs& g, ConstAt constAt) {
     const uint64_t totalWords = (uint64_t)g.rows << g.logN;
     constexpr bool needB = (OP == OP_ADD || OP == OP_SUB || OP == OP_MUL || OP == OP_SUB_MUL_CONST ||
                             OP == OP_MUL_CONST_ADD || OP == OP_MULT_ACC || OP == OP_SUB_MUL_CONST_ACC);
-    constexpr bool needC = (OP == OP_MUL_CONST || OP == OP_SUB_MUL_CONST || OP == OP_MUL_CONST_ADD || OP == OP_SUB_MUL_CONST_ACC);
+    constexpr bool needC = (OP == OP_MUL_CONST || OP == OP_SUB_MUL_CONST || OP == OP_MUL_CONST_ADD || OP == OP_SUB_MUL_CONST_ACC ||
+                            OP == OP_ADD_CONST || OP == OP_ADD_CONST_AT0);
     constexpr bool needO = (OP == OP_MULT_ACC || OP == OP_SUB_MUL_CONST_ACC);
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -118,6 +124,11 @@ FHE_DEV void elemwise_body(const ElemArgs& g, ConstAt constAt) {
         if (needO) {
             o0 = g.out[ooff];
             o1 = g.out[ooff + 1];
+        }
+        if (OP == OP_ADD_CONST_AT0) {  // (off is even: only the first word of the pair can be coefficient 0)
+            g.out[ooff]     = elem_apply<OP>(o0, a0, b0, lc, ri == 0 ? c : TwPair{0, 0});
+            g.out[ooff + 1] = a1;
+            continue;
         }
         g.out[ooff]     = elem_apply<OP>(o0, a0, b0, lc, c);
         g.out[ooff + 1] = elem_apply<OP>(o1, a1, b1, lc, c);

@@ -972,6 +972,30 @@ extern "C" fhe_status fhe_mul_const(fhe_ctx* c, uint64_t* o, const uint64_t* a, 
         return s;
     return elem_cv_run<OP_MUL_CONST>(c, o, a, nullptr, cv, li, nl, bt, st, "fhe_mul_const");
 }
+// DCRTPolyImpl::Plus(vector<Integer>) (dcrtpoly-impl.h:520-527 -> PolyImpl::Plus(Integer), poly-impl.h:211-218): limb i plus the
+// constant polynomial consts[i] — every word in EVALUATION, coefficient 0 only in COEFFICIENT (coeff0Only)
+extern "C" fhe_status fhe_add_const(fhe_ctx* c, uint64_t* o, const uint64_t* a, const uint64_t* consts, const uint32_t* li,
+                                    uint32_t nl, uint32_t bt, int coeff0Only, void* st) {
+    ConstVec cv;
+    if (fhe_status s = make_const_vec(c, consts, li, nl, &cv, "fhe_add_const"))
+        return s;
+    if (coeff0Only)
+        return elem_cv_run<OP_ADD_CONST_AT0>(c, o, a, nullptr, cv, li, nl, bt, st, "fhe_add_const");
+    return elem_cv_run<OP_ADD_CONST>(c, o, a, nullptr, cv, li, nl, bt, st, "fhe_add_const");
+}
+// DCRTPolyImpl::Minus(vector<Integer>) (dcrtpoly-impl.h:541-548 -> PolyImpl::Minus(Integer), poly-impl.h:221-225: ModSub on
+// every word in both formats)
+extern "C" fhe_status fhe_sub_const(fhe_ctx* c, uint64_t* o, const uint64_t* a, const uint64_t* consts, const uint32_t* li,
+                                    uint32_t nl, uint32_t bt, void* st) {
+    ConstVec cv;
+    if (fhe_status s = make_const_vec(c, consts, li, nl, &cv, "fhe_sub_const"))
+        return s;
+    for (uint32_t i = 0; i < nl; ++i) {  // a - k = a + (q - k)
+        const uint64_t ql = c->q[li ? li[i] : i], k = cv.c[i].w;
+        cv.c[i]           = TwPair{k ? ql - k : 0, 0};
+    }
+    return elem_cv_run<OP_ADD_CONST>(c, o, a, nullptr, cv, li, nl, bt, st, "fhe_sub_const");
+}
 // NativeVectorT::MultAccEqNoCheck per limb (mubintvecnat.cpp:132-142): acc[r] += v[r] * I[r]  (I reduced first, Shoup
 // product, ModAddFastEq)
 extern "C" fhe_status fhe_mult_acc(fhe_ctx* c, uint64_t* acc, const uint64_t* v, const uint64_t* consts,

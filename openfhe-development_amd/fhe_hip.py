@@ -80,6 +80,8 @@ class Lib:
         S("fhe_neg", C.c_int, [vp, vp, vp, u32p, u32, u32, vp])
         S("fhe_mul_const", C.c_int, [vp, vp, vp, u64p, u32p, u32, u32, vp])
         S("fhe_mult_acc", C.c_int, [vp, vp, vp, u64p, u32p, u32, u32, vp])
+        S("fhe_add_const", C.c_int, [vp, vp, vp, u64p, u32p, u32, u32, C.c_int, vp])
+        S("fhe_sub_const", C.c_int, [vp, vp, vp, u64p, u32p, u32, u32, vp])
         S("fhe_poly_mul_workspace_bytes", C.c_size_t, [vp, u32, u32])
         S("fhe_poly_mul", C.c_int, [vp, vp, vp, vp, u32p, u32, u32, vp, C.c_size_t, vp])
         S("fhe_tensor_square", C.c_int, [vp, vp, vp, vp, vp, vp, u32p, u32, u32, vp])

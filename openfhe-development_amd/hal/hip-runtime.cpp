@@ -77,7 +77,7 @@ Runtime* build() {
                   sym(h, "fhe_stream_sync", &a.sync) && sym(h, "fhe_ntt_fwd", &a.ntt_fwd) && sym(h, "fhe_ntt_inv", &a.ntt_inv) &&
                   sym(h, "fhe_ntt_inv_oop", &a.ntt_inv_oop) && sym(h, "fhe_add", &a.add) && sym(h, "fhe_sub", &a.sub) &&
                   sym(h, "fhe_mul", &a.mul) && sym(h, "fhe_neg", &a.neg) && sym(h, "fhe_mul_add", &a.mul_add) && sym(h, "fhe_mul_const", &a.mul_const) &&
-                  sym(h, "fhe_mult_acc", &a.mult_acc) && sym(h, "fhe_automorph", &a.automorph) &&
+                  sym(h, "fhe_mult_acc", &a.mult_acc) && sym(h, "fhe_add_const", &a.add_const) && sym(h, "fhe_sub_const", &a.sub_const) && sym(h, "fhe_automorph", &a.automorph) &&
                   sym(h, "fhe_switch_modulus", &a.switch_modulus) && sym(h, "fhe_conv_create_custom", &a.conv_create_custom) &&
                   sym(h, "fhe_approx_switch_basis", &a.approx_switch_basis) &&
                   sym(h, "fhe_switch_basis_exact", &a.switch_basis_exact);
@@ -111,43 +111,55 @@ void Check(fhe_status s, const char* what) {
         OPENFHE_THROW(std::string(what) + ": " + rt().api.last_error());
 }
 void CountDevice() { rt().deviceOps.fetch_add(1, std::memory_order_relaxed); }
-void CountHost() {
-    rt().hostFallbacks.fetch_add(1, std::memory_order_relaxed);
-    // FHE_HAL_TRACE=1: which callers send work to the host mirror (a tuning aid: call sites by frequency at exit)
+static std::mutex g_traceMutex;
+static std::map<std::string, uint64_t>* g_traceSites = nullptr;
+// FHE_HAL_TRACE=1: which callers send work to the host mirror or move words over PCIe (a tuning aid: call sites by
+// frequency / by bytes at exit)
+static thread_local const char* t_member = nullptr;
+void TraceMember(const char* member) { t_member = member; }
+static void trace_site(const char* kind, const char* member, uint64_t amount) {
     static const bool trace = std::getenv("FHE_HAL_TRACE") != nullptr;
-    if (trace) {
-        static std::mutex mu;
-        static std::map<std::string, uint64_t>* sites = nullptr;
-        void* bt[6];
-        const int n = backtrace(bt, 6);
-        std::string key;
-        for (int i = 2; i < n; ++i) {
-            Dl_info info;
-            if (dladdr(bt[i], &info) && info.dli_sname) {
-                int st = 0;
-                char* dm = abi::__cxa_demangle(info.dli_sname, nullptr, nullptr, &st);
-                std::string nm = dm ? dm : info.dli_sname;
-                free(dm);
-                key += nm.substr(0, nm.find('(')).substr(0, 70) + " <- ";
-            }
+    if (!trace)
+        return;
+    void* bt[8];
+    const int n     = backtrace(bt, 8);
+    std::string key = std::string(kind) + " " + (member ? member : (t_member ? t_member : "")) + " <- ";
+    for (int i = 3; i < n; ++i) {
+        Dl_info info;
+        if (dladdr(bt[i], &info) && info.dli_sname) {
+            int st      = 0;
+            char* dm    = abi::__cxa_demangle(info.dli_sname, nullptr, nullptr, &st);
+            std::string nm = dm ? dm : info.dli_sname;
+            free(dm);
+            key += nm.substr(0, nm.find('(')).substr(0, 60) + " <- ";
         }
-        std::lock_guard<std::mutex> lk(mu);
-        if (!sites) {
-            sites = new std::map<std::string, uint64_t>;
-            std::atexit([] {
-                std::vector<std::pair<uint64_t, std::string>> v;
-                for (auto& kv : *sites)
-                    v.emplace_back(kv.second, kv.first);
-                std::sort(v.rbegin(), v.rend());
-                for (size_t i = 0; i < v.size() && i < 25; ++i)
-                    fprintf(stderr, "hal host site %8lu  %s\n", (unsigned long)v[i].first, v[i].second.c_str());
-            });
-        }
-        ++(*sites)[key];
     }
+    std::lock_guard<std::mutex> lk(g_traceMutex);
+    if (!g_traceSites) {
+        g_traceSites = new std::map<std::string, uint64_t>;
+        std::atexit([] {
+            std::vector<std::pair<uint64_t, std::string>> v;
+            for (auto& kv : *g_traceSites)
+                v.emplace_back(kv.second, kv.first);
+            std::sort(v.rbegin(), v.rend());
+            for (size_t i = 0; i < v.size() && i < 400; ++i)
+                fprintf(stderr, "hal trace %12lu  %s\n", (unsigned long)v[i].first, v[i].second.c_str());
+        });
+    }
+    (*g_traceSites)[key] += amount;
 }
-void CountH2D(size_t b) { rt().h2dBytes.fetch_add(b, std::memory_order_relaxed); }
-void CountD2H(size_t b) { rt().d2hBytes.fetch_add(b, std::memory_order_relaxed); }
+void CountHost(const char* member) {
+    rt().hostFallbacks.fetch_add(1, std::memory_order_relaxed);
+    trace_site("hostop", member, 1);
+}
+void CountH2D(size_t b) {
+    rt().h2dBytes.fetch_add(b, std::memory_order_relaxed);
+    trace_site("h2dBytes", nullptr, b);
+}
+void CountD2H(size_t b) {
+    rt().d2hBytes.fetch_add(b, std::memory_order_relaxed);
+    trace_site("d2hBytes", nullptr, b);
+}
 
 // ---- allocator ----
 static size_t bucket_of(size_t words) {
@@ -304,3 +316,8 @@ extern "C" void fhe_hal_stats(uint64_t out[4]) {
     out[0] = r.deviceOps, out[1] = r.hostFallbacks, out[2] = r.h2dBytes, out[3] = r.d2hBytes;
 }
 extern "C" int fhe_hal_available(void) { return lbcrypto::hiprt::Available() ? 1 : 0; }
+extern "C" void fhe_hal_trace_reset(void) {
+    std::lock_guard<std::mutex> lk(lbcrypto::hiprt::g_traceMutex);
+    if (lbcrypto::hiprt::g_traceSites)
+        lbcrypto::hiprt::g_traceSites->clear();
+}

@@ -168,4 +168,42 @@ Ciphertext<DCRTPoly> LeveledSHECKKSRNS::EvalFastRotationExt(ConstCiphertext<DCRT
     return result;
 }
 
+// ---- scalar operations of CKKS: LeveledSHECKKSRNS::EvalAddInPlace / EvalSubInPlace(ciphertext, double)
+// (ckksrns-leveledshe.cpp:60-68, :112-120) and EvalMultCoreInPlace(ciphertext, double) (:748-759), hooked the same way.  The
+// reference reads the moduli from the LIMB OBJECTS of element 0 (GetElementForEvalAddOrSub :219-224, GetElementForEvalMult
+// :445-449), which would pull the whole element over PCIe for its metadata, and adds the constants in a loop over host limbs.
+// Here the reference's own GetElementFor* runs on a ciphertext that carries the same metadata and an element of the same
+// shape without words, and the constants are applied to the device tower (DCRTPoly::Plus / Minus / Times(vector<Integer>) =
+// the same per-limb NativeInteger arithmetic, dcrtpoly-impl.h:520-548, :572-580). ----
+static ConstCiphertext<DCRTPoly> ShapeOf(const Ciphertext<DCRTPoly>& ciphertext) {
+    const auto& e0 = ciphertext->GetElements()[0];
+    auto shape     = ciphertext->CloneEmpty();
+    std::vector<DCRTPoly> elements;
+    elements.emplace_back(e0.GetParams(), e0.GetFormat(), false);
+    shape->SetElements(std::move(elements));
+    return shape;
+}
+
+void LeveledSHECKKSRNS::EvalAddInPlace(Ciphertext<DCRTPoly>& ciphertext, double operand) const {
+    const auto elmnts = GetElementForEvalAddOrSub(ShapeOf(ciphertext), operand);
+    auto& cv          = ciphertext->GetElements();
+    cv[0]             = cv[0].Plus(elmnts);
+}
+
+void LeveledSHECKKSRNS::EvalSubInPlace(Ciphertext<DCRTPoly>& ciphertext, double operand) const {
+    const auto elmnts = GetElementForEvalAddOrSub(ShapeOf(ciphertext), operand);
+    auto& cv          = ciphertext->GetElements();
+    cv[0]             = cv[0].Minus(elmnts);
+}
+
+void LeveledSHECKKSRNS::EvalMultCoreInPlace(Ciphertext<DCRTPoly>& ciphertext, double operand) const {
+    const auto factors = GetElementForEvalMult(ShapeOf(ciphertext), operand);
+    auto& cv           = ciphertext->GetElements();
+    for (uint32_t i = 0; i < cv.size(); ++i)
+        cv[i] = cv[i] * factors;
+    ciphertext->SetNoiseScaleDeg(ciphertext->GetNoiseScaleDeg() + 1);
+    const auto cryptoParams = std::dynamic_pointer_cast<CryptoParametersCKKSRNS>(ciphertext->GetCryptoParameters());
+    ciphertext->SetScalingFactor(ciphertext->GetScalingFactor() * cryptoParams->GetScalingFactorReal(ciphertext->GetLevel()));
+}
+
 }  // namespace lbcrypto

@@ -69,11 +69,12 @@ public:
         return *this;
     }
     DCRTPolyHipImpl(DCRTPolyType&& e) noexcept
-        : m_h{std::move(e.m_h)}, m_d{std::move(e.m_d)}, m_hostValid{e.m_hostValid} {}
+        : m_h{std::move(e.m_h)}, m_d{std::move(e.m_d)}, m_hostValid{e.m_hostValid}, m_zero{e.m_zero} {}
     DCRTPolyType& operator=(DCRTPolyType&& rhs) noexcept override {
         m_h         = std::move(rhs.m_h);
         m_d         = std::move(rhs.m_d);
         m_hostValid = rhs.m_hostValid;
+        m_zero      = rhs.m_zero;
         return *this;
     }
     explicit DCRTPolyHipImpl(HostType&& h) noexcept : m_h{std::move(h)} {}
@@ -94,9 +95,16 @@ public:
         return *this;
     }
     explicit DCRTPolyHipImpl(const std::vector<PolyType>& elements) : m_h{elements} {}
+    // a zero tower stays unmaterialised (m_zero) until its first use decides where it lives: accumulators of the evaluation
+    // path (`DCRTPoly first(params, EVALUATION, true); first += ...`) never cross PCIe
     DCRTPolyHipImpl(const std::shared_ptr<Params>& params, Format format = Format::EVALUATION,
                     bool initializeElementToZero = false) noexcept
-        : m_h{params, format, initializeElementToZero} {}
+        : m_h{params, format, initializeElementToZero && !hiprt::Available()} {
+        if (initializeElementToZero && hiprt::Available()) {
+            m_hostValid = false;
+            m_zero      = true;
+        }
+    }
     DCRTPolyHipImpl(const DggType& dgg, const std::shared_ptr<Params>& p, Format f = Format::EVALUATION) : m_h{dgg, p, f} {}
     DCRTPolyHipImpl(const BugType& bug, const std::shared_ptr<Params>& p, Format f = Format::EVALUATION) : m_h{bug, p, f} {}
     DCRTPolyHipImpl(const TugType& tug, const std::shared_ptr<Params>& p, Format f = Format::EVALUATION, uint32_t h = 0)
@@ -241,7 +249,10 @@ public:
     DCRTPolyType Plus(const Integer& rhs) const override {
         return Wrap(Hc().Plus(rhs));
     }
-    DCRTPolyType Plus(const std::vector<Integer>& rhs) const {
+    DCRTPolyType Plus(const std::vector<Integer>& rhs) const {  // dcrtpoly-impl.h:520-527
+        DCRTPolyType out;
+        if (AddConstOnDevice(rhs, false, &out))
+            return out;
         return Wrap(Hc().Plus(rhs));
     }
     DCRTPolyType Plus(const DCRTPolyType& rhs) const override {
@@ -259,7 +270,10 @@ public:
     DCRTPolyType Minus(const Integer& rhs) const override {
         return Wrap(Hc().Minus(rhs));
     }
-    DCRTPolyType Minus(const std::vector<Integer>& rhs) const {
+    DCRTPolyType Minus(const std::vector<Integer>& rhs) const {  // dcrtpoly-impl.h:541-548
+        DCRTPolyType out;
+        if (AddConstOnDevice(rhs, true, &out))
+            return out;
         return Wrap(Hc().Minus(rhs));
     }
     DCRTPolyType Times(const DCRTPolyType& rhs) const override {
@@ -319,10 +333,19 @@ public:
         return Hc().InverseExists();
     }
     bool IsEmpty() const override {
-        return (m_d && !m_hostValid) ? false : m_h.IsEmpty();
+        return (m_zero || (m_d && !m_hostValid)) ? false : m_h.IsEmpty();
     }
 
     void SetValuesToZero() override {
+        if (hiprt::Available() && m_h.GetParams() && NumLimbs() == m_h.GetParams()->GetParams().size()) {
+            std::lock_guard<std::mutex> lk(m_lock.m);
+            auto P      = m_h.GetParams();
+            m_h         = HostType(P, m_h.GetFormat(), false);
+            m_d.reset();
+            m_hostValid = false;
+            m_zero      = true;
+            return;
+        }
         Hm().SetValuesToZero();
     }
     void AddILElementOne() override {
@@ -542,6 +565,7 @@ public:
     void load(Archive& ar, std::uint32_t const version) {
         m_d.reset();
         m_hostValid = true;
+        m_zero      = false;
         m_h.load(ar, version);
     }
     static const std::string GetElementName() {
@@ -564,6 +588,9 @@ public:
         return m_h.GetParams();
     }
     // the limbs as host objects: filled from the device on demand (const) / the device copy is dropped (mutable access)
+    usint GetNumOfElements() const {  // (the interface's version reaches GetAllElements(): a device -> host copy for a count)
+        return NumLimbs();
+    }
     const std::vector<PolyType>& GetAllElements() const {
         return Hc().GetAllElements();
     }
@@ -622,7 +649,7 @@ public:
                 if (pc.src)
                     out.m_h.SetElementAtIndex(at, pc.src->Hc().GetElementAtIndex(pc.first + i));
         }
-        hiprt::CountHost();
+        hiprt::CountHost("AssembleRows");
         return out;
     }
     // this[outFirst + i] += a[aFirst + i] * b[bFirst + i], i < n, EVALUATION — the accumulation of EvalFastKeySwitchCoreExt
@@ -668,6 +695,7 @@ private:
     mutable HostType m_h;           // metadata always; words valid iff m_hostValid
     mutable hiprt::Buf m_d;         // device words [nLimbs][N] (may hold more rows than nLimbs after DropLastElement)
     mutable bool m_hostValid{true};
+    mutable bool m_zero{false};     // an all-zero tower not yet materialised on either side (then !m_hostValid && !m_d)
     mutable Lock m_lock;
 
     uint32_t NumLimbs() const {
@@ -676,8 +704,8 @@ private:
     size_t Words() const {
         return (size_t)NumLimbs() * m_h.GetParams()->GetRingDimension();
     }
-    static DCRTPolyType Wrap(HostType&& h) {
-        hiprt::CountHost();
+    static DCRTPolyType Wrap(HostType&& h, const char* who = __builtin_FUNCTION()) {
+        hiprt::CountHost(who);
         return DCRTPolyType(std::move(h));
     }
     static std::vector<DCRTPolyType> WrapAll(std::vector<HostType>&& v) {
@@ -719,14 +747,20 @@ private:
     // ---- the two copies ---------------------------------------------------------------------------------------------
     void CopyFrom(const DCRTPolyType& e) {
         std::lock_guard<std::mutex> lk(e.m_lock.m);
-        m_h         = e.m_h;
-        m_hostValid = e.m_hostValid;
+        m_zero = e.m_zero;
         m_d.reset();
-        if (e.m_d && !e.m_hostValid) {  // device-resident source: device-to-device copy of its limbs
+        if (e.m_d && e.m_h.GetParams() && e.m_h.GetAllElements().size() == e.m_h.GetParams()->GetParams().size()) {
+            // a source with a device copy (even next to a valid mirror): its limbs are copied on the device, the mirror of the
+            // copy holds (params, format) only
             const size_t w = (size_t)e.m_h.GetAllElements().size() * e.m_h.GetParams()->GetRingDimension();
             m_d            = hiprt::Alloc(w);
             hiprt::Check(hiprt::api().d2d(AnyCtx(e.m_h.GetParams()), m_d->p, e.m_d->p, w * 8, nullptr), "DCRTPoly copy");
+            m_h         = HostType(e.m_h.GetParams(), e.m_h.GetFormat(), false);
+            m_hostValid = false;
+            return;
         }
+        m_h         = e.m_h;
+        m_hostValid = e.m_hostValid;
     }
     static fhe_ctx* AnyCtx(const std::shared_ptr<Params>& p) {
         hiprt::Resolved r;
@@ -752,6 +786,12 @@ private:
         std::lock_guard<std::mutex> lk(m_lock.m);
         if (m_hostValid)
             return;
+        if (m_zero) {
+            m_h         = HostType(m_h.GetParams(), m_h.GetFormat(), true);
+            m_hostValid = true;
+            m_zero      = false;
+            return;
+        }
         const auto P     = m_h.GetParams();
         const Format f   = m_h.GetFormat();
         const uint32_t L = (uint32_t)m_h.GetAllElements().size();
@@ -774,18 +814,20 @@ private:
         m_h         = std::move(h);
         m_hostValid = true;
     }
-    const HostType& Hc() const {
+    const HostType& Hc(const char* who = __builtin_FUNCTION()) const {
+        hiprt::TraceMember(who);
         SyncHost();
         return m_h;
     }
-    HostType& Hm() {  // mutable host access: the device copy is stale afterwards
+    HostType& Hm(const char* who = __builtin_FUNCTION()) {  // mutable host access: the device copy is stale afterwards
         SyncHost();
         m_d.reset();
-        hiprt::CountHost();
+        hiprt::CountHost(who);
         return m_h;
     }
     // device words valid (uploads the mirror if needed); r.idx[0] = context limbs of this tower
-    bool OnDevice(hiprt::Resolved* r) const {
+    bool OnDevice(hiprt::Resolved* r, const char* who = __builtin_FUNCTION()) const {
+        hiprt::TraceMember(who);
         const auto& P = m_h.GetParams();
         if (!P || NumLimbs() == 0 || NumLimbs() != P->GetParams().size())
             return false;
@@ -799,6 +841,13 @@ private:
             return true;
         const uint32_t L = NumLimbs();
         const size_t N   = m_h.GetParams()->GetRingDimension();
+        if (m_zero) {
+            auto d = hiprt::Alloc((size_t)L * N);
+            ZeroRows(c, d->p, (size_t)L * N);
+            m_d    = std::move(d);
+            m_zero = false;
+            return true;
+        }
         for (const auto& e : m_h.GetAllElements())
             if (e.IsEmpty() || e.GetLength() != N)
                 return false;  // an unfilled tower: leave it (and its exceptions) to the host code
@@ -853,6 +902,25 @@ private:
         hiprt::Check(fn(r.ctx, m_d->p, m_d->p, rhs.m_d->p, r.idx[0].data(), NumLimbs(), 1, nullptr), "DCRTPoly arithmetic");
         hiprt::CountDevice();
         DeviceIsNewer(m_h.GetFormat());
+        return true;
+    }
+    // limb i plus / minus NativeInteger(k[i]) as a constant polynomial (PolyImpl::Plus / Minus(Integer), poly-impl.h:211-225)
+    bool AddConstOnDevice(const std::vector<Integer>& k, bool minus, DCRTPolyType* out) const {
+        hiprt::Resolved r;
+        if (k.size() < NumLimbs() || !OnDevice(&r))
+            return false;
+        std::vector<uint64_t> c(NumLimbs());
+        for (uint32_t i = 0; i < NumLimbs(); ++i)
+            c[i] = NativeInteger(k[i]).template ConvertToInt<uint64_t>();
+        auto d = hiprt::Alloc(Words());
+        if (minus)
+            hiprt::Check(hiprt::api().sub_const(r.ctx, d->p, m_d->p, c.data(), r.idx[0].data(), NumLimbs(), 1, nullptr), "DCRTPoly Minus(constants)");
+        else
+            hiprt::Check(hiprt::api().add_const(r.ctx, d->p, m_d->p, c.data(), r.idx[0].data(), NumLimbs(), 1,
+                                                m_h.GetFormat() == Format::COEFFICIENT ? 1 : 0, nullptr),
+                         "DCRTPoly Plus(constants)");
+        hiprt::CountDevice();
+        *out = FromDevice(m_h.GetParams(), m_h.GetFormat(), std::move(d));
         return true;
     }
     bool TimesConstInPlace(const std::vector<NativeInteger>& c) {

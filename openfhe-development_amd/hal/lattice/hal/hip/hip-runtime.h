@@ -36,6 +36,8 @@ struct Api {
     decltype(&fhe_mul_add) mul_add;
     decltype(&fhe_mul_const) mul_const;
     decltype(&fhe_mult_acc) mult_acc;
+    decltype(&fhe_add_const) add_const;
+    decltype(&fhe_sub_const) sub_const;
     decltype(&fhe_automorph) automorph;
     decltype(&fhe_switch_modulus) switch_modulus;
     decltype(&fhe_conv_create_custom) conv_create_custom;
@@ -81,8 +83,9 @@ fhe_conv* ConvPlan(fhe_ctx* ctx, const std::vector<uint32_t>& srcIdx, const std:
 struct Stats {
     uint64_t deviceOps, hostFallbacks, h2dBytes, d2hBytes;
 };
+void TraceMember(const char* member);  // the member about to touch words (FHE_HAL_TRACE attributes PCIe bytes to it)
 void CountDevice();
-void CountHost();
+void CountHost(const char* member);  // member = the DCRTPoly member that went to the host mirror (FHE_HAL_TRACE)
 void CountH2D(size_t bytes);
 void CountD2H(size_t bytes);
 
@@ -94,6 +97,8 @@ extern "C" {
 void fhe_hal_stats(uint64_t out[4]);
 // 1 when the HIP backend is live (library loaded, device present), 0 when every operation runs on the host mirror
 int fhe_hal_available(void);
+// forgets the call sites FHE_HAL_TRACE has collected so far (a test program calls it after its set-up phase)
+void fhe_hal_trace_reset(void);
 }
 
 #endif

@@ -526,6 +526,21 @@ void orc_vec_mult_acc(uint64_t* acc, const uint64_t* v, uint64_t c, size_t n, ui
     for (size_t i = 0; i < n; ++i)
         acc[i] = orc_mod_add_fast(acc[i], orc_mod_mul_fast_const(v[i], c, q, pre), q);
 }
+/* PolyImpl::Plus(Integer) (poly-impl.h:211-218): ModAdd on every word in EVALUATION (mubintvecnat.cpp ModAdd: the constant
+ * reduced first), ModAddAtIndex(0, .) in COEFFICIENT */
+void orc_vec_add_const(uint64_t* out, const uint64_t* a, uint64_t c, size_t n, uint64_t q, int coeff0Only) {
+    if (c >= q)
+        c %= q;
+    for (size_t i = 0; i < n; ++i)
+        out[i] = (coeff0Only && i != 0) ? a[i] : orc_mod_add_fast(a[i], c, q);
+}
+/* PolyImpl::Minus(Integer) (poly-impl.h:221-225): ModSub on every word in both formats */
+void orc_vec_sub_const(uint64_t* out, const uint64_t* a, uint64_t c, size_t n, uint64_t q) {
+    if (c >= q)
+        c %= q;
+    for (size_t i = 0; i < n; ++i)
+        out[i] = orc_mod_sub_fast(a[i], c, q);
+}
 /* dcrtpoly-impl.h:347-354 -> poly Negate -> q - v (0 stays 0 via ModSub(0, v)) */
 void orc_vec_neg(uint64_t* out, const uint64_t* a, size_t n, uint64_t q) {
     for (size_t i = 0; i < n; ++i)

@@ -295,6 +295,17 @@ void ref_mult_acc(uint32_t N, uint32_t L, const uint64_t* q, const uint64_t* psi
     }
     export_poly(A, acc);
 }
+// DCRTPolyImpl::Plus / Minus(const std::vector<Integer>&) (dcrtpoly-impl.h:520-548); fmt 0 = EVALUATION, 1 = COEFFICIENT
+void ref_plus_minus_const(uint32_t N, uint32_t L, const uint64_t* q, const uint64_t* psi, const uint64_t* a, const uint64_t* consts,
+                          int fmt, int minus, uint64_t* out) {
+    auto pq = make_params(N, L, q, psi);
+    auto A  = make_poly(pq, a, fmt ? Format::COEFFICIENT : Format::EVALUATION);
+    std::vector<DCRTPoly::Integer> k(L);
+    for (uint32_t i = 0; i < L; ++i)
+        k[i] = DCRTPoly::Integer(std::to_string(consts[i]));
+    DCRTPoly R = minus ? A.Minus(k) : A.Plus(k);
+    export_poly(R, out);
+}
 // the "ModRaise" constructor DCRTPolyImpl(const PolyType&, params) (dcrtpoly-impl.h:87-93): x [N] modulo q[0], COEFFICIENT
 void ref_mod_raise(uint32_t N, uint32_t L, const uint64_t* q, const uint64_t* psi, const uint64_t* x, uint64_t* out) {
     auto pq = make_params(N, L, q, psi);

@@ -20,6 +20,7 @@ using namespace lbcrypto;
 
 extern "C" void fhe_hal_stats(uint64_t out[4]) __attribute__((weak));
 extern "C" int fhe_hal_available(void) __attribute__((weak));
+extern "C" void fhe_hal_trace_reset(void) __attribute__((weak));
 
 static std::ofstream g_out;
 static void dump(const char* name, const Ciphertext<DCRTPoly>& ct) {
@@ -152,10 +153,23 @@ int main(int argc, char** argv) {
             auto c  = cc->Encrypt(kp.publicKey, pt);
             auto b  = cc->EvalBootstrap(c);  // warm-up (tables, plans)
             const int reps = argc > 6 ? std::atoi(argv[6]) : 1;
+            if (fhe_hal_trace_reset)
+                fhe_hal_trace_reset();
+            uint64_t s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+            if (fhe_hal_stats)
+                fhe_hal_stats(s0);
             t0 = now();
-            for (int i = 0; i < reps; ++i)
-                b = cc->EvalBootstrap(c);
+            for (int i = 0; i < reps; ++i) {
+                auto t1 = now();
+                b       = cc->EvalBootstrap(c);
+                std::cout << "  rep " << i << " seconds " << secs(t1, now()) << std::endl;
+            }
             std::cout << "bootstrap seconds " << secs(t0, now()) / reps << " (" << reps << " reps)" << std::endl;
+            if (fhe_hal_stats) {
+                fhe_hal_stats(s1);
+                std::cout << "per bootstrap: deviceOps " << (s1[0] - s0[0]) / reps << " hostOps " << (s1[1] - s0[1]) / reps << " h2dMB "
+                          << (s1[2] - s0[2]) / reps / 1e6 << " d2hMB " << (s1[3] - s0[3]) / reps / 1e6 << std::endl;
+            }
             dump("bootstrapped", b);
             show("bootstrapped", cc, kp.secretKey, b, 8);
         }

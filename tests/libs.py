@@ -74,6 +74,8 @@ def load_oracle():
         S(n, None, [P64, P64, P64, C.c_size_t, u64])
     S("orc_vec_mul_const", None, [P64, P64, u64, C.c_size_t, u64])
     S("orc_vec_mult_acc", None, [P64, P64, u64, C.c_size_t, u64])
+    S("orc_vec_add_const", None, [P64, P64, u64, C.c_size_t, u64, C.c_int])
+    S("orc_vec_sub_const", None, [P64, P64, u64, C.c_size_t, u64])
     S("orc_vec_neg", None, [P64, P64, C.c_size_t, u64])
     S("orc_automorph_eval", None, [P64, P64, u32, P32])
     S("orc_automorph_eval_k", None, [P64, P64, u32, u32])
@@ -216,6 +218,7 @@ def load_ref():
     S("ref_approx_mod_up", None, [u32, u32, P64, P64, P64, C.c_int, P64, P64, u32, P64, P64, P64])
     S("ref_expand_crt_basis_ql_hat", None, [u32, u32, P64, P64, P64, u32, C.c_int, P64, P64])
     S("ref_mult_acc", None, [u32, u32, P64, P64, P64, P64, P64])
+    S("ref_plus_minus_const", None, [u32, u32, P64, P64, P64, P64, C.c_int, C.c_int, P64])
     S("ref_mod_raise", None, [u32, u32, P64, P64, P64, P64])
     S("ref_ckks_eval_square_no_relin", C.c_int, [vp, C.c_int])
     S("ref_bfv_create", vp, [u32, u64, u32, u32, C.c_int])

@@ -838,3 +838,30 @@ def test_eval_square_core_against_live_reference(oracle, ref):
     for e in range(3):
         assert np.array_equal(got[e], want[e]), f"EvalSquareCore element {e}"
     r.ref_ckks_destroy(h)
+
+
+def test_plus_minus_constants_against_live_reference(oracle, ref):
+    """orc_vec_add_const / orc_vec_sub_const vs DCRTPolyImpl::Plus / Minus(vector<Integer>) (dcrtpoly-impl.h:520-548) of the
+    compiled reference, both formats"""
+    o, r = oracle, ref
+    rng = np.random.default_rng(4242)
+    for logN, L in [(4, 2), (10, 4)]:
+        N = 1 << logN
+        q = np.zeros(L, np.uint64)
+        psi = np.zeros(L, np.uint64)
+        o.orc_dcrt_params(2 * N, L, 59, q, psi)
+        a = np.stack([rng.integers(0, int(m), N, dtype=np.uint64) for m in q])
+        a[:, 0] = q - np.uint64(1)
+        consts = np.array([int(rng.integers(0, 1 << 63)) for _ in range(L)], np.uint64)
+        consts[0] = 0
+        for fmt in (0, 1):
+            for minus in (0, 1):
+                want = np.empty_like(a)
+                r.ref_plus_minus_const(N, L, q, psi, a, consts, fmt, minus, want)
+                got = np.empty_like(a)
+                for i in range(L):
+                    if minus:
+                        o.orc_vec_sub_const(got[i], a[i], consts[i], N, q[i])
+                    else:
+                        o.orc_vec_add_const(got[i], a[i], consts[i], N, q[i], fmt)
+                assert np.array_equal(got, want), (logN, fmt, minus)

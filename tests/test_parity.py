@@ -149,6 +149,44 @@ def test_elementwise(backend, oracle):
         ctx.close()
 
 
+def test_plus_minus_constants(backend, oracle):
+    """fhe_add_const / fhe_sub_const = DCRTPolyImpl::Plus / Minus(vector<Integer>) (dcrtpoly-impl.h:520-548): every word in
+    EVALUATION, coefficient 0 only for Plus in COEFFICIENT; constants >= q are reduced first; in place and out of place"""
+    o = oracle
+    rng = np.random.default_rng(977)
+    u64p = C.POINTER(C.c_uint64)
+    for logN, L, B in [(4, 2, 1), (11, 5, 2), (13, 3, 1)]:
+        N = 1 << logN
+        q, psi = params(o, logN, L)
+        ctx = fh.Context(backend, logN, q, psi)
+        a = libs.rand_tower(rng, q, N, B)
+        a[0, :, 0] = q - np.uint64(1)
+        consts = np.array([int(rng.integers(0, 1 << 62)) for _ in range(L)], np.uint64)
+        consts[0] = 0
+        if L > 2:
+            consts[2] = q[2]  # reduces to zero
+        for mode in ("plus", "plus0", "minus"):
+            want = np.empty_like(a)
+            for bb in range(B):
+                for l in range(L):
+                    if mode == "minus":
+                        o.orc_vec_sub_const(want[bb, l], a[bb, l], consts[l], N, q[l])
+                    else:
+                        o.orc_vec_add_const(want[bb, l], a[bb, l], consts[l], N, q[l], 1 if mode == "plus0" else 0)
+            ta = ctx.tower(a)
+            out = ta.like()
+            cp = consts.ctypes.data_as(u64p)
+            if mode == "minus":
+                backend.check(backend.L.fhe_sub_const(ctx.h, out.ptr, ta.ptr, cp, None, L, B, None))
+                backend.check(backend.L.fhe_sub_const(ctx.h, ta.ptr, ta.ptr, cp, None, L, B, None))
+            else:
+                backend.check(backend.L.fhe_add_const(ctx.h, out.ptr, ta.ptr, cp, None, L, B, int(mode == "plus0"), None))
+                backend.check(backend.L.fhe_add_const(ctx.h, ta.ptr, ta.ptr, cp, None, L, B, int(mode == "plus0"), None))
+            assert np.array_equal(out.to_host(), want), f"{mode} logN={logN}"
+            assert np.array_equal(ta.to_host(), want), f"{mode} in place logN={logN}"
+        ctx.close()
+
+
 def test_mult_acc_square_ql_hat_async_consts(backend, oracle):
     """fhe_mult_acc (MultAccEqNoCheck), fhe_tensor_square (EvalSquareCore), fhe_expand_crt_basis_ql_hat (ExpandCRTBasisQlHat);
     the host constants of fhe_mul_const / fhe_mult_acc travel in the kernel arguments: the host array may change right after
