@@ -270,6 +270,16 @@ fhe_status fhe_eval_fast_rotation(fhe_ks_plan* plan, const fhe_ks_key* key, cons
 fhe_status fhe_eval_automorphism(fhe_ks_plan* plan, const fhe_ks_key* key, const uint64_t* c0, const uint64_t* c1,
                                  uint32_t k, uint32_t sizeQl, uint32_t batch, uint64_t* out0, uint64_t* out1, void* ws,
                                  size_t wsBytes, void* stream);
+/* The inner product of HYBRID key switching (KeySwitchHYBRID::EvalFastKeySwitchCoreExt, keyswitch-hybrid.cpp:419-430) over
+ * towers that live in separate allocations — what a DCRTPoly backend holds: every digit and every element of the evaluation
+ * key is its own tower.  out_e[b][i] = sum_{t < nTerms} x[t][b][i] * k_e[t][keyRow[i]] mod q_{limbIdx[i]}, e = 0 (k0 -> out0)
+ * and, when k1/out1 are given, e = 1.  x[t] is [batch][rows][N], k_e[t] is a tower of at least max(keyRow)+1 rows, keyRow NULL
+ * = identity (the reference's idx(i) = i < sizeQl ? i : i + sizeQ - sizeQl, :425).  x, k0, k1 are HOST arrays of device
+ * pointers; all operands are canonical residues; 1 <= nTerms <= 8 (FHE_ERR_UNSUPPORTED beyond). */
+fhe_status fhe_inner_product(fhe_ctx* ctx, uint32_t nTerms, const uint64_t* const* x, const uint64_t* const* k0,
+                             const uint64_t* const* k1, const uint32_t* keyRow, const uint32_t* limbIdx, uint32_t rows,
+                             uint32_t batch, uint64_t* out0, uint64_t* out1, void* stream);
+
 /* Double hoisting (ckksrns-fhe.cpp:1830-2000) works in the extended basis Q_l u P and mods down once:
  *   fhe_ks_ext                 = KeySwitchHYBRID::KeySwitchExt for one element (keyswitch-hybrid.cpp:217-243):
  *                                out [batch][sizeQl+sizeP][N], Q_l rows = c * [P]_{q_i}, P rows = 0;

@@ -215,6 +215,61 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ks_inner_product_kernel(const KsInne
     }
 }
 
+// ---- the same inner product over towers that live in separate allocations (the HAL backend of DCRTPoly: every digit and
+// every key element is its own tower) ----
+//   out_e[b][i] = sum_t x_t[b][i] * k_{e,t}[keyRow[i]]   (e = 0, 1; t < nTerms <= 8; all operands canonical residues)
+struct InnerRowsArgs {
+    const uint64_t* x[kMaxDigits];   // [batch][rows][N]
+    const uint64_t* k0[kMaxDigits];  // [keyRows][N]
+    const uint64_t* k1[kMaxDigits];  // may all be null (one output)
+    uint64_t* out0;                  // [batch][rows][N]
+    uint64_t* out1;
+    const LimbConst* lc;
+    const uint64_t* mu128;
+    uint32_t logN, batch, rows, nTerms;
+    uint8_t keyRow[kMaxLimbs];
+    LimbSel sel;
+};
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) inner_rows_kernel(const InnerRowsArgs g) {
+    // one workgroup = one 4096-word tile of one output row; 2 words per thread and step (16-byte accesses)
+    const uint32_t t           = FHE_TID;
+    const uint32_t N           = 1u << g.logN;
+    const uint32_t tilesPerRow = N >> kTileLog ? (N >> kTileLog) : 1u;
+    const uint32_t tr          = FHE_BID % tilesPerRow;
+    const uint32_t row         = FHE_BID / tilesPerRow;  // b * rows + i
+    const uint32_t i           = row % g.rows;
+    const uint32_t idx         = g.sel.idx[i];
+    const LimbConst lc         = g.lc[idx];
+    const uint64_t mulo = g.mu128[2 * idx], muhi = g.mu128[2 * idx + 1];
+    const uint64_t q    = lc.q;
+    const uint32_t rEnd = ((tr + 1u) << kTileLog) < N ? ((tr + 1u) << kTileLog) : N;
+    const uint64_t xoff = (uint64_t)row << g.logN;
+    const uint64_t koff = (uint64_t)g.keyRow[i] << g.logN;
+    const bool two      = g.k1[0] != nullptr;
+    for (uint32_t r = (tr << kTileLog) + 2u * t; r < rEnd; r += 2u * kThreads) {
+        sum8 a0, a1, b0, b1;
+        sum8_clear(a0);
+        sum8_clear(a1);
+        sum8_clear(b0);
+        sum8_clear(b1);
+        for (uint32_t j = 0; j < g.nTerms; ++j) {
+            const uint64_t x0 = g.x[j][xoff + r], x1 = g.x[j][xoff + r + 1];
+            sum8_add(a0, x0, g.k0[j][koff + r]);
+            sum8_add(a1, x1, g.k0[j][koff + r + 1]);
+            if (two) {
+                sum8_add(b0, x0, g.k1[j][koff + r]);
+                sum8_add(b1, x1, g.k1[j][koff + r + 1]);
+            }
+        }
+        g.out0[xoff + r]     = sum8_reduce(a0, q, lc.msb, mulo, muhi);
+        g.out0[xoff + r + 1] = sum8_reduce(a1, q, lc.msb, mulo, muhi);
+        if (two) {
+            g.out1[xoff + r]     = sum8_reduce(b0, q, lc.msb, mulo, muhi);
+            g.out1[xoff + r + 1] = sum8_reduce(b1, q, lc.msb, mulo, muhi);
+        }
+    }
+}
+
 // ---- baby-step/giant-step inner sums (double hoisting) --------------------------------------------
 // inner_i[e][b][l][r] = sum_j rot_j[e][b][l][r] * diag_{i,j}[l][r]  over the extended basis Q_l u P, for ALL outer steps i
 // in one pass: the EvalMultExt / EvalAddExtInPlace chains of FHECKKSRNS::EvalLinearTransform (ckksrns-fhe.cpp:1855-1859,

@@ -1678,6 +1678,37 @@ static fhe_status ks_inner_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const fhe
     LAUNCH_CHECK();
     return FHE_OK;
 }
+// the HYBRID inner product (keyswitch-hybrid.cpp:419-430) over towers in separate allocations: see inner_rows_kernel
+extern "C" fhe_status fhe_inner_product(fhe_ctx* c, uint32_t nTerms, const uint64_t* const* x, const uint64_t* const* k0,
+                                        const uint64_t* const* k1, const uint32_t* keyRow, const uint32_t* limbIdx,
+                                        uint32_t rows, uint32_t batch, uint64_t* out0, uint64_t* out1, void* st) {
+    ARG_CHECK(c && x && k0 && out0, "fhe_inner_product: null argument");
+    ARG_CHECK((k1 != nullptr) == (out1 != nullptr), "fhe_inner_product: the second key and the second output go together");
+    ARG_CHECK(batch >= 1, "fhe_inner_product: batch must be >= 1");
+    if (nTerms < 1 || nTerms > (uint32_t)kMaxDigits)
+        return fail(FHE_ERR_UNSUPPORTED, "fhe_inner_product: 1..8 terms per launch");
+    InnerRowsArgs g;
+    if (fhe_status s = make_sel(c, limbIdx, rows, &g.sel, "fhe_inner_product"))
+        return s;
+    for (uint32_t i = 0; i < (uint32_t)kMaxLimbs; ++i) {
+        const uint32_t kr = i < rows ? (keyRow ? keyRow[i] : i) : 0u;
+        ARG_CHECK(kr < 256u, "fhe_inner_product: key row out of range");
+        g.keyRow[i] = (uint8_t)kr;
+    }
+    for (uint32_t j = 0; j < (uint32_t)kMaxDigits; ++j) {
+        ARG_CHECK(j >= nTerms || (x[j] && k0[j] && (!k1 || k1[j])), "fhe_inner_product: null term");
+        g.x[j]  = j < nTerms ? x[j] : nullptr;
+        g.k0[j] = j < nTerms ? k0[j] : nullptr;
+        g.k1[j] = (j < nTerms && k1) ? k1[j] : nullptr;
+    }
+    RT_CHECK(rt::set_device(c->device));
+    g.out0 = out0, g.out1 = out1, g.lc = c->d_lc, g.mu128 = c->d_mu128;
+    g.logN = c->logN, g.batch = batch, g.rows = rows, g.nTerms = nTerms;
+    const uint32_t tilesPerRow = c->N >= (uint32_t)kTile ? (c->N >> kTileLog) : 1u;
+    FHE_LAUNCH(inner_rows_kernel, (uint64_t)tilesPerRow * rows * batch, st, g);
+    LAUNCH_CHECK();
+    return FHE_OK;
+}
 static fhe_status ks_fast_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const fhe_ks_key* key, const uint64_t* cin,
                               uint32_t batch, uint64_t* out0, uint64_t* out1, uint64_t* ws, const KsLayout& w, void* st,
                               bool accumulate) {

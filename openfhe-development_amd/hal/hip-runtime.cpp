@@ -75,7 +75,8 @@ Runtime* build() {
                   sym(h, "fhe_ctx_create", &a.ctx_create) && sym(h, "fhe_malloc", &a.malloc_) && sym(h, "fhe_free", &a.free_) &&
                   sym(h, "fhe_memcpy_h2d", &a.h2d) && sym(h, "fhe_memcpy_d2h", &a.d2h) && sym(h, "fhe_memcpy_d2d", &a.d2d) &&
                   sym(h, "fhe_stream_sync", &a.sync) && sym(h, "fhe_ntt_fwd", &a.ntt_fwd) && sym(h, "fhe_ntt_inv", &a.ntt_inv) &&
-                  sym(h, "fhe_ntt_inv_oop", &a.ntt_inv_oop) && sym(h, "fhe_add", &a.add) && sym(h, "fhe_sub", &a.sub) &&
+                  sym(h, "fhe_ntt_inv_oop", &a.ntt_inv_oop) && sym(h, "fhe_ntt_fwd_oop", &a.ntt_fwd_oop) &&
+                  sym(h, "fhe_inner_product", &a.inner_product) && sym(h, "fhe_add", &a.add) && sym(h, "fhe_sub", &a.sub) &&
                   sym(h, "fhe_mul", &a.mul) && sym(h, "fhe_neg", &a.neg) && sym(h, "fhe_mul_add", &a.mul_add) && sym(h, "fhe_mul_const", &a.mul_const) &&
                   sym(h, "fhe_mult_acc", &a.mult_acc) && sym(h, "fhe_add_const", &a.add_const) && sym(h, "fhe_sub_const", &a.sub_const) && sym(h, "fhe_automorph", &a.automorph) &&
                   sym(h, "fhe_switch_modulus", &a.switch_modulus) && sym(h, "fhe_conv_create_custom", &a.conv_create_custom) &&
@@ -151,6 +152,10 @@ static void trace_site(const char* kind, const char* member, uint64_t amount) {
 void CountHost(const char* member) {
     rt().hostFallbacks.fetch_add(1, std::memory_order_relaxed);
     trace_site("hostop", member, 1);
+}
+void D2D(fhe_ctx* c, uint64_t* dst, const uint64_t* src, size_t bytes, const char* what) {
+    Check(rt().api.d2d(c, dst, src, bytes, nullptr), what);
+    trace_site("d2dBytes", what, bytes);
 }
 void CountH2D(size_t b) {
     rt().h2dBytes.fetch_add(b, std::memory_order_relaxed);

@@ -80,18 +80,18 @@ std::shared_ptr<std::vector<DCRTPoly>> KeySwitchHYBRID::EvalKeySwitchPrecomputeC
         const uint32_t sizePartQl   = paramsPart->GetParams().size();
         const uint32_t startPartIdx = alpha * part, endPartIdx = startPartIdx + sizePartQl;
 
-        DCRTPoly partsCt = DCRTPoly::AssembleRows(paramsPart, Format::EVALUATION, {RowPiece{&c, startPartIdx, sizePartQl}});  // :357-360
-        partsCt.SetFormat(Format::COEFFICIENT);                                                                             // :362
+        // the digit's rows of c in COEFFICIENT format (:357-362: copy, then SetFormat)
+        DCRTPoly partsCt = DCRTPoly::AssembleRows(paramsPart, Format::COEFFICIENT, {RowPiece{&c, startPartIdx, sizePartQl, true}});
         auto partsCtCompl = partsCt.ApproxSwitchCRTBasis(cryptoParams->GetParamsPartQ(part), cryptoParams->GetParamsComplPartQ(sizeQl - 1, part),
                                                          cryptoParams->GetPartQlHatInvModq(part, sizePartQl - 1),
                                                          cryptoParams->GetPartQlHatInvModqPrecon(part, sizePartQl - 1),
                                                          cryptoParams->GetPartQlHatModp(sizeQl - 1, part),
                                                          cryptoParams->GetmodComplPartqBarrettMu(sizeQl - 1, part));  // :363-368
-        partsCtCompl.SetFormat(Format::EVALUATION);                                                                   // :369
-        // [ complement rows below the digit | the digit's own rows of c | the remaining complement rows ]  (:371-378)
+        // [ complement rows below the digit | the digit's own rows of c | the remaining complement rows ]  (:369-378: the
+        // complement goes to EVALUATION on its way into place)
         (*result)[part] = DCRTPoly::AssembleRows(paramsQlP, Format::EVALUATION,
-                                                 {RowPiece{&partsCtCompl, 0, startPartIdx}, RowPiece{&c, startPartIdx, sizePartQl},
-                                                  RowPiece{&partsCtCompl, startPartIdx, sizeQl + sizeP - endPartIdx}});
+                                                 {RowPiece{&partsCtCompl, 0, startPartIdx, true}, RowPiece{&c, startPartIdx, sizePartQl},
+                                                  RowPiece{&partsCtCompl, startPartIdx, sizeQl + sizeP - endPartIdx, true}});
     }
     return result;
 }
@@ -101,27 +101,13 @@ std::shared_ptr<std::vector<DCRTPoly>> KeySwitchHYBRID::EvalKeySwitchPrecomputeC
 std::shared_ptr<std::vector<DCRTPoly>> KeySwitchHYBRID::EvalFastKeySwitchCoreExt(
     const std::shared_ptr<std::vector<DCRTPoly>> digits, const EvalKey<DCRTPoly> evalKey,
     const std::shared_ptr<ParmType> paramsQl) const {
-    const auto paramsQlP   = (*digits)[0].GetParams();
-    const uint32_t sizeQlP = paramsQlP->GetParams().size();
     const uint32_t sizeQl  = paramsQl->GetParams().size();
-    const uint32_t sizeP   = sizeQlP - sizeQl;
     auto&& cryptoParams    = std::dynamic_pointer_cast<CryptoParametersRNS>(evalKey->GetCryptoParameters());
     const uint32_t sizeQ   = cryptoParams->GetElementParams()->GetParams().size();
     const auto& av = evalKey->GetAVector();
     const auto& bv = evalKey->GetBVector();
 
-    auto result = std::make_shared<std::vector<DCRTPoly>>();
-    result->reserve(2);
-    result->emplace_back(paramsQlP, Format::EVALUATION, true);
-    result->emplace_back(paramsQlP, Format::EVALUATION, true);
-    for (uint32_t j = 0; j < digits->size(); ++j) {
-        const DCRTPoly& d = (*digits)[j];
-        (*result)[0].MultAccRows(0, d, 0, bv[j], 0, sizeQl);
-        (*result)[0].MultAccRows(sizeQl, d, sizeQl, bv[j], sizeQ, sizeP);
-        (*result)[1].MultAccRows(0, d, 0, av[j], 0, sizeQl);
-        (*result)[1].MultAccRows(sizeQl, d, sizeQl, av[j], sizeQ, sizeP);
-    }
-    return result;
+    return std::make_shared<std::vector<DCRTPoly>>(DCRTPoly::InnerProduct(*digits, bv, av, sizeQl, sizeQ - sizeQl));
 }
 
 }  // namespace lbcrypto

@@ -142,7 +142,7 @@ public:
             auto params   = std::make_shared<Params>(P->GetCyclotomicOrder(), P->GetParamPartition(startTower, endTower));
             const size_t N = P->GetRingDimension(), n = endTower - startTower + 1;
             auto d         = hiprt::Alloc(n * N);
-            hiprt::Check(hiprt::api().d2d(AnyCtx(P), d->p, m_d->p + (size_t)startTower * N, n * N * 8, nullptr), "CloneTowers");
+            hiprt::D2D(AnyCtx(P), d->p, m_d->p + (size_t)startTower * N, n * N * 8, "CloneTowers");
             hiprt::CountDevice();
             return FromDevice(params, m_h.GetFormat(), std::move(d));
         }
@@ -545,8 +545,16 @@ public:
         hiprt::Resolved r;
         if (OnDevice(&r)) {
             const bool toCoeff = m_h.GetFormat() == Format::EVALUATION;
-            auto f             = toCoeff ? hiprt::api().ntt_inv : hiprt::api().ntt_fwd;
-            hiprt::Check(f(r.ctx, m_d->p, r.idx[0].data(), NumLimbs(), 1, nullptr), "SwitchFormat");
+            if (m_d.use_count() > 1) {  // words shared with a copy: transform into a buffer of its own
+                auto d = hiprt::Alloc(Words());
+                auto f = toCoeff ? hiprt::api().ntt_inv_oop : hiprt::api().ntt_fwd_oop;
+                hiprt::Check(f(r.ctx, m_d->p, d->p, r.idx[0].data(), NumLimbs(), 1, nullptr), "SwitchFormat");
+                m_d = std::move(d);
+            }
+            else {
+                auto f = toCoeff ? hiprt::api().ntt_inv : hiprt::api().ntt_fwd;
+                hiprt::Check(f(r.ctx, m_d->p, r.idx[0].data(), NumLimbs(), 1, nullptr), "SwitchFormat");
+            }
             hiprt::CountDevice();
             DeviceIsNewer(toCoeff ? Format::COEFFICIENT : Format::EVALUATION);
             return;
@@ -608,9 +616,12 @@ public:
     // A piece = rows [first, first + n) of `src` (nullptr: n rows of zeros).  The pieces, laid out one after the other, become
     // the limbs of a new tower over `params` in format `f` — what pke writes as a loop of
     // `result.SetElementAtIndex(i, src.GetElementAtIndex(j))` (keyswitch-hybrid.cpp:356-376, :228-237).
+    // transform: the source rows are in the OTHER format than the assembled tower and are transformed while they are placed
+    // (pke's `partsCt.SetFormat(COEFFICIENT)` / `partsCtCompl.SetFormat(EVALUATION)` around the copies, :362, :369)
     struct RowPiece {
         const DCRTPolyType* src;
         uint32_t first, n;
+        bool transform = false;
     };
     static DCRTPolyType AssembleRows(const std::shared_ptr<Params>& params, Format f, const std::vector<RowPiece>& pieces) {
         const size_t N   = params->GetRingDimension();
@@ -632,9 +643,13 @@ public:
             auto d      = hiprt::Alloc((size_t)total * N);
             uint32_t at = 0;
             for (const auto& pc : pieces) {
-                if (pc.src)
-                    hiprt::Check(hiprt::api().d2d(r.ctx, d->p + (size_t)at * N, pc.src->m_d->p + (size_t)pc.first * N, (size_t)pc.n * N * 8, nullptr),
+                if (pc.src && pc.n && pc.transform) {
+                    auto fn = f == Format::EVALUATION ? hiprt::api().ntt_fwd_oop : hiprt::api().ntt_inv_oop;
+                    hiprt::Check(fn(r.ctx, pc.src->m_d->p + (size_t)pc.first * N, d->p + (size_t)at * N, r.idx[0].data() + at, pc.n, 1, nullptr),
                                  "AssembleRows");
+                }
+                else if (pc.src && pc.n)
+                    hiprt::D2D(r.ctx, d->p + (size_t)at * N, pc.src->m_d->p + (size_t)pc.first * N, (size_t)pc.n * N * 8, "AssembleRows");
                 else if (pc.n)
                     ZeroRows(r.ctx, d->p + (size_t)at * N, (size_t)pc.n * N);
                 at += pc.n;
@@ -646,10 +661,53 @@ public:
         uint32_t at = 0;
         for (const auto& pc : pieces) {
             for (uint32_t i = 0; i < pc.n; ++i, ++at)
-                if (pc.src)
-                    out.m_h.SetElementAtIndex(at, pc.src->Hc().GetElementAtIndex(pc.first + i));
+                if (pc.src) {
+                    PolyType e = pc.src->Hc().GetElementAtIndex(pc.first + i);
+                    if (pc.transform)
+                        e.SetFormat(f);
+                    out.m_h.SetElementAtIndex(at, std::move(e));
+                }
         }
         hiprt::CountHost("AssembleRows");
+        return out;
+    }
+    // { sum_j x[j][i] * k0[j][idx(i)],  sum_j x[j][i] * k1[j][idx(i)] },  idx(i) = i < sizeQl ? i : i + keySkip — the two sums
+    // of EvalFastKeySwitchCoreExt (keyswitch-hybrid.cpp:419-430) in one pass over the digits (fhe_inner_product)
+    static std::vector<DCRTPolyType> InnerProduct(const std::vector<DCRTPolyType>& x, const std::vector<DCRTPolyType>& k0,
+                                                  const std::vector<DCRTPolyType>& k1, uint32_t sizeQl, uint32_t keySkip) {
+        const auto& params = x[0].GetParams();
+        const uint32_t rows = x[0].NumLimbs(), n = (uint32_t)x.size();
+        hiprt::Resolved r;
+        bool deviceOk = n >= 1 && n <= 8 && k0.size() >= n && k1.size() >= n && x[0].OnDevice(&r);
+        for (uint32_t j = 0; deviceOk && j < n; ++j)
+            deviceOk = x[j].NumLimbs() == rows && x[j].GetFormat() == Format::EVALUATION && k0[j].NumLimbs() >= rows + keySkip &&
+                       k1[j].NumLimbs() >= rows + keySkip && x[j].Upload(r.ctx) && k0[j].Upload(r.ctx) && k1[j].Upload(r.ctx);
+        std::vector<DCRTPolyType> out;
+        if (deviceOk) {
+            const size_t N = params->GetRingDimension();
+            std::vector<const uint64_t*> px(n), p0(n), p1(n);
+            for (uint32_t j = 0; j < n; ++j)
+                px[j] = x[j].m_d->p, p0[j] = k0[j].m_d->p, p1[j] = k1[j].m_d->p;
+            std::vector<uint32_t> keyRow(rows);
+            for (uint32_t i = 0; i < rows; ++i)
+                keyRow[i] = i < sizeQl ? i : i + keySkip;
+            auto d0 = hiprt::Alloc((size_t)rows * N), d1 = hiprt::Alloc((size_t)rows * N);
+            hiprt::Check(hiprt::api().inner_product(r.ctx, n, px.data(), p0.data(), p1.data(), keyRow.data(), r.idx[0].data(), rows, 1,
+                                                    d0->p, d1->p, nullptr),
+                         "InnerProduct");
+            hiprt::CountDevice();
+            out.push_back(FromDevice(params, Format::EVALUATION, std::move(d0)));
+            out.push_back(FromDevice(params, Format::EVALUATION, std::move(d1)));
+            return out;
+        }
+        out.emplace_back(params, Format::EVALUATION, true);
+        out.emplace_back(params, Format::EVALUATION, true);
+        for (uint32_t j = 0; j < n; ++j) {
+            out[0].MultAccRows(0, x[j], 0, k0[j], 0, sizeQl);
+            out[0].MultAccRows(sizeQl, x[j], sizeQl, k0[j], sizeQl + keySkip, rows - sizeQl);
+            out[1].MultAccRows(0, x[j], 0, k1[j], 0, sizeQl);
+            out[1].MultAccRows(sizeQl, x[j], sizeQl, k1[j], sizeQl + keySkip, rows - sizeQl);
+        }
         return out;
     }
     // this[outFirst + i] += a[aFirst + i] * b[bFirst + i], i < n, EVALUATION — the accumulation of EvalFastKeySwitchCoreExt
@@ -660,6 +718,7 @@ public:
         hiprt::Resolved r;
         if (OnDevice(&r) && a.Upload(r.ctx) && b.Upload(r.ctx)) {
             const size_t N = m_h.GetParams()->GetRingDimension();
+            Unshare(r.ctx);
             hiprt::Check(hiprt::api().mul_add(r.ctx, m_d->p + (size_t)outFirst * N, a.m_d->p + (size_t)aFirst * N, b.m_d->p + (size_t)bFirst * N,
                                               r.idx[0].data() + outFirst, n, 1, nullptr),
                          "MultAccRows");
@@ -750,11 +809,9 @@ private:
         m_zero = e.m_zero;
         m_d.reset();
         if (e.m_d && e.m_h.GetParams() && e.m_h.GetAllElements().size() == e.m_h.GetParams()->GetParams().size()) {
-            // a source with a device copy (even next to a valid mirror): its limbs are copied on the device, the mirror of the
-            // copy holds (params, format) only
-            const size_t w = (size_t)e.m_h.GetAllElements().size() * e.m_h.GetParams()->GetRingDimension();
-            m_d            = hiprt::Alloc(w);
-            hiprt::Check(hiprt::api().d2d(AnyCtx(e.m_h.GetParams()), m_d->p, e.m_d->p, w * 8, nullptr), "DCRTPoly copy");
+            // a source with a device copy (even next to a valid mirror): copy-on-write, the mirror of the copy holds (params,
+            // format) only.  Device words are never modified while shared: every writer goes through WriteTarget / Unshare
+            m_d         = e.m_d;  // shared until one of the two is written (WriteTarget / Unshare)
             m_h         = HostType(e.m_h.GetParams(), e.m_h.GetFormat(), false);
             m_hostValid = false;
             return;
@@ -766,6 +823,18 @@ private:
         hiprt::Resolved r;
         ResolveSets(p->GetRingDimension(), {p}, &r);
         return r.ctx;
+    }
+    // where an in-place operation writes: the tower's own buffer, or a fresh one while the words are shared with a copy
+    hiprt::Buf WriteTarget() const {
+        return m_d.use_count() > 1 ? hiprt::Alloc(Words()) : m_d;
+    }
+    // a private copy of shared words (operations that read-modify-write in place)
+    void Unshare(fhe_ctx* c) {
+        if (m_d.use_count() > 1) {
+            auto d = hiprt::Alloc(Words());
+            hiprt::D2D(c, d->p, m_d->p, Words() * 8, "DCRTPoly copy");
+            m_d = std::move(d);
+        }
     }
     static void ZeroRows(fhe_ctx* c, uint64_t* p, size_t words) {
         // (the C ABI has no memset: a zero tower is uploaded once per size and copied on the device)
@@ -779,7 +848,7 @@ private:
             hiprt::Check(hiprt::api().sync(c, nullptr), "zero rows");
             zeros = std::move(b);
         }
-        hiprt::Check(hiprt::api().d2d(c, p, zeros->p, words * 8, nullptr), "zero rows");
+        hiprt::D2D(c, p, zeros->p, words * 8, "zero rows");
     }
     // host words valid (fills the mirror from the device if needed)
     void SyncHost() const {
@@ -899,7 +968,9 @@ private:
         hiprt::Resolved r;
         if (!Compatible(rhs, evalOnly) || !OnDevice(&r) || !rhs.Upload(r.ctx))
             return false;
-        hiprt::Check(fn(r.ctx, m_d->p, m_d->p, rhs.m_d->p, r.idx[0].data(), NumLimbs(), 1, nullptr), "DCRTPoly arithmetic");
+        auto dst = WriteTarget();
+        hiprt::Check(fn(r.ctx, dst->p, m_d->p, rhs.m_d->p, r.idx[0].data(), NumLimbs(), 1, nullptr), "DCRTPoly arithmetic");
+        m_d = std::move(dst);
         hiprt::CountDevice();
         DeviceIsNewer(m_h.GetFormat());
         return true;
@@ -930,8 +1001,10 @@ private:
         std::vector<uint64_t> k(NumLimbs());
         for (uint32_t i = 0; i < NumLimbs(); ++i)
             k[i] = c[i].ConvertToInt<uint64_t>();
-        hiprt::Check(hiprt::api().mul_const(r.ctx, m_d->p, m_d->p, k.data(), r.idx[0].data(), NumLimbs(), 1, nullptr),
+        auto dst = WriteTarget();
+        hiprt::Check(hiprt::api().mul_const(r.ctx, dst->p, m_d->p, k.data(), r.idx[0].data(), NumLimbs(), 1, nullptr),
                      "DCRTPoly Times(constants)");
+        m_d = std::move(dst);
         hiprt::CountDevice();
         DeviceIsNewer(m_h.GetFormat());
         return true;
@@ -1017,8 +1090,8 @@ private:
             return false;
         const size_t N = paramsQP->GetRingDimension();
         auto d         = hiprt::Alloc((size_t)(sizeQ + sizeP) * N);
-        hiprt::Check(hiprt::api().d2d(r.ctx, d->p, qpart.m_d->p, (size_t)sizeQ * N * 8, nullptr), "ApproxModUp");
-        hiprt::Check(hiprt::api().d2d(r.ctx, d->p + (size_t)sizeQ * N, partP.m_d->p, (size_t)sizeP * N * 8, nullptr), "ApproxModUp");
+        hiprt::D2D(r.ctx, d->p, qpart.m_d->p, (size_t)sizeQ * N * 8, "ApproxModUp");
+        hiprt::D2D(r.ctx, d->p + (size_t)sizeQ * N, partP.m_d->p, (size_t)sizeP * N * 8, "ApproxModUp");
         if (!wasEval)
             hiprt::Check(hiprt::api().ntt_fwd(r.ctx, d->p, r.idx[2].data(), sizeQ, 1, nullptr), "ApproxModUp");
         hiprt::Check(hiprt::api().ntt_fwd(r.ctx, d->p + (size_t)sizeQ * N, r.idx[1].data(), sizeP, 1, nullptr), "ApproxModUp");
@@ -1099,8 +1172,9 @@ private:
         hiprt::Check(A.switch_modulus(r.ctx, tmp->p, idx.data(), l, last->p, 1, 0, lastLimb, 1, nullptr), "DropLastElementAndScale");  // :703-704
         hiprt::Check(A.mul_const(r.ctx, tmp->p, tmp->p, a.data(), idx.data(), l, 1, nullptr), "DropLastElementAndScale");            // :705
         hiprt::Check(A.ntt_fwd(r.ctx, tmp->p, idx.data(), l, 1, nullptr), "DropLastElementAndScale");                                 // :706-707
-        hiprt::Check(A.mul_const(r.ctx, m_d->p, m_d->p, b.data(), idx.data(), l, 1, nullptr), "DropLastElementAndScale");             // :708
-        hiprt::Check(A.add(r.ctx, m_d->p, m_d->p, tmp->p, idx.data(), l, 1, nullptr), "DropLastElementAndScale");                     // :709
+        // :708-709  m_vectors[i] = m_vectors[i] * qlInvModq[i] + tmp[i]: accumulated into tmp, which becomes the tower
+        hiprt::Check(A.mult_acc(r.ctx, tmp->p, m_d->p, b.data(), idx.data(), l, 1, nullptr), "DropLastElementAndScale");
+        m_d = std::move(tmp);
         hiprt::CountDevice();
         DeviceIsNewer(Format::EVALUATION);
         DropLastElement();  // :698 (metadata; the device copy keeps its leading limbs)

@@ -29,6 +29,8 @@ struct Api {
     decltype(&fhe_ntt_fwd) ntt_fwd;
     decltype(&fhe_ntt_inv) ntt_inv;
     decltype(&fhe_ntt_inv_oop) ntt_inv_oop;
+    decltype(&fhe_ntt_fwd_oop) ntt_fwd_oop;
+    decltype(&fhe_inner_product) inner_product;
     decltype(&fhe_add) add;
     decltype(&fhe_sub) sub;
     decltype(&fhe_mul) mul;
@@ -84,6 +86,7 @@ struct Stats {
     uint64_t deviceOps, hostFallbacks, h2dBytes, d2hBytes;
 };
 void TraceMember(const char* member);  // the member about to touch words (FHE_HAL_TRACE attributes PCIe bytes to it)
+void D2D(fhe_ctx* c, uint64_t* dst, const uint64_t* src, size_t bytes, const char* what);  // device copy (+ trace)
 void CountDevice();
 void CountHost(const char* member);  // member = the DCRTPoly member that went to the host mirror (FHE_HAL_TRACE)
 void CountH2D(size_t bytes);

@@ -541,6 +541,15 @@ void orc_vec_sub_const(uint64_t* out, const uint64_t* a, uint64_t c, size_t n, u
     for (size_t i = 0; i < n; ++i)
         out[i] = orc_mod_sub_fast(a[i], c, q);
 }
+/* keyswitch-hybrid.cpp:419-430 for one limb: out[r] = sum_t x_t[r] * k_t[r] (NativePoly products, operator+=) */
+void orc_vec_inner_product(uint64_t* out, const uint64_t* const* x, const uint64_t* const* k, uint32_t nTerms, size_t n, uint64_t q) {
+    for (size_t r = 0; r < n; ++r) {
+        uint64_t acc = 0;
+        for (uint32_t t = 0; t < nTerms; ++t)
+            acc = orc_mod_add_fast(acc, orc_mulmod(x[t][r], k[t][r], q), q);
+        out[r] = acc;
+    }
+}
 /* dcrtpoly-impl.h:347-354 -> poly Negate -> q - v (0 stays 0 via ModSub(0, v)) */
 void orc_vec_neg(uint64_t* out, const uint64_t* a, size_t n, uint64_t q) {
     for (size_t i = 0; i < n; ++i)

@@ -79,6 +79,7 @@ void orc_vec_mul(uint64_t* out, const uint64_t* a, const uint64_t* b, size_t n, 
 void orc_vec_mul_const(uint64_t* out, const uint64_t* a, uint64_t c, size_t n, uint64_t q);
 void orc_vec_add_const(uint64_t* out, const uint64_t* a, uint64_t c, size_t n, uint64_t q, int coeff0Only);
 void orc_vec_sub_const(uint64_t* out, const uint64_t* a, uint64_t c, size_t n, uint64_t q);
+void orc_vec_inner_product(uint64_t* out, const uint64_t* const* x, const uint64_t* const* k, uint32_t nTerms, size_t n, uint64_t q);
 void orc_vec_mult_acc(uint64_t* acc, const uint64_t* v, uint64_t c, size_t n, uint64_t q);
 void orc_vec_neg(uint64_t* out, const uint64_t* a, size_t n, uint64_t q);
 

@@ -74,6 +74,7 @@ def load_oracle():
         S(n, None, [P64, P64, P64, C.c_size_t, u64])
     S("orc_vec_mul_const", None, [P64, P64, u64, C.c_size_t, u64])
     S("orc_vec_mult_acc", None, [P64, P64, u64, C.c_size_t, u64])
+    S("orc_vec_inner_product", None, [P64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), u32, C.c_size_t, u64])
     S("orc_vec_add_const", None, [P64, P64, u64, C.c_size_t, u64, C.c_int])
     S("orc_vec_sub_const", None, [P64, P64, u64, C.c_size_t, u64])
     S("orc_vec_neg", None, [P64, P64, C.c_size_t, u64])

@@ -149,6 +149,57 @@ def test_elementwise(backend, oracle):
         ctx.close()
 
 
+def test_inner_product_over_separate_towers(backend, oracle):
+    """fhe_inner_product = the sum of EvalFastKeySwitchCoreExt (keyswitch-hybrid.cpp:419-430) with every digit and every key
+    element in its own allocation; key rows through keyRow (the reference's idx(i)), one or two outputs, 1..8 terms, batch"""
+    o = oracle
+    rng = np.random.default_rng(5150)
+    vp = C.c_void_p
+    for logN, rows, keyRows, nTerms, B, two in [(4, 2, 3, 1, 1, True), (11, 5, 8, 3, 2, True), (12, 4, 4, 8, 1, False),
+                                                (13, 3, 6, 2, 1, True)]:
+        N = 1 << logN
+        q, psi = params(o, logN, keyRows)
+        ctx = fh.Context(backend, logN, q, psi)
+        # output row i lives on context limb limb[i] and multiplies key row keyRow[i] (= the same limb of the key tower)
+        skip = keyRows - rows
+        keyRow = np.array([i if i < rows - 1 else i + skip for i in range(rows)], np.uint32)
+        limb = keyRow.copy()
+        xs = [np.stack([np.stack([rng.integers(0, int(q[l]), N, dtype=np.uint64) for l in limb]) for _ in range(B)]) for _ in range(nTerms)]
+        xs[0][0, 0, :3] = q[limb[0]] - np.uint64(1)
+        k0 = [libs.rand_tower(rng, q, N) for _ in range(nTerms)]
+        k1 = [libs.rand_tower(rng, q, N) for _ in range(nTerms)]
+        k0[0][limb[0], :3] = q[limb[0]] - np.uint64(1)
+        want0 = np.empty((B, rows, N), np.uint64)
+        want1 = np.empty((B, rows, N), np.uint64)
+        for bb in range(B):
+            for i in range(rows):
+                for keys, want in ((k0, want0), (k1, want1)):
+                    xp = (vp * nTerms)(*[x[bb, i].ctypes.data for x in xs])
+                    kp = (vp * nTerms)(*[k[keyRow[i]].ctypes.data for k in keys])
+                    o.orc_vec_inner_product(want[bb, i], xp, kp, nTerms, N, q[limb[i]])
+        tx = [ctx.tower(x, limb_idx=limb) for x in xs]
+        tk0 = [ctx.tower(k[None]) for k in k0]
+        tk1 = [ctx.tower(k[None]) for k in k1]
+        out0, out1 = tx[0].like(), tx[0].like()
+        px = (vp * nTerms)(*[t.ptr for t in tx])
+        p0 = (vp * nTerms)(*[t.ptr for t in tk0])
+        p1 = (vp * nTerms)(*[t.ptr for t in tk1])
+        u32p = C.POINTER(C.c_uint32)
+        backend.check(backend.L.fhe_inner_product(ctx.h, nTerms, px, p0, p1 if two else None, keyRow.ctypes.data_as(u32p),
+                                                  limb.ctypes.data_as(u32p), rows, B, out0.ptr, out1.ptr if two else None, None))
+        assert np.array_equal(out0.to_host(), want0), f"inner product (b half) logN={logN}"
+        if two:
+            assert np.array_equal(out1.to_host(), want1), f"inner product (a half) logN={logN}"
+        ctx.close()
+    # more than 8 terms: refused, not miscomputed
+    q, psi = params(o, 4, 2)
+    ctx = fh.Context(backend, 4, q, psi)
+    t = ctx.tower(libs.rand_tower(rng, q, 16, 1))
+    p9 = (vp * 9)(*[t.ptr] * 9)
+    assert backend.L.fhe_inner_product(ctx.h, 9, p9, p9, None, None, None, 2, 1, t.like().ptr, None, None) != 0
+    ctx.close()
+
+
 def test_plus_minus_constants(backend, oracle):
     """fhe_add_const / fhe_sub_const = DCRTPolyImpl::Plus / Minus(vector<Integer>) (dcrtpoly-impl.h:520-548): every word in
     EVALUATION, coefficient 0 only for Plus in COEFFICIENT; constants >= q are reduced first; in place and out of place"""
