@@ -18,7 +18,7 @@ fi
 echo "== config-4-size bootstrap, stock backend (OMP_NUM_THREADS=32)"
 (time OMP_NUM_THREADS=32 timeout 900 $B/shim_ckks_stock gpurun_out/boot_stock.bin $PWD/$B/libdetprng.so boottime $LOGN) 2>&1 | grep -v "^dumped" | tail -9
 echo "== config-4-size bootstrap, HIP backend of DCRTPoly (same program, same PRNG)"
-(time OMP_NUM_THREADS=32 FHE_HAL_REQUIRE_DEVICE=1 FHE_HAL_TRACE=1 timeout 900 $B/shim_ckks_hip gpurun_out/boot_hip.bin $PWD/$B/libdetprng.so boottime $LOGN $((1 << (LOGN - 1))) 3) 2>&1 | grep -v "^dumped" | cut -c1-220 | tail -22
+(time OMP_NUM_THREADS=32 FHE_HAL_REQUIRE_DEVICE=1 timeout 900 $B/shim_ckks_hip gpurun_out/boot_hip.bin $PWD/$B/libdetprng.so boottime $LOGN $((1 << (LOGN - 1))) 3) 2>&1 | grep -v "^dumped" | cut -c1-220 | tail -22
 cmp gpurun_out/boot_stock.bin gpurun_out/boot_hip.bin && echo "BOOTSTRAP at 2^$LOGN: HIP backend == stock backend, bit for bit"
 rm -f gpurun_out/boot_stock.bin gpurun_out/boot_hip.bin
 } 2>&1 | tee gpurun_out/session_shim.log
