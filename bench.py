@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--no-bfv", action="store_true", help="skip the BFV EvalMult (BEHZ) leg (BASELINE configs[4] shape)")
     ap.add_argument("--bfv-batch", type=int, default=64)
     ap.add_argument("--no-lt", action="store_true", help="skip the BSGS linear-transform leg (bootstrapping's inner loop)")
+    ap.add_argument("--no-bootstrap", action="store_true",
+                    help="skip the EvalBootstrap leg (BASELINE configs[3] shape through the reference's CryptoContext on the HIP backend of DCRTPoly)")
+    ap.add_argument("--bootstrap-logn", type=int, default=17)
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparisons of the legs' results")
     ap.add_argument("--evalmult-logn", type=int, default=16, help="ring of the EvalMult leg (config 3: 16)")
     ap.add_argument("--evalmult-limbs", type=int, default=21, help="Q limbs of the EvalMult leg (config 3: 21)")
@@ -630,6 +633,67 @@ def free_port():
         return sk.getsockname()[1]
 
 
+def bootstrap_leg(logN, with_cpu, libpath):
+    """BASELINE configs[3]'s operation at its full single-ciphertext size (benchmark/src/ckks-bootstrapping.cpp:70: N = 2^17, 2^16
+    slots, level budget {4,4}, SPARSE_TERNARY, FLEXIBLEAUTO): the reference's own `cc->EvalBootstrap`, i.e. the reference's pke
+    sources compiled against the HIP backend of lbcrypto::DCRTPoly (openfhe-development_amd/hal, INTEGRATION.md §1).  The program
+    is tests/hal/shim_ckks.cpp; the CPU leg is the same program linked against the stock libraries (oracle/_ref), run with the
+    same deterministic PRNG, and the two bootstrapped ciphertexts are compared byte for byte."""
+    import re
+    import subprocess
+    import tempfile
+    bdir = os.path.join(ROOT, "tests", "hal", "_build")
+    hip, stock, prng = (os.path.join(bdir, n) for n in ("shim_ckks_hip", "shim_ckks_stock", "libdetprng.so"))
+    if not (os.path.exists(hip) and os.path.exists(prng)):
+        return {"skipped": "tests/hal/_build/shim_ckks_hip not built (./build.sh hal needs the reference sources)"}
+    tmp = tempfile.mkdtemp(prefix="fhe_boot_")
+    slots = 1 << (logN - 1)
+
+    def run(exe, out, reps, env_extra):
+        env = dict(os.environ)
+        env.update(env_extra)
+        env.setdefault("OMP_NUM_THREADS", str(os.cpu_count() or 1))
+        t0 = time.perf_counter()
+        p = subprocess.run([exe, out, prng, "boottime", str(logN), str(slots), str(reps)], env=env, capture_output=True, text=True,
+                           timeout=900)
+        wall = time.perf_counter() - t0
+        txt = p.stdout + p.stderr
+        m = re.search(r"bootstrap seconds ([0-9.eE+-]+)", txt)
+        if p.returncode != 0 or not m:
+            return None, txt[-400:], wall
+        return float(m.group(1)), txt, wall
+
+    sec, txt, wall = run(hip, os.path.join(tmp, "hip.bin"), 5, {"FHE_HIP_LIB": libpath, "FHE_HAL_REQUIRE_DEVICE": "1"})
+    if sec is None:
+        return {"error": txt}
+    shape = re.search(r"config4 (.*)", txt)
+    per = re.search(r"per bootstrap: deviceOps (\d+) hostOps (\d+) h2dMB ([0-9.]+) d2hMB ([0-9.]+)", txt)
+    res = {"workload": "one ciphertext, " + (shape.group(1).strip() if shape else f"ring 2^{logN}"),
+           "seconds_per_bootstrap": round(sec, 5), "bootstraps_per_s": round(1.0 / sec, 2),
+           "host_threads": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)), "process_wall_s": round(wall, 1),
+           "how": "reference pke (unmodified sources) on the HIP backend of DCRTPoly; 1 warm-up + 5 timed cc->EvalBootstrap",
+           "parity": "not checked", "cpu_baseline": None}
+    if per:
+        res.update({"device_ops": int(per.group(1)), "host_mirror_ops": int(per.group(2)), "pcie_MB_h2d": float(per.group(3)),
+                    "pcie_MB_d2h": float(per.group(4))})
+    if with_cpu and os.path.exists(stock):
+        csec, ctxt, cwall = run(stock, os.path.join(tmp, "stock.bin"), 1, {})
+        if csec is not None:
+            res["cpu_baseline"] = {"value": round(1.0 / csec, 4), "unit": "bootstraps/s", "seconds_per_bootstrap": round(csec, 3),
+                                   "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)), "kind": "reference",
+                                   "sample": "the same program on the stock backend (oracle/_ref), 1 warm-up + 1 timed bootstrap"}
+            res["speedup_vs_cpu"] = round(csec / sec, 1)
+            try:
+                same = open(os.path.join(tmp, "hip.bin"), "rb").read() == open(os.path.join(tmp, "stock.bin"), "rb").read()
+                res["parity"] = ("bootstrapped ciphertext identical byte for byte to the stock backend's" if same
+                                 else "MISMATCH vs the stock backend")
+            except OSError as e:
+                res["parity"] = f"dumps unreadable: {e}"
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    return res
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -913,6 +977,13 @@ def main():
         ltr = linear_transform_leg(lib, device, (1, 8), max(10, a.steps), 3, rank == 0 and not a.no_cpu_baseline,
                                    parity=not a.no_parity)
 
+    boot = None
+    if rank == 0 and world == 1 and not a.no_bootstrap and logN == 16 and not os.environ.get("FHE_HIP_LIB", "").endswith("libfhe_emu.so"):
+        try:
+            boot = bootstrap_leg(a.bootstrap_logn, not a.no_cpu_baseline, lib.path)
+        except Exception as e:  # the leg is an extra: never takes the headline line down
+            boot = {"error": f"{type(e).__name__}: {e}"}
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(q, psi, logN, L, a.cpu_seconds)
@@ -937,6 +1008,8 @@ def main():
             out["bfv_evalmult"] = bfv
         if ltr is not None:
             out["linear_transform"] = ltr
+        if boot is not None:
+            out["evalbootstrap"] = boot
         print(json.dumps(out))
     ctx.close()
     if dist is not None:

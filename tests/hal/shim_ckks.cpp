@@ -103,6 +103,47 @@ int main(int argc, char** argv) {
         show("rot", cc, kp.secretKey, rot2, 8);
         show("final", cc, kp.secretKey, d, 8);
     }
+    else if (mode == "opbench") {
+        // host cost per DCRTPoly operation: small towers (the kernels take a few microseconds), many repetitions, one thread
+        const uint32_t L = argc > 5 ? std::atoi(argv[5]) : 8;
+        CCParams<CryptoContextCKKSRNS> p;
+        p.SetSecurityLevel(HEStd_NotSet);
+        p.SetRingDim(1u << logN);
+        p.SetMultiplicativeDepth(L - 1);
+        p.SetScalingModSize(50);
+        p.SetFirstModSize(60);
+        p.SetScalingTechnique(FIXEDMANUAL);
+        auto cc = GenCryptoContext(p);
+        cc->Enable(PKE);
+        cc->Enable(LEVELEDSHE);
+        auto kp = cc->KeyGen();
+        std::vector<double> x = {0.25, 0.5};
+        auto ct               = cc->Encrypt(kp.publicKey, cc->MakeCKKSPackedPlaintext(x));
+        DCRTPoly a = ct->GetElements()[0], b = ct->GetElements()[1];
+        std::vector<NativeInteger> consts(a.GetNumOfElements(), NativeInteger(12345));
+        auto time = [&](const char* what, int reps, auto&& body) {
+            body();
+            (void)a.GetElementAtIndex(0);  // drain the device queue
+            auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < reps; ++i)
+                body();
+            auto t1 = std::chrono::steady_clock::now();
+            (void)a.GetElementAtIndex(0);
+            auto t2 = std::chrono::steady_clock::now();
+            std::printf("%-28s %8.2f us/op issue   %8.2f us/op incl. drain\n", what, std::chrono::duration<double, std::micro>(t1 - t0).count() / reps,
+                        std::chrono::duration<double, std::micro>(t2 - t0).count() / reps);
+        };
+        const int R = 2000;
+        time("a += b", R, [&] { a += b; });
+        time("c = a + b", R, [&] { DCRTPoly c = a + b; });
+        time("c = a * b", R, [&] { DCRTPoly c = a * b; });
+        time("copy (shares words)", R, [&] { DCRTPoly c(a); });
+        time("copy then += (COW)", R, [&] { DCRTPoly c(a); c += b; });
+        time("Times(vector<NativeInt>)", R, [&] { DCRTPoly c = a.Times(consts); });
+        time("SwitchFormat x2", R / 2, [&] { a.SwitchFormat(); a.SwitchFormat(); });
+        time("Negate", R, [&] { DCRTPoly c = a.Negate(); });
+        time("GetNumOfElements/GetParams", R, [&] { volatile auto n = a.GetNumOfElements() + a.GetParams()->GetParams().size(); (void)n; });
+    }
     else if (mode == "bootkeys" || mode == "boottime") {
         // BASELINE configs[3]: benchmark/src/ckks-bootstrapping.cpp:70 {2^17, 2^16 slots, 59, 60, auto digits, 5 levels after,
         // {4,4}, SPARSE_TERNARY, FLEXIBLEAUTO} (ring overridable).  bootkeys: size of the rotation-key set; boottime: + one timed EvalBootstrap
