@@ -48,6 +48,8 @@ struct Runtime {
     // conversion plans
     std::mutex convMutex;
     std::map<std::vector<uint64_t>, fhe_conv*> convs;  // key = {ctx, nSrc, nDst, idx..., table words...}
+    std::map<std::vector<uint64_t>, fhe_sr_plan*> srPlans;
+    std::map<std::vector<uint64_t>, fhe_behz*> behzPlans;  // key = {ctx, numQ, qIdx..., bskIdx..., t}
     std::atomic<uint64_t> deviceOps{0}, hostFallbacks{0}, h2dBytes{0}, d2hBytes{0};
 };
 
@@ -81,7 +83,10 @@ Runtime* build() {
                   sym(h, "fhe_mult_acc", &a.mult_acc) && sym(h, "fhe_add_const", &a.add_const) && sym(h, "fhe_sub_const", &a.sub_const) && sym(h, "fhe_automorph", &a.automorph) &&
                   sym(h, "fhe_switch_modulus", &a.switch_modulus) && sym(h, "fhe_conv_create_custom", &a.conv_create_custom) &&
                   sym(h, "fhe_approx_switch_basis", &a.approx_switch_basis) &&
-                  sym(h, "fhe_switch_basis_exact", &a.switch_basis_exact);
+                  sym(h, "fhe_switch_basis_exact", &a.switch_basis_exact) && sym(h, "fhe_sr_plan_create", &a.sr_plan_create) &&
+                  sym(h, "fhe_scale_and_round", &a.scale_and_round) && sym(h, "fhe_behz_create", &a.behz_create) &&
+                  sym(h, "fhe_behz_workspace_bytes", &a.behz_workspace_bytes) && sym(h, "fhe_behz_q_to_bsk", &a.behz_q_to_bsk) &&
+                  sym(h, "fhe_behz_floorq", &a.behz_floorq) && sym(h, "fhe_behz_conv_sk", &a.behz_conv_sk);
         if (!ok)
             r->why = path + " does not export the C ABI of include/fhe_hip.h";
         else if (a.device_count() < 1)
@@ -311,6 +316,49 @@ fhe_conv* ConvPlan(fhe_ctx* ctx, const std::vector<uint32_t>& srcIdx, const std:
           "HIP backend: basis-conversion plan");
     r.convs.emplace(std::move(key), cv);
     return cv;
+}
+
+fhe_sr_plan* SrPlan(fhe_ctx* ctx, uint32_t sizeI, const std::vector<uint32_t>& outIdx, const uint64_t* tab, const double* frac) {
+    Runtime& r         = rt();
+    const size_t sizeO = outIdx.size();
+    std::vector<uint64_t> key{reinterpret_cast<uintptr_t>(ctx), sizeI, sizeO, frac ? 1u : 0u};
+    key.insert(key.end(), outIdx.begin(), outIdx.end());
+    key.insert(key.end(), tab, tab + sizeO * (sizeI + 1));
+    for (uint32_t i = 0; frac && i < sizeI; ++i) {
+        uint64_t w;
+        std::memcpy(&w, frac + i, 8);
+        key.push_back(w);
+    }
+    std::lock_guard<std::mutex> lk(r.convMutex);
+    auto it = r.srPlans.find(key);
+    if (it != r.srPlans.end())
+        return it->second;
+    fhe_sr_plan* p = nullptr;
+    Check(r.api.sr_plan_create(ctx, sizeI, outIdx.data(), (uint32_t)sizeO, tab, frac, &p), "HIP backend: ScaleAndRound plan");
+    r.srPlans.emplace(std::move(key), p);
+    return p;
+}
+fhe_behz* BehzPlan(fhe_ctx* ctx, const std::vector<uint32_t>& qIdx, const std::vector<uint32_t>& bskIdx, uint64_t t) {
+    Runtime& r = rt();
+    std::vector<uint64_t> key{reinterpret_cast<uintptr_t>(ctx), qIdx.size()};
+    key.insert(key.end(), qIdx.begin(), qIdx.end());
+    key.insert(key.end(), bskIdx.begin(), bskIdx.end());
+    std::lock_guard<std::mutex> lk(r.convMutex);
+    if (t == 0) {  // any plan over these bases
+        auto lo = r.behzPlans.lower_bound(key);
+        if (lo != r.behzPlans.end() && lo->first.size() == key.size() + 1 && std::equal(key.begin(), key.end(), lo->first.begin()))
+            return lo->second;
+        t = 65537;
+    }
+    key.push_back(t);
+    auto it = r.behzPlans.find(key);
+    if (it != r.behzPlans.end())
+        return it->second;
+    fhe_behz* p = nullptr;
+    if (r.api.behz_create(ctx, qIdx.data(), (uint32_t)qIdx.size(), bskIdx.data(), t, &p) != FHE_OK)
+        return nullptr;  // (bases the device kernels do not take: the member runs on the host mirror)
+    r.behzPlans.emplace(std::move(key), p);
+    return p;
 }
 
 }  // namespace hiprt

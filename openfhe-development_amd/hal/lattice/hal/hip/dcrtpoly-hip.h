@@ -451,6 +451,8 @@ public:
                         const std::vector<std::vector<NativeInteger>>& alphaQModp,
                         const std::vector<DoubleNativeInt>& modpBarrettMu, const std::vector<double>& qInv,
                         Format resultFormat) override {
+        if (ExpandOnDevice(paramsQP, paramsP, QHatInvModq, QHatInvModqPrecon, QHatModp, alphaQModp, modpBarrettMu, qInv, resultFormat, false))
+            return;
         Hm().ExpandCRTBasis(paramsQP, paramsP, QHatInvModq, QHatInvModqPrecon, QHatModp, alphaQModp, modpBarrettMu, qInv,
                             resultFormat);
     }
@@ -461,10 +463,24 @@ public:
                                     const std::vector<std::vector<NativeInteger>>& alphaQModp,
                                     const std::vector<DoubleNativeInt>& modpBarrettMu, const std::vector<double>& qInv,
                                     Format resultFormat) override {
+        if (ExpandOnDevice(paramsQP, paramsP, QHatInvModq, QHatInvModqPrecon, QHatModp, alphaQModp, modpBarrettMu, qInv, resultFormat, true))
+            return;
         Hm().ExpandCRTBasisReverseOrder(paramsQP, paramsP, QHatInvModq, QHatInvModqPrecon, QHatModp, alphaQModp, modpBarrettMu,
                                         qInv, resultFormat);
     }
     void FastExpandCRTBasisPloverQ(const Precomputations& pre) override {
+        // dcrtpoly-impl.h:1151-1164: Q -> Pl (approximate, tables mPlQHatInvModq / qInvModp), Pl -> Ql (exact), result [Ql | Pl]
+        if (hiprt::Available()) {
+            DCRTPolyType partPl = ApproxSwitchCRTBasis(m_h.GetParams(), pre.paramsPl, pre.mPlQHatInvModq, pre.mPlQHatInvModqPrecon,
+                                                       pre.qInvModp, pre.modpBarrettMu);
+            DCRTPolyType partQl = partPl.SwitchCRTBasis(pre.paramsQl, pre.PlHatInvModp, pre.PlHatInvModpPrecon, pre.PlHatModq,
+                                                        pre.alphaPlModq, pre.modqBarrettMu, pre.pInv);
+            if (partPl.IsDeviceResident() && partQl.IsDeviceResident()) {
+                const Format f = m_h.GetFormat();
+                *this = AssembleRows(pre.paramsQlPl, f, {RowPiece{&partQl, 0, partQl.NumLimbs()}, RowPiece{&partPl, 0, partPl.NumLimbs()}});
+                return;
+            }
+        }
         // (the struct is the interface's nested type; the mirror's is the same layout under its own name)
         typename HostType::Precomputations hp{pre.paramsQlPl,        pre.paramsPl,           pre.paramsQl,
                                               pre.mPlQHatInvModq,    pre.mPlQHatInvModqPrecon, pre.qInvModp,
@@ -475,6 +491,15 @@ public:
     }
     void ExpandCRTBasisQlHat(const std::shared_ptr<Params>& paramsQ, const std::vector<NativeInteger>& QlHatModq,
                              const std::vector<NativeInteger>& QlHatModqPrecon, const usint sizeQ) override {
+        // dcrtpoly-impl.h:1167-1187: limb i times QlHatModq[i], the limbs [sizeQl, sizeQ) zero
+        const uint32_t sizeQl = NumLimbs();
+        if (hiprt::Available() && QlHatModq.size() >= sizeQl && sizeQ >= sizeQl && paramsQ->GetParams().size() == sizeQ) {
+            DCRTPolyType scaled(*this);
+            if (scaled.TimesConstInPlace(QlHatModq)) {
+                *this = AssembleRows(paramsQ, m_h.GetFormat(), {RowPiece{&scaled, 0, sizeQl}, RowPiece{nullptr, 0, sizeQ - sizeQl}});
+                return;
+            }
+        }
         Hm().ExpandCRTBasisQlHat(paramsQ, QlHatModq, QlHatModqPrecon, sizeQ);
     }
 
@@ -490,12 +515,18 @@ public:
     DCRTPolyType ApproxScaleAndRound(const std::shared_ptr<Params>& paramsP,
                                      const std::vector<std::vector<NativeInteger>>& tPSHatInvModsDivsModp,
                                      const std::vector<DoubleNativeInt>& modpBarretMu) const override {
+        DCRTPolyType out;
+        if (ScaleAndRoundOnDevice(paramsP, tPSHatInvModsDivsModp, nullptr, &out))
+            return out;
         return Wrap(Hc().ApproxScaleAndRound(paramsP, tPSHatInvModsDivsModp, modpBarretMu));
     }
     DCRTPolyType ScaleAndRound(const std::shared_ptr<Params>& paramsOutput,
                                const std::vector<std::vector<NativeInteger>>& tOSHatInvModsDivsModo,
                                const std::vector<double>& tOSHatInvModsDivsFrac,
                                const std::vector<DoubleNativeInt>& modoBarretMu) const override {
+        DCRTPolyType out;
+        if (ScaleAndRoundOnDevice(paramsOutput, tOSHatInvModsDivsModo, &tOSHatInvModsDivsFrac, &out))
+            return out;
         return Wrap(Hc().ScaleAndRound(paramsOutput, tOSHatInvModsDivsModo, tOSHatInvModsDivsFrac, modoBarretMu));
     }
     PolyType ScaleAndRound(const std::vector<NativeInteger>& moduliQ, const NativeInteger& t, const NativeInteger& tgamma,
@@ -517,6 +548,8 @@ public:
         const std::vector<NativeInteger>& QModbsk, const std::vector<NativeInteger>& QModbskPrecon,
         const uint64_t& negQInvModmtilde, const std::vector<NativeInteger>& mtildeInvModbsk,
         const std::vector<NativeInteger>& mtildeInvModbskPrecon) override {
+        if (BehzOnDevice(0, paramsQBsk, (uint32_t)moduliQ.size(), (uint32_t)moduliBsk.size(), 0))
+            return;
         Hm().FastBaseConvqToBskMontgomery(paramsQBsk, moduliQ, moduliBsk, modbskBarrettMu, mtildeQHatInvModq, mtildeQHatInvModqPrecon,
                                           QHatModbsk, QHatModmtilde, QModbsk, QModbskPrecon, negQInvModmtilde, mtildeInvModbsk,
                                           mtildeInvModbskPrecon);
@@ -527,6 +560,8 @@ public:
                        const std::vector<std::vector<NativeInteger>>& QHatModbsk,
                        const std::vector<std::vector<NativeInteger>>& qInvModbsk, const std::vector<NativeInteger>& tQInvModbsk,
                        const std::vector<NativeInteger>& tQInvModbskPrecon) override {
+        if (BehzOnDevice(1, m_h.GetParams(), (uint32_t)moduliQ.size(), (uint32_t)moduliBsk.size(), t.ConvertToInt<uint64_t>()))
+            return;
         Hm().FastRNSFloorq(t, moduliQ, moduliBsk, modbskBarrettMu, tQHatInvModq, tQHatInvModqPrecon, QHatModbsk, qInvModbsk,
                            tQInvModbsk, tQInvModbskPrecon);
     }
@@ -536,6 +571,8 @@ public:
                         const std::vector<NativeInteger>& BHatModmsk, const NativeInteger& BInvModmsk,
                         const NativeInteger& BInvModmskPrecon, const std::vector<std::vector<NativeInteger>>& BHatModq,
                         const std::vector<NativeInteger>& BModq, const std::vector<NativeInteger>& BModqPrecon) override {
+        if (BehzOnDevice(2, paramsQ, (uint32_t)paramsQ->GetParams().size(), (uint32_t)moduliBsk.size(), 0))
+            return;
         Hm().FastBaseConvSK(paramsQ, modqBarrettMu, moduliBsk, modbskBarrettMu, BHatInvModb, BHatInvModbPrecon, BHatModmsk,
                             BInvModmsk, BInvModmskPrecon, BHatModq, BModq, BModqPrecon);
     }
@@ -1035,6 +1072,128 @@ private:
         for (size_t i = 0; i < rows; ++i)
             for (size_t j = 0; j < cols; ++j)
                 out[i * cols + j] = (transposed ? m[j][i] : m[i][j]).ConvertToInt<uint64_t>();
+    }
+    // ExpandCRTBasis / ExpandCRTBasisReverseOrder (dcrtpoly-impl.h:1086-1148): this (Q) -> [Q | P] (or [P | Q]) in resultFormat; the
+    // EVALUATION form of the Q limbs is reused when the input has one, the P limbs come from the exact conversion of the
+    // COEFFICIENT form and are transformed on their way into place
+    bool ExpandOnDevice(const std::shared_ptr<Params>& paramsQP, const std::shared_ptr<Params>& paramsP,
+                        const std::vector<NativeInteger>& QHatInvModq, const std::vector<NativeInteger>& QHatInvModqPrecon,
+                        const std::vector<std::vector<NativeInteger>>& QHatModp, const std::vector<std::vector<NativeInteger>>& alphaQModp,
+                        const std::vector<DoubleNativeInt>& modpBarrettMu, const std::vector<double>& qInv, Format resultFormat,
+                        bool reverse) {
+        const uint32_t sizeQ = NumLimbs(), sizeP = (uint32_t)paramsP->GetParams().size();
+        if (!hiprt::Available() || paramsQP->GetParams().size() != sizeQ + sizeP)
+            return false;
+        const bool wasEval = m_h.GetFormat() == Format::EVALUATION;
+        DCRTPolyType coeff(*this);
+        if (wasEval)
+            coeff.SwitchFormat();
+        DCRTPolyType partP = coeff.SwitchCRTBasis(paramsP, QHatInvModq, QHatInvModqPrecon, QHatModp, alphaQModp, modpBarrettMu, qInv);
+        if (!partP.IsDeviceResident())
+            return false;
+        const bool toEval       = resultFormat == Format::EVALUATION;
+        const DCRTPolyType& qsrc = (toEval && wasEval) ? *this : coeff;
+        RowPiece pq{&qsrc, 0, sizeQ, toEval && !wasEval}, pp{&partP, 0, sizeP, toEval};
+        DCRTPolyType out = reverse ? AssembleRows(paramsQP, resultFormat, {pp, pq}) : AssembleRows(paramsQP, resultFormat, {pq, pp});
+        *this            = std::move(out);
+        return true;
+    }
+    // ScaleAndRound / ApproxScaleAndRound, DCRTPoly -> DCRTPoly (dcrtpoly-impl.h:1470-1628): the caller's table [sizeO][sizeI+1]
+    // and fractions [sizeI]; the output basis is the leading limbs of this tower iff the first moduli agree (:1527-1534)
+    bool ScaleAndRoundOnDevice(const std::shared_ptr<Params>& paramsO, const std::vector<std::vector<NativeInteger>>& tab,
+                               const std::vector<double>* frac, DCRTPolyType* out) const {
+        const uint32_t sizeQP = NumLimbs(), sizeO = (uint32_t)paramsO->GetParams().size();
+        if (hiprt::Available() && sizeO >= 1 && sizeQP == sizeO && tab.size() >= sizeO) {
+            // no input limbs (the leveled technique at its top level, bfvrns-leveledshe.cpp): nu = 0.5, alpha = 0, every sum is
+            // the single product x_j * tab[j][0]  (dcrtpoly-impl.h:1549-1567)
+            std::vector<NativeInteger> c(sizeO);
+            for (uint32_t j = 0; j < sizeO; ++j) {
+                if (tab[j].empty())
+                    return false;
+                c[j] = tab[j][0];
+            }
+            DCRTPolyType scaled(*this);
+            if (!scaled.TimesConstInPlace(c))
+                return false;
+            scaled.m_h = HostType(paramsO, m_h.GetFormat(), false);
+            *out       = std::move(scaled);
+            return true;
+        }
+        if (!hiprt::Available() || sizeO == 0 || sizeQP <= sizeO || sizeQP - sizeO > 64 || sizeO > 64)
+            return false;
+        const uint32_t sizeI = sizeQP - sizeO;
+        if (tab.size() < sizeO || (frac && frac->size() < sizeI))
+            return false;
+        for (uint32_t j = 0; j < sizeO; ++j)
+            if (tab[j].size() < sizeI + 1)
+                return false;
+        hiprt::Resolved r;
+        const auto& mine = m_h.GetParams();
+        if (!ResolveSets(mine->GetRingDimension(), {mine, paramsO}, &r) || !Upload(r.ctx))
+            return false;
+        std::vector<uint64_t> flat;
+        Flatten(tab, sizeO, sizeI + 1, false, flat);
+        fhe_sr_plan* plan      = hiprt::SrPlan(r.ctx, sizeI, r.idx[1], flat.data(), frac ? frac->data() : nullptr);
+        const bool outputFirst = paramsO->GetParams()[0]->GetModulus() == mine->GetParams()[0]->GetModulus();
+        const size_t N         = mine->GetRingDimension();
+        auto d                 = hiprt::Alloc((size_t)sizeO * N);
+        hiprt::Check(hiprt::api().scale_and_round(plan, m_d->p, outputFirst ? 1 : 0, d->p, 1, nullptr), "ScaleAndRound");
+        hiprt::CountDevice();
+        *out = FromDevice(paramsO, m_h.GetFormat(), std::move(d));
+        return true;
+    }
+    // the BEHZ trio (dcrtpoly-impl.h:1694-1929); which: 0 = FastBaseConvqToBskMontgomery (this over Q -> Q u Bsk, EVALUATION),
+    // 1 = FastRNSFloorq (in place on Q u Bsk, COEFFICIENT), 2 = FastBaseConvSK (Q u Bsk -> Q, COEFFICIENT).  The plan's tables
+    // are derived from the moduli and t the way CryptoParametersBFVRNS derives the arguments the reference passes here.
+    bool BehzOnDevice(int which, const std::shared_ptr<Params>& params, uint32_t numQ, uint32_t numBsk, uint64_t t) {
+        if (!hiprt::Available() || numQ == 0 || numBsk != numQ + 1)
+            return false;
+        const auto mine = m_h.GetParams();
+        const size_t N  = mine->GetRingDimension();
+        hiprt::Resolved r;
+        if (which == 0) {  // params = paramsQBsk
+            if (NumLimbs() != numQ || params->GetParams().size() != numQ + numBsk)
+                return false;
+            if (!ResolveSets(N, {params, mine}, &r) || !Upload(r.ctx))
+                return false;
+            for (uint32_t i = 0; i < numQ; ++i)
+                if (r.idx[0][i] != r.idx[1][i])
+                    return false;
+        }
+        else {  // this tower is over Q u Bsk
+            if (NumLimbs() != numQ + numBsk || m_h.GetFormat() != Format::COEFFICIENT)
+                return false;
+            if (!ResolveSets(N, {mine}, &r) || !Upload(r.ctx))
+                return false;
+        }
+        std::vector<uint32_t> qIdx(r.idx[0].begin(), r.idx[0].begin() + numQ), bskIdx(r.idx[0].begin() + numQ, r.idx[0].end());
+        fhe_behz* plan = hiprt::BehzPlan(r.ctx, qIdx, bskIdx, which == 1 ? t : 0);
+        if (!plan)
+            return false;
+        const auto& A = hiprt::api();
+        if (which == 0) {
+            const bool wasEval = m_h.GetFormat() == Format::EVALUATION;
+            auto d             = hiprt::Alloc((size_t)(numQ + numBsk) * N);
+            hiprt::D2D(r.ctx, d->p, m_d->p, (size_t)numQ * N * 8, "FastBaseConvqToBskMontgomery");
+            const size_t wsB = A.behz_workspace_bytes(plan, 1);
+            auto ws          = hiprt::Alloc(wsB / 8 + 1);
+            hiprt::Check(A.behz_q_to_bsk(plan, d->p, wasEval ? 1 : 0, 1, ws->p, wsB, nullptr), "FastBaseConvqToBskMontgomery");
+            hiprt::CountDevice();
+            *this = FromDevice(params, Format::EVALUATION, std::move(d));
+            return true;
+        }
+        if (which == 1) {
+            Unshare(r.ctx);
+            hiprt::Check(A.behz_floorq(plan, m_d->p, 1, nullptr), "FastRNSFloorq");
+            hiprt::CountDevice();
+            DeviceIsNewer(Format::COEFFICIENT);
+            return true;
+        }
+        auto d = hiprt::Alloc((size_t)numQ * N);
+        hiprt::Check(A.behz_conv_sk(plan, m_d->p, d->p, 1, nullptr), "FastBaseConvSK");
+        hiprt::CountDevice();
+        *this = FromDevice(params, Format::COEFFICIENT, std::move(d));
+        return true;
     }
     // ApproxSwitchCRTBasis (alpha == nullptr) / SwitchCRTBasis on the device; this tower over paramsQ -> *out over paramsP
     bool SwitchBasisOnDevice(const std::shared_ptr<Params>& paramsQ, const std::shared_ptr<Params>& paramsP,

@@ -45,6 +45,13 @@ struct Api {
     decltype(&fhe_conv_create_custom) conv_create_custom;
     decltype(&fhe_approx_switch_basis) approx_switch_basis;
     decltype(&fhe_switch_basis_exact) switch_basis_exact;
+    decltype(&fhe_sr_plan_create) sr_plan_create;
+    decltype(&fhe_scale_and_round) scale_and_round;
+    decltype(&fhe_behz_create) behz_create;
+    decltype(&fhe_behz_workspace_bytes) behz_workspace_bytes;
+    decltype(&fhe_behz_q_to_bsk) behz_q_to_bsk;
+    decltype(&fhe_behz_floorq) behz_floorq;
+    decltype(&fhe_behz_conv_sk) behz_conv_sk;
 };
 
 // true when the library is loaded and a device is usable; otherwise every DCRTPoly member runs on its host mirror
@@ -80,6 +87,12 @@ bool Resolve(uint32_t ringDim, const std::vector<LimbSet>& sets, Resolved* out);
 // hatInv[nSrc], hatMod[nSrc][nDst] row-major; alphaMod[(nSrc+1)][nDst] + qInv[nSrc] for the exact variant or both null
 fhe_conv* ConvPlan(fhe_ctx* ctx, const std::vector<uint32_t>& srcIdx, const std::vector<uint32_t>& dstIdx, const uint64_t* hatInv,
                    const uint64_t* hatMod, const uint64_t* alphaMod, const double* qInv);
+
+// ---- ScaleAndRound plans (the caller's tables: tab [sizeO][sizeI+1], frac [sizeI] or null for ApproxScaleAndRound) and BEHZ
+// plans (tables derived from the moduli and t exactly as CryptoParametersBFVRNS derives them: bfvrns-cryptoparameters.cpp:673-850;
+// t = 0: any plan over these bases will do — FastBaseConvqToBskMontgomery and FastBaseConvSK do not depend on t) ----
+fhe_sr_plan* SrPlan(fhe_ctx* ctx, uint32_t sizeI, const std::vector<uint32_t>& outIdx, const uint64_t* tab, const double* frac);
+fhe_behz* BehzPlan(fhe_ctx* ctx, const std::vector<uint32_t>& qIdx, const std::vector<uint32_t>& bskIdx, uint64_t t);
 
 // ---- counters (tests assert that the device path really ran) ----
 struct Stats {

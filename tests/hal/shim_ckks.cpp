@@ -103,6 +103,62 @@ int main(int argc, char** argv) {
         show("rot", cc, kp.secretKey, rot2, 8);
         show("final", cc, kp.secretKey, d, 8);
     }
+    else if (mode == "bfv") {
+        // BFV (BASELINE configs[4]): EvalMult in each of the reference's multiplication techniques (bfvrns-leveledshe.cpp:198-445:
+        // BEHZ = FastBaseConvqToBskMontgomery / FastRNSFloorq / FastBaseConvSK; HPS* = ExpandCRTBasis, FastExpandCRTBasisPloverQ,
+        // ScaleAndRound, SwitchCRTBasis, ExpandCRTBasisQlHat), HYBRID relinearisation, a rotation, a second multiplication
+        const std::string tech = argc > 5 ? argv[5] : "BEHZ";
+        CCParams<CryptoContextBFVRNS> p;
+        p.SetSecurityLevel(HEStd_NotSet);
+        p.SetRingDim(1u << logN);
+        p.SetPlaintextModulus(65537);
+        p.SetMultiplicativeDepth(argc > 6 ? std::atoi(argv[6]) : 2);
+        p.SetScalingModSize(60);
+        p.SetKeySwitchTechnique(HYBRID);
+        p.SetMultiplicationTechnique(tech == "BEHZ" ? BEHZ : tech == "HPS" ? HPS : tech == "HPSPOVERQ" ? HPSPOVERQ : HPSPOVERQLEVELED);
+        auto cc = GenCryptoContext(p);
+        cc->Enable(PKE);
+        cc->Enable(KEYSWITCH);
+        cc->Enable(LEVELEDSHE);
+        auto kp = cc->KeyGen();
+        cc->EvalMultKeyGen(kp.secretKey);
+        cc->EvalRotateKeyGen(kp.secretKey, {1});
+        std::vector<int64_t> x = {1, 2, 3, 4, 5, 6, 7, 8}, y = {3, -2, 5, 1, -4, 2, 9, -7};
+        auto cx = cc->Encrypt(kp.publicKey, cc->MakePackedPlaintext(x));
+        auto cy = cc->Encrypt(kp.publicKey, cc->MakePackedPlaintext(y));
+        dump("x", cx);
+        dump("y", cy);
+        auto t0 = std::chrono::steady_clock::now();
+        auto m3 = cc->EvalMultNoRelin(cx, cy);
+        dump("x*y (3 elements)", m3);
+        auto m = cc->EvalMult(cx, cy);
+        dump("x*y", m);
+        auto r = cc->EvalRotate(m, 1);
+        dump("rotate1", r);
+        auto m2 = cc->EvalMult(cc->EvalAdd(r, cx), m);  // second level
+        dump("second", m2);
+        auto sq = cc->EvalSquare(cx);
+        dump("square", sq);
+        std::cout << "bfv " << tech << " ring 2^" << logN << " limbs " << cx->GetElements()[0].GetNumOfElements() << " eval seconds "
+                  << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << std::endl;
+        for (auto& pr : std::vector<std::pair<const char*, Ciphertext<DCRTPoly>>>{{"x*y", m}, {"second", m2}, {"square", sq}}) {
+            Plaintext pt;
+            cc->Decrypt(kp.secretKey, pr.second, &pt);
+            pt->SetLength(8);
+            std::cout << "value " << pr.first << ": " << pt->GetPackedValue() << std::endl;
+        }
+        if (argc > 7) {  // timing: EvalMult (with relinearisation) repeated
+            const int reps = std::atoi(argv[7]);
+            auto w         = cc->EvalMult(cx, cy);
+            (void)w->GetElements()[0].GetElementAtIndex(0);
+            t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < reps; ++i)
+                w = cc->EvalMult(cx, cy);
+            (void)w->GetElements()[0].GetElementAtIndex(0);
+            std::cout << "bfv EvalMult seconds " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps << " ("
+                      << reps << " reps)" << std::endl;
+        }
+    }
     else if (mode == "opbench") {
         // host cost per DCRTPoly operation: small towers (the kernels take a few microseconds), many repetitions, one thread
         const uint32_t L = argc > 5 ? std::atoi(argv[5]) : 8;

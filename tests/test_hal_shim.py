@@ -27,26 +27,27 @@ def ensure_built():
         pytest.skip("tests/hal/_build not present and /root/reference not mounted")
 
 
-def run(prog, out, mode, logN, device_lib=None):
+def run(prog, out, mode, logN, device_lib=None, extra=()):
     env = dict(os.environ, OMP_NUM_THREADS="1")
     if device_lib:
         env["FHE_HIP_LIB"] = device_lib
         env["FHE_HAL_REQUIRE_DEVICE"] = "1"  # the shim must not silently degrade to its host mirror
-    r = subprocess.run([prog, out, PROGS[2], mode, str(logN)], env=env, capture_output=True, text=True, timeout=1500)
+    r = subprocess.run([prog, out, PROGS[2], mode, str(logN)] + [str(e) for e in extra], env=env, capture_output=True, text=True,
+                       timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     return r.stdout
 
 
 def values(stdout, name):
     m = re.search(r"value " + re.escape(name) + r":(.*)", stdout)
-    return [float(v) for v in m.group(1).split()]
+    return [float(v) for v in m.group(1).replace("[", " ").replace("]", " ").split()]
 
 
-def check(tmp_path, mode, logN, device_lib, expect):
+def check(tmp_path, mode, logN, device_lib, expect, extra=()):
     ensure_built()
     so, sh = str(tmp_path / "stock.bin"), str(tmp_path / "hip.bin")
-    out_stock = run(PROGS[0], so, mode, logN)
-    out_hip = run(PROGS[1], sh, mode, logN, device_lib)
+    out_stock = run(PROGS[0], so, mode, logN, extra=extra)
+    out_hip = run(PROGS[1], sh, mode, logN, device_lib, extra=extra)
     assert "hal: stock backend" in out_stock
     m = re.search(r"hal: available (\d+) deviceOps (\d+) hostOps (\d+)", out_hip)
     assert m and int(m.group(1)) == 1 and int(m.group(2)) > 0, out_hip[-500:]
@@ -67,6 +68,10 @@ ROT = [0.0] + XY[:7]
 FINAL = [0.5 * (r + s) ** 2 for r, s in zip(ROT, XY)]
 LEVELED = {"x*y": XY, "rot": ROT, "final": FINAL}
 BOOT = {"bootstrapped": [0.25, 0.5, 0.75, 1.0, 2.0, 3.0, 4.0, 5.0]}
+BX, BY = [1, 2, 3, 4, 5, 6, 7, 8], [3, -2, 5, 1, -4, 2, 9, -7]
+BXY = [a * b for a, b in zip(BX, BY)]
+BROT = BXY[1:] + [0]
+BFV = {"x*y": BXY, "second": [(r + x) * m for r, x, m in zip(BROT, BX, BXY)], "square": [a * a for a in BX]}
 EMU = os.path.join(ROOT, "tests", "emu", "libfhe_emu.so")
 HIP = os.path.join(ROOT, "openfhe-development_amd", "csrc", "libfhe_hip.so")
 
@@ -89,3 +94,18 @@ def test_shim_leveled_ckks_matches_default_backend_on_gpu(tmp_path, logN):
 def test_shim_bootstrap_matches_default_backend_on_gpu(tmp_path):
     ops = check(tmp_path, "bootstrap", 13, HIP, BOOT)
     assert ops > 500  # ModRaise, the CoeffsToSlots / SlotsToCoeffs transforms and the Chebyshev evaluation ran on the device
+
+
+# BFV (BASELINE configs[4]) through the reference's CryptoContext, every multiplication technique of bfvrns-leveledshe.cpp:198-445:
+# the BEHZ trio, ExpandCRTBasis, FastExpandCRTBasisPloverQ, ScaleAndRound, SwitchCRTBasis, ExpandCRTBasisQlHat as device members
+@pytest.mark.parametrize("tech", ["BEHZ", "HPSPOVERQ", "HPS", "HPSPOVERQLEVELED"])
+def test_shim_bfv_matches_default_backend_on_emulator(tmp_path, tech):
+    ops = check(tmp_path, "bfv", 10, EMU, BFV, extra=(tech,))
+    assert ops > 100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tech,logN,depth", [("BEHZ", 13, 2), ("HPSPOVERQ", 13, 2), ("HPS", 12, 3), ("HPSPOVERQLEVELED", 12, 3), ("BEHZ", 15, 5)])
+def test_shim_bfv_matches_default_backend_on_gpu(tmp_path, tech, logN, depth):
+    ops = check(tmp_path, "bfv", logN, HIP, BFV, extra=(tech, depth))
+    assert ops > 100
