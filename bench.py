@@ -648,11 +648,14 @@ def bootstrap_leg(logN, with_cpu, libpath):
         return {"skipped": "tests/hal/_build/shim_ckks_hip not built (./build.sh hal needs the reference sources)"}
     tmp = tempfile.mkdtemp(prefix="fhe_boot_")
     slots = 1 << (logN - 1)
+    # 32 host threads for both programs: the stock backend's best team on the GPU boxes' hosts (8.9-10.2 s per bootstrap at
+    # N = 2^17; 45 s with all 256 hardware threads), and the HIP backend is GPU-bound from 8 threads on (profiles/r02_sweeps.md)
+    threads = int(os.environ.get("FHE_BENCH_BOOT_THREADS", min(32, os.cpu_count() or 1)))
 
     def run(exe, out, reps, env_extra):
         env = dict(os.environ)
         env.update(env_extra)
-        env.setdefault("OMP_NUM_THREADS", str(os.cpu_count() or 1))
+        env["OMP_NUM_THREADS"] = str(threads)
         t0 = time.perf_counter()
         p = subprocess.run([exe, out, prng, "boottime", str(logN), str(slots), str(reps)], env=env, capture_output=True, text=True,
                            timeout=900)
@@ -670,7 +673,7 @@ def bootstrap_leg(logN, with_cpu, libpath):
     per = re.search(r"per bootstrap: deviceOps (\d+) hostOps (\d+) h2dMB ([0-9.]+) d2hMB ([0-9.]+)", txt)
     res = {"workload": "one ciphertext, " + (shape.group(1).strip() if shape else f"ring 2^{logN}"),
            "seconds_per_bootstrap": round(sec, 5), "bootstraps_per_s": round(1.0 / sec, 2),
-           "host_threads": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)), "process_wall_s": round(wall, 1),
+           "host_threads": threads, "process_wall_s": round(wall, 1),
            "how": "reference pke (unmodified sources) on the HIP backend of DCRTPoly; 1 warm-up + 5 timed cc->EvalBootstrap",
            "parity": "not checked", "cpu_baseline": None}
     if per:
@@ -680,7 +683,7 @@ def bootstrap_leg(logN, with_cpu, libpath):
         csec, ctxt, cwall = run(stock, os.path.join(tmp, "stock.bin"), 1, {})
         if csec is not None:
             res["cpu_baseline"] = {"value": round(1.0 / csec, 4), "unit": "bootstraps/s", "seconds_per_bootstrap": round(csec, 3),
-                                   "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)), "kind": "reference",
+                                   "cores": threads, "kind": "reference",
                                    "sample": "the same program on the stock backend (oracle/_ref), 1 warm-up + 1 timed bootstrap"}
             res["speedup_vs_cpu"] = round(csec / sec, 1)
             try:
