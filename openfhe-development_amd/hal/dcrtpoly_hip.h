@@ -375,6 +375,7 @@ public:
         check(fhe_malloc(m_params->ctx(), rows.size() * sizeof(uint64_t), &d));
         m_diag.push_back(d);
         check(fhe_memcpy_h2d(m_params->ctx(), d, rows.data(), rows.size() * sizeof(uint64_t), nullptr));
+        check(fhe_stream_sync(m_params->ctx(), nullptr));  // the copy reads the caller's vector: it may die right after the call
         return static_cast<const uint64_t*>(d);
     }
     // A[i] = diagonal i (nullptr = absent); baby step bStep, giant steps ceil(|A| / bStep)
