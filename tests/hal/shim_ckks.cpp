@@ -159,6 +159,53 @@ int main(int argc, char** argv) {
                       << reps << " reps)" << std::endl;
         }
     }
+    else if (mode == "multbatch") {
+        // BASELINE configs[2] through the reference's CryptoContext: B ciphertexts at N = 2^logN, depth 20 (l = 21, dnum = 3),
+        // cc->EvalMult (tensor + HYBRID key switch) on each, the ciphertexts spread over host threads (one OpenMP loop over the
+        // batch: pke's own inner loops then run inside each thread); the products are dumped for the byte comparison
+        const uint32_t depth = argc > 5 ? std::atoi(argv[5]) : 20;
+        const int B          = argc > 6 ? std::atoi(argv[6]) : 64;
+        const int reps       = argc > 7 ? std::atoi(argv[7]) : 3;
+        CCParams<CryptoContextCKKSRNS> p;
+        p.SetSecurityLevel(HEStd_NotSet);
+        p.SetRingDim(1u << logN);
+        p.SetMultiplicativeDepth(depth);
+        p.SetScalingModSize(59);
+        p.SetFirstModSize(60);
+        p.SetKeySwitchTechnique(HYBRID);
+        p.SetScalingTechnique(FLEXIBLEAUTO);
+        auto cc = GenCryptoContext(p);
+        cc->Enable(PKE);
+        cc->Enable(KEYSWITCH);
+        cc->Enable(LEVELEDSHE);
+        auto kp = cc->KeyGen();
+        cc->EvalMultKeyGen(kp.secretKey);
+        std::vector<Ciphertext<DCRTPoly>> a(B), b(B), c(B);
+        for (int i = 0; i < B; ++i) {
+            std::vector<double> x = {0.25 + i, 0.5, -1.0}, y = {2.0, 0.5 * i, 3.0};
+            a[i] = cc->Encrypt(kp.publicKey, cc->MakeCKKSPackedPlaintext(x));
+            b[i] = cc->Encrypt(kp.publicKey, cc->MakeCKKSPackedPlaintext(y));
+        }
+        const auto cp = std::dynamic_pointer_cast<CryptoParametersRNS>(cc->GetCryptoParameters());
+        std::cout << "multbatch ring 2^" << logN << " sizeQ " << a[0]->GetElements()[0].GetNumOfElements() << " sizeP "
+                  << cp->GetParamsP()->GetParams().size() << " dnum " << cp->GetNumPartQ() << " ciphertexts " << B << std::endl;
+        auto pass = [&] {
+#pragma omp parallel for schedule(dynamic, 1)
+            for (int i = 0; i < B; ++i)
+                c[i] = cc->EvalMult(a[i], b[i]);
+            for (int i = 0; i < B; i += std::max(1, B / 4))
+                (void)c[i]->GetElements()[0].GetElementAtIndex(0);  // drain the device queue
+        };
+        pass();
+        auto t0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < reps; ++r)
+            pass();
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps;
+        std::cout << "multbatch seconds per pass " << sec << " EvalMult per second " << B / sec << std::endl;
+        dump("product 0", c[0]);
+        dump("product last", c[B - 1]);
+        show("product 0", cc, kp.secretKey, c[0], 3);
+    }
     else if (mode == "opbench") {
         // host cost per DCRTPoly operation: small towers (the kernels take a few microseconds), many repetitions, one thread
         const uint32_t L = argc > 5 ? std::atoi(argv[5]) : 8;
