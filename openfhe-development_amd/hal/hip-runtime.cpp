@@ -2,9 +2,9 @@
 // Compiled into libOPENFHEcore when OpenFHE is built with this repo's lattice/lat-hal.h in front of the reference's.
 //
 // The device library is loaded at first use with dlopen: $FHE_HIP_LIB, else the path compiled in as FHE_HIP_DEFAULT_LIB
-// (libfhe_hip.so of this repo).  If it cannot be loaded or no device is visible, Available() is false and DCRTPolyHipImpl
-// behaves exactly like the default backend (every member runs on its host mirror) unless FHE_HAL_REQUIRE_DEVICE=1 asks for
-// a loud failure instead.
+// (libfhe_hip.so of this repo).  If it cannot be loaded or no device is visible the first DCRTPoly operation FAILS LOUDLY (message
+// on stderr + exception): the backend has no silent CPU path.  FHE_HAL_ALLOW_HOST=1 opts into running every member on the host
+// mirror instead (the class then behaves exactly like the default backend) — for machines without a GPU, never for measurements.
 #include "lattice/hal/hip/hip-runtime.h"
 
 #include <cxxabi.h>
@@ -94,8 +94,10 @@ Runtime* build() {
         else
             r->live = true;
     }
-    if (!r->live && std::getenv("FHE_HAL_REQUIRE_DEVICE"))
+    if (!r->live && !std::getenv("FHE_HAL_ALLOW_HOST")) {
+        std::fprintf(stderr, "HIP backend of DCRTPoly: %s (set FHE_HAL_ALLOW_HOST=1 to run on the host mirror instead)\n", r->why.c_str());
         OPENFHE_THROW("HIP backend of DCRTPoly: " + r->why);
+    }
     return r;
 }
 Runtime& rt() {

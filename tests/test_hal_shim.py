@@ -109,3 +109,16 @@ def test_shim_bfv_matches_default_backend_on_emulator(tmp_path, tech):
 def test_shim_bfv_matches_default_backend_on_gpu(tmp_path, tech, logN, depth):
     ops = check(tmp_path, "bfv", logN, HIP, BFV, extra=(tech, depth))
     assert ops > 100
+
+
+def test_shim_without_a_device_library_fails_loudly(tmp_path):
+    """no silent CPU path: an unloadable device library aborts the first DCRTPoly operation with a message; FHE_HAL_ALLOW_HOST=1 is
+    the explicit opt-in to the host mirror (the class then is the default backend)"""
+    ensure_built()
+    env = dict(os.environ, OMP_NUM_THREADS="1", FHE_HIP_LIB=str(tmp_path / "no_such_lib.so"))
+    env.pop("FHE_HAL_ALLOW_HOST", None)
+    r = subprocess.run([PROGS[1], str(tmp_path / "x.bin"), PROGS[2], "leveled", "10"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "HIP backend of DCRTPoly: cannot load" in r.stderr
+    env["FHE_HAL_ALLOW_HOST"] = "1"
+    r = subprocess.run([PROGS[1], str(tmp_path / "x.bin"), PROGS[2], "leveled", "10"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "hal: available 0 deviceOps 0" in r.stdout
