@@ -73,7 +73,10 @@ int main(int argc, char** argv) {
         p.SetFirstModSize(60);
         p.SetKeySwitchTechnique(HYBRID);
         p.SetNumLargeDigits(2);
-        p.SetScalingTechnique(FIXEDMANUAL);
+        // argv[5]: FIXEDMANUAL (default) | FIXEDAUTO | FLEXIBLEAUTO | FLEXIBLEAUTOEXT (the library default): the automatic
+        // techniques rescale inside EvalMult / adjust levels inside EvalAdd, the explicit Rescale calls below are then no-ops
+        const std::string st = argc > 5 ? argv[5] : "FIXEDMANUAL";
+        p.SetScalingTechnique(st == "FIXEDAUTO" ? FIXEDAUTO : st == "FLEXIBLEAUTO" ? FLEXIBLEAUTO : st == "FLEXIBLEAUTOEXT" ? FLEXIBLEAUTOEXT : FIXEDMANUAL);
         auto cc = GenCryptoContext(p);
         cc->Enable(PKE);
         cc->Enable(KEYSWITCH);

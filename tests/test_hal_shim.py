@@ -80,6 +80,12 @@ def test_shim_leveled_ckks_matches_default_backend_on_emulator(tmp_path):
     check(tmp_path, "leveled", 11, EMU, LEVELED)
 
 
+@pytest.mark.parametrize("technique", ["FIXEDAUTO", "FLEXIBLEAUTOEXT"])
+def test_shim_automatic_scaling_techniques_on_emulator(tmp_path, technique):
+    """the same circuit with rescaling / level adjustment done inside EvalMult / EvalAdd (FLEXIBLEAUTOEXT is the library default)"""
+    check(tmp_path, "leveled", 10, EMU, LEVELED, extra=(technique,))
+
+
 def test_shim_bootstrap_matches_default_backend_on_emulator(tmp_path):
     check(tmp_path, "bootstrap", 10, EMU, BOOT)
 
