@@ -369,6 +369,8 @@ public:
     void ModReduce(const NativeInteger& t, const std::vector<NativeInteger>& tModqPrecon, const NativeInteger& negtInvModq,
                    const NativeInteger& negtInvModqPrecon, const std::vector<NativeInteger>& qlInvModq,
                    const std::vector<NativeInteger>& qlInvModqPrecon) override {
+        if (ModReduceOnDevice(t, negtInvModq, qlInvModq))
+            return;
         Hm().ModReduce(t, tModqPrecon, negtInvModq, negtInvModqPrecon, qlInvModq, qlInvModqPrecon);
     }
 
@@ -428,7 +430,7 @@ public:
                                const std::vector<NativeInteger>& tInvModpPrecon, const NativeInteger& t,
                                const std::vector<NativeInteger>& tModqPrecon) const override {
         DCRTPolyType out;
-        if (t == NativeInteger(0) && ModDownOnDevice(paramsQ, paramsP, PInvModq, PHatInvModp, PHatModq, &out))
+        if (ModDownOnDevice(paramsQ, paramsP, PInvModq, PHatInvModp, PHatModq, tInvModp, t, &out))
             return out;
         return Wrap(Hc().ApproxModDown(paramsQ, paramsP, PInvModq, PInvModqPrecon, PHatInvModp, PHatInvModpPrecon, PHatModq,
                                        modqBarrettMu, tInvModp, tInvModpPrecon, t, tModqPrecon));
@@ -1261,9 +1263,13 @@ private:
     // ApproxModDown with t = 0 (dcrtpoly-impl.h:966-1005): this over Q_l u P -> *out over Q_l, EVALUATION
     bool ModDownOnDevice(const std::shared_ptr<Params>& paramsQ, const std::shared_ptr<Params>& paramsP,
                          const std::vector<NativeInteger>& PInvModq, const std::vector<NativeInteger>& PHatInvModp,
-                         const std::vector<std::vector<NativeInteger>>& PHatModq, DCRTPolyType* out) const {
+                         const std::vector<std::vector<NativeInteger>>& PHatModq, const std::vector<NativeInteger>& tInvModp,
+                         const NativeInteger& t, DCRTPolyType* out) const {
         const uint32_t sizeP = (uint32_t)paramsP->GetParams().size(), L = NumLimbs();
         if (L <= sizeP || sizeP > 32 || m_h.GetFormat() != Format::EVALUATION)
+            return false;
+        const bool bgv = t > NativeInteger(0);  // BGV: the P part times -t^-1 before, the switched part times t after the conversion
+        if (bgv && tInvModp.size() < sizeP)
             return false;
         const uint32_t sizeQ = L - sizeP;
         if (sizeQ > paramsQ->GetParams().size() || PInvModq.size() < sizeQ || PHatInvModp.size() < sizeP || PHatModq.size() < sizeP)
@@ -1281,6 +1287,12 @@ private:
         // P part to COEFFICIENT (:978-985)
         auto pcoef = hiprt::Alloc((size_t)sizeP * N);
         hiprt::Check(hiprt::api().ntt_inv_oop(r.ctx, m_d->p + (size_t)sizeQ * N, pcoef->p, r.idx[1].data(), sizeP, 1, nullptr), "ApproxModDown");
+        if (bgv) {  // :982-984
+            std::vector<uint64_t> ti(sizeP);
+            for (uint32_t j = 0; j < sizeP; ++j)
+                ti[j] = tInvModp[j].ConvertToInt<uint64_t>();
+            hiprt::Check(hiprt::api().mul_const(r.ctx, pcoef->p, pcoef->p, ti.data(), r.idx[1].data(), sizeP, 1, nullptr), "ApproxModDown");
+        }
         // P -> Q_l (:987-988), with the reference's PHatInvModp / PHatModq tables
         std::vector<uint64_t> hi(sizeP), hm((size_t)sizeP * sizeQ);
         for (uint32_t j = 0; j < sizeP; ++j) {
@@ -1291,6 +1303,10 @@ private:
         fhe_conv* cv = hiprt::ConvPlan(r.ctx, r.idx[1], idxQ, hi.data(), hm.data(), nullptr, nullptr);
         auto sw      = hiprt::Alloc((size_t)sizeQ * N);
         hiprt::Check(hiprt::api().approx_switch_basis(cv, pcoef->p, sizeP, 0, sw->p, sizeQ, 0, 1, nullptr), "ApproxModDown");
+        if (bgv) {  // :998-1000
+            std::vector<uint64_t> tq(sizeQ, t.ConvertToInt<uint64_t>());
+            hiprt::Check(hiprt::api().mul_const(r.ctx, sw->p, sw->p, tq.data(), idxQ.data(), sizeQ, 1, nullptr), "ApproxModDown");
+        }
         hiprt::Check(hiprt::api().ntt_fwd(r.ctx, sw->p, idxQ.data(), sizeQ, 1, nullptr), "ApproxModDown");  // :1001
         // (x_i - switched_i) * [P^-1]_{q_i}   (:1002)
         std::vector<uint64_t> pinv(sizeQ);
@@ -1305,6 +1321,44 @@ private:
         if (diffQ > 0)
             ans.DropLastElements(diffQ);
         *out = std::move(ans);
+        return true;
+    }
+    // ModReduce (dcrtpoly-impl.h:736-755), BGV's modulus switch: delta = INTT(last limb) * (-t^-1 mod q_l); every remaining limb
+    // x_i = (x_i + t * SwitchModulus(delta -> q_i) [to EVALUATION if the tower is]) * q_l^-1
+    bool ModReduceOnDevice(const NativeInteger& t, const NativeInteger& negtInvModq, const std::vector<NativeInteger>& qlInvModq) {
+        const uint32_t L = NumLimbs();
+        if (L < 2 || qlInvModq.size() < L - 1)
+            return false;
+        hiprt::Resolved r;
+        if (!OnDevice(&r))
+            return false;
+        const size_t N          = m_h.GetParams()->GetRingDimension();
+        const uint32_t l        = L - 1;
+        const uint32_t lastLimb = r.idx[0][l];
+        const bool eval         = m_h.GetFormat() == Format::EVALUATION;
+        std::vector<uint32_t> idx(r.idx[0].begin(), r.idx[0].begin() + l);
+        std::vector<uint64_t> tq(l, t.ConvertToInt<uint64_t>()), qi(l);
+        for (uint32_t i = 0; i < l; ++i)
+            qi[i] = qlInvModq[i].ConvertToInt<uint64_t>();
+        const uint64_t nt = negtInvModq.ConvertToInt<uint64_t>();
+        const auto& A     = hiprt::api();
+        auto delta        = hiprt::Alloc(N);
+        auto tmp          = hiprt::Alloc((size_t)l * N);
+        if (eval)
+            hiprt::Check(A.ntt_inv_oop(r.ctx, m_d->p + (size_t)l * N, delta->p, &lastLimb, 1, 1, nullptr), "ModReduce");
+        else
+            hiprt::D2D(r.ctx, delta->p, m_d->p + (size_t)l * N, N * 8, "ModReduce");
+        hiprt::Check(A.mul_const(r.ctx, delta->p, delta->p, &nt, &lastLimb, 1, 1, nullptr), "ModReduce");
+        hiprt::Check(A.switch_modulus(r.ctx, tmp->p, idx.data(), l, delta->p, 1, 0, lastLimb, 1, nullptr), "ModReduce");
+        if (eval)
+            hiprt::Check(A.ntt_fwd(r.ctx, tmp->p, idx.data(), l, 1, nullptr), "ModReduce");
+        hiprt::Check(A.mul_const(r.ctx, tmp->p, tmp->p, tq.data(), idx.data(), l, 1, nullptr), "ModReduce");
+        hiprt::Check(A.add(r.ctx, tmp->p, m_d->p, tmp->p, idx.data(), l, 1, nullptr), "ModReduce");
+        hiprt::Check(A.mul_const(r.ctx, tmp->p, tmp->p, qi.data(), idx.data(), l, 1, nullptr), "ModReduce");
+        m_d = std::move(tmp);
+        hiprt::CountDevice();
+        DeviceIsNewer(m_h.GetFormat());
+        DropLastElement();
         return true;
     }
     // DropLastElementAndScale, EVALUATION format (dcrtpoly-impl.h:693-712)

@@ -209,6 +209,42 @@ int main(int argc, char** argv) {
         dump("product last", c[B - 1]);
         show("product 0", cc, kp.secretKey, c[0], 3);
     }
+    else if (mode == "bgv") {
+        // BGV: EvalMult + HYBRID key switch (ApproxModDown with t > 0), ModReduce, a rotation, a second level
+        CCParams<CryptoContextBGVRNS> p;
+        p.SetSecurityLevel(HEStd_NotSet);
+        p.SetRingDim(1u << logN);
+        p.SetPlaintextModulus(65537);
+        p.SetMultiplicativeDepth(3);
+        p.SetKeySwitchTechnique(HYBRID);
+        const std::string st = argc > 5 ? argv[5] : "FIXEDMANUAL";
+        p.SetScalingTechnique(st == "FIXEDAUTO" ? FIXEDAUTO : st == "FLEXIBLEAUTO" ? FLEXIBLEAUTO : st == "FLEXIBLEAUTOEXT" ? FLEXIBLEAUTOEXT : FIXEDMANUAL);
+        auto cc = GenCryptoContext(p);
+        cc->Enable(PKE);
+        cc->Enable(KEYSWITCH);
+        cc->Enable(LEVELEDSHE);
+        auto kp = cc->KeyGen();
+        cc->EvalMultKeyGen(kp.secretKey);
+        cc->EvalRotateKeyGen(kp.secretKey, {1});
+        std::vector<int64_t> x = {1, 2, 3, 4, 5, 6, 7, 8}, y = {3, -2, 5, 1, -4, 2, 9, -7};
+        auto cx = cc->Encrypt(kp.publicKey, cc->MakePackedPlaintext(x));
+        auto cy = cc->Encrypt(kp.publicKey, cc->MakePackedPlaintext(y));
+        dump("x", cx);
+        auto m = cc->EvalMult(cx, cy);
+        dump("x*y", m);
+        auto r = cc->ModReduce(m);
+        dump("modreduce", r);
+        auto rot = cc->EvalRotate(r, 1);
+        dump("rotate1", rot);
+        auto m2 = cc->ModReduce(cc->EvalMult(cc->EvalAdd(rot, r), r));
+        dump("second", m2);
+        for (auto& pr : std::vector<std::pair<const char*, Ciphertext<DCRTPoly>>>{{"x*y", r}, {"second", m2}}) {
+            Plaintext pt;
+            cc->Decrypt(kp.secretKey, pr.second, &pt);
+            pt->SetLength(8);
+            std::cout << "value " << pr.first << ": " << pt->GetPackedValue() << std::endl;
+        }
+    }
     else if (mode == "opbench") {
         // host cost per DCRTPoly operation: small towers (the kernels take a few microseconds), many repetitions, one thread
         const uint32_t L = argc > 5 ? std::atoi(argv[5]) : 8;
