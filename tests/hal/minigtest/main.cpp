@@ -1,0 +1,22 @@
+// TEST INFRASTRUCTURE — main() of the reference's pke unit tests built on tests/hal/minigtest/gtest/gtest.h
+#include "gtest/gtest.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+extern "C" void fhe_hal_stats(uint64_t out[4]) __attribute__((weak));
+extern "C" int fhe_hal_available(void) __attribute__((weak));
+
+int main(int argc, char** argv) {
+    ::testing::InitGoogleTest(&argc, argv);
+    const int rc = RUN_ALL_TESTS();
+    if (fhe_hal_stats) {
+        uint64_t st[4];
+        fhe_hal_stats(st);
+        std::printf("hal: available %d deviceOps %llu hostOps %llu h2dBytes %llu d2hBytes %llu\n", fhe_hal_available ? fhe_hal_available() : -1,
+                    (unsigned long long)st[0], (unsigned long long)st[1], (unsigned long long)st[2], (unsigned long long)st[3]);
+    }
+    else
+        std::printf("hal: stock backend\n");
+    return rc;
+}

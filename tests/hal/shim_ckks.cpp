@@ -334,7 +334,9 @@ int main(int argc, char** argv) {
             std::vector<double> x = {0.25, 0.5, 0.75, 1.0, 2.0, 3.0, 4.0, 5.0};
             auto pt = cc->MakeCKKSPackedPlaintext(x, 1, depth - 1, nullptr, slots);
             auto c  = cc->Encrypt(kp.publicKey, pt);
-            auto b  = cc->EvalBootstrap(c);  // warm-up (tables, plans)
+            // argv[7]: iterations of EvalBootstrap (2 = the two-iteration "Meta-BTS" variant, ckksrns-fhe.cpp:464-519), argv[8]: its precision
+            const uint32_t iters = argc > 7 ? std::atoi(argv[7]) : 1, prec = argc > 8 ? std::atoi(argv[8]) : 0;
+            auto b  = cc->EvalBootstrap(c, iters, prec);  // warm-up (tables, plans)
             const int reps = argc > 6 ? std::atoi(argv[6]) : 1;
             if (fhe_hal_trace_reset)
                 fhe_hal_trace_reset();
@@ -344,7 +346,7 @@ int main(int argc, char** argv) {
             t0 = now();
             for (int i = 0; i < reps; ++i) {
                 auto t1 = now();
-                b       = cc->EvalBootstrap(c);
+                b       = cc->EvalBootstrap(c, iters, prec);
                 std::cout << "  rep " << i << " seconds " << secs(t1, now()) << std::endl;
             }
             std::cout << "bootstrap seconds " << secs(t0, now()) / reps << " (" << reps << " reps)" << std::endl;
