@@ -5,7 +5,8 @@
 #   ./build.sh oracle  -> oracle/libfhe_oracle.so   (TEST ONLY: C restatement of the reference)
 #   ./build.sh ref     -> oracle/_ref/*.so          (TEST ONLY: the reference itself, needs /root/reference)
 #   ./build.sh hal     -> openfhe-development_amd/hal/_build/*.so: the reference's sources compiled against the HIP backend
-#                         of lbcrypto::DCRTPoly (lattice/hal/hip/), + the test programs of tests/hal (needs /root/reference)
+#                         of lbcrypto::DCRTPoly (lattice/hal/hip/), + the test programs of tests/hal incl. the reference's own pke unit
+#                         tests on both backends (needs /root/reference)
 #   ./build.sh all     -> hip + emu + oracle (+ ref + hal when /root/reference exists)
 set -e
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
@@ -22,7 +23,10 @@ build_emu() {
 }
 build_oracle() { make -s -C "$ROOT/oracle" oracle; }
 build_ref() { make -s -j"$(nproc)" -C "$ROOT/oracle" ref; }
-build_hal() { make -s -j"$(nproc)" -C "$ROOT/openfhe-development_amd/hal" && make -s -j3 -C "$ROOT/tests/hal"; }
+build_hal() {
+  make -s -j"$(nproc)" -C "$ROOT/openfhe-development_amd/hal" && make -s -j3 -C "$ROOT/tests/hal" &&
+    make -s -j"$(nproc)" -C "$ROOT/tests/hal" -f Makefile.ut  # the reference's own pke unit tests on both backends
+}
 case "$what" in
   hip) build_hip ;;
   emu) build_emu ;;
