@@ -32,6 +32,28 @@ public:
     virtual void TestBody() = 0;
 };
 
+// the result type helper functions of tests return (usable where a bool is expected, message ignored)
+class AssertionResult {
+public:
+    explicit AssertionResult(bool ok) : ok_(ok) {}
+    explicit operator bool() const {
+        return ok_;
+    }
+    template <typename T>
+    AssertionResult& operator<<(const T&) {
+        return *this;
+    }
+
+private:
+    bool ok_;
+};
+inline AssertionResult AssertionSuccess() {
+    return AssertionResult(true);
+}
+inline AssertionResult AssertionFailure() {
+    return AssertionResult(false);
+}
+
 template <typename T>
 struct TestParamInfo {
     T param;

@@ -4,6 +4,9 @@
 #include <cstdio>
 #include <cstdlib>
 
+// switches of the reference's test driver (test/Main_TestAll.cpp: which math backends the templated core tests cover); all on
+bool TestB2 = true, TestB4 = true, TestB6 = true, TestNative = true;
+
 extern "C" void fhe_hal_stats(uint64_t out[4]) __attribute__((weak));
 extern "C" int fhe_hal_available(void) __attribute__((weak));
 

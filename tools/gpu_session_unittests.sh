@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU session: the reference's own pke unit tests (1589 that need neither a serialisation library nor the reference tree at run
 # time) on the HIP backend of DCRTPoly.   usage: tools/gpu_session_unittests.sh [gtest filter] [threads]
-FILTER=${1:--*SERIALIZE*}
+FILTER=${1:--*SERIALIZE*:UTBinInt.GetInternalRepresentation}
 T=${2:-8}
 mkdir -p gpurun_out
 export FHE_HIP_LIB=$PWD/openfhe-development_amd/csrc/libfhe_hip.so
