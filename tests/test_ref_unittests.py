@@ -61,6 +61,17 @@ def test_reference_unit_tests_slice_on_emulator():
     assert dev_ops > 500, "the HIP backend's device path did not run"
 
 
+BINFHE = "UnitTestFHEW*:UnitTestFunc*:*FHEW*"  # src/binfhe/unittest: NativePoly callers, must not notice the DCRTPoly backend
+
+
+def test_reference_binfhe_unit_tests_on_backend_libraries():
+    ensure_built()
+    ran_s, passed_s, failed_s, _, out_s = run(UT_STOCK, BINFHE, threads=8)
+    assert ran_s >= 70 and failed_s == 0, out_s[-1500:]
+    ran, passed, failed, _, out = run(UT_HIP, BINFHE, EMU, threads=8)
+    assert (ran, passed, failed) == (ran_s, passed_s, 0), [l for l in out.split("\n") if "FAILED" in l][:10]
+
+
 def test_reference_core_lattice_unit_tests_on_emulator():
     ensure_built()
     ran_s, passed_s, failed_s, _, out_s = run(UT_STOCK, CORE)
@@ -76,5 +87,5 @@ def test_reference_unit_tests_on_gpu():
     ran, passed, failed, dev_ops, out = run(UT_HIP, "-*SERIALIZE*:UTBinInt.GetInternalRepresentation", HIP, threads=8)
     failures = [l for l in out.split("\n") if "FAILED" in l][:20]
     assert failed == 0 and passed == ran, failures
-    assert ran >= 1700, f"only {ran} tests ran"
+    assert ran >= 1780, f"only {ran} tests ran"
     assert dev_ops > 1_000_000
