@@ -17,12 +17,13 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 B = os.path.join(ROOT, "tests", "hal", "_build")
 UT_HIP, UT_STOCK = os.path.join(B, "ut_hip"), os.path.join(B, "ut_stock")
+UT_HIP_BIN, UT_STOCK_BIN = os.path.join(B, "ut_hip_binfhe"), os.path.join(B, "ut_stock_binfhe")
 EMU = os.path.join(ROOT, "tests", "emu", "libfhe_emu.so")
 HIP = os.path.join(ROOT, "openfhe-development_amd", "csrc", "libfhe_hip.so")
 
 
 def ensure_built():
-    if os.path.exists(UT_HIP) and os.path.exists(UT_STOCK):
+    if all(os.path.exists(p) for p in (UT_HIP, UT_STOCK, UT_HIP_BIN, UT_STOCK_BIN)):
         return
     if os.path.isdir("/root/reference/src"):
         subprocess.check_call([os.path.join(ROOT, "build.sh"), "hal"])
@@ -30,7 +31,7 @@ def ensure_built():
         pytest.skip("tests/hal/_build/ut_* not present and /root/reference not mounted")
 
 
-def run(exe, flt, lib=None, threads=4, timeout=3000):
+def run(exe, flt, lib=None, threads=4, timeout=900):
     env = dict(os.environ, OMP_NUM_THREADS=str(threads))
     env.pop("FHE_HAL_ALLOW_HOST", None)
     if lib:
@@ -61,14 +62,13 @@ def test_reference_unit_tests_slice_on_emulator():
     assert dev_ops > 500, "the HIP backend's device path did not run"
 
 
-BINFHE = "UnitTestFHEW*:UnitTestFunc*:*FHEW*"  # src/binfhe/unittest: NativePoly callers, must not notice the DCRTPoly backend
-
-
+# src/binfhe/unittest (binaries of their own): NativePoly callers, must not notice the DCRTPoly backend the libraries were built with
 def test_reference_binfhe_unit_tests_on_backend_libraries():
     ensure_built()
-    ran_s, passed_s, failed_s, _, out_s = run(UT_STOCK, BINFHE, threads=8)
+    flt = "-UnitTestFHEDeep*"  # (the *_VERY_LONG chains of gates: many minutes of CPU time on any backend)
+    ran_s, passed_s, failed_s, _, out_s = run(UT_STOCK_BIN, flt, threads=8)
     assert ran_s >= 70 and failed_s == 0, out_s[-1500:]
-    ran, passed, failed, _, out = run(UT_HIP, BINFHE, EMU, threads=8)
+    ran, passed, failed, _, out = run(UT_HIP_BIN, flt, EMU, threads=8)
     assert (ran, passed, failed) == (ran_s, passed_s, 0), [l for l in out.split("\n") if "FAILED" in l][:10]
 
 
@@ -84,8 +84,8 @@ def test_reference_core_lattice_unit_tests_on_emulator():
 @pytest.mark.gpu
 def test_reference_unit_tests_on_gpu():
     ensure_built()
-    ran, passed, failed, dev_ops, out = run(UT_HIP, "-*SERIALIZE*:UTBinInt.GetInternalRepresentation", HIP, threads=8)
+    ran, passed, failed, dev_ops, out = run(UT_HIP, "-*SERIALIZE*:UTBinInt.GetInternalRepresentation", HIP, threads=8, timeout=600)
     failures = [l for l in out.split("\n") if "FAILED" in l][:20]
     assert failed == 0 and passed == ran, failures
-    assert ran >= 1780, f"only {ran} tests ran"
+    assert ran >= 1700, f"only {ran} tests ran"
     assert dev_ops > 1_000_000

@@ -5,7 +5,7 @@
 R=${1:-r02}
 mkdir -p gpurun_out
 if [ "$2" != "notests" ]; then
-  echo "== gpu tests"; timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
+  echo "== gpu tests"; timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
 fi
 echo "== bench (default flags, as the driver runs it)"; timeout 1200 python bench.py 2>gpurun_out/bench_$R.err | tail -1 | tee gpurun_out/bench_$R.json | cut -c1-600
 export FHE_BENCH_NO_TORCH=1
