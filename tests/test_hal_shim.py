@@ -27,8 +27,8 @@ def ensure_built():
         pytest.skip("tests/hal/_build not present and /root/reference not mounted")
 
 
-def run(prog, out, mode, logN, device_lib=None, extra=()):
-    env = dict(os.environ, OMP_NUM_THREADS="1")
+def run(prog, out, mode, logN, device_lib=None, extra=(), threads=1):
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads))
     if device_lib:
         env["FHE_HIP_LIB"] = device_lib
         env["FHE_HAL_REQUIRE_DEVICE"] = "1"  # the shim must not silently degrade to its host mirror
@@ -43,11 +43,11 @@ def values(stdout, name):
     return [float(v) for v in m.group(1).replace("[", " ").replace("]", " ").split()]
 
 
-def check(tmp_path, mode, logN, device_lib, expect, extra=()):
+def check(tmp_path, mode, logN, device_lib, expect, extra=(), threads=1):
     ensure_built()
     so, sh = str(tmp_path / "stock.bin"), str(tmp_path / "hip.bin")
-    out_stock = run(PROGS[0], so, mode, logN, extra=extra)
-    out_hip = run(PROGS[1], sh, mode, logN, device_lib, extra=extra)
+    out_stock = run(PROGS[0], so, mode, logN, extra=extra, threads=threads)
+    out_hip = run(PROGS[1], sh, mode, logN, device_lib, extra=extra, threads=threads)
     assert "hal: stock backend" in out_stock
     m = re.search(r"hal: available (\d+) deviceOps (\d+) hostOps (\d+)", out_hip)
     assert m and int(m.group(1)) == 1 and int(m.group(2)) > 0, out_hip[-500:]
@@ -144,3 +144,16 @@ def test_shim_bgv_matches_default_backend_on_emulator(tmp_path, technique):
 def test_shim_bgv_matches_default_backend_on_gpu(tmp_path, technique, logN):
     ops = check(tmp_path, "bgv", logN, HIP, BGV, extra=(technique,))
     assert ops > 50
+
+
+def test_shim_batch_of_ciphertexts_over_host_threads_on_emulator(tmp_path):
+    """cc->EvalMult on 8 ciphertexts spread over 4 OpenMP threads (one device, shared pool / plan caches / copy-on-write words): the
+    first and the last product are the stock backend's, byte for byte (pke's own inner parallel loops run inside each thread)"""
+    ops = check(tmp_path, "multbatch", 11, EMU, {"product 0": [0.5, 0.0, -3.0]}, extra=(4, 8, 1), threads=4)
+    assert ops > 200
+
+
+@pytest.mark.gpu
+def test_shim_batch_of_ciphertexts_over_host_threads_on_gpu(tmp_path):
+    ops = check(tmp_path, "multbatch", 14, HIP, {"product 0": [0.5, 0.0, -3.0]}, extra=(8, 32, 1), threads=8)
+    assert ops > 1000
