@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstdio>
 #include <vector>
 #include <cstdlib>
@@ -364,6 +365,43 @@ fhe_behz* BehzPlan(fhe_ctx* ctx, const std::vector<uint32_t>& qIdx, const std::v
 }
 
 }  // namespace hiprt
+}  // namespace lbcrypto
+
+// ---- PrecomputeAutoMap (nbtheory2.cpp:264-275), memoised: precomp[bitrev(j)] = bitrev(((2j+1)k mod 2n) >> 1).  pke calls it for
+// every rotation and EvalFastRotation (ckksrns-leveledshe.cpp, ckksrns-fhe.cpp, base-leveledshe.cpp); at N = 2^17 that is 0.4 ms of
+// host time 260 times per bootstrap.  The HIP build weakens the reference's definition (hal/Makefile) and links this one. ----
+namespace lbcrypto {
+void PrecomputeAutoMap(uint32_t n, uint32_t k, std::vector<uint32_t>* precomp) {
+    static std::mutex mu;
+    static std::map<std::pair<uint32_t, uint32_t>, std::shared_ptr<const std::vector<uint32_t>>> cache;
+    std::shared_ptr<const std::vector<uint32_t>> tab;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = cache.find({n, k});
+        if (it != cache.end())
+            tab = it->second;
+    }
+    if (!tab) {
+        const uint32_t logn = (uint32_t)std::round(std::log2(n)), logm = (uint32_t)std::round(std::log2(2.0 * n));  // (:266-267)
+        const uint64_t m    = 1ull << logm;
+        auto rev = [logn](uint32_t x) {
+            uint32_t y = 0;
+            for (uint32_t b = 0; b < logn; ++b)
+                y |= ((x >> b) & 1u) << (logn - 1u - b);
+            return y;
+        };
+        auto t = std::make_shared<std::vector<uint32_t>>(n);
+        for (uint32_t j = 0; j < n; ++j) {
+            const uint32_t idx = (uint32_t)(((2ull * j + 1ull) * k) & (m - 1ull)) >> 1;
+            (*t)[rev(j)]       = rev(idx);
+        }
+        tab = t;
+        std::lock_guard<std::mutex> lk(mu);
+        if (cache.size() < 1024)  // (a few hundred rotation indices per context at most; 4n bytes each)
+            cache.emplace(std::make_pair(n, k), tab);
+    }
+    std::copy(tab->begin(), tab->end(), precomp->begin());
+}
 }  // namespace lbcrypto
 
 extern "C" void fhe_hal_stats(uint64_t out[4]) {
