@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-bootstrap", action="store_true",
                     help="skip the EvalBootstrap leg (BASELINE configs[3] shape through the reference's CryptoContext on the HIP backend of DCRTPoly)")
     ap.add_argument("--bootstrap-logn", type=int, default=17)
+    ap.add_argument("--no-cc-evalmult", action="store_true",
+                    help="skip the leg that runs BASELINE configs[2]'s EvalMult through the reference's CryptoContext on the HIP backend")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparisons of the legs' results")
     ap.add_argument("--evalmult-logn", type=int, default=16, help="ring of the EvalMult leg (config 3: 16)")
     ap.add_argument("--evalmult-limbs", type=int, default=21, help="Q limbs of the EvalMult leg (config 3: 21)")
@@ -697,6 +699,55 @@ def bootstrap_leg(logN, with_cpu, libpath):
     return res
 
 
+def cc_evalmult_leg(with_cpu, libpath):
+    """BASELINE configs[2]'s operation through the reference's own API: cc->EvalMult (tensor + HYBRID key switch) on a batch of
+    ciphertexts at N = 2^16, depth 20 (21 Q limbs, dnum 3), spread over host threads — the reference's pke sources on the HIP backend
+    of DCRTPoly against the same program on the stock backend (tests/hal/shim_ckks.cpp multbatch); first and last product compared
+    byte for byte (64 ciphertexts, same PRNG, same thread count)."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    bdir = os.path.join(ROOT, "tests", "hal", "_build")
+    hip, stock, prng = (os.path.join(bdir, n) for n in ("shim_ckks_hip", "shim_ckks_stock", "libdetprng.so"))
+    if not (os.path.exists(hip) and os.path.exists(prng)):
+        return {"skipped": "tests/hal/_build/shim_ckks_hip not built (./build.sh hal needs the reference sources)"}
+    tmp = tempfile.mkdtemp(prefix="fhe_ccmult_")
+
+    def run(exe, out, batch, reps, threads, extra_env):
+        env = dict(os.environ)
+        env.update(extra_env)
+        env["OMP_NUM_THREADS"] = str(threads)
+        p = subprocess.run([exe, out, prng, "multbatch", "16", "20", str(batch), str(reps)], env=env, capture_output=True, text=True, timeout=900)
+        m = re.search(r"EvalMult per second ([0-9.eE+-]+)", p.stdout)
+        return (float(m.group(1)) if p.returncode == 0 and m else None), (p.stdout + p.stderr)[-400:]
+
+    hipenv = {"FHE_HIP_LIB": libpath}
+    rate, txt = run(hip, os.path.join(tmp, "h256.bin"), 256, 3, 8, hipenv)
+    if rate is None:
+        shutil.rmtree(tmp, ignore_errors=True)
+        return {"error": txt}
+    res = {"workload": "cc->EvalMult(ct, ct) with HYBRID relinearisation, N=2^16, 21 Q + 7 P limbs, dnum 3, 256 ciphertexts over 8 host threads",
+           "ops_per_s": round(rate, 1), "how": "reference pke (unmodified sources) on the HIP backend of DCRTPoly, one tower per operation",
+           "parity": "not checked", "cpu_baseline": None}
+    if with_cpu and os.path.exists(stock):
+        threads = min(32, os.cpu_count() or 1)
+        crate, ctxt = run(stock, os.path.join(tmp, "s64.bin"), 64, 1, threads, {})
+        hrate, _ = run(hip, os.path.join(tmp, "h64.bin"), 64, 1, threads, hipenv)
+        if crate is not None:
+            res["cpu_baseline"] = {"value": round(crate, 2), "unit": "EvalMult/s", "cores": threads, "kind": "reference",
+                                   "sample": "the same program on the stock backend, 64 ciphertexts over the same threads, 1 timed pass"}
+            res["speedup_vs_cpu"] = round(rate / crate, 1)
+            try:
+                same = hrate is not None and open(os.path.join(tmp, "h64.bin"), "rb").read() == open(os.path.join(tmp, "s64.bin"), "rb").read()
+                res["parity"] = ("first and last product of the 64-ciphertext batch identical byte for byte to the stock backend's" if same
+                                 else "MISMATCH vs the stock backend")
+            except OSError as e:
+                res["parity"] = f"dumps unreadable: {e}"
+    shutil.rmtree(tmp, ignore_errors=True)
+    return res
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -987,6 +1038,13 @@ def main():
         except Exception as e:  # the leg is an extra: never takes the headline line down
             boot = {"error": f"{type(e).__name__}: {e}"}
 
+    ccm = None
+    if rank == 0 and world == 1 and not a.no_cc_evalmult and logN == 16 and not os.environ.get("FHE_HIP_LIB", "").endswith("libfhe_emu.so"):
+        try:
+            ccm = cc_evalmult_leg(not a.no_cpu_baseline, lib.path)
+        except Exception as e:
+            ccm = {"error": f"{type(e).__name__}: {e}"}
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(q, psi, logN, L, a.cpu_seconds)
@@ -1013,6 +1071,8 @@ def main():
             out["linear_transform"] = ltr
         if boot is not None:
             out["evalbootstrap"] = boot
+        if ccm is not None:
+            out["cryptocontext_evalmult"] = ccm
         print(json.dumps(out))
     ctx.close()
     if dist is not None:

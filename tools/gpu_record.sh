@@ -12,13 +12,13 @@ export FHE_BENCH_NO_TORCH=1
 cd /tmp && export TMPDIR=/tmp
 G=$GRAFT_REPO_ROOT
 echo "== rocprof kernel stats (same command as the bench line)"
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $G/gpurun_out/prof_$R -- python $G/bench.py --no-bootstrap --no-cpu-baseline --no-parity > $G/gpurun_out/prof_$R.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $G/gpurun_out/prof_$R -- python $G/bench.py --no-bootstrap --no-cc-evalmult --no-cpu-baseline --no-parity > $G/gpurun_out/prof_$R.log 2>&1
 echo "== rocprof kernel stats, headline leg only (per-kernel averages = the B=1024 launches alone)"
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $G/gpurun_out/prof_${R}_ntt -- python $G/bench.py --no-bootstrap --no-cpu-baseline --no-parity --no-evalmult --no-bfv --no-hadamard --no-lt > $G/gpurun_out/prof_${R}_ntt.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $G/gpurun_out/prof_${R}_ntt -- python $G/bench.py --no-bootstrap --no-cc-evalmult --no-cpu-baseline --no-parity --no-evalmult --no-bfv --no-hadamard --no-lt > $G/gpurun_out/prof_${R}_ntt.log 2>&1
 echo "== rocprof kernel stats, EvalMult leg at batch 256 (the NTT leg shrunk to 8 towers)"
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $G/gpurun_out/prof_${R}_evalmult -- python $G/bench.py --no-bootstrap --batch 8 --steps 1 --warmup 0 --no-cpu-baseline --no-parity --no-bfv --no-hadamard --no-lt > $G/gpurun_out/prof_${R}_evalmult.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $G/gpurun_out/prof_${R}_evalmult -- python $G/bench.py --no-bootstrap --no-cc-evalmult --batch 8 --steps 1 --warmup 0 --no-cpu-baseline --no-parity --no-bfv --no-hadamard --no-lt > $G/gpurun_out/prof_${R}_evalmult.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $G/gpurun_out/pmc_${R}_$c -- python $G/bench.py --no-bootstrap --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-evalmult --no-bfv --no-hadamard --no-lt > $G/gpurun_out/pmc_${R}_$c.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $G/gpurun_out/pmc_${R}_$c -- python $G/bench.py --no-bootstrap --no-cc-evalmult --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-evalmult --no-bfv --no-hadamard --no-lt > $G/gpurun_out/pmc_${R}_$c.log 2>&1
 done
 cd $G
 f=$(ls -t gpurun_out/prof_${R}_ntt/*/*kernel_stats.csv | head -1); head -8 $f | cut -c1-170
