@@ -78,6 +78,10 @@ fhe_status fhe_stream_sync(fhe_ctx* ctx, void* stream);
  * stream).  Run the sequence once before capturing (tables are built on first use; building is not capturable). */
 fhe_status fhe_stream_create(fhe_ctx* ctx, void** stream);
 fhe_status fhe_stream_destroy(fhe_ctx* ctx, void* stream);
+/* `stream` waits ON THE DEVICE (the host is not blocked) for everything enqueued so far on `other`: the hand-over of a tower
+ * from one host thread's stream to another's (the HAL backend gives every host thread a stream of its own). */
+fhe_status fhe_stream_wait(fhe_ctx* ctx, void* stream, void* other);
+fhe_status fhe_memset_zero(fhe_ctx* ctx, void* dst, size_t bytes, void* stream);
 fhe_status fhe_graph_begin(fhe_ctx* ctx, void* stream);
 fhe_status fhe_graph_end(fhe_ctx* ctx, void* stream, void** graph);
 fhe_status fhe_graph_launch(fhe_ctx* ctx, void* graph, void* stream);
@@ -388,6 +392,19 @@ uint32_t   fhe_param_behz_bsk(uint32_t logN, uint32_t numQ, const uint64_t* q, u
 fhe_status fhe_behz_create(fhe_ctx* ctx, const uint32_t* qLimbIdx, uint32_t numQ, const uint32_t* bskLimbIdx, uint64_t t,
                            fhe_behz** out);
 void       fhe_behz_destroy(fhe_behz* plan);
+/* The CALLER's tables in place of the derived ones, one member at a time — the vectors the reference passes to that member
+ * (dcrtpoly-interface.h: FastBaseConvqToBskMontgomery, FastRNSFloorq, FastBaseConvSK), flattened row-major in the reference's index
+ * order: QHatModbsk / qInvModbsk [numQ][numBsk], BHatModq [numB][numQ], vectors over Q, Bsk or B.  With an override the member
+ * computes with the caller's VALUES (whatever they are), as DCRTPolyImpl does; a DCRTPoly backend keeps one plan per member and
+ * table content.  The Barrett constants are functions of the moduli and stay derived. */
+fhe_status fhe_behz_override_q_to_bsk(fhe_behz* plan, const uint64_t* mtildeQHatInvModq, const uint64_t* QHatModbsk,
+                                      const uint64_t* QHatModmtilde, const uint64_t* QModbsk, uint64_t negQInvModmtilde,
+                                      const uint64_t* mtildeInvModbsk);
+fhe_status fhe_behz_override_floorq(fhe_behz* plan, const uint64_t* tQHatInvModq, const uint64_t* QHatModbsk,
+                                    const uint64_t* qInvModbsk, const uint64_t* tQInvModbsk);
+fhe_status fhe_behz_override_conv_sk(fhe_behz* plan, const uint64_t* BHatInvModb, const uint64_t* BHatModmsk, uint64_t BInvModmsk,
+                                     const uint64_t* BHatModq, const uint64_t* BModq);
+
 size_t     fhe_behz_workspace_bytes(const fhe_behz* plan, uint32_t batch);
 fhe_status fhe_behz_q_to_bsk(fhe_behz* plan, uint64_t* x, int evalFormat, uint32_t batch, void* ws, size_t wsBytes,
                              void* stream);
@@ -408,6 +425,12 @@ size_t     fhe_bfv_eval_mult_relin_workspace_bytes(const fhe_behz* plan, const f
 fhe_status fhe_bfv_eval_mult_relin_behz(fhe_behz* plan, fhe_ks_plan* ks, const fhe_ks_key* key, const uint64_t* a0,
                                         const uint64_t* a1, const uint64_t* b0, const uint64_t* b1, uint64_t* c0, uint64_t* c1,
                                         uint32_t batch, void* ws, size_t wsBytes, void* stream);
+
+/* ---- parity helper: whole-tower checksums ----------------------------------------------------------------
+ * out[row] = { sum of the row's N words mod 2^64, xor of the row's N words } for every limb-row of x[rows][N] (rows = batch *
+ * nLimbs); out is DEVICE memory, uint64_t[rows][2].  One read of the batch: bench.py and the full-shape tests compare EVERY
+ * tower of a resident batch with the oracle's words summed on the host, instead of sampling a few towers. */
+fhe_status fhe_checksum(fhe_ctx* ctx, const uint64_t* x, uint32_t rows, uint64_t* out, void* stream);
 
 /* ---- host-side parameter helpers (no device work) -------------------------------------------------
  * Number theory the reference uses to pick moduli and roots, restated with 64-bit arithmetic so that a

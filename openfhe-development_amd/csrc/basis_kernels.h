@@ -43,6 +43,14 @@ struct ConvArgs {
     uint32_t logN, batch;
     uint32_t nSrc, nDst;
     uint32_t inStride, inFirst, outStride, outFirst;
+    // chunked plans (more than 32 source limbs: one launch per chunk of <= 32, CHUNK instantiation only)
+    uint32_t acc;              // this chunk's sums are added to what the previous chunks left in `out`
+    uint32_t last;             // exact variant: the last chunk subtracts [alpha*Q]_{p_j}, alpha counted over ALL source limbs
+    uint32_t nSrcAll;          // source limbs of the whole plan
+    const uint64_t* inAll;     // source limb 0 of the whole plan (same layout as `in`)
+    const TwPair* allHatInv;   // [nSrcAll]
+    const uint64_t* allSrcQ;   // [nSrcAll]
+    const double* allQInv;     // [nSrcAll]
 };
 
 // NSRC = compile-time upper bound of the number of source limbs (8, 16 or 32): y_i live in registers, the output limbs
@@ -51,7 +59,10 @@ struct ConvArgs {
 // SUM8 = 2 (default since round 2: EvalMult +2.8 %, BFV +1 % on MI355X, profiles/r02_sweeps.md): both factors split at 30
 // bits, no carry bookkeeping at all (sum8s, modarith.h); SUM8 = 1 (FHE_CONV_SUM8=1): plain 64-bit columns whose low one
 // counts its carries (sum8).  Both are exact; any exact reduction equals BarrettUint128ModUint64 (utilities-int.h:60-99).
-template <int NSRC, bool EXACT, int SUM8 = 2>
+// CHUNK: one chunk of a plan with more than 32 source limbs (the reference's loop dcrtpoly-impl.h:895-915 has no bound): the chunk's
+// sums are exact residues, so out_j = sum over chunks mod p_j; the overflow count of the exact variant is accumulated over all
+// source limbs in the reference's order (i ascending) by the last chunk, which recomputes every y_i for it.
+template <int NSRC, bool EXACT, int SUM8 = 2, bool CHUNK = false>
 FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) switch_basis_kernel(const ConvArgs g) {
     const uint32_t N     = 1u << g.logN;
     const uint64_t gid   = (uint64_t)FHE_BID * kThreads + FHE_TID;  // over batch*N coefficients
@@ -87,7 +98,16 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) switch_basis_kernel(const ConvArgs g
                 nu += (double)y[i] * qinv;
         }
     }
-    const uint32_t alpha = EXACT ? (uint32_t)nu : 0u;
+    if (CHUNK && EXACT && g.last) {
+        nu = 0.5;
+        const uint64_t* hpa = reinterpret_cast<const uint64_t*>(g.allHatInv);
+        const uint64_t* ina = g.inAll + (((uint64_t)b * g.inStride) << g.logN) + ri;
+        for (uint32_t i = 0; i < g.nSrcAll; ++i) {
+            const uint64_t yi = mul_shoup(ina[(uint64_t)i << g.logN], hpa[2 * i], hpa[2 * i + 1], g.allSrcQ[i]);
+            nu += (double)yi * g.allQInv[i];
+        }
+    }
+    const uint32_t alpha = EXACT && (!CHUNK || g.last) ? (uint32_t)nu : 0u;
 
     for (uint32_t j = 0; j < g.nDst; ++j) {
         uint64_t h[NSRC];
@@ -115,7 +135,9 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) switch_basis_kernel(const ConvArgs g
                 const uint64_t rj = sum8s_reduce(s8, p, k, mulo, muhi);
                 v                 = c0 ? add_mod(v, rj, p) : rj;
             }
-            if (EXACT)
+            if (CHUNK && g.acc)
+                v = add_mod(v, out[(uint64_t)j << g.logN], p);
+            if (EXACT && (!CHUNK || g.last))
                 v = sub_mod(v, g.tb.alphaMod[(uint64_t)alpha * g.nDst + j], p);
             out[(uint64_t)j << g.logN] = v;
             continue;
@@ -136,7 +158,9 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) switch_basis_kernel(const ConvArgs g
                 const uint64_t rj = sum8_reduce(s8, p, k, mulo, muhi);
                 v                 = c0 ? add_mod(v, rj, p) : rj;
             }
-            if (EXACT)
+            if (CHUNK && g.acc)
+                v = add_mod(v, out[(uint64_t)j << g.logN], p);
+            if (EXACT && (!CHUNK || g.last))
                 v = sub_mod(v, g.tb.alphaMod[(uint64_t)alpha * g.nDst + j], p);
             out[(uint64_t)j << g.logN] = v;
         }
@@ -161,6 +185,8 @@ struct KsInnerArgs {
     const uint64_t* mu128;             // [ctxLimbs][2]
     uint32_t logN, batch, sizeQl, sizeQ, sizeP, numDigits, alpha;
     uint32_t nc[kMaxDigits];           // complement size of digit j = sizeQl - size_j + sizeP
+    uint32_t j0, acc;                  // more than kMaxDigits digits: this launch covers digits j0 .. j0+numDigits-1 and, for j0 > 0,
+                                       // adds its (exact) sums to what the previous launches left in out0 / out1
 };
 FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ks_inner_product_kernel(const KsInnerArgs g) {
     // one workgroup = 4096 consecutive coefficients of one (b, i) output row.  The key rows of a (limb, tile) group are
@@ -192,7 +218,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ks_inner_product_kernel(const KsInne
         sum8_clear(s0);
         sum8_clear(s1);
         for (uint32_t j = 0; j < g.numDigits; ++j) {
-            const uint32_t start = j * g.alpha;
+            const uint32_t start = (g.j0 + j) * g.alpha;
             const uint32_t sz    = sizeQlP - g.nc[j];
             uint64_t d;
             if (i >= start && i < start + sz)
@@ -205,13 +231,18 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ks_inner_product_kernel(const KsInne
             d = csub(d, q << 2);
             d = csub(d, q << 1);
             d = csub(d, q);
-            const uint64_t koff = (((uint64_t)j * (g.sizeQ + g.sizeP) + idx) << g.logN) + r;
+            const uint64_t koff = (((uint64_t)(g.j0 + j) * (g.sizeQ + g.sizeP) + idx) << g.logN) + r;
             sum8_add(s0, d, g.keyB[koff]);
             sum8_add(s1, d, g.keyA[koff]);
         }
         const uint64_t ooff = (((uint64_t)b * sizeQlP + i) << g.logN) + r;
-        g.out0[ooff] = sum8_reduce(s0, q, lc.msb, mulo, muhi);
-        g.out1[ooff] = sum8_reduce(s1, q, lc.msb, mulo, muhi);
+        uint64_t v0 = sum8_reduce(s0, q, lc.msb, mulo, muhi), v1 = sum8_reduce(s1, q, lc.msb, mulo, muhi);
+        if (g.acc) {
+            v0 = add_mod(v0, g.out0[ooff], q);
+            v1 = add_mod(v1, g.out1[ooff], q);
+        }
+        g.out0[ooff] = v0;
+        g.out1[ooff] = v1;
     }
 }
 
@@ -227,6 +258,7 @@ struct InnerRowsArgs {
     const LimbConst* lc;
     const uint64_t* mu128;
     uint32_t logN, batch, rows, nTerms;
+    uint32_t acc;                    // more than 8 terms: later launches add their sums to out0 / out1
     uint8_t keyRow[kMaxLimbs];
     LimbSel sel;
 };
@@ -261,11 +293,21 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) inner_rows_kernel(const InnerRowsArg
                 sum8_add(b1, x1, g.k1[j][koff + r + 1]);
             }
         }
-        g.out0[xoff + r]     = sum8_reduce(a0, q, lc.msb, mulo, muhi);
-        g.out0[xoff + r + 1] = sum8_reduce(a1, q, lc.msb, mulo, muhi);
+        uint64_t v0 = sum8_reduce(a0, q, lc.msb, mulo, muhi), v1 = sum8_reduce(a1, q, lc.msb, mulo, muhi);
+        if (g.acc) {
+            v0 = add_mod(v0, g.out0[xoff + r], q);
+            v1 = add_mod(v1, g.out0[xoff + r + 1], q);
+        }
+        g.out0[xoff + r]     = v0;
+        g.out0[xoff + r + 1] = v1;
         if (two) {
-            g.out1[xoff + r]     = sum8_reduce(b0, q, lc.msb, mulo, muhi);
-            g.out1[xoff + r + 1] = sum8_reduce(b1, q, lc.msb, mulo, muhi);
+            v0 = sum8_reduce(b0, q, lc.msb, mulo, muhi), v1 = sum8_reduce(b1, q, lc.msb, mulo, muhi);
+            if (g.acc) {
+                v0 = add_mod(v0, g.out1[xoff + r], q);
+                v1 = add_mod(v1, g.out1[xoff + r + 1], q);
+            }
+            g.out1[xoff + r]     = v0;
+            g.out1[xoff + r + 1] = v1;
         }
     }
 }

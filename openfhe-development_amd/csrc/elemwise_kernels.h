@@ -338,5 +338,53 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) switch_modulus_kernel(const SwitchMo
     }
 }
 
+// ---- whole-tower checksums ---------------------------------------------------------------------------------------------
+// out[row] = { sum of the row's N words mod 2^64, xor of the row's N words } for every limb-row of x[rows][N]: a parity check of
+// EVERY tower of a resident batch costs one read of the batch (the oracle's words of the seed towers are summed on the host).
+// One workgroup per 4096-word tile; the tile's partial results go to the row's two words with atomics (out is zeroed first).
+struct ChecksumArgs {
+    const uint64_t* x;
+    uint64_t* out;  // [rows][2]
+    uint32_t logN, rows;
+};
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) checksum_kernel(const ChecksumArgs g) {
+    const uint32_t t          = FHE_TID;
+    const uint32_t tileLog    = g.logN < (uint32_t)kTileLog ? g.logN : (uint32_t)kTileLog;  // small rings: one workgroup per row
+    const uint64_t base       = (uint64_t)FHE_BID << tileLog;
+    const uint64_t totalWords = (uint64_t)g.rows << g.logN;
+    uint64_t s = 0, x = 0;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const uint32_t in  = ((uint32_t)m * kThreads + t) << 1;
+        const uint64_t off = base + in;
+        if (in >= (1u << tileLog) || off >= totalWords)
+            continue;
+        const uint64_t a = g.x[off], b = g.x[off + 1];
+        s += a + b;
+        x ^= a ^ b;
+    }
+    FHE_SHARED_U64(red, 2 * kThreads);
+    red[t]            = s;
+    red[kThreads + t] = x;
+    FHE_SYNC();
+    for (uint32_t w = kThreads / 2; w >= 1; w >>= 1) {
+        if (t < w) {
+            red[t] += red[t + w];
+            red[kThreads + t] ^= red[kThreads + t + w];
+        }
+        FHE_SYNC();
+    }
+    if (t == 0 && base < totalWords) {
+        const uint64_t row = base >> g.logN;
+#ifdef FHE_EMU
+        g.out[2 * row] += red[0];
+        g.out[2 * row + 1] ^= red[kThreads];
+#else
+        atomicAdd((unsigned long long*)&g.out[2 * row], (unsigned long long)red[0]);
+        atomicXor((unsigned long long*)&g.out[2 * row + 1], (unsigned long long)red[kThreads]);
+#endif
+    }
+}
+
 }  // namespace fhe
 #endif

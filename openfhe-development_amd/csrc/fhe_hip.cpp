@@ -420,6 +420,22 @@ extern "C" fhe_status fhe_stream_destroy(fhe_ctx* c, void* stream) {
     RT_CHECK(rt::stream_destroy((rt::stream_t)stream));
     return FHE_OK;
 }
+// `stream` waits on the device (the host is not blocked) for everything enqueued so far on `other`: the one cross-stream
+// primitive a multi-threaded host needs (one stream per host thread, hand-over of a tower between threads)
+extern "C" fhe_status fhe_stream_wait(fhe_ctx* c, void* stream, void* other) {
+    ARG_CHECK(c, "fhe_stream_wait: null context");
+    if (stream == other)
+        return FHE_OK;
+    RT_CHECK(rt::set_device(c->device));
+    RT_CHECK(rt::stream_wait((rt::stream_t)stream, (rt::stream_t)other));
+    return FHE_OK;
+}
+extern "C" fhe_status fhe_memset_zero(fhe_ctx* c, void* dst, size_t bytes, void* stream) {
+    ARG_CHECK(c && dst, "fhe_memset_zero: null argument");
+    RT_CHECK(rt::set_device(c->device));
+    RT_CHECK(rt::dzero(dst, bytes, (rt::stream_t)stream));
+    return FHE_OK;
+}
 extern "C" fhe_status fhe_graph_begin(fhe_ctx* c, void* stream) {
     ARG_CHECK(c && stream, "fhe_graph_begin: capture needs a stream created with fhe_stream_create");
     RT_CHECK(rt::set_device(c->device));
@@ -1120,7 +1136,11 @@ struct fhe_conv {
     fhe_ctx* ctx;
     uint32_t nSrc, nDst;
     std::vector<uint32_t> srcIdx, dstIdx;  // context limbs of the two bases (empty for internal plans)
-    ConvTables tb;
+    ConvTables tb;                   // = chunks[0]
+    std::vector<ConvTables> chunks;  // source limbs [32k, 32k+32): one launch each (more than one only beyond 32 source limbs)
+    const TwPair* allHatInv  = nullptr;  // chunked exact plans: every source limb's multiplier / modulus / 1.0/q_i
+    const uint64_t* allSrcQ  = nullptr;
+    const double* allQInv    = nullptr;
     std::vector<void*> owned;
 };
 
@@ -1143,26 +1163,14 @@ static fhe_status conv_from_tables(fhe_ctx* c, const std::vector<uint64_t>& src,
                                    const uint64_t* hatInvIn, const uint64_t* hatModIn, const uint64_t* alphaIn,
                                    const double* qInvIn, fhe_conv** out) {
     const uint32_t nSrc = (uint32_t)src.size(), nDst = (uint32_t)dst.size();
-    if (nSrc < 1 || nSrc > 32u || nDst < 1 || nDst > (uint32_t)kMaxLimbs)  // table layout and kernel instances end at NSRC = 32
-        return fail(FHE_ERR_UNSUPPORTED, "basis conversion: at most 32 source and 128 target limbs supported");
+    if (nSrc < 1 || nSrc > (uint32_t)kMaxLimbs || nDst < 1 || nDst > (uint32_t)kMaxLimbs)
+        return fail(FHE_ERR_ARG, "basis conversion: 1..128 source and target limbs");
     fhe_conv* cv = new fhe_conv;
     cv->ctx      = c;
     cv->nSrc     = nSrc;
     cv->nDst     = nDst;
-    const uint32_t pad = conv_nsrc_pad(nSrc);
-    std::vector<TwPair> hatInv(32, TwPair{0, 0});
-    std::vector<uint64_t> hatMod((size_t)pad * nDst, 0), mu(2 * (size_t)nDst), alphaMod((size_t)(nSrc + 1) * nDst, 0);
-    std::vector<uint64_t> srcPad(32, 1);
-    std::vector<double> qInv(32, 0.0);
-    for (uint32_t i = 0; i < nSrc; ++i) {
-        const uint64_t inv = hatInvIn[i] % src[i];
-        hatInv[i]          = TwPair{inv, host::shoup(inv, src[i])};
-        qInv[i]            = qInvIn ? qInvIn[i] : 1.0 / static_cast<double>(src[i]);
-        srcPad[i]          = src[i];
-        for (uint32_t j = 0; j < nDst; ++j)
-            hatMod[(size_t)j * pad + i] = hatModIn[(size_t)i * nDst + j] % dst[j];
-    }
-    std::vector<uint64_t> red(4 * (size_t)nDst);
+    // target-side tables, shared by all chunks
+    std::vector<uint64_t> mu(2 * (size_t)nDst), alphaMod((size_t)(nSrc + 1) * nDst, 0), red(4 * (size_t)nDst);
     for (uint32_t j = 0; j < nDst; ++j) {
         host::mu128(dst[j], &mu[2 * j]);
         const uint64_t R = (uint64_t)((((unsigned __int128)1) << 64) % dst[j]);
@@ -1174,17 +1182,55 @@ static fhe_status conv_from_tables(fhe_ctx* c, const std::vector<uint64_t>& src,
     if (alphaIn)
         for (size_t k = 0; k < alphaMod.size(); ++k)
             alphaMod[k] = alphaIn[k] % dst[k % nDst];
+    ConvTables shared{};
     fhe_status s;
-    if ((s = conv_upload(cv, hatInv.data(), hatInv.size() * sizeof(TwPair), (const void**)&cv->tb.hatInv)) ||
-        (s = conv_upload(cv, hatMod.data(), hatMod.size() * 8, (const void**)&cv->tb.hatMod)) ||
-        (s = conv_upload(cv, srcPad.data(), srcPad.size() * 8, (const void**)&cv->tb.srcQ)) ||
-        (s = conv_upload(cv, dst.data(), dst.size() * 8, (const void**)&cv->tb.dstQ)) ||
-        (s = conv_upload(cv, mu.data(), mu.size() * 8, (const void**)&cv->tb.dstMu)) ||
-        (s = conv_upload(cv, red.data(), red.size() * 8, (const void**)&cv->tb.dstRed)) ||
-        (s = conv_upload(cv, qInv.data(), qInv.size() * sizeof(double), (const void**)&cv->tb.srcQInv)) ||
-        (s = conv_upload(cv, alphaMod.data(), alphaMod.size() * 8, (const void**)&cv->tb.alphaMod))) {
+    if ((s = conv_upload(cv, dst.data(), dst.size() * 8, (const void**)&shared.dstQ)) ||
+        (s = conv_upload(cv, mu.data(), mu.size() * 8, (const void**)&shared.dstMu)) ||
+        (s = conv_upload(cv, red.data(), red.size() * 8, (const void**)&shared.dstRed)) ||
+        (s = conv_upload(cv, alphaMod.data(), alphaMod.size() * 8, (const void**)&shared.alphaMod))) {
         fhe_conv_destroy(cv);
         return s;
+    }
+    // source-side tables per chunk of <= 32 source limbs (one chunk = one kernel launch; the usual case is one chunk)
+    for (uint32_t c0 = 0; c0 < nSrc; c0 += 32u) {
+        const uint32_t n   = std::min(32u, nSrc - c0);
+        const uint32_t pad = conv_nsrc_pad(n);
+        std::vector<TwPair> hatInv(32, TwPair{0, 0});
+        std::vector<uint64_t> hatMod((size_t)pad * nDst, 0), srcPad(32, 1);
+        std::vector<double> qInv(32, 0.0);
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint64_t inv = hatInvIn[c0 + i] % src[c0 + i];
+            hatInv[i]          = TwPair{inv, host::shoup(inv, src[c0 + i])};
+            qInv[i]            = qInvIn ? qInvIn[c0 + i] : 1.0 / static_cast<double>(src[c0 + i]);
+            srcPad[i]          = src[c0 + i];
+            for (uint32_t j = 0; j < nDst; ++j)
+                hatMod[(size_t)j * pad + i] = hatModIn[(size_t)(c0 + i) * nDst + j] % dst[j];
+        }
+        ConvTables tb = shared;
+        if ((s = conv_upload(cv, hatInv.data(), hatInv.size() * sizeof(TwPair), (const void**)&tb.hatInv)) ||
+            (s = conv_upload(cv, hatMod.data(), hatMod.size() * 8, (const void**)&tb.hatMod)) ||
+            (s = conv_upload(cv, srcPad.data(), srcPad.size() * 8, (const void**)&tb.srcQ)) ||
+            (s = conv_upload(cv, qInv.data(), qInv.size() * sizeof(double), (const void**)&tb.srcQInv))) {
+            fhe_conv_destroy(cv);
+            return s;
+        }
+        cv->chunks.push_back(tb);
+    }
+    cv->tb = cv->chunks[0];
+    if (nSrc > 32u) {  // the last chunk of the exact variant counts the overflow over all source limbs
+        std::vector<TwPair> allInv(nSrc);
+        std::vector<double> allQInv(nSrc);
+        for (uint32_t i = 0; i < nSrc; ++i) {
+            const uint64_t inv = hatInvIn[i] % src[i];
+            allInv[i]          = TwPair{inv, host::shoup(inv, src[i])};
+            allQInv[i]         = qInvIn ? qInvIn[i] : 1.0 / static_cast<double>(src[i]);
+        }
+        if ((s = conv_upload(cv, allInv.data(), allInv.size() * sizeof(TwPair), (const void**)&cv->allHatInv)) ||
+            (s = conv_upload(cv, src.data(), src.size() * 8, (const void**)&cv->allSrcQ)) ||
+            (s = conv_upload(cv, allQInv.data(), allQInv.size() * sizeof(double), (const void**)&cv->allQInv))) {
+            fhe_conv_destroy(cv);
+            return s;
+        }
     }
     *out = cv;
     return FHE_OK;
@@ -1219,7 +1265,7 @@ static fhe_status conv_build(fhe_ctx* c, const std::vector<uint64_t>& src, const
 extern "C" fhe_status fhe_conv_create(fhe_ctx* c, const uint32_t* srcIdx, uint32_t nSrc, const uint32_t* dstIdx,
                                       uint32_t nDst, fhe_conv** out) {
     ARG_CHECK(c && srcIdx && dstIdx && out, "fhe_conv_create: null argument");
-    ARG_CHECK(nSrc >= 1 && nSrc <= 32 && nDst >= 1 && nDst <= (uint32_t)kMaxLimbs, "fhe_conv_create: bad basis size");
+    ARG_CHECK(nSrc >= 1 && nSrc <= (uint32_t)kMaxLimbs && nDst >= 1 && nDst <= (uint32_t)kMaxLimbs, "fhe_conv_create: bad basis size");
     std::vector<uint64_t> src(nSrc), dst(nDst);
     for (uint32_t i = 0; i < nSrc; ++i) {
         ARG_CHECK(srcIdx[i] < c->L, "fhe_conv_create: source limb exceeds context size");
@@ -1244,7 +1290,7 @@ extern "C" fhe_status fhe_conv_create_custom(fhe_ctx* c, const uint32_t* srcIdx,
                                              uint32_t nDst, const uint64_t* hatInv, const uint64_t* hatMod,
                                              const uint64_t* alphaMod, const double* qInv, fhe_conv** out) {
     ARG_CHECK(c && srcIdx && dstIdx && hatInv && hatMod && out, "fhe_conv_create_custom: null argument");
-    ARG_CHECK(nSrc >= 1 && nSrc <= 32 && nDst >= 1 && nDst <= (uint32_t)kMaxLimbs, "fhe_conv_create_custom: bad basis size");
+    ARG_CHECK(nSrc >= 1 && nSrc <= (uint32_t)kMaxLimbs && nDst >= 1 && nDst <= (uint32_t)kMaxLimbs, "fhe_conv_create_custom: bad basis size");
     ARG_CHECK((alphaMod == nullptr) == (qInv == nullptr), "fhe_conv_create_custom: alphaMod and qInv go together");
     std::vector<uint64_t> src(nSrc), dst(nDst);
     for (uint32_t i = 0; i < nSrc; ++i) {
@@ -1277,15 +1323,35 @@ static fhe_status conv_run(fhe_conv* cv, const uint64_t* in, uint32_t inStride, 
     ARG_CHECK(batch >= 1 && inFirst + cv->nSrc <= inStride && outFirst + cv->nDst <= outStride,
               "fhe_switch_basis: limb window exceeds tower stride");
     RT_CHECK(rt::set_device(cv->ctx->device));
-    ConvArgs g;
+    ConvArgs g{};
     g.in = in, g.out = out, g.tb = cv->tb;
     g.logN = cv->ctx->logN, g.batch = batch, g.nSrc = cv->nSrc, g.nDst = cv->nDst;
     g.inStride = inStride, g.inFirst = inFirst, g.outStride = outStride, g.outFirst = outFirst;
     const uint64_t coeffs = (uint64_t)batch << g.logN;
     const uint32_t grid   = (uint32_t)((coeffs + kThreads - 1) / kThreads);
-    const uint32_t pad = conv_nsrc_pad(cv->nSrc);
     // column-sum form of the kernel: 2 = factors split at 30 bits (default), FHE_CONV_SUM8=1 = carry-counted 64-bit columns
     static const bool split30 = env_u32("FHE_CONV_SUM8", 2) != 1u;
+    if (cv->chunks.size() > 1) {  // more than 32 source limbs: one launch per chunk, sums accumulated in `out`
+        g.nSrcAll = cv->nSrc, g.inAll = in + ((size_t)inFirst << g.logN);
+        g.allHatInv = cv->allHatInv, g.allSrcQ = cv->allSrcQ, g.allQInv = cv->allQInv;
+        for (size_t k = 0; k < cv->chunks.size(); ++k) {
+            g.tb      = cv->chunks[k];
+            g.nSrc    = std::min(32u, cv->nSrc - 32u * (uint32_t)k);
+            g.inFirst = inFirst + 32u * (uint32_t)k;
+            g.acc     = k > 0;
+            g.last    = k + 1 == cv->chunks.size();
+            const uint32_t pad = conv_nsrc_pad(g.nSrc);
+            if (pad == 8)
+                FHE_LAUNCH((switch_basis_kernel<8, EXACT, 2, true>), grid, st, g);
+            else if (pad == 16)
+                FHE_LAUNCH((switch_basis_kernel<16, EXACT, 2, true>), grid, st, g);
+            else
+                FHE_LAUNCH((switch_basis_kernel<32, EXACT, 2, true>), grid, st, g);
+            LAUNCH_CHECK();
+        }
+        return FHE_OK;
+    }
+    const uint32_t pad = conv_nsrc_pad(cv->nSrc);
     if (pad == 8 && split30)
         FHE_LAUNCH((switch_basis_kernel<8, EXACT, 2>), grid, st, g);
     else if (pad == 8)
@@ -1409,10 +1475,8 @@ extern "C" fhe_status fhe_ks_plan_create(fhe_ctx* c, uint32_t sizeQ, uint32_t si
     // rns-cryptoparameters.cpp:87-91
     ARG_CHECK(sizeQ > a * (numPartQ - 1),
               "HYBRID key switching parameters: Can't appropriately distribute towers into digits");
-    ARG_CHECK(numPartQ <= (uint32_t)kMaxDigits, "fhe_ks_plan_create: at most 8 digits supported");
-    // the conversion kernels take at most 32 source limbs (switch_basis_kernel<NSRC <= 32>): digits (ModUp) and P (ModDown)
-    if (a > 32u || sizeP > 32u)
-        return fail(FHE_ERR_UNSUPPORTED, "fhe_ks_plan_create: digit size ceil(sizeQ/numPartQ) and sizeP must be <= 32");
+    // (digits or P of more than 32 limbs — dnum = 1 or 2 on long chains — run as chunked conversions; more than 8 digits as
+    // chunked inner products: the reference's loops have no such bounds, dcrtpoly-impl.h:895-915, keyswitch-hybrid.cpp:419-430)
     fhe_ks_plan* p = new fhe_ks_plan;
     p->ctx = c, p->sizeQ = sizeQ, p->sizeP = sizeP, p->numPartQ = numPartQ, p->alpha = a;
     p->levels.assign(sizeQ + 1, nullptr);
@@ -1568,12 +1632,14 @@ extern "C" size_t fhe_ks_key_words(const fhe_ks_key* k) { return k ? k->words : 
 //   pcoef  [2*batch][sizeP][N]
 //   d2     [batch][sizeQl][N], k0,k1 [batch][sizeQl][N]   (eval_mult only)
 struct KsLayout {
-    size_t coef, dig[kMaxDigits], e0, e1, md, pcoef, d2, k0, k1, total;
+    size_t coef = 0, e0 = 0, e1 = 0, md = 0, pcoef = 0, d2 = 0, k0 = 0, k1 = 0, total = 0;
+    std::vector<size_t> dig;
 };
 static KsLayout ks_layout(const fhe_ks_plan* p, uint32_t sizeQl, uint32_t batch) {
-    KsLayout w{};
+    KsLayout w;
     const size_t N = (size_t)1 << p->ctx->logN;
     const uint32_t numParts = std::min((sizeQl + p->alpha - 1) / p->alpha, p->numPartQ);
+    w.dig.assign(numParts, 0);
     size_t off = 0;
     w.coef = off, off += (size_t)batch * sizeQl * N;
     for (uint32_t j = 0; j < numParts; ++j) {
@@ -1663,19 +1729,22 @@ static fhe_status ks_inner_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const fhe
                                uint32_t towOff = 0) {
     fhe_ctx* c            = p->ctx;
     const uint32_t sizeQl = lv->sizeQl, sizeP = p->sizeP, sizeQlP = sizeQl + sizeP;
-    KsInnerArgs g;
-    for (uint32_t j = 0; j < (uint32_t)kMaxDigits; ++j) {
-        g.nc[j]     = j < lv->numParts ? (uint32_t)lv->cidx[j].size() : 0u;
-        g.digits[j] = j < lv->numParts ? ws + w.dig[j] + (((size_t)towOff * g.nc[j]) << c->logN) : nullptr;
-    }
-    g.c = cin + (((size_t)towOff * sizeQl) << c->logN), g.keyB = key->d_b, g.keyA = key->d_a;
-    g.out0 = e0, g.out1 = e1;
-    g.lc = c->d_lc, g.mu128 = c->d_mu128;
-    g.logN = c->logN, g.batch = batch, g.sizeQl = sizeQl, g.sizeQ = p->sizeQ, g.sizeP = sizeP;
-    g.numDigits = lv->numParts, g.alpha = p->alpha;
     const uint32_t tilesPerRow = c->N >= (uint32_t)kTile ? (c->N >> kTileLog) : 1u;
-    FHE_LAUNCH(ks_inner_product_kernel, (((uint64_t)tilesPerRow * sizeQlP + 7) / 8) * 8 * batch, st, g);
-    LAUNCH_CHECK();
+    for (uint32_t j0 = 0; j0 < lv->numParts; j0 += (uint32_t)kMaxDigits) {  // (one launch up to 8 digits)
+        KsInnerArgs g;
+        const uint32_t nd = std::min<uint32_t>(kMaxDigits, lv->numParts - j0);
+        for (uint32_t j = 0; j < (uint32_t)kMaxDigits; ++j) {
+            g.nc[j]     = j < nd ? (uint32_t)lv->cidx[j0 + j].size() : 0u;
+            g.digits[j] = j < nd ? ws + w.dig[j0 + j] + (((size_t)towOff * g.nc[j]) << c->logN) : nullptr;
+        }
+        g.c = cin + (((size_t)towOff * sizeQl) << c->logN), g.keyB = key->d_b, g.keyA = key->d_a;
+        g.out0 = e0, g.out1 = e1;
+        g.lc = c->d_lc, g.mu128 = c->d_mu128;
+        g.logN = c->logN, g.batch = batch, g.sizeQl = sizeQl, g.sizeQ = p->sizeQ, g.sizeP = sizeP;
+        g.numDigits = nd, g.alpha = p->alpha, g.j0 = j0, g.acc = j0 > 0;
+        FHE_LAUNCH(ks_inner_product_kernel, (((uint64_t)tilesPerRow * sizeQlP + 7) / 8) * 8 * batch, st, g);
+        LAUNCH_CHECK();
+    }
     return FHE_OK;
 }
 // the HYBRID inner product (keyswitch-hybrid.cpp:419-430) over towers in separate allocations: see inner_rows_kernel
@@ -1685,8 +1754,7 @@ extern "C" fhe_status fhe_inner_product(fhe_ctx* c, uint32_t nTerms, const uint6
     ARG_CHECK(c && x && k0 && out0, "fhe_inner_product: null argument");
     ARG_CHECK((k1 != nullptr) == (out1 != nullptr), "fhe_inner_product: the second key and the second output go together");
     ARG_CHECK(batch >= 1, "fhe_inner_product: batch must be >= 1");
-    if (nTerms < 1 || nTerms > (uint32_t)kMaxDigits)
-        return fail(FHE_ERR_UNSUPPORTED, "fhe_inner_product: 1..8 terms per launch");
+    ARG_CHECK(nTerms >= 1, "fhe_inner_product: no terms");
     InnerRowsArgs g;
     if (fhe_status s = make_sel(c, limbIdx, rows, &g.sel, "fhe_inner_product"))
         return s;
@@ -1695,18 +1763,23 @@ extern "C" fhe_status fhe_inner_product(fhe_ctx* c, uint32_t nTerms, const uint6
         ARG_CHECK(kr < 256u, "fhe_inner_product: key row out of range");
         g.keyRow[i] = (uint8_t)kr;
     }
-    for (uint32_t j = 0; j < (uint32_t)kMaxDigits; ++j) {
-        ARG_CHECK(j >= nTerms || (x[j] && k0[j] && (!k1 || k1[j])), "fhe_inner_product: null term");
-        g.x[j]  = j < nTerms ? x[j] : nullptr;
-        g.k0[j] = j < nTerms ? k0[j] : nullptr;
-        g.k1[j] = (j < nTerms && k1) ? k1[j] : nullptr;
-    }
+    for (uint32_t j = 0; j < nTerms; ++j)
+        ARG_CHECK(x[j] && k0[j] && (!k1 || k1[j]), "fhe_inner_product: null term");
     RT_CHECK(rt::set_device(c->device));
     g.out0 = out0, g.out1 = out1, g.lc = c->d_lc, g.mu128 = c->d_mu128;
-    g.logN = c->logN, g.batch = batch, g.rows = rows, g.nTerms = nTerms;
+    g.logN = c->logN, g.batch = batch, g.rows = rows;
     const uint32_t tilesPerRow = c->N >= (uint32_t)kTile ? (c->N >> kTileLog) : 1u;
-    FHE_LAUNCH(inner_rows_kernel, (uint64_t)tilesPerRow * rows * batch, st, g);
-    LAUNCH_CHECK();
+    for (uint32_t t0 = 0; t0 < nTerms; t0 += (uint32_t)kMaxDigits) {  // (one launch up to 8 terms; exact sums, so chunks add up)
+        const uint32_t nt = std::min<uint32_t>(kMaxDigits, nTerms - t0);
+        for (uint32_t j = 0; j < (uint32_t)kMaxDigits; ++j) {
+            g.x[j]  = j < nt ? x[t0 + j] : nullptr;
+            g.k0[j] = j < nt ? k0[t0 + j] : nullptr;
+            g.k1[j] = (j < nt && k1) ? k1[t0 + j] : nullptr;
+        }
+        g.nTerms = nt, g.acc = t0 > 0;
+        FHE_LAUNCH(inner_rows_kernel, (uint64_t)tilesPerRow * rows * batch, st, g);
+        LAUNCH_CHECK();
+    }
     return FHE_OK;
 }
 static fhe_status ks_fast_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const fhe_ks_key* key, const uint64_t* cin,
@@ -2699,6 +2772,99 @@ extern "C" void fhe_behz_destroy(fhe_behz* h) {
         rt::dfree(p);
     delete h;
 }
+// The caller's tables in place of the derived ones, per member (the arguments the reference passes to that member, row-major as it
+// indexes them).  A DCRTPoly backend receives exactly these vectors from pke (CryptoParametersBFVRNS getters): with an override the
+// member computes with the CALLER's values, whatever they are, as the reference's member does.
+static fhe_status behz_pairs(fhe_behz* h, const uint64_t* v, const uint64_t* mod, uint32_t n, const TwPair** slot) {
+    std::vector<TwPair> t(kMaxBfvLimbs, TwPair{0, 0});
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t w = v[i] % mod[i];
+        t[i]             = TwPair{w, host::shoup(w, mod[i])};
+    }
+    TwPair* d = nullptr;
+    if (fhe_status s = dev_copy(h->owned, t.data(), t.size(), &d))
+        return s;
+    *slot = d;
+    return FHE_OK;
+}
+// matrix given as [nRow][nCol] (reference order) -> device [nCol][kMaxBfvLimbs] (one target's weights contiguous)
+static fhe_status behz_matrix(fhe_behz* h, const uint64_t* m, uint32_t nRow, uint32_t nCol, const uint64_t* colMod, const uint64_t** slot) {
+    constexpr size_t W = kMaxBfvLimbs;
+    std::vector<uint64_t> t(W * nCol, 0);
+    for (uint32_t i = 0; i < nRow; ++i)
+        for (uint32_t j = 0; j < nCol; ++j)
+            t[(size_t)j * W + i] = m[(size_t)i * nCol + j] % colMod[j];
+    uint64_t* d = nullptr;
+    if (fhe_status s = dev_copy(h->owned, t.data(), t.size(), &d))
+        return s;
+    *slot = d;
+    return FHE_OK;
+}
+static void behz_moduli(const fhe_behz* h, std::vector<uint64_t>& q, std::vector<uint64_t>& bsk) {
+    q.resize(h->numQ), bsk.resize(h->numBsk);
+    for (uint32_t i = 0; i < h->numQ; ++i)
+        q[i] = h->ctx->q[h->qIdx[i]];
+    for (uint32_t j = 0; j < h->numBsk; ++j)
+        bsk[j] = h->ctx->q[h->bskIdx[j]];
+}
+extern "C" fhe_status fhe_behz_override_q_to_bsk(fhe_behz* h, const uint64_t* mtildeQHatInvModq, const uint64_t* QHatModbsk,
+                                                 const uint64_t* QHatModmtilde, const uint64_t* QModbsk, uint64_t negQInvModmtilde,
+                                                 const uint64_t* mtildeInvModbsk) {
+    ARG_CHECK(h && mtildeQHatInvModq && QHatModbsk && QHatModmtilde && QModbsk && mtildeInvModbsk, "fhe_behz_override_q_to_bsk: null argument");
+    RT_CHECK(rt::set_device(h->ctx->device));
+    std::vector<uint64_t> q, bsk;
+    behz_moduli(h, q, bsk);
+    fhe_status s;
+    if ((s = behz_pairs(h, mtildeQHatInvModq, q.data(), h->numQ, &h->tb.mtQHatInv)) ||
+        (s = behz_matrix(h, QHatModbsk, h->numQ, h->numBsk, bsk.data(), &h->tb.QHatModbsk)) ||
+        (s = behz_pairs(h, QModbsk, bsk.data(), h->numBsk, &h->tb.QModbsk)) ||
+        (s = behz_pairs(h, mtildeInvModbsk, bsk.data(), h->numBsk, &h->tb.mtInvModbsk)))
+        return s;
+    std::vector<uint64_t> mt(kMaxBfvLimbs, 0);
+    std::copy(QHatModmtilde, QHatModmtilde + h->numQ, mt.begin());
+    uint64_t* d = nullptr;
+    if ((s = dev_copy(h->owned, mt.data(), mt.size(), &d)))
+        return s;
+    h->tb.QHatModmt    = d;
+    h->tb.negQInvModmt = negQInvModmtilde;
+    return FHE_OK;
+}
+extern "C" fhe_status fhe_behz_override_floorq(fhe_behz* h, const uint64_t* tQHatInvModq, const uint64_t* QHatModbsk,
+                                               const uint64_t* qInvModbsk, const uint64_t* tQInvModbsk) {
+    ARG_CHECK(h && tQHatInvModq && QHatModbsk && qInvModbsk && tQInvModbsk, "fhe_behz_override_floorq: null argument");
+    RT_CHECK(rt::set_device(h->ctx->device));
+    std::vector<uint64_t> q, bsk;
+    behz_moduli(h, q, bsk);
+    fhe_status s;
+    if ((s = behz_pairs(h, tQHatInvModq, q.data(), h->numQ, &h->tb.tQHatInv)) ||
+        (s = behz_matrix(h, QHatModbsk, h->numQ, h->numBsk, bsk.data(), &h->tb.QHatModbsk)) ||
+        (s = behz_matrix(h, qInvModbsk, h->numQ, h->numBsk, bsk.data(), &h->tb.qInvModbsk)) ||
+        (s = behz_pairs(h, tQInvModbsk, bsk.data(), h->numBsk, &h->tb.tQInvModbsk)))
+        return s;
+    return FHE_OK;
+}
+extern "C" fhe_status fhe_behz_override_conv_sk(fhe_behz* h, const uint64_t* BHatInvModb, const uint64_t* BHatModmsk, uint64_t BInvModmsk,
+                                                const uint64_t* BHatModq, const uint64_t* BModq) {
+    ARG_CHECK(h && BHatInvModb && BHatModmsk && BHatModq && BModq, "fhe_behz_override_conv_sk: null argument");
+    RT_CHECK(rt::set_device(h->ctx->device));
+    std::vector<uint64_t> q, bsk;
+    behz_moduli(h, q, bsk);
+    const uint32_t numB = h->numQ;
+    const uint64_t msk  = bsk[numB];
+    fhe_status s;
+    if ((s = behz_pairs(h, BHatInvModb, bsk.data(), numB, &h->tb.BHatInv)) ||
+        (s = behz_matrix(h, BHatModq, numB, h->numQ, q.data(), &h->tb.BHatModq)) || (s = behz_pairs(h, BModq, q.data(), h->numQ, &h->tb.BModq)))
+        return s;
+    std::vector<uint64_t> bm(kMaxBfvLimbs, 0);
+    for (uint32_t i = 0; i < numB; ++i)
+        bm[i] = BHatModmsk[i] % msk;
+    uint64_t* d = nullptr;
+    if ((s = dev_copy(h->owned, bm.data(), bm.size(), &d)))
+        return s;
+    h->tb.BHatModmsk = d;
+    h->tb.BInvModmsk = TwPair{BInvModmsk % msk, host::shoup(BInvModmsk % msk, msk)};
+    return FHE_OK;
+}
 static bool behz_split30() {  // the BEHZ dot products with 30-bit split factors (default; same knob as the conversion kernel)
     static const bool on = env_u32("FHE_CONV_SUM8", 2) != 1u;
     return on;
@@ -2850,5 +3016,18 @@ extern "C" fhe_status fhe_bfv_eval_mult_relin_behz(fhe_behz* bz, fhe_ks_plan* p,
         return s;
     const KsLayout lay = ks_layout(p, p->sizeQ, batch);
     return keyswitch_run(p, key, d2, p->sizeQ, batch, c0, c1, (uint64_t*)(w + nrB), lay, st, true);
+}
+
+// whole-tower checksums (checksum_kernel): out[row] = {sum mod 2^64, xor} of every limb-row of x[rows][N]; out is DEVICE memory
+extern "C" fhe_status fhe_checksum(fhe_ctx* c, const uint64_t* x, uint32_t rows, uint64_t* out, void* st) {
+    ARG_CHECK(c && x && out && rows >= 1, "fhe_checksum: bad argument");
+    RT_CHECK(rt::set_device(c->device));
+    RT_CHECK(rt::dzero(out, (size_t)rows * 16, (rt::stream_t)st));
+    ChecksumArgs g;
+    g.x = x, g.out = out, g.logN = c->logN, g.rows = rows;
+    const uint32_t tileLog = std::min<uint32_t>(c->logN, kTileLog);
+    FHE_LAUNCH(checksum_kernel, ((uint64_t)rows << c->logN) >> tileLog, st, g);
+    LAUNCH_CHECK();
+    return FHE_OK;
 }
 

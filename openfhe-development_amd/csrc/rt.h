@@ -54,6 +54,11 @@ inline const char* stream_create(stream_t* s) {
     return nullptr;
 }
 inline const char* stream_destroy(stream_t) { return nullptr; }
+inline const char* stream_wait(stream_t, stream_t) { return nullptr; }  // (the emulator runs every launch synchronously)
+inline const char* dzero(void* d, size_t n, stream_t) {
+    std::memset(d, 0, n);
+    return nullptr;
+}
 inline const char* capture_begin(stream_t) { return "stream capture needs the HIP build"; }
 inline const char* capture_end(stream_t, graph_t*) { return "stream capture needs the HIP build"; }
 inline const char* graph_launch(graph_t, stream_t) { return "stream capture needs the HIP build"; }
@@ -116,6 +121,22 @@ inline const char* dzero_2d(void* d, size_t pitch, size_t width, size_t height, 
 typedef hipGraphExec_t graph_t;
 inline const char* stream_create(stream_t* s) { return err(hipStreamCreateWithFlags(s, hipStreamNonBlocking)); }
 inline const char* stream_destroy(stream_t s) { return err(hipStreamDestroy(s)); }
+// `waiter` waits (on the device, without blocking the host) for everything enqueued on `signaler` so far.  A waiting stream
+// keeps the event's state at the time of the call, so a small per-thread ring of events is re-recorded freely.
+inline const char* stream_wait(stream_t waiter, stream_t signaler) {
+    constexpr int kRing = 32;
+    static thread_local hipEvent_t ring[kRing] = {};
+    static thread_local int at = 0;
+    hipEvent_t& e = ring[at];
+    at = (at + 1) % kRing;
+    if (!e)
+        if (auto m = err(hipEventCreateWithFlags(&e, hipEventDisableTiming)))
+            return m;
+    if (auto m = err(hipEventRecord(e, signaler)))
+        return m;
+    return err(hipStreamWaitEvent(waiter, e, 0));
+}
+inline const char* dzero(void* d, size_t n, stream_t st) { return err(hipMemsetAsync(d, 0, n, st)); }
 inline const char* capture_begin(stream_t s) { return err(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal)); }
 inline const char* capture_end(stream_t s, graph_t* out) {
     hipGraph_t g = nullptr;

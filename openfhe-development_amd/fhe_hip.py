@@ -67,6 +67,9 @@ class Lib:
         S("fhe_stream_sync", C.c_int, [vp, vp])
         S("fhe_stream_create", C.c_int, [vp, C.POINTER(vp)])
         S("fhe_stream_destroy", C.c_int, [vp, vp])
+        S("fhe_stream_wait", C.c_int, [vp, vp, vp])
+        S("fhe_memset_zero", C.c_int, [vp, vp, C.c_size_t, vp])
+        S("fhe_checksum", C.c_int, [vp, vp, u32, vp, vp])
         S("fhe_graph_begin", C.c_int, [vp, vp])
         S("fhe_graph_end", C.c_int, [vp, vp, C.POINTER(vp)])
         S("fhe_graph_launch", C.c_int, [vp, vp, vp])
@@ -136,6 +139,9 @@ class Lib:
         S("fhe_param_behz_bsk", u32, [u32, u32, u64p, u64, u64p, u64p])
         S("fhe_behz_create", C.c_int, [vp, u32p, u32, u32p, u64, C.POINTER(vp)])
         S("fhe_behz_destroy", None, [vp])
+        S("fhe_behz_override_q_to_bsk", C.c_int, [vp, u64p, u64p, u64p, u64p, u64, u64p])
+        S("fhe_behz_override_floorq", C.c_int, [vp, u64p, u64p, u64p, u64p])
+        S("fhe_behz_override_conv_sk", C.c_int, [vp, u64p, u64p, u64, u64p, u64p])
         S("fhe_behz_workspace_bytes", C.c_size_t, [vp, u32])
         S("fhe_behz_q_to_bsk", C.c_int, [vp, vp, C.c_int, u32, vp, C.c_size_t, vp])
         S("fhe_behz_floorq", C.c_int, [vp, vp, u32, vp])
@@ -259,6 +265,16 @@ class Context:
 
     def sync(self, stream=None):
         self.lib.check(self.lib.L.fhe_stream_sync(self.h, stream))
+
+    def checksum(self, tower, stream=None):
+        """uint64[batch * limbs][2] = {sum mod 2^64, xor} of every limb-row of the tower (fhe_checksum)"""
+        rows = tower.batch * tower.n_limbs
+        d = self.malloc(rows * 16)
+        try:
+            self.lib.check(self.lib.L.fhe_checksum(self.h, tower.ptr, rows, d, stream))
+            return self.download(d, (rows, 2), stream)
+        finally:
+            self.free(d)
 
     def tower(self, host, limb_idx=None, fmt=EVALUATION):
         """host: uint64 [batch][nLimbs][N] (or [nLimbs][N])"""

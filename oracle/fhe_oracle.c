@@ -617,7 +617,7 @@ void orc_approx_switch_crt_basis(const uint64_t* x, uint32_t sizeQ, uint32_t N, 
                                  const uint64_t* mu128, uint64_t* out) {
 #pragma omp parallel for
     for (uint32_t ri = 0; ri < N; ++ri) {
-        u128 sum[64];
+        u128 sum[128];
         for (uint32_t j = 0; j < sizeP; ++j)
             sum[j] = 0;
         for (uint32_t i = 0; i < sizeQ; ++i) {
@@ -642,7 +642,7 @@ void orc_switch_crt_basis(const uint64_t* x, uint32_t sizeQ, uint32_t N, const u
                           const uint64_t* p, const uint64_t* mu128, const double* qInv, uint64_t* out) {
 #pragma omp parallel for
     for (uint32_t ri = 0; ri < N; ++ri) {
-        uint64_t y[64];
+        uint64_t y[128];
         double nu = 0.5;
         for (uint32_t i = 0; i < sizeQ; ++i) {
             y[i] = orc_mod_mul_fast_const(x[(size_t)i * N + ri], QHatInvModq[i], q[i], QHatInvModqPrecon[i]);
@@ -873,7 +873,7 @@ uint32_t orc_hybrid_precompute_digits(const orc_hybrid* h, const uint64_t* c, ui
 #pragma omp parallel for
         for (uint32_t i = 0; i < sz; ++i)
             ctx_inv(h->ctx, partsCt + (size_t)i * N, start + i);
-        uint64_t hatInv[64], hatInvPre[64], cm[128], mu[256];
+        uint64_t hatInv[128], hatInvPre[128], cm[128], mu[256];
         uint64_t* hatModp = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)sz * nc);
         orc_hybrid_get_PartQlHatInvModq(h, part, sizeQl, hatInv);
         for (uint32_t i = 0; i < sz; ++i)

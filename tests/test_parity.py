@@ -151,12 +151,13 @@ def test_elementwise(backend, oracle):
 
 def test_inner_product_over_separate_towers(backend, oracle):
     """fhe_inner_product = the sum of EvalFastKeySwitchCoreExt (keyswitch-hybrid.cpp:419-430) with every digit and every key
-    element in its own allocation; key rows through keyRow (the reference's idx(i)), one or two outputs, 1..8 terms, batch"""
+    element in its own allocation; key rows through keyRow (the reference's idx(i)), one or two outputs, batch; more than 8 terms run
+    as several launches whose exact sums add up (the reference's loop over digits has no bound)"""
     o = oracle
     rng = np.random.default_rng(5150)
     vp = C.c_void_p
     for logN, rows, keyRows, nTerms, B, two in [(4, 2, 3, 1, 1, True), (11, 5, 8, 3, 2, True), (12, 4, 4, 8, 1, False),
-                                                (13, 3, 6, 2, 1, True)]:
+                                                (13, 3, 6, 2, 1, True), (6, 3, 4, 9, 2, True), (5, 2, 2, 19, 1, False)]:
         N = 1 << logN
         q, psi = params(o, logN, keyRows)
         ctx = fh.Context(backend, logN, q, psi)
@@ -191,13 +192,6 @@ def test_inner_product_over_separate_towers(backend, oracle):
         if two:
             assert np.array_equal(out1.to_host(), want1), f"inner product (a half) logN={logN}"
         ctx.close()
-    # more than 8 terms: refused, not miscomputed
-    q, psi = params(o, 4, 2)
-    ctx = fh.Context(backend, 4, q, psi)
-    t = ctx.tower(libs.rand_tower(rng, q, 16, 1))
-    p9 = (vp * 9)(*[t.ptr] * 9)
-    assert backend.L.fhe_inner_product(ctx.h, 9, p9, p9, None, None, None, 2, 1, t.like().ptr, None, None) != 0
-    ctx.close()
 
 
 def test_plus_minus_constants(backend, oracle):
@@ -425,7 +419,9 @@ def conv_tables(o, src, dst):
 def test_approx_and_exact_switch_crt_basis(backend, oracle):
     o = oracle
     rng = np.random.default_rng(15)
-    for logN, nS, nD, B in [(5, 2, 3, 2), (12, 3, 9, 1), (12, 7, 21, 1), (13, 4, 5, 2), (10, 12, 3, 1), (10, 20, 2, 1)]:
+    # (more than 32 source limbs: chunked plans, one launch per 32 — the reference's loop dcrtpoly-impl.h:895-915 has no bound)
+    for logN, nS, nD, B in [(5, 2, 3, 2), (12, 3, 9, 1), (12, 7, 21, 1), (13, 4, 5, 2), (10, 12, 3, 1), (10, 20, 2, 1), (6, 33, 3, 2), (8, 40, 5, 1),
+                            (5, 70, 2, 1)]:
         N = 1 << logN
         q, psi = params(o, logN, nS + nD)
         ctx = fh.Context(backend, logN, q, psi)
@@ -475,7 +471,11 @@ def ckks_like_params(o, logN, sizeQ, dnum, first_bits=60, scale_bits=50, aux_bit
 
 
 @pytest.mark.parametrize("logN,sizeQ,dnum,sizeQl,B", [(10, 4, 2, 4, 3), (8, 5, 2, 3, 2), (12, 6, 3, 6, 2), (12, 7, 2, 5, 1), (12, 5, 3, 2, 1), (13, 4, 2, 4, 1),
-                                                      (16, 2, 2, 2, 1), (17, 2, 2, 2, 1)])  # 12-stage row passes: BASELINE configs[2] / [3] rings
+                                                      (16, 2, 2, 2, 1), (17, 2, 2, 2, 1),  # 12-stage row passes: BASELINE configs[2] / [3] rings
+                                                      # shapes past the kernels' per-launch bounds: a digit and a P basis of more than 32
+                                                      # limbs (dnum = 1 on a 40-limb chain: chunked conversions), more than 8 digits (chunked
+                                                      # inner products)
+                                                      (10, 40, 1, 40, 1), (9, 36, 1, 34, 2), (9, 20, 10, 20, 2), (8, 24, 12, 19, 1)])
 def test_hybrid_keyswitch_and_eval_mult(backend, oracle, logN, sizeQ, dnum, sizeQl, B):
     o = oracle
     if is_emu(backend) and logN > 12 and not os.environ.get("FHE_TEST_BIG_EMU"):
@@ -707,21 +707,19 @@ def test_conversion_kernel_variants_on_emulator(backend, variant):
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
 
 
-def test_oversized_digits_are_refused_not_miscomputed(backend, oracle):
-    """the conversion kernels end at 32 source limbs: a HYBRID plan whose digit (or P basis) is larger must be refused with
-    FHE_ERR_UNSUPPORTED instead of overflowing its tables (round-1 advisor finding)"""
-    o = oracle
-    logN = 4
-    q, psi = params(o, logN, 40, bits=40)
-    ctx = fh.Context(backend, logN, q, psi)
-    h = C.c_void_p()
-    st = backend.L.fhe_ks_plan_create(ctx.h, 34, 6, 1, C.byref(h))  # alpha = 34 > 32
-    assert st == 4 and b"<= 32" in backend.L.fhe_last_error()
-    st = backend.L.fhe_ks_plan_create(ctx.h, 6, 34, 2, C.byref(h))  # sizeP = 34 > 32
-    assert st == 4
-    plan = fh.KeySwitchPlan(ctx, 34, 6, 2)  # alpha = 17: fine
-    plan.close()
-    ctx.close()
+def test_whole_tower_checksums(backend, oracle):
+    """fhe_checksum: {sum mod 2^64, xor} of every limb-row of a resident batch in one read (the all-towers parity check of bench.py
+    and of the full-shape tests)"""
+    rng = np.random.default_rng(23)
+    for logN, L, B in [(4, 3, 2), (9, 2, 3), (12, 2, 2), (13, 3, 1)]:
+        q, psi = params(oracle, logN, L)
+        ctx = fh.Context(backend, logN, q, psi)
+        x = libs.rand_tower(rng, q, 1 << logN, B)
+        t = ctx.tower(x)
+        got = ctx.checksum(t)
+        want = np.stack([x.reshape(B * L, -1).sum(axis=1, dtype=np.uint64), np.bitwise_xor.reduce(x.reshape(B * L, -1), axis=1)], axis=1)
+        assert np.array_equal(got, want)
+        ctx.close()
 
 
 @pytest.mark.parametrize("logN,L,B", [(5, 2, 2), (12, 2, 2), (13, 3, 2), (14, 2, 1), (15, 1, 2), (16, 2, 1), (17, 1, 1)])
