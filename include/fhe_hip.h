@@ -142,6 +142,15 @@ fhe_status fhe_mul_add(fhe_ctx* ctx, uint64_t* acc, const uint64_t* a, const uin
  * array may be released as soon as the call returns. */
 fhe_status fhe_mul_const(fhe_ctx* ctx, uint64_t* out, const uint64_t* a, const uint64_t* consts,
                          const uint32_t* limbIdx, uint32_t nLimbs, uint32_t batch, void* stream);
+/* DCRTPolyImpl::TimesQovert (dcrtpoly-impl.h:868-885): every word x of limb r becomes ((x * NegQModt) mod t) * tInvModq[r] mod q_r —
+ * ModMulFastConst modulo the plaintext modulus, then the generalized Barrett product modulo q_r (BFV encryption scales the message
+ * by Q/t with it).  out may alias a; tInvModq is a HOST array (by value in the kernel arguments). */
+fhe_status fhe_times_q_over_t(fhe_ctx* ctx, uint64_t* out, const uint64_t* a, uint64_t t, uint64_t negQModt,
+                              const uint64_t* tInvModq, const uint32_t* limbIdx, uint32_t nLimbs, uint32_t batch, void* stream);
+/* DCRTPolyImpl::SetValuesModSwitch (dcrtpoly-impl.h:630-647): `words` COEFFICIENT words modulo qFrom scaled to the modulus qTo,
+ * out[j] = uint64(floor(0.5 + double(x[j]) * (double(qTo) / double(qFrom)))) mod qTo, in the reference's double arithmetic. */
+fhe_status fhe_mod_switch_round(fhe_ctx* ctx, const uint64_t* x, uint64_t qFrom, uint64_t qTo, uint64_t* out, size_t words,
+                                void* stream);
 /* NativeVectorT::MultAccEqNoCheck per limb (src/core/lib/math/hal/intnat/mubintvecnat.cpp:132-142; PolyImpl wrapper
  * poly.h:323): acc[r] += v[r] * consts[r]  (constant reduced mod q first, Shoup product, ModAddFast) */
 fhe_status fhe_mult_acc(fhe_ctx* ctx, uint64_t* acc, const uint64_t* v, const uint64_t* consts,

@@ -38,6 +38,7 @@ enum ElemOp : int {
     OP_SUB_MUL_CONST_ACC = 9,  // out = out + (a - b) * c[row]   (ApproxModDown tail fused with EvalMult's `+= ks`)
     OP_ADD_CONST = 10,     // out = a + c[row]         (PolyImpl::Plus(Integer) in EVALUATION / Minus(Integer) with c = q - c)
     OP_ADD_CONST_AT0 = 11, // out = a + c[row] at coefficient 0 only (PolyImpl::Plus(Integer) in COEFFICIENT, poly-impl.h:213-214)
+    OP_TIMES_QOVERT = 12,  // out = ((a * pre) mod preMod) * c[row]   (DCRTPolyImpl::TimesQovert, dcrtpoly-impl.h:868-885)
 };
 
 struct ElemArgs {
@@ -50,6 +51,8 @@ struct ElemArgs {
     uint32_t aStride, aFirst;  // aStride != 0: operand a is a [batch][aStride][N] view, rows aFirst.. of each tower
     uint32_t bStride, bFirst;  // same for b
     uint32_t oStride, oFirst;  // same for out
+    TwPair pre = {0, 0};       // OP_TIMES_QOVERT only: the first factor (Shoup pair modulo preMod) ...
+    uint64_t preMod = 0;       // ... and its modulus (the plaintext modulus t)
     LimbSel sel;
 };
 
@@ -78,6 +81,8 @@ FHE_HD uint64_t elem_apply(uint64_t o, uint64_t a, uint64_t b, const LimbConst l
         case OP_ADD_CONST:
         case OP_ADD_CONST_AT0:
             return add_mod(a, c.w, q);
+        case OP_TIMES_QOVERT:  // (a already holds (x * NegQModt) mod t, see elemwise_body; :882 ModMulFastEq = generalized Barrett)
+            return mul_mod_barrett(a, c.w, q, lc.mu, (int)lc.msb);
         default:
             return a;
     }
@@ -97,7 +102,7 @@ FHE_DEV void elemwise_body(const ElemArgs& g, ConstAt constAt) {
     constexpr bool needB = (OP == OP_ADD || OP == OP_SUB || OP == OP_MUL || OP == OP_SUB_MUL_CONST ||
                             OP == OP_MUL_CONST_ADD || OP == OP_MULT_ACC || OP == OP_SUB_MUL_CONST_ACC);
     constexpr bool needC = (OP == OP_MUL_CONST || OP == OP_SUB_MUL_CONST || OP == OP_MUL_CONST_ADD || OP == OP_SUB_MUL_CONST_ACC ||
-                            OP == OP_ADD_CONST || OP == OP_ADD_CONST_AT0);
+                            OP == OP_ADD_CONST || OP == OP_ADD_CONST_AT0 || OP == OP_TIMES_QOVERT);
     constexpr bool needO = (OP == OP_MULT_ACC || OP == OP_SUB_MUL_CONST_ACC);
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -114,6 +119,10 @@ FHE_DEV void elemwise_body(const ElemArgs& g, ConstAt constAt) {
         const uint64_t ri   = off & (((uint64_t)1 << g.logN) - 1u);
         const uint64_t aoff = g.aStride ? ((((uint64_t)tb * g.aStride + g.aFirst + rit) << g.logN) + ri) : off;
         uint64_t a0 = g.a[aoff], a1 = g.a[aoff + 1];
+        if (OP == OP_TIMES_QOVERT) {  // :881 xi.ModMulFastConstEq(NegQModt, t, NegQModtPrecon)
+            a0 = mul_shoup(a0, g.pre.w, g.pre.wp, g.preMod);
+            a1 = mul_shoup(a1, g.pre.w, g.pre.wp, g.preMod);
+        }
         uint64_t b0 = 0, b1 = 0, o0 = 0, o1 = 0;
         if (needB) {
             const uint64_t boff = g.bStride ? ((((uint64_t)tb * g.bStride + g.bFirst + rit) << g.logN) + ri) : off;
@@ -336,6 +345,24 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) switch_modulus_kernel(const SwitchMo
         }
         g.out[off] = v;
     }
+}
+
+// ---- DCRTPolyImpl::SetValuesModSwitch (dcrtpoly-impl.h:630-647): one COEFFICIENT limb modulo qFrom scaled to a modulus qTo through
+// double precision, out[j] = uint64(floor(0.5 + double(x[j]) * (double(qTo) / double(qFrom)))) mod qTo — the reference's expression,
+// one rounding per operation (no contraction: the library is compiled with -ffp-contract=off)
+struct ModSwitchRoundArgs {
+    const uint64_t* x;
+    uint64_t* out;
+    double ratio;
+    uint64_t qTo;
+    uint64_t words;
+};
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) mod_switch_round_kernel(const ModSwitchRoundArgs g) {
+    const uint64_t i = (uint64_t)FHE_BID * kThreads + FHE_TID;
+    if (i >= g.words)
+        return;
+    const double v = __builtin_floor(0.5 + (double)g.x[i] * g.ratio);
+    g.out[i]       = (uint64_t)v % g.qTo;
 }
 
 // ---- whole-tower checksums ---------------------------------------------------------------------------------------------

@@ -1012,6 +1012,38 @@ extern "C" fhe_status fhe_sub_const(fhe_ctx* c, uint64_t* o, const uint64_t* a, 
     }
     return elem_cv_run<OP_ADD_CONST>(c, o, a, nullptr, cv, li, nl, bt, st, "fhe_sub_const");
 }
+// DCRTPolyImpl::TimesQovert (dcrtpoly-impl.h:868-885): every word x of limb i becomes ((x * NegQModt) mod t) * tInvModq[i] mod q_i
+// (ModMulFastConst modulo t, then the generalized Barrett product modulo q_i); BFV encryption's scaling of the message by Q/t
+extern "C" fhe_status fhe_times_q_over_t(fhe_ctx* c, uint64_t* o, const uint64_t* a, uint64_t t, uint64_t negQModt,
+                                         const uint64_t* tInvModq, const uint32_t* li, uint32_t nl, uint32_t bt, void* st) {
+    ARG_CHECK(c && o && a && tInvModq && t >= 2 && bt >= 1, "fhe_times_q_over_t: bad argument");
+    ConstVec cv;
+    if (fhe_status s = make_const_vec(c, tInvModq, li, nl, &cv, "fhe_times_q_over_t"))
+        return s;
+    ElemArgs g;
+    if (fhe_status s = make_sel(c, li, nl, &g.sel, "fhe_times_q_over_t"))
+        return s;
+    RT_CHECK(rt::set_device(c->device));
+    g.out = o, g.a = a, g.b = nullptr, g.lc = c->d_lc, g.consts = nullptr;
+    g.logN = c->logN, g.nLimbs = nl, g.rows = bt * nl;
+    g.aStride = g.aFirst = g.bStride = g.bFirst = g.oStride = g.oFirst = 0;
+    g.pre = TwPair{negQModt % t, host::shoup(negQModt % t, t)}, g.preMod = t;
+    FHE_LAUNCH((elemwise_cv_kernel<OP_TIMES_QOVERT>), tiles_for(c, g.rows), st, g, cv);
+    LAUNCH_CHECK();
+    return FHE_OK;
+}
+// DCRTPolyImpl::SetValuesModSwitch (dcrtpoly-impl.h:630-647) on `words` COEFFICIENT words modulo qFrom -> residues modulo qTo
+extern "C" fhe_status fhe_mod_switch_round(fhe_ctx* c, const uint64_t* x, uint64_t qFrom, uint64_t qTo, uint64_t* out, size_t words,
+                                           void* st) {
+    ARG_CHECK(c && x && out && qFrom >= 2 && qTo >= 2 && words >= 1, "fhe_mod_switch_round: bad argument");
+    RT_CHECK(rt::set_device(c->device));
+    ModSwitchRoundArgs g;
+    g.x = x, g.out = out, g.qTo = qTo, g.words = words;
+    g.ratio = static_cast<double>(qTo) / static_cast<double>(qFrom);  // :641
+    FHE_LAUNCH(mod_switch_round_kernel, (words + kThreads - 1) / kThreads, st, g);
+    LAUNCH_CHECK();
+    return FHE_OK;
+}
 // NativeVectorT::MultAccEqNoCheck per limb (mubintvecnat.cpp:132-142): acc[r] += v[r] * I[r]  (I reduced first, Shoup
 // product, ModAddFastEq)
 extern "C" fhe_status fhe_mult_acc(fhe_ctx* c, uint64_t* acc, const uint64_t* v, const uint64_t* consts,

@@ -83,6 +83,8 @@ class Lib:
         S("fhe_neg", C.c_int, [vp, vp, vp, u32p, u32, u32, vp])
         S("fhe_mul_const", C.c_int, [vp, vp, vp, u64p, u32p, u32, u32, vp])
         S("fhe_mult_acc", C.c_int, [vp, vp, vp, u64p, u32p, u32, u32, vp])
+        S("fhe_times_q_over_t", C.c_int, [vp, vp, vp, u64, u64, u64p, u32p, u32, u32, vp])
+        S("fhe_mod_switch_round", C.c_int, [vp, vp, u64, u64, vp, C.c_size_t, vp])
         S("fhe_inner_product", C.c_int, [vp, u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), u32p, u32p, u32, u32, vp, vp, vp])
         S("fhe_add_const", C.c_int, [vp, vp, vp, u64p, u32p, u32, u32, C.c_int, vp])
         S("fhe_sub_const", C.c_int, [vp, vp, vp, u64p, u32p, u32, u32, vp])

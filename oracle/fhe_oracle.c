@@ -1316,6 +1316,26 @@ void orc_scale_and_round_p_over_q(const uint64_t* x, uint32_t sizeQ, uint32_t N,
     }
 }
 
+/* DCRTPolyImpl::TimesQovert (dcrtpoly-impl.h:868-885): xi.ModMulFastConstEq(NegQModt, t, precon) then xi.ModMulFastEq(tInvModq[i], q_i, mu)
+ * on every word of limb i; x [L][N] in place */
+void orc_times_q_over_t(uint64_t* x, uint32_t L, uint32_t N, const uint64_t* q, uint64_t t, uint64_t negQModt, const uint64_t* tInvModq) {
+    const uint64_t pre = orc_prep_mod_mul_const(negQModt, t);
+    for (uint32_t i = 0; i < L; ++i) {
+        const uint64_t mu = orc_compute_mu(q[i]);
+        for (uint32_t ri = 0; ri < N; ++ri) {
+            uint64_t v = orc_mod_mul_fast_const(x[(size_t)i * N + ri], negQModt, t, pre);
+            x[(size_t)i * N + ri] = orc_mod_mul_fast(v, tInvModq[i], q[i], mu);
+        }
+    }
+}
+/* DCRTPolyImpl::SetValuesModSwitch (dcrtpoly-impl.h:630-647), the arithmetic of the one-limb case: x [N] COEFFICIENT modulo qFrom ->
+ * out [N] modulo qTo through double precision (:641-644) */
+void orc_set_values_mod_switch(const uint64_t* x, uint32_t N, uint64_t qFrom, uint64_t qTo, uint64_t* out) {
+    const double ratio = (double)qTo / (double)qFrom;
+    for (uint32_t j = 0; j < N; ++j)
+        out[j] = (uint64_t)floor(0.5 + (double)x[j] * ratio) % qTo;
+}
+
 /* DCRTPolyImpl::ScaleAndRound -> NativePoly mod t (dcrtpoly-impl.h:1190-1467; BFV HPS decryption).  The eight branches
  * differ in three switches: t a power of two (final `& (t-1)` vs the double-precision reduction :1375-1377), the
  * hi/lo split of every residue at bit qMSB/2 when qMSB + sizeQMSB >= 52 (:1247ff), and plain wrap-around products

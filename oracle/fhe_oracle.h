@@ -203,6 +203,9 @@ void orc_scale_and_round(const uint64_t* x, uint32_t sizeI, uint32_t sizeO, uint
 /* ApproxScaleAndRound (:1470-1510): x [sizeQ+sizeP][N] -> out [sizeP][N], tab [sizeP][sizeQ+1] */
 void orc_approx_scale_and_round(const uint64_t* x, uint32_t sizeQ, uint32_t sizeP, uint32_t N, const uint64_t* tab,
                                 const uint64_t* p, const uint64_t* mu128, uint64_t* out);
+/* TimesQovert (:868-885): x [L][N] in place;  SetValuesModSwitch (:630-647): one limb through double precision */
+void orc_times_q_over_t(uint64_t* x, uint32_t L, uint32_t N, const uint64_t* q, uint64_t t, uint64_t negQModt, const uint64_t* tInvModq);
+void orc_set_values_mod_switch(const uint64_t* x, uint32_t N, uint64_t qFrom, uint64_t qTo, uint64_t* out);
 /* ScaleAndRoundPOverQ (:1674-1689): x [sizeQ+1][N] (last limb modulus pLast) -> out [sizeQ][N] */
 void orc_scale_and_round_p_over_q(const uint64_t* x, uint32_t sizeQ, uint32_t N, const uint64_t* q, uint64_t pLast,
                                   const uint64_t* pInvModq, uint64_t* out);

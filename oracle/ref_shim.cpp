@@ -814,6 +814,22 @@ void ref_scale_and_round_p_over_q(uint32_t N, uint32_t sizeQ, const uint64_t* mo
     export_poly(X, out);
 }
 
+void ref_times_q_over_t(uint32_t N, uint32_t L, const uint64_t* q, const uint64_t* psi, uint64_t* x, uint64_t t, uint64_t negQModt,
+                        const uint64_t* tInvModq) {
+    auto pq = make_params(N, L, q, psi);
+    auto X  = make_poly(pq, x, Format::COEFFICIENT);
+    const NativeInteger T(t), NQ(negQModt);
+    X.TimesQovert(pq, vecNI(tInvModq, L), T, NQ, NQ.PrepModMulConst(T));
+    export_poly(X, x);
+}
+void ref_set_values_mod_switch(uint32_t N, uint64_t qFrom, uint64_t psiFrom, const uint64_t* x, uint64_t qTo, uint64_t psiTo, uint64_t* out) {
+    auto pf = make_params(N, 1, &qFrom, &psiFrom), pt = make_params(N, 1, &qTo, &psiTo);
+    auto X  = make_poly(pf, x, Format::COEFFICIENT);
+    DCRTPoly Y(pt, Format::COEFFICIENT, true);
+    Y.SetValuesModSwitch(X, NativeInteger(qTo));
+    export_poly(Y, out);
+}
+
 // ScaleAndRound -> NativePoly mod t (decryption) with caller tables; out [N]
 void ref_scale_and_round_native(uint32_t N, uint32_t sizeQ, const uint64_t* q, const uint64_t* psi, const uint64_t* x, uint64_t t,
                                 const uint64_t* tabModt, const uint64_t* tabBModt, const double* frac, const double* bfrac,

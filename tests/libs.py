@@ -104,6 +104,8 @@ def load_oracle():
     S("orc_scale_and_round", None, [P64, u32, u32, u32, C.c_int, P64, PF64, P64, P64, P64])
     S("orc_approx_scale_and_round", None, [P64, u32, u32, u32, P64, P64, P64, P64])
     S("orc_scale_and_round_p_over_q", None, [P64, u32, u32, P64, u64, P64, P64])
+    S("orc_times_q_over_t", None, [P64, u32, u32, P64, u64, u64, P64])
+    S("orc_set_values_mod_switch", None, [P64, u32, u64, u64, P64])
     S("orc_mod_reduce", None, [vp, P64, u32, u64, C.c_int, P64])
     S("orc_scale_and_round_native", None, [P64, u32, u32, P64, u64, P64, P64, PF64, PF64, P64])
     S("orc_scale_and_round_behz_decrypt", None, [P64, u32, u32, P64, u64, P64, P64, P64])
@@ -193,6 +195,8 @@ def load_ref():
     S("ref_scale_and_round", None, [u32, u32, u32, C.c_int, P64, P64, P64, P64, PF64, P64])
     S("ref_approx_scale_and_round", None, [u32, u32, u32, P64, P64, P64, P64, P64])
     S("ref_scale_and_round_p_over_q", None, [u32, u32, P64, P64, P64, P64, P64])
+    S("ref_times_q_over_t", None, [u32, u32, P64, P64, P64, u64, u64, P64])
+    S("ref_set_values_mod_switch", None, [u32, u64, u64, P64, u64, u64, P64])
     S("ref_mod_reduce", None, [u32, u32, P64, P64, P64, u64, C.c_int, P64])
     S("ref_scale_and_round_native", None, [u32, u32, P64, P64, P64, u64, P64, P64, PF64, PF64, P64])
     S("ref_scale_and_round_behz_decrypt", None, [u32, u32, P64, P64, P64, u64, u64, P64, P64, P64])

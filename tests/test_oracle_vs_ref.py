@@ -474,6 +474,33 @@ def test_scale_and_round_p_over_q_against_live_reference(oracle, ref):
     assert np.array_equal(want, got)
 
 
+def test_times_q_over_t_and_set_values_mod_switch_against_live_reference(oracle, ref):
+    """DCRTPolyImpl::TimesQovert (dcrtpoly-impl.h:868-885) and SetValuesModSwitch (:630-647) run by the reference vs the oracle"""
+    o, r = oracle, ref
+    rng = np.random.default_rng(47)
+    N, L = 64, 3
+    q, psi = np.zeros(L, np.uint64), np.zeros(L, np.uint64)
+    o.orc_dcrt_params(2 * N, L, 55, q, psi)
+    for t in (65537, 2, 786433):
+        Q = 1
+        for v in q:
+            Q *= int(v)
+        neg = (t - Q % t) % t
+        tinv = np.array([pow(t, -1, int(v)) for v in q], np.uint64)
+        x = rng.integers(0, t, (L, N), dtype=np.uint64)
+        want, got = x.copy(), x.copy()
+        r.ref_times_q_over_t(N, L, q, psi, want, t, neg, tinv)
+        o.orc_times_q_over_t(got, L, N, q, t, neg, tinv)
+        assert np.array_equal(want, got), t
+    x = rng.integers(0, int(q[0]), N, dtype=np.uint64)
+    x[:2] = (0, q[0] - np.uint64(1))
+    for qTo, psiTo in ((int(q[1]), int(psi[1])), (int(q[2]), int(psi[2]))):
+        want, got = np.zeros(N, np.uint64), np.zeros(N, np.uint64)
+        r.ref_set_values_mod_switch(N, int(q[0]), int(psi[0]), x, qTo, psiTo, want)
+        o.orc_set_values_mod_switch(x, N, int(q[0]), qTo, got)
+        assert np.array_equal(want, got)
+
+
 def test_rotations_against_live_reference(oracle, ref):
     """EvalRotate and hoisted EvalFastRotation of the reference (its own rotation keys) vs the oracle"""
     o, r = oracle, ref

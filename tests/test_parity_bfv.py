@@ -52,6 +52,39 @@ def test_scale_and_round(backend, oracle, logN, sizeI, sizeO, outputFirst, fscal
     ctx.close()
 
 
+def test_times_q_over_t_and_mod_switch_round(backend, oracle):
+    """fhe_times_q_over_t (DCRTPolyImpl::TimesQovert) and fhe_mod_switch_round (SetValuesModSwitch) vs the oracle"""
+    import ctypes as C
+    o = oracle
+    rng = np.random.default_rng(48)
+    for logN, L, B, t in [(4, 2, 2, 65537), (11, 3, 1, 2), (12, 4, 2, 786433), (13, 2, 1, 65537)]:
+        N = 1 << logN
+        q, psi = np.zeros(L, np.uint64), np.zeros(L, np.uint64)
+        o.orc_dcrt_params(2 * N, L, 58, q, psi)
+        ctx = fh.Context(backend, logN, q, psi)
+        Q = 1
+        for v in q:
+            Q *= int(v)
+        neg = (t - Q % t) % t
+        tinv = np.array([pow(t, -1, int(v)) for v in q], np.uint64)
+        x = rng.integers(0, t, (B, L, N), dtype=np.uint64)
+        want = x.copy()
+        for b in range(B):
+            o.orc_times_q_over_t(want[b], L, N, q, t, neg, tinv)
+        tw = ctx.tower(x, fmt=fh.COEFFICIENT)
+        backend.check(backend.L.fhe_times_q_over_t(ctx.h, tw.ptr, tw.ptr, t, neg, tinv.ctypes.data_as(C.POINTER(C.c_uint64)), None, L, B, None))
+        assert np.array_equal(tw.to_host(), want)
+        y = rng.integers(0, int(q[0]), (1, 1, N), dtype=np.uint64)
+        y[0, 0, :2] = (0, q[0] - np.uint64(1))
+        wy = np.zeros(N, np.uint64)
+        o.orc_set_values_mod_switch(y[0, 0], N, int(q[0]), int(q[L - 1]), wy)
+        ty = ctx.tower(y, limb_idx=[0], fmt=fh.COEFFICIENT)
+        out = ctx.empty(1, 1, [L - 1], fh.COEFFICIENT)
+        backend.check(backend.L.fhe_mod_switch_round(ctx.h, ty.ptr, int(q[0]), int(q[L - 1]), out.ptr, N, None))
+        assert np.array_equal(out.to_host()[0, 0], wy)
+        ctx.close()
+
+
 def test_scale_and_round_p_over_q(backend, oracle):
     o = oracle
     rng = np.random.default_rng(22)
