@@ -262,6 +262,10 @@ size_t     fhe_ks_workspace_bytes(const fhe_ks_plan* plan, uint32_t sizeQl, uint
 fhe_status fhe_keyswitch_hybrid(fhe_ks_plan* plan, const fhe_ks_key* key, const uint64_t* c, uint32_t sizeQl,
                                 uint32_t batch, uint64_t* out0, uint64_t* out1, void* ws, size_t wsBytes,
                                 void* stream);
+/* acc0 += ks0(c), acc1 += ks1(c): the tail of LeveledSHEBase::EvalMult(ct, ct, key) (base-leveledshe.cpp:207-211), the two
+ * additions fused into the last kernel of the key switch.  Same layout and workspace as fhe_keyswitch_hybrid. */
+fhe_status fhe_keyswitch_hybrid_acc(fhe_ks_plan* plan, const fhe_ks_key* key, const uint64_t* c, uint32_t sizeQl,
+                                    uint32_t batch, uint64_t* acc0, uint64_t* acc1, void* ws, size_t wsBytes, void* stream);
 /* cc->EvalMult(ct1, ct2) for 2-element ciphertexts: EvalMultCore + KeySwitchCore + add
  * (src/pke/lib/schemebase/base-leveledshe.cpp:201-214, 607-644).  All towers [batch][sizeQl][N] EVALUATION.
  * c0/c1 may alias a0/a1. */

@@ -1860,6 +1860,19 @@ extern "C" fhe_status fhe_keyswitch_hybrid(fhe_ks_plan* p, const fhe_ks_key* key
     return keyswitch_run(p, key, cin, sizeQl, batch, out0, out1, (uint64_t*)ws, w, st);
 }
 
+// the same with `acc0 += ks0(c); acc1 += ks1(c)`: the tail of LeveledSHEBase::EvalMult(ct, ct, key) (base-leveledshe.cpp:207-211:
+// KeySwitchCore on the third element, `cv[0] += ab[0]; cv[1] += ab[1]`), the additions fused into the ModDown epilogue
+extern "C" fhe_status fhe_keyswitch_hybrid_acc(fhe_ks_plan* p, const fhe_ks_key* key, const uint64_t* cin, uint32_t sizeQl,
+                                               uint32_t batch, uint64_t* acc0, uint64_t* acc1, void* ws, size_t wsBytes, void* st) {
+    ARG_CHECK(p && key && cin && acc0 && acc1 && ws, "fhe_keyswitch_hybrid_acc: null argument");
+    ARG_CHECK(key->plan == p, "fhe_keyswitch_hybrid_acc: key belongs to another plan");
+    ARG_CHECK(sizeQl >= 1 && sizeQl <= p->sizeQ && batch >= 1, "fhe_keyswitch_hybrid_acc: bad level or batch");
+    const KsLayout w = ks_layout(p, sizeQl, batch);
+    ARG_CHECK(wsBytes >= w.total * 8, "fhe_keyswitch_hybrid_acc: workspace too small");
+    RT_CHECK(rt::set_device(p->ctx->device));
+    return keyswitch_run(p, key, cin, sizeQl, batch, acc0, acc1, (uint64_t*)ws, w, st, true);
+}
+
 extern "C" fhe_status fhe_ckks_eval_mult(fhe_ks_plan* p, const fhe_ks_key* key, const uint64_t* a0, const uint64_t* a1,
                                          const uint64_t* b0, const uint64_t* b1, uint32_t sizeQl, uint32_t batch,
                                          uint64_t* c0, uint64_t* c1, void* wsv, size_t wsBytes, void* st) {

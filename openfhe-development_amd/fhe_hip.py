@@ -115,6 +115,7 @@ class Lib:
         S("fhe_ks_key_words", C.c_size_t, [vp])
         S("fhe_ks_workspace_bytes", C.c_size_t, [vp, u32, u32])
         S("fhe_keyswitch_hybrid", C.c_int, [vp, vp, vp, u32, u32, vp, vp, vp, C.c_size_t, vp])
+        S("fhe_keyswitch_hybrid_acc", C.c_int, [vp, vp, vp, u32, u32, vp, vp, vp, C.c_size_t, vp])
         S("fhe_ckks_eval_mult", C.c_int, [vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp, C.c_size_t, vp])
         S("fhe_ks_precompute", C.c_int, [vp, vp, u32, u32, vp, C.c_size_t, vp])
         S("fhe_ks_fast_keyswitch", C.c_int, [vp, vp, vp, u32, u32, vp, vp, vp, C.c_size_t, vp])
@@ -516,6 +517,11 @@ class KeySwitchPlan:
         self.ctx.lib.check(self.ctx.lib.L.fhe_keyswitch_hybrid(self.h, self.key, c.ptr, c.n_limbs, c.batch, o0.ptr,
                                                                o1.ptr, ws, wsb, stream))
         return o0, o1
+
+    def KeySwitchCoreAcc(self, c, acc0, acc1, stream=None):  # base-leveledshe.cpp:207-211: acc += KeySwitchCore(c), in place
+        ws, wsb = self.workspace(c.n_limbs, c.batch)
+        self.ctx.lib.check(self.ctx.lib.L.fhe_keyswitch_hybrid_acc(self.h, self.key, c.ptr, c.n_limbs, c.batch, acc0.ptr, acc1.ptr, ws, wsb,
+                                                                   stream))
 
     def EvalMult(self, a0, a1, b0, b1, stream=None):  # base-leveledshe.cpp:201-214
         ws, wsb = self.workspace(a0.n_limbs, a0.batch)

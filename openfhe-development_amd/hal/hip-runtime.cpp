@@ -5,23 +5,26 @@
 // (libfhe_hip.so of this repo).  If it cannot be loaded or no device is visible the first DCRTPoly operation FAILS LOUDLY (message
 // on stderr + exception): the backend has no silent CPU path.  FHE_HAL_ALLOW_HOST=1 opts into running every member on the host
 // mirror instead (the class then behaves exactly like the default backend) — for machines without a GPU, never for measurements.
+// FHE_HAL_REQUIRE_DEVICE=1 is the opposite switch: a member that HAS a device path and nevertheless executes on the host mirror
+// (a modulus outside the library's domain, a failed table build ...) throws instead of degrading silently.
 #include "lattice/hal/hip/hip-runtime.h"
 
 #include <cxxabi.h>
 #include <dlfcn.h>
 #include <execinfo.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
-#include <vector>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <vector>
 
 #include "utils/exception.h"
 
@@ -29,14 +32,28 @@ namespace lbcrypto {
 namespace hiprt {
 
 namespace {
+// ---- streams: one per host thread ----
+constexpr uint32_t kMaxStreams = 1024;
+struct StreamState {
+    void* s = nullptr;
+    bool made = false;
+    std::atomic<uint64_t> issued{0};    // operations started by the owning thread
+    std::atomic<uint64_t> enqueued{0};  // ... whose launches have all been enqueued (published by the outermost Op)
+};
 struct Runtime {
     Api api{};
     bool live = false;
     std::string why;
-    // allocator
+    int device       = 0;
+    fhe_ctx* anyCtx  = nullptr;  // a minimal context of the device (allocation, copies and stream calls want a handle)
+    // streams
+    StreamState streams[kMaxStreams];
+    std::mutex streamMutex;
+    std::vector<uint32_t> freeStreamIds;
+    uint32_t nextStreamId = 1;  // 0 = "no stream": host-complete
+    // allocator: buffers nobody's stream has pending work on (handed over by exiting threads)
     std::mutex poolMutex;
-    std::map<size_t, std::vector<uint64_t*>> freeLists;  // bucket (words) -> free buffers
-    fhe_ctx* anyCtx = nullptr;                           // fhe_malloc wants a context handle (device selection only)
+    std::map<size_t, std::vector<uint64_t*>> orphanLists;  // bucket (words) -> free buffers
     // contexts
     struct Universe {
         uint32_t logN = 0;
@@ -46,12 +63,13 @@ struct Runtime {
     };
     std::mutex ctxMutex;
     std::map<uint32_t, Universe> universes;  // by ring dimension
-    // conversion plans
+    // plans
     std::mutex convMutex;
     std::map<std::vector<uint64_t>, fhe_conv*> convs;  // key = {ctx, nSrc, nDst, idx..., table words...}
     std::map<std::vector<uint64_t>, fhe_sr_plan*> srPlans;
-    std::map<std::vector<uint64_t>, fhe_behz*> behzPlans;  // key = {ctx, numQ, qIdx..., bskIdx..., t}
+    std::map<std::vector<uint64_t>, fhe_behz*> behzPlans;  // key = {ctx, which, t, numQ, qIdx..., bskIdx..., table words...}
     std::atomic<uint64_t> deviceOps{0}, hostFallbacks{0}, h2dBytes{0}, d2hBytes{0};
+    bool requireDevice = false;
 };
 
 template <typename F>
@@ -59,6 +77,7 @@ bool sym(void* h, const char* name, F* out) {
     *out = reinterpret_cast<F>(dlsym(h, name));
     return *out != nullptr;
 }
+std::atomic<int> g_deviceOverride{-1};
 
 Runtime* build() {
     auto* r         = new Runtime;
@@ -68,32 +87,62 @@ Runtime* build() {
 #else
     const std::string path = env ? env : "libfhe_hip.so";
 #endif
+    r->requireDevice = std::getenv("FHE_HAL_REQUIRE_DEVICE") != nullptr && std::string(std::getenv("FHE_HAL_REQUIRE_DEVICE")) != "0";
+    r->device        = g_deviceOverride.load() >= 0 ? g_deviceOverride.load() : (std::getenv("FHE_HIP_DEVICE") ? std::atoi(std::getenv("FHE_HIP_DEVICE")) : 0);
     void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (!h) {
         r->why = std::string("cannot load ") + path + ": " + dlerror();
     }
     else {
-        Api& a  = r->api;
-        bool ok = sym(h, "fhe_last_error", &a.last_error) && sym(h, "fhe_device_count", &a.device_count) &&
-                  sym(h, "fhe_ctx_create", &a.ctx_create) && sym(h, "fhe_malloc", &a.malloc_) && sym(h, "fhe_free", &a.free_) &&
-                  sym(h, "fhe_memcpy_h2d", &a.h2d) && sym(h, "fhe_memcpy_d2h", &a.d2h) && sym(h, "fhe_memcpy_d2d", &a.d2d) &&
-                  sym(h, "fhe_stream_sync", &a.sync) && sym(h, "fhe_ntt_fwd", &a.ntt_fwd) && sym(h, "fhe_ntt_inv", &a.ntt_inv) &&
-                  sym(h, "fhe_ntt_inv_oop", &a.ntt_inv_oop) && sym(h, "fhe_ntt_fwd_oop", &a.ntt_fwd_oop) &&
-                  sym(h, "fhe_inner_product", &a.inner_product) && sym(h, "fhe_add", &a.add) && sym(h, "fhe_sub", &a.sub) &&
-                  sym(h, "fhe_mul", &a.mul) && sym(h, "fhe_neg", &a.neg) && sym(h, "fhe_mul_add", &a.mul_add) && sym(h, "fhe_mul_const", &a.mul_const) &&
-                  sym(h, "fhe_mult_acc", &a.mult_acc) && sym(h, "fhe_add_const", &a.add_const) && sym(h, "fhe_sub_const", &a.sub_const) && sym(h, "fhe_automorph", &a.automorph) &&
-                  sym(h, "fhe_switch_modulus", &a.switch_modulus) && sym(h, "fhe_conv_create_custom", &a.conv_create_custom) &&
-                  sym(h, "fhe_approx_switch_basis", &a.approx_switch_basis) &&
-                  sym(h, "fhe_switch_basis_exact", &a.switch_basis_exact) && sym(h, "fhe_sr_plan_create", &a.sr_plan_create) &&
-                  sym(h, "fhe_scale_and_round", &a.scale_and_round) && sym(h, "fhe_behz_create", &a.behz_create) &&
-                  sym(h, "fhe_behz_workspace_bytes", &a.behz_workspace_bytes) && sym(h, "fhe_behz_q_to_bsk", &a.behz_q_to_bsk) &&
-                  sym(h, "fhe_behz_floorq", &a.behz_floorq) && sym(h, "fhe_behz_conv_sk", &a.behz_conv_sk);
+        Api& a = r->api;
+#define FHE_SYM(field, name) sym(h, #name, &a.field)
+        bool ok = FHE_SYM(last_error, fhe_last_error) && FHE_SYM(device_count, fhe_device_count) && FHE_SYM(ctx_create, fhe_ctx_create) &&
+                  FHE_SYM(malloc_, fhe_malloc) && FHE_SYM(free_, fhe_free) && FHE_SYM(h2d, fhe_memcpy_h2d) && FHE_SYM(d2h, fhe_memcpy_d2h) &&
+                  FHE_SYM(d2d, fhe_memcpy_d2d) && FHE_SYM(memset_zero, fhe_memset_zero) && FHE_SYM(sync, fhe_stream_sync) &&
+                  FHE_SYM(stream_create, fhe_stream_create) && FHE_SYM(stream_wait, fhe_stream_wait) && FHE_SYM(ntt_fwd, fhe_ntt_fwd) &&
+                  FHE_SYM(ntt_inv, fhe_ntt_inv) && FHE_SYM(ntt_inv_oop, fhe_ntt_inv_oop) && FHE_SYM(ntt_fwd_oop, fhe_ntt_fwd_oop) &&
+                  FHE_SYM(inner_product, fhe_inner_product) && FHE_SYM(add, fhe_add) && FHE_SYM(sub, fhe_sub) && FHE_SYM(mul, fhe_mul) &&
+                  FHE_SYM(neg, fhe_neg) && FHE_SYM(mul_add, fhe_mul_add) && FHE_SYM(mul_const, fhe_mul_const) && FHE_SYM(mult_acc, fhe_mult_acc) &&
+                  FHE_SYM(add_const, fhe_add_const) && FHE_SYM(sub_const, fhe_sub_const) && FHE_SYM(times_q_over_t, fhe_times_q_over_t) &&
+                  FHE_SYM(mod_switch_round, fhe_mod_switch_round) && FHE_SYM(automorph, fhe_automorph) &&
+                  FHE_SYM(switch_modulus, fhe_switch_modulus) && FHE_SYM(conv_create_custom, fhe_conv_create_custom) &&
+                  FHE_SYM(approx_switch_basis, fhe_approx_switch_basis) && FHE_SYM(switch_basis_exact, fhe_switch_basis_exact) &&
+                  FHE_SYM(sr_plan_create, fhe_sr_plan_create) && FHE_SYM(scale_and_round, fhe_scale_and_round) &&
+                  FHE_SYM(scale_and_round_p_over_q, fhe_scale_and_round_p_over_q) && FHE_SYM(scale_and_round_native, fhe_scale_and_round_native) &&
+                  FHE_SYM(scale_and_round_behz_decrypt, fhe_scale_and_round_behz_decrypt) && FHE_SYM(behz_create, fhe_behz_create) &&
+                  FHE_SYM(behz_override_q_to_bsk, fhe_behz_override_q_to_bsk) && FHE_SYM(behz_override_floorq, fhe_behz_override_floorq) &&
+                  FHE_SYM(behz_override_conv_sk, fhe_behz_override_conv_sk) && FHE_SYM(behz_workspace_bytes, fhe_behz_workspace_bytes) &&
+                  FHE_SYM(behz_q_to_bsk, fhe_behz_q_to_bsk) && FHE_SYM(behz_floorq, fhe_behz_floorq) && FHE_SYM(behz_conv_sk, fhe_behz_conv_sk) &&
+                  FHE_SYM(tensor, fhe_tensor) && FHE_SYM(tensor_square, fhe_tensor_square) && FHE_SYM(ks_plan_create, fhe_ks_plan_create) &&
+                  FHE_SYM(ks_key_wrap, fhe_ks_key_wrap) && FHE_SYM(ks_key_destroy, fhe_ks_key_destroy) &&
+                  FHE_SYM(ks_workspace_bytes, fhe_ks_workspace_bytes) && FHE_SYM(keyswitch_hybrid, fhe_keyswitch_hybrid) &&
+                  FHE_SYM(ckks_eval_mult, fhe_ckks_eval_mult) && FHE_SYM(bsgs_workspace_bytes, fhe_ckks_bsgs_workspace_bytes) &&
+                  FHE_SYM(bsgs_transform, fhe_ckks_bsgs_transform) && FHE_SYM(checksum, fhe_checksum);
+#undef FHE_SYM
         if (!ok)
             r->why = path + " does not export the C ABI of include/fhe_hip.h";
         else if (a.device_count() < 1)
             r->why = path + ": no HIP device visible";
-        else
-            r->live = true;
+        else if (r->device < 0 || r->device >= a.device_count())
+            r->why = path + ": device " + std::to_string(r->device) + " requested (FHE_HIP_DEVICE / fhe_hal_set_device), " +
+                     std::to_string(a.device_count()) + " visible";
+        else {
+            // the smallest context the library builds (N = 16, q = 97 = 1 mod 32, psi = a primitive 32nd root of unity mod 97): its
+            // only purpose is to name the device in calls that take a context for that (allocation, copies, streams)
+            const uint64_t q = 97;
+            uint64_t psi     = 0;
+            for (uint64_t g = 2; g < q && !psi; ++g) {
+                uint64_t p16 = 1;
+                for (int i = 0; i < 16; ++i)
+                    p16 = p16 * g % q;
+                if (p16 == q - 1)  // g^16 = -1: order exactly 32
+                    psi = g;
+            }
+            if (a.ctx_create(4, 1, &q, &psi, r->device, &r->anyCtx) != FHE_OK)
+                r->why = path + ": " + a.last_error();
+            else
+                r->live = true;
+        }
     }
     if (!r->live && !std::getenv("FHE_HAL_ALLOW_HOST")) {
         std::fprintf(stderr, "HIP backend of DCRTPoly: %s (set FHE_HAL_ALLOW_HOST=1 to run on the host mirror instead)\n", r->why.c_str());
@@ -111,20 +160,282 @@ uint32_t log2u(uint32_t n) {
         ++l;
     return l;
 }
+
+// ---- per-thread state: the thread's stream, what it has already waited for, its free lists ----
+size_t bucket_of(size_t words) {
+    size_t b = 1024;
+    while (b < words)
+        b <<= 1;
+    if (b > (1u << 20) && words <= b - (b >> 2))  // above 8 MiB: 3/4 steps, so that odd tower heights do not waste 2x
+        b -= b >> 2;
+    return b;
+}
+struct ThreadState {
+    uint32_t id   = 0;
+    uint32_t depth = 0;                 // nesting of Op objects on this thread
+    uint64_t outerSeq = 0;
+    std::vector<uint64_t> waited;       // per stream id: everything enqueued there up to this seq precedes this thread's later work
+    std::map<size_t, std::vector<uint64_t*>> freeLists;
+    ThreadState() {
+        Runtime& r = rt();
+        std::lock_guard<std::mutex> lk(r.streamMutex);
+        if (!r.freeStreamIds.empty()) {
+            id = r.freeStreamIds.back();
+            r.freeStreamIds.pop_back();
+        }
+        else {
+            if (r.nextStreamId >= kMaxStreams)
+                OPENFHE_THROW("HIP backend: more than 1023 host threads with device work alive at once");
+            id = r.nextStreamId++;
+        }
+        StreamState& st = r.streams[id];
+        if (!st.made) {
+            Check(r.api.stream_create(r.anyCtx, &st.s), "HIP backend: stream for a host thread");
+            st.made = true;
+        }
+        waited.assign(kMaxStreams, 0);
+    }
+    ~ThreadState() {
+        // the thread ends: drain its stream, hand its cached buffers to the shared lists (nothing is pending on them any more)
+        // and let a later thread reuse the stream (the sequence counters keep counting: old stamps stay "enqueued")
+        Runtime& r = rt();
+        r.api.sync(r.anyCtx, r.streams[id].s);
+        {
+            std::lock_guard<std::mutex> lk(r.poolMutex);
+            for (auto& kv : freeLists)
+                for (uint64_t* p : kv.second)
+                    r.orphanLists[kv.first].push_back(p);
+        }
+        std::lock_guard<std::mutex> lk(r.streamMutex);
+        r.freeStreamIds.push_back(id);
+    }
+};
+thread_local bool t_dead = false;
+struct ThreadHolder {
+    ThreadState* ts = nullptr;
+    ~ThreadHolder() {
+        delete ts;
+        ts     = nullptr;
+        t_dead = true;
+    }
+};
+thread_local ThreadHolder t_holder;
+ThreadState* thread_state() {  // nullptr once the thread's state has been destroyed (static destruction at exit)
+    if (t_dead)
+        return nullptr;
+    if (!t_holder.ts)
+        t_holder.ts = new ThreadState;
+    return t_holder.ts;
+}
+// the calling thread's later work must come after use `u` of a buffer
+void order_after(ThreadState* ts, const DevBuf::Use& u) {
+    Runtime& r = rt();
+    if (u.stream == 0 || u.stream == ts->id || u.seq <= ts->waited[u.stream])
+        return;
+    StreamState& other = r.streams[u.stream];
+    uint64_t mark      = other.enqueued.load(std::memory_order_acquire);
+    for (int spin = 0; mark < u.seq; ++spin) {  // (the other thread is still inside the operation that made this use: it is about to finish)
+        if (spin > 1000000) {
+            r.api.sync(r.anyCtx, other.s);
+            break;
+        }
+        sched_yield();
+        mark = other.enqueued.load(std::memory_order_acquire);
+    }
+    Check(r.api.stream_wait(r.anyCtx, r.streams[ts->id].s, other.s), "HIP backend: ordering two host threads' streams");
+    ts->waited[u.stream] = std::max(mark, u.seq);
+}
+DevBuf* root_of(DevBuf* b) {
+    while (b->parent)
+        b = b->parent.get();
+    return b;
+}
 }  // namespace
 
 bool Available() { return rt().live; }
 const Api& api() { return rt().api; }
+int Device() { return rt().device; }
+fhe_ctx* AnyCtx() { return rt().anyCtx; }
 void Check(fhe_status s, const char* what) {
     if (s != FHE_OK)
         OPENFHE_THROW(std::string(what) + ": " + rt().api.last_error());
 }
-void CountDevice() { rt().deviceOps.fetch_add(1, std::memory_order_relaxed); }
+
+// ---- operations and buffers ----
+Op::Op() {
+    ThreadState* ts = thread_state();
+    if (!ts)
+        OPENFHE_THROW("HIP backend: device operation on a thread that is shutting down");
+    Runtime& r = rt();
+    s          = r.streams[ts->id].s;
+    m_seq      = r.streams[ts->id].issued.fetch_add(1, std::memory_order_relaxed) + 1;
+    if (ts->depth++ == 0)
+        ts->outerSeq = m_seq;
+}
+Op::~Op() {
+    ThreadState* ts = thread_state();
+    if (ts && --ts->depth == 0) {
+        StreamState& st = rt().streams[ts->id];
+        st.enqueued.store(st.issued.load(std::memory_order_relaxed), std::memory_order_release);
+    }
+}
+const uint64_t* Op::R(const Buf& b) {
+    ThreadState* ts = thread_state();
+    DevBuf* root    = root_of(b.get());
+    std::lock_guard<std::mutex> lk(root->mu);
+    order_after(ts, root->writer);
+    for (auto& u : root->readers)
+        if (u.stream == ts->id) {
+            u.seq = m_seq;
+            return b->p;
+        }
+    root->readers.push_back(DevBuf::Use{ts->id, m_seq});
+    return b->p;
+}
+uint64_t* Op::W(const Buf& b) {
+    ThreadState* ts = thread_state();
+    DevBuf* root    = root_of(b.get());
+    std::lock_guard<std::mutex> lk(root->mu);
+    order_after(ts, root->writer);
+    for (const auto& u : root->readers)
+        order_after(ts, u);
+    root->readers.clear();
+    root->writer = DevBuf::Use{ts->id, m_seq};
+    return b->p;
+}
+void Op::HostSync() {
+    Runtime& r = rt();
+    Check(r.api.sync(r.anyCtx, s), "HIP backend: stream synchronisation");
+}
+
+DevBuf::~DevBuf() {
+    if (!p || parent)
+        return;
+    Runtime& r      = rt();
+    ThreadState* ts = thread_state();
+    if (!ts) {  // static destruction at process exit: wait for the pending uses on the host, park the buffer
+        if (writer.stream)
+            r.api.sync(r.anyCtx, r.streams[writer.stream].s);
+        for (const auto& u : readers)
+            r.api.sync(r.anyCtx, r.streams[u.stream].s);
+        std::lock_guard<std::mutex> lk(r.poolMutex);
+        r.orphanLists[bucket_of(words)].push_back(p);
+        return;
+    }
+    // the buffer joins THIS thread's free lists: whatever this thread launches later is ordered behind the buffer's pending uses
+    order_after(ts, writer);
+    for (const auto& u : readers)
+        order_after(ts, u);
+    ts->freeLists[bucket_of(words)].push_back(p);
+}
+Buf Alloc(size_t words) {
+    Runtime& r      = rt();
+    ThreadState* ts = thread_state();
+    const size_t bk = bucket_of(words);
+    auto b          = std::make_shared<DevBuf>();
+    b->words        = words;
+    if (ts) {
+        auto& fl = ts->freeLists[bk];
+        if (!fl.empty()) {
+            b->p = fl.back();
+            fl.pop_back();
+            return b;
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lk(r.poolMutex);
+        auto& fl = r.orphanLists[bk];
+        if (!fl.empty()) {
+            b->p = fl.back();
+            fl.pop_back();
+            return b;
+        }
+    }
+    void* d      = nullptr;
+    fhe_status s = r.api.malloc_(r.anyCtx, bk * 8, &d);
+    if (s != FHE_OK) {  // memory pressure: give this thread's and the shared cached buffers back to the device and retry once
+        if (ts) {
+            r.api.sync(r.anyCtx, r.streams[ts->id].s);
+            for (auto& kv : ts->freeLists) {
+                for (uint64_t* q : kv.second)
+                    r.api.free_(r.anyCtx, q);
+                kv.second.clear();
+            }
+        }
+        std::lock_guard<std::mutex> lk(r.poolMutex);
+        for (auto& kv : r.orphanLists) {
+            for (uint64_t* q : kv.second)
+                r.api.free_(r.anyCtx, q);
+            kv.second.clear();
+        }
+        s = r.api.malloc_(r.anyCtx, bk * 8, &d);
+    }
+    Check(s, "HIP backend: device allocation");
+    b->p = static_cast<uint64_t*>(d);
+    return b;
+}
+Buf View(const Buf& parent, size_t offsetWords, size_t words) {
+    auto b    = std::make_shared<DevBuf>();
+    b->p      = parent->p + offsetWords;
+    b->words  = words;
+    b->parent = parent;
+    return b;
+}
+
+// ---- counters ----
+namespace {
+struct MemberCounters {
+    std::atomic<const char*> name{nullptr};
+    std::atomic<uint64_t> device{0}, host{0}, reads{0};
+};
+constexpr size_t kMemberSlots = 1024;
+MemberCounters g_members[kMemberSlots];
+MemberCounters& member_slot(const char* name) {  // keyed by the literal's address (merged by content when reported)
+    size_t h = (reinterpret_cast<uintptr_t>(name) >> 3) * 0x9E3779B97F4A7C15ull >> 54;
+    for (size_t probe = 0; probe < kMemberSlots; ++probe, h = (h + 1) % kMemberSlots) {
+        const char* cur = g_members[h].name.load(std::memory_order_acquire);
+        if (cur == name)
+            return g_members[h];
+        if (!cur) {
+            const char* expected = nullptr;
+            if (g_members[h].name.compare_exchange_strong(expected, name) || expected == name)
+                return g_members[h];
+        }
+    }
+    return g_members[0];
+}
+thread_local const char* t_scope  = nullptr;
+thread_local const char* t_member = nullptr;
+// members of the backend class that have a device path: with FHE_HAL_REQUIRE_DEVICE they may not run on the host mirror
+const char* const kDeviceMembers[] = {"SwitchFormat", "operator+=", "operator-=", "operator*=", "Plus", "Minus", "Times", "TimesNoCheck", "Negate",
+                                      "operator-", "AutomorphismTransform", "ApproxSwitchCRTBasis", "ApproxModUp", "ApproxModDown", "SwitchCRTBasis",
+                                      "ExpandCRTBasis", "ExpandCRTBasisReverseOrder", "FastExpandCRTBasisPloverQ", "ExpandCRTBasisQlHat",
+                                      "ScaleAndRound", "ApproxScaleAndRound", "ScaleAndRoundPOverQ", "FastBaseConvqToBskMontgomery", "FastRNSFloorq",
+                                      "FastBaseConvSK", "DropLastElementAndScale", "ModReduce", "CloneTowers", "TimesQovert", "AssembleRows",
+                                      "InnerProduct", "MultAccRows", "DropLastElement", "DropLastElements", "SetValuesToZero"};
+bool has_device_path(const char* member) {
+    for (const char* m : kDeviceMembers)
+        if (std::strcmp(m, member) == 0)
+            return true;
+    return false;
+}
+}  // namespace
+MemberScope::MemberScope(const char* member) : outer(t_scope == nullptr) {
+    if (outer)
+        t_scope = member;
+}
+MemberScope::~MemberScope() {
+    if (outer)
+        t_scope = nullptr;
+}
+void CountDevice(const char* member) {
+    rt().deviceOps.fetch_add(1, std::memory_order_relaxed);
+    member_slot(t_scope ? t_scope : member).device.fetch_add(1, std::memory_order_relaxed);
+}
 static std::mutex g_traceMutex;
 static std::map<std::string, uint64_t>* g_traceSites = nullptr;
 // FHE_HAL_TRACE=1: which callers send work to the host mirror or move words over PCIe (a tuning aid: call sites by
 // frequency / by bytes at exit)
-static thread_local const char* t_member = nullptr;
 void TraceMember(const char* member) { t_member = member; }
 static void trace_site(const char* kind, const char* member, uint64_t amount) {
     static const bool trace = std::getenv("FHE_HAL_TRACE") != nullptr;
@@ -132,12 +443,12 @@ static void trace_site(const char* kind, const char* member, uint64_t amount) {
         return;
     void* bt[8];
     const int n     = backtrace(bt, 8);
-    std::string key = std::string(kind) + " " + (member ? member : (t_member ? t_member : "")) + " <- ";
+    std::string key = std::string(kind) + " " + (member ? member : (t_scope ? t_scope : (t_member ? t_member : ""))) + " <- ";
     for (int i = 3; i < n; ++i) {
         Dl_info info;
         if (dladdr(bt[i], &info) && info.dli_sname) {
-            int st      = 0;
-            char* dm    = abi::__cxa_demangle(info.dli_sname, nullptr, nullptr, &st);
+            int st         = 0;
+            char* dm       = abi::__cxa_demangle(info.dli_sname, nullptr, nullptr, &st);
             std::string nm = dm ? dm : info.dli_sname;
             free(dm);
             key += nm.substr(0, nm.find('(')).substr(0, 60) + " <- ";
@@ -158,11 +469,21 @@ static void trace_site(const char* kind, const char* member, uint64_t amount) {
     (*g_traceSites)[key] += amount;
 }
 void CountHost(const char* member) {
-    rt().hostFallbacks.fetch_add(1, std::memory_order_relaxed);
-    trace_site("hostop", member, 1);
+    Runtime& r       = rt();
+    const char* name = t_scope ? t_scope : member;
+    r.hostFallbacks.fetch_add(1, std::memory_order_relaxed);
+    member_slot(name).host.fetch_add(1, std::memory_order_relaxed);
+    trace_site("hostop", name, 1);
+    if (r.requireDevice && r.live && has_device_path(name))
+        OPENFHE_THROW(std::string("HIP backend: DCRTPoly::") + name + " ran on the host mirror although FHE_HAL_REQUIRE_DEVICE is set");
 }
-void D2D(fhe_ctx* c, uint64_t* dst, const uint64_t* src, size_t bytes, const char* what) {
-    Check(rt().api.d2d(c, dst, src, bytes, nullptr), what);
+void CountHostRead(const char* member) {
+    const char* name = t_scope ? t_scope : member;
+    member_slot(name).reads.fetch_add(1, std::memory_order_relaxed);
+    trace_site("hostread", name, 1);
+}
+void D2D(Op& op, uint64_t* dst, const uint64_t* src, size_t bytes, const char* what) {
+    Check(rt().api.d2d(rt().anyCtx, dst, src, bytes, op.s), what);
     trace_site("d2dBytes", what, bytes);
 }
 void CountH2D(size_t b) {
@@ -172,52 +493,6 @@ void CountH2D(size_t b) {
 void CountD2H(size_t b) {
     rt().d2hBytes.fetch_add(b, std::memory_order_relaxed);
     trace_site("d2hBytes", nullptr, b);
-}
-
-// ---- allocator ----
-static size_t bucket_of(size_t words) {
-    size_t b = 1024;
-    while (b < words)
-        b <<= 1;
-    if (b > (1u << 20) && words <= b - (b >> 2))  // above 8 MiB: 3/4 steps, so that odd tower heights do not waste 2x
-        b -= b >> 2;
-    return b;
-}
-DevBuf::~DevBuf() {
-    if (!p)
-        return;
-    Runtime& r = rt();
-    std::lock_guard<std::mutex> lk(r.poolMutex);
-    r.freeLists[bucket_of(words)].push_back(p);
-}
-Buf Alloc(size_t words) {
-    Runtime& r      = rt();
-    const size_t bk = bucket_of(words);
-    auto b          = std::make_shared<DevBuf>();
-    b->words        = words;
-    {
-        std::lock_guard<std::mutex> lk(r.poolMutex);
-        auto& fl = r.freeLists[bk];
-        if (!fl.empty()) {
-            b->p = fl.back();
-            fl.pop_back();
-            return b;
-        }
-    }
-    void* d = nullptr;
-    fhe_status s = r.api.malloc_(r.anyCtx, bk * 8, &d);
-    if (s != FHE_OK) {  // memory pressure: give the cached buffers back to the device and retry once
-        std::lock_guard<std::mutex> lk(r.poolMutex);
-        for (auto& kv : r.freeLists) {
-            for (uint64_t* q : kv.second)
-                r.api.free_(r.anyCtx, q);
-            kv.second.clear();
-        }
-        s = r.api.malloc_(r.anyCtx, bk * 8, &d);
-    }
-    Check(s, "HIP backend: device allocation");
-    b->p = static_cast<uint64_t*>(d);
-    return b;
 }
 
 // ---- contexts ----
@@ -232,46 +507,36 @@ bool Resolve(uint32_t ringDim, const std::vector<LimbSet>& sets, Resolved* out) 
                 return false;
     std::lock_guard<std::mutex> lk(r.ctxMutex);
     auto& u = r.universes[ringDim];
-    std::vector<uint64_t> q = u.q, psi = u.psi;
-    bool grew = false;
-    for (const auto& s : sets)
-        for (uint32_t i = 0; i < s.n; ++i) {
-            bool known = false;
-            for (size_t k = 0; k < q.size() && !known; ++k)
-                known = q[k] == s.q[i];
-            if (!known) {
-                q.push_back(s.q[i]);
-                psi.push_back(s.psi[i]);
-                grew = true;
-            }
+    // fast path: every modulus is known (the usual case after the first few operations of a CryptoContext)
+    bool known = u.ctx != nullptr;
+    for (size_t si = 0; known && si < sets.size(); ++si)
+        for (uint32_t i = 0; known && i < sets[si].n; ++i)
+            known = u.limbOf.count(sets[si].q[i]) != 0;
+    if (!known) {
+        std::vector<uint64_t> q = u.q, psi = u.psi;
+        auto add = [&](std::vector<uint64_t>& qq, std::vector<uint64_t>& pp) {
+            for (const auto& s : sets)
+                for (uint32_t i = 0; i < s.n; ++i)
+                    if (std::find(qq.begin(), qq.end(), s.q[i]) == qq.end())
+                        qq.push_back(s.q[i]), pp.push_back(s.psi[i]);
+        };
+        add(q, psi);
+        if (q.size() > 128) {
+            // more distinct moduli than one device context holds (many CryptoContexts in one process): start over with the
+            // moduli of this call; towers already on the device are plain words and resolve again at their next operation
+            q.clear(), psi.clear();
+            add(q, psi);
+            if (q.size() > 128)
+                return false;
         }
-    if (q.size() > 128) {
-        // more distinct moduli than one device context holds (many CryptoContexts in one process): start over with the
-        // moduli of this call; towers already on the device are plain words and resolve again at their next operation
-        q.clear(), psi.clear();
-        for (const auto& s : sets)
-            for (uint32_t i = 0; i < s.n; ++i) {
-                bool known = false;
-                for (size_t k = 0; k < q.size() && !known; ++k)
-                    known = q[k] == s.q[i];
-                if (!known)
-                    q.push_back(s.q[i]), psi.push_back(s.psi[i]);
-            }
-        if (q.size() > 128)
-            return false;
-        grew = true;
-    }
-    if (grew || !u.ctx) {
         fhe_ctx* c = nullptr;
-        if (r.api.ctx_create(log2u(ringDim), (uint32_t)q.size(), q.data(), psi.data(), 0, &c) != FHE_OK)
+        if (r.api.ctx_create(log2u(ringDim), (uint32_t)q.size(), q.data(), psi.data(), r.device, &c) != FHE_OK)
             return false;  // (e.g. a root that is not primitive: leave the operation to the host mirror)
         // the previous context stays alive: operations of other threads may still be using its tables
         u.ctx = c, u.q = q, u.psi = psi, u.logN = log2u(ringDim);
         u.limbOf.clear();
         for (uint32_t k = 0; k < q.size(); ++k)
             u.limbOf[q[k]] = k;
-        if (!r.anyCtx)
-            r.anyCtx = c;
     }
     out->ctx = u.ctx;
     out->idx.assign(sets.size(), {});
@@ -341,65 +606,94 @@ fhe_sr_plan* SrPlan(fhe_ctx* ctx, uint32_t sizeI, const std::vector<uint32_t>& o
     r.srPlans.emplace(std::move(key), p);
     return p;
 }
-fhe_behz* BehzPlan(fhe_ctx* ctx, const std::vector<uint32_t>& qIdx, const std::vector<uint32_t>& bskIdx, uint64_t t) {
+// One plan per (bases, member, content of the member's table arguments): the plan is created with derived tables (which also fixes
+// the Barrett constants, functions of the moduli alone) and the member's tables are then REPLACED by the caller's values, so the
+// kernel computes with exactly what the reference's member would read.
+// tables layout (numQ = |Q|, numBsk = |Bsk| = numQ + 1, numB = numQ):
+//   which 0: mtildeQHatInvModq[numQ] QHatModbsk[numQ][numBsk] QHatModmtilde[numQ] QModbsk[numBsk] negQInvModmtilde mtildeInvModbsk[numBsk]
+//   which 1: tQHatInvModq[numQ] QHatModbsk[numQ][numBsk] qInvModbsk[numQ][numBsk] tQInvModbsk[numBsk]
+//   which 2: BHatInvModb[numB] BHatModmsk[numB] BInvModmsk BHatModq[numB][numQ] BModq[numQ]
+fhe_behz* BehzPlan(fhe_ctx* ctx, const std::vector<uint32_t>& qIdx, const std::vector<uint32_t>& bskIdx, int which, uint64_t t,
+                   const std::vector<uint64_t>& tables) {
     Runtime& r = rt();
-    std::vector<uint64_t> key{reinterpret_cast<uintptr_t>(ctx), qIdx.size()};
+    const size_t numQ = qIdx.size(), numBsk = bskIdx.size();
+    const size_t need = which == 0 ? numQ + numQ * numBsk + numQ + numBsk + 1 + numBsk
+                                   : which == 1 ? numQ + 2 * numQ * numBsk + numBsk : numQ + numQ + 1 + numQ * numQ + numQ;
+    if (tables.size() != need)
+        return nullptr;
+    std::vector<uint64_t> key{reinterpret_cast<uintptr_t>(ctx), (uint64_t)which, t, numQ};
     key.insert(key.end(), qIdx.begin(), qIdx.end());
     key.insert(key.end(), bskIdx.begin(), bskIdx.end());
+    key.insert(key.end(), tables.begin(), tables.end());
     std::lock_guard<std::mutex> lk(r.convMutex);
-    if (t == 0) {  // any plan over these bases
-        auto lo = r.behzPlans.lower_bound(key);
-        if (lo != r.behzPlans.end() && lo->first.size() == key.size() + 1 && std::equal(key.begin(), key.end(), lo->first.begin()))
-            return lo->second;
-        t = 65537;
-    }
-    key.push_back(t);
     auto it = r.behzPlans.find(key);
     if (it != r.behzPlans.end())
         return it->second;
     fhe_behz* p = nullptr;
-    if (r.api.behz_create(ctx, qIdx.data(), (uint32_t)qIdx.size(), bskIdx.data(), t, &p) != FHE_OK)
+    if (r.api.behz_create(ctx, qIdx.data(), (uint32_t)numQ, bskIdx.data(), t ? t : 65537, &p) != FHE_OK)
         return nullptr;  // (bases the device kernels do not take: the member runs on the host mirror)
+    const uint64_t* T = tables.data();
+    fhe_status s;
+    if (which == 0)
+        s = r.api.behz_override_q_to_bsk(p, T, T + numQ, T + numQ + numQ * numBsk, T + 2 * numQ + numQ * numBsk,
+                                         T[2 * numQ + numQ * numBsk + numBsk], T + 2 * numQ + numQ * numBsk + numBsk + 1);
+    else if (which == 1)
+        s = r.api.behz_override_floorq(p, T, T + numQ, T + numQ + numQ * numBsk, T + numQ + 2 * numQ * numBsk);
+    else
+        s = r.api.behz_override_conv_sk(p, T, T + numQ, T[2 * numQ], T + 2 * numQ + 1, T + 2 * numQ + 1 + numQ * numQ);
+    Check(s, "HIP backend: BEHZ plan from the caller's tables");
     r.behzPlans.emplace(std::move(key), p);
     return p;
+}
+
+// ---- PrecomputeAutoMap (nbtheory2.cpp:264-275), memoised: precomp[bitrev(j)] = bitrev(((2j+1)k mod 2n) >> 1) ----
+namespace {
+std::shared_ptr<const std::vector<uint32_t>> auto_map(uint32_t n, uint32_t k) {
+    static std::mutex mu;
+    static std::map<std::pair<uint32_t, uint32_t>, std::shared_ptr<const std::vector<uint32_t>>> cache;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = cache.find({n, k});
+        if (it != cache.end())
+            return it->second;
+    }
+    const uint32_t logn = (uint32_t)std::round(std::log2(n)), logm = (uint32_t)std::round(std::log2(2.0 * n));  // (:266-267)
+    const uint64_t m    = 1ull << logm;
+    auto rev = [logn](uint32_t x) {
+        uint32_t y = 0;
+        for (uint32_t b = 0; b < logn; ++b)
+            y |= ((x >> b) & 1u) << (logn - 1u - b);
+        return y;
+    };
+    auto t = std::make_shared<std::vector<uint32_t>>(n);
+    for (uint32_t j = 0; j < n; ++j) {
+        const uint32_t idx = (uint32_t)(((2ull * j + 1ull) * k) & (m - 1ull)) >> 1;
+        (*t)[rev(j)]       = rev(idx);
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    if (cache.size() < 4096)  // (a few hundred rotation indices per context at most; 4n bytes each)
+        cache.emplace(std::make_pair(n, k), t);
+    return t;
+}
+}  // namespace
+// the map a caller hands to AutomorphismTransform(i, vec), compared word for word with PrecomputeAutoMap(n, i): the device kernel
+// computes that permutation on the fly, so any other map must take the reference's code
+bool IsAutoMap(uint32_t n, uint32_t k, const std::vector<uint32_t>& vec) {
+    if (vec.size() != n || !(k & 1u) || n == 0 || (n & (n - 1)))
+        return false;
+    const auto tab = auto_map(n, k);
+    return std::memcmp(tab->data(), vec.data(), (size_t)n * 4) == 0;
 }
 
 }  // namespace hiprt
 }  // namespace lbcrypto
 
-// ---- PrecomputeAutoMap (nbtheory2.cpp:264-275), memoised: precomp[bitrev(j)] = bitrev(((2j+1)k mod 2n) >> 1).  pke calls it for
-// every rotation and EvalFastRotation (ckksrns-leveledshe.cpp, ckksrns-fhe.cpp, base-leveledshe.cpp); at N = 2^17 that is 0.4 ms of
-// host time 260 times per bootstrap.  The HIP build weakens the reference's definition (hal/Makefile) and links this one. ----
+// pke calls PrecomputeAutoMap for every rotation and EvalFastRotation (ckksrns-leveledshe.cpp, ckksrns-fhe.cpp, base-leveledshe.cpp); at
+// N = 2^17 that is 0.4 ms of host time 260 times per bootstrap.  The HIP build weakens the reference's definition (hal/Makefile) and
+// links this memoising one (same table).
 namespace lbcrypto {
 void PrecomputeAutoMap(uint32_t n, uint32_t k, std::vector<uint32_t>* precomp) {
-    static std::mutex mu;
-    static std::map<std::pair<uint32_t, uint32_t>, std::shared_ptr<const std::vector<uint32_t>>> cache;
-    std::shared_ptr<const std::vector<uint32_t>> tab;
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        auto it = cache.find({n, k});
-        if (it != cache.end())
-            tab = it->second;
-    }
-    if (!tab) {
-        const uint32_t logn = (uint32_t)std::round(std::log2(n)), logm = (uint32_t)std::round(std::log2(2.0 * n));  // (:266-267)
-        const uint64_t m    = 1ull << logm;
-        auto rev = [logn](uint32_t x) {
-            uint32_t y = 0;
-            for (uint32_t b = 0; b < logn; ++b)
-                y |= ((x >> b) & 1u) << (logn - 1u - b);
-            return y;
-        };
-        auto t = std::make_shared<std::vector<uint32_t>>(n);
-        for (uint32_t j = 0; j < n; ++j) {
-            const uint32_t idx = (uint32_t)(((2ull * j + 1ull) * k) & (m - 1ull)) >> 1;
-            (*t)[rev(j)]       = rev(idx);
-        }
-        tab = t;
-        std::lock_guard<std::mutex> lk(mu);
-        if (cache.size() < 1024)  // (a few hundred rotation indices per context at most; 4n bytes each)
-            cache.emplace(std::make_pair(n, k), tab);
-    }
+    const auto tab = hiprt::auto_map(n, k);
     std::copy(tab->begin(), tab->end(), precomp->begin());
 }
 }  // namespace lbcrypto
@@ -408,7 +702,36 @@ extern "C" void fhe_hal_stats(uint64_t out[4]) {
     auto& r = lbcrypto::hiprt::rt();
     out[0] = r.deviceOps, out[1] = r.hostFallbacks, out[2] = r.h2dBytes, out[3] = r.d2hBytes;
 }
+extern "C" size_t fhe_hal_member_stats(char* buf, size_t cap) {
+    using namespace lbcrypto::hiprt;
+    std::map<std::string, std::array<uint64_t, 3>> merged;
+    for (auto& m : g_members) {
+        const char* n = m.name.load();
+        if (!n)
+            continue;
+        auto& e = merged[n];
+        e[0] += m.device.load(), e[1] += m.host.load(), e[2] += m.reads.load();
+    }
+    std::string s;
+    for (auto& kv : merged)
+        s += kv.first + " " + std::to_string(kv.second[0]) + " " + std::to_string(kv.second[1]) + " " + std::to_string(kv.second[2]) + "\n";
+    if (buf && cap) {
+        const size_t n = std::min(cap - 1, s.size());
+        std::memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return s.size() + 1;
+}
+extern "C" void fhe_hal_stats_reset(void) {
+    using namespace lbcrypto::hiprt;
+    auto& r = rt();
+    r.deviceOps = 0, r.hostFallbacks = 0, r.h2dBytes = 0, r.d2hBytes = 0;
+    for (auto& m : g_members)
+        m.device = 0, m.host = 0, m.reads = 0;
+}
 extern "C" int fhe_hal_available(void) { return lbcrypto::hiprt::Available() ? 1 : 0; }
+extern "C" void fhe_hal_set_device(int device) { lbcrypto::hiprt::g_deviceOverride.store(device); }
+extern "C" int fhe_hal_device(void) { return lbcrypto::hiprt::Device(); }
 extern "C" void fhe_hal_trace_reset(void) {
     std::lock_guard<std::mutex> lk(lbcrypto::hiprt::g_traceMutex);
     if (lbcrypto::hiprt::g_traceSites)

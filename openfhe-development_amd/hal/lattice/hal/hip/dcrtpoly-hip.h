@@ -19,6 +19,12 @@
 // (ring outside 2^4..2^17, a modulus >= 2^60 or != 1 mod 2N, a missing root of unity, BGV's t > 0 in ApproxModDown ...)
 // falls back to the mirror, so behaviour — including the exceptions thrown — is the default backend's.
 // Without a usable device (hiprt::Available() == false) the class IS the default backend with one indirection.
+//
+// Threads.  Every host thread enqueues on a HIP stream of its own (hiprt::Op): towers handed from one thread to another — pke's
+// OpenMP loops, a batch of ciphertexts spread over threads — are ordered with device-side waits, never by blocking the host.
+// Counters.  Every member that touches words opens a hiprt::MemberScope: tests assert, member by member, that the evaluation
+// paths executed on the device and what ran on the host mirror (fhe_hal_member_stats); FHE_HAL_REQUIRE_DEVICE=1 turns a host-mirror
+// execution of a member that has a device path into an exception.
 #ifndef LBCRYPTO_INC_LATTICE_HAL_HIP_DCRTPOLY_HIP_H
 #define LBCRYPTO_INC_LATTICE_HAL_HIP_DCRTPOLY_HIP_H
 
@@ -33,6 +39,8 @@
 #include "lattice/hal/dcrtpoly-interface.h"
 #include "lattice/hal/default/dcrtpoly.h"
 #include "lattice/hal/hip/hip-runtime.h"
+
+#define FHE_HAL_MEMBER() hiprt::MemberScope fhe_hal_scope_(__func__)
 
 namespace lbcrypto {
 
@@ -60,10 +68,10 @@ public:
     // first device member touches the object
     // ---------------------------------------------------------------------------------------------------------------
     DCRTPolyHipImpl() = default;
-    DCRTPolyHipImpl(const DCRTPolyType& e) noexcept {
+    DCRTPolyHipImpl(const DCRTPolyType& e) {
         CopyFrom(e);
     }
-    DCRTPolyType& operator=(const DCRTPolyType& rhs) noexcept override {
+    DCRTPolyType& operator=(const DCRTPolyType& rhs) override {
         if (this != &rhs)
             CopyFrom(rhs);
         return *this;
@@ -80,17 +88,22 @@ public:
     explicit DCRTPolyHipImpl(HostType&& h) noexcept : m_h{std::move(h)} {}
     explicit DCRTPolyHipImpl(const HostType& h) : m_h{h} {}
 
-    DCRTPolyHipImpl(const PolyLargeType& e, const std::shared_ptr<Params>& params) noexcept : m_h{e, params} {}
-    DCRTPolyType& operator=(const PolyLargeType& rhs) noexcept {
+    DCRTPolyHipImpl(const PolyLargeType& e, const std::shared_ptr<Params>& params) : m_h{e, params} {}
+    DCRTPolyType& operator=(const PolyLargeType& rhs) {
+        FHE_HAL_MEMBER();
         Hm() = rhs;
         return *this;
     }
     // the "ModRaise" constructor (dcrtpoly-impl.h:87-93): one polynomial modulo q_0 lifted, centred, into every limb
-    DCRTPolyHipImpl(const PolyType& e, const std::shared_ptr<Params>& params) noexcept {
-        if (!ModRaiseOnDevice(e, params))
+    DCRTPolyHipImpl(const PolyType& e, const std::shared_ptr<Params>& params) {
+        hiprt::MemberScope scope("ModRaise");
+        if (!ModRaiseOnDevice(e, params)) {
             m_h = HostType(e, params);
+            hiprt::CountHost("ModRaise");
+        }
     }
-    DCRTPolyType& operator=(const PolyType& rhs) noexcept {
+    DCRTPolyType& operator=(const PolyType& rhs) {
+        FHE_HAL_MEMBER();
         Hm() = rhs;
         return *this;
     }
@@ -98,7 +111,7 @@ public:
     // a zero tower stays unmaterialised (m_zero) until its first use decides where it lives: accumulators of the evaluation
     // path (`DCRTPoly first(params, EVALUATION, true); first += ...`) never cross PCIe
     DCRTPolyHipImpl(const std::shared_ptr<Params>& params, Format format = Format::EVALUATION,
-                    bool initializeElementToZero = false) noexcept
+                    bool initializeElementToZero = false)
         : m_h{params, format, initializeElementToZero && !hiprt::Available()} {
         if (initializeElementToZero && hiprt::Available()) {
             m_hostValid = false;
@@ -111,38 +124,46 @@ public:
         : m_h{tug, p, f, h} {}
     DCRTPolyHipImpl(DugType& dug, const std::shared_ptr<Params>& p, Format f = Format::EVALUATION) : m_h{dug, p, f} {}
 
-    DCRTPolyType& operator=(std::initializer_list<uint64_t> rhs) noexcept override {
+    DCRTPolyType& operator=(std::initializer_list<uint64_t> rhs) override {
+        FHE_HAL_MEMBER();
         Hm() = rhs;
         return *this;
     }
-    DCRTPolyType& operator=(uint64_t val) noexcept {
+    DCRTPolyType& operator=(uint64_t val) {
+        FHE_HAL_MEMBER();
         Hm() = val;
         return *this;
     }
-    DCRTPolyType& operator=(const std::vector<int64_t>& rhs) noexcept {
+    DCRTPolyType& operator=(const std::vector<int64_t>& rhs) {
+        FHE_HAL_MEMBER();
         Hm() = rhs;
         return *this;
     }
-    DCRTPolyType& operator=(const std::vector<int32_t>& rhs) noexcept {
+    DCRTPolyType& operator=(const std::vector<int32_t>& rhs) {
+        FHE_HAL_MEMBER();
         Hm() = rhs;
         return *this;
     }
-    DCRTPolyType& operator=(std::initializer_list<std::string> rhs) noexcept {
+    DCRTPolyType& operator=(std::initializer_list<std::string> rhs) {
+        FHE_HAL_MEMBER();
         Hm() = rhs;
         return *this;
     }
 
     DCRTPolyType CloneWithNoise(const DiscreteGaussianGeneratorImpl<VecType>& dgg, Format format) const override {
+        FHE_HAL_MEMBER();
         return Wrap(Hc().CloneWithNoise(dgg, format));
     }
     // dcrtpoly-impl.h:207-214
     DCRTPolyType CloneTowers(uint32_t startTower, uint32_t endTower) const {
+        FHE_HAL_MEMBER();
         if (m_d && !m_hostValid && endTower < NumLimbs() && startTower <= endTower) {
             const auto& P = m_h.GetParams();
             auto params   = std::make_shared<Params>(P->GetCyclotomicOrder(), P->GetParamPartition(startTower, endTower));
             const size_t N = P->GetRingDimension(), n = endTower - startTower + 1;
-            auto d         = hiprt::Alloc(n * N);
-            hiprt::D2D(AnyCtx(P), d->p, m_d->p + (size_t)startTower * N, n * N * 8, "CloneTowers");
+            hiprt::Op op;
+            auto d = hiprt::Alloc(n * N);
+            hiprt::D2D(op, op.W(d), op.R(m_d) + (size_t)startTower * N, n * N * 8, "CloneTowers");
             hiprt::CountDevice();
             return FromDevice(params, m_h.GetFormat(), std::move(d));
         }
@@ -150,6 +171,7 @@ public:
     }
 
     bool operator==(const DCRTPolyType& rhs) const override {
+        FHE_HAL_MEMBER();
         return Hc() == rhs.Hc();
     }
 
@@ -157,43 +179,59 @@ public:
     // tower arithmetic (dcrtpoly.h:131-189, dcrtpoly-impl.h:347-408, 582-620)
     // ---------------------------------------------------------------------------------------------------------------
     DCRTPolyType& operator+=(const DCRTPolyType& rhs) override {
+        FHE_HAL_MEMBER();
         if (!BinaryInPlace(rhs, hiprt::api().add, false))
             Hm() += rhs.Hc();
         return *this;
     }
+    // dcrtpoly-impl.h:383-399: every limb += NativeInteger(rhs) as a constant polynomial (PolyImpl::Plus(Integer), poly-impl.h:211-218)
     DCRTPolyType& operator+=(const Integer& rhs) override {
-        Hm() += rhs;
+        FHE_HAL_MEMBER();
+        if (!AddScalarInPlace(NativeInteger{rhs}, false))
+            Hm() += rhs;
         return *this;
     }
     DCRTPolyType& operator+=(const NativeInteger& rhs) override {
-        Hm() += rhs;
+        FHE_HAL_MEMBER();
+        if (!AddScalarInPlace(rhs, false))
+            Hm() += rhs;
         return *this;
     }
     DCRTPolyType& operator-=(const DCRTPolyType& rhs) override {
+        FHE_HAL_MEMBER();
         if (!BinaryInPlace(rhs, hiprt::api().sub, false))
             Hm() -= rhs.Hc();
         return *this;
     }
+    // dcrtpoly-impl.h:411-427: every word of every limb -= NativeInteger(rhs) (poly.h:249-252: ModSubEq, both formats)
     DCRTPolyType& operator-=(const Integer& rhs) override {
-        Hm() -= rhs;
+        FHE_HAL_MEMBER();
+        if (!AddScalarInPlace(NativeInteger{rhs}, true))
+            Hm() -= rhs;
         return *this;
     }
     DCRTPolyType& operator-=(const NativeInteger& rhs) override {
-        Hm() -= rhs;
+        FHE_HAL_MEMBER();
+        if (!AddScalarInPlace(rhs, true))
+            Hm() -= rhs;
         return *this;
     }
     DCRTPolyType& operator*=(const DCRTPolyType& rhs) override {
-        if (!BinaryInPlace(rhs, hiprt::api().mul, false))
+        FHE_HAL_MEMBER();
+        // (EVALUATION only on the device: for COEFFICIENT operands the reference's PolyImpl::operator*= throws, poly.h:254-263)
+        if (!BinaryInPlace(rhs, hiprt::api().mul, true))
             Hm() *= rhs.Hc();
         return *this;
     }
     DCRTPolyType& operator*=(const Integer& rhs) override {  // dcrtpoly-impl.h:604-611: NativeInteger val{rhs}, every limb *= val
+        FHE_HAL_MEMBER();
         std::vector<NativeInteger> c(NumLimbs(), NativeInteger{rhs});
         if (!TimesConstInPlace(c))
             Hm() *= rhs;
         return *this;
     }
     DCRTPolyType& operator*=(const NativeInteger& rhs) override {
+        FHE_HAL_MEMBER();
         std::vector<NativeInteger> c(NumLimbs(), rhs);
         if (!TimesConstInPlace(c))
             Hm() *= rhs;
@@ -201,36 +239,44 @@ public:
     }
 
     DCRTPolyType Negate() const override {
+        FHE_HAL_MEMBER();
         hiprt::Resolved r;
         if (OnDevice(&r)) {
+            hiprt::Op op;
             auto d = hiprt::Alloc(Words());
-            hiprt::Check(hiprt::api().neg(r.ctx, d->p, m_d->p, r.idx[0].data(), NumLimbs(), 1, nullptr), "Negate");
+            hiprt::Check(hiprt::api().neg(r.ctx, op.W(d), op.R(m_d), r.idx[0].data(), NumLimbs(), 1, op.s), "Negate");
             hiprt::CountDevice();
             return FromDevice(m_h.GetParams(), m_h.GetFormat(), std::move(d));
         }
         return Wrap(Hc().Negate());
     }
     DCRTPolyType operator-() const override {
+        FHE_HAL_MEMBER();
         return DCRTPolyType(m_h.GetParams(), m_h.GetFormat(), true) -= *this;
     }
 
     std::vector<DCRTPolyType> BaseDecompose(usint baseBits, bool evalModeAnswer) const override {
+        FHE_HAL_MEMBER();
         return WrapAll(Hc().BaseDecompose(baseBits, evalModeAnswer));
     }
     std::vector<DCRTPolyType> PowersOfBase(usint baseBits) const override {
+        FHE_HAL_MEMBER();
         return WrapAll(Hc().PowersOfBase(baseBits));
     }
     std::vector<DCRTPolyType> CRTDecompose(uint32_t baseBits) const {
+        FHE_HAL_MEMBER();
         return WrapAll(Hc().CRTDecompose(baseBits));
     }
 
     // dcrtpoly-impl.h:314-333 -> poly-impl.h:310-376 (EVALUATION: gather through PrecomputeAutoMap, COEFFICIENT: signed permutation)
     DCRTPolyType AutomorphismTransform(uint32_t i) const override {
+        FHE_HAL_MEMBER();
         hiprt::Resolved r;
         if ((i & 1u) && OnDevice(&r)) {
+            hiprt::Op op;
             auto d = hiprt::Alloc(Words());
-            hiprt::Check(hiprt::api().automorph(r.ctx, d->p, m_d->p, i, m_h.GetFormat() == Format::EVALUATION ? 1 : 0,
-                                                r.idx[0].data(), NumLimbs(), 1, nullptr),
+            hiprt::Check(hiprt::api().automorph(r.ctx, op.W(d), op.R(m_d), i, m_h.GetFormat() == Format::EVALUATION ? 1 : 0,
+                                                r.idx[0].data(), NumLimbs(), 1, op.s),
                          "AutomorphismTransform");
             hiprt::CountDevice();
             return FromDevice(m_h.GetParams(), m_h.GetFormat(), std::move(d));
@@ -238,51 +284,66 @@ public:
         return Wrap(Hc().AutomorphismTransform(i));
     }
     DCRTPolyType AutomorphismTransform(uint32_t i, const std::vector<uint32_t>& vec) const override {
-        // `vec` is PrecomputeAutoMap(N, i) in every caller (nbtheory2.cpp:264-275); the kernel computes that map on the fly.
-        // The whole table is compared once per (N, i) would cost more than the transform; its ends and middle are checked.
+        FHE_HAL_MEMBER();
+        // The device kernel computes the permutation of PrecomputeAutoMap(N, i) (nbtheory2.cpp:264-275) on the fly: `vec` is compared
+        // with that table word for word (memoised per (N, i)); any other map is applied by the reference's own code.
         const uint32_t N = m_h.GetParams()->GetRingDimension();
-        if (m_h.GetFormat() == Format::EVALUATION && vec.size() == N && AutoMapLooksRight(N, i, vec))
+        if (m_h.GetFormat() == Format::EVALUATION && hiprt::Available() && hiprt::IsAutoMap(N, i, vec))
             return AutomorphismTransform(i);
         return Wrap(Hc().AutomorphismTransform(i, vec));
     }
 
-    DCRTPolyType Plus(const Integer& rhs) const override {
+    DCRTPolyType Plus(const Integer& rhs) const override {  // dcrtpoly-impl.h:509-517
+        FHE_HAL_MEMBER();
+        DCRTPolyType out(*this);
+        if (out.AddScalarInPlace(NativeInteger{rhs}, false))
+            return out;
         return Wrap(Hc().Plus(rhs));
     }
     DCRTPolyType Plus(const std::vector<Integer>& rhs) const {  // dcrtpoly-impl.h:520-527
+        FHE_HAL_MEMBER();
         DCRTPolyType out;
         if (AddConstOnDevice(rhs, false, &out))
             return out;
         return Wrap(Hc().Plus(rhs));
     }
     DCRTPolyType Plus(const DCRTPolyType& rhs) const override {
+        FHE_HAL_MEMBER();
         DCRTPolyType out;
         if (Binary(rhs, hiprt::api().add, false, &out))
             return out;
         return Wrap(Hc().Plus(rhs.Hc()));
     }
     DCRTPolyType Minus(const DCRTPolyType& rhs) const override {
+        FHE_HAL_MEMBER();
         DCRTPolyType out;
         if (Binary(rhs, hiprt::api().sub, false, &out))
             return out;
         return Wrap(Hc().Minus(rhs.Hc()));
     }
-    DCRTPolyType Minus(const Integer& rhs) const override {
+    DCRTPolyType Minus(const Integer& rhs) const override {  // dcrtpoly-impl.h:530-538
+        FHE_HAL_MEMBER();
+        DCRTPolyType out(*this);
+        if (out.AddScalarInPlace(NativeInteger{rhs}, true))
+            return out;
         return Wrap(Hc().Minus(rhs));
     }
     DCRTPolyType Minus(const std::vector<Integer>& rhs) const {  // dcrtpoly-impl.h:541-548
+        FHE_HAL_MEMBER();
         DCRTPolyType out;
         if (AddConstOnDevice(rhs, true, &out))
             return out;
         return Wrap(Hc().Minus(rhs));
     }
     DCRTPolyType Times(const DCRTPolyType& rhs) const override {
+        FHE_HAL_MEMBER();
         DCRTPolyType out;
         if (Binary(rhs, hiprt::api().mul, true, &out))
             return out;
         return Wrap(Hc().Times(rhs.Hc()));
     }
     DCRTPolyType Times(const Integer& rhs) const override {  // dcrtpoly-impl.h:551-559
+        FHE_HAL_MEMBER();
         DCRTPolyType out(*this);
         std::vector<NativeInteger> c(NumLimbs(), NativeInteger{rhs});
         if (out.TimesConstInPlace(c))
@@ -290,6 +351,7 @@ public:
         return Wrap(Hc().Times(rhs));
     }
     DCRTPolyType Times(const std::vector<Integer>& rhs) const {  // dcrtpoly-impl.h:572-580: limb i times NativeInteger(rhs[i])
+        FHE_HAL_MEMBER();
         if (rhs.size() >= NumLimbs()) {
             std::vector<NativeInteger> c(NumLimbs());
             for (uint32_t i = 0; i < NumLimbs(); ++i)
@@ -300,7 +362,22 @@ public:
         }
         return Wrap(Hc().Times(rhs));
     }
+    // dcrtpoly-impl.h:562-570 -> PolyImpl::Times(SignedNativeInt) (poly-impl.h:235-251): limb i times |rhs| mod q_i, or q_i minus that
     DCRTPolyType Times(NativeInteger::SignedNativeInt rhs) const override {
+        FHE_HAL_MEMBER();
+        const auto& P = m_h.GetParams();
+        if (P && NumLimbs() == P->GetParams().size()) {
+            const uint64_t mag = rhs < 0 ? (uint64_t)0 - (uint64_t)rhs : (uint64_t)rhs;
+            std::vector<NativeInteger> c(NumLimbs());
+            for (uint32_t i = 0; i < NumLimbs(); ++i) {
+                const uint64_t q = P->GetParams()[i]->GetModulus().template ConvertToInt<uint64_t>();
+                const uint64_t m = mag % q;
+                c[i]             = NativeInteger(rhs < 0 ? (m ? q - m : 0) : m);
+            }
+            DCRTPolyType out(*this);
+            if (out.TimesConstInPlace(c))
+                return out;
+        }
         return Wrap(Hc().Times(rhs));
     }
 #if NATIVEINT != 64
@@ -310,6 +387,7 @@ public:
 #endif
     // dcrtpoly-impl.h:582-601
     DCRTPolyType Times(const std::vector<NativeInteger>& rhs) const {
+        FHE_HAL_MEMBER();
         if (rhs.size() == NumLimbs()) {
             DCRTPolyType out(*this);
             if (out.TimesConstInPlace(rhs))
@@ -318,6 +396,7 @@ public:
         return Wrap(Hc().Times(rhs));
     }
     DCRTPolyType TimesNoCheck(const std::vector<NativeInteger>& rhs) const {
+        FHE_HAL_MEMBER();
         if (rhs.size() >= NumLimbs()) {
             DCRTPolyType out(*this);
             if (out.TimesConstInPlace(rhs))
@@ -327,9 +406,11 @@ public:
     }
 
     DCRTPolyType MultiplicativeInverse() const override {
+        FHE_HAL_MEMBER();
         return Wrap(Hc().MultiplicativeInverse());
     }
     bool InverseExists() const override {
+        FHE_HAL_MEMBER();
         return Hc().InverseExists();
     }
     bool IsEmpty() const override {
@@ -337,6 +418,7 @@ public:
     }
 
     void SetValuesToZero() override {
+        FHE_HAL_MEMBER();
         if (hiprt::Available() && m_h.GetParams() && NumLimbs() == m_h.GetParams()->GetParams().size()) {
             std::lock_guard<std::mutex> lk(m_lock.m);
             auto P      = m_h.GetParams();
@@ -349,6 +431,7 @@ public:
         Hm().SetValuesToZero();
     }
     void AddILElementOne() override {
+        FHE_HAL_MEMBER();
         Hm().AddILElementOne();
     }
     // dcrtpoly-impl.h:669-689: the device copy keeps its leading limbs, the mirror object keeps the metadata in step
@@ -363,40 +446,66 @@ public:
     // dcrtpoly-impl.h:693-712 (CKKS rescale)
     void DropLastElementAndScale(const std::vector<NativeInteger>& QlQlInvModqlDivqlModq,
                                  const std::vector<NativeInteger>& qlInvModq) override {
+        FHE_HAL_MEMBER();
         if (!RescaleOnDevice(QlQlInvModqlDivqlModq, qlInvModq))
             Hm().DropLastElementAndScale(QlQlInvModqlDivqlModq, qlInvModq);
     }
     void ModReduce(const NativeInteger& t, const std::vector<NativeInteger>& tModqPrecon, const NativeInteger& negtInvModq,
                    const NativeInteger& negtInvModqPrecon, const std::vector<NativeInteger>& qlInvModq,
                    const std::vector<NativeInteger>& qlInvModqPrecon) override {
+        FHE_HAL_MEMBER();
         if (ModReduceOnDevice(t, negtInvModq, qlInvModq))
             return;
         Hm().ModReduce(t, tModqPrecon, negtInvModq, negtInvModqPrecon, qlInvModq, qlInvModqPrecon);
     }
 
     PolyLargeType CRTInterpolate() const override {
+        FHE_HAL_MEMBER();
         return Hc().CRTInterpolate();
     }
     PolyType DecryptionCRTInterpolate(PlaintextModulus ptm) const override {
+        FHE_HAL_MEMBER();
         return Hc().DecryptionCRTInterpolate(ptm);
     }
     PolyType ToNativePoly() const override {
+        FHE_HAL_MEMBER();
         return Hc().ToNativePoly();
     }
     PolyLargeType CRTInterpolateIndex(usint i) const override {
+        FHE_HAL_MEMBER();
         return Hc().CRTInterpolateIndex(i);
     }
     Integer GetWorkingModulus() const override {
         return m_h.GetWorkingModulus();
     }
+    // dcrtpoly-impl.h:630-647: one limb of `element`, in COEFFICIENT form, scaled to `modulus` through double precision
     void SetValuesModSwitch(const DCRTPolyType& element, const NativeInteger& modulus) override {
-        Hm().SetValuesModSwitch(element.Hc(), modulus);
+        FHE_HAL_MEMBER();
+        if (!ModSwitchOnDevice(element, modulus))
+            Hm().SetValuesModSwitch(element.Hc(), modulus);
     }
     std::shared_ptr<Params> GetExtendedCRTBasis(const std::shared_ptr<Params>& paramsP) const override {
         return m_h.GetExtendedCRTBasis(paramsP);
     }
+    // dcrtpoly-impl.h:868-885
     void TimesQovert(const std::shared_ptr<Params>& paramsQ, const std::vector<NativeInteger>& tInvModq, const NativeInteger& t,
                      const NativeInteger& NegQModt, const NativeInteger& NegQModtPrecon) override {
+        FHE_HAL_MEMBER();
+        hiprt::Resolved r;
+        if (tInvModq.size() >= NumLimbs() && t > NativeInteger(1) && NegQModt < t && OnDevice(&r)) {
+            std::vector<uint64_t> ti(NumLimbs());
+            for (uint32_t i = 0; i < NumLimbs(); ++i)
+                ti[i] = tInvModq[i].ConvertToInt<uint64_t>();
+            hiprt::Op op;
+            auto dst = WriteTarget();
+            hiprt::Check(hiprt::api().times_q_over_t(r.ctx, op.W(dst), op.R(m_d), t.ConvertToInt<uint64_t>(), NegQModt.ConvertToInt<uint64_t>(),
+                                                     ti.data(), r.idx[0].data(), NumLimbs(), 1, op.s),
+                         "TimesQovert");
+            m_d = std::move(dst);
+            hiprt::CountDevice();
+            DeviceIsNewer(m_h.GetFormat());
+            return;
+        }
         Hm().TimesQovert(paramsQ, tInvModq, t, NegQModt, NegQModtPrecon);
     }
 
@@ -408,6 +517,7 @@ public:
                                       const std::vector<NativeInteger>& QHatInvModqPrecon,
                                       const std::vector<std::vector<NativeInteger>>& QHatModp,
                                       const std::vector<DoubleNativeInt>& modpBarrettMu) const override {
+        FHE_HAL_MEMBER();
         DCRTPolyType out;
         if (SwitchBasisOnDevice(paramsQ, paramsP, QHatInvModq, QHatModp, nullptr, nullptr, &out))
             return out;
@@ -418,6 +528,7 @@ public:
                      const std::vector<NativeInteger>& QHatInvModqPrecon,
                      const std::vector<std::vector<NativeInteger>>& QHatModp,
                      const std::vector<DoubleNativeInt>& modpBarrettMu) override {
+        FHE_HAL_MEMBER();
         if (!ModUpOnDevice(paramsQ, paramsP, paramsQP, QHatInvModq, QHatModp))
             Hm().ApproxModUp(paramsQ, paramsP, paramsQP, QHatInvModq, QHatInvModqPrecon, QHatModp, modpBarrettMu);
     }
@@ -429,6 +540,7 @@ public:
                                const std::vector<DoubleNativeInt>& modqBarrettMu, const std::vector<NativeInteger>& tInvModp,
                                const std::vector<NativeInteger>& tInvModpPrecon, const NativeInteger& t,
                                const std::vector<NativeInteger>& tModqPrecon) const override {
+        FHE_HAL_MEMBER();
         DCRTPolyType out;
         if (ModDownOnDevice(paramsQ, paramsP, PInvModq, PHatInvModp, PHatModq, tInvModp, t, &out))
             return out;
@@ -441,6 +553,7 @@ public:
                                 const std::vector<std::vector<NativeInteger>>& alphaQModp,
                                 const std::vector<DoubleNativeInt>& modpBarrettMu,
                                 const std::vector<double>& qInv) const override {
+        FHE_HAL_MEMBER();
         DCRTPolyType out;
         // (:1008-1085 index QHatModp as [j][i]: transposed with respect to ApproxSwitchCRTBasis)
         if (SwitchBasisOnDevice(m_h.GetParams(), paramsP, QHatInvModq, QHatModp, &alphaQModp, &qInv, &out, /*transposed=*/true))
@@ -453,6 +566,7 @@ public:
                         const std::vector<std::vector<NativeInteger>>& alphaQModp,
                         const std::vector<DoubleNativeInt>& modpBarrettMu, const std::vector<double>& qInv,
                         Format resultFormat) override {
+        FHE_HAL_MEMBER();
         if (ExpandOnDevice(paramsQP, paramsP, QHatInvModq, QHatInvModqPrecon, QHatModp, alphaQModp, modpBarrettMu, qInv, resultFormat, false))
             return;
         Hm().ExpandCRTBasis(paramsQP, paramsP, QHatInvModq, QHatInvModqPrecon, QHatModp, alphaQModp, modpBarrettMu, qInv,
@@ -465,12 +579,14 @@ public:
                                     const std::vector<std::vector<NativeInteger>>& alphaQModp,
                                     const std::vector<DoubleNativeInt>& modpBarrettMu, const std::vector<double>& qInv,
                                     Format resultFormat) override {
+        FHE_HAL_MEMBER();
         if (ExpandOnDevice(paramsQP, paramsP, QHatInvModq, QHatInvModqPrecon, QHatModp, alphaQModp, modpBarrettMu, qInv, resultFormat, true))
             return;
         Hm().ExpandCRTBasisReverseOrder(paramsQP, paramsP, QHatInvModq, QHatInvModqPrecon, QHatModp, alphaQModp, modpBarrettMu,
                                         qInv, resultFormat);
     }
     void FastExpandCRTBasisPloverQ(const Precomputations& pre) override {
+        FHE_HAL_MEMBER();
         // dcrtpoly-impl.h:1151-1164: Q -> Pl (approximate, tables mPlQHatInvModq / qInvModp), Pl -> Ql (exact), result [Ql | Pl]
         if (hiprt::Available()) {
             DCRTPolyType partPl = ApproxSwitchCRTBasis(m_h.GetParams(), pre.paramsPl, pre.mPlQHatInvModq, pre.mPlQHatInvModqPrecon,
@@ -493,6 +609,7 @@ public:
     }
     void ExpandCRTBasisQlHat(const std::shared_ptr<Params>& paramsQ, const std::vector<NativeInteger>& QlHatModq,
                              const std::vector<NativeInteger>& QlHatModqPrecon, const usint sizeQ) override {
+        FHE_HAL_MEMBER();
         // dcrtpoly-impl.h:1167-1187: limb i times QlHatModq[i], the limbs [sizeQl, sizeQ) zero
         const uint32_t sizeQl = NumLimbs();
         if (hiprt::Available() && QlHatModq.size() >= sizeQl && sizeQ >= sizeQl && paramsQ->GetParams().size() == sizeQ) {
@@ -505,18 +622,26 @@ public:
         Hm().ExpandCRTBasisQlHat(paramsQ, QlHatModq, QlHatModqPrecon, sizeQ);
     }
 
+    // dcrtpoly-impl.h:1190-1467 (BFV decryption, HPS): the tower scaled by t/Q and rounded -> one polynomial modulo t
     PolyType ScaleAndRound(const NativeInteger& t, const std::vector<NativeInteger>& tQHatInvModqDivqModt,
                            const std::vector<NativeInteger>& tQHatInvModqDivqModtPrecon,
                            const std::vector<NativeInteger>& tQHatInvModqBDivqModt,
                            const std::vector<NativeInteger>& tQHatInvModqBDivqModtPrecon,
                            const std::vector<double>& tQHatInvModqDivqFrac,
                            const std::vector<double>& tQHatInvModqBDivqFrac) const override {
+        FHE_HAL_MEMBER();
+        PolyType out;
+        if (ScaleAndRoundNativeOnDevice(t, &tQHatInvModqDivqModt, &tQHatInvModqBDivqModt, &tQHatInvModqDivqFrac, &tQHatInvModqBDivqFrac, nullptr,
+                                        NativeInteger(0), nullptr, nullptr, &out))
+            return out;
+        hiprt::CountHost(__func__);
         return Hc().ScaleAndRound(t, tQHatInvModqDivqModt, tQHatInvModqDivqModtPrecon, tQHatInvModqBDivqModt,
                                   tQHatInvModqBDivqModtPrecon, tQHatInvModqDivqFrac, tQHatInvModqBDivqFrac);
     }
     DCRTPolyType ApproxScaleAndRound(const std::shared_ptr<Params>& paramsP,
                                      const std::vector<std::vector<NativeInteger>>& tPSHatInvModsDivsModp,
                                      const std::vector<DoubleNativeInt>& modpBarretMu) const override {
+        FHE_HAL_MEMBER();
         DCRTPolyType out;
         if (ScaleAndRoundOnDevice(paramsP, tPSHatInvModsDivsModp, nullptr, &out))
             return out;
@@ -526,21 +651,31 @@ public:
                                const std::vector<std::vector<NativeInteger>>& tOSHatInvModsDivsModo,
                                const std::vector<double>& tOSHatInvModsDivsFrac,
                                const std::vector<DoubleNativeInt>& modoBarretMu) const override {
+        FHE_HAL_MEMBER();
         DCRTPolyType out;
         if (ScaleAndRoundOnDevice(paramsOutput, tOSHatInvModsDivsModo, &tOSHatInvModsDivsFrac, &out))
             return out;
         return Wrap(Hc().ScaleAndRound(paramsOutput, tOSHatInvModsDivsModo, tOSHatInvModsDivsFrac, modoBarretMu));
     }
+    // dcrtpoly-impl.h:1631-1671 (BFV decryption, BEHZ)
     PolyType ScaleAndRound(const std::vector<NativeInteger>& moduliQ, const NativeInteger& t, const NativeInteger& tgamma,
                            const std::vector<NativeInteger>& tgammaQHatModq,
                            const std::vector<NativeInteger>& tgammaQHatModqPrecon,
                            const std::vector<NativeInteger>& negInvqModtgamma,
                            const std::vector<NativeInteger>& negInvqModtgammaPrecon) const override {
+        FHE_HAL_MEMBER();
+        PolyType out;
+        if (ScaleAndRoundNativeOnDevice(t, nullptr, nullptr, nullptr, nullptr, &moduliQ, tgamma, &tgammaQHatModq, &negInvqModtgamma, &out))
+            return out;
+        hiprt::CountHost(__func__);
         return Hc().ScaleAndRound(moduliQ, t, tgamma, tgammaQHatModq, tgammaQHatModqPrecon, negInvqModtgamma,
                                   negInvqModtgammaPrecon);
     }
+    // dcrtpoly-impl.h:1674-1689
     void ScaleAndRoundPOverQ(const std::shared_ptr<Params>& paramsQ, const std::vector<NativeInteger>& pInvModq) override {
-        Hm().ScaleAndRoundPOverQ(paramsQ, pInvModq);
+        FHE_HAL_MEMBER();
+        if (!POverQOnDevice(paramsQ, pInvModq))
+            Hm().ScaleAndRoundPOverQ(paramsQ, pInvModq);
     }
     void FastBaseConvqToBskMontgomery(
         const std::shared_ptr<Params>& paramsQBsk, const std::vector<NativeInteger>& moduliQ,
@@ -550,8 +685,22 @@ public:
         const std::vector<NativeInteger>& QModbsk, const std::vector<NativeInteger>& QModbskPrecon,
         const uint64_t& negQInvModmtilde, const std::vector<NativeInteger>& mtildeInvModbsk,
         const std::vector<NativeInteger>& mtildeInvModbskPrecon) override {
-        if (BehzOnDevice(0, paramsQBsk, (uint32_t)moduliQ.size(), (uint32_t)moduliBsk.size(), 0))
-            return;
+        FHE_HAL_MEMBER();
+        // the plan computes with THESE tables (hiprt::BehzPlan, one per member and table content)
+        const size_t numQ = moduliQ.size(), numBsk = moduliBsk.size();
+        std::vector<uint64_t> tabs;
+        if (mtildeQHatInvModq.size() >= numQ && QHatModbsk.size() >= numQ && QHatModmtilde.size() >= numQ && QModbsk.size() >= numBsk &&
+            mtildeInvModbsk.size() >= numBsk && PushMatrix(tabs, QHatModbsk, numQ, numBsk, true)) {
+            tabs.clear();
+            PushVector(tabs, mtildeQHatInvModq, numQ);
+            PushMatrix(tabs, QHatModbsk, numQ, numBsk);
+            tabs.insert(tabs.end(), QHatModmtilde.begin(), QHatModmtilde.begin() + numQ);
+            PushVector(tabs, QModbsk, numBsk);
+            tabs.push_back(negQInvModmtilde);
+            PushVector(tabs, mtildeInvModbsk, numBsk);
+            if (BehzOnDevice(0, paramsQBsk, moduliQ, moduliBsk, 0, tabs))
+                return;
+        }
         Hm().FastBaseConvqToBskMontgomery(paramsQBsk, moduliQ, moduliBsk, modbskBarrettMu, mtildeQHatInvModq, mtildeQHatInvModqPrecon,
                                           QHatModbsk, QHatModmtilde, QModbsk, QModbskPrecon, negQInvModmtilde, mtildeInvModbsk,
                                           mtildeInvModbskPrecon);
@@ -562,8 +711,19 @@ public:
                        const std::vector<std::vector<NativeInteger>>& QHatModbsk,
                        const std::vector<std::vector<NativeInteger>>& qInvModbsk, const std::vector<NativeInteger>& tQInvModbsk,
                        const std::vector<NativeInteger>& tQInvModbskPrecon) override {
-        if (BehzOnDevice(1, m_h.GetParams(), (uint32_t)moduliQ.size(), (uint32_t)moduliBsk.size(), t.ConvertToInt<uint64_t>()))
-            return;
+        FHE_HAL_MEMBER();
+        const size_t numQ = moduliQ.size(), numBsk = moduliBsk.size();
+        std::vector<uint64_t> tabs;
+        if (tQHatInvModq.size() >= numQ && tQInvModbsk.size() >= numBsk && PushMatrix(tabs, QHatModbsk, numQ, numBsk, true) &&
+            PushMatrix(tabs, qInvModbsk, numQ, numBsk, true)) {
+            tabs.clear();
+            PushVector(tabs, tQHatInvModq, numQ);
+            PushMatrix(tabs, QHatModbsk, numQ, numBsk);
+            PushMatrix(tabs, qInvModbsk, numQ, numBsk);
+            PushVector(tabs, tQInvModbsk, numBsk);
+            if (BehzOnDevice(1, m_h.GetParams(), moduliQ, moduliBsk, t.ConvertToInt<uint64_t>(), tabs))
+                return;
+        }
         Hm().FastRNSFloorq(t, moduliQ, moduliBsk, modbskBarrettMu, tQHatInvModq, tQHatInvModqPrecon, QHatModbsk, qInvModbsk,
                            tQInvModbsk, tQInvModbskPrecon);
     }
@@ -573,26 +733,43 @@ public:
                         const std::vector<NativeInteger>& BHatModmsk, const NativeInteger& BInvModmsk,
                         const NativeInteger& BInvModmskPrecon, const std::vector<std::vector<NativeInteger>>& BHatModq,
                         const std::vector<NativeInteger>& BModq, const std::vector<NativeInteger>& BModqPrecon) override {
-        if (BehzOnDevice(2, paramsQ, (uint32_t)paramsQ->GetParams().size(), (uint32_t)moduliBsk.size(), 0))
-            return;
+        FHE_HAL_MEMBER();
+        const size_t numQ = paramsQ->GetParams().size(), numBsk = moduliBsk.size(), numB = numBsk ? numBsk - 1 : 0;
+        std::vector<uint64_t> tabs;
+        if (numB == numQ && BHatInvModb.size() >= numB && BHatModmsk.size() >= numB && BModq.size() >= numQ &&
+            PushMatrix(tabs, BHatModq, numB, numQ, true)) {
+            tabs.clear();
+            PushVector(tabs, BHatInvModb, numB);
+            PushVector(tabs, BHatModmsk, numB);
+            tabs.push_back(BInvModmsk.ConvertToInt<uint64_t>());
+            PushMatrix(tabs, BHatModq, numB, numQ);
+            PushVector(tabs, BModq, numQ);
+            std::vector<NativeInteger> moduliQ(numQ);
+            for (size_t i = 0; i < numQ; ++i)
+                moduliQ[i] = paramsQ->GetParams()[i]->GetModulus();
+            if (BehzOnDevice(2, paramsQ, moduliQ, moduliBsk, 0, tabs))
+                return;
+        }
         Hm().FastBaseConvSK(paramsQ, modqBarrettMu, moduliBsk, modbskBarrettMu, BHatInvModb, BHatInvModbPrecon, BHatModmsk,
                             BInvModmsk, BInvModmskPrecon, BHatModq, BModq, BModqPrecon);
     }
 
     // dcrtpoly-impl.h:1932-1940 -> ChineseRemainderTransformFTT (transformnat-impl.h:303-374, 512-625)
     void SwitchFormat(uint32_t thread_limit = 0) override {
+        FHE_HAL_MEMBER();
         hiprt::Resolved r;
         if (OnDevice(&r)) {
             const bool toCoeff = m_h.GetFormat() == Format::EVALUATION;
+            hiprt::Op op;
             if (m_d.use_count() > 1) {  // words shared with a copy: transform into a buffer of its own
                 auto d = hiprt::Alloc(Words());
                 auto f = toCoeff ? hiprt::api().ntt_inv_oop : hiprt::api().ntt_fwd_oop;
-                hiprt::Check(f(r.ctx, m_d->p, d->p, r.idx[0].data(), NumLimbs(), 1, nullptr), "SwitchFormat");
+                hiprt::Check(f(r.ctx, op.R(m_d), op.W(d), r.idx[0].data(), NumLimbs(), 1, op.s), "SwitchFormat");
                 m_d = std::move(d);
             }
             else {
                 auto f = toCoeff ? hiprt::api().ntt_inv : hiprt::api().ntt_fwd;
-                hiprt::Check(f(r.ctx, m_d->p, r.idx[0].data(), NumLimbs(), 1, nullptr), "SwitchFormat");
+                hiprt::Check(f(r.ctx, op.W(m_d), r.idx[0].data(), NumLimbs(), 1, op.s), "SwitchFormat");
             }
             hiprt::CountDevice();
             DeviceIsNewer(toCoeff ? Format::COEFFICIENT : Format::EVALUATION);
@@ -601,6 +778,7 @@ public:
         Hm().SwitchFormat(thread_limit);
     }
     void SwitchModulusAtIndex(size_t index, const Integer& modulus, const Integer& rootOfUnity) override {
+        FHE_HAL_MEMBER();
         Hm().SwitchModulusAtIndex(index, modulus, rootOfUnity);
     }
 
@@ -626,28 +804,33 @@ public:
     }
 
     inline Format GetFormat() const final {
-        return m_h.GetFormat();
+        return Meta().GetFormat();
     }
     void OverrideFormat(const Format f) final {
+        std::lock_guard<std::mutex> lk(m_lock.m);
         m_h.OverrideFormat(f);
     }
     inline const std::shared_ptr<Params>& GetParams() const {
-        return m_h.GetParams();
+        return Meta().GetParams();
     }
     // the limbs as host objects: filled from the device on demand (const) / the device copy is dropped (mutable access)
     usint GetNumOfElements() const {  // (the interface's version reaches GetAllElements(): a device -> host copy for a count)
         return NumLimbs();
     }
     const std::vector<PolyType>& GetAllElements() const {
+        FHE_HAL_MEMBER();
         return Hc().GetAllElements();
     }
     std::vector<PolyType>& GetAllElements() {
+        FHE_HAL_MEMBER();
         return Hm().GetAllElements();
     }
     void SetElementAtIndex(usint index, const PolyType& element) {
+        FHE_HAL_MEMBER();
         Hm().SetElementAtIndex(index, element);
     }
     void SetElementAtIndex(usint index, PolyType&& element) {
+        FHE_HAL_MEMBER();
         Hm().SetElementAtIndex(index, std::move(element));
     }
 
@@ -663,6 +846,7 @@ public:
         bool transform = false;
     };
     static DCRTPolyType AssembleRows(const std::shared_ptr<Params>& params, Format f, const std::vector<RowPiece>& pieces) {
+        FHE_HAL_MEMBER();
         const size_t N   = params->GetRingDimension();
         uint32_t total   = 0;
         bool deviceOk    = hiprt::Available();
@@ -677,26 +861,28 @@ public:
         deviceOk = deviceOk && ResolveSets(params->GetRingDimension(), {params}, &r);
         for (const auto& pc : pieces)
             if (deviceOk && pc.src)
-                deviceOk = pc.src->Upload(r.ctx);
+                deviceOk = pc.src->Upload();
         if (deviceOk) {
-            auto d      = hiprt::Alloc((size_t)total * N);
-            uint32_t at = 0;
+            hiprt::Op op;
+            auto d       = hiprt::Alloc((size_t)total * N);
+            uint64_t* dp = op.W(d);
+            uint32_t at  = 0;
             for (const auto& pc : pieces) {
                 if (pc.src && pc.n && pc.transform) {
                     auto fn = f == Format::EVALUATION ? hiprt::api().ntt_fwd_oop : hiprt::api().ntt_inv_oop;
-                    hiprt::Check(fn(r.ctx, pc.src->m_d->p + (size_t)pc.first * N, d->p + (size_t)at * N, r.idx[0].data() + at, pc.n, 1, nullptr),
+                    hiprt::Check(fn(r.ctx, op.R(pc.src->m_d) + (size_t)pc.first * N, dp + (size_t)at * N, r.idx[0].data() + at, pc.n, 1, op.s),
                                  "AssembleRows");
                 }
                 else if (pc.src && pc.n)
-                    hiprt::D2D(r.ctx, d->p + (size_t)at * N, pc.src->m_d->p + (size_t)pc.first * N, (size_t)pc.n * N * 8, "AssembleRows");
+                    hiprt::D2D(op, dp + (size_t)at * N, op.R(pc.src->m_d) + (size_t)pc.first * N, (size_t)pc.n * N * 8, "AssembleRows");
                 else if (pc.n)
-                    ZeroRows(r.ctx, d->p + (size_t)at * N, (size_t)pc.n * N);
+                    hiprt::Check(hiprt::api().memset_zero(r.ctx, dp + (size_t)at * N, (size_t)pc.n * N * 8, op.s), "AssembleRows");
                 at += pc.n;
             }
             hiprt::CountDevice();
             return FromDevice(params, f, std::move(d));
         }
-        DCRTPolyType out(params, f, true);  // host: the reference's own loop
+        HostType h(params, f, true);  // host: the reference's own loop, on an object of the reference's class
         uint32_t at = 0;
         for (const auto& pc : pieces) {
             for (uint32_t i = 0; i < pc.n; ++i, ++at)
@@ -704,35 +890,36 @@ public:
                     PolyType e = pc.src->Hc().GetElementAtIndex(pc.first + i);
                     if (pc.transform)
                         e.SetFormat(f);
-                    out.m_h.SetElementAtIndex(at, std::move(e));
+                    h.SetElementAtIndex(at, std::move(e));
                 }
         }
-        hiprt::CountHost("AssembleRows");
-        return out;
+        return Wrap(std::move(h));
     }
     // { sum_j x[j][i] * k0[j][idx(i)],  sum_j x[j][i] * k1[j][idx(i)] },  idx(i) = i < sizeQl ? i : i + keySkip — the two sums
     // of EvalFastKeySwitchCoreExt (keyswitch-hybrid.cpp:419-430) in one pass over the digits (fhe_inner_product)
     static std::vector<DCRTPolyType> InnerProduct(const std::vector<DCRTPolyType>& x, const std::vector<DCRTPolyType>& k0,
                                                   const std::vector<DCRTPolyType>& k1, uint32_t sizeQl, uint32_t keySkip) {
+        FHE_HAL_MEMBER();
         const auto& params = x[0].GetParams();
         const uint32_t rows = x[0].NumLimbs(), n = (uint32_t)x.size();
         hiprt::Resolved r;
-        bool deviceOk = n >= 1 && n <= 8 && k0.size() >= n && k1.size() >= n && x[0].OnDevice(&r);
+        bool deviceOk = n >= 1 && k0.size() >= n && k1.size() >= n && x[0].OnDevice(&r);
         for (uint32_t j = 0; deviceOk && j < n; ++j)
             deviceOk = x[j].NumLimbs() == rows && x[j].GetFormat() == Format::EVALUATION && k0[j].NumLimbs() >= rows + keySkip &&
-                       k1[j].NumLimbs() >= rows + keySkip && x[j].Upload(r.ctx) && k0[j].Upload(r.ctx) && k1[j].Upload(r.ctx);
+                       k1[j].NumLimbs() >= rows + keySkip && x[j].Upload() && k0[j].Upload() && k1[j].Upload();
         std::vector<DCRTPolyType> out;
         if (deviceOk) {
             const size_t N = params->GetRingDimension();
+            hiprt::Op op;
             std::vector<const uint64_t*> px(n), p0(n), p1(n);
             for (uint32_t j = 0; j < n; ++j)
-                px[j] = x[j].m_d->p, p0[j] = k0[j].m_d->p, p1[j] = k1[j].m_d->p;
+                px[j] = op.R(x[j].m_d), p0[j] = op.R(k0[j].m_d), p1[j] = op.R(k1[j].m_d);
             std::vector<uint32_t> keyRow(rows);
             for (uint32_t i = 0; i < rows; ++i)
                 keyRow[i] = i < sizeQl ? i : i + keySkip;
             auto d0 = hiprt::Alloc((size_t)rows * N), d1 = hiprt::Alloc((size_t)rows * N);
             hiprt::Check(hiprt::api().inner_product(r.ctx, n, px.data(), p0.data(), p1.data(), keyRow.data(), r.idx[0].data(), rows, 1,
-                                                    d0->p, d1->p, nullptr),
+                                                    op.W(d0), op.W(d1), op.s),
                          "InnerProduct");
             hiprt::CountDevice();
             out.push_back(FromDevice(params, Format::EVALUATION, std::move(d0)));
@@ -752,14 +939,16 @@ public:
     // this[outFirst + i] += a[aFirst + i] * b[bFirst + i], i < n, EVALUATION — the accumulation of EvalFastKeySwitchCoreExt
     // (keyswitch-hybrid.cpp:419-430) on whole row ranges
     void MultAccRows(uint32_t outFirst, const DCRTPolyType& a, uint32_t aFirst, const DCRTPolyType& b, uint32_t bFirst, uint32_t n) {
+        FHE_HAL_MEMBER();
         if (outFirst + n > NumLimbs() || aFirst + n > a.NumLimbs() || bFirst + n > b.NumLimbs())
             OPENFHE_THROW("MultAccRows: row range outside a tower");
         hiprt::Resolved r;
-        if (OnDevice(&r) && a.Upload(r.ctx) && b.Upload(r.ctx)) {
+        if (OnDevice(&r) && a.Upload() && b.Upload()) {
             const size_t N = m_h.GetParams()->GetRingDimension();
-            Unshare(r.ctx);
-            hiprt::Check(hiprt::api().mul_add(r.ctx, m_d->p + (size_t)outFirst * N, a.m_d->p + (size_t)aFirst * N, b.m_d->p + (size_t)bFirst * N,
-                                              r.idx[0].data() + outFirst, n, 1, nullptr),
+            Unshare();
+            hiprt::Op op;
+            hiprt::Check(hiprt::api().mul_add(r.ctx, op.W(m_d) + (size_t)outFirst * N, op.R(a.m_d) + (size_t)aFirst * N,
+                                              op.R(b.m_d) + (size_t)bFirst * N, r.idx[0].data() + outFirst, n, 1, op.s),
                          "MultAccRows");
             hiprt::CountDevice();
             DeviceIsNewer(m_h.GetFormat());
@@ -779,6 +968,24 @@ public:
     bool IsDeviceResident() const {
         return m_d && !m_hostValid;
     }
+    // ---- for the backend's composite hooks (hal/keyswitch-hybrid-hip.cpp: whole pke operations as ONE library call) ----
+    // the tower's device words (uploaded if they are on the host), nullptr when the tower cannot live on the device
+    hiprt::Buf DeviceWords() const {
+        const auto& P = m_h.GetParams();
+        if (!hiprt::Available() || !P || NumLimbs() == 0 || NumLimbs() != P->GetParams().size() || !Upload())
+            return nullptr;
+        return m_d;
+    }
+    // a tower over `params` in format f whose words are the device buffer d ([limbs][N])
+    static DCRTPolyType FromDeviceWords(const std::shared_ptr<Params>& params, Format f, hiprt::Buf d) {
+        return FromDevice(params, f, std::move(d));
+    }
+    // replaces this tower's device words by a window of a packed buffer holding the same values (evaluation keys packed for the
+    // library's plans: no second copy stays behind)
+    void AdoptDeviceWords(hiprt::Buf d) {
+        std::lock_guard<std::mutex> lk(m_lock.m);
+        m_d = std::move(d);
+    }
 
 private:
     struct Lock {  // a mutex that does not travel with copies
@@ -796,6 +1003,10 @@ private:
     mutable bool m_zero{false};     // an all-zero tower not yet materialised on either side (then !m_hostValid && !m_d)
     mutable Lock m_lock;
 
+    // (params, format, limb count) live in the mirror object, which SyncHost() never replaces (see there)
+    const HostType& Meta() const {
+        return m_h;
+    }
     uint32_t NumLimbs() const {
         return (uint32_t)m_h.GetAllElements().size();
     }
@@ -806,7 +1017,8 @@ private:
         hiprt::CountHost(who);
         return DCRTPolyType(std::move(h));
     }
-    static std::vector<DCRTPolyType> WrapAll(std::vector<HostType>&& v) {
+    static std::vector<DCRTPolyType> WrapAll(std::vector<HostType>&& v, const char* who = __builtin_FUNCTION()) {
+        hiprt::CountHost(who);
         std::vector<DCRTPolyType> r;
         r.reserve(v.size());
         for (auto& h : v)
@@ -841,6 +1053,23 @@ private:
         }
         return hiprt::Resolve(N, ls, r);
     }
+    static void PushVector(std::vector<uint64_t>& out, const std::vector<NativeInteger>& v, size_t n) {
+        for (size_t i = 0; i < n; ++i)
+            out.push_back(v[i].ConvertToInt<uint64_t>());
+    }
+    // appends m[0..rows)[0..cols) row-major; checkOnly: only tells whether the matrix has that many entries
+    static bool PushMatrix(std::vector<uint64_t>& out, const std::vector<std::vector<NativeInteger>>& m, size_t rows, size_t cols,
+                           bool checkOnly = false) {
+        if (m.size() < rows)
+            return false;
+        for (size_t i = 0; i < rows; ++i)
+            if (m[i].size() < cols)
+                return false;
+        if (!checkOnly)
+            for (size_t i = 0; i < rows; ++i)
+                PushVector(out, m[i], cols);
+        return true;
+    }
 
     // ---- the two copies ---------------------------------------------------------------------------------------------
     void CopyFrom(const DCRTPolyType& e) {
@@ -858,77 +1087,60 @@ private:
         m_h         = e.m_h;
         m_hostValid = e.m_hostValid;
     }
-    static fhe_ctx* AnyCtx(const std::shared_ptr<Params>& p) {
-        hiprt::Resolved r;
-        ResolveSets(p->GetRingDimension(), {p}, &r);
-        return r.ctx;
-    }
     // where an in-place operation writes: the tower's own buffer, or a fresh one while the words are shared with a copy
     hiprt::Buf WriteTarget() const {
         return m_d.use_count() > 1 ? hiprt::Alloc(Words()) : m_d;
     }
     // a private copy of shared words (operations that read-modify-write in place)
-    void Unshare(fhe_ctx* c) {
+    void Unshare() {
         if (m_d.use_count() > 1) {
+            hiprt::Op op;
             auto d = hiprt::Alloc(Words());
-            hiprt::D2D(c, d->p, m_d->p, Words() * 8, "DCRTPoly copy");
+            hiprt::D2D(op, op.W(d), op.R(m_d), Words() * 8, "DCRTPoly copy");
             m_d = std::move(d);
         }
     }
-    static void ZeroRows(fhe_ctx* c, uint64_t* p, size_t words) {
-        // (the C ABI has no memset: a zero tower is uploaded once per size and copied on the device)
-        static std::mutex mu;
-        static hiprt::Buf zeros;
-        std::lock_guard<std::mutex> lk(mu);
-        if (!zeros || zeros->words < words) {
-            std::vector<uint64_t> z(words, 0);
-            auto b = hiprt::Alloc(words);
-            hiprt::Check(hiprt::api().h2d(c, b->p, z.data(), words * 8, nullptr), "zero rows");
-            hiprt::Check(hiprt::api().sync(c, nullptr), "zero rows");
-            zeros = std::move(b);
-        }
-        hiprt::D2D(c, p, zeros->p, words * 8, "zero rows");
-    }
-    // host words valid (fills the mirror from the device if needed)
-    void SyncHost() const {
+    // host words valid (fills the mirror from the device if needed).  The mirror object itself stays in place — only its limbs are
+    // filled in — so that (params, format, limb count) can be read by other threads of a const tower while one of them synchronises
+    void SyncHost(const char* who) const {
         std::lock_guard<std::mutex> lk(m_lock.m);
         if (m_hostValid)
             return;
+        const auto& P    = m_h.GetParams();
+        const Format f   = m_h.GetFormat();
+        const uint32_t L = (uint32_t)m_h.GetAllElements().size();
+        const size_t N   = P->GetRingDimension();
         if (m_zero) {
-            m_h         = HostType(m_h.GetParams(), m_h.GetFormat(), true);
+            for (uint32_t i = 0; i < L; ++i)
+                m_h.SetElementAtIndex(i, PolyType(P->GetParams()[i], f, true));
             m_hostValid = true;
             m_zero      = false;
             return;
         }
-        const auto P     = m_h.GetParams();
-        const Format f   = m_h.GetFormat();
-        const uint32_t L = (uint32_t)m_h.GetAllElements().size();
-        const size_t N   = P->GetRingDimension();
-        HostType h(P, f, false);
-        if (L < P->GetParams().size())  // (cannot happen: DropLastElement re-derives the params)
-            h.DropLastElements(P->GetParams().size() - L);
         std::vector<uint64_t> stage((size_t)L * N);
-        fhe_ctx* c = AnyCtx(P);
-        hiprt::Check(hiprt::api().d2h(c, stage.data(), m_d->p, stage.size() * 8, nullptr), "DCRTPoly device -> host");
-        hiprt::Check(hiprt::api().sync(c, nullptr), "DCRTPoly device -> host");
+        {
+            hiprt::Op op;
+            hiprt::Check(hiprt::api().d2h(hiprt::AnyCtx(), stage.data(), op.R(m_d), stage.size() * 8, op.s), "DCRTPoly device -> host");
+            op.HostSync();
+        }
         hiprt::CountD2H(stage.size() * 8);
+        hiprt::CountHostRead(who);
         for (uint32_t i = 0; i < L; ++i) {
             NativeVector v(N, P->GetParams()[i]->GetModulus());
             std::memcpy(&v[0], stage.data() + (size_t)i * N, N * 8);
             PolyType poly(P->GetParams()[i], f, false);
             poly.SetValues(std::move(v), f);
-            h.SetElementAtIndex(i, std::move(poly));
+            m_h.SetElementAtIndex(i, std::move(poly));
         }
-        m_h         = std::move(h);
         m_hostValid = true;
     }
     const HostType& Hc(const char* who = __builtin_FUNCTION()) const {
         hiprt::TraceMember(who);
-        SyncHost();
+        SyncHost(who);
         return m_h;
     }
     HostType& Hm(const char* who = __builtin_FUNCTION()) {  // mutable host access: the device copy is stale afterwards
-        SyncHost();
+        SyncHost(who);
         m_d.reset();
         hiprt::CountHost(who);
         return m_h;
@@ -941,17 +1153,18 @@ private:
             return false;
         if (!ResolveSets(P->GetRingDimension(), {P}, r))
             return false;
-        return Upload(r->ctx);
+        return Upload();
     }
-    bool Upload(fhe_ctx* c) const {
+    bool Upload() const {
         std::lock_guard<std::mutex> lk(m_lock.m);
         if (m_d)
             return true;
         const uint32_t L = NumLimbs();
         const size_t N   = m_h.GetParams()->GetRingDimension();
         if (m_zero) {
+            hiprt::Op op;
             auto d = hiprt::Alloc((size_t)L * N);
-            ZeroRows(c, d->p, (size_t)L * N);
+            hiprt::Check(hiprt::api().memset_zero(hiprt::AnyCtx(), op.W(d), (size_t)L * N * 8, op.s), "DCRTPoly zero tower");
             m_d    = std::move(d);
             m_zero = false;
             return true;
@@ -959,11 +1172,13 @@ private:
         for (const auto& e : m_h.GetAllElements())
             if (e.IsEmpty() || e.GetLength() != N)
                 return false;  // an unfilled tower: leave it (and its exceptions) to the host code
-        auto d = hiprt::Alloc((size_t)L * N);
+        hiprt::Op op;
+        auto d       = hiprt::Alloc((size_t)L * N);
+        uint64_t* dp = op.W(d);
         for (uint32_t i = 0; i < L; ++i)
-            hiprt::Check(hiprt::api().h2d(c, d->p + (size_t)i * N, &m_h.GetAllElements()[i].GetValues()[0], N * 8, nullptr),
+            hiprt::Check(hiprt::api().h2d(hiprt::AnyCtx(), dp + (size_t)i * N, &m_h.GetAllElements()[i].GetValues()[0], N * 8, op.s),
                          "DCRTPoly host -> device");
-        hiprt::Check(hiprt::api().sync(c, nullptr), "DCRTPoly host -> device");
+        op.HostSync();  // (the host vectors may change or go away as soon as this returns)
         hiprt::CountH2D((size_t)L * N * 8);
         m_d = std::move(d);
         return true;
@@ -988,6 +1203,8 @@ private:
         const auto &a = A->GetParams(), &b = B->GetParams();
         if (a.size() != b.size() || a.size() != NumLimbs() || b.size() != rhs.NumLimbs())
             return false;
+        if (A.get() == B.get())
+            return true;
         for (size_t i = 0; i < a.size(); ++i)
             if (a[i]->GetModulus() != b[i]->GetModulus())
                 return false;
@@ -995,20 +1212,24 @@ private:
     }
     bool Binary(const DCRTPolyType& rhs, BinFn fn, bool evalOnly, DCRTPolyType* out) const {
         hiprt::Resolved r;
-        if (!Compatible(rhs, evalOnly) || !OnDevice(&r) || !rhs.Upload(r.ctx))
+        if (!Compatible(rhs, evalOnly) || !OnDevice(&r) || !rhs.Upload())
             return false;
+        hiprt::Op op;
         auto d = hiprt::Alloc(Words());
-        hiprt::Check(fn(r.ctx, d->p, m_d->p, rhs.m_d->p, r.idx[0].data(), NumLimbs(), 1, nullptr), "DCRTPoly arithmetic");
+        hiprt::Check(fn(r.ctx, op.W(d), op.R(m_d), op.R(rhs.m_d), r.idx[0].data(), NumLimbs(), 1, op.s), "DCRTPoly arithmetic");
         hiprt::CountDevice();
         *out = FromDevice(m_h.GetParams(), m_h.GetFormat(), std::move(d));
         return true;
     }
     bool BinaryInPlace(const DCRTPolyType& rhs, BinFn fn, bool evalOnly) {
         hiprt::Resolved r;
-        if (!Compatible(rhs, evalOnly) || !OnDevice(&r) || !rhs.Upload(r.ctx))
+        if (!Compatible(rhs, evalOnly) || !OnDevice(&r) || !rhs.Upload())
             return false;
-        auto dst = WriteTarget();
-        hiprt::Check(fn(r.ctx, dst->p, m_d->p, rhs.m_d->p, r.idx[0].data(), NumLimbs(), 1, nullptr), "DCRTPoly arithmetic");
+        hiprt::Op op;
+        auto dst             = WriteTarget();
+        const uint64_t* lhsP = op.R(m_d);  // (before W: an in-place target is both)
+        const uint64_t* rhsP = op.R(rhs.m_d);
+        hiprt::Check(fn(r.ctx, op.W(dst), lhsP, rhsP, r.idx[0].data(), NumLimbs(), 1, op.s), "DCRTPoly arithmetic");
         m_d = std::move(dst);
         hiprt::CountDevice();
         DeviceIsNewer(m_h.GetFormat());
@@ -1022,15 +1243,37 @@ private:
         std::vector<uint64_t> c(NumLimbs());
         for (uint32_t i = 0; i < NumLimbs(); ++i)
             c[i] = NativeInteger(k[i]).template ConvertToInt<uint64_t>();
+        hiprt::Op op;
         auto d = hiprt::Alloc(Words());
         if (minus)
-            hiprt::Check(hiprt::api().sub_const(r.ctx, d->p, m_d->p, c.data(), r.idx[0].data(), NumLimbs(), 1, nullptr), "DCRTPoly Minus(constants)");
+            hiprt::Check(hiprt::api().sub_const(r.ctx, op.W(d), op.R(m_d), c.data(), r.idx[0].data(), NumLimbs(), 1, op.s), "DCRTPoly Minus(constants)");
         else
-            hiprt::Check(hiprt::api().add_const(r.ctx, d->p, m_d->p, c.data(), r.idx[0].data(), NumLimbs(), 1,
-                                                m_h.GetFormat() == Format::COEFFICIENT ? 1 : 0, nullptr),
+            hiprt::Check(hiprt::api().add_const(r.ctx, op.W(d), op.R(m_d), c.data(), r.idx[0].data(), NumLimbs(), 1,
+                                                m_h.GetFormat() == Format::COEFFICIENT ? 1 : 0, op.s),
                          "DCRTPoly Plus(constants)");
         hiprt::CountDevice();
         *out = FromDevice(m_h.GetParams(), m_h.GetFormat(), std::move(d));
+        return true;
+    }
+    // += / -= one scalar on every limb (dcrtpoly-impl.h:383-427): Plus(Integer) touches coefficient 0 only in COEFFICIENT format
+    // (poly-impl.h:211-218), -= subtracts from every word in both formats (poly.h:249-252)
+    bool AddScalarInPlace(const NativeInteger& v, bool minus) {
+        hiprt::Resolved r;
+        if (!OnDevice(&r))
+            return false;
+        std::vector<uint64_t> c(NumLimbs(), v.ConvertToInt<uint64_t>());
+        hiprt::Op op;
+        auto dst            = WriteTarget();
+        const uint64_t* src = op.R(m_d);
+        if (minus)
+            hiprt::Check(hiprt::api().sub_const(r.ctx, op.W(dst), src, c.data(), r.idx[0].data(), NumLimbs(), 1, op.s), "DCRTPoly -= scalar");
+        else
+            hiprt::Check(hiprt::api().add_const(r.ctx, op.W(dst), src, c.data(), r.idx[0].data(), NumLimbs(), 1,
+                                                m_h.GetFormat() == Format::COEFFICIENT ? 1 : 0, op.s),
+                         "DCRTPoly += scalar");
+        m_d = std::move(dst);
+        hiprt::CountDevice();
+        DeviceIsNewer(m_h.GetFormat());
         return true;
     }
     bool TimesConstInPlace(const std::vector<NativeInteger>& c) {
@@ -1040,33 +1283,15 @@ private:
         std::vector<uint64_t> k(NumLimbs());
         for (uint32_t i = 0; i < NumLimbs(); ++i)
             k[i] = c[i].ConvertToInt<uint64_t>();
-        auto dst = WriteTarget();
-        hiprt::Check(hiprt::api().mul_const(r.ctx, dst->p, m_d->p, k.data(), r.idx[0].data(), NumLimbs(), 1, nullptr),
+        hiprt::Op op;
+        auto dst            = WriteTarget();
+        const uint64_t* src = op.R(m_d);
+        hiprt::Check(hiprt::api().mul_const(r.ctx, op.W(dst), src, k.data(), r.idx[0].data(), NumLimbs(), 1, op.s),
                      "DCRTPoly Times(constants)");
         m_d = std::move(dst);
         hiprt::CountDevice();
         DeviceIsNewer(m_h.GetFormat());
         return true;
-    }
-    static bool AutoMapLooksRight(uint32_t N, uint32_t k, const std::vector<uint32_t>& vec) {
-        uint32_t logN = 0;
-        while ((1u << logN) < N)
-            ++logN;
-        auto rev = [logN](uint32_t x) {
-            uint32_t y = 0;
-            for (uint32_t b = 0; b < logN; ++b)
-                y |= ((x >> b) & 1u) << (logN - 1 - b);
-            return y;
-        };
-        const uint32_t probes[5] = {0, 1, N / 2, N - 2, N - 1};
-        for (uint32_t j : probes) {  // precomp[bitrev(j)] = bitrev(((2j+1)k mod 2N) >> 1)   (nbtheory2.cpp:264-275)
-            if (j >= N)
-                continue;
-            const uint32_t idx = (uint32_t)((((uint64_t)2 * j + 1) * k) & (2 * (uint64_t)N - 1)) >> 1;
-            if (vec[rev(j)] != rev(idx))
-                return false;
-        }
-        return (k & 1u) != 0;
     }
     static void Flatten(const std::vector<std::vector<NativeInteger>>& m, size_t rows, size_t cols, bool transposed,
                         std::vector<uint64_t>& out) {
@@ -1090,8 +1315,8 @@ private:
         DCRTPolyType coeff(*this);
         if (wasEval)
             coeff.SwitchFormat();
-        DCRTPolyType partP = coeff.SwitchCRTBasis(paramsP, QHatInvModq, QHatInvModqPrecon, QHatModp, alphaQModp, modpBarrettMu, qInv);
-        if (!partP.IsDeviceResident())
+        DCRTPolyType partP;
+        if (!coeff.SwitchBasisOnDevice(coeff.m_h.GetParams(), paramsP, QHatInvModq, QHatModp, &alphaQModp, &qInv, &partP, /*transposed=*/true))
             return false;
         const bool toEval       = resultFormat == Format::EVALUATION;
         const DCRTPolyType& qsrc = (toEval && wasEval) ? *this : coeff;
@@ -1131,68 +1356,187 @@ private:
                 return false;
         hiprt::Resolved r;
         const auto& mine = m_h.GetParams();
-        if (!ResolveSets(mine->GetRingDimension(), {mine, paramsO}, &r) || !Upload(r.ctx))
+        if (!ResolveSets(mine->GetRingDimension(), {mine, paramsO}, &r) || !Upload())
             return false;
         std::vector<uint64_t> flat;
         Flatten(tab, sizeO, sizeI + 1, false, flat);
         fhe_sr_plan* plan      = hiprt::SrPlan(r.ctx, sizeI, r.idx[1], flat.data(), frac ? frac->data() : nullptr);
         const bool outputFirst = paramsO->GetParams()[0]->GetModulus() == mine->GetParams()[0]->GetModulus();
         const size_t N         = mine->GetRingDimension();
-        auto d                 = hiprt::Alloc((size_t)sizeO * N);
-        hiprt::Check(hiprt::api().scale_and_round(plan, m_d->p, outputFirst ? 1 : 0, d->p, 1, nullptr), "ScaleAndRound");
+        hiprt::Op op;
+        auto d = hiprt::Alloc((size_t)sizeO * N);
+        hiprt::Check(hiprt::api().scale_and_round(plan, op.R(m_d), outputFirst ? 1 : 0, op.W(d), 1, op.s), "ScaleAndRound");
         hiprt::CountDevice();
         *out = FromDevice(paramsO, m_h.GetFormat(), std::move(d));
         return true;
     }
+    // ScaleAndRound -> NativePoly modulo t, the two decryption overloads (dcrtpoly-impl.h:1190-1467 HPS with the caller's four tables;
+    // :1631-1671 BEHZ with moduliQ / tgamma / two tables): N words come back over PCIe instead of the whole tower going out
+    bool ScaleAndRoundNativeOnDevice(const NativeInteger& t, const std::vector<NativeInteger>* tabModt, const std::vector<NativeInteger>* tabBModt,
+                                     const std::vector<double>* frac, const std::vector<double>* bfrac,
+                                     const std::vector<NativeInteger>* moduliQ, const NativeInteger& tgamma,
+                                     const std::vector<NativeInteger>* tgammaQHatModq, const std::vector<NativeInteger>* negInvqModtgamma,
+                                     PolyType* out) const {
+        hiprt::Resolved r;
+        const uint32_t sizeQ = NumLimbs();
+        if (m_h.GetFormat() != Format::COEFFICIENT || sizeQ == 0 || !OnDevice(&r))
+            return false;
+        const auto& P  = m_h.GetParams();
+        const size_t N = P->GetRingDimension();
+        std::vector<uint64_t> a(sizeQ), b(sizeQ);
+        const uint64_t tt = t.ConvertToInt<uint64_t>();
+        hiprt::Op op;
+        auto d = hiprt::Alloc(N);
+        if (moduliQ) {  // BEHZ
+            if (moduliQ->size() < sizeQ || tgammaQHatModq->size() < sizeQ || negInvqModtgamma->size() < sizeQ)
+                return false;
+            for (uint32_t i = 0; i < sizeQ; ++i) {
+                if ((*moduliQ)[i] != P->GetParams()[i]->GetModulus())
+                    return false;  // (the reference multiplies modulo the caller's moduli: only the tower's own are the device's)
+                a[i] = (*tgammaQHatModq)[i].ConvertToInt<uint64_t>();
+                b[i] = (*negInvqModtgamma)[i].ConvertToInt<uint64_t>();
+            }
+            hiprt::Check(hiprt::api().scale_and_round_behz_decrypt(r.ctx, op.R(m_d), r.idx[0].data(), sizeQ, tgamma.ConvertToInt<uint64_t>(),
+                                                                   a.data(), b.data(), 1, op.W(d), op.s),
+                         "ScaleAndRound (BEHZ decryption)");
+        }
+        else {
+            if (tabModt->size() < sizeQ || frac->size() < sizeQ)
+                return false;
+            const bool haveB = tabBModt->size() >= sizeQ && bfrac->size() >= sizeQ;
+            for (uint32_t i = 0; i < sizeQ; ++i) {
+                a[i] = (*tabModt)[i].ConvertToInt<uint64_t>();
+                b[i] = haveB ? (*tabBModt)[i].ConvertToInt<uint64_t>() : 0;
+            }
+            if (hiprt::api().scale_and_round_native(r.ctx, op.R(m_d), r.idx[0].data(), sizeQ, tt, a.data(), haveB ? b.data() : nullptr, frac->data(),
+                                                    haveB ? bfrac->data() : nullptr, 1, op.W(d), op.s) != FHE_OK)
+                return false;  // (a branch of the reference that needs the split tables the caller did not provide)
+        }
+        typename PolyType::Vector coefficients(N, tt);
+        hiprt::Check(hiprt::api().d2h(hiprt::AnyCtx(), &coefficients[0], op.R(d), N * 8, op.s), "ScaleAndRound result");
+        op.HostSync();
+        hiprt::CountD2H(N * 8);
+        hiprt::CountDevice();
+        // (:1458-1465: the root of unity is set to ONE, "as the calculation is expensive")
+        PolyType result(std::make_shared<typename PolyType::Params>(P->GetCyclotomicOrder(), tt, 1));
+        result.SetValues(std::move(coefficients), Format::COEFFICIENT);
+        *out = std::move(result);
+        return true;
+    }
+    // ScaleAndRoundPOverQ (dcrtpoly-impl.h:1674-1689): this over Q u {p} -> Q: x_i = (x_i - SwitchModulus(x_last -> q_i)) * [p^-1]_{q_i}; the
+    // format is whatever the tower's is (the reference switches the last limb's modulus in that format, the callers use COEFFICIENT)
+    bool POverQOnDevice(const std::shared_ptr<Params>& paramsQ, const std::vector<NativeInteger>& pInvModq) {
+        const uint32_t L = NumLimbs();
+        if (L < 2 || paramsQ->GetParams().size() != L - 1 || pInvModq.size() < L - 1 || m_h.GetFormat() != Format::COEFFICIENT)
+            return false;
+        hiprt::Resolved r;
+        if (!OnDevice(&r))
+            return false;
+        const auto& mine = m_h.GetParams();
+        for (uint32_t i = 0; i + 1 < L; ++i)
+            if (mine->GetParams()[i]->GetModulus() != paramsQ->GetParams()[i]->GetModulus())
+                return false;
+        // fhe_scale_and_round_p_over_q derives [p^-1]_{q_i} itself: the caller's table must be that
+        const uint64_t p = mine->GetParams()[L - 1]->GetModulus().template ConvertToInt<uint64_t>();
+        for (uint32_t i = 0; i + 1 < L; ++i) {
+            const uint64_t q = mine->GetParams()[i]->GetModulus().template ConvertToInt<uint64_t>();
+            if ((unsigned __int128)(p % q) * pInvModq[i].ConvertToInt<uint64_t>() % q != 1)
+                return false;
+        }
+        const size_t N = mine->GetRingDimension();
+        hiprt::Op op;
+        auto d = hiprt::Alloc((size_t)(L - 1) * N);
+        hiprt::Check(hiprt::api().scale_and_round_p_over_q(r.ctx, op.R(m_d), r.idx[0].data(), L - 1, op.W(d), 1, op.s), "ScaleAndRoundPOverQ");
+        hiprt::CountDevice();
+        *this = FromDevice(paramsQ, Format::COEFFICIENT, std::move(d));
+        return true;
+    }
+    // SetValuesModSwitch (dcrtpoly-impl.h:630-647): this (one limb, modulus `modulus`) = round(element (one limb) * modulus / q) in double
+    bool ModSwitchOnDevice(const DCRTPolyType& element, const NativeInteger& modulus) {
+        if (NumLimbs() != 1 || element.NumLimbs() != 1 || !m_h.GetParams() || !element.m_h.GetParams() ||
+            m_h.GetParams()->GetRingDimension() != element.m_h.GetParams()->GetRingDimension() || m_h.GetFormat() != Format::COEFFICIENT ||
+            m_h.GetParams()->GetParams().size() != 1 || m_h.GetParams()->GetParams()[0]->GetModulus() != modulus)  // (PolyImpl::SetValues throws)
+            return false;
+        DCRTPolyType input(element);  // (:637-638: a copy of the limb, in COEFFICIENT form)
+        if (input.GetFormat() != Format::COEFFICIENT)
+            input.SwitchFormat();
+        hiprt::Resolved r;
+        if (!input.IsDeviceResident() || !input.OnDevice(&r))
+            return false;
+        const size_t N      = m_h.GetParams()->GetRingDimension();
+        const uint64_t from = element.m_h.GetParams()->GetParams()[0]->GetModulus().template ConvertToInt<uint64_t>();
+        hiprt::Op op;
+        auto d = hiprt::Alloc(N);
+        hiprt::Check(hiprt::api().mod_switch_round(r.ctx, op.R(input.m_d), from, modulus.ConvertToInt<uint64_t>(), op.W(d), N, op.s),
+                     "SetValuesModSwitch");
+        hiprt::CountDevice();
+        // (:646 m_vectors[0].SetValues(tmp, COEFFICIENT): the limb keeps its parameter object, its words now carry `modulus`; the tower's
+        // format flag is not touched by the reference)
+        m_d = std::move(d);
+        DeviceIsNewer(m_h.GetFormat());
+        return true;
+    }
     // the BEHZ trio (dcrtpoly-impl.h:1694-1929); which: 0 = FastBaseConvqToBskMontgomery (this over Q -> Q u Bsk, EVALUATION),
-    // 1 = FastRNSFloorq (in place on Q u Bsk, COEFFICIENT), 2 = FastBaseConvSK (Q u Bsk -> Q, COEFFICIENT).  The plan's tables
-    // are derived from the moduli and t the way CryptoParametersBFVRNS derives the arguments the reference passes here.
-    bool BehzOnDevice(int which, const std::shared_ptr<Params>& params, uint32_t numQ, uint32_t numBsk, uint64_t t) {
+    // 1 = FastRNSFloorq (in place on Q u Bsk, COEFFICIENT), 2 = FastBaseConvSK (Q u Bsk -> Q, COEFFICIENT).  `tabs` = the member's
+    // table arguments flattened (hiprt::BehzPlan): the device plan computes with the caller's values.
+    bool BehzOnDevice(int which, const std::shared_ptr<Params>& params, const std::vector<NativeInteger>& moduliQ,
+                      const std::vector<NativeInteger>& moduliBsk, uint64_t t, const std::vector<uint64_t>& tabs) {
+        const uint32_t numQ = (uint32_t)moduliQ.size(), numBsk = (uint32_t)moduliBsk.size();
         if (!hiprt::Available() || numQ == 0 || numBsk != numQ + 1)
             return false;
         const auto mine = m_h.GetParams();
         const size_t N  = mine->GetRingDimension();
         hiprt::Resolved r;
-        if (which == 0) {  // params = paramsQBsk
+        std::shared_ptr<Params> qbsk;  // the parameter set Q u Bsk whose moduli must be the caller's moduliQ / moduliBsk
+        if (which == 0) {              // params = paramsQBsk
             if (NumLimbs() != numQ || params->GetParams().size() != numQ + numBsk)
                 return false;
-            if (!ResolveSets(N, {params, mine}, &r) || !Upload(r.ctx))
+            if (!ResolveSets(N, {params, mine}, &r) || !Upload())
                 return false;
             for (uint32_t i = 0; i < numQ; ++i)
                 if (r.idx[0][i] != r.idx[1][i])
                     return false;
+            qbsk = params;
         }
         else {  // this tower is over Q u Bsk
             if (NumLimbs() != numQ + numBsk || m_h.GetFormat() != Format::COEFFICIENT)
                 return false;
-            if (!ResolveSets(N, {mine}, &r) || !Upload(r.ctx))
+            if (!ResolveSets(N, {mine}, &r) || !Upload())
                 return false;
+            qbsk = mine;
         }
+        for (uint32_t i = 0; i < numQ; ++i)
+            if (qbsk->GetParams()[i]->GetModulus() != moduliQ[i])
+                return false;
+        for (uint32_t j = 0; j < numBsk; ++j)
+            if (qbsk->GetParams()[numQ + j]->GetModulus() != moduliBsk[j])
+                return false;
         std::vector<uint32_t> qIdx(r.idx[0].begin(), r.idx[0].begin() + numQ), bskIdx(r.idx[0].begin() + numQ, r.idx[0].end());
-        fhe_behz* plan = hiprt::BehzPlan(r.ctx, qIdx, bskIdx, which == 1 ? t : 0);
+        fhe_behz* plan = hiprt::BehzPlan(r.ctx, qIdx, bskIdx, which, t, tabs);
         if (!plan)
             return false;
         const auto& A = hiprt::api();
+        hiprt::Op op;
         if (which == 0) {
             const bool wasEval = m_h.GetFormat() == Format::EVALUATION;
             auto d             = hiprt::Alloc((size_t)(numQ + numBsk) * N);
-            hiprt::D2D(r.ctx, d->p, m_d->p, (size_t)numQ * N * 8, "FastBaseConvqToBskMontgomery");
+            hiprt::D2D(op, op.W(d), op.R(m_d), (size_t)numQ * N * 8, "FastBaseConvqToBskMontgomery");
             const size_t wsB = A.behz_workspace_bytes(plan, 1);
             auto ws          = hiprt::Alloc(wsB / 8 + 1);
-            hiprt::Check(A.behz_q_to_bsk(plan, d->p, wasEval ? 1 : 0, 1, ws->p, wsB, nullptr), "FastBaseConvqToBskMontgomery");
+            hiprt::Check(A.behz_q_to_bsk(plan, d->p, wasEval ? 1 : 0, 1, op.W(ws), wsB, op.s), "FastBaseConvqToBskMontgomery");
             hiprt::CountDevice();
             *this = FromDevice(params, Format::EVALUATION, std::move(d));
             return true;
         }
         if (which == 1) {
-            Unshare(r.ctx);
-            hiprt::Check(A.behz_floorq(plan, m_d->p, 1, nullptr), "FastRNSFloorq");
+            Unshare();
+            hiprt::Check(A.behz_floorq(plan, op.W(m_d), 1, op.s), "FastRNSFloorq");
             hiprt::CountDevice();
             DeviceIsNewer(Format::COEFFICIENT);
             return true;
         }
         auto d = hiprt::Alloc((size_t)numQ * N);
-        hiprt::Check(A.behz_conv_sk(plan, m_d->p, d->p, 1, nullptr), "FastBaseConvSK");
+        hiprt::Check(A.behz_conv_sk(plan, op.R(m_d), op.W(d), 1, op.s), "FastBaseConvSK");
         hiprt::CountDevice();
         *this = FromDevice(params, Format::COEFFICIENT, std::move(d));
         return true;
@@ -1205,13 +1549,18 @@ private:
         // (:892: sizeQ = min(limbs of this tower, limbs of paramsQ) — the last digit of a lower level is shorter than its params)
         const uint32_t sizeQ = std::min<uint32_t>(NumLimbs(), (uint32_t)paramsQ->GetParams().size());
         const uint32_t sizeP = (uint32_t)paramsP->GetParams().size();
-        if (sizeQ == 0 || sizeQ > 32 || sizeP == 0 || sizeQ != NumLimbs() || QHatInvModq.size() < sizeQ)
+        if (sizeQ == 0 || sizeQ > 128 || sizeP == 0 || sizeP > 128 || sizeQ != NumLimbs() || QHatInvModq.size() < sizeQ)
             return false;
         if ((transposed ? QHatModp.size() < sizeP : QHatModp.size() < sizeQ))
             return false;
+        for (uint32_t i = 0; i < (transposed ? sizeP : sizeQ); ++i)
+            if (QHatModp[i].size() < (transposed ? sizeQ : sizeP))
+                return false;
+        if (alpha && (alpha->size() < sizeQ + 1 || qInv->size() < sizeQ))
+            return false;
         hiprt::Resolved r;
         const auto& mine = m_h.GetParams();
-        if (!ResolveSets(mine->GetRingDimension(), {mine, paramsP}, &r) || !Upload(r.ctx))
+        if (!ResolveSets(mine->GetRingDimension(), {mine, paramsP}, &r) || !Upload())
             return false;
         std::vector<uint64_t> hi(sizeQ), hm, al;
         for (uint32_t i = 0; i < sizeQ; ++i)
@@ -1222,9 +1571,10 @@ private:
         fhe_conv* cv = hiprt::ConvPlan(r.ctx, r.idx[0], r.idx[1], hi.data(), hm.data(), alpha ? al.data() : nullptr,
                                        alpha ? qInv->data() : nullptr);
         const size_t N = mine->GetRingDimension();
-        auto d         = hiprt::Alloc((size_t)sizeP * N);
-        auto fn        = alpha ? hiprt::api().switch_basis_exact : hiprt::api().approx_switch_basis;
-        hiprt::Check(fn(cv, m_d->p, sizeQ, 0, d->p, sizeP, 0, 1, nullptr), "SwitchCRTBasis");
+        hiprt::Op op;
+        auto d  = hiprt::Alloc((size_t)sizeP * N);
+        auto fn = alpha ? hiprt::api().switch_basis_exact : hiprt::api().approx_switch_basis;
+        hiprt::Check(fn(cv, op.R(m_d), sizeQ, 0, op.W(d), sizeP, 0, 1, op.s), "SwitchCRTBasis");
         hiprt::CountDevice();
         *out = FromDevice(paramsP, m_h.GetFormat(), std::move(d));
         return true;
@@ -1247,26 +1597,28 @@ private:
         if (!ResolveSets(paramsQP->GetRingDimension(), {paramsQP, paramsP, m_h.GetParams()}, &r))
             return false;
         DCRTPolyType& qpart = wasEval ? *this : coeff;  // the EVALUATION copy of the Q limbs is kept when there is one
-        if (!qpart.Upload(r.ctx))
+        if (!qpart.Upload())
             return false;
         const size_t N = paramsQP->GetRingDimension();
-        auto d         = hiprt::Alloc((size_t)(sizeQ + sizeP) * N);
-        hiprt::D2D(r.ctx, d->p, qpart.m_d->p, (size_t)sizeQ * N * 8, "ApproxModUp");
-        hiprt::D2D(r.ctx, d->p + (size_t)sizeQ * N, partP.m_d->p, (size_t)sizeP * N * 8, "ApproxModUp");
+        hiprt::Op op;
+        auto d       = hiprt::Alloc((size_t)(sizeQ + sizeP) * N);
+        uint64_t* dp = op.W(d);
+        hiprt::D2D(op, dp, op.R(qpart.m_d), (size_t)sizeQ * N * 8, "ApproxModUp");
+        hiprt::D2D(op, dp + (size_t)sizeQ * N, op.R(partP.m_d), (size_t)sizeP * N * 8, "ApproxModUp");
         if (!wasEval)
-            hiprt::Check(hiprt::api().ntt_fwd(r.ctx, d->p, r.idx[2].data(), sizeQ, 1, nullptr), "ApproxModUp");
-        hiprt::Check(hiprt::api().ntt_fwd(r.ctx, d->p + (size_t)sizeQ * N, r.idx[1].data(), sizeP, 1, nullptr), "ApproxModUp");
+            hiprt::Check(hiprt::api().ntt_fwd(r.ctx, dp, r.idx[2].data(), sizeQ, 1, op.s), "ApproxModUp");
+        hiprt::Check(hiprt::api().ntt_fwd(r.ctx, dp + (size_t)sizeQ * N, r.idx[1].data(), sizeP, 1, op.s), "ApproxModUp");
         hiprt::CountDevice();
         *this = FromDevice(paramsQP, Format::EVALUATION, std::move(d));
         return true;
     }
-    // ApproxModDown with t = 0 (dcrtpoly-impl.h:966-1005): this over Q_l u P -> *out over Q_l, EVALUATION
+    // ApproxModDown (dcrtpoly-impl.h:966-1005): this over Q_l u P -> *out over Q_l, EVALUATION (t > 0: BGV's factors)
     bool ModDownOnDevice(const std::shared_ptr<Params>& paramsQ, const std::shared_ptr<Params>& paramsP,
                          const std::vector<NativeInteger>& PInvModq, const std::vector<NativeInteger>& PHatInvModp,
                          const std::vector<std::vector<NativeInteger>>& PHatModq, const std::vector<NativeInteger>& tInvModp,
                          const NativeInteger& t, DCRTPolyType* out) const {
         const uint32_t sizeP = (uint32_t)paramsP->GetParams().size(), L = NumLimbs();
-        if (L <= sizeP || sizeP > 32 || m_h.GetFormat() != Format::EVALUATION)
+        if (L <= sizeP || sizeP > 128 || m_h.GetFormat() != Format::EVALUATION)
             return false;
         const bool bgv = t > NativeInteger(0);  // BGV: the P part times -t^-1 before, the switched part times t after the conversion
         if (bgv && tInvModp.size() < sizeP)
@@ -1274,24 +1626,31 @@ private:
         const uint32_t sizeQ = L - sizeP;
         if (sizeQ > paramsQ->GetParams().size() || PInvModq.size() < sizeQ || PHatInvModp.size() < sizeP || PHatModq.size() < sizeP)
             return false;
+        for (uint32_t j = 0; j < sizeP; ++j)
+            if (PHatModq[j].size() < sizeQ)
+                return false;
         // the Q limbs of this tower are the first sizeQ limbs of paramsQ (:991-994 drops the others)
         const auto& mine = m_h.GetParams();
         for (uint32_t i = 0; i < sizeQ; ++i)
             if (mine->GetParams()[i]->GetModulus() != paramsQ->GetParams()[i]->GetModulus())
                 return false;
         hiprt::Resolved r;
-        if (!ResolveSets(mine->GetRingDimension(), {mine, paramsP}, &r) || !Upload(r.ctx))
+        if (!ResolveSets(mine->GetRingDimension(), {mine, paramsP}, &r) || !Upload())
             return false;
         std::vector<uint32_t> idxQ(r.idx[0].begin(), r.idx[0].begin() + sizeQ);
         const size_t N = mine->GetRingDimension();
+        const auto& A  = hiprt::api();
+        hiprt::Op op;
+        const uint64_t* self = op.R(m_d);
         // P part to COEFFICIENT (:978-985)
-        auto pcoef = hiprt::Alloc((size_t)sizeP * N);
-        hiprt::Check(hiprt::api().ntt_inv_oop(r.ctx, m_d->p + (size_t)sizeQ * N, pcoef->p, r.idx[1].data(), sizeP, 1, nullptr), "ApproxModDown");
+        auto pcoef   = hiprt::Alloc((size_t)sizeP * N);
+        uint64_t* pc = op.W(pcoef);
+        hiprt::Check(A.ntt_inv_oop(r.ctx, self + (size_t)sizeQ * N, pc, r.idx[1].data(), sizeP, 1, op.s), "ApproxModDown");
         if (bgv) {  // :982-984
             std::vector<uint64_t> ti(sizeP);
             for (uint32_t j = 0; j < sizeP; ++j)
                 ti[j] = tInvModp[j].ConvertToInt<uint64_t>();
-            hiprt::Check(hiprt::api().mul_const(r.ctx, pcoef->p, pcoef->p, ti.data(), r.idx[1].data(), sizeP, 1, nullptr), "ApproxModDown");
+            hiprt::Check(A.mul_const(r.ctx, pc, pc, ti.data(), r.idx[1].data(), sizeP, 1, op.s), "ApproxModDown");
         }
         // P -> Q_l (:987-988), with the reference's PHatInvModp / PHatModq tables
         std::vector<uint64_t> hi(sizeP), hm((size_t)sizeP * sizeQ);
@@ -1302,18 +1661,19 @@ private:
         }
         fhe_conv* cv = hiprt::ConvPlan(r.ctx, r.idx[1], idxQ, hi.data(), hm.data(), nullptr, nullptr);
         auto sw      = hiprt::Alloc((size_t)sizeQ * N);
-        hiprt::Check(hiprt::api().approx_switch_basis(cv, pcoef->p, sizeP, 0, sw->p, sizeQ, 0, 1, nullptr), "ApproxModDown");
+        uint64_t* sp = op.W(sw);
+        hiprt::Check(A.approx_switch_basis(cv, pc, sizeP, 0, sp, sizeQ, 0, 1, op.s), "ApproxModDown");
         if (bgv) {  // :998-1000
             std::vector<uint64_t> tq(sizeQ, t.ConvertToInt<uint64_t>());
-            hiprt::Check(hiprt::api().mul_const(r.ctx, sw->p, sw->p, tq.data(), idxQ.data(), sizeQ, 1, nullptr), "ApproxModDown");
+            hiprt::Check(A.mul_const(r.ctx, sp, sp, tq.data(), idxQ.data(), sizeQ, 1, op.s), "ApproxModDown");
         }
-        hiprt::Check(hiprt::api().ntt_fwd(r.ctx, sw->p, idxQ.data(), sizeQ, 1, nullptr), "ApproxModDown");  // :1001
+        hiprt::Check(A.ntt_fwd(r.ctx, sp, idxQ.data(), sizeQ, 1, op.s), "ApproxModDown");  // :1001
         // (x_i - switched_i) * [P^-1]_{q_i}   (:1002)
         std::vector<uint64_t> pinv(sizeQ);
         for (uint32_t i = 0; i < sizeQ; ++i)
             pinv[i] = PInvModq[i].ConvertToInt<uint64_t>();
-        hiprt::Check(hiprt::api().sub(r.ctx, sw->p, m_d->p, sw->p, idxQ.data(), sizeQ, 1, nullptr), "ApproxModDown");
-        hiprt::Check(hiprt::api().mul_const(r.ctx, sw->p, sw->p, pinv.data(), idxQ.data(), sizeQ, 1, nullptr), "ApproxModDown");
+        hiprt::Check(A.sub(r.ctx, sp, self, sp, idxQ.data(), sizeQ, 1, op.s), "ApproxModDown");
+        hiprt::Check(A.mul_const(r.ctx, sp, sp, pinv.data(), idxQ.data(), sizeQ, 1, op.s), "ApproxModDown");
         hiprt::CountDevice();
         // the result's params: paramsQ, shortened to sizeQ limbs like `ans.DropLastElements(diffQ)` does (:991-994)
         DCRTPolyType ans = FromDevice(paramsQ, Format::EVALUATION, std::move(sw));
@@ -1342,19 +1702,22 @@ private:
             qi[i] = qlInvModq[i].ConvertToInt<uint64_t>();
         const uint64_t nt = negtInvModq.ConvertToInt<uint64_t>();
         const auto& A     = hiprt::api();
-        auto delta        = hiprt::Alloc(N);
-        auto tmp          = hiprt::Alloc((size_t)l * N);
+        hiprt::Op op;
+        const uint64_t* self = op.R(m_d);
+        auto delta           = hiprt::Alloc(N);
+        auto tmp             = hiprt::Alloc((size_t)l * N);
+        uint64_t *dl = op.W(delta), *tp = op.W(tmp);
         if (eval)
-            hiprt::Check(A.ntt_inv_oop(r.ctx, m_d->p + (size_t)l * N, delta->p, &lastLimb, 1, 1, nullptr), "ModReduce");
+            hiprt::Check(A.ntt_inv_oop(r.ctx, self + (size_t)l * N, dl, &lastLimb, 1, 1, op.s), "ModReduce");
         else
-            hiprt::D2D(r.ctx, delta->p, m_d->p + (size_t)l * N, N * 8, "ModReduce");
-        hiprt::Check(A.mul_const(r.ctx, delta->p, delta->p, &nt, &lastLimb, 1, 1, nullptr), "ModReduce");
-        hiprt::Check(A.switch_modulus(r.ctx, tmp->p, idx.data(), l, delta->p, 1, 0, lastLimb, 1, nullptr), "ModReduce");
+            hiprt::D2D(op, dl, self + (size_t)l * N, N * 8, "ModReduce");
+        hiprt::Check(A.mul_const(r.ctx, dl, dl, &nt, &lastLimb, 1, 1, op.s), "ModReduce");
+        hiprt::Check(A.switch_modulus(r.ctx, tp, idx.data(), l, dl, 1, 0, lastLimb, 1, op.s), "ModReduce");
         if (eval)
-            hiprt::Check(A.ntt_fwd(r.ctx, tmp->p, idx.data(), l, 1, nullptr), "ModReduce");
-        hiprt::Check(A.mul_const(r.ctx, tmp->p, tmp->p, tq.data(), idx.data(), l, 1, nullptr), "ModReduce");
-        hiprt::Check(A.add(r.ctx, tmp->p, m_d->p, tmp->p, idx.data(), l, 1, nullptr), "ModReduce");
-        hiprt::Check(A.mul_const(r.ctx, tmp->p, tmp->p, qi.data(), idx.data(), l, 1, nullptr), "ModReduce");
+            hiprt::Check(A.ntt_fwd(r.ctx, tp, idx.data(), l, 1, op.s), "ModReduce");
+        hiprt::Check(A.mul_const(r.ctx, tp, tp, tq.data(), idx.data(), l, 1, op.s), "ModReduce");
+        hiprt::Check(A.add(r.ctx, tp, self, tp, idx.data(), l, 1, op.s), "ModReduce");
+        hiprt::Check(A.mul_const(r.ctx, tp, tp, qi.data(), idx.data(), l, 1, op.s), "ModReduce");
         m_d = std::move(tmp);
         hiprt::CountDevice();
         DeviceIsNewer(m_h.GetFormat());
@@ -1379,14 +1742,17 @@ private:
             b[i] = qlInvModq[i].ConvertToInt<uint64_t>();
         }
         const auto& A = hiprt::api();
-        auto last     = hiprt::Alloc(N);
-        auto tmp      = hiprt::Alloc((size_t)l * N);
-        hiprt::Check(A.ntt_inv_oop(r.ctx, m_d->p + (size_t)l * N, last->p, &lastLimb, 1, 1, nullptr), "DropLastElementAndScale");  // :696-697
-        hiprt::Check(A.switch_modulus(r.ctx, tmp->p, idx.data(), l, last->p, 1, 0, lastLimb, 1, nullptr), "DropLastElementAndScale");  // :703-704
-        hiprt::Check(A.mul_const(r.ctx, tmp->p, tmp->p, a.data(), idx.data(), l, 1, nullptr), "DropLastElementAndScale");            // :705
-        hiprt::Check(A.ntt_fwd(r.ctx, tmp->p, idx.data(), l, 1, nullptr), "DropLastElementAndScale");                                 // :706-707
+        hiprt::Op op;
+        const uint64_t* self = op.R(m_d);
+        auto last            = hiprt::Alloc(N);
+        auto tmp             = hiprt::Alloc((size_t)l * N);
+        uint64_t *lp = op.W(last), *tp = op.W(tmp);
+        hiprt::Check(A.ntt_inv_oop(r.ctx, self + (size_t)l * N, lp, &lastLimb, 1, 1, op.s), "DropLastElementAndScale");  // :696-697
+        hiprt::Check(A.switch_modulus(r.ctx, tp, idx.data(), l, lp, 1, 0, lastLimb, 1, op.s), "DropLastElementAndScale");  // :703-704
+        hiprt::Check(A.mul_const(r.ctx, tp, tp, a.data(), idx.data(), l, 1, op.s), "DropLastElementAndScale");            // :705
+        hiprt::Check(A.ntt_fwd(r.ctx, tp, idx.data(), l, 1, op.s), "DropLastElementAndScale");                             // :706-707
         // :708-709  m_vectors[i] = m_vectors[i] * qlInvModq[i] + tmp[i]: accumulated into tmp, which becomes the tower
-        hiprt::Check(A.mult_acc(r.ctx, tmp->p, m_d->p, b.data(), idx.data(), l, 1, nullptr), "DropLastElementAndScale");
+        hiprt::Check(A.mult_acc(r.ctx, tp, self, b.data(), idx.data(), l, 1, op.s), "DropLastElementAndScale");
         m_d = std::move(tmp);
         hiprt::CountDevice();
         DeviceIsNewer(Format::EVALUATION);
@@ -1402,11 +1768,12 @@ private:
             return false;
         const size_t N   = params->GetRingDimension();
         const uint32_t L = (uint32_t)params->GetParams().size();
-        auto src         = hiprt::Alloc(N);
-        auto d           = hiprt::Alloc((size_t)L * N);
-        hiprt::Check(hiprt::api().h2d(r.ctx, src->p, &e.GetValues()[0], N * 8, nullptr), "ModRaise");
-        hiprt::Check(hiprt::api().switch_modulus(r.ctx, d->p, r.idx[0].data(), L, src->p, 1, 0, r.idx[0][0], 1, nullptr), "ModRaise");
-        hiprt::Check(hiprt::api().sync(r.ctx, nullptr), "ModRaise");
+        hiprt::Op op;
+        auto src = hiprt::Alloc(N);
+        auto d   = hiprt::Alloc((size_t)L * N);
+        hiprt::Check(hiprt::api().h2d(r.ctx, op.W(src), &e.GetValues()[0], N * 8, op.s), "ModRaise");
+        hiprt::Check(hiprt::api().switch_modulus(r.ctx, op.W(d), r.idx[0].data(), L, src->p, 1, 0, r.idx[0][0], 1, op.s), "ModRaise");
+        op.HostSync();
         hiprt::CountH2D(N * 8);
         hiprt::CountDevice();
         m_h         = HostType(params, Format::COEFFICIENT, false);

@@ -1,6 +1,7 @@
 // hip-runtime.h — the non-template part of the HIP backend of lbcrypto::DCRTPoly: binding of the C ABI (include/fhe_hip.h,
-// libfhe_hip.so loaded with dlopen), the registry that maps (ring dimension, modulus) to a limb of a device context, a
-// caching device allocator and the cache of basis-conversion plans built from the reference's own CRT tables.
+// libfhe_hip.so loaded with dlopen), the registry that maps (ring dimension, modulus) to a limb of a device context, one HIP stream
+// per host thread with the cross-thread ordering of device buffers, a caching device allocator, the caches of plans built from
+// the reference's own CRT tables, and the per-member device / host-mirror counters the tests assert on.
 // Implemented in openfhe-development_amd/hal/hip-runtime.cpp (one translation unit added to libOPENFHEcore).
 #ifndef LBCRYPTO_INC_LATTICE_HAL_HIP_RUNTIME_H
 #define LBCRYPTO_INC_LATTICE_HAL_HIP_RUNTIME_H
@@ -8,6 +9,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "fhe_hip.h"  // the C ABI (repo root include/)
@@ -15,7 +17,7 @@
 namespace lbcrypto {
 namespace hiprt {
 
-// entry points of the C ABI the shim uses (resolved once with dlsym)
+// entry points of the C ABI the backend uses (resolved once with dlsym)
 struct Api {
     decltype(&fhe_last_error) last_error;
     decltype(&fhe_device_count) device_count;
@@ -25,7 +27,10 @@ struct Api {
     decltype(&fhe_memcpy_h2d) h2d;
     decltype(&fhe_memcpy_d2h) d2h;
     decltype(&fhe_memcpy_d2d) d2d;
+    decltype(&fhe_memset_zero) memset_zero;
     decltype(&fhe_stream_sync) sync;
+    decltype(&fhe_stream_create) stream_create;
+    decltype(&fhe_stream_wait) stream_wait;
     decltype(&fhe_ntt_fwd) ntt_fwd;
     decltype(&fhe_ntt_inv) ntt_inv;
     decltype(&fhe_ntt_inv_oop) ntt_inv_oop;
@@ -40,6 +45,8 @@ struct Api {
     decltype(&fhe_mult_acc) mult_acc;
     decltype(&fhe_add_const) add_const;
     decltype(&fhe_sub_const) sub_const;
+    decltype(&fhe_times_q_over_t) times_q_over_t;
+    decltype(&fhe_mod_switch_round) mod_switch_round;
     decltype(&fhe_automorph) automorph;
     decltype(&fhe_switch_modulus) switch_modulus;
     decltype(&fhe_conv_create_custom) conv_create_custom;
@@ -47,11 +54,28 @@ struct Api {
     decltype(&fhe_switch_basis_exact) switch_basis_exact;
     decltype(&fhe_sr_plan_create) sr_plan_create;
     decltype(&fhe_scale_and_round) scale_and_round;
+    decltype(&fhe_scale_and_round_p_over_q) scale_and_round_p_over_q;
+    decltype(&fhe_scale_and_round_native) scale_and_round_native;
+    decltype(&fhe_scale_and_round_behz_decrypt) scale_and_round_behz_decrypt;
     decltype(&fhe_behz_create) behz_create;
+    decltype(&fhe_behz_override_q_to_bsk) behz_override_q_to_bsk;
+    decltype(&fhe_behz_override_floorq) behz_override_floorq;
+    decltype(&fhe_behz_override_conv_sk) behz_override_conv_sk;
     decltype(&fhe_behz_workspace_bytes) behz_workspace_bytes;
     decltype(&fhe_behz_q_to_bsk) behz_q_to_bsk;
     decltype(&fhe_behz_floorq) behz_floorq;
     decltype(&fhe_behz_conv_sk) behz_conv_sk;
+    decltype(&fhe_tensor) tensor;
+    decltype(&fhe_tensor_square) tensor_square;
+    decltype(&fhe_ks_plan_create) ks_plan_create;
+    decltype(&fhe_ks_key_wrap) ks_key_wrap;
+    decltype(&fhe_ks_key_destroy) ks_key_destroy;
+    decltype(&fhe_ks_workspace_bytes) ks_workspace_bytes;
+    decltype(&fhe_keyswitch_hybrid) keyswitch_hybrid;
+    decltype(&fhe_ckks_eval_mult) ckks_eval_mult;
+    decltype(&fhe_ckks_bsgs_workspace_bytes) bsgs_workspace_bytes;
+    decltype(&fhe_ckks_bsgs_transform) bsgs_transform;
+    decltype(&fhe_checksum) checksum;
 };
 
 // true when the library is loaded and a device is usable; otherwise every DCRTPoly member runs on its host mirror
@@ -59,15 +83,47 @@ bool Available();
 const Api& api();
 // throws (OPENFHE_THROW) with the library's message when a call failed
 void Check(fhe_status s, const char* what);
+// the device this process computes on: fhe_hal_set_device(), else $FHE_HIP_DEVICE, else 0 (one process per GPU: a rank of a
+// multi-GPU job passes its LOCAL_RANK)
+int Device();
+// a context of that device (for calls that need one only to name the device: allocation, copies, stream primitives)
+fhe_ctx* AnyCtx();
 
-// ---- device memory: size-bucketed free lists over fhe_malloc (hipMalloc / hipFree are far too slow per operation) ----
+// ---- device memory.  A buffer remembers which stream wrote it last and which streams read it since (every host thread has a
+// stream of its own): Op::R / Op::W below order a thread's kernels after the foreign ones they depend on with device-side
+// waits (fhe_stream_wait: the host never blocks), and a buffer returns to the free lists of the thread that drops its last
+// reference only after that thread's stream has been ordered behind the buffer's pending uses. ----
 struct DevBuf {
     uint64_t* p  = nullptr;
     size_t words = 0;
+    std::shared_ptr<DevBuf> parent;  // a window of another buffer (packed evaluation keys): uses are recorded on the parent
+    struct Use {
+        uint32_t stream;
+        uint64_t seq;
+    };
+    std::mutex mu;
+    Use writer{0, 0};
+    std::vector<Use> readers;
     ~DevBuf();
 };
 using Buf = std::shared_ptr<DevBuf>;
 Buf Alloc(size_t words);
+Buf View(const Buf& parent, size_t offsetWords, size_t words);
+
+// One device operation (a group of launches) of the calling thread, on that thread's stream.
+class Op {
+public:
+    Op();
+    ~Op();
+    Op(const Op&)            = delete;
+    Op& operator=(const Op&) = delete;
+    void* s;                              // the stream the launches of this operation go to
+    const uint64_t* R(const Buf& b);      // this operation reads b   (ordered after b's foreign writer)
+    uint64_t* W(const Buf& b);            // this operation writes b  (ordered after b's foreign writer and readers)
+    void HostSync();                      // the host waits for everything this thread has enqueued so far
+private:
+    uint64_t m_seq;
+};
 
 // ---- contexts: one device context per ring dimension holding every modulus seen so far ----
 struct LimbSet {  // the moduli / roots of one tower (an ILDCRTParams), in tower order
@@ -88,20 +144,34 @@ bool Resolve(uint32_t ringDim, const std::vector<LimbSet>& sets, Resolved* out);
 fhe_conv* ConvPlan(fhe_ctx* ctx, const std::vector<uint32_t>& srcIdx, const std::vector<uint32_t>& dstIdx, const uint64_t* hatInv,
                    const uint64_t* hatMod, const uint64_t* alphaMod, const double* qInv);
 
-// ---- ScaleAndRound plans (the caller's tables: tab [sizeO][sizeI+1], frac [sizeI] or null for ApproxScaleAndRound) and BEHZ
-// plans (tables derived from the moduli and t exactly as CryptoParametersBFVRNS derives them: bfvrns-cryptoparameters.cpp:673-850;
-// t = 0: any plan over these bases will do — FastBaseConvqToBskMontgomery and FastBaseConvSK do not depend on t) ----
+// ---- ScaleAndRound plans (the caller's tables: tab [sizeO][sizeI+1], frac [sizeI] or null for ApproxScaleAndRound) ----
 fhe_sr_plan* SrPlan(fhe_ctx* ctx, uint32_t sizeI, const std::vector<uint32_t>& outIdx, const uint64_t* tab, const double* frac);
-fhe_behz* BehzPlan(fhe_ctx* ctx, const std::vector<uint32_t>& qIdx, const std::vector<uint32_t>& bskIdx, uint64_t t);
+// ---- BEHZ plans, one per member (which: 0 = FastBaseConvqToBskMontgomery, 1 = FastRNSFloorq, 2 = FastBaseConvSK) and table
+// content: `tables` is the concatenation of the member's table arguments as the reference passes them (flattened row-major), the
+// plan computes with exactly these values (fhe_behz_override_*); nullptr when the library does not take the bases ----
+fhe_behz* BehzPlan(fhe_ctx* ctx, const std::vector<uint32_t>& qIdx, const std::vector<uint32_t>& bskIdx, int which, uint64_t t,
+                   const std::vector<uint64_t>& tables);
 
-// ---- counters (tests assert that the device path really ran) ----
+// ---- PrecomputeAutoMap(n, k) memoised (the table pke passes to AutomorphismTransform(i, vec)); `vec` is compared with it in full ----
+bool IsAutoMap(uint32_t n, uint32_t k, const std::vector<uint32_t>& vec);
+
+// ---- counters.  Every public member of the backend class opens a MemberScope; device operations, host-mirror executions
+// (the member ran the reference's code on the mirror and produced / modified words there) and host reads (a const member was
+// served by the mirror after a device -> host copy) are attributed to the OUTERMOST member of the calling thread.  With
+// FHE_HAL_REQUIRE_DEVICE=1 a host-mirror execution of a member that has a device path throws instead of degrading silently. ----
+struct MemberScope {
+    explicit MemberScope(const char* member);
+    ~MemberScope();
+    bool outer;
+};
 struct Stats {
     uint64_t deviceOps, hostFallbacks, h2dBytes, d2hBytes;
 };
 void TraceMember(const char* member);  // the member about to touch words (FHE_HAL_TRACE attributes PCIe bytes to it)
-void D2D(fhe_ctx* c, uint64_t* dst, const uint64_t* src, size_t bytes, const char* what);  // device copy (+ trace)
-void CountDevice();
-void CountHost(const char* member);  // member = the DCRTPoly member that went to the host mirror (FHE_HAL_TRACE)
+void D2D(Op& op, uint64_t* dst, const uint64_t* src, size_t bytes, const char* what);  // device copy (+ trace)
+void CountDevice(const char* member = __builtin_FUNCTION());
+void CountHost(const char* member);      // member = the DCRTPoly member that went to the host mirror
+void CountHostRead(const char* member);  // a const member read the mirror after a device -> host copy
 void CountH2D(size_t bytes);
 void CountD2H(size_t bytes);
 
@@ -111,8 +181,15 @@ void CountD2H(size_t bytes);
 extern "C" {
 // {device operations, host fallbacks, bytes host->device, bytes device->host} since process start
 void fhe_hal_stats(uint64_t out[4]);
+// per member: "name deviceOps hostOps hostReads\n" for every member seen so far, into buf (returns the length needed)
+size_t fhe_hal_member_stats(char* buf, size_t cap);
+// forgets all counters (a test program calls it after its set-up phase)
+void fhe_hal_stats_reset(void);
 // 1 when the HIP backend is live (library loaded, device present), 0 when every operation runs on the host mirror
 int fhe_hal_available(void);
+// the device of this process; call before the first DCRTPoly operation (a rank of a multi-GPU job: its LOCAL_RANK)
+void fhe_hal_set_device(int device);
+int fhe_hal_device(void);
 // forgets the call sites FHE_HAL_TRACE has collected so far (a test program calls it after its set-up phase)
 void fhe_hal_trace_reset(void);
 }

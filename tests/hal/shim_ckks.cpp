@@ -21,6 +21,16 @@ using namespace lbcrypto;
 extern "C" void fhe_hal_stats(uint64_t out[4]) __attribute__((weak));
 extern "C" int fhe_hal_available(void) __attribute__((weak));
 extern "C" void fhe_hal_trace_reset(void) __attribute__((weak));
+extern "C" size_t fhe_hal_member_stats(char* buf, size_t cap) __attribute__((weak));
+extern "C" void fhe_hal_stats_reset(void) __attribute__((weak));
+// the set-up phase (context, keys, encryption: samplers and encoders produce their words on the host) ends here: the counters the
+// tests assert on cover the EVALUATION phase (and the decryptions at the end) only
+static void evaluation_phase_begins() {
+    if (fhe_hal_stats_reset)
+        fhe_hal_stats_reset();
+    if (fhe_hal_trace_reset)
+        fhe_hal_trace_reset();
+}
 
 static std::ofstream g_out;
 static void dump(const char* name, const Ciphertext<DCRTPoly>& ct) {
@@ -89,6 +99,7 @@ int main(int argc, char** argv) {
         auto cy = cc->Encrypt(kp.publicKey, cc->MakeCKKSPackedPlaintext(y));
         dump("x", cx);
         dump("y", cy);
+        evaluation_phase_begins();
         auto m = cc->EvalMult(cx, cy);  // EvalMultCore + HYBRID KeySwitchCore (base-leveledshe.cpp:201-214)
         dump("x*y", m);
         auto r = cc->Rescale(m);  // DropLastElementAndScale
@@ -131,6 +142,7 @@ int main(int argc, char** argv) {
         auto cy = cc->Encrypt(kp.publicKey, cc->MakePackedPlaintext(y));
         dump("x", cx);
         dump("y", cy);
+        evaluation_phase_begins();
         auto t0 = std::chrono::steady_clock::now();
         auto m3 = cc->EvalMultNoRelin(cx, cy);
         dump("x*y (3 elements)", m3);
@@ -160,6 +172,93 @@ int main(int argc, char** argv) {
             (void)w->GetElements()[0].GetElementAtIndex(0);
             std::cout << "bfv EvalMult seconds " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps << " ("
                       << reps << " reps)" << std::endl;
+        }
+    }
+    else if (mode == "behztables") {
+        // The BEHZ members with tables that are NOT CryptoParametersBFVRNS's: a backend that derived its own tables from the moduli
+        // instead of using the arguments would compute something else than the reference here.  Run 0 passes the parameters' own
+        // tables, run 1 a perturbed copy of every table set (entries kept below their moduli, Shoup companions recomputed).
+        CCParams<CryptoContextBFVRNS> p;
+        p.SetSecurityLevel(HEStd_NotSet);
+        p.SetRingDim(1u << logN);
+        p.SetPlaintextModulus(65537);
+        p.SetMultiplicativeDepth(2);
+        p.SetScalingModSize(60);
+        p.SetKeySwitchTechnique(HYBRID);
+        p.SetMultiplicationTechnique(BEHZ);
+        auto cc = GenCryptoContext(p);
+        cc->Enable(PKE);
+        cc->Enable(KEYSWITCH);
+        cc->Enable(LEVELEDSHE);
+        auto kp = cc->KeyGen();
+        std::vector<int64_t> x = {1, 2, 3, 4, 5, 6, 7, 8};
+        auto cx       = cc->Encrypt(kp.publicKey, cc->MakePackedPlaintext(x));
+        const auto cp = std::dynamic_pointer_cast<CryptoParametersBFVRNS>(cc->GetCryptoParameters());
+        auto dumpTower = [&](const char* name, const DCRTPoly& e) {
+            const auto& limbs = e.GetAllElements();
+            uint64_t h2[3]    = {limbs.size(), e.GetRingDimension(), static_cast<uint64_t>(e.GetFormat())};
+            g_out.write(reinterpret_cast<const char*>(h2), 24);
+            for (const auto& l : limbs)
+                for (uint32_t j = 0; j < l.GetLength(); ++j) {
+                    uint64_t v = l[j].ConvertToInt<uint64_t>();
+                    g_out.write(reinterpret_cast<const char*>(&v), 8);
+                }
+            std::cout << "dumped " << name << ": " << limbs.size() << " limbs" << std::endl;
+        };
+        auto precon = [](const std::vector<NativeInteger>& v, const std::vector<NativeInteger>& mod) {
+            std::vector<NativeInteger> r(v.size());
+            for (size_t i = 0; i < v.size(); ++i)
+                r[i] = v[i].PrepModMulConst(mod[i]);
+            return r;
+        };
+        auto bump = [](NativeInteger& v, const NativeInteger& mod, uint64_t by) { v = (v + NativeInteger(by)).Mod(mod); };
+        evaluation_phase_begins();
+        for (int run = 0; run < 2; ++run) {
+            const auto& Q   = cp->GetModuliQ();
+            const auto& Bsk = cp->GetModuliBsk();
+            auto mtQHatInv = cp->GetmtildeQHatInvModq();
+            auto QHatModbsk = cp->GetQHatModbsk();
+            auto QHatModmt  = cp->GetQHatModmtilde();
+            auto QModbsk    = cp->GetQModbsk();
+            uint64_t negQInv = cp->GetNegQInvModmtilde();
+            auto mtInvModbsk = cp->GetmtildeInvModbsk();
+            auto tQHatInv    = cp->GettQHatInvModq();
+            auto qInvModbsk  = cp->GetqInvModbsk();
+            auto tQInvModbsk = cp->GettQInvModbsk();
+            auto BHatInv     = cp->GetBHatInvModb();
+            auto BHatModmsk  = cp->GetBHatModmsk();
+            auto BInvModmsk  = cp->GetBInvModmsk();
+            auto BHatModq    = cp->GetBHatModq();
+            auto BModq       = cp->GetBModq();
+            const NativeInteger msk = Bsk.back();
+            std::vector<NativeInteger> B(Bsk.begin(), Bsk.end() - 1);
+            if (run == 1) {
+                bump(mtQHatInv[0], Q[0], 1);
+                bump(QHatModbsk[0][1], Bsk[1], 3);
+                QHatModmt[0] = (QHatModmt[0] + 7) & 0xffff;
+                bump(QModbsk[0], Bsk[0], 11);
+                negQInv = (negQInv ^ 0x55) & 0xffff;
+                bump(mtInvModbsk[1], Bsk[1], 5);
+                bump(tQHatInv[0], Q[0], 1);
+                bump(qInvModbsk[1][0], Bsk[0], 2);
+                bump(tQInvModbsk[0], Bsk[0], 9);
+                bump(BHatInv[0], B[0], 1);
+                bump(BHatModmsk[0], msk, 4);
+                bump(BInvModmsk, msk, 1);
+                bump(BHatModq[0][0], Q[0], 1);
+                bump(BModq[0], Q[0], 5);
+            }
+            DCRTPoly a = cx->GetElements()[0];
+            a.FastBaseConvqToBskMontgomery(cp->GetParamsQBsk(), Q, Bsk, cp->GetModbskBarrettMu(), mtQHatInv, precon(mtQHatInv, Q), QHatModbsk,
+                                           QHatModmt, QModbsk, precon(QModbsk, Bsk), negQInv, mtInvModbsk, precon(mtInvModbsk, Bsk));
+            dumpTower(run ? "q->Bsk, perturbed tables" : "q->Bsk", a);
+            a.SetFormat(Format::COEFFICIENT);
+            a.FastRNSFloorq(NativeInteger(65537), Q, Bsk, cp->GetModbskBarrettMu(), tQHatInv, precon(tQHatInv, Q), QHatModbsk, qInvModbsk,
+                            tQInvModbsk, precon(tQInvModbsk, Bsk));
+            dumpTower(run ? "floor, perturbed tables" : "floor", a);
+            a.FastBaseConvSK(cp->GetElementParams(), cp->GetModqBarrettMu(), Bsk, cp->GetModbskBarrettMu(), BHatInv, precon(BHatInv, B), BHatModmsk,
+                             BInvModmsk, BInvModmsk.PrepModMulConst(msk), BHatModq, BModq, precon(BModq, Q));
+            dumpTower(run ? "SK, perturbed tables" : "SK", a);
         }
     }
     else if (mode == "multbatch") {
@@ -192,6 +291,7 @@ int main(int argc, char** argv) {
         const auto cp = std::dynamic_pointer_cast<CryptoParametersRNS>(cc->GetCryptoParameters());
         std::cout << "multbatch ring 2^" << logN << " sizeQ " << a[0]->GetElements()[0].GetNumOfElements() << " sizeP "
                   << cp->GetParamsP()->GetParams().size() << " dnum " << cp->GetNumPartQ() << " ciphertexts " << B << std::endl;
+        evaluation_phase_begins();
         auto pass = [&] {
 #pragma omp parallel for schedule(dynamic, 1)
             for (int i = 0; i < B; ++i)
@@ -230,6 +330,7 @@ int main(int argc, char** argv) {
         auto cx = cc->Encrypt(kp.publicKey, cc->MakePackedPlaintext(x));
         auto cy = cc->Encrypt(kp.publicKey, cc->MakePackedPlaintext(y));
         dump("x", cx);
+        evaluation_phase_begins();
         auto m = cc->EvalMult(cx, cy);
         dump("x*y", m);
         auto r = cc->ModReduce(m);
@@ -389,6 +490,7 @@ int main(int argc, char** argv) {
         auto pt = cc->MakeCKKSPackedPlaintext(x, 1, depth - 1, nullptr, slots);
         auto c  = cc->Encrypt(kp.publicKey, pt);
         dump("in", c);
+        evaluation_phase_begins();
         auto b = cc->EvalBootstrap(c);
         dump("bootstrapped", b);
         std::cout << "levels remaining " << depth - b->GetLevel() - (b->GetNoiseScaleDeg() - 1) << std::endl;
@@ -398,6 +500,16 @@ int main(int argc, char** argv) {
     if (fhe_hal_stats) {
         uint64_t st[4];
         fhe_hal_stats(st);
+        if (fhe_hal_member_stats) {  // "halmember <member> <device ops> <host-mirror executions> <host reads after a device->host copy>"
+            std::string buf(fhe_hal_member_stats(nullptr, 0), '\0');
+            fhe_hal_member_stats(&buf[0], buf.size());
+            size_t at = 0;
+            while (at < buf.size() && buf[at]) {
+                const size_t nl = buf.find('\n', at);
+                std::cout << "halmember " << buf.substr(at, nl - at) << std::endl;
+                at = nl + 1;
+            }
+        }
         std::cout << "hal: available " << (fhe_hal_available ? fhe_hal_available() : -1) << " deviceOps " << st[0] << " hostOps " << st[1]
                   << " h2dBytes " << st[2] << " d2hBytes " << st[3] << std::endl;
     }

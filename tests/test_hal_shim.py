@@ -6,7 +6,12 @@ backend) and against openfhe-development_amd/hal/_build (HIP backend) — and ru
 processes draw the same keys and randomness.  Every ciphertext either run produces (fresh encryptions, EvalMult + HYBRID key
 switch, Rescale, EvalRotate, a second multiplication one level down, a plaintext-constant multiplication; and the input /
 output of FHECKKSRNS::EvalBootstrap) is dumped limb by limb; the dumps must be IDENTICAL byte for byte, the decryptions must
-be right, and the shim run must report device operations (fhe_hal_stats)."""
+be right, and — member by member (fhe_hal_member_stats, counted over the evaluation phase and the final decryptions) — the
+evaluation ran on the DEVICE: the class's host mirror is the reference's own DCRTPolyImpl, so a member that fell back to it would
+compare the reference with itself.  Every member with a device path must show ZERO host-mirror executions (DEVICE_MEMBERS), the
+total of host-mirror executions must be the committed constant (0 for every program here), device -> host copies happen only
+for the members that hand words to the caller (HOST_READERS), and FHE_HAL_REQUIRE_DEVICE=1 makes the backend itself throw if a
+device member ever degrades."""
 import os
 import re
 import subprocess
@@ -27,6 +32,36 @@ def ensure_built():
         pytest.skip("tests/hal/_build not present and /root/reference not mounted")
 
 
+# the members SURVEY.md 8(a) a6-a19 name (+ the backend's row-level helpers behind pke's limb loops): no host-mirror execution allowed
+DEVICE_MEMBERS = {"SwitchFormat", "operator+=", "operator-=", "operator*=", "Plus", "Minus", "Times", "TimesNoCheck", "Negate", "operator-",
+                  "AutomorphismTransform", "ApproxSwitchCRTBasis", "ApproxModUp", "ApproxModDown", "SwitchCRTBasis", "ExpandCRTBasis",
+                  "ExpandCRTBasisReverseOrder", "FastExpandCRTBasisPloverQ", "ExpandCRTBasisQlHat", "ScaleAndRound", "ApproxScaleAndRound",
+                  "ScaleAndRoundPOverQ", "FastBaseConvqToBskMontgomery", "FastRNSFloorq", "FastBaseConvSK", "DropLastElementAndScale",
+                  "ModReduce", "CloneTowers", "TimesQovert", "AssembleRows", "InnerProduct", "MultAccRows", "ModRaise", "DropLastElement",
+                  "DropLastElements", "SetValuesToZero"}
+# members that exist to hand words to the caller: the dumps of this test (GetAllElements), the decoders of Decrypt (CRTInterpolate ...)
+HOST_READERS = {"GetAllElements", "CRTInterpolate", "CRTInterpolateIndex", "DecryptionCRTInterpolate", "ToNativePoly", "operator=="}
+
+
+def member_stats(stdout):
+    """{member: (device ops, host-mirror executions, host reads)} of the evaluation phase"""
+    return {m.group(1): tuple(int(m.group(i)) for i in (2, 3, 4)) for m in re.finditer(r"halmember (\S+) (\d+) (\d+) (\d+)", stdout)}
+
+
+def assert_ran_on_device(stdout, must_run=(), host_ops=0):
+    st = member_stats(stdout)
+    assert st, "the backend reported no per-member counters"
+    on_mirror = {m: v[1] for m, v in st.items() if v[1] and m in DEVICE_MEMBERS}
+    assert not on_mirror, f"members with a device path executed on the host mirror: {on_mirror}"
+    total = sum(v[1] for v in st.values())
+    assert total == host_ops, f"host-mirror executions: {total}, committed constant {host_ops}: { {m: v[1] for m, v in st.items() if v[1]} }"
+    readers = {m: v[2] for m, v in st.items() if v[2] and m not in HOST_READERS}
+    assert not readers, f"device -> host copies outside the members that hand words to the caller: {readers}"
+    for m in must_run:
+        assert st.get(m, (0, 0, 0))[0] > 0, f"{m} did not run on the device"
+    return st
+
+
 def run(prog, out, mode, logN, device_lib=None, extra=(), threads=1):
     env = dict(os.environ, OMP_NUM_THREADS=str(threads))
     if device_lib:
@@ -43,7 +78,7 @@ def values(stdout, name):
     return [float(v) for v in m.group(1).replace("[", " ").replace("]", " ").split()]
 
 
-def check(tmp_path, mode, logN, device_lib, expect, extra=(), threads=1):
+def check(tmp_path, mode, logN, device_lib, expect, extra=(), threads=1, must_run=()):
     ensure_built()
     so, sh = str(tmp_path / "stock.bin"), str(tmp_path / "hip.bin")
     out_stock = run(PROGS[0], so, mode, logN, extra=extra, threads=threads)
@@ -53,6 +88,7 @@ def check(tmp_path, mode, logN, device_lib, expect, extra=(), threads=1):
     assert m and int(m.group(1)) == 1 and int(m.group(2)) > 0, out_hip[-500:]
     a, b = open(so, "rb").read(), open(sh, "rb").read()
     assert len(a) > 1000 and a == b, "the HIP backend's ciphertext limbs differ from the default backend's"
+    assert_ran_on_device(out_hip, must_run)
     for name, want in expect.items():
         for run_out in (out_stock, out_hip):
             got = values(run_out, name)
@@ -78,29 +114,40 @@ EMU = os.path.join(ROOT, "tests", "emu", "libfhe_emu.so")
 HIP = os.path.join(ROOT, "openfhe-development_amd", "csrc", "libfhe_hip.so")
 
 
+CKKS_MEMBERS = ("SwitchFormat", "Times", "operator+=", "ApproxSwitchCRTBasis", "ApproxModDown", "DropLastElementAndScale",
+                "AutomorphismTransform", "AssembleRows", "InnerProduct")
+BOOT_MEMBERS = CKKS_MEMBERS + ("ModRaise", "TimesNoCheck")
+BEHZ_MEMBERS = ("FastBaseConvqToBskMontgomery", "FastRNSFloorq", "FastBaseConvSK", "ScaleAndRound", "SwitchFormat", "ApproxModDown")
+HPS_MEMBERS = {"HPS": ("ExpandCRTBasis", "ScaleAndRound", "SwitchCRTBasis", "SwitchFormat", "ApproxModDown"),
+               "HPSPOVERQ": ("ExpandCRTBasis", "FastExpandCRTBasisPloverQ", "ScaleAndRound", "SwitchFormat", "ApproxModDown"),
+               "HPSPOVERQLEVELED": ("ExpandCRTBasis", "FastExpandCRTBasisPloverQ", "ExpandCRTBasisQlHat", "ScaleAndRound", "SwitchFormat",
+                                    "ApproxModDown")}
+BGV_MEMBERS = ("ApproxModDown", "ModReduce", "SwitchFormat", "AutomorphismTransform")
+
+
 def test_shim_leveled_ckks_matches_default_backend_on_emulator(tmp_path):
-    check(tmp_path, "leveled", 11, EMU, LEVELED)
+    check(tmp_path, "leveled", 11, EMU, LEVELED, must_run=CKKS_MEMBERS)
 
 
 @pytest.mark.parametrize("technique", ["FIXEDAUTO", "FLEXIBLEAUTOEXT"])
 def test_shim_automatic_scaling_techniques_on_emulator(tmp_path, technique):
     """the same circuit with rescaling / level adjustment done inside EvalMult / EvalAdd (FLEXIBLEAUTOEXT is the library default)"""
-    check(tmp_path, "leveled", 10, EMU, LEVELED, extra=(technique,))
+    check(tmp_path, "leveled", 10, EMU, LEVELED, extra=(technique,), must_run=CKKS_MEMBERS)
 
 
 def test_shim_bootstrap_matches_default_backend_on_emulator(tmp_path):
-    check(tmp_path, "bootstrap", 10, EMU, BOOT)
+    check(tmp_path, "bootstrap", 10, EMU, BOOT, must_run=BOOT_MEMBERS)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("logN", [12, 14])
 def test_shim_leveled_ckks_matches_default_backend_on_gpu(tmp_path, logN):
-    check(tmp_path, "leveled", logN, HIP, LEVELED)
+    check(tmp_path, "leveled", logN, HIP, LEVELED, must_run=CKKS_MEMBERS)
 
 
 @pytest.mark.gpu
 def test_shim_bootstrap_matches_default_backend_on_gpu(tmp_path):
-    ops = check(tmp_path, "bootstrap", 13, HIP, BOOT)
+    ops = check(tmp_path, "bootstrap", 13, HIP, BOOT, must_run=BOOT_MEMBERS)
     assert ops > 500  # ModRaise, the CoeffsToSlots / SlotsToCoeffs transforms and the Chebyshev evaluation ran on the device
 
 
@@ -108,15 +155,37 @@ def test_shim_bootstrap_matches_default_backend_on_gpu(tmp_path):
 # the BEHZ trio, ExpandCRTBasis, FastExpandCRTBasisPloverQ, ScaleAndRound, SwitchCRTBasis, ExpandCRTBasisQlHat as device members
 @pytest.mark.parametrize("tech", ["BEHZ", "HPSPOVERQ", "HPS", "HPSPOVERQLEVELED"])
 def test_shim_bfv_matches_default_backend_on_emulator(tmp_path, tech):
-    ops = check(tmp_path, "bfv", 10, EMU, BFV, extra=(tech,))
+    ops = check(tmp_path, "bfv", 10, EMU, BFV, extra=(tech,), must_run=BEHZ_MEMBERS if tech == "BEHZ" else HPS_MEMBERS[tech])
     assert ops > 100
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("tech,logN,depth", [("BEHZ", 13, 2), ("HPSPOVERQ", 13, 2), ("HPS", 12, 3), ("HPSPOVERQLEVELED", 12, 3), ("BEHZ", 15, 5)])
 def test_shim_bfv_matches_default_backend_on_gpu(tmp_path, tech, logN, depth):
-    ops = check(tmp_path, "bfv", logN, HIP, BFV, extra=(tech, depth))
+    ops = check(tmp_path, "bfv", logN, HIP, BFV, extra=(tech, depth), must_run=BEHZ_MEMBERS if tech == "BEHZ" else HPS_MEMBERS[tech])
     assert ops > 100
+
+
+def behz_tables(tmp_path, logN, device_lib):
+    ensure_built()
+    so, sh = str(tmp_path / "stock.bin"), str(tmp_path / "hip.bin")
+    run(PROGS[0], so, "behztables", logN)
+    out_hip = run(PROGS[1], sh, "behztables", logN, device_lib)
+    a, b = open(so, "rb").read(), open(sh, "rb").read()
+    assert len(a) > 1000 and a == b, "BEHZ members with the caller's (perturbed) tables differ from the default backend's"
+    assert a[:len(a) // 2] != a[len(a) // 2:], "the perturbed tables did not change the result: the test proves nothing"
+    assert_ran_on_device(out_hip, ("FastBaseConvqToBskMontgomery", "FastRNSFloorq", "FastBaseConvSK"))
+
+
+def test_shim_behz_members_use_the_callers_tables_on_emulator(tmp_path):
+    """FastBaseConvqToBskMontgomery / FastRNSFloorq / FastBaseConvSK called with tables that are NOT the ones CryptoParametersBFVRNS
+    derives (every table set perturbed): the device members compute with the arguments, as the reference's members do"""
+    behz_tables(tmp_path, 10, EMU)
+
+
+@pytest.mark.gpu
+def test_shim_behz_members_use_the_callers_tables_on_gpu(tmp_path):
+    behz_tables(tmp_path, 13, HIP)
 
 
 def test_shim_without_a_device_library_fails_loudly(tmp_path):
@@ -135,14 +204,14 @@ def test_shim_without_a_device_library_fails_loudly(tmp_path):
 # BGV: ApproxModDown with the plaintext modulus (t > 0) and ModReduce (dcrtpoly-impl.h:736-755, :966-1005) as device members
 @pytest.mark.parametrize("technique", ["FIXEDMANUAL", "FLEXIBLEAUTOEXT"])
 def test_shim_bgv_matches_default_backend_on_emulator(tmp_path, technique):
-    ops = check(tmp_path, "bgv", 10, EMU, BGV, extra=(technique,))
+    ops = check(tmp_path, "bgv", 10, EMU, BGV, extra=(technique,), must_run=BGV_MEMBERS)
     assert ops > 50
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("technique,logN", [("FIXEDMANUAL", 13), ("FLEXIBLEAUTOEXT", 14)])
 def test_shim_bgv_matches_default_backend_on_gpu(tmp_path, technique, logN):
-    ops = check(tmp_path, "bgv", logN, HIP, BGV, extra=(technique,))
+    ops = check(tmp_path, "bgv", logN, HIP, BGV, extra=(technique,), must_run=BGV_MEMBERS)
     assert ops > 50
 
 

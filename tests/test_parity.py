@@ -500,6 +500,15 @@ def test_hybrid_keyswitch_and_eval_mult(backend, oracle, logN, sizeQ, dnum, size
         o.orc_hybrid_key_switch(hy, a0[bb], sizeQl, keyB, keyA, w0[bb], w1[bb])
     g0, g1 = plan.KeySwitchCore(ctx.tower(a0))
     assert np.array_equal(g0.to_host(), w0) and np.array_equal(g1.to_host(), w1), "KeySwitchCore mismatch"
+    # ... and accumulated into two towers (`cv[0] += ab[0]; cv[1] += ab[1]`, base-leveledshe.cpp:210-211)
+    acc0, acc1 = ctx.tower(a1), ctx.tower(b0)
+    plan.KeySwitchCoreAcc(ctx.tower(a0), acc0, acc1)
+    wa0, wa1 = np.empty_like(a0), np.empty_like(a0)
+    for bb in range(B):
+        for l in range(sizeQl):
+            o.orc_vec_add(wa0[bb, l], a1[bb, l], w0[bb, l], N, ql[l])
+            o.orc_vec_add(wa1[bb, l], b0[bb, l], w1[bb, l], N, ql[l])
+    assert np.array_equal(acc0.to_host(), wa0) and np.array_equal(acc1.to_host(), wa1), "KeySwitchCore (accumulating) mismatch"
     # EvalMult = tensor + key switch + add
     c0 = np.empty_like(a0)
     c1 = np.empty_like(a0)
