@@ -8,6 +8,7 @@
 // FHE_HAL_REQUIRE_DEVICE=1 is the opposite switch: a member that HAS a device path and nevertheless executes on the host mirror
 // (a modulus outside the library's domain, a failed table build ...) throws instead of degrading silently.
 #include "lattice/hal/hip/hip-runtime.h"
+#include "hip-hooks.h"
 
 #include <cxxabi.h>
 #include <dlfcn.h>
@@ -15,6 +16,7 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -30,6 +32,18 @@
 
 namespace lbcrypto {
 namespace hiprt {
+
+// a device context and every plan built on it.  The registry keeps the current one of a ring dimension; an operation keeps the one
+// it resolved against (Resolved::hold); when a context has been replaced (new moduli appeared) and its last operation is over,
+// the context, its twiddle tables and its plans go away (hipFree waits for the kernels still queued on them).
+struct CtxHolder {
+    fhe_ctx* ctx = nullptr;
+    std::mutex mu;
+    std::map<std::vector<uint64_t>, fhe_conv*> convs;      // key = {nSrc, nDst, exact, idx..., table words...}
+    std::map<std::vector<uint64_t>, fhe_sr_plan*> srPlans;
+    std::map<std::vector<uint64_t>, fhe_behz*> behzPlans;  // key = {which, t, numQ, qIdx..., bskIdx..., table words...}
+    ~CtxHolder();
+};
 
 namespace {
 // ---- streams: one per host thread ----
@@ -57,17 +71,15 @@ struct Runtime {
     // contexts
     struct Universe {
         uint32_t logN = 0;
-        fhe_ctx* ctx  = nullptr;
+        std::shared_ptr<CtxHolder> cur;
         std::vector<uint64_t> q, psi;
         std::unordered_map<uint64_t, uint32_t> limbOf;  // modulus -> context limb
     };
     std::mutex ctxMutex;
     std::map<uint32_t, Universe> universes;  // by ring dimension
-    // plans
-    std::mutex convMutex;
-    std::map<std::vector<uint64_t>, fhe_conv*> convs;  // key = {ctx, nSrc, nDst, idx..., table words...}
-    std::map<std::vector<uint64_t>, fhe_sr_plan*> srPlans;
-    std::map<std::vector<uint64_t>, fhe_behz*> behzPlans;  // key = {ctx, which, t, numQ, qIdx..., bskIdx..., table words...}
+    // the holder of every live context (plan look-ups go ctx -> holder; the caller of a look-up holds a reference)
+    std::mutex holderMutex;
+    std::map<fhe_ctx*, CtxHolder*> holders;
     std::atomic<uint64_t> deviceOps{0}, hostFallbacks{0}, h2dBytes{0}, d2hBytes{0};
     bool requireDevice = false;
 };
@@ -97,6 +109,10 @@ Runtime* build() {
         Api& a = r->api;
 #define FHE_SYM(field, name) sym(h, #name, &a.field)
         bool ok = FHE_SYM(last_error, fhe_last_error) && FHE_SYM(device_count, fhe_device_count) && FHE_SYM(ctx_create, fhe_ctx_create) &&
+                  FHE_SYM(ctx_destroy, fhe_ctx_destroy) && FHE_SYM(conv_destroy, fhe_conv_destroy) && FHE_SYM(sr_plan_destroy, fhe_sr_plan_destroy) &&
+                  FHE_SYM(behz_destroy, fhe_behz_destroy) && FHE_SYM(ks_plan_destroy, fhe_ks_plan_destroy) &&
+                  FHE_SYM(keyswitch_hybrid_acc, fhe_keyswitch_hybrid_acc) && FHE_SYM(ks_precompute, fhe_ks_precompute) &&
+                  FHE_SYM(ks_fast_keyswitch, fhe_ks_fast_keyswitch) &&
                   FHE_SYM(malloc_, fhe_malloc) && FHE_SYM(free_, fhe_free) && FHE_SYM(h2d, fhe_memcpy_h2d) && FHE_SYM(d2h, fhe_memcpy_d2h) &&
                   FHE_SYM(d2d, fhe_memcpy_d2d) && FHE_SYM(memset_zero, fhe_memset_zero) && FHE_SYM(sync, fhe_stream_sync) &&
                   FHE_SYM(stream_create, fhe_stream_create) && FHE_SYM(stream_wait, fhe_stream_wait) && FHE_SYM(ntt_fwd, fhe_ntt_fwd) &&
@@ -153,6 +169,14 @@ Runtime* build() {
 Runtime& rt() {
     static Runtime* r = build();  // (never destroyed: device buffers of static objects may outlive main)
     return *r;
+}
+CtxHolder& holder_of(fhe_ctx* ctx) {
+    Runtime& r = rt();
+    std::lock_guard<std::mutex> lk(r.holderMutex);
+    auto it = r.holders.find(ctx);
+    if (it == r.holders.end())
+        OPENFHE_THROW("HIP backend: plan requested on a context the registry does not know");
+    return *it->second;
 }
 uint32_t log2u(uint32_t n) {
     uint32_t l = 0;
@@ -252,6 +276,20 @@ DevBuf* root_of(DevBuf* b) {
 }
 }  // namespace
 
+CtxHolder::~CtxHolder() {
+    Runtime& r = rt();
+    {
+        std::lock_guard<std::mutex> lk(r.holderMutex);
+        r.holders.erase(ctx);
+    }
+    for (auto& kv : convs)
+        r.api.conv_destroy(kv.second);
+    for (auto& kv : srPlans)
+        r.api.sr_plan_destroy(kv.second);
+    for (auto& kv : behzPlans)
+        r.api.behz_destroy(kv.second);
+    r.api.ctx_destroy(ctx);
+}
 bool Available() { return rt().live; }
 const Api& api() { return rt().api; }
 int Device() { return rt().device; }
@@ -508,7 +546,7 @@ bool Resolve(uint32_t ringDim, const std::vector<LimbSet>& sets, Resolved* out) 
     std::lock_guard<std::mutex> lk(r.ctxMutex);
     auto& u = r.universes[ringDim];
     // fast path: every modulus is known (the usual case after the first few operations of a CryptoContext)
-    bool known = u.ctx != nullptr;
+    bool known = u.cur != nullptr;
     for (size_t si = 0; known && si < sets.size(); ++si)
         for (uint32_t i = 0; known && i < sets[si].n; ++i)
             known = u.limbOf.count(sets[si].q[i]) != 0;
@@ -532,13 +570,20 @@ bool Resolve(uint32_t ringDim, const std::vector<LimbSet>& sets, Resolved* out) 
         fhe_ctx* c = nullptr;
         if (r.api.ctx_create(log2u(ringDim), (uint32_t)q.size(), q.data(), psi.data(), r.device, &c) != FHE_OK)
             return false;  // (e.g. a root that is not primitive: leave the operation to the host mirror)
-        // the previous context stays alive: operations of other threads may still be using its tables
-        u.ctx = c, u.q = q, u.psi = psi, u.logN = log2u(ringDim);
+        // the previous context lives on while operations of other threads hold it (Resolved::hold), then it is destroyed
+        auto h = std::make_shared<CtxHolder>();
+        h->ctx = c;
+        {
+            std::lock_guard<std::mutex> hl(r.holderMutex);
+            r.holders[c] = h.get();
+        }
+        u.cur = std::move(h), u.q = q, u.psi = psi, u.logN = log2u(ringDim);
         u.limbOf.clear();
         for (uint32_t k = 0; k < q.size(); ++k)
             u.limbOf[q[k]] = k;
     }
-    out->ctx = u.ctx;
+    out->ctx  = u.cur->ctx;
+    out->hold = u.cur;
     out->idx.assign(sets.size(), {});
     for (size_t si = 0; si < sets.size(); ++si) {
         out->idx[si].resize(sets[si].n);
@@ -559,7 +604,6 @@ fhe_conv* ConvPlan(fhe_ctx* ctx, const std::vector<uint32_t>& srcIdx, const std:
     const size_t nSrc = srcIdx.size(), nDst = dstIdx.size();
     std::vector<uint64_t> key;
     key.reserve(4 + nSrc + nDst + nSrc + nSrc * nDst + (alphaMod ? (nSrc + 1) * nDst + nSrc : 0));
-    key.push_back(reinterpret_cast<uintptr_t>(ctx));
     key.push_back(nSrc);
     key.push_back(nDst);
     key.push_back(alphaMod ? 1 : 0);
@@ -575,21 +619,22 @@ fhe_conv* ConvPlan(fhe_ctx* ctx, const std::vector<uint32_t>& srcIdx, const std:
             key.push_back(w);
         }
     }
-    std::lock_guard<std::mutex> lk(r.convMutex);
-    auto it = r.convs.find(key);
-    if (it != r.convs.end())
+    CtxHolder& H = holder_of(ctx);
+    std::lock_guard<std::mutex> lk(H.mu);
+    auto it = H.convs.find(key);
+    if (it != H.convs.end())
         return it->second;
     fhe_conv* cv = nullptr;
     Check(r.api.conv_create_custom(ctx, srcIdx.data(), (uint32_t)nSrc, dstIdx.data(), (uint32_t)nDst, hatInv, hatMod, alphaMod, qInv, &cv),
           "HIP backend: basis-conversion plan");
-    r.convs.emplace(std::move(key), cv);
+    H.convs.emplace(std::move(key), cv);
     return cv;
 }
 
 fhe_sr_plan* SrPlan(fhe_ctx* ctx, uint32_t sizeI, const std::vector<uint32_t>& outIdx, const uint64_t* tab, const double* frac) {
     Runtime& r         = rt();
     const size_t sizeO = outIdx.size();
-    std::vector<uint64_t> key{reinterpret_cast<uintptr_t>(ctx), sizeI, sizeO, frac ? 1u : 0u};
+    std::vector<uint64_t> key{sizeI, sizeO, frac ? 1u : 0u};
     key.insert(key.end(), outIdx.begin(), outIdx.end());
     key.insert(key.end(), tab, tab + sizeO * (sizeI + 1));
     for (uint32_t i = 0; frac && i < sizeI; ++i) {
@@ -597,13 +642,14 @@ fhe_sr_plan* SrPlan(fhe_ctx* ctx, uint32_t sizeI, const std::vector<uint32_t>& o
         std::memcpy(&w, frac + i, 8);
         key.push_back(w);
     }
-    std::lock_guard<std::mutex> lk(r.convMutex);
-    auto it = r.srPlans.find(key);
-    if (it != r.srPlans.end())
+    CtxHolder& H = holder_of(ctx);
+    std::lock_guard<std::mutex> lk(H.mu);
+    auto it = H.srPlans.find(key);
+    if (it != H.srPlans.end())
         return it->second;
     fhe_sr_plan* p = nullptr;
     Check(r.api.sr_plan_create(ctx, sizeI, outIdx.data(), (uint32_t)sizeO, tab, frac, &p), "HIP backend: ScaleAndRound plan");
-    r.srPlans.emplace(std::move(key), p);
+    H.srPlans.emplace(std::move(key), p);
     return p;
 }
 // One plan per (bases, member, content of the member's table arguments): the plan is created with derived tables (which also fixes
@@ -621,13 +667,14 @@ fhe_behz* BehzPlan(fhe_ctx* ctx, const std::vector<uint32_t>& qIdx, const std::v
                                    : which == 1 ? numQ + 2 * numQ * numBsk + numBsk : numQ + numQ + 1 + numQ * numQ + numQ;
     if (tables.size() != need)
         return nullptr;
-    std::vector<uint64_t> key{reinterpret_cast<uintptr_t>(ctx), (uint64_t)which, t, numQ};
+    std::vector<uint64_t> key{(uint64_t)which, t, numQ};
     key.insert(key.end(), qIdx.begin(), qIdx.end());
     key.insert(key.end(), bskIdx.begin(), bskIdx.end());
     key.insert(key.end(), tables.begin(), tables.end());
-    std::lock_guard<std::mutex> lk(r.convMutex);
-    auto it = r.behzPlans.find(key);
-    if (it != r.behzPlans.end())
+    CtxHolder& H = holder_of(ctx);
+    std::lock_guard<std::mutex> lk(H.mu);
+    auto it = H.behzPlans.find(key);
+    if (it != H.behzPlans.end())
         return it->second;
     fhe_behz* p = nullptr;
     if (r.api.behz_create(ctx, qIdx.data(), (uint32_t)numQ, bskIdx.data(), t ? t : 65537, &p) != FHE_OK)
@@ -642,7 +689,7 @@ fhe_behz* BehzPlan(fhe_ctx* ctx, const std::vector<uint32_t>& qIdx, const std::v
     else
         s = r.api.behz_override_conv_sk(p, T, T + numQ, T[2 * numQ], T + 2 * numQ + 1, T + 2 * numQ + 1 + numQ * numQ);
     Check(s, "HIP backend: BEHZ plan from the caller's tables");
-    r.behzPlans.emplace(std::move(key), p);
+    H.behzPlans.emplace(std::move(key), p);
     return p;
 }
 
@@ -684,6 +731,143 @@ bool IsAutoMap(uint32_t n, uint32_t k, const std::vector<uint32_t>& vec) {
     const auto tab = auto_map(n, k);
     return std::memcmp(tab->data(), vec.data(), (size_t)n * 4) == 0;
 }
+
+// ---- key-switching domains for the batched composites (hip-hooks.h) ----
+struct KsDomain {
+    fhe_ctx* ctx      = nullptr;
+    fhe_ks_plan* plan = nullptr;
+    uint32_t sizeQ = 0, sizeP = 0, numPartQ = 0;
+    size_t N = 0;
+    std::mutex mu;
+    struct Entry {
+        PackedKey pk;
+        std::vector<Buf> sources;  // kept alive: their identity IS the cache key
+        uint64_t lastUse = 0;
+    };
+    std::map<std::vector<const DevBuf*>, Entry> keys;
+    uint64_t tick = 0;
+    std::array<std::vector<uint8_t>, kCompositeKinds> checked;
+    ~KsDomain() {
+        Runtime& r = rt();
+        keys.clear();
+        if (plan)
+            r.api.ks_plan_destroy(plan);
+        if (ctx)
+            r.api.ctx_destroy(ctx);
+    }
+};
+namespace {
+std::mutex g_domainMutex;
+std::vector<std::pair<std::vector<uint64_t>, std::shared_ptr<KsDomain>>> g_domains;  // most recently used first
+std::atomic<uint64_t> g_compositeCalls{0}, g_checksOk{0}, g_checksBad{0};
+}  // namespace
+std::shared_ptr<KsDomain> GetKsDomain(uint32_t ringDim, const LimbSet& Q, const LimbSet& P, uint32_t numPartQ) {
+    Runtime& r = rt();
+    if (!r.live || ringDim < 16 || ringDim > (1u << 17) || (ringDim & (ringDim - 1)) || Q.n == 0 || P.n == 0 || Q.n + P.n > 128 || numPartQ == 0)
+        return nullptr;
+    std::vector<uint64_t> key{ringDim, numPartQ, Q.n, P.n};
+    key.insert(key.end(), Q.q, Q.q + Q.n);
+    key.insert(key.end(), Q.psi, Q.psi + Q.n);
+    key.insert(key.end(), P.q, P.q + P.n);
+    key.insert(key.end(), P.psi, P.psi + P.n);
+    std::lock_guard<std::mutex> lk(g_domainMutex);
+    for (size_t i = 0; i < g_domains.size(); ++i)
+        if (g_domains[i].first == key) {
+            auto hit = g_domains[i];
+            g_domains.erase(g_domains.begin() + i);
+            g_domains.insert(g_domains.begin(), hit);
+            return hit.second;
+        }
+    const uint64_t twoN = 2ull * ringDim;
+    std::vector<uint64_t> q(Q.q, Q.q + Q.n), psi(Q.psi, Q.psi + Q.n);
+    q.insert(q.end(), P.q, P.q + P.n);
+    psi.insert(psi.end(), P.psi, P.psi + P.n);
+    for (size_t i = 0; i < q.size(); ++i)
+        if (q[i] < 3 || q[i] >= (1ull << 60) || (q[i] - 1) % twoN != 0 || psi[i] == 0)
+            return nullptr;
+    auto d = std::make_shared<KsDomain>();
+    if (r.api.ctx_create(log2u(ringDim), (uint32_t)q.size(), q.data(), psi.data(), r.device, &d->ctx) != FHE_OK)
+        return nullptr;
+    if (r.api.ks_plan_create(d->ctx, Q.n, P.n, numPartQ, &d->plan) != FHE_OK)
+        return nullptr;
+    d->sizeQ = Q.n, d->sizeP = P.n, d->numPartQ = numPartQ, d->N = ringDim;
+    for (auto& c : d->checked)
+        c.assign(Q.n + 1, 0);
+    g_domains.insert(g_domains.begin(), {key, d});
+    if (g_domains.size() > 4)  // (a domain holds twiddle tables for Q u P and packed copies of its keys)
+        g_domains.pop_back();
+    return d;
+}
+fhe_ctx* DomainCtx(const KsDomain& d) { return d.ctx; }
+fhe_ks_plan* DomainPlan(const KsDomain& d) { return d.plan; }
+PackedKey DomainKey(KsDomain& d, const std::vector<Buf>& b, const std::vector<Buf>& a, Op& op) {
+    Runtime& r = rt();
+    PackedKey none;
+    if (b.size() != d.numPartQ || a.size() != d.numPartQ)
+        return none;
+    const size_t towerWords = (size_t)(d.sizeQ + d.sizeP) * d.N;
+    std::vector<const DevBuf*> id;
+    for (const auto& x : b)
+        id.push_back(x.get());
+    for (const auto& x : a)
+        id.push_back(x.get());
+    for (const auto* x : id)
+        if (!x || x->words < towerWords)
+            return none;
+    std::lock_guard<std::mutex> lk(d.mu);
+    auto it = d.keys.find(id);
+    if (it != d.keys.end()) {
+        it->second.lastUse = ++d.tick;
+        return it->second.pk;
+    }
+    if (d.keys.size() >= 160) {  // (a bootstrapping key set is 60-70 keys) drop the least recently used one
+        auto victim = d.keys.begin();
+        for (auto jt = d.keys.begin(); jt != d.keys.end(); ++jt)
+            if (jt->second.lastUse < victim->second.lastUse)
+                victim = jt;
+        d.keys.erase(victim);
+    }
+    KsDomain::Entry e;
+    e.pk.b = Alloc(towerWords * d.numPartQ);
+    e.pk.a = Alloc(towerWords * d.numPartQ);
+    uint64_t *pb = op.W(e.pk.b), *pa = op.W(e.pk.a);
+    for (uint32_t j = 0; j < d.numPartQ; ++j) {
+        D2D(op, pb + j * towerWords, op.R(b[j]), towerWords * 8, "evaluation key packed for the key-switching plan");
+        D2D(op, pa + j * towerWords, op.R(a[j]), towerWords * 8, "evaluation key packed for the key-switching plan");
+    }
+    fhe_ks_key* raw = nullptr;
+    Check(r.api.ks_key_wrap(d.plan, pb, pa, &raw), "HIP backend: evaluation key for the key-switching plan");
+    e.pk.key = std::shared_ptr<fhe_ks_key>(raw, [](fhe_ks_key* k) { rt().api.ks_key_destroy(k); });
+    e.sources = b;
+    e.sources.insert(e.sources.end(), a.begin(), a.end());
+    e.lastUse = ++d.tick;
+    PackedKey out = e.pk;
+    d.keys.emplace(std::move(id), std::move(e));
+    return out;
+}
+int DomainChecked(const KsDomain& d, CompositeKind kind, uint32_t sizeQl) {
+    return sizeQl < d.checked[kind].size() ? d.checked[kind][sizeQl] : 2;
+}
+void DomainSetChecked(KsDomain& d, CompositeKind kind, uint32_t sizeQl, bool identical) {
+    std::lock_guard<std::mutex> lk(d.mu);
+    if (sizeQl < d.checked[kind].size())
+        d.checked[kind][sizeQl] = identical ? 1 : 2;
+    (identical ? g_checksOk : g_checksBad).fetch_add(1);
+    if (!identical)
+        std::fprintf(stderr, "HIP backend: the batched composite %u differs from the member-by-member path at level %u: composite disabled for it\n",
+                     (unsigned)kind, sizeQl);
+}
+std::vector<uint64_t> Checksums(fhe_ctx* ctx, const Buf& words, uint32_t rows) {
+    Runtime& r = rt();
+    std::vector<uint64_t> out((size_t)rows * 2);
+    Op op;
+    auto d = Alloc(out.size());
+    Check(r.api.checksum(ctx, op.R(words), rows, op.W(d), op.s), "HIP backend: checksums");
+    Check(r.api.d2h(r.anyCtx, out.data(), d->p, out.size() * 8, op.s), "HIP backend: checksums");
+    op.HostSync();
+    return out;
+}
+void CountComposite() { g_compositeCalls.fetch_add(1, std::memory_order_relaxed); }
 
 }  // namespace hiprt
 }  // namespace lbcrypto
@@ -736,4 +920,7 @@ extern "C" void fhe_hal_trace_reset(void) {
     std::lock_guard<std::mutex> lk(lbcrypto::hiprt::g_traceMutex);
     if (lbcrypto::hiprt::g_traceSites)
         lbcrypto::hiprt::g_traceSites->clear();
+}
+extern "C" void fhe_hal_composite_stats(uint64_t out[3]) {
+    out[0] = lbcrypto::hiprt::g_compositeCalls, out[1] = lbcrypto::hiprt::g_checksOk, out[2] = lbcrypto::hiprt::g_checksBad;
 }

@@ -193,3 +193,290 @@ void LeveledSHECKKSRNS::EvalMultCoreInPlace(Ciphertext<DCRTPoly>& ciphertext, do
 }
 
 }  // namespace lbcrypto
+
+// ---- whole pke operations as ONE call of the device library --------------------------------------------------------------------
+// Through the class surface an EvalMult is ~40 tower operations (each a launch or two, each with its own buffers); the device library
+// has the same sequence as one composite over a key-switching plan (fhe_keyswitch_hybrid_acc: digit decomposition, ModUp of every
+// digit, inner product with the key, both ModDowns, the two accumulations fused into the last kernel).  The hooks below route
+//   LeveledSHEBase<DCRTPoly>::EvalMultCore / EvalSquareCore  (base-leveledshe.cpp:607-664)  -> one tensor kernel
+//   LeveledSHEBase<DCRTPoly>::EvalMult(ct, ct, key) / EvalSquare(ct, key)  (:201-214, :281-293) -> + ONE composite key switch
+// to it.  The composite derives its CRT tables from the moduli; the member-by-member path computes with the tables pke passes (the
+// reference's CryptoParameters).  So the FIRST use of a composite at a level runs both and compares every word on the device
+// (checksums): only a composite that reproduced the member-by-member result is used from then on (hiprt::DomainChecked).
+// LeveledSHEBase's members are template instantiations (weak symbols in the reference's object): the explicit specialisations here
+// are the strong definitions the library links.
+#include "hip-hooks.h"
+#include "schemebase/base-leveledshe.h"
+
+namespace lbcrypto {
+namespace {
+void LimbsOfParams(const std::shared_ptr<DCRTPoly::Params>& p, std::vector<uint64_t>& q, std::vector<uint64_t>& psi) {
+    const auto& v = p->GetParams();
+    q.resize(v.size()), psi.resize(v.size());
+    for (size_t i = 0; i < v.size(); ++i) {
+        q[i]   = v[i]->GetModulus().ConvertToInt<uint64_t>();
+        psi[i] = v[i]->GetRootOfUnity().ConvertToInt<uint64_t>();
+    }
+}
+// the key-switching domain of a parameter set, and the level of a tower in it (0: the tower is not a prefix of Q)
+std::shared_ptr<hiprt::KsDomain> DomainOf(const std::shared_ptr<CryptoParametersRNS>& cp, const DCRTPoly& c, uint32_t* sizeQl) {
+    if (!hiprt::Available() || !cp || cp->GetKeySwitchTechnique() != HYBRID)
+        return nullptr;
+    std::vector<uint64_t> q, psiQ, p, psiP, ql, psiQl;
+    LimbsOfParams(cp->GetElementParams(), q, psiQ);
+    LimbsOfParams(cp->GetParamsP(), p, psiP);
+    LimbsOfParams(c.GetParams(), ql, psiQl);
+    if (ql.empty() || ql.size() > q.size() || !std::equal(ql.begin(), ql.end(), q.begin()) || !std::equal(psiQl.begin(), psiQl.end(), psiQ.begin()))
+        return nullptr;
+    const uint32_t numPartQ = cp->GetNumPartQ();
+    if (numPartQ == 0 || cp->GetNumPerPartQ() != (q.size() + numPartQ - 1) / numPartQ)
+        return nullptr;  // (a digit partition the plan does not derive the same way)
+    *sizeQl = (uint32_t)ql.size();
+    return hiprt::GetKsDomain(c.GetParams()->GetRingDimension(), hiprt::LimbSet{q.data(), psiQ.data(), (uint32_t)q.size()},
+                              hiprt::LimbSet{p.data(), psiP.data(), (uint32_t)p.size()}, numPartQ);
+}
+bool KeyBuffers(const EvalKey<DCRTPoly>& evalKey, size_t numPartQ, size_t limbs, std::vector<hiprt::Buf>& b, std::vector<hiprt::Buf>& a) {
+    const auto &bv = evalKey->GetBVector(), &av = evalKey->GetAVector();
+    if (bv.size() != numPartQ || av.size() != numPartQ)
+        return false;
+    for (size_t j = 0; j < numPartQ; ++j) {
+        if (bv[j].GetNumOfElements() != limbs || av[j].GetNumOfElements() != limbs || bv[j].GetFormat() != Format::EVALUATION ||
+            av[j].GetFormat() != Format::EVALUATION)
+            return false;
+        b.push_back(bv[j].DeviceWords());
+        a.push_back(av[j].DeviceWords());
+        if (!b.back() || !a.back())
+            return false;
+    }
+    return true;
+}
+// acc0 += ks0(c), acc1 += ks1(c) in one call; false: the composite cannot take these towers
+bool CompositeKeySwitchAcc(hiprt::KsDomain& dom, uint32_t sizeQl, const std::vector<hiprt::Buf>& kb, const std::vector<hiprt::Buf>& ka, DCRTPoly& acc0,
+                           DCRTPoly& acc1, const DCRTPoly& c) {
+    auto b0 = acc0.DeviceWordsForUpdate(), b1 = acc1.DeviceWordsForUpdate();
+    auto bc = c.DeviceWords();
+    if (!b0 || !b1 || !bc)
+        return false;
+    const auto& A = hiprt::api();
+    hiprt::Op op;
+    hiprt::PackedKey pk = hiprt::DomainKey(dom, kb, ka, op);
+    if (!pk.key)
+        return false;
+    const size_t wsB = A.ks_workspace_bytes(hiprt::DomainPlan(dom), sizeQl, 1);
+    auto ws          = hiprt::Alloc(wsB / 8 + 1);
+    op.R(pk.b), op.R(pk.a);
+    hiprt::Check(A.keyswitch_hybrid_acc(hiprt::DomainPlan(dom), pk.key.get(), op.R(bc), sizeQl, 1, op.W(b0), op.W(b1), op.W(ws), wsB, op.s),
+                 "EvalMult: composite key switch");
+    hiprt::CountDevice("EvalMult.KeySwitchAccumulate");
+    hiprt::CountComposite();
+    return true;
+}
+// cv[0] += ks0(cv[2]); cv[1] += ks1(cv[2])  (base-leveledshe.cpp:207-211) — composite when it applies and has been checked at this level
+void KeySwitchAccumulate(const Ciphertext<DCRTPoly>& ciphertext, const EvalKey<DCRTPoly>& evalKey) {
+    auto& cv = ciphertext->GetElements();
+    uint32_t sizeQl = 0;
+    std::shared_ptr<hiprt::KsDomain> dom;
+    std::vector<hiprt::Buf> kb, ka;
+    const auto cp = std::dynamic_pointer_cast<CryptoParametersRNS>(evalKey->GetCryptoParameters());
+    bool usable   = cv.size() == 3 && cv[0].GetFormat() == Format::EVALUATION && cv[1].GetFormat() == Format::EVALUATION &&
+                  cv[2].GetFormat() == Format::EVALUATION && cv[0].GetNumOfElements() == cv[2].GetNumOfElements() &&
+                  cv[1].GetNumOfElements() == cv[2].GetNumOfElements();
+    if (usable)
+        dom = DomainOf(cp, cv[2], &sizeQl);
+    usable = usable && dom && hiprt::DomainChecked(*dom, hiprt::kKeySwitchAcc, sizeQl) != 2 &&
+             KeyBuffers(evalKey, cp->GetNumPartQ(), cp->GetParamsQP()->GetParams().size(), kb, ka);
+    if (usable && hiprt::DomainChecked(*dom, hiprt::kKeySwitchAcc, sizeQl) == 1 && CompositeKeySwitchAcc(*dom, sizeQl, kb, ka, cv[0], cv[1], cv[2]))
+        return;
+    // the reference's lines (member by member, with the reference's tables) ...
+    DCRTPoly try0, try1;
+    bool tried = false;
+    if (usable) {  // ... and, at the first use of this level, the composite on copies, compared word for word on the device
+        try0 = cv[0], try1 = cv[1];
+        tried = CompositeKeySwitchAcc(*dom, sizeQl, kb, ka, try0, try1, cv[2]);
+    }
+    auto ab = ciphertext->GetCryptoContext()->GetScheme()->KeySwitchCore(cv[2], evalKey);
+    cv[0] += (*ab)[0];
+    cv[1] += (*ab)[1];
+    if (tried) {
+        auto r0 = cv[0].DeviceWords(), r1 = cv[1].DeviceWords(), t0 = try0.DeviceWords(), t1 = try1.DeviceWords();
+        const bool same = r0 && r1 && t0 && t1 && hiprt::Checksums(hiprt::DomainCtx(*dom), r0, sizeQl) == hiprt::Checksums(hiprt::DomainCtx(*dom), t0, sizeQl) &&
+                          hiprt::Checksums(hiprt::DomainCtx(*dom), r1, sizeQl) == hiprt::Checksums(hiprt::DomainCtx(*dom), t1, sizeQl);
+        hiprt::DomainSetChecked(*dom, hiprt::kKeySwitchAcc, sizeQl, same);
+    }
+}
+}  // namespace
+
+// base-leveledshe.cpp:201-214
+template <>
+Ciphertext<DCRTPoly> LeveledSHEBase<DCRTPoly>::EvalMult(ConstCiphertext<DCRTPoly>& ciphertext1, ConstCiphertext<DCRTPoly>& ciphertext2,
+                                                        const EvalKey<DCRTPoly> evalKey) const {
+    auto ciphertext = EvalMult(ciphertext1, ciphertext2);
+    hiprt::MemberScope scope("EvalMult.KeySwitchAccumulate");
+    KeySwitchAccumulate(ciphertext, evalKey);
+    ciphertext->GetElements().resize(2);
+    return ciphertext;
+}
+// base-leveledshe.cpp:281-293
+template <>
+Ciphertext<DCRTPoly> LeveledSHEBase<DCRTPoly>::EvalSquare(ConstCiphertext<DCRTPoly>& ciphertext, const EvalKey<DCRTPoly> evalKey) const {
+    auto csquare = EvalSquare(ciphertext);
+    hiprt::MemberScope scope("EvalMult.KeySwitchAccumulate");
+    KeySwitchAccumulate(csquare, evalKey);
+    csquare->GetElements().resize(2);
+    return csquare;
+}
+
+// base-leveledshe.cpp:607-644: the product of two 2-element ciphertexts as one tensor kernel; every other shape as in the reference
+template <>
+Ciphertext<DCRTPoly> LeveledSHEBase<DCRTPoly>::EvalMultCore(ConstCiphertext<DCRTPoly>& ctxt1, ConstCiphertext<DCRTPoly>& ctxt2) const {
+    VerifyNumOfTowers(ctxt1, ctxt2);
+    auto& cv1 = ctxt1->GetElements();
+    auto& cv2 = ctxt2->GetElements();
+    const uint32_t n1 = cv1.size(), n2 = cv2.size(), nr = n1 + n2 - 1;
+    std::vector<DCRTPoly> cvr;
+    if (n1 == 2 && n2 == 2)
+        cvr = DCRTPoly::Tensor(cv1[0], cv1[1], &cv2[0], &cv2[1]);
+    if (cvr.empty()) {
+        cvr.reserve(nr);
+        for (uint32_t k = 0; k < nr; ++k) {  // element k = sum over i + j = k of cv1[i] * cv2[j]  (:619-638)
+            for (uint32_t i = 0; i < n1; ++i) {
+                if (k < i || k - i >= n2)
+                    continue;
+                if (cvr.size() == k)
+                    cvr.emplace_back(cv1[i] * cv2[k - i]);
+                else
+                    cvr[k] += (cv1[i] * cv2[k - i]);
+            }
+        }
+    }
+    auto result = ctxt1->CloneEmpty();
+    result->SetElements(std::move(cvr));
+    result->SetNoiseScaleDeg(ctxt1->GetNoiseScaleDeg() + ctxt2->GetNoiseScaleDeg());
+    result->SetScalingFactor(ctxt1->GetScalingFactor() * ctxt2->GetScalingFactor());
+    result->SetScalingFactorInt(
+        ctxt1->GetScalingFactorInt().ModMul(ctxt2->GetScalingFactorInt(), ctxt1->GetCryptoParameters()->GetPlaintextModulus()));
+    return result;
+}
+
+}  // namespace lbcrypto
+
+// ---- KeySwitchHYBRID::KeySwitchGenInternal (keyswitch-hybrid.cpp:51-195), hooked like the members above (weak symbols in the reference's
+// object).  The reference assembles every key element limb by limb on the host (2 * numPartQ * (sizeQ + sizeP) SetElementAtIndex per
+// key; a bootstrapping key set is 60-70 keys).  Here the samplers still run on the host, in the reference's order (a, then e, per digit:
+// the deterministic test PRNG gives the same words), and the arithmetic runs on whole device towers:
+//   sNewExt = [ sNew (EVALUATION) | SwitchModulus(sNew limb 0 -> p_j) to EVALUATION ]                         (:60-81)
+//   b_part  = -a * sNewExt + ns * e + [ PModq_i * sOld_i on the limbs of digit `part`, 0 elsewhere ]            (:100-118)
+// (exact modular sums and products: any order gives the reference's residues).
+namespace lbcrypto {
+namespace {
+// [ 0 ... 0 | rows [first, first+n) of src | 0 ... 0 ] over paramsQP
+DCRTPoly RowsInZeros(const std::shared_ptr<DCRTPoly::Params>& paramsQP, const DCRTPoly& src, uint32_t first, uint32_t n) {
+    const uint32_t total = paramsQP->GetParams().size();
+    return DCRTPoly::AssembleRows(paramsQP, Format::EVALUATION,
+                                  {RowPiece{nullptr, 0, first}, RowPiece{&src, first, n}, RowPiece{nullptr, 0, total - first - n}});
+}
+}  // namespace
+
+EvalKey<DCRTPoly> KeySwitchHYBRID::KeySwitchGenInternal(const PrivateKey<DCRTPoly> oldKey, const PrivateKey<DCRTPoly> newKey) const {
+    return KeySwitchHYBRID::KeySwitchGenInternal(oldKey, newKey, nullptr);
+}
+
+EvalKey<DCRTPoly> KeySwitchHYBRID::KeySwitchGenInternal(const PrivateKey<DCRTPoly> oldKey, const PrivateKey<DCRTPoly> newKey,
+                                                        const EvalKey<DCRTPoly> ekPrev) const {
+    hiprt::MemberScope scope("KeySwitchGenInternal");
+    const auto cryptoParams = std::dynamic_pointer_cast<CryptoParametersRNS>(newKey->GetCryptoParameters());
+    const auto& paramsQ     = cryptoParams->GetElementParams();
+    const auto& paramsQP    = cryptoParams->GetParamsQP();
+    const auto& paramsP     = cryptoParams->GetParamsP();
+    const uint32_t sizeQ = paramsQ->GetParams().size(), sizeP = paramsP->GetParams().size();
+
+    // sNew over Q extended to Q u P (:60-81): the P limbs are limb 0 in COEFFICIENT form, lifted centred to every p_j (the ModRaise
+    // constructor of the backend class is exactly PolyImpl::SwitchModulus into every limb, dcrtpoly-impl.h:87-93)
+    DCRTPoly sNewEval = newKey->GetPrivateElement();
+    sNewEval.SetFormat(Format::EVALUATION);
+    DCRTPoly sNew0 = newKey->GetPrivateElement().CloneTowers(0, 0);
+    sNew0.SetFormat(Format::COEFFICIENT);
+    // (one polynomial modulo q_0 -> every limb of Q u P, centred; the Q limbs of that lift are not used)
+    DCRTPoly lifted(sNew0.GetElementAtIndex(0), paramsQP);
+    lifted.SetFormat(Format::EVALUATION);
+    const DCRTPoly sNewExt = DCRTPoly::AssembleRows(paramsQP, Format::EVALUATION, {RowPiece{&sNewEval, 0, sizeQ}, RowPiece{&lifted, sizeQ, sizeP}});
+
+    const auto ns              = cryptoParams->GetNoiseScale();
+    const uint32_t numPerPartQ = cryptoParams->GetNumPerPartQ();
+    const uint32_t numPartQ    = cryptoParams->GetNumPartQ();
+    std::vector<DCRTPoly> av(numPartQ), bv(numPartQ);
+    DugType dug;
+    auto dgg = cryptoParams->GetDiscreteGaussianGenerator();
+    const auto& sOld  = oldKey->GetPrivateElement();
+    const DCRTPoly sOldP = sOld.TimesNoCheck(cryptoParams->GetPModq());  // [P]_{q_i} * sOld_i on every Q limb (:113)
+
+    // The reference's loop header, verbatim (:96): the samplers read a thread-local PRNG, so the keys are reproduced word for word only
+    // if the same thread draws the same digit; and OpenMP's private clause hands every thread a DEFAULT-constructed dgg (not a copy of
+    // the parameters' one), which is therefore what the reference's evaluation-key noise is drawn with.
+#pragma omp parallel for num_threads(OpenFHEParallelControls.GetThreadLimit(numPartQ)) private(dug, dgg)
+    for (uint32_t part = 0; part < numPartQ; ++part) {
+        DCRTPoly a = (ekPrev == nullptr) ? DCRTPoly(dug, paramsQP, Format::EVALUATION) : ekPrev->GetAVector()[part];
+        DCRTPoly e(dgg, paramsQP, Format::EVALUATION);
+        const uint32_t startPartIdx = numPerPartQ * part;
+        const uint32_t endPartIdx   = (sizeQ > (startPartIdx + numPerPartQ)) ? (startPartIdx + numPerPartQ) : sizeQ;
+        DCRTPoly b = (a * sNewExt).Negate();
+        if (ns != 1)
+            e *= NativeInteger(ns);
+        b += e;
+        b += RowsInZeros(paramsQP, sOldP, startPartIdx, endPartIdx - startPartIdx);
+        av[part] = std::move(a);
+        bv[part] = std::move(b);
+    }
+    EvalKeyRelin<DCRTPoly> ek(std::make_shared<EvalKeyRelinImpl<DCRTPoly>>(newKey->GetCryptoContext()));
+    ek->SetAVector(std::move(av));
+    ek->SetBVector(std::move(bv));
+    ek->SetKeyTag(newKey->GetKeyTag());
+    return ek;
+}
+
+// the public-key variant (:132-195): a = newp1 * u + ns * e1,  b = newp0 * u + ns * e0 + [ PModq_i * sOld_i on the digit's limbs ]
+EvalKey<DCRTPoly> KeySwitchHYBRID::KeySwitchGenInternal(const PrivateKey<DCRTPoly> oldKey, const PublicKey<DCRTPoly> newKey) const {
+    hiprt::MemberScope scope("KeySwitchGenInternal");
+    const auto cryptoParams = std::dynamic_pointer_cast<CryptoParametersRNS>(newKey->GetCryptoParameters());
+    const auto& paramsQ     = cryptoParams->GetElementParams();
+    const auto& paramsQP    = cryptoParams->GetParamsQP();
+    const uint32_t sizeQ    = paramsQ->GetParams().size();
+    const auto ns              = cryptoParams->GetNoiseScale();
+    const uint32_t numPerPartQ = cryptoParams->GetNumPerPartQ();
+    const uint32_t numPartQ    = cryptoParams->GetNumPartQ();
+    std::vector<DCRTPoly> av(numPartQ), bv(numPartQ);
+    TugType tug;
+    auto dgg = cryptoParams->GetDiscreteGaussianGenerator();
+    const auto& sOld  = oldKey->GetPrivateElement();
+    const auto& newp0 = newKey->GetPublicElements().at(0);
+    const auto& newp1 = newKey->GetPublicElements().at(1);
+    const DCRTPoly sOldP = sOld.TimesNoCheck(cryptoParams->GetPModq());
+
+#pragma omp parallel for num_threads(OpenFHEParallelControls.GetThreadLimit(numPartQ)) private(dgg, tug)  // (:157, see above)
+    for (uint32_t part = 0; part < numPartQ; ++part) {
+        DCRTPoly u = (cryptoParams->GetSecretKeyDist() == GAUSSIAN) ? DCRTPoly(dgg, paramsQP, Format::EVALUATION) :
+                                                                      DCRTPoly(tug, paramsQP, Format::EVALUATION);
+        DCRTPoly e0(dgg, paramsQP, Format::EVALUATION);
+        DCRTPoly e1(dgg, paramsQP, Format::EVALUATION);
+        const uint32_t startPartIdx = numPerPartQ * part;
+        const uint32_t endPartIdx   = (sizeQ > startPartIdx + numPerPartQ) ? (startPartIdx + numPerPartQ) : sizeQ;
+        if (ns != 1) {
+            e0 *= NativeInteger(ns);
+            e1 *= NativeInteger(ns);
+        }
+        DCRTPoly a = newp1 * u;
+        a += e1;
+        DCRTPoly b = newp0 * u;
+        b += e0;
+        b += RowsInZeros(paramsQP, sOldP, startPartIdx, endPartIdx - startPartIdx);
+        av[part] = std::move(a);
+        bv[part] = std::move(b);
+    }
+    EvalKeyRelin<DCRTPoly> ek = std::make_shared<EvalKeyRelinImpl<DCRTPoly>>(newKey->GetCryptoContext());
+    ek->SetAVector(std::move(av));
+    ek->SetBVector(std::move(bv));
+    ek->SetKeyTag(newKey->GetKeyTag());
+    return ek;
+}
+
+}  // namespace lbcrypto

@@ -960,6 +960,34 @@ public:
                                                   a.Hc().GetElementAtIndex(aFirst + i) * b.Hc().GetElementAtIndex(bFirst + i));
     }
 
+    // { a0*b0, a0*b1 + a1*b0, a1*b1 }: LeveledSHEBase::EvalMultCore for two 2-element ciphertexts (base-leveledshe.cpp:619-623) in one
+    // pass over the four towers (fhe_tensor); b0 == nullptr: EvalSquareCore's { a0*a0, 2*a0*a1, a1*a1 } (:646-664).  Empty when the
+    // towers cannot take the device path (the caller then runs the reference's five tower operations).
+    static std::vector<DCRTPolyType> Tensor(const DCRTPolyType& a0, const DCRTPolyType& a1, const DCRTPolyType* b0, const DCRTPolyType* b1) {
+        FHE_HAL_MEMBER();
+        std::vector<DCRTPolyType> out;
+        hiprt::Resolved r;
+        if (!a0.Compatible(a1, true) || (b0 && (!a0.Compatible(*b0, true) || !a0.Compatible(*b1, true))) || !a0.OnDevice(&r) || !a1.Upload() ||
+            (b0 && (!b0->Upload() || !b1->Upload())))
+            return out;
+        const uint32_t L = a0.NumLimbs();
+        hiprt::Op op;
+        auto d0 = hiprt::Alloc(a0.Words()), d1 = hiprt::Alloc(a0.Words()), d2 = hiprt::Alloc(a0.Words());
+        if (b0)
+            hiprt::Check(hiprt::api().tensor(r.ctx, op.R(a0.m_d), op.R(a1.m_d), op.R(b0->m_d), op.R(b1->m_d), op.W(d0), op.W(d1), op.W(d2),
+                                             r.idx[0].data(), L, 1, op.s),
+                         "EvalMultCore");
+        else
+            hiprt::Check(hiprt::api().tensor_square(r.ctx, op.R(a0.m_d), op.R(a1.m_d), op.W(d0), op.W(d1), op.W(d2), r.idx[0].data(), L, 1, op.s),
+                         "EvalSquareCore");
+        hiprt::CountDevice();
+        const auto& P = a0.m_h.GetParams();
+        out.push_back(FromDevice(P, Format::EVALUATION, std::move(d0)));
+        out.push_back(FromDevice(P, Format::EVALUATION, std::move(d1)));
+        out.push_back(FromDevice(P, Format::EVALUATION, std::move(d2)));
+        return out;
+    }
+
     // the host mirror (synchronised), for code that wants the default implementation's object
     const HostType& Host() const {
         return Hc();
@@ -976,13 +1004,22 @@ public:
             return nullptr;
         return m_d;
     }
+    // the same for an operation that UPDATES the words in place: a private copy if they were shared with another tower, the device
+    // copy becomes the authoritative one
+    hiprt::Buf DeviceWordsForUpdate() {
+        if (!DeviceWords())
+            return nullptr;
+        Unshare();
+        DeviceIsNewer(m_h.GetFormat());
+        return m_d;
+    }
     // a tower over `params` in format f whose words are the device buffer d ([limbs][N])
     static DCRTPolyType FromDeviceWords(const std::shared_ptr<Params>& params, Format f, hiprt::Buf d) {
         return FromDevice(params, f, std::move(d));
     }
     // replaces this tower's device words by a window of a packed buffer holding the same values (evaluation keys packed for the
     // library's plans: no second copy stays behind)
-    void AdoptDeviceWords(hiprt::Buf d) {
+    void AdoptDeviceWords(hiprt::Buf d) const {
         std::lock_guard<std::mutex> lk(m_lock.m);
         m_d = std::move(d);
     }

@@ -22,6 +22,7 @@ struct Api {
     decltype(&fhe_last_error) last_error;
     decltype(&fhe_device_count) device_count;
     decltype(&fhe_ctx_create) ctx_create;
+    decltype(&fhe_ctx_destroy) ctx_destroy;
     decltype(&fhe_malloc) malloc_;
     decltype(&fhe_free) free_;
     decltype(&fhe_memcpy_h2d) h2d;
@@ -50,14 +51,17 @@ struct Api {
     decltype(&fhe_automorph) automorph;
     decltype(&fhe_switch_modulus) switch_modulus;
     decltype(&fhe_conv_create_custom) conv_create_custom;
+    decltype(&fhe_conv_destroy) conv_destroy;
     decltype(&fhe_approx_switch_basis) approx_switch_basis;
     decltype(&fhe_switch_basis_exact) switch_basis_exact;
     decltype(&fhe_sr_plan_create) sr_plan_create;
+    decltype(&fhe_sr_plan_destroy) sr_plan_destroy;
     decltype(&fhe_scale_and_round) scale_and_round;
     decltype(&fhe_scale_and_round_p_over_q) scale_and_round_p_over_q;
     decltype(&fhe_scale_and_round_native) scale_and_round_native;
     decltype(&fhe_scale_and_round_behz_decrypt) scale_and_round_behz_decrypt;
     decltype(&fhe_behz_create) behz_create;
+    decltype(&fhe_behz_destroy) behz_destroy;
     decltype(&fhe_behz_override_q_to_bsk) behz_override_q_to_bsk;
     decltype(&fhe_behz_override_floorq) behz_override_floorq;
     decltype(&fhe_behz_override_conv_sk) behz_override_conv_sk;
@@ -68,6 +72,10 @@ struct Api {
     decltype(&fhe_tensor) tensor;
     decltype(&fhe_tensor_square) tensor_square;
     decltype(&fhe_ks_plan_create) ks_plan_create;
+    decltype(&fhe_ks_plan_destroy) ks_plan_destroy;
+    decltype(&fhe_keyswitch_hybrid_acc) keyswitch_hybrid_acc;
+    decltype(&fhe_ks_precompute) ks_precompute;
+    decltype(&fhe_ks_fast_keyswitch) ks_fast_keyswitch;
     decltype(&fhe_ks_key_wrap) ks_key_wrap;
     decltype(&fhe_ks_key_destroy) ks_key_destroy;
     decltype(&fhe_ks_workspace_bytes) ks_workspace_bytes;
@@ -131,9 +139,12 @@ struct LimbSet {  // the moduli / roots of one tower (an ILDCRTParams), in tower
     const uint64_t* psi;
     uint32_t n;
 };
+struct CtxHolder;  // a device context with the plans built on it; destroyed when the registry has replaced it and the last
+                   // operation that resolved against it is over
 struct Resolved {
     fhe_ctx* ctx = nullptr;
     std::vector<std::vector<uint32_t>> idx;  // context limbs of every requested set
+    std::shared_ptr<CtxHolder> hold;         // keeps ctx (and its plans) alive for the duration of the operation
 };
 // registers the moduli of all sets (growing the context when new ones appear) and returns their context limbs; false when
 // the ring or a modulus is outside the device library's domain (N not 2^4..2^17, q >= 2^60, q != 1 mod 2N, > 128 limbs)

@@ -23,6 +23,7 @@ extern "C" int fhe_hal_available(void) __attribute__((weak));
 extern "C" void fhe_hal_trace_reset(void) __attribute__((weak));
 extern "C" size_t fhe_hal_member_stats(char* buf, size_t cap) __attribute__((weak));
 extern "C" void fhe_hal_stats_reset(void) __attribute__((weak));
+extern "C" void fhe_hal_composite_stats(uint64_t out[3]) __attribute__((weak));
 // the set-up phase (context, keys, encryption: samplers and encoders produce their words on the host) ends here: the counters the
 // tests assert on cover the EVALUATION phase (and the decryptions at the end) only
 static void evaluation_phase_begins() {
@@ -509,6 +510,11 @@ int main(int argc, char** argv) {
                 std::cout << "halmember " << buf.substr(at, nl - at) << std::endl;
                 at = nl + 1;
             }
+        }
+        if (fhe_hal_composite_stats) {
+            uint64_t cs[3];
+            fhe_hal_composite_stats(cs);
+            std::cout << "halcomposite calls " << cs[0] << " checksIdentical " << cs[1] << " checksDiffered " << cs[2] << std::endl;
         }
         std::cout << "hal: available " << (fhe_hal_available ? fhe_hal_available() : -1) << " deviceOps " << st[0] << " hostOps " << st[1]
                   << " h2dBytes " << st[2] << " d2hBytes " << st[3] << std::endl;

@@ -89,6 +89,10 @@ def check(tmp_path, mode, logN, device_lib, expect, extra=(), threads=1, must_ru
     a, b = open(so, "rb").read(), open(sh, "rb").read()
     assert len(a) > 1000 and a == b, "the HIP backend's ciphertext limbs differ from the default backend's"
     assert_ran_on_device(out_hip, must_run)
+    # the batched composites (one library call per key switch): every first-use check against the member-by-member path matched
+    cm = re.search(r"halcomposite calls (\d+) checksIdentical (\d+) checksDiffered (\d+)", out_hip)
+    assert cm and int(cm.group(3)) == 0, out_hip[-600:]
+    check.composite_calls = int(cm.group(1))
     for name, want in expect.items():
         for run_out in (out_stock, out_hip):
             got = values(run_out, name)
@@ -219,10 +223,10 @@ def test_shim_batch_of_ciphertexts_over_host_threads_on_emulator(tmp_path):
     """cc->EvalMult on 8 ciphertexts spread over 4 OpenMP threads (one device, shared pool / plan caches / copy-on-write words): the
     first and the last product are the stock backend's, byte for byte (pke's own inner parallel loops run inside each thread)"""
     ops = check(tmp_path, "multbatch", 11, EMU, {"product 0": [0.5, 0.0, -3.0]}, extra=(4, 8, 1), threads=4)
-    assert ops > 200
+    assert ops > 50 and check.composite_calls >= 8  # (the timed pass: one composite key switch per EvalMult)
 
 
 @pytest.mark.gpu
 def test_shim_batch_of_ciphertexts_over_host_threads_on_gpu(tmp_path):
     ops = check(tmp_path, "multbatch", 14, HIP, {"product 0": [0.5, 0.0, -3.0]}, extra=(8, 32, 1), threads=8)
-    assert ops > 1000
+    assert ops > 100 and check.composite_calls >= 32
