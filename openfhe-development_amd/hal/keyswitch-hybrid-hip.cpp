@@ -220,7 +220,9 @@ void LimbsOfParams(const std::shared_ptr<DCRTPoly::Params>& p, std::vector<uint6
 }
 // the key-switching domain of a parameter set, and the level of a tower in it (0: the tower is not a prefix of Q)
 std::shared_ptr<hiprt::KsDomain> DomainOf(const std::shared_ptr<CryptoParametersRNS>& cp, const DCRTPoly& c, uint32_t* sizeQl) {
-    if (!hiprt::Available() || !cp || cp->GetKeySwitchTechnique() != HYBRID)
+    // (a noise scale other than 1 — BGV — makes KeySwitchHYBRID pass the plaintext modulus to ApproxModDown, keyswitch-hybrid.cpp:385-398:
+    // the composite is the t = 0 form)
+    if (!hiprt::Available() || !cp || cp->GetKeySwitchTechnique() != HYBRID || cp->GetNoiseScale() != 1)
         return nullptr;
     std::vector<uint64_t> q, psiQ, p, psiP, ql, psiQl;
     LimbsOfParams(cp->GetElementParams(), q, psiQ);
