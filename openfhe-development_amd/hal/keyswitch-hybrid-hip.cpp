@@ -482,3 +482,262 @@ EvalKey<DCRTPoly> KeySwitchHYBRID::KeySwitchGenInternal(const PrivateKey<DCRTPol
 }
 
 }  // namespace lbcrypto
+
+// ---- the linear transforms of CKKS bootstrapping as ONE library call per level ------------------------------------------------------
+// FHECKKSRNS::EvalLinearTransform (ckksrns-fhe.cpp:1832-1882), EvalCoeffsToSlots (:1884-2039) and EvalSlotsToCoeffs (:2041-2198) are, level
+// by level, the same baby-step/giant-step shape: hoisted inner rotations in the extended basis, a plaintext multiply-accumulate per
+// giant step, KeySwitchDown, an outer rotation, one final KeySwitchDown.  Through the class surface a level is ~400 tower operations;
+// the device library runs it as one composite with every stage batched over all giant steps (fhe_ckks_bsgs_transform, double hoisting).
+// The hooks below keep the reference's level structure (rotation amounts per level by the reference's formulas, ModReduce between
+// levels through the scheme) and hand every level to the composite.  The reference's own definitions stay in the library under the
+// names fhe_ref_* (objcopy --redefine-sym, hal/Makefile): they are the fall-back for everything the composite does not take, and the
+// FIRST use of a hooked function at a level computes both and compares every word and the ciphertext metadata (hiprt::DomainChecked).
+#include "scheme/ckksrns/ckksrns-fhe.h"
+#include "scheme/ckksrns/ckksrns-utils.h"
+
+extern "C" {
+lbcrypto::Ciphertext<lbcrypto::DCRTPoly> fhe_ref_EvalLinearTransform(const lbcrypto::FHECKKSRNS* self, const std::vector<lbcrypto::ReadOnlyPlaintext>& A,
+                                                                     lbcrypto::ConstCiphertext<lbcrypto::DCRTPoly>& ct);
+lbcrypto::Ciphertext<lbcrypto::DCRTPoly> fhe_ref_EvalCoeffsToSlots(const lbcrypto::FHECKKSRNS* self,
+                                                                   const std::vector<std::vector<lbcrypto::ReadOnlyPlaintext>>& A,
+                                                                   lbcrypto::ConstCiphertext<lbcrypto::DCRTPoly>& ctxt);
+lbcrypto::Ciphertext<lbcrypto::DCRTPoly> fhe_ref_EvalSlotsToCoeffs(const lbcrypto::FHECKKSRNS* self,
+                                                                   const std::vector<std::vector<lbcrypto::ReadOnlyPlaintext>>& A,
+                                                                   lbcrypto::ConstCiphertext<lbcrypto::DCRTPoly>& ctxt);
+}
+
+namespace lbcrypto {
+namespace {
+constexpr uint32_t kNoSkip = 0xffffffffu;
+// result = sum_i Rot_{rotOut[i]}( sum_j Rot_{rotIn[j]}(ct) * A[i * |rotIn| + j] ) — terms with index == skip or beyond A absent —
+// with the reference's metadata (EvalMultExt, :2723-2732: noise-scale degree and scaling factor of the plaintexts join the ciphertext's).
+// false: the composite does not take this level (the caller runs the reference's function instead).
+bool BsgsLevelOnDevice(Ciphertext<DCRTPoly>& ct, const std::vector<int32_t>& rotIn, const std::vector<int32_t>& rotOut,
+                       const std::vector<ReadOnlyPlaintext>& A, uint32_t skip) {
+    const auto cc = ct->GetCryptoContext();
+    const auto cp = std::dynamic_pointer_cast<CryptoParametersCKKSRNS>(ct->GetCryptoParameters());
+    auto& cv      = ct->GetElements();
+    if (!cp || cv.size() != 2 || cv[0].GetFormat() != Format::EVALUATION || cv[1].GetFormat() != Format::EVALUATION || A.empty() || !A[0])
+        return false;
+    uint32_t sizeQl = 0;
+    auto dom        = DomainOf(cp, cv[0], &sizeQl);
+    if (!dom || cv[1].GetNumOfElements() != sizeQl)
+        return false;
+    const uint32_t M = cc->GetCyclotomicOrder(), nIn = rotIn.size(), nOut = rotOut.size();
+    const size_t sizeP = cp->GetParamsP()->GetParams().size(), sizeQP = cp->GetParamsQP()->GetParams().size();
+    const auto& keyMap = cc->GetEvalAutomorphismKeyMap(ct->GetKeyTag());
+    hiprt::Op op;
+    std::vector<hiprt::PackedKey> keep;
+    auto keysOf = [&](const std::vector<int32_t>& rot, std::vector<uint32_t>& k, std::vector<const fhe_ks_key*>& keys) {
+        k.assign(rot.size(), 0), keys.assign(rot.size(), nullptr);
+        for (size_t j = 0; j < rot.size(); ++j) {
+            if (rot[j] == 0)
+                continue;
+            k[j]    = FindAutomorphismIndex2nComplex(rot[j], M);
+            auto it = keyMap.find(k[j]);
+            std::vector<hiprt::Buf> kb, ka;
+            if (it == keyMap.end() || !KeyBuffers(it->second, cp->GetNumPartQ(), sizeQP, kb, ka))
+                return false;
+            keep.push_back(hiprt::DomainKey(*dom, kb, ka, op));
+            if (!keep.back().key)
+                return false;
+            op.R(keep.back().b), op.R(keep.back().a);
+            keys[j] = keep.back().key.get();
+        }
+        return true;
+    };
+    std::vector<uint32_t> inK, outK;
+    std::vector<const fhe_ks_key*> inKeys, outKeys;
+    if (!keysOf(rotIn, inK, inKeys) || !keysOf(rotOut, outK, outKeys))
+        return false;
+    // the encoded diagonals: towers over Q_l u P in EVALUATION (EvalLinearTransformPrecompute's aux plaintexts), device resident after
+    // their first use
+    std::vector<const uint64_t*> diag((size_t)nOut * nIn, nullptr);
+    std::vector<hiprt::Buf> diagKeep;
+    const auto& ql = cv[0].GetParams()->GetParams();
+    for (uint32_t i = 0; i < nOut; ++i)
+        for (uint32_t j = 0; j < nIn; ++j) {
+            const size_t idx = (size_t)i * nIn + j;
+            if (idx == skip || idx >= A.size())
+                continue;
+            if (!A[idx])
+                return false;
+            const DCRTPoly& pt = A[idx]->GetElement<DCRTPoly>();
+            const auto& pl     = pt.GetParams()->GetParams();
+            if (pt.GetFormat() != Format::EVALUATION || pl.size() != sizeQl + sizeP || pl[0]->GetModulus() != ql[0]->GetModulus() ||
+                pl[sizeQl - 1]->GetModulus() != ql[sizeQl - 1]->GetModulus() ||
+                pl[sizeQl]->GetModulus() != cp->GetParamsP()->GetParams()[0]->GetModulus())
+                return false;
+            diagKeep.push_back(pt.DeviceWords());
+            if (!diagKeep.back())
+                return false;
+            diag[idx] = op.R(diagKeep.back());
+        }
+    auto b0 = cv[0].DeviceWords(), b1 = cv[1].DeviceWords();
+    if (!b0 || !b1)
+        return false;
+    const auto& Api  = hiprt::api();
+    const size_t N   = cv[0].GetParams()->GetRingDimension();
+    const size_t wsB = Api.bsgs_workspace_bytes(hiprt::DomainPlan(*dom), sizeQl, 1, nIn, nOut);
+    auto ws = hiprt::Alloc(wsB / 8 + 1), o0 = hiprt::Alloc(sizeQl * N), o1 = hiprt::Alloc(sizeQl * N);
+    if (Api.bsgs_transform(hiprt::DomainPlan(*dom), op.R(b0), op.R(b1), sizeQl, 1, nIn, inK.data(), inKeys.data(), nOut, outK.data(), outKeys.data(),
+                           diag.data(), op.W(o0), op.W(o1), op.W(ws), wsB, op.s) != FHE_OK)
+        return false;
+    hiprt::CountDevice("Bootstrap.BsgsLevel");
+    hiprt::CountComposite();
+    auto result = ct->CloneEmpty();
+    std::vector<DCRTPoly> elements;
+    elements.push_back(DCRTPoly::FromDeviceWords(cv[0].GetParams(), Format::EVALUATION, std::move(o0)));
+    elements.push_back(DCRTPoly::FromDeviceWords(cv[0].GetParams(), Format::EVALUATION, std::move(o1)));
+    result->SetElements(std::move(elements));
+    result->SetNoiseScaleDeg(ct->GetNoiseScaleDeg() + A[0]->GetNoiseScaleDeg());
+    result->SetScalingFactor(ct->GetScalingFactor() * A[0]->GetScalingFactor());
+    ct = std::move(result);
+    return true;
+}
+bool SameCiphertext(const hiprt::KsDomain& dom, const Ciphertext<DCRTPoly>& a, const Ciphertext<DCRTPoly>& b) {
+    if (!a || !b || a->GetElements().size() != b->GetElements().size() || a->GetLevel() != b->GetLevel() ||
+        a->GetNoiseScaleDeg() != b->GetNoiseScaleDeg() || a->GetScalingFactor() != b->GetScalingFactor() || a->GetSlots() != b->GetSlots())
+        return false;
+    for (size_t e = 0; e < a->GetElements().size(); ++e) {
+        const auto &x = a->GetElements()[e], &y = b->GetElements()[e];
+        auto bx = x.DeviceWords(), by = y.DeviceWords();
+        if (!bx || !by || x.GetNumOfElements() != y.GetNumOfElements() || x.GetFormat() != y.GetFormat() ||
+            hiprt::Checksums(hiprt::DomainCtx(dom), bx, x.GetNumOfElements()) != hiprt::Checksums(hiprt::DomainCtx(dom), by, y.GetNumOfElements()))
+            return false;
+    }
+    return true;
+}
+// runs `composite` (false: not applicable) with the first-use check against `reference`
+template <typename Composite, typename Reference>
+Ciphertext<DCRTPoly> CheckedComposite(ConstCiphertext<DCRTPoly>& ctxt, Composite composite, Reference reference) {
+    uint32_t sizeQl = 0;
+    const auto cp   = std::dynamic_pointer_cast<CryptoParametersCKKSRNS>(ctxt->GetCryptoParameters());
+    auto dom        = (cp && ctxt->GetElements().size() == 2) ? DomainOf(cp, ctxt->GetElements()[0], &sizeQl) : nullptr;
+    const int state = dom ? hiprt::DomainChecked(*dom, hiprt::kBsgs, sizeQl) : 2;
+    if (state == 2)
+        return reference();
+    Ciphertext<DCRTPoly> mine;
+    if (!composite(mine))
+        return reference();
+    if (state == 1)
+        return mine;
+    auto ref = reference();
+    hiprt::DomainSetChecked(*dom, hiprt::kBsgs, sizeQl, SameCiphertext(*dom, mine, ref));
+    return ref;
+}
+}  // namespace
+
+Ciphertext<DCRTPoly> FHECKKSRNS::EvalLinearTransform(const std::vector<ReadOnlyPlaintext>& A, ConstCiphertext<DCRTPoly>& ct) const {
+    hiprt::MemberScope scope("Bootstrap.EvalLinearTransform");
+    return CheckedComposite(
+        ct,
+        [&](Ciphertext<DCRTPoly>& out) {
+            const uint32_t slots = A.size();  // (:1835-1838)
+            const auto& p        = GetBootPrecom(slots);
+            const uint32_t bStep = (p.m_paramsEnc.g == 0) ? std::ceil(std::sqrt(slots)) : p.m_paramsEnc.g;
+            const uint32_t gStep = std::ceil(static_cast<double>(slots) / bStep);
+            std::vector<int32_t> rotIn(bStep), rotOut(gStep);
+            for (uint32_t j = 0; j < bStep; ++j)
+                rotIn[j] = j;  // (:1846-1847: fast rotations by 1 .. bStep-1; the unrotated term is KeySwitchExt, :1855)
+            for (uint32_t i = 0; i < gStep; ++i)
+                rotOut[i] = bStep * i;  // (:1871)
+            out = ct->Clone();
+            return BsgsLevelOnDevice(out, rotIn, rotOut, A, kNoSkip);
+        },
+        [&] { return fhe_ref_EvalLinearTransform(this, A, ct); });
+}
+
+Ciphertext<DCRTPoly> FHECKKSRNS::EvalCoeffsToSlots(const std::vector<std::vector<ReadOnlyPlaintext>>& A, ConstCiphertext<DCRTPoly>& ctxt) const {
+    hiprt::MemberScope scope("Bootstrap.EvalCoeffsToSlots");
+    return CheckedComposite(
+        ctxt,
+        [&](Ciphertext<DCRTPoly>& out) {
+            const uint32_t slots = ctxt->GetSlots();
+            const auto& p        = GetBootPrecom(slots).m_paramsEnc;
+            const auto cc        = ctxt->GetCryptoContext();
+            const uint32_t M4    = cc->GetCyclotomicOrder() / 4;
+            const int32_t flagRem = p.remCollapse != 0 ? 1 : 0, stop = flagRem ? 0 : -1;  // (:1895-1903)
+            const auto cp         = std::dynamic_pointer_cast<CryptoParametersCKKSRNS>(cc->GetCryptoParameters());
+            out = ctxt->Clone();
+            bool firstLevel = true;
+            auto level = [&](const std::vector<int32_t>& rotIn, const std::vector<int32_t>& rotOut, const std::vector<ReadOnlyPlaintext>& Al, uint32_t skip) {
+                if (!firstLevel)
+                    cc->GetScheme()->ModReduceInternalInPlace(out, cp->GetCompositeDegree());  // (:1936-1937, :1989)
+                firstLevel = false;
+                return BsgsLevelOnDevice(out, rotIn, rotOut, Al, skip);
+            };
+            // levels lvlb-1 down to stop+1 (:1911-1918, :1933-1985): rotations scaled by 2^((s - flagRem) * layersCollapse + remCollapse)
+            const int32_t offset = static_cast<int32_t>((p.numRotations + 1) / 2) - 1;
+            for (int32_t s = p.lvlb - 1; s > stop; --s) {
+                const int32_t scale = 1 << ((s - flagRem) * p.layersCollapse + p.remCollapse);
+                std::vector<int32_t> rotIn(p.g), rotOut(p.b);
+                for (uint32_t i = 0; i < p.b; ++i)
+                    rotOut[i] = ReduceRotation(scale * p.g * i, M4);
+                for (uint32_t j = 0; j < p.g; ++j)
+                    rotIn[j] = ReduceRotation(scale * (static_cast<int32_t>(j) - offset), slots);
+                if (!level(rotIn, rotOut, A[s], p.numRotations))
+                    return false;
+            }
+            if (flagRem) {  // the remainder level (:1920-1926, :1988-2037)
+                const int32_t offsetRem = static_cast<int32_t>((p.numRotationsRem + 1) / 2) - 1;
+                std::vector<int32_t> rotIn(p.gRem), rotOut(p.bRem);
+                for (uint32_t i = 0; i < p.bRem; ++i)
+                    rotOut[i] = ReduceRotation(p.gRem * i, M4);
+                for (uint32_t j = 0; j < p.gRem; ++j)
+                    rotIn[j] = ReduceRotation(static_cast<int32_t>(j) - offsetRem, slots);
+                if (!level(rotIn, rotOut, A[stop], p.numRotationsRem))
+                    return false;
+            }
+            return true;
+        },
+        [&] { return fhe_ref_EvalCoeffsToSlots(this, A, ctxt); });
+}
+
+Ciphertext<DCRTPoly> FHECKKSRNS::EvalSlotsToCoeffs(const std::vector<std::vector<ReadOnlyPlaintext>>& A, ConstCiphertext<DCRTPoly>& ctxt) const {
+    hiprt::MemberScope scope("Bootstrap.EvalSlotsToCoeffs");
+    return CheckedComposite(
+        ctxt,
+        [&](Ciphertext<DCRTPoly>& out) {
+            const uint32_t slots = ctxt->GetSlots();
+            const auto& p        = GetBootPrecom(slots).m_paramsDec;
+            const auto cc        = ctxt->GetCryptoContext();
+            const uint32_t M4    = cc->GetCyclotomicOrder() / 4;
+            const int32_t flagRem = (p.remCollapse == 0) ? 0 : 1, smax = p.lvlb - flagRem;  // (:2049-2058)
+            const auto cp         = std::dynamic_pointer_cast<CryptoParametersCKKSRNS>(cc->GetCryptoParameters());
+            out = ctxt->Clone();
+            bool firstLevel = true;
+            auto level = [&](const std::vector<int32_t>& rotIn, const std::vector<int32_t>& rotOut, const std::vector<ReadOnlyPlaintext>& Al, uint32_t skip) {
+                if (!firstLevel)
+                    cc->GetScheme()->ModReduceInternalInPlace(out, cp->GetCompositeDegree());  // (:2090-2091, :2143)
+                firstLevel = false;
+                return BsgsLevelOnDevice(out, rotIn, rotOut, Al, skip);
+            };
+            const int32_t offset = static_cast<int32_t>((p.numRotations + 1) / 2) - 1;
+            for (int32_t s = 0; s < smax; ++s) {  // (:2061-2067, :2089-2140): rotations scaled by 2^(s * layersCollapse)
+                const int32_t scale = 1 << (s * p.layersCollapse);
+                std::vector<int32_t> rotIn(p.g), rotOut(p.b);
+                for (uint32_t j = 0; j < p.g; ++j)
+                    rotIn[j] = ReduceRotation((static_cast<int32_t>(j) - offset) * scale, M4);
+                for (uint32_t i = 0; i < p.b; ++i)
+                    rotOut[i] = ReduceRotation((p.g * i) * scale, M4);
+                if (!level(rotIn, rotOut, A[s], p.numRotations))
+                    return false;
+            }
+            if (flagRem) {  // (:2069-2076, :2142-2193)
+                const int32_t scaleRem  = 1 << (smax * p.layersCollapse);
+                const int32_t offsetRem = static_cast<int32_t>((p.numRotationsRem + 1) / 2) - 1;
+                std::vector<int32_t> rotIn(p.gRem), rotOut(p.bRem);
+                for (uint32_t j = 0; j < p.gRem; ++j)
+                    rotIn[j] = ReduceRotation((static_cast<int32_t>(j) - offsetRem) * scaleRem, M4);
+                for (uint32_t i = 0; i < p.bRem; ++i)
+                    rotOut[i] = ReduceRotation((p.gRem * i) * scaleRem, M4);
+                if (!level(rotIn, rotOut, A[smax], p.numRotationsRem))
+                    return false;
+            }
+            return true;
+        },
+        [&] { return fhe_ref_EvalSlotsToCoeffs(this, A, ctxt); });
+}
+
+}  // namespace lbcrypto
