@@ -29,7 +29,7 @@ struct PackedKey {
 PackedKey DomainKey(KsDomain& d, const std::vector<Buf>& b, const std::vector<Buf>& a, Op& op);
 // Composites are checked once per (domain, kind, level) against the member-by-member path, which computes with the tables the
 // caller passes (the reference's CryptoParameters): 0 = not yet checked, 1 = identical (use the composite), 2 = differed (never use).
-enum CompositeKind : uint32_t { kKeySwitchAcc = 0, kBsgs = 1, kCompositeKinds = 2 };
+enum CompositeKind : uint32_t { kKeySwitchAcc = 0, kBsgs = 1, kKeySwitch = 2, kCompositeKinds = 3 };
 int DomainChecked(const KsDomain& d, CompositeKind kind, uint32_t sizeQl);
 void DomainSetChecked(KsDomain& d, CompositeKind kind, uint32_t sizeQl, bool identical);
 // {sum, xor} of every row of a device buffer [rows][N] brought to the host (fhe_checksum): the comparison of two results on the device

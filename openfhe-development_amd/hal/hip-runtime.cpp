@@ -347,7 +347,7 @@ void Op::HostSync() {
 }
 
 DevBuf::~DevBuf() {
-    if (!p || parent)
+    if (!p || parent || external)
         return;
     Runtime& r      = rt();
     ThreadState* ts = thread_state();
@@ -410,6 +410,13 @@ Buf Alloc(size_t words) {
     }
     Check(s, "HIP backend: device allocation");
     b->p = static_cast<uint64_t*>(d);
+    return b;
+}
+Buf WrapExternal(uint64_t* devPtr, size_t words) {
+    auto b      = std::make_shared<DevBuf>();
+    b->p        = devPtr;
+    b->words    = words;
+    b->external = true;
     return b;
 }
 Buf View(const Buf& parent, size_t offsetWords, size_t words) {
@@ -496,12 +503,15 @@ static void trace_site(const char* kind, const char* member, uint64_t amount) {
     if (!g_traceSites) {
         g_traceSites = new std::map<std::string, uint64_t>;
         std::atexit([] {
-            std::vector<std::pair<uint64_t, std::string>> v;
+            std::map<std::string, std::vector<std::pair<uint64_t, std::string>>> byKind;  // hostop / hostread / h2dBytes / d2hBytes / d2dBytes
             for (auto& kv : *g_traceSites)
-                v.emplace_back(kv.second, kv.first);
-            std::sort(v.rbegin(), v.rend());
-            for (size_t i = 0; i < v.size() && i < 400; ++i)
-                fprintf(stderr, "hal trace %12lu  %s\n", (unsigned long)v[i].first, v[i].second.c_str());
+                byKind[kv.first.substr(0, kv.first.find(' '))].emplace_back(kv.second, kv.first);
+            for (auto& kind : byKind) {
+                auto& v = kind.second;
+                std::sort(v.rbegin(), v.rend());
+                for (size_t i = 0; i < v.size() && i < 120; ++i)
+                    fprintf(stderr, "hal trace %12lu  %s\n", (unsigned long)v[i].first, v[i].second.c_str());
+            }
         });
     }
     (*g_traceSites)[key] += amount;
@@ -828,12 +838,27 @@ PackedKey DomainKey(KsDomain& d, const std::vector<Buf>& b, const std::vector<Bu
         d.keys.erase(victim);
     }
     KsDomain::Entry e;
-    e.pk.b = Alloc(towerWords * d.numPartQ);
-    e.pk.a = Alloc(towerWords * d.numPartQ);
-    uint64_t *pb = op.W(e.pk.b), *pa = op.W(e.pk.a);
-    for (uint32_t j = 0; j < d.numPartQ; ++j) {
-        D2D(op, pb + j * towerWords, op.R(b[j]), towerWords * 8, "evaluation key packed for the key-switching plan");
-        D2D(op, pa + j * towerWords, op.R(a[j]), towerWords * 8, "evaluation key packed for the key-switching plan");
+    // towers that are consecutive windows of one buffer (a key set adopted from a replicated buffer, fbb_adopt_keys) ARE the packed
+    // layout: no copy; anything else is packed once
+    auto packed = [&](const std::vector<Buf>& v) -> Buf {
+        for (uint32_t j = 0; j < d.numPartQ; ++j)
+            if (!v[j]->parent || v[j]->parent != v[0]->parent || v[j]->p != v[0]->p + j * towerWords)
+                return nullptr;
+        return View(v[0]->parent, (size_t)(v[0]->p - v[0]->parent->p), towerWords * d.numPartQ);
+    };
+    uint64_t *pb, *pa;
+    if ((e.pk.b = packed(b)) && (e.pk.a = packed(a))) {
+        pb = e.pk.b->p, pa = e.pk.a->p;
+        op.R(e.pk.b), op.R(e.pk.a);
+    }
+    else {
+        e.pk.b = Alloc(towerWords * d.numPartQ);
+        e.pk.a = Alloc(towerWords * d.numPartQ);
+        pb = op.W(e.pk.b), pa = op.W(e.pk.a);
+        for (uint32_t j = 0; j < d.numPartQ; ++j) {
+            D2D(op, pb + j * towerWords, op.R(b[j]), towerWords * 8, "evaluation key packed for the key-switching plan");
+            D2D(op, pa + j * towerWords, op.R(a[j]), towerWords * 8, "evaluation key packed for the key-switching plan");
+        }
     }
     fhe_ks_key* raw = nullptr;
     Check(r.api.ks_key_wrap(d.plan, pb, pa, &raw), "HIP backend: evaluation key for the key-switching plan");

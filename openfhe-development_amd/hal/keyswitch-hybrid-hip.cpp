@@ -208,6 +208,9 @@ void LeveledSHECKKSRNS::EvalMultCoreInPlace(Ciphertext<DCRTPoly>& ciphertext, do
 #include "hip-hooks.h"
 #include "schemebase/base-leveledshe.h"
 
+extern "C" std::shared_ptr<std::vector<lbcrypto::DCRTPoly>> fhe_ref_KeySwitchCore(const lbcrypto::KeySwitchHYBRID* self, const lbcrypto::DCRTPoly& a,
+                                                                                 const lbcrypto::EvalKey<lbcrypto::DCRTPoly> evalKey);
+
 namespace lbcrypto {
 namespace {
 void LimbsOfParams(const std::shared_ptr<DCRTPoly::Params>& p, std::vector<uint64_t>& q, std::vector<uint64_t>& psi) {
@@ -296,7 +299,11 @@ void KeySwitchAccumulate(const Ciphertext<DCRTPoly>& ciphertext, const EvalKey<D
         try0 = cv[0], try1 = cv[1];
         tried = CompositeKeySwitchAcc(*dom, sizeQl, kb, ka, try0, try1, cv[2]);
     }
-    auto ab = ciphertext->GetCryptoContext()->GetScheme()->KeySwitchCore(cv[2], evalKey);
+    // (KeySwitchCore itself is a composite too, below: the check needs the reference's own sequence)
+    const auto scheme = ciphertext->GetCryptoContext()->GetScheme();
+    auto ab = usable ? scheme->EvalFastKeySwitchCore(scheme->EvalKeySwitchPrecomputeCore(cv[2], evalKey->GetCryptoParameters()), evalKey,
+                                                     cv[2].GetParams())  // (= KeySwitchHYBRID::KeySwitchCore, keyswitch-hybrid.cpp:308-312)
+                     : scheme->KeySwitchCore(cv[2], evalKey);
     cv[0] += (*ab)[0];
     cv[1] += (*ab)[1];
     if (tried) {
@@ -307,6 +314,50 @@ void KeySwitchAccumulate(const Ciphertext<DCRTPoly>& ciphertext, const EvalKey<D
     }
 }
 }  // namespace
+
+// KeySwitchHYBRID::KeySwitchCore (keyswitch-hybrid.cpp:308-312) — every relinearisation, rotation and conjugation of pke ends here — as one
+// composite (fhe_keyswitch_hybrid); the reference's definition (precompute + fast key switch, member by member) is fhe_ref_KeySwitchCore
+std::shared_ptr<std::vector<DCRTPoly>> KeySwitchHYBRID::KeySwitchCore(const DCRTPoly& a, const EvalKey<DCRTPoly> evalKey) const {
+    hiprt::MemberScope scope("KeySwitchCore");
+    uint32_t sizeQl = 0;
+    std::vector<hiprt::Buf> kb, ka;
+    const auto cp = std::dynamic_pointer_cast<CryptoParametersRNS>(evalKey->GetCryptoParameters());
+    auto dom      = a.GetFormat() == Format::EVALUATION ? DomainOf(cp, a, &sizeQl) : nullptr;
+    const int st  = dom ? hiprt::DomainChecked(*dom, hiprt::kKeySwitch, sizeQl) : 2;
+    if (st == 2 || !KeyBuffers(evalKey, cp->GetNumPartQ(), cp->GetParamsQP()->GetParams().size(), kb, ka))
+        return fhe_ref_KeySwitchCore(this, a, evalKey);
+    auto bc = a.DeviceWords();
+    if (!bc)
+        return fhe_ref_KeySwitchCore(this, a, evalKey);
+    std::shared_ptr<std::vector<DCRTPoly>> mine;
+    {
+        const auto& A = hiprt::api();
+        hiprt::Op op;
+        hiprt::PackedKey pk = hiprt::DomainKey(*dom, kb, ka, op);
+        if (!pk.key)
+            return fhe_ref_KeySwitchCore(this, a, evalKey);
+        const size_t N   = a.GetParams()->GetRingDimension();
+        const size_t wsB = A.ks_workspace_bytes(hiprt::DomainPlan(*dom), sizeQl, 1);
+        auto ws = hiprt::Alloc(wsB / 8 + 1), o0 = hiprt::Alloc(sizeQl * N), o1 = hiprt::Alloc(sizeQl * N);
+        op.R(pk.b), op.R(pk.a);
+        hiprt::Check(A.keyswitch_hybrid(hiprt::DomainPlan(*dom), pk.key.get(), op.R(bc), sizeQl, 1, op.W(o0), op.W(o1), op.W(ws), wsB, op.s),
+                     "KeySwitchCore: composite key switch");
+        hiprt::CountDevice("KeySwitchCore");
+        hiprt::CountComposite();
+        mine = std::make_shared<std::vector<DCRTPoly>>();
+        mine->push_back(DCRTPoly::FromDeviceWords(a.GetParams(), Format::EVALUATION, std::move(o0)));
+        mine->push_back(DCRTPoly::FromDeviceWords(a.GetParams(), Format::EVALUATION, std::move(o1)));
+    }
+    if (st == 1)
+        return mine;
+    auto ref = fhe_ref_KeySwitchCore(this, a, evalKey);  // first use at this level: both, compared word for word on the device
+    auto r0 = (*ref)[0].DeviceWords(), r1 = (*ref)[1].DeviceWords();
+    const bool same = r0 && r1 && (*ref)[0].GetNumOfElements() == sizeQl &&
+                      hiprt::Checksums(hiprt::DomainCtx(*dom), r0, sizeQl) == hiprt::Checksums(hiprt::DomainCtx(*dom), (*mine)[0].DeviceWords(), sizeQl) &&
+                      hiprt::Checksums(hiprt::DomainCtx(*dom), r1, sizeQl) == hiprt::Checksums(hiprt::DomainCtx(*dom), (*mine)[1].DeviceWords(), sizeQl);
+    hiprt::DomainSetChecked(*dom, hiprt::kKeySwitch, sizeQl, same);
+    return ref;
+}
 
 // base-leveledshe.cpp:201-214
 template <>

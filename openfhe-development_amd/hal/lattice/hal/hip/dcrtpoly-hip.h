@@ -1021,7 +1021,11 @@ public:
     // library's plans: no second copy stays behind)
     void AdoptDeviceWords(hiprt::Buf d) const {
         std::lock_guard<std::mutex> lk(m_lock.m);
-        m_d = std::move(d);
+        auto P      = m_h.GetParams();
+        m_h         = HostType(P, m_h.GetFormat(), false);  // (the device words are the tower now: no stale host copy stays behind)
+        m_d         = std::move(d);
+        m_hostValid = false;
+        m_zero      = false;
     }
 
 private:

@@ -105,6 +105,7 @@ struct DevBuf {
     uint64_t* p  = nullptr;
     size_t words = 0;
     std::shared_ptr<DevBuf> parent;  // a window of another buffer (packed evaluation keys): uses are recorded on the parent
+    bool external = false;           // memory the backend does not own (e.g. a tensor an RCCL collective filled): never pooled or freed
     struct Use {
         uint32_t stream;
         uint64_t seq;
@@ -117,6 +118,8 @@ struct DevBuf {
 using Buf = std::shared_ptr<DevBuf>;
 Buf Alloc(size_t words);
 Buf View(const Buf& parent, size_t offsetWords, size_t words);
+// device memory owned by the caller (it must outlive every tower that adopts a window of it)
+Buf WrapExternal(uint64_t* devPtr, size_t words);
 
 // One device operation (a group of launches) of the calling thread, on that thread's stream.
 class Op {
