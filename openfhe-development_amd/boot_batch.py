@@ -1,0 +1,154 @@
+"""BASELINE configs[3] as north_star states it: a batch of CKKS ciphertexts bootstrapped through the reference's own API
+(cc->EvalBootstrap) on the HIP backend of DCRTPoly, the batch sharded over one process per GPU, the evaluation keys generated on
+rank 0 and replicated over xGMI with scatter + all-gather (shard.allgather_words).
+
+The native side is openfhe-development_amd/hal/bootstrap_batch.cpp (a C ABI over the reference's CryptoContext, built into
+hal/_build/libfhe_boot_batch_hip.so; the same source against the stock libraries is the TEST-ONLY byte-for-byte reference).  This
+module is the ctypes binding and the per-rank sequence; bench.py and tests/test_multi_gpu_gloo.py call `run_rank`."""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIP_SO = os.path.join(ROOT, "openfhe-development_amd", "hal", "_build", "libfhe_boot_batch_hip.so")
+STOCK_SO = os.path.join(ROOT, "tests", "hal", "_build", "libfhe_boot_batch_stock.so")
+u32, u64, vp = C.c_uint32, C.c_uint64, C.c_void_p
+
+
+class BootBatch:
+    def __init__(self, so, logN, slots, budget=(4, 4), levels_after=5, prng=None, device=0):
+        if not os.path.exists(so):
+            raise RuntimeError(f"{so} not built (./build.sh hal needs the reference sources)")
+        L = self.L = C.CDLL(so)
+        L.fbb_create.restype, L.fbb_create.argtypes = vp, [u32, u32, u32, u32, u32, C.c_char_p, C.c_int]
+        L.fbb_error.restype, L.fbb_error.argtypes = C.c_char_p, [vp]
+        L.fbb_destroy.argtypes = [vp]
+        L.fbb_shape.argtypes = [vp, C.POINTER(u32)]
+        L.fbb_encrypt.argtypes = [vp, u32, u32, u32]
+        L.fbb_keygen.argtypes = [vp]
+        L.fbb_key_count.restype, L.fbb_key_count.argtypes = u32, [vp, C.POINTER(u32), u32]
+        L.fbb_key_layout.argtypes = [vp, C.POINTER(u64), C.POINTER(u32)]
+        L.fbb_make_key_shells.argtypes = [vp, C.POINTER(u32), u32]
+        L.fbb_export_keys.argtypes = [vp, vp]
+        L.fbb_adopt_keys.argtypes = [vp, vp]
+        L.fbb_bootstrap_all.restype, L.fbb_bootstrap_all.argtypes = C.c_double, [vp, C.c_int, C.c_int, C.c_int]
+        L.fbb_check.restype, L.fbb_check.argtypes = C.c_double, [vp, u32, C.POINTER(C.c_double)]
+        L.fbb_dump.argtypes = [vp, C.c_char_p, u32, u32]
+        self.h = L.fbb_create(logN, slots, budget[0], budget[1], levels_after, prng.encode() if prng else None, device)
+        self._ok(0)
+        sh = (u32 * 5)()
+        L.fbb_shape(self.h, sh)
+        self.N, self.sizeQ, self.sizeP, self.dnum, self.depth = (int(v) for v in sh)
+
+    def _ok(self, rc):
+        err = self.L.fbb_error(self.h).decode()
+        if rc != 0 or err:
+            raise RuntimeError("bootstrap batch: " + (err or f"status {rc}"))
+
+    def encrypt(self, total, first, count):
+        self._ok(self.L.fbb_encrypt(self.h, total, first, count))
+
+    def keygen(self):
+        self._ok(self.L.fbb_keygen(self.h))
+
+    def key_indices(self):
+        n = self.L.fbb_key_count(self.h, None, 0)
+        idx = (u32 * n)()
+        self.L.fbb_key_count(self.h, idx, n)
+        return np.array(list(idx), np.uint32)
+
+    def key_layout(self):
+        w, per = u64(), u32()
+        self.L.fbb_key_layout(self.h, C.byref(w), C.byref(per))
+        return int(w.value), int(per.value)
+
+    def make_key_shells(self, indices):
+        idx = np.ascontiguousarray(indices, dtype=np.uint32)
+        self._ok(self.L.fbb_make_key_shells(self.h, idx.ctypes.data_as(C.POINTER(u32)), len(idx)))
+
+    def export_keys(self, dev_ptr):
+        self._ok(self.L.fbb_export_keys(self.h, vp(dev_ptr)))
+
+    def adopt_keys(self, dev_ptr):
+        self._ok(self.L.fbb_adopt_keys(self.h, vp(dev_ptr)))
+
+    def bootstrap_all(self, threads, reps, warmup=1):
+        s = self.L.fbb_bootstrap_all(self.h, threads, reps, warmup)
+        self._ok(0 if s >= 0 else 1)
+        return s
+
+    def check(self, i):
+        vals = (C.c_double * 8)()
+        return self.L.fbb_check(self.h, i, vals), list(vals)
+
+    def dump(self, path, lo, hi):
+        self._ok(self.L.fbb_dump(self.h, path.encode(), lo, hi))
+
+    def close(self):
+        if self.h:
+            self.L.fbb_destroy(self.h)
+            self.h = None
+
+
+def run_rank(logN, slots, total, threads, reps, device, prng, dist=None, torch_device="cpu", budget=(4, 4), levels_after=5, so=HIP_SO,
+             dump_path=None, warmup=1):
+    """One rank of the sharded batch.  dist: torch.distributed (initialised) or None for a single process.  Returns a dict of
+    timings; with dump_path the rank's bootstrapped ciphertexts are written there (tests)."""
+    from . import shard
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
+    t0 = time.perf_counter()
+    bb = BootBatch(so, logN, slots, budget, levels_after, prng, device)
+    lo, hi = shard.shard_range(total, rank, world)
+    bb.encrypt(total, lo, hi - lo)  # (before any key generation: every rank draws the same randomness for the same ciphertext)
+    t_setup = time.perf_counter() - t0
+    res = {"rank": rank, "world": world, "ciphertexts": hi - lo, "setup_s": round(t_setup, 2)}
+    t0 = time.perf_counter()
+    if rank == 0:
+        bb.keygen()
+    res["keygen_s"] = round(time.perf_counter() - t0, 2)
+    if world > 1:
+        import torch
+        # rank 0 tells the others which keys exist, then the packed key words travel: scatter + all-gather over xGMI
+        n = torch.zeros(1, dtype=torch.int64, device=torch_device)
+        idx = bb.key_indices() if rank == 0 else None
+        if rank == 0:
+            n[0] = len(idx)
+        dist.broadcast(n, src=0)
+        it = torch.zeros(int(n[0]), dtype=torch.int64, device=torch_device)
+        if rank == 0:
+            it.copy_(torch.from_numpy(idx.astype(np.int64)))
+        dist.broadcast(it, src=0)
+        if rank != 0:
+            bb.make_key_shells(it.cpu().numpy().astype(np.uint32))
+        words, per = bb.key_layout()
+        shape = (int(n[0]), per, words)
+        packed = None
+        if rank == 0:
+            packed = torch.empty(shape, dtype=torch.int64, device=torch_device)
+            bb.export_keys(packed.data_ptr())
+        dist.barrier()
+        t0 = time.perf_counter()
+        keys = shard.allgather_words(packed, shape, torch_device, src=0)
+        if str(torch_device).startswith("cuda"):
+            torch.cuda.synchronize()
+        dist.barrier()
+        t_rep = time.perf_counter() - t0
+        bb.adopt_keys(keys.data_ptr())
+        res["keys"] = keys  # (keep the tensor alive: the key towers are windows of it)
+        res["key_set_GB"] = round(keys.numel() * 8 / 1e9, 3)
+        res["key_replication_s"] = round(t_rep, 3)
+        res["key_replication_GBps"] = round(keys.numel() * 8 / 1e9 / max(t_rep, 1e-9), 1)
+        dist.barrier()
+    sec = bb.bootstrap_all(threads, reps, warmup)
+    res["seconds_per_pass"] = sec
+    res["bootstraps_per_s"] = (hi - lo) / sec if sec > 0 else 0.0
+    worst = 0.0
+    for i in range(hi - lo):
+        worst = max(worst, bb.check(i)[0])
+    res["max_abs_error"] = worst
+    if dump_path:
+        bb.dump(dump_path, 0, hi - lo)
+    res["handle"] = bb
+    return res

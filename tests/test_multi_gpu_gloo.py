@@ -229,3 +229,60 @@ dist.destroy_process_group()
            "--master-port", str(port), str(worker), ROOT, str(ok)]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and ok.exists(), out.stdout[-2000:] + out.stderr[-3000:]
+
+
+WORKER_BOOT = r"""
+import os, sys
+ROOT = sys.argv[1]; out = sys.argv[2]
+sys.path.insert(0, ROOT)
+import torch, torch.distributed as dist
+from openfhe_amd import boot_batch as bb
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+os.environ["FHE_HIP_LIB"] = os.path.join(ROOT, "tests", "emu", "libfhe_emu.so")   # the lane emulator: CPU tensors are its device memory
+os.environ["FHE_HAL_REQUIRE_DEVICE"] = "1"
+prng = os.path.join(ROOT, "tests", "hal", "_build", "libdetprng.so")
+r = bb.run_rank(8, 8, 2, 1, 1, 0, prng, dist=dist, torch_device="cpu", budget=(1, 1), levels_after=1, dump_path=out + f".rank{rank}.bin", warmup=0)
+assert r["ciphertexts"] == 1 and r["max_abs_error"] < 1e-3, r
+assert r["key_set_GB"] > 0 and r["key_replication_s"] >= 0
+if rank != 0:
+    assert r["keygen_s"] < 0.5, "a rank other than 0 generated keys"   # (its key objects are shells: the words arrived by all-gather)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_sharded_bootstrap_batch_with_replicated_keys(tmp_path):
+    """BASELINE configs[3] in miniature (N = 2^8, gloo, the lane emulator): 2 ciphertexts, one per rank; rank 0 generates the relinearisation
+    and rotation keys, the packed key words reach rank 1 by scatter + all-gather and become the device words of key objects that never had
+    any; every rank's cc->EvalBootstrap output is identical, byte for byte, to the stock backend's bootstrap of the same ciphertext"""
+    import pytest
+    sys.path.insert(0, ROOT)
+    from openfhe_amd import boot_batch as bb
+    if not (os.path.exists(bb.HIP_SO) and os.path.exists(bb.STOCK_SO)):
+        pytest.skip("hal/_build/libfhe_boot_batch_hip.so not built (./build.sh hal needs the reference sources)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    worker = tmp_path / "worker_boot.py"
+    worker.write_text(WORKER_BOOT)
+    out = str(tmp_path / "boot")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        env.pop("FHE_HAL_ALLOW_HOST", None)
+        procs.append(subprocess.Popen([sys.executable, str(worker), ROOT, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=1200)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    # the stock backend, one process, the whole batch
+    ref = subprocess.run([sys.executable, "-c", f"""
+import sys; sys.path.insert(0, {ROOT!r})
+from openfhe_amd import boot_batch as bb
+r = bb.run_rank(8, 8, 2, 1, 1, 0, {os.path.join(ROOT, 'tests', 'hal', '_build', 'libdetprng.so')!r}, budget=(1, 1), levels_after=1,
+                dump_path={out + '.stock.bin'!r}, warmup=0, so=bb.STOCK_SO)
+"""], env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=600)
+    assert ref.returncode == 0, ref.stdout + ref.stderr
+    stock = open(out + ".stock.bin", "rb").read()
+    got = open(out + ".rank0.bin", "rb").read() + open(out + ".rank1.bin", "rb").read()
+    assert len(stock) > 10000 and got == stock, "a rank's bootstrapped ciphertext differs from the stock backend's"
