@@ -25,6 +25,7 @@ class BootBatch:
         L.fbb_create.restype, L.fbb_create.argtypes = vp, [u32, u32, u32, u32, u32, C.c_char_p, C.c_int]
         L.fbb_error.restype, L.fbb_error.argtypes = C.c_char_p, [vp]
         L.fbb_destroy.argtypes = [vp]
+        L.fbb_set_omp_threads.argtypes = [C.c_int]
         L.fbb_shape.argtypes = [vp, C.POINTER(u32)]
         L.fbb_encrypt.argtypes = [vp, u32, u32, u32]
         L.fbb_keygen.argtypes = [vp]
@@ -93,13 +94,16 @@ class BootBatch:
 
 
 def run_rank(logN, slots, total, threads, reps, device, prng, dist=None, torch_device="cpu", budget=(4, 4), levels_after=5, so=HIP_SO,
-             dump_path=None, warmup=1):
+             dump_path=None, warmup=1, key_threads=None):
     """One rank of the sharded batch.  dist: torch.distributed (initialised) or None for a single process.  Returns a dict of
-    timings; with dump_path the rank's bootstrapped ciphertexts are written there (tests)."""
+    timings; with dump_path the rank's bootstrapped ciphertexts are written there (tests).  key_threads: the OpenMP team during
+    set-up, encryption and key generation (pke draws from thread-local PRNGs there: equal teams give equal keys)."""
     from . import shard
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
     t0 = time.perf_counter()
     bb = BootBatch(so, logN, slots, budget, levels_after, prng, device)
+    if key_threads:
+        bb.L.fbb_set_omp_threads(key_threads)
     lo, hi = shard.shard_range(total, rank, world)
     bb.encrypt(total, lo, hi - lo)  # (before any key generation: every rank draws the same randomness for the same ciphertext)
     t_setup = time.perf_counter() - t0
@@ -141,6 +145,7 @@ def run_rank(logN, slots, total, threads, reps, device, prng, dist=None, torch_d
         res["key_replication_s"] = round(t_rep, 3)
         res["key_replication_GBps"] = round(keys.numel() * 8 / 1e9 / max(t_rep, 1e-9), 1)
         dist.barrier()
+    bb.L.fbb_set_omp_threads(max(1, threads))  # (pke's inner loops of a bootstrap running outside the batch loop stay within this team)
     sec = bb.bootstrap_all(threads, reps, warmup)
     res["seconds_per_pass"] = sec
     res["bootstraps_per_s"] = (hi - lo) / sec if sec > 0 else 0.0

@@ -112,6 +112,9 @@ void* fbb_create(uint32_t logN, uint32_t slots, uint32_t budgetEnc, uint32_t bud
     return b;
 }
 const char* fbb_error(void* h) { return static_cast<Batch*>(h)->error.c_str(); }
+// the OpenMP team of pke's own loops on the calling thread (key generation draws from thread-local PRNGs: two runs produce the same
+// keys only with the same team)
+void fbb_set_omp_threads(int n) { omp_set_num_threads(n); }
 void fbb_destroy(void* h) { delete static_cast<Batch*>(h); }
 // {ring dimension, Q limbs, P limbs, digits, depth}
 void fbb_shape(void* h, uint32_t out[5]) {
