@@ -80,7 +80,7 @@ struct Runtime {
     // the holder of every live context (plan look-ups go ctx -> holder; the caller of a look-up holds a reference)
     std::mutex holderMutex;
     std::map<fhe_ctx*, CtxHolder*> holders;
-    std::atomic<uint64_t> deviceOps{0}, hostFallbacks{0}, h2dBytes{0}, d2hBytes{0};
+    std::atomic<uint64_t> deviceOps{0}, hostFallbacks{0}, h2dBytes{0}, d2hBytes{0}, hostSmallRing{0}, hostData{0};
     bool requireDevice = false;
 };
 
@@ -90,6 +90,11 @@ bool sym(void* h, const char* name, F* out) {
     return *out != nullptr;
 }
 std::atomic<int> g_deviceOverride{-1};
+// set by an atexit handler that is registered right after the device library (and with it the HIP runtime) was loaded, hence runs
+// BEFORE the HIP runtime's own exit handlers: from then on no destructor of this backend calls into the device library any more
+// (objects with static storage — crypto contexts, cached plaintexts — are destroyed after the HIP runtime is gone; what they hold is
+// left to the process's end)
+std::atomic<bool> g_exiting{false};
 
 Runtime* build() {
     auto* r         = new Runtime;
@@ -156,8 +161,10 @@ Runtime* build() {
             }
             if (a.ctx_create(4, 1, &q, &psi, r->device, &r->anyCtx) != FHE_OK)
                 r->why = path + ": " + a.last_error();
-            else
+            else {
                 r->live = true;
+                std::atexit([] { g_exiting.store(true); });
+            }
         }
     }
     if (!r->live && !std::getenv("FHE_HAL_ALLOW_HOST")) {
@@ -220,6 +227,8 @@ struct ThreadState {
         waited.assign(kMaxStreams, 0);
     }
     ~ThreadState() {
+        if (g_exiting.load())
+            return;
         // the thread ends: drain its stream, hand its cached buffers to the shared lists (nothing is pending on them any more)
         // and let a later thread reuse the stream (the sequence counters keep counting: old stamps stay "enqueued")
         Runtime& r = rt();
@@ -277,6 +286,8 @@ DevBuf* root_of(DevBuf* b) {
 }  // namespace
 
 CtxHolder::~CtxHolder() {
+    if (g_exiting.load())
+        return;
     Runtime& r = rt();
     {
         std::lock_guard<std::mutex> lk(r.holderMutex);
@@ -347,7 +358,7 @@ void Op::HostSync() {
 }
 
 DevBuf::~DevBuf() {
-    if (!p || parent || external)
+    if (!p || parent || external || g_exiting.load())
         return;
     Runtime& r      = rt();
     ThreadState* ts = thread_state();
@@ -516,9 +527,20 @@ static void trace_site(const char* kind, const char* member, uint64_t amount) {
     }
     (*g_traceSites)[key] += amount;
 }
-void CountHost(const char* member) {
+void OtherHostCounts(uint64_t out[2]) { out[0] = rt().hostSmallRing, out[1] = rt().hostData; }
+void CountHost(const char* member, uint32_t ringDim, bool hostData) {
     Runtime& r       = rt();
     const char* name = t_scope ? t_scope : member;
+    if (hostData) {
+        r.hostData.fetch_add(1, std::memory_order_relaxed);
+        trace_site("hostdata", name, 1);
+        return;
+    }
+    if (ringDim != 0 && ringDim < 16) {
+        r.hostSmallRing.fetch_add(1, std::memory_order_relaxed);
+        trace_site("hostop-ring<16", name, 1);
+        return;
+    }
     r.hostFallbacks.fetch_add(1, std::memory_order_relaxed);
     member_slot(name).host.fetch_add(1, std::memory_order_relaxed);
     trace_site("hostop", name, 1);
@@ -758,6 +780,8 @@ struct KsDomain {
     uint64_t tick = 0;
     std::array<std::vector<uint8_t>, kCompositeKinds> checked;
     ~KsDomain() {
+        if (g_exiting.load())
+            return;
         Runtime& r = rt();
         keys.clear();
         if (plan)
@@ -862,7 +886,10 @@ PackedKey DomainKey(KsDomain& d, const std::vector<Buf>& b, const std::vector<Bu
     }
     fhe_ks_key* raw = nullptr;
     Check(r.api.ks_key_wrap(d.plan, pb, pa, &raw), "HIP backend: evaluation key for the key-switching plan");
-    e.pk.key = std::shared_ptr<fhe_ks_key>(raw, [](fhe_ks_key* k) { rt().api.ks_key_destroy(k); });
+    e.pk.key = std::shared_ptr<fhe_ks_key>(raw, [](fhe_ks_key* k) {
+        if (!g_exiting.load())
+            rt().api.ks_key_destroy(k);
+    });
     e.sources = b;
     e.sources.insert(e.sources.end(), a.begin(), a.end());
     e.lastUse = ++d.tick;
@@ -934,7 +961,7 @@ extern "C" size_t fhe_hal_member_stats(char* buf, size_t cap) {
 extern "C" void fhe_hal_stats_reset(void) {
     using namespace lbcrypto::hiprt;
     auto& r = rt();
-    r.deviceOps = 0, r.hostFallbacks = 0, r.h2dBytes = 0, r.d2hBytes = 0;
+    r.deviceOps = 0, r.hostFallbacks = 0, r.h2dBytes = 0, r.d2hBytes = 0, r.hostSmallRing = 0, r.hostData = 0;
     for (auto& m : g_members)
         m.device = 0, m.host = 0, m.reads = 0;
 }
@@ -949,3 +976,4 @@ extern "C" void fhe_hal_trace_reset(void) {
 extern "C" void fhe_hal_composite_stats(uint64_t out[3]) {
     out[0] = lbcrypto::hiprt::g_compositeCalls, out[1] = lbcrypto::hiprt::g_checksOk, out[2] = lbcrypto::hiprt::g_checksBad;
 }
+extern "C" void fhe_hal_other_host_counts(uint64_t out[2]) { lbcrypto::hiprt::OtherHostCounts(out); }

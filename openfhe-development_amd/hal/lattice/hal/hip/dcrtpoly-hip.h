@@ -91,7 +91,7 @@ public:
     DCRTPolyHipImpl(const PolyLargeType& e, const std::shared_ptr<Params>& params) : m_h{e, params} {}
     DCRTPolyType& operator=(const PolyLargeType& rhs) {
         FHE_HAL_MEMBER();
-        Hm() = rhs;
+        Hm(__func__, true) = rhs;
         return *this;
     }
     // the "ModRaise" constructor (dcrtpoly-impl.h:87-93): one polynomial modulo q_0 lifted, centred, into every limb
@@ -99,12 +99,12 @@ public:
         hiprt::MemberScope scope("ModRaise");
         if (!ModRaiseOnDevice(e, params)) {
             m_h = HostType(e, params);
-            hiprt::CountHost("ModRaise");
+            hiprt::CountHost("ModRaise", params->GetRingDimension());
         }
     }
     DCRTPolyType& operator=(const PolyType& rhs) {
         FHE_HAL_MEMBER();
-        Hm() = rhs;
+        Hm(__func__, true) = rhs;
         return *this;
     }
     explicit DCRTPolyHipImpl(const std::vector<PolyType>& elements) : m_h{elements} {}
@@ -126,27 +126,27 @@ public:
 
     DCRTPolyType& operator=(std::initializer_list<uint64_t> rhs) override {
         FHE_HAL_MEMBER();
-        Hm() = rhs;
+        Hm(__func__, true) = rhs;
         return *this;
     }
     DCRTPolyType& operator=(uint64_t val) {
         FHE_HAL_MEMBER();
-        Hm() = val;
+        Hm(__func__, true) = val;
         return *this;
     }
     DCRTPolyType& operator=(const std::vector<int64_t>& rhs) {
         FHE_HAL_MEMBER();
-        Hm() = rhs;
+        Hm(__func__, true) = rhs;
         return *this;
     }
     DCRTPolyType& operator=(const std::vector<int32_t>& rhs) {
         FHE_HAL_MEMBER();
-        Hm() = rhs;
+        Hm(__func__, true) = rhs;
         return *this;
     }
     DCRTPolyType& operator=(std::initializer_list<std::string> rhs) {
         FHE_HAL_MEMBER();
-        Hm() = rhs;
+        Hm(__func__, true) = rhs;
         return *this;
     }
 
@@ -634,7 +634,7 @@ public:
         if (ScaleAndRoundNativeOnDevice(t, &tQHatInvModqDivqModt, &tQHatInvModqBDivqModt, &tQHatInvModqDivqFrac, &tQHatInvModqBDivqFrac, nullptr,
                                         NativeInteger(0), nullptr, nullptr, &out))
             return out;
-        hiprt::CountHost(__func__);
+        hiprt::CountHost(__func__, RingOf(m_h));
         return Hc().ScaleAndRound(t, tQHatInvModqDivqModt, tQHatInvModqDivqModtPrecon, tQHatInvModqBDivqModt,
                                   tQHatInvModqBDivqModtPrecon, tQHatInvModqDivqFrac, tQHatInvModqBDivqFrac);
     }
@@ -667,7 +667,7 @@ public:
         PolyType out;
         if (ScaleAndRoundNativeOnDevice(t, nullptr, nullptr, nullptr, nullptr, &moduliQ, tgamma, &tgammaQHatModq, &negInvqModtgamma, &out))
             return out;
-        hiprt::CountHost(__func__);
+        hiprt::CountHost(__func__, RingOf(m_h));
         return Hc().ScaleAndRound(moduliQ, t, tgamma, tgammaQHatModq, tgammaQHatModqPrecon, negInvqModtgamma,
                                   negInvqModtgammaPrecon);
     }
@@ -823,15 +823,15 @@ public:
     }
     std::vector<PolyType>& GetAllElements() {
         FHE_HAL_MEMBER();
-        return Hm().GetAllElements();
+        return Hm(__func__, true).GetAllElements();
     }
     void SetElementAtIndex(usint index, const PolyType& element) {
         FHE_HAL_MEMBER();
-        Hm().SetElementAtIndex(index, element);
+        Hm(__func__, true).SetElementAtIndex(index, element);
     }
     void SetElementAtIndex(usint index, PolyType&& element) {
         FHE_HAL_MEMBER();
-        Hm().SetElementAtIndex(index, std::move(element));
+        Hm(__func__, true).SetElementAtIndex(index, std::move(element));
     }
 
     // ---- row-level helpers for the backend's own overrides of pke's limb loops (keyswitch/keyswitch-hybrid.h in this directory) --
@@ -1054,12 +1054,15 @@ private:
     size_t Words() const {
         return (size_t)NumLimbs() * m_h.GetParams()->GetRingDimension();
     }
+    static uint32_t RingOf(const HostType& h) {
+        return h.GetParams() ? h.GetParams()->GetRingDimension() : 0;
+    }
     static DCRTPolyType Wrap(HostType&& h, const char* who = __builtin_FUNCTION()) {
-        hiprt::CountHost(who);
+        hiprt::CountHost(who, RingOf(h));
         return DCRTPolyType(std::move(h));
     }
     static std::vector<DCRTPolyType> WrapAll(std::vector<HostType>&& v, const char* who = __builtin_FUNCTION()) {
-        hiprt::CountHost(who);
+        hiprt::CountHost(who, v.empty() ? 0 : RingOf(v[0]));
         std::vector<DCRTPolyType> r;
         r.reserve(v.size());
         for (auto& h : v)
@@ -1180,10 +1183,13 @@ private:
         SyncHost(who);
         return m_h;
     }
-    HostType& Hm(const char* who = __builtin_FUNCTION()) {  // mutable host access: the device copy is stale afterwards
+    // mutable host access: the device copy is stale afterwards.  hostData: the caller PRODUCES words on the host (an encoder or a sampler
+    // filling limbs); while the tower has no device copy that is not a fall-back of anything and is counted apart
+    HostType& Hm(const char* who = __builtin_FUNCTION(), bool hostData = false) {
+        const bool hadDevice = m_d != nullptr;
         SyncHost(who);
         m_d.reset();
-        hiprt::CountHost(who);
+        hiprt::CountHost(who, RingOf(m_h), hostData && !hadDevice);
         return m_h;
     }
     // device words valid (uploads the mirror if needed); r.idx[0] = context limbs of this tower

@@ -181,10 +181,15 @@ struct MemberScope {
 struct Stats {
     uint64_t deviceOps, hostFallbacks, h2dBytes, d2hBytes;
 };
+// {host-mirror executions on rings below 16, host-side productions of words} since process start / the last reset
+void OtherHostCounts(uint64_t out[2]);
 void TraceMember(const char* member);  // the member about to touch words (FHE_HAL_TRACE attributes PCIe bytes to it)
 void D2D(Op& op, uint64_t* dst, const uint64_t* src, size_t bytes, const char* what);  // device copy (+ trace)
 void CountDevice(const char* member = __builtin_FUNCTION());
-void CountHost(const char* member);      // member = the DCRTPoly member that went to the host mirror
+// member = the DCRTPoly member that went to the host mirror.  ringDim < 16 (outside the device library's domain by specification) and
+// hostData (the host PRODUCES the words: encoders and samplers filling limbs with SetElementAtIndex / operator=, no device copy involved)
+// are counted apart from the fall-backs of arithmetic
+void CountHost(const char* member, uint32_t ringDim = 0, bool hostData = false);
 void CountHostRead(const char* member);  // a const member read the mirror after a device -> host copy
 void CountH2D(size_t bytes);
 void CountD2H(size_t bytes);
@@ -195,6 +200,8 @@ void CountD2H(size_t bytes);
 extern "C" {
 // {device operations, host fallbacks, bytes host->device, bytes device->host} since process start
 void fhe_hal_stats(uint64_t out[4]);
+// {host-mirror executions on rings of dimension < 16, words produced on the host (encoders, samplers)}: not fall-backs, counted apart
+void fhe_hal_other_host_counts(uint64_t out[2]);
 // per member: "name deviceOps hostOps hostReads\n" for every member seen so far, into buf (returns the length needed)
 size_t fhe_hal_member_stats(char* buf, size_t cap);
 // forgets all counters (a test program calls it after its set-up phase)

@@ -24,6 +24,7 @@ extern "C" void fhe_hal_trace_reset(void) __attribute__((weak));
 extern "C" size_t fhe_hal_member_stats(char* buf, size_t cap) __attribute__((weak));
 extern "C" void fhe_hal_stats_reset(void) __attribute__((weak));
 extern "C" void fhe_hal_composite_stats(uint64_t out[3]) __attribute__((weak));
+extern "C" void fhe_hal_other_host_counts(uint64_t out[2]) __attribute__((weak));
 // the set-up phase (context, keys, encryption: samplers and encoders produce their words on the host) ends here: the counters the
 // tests assert on cover the EVALUATION phase (and the decryptions at the end) only
 static void evaluation_phase_begins() {
