@@ -977,3 +977,104 @@ extern "C" void fhe_hal_composite_stats(uint64_t out[3]) {
     out[0] = lbcrypto::hiprt::g_compositeCalls, out[1] = lbcrypto::hiprt::g_checksOk, out[2] = lbcrypto::hiprt::g_checksBad;
 }
 extern "C" void fhe_hal_other_host_counts(uint64_t out[2]) { lbcrypto::hiprt::OtherHostCounts(out); }
+
+// ---- ChineseRemainderTransformFTT<NativeVector> (math/math-hal.h:60-106, math/hal/transform.h:60-163): the four transform members, declared
+// as explicit specialisations by this backend's math/hal/intnat/transformnat-impl.h.  One limb of a ring N >= 2^12 (FHE_HAL_FTT_MIN_LOGN) whose
+// modulus is in the device library's domain goes to the device with the CALLER's root of unity (the context is built from it: identical
+// twiddles); everything else runs the reference's wrapper lines (transformnat-impl.h:646-712) on its NumberTheoreticTransformNat. ----
+#include "math/math-hal.h"
+#include "math/nbtheory.h"
+namespace intnat {
+namespace {
+// element (N words modulo q) through fhe_ntt_fwd / fhe_ntt_inv; false: not the device's
+bool FttOnDevice(bool inverse, const HipFttInteger& rootOfUnity, uint32_t cycloOrder, const HipFttVector& in, HipFttVector* out) {
+    using namespace lbcrypto::hiprt;
+    static const uint32_t minLogN = std::getenv("FHE_HAL_FTT_MIN_LOGN") ? std::atoi(std::getenv("FHE_HAL_FTT_MIN_LOGN")) : 12;
+    const uint32_t N = cycloOrder >> 1;
+    if (!Available() || N < (1u << minLogN) || in.GetLength() != N || (N & (N - 1)))
+        return false;
+    const uint64_t q = in.GetModulus().ConvertToInt<uint64_t>(), psi = rootOfUnity.ConvertToInt<uint64_t>();
+    Resolved r;
+    if (!Resolve(N, {LimbSet{&q, &psi, 1}}, &r))
+        return false;
+    if (out != &in) {
+        if (out->GetLength() != N)
+            *out = HipFttVector(N, in.GetModulus());
+        else
+            out->SetModulus(in.GetModulus());
+    }
+    Op op;
+    auto d       = Alloc(N);
+    uint64_t* dp = op.W(d);
+    Check(api().h2d(r.ctx, dp, &in[0], (size_t)N * 8, op.s), "ChineseRemainderTransformFTT host -> device");
+    Check((inverse ? api().ntt_inv : api().ntt_fwd)(r.ctx, dp, r.idx[0].data(), 1, 1, op.s), "ChineseRemainderTransformFTT");
+    Check(api().d2h(r.ctx, &(*out)[0], dp, (size_t)N * 8, op.s), "ChineseRemainderTransformFTT device -> host");
+    op.HostSync();
+    CountH2D((size_t)N * 8);
+    CountD2H((size_t)N * 8);
+    CountDevice("ChineseRemainderTransformFTT");
+    return true;
+}
+}  // namespace
+
+template <>
+void ChineseRemainderTransformFTTNat<HipFttVector>::ForwardTransformToBitReverseInPlace(const HipFttInteger& rootOfUnity, const uint32_t cycloOrder,
+                                                                                        HipFttVector* element) {
+    if (rootOfUnity == HipFttInteger(1) || rootOfUnity == HipFttInteger(0))
+        return;
+    if (FttOnDevice(false, rootOfUnity, cycloOrder, *element, element))
+        return;
+    auto modulus = element->GetModulus();
+    PreCompute(rootOfUnity, cycloOrder, modulus);
+    NumberTheoreticTransformNat<HipFttVector>().ForwardTransformToBitReverseInPlace(m_rootOfUnityReverseTableByModulus[modulus],
+                                                                                   m_rootOfUnityPreconReverseTableByModulus[modulus], element);
+}
+template <>
+void ChineseRemainderTransformFTTNat<HipFttVector>::ForwardTransformToBitReverse(const HipFttVector& element, const HipFttInteger& rootOfUnity,
+                                                                                 const uint32_t cycloOrder, HipFttVector* result) {
+    if (rootOfUnity == HipFttInteger(1) || rootOfUnity == HipFttInteger(0)) {
+        *result = element;
+        return;
+    }
+    if (FttOnDevice(false, rootOfUnity, cycloOrder, element, result))
+        return;
+    auto modulus = element.GetModulus();
+    PreCompute(rootOfUnity, cycloOrder, modulus);
+    NumberTheoreticTransformNat<HipFttVector>().ForwardTransformToBitReverse(element, m_rootOfUnityReverseTableByModulus[modulus],
+                                                                            m_rootOfUnityPreconReverseTableByModulus[modulus], result);
+}
+template <>
+void ChineseRemainderTransformFTTNat<HipFttVector>::InverseTransformFromBitReverseInPlace(const HipFttInteger& rootOfUnity, const uint32_t cycloOrder,
+                                                                                          HipFttVector* element) {
+    if (rootOfUnity == HipFttInteger(1) || rootOfUnity == HipFttInteger(0))
+        return;
+    if (FttOnDevice(true, rootOfUnity, cycloOrder, *element, element))
+        return;
+    auto modulus = element->GetModulus();
+    PreCompute(rootOfUnity, cycloOrder, modulus);
+    const uint32_t msb = lbcrypto::GetMSB((cycloOrder >> 1) - 1);
+    NumberTheoreticTransformNat<HipFttVector>().InverseTransformFromBitReverseInPlace(
+        m_rootOfUnityInverseReverseTableByModulus[modulus], m_rootOfUnityInversePreconReverseTableByModulus[modulus],
+        m_cycloOrderInverseTableByModulus[modulus][msb], m_cycloOrderInversePreconTableByModulus[modulus][msb], element);
+}
+template <>
+void ChineseRemainderTransformFTTNat<HipFttVector>::InverseTransformFromBitReverse(const HipFttVector& element, const HipFttInteger& rootOfUnity,
+                                                                                   const uint32_t cycloOrder, HipFttVector* result) {
+    if (rootOfUnity == HipFttInteger(1) || rootOfUnity == HipFttInteger(0)) {
+        *result = element;
+        return;
+    }
+    if (FttOnDevice(true, rootOfUnity, cycloOrder, element, result))
+        return;
+    auto modulus = element.GetModulus();
+    result->SetModulus(modulus);
+    PreCompute(rootOfUnity, cycloOrder, modulus);
+    const uint32_t n = element.GetLength();
+    for (uint32_t i = 0; i < n; ++i)
+        (*result)[i] = element[i];
+    const uint32_t msb = lbcrypto::GetMSB(n - 1);
+    NumberTheoreticTransformNat<HipFttVector>().InverseTransformFromBitReverseInPlace(
+        m_rootOfUnityInverseReverseTableByModulus[modulus], m_rootOfUnityInversePreconReverseTableByModulus[modulus],
+        m_cycloOrderInverseTableByModulus[modulus][msb], m_cycloOrderInversePreconTableByModulus[modulus][msb], result);
+}
+}  // namespace intnat

@@ -263,6 +263,46 @@ int main(int argc, char** argv) {
             dumpTower(run ? "SK, perturbed tables" : "SK", a);
         }
     }
+    else if (mode == "ftt") {
+        // ChineseRemainderTransformFTT<NativeVector> (math/math-hal.h:60-106) directly and through NativePoly::SwitchFormat (poly-impl.h:420-440):
+        // rings 2^lo .. 2^logN, a 59-bit NTT prime each, deterministic coefficients; every transform's output is dumped
+        const uint32_t lo = argc > 5 ? std::atoi(argv[5]) : 12;
+        evaluation_phase_begins();
+        for (uint32_t ln = lo; ln <= logN; ++ln) {
+            const uint32_t N = 1u << ln, M = 2 * N;
+            const NativeInteger q = LastPrime<NativeInteger>(59, M), root = RootOfUnity<NativeInteger>(M, q);
+            auto params = std::make_shared<ILNativeParams>(M, q, root);
+            NativeVector v(N, q);
+            uint64_t x = 0x9E3779B97F4A7C15ull * (ln + 1);
+            for (uint32_t i = 0; i < N; ++i) {
+                x ^= x << 13, x ^= x >> 7, x ^= x << 17;
+                v[i] = NativeInteger(x).Mod(q);
+            }
+            v[0] = NativeInteger(0), v[1] = q - NativeInteger(1);
+            auto dumpVec = [&](const NativeVector& w) {
+                for (uint32_t i = 0; i < w.GetLength(); ++i) {
+                    const uint64_t u = w[i].ConvertToInt<uint64_t>();
+                    g_out.write(reinterpret_cast<const char*>(&u), 8);
+                }
+            };
+            NativePoly p(params, Format::COEFFICIENT, true);
+            p.SetValues(v, Format::COEFFICIENT);
+            p.SwitchFormat();  // forward, in place
+            dumpVec(p.GetValues());
+            p.SwitchFormat();  // inverse, in place: the round trip
+            dumpVec(p.GetValues());
+            if (p.GetValues() != v) {
+                std::cerr << "ftt: round trip failed at 2^" << ln << std::endl;
+                return 1;
+            }
+            NativeVector f(N, q), b(N, q);
+            ChineseRemainderTransformFTT<NativeVector>().ForwardTransformToBitReverse(v, root, M, &f);  // out of place
+            dumpVec(f);
+            ChineseRemainderTransformFTT<NativeVector>().InverseTransformFromBitReverse(f, root, M, &b);
+            dumpVec(b);
+            std::cout << "ftt ring 2^" << ln << " modulus " << q << " done" << std::endl;
+        }
+    }
     else if (mode == "multbatch") {
         // BASELINE configs[2] through the reference's CryptoContext: B ciphertexts at N = 2^logN, depth 20 (l = 21, dnum = 3),
         // cc->EvalMult (tensor + HYBRID key switch) on each, the ciphertexts spread over host threads (one OpenMP loop over the

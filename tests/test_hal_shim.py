@@ -192,6 +192,34 @@ def test_shim_behz_members_use_the_callers_tables_on_gpu(tmp_path):
     behz_tables(tmp_path, 13, HIP)
 
 
+def ftt(tmp_path, lo, hi, device_lib, env_extra=None):
+    ensure_built()
+    so, sh = str(tmp_path / "stock.bin"), str(tmp_path / "hip.bin")
+    run(PROGS[0], so, "ftt", hi, extra=(lo,))
+    if env_extra:
+        os.environ.update(env_extra)
+    try:
+        out_hip = run(PROGS[1], sh, "ftt", hi, device_lib, extra=(lo,))
+    finally:
+        for k in (env_extra or {}):
+            os.environ.pop(k, None)
+    a, b = open(so, "rb").read(), open(sh, "rb").read()
+    assert len(a) == sum(4 * 8 << ln for ln in range(lo, hi + 1)) and a == b, "NativePoly / ChineseRemainderTransformFTT transforms differ from the default backend's"
+    st = member_stats(out_hip)
+    assert st.get("ChineseRemainderTransformFTT", (0, 0, 0))[0] == 4 * (hi - lo + 1), st  # every transform of every ring ran on the device
+
+
+def test_shim_ftt_hook_on_emulator(tmp_path):
+    """ChineseRemainderTransformFTT<NativeVector> (the NTT hook of SURVEY 8(b)) — NativePoly::SwitchFormat and the out-of-place members —
+    on the device: byte-identical to the default backend (threshold lowered so that the emulator's small rings take the device path)"""
+    ftt(tmp_path, 5, 12, EMU, {"FHE_HAL_FTT_MIN_LOGN": "5"})
+
+
+@pytest.mark.gpu
+def test_shim_ftt_hook_on_gpu(tmp_path):
+    ftt(tmp_path, 12, 16, HIP)
+
+
 def test_shim_without_a_device_library_fails_loudly(tmp_path):
     """no silent CPU path: an unloadable device library aborts the first DCRTPoly operation with a message; FHE_HAL_ALLOW_HOST=1 is
     the explicit opt-in to the host mirror (the class then is the default backend)"""
