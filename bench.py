@@ -685,13 +685,11 @@ def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev,
     os.environ["FHE_HAL_REQUIRE_DEVICE"] = "1"
     slots, total, key_threads = 1 << (logN - 1), per_gpu * world, 8
     tmp = tempfile.mkdtemp(prefix="fhe_bootbatch_")
-    dump = os.path.join(tmp, f"hip{rank}.bin")
     r = bb.run_rank(logN, slots, total, threads, 2, device, prng, dist=dist if world > 1 else None,
                     torch_device=tdev if tdev is not None else "cpu", dump_path=None, warmup=1, key_threads=key_threads)
     h = r.pop("handle")
-    r.pop("keys", None)
-    single = h.bootstrap_all(1, 1, 0) / max(1, r["ciphertexts"])  # latency of one bootstrap: the same slice on one thread
-    h.dump(dump, 0, 1)
+    keep_keys = r.pop("keys", None)  # (the replicated key tensor: the key towers are windows of it until h.close())
+    single = h.single_thread_latency() / max(1, r["ciphertexts"])  # latency of one bootstrap: the same slice on one thread, one stream
     rate = r["bootstraps_per_s"]
     total_rate = rate
     if dist is not None and world > 1:
@@ -704,31 +702,44 @@ def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev,
            "bootstraps_per_s_per_gpu": round(rate, 2), "bootstraps_per_s_total": round(total_rate, 2),
            "seconds_per_bootstrap": round(single, 5), "seconds_per_pass": round(r["seconds_per_pass"], 4),
            "max_abs_error_vs_message": r["max_abs_error"], "setup_s": r["setup_s"], "keygen_s_rank0": r["keygen_s"],
-           "how": "reference pke (unmodified sources) on the HIP backend of DCRTPoly; 1 warm-up + 2 timed passes over the rank's ciphertexts",
+           "how": "reference pke (unmodified sources) on the HIP backend of DCRTPoly; 1 warm-up + 2 timed passes over the rank's ciphertexts; "
+                  "seconds_per_bootstrap = the same ciphertexts on ONE host thread / stream",
            "parity": "every output decrypted and compared with its message; byte comparison with the stock backend not run", "cpu_baseline": None}
     for k in ("key_set_GB", "key_replication_s", "key_replication_GBps"):
         if k in r:
             res[k] = r[k]
+    h.close()
+    del keep_keys
     if with_cpu and rank == 0 and world == 1 and os.path.exists(bb.STOCK_SO):
-        sdump = os.path.join(tmp, "stock.bin")
+        # parity + CPU baseline: the SAME program twice as separate processes with the same OpenMP environment (pke's samplers read
+        # thread-local PRNGs, so the keys are reproduced only by equal teams): ciphertext 0 bootstrapped on the HIP backend and on
+        # the stock backend, the two results compared byte for byte
         cthreads = min(32, os.cpu_count() or 1)
-        code = (f"import sys, time; sys.path.insert(0, {ROOT!r}); from openfhe_amd import boot_batch as bb; "
-                f"r = bb.run_rank({logN}, {slots}, 1, {cthreads}, 1, 0, {prng!r}, so=bb.STOCK_SO, dump_path={sdump!r}, warmup=0, key_threads={key_threads}); "
-                "print('seconds', r['seconds_per_pass'])")
         env = dict(os.environ, OMP_NUM_THREADS=str(cthreads))
-        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1500)
-        m = [ln for ln in p.stdout.split("\n") if ln.startswith("seconds")]
-        if p.returncode == 0 and m:
-            csec = float(m[0].split()[1])
+        secs, dumps, errs = {}, {}, ""
+        for tag, so in (("hip", "bb.HIP_SO"), ("stock", "bb.STOCK_SO")):
+            dumps[tag] = os.path.join(tmp, tag + ".bin")
+            code = (f"import sys; sys.path.insert(0, {ROOT!r}); from openfhe_amd import boot_batch as bb; "
+                    f"r = bb.run_rank({logN}, {slots}, 1, 1, 1, 0, {prng!r}, so={so}, dump_path={dumps[tag]!r}, warmup=0); "
+                    "print('seconds', r['seconds_per_pass'])")
+            p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1500)
+            m = [ln for ln in p.stdout.split("\n") if ln.startswith("seconds")]
+            if p.returncode == 0 and m:
+                secs[tag] = float(m[0].split()[1])
+            else:
+                errs += f"{tag}: {(p.stdout + p.stderr)[-300:]} "
+        if "stock" in secs:
+            csec = secs["stock"]
             res["cpu_baseline"] = {"value": round(1.0 / csec, 4), "unit": "bootstraps/s", "seconds_per_bootstrap": round(csec, 3), "cores": cthreads,
                                    "kind": "reference", "sample": "ciphertext 0 of the batch, the same program on the stock backend (oracle/_ref), 1 bootstrap"}
             res["speedup_vs_cpu"] = round(rate * csec, 1)
-            same = open(dump, "rb").read() == open(sdump, "rb").read()
-            res["parity"] = ("bootstrapped ciphertext 0 identical byte for byte to the stock backend's; every output decrypted and compared with its message"
-                             if same else "MISMATCH vs the stock backend (ciphertext 0)")
-        else:
-            res["cpu_baseline"] = {"error": (p.stdout + p.stderr)[-300:]}
-    h.close()
+        if "hip" in secs and "stock" in secs:
+            same = open(dumps["hip"], "rb").read() == open(dumps["stock"], "rb").read()
+            res["parity"] = ("bootstrapped ciphertext 0 identical byte for byte to the stock backend's (same program, same OpenMP team, deterministic "
+                             "PRNG); every output of the batch decrypted and compared with its message" if same
+                             else "MISMATCH vs the stock backend (ciphertext 0)")
+        elif errs:
+            res["parity"] = "byte comparison failed to run: " + errs
     import shutil
     shutil.rmtree(tmp, ignore_errors=True)
     return res
@@ -1128,6 +1139,12 @@ def main():
             "hbm_roofline_frac_fwd_inv": round(value / world / HBM_PEAK_GBPS, 4),
             "roofline": roof, "cpu_baseline": cpu, "evalmult": em,
             "hadamard": hadamard, "parity_at_full_size": roundtrip, "ms_per_step_per_rank": per_rank_ms,
+            # ONE rule for every cpu_baseline of this line: the reference runs with its best OpenMP team out of {8, 16, 32, 64, 128, all
+            # logical cores}.  Legs whose probe takes seconds search it live (headline NTT, linear transform, BFV: "cores" = the winner);
+            # the legs where one probe is a 10-100 s program (bootstrap, cc->EvalMult) use 32, the team that search selects on this host
+            # class (rounds 1-3: 32 every time; 8.9-10.2 s per bootstrap at 32 threads, 45 s at 256).
+            "cpu_team_rule": "best OpenMP team of {8,16,32,64,128,all}: searched live by the in-process legs, fixed at 32 (= what the search "
+                             "picks on these hosts) for the legs that run the reference as a separate program",
         }
         if keyrep is not None:
             out["rotation_key_replication"] = keyrep

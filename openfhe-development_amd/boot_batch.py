@@ -26,6 +26,7 @@ class BootBatch:
         L.fbb_error.restype, L.fbb_error.argtypes = C.c_char_p, [vp]
         L.fbb_destroy.argtypes = [vp]
         L.fbb_set_omp_threads.argtypes = [C.c_int]
+        L.fbb_set_active_levels.argtypes = [C.c_int]
         L.fbb_shape.argtypes = [vp, C.POINTER(u32)]
         L.fbb_encrypt.argtypes = [vp, u32, u32, u32]
         L.fbb_keygen.argtypes = [vp]
@@ -74,6 +75,15 @@ class BootBatch:
 
     def adopt_keys(self, dev_ptr):
         self._ok(self.L.fbb_adopt_keys(self.h, vp(dev_ptr)))
+
+    def single_thread_latency(self, reps=1):
+        """seconds per bootstrap with every OpenMP region of the process confined to its calling thread: ONE host thread, ONE stream"""
+        self.L.fbb_set_active_levels(0)
+        try:
+            s = self.bootstrap_all(1, reps, 0)
+        finally:
+            self.L.fbb_set_active_levels(1)
+        return s
 
     def bootstrap_all(self, threads, reps, warmup=1):
         s = self.L.fbb_bootstrap_all(self.h, threads, reps, warmup)
@@ -145,7 +155,6 @@ def run_rank(logN, slots, total, threads, reps, device, prng, dist=None, torch_d
         res["key_replication_s"] = round(t_rep, 3)
         res["key_replication_GBps"] = round(keys.numel() * 8 / 1e9 / max(t_rep, 1e-9), 1)
         dist.barrier()
-    bb.L.fbb_set_omp_threads(max(1, threads))  # (pke's inner loops of a bootstrap running outside the batch loop stay within this team)
     sec = bb.bootstrap_all(threads, reps, warmup)
     res["seconds_per_pass"] = sec
     res["bootstraps_per_s"] = (hi - lo) / sec if sec > 0 else 0.0

@@ -115,6 +115,9 @@ const char* fbb_error(void* h) { return static_cast<Batch*>(h)->error.c_str(); }
 // the OpenMP team of pke's own loops on the calling thread (key generation draws from thread-local PRNGs: two runs produce the same
 // keys only with the same team)
 void fbb_set_omp_threads(int n) { omp_set_num_threads(n); }
+// 0: every OpenMP region of the process runs on its calling thread alone (the latency of ONE bootstrap on ONE host thread / stream:
+// pke's inner loops would otherwise fork inside a one-thread batch loop); 1: the default (one level of parallelism)
+void fbb_set_active_levels(int n) { omp_set_max_active_levels(n); }
 void fbb_destroy(void* h) { delete static_cast<Batch*>(h); }
 // {ring dimension, Q limbs, P limbs, digits, depth}
 void fbb_shape(void* h, uint32_t out[5]) {
