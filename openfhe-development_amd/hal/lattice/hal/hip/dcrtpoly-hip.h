@@ -157,7 +157,7 @@ public:
     // dcrtpoly-impl.h:207-214
     DCRTPolyType CloneTowers(uint32_t startTower, uint32_t endTower) const {
         FHE_HAL_MEMBER();
-        if (m_d && !m_hostValid && endTower < NumLimbs() && startTower <= endTower) {
+        if (endTower < NumLimbs() && startTower <= endTower && DeviceWords()) {
             const auto& P = m_h.GetParams();
             auto params   = std::make_shared<Params>(P->GetCyclotomicOrder(), P->GetParamPartition(startTower, endTower));
             const size_t N = P->GetRingDimension(), n = endTower - startTower + 1;
