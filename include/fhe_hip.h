@@ -350,6 +350,13 @@ fhe_status fhe_approx_mod_down_bgv(fhe_ks_plan* plan, const uint64_t* x, uint32_
 size_t     fhe_rescale_workspace_bytes(const fhe_ctx* ctx, uint32_t sizeQl, uint32_t batch);
 fhe_status fhe_rescale(fhe_ctx* ctx, const uint64_t* x, uint32_t sizeQl, uint32_t batch, uint64_t* out, void* ws,
                        size_t wsBytes, void* stream);
+/* The same over any limbs of the context (limbIdx[sizeQl], NULL = the leading ones; the last entry is the dropped limb) with the
+ * CALLER's tables, host arrays of sizeQl-1 residues as DropLastElementAndScale receives them (dcrtpoly-impl.h:693-694).  When
+ * QlQlInvModqlDivqlModq[i] == -qlInvModq[i] mod q_i (the reference's own tables) on a ring of two static passes, the call is 4
+ * launches: the switched tower and its transform never go to HBM (fhe_hip.cpp rescale_run).  out must not alias x. */
+fhe_status fhe_rescale_limbs(fhe_ctx* ctx, const uint64_t* x, const uint32_t* limbIdx, uint32_t sizeQl,
+                             const uint64_t* QlQlInvModqlDivqlModq, const uint64_t* qlInvModq, uint32_t batch, uint64_t* out,
+                             void* ws, size_t wsBytes, void* stream);
 /* DCRTPolyImpl::ModReduce (dcrtpoly-impl.h:736-755) — BGV modulus switching by the last limb with plaintext modulus t
  * (tables negtInvModq / qlInvModq / tModqPrecon of CryptoParametersBGVRNS are derived inside): x [batch][sizeQl][N] in
  * `evalFormat`, out [batch][sizeQl-1][N] in the same format; ws as for fhe_rescale. */
@@ -444,6 +451,11 @@ fhe_status fhe_bfv_eval_mult_relin_behz(fhe_behz* plan, fhe_ks_plan* ks, const f
  * nLimbs); out is DEVICE memory, uint64_t[rows][2].  One read of the batch: bench.py and the full-shape tests compare EVERY
  * tower of a resident batch with the oracle's words summed on the host, instead of sampling a few towers. */
 fhe_status fhe_checksum(fhe_ctx* ctx, const uint64_t* x, uint32_t rows, uint64_t* out, void* stream);
+
+/* Kernel launches issued by this library since it was loaded, by kernel: writes lines "<kernel> <launches>\n" (most frequent first)
+ * into buf (at most cap bytes, NUL-terminated when cap > 0) and returns the length the full text needs; *total, when given, receives
+ * the sum.  (Tuning aid: the launch count of one pke operation is the difference of two calls.) */
+size_t fhe_launch_stats(char* buf, size_t cap, uint64_t* total);
 
 /* ---- host-side parameter helpers (no device work) -------------------------------------------------
  * Number theory the reference uses to pick moduli and roots, restated with 64-bit arithmetic so that a

@@ -326,19 +326,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) switch_modulus_kernel(const SwitchMo
         const uint32_t b = row / g.nLimbs, rit = row % g.nLimbs;
         const uint64_t qn = g.q[g.sel.idx[rit]];
         uint64_t v = g.src[(((uint64_t)b * g.srcStrideLimbs + g.srcLimbPos) << g.logN) + ((uint32_t)off & mask)];
-        if (qn > qs) {
-            v += (v > halfQ) ? (qn - qs) : 0;
-        }
-        else {
-            // ModSubEq semantics (ubintnat.h:889-899): operands reduced mod qn first
-            uint64_t bv = (v > halfQ) ? (qs - qn) : 0;
-            uint64_t av = v;
-            if (av >= qn)
-                av %= qn;
-            if (bv >= qn)
-                bv %= qn;
-            v = (av < bv) ? av + qn - bv : av - bv;
-        }
+        v = switch_modulus_word(v, qs, halfQ, qn);
         if (g.consts) {
             const TwPair c = g.consts[rit];
             v              = mul_shoup(v, c.w, c.wp, qn);

@@ -257,6 +257,7 @@ struct fhe_ctx {
     std::vector<void*> owned;     // every device allocation made for tables (freed in destroy)
     // cached per-level rescale tables (ckksrns-cryptoparameters.cpp:60-81): sizeQl -> {A, B} device arrays
     std::map<uint32_t, std::pair<TwPair*, TwPair*>> rescaleTabs;
+    std::map<std::vector<uint64_t>, TwPair*> constTabs;  // per-limb constants of callers' tables, by content (const_table)
     // cached ModReduce tables per (sizeQl, t): [0..l) = A_i, [l..2l) = B_i, [2l] = negtInvModq   (fhe_mod_reduce)
     std::map<std::pair<uint32_t, uint64_t>, TwPair*> modReduceTabs;
     std::mutex cacheMutex;        // guards the lazily filled caches above (callers may be OpenMP threads)
@@ -611,6 +612,7 @@ static uint32_t fill_pass_args(const fhe_ctx* c, const PassPlan& pp, bool invers
     a.xcdSwizzle = (c->N >= (uint32_t)kTile && ((nLimbs * tilesPerRow) % 8u == 0)) ? 1u : 0u;
     a.epiMode = 0, a.epiSplit = 0, a.epiAStride = 0, a.epiAFirst = 0;
     a.epiA = nullptr, a.epiC = nullptr, a.epiOut0 = a.epiOut1 = nullptr;
+    a.proMode = 0, a.proSrcLimb = 0;
     return grid;
 }
 // forward: bound class of a static pass's input; inverse: does the pass end the transform (ntt_static.h MODE)
@@ -624,10 +626,23 @@ static int static_mode(const fhe_ctx* c, const PassPlan& pp, bool inverse) {
 static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse, const uint64_t* xin, uint64_t* xout,
                               const LimbSel& sel, uint32_t nLimbs, uint32_t batch, bool canonOut, void* stream,
                               uint32_t inStride = 0, uint32_t inFirst = 0, uint32_t outStride = 0, uint32_t outFirst = 0,
-                              const NttEpilogue* epi = nullptr) {
+                              const NttEpilogue* epi = nullptr, const uint32_t* proSrcLimb = nullptr) {
     NttPassArgs a;
     const uint32_t grid = fill_pass_args(c, pp, inverse, xin, xout, sel, nLimbs, batch, canonOut, inStride, inFirst, outStride,
                                          outFirst, a);
+    if (proSrcLimb) {
+        // the forward column pass that loads every limb from one row modulo q[*proSrcLimb] (ntt_prologue_supported)
+        a.proMode = 1, a.proSrcLimb = *proSrcLimb;
+        const int mode = static_mode(c, pp, inverse);
+        if (pp.layoutA && !inverse && mode == 1 && pp.T == 4)
+            FHE_LAUNCH((ntt_static_kernel<true, false, 4, 1, false, true>), grid, stream, a);
+        else if (pp.layoutA && !inverse && mode == 1 && pp.T == 5)
+            FHE_LAUNCH((ntt_static_kernel<true, false, 5, 1, false, true>), grid, stream, a);
+        else
+            return fail(FHE_ERR_UNSUPPORTED, "ntt: no prologue kernel for this pass shape");
+        LAUNCH_CHECK();
+        return FHE_OK;
+    }
     if (epi && epi->mode) {
         // only the static forward row / single pass kernels carry the epilogue (ntt_epilogue_supported)
         a.epiMode = epi->mode, a.epiSplit = epi->split, a.epiAStride = epi->aStride, a.epiAFirst = epi->aFirst;
@@ -708,10 +723,14 @@ static bool ntt_epilogue_supported(const fhe_ctx* c) {
     const uint32_t t1 = ntt_t1(c->logN), t2 = c->logN - t1;
     return t2 == 12u || (t1 == 4u && t2 >= 9u && t2 <= 12u);
 }
+// a two-pass forward transform whose column pass can carry the load prologue (NttPassArgs::proMode)
+static bool ntt_prologue_supported(const fhe_ctx* c) {
+    return c->logN > (uint32_t)kTileLog && ntt_t1(c->logN) <= 5u;
+}
 static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_t* xout, const uint32_t* limbIdx,
                           uint32_t nLimbs, uint32_t batch, void* stream, uint32_t inStride = 0, uint32_t inFirst = 0,
                           uint32_t outStride = 0, uint32_t outFirst = 0, const NttEpilogue* epi = nullptr,
-                          bool canonOut = true) {
+                          bool canonOut = true, const uint32_t* proSrcLimb = nullptr) {
     ARG_CHECK(c && xin && xout, "fhe_ntt: null argument");
     ARG_CHECK(batch >= 1, "fhe_ntt: batch must be >= 1");
     LimbSel sel;
@@ -754,7 +773,8 @@ static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_
     // (profiles/r01_sweeps.md): two streams (the hardware does not co-schedule two grids that each fill the chip) and
     // one grid whose workgroups alternate between the two roles (the waiting column workgroups take half of the four
     // resident slots of a CU away from the row workgroups: 33.2 ms instead of 30.4 ms per forward+inverse step).
-    if (fhe_status s = launch_pass(c, p1, inverse, xin, xout, sel, nLimbs, batch, false, stream, inStride, inFirst, outStride, outFirst))
+    if (fhe_status s = launch_pass(c, p1, inverse, xin, xout, sel, nLimbs, batch, false, stream, inStride, inFirst, outStride, outFirst,
+                                   nullptr, proSrcLimb))
         return s;
     return launch_pass(c, p2, inverse, xout, xout, sel, nLimbs, batch, canonOut, stream, outStride, outFirst, outStride, outFirst, epi);
 }
@@ -2349,6 +2369,75 @@ extern "C" size_t fhe_rescale_workspace_bytes(const fhe_ctx* c, uint32_t sizeQl,
     // last[batch][1][N] + tmp[batch][sizeQl-1][N]
     return ((size_t)batch * sizeQl << c->logN) * 8;
 }
+// device copy of per-limb constants {v[i], Shoup(v[i], q[limb_i])}, cached by content (the caller's tables of one level)
+static fhe_status const_table(fhe_ctx* c, const uint32_t* limbIdx, const uint64_t* v, uint32_t n, const TwPair** out) {
+    std::vector<uint64_t> key(2 * (size_t)n);
+    for (uint32_t i = 0; i < n; ++i)
+        key[i] = limbIdx ? limbIdx[i] : i, key[n + i] = v[i];
+    std::lock_guard<std::mutex> lock(c->cacheMutex);
+    auto it = c->constTabs.find(key);
+    if (it == c->constTabs.end()) {
+        std::vector<TwPair> h(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint64_t qi = c->q[key[i]];
+            if (v[i] >= qi)
+                return fail(FHE_ERR_ARG, "const_table: constant is not reduced modulo its limb");
+            h[i] = TwPair{v[i], host::shoup(v[i], qi)};
+        }
+        void* d = nullptr;
+        RT_CHECK(rt::dmalloc(&d, n * sizeof(TwPair)));
+        c->owned.push_back(d);
+        RT_CHECK(rt::h2d(d, h.data(), n * sizeof(TwPair), nullptr));
+        RT_CHECK(rt::sync(nullptr));
+        it = c->constTabs.emplace(std::move(key), (TwPair*)d).first;
+    }
+    *out = it->second;
+    return FHE_OK;
+}
+// DropLastElementAndScale (dcrtpoly-impl.h:693-712) of towers x[batch][sizeQl][N] over context limbs limbIdx[0..sizeQl) (null: the
+// leading ones) -> out[batch][sizeQl-1][N]; dA / dB: device constants QlQlInvModqlDivqlModq / qlInvModq of the kept limbs;
+// negated: dA[i] == -dB[i] mod q_i (true for the reference's own tables).  ws: last[batch][N] (+ tmp[batch][l][N] on
+// the unfused path).
+//   fused (rings of two static passes, negated tables): x*B + NTT(SwitchModulus(last)*(-B)) == (x - NTT(SwitchModulus(last)))*B with
+//   canonical residues on both sides, so the words are the reference's.  4 launches: INTT of the last limb (2), the column pass
+//   that loads every limb from the one INTT row through SwitchModulus, the row pass whose store is (x - r)*B.  Neither the
+//   switched tower nor its transform goes to HBM outside `out`.
+static fhe_status rescale_run(fhe_ctx* c, const uint64_t* x, const uint32_t* limbIdx, uint32_t sizeQl, const TwPair* dA,
+                              const TwPair* dB, bool negated, uint32_t batch, uint64_t* out, uint64_t* ws, void* st) {
+    const uint32_t l       = sizeQl - 1;
+    const uint32_t lastIdx = limbIdx ? limbIdx[l] : l;
+    uint64_t* last         = ws;                                 // [batch][N]
+    uint64_t* tmp          = last + ((size_t)batch << c->logN);  // [batch][l][N]
+    // lastPoly.SetFormat(COEFFICIENT)  (:696-697): INTT of the last limb of every tower, written densely
+    if (fhe_status s = ntt_run(c, true, x, last, &lastIdx, 1, batch, st, sizeQl, l))
+        return s;
+    static const bool noFuse = env_u32("FHE_RESCALE_UNFUSED", 0) != 0;
+    if (negated && !noFuse && ntt_epilogue_supported(c)) {
+        NttEpilogue epi;
+        epi.mode = 1, epi.split = batch, epi.aStride = sizeQl, epi.aFirst = 0;
+        epi.A = x, epi.C = dB, epi.out0 = out, epi.out1 = out;
+        if (ntt_prologue_supported(c))
+            return ntt_run(c, false, last, out, limbIdx, l, batch, st, 1, 0, 0, 0, &epi, true, &lastIdx);
+        // the single pass of N = 4096: SwitchModulus as a kernel of its own, then the transform with the fused store
+        LimbSel sel;
+        if (fhe_status s = make_sel(c, limbIdx, l, &sel, "fhe_rescale"))
+            return s;
+        if (fhe_status s = switch_modulus_run(c, out, sel, l, last, 1, 0, lastIdx, nullptr, batch, st))
+            return s;
+        return ntt_run(c, false, out, out, limbIdx, l, batch, st, 0, 0, 0, 0, &epi);
+    }
+    // tmp = SwitchModulus(last -> q_i) * QlQlInvModqlDivqlModq[i]   (:703-705)
+    LimbSel sel;
+    if (fhe_status s = make_sel(c, limbIdx, l, &sel, "fhe_rescale"))
+        return s;
+    if (fhe_status s = switch_modulus_run(c, tmp, sel, l, last, 1, 0, lastIdx, dA, batch, st))
+        return s;
+    // tmp.SwitchFormat()  (:706-707)
+    if (fhe_status s = fhe_ntt_fwd(c, tmp, limbIdx, l, batch, st))
+        return s;
+    // m_vectors[i] = m_vectors[i] * qlInvModq[i] + tmp  (:708-709); x towers are sizeQl rows apart
+    return elem_run<OP_MUL_CONST_ADD>(c, out, x, tmp, dB, limbIdx, l, batch, st, "fhe_rescale", sizeQl, 0);
+}
 extern "C" fhe_status fhe_rescale(fhe_ctx* c, const uint64_t* x, uint32_t sizeQl, uint32_t batch, uint64_t* out,
                                   void* wsv, size_t wsBytes, void* st) {
     ARG_CHECK(c && x && out && wsv, "fhe_rescale: null argument");
@@ -2356,8 +2445,6 @@ extern "C" fhe_status fhe_rescale(fhe_ctx* c, const uint64_t* x, uint32_t sizeQl
     ARG_CHECK(batch >= 1 && wsBytes >= fhe_rescale_workspace_bytes(c, sizeQl, batch), "fhe_rescale: workspace too small");
     RT_CHECK(rt::set_device(c->device));
     const uint32_t l = sizeQl - 1;
-    uint64_t* last   = (uint64_t*)wsv;                       // [batch][N]
-    uint64_t* tmp    = last + ((size_t)batch << c->logN);     // [batch][l][N]
     // tables (ckksrns-cryptoparameters.cpp:60-81): qlInvModq[i] = q_l^-1 mod q_i,
     // QlQlInvModqlDivqlModq[i] = floor(Q'*(Q'^-1 mod q_l)/q_l) mod q_i = -(q_l^-1) mod q_i   
     std::unique_lock<std::mutex> lock(c->cacheMutex);
@@ -2383,21 +2470,31 @@ extern "C" fhe_status fhe_rescale(fhe_ctx* c, const uint64_t* x, uint32_t sizeQl
     }
     TwPair *dA = it->second.first, *dB = it->second.second;
     lock.unlock();
-    // lastPoly.SetFormat(COEFFICIENT)  (:696-697): INTT of the last limb of every tower, written densely
-    const uint32_t lastIdx = l;
-    if (fhe_status s = ntt_run(c, true, x, last, &lastIdx, 1, batch, st, sizeQl, l))
+    return rescale_run(c, x, nullptr, sizeQl, dA, dB, true, batch, out, (uint64_t*)wsv, st);
+}
+// the same with the caller's tables (host arrays of sizeQl-1 residues: CryptoParametersRNS::GetQlQlInvModqlDivqlModq(l) /
+// GetqlInvModq(l)) over any limbs of the context: what the DCRTPoly backend's DropLastElementAndScale calls
+extern "C" fhe_status fhe_rescale_limbs(fhe_ctx* c, const uint64_t* x, const uint32_t* limbIdx, uint32_t sizeQl,
+                                        const uint64_t* QlQlInvModqlDivqlModq, const uint64_t* qlInvModq, uint32_t batch,
+                                        uint64_t* out, void* wsv, size_t wsBytes, void* st) {
+    ARG_CHECK(c && x && out && wsv && QlQlInvModqlDivqlModq && qlInvModq, "fhe_rescale_limbs: null argument");
+    ARG_CHECK(sizeQl >= 2 && sizeQl <= (uint32_t)kMaxLimbs, "Removing last element of DCRTPoly renders it invalid.");  // :672-673
+    ARG_CHECK(batch >= 1 && wsBytes >= fhe_rescale_workspace_bytes(c, sizeQl, batch), "fhe_rescale_limbs: workspace too small");
+    RT_CHECK(rt::set_device(c->device));
+    const uint32_t l = sizeQl - 1;
+    for (uint32_t i = 0; i < sizeQl; ++i)
+        ARG_CHECK((limbIdx ? limbIdx[i] : i) < c->L, "fhe_rescale_limbs: limb index exceeds context size");
+    bool negated = true;
+    for (uint32_t i = 0; i < l; ++i) {
+        const uint64_t qi = c->q[limbIdx ? limbIdx[i] : i];
+        negated           = negated && qlInvModq[i] < qi && QlQlInvModqlDivqlModq[i] == (qi - qlInvModq[i]) % qi;
+    }
+    const TwPair *dA = nullptr, *dB = nullptr;
+    if (fhe_status s = const_table(c, limbIdx, QlQlInvModqlDivqlModq, l, &dA))
         return s;
-    // tmp = SwitchModulus(last -> q_i) * QlQlInvModqlDivqlModq[i]   (:703-705)
-    LimbSel sel;
-    if (fhe_status s = make_sel(c, nullptr, l, &sel, "fhe_rescale"))
+    if (fhe_status s = const_table(c, limbIdx, qlInvModq, l, &dB))
         return s;
-    if (fhe_status s = switch_modulus_run(c, tmp, sel, l, last, 1, 0, l, dA, batch, st))
-        return s;
-    // tmp.SwitchFormat()  (:706-707)
-    if (fhe_status s = fhe_ntt_fwd(c, tmp, nullptr, l, batch, st))
-        return s;
-    // m_vectors[i] = m_vectors[i] * qlInvModq[i] + tmp  (:708-709); x towers are sizeQl rows apart
-    return elem_run<OP_MUL_CONST_ADD>(c, out, x, tmp, dB, nullptr, l, batch, st, "fhe_rescale", sizeQl, 0);
+    return rescale_run(c, x, limbIdx, sizeQl, dA, dB, negated, batch, out, (uint64_t*)wsv, st);
 }
 
 // DCRTPolyImpl::ModReduce (dcrtpoly-impl.h:736-755), the BGV modulus switch by the last limb with plaintext modulus t:
@@ -3076,3 +3173,30 @@ extern "C" fhe_status fhe_checksum(fhe_ctx* c, const uint64_t* x, uint32_t rows,
     return FHE_OK;
 }
 
+extern "C" size_t fhe_launch_stats(char* buf, size_t cap, uint64_t* total) {
+    std::map<std::string, uint64_t> byKernel;
+    uint64_t sum = 0;
+    for (auto* s = fhe::rt::LaunchSite::head().load(); s; s = s->next) {
+        std::string k = s->kernel;
+        k = k.substr(0, k.find('<'));
+        k.erase(std::remove(k.begin(), k.end(), '('), k.end());
+        byKernel[k] += s->n.load();
+        sum += s->n.load();
+    }
+    std::vector<std::pair<uint64_t, std::string>> v;
+    for (auto& kv : byKernel)
+        if (kv.second)
+            v.emplace_back(kv.second, kv.first);
+    std::sort(v.rbegin(), v.rend());
+    std::string text;
+    for (auto& e : v)
+        text += e.second + " " + std::to_string(e.first) + "\n";
+    if (total)
+        *total = sum;
+    if (buf && cap) {
+        const size_t n = std::min(cap - 1, text.size());
+        std::memcpy(buf, text.data(), n);
+        buf[n] = 0;
+    }
+    return text.size() + 1;
+}

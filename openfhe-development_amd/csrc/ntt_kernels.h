@@ -87,7 +87,25 @@ struct NttPassArgs {
     const uint64_t* epiA;
     const TwPair* epiC;
     uint64_t *epiOut0, *epiOut1;
+    // Optional prologue of a forward transform's first pass (static column kernels only, PRO instances): every limb of a tower
+    // is loaded from ONE row of xin (row inFirst of the tower's inStride rows), a COEFFICIENT limb modulo q[proSrcLimb], and
+    // brought to the limb's own modulus on the way in (SwitchModulus, mubintvecnat.cpp:109-122) — the `tmp[i] = lastPoly;
+    // tmp[i].SwitchModulus(q_i)` of DropLastElementAndScale (dcrtpoly-impl.h:703-704) never goes to HBM.  0: off.
+    uint32_t proMode, proSrcLimb;
 };
+// SwitchModulus of one residue (mubintvecnat.cpp:109-122): v modulo qs, centred, to the modulus qn
+FHE_HD uint64_t switch_modulus_word(uint64_t v, uint64_t qs, uint64_t halfQs, uint64_t qn) {
+    if (qn > qs)
+        return v + ((v > halfQs) ? (qn - qs) : 0);
+    // ModSubEq semantics (ubintnat.h:889-899): operands reduced mod qn first
+    uint64_t bv = (v > halfQs) ? (qs - qn) : 0;
+    uint64_t av = v;
+    if (av >= qn)
+        av %= qn;
+    if (bv >= qn)
+        bv %= qn;
+    return (av < bv) ? av + qn - bv : av - bv;
+}
 
 // LDS word index swizzle: conflict-free ds_read_b64/ds_write_b64 for every register-field position
 // (sigma is GF(2)-linear: sigma(a ^ b) = sigma(a) ^ sigma(b))

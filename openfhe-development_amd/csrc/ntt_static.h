@@ -426,10 +426,13 @@ FHE_HD void lane_geom_s(uint32_t t, uint32_t S, uint32_t& Ib, uint32_t& jrel, ui
 // RAWIN: the pass starts from residues already in the registers of its first step's lane layout (no load, no staging).
 // Both exist for the fused polynomial product (poly_mul kernels below): a forward row pass whose last step and an inverse
 // row pass whose first step both act on tile bit 0 hold the same 16 consecutive residues per lane.
-template <bool LA, bool INV, int T, int MODE, bool EPI = false, bool RAWIN = false, bool RAWOUT = false>
+// PRO: the first load takes every limb of a tower from one COEFFICIENT row modulo another limb's modulus and switches it to the
+// limb's own modulus (NttPassArgs::proMode) — forward column passes only.
+template <bool LA, bool INV, int T, int MODE, bool EPI = false, bool RAWIN = false, bool RAWOUT = false, bool PRO = false>
 FHE_DEV void ntt_static_core(const NttPassArgs& a, uint32_t bid, uint64_t* lds, uint64_t (&r)[16]) {
     using P = SPlan<LA, INV, T>;
     static_assert(!(RAWIN || RAWOUT) || !LA, "register hand-over exists for row passes only");
+    static_assert(!PRO || (LA && !INV && !RAWIN), "the load prologue exists for forward column passes only");
     const uint32_t t    = FHE_TID;
     const uint32_t logN = a.logN;
     const uint32_t N    = 1u << logN;
@@ -446,7 +449,8 @@ FHE_DEV void ntt_static_core(const NttPassArgs& a, uint32_t bid, uint64_t* lds, 
     const uint32_t row  = tile / tilesPerRow, tr = tile % tilesPerRow;
     const uint32_t jbase = LA ? (tr << logC) : (tr << kTileLog);
     const uint32_t tb = row / a.nLimbs, rit = row % a.nLimbs;
-    const uint64_t inRow  = a.inStride ? ((uint64_t)tb * a.inStride + a.inFirst + rit) : (uint64_t)row;
+    const uint64_t inRow  = PRO ? ((uint64_t)tb * a.inStride + a.inFirst)
+                                : a.inStride ? ((uint64_t)tb * a.inStride + a.inFirst + rit) : (uint64_t)row;
     const uint64_t outRow = a.outStride ? ((uint64_t)tb * a.outStride + a.outFirst + rit) : (uint64_t)row;
     const uint32_t limb = FHE_UNIFORM(a.sel.idx[rit]);
     const uint64_t q    = FHE_ULOAD64(a.q, limb);
@@ -538,6 +542,13 @@ FHE_DEV void ntt_static_core(const NttPassArgs& a, uint32_t bid, uint64_t* lds, 
         }
     };
 
+    auto pro_switch = [&](uint64_t (&v)[16]) {
+        const uint64_t qs = FHE_ULOAD64(a.q, a.proSrcLimb), halfQs = qs >> 1;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            v[k] = switch_modulus_word(v[k], qs, halfQs, q);
+    };
+
 #define FHE_SHARED_TW_TO_LDS()                                             \
     if constexpr (useShared) {                                             \
         if (t < (uint32_t)SS::total)                                       \
@@ -562,6 +573,8 @@ FHE_DEV void ntt_static_core(const NttPassArgs& a, uint32_t bid, uint64_t* lds, 
 #pragma unroll
         for (int k = 0; k < 16; ++k)
             r[k] = src[jrel + k * ks];
+        if constexpr (PRO)
+            pro_switch(r);
         FHE_SHARED_TW_TO_LDS()
         uint64_t* L = lds + lds_pad(Ib);
 #pragma unroll
@@ -579,6 +592,8 @@ FHE_DEV void ntt_static_core(const NttPassArgs& a, uint32_t bid, uint64_t* lds, 
         }                                                                                                         \
         else if constexpr (I == 0 && !P::stageFirst) {                                                            \
             _Pragma("unroll") for (int k = 0; k < 16; ++k) r[k] = src[jrel + k * ks];                             \
+            if constexpr (PRO)                                                                                    \
+                pro_switch(r);                                                                                    \
             FHE_SHARED_TW_TO_LDS()                                                                                \
         }                                                                                                         \
         else {                                                                                                    \
@@ -636,20 +651,20 @@ FHE_DEV void ntt_static_core(const NttPassArgs& a, uint32_t bid, uint64_t* lds, 
     }
 }
 
-template <bool LA, bool INV, int T, int MODE, bool EPI = false>
+template <bool LA, bool INV, int T, int MODE, bool EPI = false, bool PRO = false>
 FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) {
     uint64_t r[16];
-    ntt_static_core<LA, INV, T, MODE, EPI>(a, bid, lds, r);
+    ntt_static_core<LA, INV, T, MODE, EPI, false, false, PRO>(a, bid, lds, r);
 }
 
-template <bool LA, bool INV, int T, int MODE, bool EPI = false>
+template <bool LA, bool INV, int T, int MODE, bool EPI = false, bool PRO = false>
 FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_static_kernel(const NttPassArgs a) {
     // a single-step pass without staging (the 4-stage column pass) never touches LDS: do not reserve any, so that
     // more workgroups fit on a CU
     using P = SPlan<LA, INV, T>;
     constexpr bool needsLds = P::nst > 1 || P::stageFirst || P::stageLast;
     FHE_SHARED_U64(lds, needsLds ? kLdsPadWords + kSharedTwWords : 1);
-    ntt_static_body<LA, INV, T, MODE, EPI>(a, FHE_BID, lds);
+    ntt_static_body<LA, INV, T, MODE, EPI, PRO>(a, FHE_BID, lds);
 }
 
 

@@ -8,6 +8,30 @@
 
 #include "launch.h"
 
+#include <atomic>
+namespace fhe {
+namespace rt {
+// one counter per FHE_LAUNCH site (a relaxed increment per launch): fhe_launch_stats() sums them by kernel name
+struct LaunchSite {
+    const char* kernel;
+    std::atomic<uint64_t> n{0};
+    LaunchSite* next;
+    static std::atomic<LaunchSite*>& head() {
+        static std::atomic<LaunchSite*> h{nullptr};
+        return h;
+    }
+    explicit LaunchSite(const char* k) : kernel(k) {
+        next = head().load();
+        while (!head().compare_exchange_weak(next, this)) {
+        }
+    }
+};
+}  // namespace rt
+}  // namespace fhe
+#define FHE_COUNT_LAUNCH(kernel)                      \
+    static fhe::rt::LaunchSite fhe_launch_site_(#kernel); \
+    fhe_launch_site_.n.fetch_add(1, std::memory_order_relaxed)
+
 #ifdef FHE_EMU
 #include <chrono>
 #include <cstdlib>
@@ -79,8 +103,11 @@ struct Timer {
 };
 }  // namespace rt
 }  // namespace fhe
-#define FHE_LAUNCH(kernel, grid, stream, ...) \
-    fhe_emu::launch((uint32_t)(grid), fhe::kThreads, [=]() { kernel(__VA_ARGS__); })
+#define FHE_LAUNCH(kernel, grid, stream, ...)                                              \
+    do {                                                                                   \
+        FHE_COUNT_LAUNCH(kernel);                                                          \
+        fhe_emu::launch((uint32_t)(grid), fhe::kThreads, [=]() { kernel(__VA_ARGS__); }); \
+    } while (0)
 #else
 #include <hip/hip_runtime.h>
 namespace fhe {
@@ -143,7 +170,7 @@ inline const char* capture_end(stream_t s, graph_t* out) {
     if (auto e = err(hipStreamEndCapture(s, &g)))
         return e;
     auto e = err(hipGraphInstantiate(out, g, nullptr, nullptr, 0));
-    hipGraphDestroy(g);
+    (void)hipGraphDestroy(g);
     return e;
 }
 inline const char* graph_launch(graph_t g, stream_t s) { return err(hipGraphLaunch(g, s)); }
@@ -166,14 +193,17 @@ struct Timer {
         if (auto e = err(hipEventSynchronize(e1)))
             return e;
         auto e = err(hipEventElapsedTime(ms, e0, e1));
-        hipEventDestroy(e0);
-        hipEventDestroy(e1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
         return e;
     }
 };
 }  // namespace rt
 }  // namespace fhe
-#define FHE_LAUNCH(kernel, grid, stream, ...) \
-    hipLaunchKernelGGL(kernel, dim3((uint32_t)(grid)), dim3(fhe::kThreads), 0, (hipStream_t)(stream), __VA_ARGS__)
+#define FHE_LAUNCH(kernel, grid, stream, ...)                                                                            \
+    do {                                                                                                                 \
+        FHE_COUNT_LAUNCH(kernel);                                                                                        \
+        hipLaunchKernelGGL(kernel, dim3((uint32_t)(grid)), dim3(fhe::kThreads), 0, (hipStream_t)(stream), __VA_ARGS__); \
+    } while (0)
 #endif
 #endif

@@ -131,6 +131,7 @@ class Lib:
         S("fhe_approx_mod_down_bgv", C.c_int, [vp, vp, u32, u64, u32, vp, vp, C.c_size_t, vp])
         S("fhe_rescale_workspace_bytes", C.c_size_t, [vp, u32, u32])
         S("fhe_rescale", C.c_int, [vp, vp, u32, u32, vp, vp, C.c_size_t, vp])
+        S("fhe_rescale_limbs", C.c_int, [vp, vp, u32p, u32, u64p, u64p, u32, vp, vp, C.c_size_t, vp])
         S("fhe_mod_reduce", C.c_int, [vp, vp, u32, u64, C.c_int, u32, vp, vp, C.c_size_t, vp])
         f64p = C.POINTER(C.c_double)
         S("fhe_sr_plan_create", C.c_int, [vp, u32, u32p, u32, u64p, f64p, C.POINTER(vp)])
@@ -635,6 +636,23 @@ def rescale(ctx, x, stream=None):
     ws = ctx.malloc(need)
     out = ctx.empty(x.batch, sizeQl - 1)
     ctx.lib.check(ctx.lib.L.fhe_rescale(ctx.h, x.ptr, sizeQl, x.batch, out.ptr, ws, need, stream))
+    ctx.sync(stream)
+    ctx.free(ws)
+    return out
+
+
+def rescale_limbs(ctx, x, scale_tab, inv_tab, stream=None):
+    """DropLastElementAndScale on a Tower over ANY limbs of the context (x.limb_idx; its last limb is dropped) with the caller's tables
+    QlQlInvModqlDivqlModq / qlInvModq (dcrtpoly-impl.h:693-694), the entry the DCRTPoly backend calls."""
+    sizeQl = x.n_limbs
+    need = ctx.lib.L.fhe_rescale_workspace_bytes(ctx.h, sizeQl, x.batch)
+    ws = ctx.malloc(need)
+    kept = None if x.limb_idx is None else x.limb_idx[:sizeQl - 1]
+    out = ctx.empty(x.batch, sizeQl - 1, kept)
+    a = np.ascontiguousarray(scale_tab, dtype=np.uint64)
+    b = np.ascontiguousarray(inv_tab, dtype=np.uint64)
+    ctx.lib.check(ctx.lib.L.fhe_rescale_limbs(ctx.h, x.ptr, x._li(), sizeQl, a.ctypes.data_as(u64p), b.ctypes.data_as(u64p), x.batch,
+                                              out.ptr, ws, need, stream))
     ctx.sync(stream)
     ctx.free(ws)
     return out

@@ -56,6 +56,7 @@ struct StreamState {
 };
 struct Runtime {
     Api api{};
+    size_t (*launch_stats)(char*, size_t, uint64_t*) = nullptr;  // (optional: the library's launch counters)
     bool live = false;
     std::string why;
     int device       = 0;
@@ -112,6 +113,7 @@ Runtime* build() {
     }
     else {
         Api& a = r->api;
+        r->launch_stats = reinterpret_cast<size_t (*)(char*, size_t, uint64_t*)>(dlsym(h, "fhe_launch_stats"));
 #define FHE_SYM(field, name) sym(h, #name, &a.field)
         bool ok = FHE_SYM(last_error, fhe_last_error) && FHE_SYM(device_count, fhe_device_count) && FHE_SYM(ctx_create, fhe_ctx_create) &&
                   FHE_SYM(ctx_destroy, fhe_ctx_destroy) && FHE_SYM(conv_destroy, fhe_conv_destroy) && FHE_SYM(sr_plan_destroy, fhe_sr_plan_destroy) &&
@@ -126,7 +128,8 @@ Runtime* build() {
                   FHE_SYM(neg, fhe_neg) && FHE_SYM(mul_add, fhe_mul_add) && FHE_SYM(mul_const, fhe_mul_const) && FHE_SYM(mult_acc, fhe_mult_acc) &&
                   FHE_SYM(add_const, fhe_add_const) && FHE_SYM(sub_const, fhe_sub_const) && FHE_SYM(times_q_over_t, fhe_times_q_over_t) &&
                   FHE_SYM(mod_switch_round, fhe_mod_switch_round) && FHE_SYM(automorph, fhe_automorph) &&
-                  FHE_SYM(switch_modulus, fhe_switch_modulus) && FHE_SYM(conv_create_custom, fhe_conv_create_custom) &&
+                  FHE_SYM(switch_modulus, fhe_switch_modulus) && FHE_SYM(rescale_limbs, fhe_rescale_limbs) &&
+                  FHE_SYM(rescale_workspace_bytes, fhe_rescale_workspace_bytes) && FHE_SYM(conv_create_custom, fhe_conv_create_custom) &&
                   FHE_SYM(approx_switch_basis, fhe_approx_switch_basis) && FHE_SYM(switch_basis_exact, fhe_switch_basis_exact) &&
                   FHE_SYM(sr_plan_create, fhe_sr_plan_create) && FHE_SYM(scale_and_round, fhe_scale_and_round) &&
                   FHE_SYM(scale_and_round_p_over_q, fhe_scale_and_round_p_over_q) && FHE_SYM(scale_and_round_native, fhe_scale_and_round_native) &&
@@ -484,9 +487,11 @@ MemberScope::~MemberScope() {
     if (outer)
         t_scope = nullptr;
 }
+static void trace_site(const char* kind, const char* member, uint64_t amount);
 void CountDevice(const char* member) {
     rt().deviceOps.fetch_add(1, std::memory_order_relaxed);
     member_slot(t_scope ? t_scope : member).device.fetch_add(1, std::memory_order_relaxed);
+    trace_site("devop", t_scope ? t_scope : member, 1);
 }
 static std::mutex g_traceMutex;
 static std::map<std::string, uint64_t>* g_traceSites = nullptr;
@@ -497,8 +502,8 @@ static void trace_site(const char* kind, const char* member, uint64_t amount) {
     static const bool trace = std::getenv("FHE_HAL_TRACE") != nullptr;
     if (!trace)
         return;
-    void* bt[8];
-    const int n     = backtrace(bt, 8);
+    void* bt[10];
+    const int n     = backtrace(bt, 10);
     std::string key = std::string(kind) + " " + (member ? member : (t_scope ? t_scope : (t_member ? t_member : ""))) + " <- ";
     for (int i = 3; i < n; ++i) {
         Dl_info info;
@@ -972,6 +977,13 @@ extern "C" void fhe_hal_trace_reset(void) {
     std::lock_guard<std::mutex> lk(lbcrypto::hiprt::g_traceMutex);
     if (lbcrypto::hiprt::g_traceSites)
         lbcrypto::hiprt::g_traceSites->clear();
+}
+// the device library's kernel launches since it was loaded ("<kernel> <launches>" lines, see fhe_launch_stats), *total = their sum
+extern "C" size_t fhe_hal_launch_stats(char* buf, size_t cap, uint64_t* total) {
+    auto& r = lbcrypto::hiprt::rt();
+    if (total)
+        *total = 0;
+    return r.launch_stats ? r.launch_stats(buf, cap, total) : 0;
 }
 extern "C" void fhe_hal_composite_stats(uint64_t out[3]) {
     out[0] = lbcrypto::hiprt::g_compositeCalls, out[1] = lbcrypto::hiprt::g_checksOk, out[2] = lbcrypto::hiprt::g_checksBad;

@@ -324,11 +324,18 @@ std::shared_ptr<std::vector<DCRTPoly>> KeySwitchHYBRID::KeySwitchCore(const DCRT
     const auto cp = std::dynamic_pointer_cast<CryptoParametersRNS>(evalKey->GetCryptoParameters());
     auto dom      = a.GetFormat() == Format::EVALUATION ? DomainOf(cp, a, &sizeQl) : nullptr;
     const int st  = dom ? hiprt::DomainChecked(*dom, hiprt::kKeySwitch, sizeQl) : 2;
-    if (st == 2 || !KeyBuffers(evalKey, cp->GetNumPartQ(), cp->GetParamsQP()->GetParams().size(), kb, ka))
+    static const bool dbg = std::getenv("FHE_HAL_DEBUG") != nullptr;
+    if (st == 2 || !KeyBuffers(evalKey, cp->GetNumPartQ(), cp->GetParamsQP()->GetParams().size(), kb, ka)) {
+        if (dbg)
+            fprintf(stderr, "hal debug: KeySwitchCore runs the reference's sequence: domain %p level %u state %d format %d\n", (void*)dom.get(), sizeQl, st,
+                    (int)a.GetFormat());
         return fhe_ref_KeySwitchCore(this, a, evalKey);
+    }
     auto bc = a.DeviceWords();
     if (!bc)
         return fhe_ref_KeySwitchCore(this, a, evalKey);
+    if (dbg && st == 0)
+        fprintf(stderr, "hal debug: KeySwitchCore first use at level %u\n", sizeQl);
     std::shared_ptr<std::vector<DCRTPoly>> mine;
     {
         const auto& A = hiprt::api();
@@ -565,15 +572,22 @@ constexpr uint32_t kNoSkip = 0xffffffffu;
 // false: the composite does not take this level (the caller runs the reference's function instead).
 bool BsgsLevelOnDevice(Ciphertext<DCRTPoly>& ct, const std::vector<int32_t>& rotIn, const std::vector<int32_t>& rotOut,
                        const std::vector<ReadOnlyPlaintext>& A, uint32_t skip) {
+    // (FHE_HAL_DEBUG=1 names the exit a level left the composite through)
+    auto Why = [](int site) {
+        static const bool dbg = std::getenv("FHE_HAL_DEBUG") != nullptr;
+        if (dbg)
+            fprintf(stderr, "hal debug: BsgsLevelOnDevice declined at exit %d (%s)\n", site, hiprt::api().last_error());
+        return false;
+    };
     const auto cc = ct->GetCryptoContext();
     const auto cp = std::dynamic_pointer_cast<CryptoParametersCKKSRNS>(ct->GetCryptoParameters());
     auto& cv      = ct->GetElements();
     if (!cp || cv.size() != 2 || cv[0].GetFormat() != Format::EVALUATION || cv[1].GetFormat() != Format::EVALUATION || A.empty() || !A[0])
-        return false;
+        return Why(1);
     uint32_t sizeQl = 0;
     auto dom        = DomainOf(cp, cv[0], &sizeQl);
     if (!dom || cv[1].GetNumOfElements() != sizeQl)
-        return false;
+        return Why(2);
     const uint32_t M = cc->GetCyclotomicOrder(), nIn = rotIn.size(), nOut = rotOut.size();
     const size_t sizeP = cp->GetParamsP()->GetParams().size(), sizeQP = cp->GetParamsQP()->GetParams().size();
     const auto& keyMap = cc->GetEvalAutomorphismKeyMap(ct->GetKeyTag());
@@ -588,10 +602,10 @@ bool BsgsLevelOnDevice(Ciphertext<DCRTPoly>& ct, const std::vector<int32_t>& rot
             auto it = keyMap.find(k[j]);
             std::vector<hiprt::Buf> kb, ka;
             if (it == keyMap.end() || !KeyBuffers(it->second, cp->GetNumPartQ(), sizeQP, kb, ka))
-                return false;
+                return Why(3);
             keep.push_back(hiprt::DomainKey(*dom, kb, ka, op));
             if (!keep.back().key)
-                return false;
+                return Why(4);
             op.R(keep.back().b), op.R(keep.back().a);
             keys[j] = keep.back().key.get();
         }
@@ -600,7 +614,7 @@ bool BsgsLevelOnDevice(Ciphertext<DCRTPoly>& ct, const std::vector<int32_t>& rot
     std::vector<uint32_t> inK, outK;
     std::vector<const fhe_ks_key*> inKeys, outKeys;
     if (!keysOf(rotIn, inK, inKeys) || !keysOf(rotOut, outK, outKeys))
-        return false;
+        return Why(5);
     // the encoded diagonals: towers over Q_l u P in EVALUATION (EvalLinearTransformPrecompute's aux plaintexts), device resident after
     // their first use
     std::vector<const uint64_t*> diag((size_t)nOut * nIn, nullptr);
@@ -612,28 +626,28 @@ bool BsgsLevelOnDevice(Ciphertext<DCRTPoly>& ct, const std::vector<int32_t>& rot
             if (idx == skip || idx >= A.size())
                 continue;
             if (!A[idx])
-                return false;
+                return Why(6);
             const DCRTPoly& pt = A[idx]->GetElement<DCRTPoly>();
             const auto& pl     = pt.GetParams()->GetParams();
             if (pt.GetFormat() != Format::EVALUATION || pl.size() != sizeQl + sizeP || pl[0]->GetModulus() != ql[0]->GetModulus() ||
                 pl[sizeQl - 1]->GetModulus() != ql[sizeQl - 1]->GetModulus() ||
                 pl[sizeQl]->GetModulus() != cp->GetParamsP()->GetParams()[0]->GetModulus())
-                return false;
+                return Why(7);
             diagKeep.push_back(pt.DeviceWords());
             if (!diagKeep.back())
-                return false;
+                return Why(8);
             diag[idx] = op.R(diagKeep.back());
         }
     auto b0 = cv[0].DeviceWords(), b1 = cv[1].DeviceWords();
     if (!b0 || !b1)
-        return false;
+        return Why(9);
     const auto& Api  = hiprt::api();
     const size_t N   = cv[0].GetParams()->GetRingDimension();
     const size_t wsB = Api.bsgs_workspace_bytes(hiprt::DomainPlan(*dom), sizeQl, 1, nIn, nOut);
     auto ws = hiprt::Alloc(wsB / 8 + 1), o0 = hiprt::Alloc(sizeQl * N), o1 = hiprt::Alloc(sizeQl * N);
     if (Api.bsgs_transform(hiprt::DomainPlan(*dom), op.R(b0), op.R(b1), sizeQl, 1, nIn, inK.data(), inKeys.data(), nOut, outK.data(), outKeys.data(),
                            diag.data(), op.W(o0), op.W(o1), op.W(ws), wsB, op.s) != FHE_OK)
-        return false;
+        return Why(10);
     hiprt::CountDevice("Bootstrap.BsgsLevel");
     hiprt::CountComposite();
     auto result = ct->CloneEmpty();
@@ -666,6 +680,10 @@ Ciphertext<DCRTPoly> CheckedComposite(ConstCiphertext<DCRTPoly>& ctxt, Composite
     const auto cp   = std::dynamic_pointer_cast<CryptoParametersCKKSRNS>(ctxt->GetCryptoParameters());
     auto dom        = (cp && ctxt->GetElements().size() == 2) ? DomainOf(cp, ctxt->GetElements()[0], &sizeQl) : nullptr;
     const int state = dom ? hiprt::DomainChecked(*dom, hiprt::kBsgs, sizeQl) : 2;
+    static const bool dbg = std::getenv("FHE_HAL_DEBUG") != nullptr;
+    if (dbg)
+        fprintf(stderr, "hal debug: CheckedComposite domain %p level %u state %d elements %zu\n", (void*)dom.get(), sizeQl, state,
+                ctxt->GetElements().size());
     if (state == 2)
         return reference();
     Ciphertext<DCRTPoly> mine;

@@ -1781,25 +1781,22 @@ private:
             return false;
         const size_t N     = m_h.GetParams()->GetRingDimension();
         const uint32_t l   = L - 1;
-        const uint32_t lastLimb = r.idx[0][l];
-        std::vector<uint32_t> idx(r.idx[0].begin(), r.idx[0].begin() + l);
         std::vector<uint64_t> a(l), b(l);
         for (uint32_t i = 0; i < l; ++i) {
             a[i] = QlQlInvModqlDivqlModq[i].ConvertToInt<uint64_t>();
             b[i] = qlInvModq[i].ConvertToInt<uint64_t>();
         }
+        // the whole member is ONE library call with the caller's tables (fhe_rescale_limbs: :696-709; 4 launches on the rings of two
+        // static passes: the INTT of the last limb, then SwitchModulus on the way into the forward transform and the `* qlInvModq +`
+        // on its way out)
         const auto& A = hiprt::api();
         hiprt::Op op;
         const uint64_t* self = op.R(m_d);
-        auto last            = hiprt::Alloc(N);
+        const size_t wsBytes = A.rescale_workspace_bytes(r.ctx, L, 1);
+        auto ws              = hiprt::Alloc(wsBytes / 8);
         auto tmp             = hiprt::Alloc((size_t)l * N);
-        uint64_t *lp = op.W(last), *tp = op.W(tmp);
-        hiprt::Check(A.ntt_inv_oop(r.ctx, self + (size_t)l * N, lp, &lastLimb, 1, 1, op.s), "DropLastElementAndScale");  // :696-697
-        hiprt::Check(A.switch_modulus(r.ctx, tp, idx.data(), l, lp, 1, 0, lastLimb, 1, op.s), "DropLastElementAndScale");  // :703-704
-        hiprt::Check(A.mul_const(r.ctx, tp, tp, a.data(), idx.data(), l, 1, op.s), "DropLastElementAndScale");            // :705
-        hiprt::Check(A.ntt_fwd(r.ctx, tp, idx.data(), l, 1, op.s), "DropLastElementAndScale");                             // :706-707
-        // :708-709  m_vectors[i] = m_vectors[i] * qlInvModq[i] + tmp[i]: accumulated into tmp, which becomes the tower
-        hiprt::Check(A.mult_acc(r.ctx, tp, self, b.data(), idx.data(), l, 1, op.s), "DropLastElementAndScale");
+        hiprt::Check(A.rescale_limbs(r.ctx, self, r.idx[0].data(), L, a.data(), b.data(), 1, op.W(tmp), op.W(ws), wsBytes, op.s),
+                     "DropLastElementAndScale");
         m_d = std::move(tmp);
         hiprt::CountDevice();
         DeviceIsNewer(Format::EVALUATION);

@@ -50,6 +50,8 @@ struct Api {
     decltype(&fhe_mod_switch_round) mod_switch_round;
     decltype(&fhe_automorph) automorph;
     decltype(&fhe_switch_modulus) switch_modulus;
+    decltype(&fhe_rescale_limbs) rescale_limbs;
+    decltype(&fhe_rescale_workspace_bytes) rescale_workspace_bytes;
     decltype(&fhe_conv_create_custom) conv_create_custom;
     decltype(&fhe_conv_destroy) conv_destroy;
     decltype(&fhe_approx_switch_basis) approx_switch_basis;

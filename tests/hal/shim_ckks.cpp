@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <map>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -22,6 +24,21 @@ extern "C" void fhe_hal_stats(uint64_t out[4]) __attribute__((weak));
 extern "C" int fhe_hal_available(void) __attribute__((weak));
 extern "C" void fhe_hal_trace_reset(void) __attribute__((weak));
 extern "C" size_t fhe_hal_member_stats(char* buf, size_t cap) __attribute__((weak));
+extern "C" size_t fhe_hal_launch_stats(char* buf, size_t cap, uint64_t* total) __attribute__((weak));
+static std::map<std::string, uint64_t> launches_by_kernel(uint64_t* total) {
+    std::map<std::string, uint64_t> m;
+    *total = 0;
+    if (!fhe_hal_launch_stats)
+        return m;
+    std::string buf(fhe_hal_launch_stats(nullptr, 0, total), '\0');
+    fhe_hal_launch_stats(&buf[0], buf.size(), total);
+    std::istringstream in(buf);
+    std::string k;
+    uint64_t n;
+    while (in >> k >> n)
+        m[k] = n;
+    return m;
+}
 extern "C" void fhe_hal_stats_reset(void) __attribute__((weak));
 extern "C" void fhe_hal_composite_stats(uint64_t out[3]) __attribute__((weak));
 extern "C" void fhe_hal_other_host_counts(uint64_t out[2]) __attribute__((weak));
@@ -483,9 +500,10 @@ int main(int argc, char** argv) {
             const int reps = argc > 6 ? std::atoi(argv[6]) : 1;
             if (fhe_hal_trace_reset)
                 fhe_hal_trace_reset();
-            uint64_t s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+            uint64_t s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, l0 = 0, l1 = 0;
             if (fhe_hal_stats)
                 fhe_hal_stats(s0);
+            auto k0 = launches_by_kernel(&l0);
             t0 = now();
             for (int i = 0; i < reps; ++i) {
                 auto t1 = now();
@@ -497,6 +515,13 @@ int main(int argc, char** argv) {
                 fhe_hal_stats(s1);
                 std::cout << "per bootstrap: deviceOps " << (s1[0] - s0[0]) / reps << " hostOps " << (s1[1] - s0[1]) / reps << " h2dMB "
                           << (s1[2] - s0[2]) / reps / 1e6 << " d2hMB " << (s1[3] - s0[3]) / reps / 1e6 << std::endl;
+            }
+            auto k1 = launches_by_kernel(&l1);
+            if (l1 > l0) {
+                std::cout << "per bootstrap: launches " << (l1 - l0) / reps << std::endl;
+                for (auto& kv : k1)
+                    if (kv.second > k0[kv.first])
+                        std::cout << "  launches " << kv.first << " " << (kv.second - k0[kv.first]) / reps << std::endl;
             }
             dump("bootstrapped", b);
             show("bootstrapped", cc, kp.secretKey, b, 8);

@@ -118,15 +118,20 @@ EMU = os.path.join(ROOT, "tests", "emu", "libfhe_emu.so")
 HIP = os.path.join(ROOT, "openfhe-development_amd", "csrc", "libfhe_hip.so")
 
 
-CKKS_MEMBERS = ("SwitchFormat", "Times", "operator+=", "ApproxSwitchCRTBasis", "ApproxModDown", "DropLastElementAndScale",
-                "AutomorphismTransform", "AssembleRows", "InnerProduct")
-BOOT_MEMBERS = CKKS_MEMBERS + ("ModRaise", "TimesNoCheck")
-BEHZ_MEMBERS = ("FastBaseConvqToBskMontgomery", "FastRNSFloorq", "FastBaseConvSK", "ScaleAndRound", "SwitchFormat", "ApproxModDown")
-HPS_MEMBERS = {"HPS": ("ExpandCRTBasis", "ScaleAndRound", "SwitchCRTBasis", "SwitchFormat", "ApproxModDown"),
-               "HPSPOVERQ": ("ExpandCRTBasis", "FastExpandCRTBasisPloverQ", "ScaleAndRound", "SwitchFormat", "ApproxModDown"),
+# (device operations are attributed to the OUTERMOST scope: the digit decomposition, ModUp / ModDown and inner products of a key switch
+# count under KeySwitchCore / EvalMult.KeySwitchAccumulate — the backend's definitions of those pke functions, one composite library call
+# each after the first-use check — and the baby-step/giant-step levels of bootstrapping under Bootstrap.Eval*.  A hook that the library
+# does not actually bind — round 3 found KeySwitchCore and the three linear transforms still bound to the reference's definitions through
+# the vtable / same-object calls — shows up here as a missing member.)
+CKKS_MEMBERS = ("SwitchFormat", "Times", "operator+=", "DropLastElementAndScale", "AutomorphismTransform", "Tensor", "KeySwitchCore",
+                "EvalMult.KeySwitchAccumulate")
+BOOT_MEMBERS = CKKS_MEMBERS + ("ModRaise", "Bootstrap.EvalCoeffsToSlots", "Bootstrap.EvalSlotsToCoeffs")
+BEHZ_MEMBERS = ("FastBaseConvqToBskMontgomery", "FastRNSFloorq", "FastBaseConvSK", "ScaleAndRound", "SwitchFormat", "KeySwitchCore")
+HPS_MEMBERS = {"HPS": ("ExpandCRTBasis", "ScaleAndRound", "SwitchCRTBasis", "SwitchFormat", "KeySwitchCore"),
+               "HPSPOVERQ": ("ExpandCRTBasis", "FastExpandCRTBasisPloverQ", "ScaleAndRound", "SwitchFormat", "KeySwitchCore"),
                "HPSPOVERQLEVELED": ("ExpandCRTBasis", "FastExpandCRTBasisPloverQ", "ExpandCRTBasisQlHat", "ScaleAndRound", "SwitchFormat",
-                                    "ApproxModDown")}
-BGV_MEMBERS = ("ApproxModDown", "ModReduce", "SwitchFormat", "AutomorphismTransform")
+                                    "KeySwitchCore")}
+BGV_MEMBERS = ("KeySwitchCore", "ModReduce", "SwitchFormat", "AutomorphismTransform")
 
 
 def test_shim_leveled_ckks_matches_default_backend_on_emulator(tmp_path):

@@ -190,7 +190,7 @@ def test_bench_self_launches_two_ranks_on_gloo(backend):
     assert d["n_gpus"] == 2 and len(d["ms_per_step_per_rank"]) == 2 and d["scaling"] == "weak"
     assert "2 rank(s)" in d["evalmult"]["eval_key"] and d["evalmult"]["ops_per_s_total"] >= d["evalmult"]["ops_per_s_per_gpu"]
     assert d["evalmult"]["parity"].startswith("bit-exact vs oracle")
-    assert d["parity_at_full_size"].startswith("forward NTT words")
+    assert d["parity_at_full_size"].startswith("forward NTT of ALL 4 towers")
     assert "scatter" in d["rotation_key_replication"]["how"] and d["rotation_key_replication"]["keys"] == 14
 
 

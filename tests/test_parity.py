@@ -535,7 +535,8 @@ def test_hybrid_keyswitch_and_eval_mult(backend, oracle, logN, sizeQ, dnum, size
 def test_rescale(backend, oracle):
     o = oracle
     rng = np.random.default_rng(17)
-    for logN, sizeQl, B in [(6, 3, 2), (9, 5, 3), (12, 4, 2), (13, 3, 1)]:
+    # (N = 4096: the single static pass with the fused store; N >= 8192: the 4-launch form, column passes of 4 and of 5 stages)
+    for logN, sizeQl, B in [(6, 3, 2), (9, 5, 3), (12, 4, 2), (13, 3, 1), (14, 9, 2), (17, 3, 1)]:
         N = 1 << logN
         q, psiQ, _, _ = ckks_like_params(o, logN, sizeQl + 1, 2)
         ctx = fh.Context(backend, logN, q, psiQ)
@@ -548,6 +549,38 @@ def test_rescale(backend, oracle):
         assert np.array_equal(got, want), f"DropLastElementAndScale mismatch logN={logN}"
         o.orc_ctx_destroy(octx)
         ctx.close()
+
+
+@pytest.mark.parametrize("logN", [8, 12, 13])
+def test_rescale_limbs_with_the_callers_tables(backend, oracle, logN):
+    """fhe_rescale_limbs: a tower over scattered limbs of the context, first with the reference's tables (the fused form on rings of
+    static passes), then with a perturbed scale table (A != -B: the member-by-member form computes exactly what the tables say)"""
+    o = oracle
+    rng = np.random.default_rng(23)
+    N = 1 << logN
+    q, psiQ, _, _ = ckks_like_params(o, logN, 7, 2)
+    ctx = fh.Context(backend, logN, q, psiQ)
+    limbs = [5, 0, 3, 6, 2]  # the tower's limbs in its own order: q_6 ... dropped limb is context limb 2
+    sizeQl, B = len(limbs), 2
+    qs = [int(q[i]) for i in limbs]
+    sub = o.orc_ctx_create(N, sizeQl, np.array(qs, np.uint64), np.array([int(psiQ[i]) for i in limbs], np.uint64))
+    x = libs.rand_tower(rng, np.array(qs, np.uint64), N, B)
+    want = np.empty((B, sizeQl - 1, N), np.uint64)
+    for bb in range(B):
+        o.orc_drop_last_element_and_scale(sub, x[bb], sizeQl, want[bb])
+    inv = [pow(qs[-1] % qi, -1, qi) for qi in qs[:-1]]
+    neg = [(qi - v) % qi for v, qi in zip(inv, qs[:-1])]
+    xt = ctx.tower(x, limbs)
+    assert np.array_equal(fh.rescale_limbs(ctx, xt, neg, inv).to_host(), want)
+    # perturbed table: out_i = x_i * inv_i + NTT(SwitchModulus(last) * a_i); with a_i = 2 * neg_i this is want + NTT(sm * neg) =
+    # 2 * want - x_i * inv_i
+    a2 = [(2 * v) % qi for v, qi in zip(neg, qs[:-1])]
+    got = fh.rescale_limbs(ctx, xt, a2, inv).to_host()
+    for i, qi in enumerate(qs[:-1]):
+        w = (2 * want[:, i].astype(object) - x[:, i].astype(object) * inv[i]) % qi
+        assert np.array_equal(got[:, i].astype(object), w), f"limb {i}"
+    o.orc_ctx_destroy(sub)
+    ctx.close()
 
 
 @pytest.mark.parametrize("logN,sizeQl,t,B,ev", [(4, 3, 65537, 2, 1), (10, 4, 786433, 2, 1), (12, 3, 65537, 1, 0), (13, 3, 2, 1, 1)])
