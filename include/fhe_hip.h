@@ -142,6 +142,15 @@ fhe_status fhe_mul_add(fhe_ctx* ctx, uint64_t* acc, const uint64_t* a, const uin
  * array may be released as soon as the call returns. */
 fhe_status fhe_mul_const(fhe_ctx* ctx, uint64_t* out, const uint64_t* a, const uint64_t* consts,
                          const uint32_t* limbIdx, uint32_t nLimbs, uint32_t batch, void* stream);
+/* The two elements of a ciphertext in ONE launch: element e of every operand is a tower allocated on its own (o_e = a_e op b_e,
+ * o_e = a_e * consts per limb).  pke applies its operations element by element (base-leveledshe.cpp:562-606,
+ * ckksrns-leveledshe.cpp:748-759); one ciphertext's tower alone leaves most of the chip idle.  In-place use (o_e == a_e) is fine. */
+fhe_status fhe_add_pair(fhe_ctx* ctx, uint64_t* o0, uint64_t* o1, const uint64_t* a0, const uint64_t* a1, const uint64_t* b0,
+                        const uint64_t* b1, const uint32_t* limbIdx, uint32_t nLimbs, void* stream);
+fhe_status fhe_sub_pair(fhe_ctx* ctx, uint64_t* o0, uint64_t* o1, const uint64_t* a0, const uint64_t* a1, const uint64_t* b0,
+                        const uint64_t* b1, const uint32_t* limbIdx, uint32_t nLimbs, void* stream);
+fhe_status fhe_mul_const_pair(fhe_ctx* ctx, uint64_t* o0, uint64_t* o1, const uint64_t* a0, const uint64_t* a1, const uint64_t* consts,
+                              const uint32_t* limbIdx, uint32_t nLimbs, void* stream);
 /* DCRTPolyImpl::TimesQovert (dcrtpoly-impl.h:868-885): every word x of limb r becomes ((x * NegQModt) mod t) * tInvModq[r] mod q_r —
  * ModMulFastConst modulo the plaintext modulus, then the generalized Barrett product modulo q_r (BFV encryption scales the message
  * by Q/t with it).  out may alias a; tInvModq is a HOST array (by value in the kernel arguments). */
@@ -357,6 +366,12 @@ fhe_status fhe_rescale(fhe_ctx* ctx, const uint64_t* x, uint32_t sizeQl, uint32_
 fhe_status fhe_rescale_limbs(fhe_ctx* ctx, const uint64_t* x, const uint32_t* limbIdx, uint32_t sizeQl,
                              const uint64_t* QlQlInvModqlDivqlModq, const uint64_t* qlInvModq, uint32_t batch, uint64_t* out,
                              void* ws, size_t wsBytes, void* stream);
+/* The two elements of one ciphertext — towers x0, x1 -> out0, out1, each allocated on its own, any distance apart — in the same
+ * four launches (LeveledSHECKKSRNS::ModReduceInternalInPlace, ckksrns-leveledshe.cpp:172-191, applies the member to both elements
+ * with the same tables); ws of fhe_rescale_workspace_bytes(ctx, sizeQl, 2). */
+fhe_status fhe_rescale_limbs_pair(fhe_ctx* ctx, const uint64_t* x0, const uint64_t* x1, const uint32_t* limbIdx, uint32_t sizeQl,
+                                  const uint64_t* QlQlInvModqlDivqlModq, const uint64_t* qlInvModq, uint64_t* out0, uint64_t* out1,
+                                  void* ws, size_t wsBytes, void* stream);
 /* DCRTPolyImpl::ModReduce (dcrtpoly-impl.h:736-755) — BGV modulus switching by the last limb with plaintext modulus t
  * (tables negtInvModq / qlInvModq / tModqPrecon of CryptoParametersBGVRNS are derived inside): x [batch][sizeQl][N] in
  * `evalFormat`, out [batch][sizeQl-1][N] in the same format; ws as for fhe_rescale. */

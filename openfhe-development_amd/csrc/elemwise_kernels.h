@@ -53,6 +53,9 @@ struct ElemArgs {
     uint32_t oStride, oFirst;  // same for out
     TwPair pre = {0, 0};       // OP_TIMES_QOVERT only: the first factor (Shoup pair modulo preMod) ...
     uint64_t preMod = 0;       // ... and its modulus (the plaintext modulus t)
+    // != 0: consecutive towers of the operand are this many WORDS apart (signed: towers allocated on their own, e.g. the two
+    // elements of a ciphertext, any distance apart in either direction); overrides the row stride
+    int64_t aDelta = 0, bDelta = 0, oDelta = 0;
     LimbSel sel;
 };
 
@@ -117,7 +120,9 @@ FHE_DEV void elemwise_body(const ElemArgs& g, ConstAt constAt) {
             c = constAt(rit);
         const uint32_t tb   = row / g.nLimbs;
         const uint64_t ri   = off & (((uint64_t)1 << g.logN) - 1u);
-        const uint64_t aoff = g.aStride ? ((((uint64_t)tb * g.aStride + g.aFirst + rit) << g.logN) + ri) : off;
+        const uint64_t inTower = ((uint64_t)rit << g.logN) + ri;
+        const uint64_t aoff = g.aDelta ? (uint64_t)((int64_t)tb * g.aDelta) + inTower
+                                       : g.aStride ? ((((uint64_t)tb * g.aStride + g.aFirst + rit) << g.logN) + ri) : off;
         uint64_t a0 = g.a[aoff], a1 = g.a[aoff + 1];
         if (OP == OP_TIMES_QOVERT) {  // :881 xi.ModMulFastConstEq(NegQModt, t, NegQModtPrecon)
             a0 = mul_shoup(a0, g.pre.w, g.pre.wp, g.preMod);
@@ -125,11 +130,13 @@ FHE_DEV void elemwise_body(const ElemArgs& g, ConstAt constAt) {
         }
         uint64_t b0 = 0, b1 = 0, o0 = 0, o1 = 0;
         if (needB) {
-            const uint64_t boff = g.bStride ? ((((uint64_t)tb * g.bStride + g.bFirst + rit) << g.logN) + ri) : off;
+            const uint64_t boff = g.bDelta ? (uint64_t)((int64_t)tb * g.bDelta) + inTower
+                                           : g.bStride ? ((((uint64_t)tb * g.bStride + g.bFirst + rit) << g.logN) + ri) : off;
             b0 = g.b[boff];
             b1 = g.b[boff + 1];
         }
-        const uint64_t ooff = g.oStride ? ((((uint64_t)tb * g.oStride + g.oFirst + rit) << g.logN) + ri) : off;
+        const uint64_t ooff = g.oDelta ? (uint64_t)((int64_t)tb * g.oDelta) + inTower
+                                       : g.oStride ? ((((uint64_t)tb * g.oStride + g.oFirst + rit) << g.logN) + ri) : off;
         if (needO) {
             o0 = g.out[ooff];
             o1 = g.out[ooff + 1];

@@ -572,6 +572,7 @@ static int static_mode(const fhe_ctx* c, const struct PassPlan& pp, bool inverse
 // fused epilogue of a forward transform's last pass (NttPassArgs::epi*)
 struct NttEpilogue {
     uint32_t mode = 0, split = 0, aStride = 0, aFirst = 0;
+    int64_t aDelta = 0;  // != 0: towers of A are this many words apart (NttPassArgs::epiADelta)
     const uint64_t* A = nullptr;
     const TwPair* C   = nullptr;
     uint64_t *out0 = nullptr, *out1 = nullptr;
@@ -613,6 +614,7 @@ static uint32_t fill_pass_args(const fhe_ctx* c, const PassPlan& pp, bool invers
     a.epiMode = 0, a.epiSplit = 0, a.epiAStride = 0, a.epiAFirst = 0;
     a.epiA = nullptr, a.epiC = nullptr, a.epiOut0 = a.epiOut1 = nullptr;
     a.proMode = 0, a.proSrcLimb = 0;
+    a.inDelta = 0, a.epiADelta = 0;
     return grid;
 }
 // forward: bound class of a static pass's input; inverse: does the pass end the transform (ntt_static.h MODE)
@@ -626,10 +628,15 @@ static int static_mode(const fhe_ctx* c, const PassPlan& pp, bool inverse) {
 static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse, const uint64_t* xin, uint64_t* xout,
                               const LimbSel& sel, uint32_t nLimbs, uint32_t batch, bool canonOut, void* stream,
                               uint32_t inStride = 0, uint32_t inFirst = 0, uint32_t outStride = 0, uint32_t outFirst = 0,
-                              const NttEpilogue* epi = nullptr, const uint32_t* proSrcLimb = nullptr) {
+                              const NttEpilogue* epi = nullptr, const uint32_t* proSrcLimb = nullptr, int64_t inDelta = 0) {
     NttPassArgs a;
     const uint32_t grid = fill_pass_args(c, pp, inverse, xin, xout, sel, nLimbs, batch, canonOut, inStride, inFirst, outStride,
                                          outFirst, a);
+    if (inDelta) {  // (the static kernels only)
+        if (c->logN < (uint32_t)kTileLog)
+            return fail(FHE_ERR_UNSUPPORTED, "ntt: separately allocated towers need a ring of at least 4096");
+        a.inDelta = inDelta;
+    }
     if (proSrcLimb) {
         // the forward column pass that loads every limb from one row modulo q[*proSrcLimb] (ntt_prologue_supported)
         a.proMode = 1, a.proSrcLimb = *proSrcLimb;
@@ -647,6 +654,7 @@ static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse
         // only the static forward row / single pass kernels carry the epilogue (ntt_epilogue_supported)
         a.epiMode = epi->mode, a.epiSplit = epi->split, a.epiAStride = epi->aStride, a.epiAFirst = epi->aFirst;
         a.epiA = epi->A, a.epiC = epi->C, a.epiOut0 = epi->out0, a.epiOut1 = epi->out1;
+        a.epiADelta = epi->aDelta;
         const int mode = static_mode(c, pp, inverse);
         bool launched  = false;
 #define FHE_EPI_CASE(TT, MODE) \
@@ -730,7 +738,7 @@ static bool ntt_prologue_supported(const fhe_ctx* c) {
 static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_t* xout, const uint32_t* limbIdx,
                           uint32_t nLimbs, uint32_t batch, void* stream, uint32_t inStride = 0, uint32_t inFirst = 0,
                           uint32_t outStride = 0, uint32_t outFirst = 0, const NttEpilogue* epi = nullptr,
-                          bool canonOut = true, const uint32_t* proSrcLimb = nullptr) {
+                          bool canonOut = true, const uint32_t* proSrcLimb = nullptr, int64_t inDelta = 0) {
     ARG_CHECK(c && xin && xout, "fhe_ntt: null argument");
     ARG_CHECK(batch >= 1, "fhe_ntt: batch must be >= 1");
     LimbSel sel;
@@ -746,7 +754,8 @@ static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_
         if (!inverse)
             schedule_fwd(p, logN, &bound);
         p.outBound = bound;
-        return launch_pass(c, p, inverse, xin, xout, sel, nLimbs, batch, canonOut, stream, inStride, inFirst, outStride, outFirst, epi);
+        return launch_pass(c, p, inverse, xin, xout, sel, nLimbs, batch, canonOut, stream, inStride, inFirst, outStride, outFirst, epi,
+                           nullptr, inDelta);
     }
     // two passes over HBM: a strided column pass of T1 stages (the coefficient index's top bits) and a
     // contiguous row pass of T2 = logN - T1 stages.  T1 is kept minimal (>= 4) so that the column pass reads
@@ -774,7 +783,7 @@ static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_
     // one grid whose workgroups alternate between the two roles (the waiting column workgroups take half of the four
     // resident slots of a CU away from the row workgroups: 33.2 ms instead of 30.4 ms per forward+inverse step).
     if (fhe_status s = launch_pass(c, p1, inverse, xin, xout, sel, nLimbs, batch, false, stream, inStride, inFirst, outStride, outFirst,
-                                   nullptr, proSrcLimb))
+                                   nullptr, proSrcLimb, inDelta))
         return s;
     return launch_pass(c, p2, inverse, xout, xout, sel, nLimbs, batch, canonOut, stream, outStride, outFirst, outStride, outFirst, epi);
 }
@@ -919,7 +928,7 @@ template <int OP>
 static fhe_status elem_run(fhe_ctx* c, uint64_t* out, const uint64_t* a, const uint64_t* b, const TwPair* d_consts,
                            const uint32_t* limbIdx, uint32_t nLimbs, uint32_t batch, void* stream, const char* who,
                            uint32_t aStride = 0, uint32_t aFirst = 0, uint32_t bStride = 0, uint32_t bFirst = 0,
-                           uint32_t oStride = 0, uint32_t oFirst = 0) {
+                           uint32_t oStride = 0, uint32_t oFirst = 0, const int64_t* deltas = nullptr) {
     ARG_CHECK(c && out && a, std::string(who) + ": null argument");
     ARG_CHECK(batch >= 1, std::string(who) + ": batch must be >= 1");
     ElemArgs g;
@@ -936,6 +945,8 @@ static fhe_status elem_run(fhe_ctx* c, uint64_t* out, const uint64_t* a, const u
     g.rows   = batch * nLimbs;
     g.aStride = aStride, g.aFirst = aFirst, g.bStride = bStride, g.bFirst = bFirst;
     g.oStride = oStride, g.oFirst = oFirst;
+    if (deltas)  // towers allocated on their own: words between tower 0 and tower 1 of out / a / b
+        g.oDelta = deltas[0], g.aDelta = deltas[1], g.bDelta = deltas[2];
     FHE_LAUNCH((elemwise_kernel<OP>), tiles_for(c, g.rows), stream, g);
     LAUNCH_CHECK();
     return FHE_OK;
@@ -986,7 +997,7 @@ static fhe_status make_const_vec(const fhe_ctx* c, const uint64_t* consts, const
 template <int OP>
 static fhe_status elem_cv_run(fhe_ctx* c, uint64_t* out, const uint64_t* a, const uint64_t* b, const ConstVec& cv,
                               const uint32_t* limbIdx, uint32_t nLimbs, uint32_t batch, void* stream, const char* who,
-                              uint32_t oStride = 0, uint32_t oFirst = 0) {
+                              uint32_t oStride = 0, uint32_t oFirst = 0, const int64_t* deltas = nullptr) {
     ARG_CHECK(c && out && a, std::string(who) + ": null argument");
     ARG_CHECK(batch >= 1, std::string(who) + ": batch must be >= 1");
     ElemArgs g;
@@ -997,6 +1008,8 @@ static fhe_status elem_cv_run(fhe_ctx* c, uint64_t* out, const uint64_t* a, cons
     g.logN = c->logN, g.nLimbs = nLimbs, g.rows = batch * nLimbs;
     g.aStride = g.aFirst = g.bStride = g.bFirst = 0;
     g.oStride = oStride, g.oFirst = oFirst;
+    if (deltas)
+        g.oDelta = deltas[0], g.aDelta = deltas[1], g.bDelta = deltas[2];
     FHE_LAUNCH((elemwise_cv_kernel<OP>), tiles_for(c, g.rows), stream, g, cv);
     LAUNCH_CHECK();
     return FHE_OK;
@@ -1007,6 +1020,35 @@ extern "C" fhe_status fhe_mul_const(fhe_ctx* c, uint64_t* o, const uint64_t* a, 
     if (fhe_status s = make_const_vec(c, consts, li, nl, &cv, "fhe_mul_const"))
         return s;
     return elem_cv_run<OP_MUL_CONST>(c, o, a, nullptr, cv, li, nl, bt, st, "fhe_mul_const");
+}
+// ---- the two elements of a ciphertext in ONE launch: towers 0 and 1 of every operand are separately allocated buffers ----
+// (pke applies every operation element by element, base-leveledshe.cpp:562-606, ckksrns-leveledshe.cpp:748-759: at one ciphertext
+// a launch per element leaves most of the chip idle — a tower of 14 limbs at N = 2^17 is 448 workgroups for 1024 resident slots)
+static bool pair_deltas(const uint64_t* o0, const uint64_t* o1, const uint64_t* a0, const uint64_t* a1, const uint64_t* b0,
+                        const uint64_t* b1, int64_t d[3]) {
+    d[0] = o1 - o0, d[1] = a1 - a0, d[2] = b0 ? b1 - b0 : 1;
+    return d[0] != 0 && d[1] != 0 && d[2] != 0;  // (0 means "dense" to the kernels: distinct towers are never 0 apart)
+}
+extern "C" fhe_status fhe_add_pair(fhe_ctx* c, uint64_t* o0, uint64_t* o1, const uint64_t* a0, const uint64_t* a1, const uint64_t* b0,
+                                   const uint64_t* b1, const uint32_t* li, uint32_t nl, void* st) {
+    int64_t d[3];
+    ARG_CHECK(o0 && o1 && a0 && a1 && b0 && b1 && pair_deltas(o0, o1, a0, a1, b0, b1, d), "fhe_add_pair: bad argument");
+    return elem_run<OP_ADD>(c, o0, a0, b0, nullptr, li, nl, 2, st, "fhe_add_pair", 0, 0, 0, 0, 0, 0, d);
+}
+extern "C" fhe_status fhe_sub_pair(fhe_ctx* c, uint64_t* o0, uint64_t* o1, const uint64_t* a0, const uint64_t* a1, const uint64_t* b0,
+                                   const uint64_t* b1, const uint32_t* li, uint32_t nl, void* st) {
+    int64_t d[3];
+    ARG_CHECK(o0 && o1 && a0 && a1 && b0 && b1 && pair_deltas(o0, o1, a0, a1, b0, b1, d), "fhe_sub_pair: bad argument");
+    return elem_run<OP_SUB>(c, o0, a0, b0, nullptr, li, nl, 2, st, "fhe_sub_pair", 0, 0, 0, 0, 0, 0, d);
+}
+extern "C" fhe_status fhe_mul_const_pair(fhe_ctx* c, uint64_t* o0, uint64_t* o1, const uint64_t* a0, const uint64_t* a1,
+                                         const uint64_t* consts, const uint32_t* li, uint32_t nl, void* st) {
+    int64_t d[3];
+    ARG_CHECK(o0 && o1 && a0 && a1 && pair_deltas(o0, o1, a0, a1, nullptr, nullptr, d), "fhe_mul_const_pair: bad argument");
+    ConstVec cv;
+    if (fhe_status s = make_const_vec(c, consts, li, nl, &cv, "fhe_mul_const_pair"))
+        return s;
+    return elem_cv_run<OP_MUL_CONST>(c, o0, a0, nullptr, cv, li, nl, 2, st, "fhe_mul_const_pair", 0, 0, d);
 }
 // DCRTPolyImpl::Plus(vector<Integer>) (dcrtpoly-impl.h:520-527 -> PolyImpl::Plus(Integer), poly-impl.h:211-218): limb i plus the
 // constant polynomial consts[i] — every word in EVALUATION, coefficient 0 only in COEFFICIENT (coeff0Only)
@@ -2402,29 +2444,41 @@ static fhe_status const_table(fhe_ctx* c, const uint32_t* limbIdx, const uint64_
 //   canonical residues on both sides, so the words are the reference's.  4 launches: INTT of the last limb (2), the column pass
 //   that loads every limb from the one INTT row through SwitchModulus, the row pass whose store is (x - r)*B.  Neither the
 //   switched tower nor its transform goes to HBM outside `out`.
+// x1 / out1 != null: the towers are the two elements of one ciphertext, allocated on their own (x, x1 -> out, out1; batch must be 2):
+// the same launches, each over both towers.
 static fhe_status rescale_run(fhe_ctx* c, const uint64_t* x, const uint32_t* limbIdx, uint32_t sizeQl, const TwPair* dA,
-                              const TwPair* dB, bool negated, uint32_t batch, uint64_t* out, uint64_t* ws, void* st) {
+                              const TwPair* dB, bool negated, uint32_t batch, uint64_t* out, uint64_t* ws, void* st,
+                              const uint64_t* x1 = nullptr, uint64_t* out1 = nullptr) {
     const uint32_t l       = sizeQl - 1;
     const uint32_t lastIdx = limbIdx ? limbIdx[l] : l;
     uint64_t* last         = ws;                                 // [batch][N]
     uint64_t* tmp          = last + ((size_t)batch << c->logN);  // [batch][l][N]
-    // lastPoly.SetFormat(COEFFICIENT)  (:696-697): INTT of the last limb of every tower, written densely
-    if (fhe_status s = ntt_run(c, true, x, last, &lastIdx, 1, batch, st, sizeQl, l))
-        return s;
     static const bool noFuse = env_u32("FHE_RESCALE_UNFUSED", 0) != 0;
-    if (negated && !noFuse && ntt_epilogue_supported(c)) {
+    const bool fused = negated && !noFuse && ntt_epilogue_supported(c);
+    if (x1 && !fused) {  // (small rings, foreign tables: element by element)
+        if (fhe_status s = rescale_run(c, x, limbIdx, sizeQl, dA, dB, negated, 1, out, ws, st))
+            return s;
+        return rescale_run(c, x1, limbIdx, sizeQl, dA, dB, negated, 1, out1, ws, st);
+    }
+    const int64_t xDelta = x1 ? x1 - x : 0;
+    // lastPoly.SetFormat(COEFFICIENT)  (:696-697): INTT of the last limb of every tower, written densely
+    if (fhe_status s = ntt_run(c, true, x, last, &lastIdx, 1, batch, st, sizeQl, l, 0, 0, nullptr, true, nullptr, xDelta))
+        return s;
+    if (fused) {
         NttEpilogue epi;
-        epi.mode = 1, epi.split = batch, epi.aStride = sizeQl, epi.aFirst = 0;
-        epi.A = x, epi.C = dB, epi.out0 = out, epi.out1 = out;
+        epi.mode = 1, epi.split = x1 ? 1 : batch, epi.aStride = sizeQl, epi.aFirst = 0, epi.aDelta = xDelta;
+        epi.A = x, epi.C = dB, epi.out0 = out, epi.out1 = x1 ? out1 : out;
+        // (two elements: the transform works in the workspace, its fused store goes to the two output towers)
+        uint64_t* work = x1 ? tmp : out;
         if (ntt_prologue_supported(c))
-            return ntt_run(c, false, last, out, limbIdx, l, batch, st, 1, 0, 0, 0, &epi, true, &lastIdx);
+            return ntt_run(c, false, last, work, limbIdx, l, batch, st, 1, 0, 0, 0, &epi, true, &lastIdx);
         // the single pass of N = 4096: SwitchModulus as a kernel of its own, then the transform with the fused store
         LimbSel sel;
         if (fhe_status s = make_sel(c, limbIdx, l, &sel, "fhe_rescale"))
             return s;
-        if (fhe_status s = switch_modulus_run(c, out, sel, l, last, 1, 0, lastIdx, nullptr, batch, st))
+        if (fhe_status s = switch_modulus_run(c, work, sel, l, last, 1, 0, lastIdx, nullptr, batch, st))
             return s;
-        return ntt_run(c, false, out, out, limbIdx, l, batch, st, 0, 0, 0, 0, &epi);
+        return ntt_run(c, false, work, work, limbIdx, l, batch, st, 0, 0, 0, 0, &epi);
     }
     // tmp = SwitchModulus(last -> q_i) * QlQlInvModqlDivqlModq[i]   (:703-705)
     LimbSel sel;
@@ -2474,16 +2528,16 @@ extern "C" fhe_status fhe_rescale(fhe_ctx* c, const uint64_t* x, uint32_t sizeQl
 }
 // the same with the caller's tables (host arrays of sizeQl-1 residues: CryptoParametersRNS::GetQlQlInvModqlDivqlModq(l) /
 // GetqlInvModq(l)) over any limbs of the context: what the DCRTPoly backend's DropLastElementAndScale calls
-extern "C" fhe_status fhe_rescale_limbs(fhe_ctx* c, const uint64_t* x, const uint32_t* limbIdx, uint32_t sizeQl,
-                                        const uint64_t* QlQlInvModqlDivqlModq, const uint64_t* qlInvModq, uint32_t batch,
-                                        uint64_t* out, void* wsv, size_t wsBytes, void* st) {
-    ARG_CHECK(c && x && out && wsv && QlQlInvModqlDivqlModq && qlInvModq, "fhe_rescale_limbs: null argument");
+static fhe_status rescale_limbs_run(fhe_ctx* c, const uint64_t* x, const uint64_t* x1, const uint32_t* limbIdx, uint32_t sizeQl,
+                                    const uint64_t* QlQlInvModqlDivqlModq, const uint64_t* qlInvModq, uint32_t batch, uint64_t* out,
+                                    uint64_t* out1, void* wsv, size_t wsBytes, void* st, const char* who) {
+    ARG_CHECK(c && x && out && wsv && QlQlInvModqlDivqlModq && qlInvModq, std::string(who) + ": null argument");
     ARG_CHECK(sizeQl >= 2 && sizeQl <= (uint32_t)kMaxLimbs, "Removing last element of DCRTPoly renders it invalid.");  // :672-673
-    ARG_CHECK(batch >= 1 && wsBytes >= fhe_rescale_workspace_bytes(c, sizeQl, batch), "fhe_rescale_limbs: workspace too small");
+    ARG_CHECK(batch >= 1 && wsBytes >= fhe_rescale_workspace_bytes(c, sizeQl, batch), std::string(who) + ": workspace too small");
     RT_CHECK(rt::set_device(c->device));
     const uint32_t l = sizeQl - 1;
     for (uint32_t i = 0; i < sizeQl; ++i)
-        ARG_CHECK((limbIdx ? limbIdx[i] : i) < c->L, "fhe_rescale_limbs: limb index exceeds context size");
+        ARG_CHECK((limbIdx ? limbIdx[i] : i) < c->L, std::string(who) + ": limb index exceeds context size");
     bool negated = true;
     for (uint32_t i = 0; i < l; ++i) {
         const uint64_t qi = c->q[limbIdx ? limbIdx[i] : i];
@@ -2494,7 +2548,22 @@ extern "C" fhe_status fhe_rescale_limbs(fhe_ctx* c, const uint64_t* x, const uin
         return s;
     if (fhe_status s = const_table(c, limbIdx, qlInvModq, l, &dB))
         return s;
-    return rescale_run(c, x, limbIdx, sizeQl, dA, dB, negated, batch, out, (uint64_t*)wsv, st);
+    return rescale_run(c, x, limbIdx, sizeQl, dA, dB, negated, batch, out, (uint64_t*)wsv, st, x1, out1);
+}
+extern "C" fhe_status fhe_rescale_limbs(fhe_ctx* c, const uint64_t* x, const uint32_t* limbIdx, uint32_t sizeQl,
+                                        const uint64_t* QlQlInvModqlDivqlModq, const uint64_t* qlInvModq, uint32_t batch,
+                                        uint64_t* out, void* wsv, size_t wsBytes, void* st) {
+    return rescale_limbs_run(c, x, nullptr, limbIdx, sizeQl, QlQlInvModqlDivqlModq, qlInvModq, batch, out, nullptr, wsv, wsBytes, st,
+                             "fhe_rescale_limbs");
+}
+// the two elements of one ciphertext (towers x0, x1 -> out0, out1, each allocated on its own) in the same four launches;
+// ws of fhe_rescale_workspace_bytes(ctx, sizeQl, 2)
+extern "C" fhe_status fhe_rescale_limbs_pair(fhe_ctx* c, const uint64_t* x0, const uint64_t* x1, const uint32_t* limbIdx, uint32_t sizeQl,
+                                             const uint64_t* QlQlInvModqlDivqlModq, const uint64_t* qlInvModq, uint64_t* out0,
+                                             uint64_t* out1, void* wsv, size_t wsBytes, void* st) {
+    ARG_CHECK(x1 && out1 && x1 != x0 && out1 != out0, "fhe_rescale_limbs_pair: needs two distinct towers");
+    return rescale_limbs_run(c, x0, x1, limbIdx, sizeQl, QlQlInvModqlDivqlModq, qlInvModq, 2, out0, out1, wsv, wsBytes, st,
+                             "fhe_rescale_limbs_pair");
 }
 
 // DCRTPolyImpl::ModReduce (dcrtpoly-impl.h:736-755), the BGV modulus switch by the last limb with plaintext modulus t:

@@ -92,6 +92,9 @@ struct NttPassArgs {
     // brought to the limb's own modulus on the way in (SwitchModulus, mubintvecnat.cpp:109-122) — the `tmp[i] = lastPoly;
     // tmp[i].SwitchModulus(q_i)` of DropLastElementAndScale (dcrtpoly-impl.h:703-704) never goes to HBM.  0: off.
     uint32_t proMode, proSrcLimb;
+    // != 0: consecutive towers of the pass's first load / of the epilogue's operand A are this many WORDS apart (signed: towers
+    // allocated on their own — the two elements of a ciphertext); overrides inStride / epiAStride (static kernels only)
+    int64_t inDelta, epiADelta;
 };
 // SwitchModulus of one residue (mubintvecnat.cpp:109-122): v modulo qs, centred, to the modulus qn
 FHE_HD uint64_t switch_modulus_word(uint64_t v, uint64_t qs, uint64_t halfQs, uint64_t qn) {

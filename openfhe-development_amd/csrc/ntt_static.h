@@ -493,7 +493,8 @@ FHE_DEV void ntt_static_core(const NttPassArgs& a, uint32_t bid, uint64_t* lds, 
     asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0" : "={v65}"(z.z0), "={v81}"(z.z1));
 #endif
     const bool canonOut = a.canonStep != 0xffffffffu;
-    const uint64_t* src = a.xin + (inRow << logN) + jbase;
+    const uint64_t* src = a.inDelta ? a.xin + (int64_t)tb * a.inDelta + ((uint64_t)(a.inFirst + (PRO ? 0u : rit)) << logN) + jbase
+                                    : a.xin + (inRow << logN) + jbase;
     uint64_t* dst       = a.x + (outRow << logN) + jbase;
 
     uint32_t Ib, jrel;
@@ -508,7 +509,8 @@ FHE_DEV void ntt_static_core(const NttPassArgs& a, uint32_t bid, uint64_t* lds, 
         else {
             const uint64_t* cw = reinterpret_cast<const uint64_t*>(a.epiC + rit);
             const uint64_t cW = FHE_ULOAD64(cw, 0), cWp = FHE_ULOAD64(cw, 1);
-            const uint64_t* A  = a.epiA + ((((uint64_t)tb * a.epiAStride + a.epiAFirst + rit)) << logN) + jbase;
+            const uint64_t* A  = a.epiADelta ? a.epiA + (int64_t)tb * a.epiADelta + ((uint64_t)(a.epiAFirst + rit) << logN) + jbase
+                                             : a.epiA + ((((uint64_t)tb * a.epiAStride + a.epiAFirst + rit)) << logN) + jbase;
             const bool second  = tb >= a.epiSplit;
             uint64_t* O        = (second ? a.epiOut1 : a.epiOut0) +
                           ((((uint64_t)(second ? tb - a.epiSplit : tb) * a.nLimbs + rit)) << logN) + jbase;

@@ -132,6 +132,10 @@ class Lib:
         S("fhe_rescale_workspace_bytes", C.c_size_t, [vp, u32, u32])
         S("fhe_rescale", C.c_int, [vp, vp, u32, u32, vp, vp, C.c_size_t, vp])
         S("fhe_rescale_limbs", C.c_int, [vp, vp, u32p, u32, u64p, u64p, u32, vp, vp, C.c_size_t, vp])
+        S("fhe_rescale_limbs_pair", C.c_int, [vp, vp, vp, u32p, u32, u64p, u64p, vp, vp, vp, C.c_size_t, vp])
+        S("fhe_add_pair", C.c_int, [vp, vp, vp, vp, vp, vp, vp, u32p, u32, vp])
+        S("fhe_sub_pair", C.c_int, [vp, vp, vp, vp, vp, vp, vp, u32p, u32, vp])
+        S("fhe_mul_const_pair", C.c_int, [vp, vp, vp, vp, vp, u64p, u32p, u32, vp])
         S("fhe_mod_reduce", C.c_int, [vp, vp, u32, u64, C.c_int, u32, vp, vp, C.c_size_t, vp])
         f64p = C.POINTER(C.c_double)
         S("fhe_sr_plan_create", C.c_int, [vp, u32, u32p, u32, u64p, f64p, C.POINTER(vp)])
@@ -656,6 +660,36 @@ def rescale_limbs(ctx, x, scale_tab, inv_tab, stream=None):
     ctx.sync(stream)
     ctx.free(ws)
     return out
+
+
+def rescale_limbs_pair(ctx, x0, x1, scale_tab, inv_tab, stream=None):
+    """the two elements of a ciphertext (two Towers of batch 1, allocated on their own) through fhe_rescale_limbs_pair"""
+    sizeQl = x0.n_limbs
+    need = ctx.lib.L.fhe_rescale_workspace_bytes(ctx.h, sizeQl, 2)
+    ws = ctx.malloc(need)
+    kept = None if x0.limb_idx is None else x0.limb_idx[:sizeQl - 1]
+    o0, o1 = ctx.empty(1, sizeQl - 1, kept), ctx.empty(1, sizeQl - 1, kept)
+    a = np.ascontiguousarray(scale_tab, dtype=np.uint64)
+    b = np.ascontiguousarray(inv_tab, dtype=np.uint64)
+    ctx.lib.check(ctx.lib.L.fhe_rescale_limbs_pair(ctx.h, x0.ptr, x1.ptr, x0._li(), sizeQl, a.ctypes.data_as(u64p), b.ctypes.data_as(u64p),
+                                                   o0.ptr, o1.ptr, ws, need, stream))
+    ctx.sync(stream)
+    ctx.free(ws)
+    return o0, o1
+
+
+def elem_pair(ctx, kind, a0, a1, b0=None, b1=None, consts=None, in_place=False, stream=None):
+    """fhe_add_pair / fhe_sub_pair / fhe_mul_const_pair on Towers of batch 1 allocated on their own"""
+    n = a0.n_limbs
+    o0, o1 = (a0, a1) if in_place else (ctx.empty(1, n, a0.limb_idx, a0.fmt), ctx.empty(1, n, a0.limb_idx, a0.fmt))
+    if kind == "mul_const":
+        k = np.ascontiguousarray(consts, dtype=np.uint64)
+        ctx.lib.check(ctx.lib.L.fhe_mul_const_pair(ctx.h, o0.ptr, o1.ptr, a0.ptr, a1.ptr, k.ctypes.data_as(u64p), a0._li(), n, stream))
+    else:
+        f = ctx.lib.L.fhe_add_pair if kind == "add" else ctx.lib.L.fhe_sub_pair
+        ctx.lib.check(f(ctx.h, o0.ptr, o1.ptr, a0.ptr, a1.ptr, b0.ptr, b1.ptr, a0._li(), n, stream))
+    ctx.sync(stream)
+    return o0, o1
 
 
 def mod_reduce(ctx, x, t, stream=None):

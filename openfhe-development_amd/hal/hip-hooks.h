@@ -42,6 +42,8 @@ void CountComposite();
 extern "C" {
 // {composite calls, first-use checks that matched, first-use checks that differed} since process start
 void fhe_hal_composite_stats(uint64_t out[3]);
+// results of pure members taken from the memo of a shared buffer (DevBuf::memo) instead of recomputed
+uint64_t fhe_hal_memo_hits();
 // the device library's kernel launches since it was loaded: "<kernel> <launches>\n" lines into buf, *total = their sum
 size_t fhe_hal_launch_stats(char* buf, size_t cap, uint64_t* total);
 }

@@ -129,6 +129,8 @@ Runtime* build() {
                   FHE_SYM(add_const, fhe_add_const) && FHE_SYM(sub_const, fhe_sub_const) && FHE_SYM(times_q_over_t, fhe_times_q_over_t) &&
                   FHE_SYM(mod_switch_round, fhe_mod_switch_round) && FHE_SYM(automorph, fhe_automorph) &&
                   FHE_SYM(switch_modulus, fhe_switch_modulus) && FHE_SYM(rescale_limbs, fhe_rescale_limbs) &&
+                  FHE_SYM(rescale_limbs_pair, fhe_rescale_limbs_pair) && FHE_SYM(add_pair, fhe_add_pair) && FHE_SYM(sub_pair, fhe_sub_pair) &&
+                  FHE_SYM(mul_const_pair, fhe_mul_const_pair) &&
                   FHE_SYM(rescale_workspace_bytes, fhe_rescale_workspace_bytes) && FHE_SYM(conv_create_custom, fhe_conv_create_custom) &&
                   FHE_SYM(approx_switch_basis, fhe_approx_switch_basis) && FHE_SYM(switch_basis_exact, fhe_switch_basis_exact) &&
                   FHE_SYM(sr_plan_create, fhe_sr_plan_create) && FHE_SYM(scale_and_round, fhe_scale_and_round) &&
@@ -347,13 +349,42 @@ const uint64_t* Op::R(const Buf& b) {
 uint64_t* Op::W(const Buf& b) {
     ThreadState* ts = thread_state();
     DevBuf* root    = root_of(b.get());
-    std::lock_guard<std::mutex> lk(root->mu);
-    order_after(ts, root->writer);
-    for (const auto& u : root->readers)
-        order_after(ts, u);
-    root->readers.clear();
-    root->writer = DevBuf::Use{ts->id, m_seq};
+    std::vector<DevBuf::Memo> history;  // (released after the lock)
+    {
+        std::lock_guard<std::mutex> lk(root->mu);
+        order_after(ts, root->writer);
+        for (const auto& u : root->readers)
+            order_after(ts, u);
+        root->readers.clear();
+        root->writer = DevBuf::Use{ts->id, m_seq};
+        history.swap(root->memo);  // the words change: what was derived from them is history
+    }
     return b->p;
+}
+std::atomic<uint64_t> g_memoHits{0};
+Buf MemoFind(const Buf& src, const std::vector<uint64_t>& key) {
+    if (!src || src->parent)
+        return nullptr;
+    std::lock_guard<std::mutex> lk(src->mu);
+    for (const auto& m : src->memo)
+        if (m.key == key) {
+            g_memoHits.fetch_add(1, std::memory_order_relaxed);
+            return m.result;
+        }
+    return nullptr;
+}
+void MemoStore(const Buf& src, std::vector<uint64_t> key, const Buf& result) {
+    if (!src || src->parent || !result)
+        return;
+    DevBuf::Memo evicted;
+    {
+        std::lock_guard<std::mutex> lk(src->mu);
+        if (src->memo.size() >= 4) {
+            evicted = std::move(src->memo.front());
+            src->memo.erase(src->memo.begin());
+        }
+        src->memo.push_back(DevBuf::Memo{std::move(key), result});
+    }
 }
 void Op::HostSync() {
     Runtime& r = rt();
@@ -985,6 +1016,8 @@ extern "C" size_t fhe_hal_launch_stats(char* buf, size_t cap, uint64_t* total) {
         *total = 0;
     return r.launch_stats ? r.launch_stats(buf, cap, total) : 0;
 }
+// results of pure members (DropLastElementAndScale, Times by constants) taken from the memo of a shared buffer instead of recomputed
+extern "C" uint64_t fhe_hal_memo_hits() { return lbcrypto::hiprt::g_memoHits.load(); }
 extern "C" void fhe_hal_composite_stats(uint64_t out[3]) {
     out[0] = lbcrypto::hiprt::g_compositeCalls, out[1] = lbcrypto::hiprt::g_checksOk, out[2] = lbcrypto::hiprt::g_checksBad;
 }

@@ -182,11 +182,30 @@ void LeveledSHECKKSRNS::EvalSubInPlace(Ciphertext<DCRTPoly>& ciphertext, double 
     cv[0]             = cv[0].Minus(elmnts);
 }
 
+// ckksrns-leveledshe.cpp:172-191: the rescale of both elements with the level's tables, one library call per level (the same four
+// launches as one element's)
+void LeveledSHECKKSRNS::ModReduceInternalInPlace(Ciphertext<DCRTPoly>& ciphertext, size_t levels) const {
+    const auto cryptoParams = std::dynamic_pointer_cast<CryptoParametersCKKSRNS>(ciphertext->GetCryptoParameters());
+    auto& cv                = ciphertext->GetElements();
+    const size_t sizeQ = cryptoParams->GetElementParams()->GetParams().size(), sizeQl = cv[0].GetNumOfElements(), diffQl = sizeQ - sizeQl;
+    ciphertext->SetNoiseScaleDeg(ciphertext->GetNoiseScaleDeg() - levels / cryptoParams->GetCompositeDegree());
+    ciphertext->SetLevel(ciphertext->GetLevel() + levels);
+    for (size_t i = 0; i < levels; ++i) {
+        const auto& scale = cryptoParams->GetQlQlInvModqlDivqlModq(diffQl + i);
+        const auto& inv   = cryptoParams->GetqlInvModq(diffQl + i);
+        if (cv.size() != 2 || !DCRTPoly::PairRescaleInPlace(cv[0], cv[1], scale, inv))
+            for (auto& dcrtpoly : cv)
+                dcrtpoly.DropLastElementAndScale(scale, inv);
+        ciphertext->SetScalingFactor(ciphertext->GetScalingFactor() / cryptoParams->GetModReduceFactor(sizeQl - 1 - i));
+    }
+}
+
 void LeveledSHECKKSRNS::EvalMultCoreInPlace(Ciphertext<DCRTPoly>& ciphertext, double operand) const {
     const auto factors = GetElementForEvalMult(ShapeOf(ciphertext), operand);
     auto& cv           = ciphertext->GetElements();
-    for (uint32_t i = 0; i < cv.size(); ++i)
-        cv[i] = cv[i] * factors;
+    if (cv.size() != 2 || !DCRTPoly::PairTimesInPlace(cv[0], cv[1], factors))  // (both elements in one launch)
+        for (uint32_t i = 0; i < cv.size(); ++i)
+            cv[i] = cv[i] * factors;
     ciphertext->SetNoiseScaleDeg(ciphertext->GetNoiseScaleDeg() + 1);
     const auto cryptoParams = std::dynamic_pointer_cast<CryptoParametersCKKSRNS>(ciphertext->GetCryptoParameters());
     ciphertext->SetScalingFactor(ciphertext->GetScalingFactor() * cryptoParams->GetScalingFactorReal(ciphertext->GetLevel()));
@@ -366,6 +385,37 @@ std::shared_ptr<std::vector<DCRTPoly>> KeySwitchHYBRID::KeySwitchCore(const DCRT
     return ref;
 }
 
+// base-leveledshe.cpp:562-579, :589-606: += / -= of the elements, both elements of a two-element pair in one launch
+template <>
+void LeveledSHEBase<DCRTPoly>::EvalAddCoreInPlace(Ciphertext<DCRTPoly>& ciphertext1, ConstCiphertext<DCRTPoly>& ciphertext2) const {
+    VerifyNumOfTowers(ciphertext1, ciphertext2);
+    auto& cv1       = ciphertext1->GetElements();
+    const auto& cv2 = ciphertext2->GetElements();
+    if (cv1.size() == 2 && cv2.size() == 2 && DCRTPoly::PairAddInPlace(cv1[0], cv1[1], cv2[0], cv2[1], false))
+        return;
+    const uint32_t c1Size = cv1.size(), c2Size = cv2.size(), cSmallSize = std::min(c1Size, c2Size);
+    cv1.reserve(c2Size);
+    uint32_t i = 0;
+    for (; i < cSmallSize; ++i)
+        cv1[i] += cv2[i];
+    for (; i < c2Size; ++i)
+        cv1.emplace_back(cv2[i]);
+}
+template <>
+void LeveledSHEBase<DCRTPoly>::EvalSubCoreInPlace(Ciphertext<DCRTPoly>& ciphertext1, ConstCiphertext<DCRTPoly>& ciphertext2) const {
+    VerifyNumOfTowers(ciphertext1, ciphertext2);
+    auto& cv1       = ciphertext1->GetElements();
+    const auto& cv2 = ciphertext2->GetElements();
+    if (cv1.size() == 2 && cv2.size() == 2 && DCRTPoly::PairAddInPlace(cv1[0], cv1[1], cv2[0], cv2[1], true))
+        return;
+    const uint32_t c1Size = cv1.size(), c2Size = cv2.size(), cSmallSize = std::min(c1Size, c2Size);
+    cv1.reserve(c2Size);
+    uint32_t i = 0;
+    for (; i < cSmallSize; ++i)
+        cv1[i] -= cv2[i];
+    for (; i < c2Size; ++i)
+        cv1.emplace_back(cv2[i].Negate());
+}
 // base-leveledshe.cpp:201-214
 template <>
 Ciphertext<DCRTPoly> LeveledSHEBase<DCRTPoly>::EvalMult(ConstCiphertext<DCRTPoly>& ciphertext1, ConstCiphertext<DCRTPoly>& ciphertext2,

@@ -356,9 +356,26 @@ public:
             std::vector<NativeInteger> c(NumLimbs());
             for (uint32_t i = 0; i < NumLimbs(); ++i)
                 c[i] = NativeInteger(rhs[i]);
+            // (a clone multiplied by the constants its original was multiplied by before — the level adjustments of pke's weighted sums
+            // — takes that result: DevBuf::memo)
+            const hiprt::Buf src = m_d;
+            std::vector<uint64_t> memoKey;
+            hiprt::Resolved r;
+            if (src && !m_hostValid && src.use_count() > 2 && !src->parent && OnDevice(&r)) {
+                memoKey.reserve(2 + 2 * (size_t)NumLimbs());
+                memoKey.push_back(2), memoKey.push_back(NumLimbs());
+                memoKey.insert(memoKey.end(), r.idx[0].begin(), r.idx[0].end());
+                for (const auto& v : c)
+                    memoKey.push_back(v.ConvertToInt<uint64_t>());
+                if (auto hit = hiprt::MemoFind(src, memoKey))
+                    return FromDevice(m_h.GetParams(), m_h.GetFormat(), std::move(hit));
+            }
             DCRTPolyType out(*this);
-            if (out.TimesConstInPlace(c))
+            if (out.TimesConstInPlace(c)) {
+                if (!memoKey.empty() && out.m_d != src)
+                    hiprt::MemoStore(src, std::move(memoKey), out.m_d);
                 return out;
+            }
         }
         return Wrap(Hc().Times(rhs));
     }
@@ -986,6 +1003,110 @@ public:
         out.push_back(FromDevice(P, Format::EVALUATION, std::move(d1)));
         out.push_back(FromDevice(P, Format::EVALUATION, std::move(d2)));
         return out;
+    }
+
+    // ---- the two elements of a ciphertext in ONE launch each (hal/keyswitch-hybrid-hip.cpp's definitions of pke's element loops):
+    // pke applies += / -= / * constants / DropLastElementAndScale to cv[0] and cv[1] one after the other (base-leveledshe.cpp:562-606,
+    // ckksrns-leveledshe.cpp:172-191, :748-759); a single ciphertext's tower fills less than half of the chip, so the second launch
+    // costs as much as the first.  false: the towers cannot take the paired device path — the caller runs the element loop.
+    static bool PairAddInPlace(DCRTPolyType& a0, DCRTPolyType& a1, const DCRTPolyType& b0, const DCRTPolyType& b1, bool subtract) {
+        hiprt::MemberScope scope(subtract ? "operator-=" : "operator+=");
+        hiprt::Resolved r;
+        if (&a0 == &a1 || !a0.Compatible(a1, false) || !a0.Compatible(b0, false) || !a0.Compatible(b1, false) || !a0.OnDevice(&r) || !a1.Upload() ||
+            !b0.Upload() || !b1.Upload() || a0.m_d == a1.m_d || b0.m_d == b1.m_d)
+            return false;
+        const auto& A = hiprt::api();
+        hiprt::Op op;
+        auto d0 = a0.WriteTarget(), d1 = a1.WriteTarget();
+        const uint64_t *pa0 = op.R(a0.m_d), *pa1 = op.R(a1.m_d), *pb0 = op.R(b0.m_d), *pb1 = op.R(b1.m_d);
+        hiprt::Check((subtract ? A.sub_pair : A.add_pair)(r.ctx, op.W(d0), op.W(d1), pa0, pa1, pb0, pb1, r.idx[0].data(), a0.NumLimbs(), op.s),
+                     "DCRTPoly arithmetic on both elements");
+        a0.m_d = std::move(d0), a1.m_d = std::move(d1);
+        hiprt::CountDevice();
+        a0.DeviceIsNewer(a0.m_h.GetFormat()), a1.DeviceIsNewer(a1.m_h.GetFormat());
+        return true;
+    }
+    // a_e = a_e * factors (limb i times NativeInteger(factors[i]), dcrtpoly-impl.h:572-580) on both elements
+    static bool PairTimesInPlace(DCRTPolyType& a0, DCRTPolyType& a1, const std::vector<Integer>& factors) {
+        hiprt::MemberScope scope("Times");
+        hiprt::Resolved r;
+        const uint32_t L = a0.NumLimbs();
+        if (&a0 == &a1 || factors.size() < L || !a0.Compatible(a1, false) || !a0.OnDevice(&r) || !a1.Upload() || a0.m_d == a1.m_d)
+            return false;
+        std::vector<uint64_t> k(L);
+        for (uint32_t i = 0; i < L; ++i)
+            k[i] = NativeInteger(factors[i]).template ConvertToInt<uint64_t>();
+        hiprt::Op op;
+        auto d0 = a0.WriteTarget(), d1 = a1.WriteTarget();
+        const uint64_t *pa0 = op.R(a0.m_d), *pa1 = op.R(a1.m_d);
+        hiprt::Check(hiprt::api().mul_const_pair(r.ctx, op.W(d0), op.W(d1), pa0, pa1, k.data(), r.idx[0].data(), L, op.s),
+                     "DCRTPoly Times(constants) on both elements");
+        a0.m_d = std::move(d0), a1.m_d = std::move(d1);
+        hiprt::CountDevice();
+        a0.DeviceIsNewer(a0.m_h.GetFormat()), a1.DeviceIsNewer(a1.m_h.GetFormat());
+        return true;
+    }
+    // DropLastElementAndScale (dcrtpoly-impl.h:693-712) of both elements with the same tables: the four launches of fhe_rescale_limbs,
+    // each over both towers.  (Elements that are clones of towers rescaled before take the remembered results, see RescaleOnDevice.)
+    static bool PairRescaleInPlace(DCRTPolyType& a0, DCRTPolyType& a1, const std::vector<NativeInteger>& QlQlInvModqlDivqlModq,
+                                   const std::vector<NativeInteger>& qlInvModq) {
+        hiprt::MemberScope scope("DropLastElementAndScale");
+        const uint32_t L = a0.NumLimbs();
+        if (&a0 == &a1 || L < 2 || !a0.Compatible(a1, true) || QlQlInvModqlDivqlModq.size() < L - 1 || qlInvModq.size() < L - 1)
+            return false;
+        hiprt::Resolved r;
+        if (!a0.OnDevice(&r) || !a1.Upload() || a0.m_d == a1.m_d)
+            return false;
+        const size_t N   = a0.m_h.GetParams()->GetRingDimension();
+        const uint32_t l = L - 1;
+        std::vector<uint64_t> a(l), b(l);
+        for (uint32_t i = 0; i < l; ++i) {
+            a[i] = QlQlInvModqlDivqlModq[i].ConvertToInt<uint64_t>();
+            b[i] = qlInvModq[i].ConvertToInt<uint64_t>();
+        }
+        // clones of towers rescaled before: both results remembered -> taken; one of them -> element by element (the member looks it up)
+        const hiprt::Buf s0 = a0.m_d, s1 = a1.m_d;
+        const bool remember = s0.use_count() > 2 && s1.use_count() > 2 && !s0->parent && !s1->parent;
+        std::vector<uint64_t> memoKey;
+        if (s0.use_count() > 2 || s1.use_count() > 2) {
+            if (!remember)
+                return false;
+            memoKey = RescaleMemoKey(r, L, a, b);
+            auto h0 = hiprt::MemoFind(s0, memoKey), h1 = hiprt::MemoFind(s1, memoKey);
+            if (h0 && h1) {
+                a0.m_d = std::move(h0), a1.m_d = std::move(h1);
+                a0.DeviceIsNewer(Format::EVALUATION), a1.DeviceIsNewer(Format::EVALUATION);
+                a0.DropLastElement(), a1.DropLastElement();
+                return true;
+            }
+            if (h0 || h1)
+                return false;
+        }
+        const auto& A = hiprt::api();
+        hiprt::Op op;
+        const uint64_t *x0 = op.R(a0.m_d), *x1 = op.R(a1.m_d);
+        const size_t wsBytes = A.rescale_workspace_bytes(r.ctx, L, 2);
+        auto ws = hiprt::Alloc(wsBytes / 8), o0 = hiprt::Alloc((size_t)l * N), o1 = hiprt::Alloc((size_t)l * N);
+        hiprt::Check(A.rescale_limbs_pair(r.ctx, x0, x1, r.idx[0].data(), L, a.data(), b.data(), op.W(o0), op.W(o1), op.W(ws), wsBytes, op.s),
+                     "DropLastElementAndScale on both elements");
+        if (remember) {
+            hiprt::MemoStore(s0, memoKey, o0);
+            hiprt::MemoStore(s1, std::move(memoKey), o1);
+        }
+        a0.m_d = std::move(o0), a1.m_d = std::move(o1);
+        hiprt::CountDevice();
+        a0.DeviceIsNewer(Format::EVALUATION), a1.DeviceIsNewer(Format::EVALUATION);
+        a0.DropLastElement(), a1.DropLastElement();
+        return true;
+    }
+    static std::vector<uint64_t> RescaleMemoKey(const hiprt::Resolved& r, uint32_t L, const std::vector<uint64_t>& a, const std::vector<uint64_t>& b) {
+        std::vector<uint64_t> key;
+        key.reserve(2 + 3 * (size_t)L);
+        key.push_back(1), key.push_back(L);
+        key.insert(key.end(), r.idx[0].begin(), r.idx[0].end());
+        key.insert(key.end(), a.begin(), a.end());
+        key.insert(key.end(), b.begin(), b.end());
+        return key;
     }
 
     // the host mirror (synchronised), for code that wants the default implementation's object
@@ -1786,6 +1907,19 @@ private:
             a[i] = QlQlInvModqlDivqlModq[i].ConvertToInt<uint64_t>();
             b[i] = qlInvModq[i].ConvertToInt<uint64_t>();
         }
+        // a clone of a tower that was rescaled with these tables before takes that result (pke's weighted sums rescale a fresh clone of
+        // every power in every sum): the same words through the same member with the same tables
+        const hiprt::Buf src = m_d;
+        std::vector<uint64_t> memoKey;
+        if (src.use_count() > 2 && !src->parent) {  // (src and m_d are two of the references)
+            memoKey = RescaleMemoKey(r, L, a, b);
+            if (auto hit = hiprt::MemoFind(src, memoKey)) {
+                m_d = std::move(hit);
+                DeviceIsNewer(Format::EVALUATION);
+                DropLastElement();
+                return true;
+            }
+        }
         // the whole member is ONE library call with the caller's tables (fhe_rescale_limbs: :696-709; 4 launches on the rings of two
         // static passes: the INTT of the last limb, then SwitchModulus on the way into the forward transform and the `* qlInvModq +`
         // on its way out)
@@ -1797,6 +1931,8 @@ private:
         auto tmp             = hiprt::Alloc((size_t)l * N);
         hiprt::Check(A.rescale_limbs(r.ctx, self, r.idx[0].data(), L, a.data(), b.data(), 1, op.W(tmp), op.W(ws), wsBytes, op.s),
                      "DropLastElementAndScale");
+        if (!memoKey.empty())
+            hiprt::MemoStore(src, std::move(memoKey), tmp);
         m_d = std::move(tmp);
         hiprt::CountDevice();
         DeviceIsNewer(Format::EVALUATION);

@@ -51,6 +51,10 @@ struct Api {
     decltype(&fhe_automorph) automorph;
     decltype(&fhe_switch_modulus) switch_modulus;
     decltype(&fhe_rescale_limbs) rescale_limbs;
+    decltype(&fhe_rescale_limbs_pair) rescale_limbs_pair;
+    decltype(&fhe_add_pair) add_pair;
+    decltype(&fhe_sub_pair) sub_pair;
+    decltype(&fhe_mul_const_pair) mul_const_pair;
     decltype(&fhe_rescale_workspace_bytes) rescale_workspace_bytes;
     decltype(&fhe_conv_create_custom) conv_create_custom;
     decltype(&fhe_conv_destroy) conv_destroy;
@@ -115,9 +119,20 @@ struct DevBuf {
     std::mutex mu;
     Use writer{0, 0};
     std::vector<Use> readers;
+    // Results of pure members applied to these words (same member, same tables, same words -> same words), kept while several towers
+    // share the buffer (clones): pke's weighted sums rescale a fresh clone of the same power T_i in every sum they form
+    // (ckksrns-advancedshe.cpp:143-193).  Dropped when the buffer is written (Op::W).
+    struct Memo {
+        std::vector<uint64_t> key;  // {member, limbs, context limbs..., table words...}
+        std::shared_ptr<DevBuf> result;
+    };
+    std::vector<Memo> memo;
     ~DevBuf();
 };
 using Buf = std::shared_ptr<DevBuf>;
+// the remembered result of `key` on src's words (nullptr: none); MemoStore keeps at most a few per buffer (whole buffers only, no windows)
+Buf MemoFind(const Buf& src, const std::vector<uint64_t>& key);
+void MemoStore(const Buf& src, std::vector<uint64_t> key, const Buf& result);
 Buf Alloc(size_t words);
 Buf View(const Buf& parent, size_t offsetWords, size_t words);
 // device memory owned by the caller (it must outlive every tower that adopts a window of it)

@@ -25,6 +25,7 @@ extern "C" int fhe_hal_available(void) __attribute__((weak));
 extern "C" void fhe_hal_trace_reset(void) __attribute__((weak));
 extern "C" size_t fhe_hal_member_stats(char* buf, size_t cap) __attribute__((weak));
 extern "C" size_t fhe_hal_launch_stats(char* buf, size_t cap, uint64_t* total) __attribute__((weak));
+extern "C" uint64_t fhe_hal_memo_hits() __attribute__((weak));
 static std::map<std::string, uint64_t> launches_by_kernel(uint64_t* total) {
     std::map<std::string, uint64_t> m;
     *total = 0;
@@ -581,6 +582,8 @@ int main(int argc, char** argv) {
             uint64_t cs[3];
             fhe_hal_composite_stats(cs);
             std::cout << "halcomposite calls " << cs[0] << " checksIdentical " << cs[1] << " checksDiffered " << cs[2] << std::endl;
+            if (fhe_hal_memo_hits)
+                std::cout << "halmemo hits " << fhe_hal_memo_hits() << std::endl;
         }
         std::cout << "hal: available " << (fhe_hal_available ? fhe_hal_available() : -1) << " deviceOps " << st[0] << " hostOps " << st[1]
                   << " h2dBytes " << st[2] << " d2hBytes " << st[3] << std::endl;

@@ -583,6 +583,47 @@ def test_rescale_limbs_with_the_callers_tables(backend, oracle, logN):
     ctx.close()
 
 
+@pytest.mark.parametrize("logN", [8, 12, 13, 17])
+def test_pair_entries_two_separately_allocated_towers_in_one_launch(backend, oracle, logN):
+    """fhe_add_pair / fhe_sub_pair / fhe_mul_const_pair / fhe_rescale_limbs_pair: the two elements of a ciphertext, each a buffer of
+    its own (allocated in both address orders), equal what the single-tower entries give element by element"""
+    o = oracle
+    rng = np.random.default_rng(29)
+    N, L = 1 << logN, 4
+    q, psiQ, _, _ = ckks_like_params(o, logN, L, 2)
+    ctx = fh.Context(backend, logN, q, psiQ)
+    qs = [int(v) for v in q[:L]]
+    mk = lambda: libs.rand_tower(rng, q[:L], N, 1)
+    ha0, ha1, hb0, hb1 = mk(), mk(), mk(), mk()
+    # (device addresses: a1 before a0 but b0 before b1, so the distances between the elements differ in sign across operands)
+    a1, a0, b0, b1 = ctx.tower(ha1), ctx.tower(ha0), ctx.tower(hb0), ctx.tower(hb1)
+    o0, o1 = fh.elem_pair(ctx, "add", a0, a1, b0, b1)
+    for got, x, y in ((o0, ha0, hb0), (o1, ha1, hb1)):
+        assert all(np.array_equal(got.to_host()[0, i], (x[0, i] + y[0, i]) % np.uint64(qs[i])) for i in range(L))
+    o0, o1 = fh.elem_pair(ctx, "sub", a0, a1, b0, b1)
+    for got, x, y in ((o0, ha0, hb0), (o1, ha1, hb1)):
+        assert all(np.array_equal(got.to_host()[0, i], (x[0, i] + (np.uint64(qs[i]) - y[0, i])) % np.uint64(qs[i])) for i in range(L))
+    k = [int(rng.integers(1, qi)) for qi in qs]
+    o0, o1 = fh.elem_pair(ctx, "mul_const", a0, a1, consts=k)
+    for got, x in ((o0, ha0), (o1, ha1)):
+        assert all(np.array_equal(got.to_host()[0, i].astype(object), (x[0, i].astype(object) * k[i]) % qs[i]) for i in range(L))
+    # rescale of both elements against the single-tower entry (itself checked against the oracle above)
+    inv = [pow(qs[-1] % qi, -1, qi) for qi in qs[:-1]]
+    neg = [(qi - v) % qi for v, qi in zip(inv, qs[:-1])]
+    r0, r1 = fh.rescale_limbs_pair(ctx, a0, a1, neg, inv)
+    assert np.array_equal(r0.to_host(), fh.rescale_limbs(ctx, a0, neg, inv).to_host())
+    assert np.array_equal(r1.to_host(), fh.rescale_limbs(ctx, a1, neg, inv).to_host())
+    octx = o.orc_ctx_create(N, L, q[:L], psiQ[:L])
+    want = np.empty((L - 1, N), np.uint64)
+    o.orc_drop_last_element_and_scale(octx, ha1[0], L, want)
+    assert np.array_equal(r1.to_host()[0], want)
+    o.orc_ctx_destroy(octx)
+    # in place: a += b on both elements
+    fh.elem_pair(ctx, "add", a0, a1, b0, b1, in_place=True)
+    assert all(np.array_equal(a1.to_host()[0, i], (ha1[0, i] + hb1[0, i]) % np.uint64(qs[i])) for i in range(L))
+    ctx.close()
+
+
 @pytest.mark.parametrize("logN,sizeQl,t,B,ev", [(4, 3, 65537, 2, 1), (10, 4, 786433, 2, 1), (12, 3, 65537, 1, 0), (13, 3, 2, 1, 1)])
 def test_mod_reduce(backend, oracle, logN, sizeQl, t, B, ev):
     """fhe_mod_reduce (DCRTPoly::ModReduce, BGV modulus switching) vs the oracle"""

@@ -16,7 +16,7 @@ def source_sha():  # the same identity bench.py computes: the kernel sources the
     return h.hexdigest()[:16]
 
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 os.makedirs("profiles", exist_ok=True)
 shutil.copy(f"gpurun_out/bench_{R}.json", f"profiles/{R}_bench.json")
 try:
@@ -51,5 +51,42 @@ for k, v in res.items():
                                   "total": v["FETCH_SIZE"] * 2048 + v["WRITE_SIZE"] * 1024,
                                   "algorithmic": 2 * 8 * 65536 * 30 * 1024}
 json.dump(out, open(f"profiles/{R}_pmc_traffic.json", "w"), indent=1)
+
+# SQ counters (one pass): VALU instructions per wave and the share of wave-cycles a VALU instruction was issuing, per kernel
+SQ = ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES", "SQ_WAVES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY")
+
+
+def short(name):
+    for k, v in names.items():
+        if "ntt_static_kernel" in name and k in name:
+            return f"{v} ({name.replace('void fhe::', '').split('(fhe::')[0]})"
+    return name.replace("void fhe::", "").split("(")[0]
+
+
+valu = {"_how": "rocprofv3 --kernel-trace --pmc " + " ".join(SQ) + " (one pass, 8 SQ slots) on `python bench.py --steps 2 --warmup 1 ...` (NTT leg: "
+                "N=2^16, L=30, B=1024) and on the EvalMult leg at batch 256 (tools/gpu_record.sh). SQ_*_CYCLES and SQ_ACTIVE_INST_* count "
+                "quad-cycles per wave (MI355X_MICROARCH.md); values are averages per launch.",
+        "kernel_source_sha": out["kernel_source_sha"], "legs": {}}
+for leg in ("ntt", "evalmult"):
+    try:
+        f = newest(f"gpurun_out/pmc_{R}_sq_{leg}/*/*counter_collection.csv")
+    except ValueError:
+        continue
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        per[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    legd = {}
+    for k, c in per.items():
+        avg = {n: sum(v) / len(v) for n, v in c.items()}
+        wc, waves = avg.get("SQ_WAVE_CYCLES", 0), avg.get("SQ_WAVES", 0)
+        if not wc or not waves:
+            continue
+        legd[k] = {"launches": len(c["SQ_WAVES"]), "waves": waves, "valu_instructions_per_wave": round(avg["SQ_INSTS_VALU"] / waves, 1),
+                   "active_valu_over_wave_cycles": round(avg["SQ_ACTIVE_INST_VALU"] / wc, 4),
+                   "wait_inst_any_over_wave_cycles": round(avg["SQ_WAIT_INST_ANY"] / wc, 4), "wait_any_over_wave_cycles": round(avg["SQ_WAIT_ANY"] / wc, 4),
+                   "active_any_over_wave_cycles": round(avg["SQ_ACTIVE_INST_ANY"] / wc, 4), "sq_busy_cycles": avg["SQ_BUSY_CYCLES"], "wave_cycles": wc}
+    valu["legs"][leg] = legd
+if valu["legs"]:
+    json.dump(valu, open(f"profiles/{R}_pmc_valu.json", "w"), indent=1)
 b = json.load(open(f"profiles/{R}_bench.json"))
 print(json.dumps({k: b[k] for k in ("value", "ms_per_step", "hbm_roofline_frac_fwd_inv", "roofline", "cpu_baseline", "evalmult")}, indent=1))

@@ -1,8 +1,9 @@
 #!/bin/bash
 # Round record on the GPU box: GPU tests, the bench line exactly as the driver runs it, rocprofv3 kernel stats of the same
-# command (whole bench, headline NTT leg alone, EvalMult leg alone) and the PMC traffic passes of the headline leg.
-#   usage: gpurun --timeout 1500 -- tools/gpu_record.sh [tag] [notests]      (tag = r02 ...; then tools/collect_profiles.py tag)
-R=${1:-r02}
+# command (whole bench, headline NTT leg alone, EvalMult leg alone), the PMC traffic passes of the headline leg (FETCH_SIZE, WRITE_SIZE, one
+# pass each) and one pass of SQ counters (VALU issue) over the headline and the EvalMult leg.
+#   usage: gpurun --timeout 1500 -- tools/gpu_record.sh [tag] [notests]      (tag = r03 ...; then tools/collect_profiles.py tag)
+R=${1:-r03}
 mkdir -p gpurun_out
 if [ "$2" != "notests" ]; then
   echo "== gpu tests"; timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
@@ -20,6 +21,9 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $G/gpurun_ou
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $G/gpurun_out/pmc_${R}_$c -- python $G/bench.py --no-bootstrap --no-cc-evalmult --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-evalmult --no-bfv --no-hadamard --no-lt > $G/gpurun_out/pmc_${R}_$c.log 2>&1
 done
+SQ="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_WAVES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY"
+timeout 600 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $G/gpurun_out/pmc_${R}_sq_ntt -- python $G/bench.py --no-bootstrap --no-cc-evalmult --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-evalmult --no-bfv --no-hadamard --no-lt > $G/gpurun_out/pmc_${R}_sq_ntt.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $G/gpurun_out/pmc_${R}_sq_evalmult -- python $G/bench.py --no-bootstrap --no-cc-evalmult --batch 8 --steps 1 --warmup 0 --no-cpu-baseline --no-parity --no-bfv --no-hadamard --no-lt > $G/gpurun_out/pmc_${R}_sq_evalmult.log 2>&1
 cd $G
 f=$(ls -t gpurun_out/prof_${R}_ntt/*/*kernel_stats.csv | head -1); head -8 $f | cut -c1-170
 f=$(ls -t gpurun_out/prof_${R}_evalmult/*/*kernel_stats.csv | head -1); head -12 $f | cut -c1-170
