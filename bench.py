@@ -769,7 +769,9 @@ def cc_evalmult_leg(with_cpu, libpath):
         return (float(m.group(1)) if p.returncode == 0 and m else None), (p.stdout + p.stderr)[-400:]
 
     hipenv = {"FHE_HIP_LIB": libpath}
-    rate, txt = run(hip, os.path.join(tmp, "h256.bin"), 256, 3, 8, hipenv)
+    # (10 timed passes after the warm-up pass: ~0.5 s, so that the clocks of a device that idled through key generation have ramped up;
+    # 5 passes of 64 ciphertexts — 60 ms — measured anything between 2.1 k and 5.1 k/s for one binary, profiles/r03_sweeps.md session i)
+    rate, txt = run(hip, os.path.join(tmp, "h256.bin"), 256, 10, 8, hipenv)
     if rate is None:
         shutil.rmtree(tmp, ignore_errors=True)
         return {"error": txt}

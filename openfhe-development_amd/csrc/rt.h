@@ -15,6 +15,7 @@ namespace rt {
 struct LaunchSite {
     const char* kernel;
     std::atomic<uint64_t> n{0};
+    bool emuLaneThreads = false;  // (lane emulator only: the site's kernel meets barriers, tests/emu/emu_runtime.h)
     LaunchSite* next;
     static std::atomic<LaunchSite*>& head() {
         static std::atomic<LaunchSite*> h{nullptr};
@@ -106,7 +107,8 @@ struct Timer {
 #define FHE_LAUNCH(kernel, grid, stream, ...)                                              \
     do {                                                                                   \
         FHE_COUNT_LAUNCH(kernel);                                                          \
-        fhe_emu::launch((uint32_t)(grid), fhe::kThreads, [=]() { kernel(__VA_ARGS__); }); \
+        fhe_emu::launch((uint32_t)(grid), fhe::kThreads, [=]() { kernel(__VA_ARGS__); },  \
+                        &fhe_launch_site_.emuLaneThreads);                                 \
     } while (0)
 #else
 #include <hip/hip_runtime.h>

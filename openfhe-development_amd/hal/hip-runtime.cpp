@@ -53,6 +53,12 @@ struct StreamState {
     bool made = false;
     std::atomic<uint64_t> issued{0};    // operations started by the owning thread
     std::atomic<uint64_t> enqueued{0};  // ... whose launches have all been enqueued (published by the outermost Op)
+    // buffers released by OTHER threads whose pending uses are all on this stream: the owning thread reuses them without any
+    // cross-stream wait (its later launches follow its earlier ones anyway)
+    std::atomic<bool> owned{false};
+    std::atomic<uint32_t> inboxCount{0};
+    std::mutex inboxMutex;
+    std::vector<std::pair<size_t, uint64_t*>> inbox;  // {bucket, pointer}
 };
 struct Runtime {
     Api api{};
@@ -230,6 +236,20 @@ struct ThreadState {
             st.made = true;
         }
         waited.assign(kMaxStreams, 0);
+        st.owned.store(true);
+    }
+    void TakeInbox() {
+        StreamState& st = rt().streams[id];
+        if (st.inboxCount.load(std::memory_order_acquire) == 0)
+            return;
+        std::vector<std::pair<size_t, uint64_t*>> in;
+        {
+            std::lock_guard<std::mutex> lk(st.inboxMutex);
+            in.swap(st.inbox);
+            st.inboxCount.store(0, std::memory_order_release);
+        }
+        for (auto& e : in)
+            freeLists[e.first].push_back(e.second);
     }
     ~ThreadState() {
         if (g_exiting.load())
@@ -237,7 +257,9 @@ struct ThreadState {
         // the thread ends: drain its stream, hand its cached buffers to the shared lists (nothing is pending on them any more)
         // and let a later thread reuse the stream (the sequence counters keep counting: old stamps stay "enqueued")
         Runtime& r = rt();
+        r.streams[id].owned.store(false);
         r.api.sync(r.anyCtx, r.streams[id].s);
+        TakeInbox();
         {
             std::lock_guard<std::mutex> lk(r.poolMutex);
             for (auto& kv : freeLists)
@@ -405,6 +427,33 @@ DevBuf::~DevBuf() {
         r.orphanLists[bucket_of(words)].push_back(p);
         return;
     }
+    // Pending uses all on ONE other thread's stream (a result computed by thread A and dropped by thread B: pke's loops over
+    // ciphertexts with dynamic schedules): the buffer goes back to that thread.  Ordering this thread's stream behind them instead
+    // would make it wait for everything the other stream has enqueued so far — streams of a batch then run in lock step.
+    static const bool toOwner = !(std::getenv("FHE_HAL_FREE_TO_OWNER") && std::string(std::getenv("FHE_HAL_FREE_TO_OWNER")) == "0");
+    uint32_t owner = writer.stream;
+    bool single    = owner != 0;
+    for (const auto& u : readers) {
+        if (owner == 0)
+            owner = u.stream, single = owner != 0;
+        else if (u.stream != owner)
+            single = false;
+    }
+    if (toOwner && single && owner != ts->id) {
+        const uint64_t last = std::max(writer.stream == owner ? writer.seq : 0, [&] {
+            uint64_t m = 0;
+            for (const auto& u : readers)
+                m = std::max(m, u.seq);
+            return m;
+        }());
+        StreamState& st = r.streams[owner];
+        if (last > ts->waited[owner] && st.owned.load()) {
+            std::lock_guard<std::mutex> lk(st.inboxMutex);
+            st.inbox.emplace_back(bucket_of(words), p);
+            st.inboxCount.fetch_add(1, std::memory_order_release);
+            return;
+        }
+    }
     // the buffer joins THIS thread's free lists: whatever this thread launches later is ordered behind the buffer's pending uses
     order_after(ts, writer);
     for (const auto& u : readers)
@@ -418,6 +467,7 @@ Buf Alloc(size_t words) {
     auto b          = std::make_shared<DevBuf>();
     b->words        = words;
     if (ts) {
+        ts->TakeInbox();
         auto& fl = ts->freeLists[bk];
         if (!fl.empty()) {
             b->p = fl.back();

@@ -53,20 +53,49 @@ Pool& pool() {
 std::mutex launchMutex;
 }  // namespace
 
-void block_sync() { pthread_barrier_wait(&pool().sync); }
+namespace {
+struct MetBarrier {};
+}  // namespace
+void block_sync() {
+    if (tls.sequential)
+        throw MetBarrier{};
+    pthread_barrier_wait(&pool().sync);
+}
 void* block_shared(size_t bytes) {
     if (bytes > sizeof(pool().shared))
         std::abort();
     return pool().shared;
 }
-void launch(uint32_t grid, uint32_t threads, const std::function<void()>& body) {
+void launch(uint32_t grid, uint32_t threads, const std::function<void()>& body, bool* needsLaneThreads) {
     if (threads != kLanes)
         std::abort();
+    uint32_t first = 0;
+    if (needsLaneThreads && !*needsLaneThreads) {
+        // lanes one after the other on this thread; the first barrier (lane 0 of the first block, before it stored anything) ends the attempt
+        const Tls saved = tls;
+        try {
+            tls.sequential = true;
+            tls.nblk       = grid;
+            for (uint32_t b = 0; b < grid; ++b)
+                for (uint32_t t = 0; t < kLanes; ++t) {
+                    tls.bid = b, tls.tid = t;
+                    body();
+                }
+            tls = saved;
+            return;
+        }
+        catch (const MetBarrier&) {
+            if (tls.bid != 0 || tls.tid != 0)
+                std::abort();  // (a kernel whose lanes reach barriers data-dependently: not a kernel of this library)
+            tls               = saved;
+            *needsLaneThreads = true;
+        }
+    }
     std::lock_guard<std::mutex> lk(launchMutex);
     Pool& p = pool();
     p.body  = &body;
     p.nblk  = grid;
-    for (uint32_t b = 0; b < grid; ++b) {
+    for (uint32_t b = first; b < grid; ++b) {
         p.bid = b;
         pthread_barrier_wait(&p.start);
         pthread_barrier_wait(&p.stop);

@@ -587,6 +587,8 @@ def test_rescale_limbs_with_the_callers_tables(backend, oracle, logN):
 def test_pair_entries_two_separately_allocated_towers_in_one_launch(backend, oracle, logN):
     """fhe_add_pair / fhe_sub_pair / fhe_mul_const_pair / fhe_rescale_limbs_pair: the two elements of a ciphertext, each a buffer of
     its own (allocated in both address orders), equal what the single-tower entries give element by element"""
+    if logN == 17 and "emulator" in backend.version():
+        pytest.skip("the 5-stage column pass with separately allocated towers is covered on the GPU; N = 2^13 covers the emulator")
     o = oracle
     rng = np.random.default_rng(29)
     N, L = 1 << logN, 4
