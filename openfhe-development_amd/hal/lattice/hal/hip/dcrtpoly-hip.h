@@ -102,8 +102,13 @@ public:
             hiprt::CountHost("ModRaise", params->GetRingDimension());
         }
     }
+    // dcrtpoly-impl.h:96-107: every limb is rhs, brought to the limb's modulus (SwitchModulus) — the ModRaise constructor's loop.  One
+    // limb crosses PCIe instead of the whole tower (MultByMonomialInPlace builds its monomial this way in every bootstrap).
     DCRTPolyType& operator=(const PolyType& rhs) {
         FHE_HAL_MEMBER();
+        const auto P = m_h.GetParams();
+        if (P && m_h.GetFormat() == Format::COEFFICIENT && rhs.GetFormat() == Format::COEFFICIENT && ModRaiseOnDevice(rhs, P))
+            return *this;
         Hm(__func__, true) = rhs;
         return *this;
     }
@@ -1959,6 +1964,7 @@ private:
         m_h         = HostType(params, Format::COEFFICIENT, false);
         m_d         = std::move(d);
         m_hostValid = false;
+        m_zero      = false;
         return true;
     }
 };
