@@ -254,17 +254,19 @@ struct ThreadState {
     ~ThreadState() {
         if (g_exiting.load())
             return;
-        // the thread ends: drain its stream, hand its cached buffers to the shared lists (nothing is pending on them any more)
-        // and let a later thread reuse the stream (the sequence counters keep counting: old stamps stay "enqueued")
-        Runtime& r = rt();
-        r.streams[id].owned.store(false);
-        r.api.sync(r.anyCtx, r.streams[id].s);
-        TakeInbox();
+        // The thread ends.  No call into the HIP runtime from here (thread-local destructors run when tools layered under the runtime —
+        // rocprofv3's per-thread state — may already be gone): the cached buffers stay with the STREAM, parked in its inbox, and the
+        // next thread that takes the stream over (ids are reused last-in first-out; the sequence counters keep counting, so old
+        // stamps stay "enqueued") finds them there — whatever is still pending on them precedes that thread's launches on the same stream.
+        Runtime& r      = rt();
+        StreamState& st = r.streams[id];
+        st.owned.store(false);
         {
-            std::lock_guard<std::mutex> lk(r.poolMutex);
+            std::lock_guard<std::mutex> lk(st.inboxMutex);
             for (auto& kv : freeLists)
                 for (uint64_t* p : kv.second)
-                    r.orphanLists[kv.first].push_back(p);
+                    st.inbox.emplace_back(kv.first, p);
+            st.inboxCount.store((uint32_t)st.inbox.size(), std::memory_order_release);
         }
         std::lock_guard<std::mutex> lk(r.streamMutex);
         r.freeStreamIds.push_back(id);
@@ -495,11 +497,27 @@ Buf Alloc(size_t words) {
                 kv.second.clear();
             }
         }
-        std::lock_guard<std::mutex> lk(r.poolMutex);
-        for (auto& kv : r.orphanLists) {
-            for (uint64_t* q : kv.second)
-                r.api.free_(r.anyCtx, q);
-            kv.second.clear();
+        {
+            std::lock_guard<std::mutex> lk(r.poolMutex);
+            for (auto& kv : r.orphanLists) {
+                for (uint64_t* q : kv.second)
+                    r.api.free_(r.anyCtx, q);
+                kv.second.clear();
+            }
+        }
+        for (uint32_t i = 1; i < r.nextStreamId; ++i) {  // what exited threads left parked with their streams
+            StreamState& st = r.streams[i];
+            if (st.owned.load() || st.inboxCount.load() == 0)
+                continue;
+            std::vector<std::pair<size_t, uint64_t*>> in;
+            {
+                std::lock_guard<std::mutex> lk(st.inboxMutex);
+                in.swap(st.inbox);
+                st.inboxCount.store(0);
+            }
+            r.api.sync(r.anyCtx, st.s);
+            for (auto& e : in)
+                r.api.free_(r.anyCtx, e.second);
         }
         s = r.api.malloc_(r.anyCtx, bk * 8, &d);
     }

@@ -162,7 +162,9 @@ public:
     // dcrtpoly-impl.h:207-214
     DCRTPolyType CloneTowers(uint32_t startTower, uint32_t endTower) const {
         FHE_HAL_MEMBER();
-        if (endTower < NumLimbs() && startTower <= endTower && DeviceWords()) {
+        // (words that exist on the host only — a secret key's towers as the sampler produced them — are cloned where they are: an upload
+        // here was read back limb by limb by key generation, 0.85 GB of PCIe over the reference's unit tests)
+        if (m_d && !m_hostValid && endTower < NumLimbs() && startTower <= endTower) {
             const auto& P = m_h.GetParams();
             auto params   = std::make_shared<Params>(P->GetCyclotomicOrder(), P->GetParamPartition(startTower, endTower));
             const size_t N = P->GetRingDimension(), n = endTower - startTower + 1;
@@ -171,6 +173,10 @@ public:
             hiprt::D2D(op, op.W(d), op.R(m_d) + (size_t)startTower * N, n * N * 8, "CloneTowers");
             hiprt::CountDevice();
             return FromDevice(params, m_h.GetFormat(), std::move(d));
+        }
+        if (!m_d && m_hostValid) {
+            hiprt::CountHost(__func__, RingOf(m_h), /*hostData=*/true);
+            return DCRTPolyType(m_h.CloneTowers(startTower, endTower));
         }
         return Wrap(Hc().CloneTowers(startTower, endTower));
     }
