@@ -1104,31 +1104,9 @@ def main():
         ltr = linear_transform_leg(lib, device, (1, 8), max(10, a.steps), 3, rank == 0 and not a.no_cpu_baseline,
                                    parity=not a.no_parity)
 
-    boot = None
-    if not a.no_bootstrap and logN == 16 and not os.environ.get("FHE_HIP_LIB", "").endswith("libfhe_emu.so"):
-        try:  # every rank takes part: the batch is sharded, the key set travels from rank 0
-            boot = bootstrap_batch_leg(a.bootstrap_logn, a.bootstrap_batch, a.bootstrap_threads, rank, world, device, dist, tdev,
-                                       not a.no_cpu_baseline, lib.path)
-        except Exception as e:  # the leg is an extra: never takes the headline line down
-            boot = {"error": f"{type(e).__name__}: {e}"}
-            if dist is not None:
-                try:
-                    dist.barrier()
-                except Exception:
-                    pass
-
-    ccm = None
-    if rank == 0 and world == 1 and not a.no_cc_evalmult and logN == 16 and not os.environ.get("FHE_HIP_LIB", "").endswith("libfhe_emu.so"):
-        try:
-            ccm = cc_evalmult_leg(not a.no_cpu_baseline, lib.path)
-        except Exception as e:
-            ccm = {"error": f"{type(e).__name__}: {e}"}
-
-    cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(q, psi, logN, L, a.cpu_seconds)
-
-    if rank == 0:
+    def emit(boot, ccm, cpu):
+        if rank != 0:
+            return
         out = {
             "metric": "NTT GB/s vs HBM roofline + CKKS EvalMultKeySwitch/sec, N=2^16 L=30, 1/2/4/8 GPU",
             "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -1158,7 +1136,44 @@ def main():
             out["evalbootstrap"] = boot
         if ccm is not None:
             out["cryptocontext_evalmult"] = ccm
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+
+    boot = None
+    if not a.no_bootstrap and logN == 16 and not os.environ.get("FHE_HIP_LIB", "").endswith("libfhe_emu.so"):
+        # The leg is an extra with collectives of its own (the key set travels from rank 0): a rank that fails or stalls inside it must
+        # not take the headline line down.  With several ranks a watchdog on every rank ends the process after the limit — rank 0 prints the
+        # line (without the leg's figures) first.
+        import threading
+        limit = float(os.environ.get("FHE_BENCH_BOOTSTRAP_LIMIT_S", "480"))
+
+        def give_up():
+            emit({"error": f"the sharded bootstrap leg did not finish within {limit:.0f} s on {world} ranks: line printed without it"}, None, None)
+            os._exit(0)
+
+        dog = threading.Timer(limit, give_up) if world > 1 else None
+        if dog is not None:
+            dog.daemon = True
+            dog.start()
+        try:  # every rank takes part: the batch is sharded, the key set travels from rank 0
+            boot = bootstrap_batch_leg(a.bootstrap_logn, a.bootstrap_batch, a.bootstrap_threads, rank, world, device, dist, tdev,
+                                       not a.no_cpu_baseline, lib.path)
+        except Exception as e:
+            boot = {"error": f"{type(e).__name__}: {e}"}
+        if dog is not None:
+            dog.cancel()
+
+    ccm = None
+    if rank == 0 and world == 1 and not a.no_cc_evalmult and logN == 16 and not os.environ.get("FHE_HIP_LIB", "").endswith("libfhe_emu.so"):
+        try:
+            ccm = cc_evalmult_leg(not a.no_cpu_baseline, lib.path)
+        except Exception as e:
+            ccm = {"error": f"{type(e).__name__}: {e}"}
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(q, psi, logN, L, a.cpu_seconds)
+
+    emit(boot, ccm, cpu)
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
