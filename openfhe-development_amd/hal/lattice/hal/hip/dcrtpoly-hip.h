@@ -29,6 +29,7 @@
 #define LBCRYPTO_INC_LATTICE_HAL_HIP_DCRTPOLY_HIP_H
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -107,7 +108,8 @@ public:
     DCRTPolyType& operator=(const PolyType& rhs) {
         FHE_HAL_MEMBER();
         const auto P = m_h.GetParams();
-        if (P && m_h.GetFormat() == Format::COEFFICIENT && rhs.GetFormat() == Format::COEFFICIENT && ModRaiseOnDevice(rhs, P))
+        static const bool onHost = std::getenv("FHE_HAL_ASSIGN_ON_HOST") != nullptr;  // (A/B switch of session l)
+        if (!onHost && P && m_h.GetFormat() == Format::COEFFICIENT && rhs.GetFormat() == Format::COEFFICIENT && ModRaiseOnDevice(rhs, P))
             return *this;
         Hm(__func__, true) = rhs;
         return *this;
