@@ -137,6 +137,46 @@ int main(int argc, char** argv) {
         show("rot", cc, kp.secretKey, rot2, 8);
         show("final", cc, kp.secretKey, d, 8);
     }
+    else if (mode == "memo") {
+        // Results of DropLastElementAndScale / Times(constants) are remembered per device buffer while clones share it (DevBuf::memo):
+        // a second clone takes the remembered result, and a write to the source's words must drop it.
+        CCParams<CryptoContextCKKSRNS> p;
+        p.SetSecurityLevel(HEStd_NotSet);
+        p.SetRingDim(1u << logN);
+        p.SetMultiplicativeDepth(3);
+        p.SetScalingModSize(50);
+        p.SetFirstModSize(60);
+        p.SetKeySwitchTechnique(HYBRID);
+        p.SetScalingTechnique(FIXEDMANUAL);
+        auto cc = GenCryptoContext(p);
+        cc->Enable(PKE);
+        cc->Enable(KEYSWITCH);
+        cc->Enable(LEVELEDSHE);
+        auto kp = cc->KeyGen();
+        cc->EvalMultKeyGen(kp.secretKey);
+        std::vector<double> x = {0.25, 0.5, 0.75, 1.0, 2.0, 3.0, 0.4, 0.5};
+        auto cx = cc->Encrypt(kp.publicKey, cc->MakeCKKSPackedPlaintext(x));
+        evaluation_phase_begins();
+        auto t = cc->EvalMult(cx, cx);
+        auto a = t->Clone();
+        cc->RescaleInPlace(a);  // computed, remembered on t's buffers (shared with the clone)
+        auto b = t->Clone();
+        cc->RescaleInPlace(b);  // the remembered result
+        const uint64_t hits1 = fhe_hal_memo_hits ? fhe_hal_memo_hits() : 0;
+        cc->EvalAddInPlace(t, t);  // t's words change in place (no clone shares them any more): what was remembered is history
+        auto c = t->Clone();
+        cc->RescaleInPlace(c);  // must be rescale(2 x*x), not the result remembered for x*x
+        auto e = cc->EvalMult(t->Clone(), 0.5);  // Times(constants) on a clone ...
+        auto f = cc->EvalMult(t->Clone(), 0.5);  // ... and its remembered result
+        dump("a", a);
+        dump("b", b);
+        dump("c", c);
+        dump("e", e);
+        dump("f", f);
+        show("a", cc, kp.secretKey, a, 8);
+        show("c", cc, kp.secretKey, c, 8);
+        std::cout << "memo hits after the second clone " << hits1 << " at the end " << (fhe_hal_memo_hits ? fhe_hal_memo_hits() : 0) << std::endl;
+    }
     else if (mode == "bfv") {
         // BFV (BASELINE configs[4]): EvalMult in each of the reference's multiplication techniques (bfvrns-leveledshe.cpp:198-445:
         // BEHZ = FastBaseConvqToBskMontgomery / FastRNSFloorq / FastBaseConvSK; HPS* = ExpandCRTBasis, FastExpandCRTBasisPloverQ,

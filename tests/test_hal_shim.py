@@ -160,6 +160,31 @@ def test_shim_bootstrap_matches_default_backend_on_gpu(tmp_path):
     assert ops > 500  # ModRaise, the CoeffsToSlots / SlotsToCoeffs transforms and the Chebyshev evaluation ran on the device
 
 
+def memo_check(tmp_path, logN, device_lib):
+    ensure_built()
+    so, sh = str(tmp_path / "stock.bin"), str(tmp_path / "hip.bin")
+    out_stock = run(PROGS[0], so, "memo", logN)
+    out_hip = run(PROGS[1], sh, "memo", logN, device_lib)
+    a, b = open(so, "rb").read(), open(sh, "rb").read()
+    assert len(a) > 1000 and a == b, "a remembered result differs from the default backend's recomputation"
+    m = re.search(r"memo hits after the second clone (\d+) at the end (\d+)", out_hip)
+    # both elements of the second clone's rescale were remembered results; the rescale after the in-place addition must NOT be one (the
+    # byte comparison above is what proves it was recomputed: no further hits)
+    assert m and int(m.group(1)) == 2 and int(m.group(2)) == 2, out_hip[-400:]
+    xx = [v * v for v in X]
+    assert all(abs(g - w) < 1e-3 for g, w in zip(values(out_hip, "a"), xx))
+    assert all(abs(g - 2 * w) < 1e-3 for g, w in zip(values(out_hip, "c"), xx))
+
+
+def test_remembered_results_are_dropped_when_the_words_change_on_emulator(tmp_path):
+    memo_check(tmp_path, 10, EMU)
+
+
+@pytest.mark.gpu
+def test_remembered_results_are_dropped_when_the_words_change_on_gpu(tmp_path):
+    memo_check(tmp_path, 13, HIP)
+
+
 # BFV (BASELINE configs[4]) through the reference's CryptoContext, every multiplication technique of bfvrns-leveledshe.cpp:198-445:
 # the BEHZ trio, ExpandCRTBasis, FastExpandCRTBasisPloverQ, ScaleAndRound, SwitchCRTBasis, ExpandCRTBasisQlHat as device members
 @pytest.mark.parametrize("tech", ["BEHZ", "HPSPOVERQ", "HPS", "HPSPOVERQLEVELED"])
