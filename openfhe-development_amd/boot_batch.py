@@ -36,6 +36,8 @@ class BootBatch:
         L.fbb_export_keys.argtypes = [vp, vp]
         L.fbb_adopt_keys.argtypes = [vp, vp]
         L.fbb_bootstrap_all.restype, L.fbb_bootstrap_all.argtypes = C.c_double, [vp, C.c_int, C.c_int, C.c_int]
+        if hasattr(L, "fbb_bootstrap_wide"):
+            L.fbb_bootstrap_wide.restype, L.fbb_bootstrap_wide.argtypes = C.c_double, [vp, u32, C.c_int]
         L.fbb_check.restype, L.fbb_check.argtypes = C.c_double, [vp, u32, C.POINTER(C.c_double)]
         L.fbb_dump.argtypes = [vp, C.c_char_p, u32, u32]
         self.h = L.fbb_create(logN, slots, budget[0], budget[1], levels_after, prng.encode() if prng else None, device)
@@ -87,6 +89,13 @@ class BootBatch:
 
     def bootstrap_all(self, threads, reps, warmup=1):
         s = self.L.fbb_bootstrap_all(self.h, threads, reps, warmup)
+        self._ok(0 if s >= 0 else 1)
+        return s
+
+    def bootstrap_wide(self, group, reps):
+        """the rank's ciphertexts in lockstep, `group` per wide evaluation (0 = all): one cc->EvalBootstrap on a ciphertext whose towers hold
+        `group` towers each (hal/bootstrap_batch.cpp fbb_bootstrap_wide); one narrow pass must have run before.  Seconds per pass."""
+        s = self.L.fbb_bootstrap_wide(self.h, group, reps)
         self._ok(0 if s >= 0 else 1)
         return s
 

@@ -275,6 +275,68 @@ double fbb_bootstrap_all(void* h, int threads, int reps, int warmup) {
     });
     return sec;
 }
+// The rank's ciphertexts bootstrapped in LOCKSTEP: pke's control flow depends on parameters and metadata only, so the K ciphertexts
+// (equal metadata: fresh encryptions at one level) are packed into ONE ciphertext whose towers hold K towers each and cc->EvalBootstrap
+// runs once — every launch works on K towers, every evaluation key is read once for all of them.  `group` ciphertexts per wide
+// evaluation (0 = all of the rank's); one narrow bootstrap must have run before (fbb_bootstrap_all with a warm-up pass: the composites
+// are checked against the member-by-member path at their first use, which is a narrow evaluation).  Seconds per pass over all ciphertexts.
+double fbb_bootstrap_wide(void* h, uint32_t group, int reps) {
+    auto* b    = static_cast<Batch*>(h);
+    double sec = -1;
+#ifdef WITH_HIP
+    Guard(b, [&] {
+        const uint32_t n = (uint32_t)b->in.size();
+        if (group == 0 || group > n)
+            group = n;
+        b->out.assign(n, nullptr);
+        auto pass = [&] {
+            for (uint32_t first = 0; first < n; first += group) {
+                const uint32_t k = std::min(group, n - first);
+                const auto& c0   = b->in[first];
+                auto wide        = c0->CloneEmpty();
+                std::vector<DCRTPoly> elements;
+                for (size_t e = 0; e < c0->GetElements().size(); ++e) {
+                    std::vector<const DCRTPoly*> towers;
+                    for (uint32_t i = 0; i < k; ++i) {
+                        const auto& ci = b->in[first + i];
+                        if (ci->GetLevel() != c0->GetLevel() || ci->GetNoiseScaleDeg() != c0->GetNoiseScaleDeg() ||
+                            ci->GetScalingFactor() != c0->GetScalingFactor() || ci->GetSlots() != c0->GetSlots() ||
+                            ci->GetElements().size() != c0->GetElements().size())
+                            OPENFHE_THROW("fbb_bootstrap_wide: the ciphertexts of a group must have equal metadata");
+                        towers.push_back(&ci->GetElements()[e]);
+                    }
+                    elements.push_back(DCRTPoly::PackWide(towers));
+                }
+                wide->SetElements(std::move(elements));
+                Ciphertext<DCRTPoly> res;
+                {
+                    hiprt::WidthScope scope(k);  // (towers pke creates on the way — accumulators — are k wide)
+                    res = b->cc->EvalBootstrap(wide);
+                }
+                for (uint32_t i = 0; i < k; ++i) {
+                    auto one = res->CloneEmpty();
+                    std::vector<DCRTPoly> el;
+                    for (const auto& t : res->GetElements())
+                        el.push_back(t.UnpackTower(i));
+                    one->SetElements(std::move(el));
+                    b->out[first + i] = one;
+                }
+            }
+            for (uint32_t i = 0; i < n; ++i)  // drain the device queue (one limb of every result comes to the host)
+                (void)b->out[i]->GetElements()[0].GetElementAtIndex(0);
+        };
+        pass();
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < reps; ++r)
+            pass();
+        sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / std::max(1, reps);
+    });
+#else
+    (void)group, (void)reps;
+    b->error = "fbb_bootstrap_wide: the stock backend has no wide towers";
+#endif
+    return sec;
+}
 // decrypts output i of the rank's slice: the first 8 slots into vals; returns the largest absolute error against the message
 double fbb_check(void* h, uint32_t i, double* vals) {
     auto* b = static_cast<Batch*>(h);

@@ -386,6 +386,10 @@ uint64_t* Op::W(const Buf& b) {
     return b->p;
 }
 std::atomic<uint64_t> g_memoHits{0};
+static thread_local uint32_t t_width = 1;
+uint32_t ThreadWidth() { return t_width; }
+WidthScope::WidthScope(uint32_t k) : saved(t_width) { t_width = k ? k : 1; }
+WidthScope::~WidthScope() { t_width = saved; }
 Buf MemoFind(const Buf& src, const std::vector<uint64_t>& key) {
     if (!src || src->parent)
         return nullptr;

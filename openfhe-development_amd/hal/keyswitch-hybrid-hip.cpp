@@ -277,6 +277,9 @@ bool KeyBuffers(const EvalKey<DCRTPoly>& evalKey, size_t numPartQ, size_t limbs,
 // acc0 += ks0(c), acc1 += ks1(c) in one call; false: the composite cannot take these towers
 bool CompositeKeySwitchAcc(hiprt::KsDomain& dom, uint32_t sizeQl, const std::vector<hiprt::Buf>& kb, const std::vector<hiprt::Buf>& ka, DCRTPoly& acc0,
                            DCRTPoly& acc1, const DCRTPoly& c) {
+    const uint32_t width = c.Width();  // (a wide ciphertext: its K towers are the composite's batch)
+    if (acc0.Width() != width || acc1.Width() != width)
+        return false;
     auto b0 = acc0.DeviceWordsForUpdate(), b1 = acc1.DeviceWordsForUpdate();
     auto bc = c.DeviceWords();
     if (!b0 || !b1 || !bc)
@@ -286,14 +289,19 @@ bool CompositeKeySwitchAcc(hiprt::KsDomain& dom, uint32_t sizeQl, const std::vec
     hiprt::PackedKey pk = hiprt::DomainKey(dom, kb, ka, op);
     if (!pk.key)
         return false;
-    const size_t wsB = A.ks_workspace_bytes(hiprt::DomainPlan(dom), sizeQl, 1);
+    const size_t wsB = A.ks_workspace_bytes(hiprt::DomainPlan(dom), sizeQl, width);
     auto ws          = hiprt::Alloc(wsB / 8 + 1);
     op.R(pk.b), op.R(pk.a);
-    hiprt::Check(A.keyswitch_hybrid_acc(hiprt::DomainPlan(dom), pk.key.get(), op.R(bc), sizeQl, 1, op.W(b0), op.W(b1), op.W(ws), wsB, op.s),
+    hiprt::Check(A.keyswitch_hybrid_acc(hiprt::DomainPlan(dom), pk.key.get(), op.R(bc), sizeQl, width, op.W(b0), op.W(b1), op.W(ws), wsB, op.s),
                  "EvalMult: composite key switch");
     hiprt::CountDevice("EvalMult.KeySwitchAccumulate");
     hiprt::CountComposite();
     return true;
+}
+[[noreturn]] void WideNeedsCheckedComposite(const char* what) {
+    OPENFHE_THROW(std::string("HIP backend: a wide evaluation (several ciphertexts in lockstep) reached ") + what +
+                  " at a level whose composite has not been checked against the member-by-member path yet: evaluate one ciphertext of the "
+                  "same shape on its own first");
 }
 // cv[0] += ks0(cv[2]); cv[1] += ks1(cv[2])  (base-leveledshe.cpp:207-211) — composite when it applies and has been checked at this level
 void KeySwitchAccumulate(const Ciphertext<DCRTPoly>& ciphertext, const EvalKey<DCRTPoly>& evalKey) {
@@ -311,6 +319,8 @@ void KeySwitchAccumulate(const Ciphertext<DCRTPoly>& ciphertext, const EvalKey<D
              KeyBuffers(evalKey, cp->GetNumPartQ(), cp->GetParamsQP()->GetParams().size(), kb, ka);
     if (usable && hiprt::DomainChecked(*dom, hiprt::kKeySwitchAcc, sizeQl) == 1 && CompositeKeySwitchAcc(*dom, sizeQl, kb, ka, cv[0], cv[1], cv[2]))
         return;
+    if (cv[2].Width() > 1)
+        WideNeedsCheckedComposite("EvalMult's key switch");
     // the reference's lines (member by member, with the reference's tables) ...
     DCRTPoly try0, try1;
     bool tried = false;
@@ -362,20 +372,23 @@ std::shared_ptr<std::vector<DCRTPoly>> KeySwitchHYBRID::KeySwitchCore(const DCRT
         hiprt::PackedKey pk = hiprt::DomainKey(*dom, kb, ka, op);
         if (!pk.key)
             return fhe_ref_KeySwitchCore(this, a, evalKey);
-        const size_t N   = a.GetParams()->GetRingDimension();
-        const size_t wsB = A.ks_workspace_bytes(hiprt::DomainPlan(*dom), sizeQl, 1);
-        auto ws = hiprt::Alloc(wsB / 8 + 1), o0 = hiprt::Alloc(sizeQl * N), o1 = hiprt::Alloc(sizeQl * N);
+        const size_t N       = a.GetParams()->GetRingDimension();
+        const uint32_t width = a.Width();  // (a wide ciphertext: its K towers are the composite's batch)
+        const size_t wsB     = A.ks_workspace_bytes(hiprt::DomainPlan(*dom), sizeQl, width);
+        auto ws = hiprt::Alloc(wsB / 8 + 1), o0 = hiprt::Alloc((size_t)width * sizeQl * N), o1 = hiprt::Alloc((size_t)width * sizeQl * N);
         op.R(pk.b), op.R(pk.a);
-        hiprt::Check(A.keyswitch_hybrid(hiprt::DomainPlan(*dom), pk.key.get(), op.R(bc), sizeQl, 1, op.W(o0), op.W(o1), op.W(ws), wsB, op.s),
+        hiprt::Check(A.keyswitch_hybrid(hiprt::DomainPlan(*dom), pk.key.get(), op.R(bc), sizeQl, width, op.W(o0), op.W(o1), op.W(ws), wsB, op.s),
                      "KeySwitchCore: composite key switch");
         hiprt::CountDevice("KeySwitchCore");
         hiprt::CountComposite();
         mine = std::make_shared<std::vector<DCRTPoly>>();
-        mine->push_back(DCRTPoly::FromDeviceWords(a.GetParams(), Format::EVALUATION, std::move(o0)));
-        mine->push_back(DCRTPoly::FromDeviceWords(a.GetParams(), Format::EVALUATION, std::move(o1)));
+        mine->push_back(DCRTPoly::FromDeviceWords(a.GetParams(), Format::EVALUATION, std::move(o0), width));
+        mine->push_back(DCRTPoly::FromDeviceWords(a.GetParams(), Format::EVALUATION, std::move(o1), width));
     }
     if (st == 1)
         return mine;
+    if (a.Width() > 1)
+        WideNeedsCheckedComposite("KeySwitchCore");
     auto ref = fhe_ref_KeySwitchCore(this, a, evalKey);  // first use at this level: both, compared word for word on the device
     auto r0 = (*ref)[0].DeviceWords(), r1 = (*ref)[1].DeviceWords();
     const bool same = r0 && r1 && (*ref)[0].GetNumOfElements() == sizeQl &&
@@ -691,19 +704,22 @@ bool BsgsLevelOnDevice(Ciphertext<DCRTPoly>& ct, const std::vector<int32_t>& rot
     auto b0 = cv[0].DeviceWords(), b1 = cv[1].DeviceWords();
     if (!b0 || !b1)
         return Why(9);
+    const uint32_t width = cv[0].Width();  // (a wide ciphertext: its K towers are the composite's batch, the diagonals are shared)
+    if (cv[1].Width() != width)
+        return Why(9);
     const auto& Api  = hiprt::api();
     const size_t N   = cv[0].GetParams()->GetRingDimension();
-    const size_t wsB = Api.bsgs_workspace_bytes(hiprt::DomainPlan(*dom), sizeQl, 1, nIn, nOut);
-    auto ws = hiprt::Alloc(wsB / 8 + 1), o0 = hiprt::Alloc(sizeQl * N), o1 = hiprt::Alloc(sizeQl * N);
-    if (Api.bsgs_transform(hiprt::DomainPlan(*dom), op.R(b0), op.R(b1), sizeQl, 1, nIn, inK.data(), inKeys.data(), nOut, outK.data(), outKeys.data(),
+    const size_t wsB = Api.bsgs_workspace_bytes(hiprt::DomainPlan(*dom), sizeQl, width, nIn, nOut);
+    auto ws = hiprt::Alloc(wsB / 8 + 1), o0 = hiprt::Alloc((size_t)width * sizeQl * N), o1 = hiprt::Alloc((size_t)width * sizeQl * N);
+    if (Api.bsgs_transform(hiprt::DomainPlan(*dom), op.R(b0), op.R(b1), sizeQl, width, nIn, inK.data(), inKeys.data(), nOut, outK.data(), outKeys.data(),
                            diag.data(), op.W(o0), op.W(o1), op.W(ws), wsB, op.s) != FHE_OK)
         return Why(10);
     hiprt::CountDevice("Bootstrap.BsgsLevel");
     hiprt::CountComposite();
     auto result = ct->CloneEmpty();
     std::vector<DCRTPoly> elements;
-    elements.push_back(DCRTPoly::FromDeviceWords(cv[0].GetParams(), Format::EVALUATION, std::move(o0)));
-    elements.push_back(DCRTPoly::FromDeviceWords(cv[0].GetParams(), Format::EVALUATION, std::move(o1)));
+    elements.push_back(DCRTPoly::FromDeviceWords(cv[0].GetParams(), Format::EVALUATION, std::move(o0), width));
+    elements.push_back(DCRTPoly::FromDeviceWords(cv[0].GetParams(), Format::EVALUATION, std::move(o1), width));
     result->SetElements(std::move(elements));
     result->SetNoiseScaleDeg(ct->GetNoiseScaleDeg() + A[0]->GetNoiseScaleDeg());
     result->SetScalingFactor(ct->GetScalingFactor() * A[0]->GetScalingFactor());
@@ -734,11 +750,17 @@ Ciphertext<DCRTPoly> CheckedComposite(ConstCiphertext<DCRTPoly>& ctxt, Composite
     if (dbg)
         fprintf(stderr, "hal debug: CheckedComposite domain %p level %u state %d elements %zu\n", (void*)dom.get(), sizeQl, state,
                 ctxt->GetElements().size());
+    const bool wide = ctxt->GetElements()[0].Width() > 1;
+    if (wide && state != 1)
+        WideNeedsCheckedComposite("a linear transform of bootstrapping");
     if (state == 2)
         return reference();
     Ciphertext<DCRTPoly> mine;
-    if (!composite(mine))
+    if (!composite(mine)) {
+        if (wide)
+            WideNeedsCheckedComposite("a linear transform of bootstrapping (the composite declined)");
         return reference();
+    }
     if (state == 1)
         return mine;
     auto ref = reference();

@@ -78,12 +78,13 @@ public:
         return *this;
     }
     DCRTPolyHipImpl(DCRTPolyType&& e) noexcept
-        : m_h{std::move(e.m_h)}, m_d{std::move(e.m_d)}, m_hostValid{e.m_hostValid}, m_zero{e.m_zero} {}
+        : m_h{std::move(e.m_h)}, m_d{std::move(e.m_d)}, m_hostValid{e.m_hostValid}, m_zero{e.m_zero}, m_k{e.m_k} {}
     DCRTPolyType& operator=(DCRTPolyType&& rhs) noexcept override {
         m_h         = std::move(rhs.m_h);
         m_d         = std::move(rhs.m_d);
         m_hostValid = rhs.m_hostValid;
         m_zero      = rhs.m_zero;
+        m_k         = rhs.m_k;
         return *this;
     }
     explicit DCRTPolyHipImpl(HostType&& h) noexcept : m_h{std::move(h)} {}
@@ -123,6 +124,7 @@ public:
         if (initializeElementToZero && hiprt::Available()) {
             m_hostValid = false;
             m_zero      = true;
+            m_k         = hiprt::ThreadWidth();  // (an accumulator of a wide evaluation is wide)
         }
     }
     DCRTPolyHipImpl(const DggType& dgg, const std::shared_ptr<Params>& p, Format f = Format::EVALUATION) : m_h{dgg, p, f} {}
@@ -169,12 +171,14 @@ public:
         if (m_d && !m_hostValid && endTower < NumLimbs() && startTower <= endTower) {
             const auto& P = m_h.GetParams();
             auto params   = std::make_shared<Params>(P->GetCyclotomicOrder(), P->GetParamPartition(startTower, endTower));
-            const size_t N = P->GetRingDimension(), n = endTower - startTower + 1;
+            const size_t N = P->GetRingDimension(), n = endTower - startTower + 1, L = NumLimbs();
             hiprt::Op op;
-            auto d = hiprt::Alloc(n * N);
-            hiprt::D2D(op, op.W(d), op.R(m_d) + (size_t)startTower * N, n * N * 8, "CloneTowers");
+            auto d        = hiprt::Alloc((size_t)m_k * n * N);
+            uint64_t* dst = op.W(d);
+            for (uint32_t k = 0; k < m_k; ++k)  // (each tower of a wide one)
+                hiprt::D2D(op, dst + (size_t)k * n * N, op.R(m_d) + ((size_t)k * L + startTower) * N, n * N * 8, "CloneTowers");
             hiprt::CountDevice();
-            return FromDevice(params, m_h.GetFormat(), std::move(d));
+            return FromDevice(params, m_h.GetFormat(), std::move(d), m_k);
         }
         if (!m_d && m_hostValid) {
             hiprt::CountHost(__func__, RingOf(m_h), /*hostData=*/true);
@@ -254,12 +258,12 @@ public:
     DCRTPolyType Negate() const override {
         FHE_HAL_MEMBER();
         hiprt::Resolved r;
-        if (OnDevice(&r)) {
+        if (OnDeviceWide(&r)) {
             hiprt::Op op;
             auto d = hiprt::Alloc(Words());
-            hiprt::Check(hiprt::api().neg(r.ctx, op.W(d), op.R(m_d), r.idx[0].data(), NumLimbs(), 1, op.s), "Negate");
+            hiprt::Check(hiprt::api().neg(r.ctx, op.W(d), op.R(m_d), r.idx[0].data(), NumLimbs(), m_k, op.s), "Negate");
             hiprt::CountDevice();
-            return FromDevice(m_h.GetParams(), m_h.GetFormat(), std::move(d));
+            return FromDevice(m_h.GetParams(), m_h.GetFormat(), std::move(d), m_k);
         }
         return Wrap(Hc().Negate());
     }
@@ -285,14 +289,14 @@ public:
     DCRTPolyType AutomorphismTransform(uint32_t i) const override {
         FHE_HAL_MEMBER();
         hiprt::Resolved r;
-        if ((i & 1u) && OnDevice(&r)) {
+        if ((i & 1u) && OnDeviceWide(&r)) {
             hiprt::Op op;
             auto d = hiprt::Alloc(Words());
             hiprt::Check(hiprt::api().automorph(r.ctx, op.W(d), op.R(m_d), i, m_h.GetFormat() == Format::EVALUATION ? 1 : 0,
-                                                r.idx[0].data(), NumLimbs(), 1, op.s),
+                                                r.idx[0].data(), NumLimbs(), m_k, op.s),
                          "AutomorphismTransform");
             hiprt::CountDevice();
-            return FromDevice(m_h.GetParams(), m_h.GetFormat(), std::move(d));
+            return FromDevice(m_h.GetParams(), m_h.GetFormat(), std::move(d), m_k);
         }
         return Wrap(Hc().AutomorphismTransform(i));
     }
@@ -374,7 +378,7 @@ public:
             const hiprt::Buf src = m_d;
             std::vector<uint64_t> memoKey;
             hiprt::Resolved r;
-            if (src && !m_hostValid && src.use_count() > 2 && !src->parent && OnDevice(&r)) {
+            if (src && m_k == 1 && !m_hostValid && src.use_count() > 2 && !src->parent && OnDevice(&r)) {
                 memoKey.reserve(2 + 2 * (size_t)NumLimbs());
                 memoKey.push_back(2), memoKey.push_back(NumLimbs());
                 memoKey.insert(memoKey.end(), r.idx[0].begin(), r.idx[0].end());
@@ -466,12 +470,30 @@ public:
     }
     // dcrtpoly-impl.h:669-689: the device copy keeps its leading limbs, the mirror object keeps the metadata in step
     void DropLastElement() override {
+        CompactForDrop(1);
+        DropLastMeta();
+    }
+    void DropLastElements(size_t i) override {
+        CompactForDrop(i);
+        std::lock_guard<std::mutex> lk(m_lock.m);
+        m_h.DropLastElements(i);
+    }
+    // (metadata only: a narrow tower's device copy keeps its leading limbs; members whose result buffer already has the new height)
+    void DropLastMeta() {
         std::lock_guard<std::mutex> lk(m_lock.m);
         m_h.DropLastElement();
     }
-    void DropLastElements(size_t i) override {
-        std::lock_guard<std::mutex> lk(m_lock.m);
-        m_h.DropLastElements(i);
+    // a wide tower stays dense ([m_k][limbs][N]): its towers move together when limbs are dropped
+    void CompactForDrop(size_t drop) {
+        if (m_k == 1 || !m_d || drop == 0 || drop >= NumLimbs())
+            return;
+        const size_t N = m_h.GetParams()->GetRingDimension(), L = NumLimbs(), l = L - drop;
+        hiprt::Op op;
+        auto d        = hiprt::Alloc((size_t)m_k * l * N);
+        uint64_t* dst = op.W(d);
+        for (uint32_t k = 0; k < m_k; ++k)
+            hiprt::D2D(op, dst + (size_t)k * l * N, op.R(m_d) + (size_t)k * L * N, l * N * 8, "wide tower: limbs dropped");
+        m_d = std::move(d);
     }
     // dcrtpoly-impl.h:693-712 (CKKS rescale)
     void DropLastElementAndScale(const std::vector<NativeInteger>& QlQlInvModqlDivqlModq,
@@ -788,18 +810,18 @@ public:
     void SwitchFormat(uint32_t thread_limit = 0) override {
         FHE_HAL_MEMBER();
         hiprt::Resolved r;
-        if (OnDevice(&r)) {
+        if (OnDeviceWide(&r)) {
             const bool toCoeff = m_h.GetFormat() == Format::EVALUATION;
             hiprt::Op op;
             if (m_d.use_count() > 1) {  // words shared with a copy: transform into a buffer of its own
                 auto d = hiprt::Alloc(Words());
                 auto f = toCoeff ? hiprt::api().ntt_inv_oop : hiprt::api().ntt_fwd_oop;
-                hiprt::Check(f(r.ctx, op.R(m_d), op.W(d), r.idx[0].data(), NumLimbs(), 1, op.s), "SwitchFormat");
+                hiprt::Check(f(r.ctx, op.R(m_d), op.W(d), r.idx[0].data(), NumLimbs(), m_k, op.s), "SwitchFormat");
                 m_d = std::move(d);
             }
             else {
                 auto f = toCoeff ? hiprt::api().ntt_inv : hiprt::api().ntt_fwd;
-                hiprt::Check(f(r.ctx, op.W(m_d), r.idx[0].data(), NumLimbs(), 1, op.s), "SwitchFormat");
+                hiprt::Check(f(r.ctx, op.W(m_d), r.idx[0].data(), NumLimbs(), m_k, op.s), "SwitchFormat");
             }
             hiprt::CountDevice();
             DeviceIsNewer(toCoeff ? Format::COEFFICIENT : Format::EVALUATION);
@@ -849,7 +871,13 @@ public:
     }
     const std::vector<PolyType>& GetAllElements() const {
         FHE_HAL_MEMBER();
-        return Hc().GetAllElements();
+        const auto& limbs = Hc().GetAllElements();
+        if (m_k > 1 && m_d && !limbs.empty() && limbs[0].GetLength() > 0) {
+            // the limbs of a wide tower read on the host are tower 0's.  Bootstrapping's ModRaise hands limb 0 straight back to the
+            // ModRaise constructor (ckksrns-fhe.cpp: `DCRTPoly tmp(dcrt.GetElementAtIndex(0), paramsRaised)`): remember whose limb it is
+            LastWideRead() = WideRead{&limbs[0].GetValues()[0], m_d, m_k, NumLimbs()};
+        }
+        return limbs;
     }
     std::vector<PolyType>& GetAllElements() {
         FHE_HAL_MEMBER();
@@ -997,24 +1025,27 @@ public:
         FHE_HAL_MEMBER();
         std::vector<DCRTPolyType> out;
         hiprt::Resolved r;
-        if (!a0.Compatible(a1, true) || (b0 && (!a0.Compatible(*b0, true) || !a0.Compatible(*b1, true))) || !a0.OnDevice(&r) || !a1.Upload() ||
+        if (!a0.Compatible(a1, true) || (b0 && (!a0.Compatible(*b0, true) || !a0.Compatible(*b1, true))) || !a0.OnDeviceWide(&r) || !a1.Upload() ||
             (b0 && (!b0->Upload() || !b1->Upload())))
             return out;
         const uint32_t L = a0.NumLimbs();
+        const uint32_t k = std::max(std::max(a0.m_k, a1.m_k), b0 ? std::max(b0->m_k, b1->m_k) : 1u);
+        const hiprt::Buf x0 = a0.Widened(k), x1 = a1.Widened(k), y0 = b0 ? b0->Widened(k) : nullptr, y1 = b0 ? b1->Widened(k) : nullptr;
+        const size_t words = (size_t)k * a0.TowerWords();
         hiprt::Op op;
-        auto d0 = hiprt::Alloc(a0.Words()), d1 = hiprt::Alloc(a0.Words()), d2 = hiprt::Alloc(a0.Words());
+        auto d0 = hiprt::Alloc(words), d1 = hiprt::Alloc(words), d2 = hiprt::Alloc(words);
         if (b0)
-            hiprt::Check(hiprt::api().tensor(r.ctx, op.R(a0.m_d), op.R(a1.m_d), op.R(b0->m_d), op.R(b1->m_d), op.W(d0), op.W(d1), op.W(d2),
-                                             r.idx[0].data(), L, 1, op.s),
+            hiprt::Check(hiprt::api().tensor(r.ctx, op.R(x0), op.R(x1), op.R(y0), op.R(y1), op.W(d0), op.W(d1), op.W(d2),
+                                             r.idx[0].data(), L, k, op.s),
                          "EvalMultCore");
         else
-            hiprt::Check(hiprt::api().tensor_square(r.ctx, op.R(a0.m_d), op.R(a1.m_d), op.W(d0), op.W(d1), op.W(d2), r.idx[0].data(), L, 1, op.s),
+            hiprt::Check(hiprt::api().tensor_square(r.ctx, op.R(x0), op.R(x1), op.W(d0), op.W(d1), op.W(d2), r.idx[0].data(), L, k, op.s),
                          "EvalSquareCore");
         hiprt::CountDevice();
         const auto& P = a0.m_h.GetParams();
-        out.push_back(FromDevice(P, Format::EVALUATION, std::move(d0)));
-        out.push_back(FromDevice(P, Format::EVALUATION, std::move(d1)));
-        out.push_back(FromDevice(P, Format::EVALUATION, std::move(d2)));
+        out.push_back(FromDevice(P, Format::EVALUATION, std::move(d0), k));
+        out.push_back(FromDevice(P, Format::EVALUATION, std::move(d1), k));
+        out.push_back(FromDevice(P, Format::EVALUATION, std::move(d2), k));
         return out;
     }
 
@@ -1025,6 +1056,8 @@ public:
     static bool PairAddInPlace(DCRTPolyType& a0, DCRTPolyType& a1, const DCRTPolyType& b0, const DCRTPolyType& b1, bool subtract) {
         hiprt::MemberScope scope(subtract ? "operator-=" : "operator+=");
         hiprt::Resolved r;
+        if (a0.m_k != 1 || a1.m_k != 1 || b0.m_k != 1 || b1.m_k != 1)
+            return false;  // (wide towers: one launch per element is already K towers)
         if (&a0 == &a1 || !a0.Compatible(a1, false) || !a0.Compatible(b0, false) || !a0.Compatible(b1, false) || !a0.OnDevice(&r) || !a1.Upload() ||
             !b0.Upload() || !b1.Upload() || a0.m_d == a1.m_d || b0.m_d == b1.m_d)
             return false;
@@ -1044,6 +1077,8 @@ public:
         hiprt::MemberScope scope("Times");
         hiprt::Resolved r;
         const uint32_t L = a0.NumLimbs();
+        if (a0.m_k != 1 || a1.m_k != 1)
+            return false;
         if (&a0 == &a1 || factors.size() < L || !a0.Compatible(a1, false) || !a0.OnDevice(&r) || !a1.Upload() || a0.m_d == a1.m_d)
             return false;
         std::vector<uint64_t> k(L);
@@ -1065,6 +1100,8 @@ public:
                                    const std::vector<NativeInteger>& qlInvModq) {
         hiprt::MemberScope scope("DropLastElementAndScale");
         const uint32_t L = a0.NumLimbs();
+        if (a0.m_k != 1 || a1.m_k != 1)
+            return false;
         if (&a0 == &a1 || L < 2 || !a0.Compatible(a1, true) || QlQlInvModqlDivqlModq.size() < L - 1 || qlInvModq.size() < L - 1)
             return false;
         hiprt::Resolved r;
@@ -1089,7 +1126,7 @@ public:
             if (h0 && h1) {
                 a0.m_d = std::move(h0), a1.m_d = std::move(h1);
                 a0.DeviceIsNewer(Format::EVALUATION), a1.DeviceIsNewer(Format::EVALUATION);
-                a0.DropLastElement(), a1.DropLastElement();
+                a0.DropLastMeta(), a1.DropLastMeta();
                 return true;
             }
             if (h0 || h1)
@@ -1109,7 +1146,7 @@ public:
         a0.m_d = std::move(o0), a1.m_d = std::move(o1);
         hiprt::CountDevice();
         a0.DeviceIsNewer(Format::EVALUATION), a1.DeviceIsNewer(Format::EVALUATION);
-        a0.DropLastElement(), a1.DropLastElement();
+        a0.DropLastMeta(), a1.DropLastMeta();
         return true;
     }
     static std::vector<uint64_t> RescaleMemoKey(const hiprt::Resolved& r, uint32_t L, const std::vector<uint64_t>& a, const std::vector<uint64_t>& b) {
@@ -1148,8 +1185,11 @@ public:
         return m_d;
     }
     // a tower over `params` in format f whose words are the device buffer d ([limbs][N])
-    static DCRTPolyType FromDeviceWords(const std::shared_ptr<Params>& params, Format f, hiprt::Buf d) {
-        return FromDevice(params, f, std::move(d));
+    static DCRTPolyType FromDeviceWords(const std::shared_ptr<Params>& params, Format f, hiprt::Buf d, uint32_t k = 1) {
+        return FromDevice(params, f, std::move(d), k);
+    }
+    uint32_t Width() const {
+        return m_k;
     }
     // replaces this tower's device words by a window of a packed buffer holding the same values (evaluation keys packed for the
     // library's plans: no second copy stays behind)
@@ -1176,6 +1216,10 @@ private:
     mutable hiprt::Buf m_d;         // device words [nLimbs][N] (may hold more rows than nLimbs after DropLastElement)
     mutable bool m_hostValid{true};
     mutable bool m_zero{false};     // an all-zero tower not yet materialised on either side (then !m_hostValid && !m_d)
+    // WIDE tower (hiprt::WidthScope): the device buffer holds m_k towers [m_k][nLimbs][N], dense, of m_k ciphertexts with equal metadata
+    // that pke evaluates in lockstep.  A wide tower has no host form: its mirror carries (params, format) and, when something reads limbs
+    // for their metadata, the words of tower 0; members without a wide device path throw.
+    uint32_t m_k{1};
     mutable Lock m_lock;
 
     // (params, format, limb count) live in the mirror object, which SyncHost() never replaces (see there)
@@ -1186,6 +1230,9 @@ private:
         return (uint32_t)m_h.GetAllElements().size();
     }
     size_t Words() const {
+        return (size_t)m_k * NumLimbs() * m_h.GetParams()->GetRingDimension();
+    }
+    size_t TowerWords() const {  // one tower of a wide one
         return (size_t)NumLimbs() * m_h.GetParams()->GetRingDimension();
     }
     static uint32_t RingOf(const HostType& h) {
@@ -1203,11 +1250,12 @@ private:
             r.emplace_back(std::move(h));
         return r;
     }
-    static DCRTPolyType FromDevice(const std::shared_ptr<Params>& p, Format f, hiprt::Buf d) {
+    static DCRTPolyType FromDevice(const std::shared_ptr<Params>& p, Format f, hiprt::Buf d, uint32_t k = 1) {
         DCRTPolyType r;
         r.m_h         = HostType(p, f, false);
         r.m_d         = std::move(d);
         r.m_hostValid = false;
+        r.m_k         = k;
         return r;
     }
     static void LimbsOf(const std::shared_ptr<Params>& p, std::vector<uint64_t>& q, std::vector<uint64_t>& psi) {
@@ -1249,10 +1297,20 @@ private:
         return true;
     }
 
+    struct WideRead {
+        const void* limb0 = nullptr;  // host address of the words of limb 0 handed out
+        hiprt::Buf words;             // the wide tower's device words [k][limbs][N]
+        uint32_t k = 1, limbs = 0;
+    };
+    static WideRead& LastWideRead() {
+        static thread_local WideRead w;
+        return w;
+    }
     // ---- the two copies ---------------------------------------------------------------------------------------------
     void CopyFrom(const DCRTPolyType& e) {
         std::lock_guard<std::mutex> lk(e.m_lock.m);
         m_zero = e.m_zero;
+        m_k    = e.m_k;
         m_d.reset();
         if (e.m_d && e.m_h.GetParams() && e.m_h.GetAllElements().size() == e.m_h.GetParams()->GetParams().size()) {
             // a source with a device copy (even next to a valid mirror): copy-on-write, the mirror of the copy holds (params,
@@ -1320,6 +1378,9 @@ private:
     // mutable host access: the device copy is stale afterwards.  hostData: the caller PRODUCES words on the host (an encoder or a sampler
     // filling limbs); while the tower has no device copy that is not a fall-back of anything and is counted apart
     HostType& Hm(const char* who = __builtin_FUNCTION(), bool hostData = false) {
+        if (m_k > 1)
+            OPENFHE_THROW(std::string("HIP backend: DCRTPoly::") + who + " on a wide tower (" + std::to_string(m_k) +
+                          " ciphertexts in lockstep): the member has no wide device path and a wide tower has no host form");
         const bool hadDevice = m_d != nullptr;
         SyncHost(who);
         m_d.reset();
@@ -1327,7 +1388,13 @@ private:
         return m_h;
     }
     // device words valid (uploads the mirror if needed); r.idx[0] = context limbs of this tower
+    // members with a wide device path (they pass m_k as the library's batch) ask with OnDeviceWide
     bool OnDevice(hiprt::Resolved* r, const char* who = __builtin_FUNCTION()) const {
+        if (m_k > 1)
+            OPENFHE_THROW(std::string("HIP backend: DCRTPoly::") + who + " on a wide tower: the member has no wide device path");
+        return OnDeviceWide(r, who);
+    }
+    bool OnDeviceWide(hiprt::Resolved* r, const char* who = __builtin_FUNCTION()) const {
         hiprt::TraceMember(who);
         const auto& P = m_h.GetParams();
         if (!P || NumLimbs() == 0 || NumLimbs() != P->GetParams().size())
@@ -1344,8 +1411,8 @@ private:
         const size_t N   = m_h.GetParams()->GetRingDimension();
         if (m_zero) {
             hiprt::Op op;
-            auto d = hiprt::Alloc((size_t)L * N);
-            hiprt::Check(hiprt::api().memset_zero(hiprt::AnyCtx(), op.W(d), (size_t)L * N * 8, op.s), "DCRTPoly zero tower");
+            auto d = hiprt::Alloc((size_t)m_k * L * N);
+            hiprt::Check(hiprt::api().memset_zero(hiprt::AnyCtx(), op.W(d), (size_t)m_k * L * N * 8, op.s), "DCRTPoly zero tower");
             m_d    = std::move(d);
             m_zero = false;
             return true;
@@ -1354,13 +1421,14 @@ private:
             if (e.IsEmpty() || e.GetLength() != N)
                 return false;  // an unfilled tower: leave it (and its exceptions) to the host code
         hiprt::Op op;
-        auto d       = hiprt::Alloc((size_t)L * N);
+        auto d       = hiprt::Alloc((size_t)m_k * L * N);
         uint64_t* dp = op.W(d);
-        for (uint32_t i = 0; i < L; ++i)
-            hiprt::Check(hiprt::api().h2d(hiprt::AnyCtx(), dp + (size_t)i * N, &m_h.GetAllElements()[i].GetValues()[0], N * 8, op.s),
-                         "DCRTPoly host -> device");
+        for (uint32_t k = 0; k < m_k; ++k)  // (a wide tower whose words were read on the host as tower 0 — a zero accumulator: every tower gets them)
+            for (uint32_t i = 0; i < L; ++i)
+                hiprt::Check(hiprt::api().h2d(hiprt::AnyCtx(), dp + ((size_t)k * L + i) * N, &m_h.GetAllElements()[i].GetValues()[0], N * 8, op.s),
+                             "DCRTPoly host -> device");
         op.HostSync();  // (the host vectors may change or go away as soon as this returns)
-        hiprt::CountH2D((size_t)L * N * 8);
+        hiprt::CountH2D((size_t)m_k * L * N * 8);
         m_d = std::move(d);
         return true;
     }
@@ -1391,26 +1459,52 @@ private:
                 return false;
         return true;
     }
+    // The words of this tower replicated to width k ([k][limbs][N]): a plaintext or a constant tower that meets a wide ciphertext tower.
+    // Remembered on the buffer (the encodings of bootstrapping's constants meet every wide ciphertext again).
+    hiprt::Buf Widened(uint32_t k) const {
+        if (m_k == k)
+            return m_d;
+        if (m_k != 1)
+            OPENFHE_THROW("HIP backend: towers of different widths (" + std::to_string(m_k) + ", " + std::to_string(k) + ") in one operation");
+        const std::vector<uint64_t> key{3, k, NumLimbs()};
+        if (auto hit = hiprt::MemoFind(m_d, key))
+            return hit;
+        const size_t w = TowerWords();
+        hiprt::Op op;
+        auto d        = hiprt::Alloc((size_t)k * w);
+        uint64_t* dst = op.W(d);
+        for (uint32_t i = 0; i < k; ++i)
+            hiprt::D2D(op, dst + (size_t)i * w, op.R(m_d), w * 8, "tower replicated for a wide operation");
+        hiprt::MemoStore(m_d, key, d);
+        return d;
+    }
     bool Binary(const DCRTPolyType& rhs, BinFn fn, bool evalOnly, DCRTPolyType* out) const {
         hiprt::Resolved r;
-        if (!Compatible(rhs, evalOnly) || !OnDevice(&r) || !rhs.Upload())
+        if (!Compatible(rhs, evalOnly) || !OnDeviceWide(&r) || !rhs.Upload())
             return false;
+        const uint32_t k = std::max(m_k, rhs.m_k);
+        const hiprt::Buf a = Widened(k), b = rhs.Widened(k);
         hiprt::Op op;
-        auto d = hiprt::Alloc(Words());
-        hiprt::Check(fn(r.ctx, op.W(d), op.R(m_d), op.R(rhs.m_d), r.idx[0].data(), NumLimbs(), 1, op.s), "DCRTPoly arithmetic");
+        auto d = hiprt::Alloc((size_t)k * TowerWords());
+        hiprt::Check(fn(r.ctx, op.W(d), op.R(a), op.R(b), r.idx[0].data(), NumLimbs(), k, op.s), "DCRTPoly arithmetic");
         hiprt::CountDevice();
-        *out = FromDevice(m_h.GetParams(), m_h.GetFormat(), std::move(d));
+        *out = FromDevice(m_h.GetParams(), m_h.GetFormat(), std::move(d), k);
         return true;
     }
     bool BinaryInPlace(const DCRTPolyType& rhs, BinFn fn, bool evalOnly) {
         hiprt::Resolved r;
-        if (!Compatible(rhs, evalOnly) || !OnDevice(&r) || !rhs.Upload())
+        if (!Compatible(rhs, evalOnly) || !OnDeviceWide(&r) || !rhs.Upload())
             return false;
+        if (rhs.m_k > m_k) {  // (a narrow tower updated by a wide one becomes wide)
+            m_d = Widened(rhs.m_k);
+            m_k = rhs.m_k;
+        }
+        const hiprt::Buf b = rhs.Widened(m_k);
         hiprt::Op op;
         auto dst             = WriteTarget();
         const uint64_t* lhsP = op.R(m_d);  // (before W: an in-place target is both)
-        const uint64_t* rhsP = op.R(rhs.m_d);
-        hiprt::Check(fn(r.ctx, op.W(dst), lhsP, rhsP, r.idx[0].data(), NumLimbs(), 1, op.s), "DCRTPoly arithmetic");
+        const uint64_t* rhsP = op.R(b);
+        hiprt::Check(fn(r.ctx, op.W(dst), lhsP, rhsP, r.idx[0].data(), NumLimbs(), m_k, op.s), "DCRTPoly arithmetic");
         m_d = std::move(dst);
         hiprt::CountDevice();
         DeviceIsNewer(m_h.GetFormat());
@@ -1419,7 +1513,7 @@ private:
     // limb i plus / minus NativeInteger(k[i]) as a constant polynomial (PolyImpl::Plus / Minus(Integer), poly-impl.h:211-225)
     bool AddConstOnDevice(const std::vector<Integer>& k, bool minus, DCRTPolyType* out) const {
         hiprt::Resolved r;
-        if (k.size() < NumLimbs() || !OnDevice(&r))
+        if (k.size() < NumLimbs() || !OnDeviceWide(&r))
             return false;
         std::vector<uint64_t> c(NumLimbs());
         for (uint32_t i = 0; i < NumLimbs(); ++i)
@@ -1427,29 +1521,29 @@ private:
         hiprt::Op op;
         auto d = hiprt::Alloc(Words());
         if (minus)
-            hiprt::Check(hiprt::api().sub_const(r.ctx, op.W(d), op.R(m_d), c.data(), r.idx[0].data(), NumLimbs(), 1, op.s), "DCRTPoly Minus(constants)");
+            hiprt::Check(hiprt::api().sub_const(r.ctx, op.W(d), op.R(m_d), c.data(), r.idx[0].data(), NumLimbs(), m_k, op.s), "DCRTPoly Minus(constants)");
         else
-            hiprt::Check(hiprt::api().add_const(r.ctx, op.W(d), op.R(m_d), c.data(), r.idx[0].data(), NumLimbs(), 1,
+            hiprt::Check(hiprt::api().add_const(r.ctx, op.W(d), op.R(m_d), c.data(), r.idx[0].data(), NumLimbs(), m_k,
                                                 m_h.GetFormat() == Format::COEFFICIENT ? 1 : 0, op.s),
                          "DCRTPoly Plus(constants)");
         hiprt::CountDevice();
-        *out = FromDevice(m_h.GetParams(), m_h.GetFormat(), std::move(d));
+        *out = FromDevice(m_h.GetParams(), m_h.GetFormat(), std::move(d), m_k);
         return true;
     }
     // += / -= one scalar on every limb (dcrtpoly-impl.h:383-427): Plus(Integer) touches coefficient 0 only in COEFFICIENT format
     // (poly-impl.h:211-218), -= subtracts from every word in both formats (poly.h:249-252)
     bool AddScalarInPlace(const NativeInteger& v, bool minus) {
         hiprt::Resolved r;
-        if (!OnDevice(&r))
+        if (!OnDeviceWide(&r))
             return false;
         std::vector<uint64_t> c(NumLimbs(), v.ConvertToInt<uint64_t>());
         hiprt::Op op;
         auto dst            = WriteTarget();
         const uint64_t* src = op.R(m_d);
         if (minus)
-            hiprt::Check(hiprt::api().sub_const(r.ctx, op.W(dst), src, c.data(), r.idx[0].data(), NumLimbs(), 1, op.s), "DCRTPoly -= scalar");
+            hiprt::Check(hiprt::api().sub_const(r.ctx, op.W(dst), src, c.data(), r.idx[0].data(), NumLimbs(), m_k, op.s), "DCRTPoly -= scalar");
         else
-            hiprt::Check(hiprt::api().add_const(r.ctx, op.W(dst), src, c.data(), r.idx[0].data(), NumLimbs(), 1,
+            hiprt::Check(hiprt::api().add_const(r.ctx, op.W(dst), src, c.data(), r.idx[0].data(), NumLimbs(), m_k,
                                                 m_h.GetFormat() == Format::COEFFICIENT ? 1 : 0, op.s),
                          "DCRTPoly += scalar");
         m_d = std::move(dst);
@@ -1459,7 +1553,7 @@ private:
     }
     bool TimesConstInPlace(const std::vector<NativeInteger>& c) {
         hiprt::Resolved r;
-        if (c.size() < NumLimbs() || !OnDevice(&r))
+        if (c.size() < NumLimbs() || !OnDeviceWide(&r))
             return false;
         std::vector<uint64_t> k(NumLimbs());
         for (uint32_t i = 0; i < NumLimbs(); ++i)
@@ -1467,7 +1561,7 @@ private:
         hiprt::Op op;
         auto dst            = WriteTarget();
         const uint64_t* src = op.R(m_d);
-        hiprt::Check(hiprt::api().mul_const(r.ctx, op.W(dst), src, k.data(), r.idx[0].data(), NumLimbs(), 1, op.s),
+        hiprt::Check(hiprt::api().mul_const(r.ctx, op.W(dst), src, k.data(), r.idx[0].data(), NumLimbs(), m_k, op.s),
                      "DCRTPoly Times(constants)");
         m_d = std::move(dst);
         hiprt::CountDevice();
@@ -1911,7 +2005,7 @@ private:
         if (L < 2 || m_h.GetFormat() != Format::EVALUATION || QlQlInvModqlDivqlModq.size() < L - 1 || qlInvModq.size() < L - 1)
             return false;
         hiprt::Resolved r;
-        if (!OnDevice(&r))
+        if (!OnDeviceWide(&r))
             return false;
         const size_t N     = m_h.GetParams()->GetRingDimension();
         const uint32_t l   = L - 1;
@@ -1929,7 +2023,7 @@ private:
             if (auto hit = hiprt::MemoFind(src, memoKey)) {
                 m_d = std::move(hit);
                 DeviceIsNewer(Format::EVALUATION);
-                DropLastElement();
+                DropLastMeta();
                 return true;
             }
         }
@@ -1939,17 +2033,17 @@ private:
         const auto& A = hiprt::api();
         hiprt::Op op;
         const uint64_t* self = op.R(m_d);
-        const size_t wsBytes = A.rescale_workspace_bytes(r.ctx, L, 1);
+        const size_t wsBytes = A.rescale_workspace_bytes(r.ctx, L, m_k);
         auto ws              = hiprt::Alloc(wsBytes / 8);
-        auto tmp             = hiprt::Alloc((size_t)l * N);
-        hiprt::Check(A.rescale_limbs(r.ctx, self, r.idx[0].data(), L, a.data(), b.data(), 1, op.W(tmp), op.W(ws), wsBytes, op.s),
+        auto tmp             = hiprt::Alloc((size_t)m_k * l * N);
+        hiprt::Check(A.rescale_limbs(r.ctx, self, r.idx[0].data(), L, a.data(), b.data(), m_k, op.W(tmp), op.W(ws), wsBytes, op.s),
                      "DropLastElementAndScale");
         if (!memoKey.empty())
             hiprt::MemoStore(src, std::move(memoKey), tmp);
         m_d = std::move(tmp);
         hiprt::CountDevice();
         DeviceIsNewer(Format::EVALUATION);
-        DropLastElement();  // :698 (metadata; the device copy keeps its leading limbs)
+        DropLastMeta();  // :698 (a narrow tower's device copy keeps its leading limbs; the result buffer already has the new height)
         return true;
     }
     bool ModRaiseOnDevice(const PolyType& e, const std::shared_ptr<Params>& params) {
@@ -1961,6 +2055,24 @@ private:
             return false;
         const size_t N   = params->GetRingDimension();
         const uint32_t L = (uint32_t)params->GetParams().size();
+        WideRead& wr     = LastWideRead();
+        if (wr.words && wr.limb0 == &e.GetValues()[0]) {
+            // limb 0 of a WIDE tower: every one of its k towers is raised from its own limb 0, which never left the device
+            const uint32_t k = wr.k;
+            hiprt::Op op;
+            auto d = hiprt::Alloc((size_t)k * L * N);
+            hiprt::Check(hiprt::api().switch_modulus(r.ctx, op.W(d), r.idx[0].data(), L, op.R(wr.words), wr.limbs, 0, r.idx[0][0], k, op.s), "ModRaise");
+            hiprt::CountDevice();
+            m_h         = HostType(params, Format::COEFFICIENT, false);
+            m_d         = std::move(d);
+            m_hostValid = false;
+            m_zero      = false;
+            m_k         = k;
+            wr          = WideRead{};
+            return true;
+        }
+        // (a host polynomial is the same for every tower of a wide evaluation — MultByMonomialInPlace's monomial: a narrow tower, replicated
+        // when it meets a wide one)
         hiprt::Op op;
         auto src = hiprt::Alloc(N);
         auto d   = hiprt::Alloc((size_t)L * N);
@@ -1973,7 +2085,44 @@ private:
         m_d         = std::move(d);
         m_hostValid = false;
         m_zero      = false;
+        m_k         = 1;
         return true;
+    }
+    // ---- wide towers: K towers with equal (params, format) as one ([K][limbs][N]) and back --------------------------------------------
+public:
+    static DCRTPolyType PackWide(const std::vector<const DCRTPolyType*>& towers) {
+        hiprt::MemberScope scope("PackWide");
+        if (towers.empty())
+            OPENFHE_THROW("PackWide: no towers");
+        const DCRTPolyType& t0 = *towers[0];
+        hiprt::Resolved r;
+        if (!t0.OnDevice(&r))
+            OPENFHE_THROW("PackWide: the towers cannot live on the device");
+        const uint32_t k = (uint32_t)towers.size();
+        const size_t w   = t0.TowerWords();
+        hiprt::Op op;
+        auto d        = hiprt::Alloc((size_t)k * w);
+        uint64_t* dst = op.W(d);
+        for (uint32_t i = 0; i < k; ++i) {
+            const DCRTPolyType& t = *towers[i];
+            if (t.m_k != 1 || !t0.Compatible(t, false) || !t.Upload())
+                OPENFHE_THROW("PackWide: towers of different shapes");
+            hiprt::D2D(op, dst + (size_t)i * w, op.R(t.m_d), w * 8, "towers packed into a wide one");
+        }
+        hiprt::CountDevice();
+        return FromDevice(t0.m_h.GetParams(), t0.m_h.GetFormat(), std::move(d), k);
+    }
+    DCRTPolyType UnpackTower(uint32_t i) const {
+        hiprt::MemberScope scope("UnpackTower");
+        hiprt::Resolved r;
+        if (i >= m_k || !OnDeviceWide(&r))
+            OPENFHE_THROW("UnpackTower: no such tower");
+        const size_t w = TowerWords();
+        hiprt::Op op;
+        auto d = hiprt::Alloc(w);
+        hiprt::D2D(op, op.W(d), op.R(m_d) + (size_t)i * w, w * 8, "tower taken out of a wide one");
+        hiprt::CountDevice();
+        return FromDevice(m_h.GetParams(), m_h.GetFormat(), std::move(d), 1);
     }
 };
 

@@ -138,6 +138,17 @@ Buf View(const Buf& parent, size_t offsetWords, size_t words);
 // device memory owned by the caller (it must outlive every tower that adopts a window of it)
 Buf WrapExternal(uint64_t* devPtr, size_t words);
 
+// WIDE towers.  pke's control flow depends on parameters and metadata only, never on ciphertext words: K ciphertexts with equal metadata
+// can be evaluated in lockstep as ONE ciphertext whose towers hold K towers each ([K][limbs][N], the C ABI's batch dimension) — every
+// launch then works on K towers and every evaluation key is read once for all of them.  The width of the towers that pke creates on
+// the way (accumulators) is the calling thread's current width.
+uint32_t ThreadWidth();
+struct WidthScope {
+    explicit WidthScope(uint32_t k);
+    ~WidthScope();
+    uint32_t saved;
+};
+
 // One device operation (a group of launches) of the calling thread, on that thread's stream.
 class Op {
 public:
