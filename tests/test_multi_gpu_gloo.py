@@ -286,3 +286,41 @@ r = bb.run_rank(8, 8, 2, 1, 1, 0, {os.path.join(ROOT, 'tests', 'hal', '_build', 
     stock = open(out + ".stock.bin", "rb").read()
     got = open(out + ".rank0.bin", "rb").read() + open(out + ".rank1.bin", "rb").read()
     assert len(stock) > 10000 and got == stock, "a rank's bootstrapped ciphertext differs from the stock backend's"
+
+
+def test_wide_bootstrap_in_lockstep_matches_the_stock_backend(tmp_path):
+    """K ciphertexts with equal metadata as ONE ciphertext whose towers hold K towers each (hal/bootstrap_batch.cpp fbb_bootstrap_wide):
+    cc->EvalBootstrap runs once, every launch works on K towers.  Fully packed (the CoeffsToSlots / SlotsToCoeffs transforms, the
+    conjugation, MultByMonomial and both Chebyshev evaluations) at N = 2^8 on the lane emulator: every output identical, byte for byte,
+    to the stock backend's bootstrap of the same ciphertext — in one group of 3 and in groups of 2 + 1."""
+    import pytest
+    sys.path.insert(0, ROOT)
+    from openfhe_amd import boot_batch as bb
+    if not (os.path.exists(bb.HIP_SO) and os.path.exists(bb.STOCK_SO)):
+        pytest.skip("hal/_build/libfhe_boot_batch_hip.so not built (./build.sh hal needs the reference sources)")
+    prng = os.path.join(ROOT, "tests", "hal", "_build", "libdetprng.so")
+    out = str(tmp_path / "wide")
+    code = f"""
+import sys, os; sys.path.insert(0, {ROOT!r})
+from openfhe_amd import boot_batch as bb
+if len(sys.argv) > 1:
+    r = bb.run_rank(8, 128, 3, 1, 1, 0, {prng!r}, dump_path={out + '.stock.bin'!r}, warmup=0, so=bb.STOCK_SO)
+    sys.exit(0)
+r = bb.run_rank(8, 128, 3, 1, 1, 0, {prng!r}, warmup=0)  # (the narrow pass: first use of every composite, checked against the members)
+h = r.pop("handle")
+for tag, group in (("g3", 0), ("g2", 2)):
+    h.bootstrap_wide(group, 0)
+    h.dump({out!r} + "." + tag + ".bin", 0, 3)
+    print(tag, "errors", [h.check(i)[0] for i in range(3)])
+h.close()
+"""
+    env = dict(os.environ, OMP_NUM_THREADS="1", FHE_HIP_LIB=os.path.join(ROOT, "tests", "emu", "libfhe_emu.so"), FHE_HAL_REQUIRE_DEVICE="1")
+    env.pop("FHE_HAL_ALLOW_HOST", None)
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    ref = subprocess.run([sys.executable, "-c", code, "stock"], env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=600)
+    assert ref.returncode == 0, ref.stdout + ref.stderr
+    stock = open(out + ".stock.bin", "rb").read()
+    assert len(stock) > 10000
+    for tag in ("g3", "g2"):
+        assert open(out + "." + tag + ".bin", "rb").read() == stock, f"wide bootstrap ({tag}) differs from the stock backend's"
