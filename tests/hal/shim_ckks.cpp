@@ -392,13 +392,55 @@ int main(int argc, char** argv) {
         std::cout << "multbatch ring 2^" << logN << " sizeQ " << a[0]->GetElements()[0].GetNumOfElements() << " sizeP "
                   << cp->GetParamsP()->GetParams().size() << " dnum " << cp->GetNumPartQ() << " ciphertexts " << B << std::endl;
         evaluation_phase_begins();
+        // argv[8] = G > 0 (HIP backend only): the ciphertexts in LOCKSTEP, G at a time as one ciphertext whose towers hold G towers each
+        // (wide towers): cc->EvalMult runs once per group, every launch works on G towers
+        const int group = argc > 8 ? std::atoi(argv[8]) : 0;
         auto pass = [&] {
+#ifdef WITH_HIP
+            if (group > 0) {
+                for (int first = 0; first < B; first += group) {
+                    const int k = std::min(group, B - first);
+                    auto packed = [&](const std::vector<Ciphertext<DCRTPoly>>& v) {
+                        auto w = v[first]->CloneEmpty();
+                        std::vector<DCRTPoly> el;
+                        for (size_t e = 0; e < v[first]->GetElements().size(); ++e) {
+                            std::vector<const DCRTPoly*> towers;
+                            for (int i = 0; i < k; ++i)
+                                towers.push_back(&v[first + i]->GetElements()[e]);
+                            el.push_back(DCRTPoly::PackWide(towers));
+                        }
+                        w->SetElements(std::move(el));
+                        return w;
+                    };
+                    auto wa = packed(a), wb = packed(b);
+                    Ciphertext<DCRTPoly> wc;
+                    {
+                        hiprt::WidthScope scope(k);
+                        wc = cc->EvalMult(wa, wb);
+                    }
+                    for (int i = 0; i < k; ++i) {
+                        auto one = wc->CloneEmpty();
+                        std::vector<DCRTPoly> el;
+                        for (const auto& t : wc->GetElements())
+                            el.push_back(t.UnpackTower(i));
+                        one->SetElements(std::move(el));
+                        c[first + i] = one;
+                    }
+                }
+                (void)c[B - 1]->GetElements()[0].GetElementAtIndex(0);  // drain the device queue
+                return;
+            }
+#endif
 #pragma omp parallel for schedule(dynamic, 1)
             for (int i = 0; i < B; ++i)
                 c[i] = cc->EvalMult(a[i], b[i]);
             for (int i = 0; i < B; i += std::max(1, B / 4))
                 (void)c[i]->GetElements()[0].GetElementAtIndex(0);  // drain the device queue
         };
+        if (group > 0) {  // (the composites' first use at this level is a narrow evaluation)
+            auto warm = cc->EvalMult(a[0], b[0]);
+            (void)warm->GetElements()[0].GetElementAtIndex(0);
+        }
         pass();
         auto t0 = std::chrono::steady_clock::now();
         for (int r = 0; r < reps; ++r)

@@ -284,6 +284,20 @@ def test_shim_batch_of_ciphertexts_over_host_threads_on_emulator(tmp_path):
     assert ops > 50 and check.composite_calls >= 8  # (the timed pass: one composite key switch per EvalMult)
 
 
+def test_shim_batch_of_ciphertexts_in_lockstep_on_emulator(tmp_path):
+    """the same batch as WIDE towers: 8 ciphertexts, 3 at a time as one ciphertext whose towers hold 3 towers each (groups of 3, 3, 2) —
+    cc->EvalMult runs once per group; first and last product are the stock backend's, byte for byte (the stock program ignores the
+    group argument)"""
+    ops = check(tmp_path, "multbatch", 10, EMU, {"product 0": [0.5, 0.0, -3.0]}, extra=(4, 8, 1, 3), threads=1)
+    assert ops > 20 and check.composite_calls >= 4  # (the narrow warm-up + one composite key switch per group and pass)
+
+
+@pytest.mark.gpu
+def test_shim_batch_of_ciphertexts_in_lockstep_on_gpu(tmp_path):
+    ops = check(tmp_path, "multbatch", 14, HIP, {"product 0": [0.5, 0.0, -3.0]}, extra=(8, 32, 1, 12), threads=1)
+    assert ops > 20 and check.composite_calls >= 4
+
+
 @pytest.mark.gpu
 def test_shim_batch_of_ciphertexts_over_host_threads_on_gpu(tmp_path):
     ops = check(tmp_path, "multbatch", 14, HIP, {"product 0": [0.5, 0.0, -3.0]}, extra=(8, 32, 1), threads=8)
