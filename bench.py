@@ -791,11 +791,12 @@ def cc_evalmult_leg(with_cpu, libpath):
         shutil.rmtree(tmp, ignore_errors=True)
         return {"error": txt}
     # the same 256 ciphertexts in lockstep: 64 at a time as one ciphertext of 64-tower towers, cc->EvalMult once per group, one host thread
-    wrate, wtxt = run(hip, os.path.join(tmp, "w256.bin"), 256, 10, 1, hipenv, group=64)
+    # (the same OpenMP team as the threaded run: pke's key generation draws from thread-local PRNGs, equal teams give equal keys)
+    wrate, wtxt = run(hip, os.path.join(tmp, "w256.bin"), 256, 10, 8, hipenv, group=64)
     threaded = rate
     if wrate is not None:
         same = open(os.path.join(tmp, "w256.bin"), "rb").read() == open(os.path.join(tmp, "h256.bin"), "rb").read()
-        lock = {"ops_per_s": round(wrate, 1), "group": 64, "host_threads": 1,
+        lock = {"ops_per_s": round(wrate, 1), "group": 64, "host_threads": 1,  # (one thread issues the group's launches)
                 "parity": "first and last product identical byte for byte to the threaded run's" if same else "MISMATCH vs the threaded run"}
         if same:
             rate = max(rate, wrate)
