@@ -48,7 +48,8 @@ def parse():
     ap.add_argument("--no-bootstrap", action="store_true",
                     help="skip the EvalBootstrap leg (BASELINE configs[3] shape through the reference's CryptoContext on the HIP backend of DCRTPoly)")
     ap.add_argument("--bootstrap-logn", type=int, default=17)
-    ap.add_argument("--bootstrap-batch", type=int, default=8, help="ciphertexts per GPU in the bootstrap leg (BASELINE configs[3]: 64; 8 keeps the default run short)")
+    ap.add_argument("--bootstrap-batch", type=int, default=16, help="ciphertexts per GPU in the bootstrap leg (BASELINE configs[3]: 64; 16 keeps the default run short "
+                                                                     "and the lockstep evaluation's workspaces small)")
     ap.add_argument("--bootstrap-threads", type=int, default=8, help="host threads (= HIP streams) the rank's ciphertexts are spread over")
     ap.add_argument("--no-cc-evalmult", action="store_true",
                     help="skip the leg that runs BASELINE configs[2]'s EvalMult through the reference's CryptoContext on the HIP backend")
