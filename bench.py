@@ -48,8 +48,9 @@ def parse():
     ap.add_argument("--no-bootstrap", action="store_true",
                     help="skip the EvalBootstrap leg (BASELINE configs[3] shape through the reference's CryptoContext on the HIP backend of DCRTPoly)")
     ap.add_argument("--bootstrap-logn", type=int, default=17)
-    ap.add_argument("--bootstrap-batch", type=int, default=16, help="ciphertexts per GPU in the bootstrap leg (BASELINE configs[3]: 64; 16 keeps the default run short "
-                                                                     "and the lockstep evaluation's workspaces small)")
+    ap.add_argument("--bootstrap-batch", type=int, default=64, help="ciphertexts per GPU in the bootstrap leg (BASELINE configs[3]: 512 over 8 GPUs = 64 per GPU; "
+                                                                     "the driver's 1-GPU run is one rank's share)")
+    ap.add_argument("--bootstrap-group", type=int, default=0, help="ciphertexts per wide (lockstep) evaluation in the bootstrap leg; 0 = the rank's whole slice")
     ap.add_argument("--bootstrap-threads", type=int, default=8, help="host threads (= HIP streams) the rank's ciphertexts are spread over")
     ap.add_argument("--no-cc-evalmult", action="store_true",
                     help="skip the leg that runs BASELINE configs[2]'s EvalMult through the reference's CryptoContext on the HIP backend")
@@ -669,13 +670,17 @@ def free_port():
         return sk.getsockname()[1]
 
 
-def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev, with_cpu, libpath):
+STOCK_BOOT_SO = os.path.join(ROOT, "tests", "hal", "_build", "libfhe_boot_batch_stock.so")  # TEST-ONLY: the same source on the stock backend
+
+
+def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev, with_cpu, libpath, group=0):
     """BASELINE configs[3] as north_star states it: a BATCH of ciphertexts bootstrapped through the reference's own API
     (cc->EvalBootstrap at N = 2^17, 2^16 slots, {4,4}, SPARSE_TERNARY, FLEXIBLEAUTO: benchmark/src/ckks-bootstrapping.cpp:70) on the HIP backend
     of DCRTPoly, `per_gpu` ciphertexts per rank spread over `threads` host threads (one HIP stream each); with several ranks the
     relinearisation + rotation key set is generated on rank 0 only and replicated by scatter + all-gather over RCCL/xGMI into key
-    objects that never had words (openfhe-development_amd/boot_batch.py, hal/bootstrap_batch.cpp).  Parity at N = 1: the bootstrapped
-    ciphertext 0 against the same program on the stock backend, byte for byte; every output is decrypted and checked."""
+    objects that never had words (openfhe-development_amd/boot_batch.py, hal/bootstrap_batch.cpp).  Parity, computed in this run: every
+    output of the lockstep (wide) pass against the threaded (narrow) pass's word for word; at N = 1 the narrow pass's ciphertext 0
+    against the same batch on the stock backend (same PRNG, same OpenMP team), byte for byte; every output decrypted and checked."""
     import subprocess
     import tempfile
     from openfhe_amd import boot_batch as bb
@@ -690,18 +695,28 @@ def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev,
                     torch_device=tdev if tdev is not None else "cpu", dump_path=None, warmup=1, key_threads=key_threads)
     h = r.pop("handle")
     keep_keys = r.pop("keys", None)  # (the replicated key tensor: the key towers are windows of it until h.close())
-    single = h.single_thread_latency() / max(1, r["ciphertexts"])  # latency of one bootstrap: the same slice on one thread, one stream
+    h.save_outputs()  # the narrow (threaded) pass's outputs: the lockstep pass is compared with them word for word below
+    ct0 = os.path.join(tmp, "hip_ct0.bin")
+    h.dump(ct0, 0, 1)
+    # latency of one bootstrap: ciphertexts of the slice on one thread, one stream (at most 8 of them: the figure is per bootstrap)
+    single = h.single_thread_latency() / max(1, r["ciphertexts"])
     threaded_rate = r["bootstraps_per_s"]
     # the same ciphertexts in LOCKSTEP: one ciphertext whose towers hold all of the rank's towers, cc->EvalBootstrap runs once, every launch
     # works on K towers and every key is read once for all (wide towers; the passes above were the narrow first use of
     # every composite).  The rank's figure is the better of the two ways of running the batch.
     wide = None
     try:
-        wsec = h.bootstrap_wide(0, 2)
-        wide = {"seconds_per_pass": round(wsec, 4), "bootstraps_per_s": round(r["ciphertexts"] / wsec, 2), "group": r["ciphertexts"],
+        wsec = h.bootstrap_wide(group, 2)
+        ndiff = h.compare_saved()
+        wide = {"seconds_per_pass": round(wsec, 4), "bootstraps_per_s": round(r["ciphertexts"] / wsec, 2),
+                "group": group if 0 < group < r["ciphertexts"] else r["ciphertexts"],
                 "max_abs_error_vs_message": max(h.check(i)[0] for i in range(r["ciphertexts"])),
-                "how": "one cc->EvalBootstrap on a ciphertext of K-tower towers, one host thread; outputs byte-identical to the narrow path "
-                       "(tests/test_multi_gpu_gloo.py, profiles/r03_wide_n.txt)"}
+                "parity": (f"all {r['ciphertexts']} outputs identical word for word to the threaded (narrow) pass's outputs of the same ciphertexts "
+                           "(compared in this run, every limb on the host)" if ndiff == 0 else
+                           f"MISMATCH: {ndiff} of {r['ciphertexts']} outputs differ from the narrow pass's"),
+                "how": "one cc->EvalBootstrap per group on a ciphertext of K-tower towers, one host thread"}
+        if ndiff != 0:
+            wide["bootstraps_per_s_unverified"] = wide.pop("bootstraps_per_s")  # a figure without parity is not reported as the rate
     except Exception as e:
         wide = {"error": f"{type(e).__name__}: {e}"}
     rate = max(threaded_rate, wide.get("bootstraps_per_s", 0.0))
@@ -725,36 +740,31 @@ def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev,
             res[k] = r[k]
     h.close()
     del keep_keys
-    if with_cpu and rank == 0 and world == 1 and os.path.exists(bb.STOCK_SO):
-        # parity + CPU baseline: the SAME program twice as separate processes with the same OpenMP environment (pke's samplers read
-        # thread-local PRNGs, so the keys are reproduced only by equal teams): ciphertext 0 bootstrapped on the HIP backend and on
-        # the stock backend, the two results compared byte for byte
+    if with_cpu and rank == 0 and world == 1 and os.path.exists(STOCK_BOOT_SO):
+        # parity + CPU baseline: the SAME batch on the stock backend in a process of its own — same deterministic PRNG, same OpenMP
+        # team during set-up, encryption and key generation (pke's samplers read thread-local PRNGs: equal teams give equal keys), all
+        # `total` ciphertexts encrypted, ciphertext 0 bootstrapped (the reference's best team) and compared byte for byte with
+        # ciphertext 0 of THIS run's narrow pass (which the lockstep pass was compared with above)
         cthreads = min(32, os.cpu_count() or 1)
         env = dict(os.environ, OMP_NUM_THREADS=str(cthreads))
-        secs, dumps, errs = {}, {}, ""
-        for tag, so in (("hip", "bb.HIP_SO"), ("stock", "bb.STOCK_SO")):
-            dumps[tag] = os.path.join(tmp, tag + ".bin")
-            code = (f"import sys; sys.path.insert(0, {ROOT!r}); from openfhe_amd import boot_batch as bb; "
-                    f"r = bb.run_rank({logN}, {slots}, 1, 1, 1, 0, {prng!r}, so={so}, dump_path={dumps[tag]!r}, warmup=0); "
-                    "print('seconds', r['seconds_per_pass'])")
-            p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1500)
-            m = [ln for ln in p.stdout.split("\n") if ln.startswith("seconds")]
-            if p.returncode == 0 and m:
-                secs[tag] = float(m[0].split()[1])
-            else:
-                errs += f"{tag}: {(p.stdout + p.stderr)[-300:]} "
-        if "stock" in secs:
-            csec = secs["stock"]
+        env.pop("FHE_HAL_REQUIRE_DEVICE", None)
+        sdump = os.path.join(tmp, "stock_ct0.bin")
+        code = (f"import sys; sys.path.insert(0, {ROOT!r}); from openfhe_amd import boot_batch as bb; "
+                f"r = bb.run_rank({logN}, {slots}, {total}, 1, 1, 0, {prng!r}, so={STOCK_BOOT_SO!r}, dump_path={sdump!r}, warmup=0, "
+                f"key_threads={key_threads}, keep=1, eval_threads={cthreads}); print('seconds', r['seconds_per_pass'])")
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=2400)
+        m = [ln for ln in p.stdout.split("\n") if ln.startswith("seconds")]
+        if p.returncode == 0 and m:
+            csec = float(m[0].split()[1])
             res["cpu_baseline"] = {"value": round(1.0 / csec, 4), "unit": "bootstraps/s", "seconds_per_bootstrap": round(csec, 3), "cores": cthreads,
                                    "kind": "reference", "sample": "ciphertext 0 of the batch, the same program on the stock backend (oracle/_ref), 1 bootstrap"}
             res["speedup_vs_cpu"] = round(rate * csec, 1)
-        if "hip" in secs and "stock" in secs:
-            same = open(dumps["hip"], "rb").read() == open(dumps["stock"], "rb").read()
-            res["parity"] = ("bootstrapped ciphertext 0 identical byte for byte to the stock backend's (same program, same OpenMP team, deterministic "
-                             "PRNG); every output of the batch decrypted and compared with its message" if same
-                             else "MISMATCH vs the stock backend (ciphertext 0)")
-        elif errs:
-            res["parity"] = "byte comparison failed to run: " + errs
+            same = open(ct0, "rb").read() == open(sdump, "rb").read()
+            res["parity"] = ("ciphertext 0 of this run's narrow pass identical byte for byte to the stock backend's bootstrap of the same batch's "
+                             "ciphertext 0 (same PRNG, same OpenMP team); every output of the batch decrypted and compared with its message"
+                             if same else "MISMATCH vs the stock backend (ciphertext 0)")
+        else:
+            res["parity"] = "byte comparison failed to run: " + (p.stdout + p.stderr)[-300:]
     import shutil
     shutil.rmtree(tmp, ignore_errors=True)
     return res
@@ -1148,6 +1158,8 @@ def main():
                        "parallelism": f"batch-sharded x{world}, no data-path collective"},
             "hbm_roofline_frac_fwd_inv": round(value / world / HBM_PEAK_GBPS, 4),
             "roofline": roof, "cpu_baseline": cpu, "evalmult": em,
+            # the legs that run the reference's own CryptoContext on the backend need the reference-built test programs
+            "hal_build": "present" if os.path.exists(os.path.join(ROOT, "tests", "hal", "_build", "shim_ckks_hip")) else "absent",
             "hadamard": hadamard, "parity_at_full_size": roundtrip, "ms_per_step_per_rank": per_rank_ms,
             # ONE rule for every cpu_baseline of this line: the reference runs with its best OpenMP team out of {8, 16, 32, 64, 128, all
             # logical cores}.  Legs whose probe takes seconds search it live (headline NTT, linear transform, BFV: "cores" = the winner);
@@ -1178,7 +1190,7 @@ def main():
 
         def give_up():
             emit({"error": f"the sharded bootstrap leg did not finish within {limit:.0f} s on {world} ranks: line printed without it"}, None, None)
-            os._exit(0)
+            os._exit(3)  # (the headline line is out; a stalled collective is a failure of the run, not a clean exit)
 
         dog = threading.Timer(limit, give_up) if world > 1 else None
         if dog is not None:
@@ -1186,7 +1198,7 @@ def main():
             dog.start()
         try:  # every rank takes part: the batch is sharded, the key set travels from rank 0
             boot = bootstrap_batch_leg(a.bootstrap_logn, a.bootstrap_batch, a.bootstrap_threads, rank, world, device, dist, tdev,
-                                       not a.no_cpu_baseline, lib.path)
+                                       not a.no_cpu_baseline, lib.path, group=a.bootstrap_group)
         except Exception as e:
             boot = {"error": f"{type(e).__name__}: {e}"}
         if dog is not None:

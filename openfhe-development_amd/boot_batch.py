@@ -13,15 +13,17 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIP_SO = os.path.join(ROOT, "openfhe-development_amd", "hal", "_build", "libfhe_boot_batch_hip.so")
-STOCK_SO = os.path.join(ROOT, "tests", "hal", "_build", "libfhe_boot_batch_stock.so")
 u32, u64, vp = C.c_uint32, C.c_uint64, C.c_void_p
 
 
 class BootBatch:
-    def __init__(self, so, logN, slots, budget=(4, 4), levels_after=5, prng=None, device=0):
+    def __init__(self, so, logN, slots, budget=(4, 4), levels_after=5, prng=None, device=0, omp_threads=None):
         if not os.path.exists(so):
             raise RuntimeError(f"{so} not built (./build.sh hal needs the reference sources)")
         L = self.L = C.CDLL(so)
+        L.fbb_set_omp_threads.argtypes = [C.c_int]
+        if omp_threads:  # (before the context exists: key-pair generation already runs pke's OpenMP regions)
+            L.fbb_set_omp_threads(omp_threads)
         L.fbb_create.restype, L.fbb_create.argtypes = vp, [u32, u32, u32, u32, u32, C.c_char_p, C.c_int]
         L.fbb_error.restype, L.fbb_error.argtypes = C.c_char_p, [vp]
         L.fbb_destroy.argtypes = [vp]
@@ -39,6 +41,8 @@ class BootBatch:
         if hasattr(L, "fbb_bootstrap_wide"):
             L.fbb_bootstrap_wide.restype, L.fbb_bootstrap_wide.argtypes = C.c_double, [vp, u32, C.c_int]
         L.fbb_check.restype, L.fbb_check.argtypes = C.c_double, [vp, u32, C.POINTER(C.c_double)]
+        L.fbb_save_outputs.argtypes = [vp]
+        L.fbb_compare_saved.restype, L.fbb_compare_saved.argtypes = C.c_long, [vp]
         L.fbb_dump.argtypes = [vp, C.c_char_p, u32, u32]
         self.h = L.fbb_create(logN, slots, budget[0], budget[1], levels_after, prng.encode() if prng else None, device)
         self._ok(0)
@@ -99,6 +103,16 @@ class BootBatch:
         self._ok(0 if s >= 0 else 1)
         return s
 
+    def save_outputs(self):
+        """keeps the current outputs for compare_saved (the next pass produces new objects)"""
+        self._ok(self.L.fbb_save_outputs(self.h))
+
+    def compare_saved(self):
+        """number of current outputs that differ from the saved ones in any word (host comparison, limb by limb); -1: nothing saved"""
+        n = self.L.fbb_compare_saved(self.h)
+        self._ok(0)
+        return int(n)
+
     def check(self, i):
         vals = (C.c_double * 8)()
         return self.L.fbb_check(self.h, i, vals), list(vals)
@@ -113,17 +127,19 @@ class BootBatch:
 
 
 def run_rank(logN, slots, total, threads, reps, device, prng, dist=None, torch_device="cpu", budget=(4, 4), levels_after=5, so=HIP_SO,
-             dump_path=None, warmup=1, key_threads=None):
+             dump_path=None, warmup=1, key_threads=None, keep=None, eval_threads=None):
     """One rank of the sharded batch.  dist: torch.distributed (initialised) or None for a single process.  Returns a dict of
     timings; with dump_path the rank's bootstrapped ciphertexts are written there (tests).  key_threads: the OpenMP team during
-    set-up, encryption and key generation (pke draws from thread-local PRNGs there: equal teams give equal keys)."""
+    set-up, encryption and key generation (pke draws from thread-local PRNGs there: equal teams give equal keys); eval_threads: the
+    team of pke's inner loops during the bootstraps (default: unchanged).  keep: bootstrap only the first `keep` ciphertexts of the
+    rank's slice (all `total` are still encrypted, so the kept ones are the batch's — the byte-comparison reference of bench.py)."""
     from . import shard
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
     t0 = time.perf_counter()
-    bb = BootBatch(so, logN, slots, budget, levels_after, prng, device)
-    if key_threads:
-        bb.L.fbb_set_omp_threads(key_threads)
+    bb = BootBatch(so, logN, slots, budget, levels_after, prng, device, omp_threads=key_threads)
     lo, hi = shard.shard_range(total, rank, world)
+    if keep is not None:
+        hi = min(hi, lo + keep)
     bb.encrypt(total, lo, hi - lo)  # (before any key generation: every rank draws the same randomness for the same ciphertext)
     t_setup = time.perf_counter() - t0
     res = {"rank": rank, "world": world, "ciphertexts": hi - lo, "setup_s": round(t_setup, 2)}
@@ -164,6 +180,8 @@ def run_rank(logN, slots, total, threads, reps, device, prng, dist=None, torch_d
         res["key_replication_s"] = round(t_rep, 3)
         res["key_replication_GBps"] = round(keys.numel() * 8 / 1e9 / max(t_rep, 1e-9), 1)
         dist.barrier()
+    if eval_threads:
+        bb.L.fbb_set_omp_threads(eval_threads)
     sec = bb.bootstrap_all(threads, reps, warmup)
     res["seconds_per_pass"] = sec
     res["bootstraps_per_s"] = (hi - lo) / sec if sec > 0 else 0.0

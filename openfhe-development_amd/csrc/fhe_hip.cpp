@@ -253,6 +253,7 @@ struct fhe_ctx {
     TwPair* d_twRowInv = nullptr; // ... inverse
     uint64_t* d_q     = nullptr;  // [L]
     LimbConst* d_lc   = nullptr;  // [L]
+    uint64_t* d_red   = nullptr;  // [L] redM | redR << 32: quotient estimate of the static NTT kernels (ntt_static.h)
     uint64_t* d_mu128 = nullptr;  // [L][2]
     std::vector<void*> owned;     // every device allocation made for tables (freed in destroy)
     // cached per-level rescale tables (ckksrns-cryptoparameters.cpp:60-81): sizeQl -> {A, B} device arrays
@@ -302,7 +303,7 @@ extern "C" fhe_status fhe_ctx_create(uint32_t logN, uint32_t nLimbs, const uint6
     const size_t rowPerLimb = rowTables ? (size_t)(N >> kTileLog) * kRowTwSlots * kThreads : 0;
     std::vector<TwPair> twRow(rowPerLimb * nLimbs), twRowInv(rowPerLimb * nLimbs);
     std::vector<LimbConst> lc(nLimbs);
-    std::vector<uint64_t> mu(2 * (size_t)nLimbs);
+    std::vector<uint64_t> mu(2 * (size_t)nLimbs), red(nLimbs);
     // one thread per limb at most: a team of every host core would keep spinning after the region (libgomp's default
     // wait policy) and slow down the caller's kernel launches for a while
 #pragma omp parallel for schedule(dynamic) num_threads(std::max(1, std::min<int>((int)nLimbs, 32)))
@@ -338,6 +339,15 @@ extern "C" fhe_status fhe_ctx_create(uint32_t logN, uint32_t nLimbs, const uint6
         fin[2 * l + 1]      = TwPair{w1n, host::shoup(w1n, ql)};
         lc[l]               = LimbConst{ql, host::barrett_mu(ql), host::bitlen(ql), 0};
         host::mu128(ql, &mu[2 * l]);
+        // k = (x.hi * redM) >> (32 + redR) is floor(x / q) or one less for every 64-bit x once bitlen(q) >= 36:
+        // redR = bitlen(q) - 33, redM = floor(2^(64 + redR) / q) < 2^32; smaller moduli take the ladder (redR = 255)
+        const uint32_t bl = host::bitlen(ql);
+        if (bl >= 36) {
+            const uint32_t rr = bl - 33;
+            red[l] = (uint64_t)((((unsigned __int128)1) << (64 + rr)) / ql) | ((uint64_t)rr << 32);
+        }
+        else
+            red[l] = (uint64_t)255 << 32;
     }
     c->h_fin = fin;
     fhe_status s;
@@ -348,6 +358,7 @@ extern "C" fhe_status fhe_ctx_create(uint32_t logN, uint32_t nLimbs, const uint6
         (rowTables && (s = upload(c, twRowInv.data(), twRowInv.size() * sizeof(TwPair), (void**)&c->d_twRowInv))) ||
         (s = upload(c, c->q.data(), nLimbs * sizeof(uint64_t), (void**)&c->d_q)) ||
         (s = upload(c, lc.data(), nLimbs * sizeof(LimbConst), (void**)&c->d_lc)) ||
+        (s = upload(c, red.data(), nLimbs * sizeof(uint64_t), (void**)&c->d_red)) ||
         (s = upload(c, mu.data(), mu.size() * sizeof(uint64_t), (void**)&c->d_mu128))) {
         fhe_ctx_destroy(c);
         return s;
@@ -536,8 +547,10 @@ static void plan_pass(bool inverse, bool layoutA, uint32_t logN, uint32_t T, Pas
     pp->nSteps = n;
 }
 
-// lazy-reduction schedule of a forward pass for the fast kernel: a butterfly adds at most 2q to the bound of
-// its operands and 16q < 2^64, so a step of r stages needs a correction only when bound + 2r would exceed 16.
+// lazy-reduction schedule of a forward pass (the static kernels derive the same at compile time, ntt_static.h SPlan): a
+// butterfly with the truncated quotient adds at most 3q to the bound of its operands and 16q < 2^64, so a step of r
+// stages needs a correction (the `a` inputs of its first stage below 2q) only when bound + 3r would exceed 16.  A column
+// pass of a two-pass ring ends by bringing its residues below 2q (it is HBM-bound: the reduction is free there).
 // `bound` (in units of q) is the bound of the pass input on entry and of its output on return.
 static void schedule_fwd(PassPlan& pp, uint32_t logN, uint32_t* bound) {
     pp.inBound = *bound;
@@ -546,15 +559,17 @@ static void schedule_fwd(PassPlan& pp, uint32_t logN, uint32_t* bound) {
         if (st.bHi < st.bLo)
             continue;
         const uint32_t r = (uint32_t)(st.bHi - st.bLo + 1);
-        if (*bound + 2 * r <= 16) {
+        if (*bound + 3 * r <= 16) {
             st.mode = 0;
-            *bound += 2 * r;
+            *bound += 3 * r;
         }
         else {
             st.mode = 1;
-            *bound  = 8 + 2 * r;
+            *bound  = 2 + 3 * r;
         }
     }
+    if (pp.layoutA && logN >= (uint32_t)kTileLog)
+        *bound = 2;
     (void)logN;
 }
 // twiddle index = 2^s + (j >> (Fj+4))...: lane-independent iff no lane-dependent bit of j lies above the field
@@ -589,6 +604,7 @@ static uint32_t fill_pass_args(const fhe_ctx* c, const PassPlan& pp, bool invers
     a.tw       = inverse ? c->d_twInv : c->d_tw;
     a.twRow    = inverse ? c->d_twRowInv : c->d_twRow;
     a.q        = c->d_q;
+    a.red      = c->d_red;
     a.fin      = c->d_fin;
     a.logN     = c->logN;
     a.T        = pp.T;
@@ -622,7 +638,7 @@ static int static_mode(const fhe_ctx* c, const PassPlan& pp, bool inverse) {
     const bool twoPass = c->logN > (uint32_t)kTileLog;
     // (forward classes: 1 = canonical input, 9 = at most 9q, 16 = anything below 16q; a 4-stage first step sweeps
     // for every class above 1, so T = 12 has one instance for both)
-    const int fclass = pp.inBound <= 1 ? 1 : (pp.inBound <= 9 || pp.T == 12) ? 9 : 16;
+    const int fclass = pp.inBound <= 1 ? 1 : 9;  // (9 = what a column pass leaves: below 2q since round 4)
     return inverse ? ((pp.layoutA || !twoPass) ? 1 : 0) : fclass;
 }
 static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse, const uint64_t* xin, uint64_t* xout,
@@ -895,7 +911,7 @@ extern "C" fhe_status fhe_time_ntt(fhe_ctx* c, uint64_t* x, const uint32_t* li, 
         plan_pass(inv, colPass, c->logN, colPass ? T1 : T2, &pp);
         mark_uniform(pp, c->logN);
         if (!inv) {
-            uint32_t bound = colPass ? 1u : 1u + 2u * T1;  // the row pass sees what the column pass leaves
+            uint32_t bound = colPass ? 1u : 2u;  // the row pass sees what the column pass leaves
             schedule_fwd(pp, c->logN, &bound);
             pp.outBound = bound;
         }

@@ -62,6 +62,7 @@ struct NttPassArgs {
     const TwPair* tw;     // [ctxLimbs][N], forward or inverse table
     const TwPair* twRow;  // [ctxLimbs][N/4096][15][256] lane-major copy for the row pass's last/first step (ntt_static.h), or null
     const uint64_t* q;    // [ctxLimbs]
+    const uint64_t* red;  // [ctxLimbs] quotient-estimate constants of the static kernels: redM | redR << 32 (ntt_static.h)
     const TwPair* fin;    // inverse only: [ctxLimbs][2] = {N^-1, Table_inv[1]*N^-1}
     uint32_t logN;
     uint32_t T;           // stages in this pass (tile = 2^T points x 2^(12-T) transforms)

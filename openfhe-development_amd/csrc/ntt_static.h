@@ -23,12 +23,17 @@ namespace fhe {
 #ifndef FHE_PINNED_ASM
 struct BflyConst {
     uint32_t nql, nqh;
-    uint64_t twoq, ntwoq;
+    uint64_t q, twoq, ntwoq, threeq;
+    uint32_t redM, redR;
 };
 struct BflyZero {
     uint32_t z0, z1;
 };
 #endif
+// Round 4 lazy ranges (tools/gen_ntt_asm.py): a forward butterfly with the truncated Shoup quotient adds at most 3q to the
+// bound of its `a` input; a step whose stages would push a bound past 16q (< 2^64) first brings the 8 `a` inputs of its
+// first stage below 2q with one quotient estimate each.
+constexpr int kFwdGrow = 3;
 
 // compile-time plan of one pass: the same grouping of the T stages into register-resident steps as plan_pass()
 template <bool LA, bool INV, int T>
@@ -60,10 +65,10 @@ struct SPlan {
     static constexpr int boundBefore(int i, int bin) {
         int b = bin;
         for (int j = 0; j < i; ++j)
-            b = (b + 2 * size(j) <= 16) ? b + 2 * size(j) : 8 + 2 * size(j);
+            b = (b + kFwdGrow * size(j) <= 16) ? b + kFwdGrow * size(j) : 2 + kFwdGrow * size(j);
         return b;
     }
-    static constexpr bool sweep(int i, int bin) { return boundBefore(i, bin) + 2 * size(i) > 16; }
+    static constexpr bool sweep(int i, int bin) { return boundBefore(i, bin) + kFwdGrow * size(i) > 16; }
     static constexpr int outBound(int bin) { return boundBefore(nst, bin); }
 };
 
@@ -91,7 +96,7 @@ FHE_HD constexpr uint32_t lds_pad(uint32_t I) {
 // `bnd` carries the bounds (units of q) through the stages of a step in the C++ build; the generated gfx950 code has
 // them folded into its constants.
 FHE_HD void inv_lazy_stage_cpp(int B, uint64_t (&r)[16], const TwPair (&w)[8], const BflyConst c, uint32_t (&bnd)[16]) {
-    const uint64_t nq = ((uint64_t)c.nqh << 32) | c.nql, q = c.twoq >> 1;
+    const uint64_t nq = ((uint64_t)c.nqh << 32) | c.nql, q = c.q;
     for (int g = 0; g < (8 >> B); ++g)
         for (int lo = 0; lo < (1 << B); ++lo) {
             const int k0 = (g << (B + 1)) | lo, k1 = k0 | (1 << B);
@@ -106,7 +111,7 @@ FHE_HD void inv_lazy_stage_cpp(int B, uint64_t (&r)[16], const TwPair (&w)[8], c
         }
 }
 FHE_HD void inv_lazy_end_cpp(uint64_t (&r)[16], const BflyConst c, uint32_t (&bnd)[16]) {
-    const uint64_t q = c.twoq >> 1;
+    const uint64_t q = c.q;
     for (int k = 0; k < 16; ++k)
         while (bnd[k] > 2u) {
             bnd[k] >>= 1;
@@ -177,7 +182,7 @@ FHE_HD void run_inv_lazy_end(uint64_t (&r)[16], const BflyConst c, uint32_t (&bn
 template <int BLO>
 FHE_HD void run_last_inv_stage(uint64_t (&r)[16], const TwPair nInv, const TwPair w1n, const BflyConst c, const BflyZero z,
                                uint32_t (&bnd)[16]) {
-    const uint64_t q = c.twoq >> 1;
+    const uint64_t q = c.q;
 #ifdef FHE_PINNED_ASM
     (void)bnd;
     if constexpr (BLO == 0) inv_lazy_pre_b3_lo0(r, c);
@@ -214,18 +219,27 @@ FHE_HD void run_last_inv_stage(uint64_t (&r)[16], const TwPair nInv, const TwPai
 #endif
 }
 
-// conditional subtraction of m on the 8 residues whose index has bit B clear (the `a` inputs of a stage on bit B)
+// the 8 residues whose index has bit B clear (the `a` inputs of a stage on bit B) below 2q (any 64-bit value before)
 template <int B>
-FHE_HD void run_csub8_a(uint64_t (&r)[16], uint64_t m) {
+FHE_HD void run_red8_a(uint64_t (&r)[16], const BflyConst c) {
 #ifdef FHE_PINNED_ASM
-    if constexpr (B == 0) csub8_a0(r, m);
-    if constexpr (B == 1) csub8_a1(r, m);
-    if constexpr (B == 2) csub8_a2(r, m);
-    if constexpr (B == 3) csub8_a3(r, m);
+    if constexpr (B == 0) red8_a0(r, c);
+    if constexpr (B == 1) red8_a1(r, c);
+    if constexpr (B == 2) red8_a2(r, c);
+    if constexpr (B == 3) red8_a3(r, c);
 #else
     for (int k = 0; k < 16; ++k)
         if (!((k >> B) & 1))
-            r[k] = csub2(r[k], m);
+            r[k] %= c.twoq;
+#endif
+}
+// every residue below 2q (any 64-bit value before)
+FHE_HD void run_red16(uint64_t (&r)[16], const BflyConst c) {
+#ifdef FHE_PINNED_ASM
+    red16(r, c);
+#else
+    for (int k = 0; k < 16; ++k)
+        r[k] %= c.twoq;
 #endif
 }
 // residues I and I|8 times the Shoup pair `cw`, lazily reduced to [0,2q)
@@ -361,7 +375,7 @@ FHE_HD void load_stage_tw(TwPair (&w)[8], const TwSrc ts, uint32_t j0, uint32_t 
     }
 }
 
-template <bool LA, bool INV, int T, int I, int B, bool ENDS>
+template <bool LA, bool INV, int T, int I, int B, bool ENDS, bool LAZYOUT>
 FHE_HD void exec_stage(uint64_t (&r)[16], const TwPair (&w)[8], const BflyConst c, const BflyZero z, uint32_t (&bnd)[16]) {
     using S = StageInfo<LA, INV, T, I, B>;
     using P = SPlan<LA, INV, T>;
@@ -373,8 +387,9 @@ FHE_HD void exec_stage(uint64_t (&r)[16], const TwPair (&w)[8], const BflyConst 
             return;
 #endif
             run_stage<INV, S::uni, B, P::bLo(I)>(r, w, c, z, bnd);
-            // a lazy inverse step ends with the reductions back below 2q (after its last stage)
-            if constexpr (INV && B == P::bHi(I))
+            // a lazy inverse step ends with the reductions back below 3q (after its last stage); the last step of a row
+            // pass that the column pass follows leaves them to that (HBM-bound) pass
+            if constexpr (INV && B == P::bHi(I) && !(LAZYOUT && I == P::nst - 1))
                 run_inv_lazy_end<P::bLo(I), P::bHi(I)>(r, c, bnd);
         }
     }
@@ -383,7 +398,7 @@ FHE_HD void exec_stage(uint64_t (&r)[16], const TwPair (&w)[8], const BflyConst 
 // one register-resident step I of the plan: its stages, highest field bit first (forward) / lowest first (inverse);
 // the twiddle loads of a stage are issued before the butterflies of the previous stage (the asm blocks are
 // scheduling barriers, so the order written here is the order executed)
-template <bool LA, bool INV, int T, int I, bool ENDS>
+template <bool LA, bool INV, int T, int I, bool ENDS, bool LAZYOUT>
 FHE_HD void run_step(uint64_t (&r)[16], const TwSrc ts, uint32_t j0, uint32_t logN, const BflyConst c, const BflyZero z) {
     TwPair w0[8], w1[8], w2[8], w3[8];
     uint32_t bnd[16];  // lazy bounds of an inverse step (C++ build only; every step starts below 2q)
@@ -392,12 +407,12 @@ FHE_HD void run_step(uint64_t (&r)[16], const TwSrc ts, uint32_t j0, uint32_t lo
     constexpr int B0 = INV ? 0 : 3, B1 = INV ? 1 : 2, B2 = INV ? 2 : 1, B3 = INV ? 3 : 0;
     load_stage_tw<LA, INV, T, I, B0, ENDS>(w0, ts, j0, logN);
     load_stage_tw<LA, INV, T, I, B1, ENDS>(w1, ts, j0, logN);
-    exec_stage<LA, INV, T, I, B0, ENDS>(r, w0, c, z, bnd);
+    exec_stage<LA, INV, T, I, B0, ENDS, LAZYOUT>(r, w0, c, z, bnd);
     load_stage_tw<LA, INV, T, I, B2, ENDS>(w2, ts, j0, logN);
-    exec_stage<LA, INV, T, I, B1, ENDS>(r, w1, c, z, bnd);
+    exec_stage<LA, INV, T, I, B1, ENDS, LAZYOUT>(r, w1, c, z, bnd);
     load_stage_tw<LA, INV, T, I, B3, ENDS>(w3, ts, j0, logN);
-    exec_stage<LA, INV, T, I, B2, ENDS>(r, w2, c, z, bnd);
-    exec_stage<LA, INV, T, I, B3, ENDS>(r, w3, c, z, bnd);
+    exec_stage<LA, INV, T, I, B2, ENDS, LAZYOUT>(r, w2, c, z, bnd);
+    exec_stage<LA, INV, T, I, B3, ENDS, LAZYOUT>(r, w3, c, z, bnd);
 }
 
 // lane geometry of a step whose register field sits at tile-index bit fI: tile index of register 0 and the
@@ -487,12 +502,17 @@ FHE_DEV void ntt_static_core(const NttPassArgs& a, uint32_t bid, uint64_t* lds, 
             sharedW = v.w, sharedWp = v.wp;
         }
     }
-    const BflyConst c{(uint32_t)nq, (uint32_t)(nq >> 32), twoq, 0 - twoq};
+    const uint64_t redc = FHE_ULOAD64(a.red, limb);  // {redM, redR} of the limb (fhe_ctx_create)
+    const BflyConst c{(uint32_t)nq, (uint32_t)(nq >> 32), q, twoq, 0 - twoq, twoq + q, (uint32_t)redc, (uint32_t)(redc >> 32)};
     BflyZero z{0, 0};
 #ifdef FHE_PINNED_ASM
     asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0" : "={v65}"(z.z0), "={v81}"(z.z1));
 #endif
     const bool canonOut = a.canonStep != 0xffffffffu;
+    // forward: bound class of the pass input (instance name 9 = what a column pass leaves: below 2q since round 4);
+    // inverse row pass that does not end the transform: its last step's reductions happen in the column pass
+    constexpr int BIN      = INV ? 0 : (MODE == 9 ? 2 : MODE);
+    constexpr bool LAZYOUT = INV && !LA && MODE == 0;
     const uint64_t* src = a.inDelta ? a.xin + (int64_t)tb * a.inDelta + ((uint64_t)(a.inFirst + (PRO ? 0u : rit)) << logN) + jbase
                                     : a.xin + (inRow << logN) + jbase;
     uint64_t* dst       = a.x + (outRow << logN) + jbase;
@@ -526,7 +546,7 @@ FHE_DEV void ntt_static_core(const NttPassArgs& a, uint32_t bid, uint64_t* lds, 
         if (acc) {                                                                                \
             _Pragma("unroll") for (int k = 0; k < 4; ++k) ov[k] = O[jr + ks4[k] * kstr];          \
         }                                                                                         \
-        _Pragma("unroll") for (int k = 0; k < 4; ++k) v[ks4[k]] = av[k] + (q << 3) - v[ks4[k]];   \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) v[ks4[k]] = av[k] + twoq - v[ks4[k]];       \
         epi_mul2<2 * G>(v, cpair, c, z);                                                          \
         epi_mul2<2 * G + 1>(v, cpair, c, z);                                                      \
         _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                           \
@@ -602,25 +622,26 @@ FHE_DEV void ntt_static_core(const NttPassArgs& a, uint32_t bid, uint64_t* lds, 
             const uint64_t* L = lds + lds_pad(Ib);                                           \
             _Pragma("unroll") for (int k = 0; k < 16; ++k) FHE_LDS_LD(r[k], L[lds_pad((uint32_t)k << fI)]);                  \
         }                                                                                                         \
-        /* lazy reduction: a forward butterfly's outputs are bounded by its `a` input + 2q whatever the `b` input  \
-           (< 2^64) is, so only the 8 `a` inputs of the step's first stage go back below 8q */                      \
-        if constexpr (!INV && P::sweep(I, MODE))                                                                 \
-            run_csub8_a<P::bHi(I)>(r, twoq << 2);                                                                 \
-        run_step<LA, INV, T, I, (INV && MODE == 1)>(r, ts, jbase + jrel, logN, c, z);                              \
+        /* an inverse column pass takes what the lazy row pass left (anything below 16q) */                        \
+        if constexpr (I == 0 && INV && LA)                                                                        \
+            run_red16(r, c);                                                                                      \
+        /* lazy reduction: a forward butterfly's outputs are bounded by its `a` input + 3q whatever the `b` input  \
+           (< 2^64) is, so only the 8 `a` inputs of the step's first stage go back below 2q */                      \
+        if constexpr (!INV && P::sweep(I, BIN))                                                                  \
+            run_red8_a<P::bHi(I)>(r, c);                                                                          \
+        run_step<LA, INV, T, I, (INV && MODE == 1), LAZYOUT>(r, ts, jbase + jrel, logN, c, z);                     \
         if constexpr (I == P::nst - 1) {                                                                          \
             if (canonOut) {                                                                                       \
                 if constexpr (INV)                                                                                \
                     run_csub16(r, q);                                                                             \
                 else {                                                                                            \
-                    constexpr int ob = P::outBound(MODE);                                                         \
-                    if constexpr (ob > 8) run_csub16(r, q << 3);                                                  \
-                    if constexpr (!EPI) { /* the epilogue takes values below 8q (A + 8q - r, then a Shoup product) */ \
-                        if constexpr (ob > 4) run_csub16(r, q << 2);                                              \
-                        if constexpr (ob > 2) run_csub16(r, q << 1);                                              \
+                    run_red16(r, c);                                                                              \
+                    if constexpr (!EPI) /* the epilogue takes values below 2q (A + 2q - r, then a Shoup product) */ \
                         run_csub16(r, q);                                                                         \
-                    }                                                                                             \
                 }                                                                                                 \
             }                                                                                                     \
+            else if constexpr (!INV && LA)                                                                        \
+                run_red16(r, c); /* the (HBM-bound) column pass hands the row pass values below 2q */             \
         }                                                                                                         \
         if constexpr (I == P::nst - 1 && RAWOUT) {                                                                \
             /* the caller takes the residues from r[] */                                                          \

@@ -35,7 +35,7 @@ struct Batch {
     KeyPair<DCRTPoly> kp;
     uint32_t slots = 0, depth = 0, logN = 0;
     std::vector<uint32_t> levelBudget;
-    std::vector<Ciphertext<DCRTPoly>> in, out;
+    std::vector<Ciphertext<DCRTPoly>> in, out, saved;
     uint32_t first = 0;
     std::string error;
 #ifdef WITH_HIP
@@ -336,6 +336,41 @@ double fbb_bootstrap_wide(void* h, uint32_t group, int reps) {
     b->error = "fbb_bootstrap_wide: the stock backend has no wide towers";
 #endif
     return sec;
+}
+// keeps the current outputs (of a narrow pass) for fbb_compare_saved: the objects stay alive, the next pass produces new ones
+int fbb_save_outputs(void* h) {
+    auto* b = static_cast<Batch*>(h);
+    return Guard(b, [&] { b->saved = b->out; });
+}
+// the current outputs (of a wide pass) against the saved ones, limb by limb and word for word on the host: the number of ciphertexts
+// that differ in any word, element count, limb count or format; -1 when nothing was saved or the counts differ
+long fbb_compare_saved(void* h) {
+    auto* b   = static_cast<Batch*>(h);
+    long diff = -1;
+    Guard(b, [&] {
+        if (b->saved.empty() || b->saved.size() != b->out.size())
+            return;
+        diff = 0;
+        for (size_t i = 0; i < b->out.size(); ++i) {
+            bool same = b->out[i] && b->saved[i] && b->out[i]->GetElements().size() == b->saved[i]->GetElements().size();
+            for (size_t e = 0; same && e < b->out[i]->GetElements().size(); ++e) {
+                const auto& x = b->out[i]->GetElements()[e];
+                const auto& y = b->saved[i]->GetElements()[e];
+                same = x.GetFormat() == y.GetFormat() && x.GetNumOfElements() == y.GetNumOfElements();
+                if (!same)
+                    break;
+                const auto& lx = x.GetAllElements();
+                const auto& ly = y.GetAllElements();
+                for (size_t l = 0; same && l < lx.size(); ++l) {
+                    same = lx[l].GetModulus() == ly[l].GetModulus() && lx[l].GetLength() == ly[l].GetLength();
+                    for (uint32_t j = 0; same && j < lx[l].GetLength(); ++j)
+                        same = lx[l][j] == ly[l][j];
+                }
+            }
+            diff += same ? 0 : 1;
+        }
+    });
+    return diff;
 }
 // decrypts output i of the rank's slice: the first 8 slots into vals; returns the largest absolute error against the message
 double fbb_check(void* h, uint32_t i, double* vals) {

@@ -11,6 +11,10 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# TEST-ONLY: hal/bootstrap_batch.cpp compiled against the stock libraries of oracle/_ref (the byte-for-byte reference)
+STOCK_BOOT_SO = os.path.join(ROOT, "tests", "hal", "_build", "libfhe_boot_batch_stock.so")
+HIP_LIB = os.path.join(ROOT, "openfhe-development_amd", "csrc", "libfhe_hip.so")
+EMU_LIB = os.path.join(ROOT, "tests", "emu", "libfhe_emu.so")
 
 WORKER = r'''
 import os, sys
@@ -259,7 +263,7 @@ def test_two_rank_sharded_bootstrap_batch_with_replicated_keys(tmp_path):
     import pytest
     sys.path.insert(0, ROOT)
     from openfhe_amd import boot_batch as bb
-    if not (os.path.exists(bb.HIP_SO) and os.path.exists(bb.STOCK_SO)):
+    if not (os.path.exists(bb.HIP_SO) and os.path.exists(STOCK_BOOT_SO)):
         pytest.skip("hal/_build/libfhe_boot_batch_hip.so not built (./build.sh hal needs the reference sources)")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -280,7 +284,7 @@ def test_two_rank_sharded_bootstrap_batch_with_replicated_keys(tmp_path):
 import sys; sys.path.insert(0, {ROOT!r})
 from openfhe_amd import boot_batch as bb
 r = bb.run_rank(8, 8, 2, 1, 1, 0, {os.path.join(ROOT, 'tests', 'hal', '_build', 'libdetprng.so')!r}, budget=(1, 1), levels_after=1,
-                dump_path={out + '.stock.bin'!r}, warmup=0, so=bb.STOCK_SO)
+                dump_path={out + '.stock.bin'!r}, warmup=0, so={STOCK_BOOT_SO!r})
 """], env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=600)
     assert ref.returncode == 0, ref.stdout + ref.stderr
     stock = open(out + ".stock.bin", "rb").read()
@@ -288,15 +292,16 @@ r = bb.run_rank(8, 8, 2, 1, 1, 0, {os.path.join(ROOT, 'tests', 'hal', '_build', 
     assert len(stock) > 10000 and got == stock, "a rank's bootstrapped ciphertext differs from the stock backend's"
 
 
-def test_wide_bootstrap_in_lockstep_matches_the_stock_backend(tmp_path):
+def wide_bootstrap(tmp_path, logN, slots, device_lib, timeout=1500):
     """K ciphertexts with equal metadata as ONE ciphertext whose towers hold K towers each (hal/bootstrap_batch.cpp fbb_bootstrap_wide):
     cc->EvalBootstrap runs once, every launch works on K towers.  Fully packed (the CoeffsToSlots / SlotsToCoeffs transforms, the
-    conjugation, MultByMonomial and both Chebyshev evaluations) at N = 2^8 on the lane emulator: every output identical, byte for byte,
-    to the stock backend's bootstrap of the same ciphertext — in one group of 3 and in groups of 2 + 1."""
+    conjugation, MultByMonomial and both Chebyshev evaluations): every output identical, byte for byte, to the stock backend's
+    bootstrap of the same ciphertext — in one group of 3 and in groups of 2 + 1 — and, inside the backend's process, word for word to
+    the narrow pass's outputs (fbb_compare_saved: the comparison bench.py's lockstep leg makes)."""
     import pytest
     sys.path.insert(0, ROOT)
     from openfhe_amd import boot_batch as bb
-    if not (os.path.exists(bb.HIP_SO) and os.path.exists(bb.STOCK_SO)):
+    if not (os.path.exists(bb.HIP_SO) and os.path.exists(STOCK_BOOT_SO)):
         pytest.skip("hal/_build/libfhe_boot_batch_hip.so not built (./build.sh hal needs the reference sources)")
     prng = os.path.join(ROOT, "tests", "hal", "_build", "libdetprng.so")
     out = str(tmp_path / "wide")
@@ -304,23 +309,40 @@ def test_wide_bootstrap_in_lockstep_matches_the_stock_backend(tmp_path):
 import sys, os; sys.path.insert(0, {ROOT!r})
 from openfhe_amd import boot_batch as bb
 if len(sys.argv) > 1:
-    r = bb.run_rank(8, 128, 3, 1, 1, 0, {prng!r}, dump_path={out + '.stock.bin'!r}, warmup=0, so=bb.STOCK_SO)
+    r = bb.run_rank({logN}, {slots}, 3, 1, 1, 0, {prng!r}, dump_path={out + '.stock.bin'!r}, warmup=0, so={STOCK_BOOT_SO!r})
     sys.exit(0)
-r = bb.run_rank(8, 128, 3, 1, 1, 0, {prng!r}, warmup=0)  # (the narrow pass: first use of every composite, checked against the members)
+r = bb.run_rank({logN}, {slots}, 3, 1, 1, 0, {prng!r}, warmup=0)  # (the narrow pass: first use of every composite, checked against the members)
 h = r.pop("handle")
+h.save_outputs()
 for tag, group in (("g3", 0), ("g2", 2)):
     h.bootstrap_wide(group, 0)
+    print(tag, "differing", h.compare_saved())
     h.dump({out!r} + "." + tag + ".bin", 0, 3)
     print(tag, "errors", [h.check(i)[0] for i in range(3)])
 h.close()
 """
-    env = dict(os.environ, OMP_NUM_THREADS="1", FHE_HIP_LIB=os.path.join(ROOT, "tests", "emu", "libfhe_emu.so"), FHE_HAL_REQUIRE_DEVICE="1")
+    env = dict(os.environ, OMP_NUM_THREADS="1", FHE_HIP_LIB=device_lib, FHE_HAL_REQUIRE_DEVICE="1")
     env.pop("FHE_HAL_ALLOW_HOST", None)
-    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1500)
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    ref = subprocess.run([sys.executable, "-c", code, "stock"], env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=600)
+    assert "g3 differing 0" in p.stdout and "g2 differing 0" in p.stdout, p.stdout[-600:]
+    ref = subprocess.run([sys.executable, "-c", code, "stock"], env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=timeout)
     assert ref.returncode == 0, ref.stdout + ref.stderr
     stock = open(out + ".stock.bin", "rb").read()
     assert len(stock) > 10000
     for tag in ("g3", "g2"):
         assert open(out + "." + tag + ".bin", "rb").read() == stock, f"wide bootstrap ({tag}) differs from the stock backend's"
+
+
+def test_wide_bootstrap_in_lockstep_matches_the_stock_backend(tmp_path):
+    """N = 2^8, fully packed, on the lane emulator"""
+    wide_bootstrap(tmp_path, 8, 128, EMU_LIB)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_wide_bootstrap_in_lockstep_matches_the_stock_backend_on_gpu(tmp_path):
+    """N = 2^13, fully packed (4096 slots), on the MI355X: the path behind bench.py's headline config-4 figure"""
+    wide_bootstrap(tmp_path, 13, 4096, HIP_LIB)

@@ -97,6 +97,18 @@ def mulhi(d, a, b):
     return ins(f"v_mul_hi_u32 {d}, {a}, {b}", sim=sim)
 
 
+def mullo(d, a, b):
+    def sim(S):
+        S.v[int(d[1:])] = (S.g(a) * S.g(b)) & M32
+    return ins(f"v_mul_lo_u32 {d}, {a}, {b}", sim=sim)
+
+
+def lshr32(d, amt, a):  # d = a >> amt (amt: scalar operand or literal, low 5 bits)
+    def sim(S):
+        S.v[int(d[1:])] = S.g(a) >> (S.g(amt) & 31)
+    return ins(f"v_lshrrev_b32 {d}, {amt}, {a}", sim=sim)
+
+
 def mov(d, a):
     def sim(S):
         S.v[int(d[1:])] = S.g(a)
@@ -172,20 +184,38 @@ def cmplt64(sd, a, b):
 
 
 # ---- instruction streams -----------------------------------------------------------------------------
-def shoup_tail(t, yl, yh, w, dst, addend):
-    """dst(pair) = lo64(y*w + Q*nq) + addend, Q = hi64(y*w'); y = (yl, yh) registers; w = operand suffix"""
+# Round 4 arithmetic (profiles/r04_sweeps.md):
+#  * TRUNCATED Shoup quotient in the butterflies: Q' = yh*ph + floor((yh*pl + yl*ph) / 2^32) — the low product
+#    yl*pl (the slowest instruction of the round-3 butterfly, v_mul_hi_u32) is dropped, so Q' is the exact quotient
+#    or one less and the product output lies in [0, 3q) instead of [0, 2q);
+#  * reductions of a lazily grown residue (anything below 2^64) to [0, 2q) by ONE quotient estimate
+#    k = (x.hi * redM) >> (32 + redR), redM = floor(2^(64+redR) / q), redR = bitlen(q) - 33, x -= k*q
+#    (5 instructions; k is floor(x/q) or one less) instead of a ladder of conditional subtractions (4 per level);
+#  * the multiplications that end a transform (N^-1, the fused epilogue's constant) keep the exact quotient.
+def shoup_tail(t, yl, yh, w, dst, addend, exact=False):
+    """dst(pair) = lo64(y*w + Q*nq) + addend, y = (yl, yh) registers; w = operand suffix.
+    exact: Q = hi64(y*w') (result < 2q);  else Q = the truncated quotient above (result < 3q)"""
     wl, wh, pl, ph = (f"%[{n}{w}]" for n in ("wl", "wh", "pl", "ph"))
-    return [
-        mulhi(v(t.Z), yl, pl),
-        mad(p(t.X), DEAD, yl, wh, "0"),
-        mad(p(t.L), DEAD, yh, pl, p(t.Z)),
+    if exact:
+        head = [
+            mulhi(v(t.Z), yl, pl),
+            mad(p(t.X), DEAD, yl, wh, "0"),
+            mad(p(t.L), DEAD, yh, pl, p(t.Z)),
+        ]
+    else:
+        head = [
+            mad(p(t.L), DEAD, yh, pl, "0"),
+            mad(p(t.X), DEAD, yl, wh, "0"),
+        ]
+    head += [
         mad(p(t.C), t.c0, yl, ph, p(t.L)),
         mad(p(t.X), DEAD, yh, wl, p(t.X)),
         mov(v(t.H), v(t.C + 1)),
         cnd01(v(t.H + 1), t.c0),
         mad(p(t.Q), DEAD, yh, ph, p(t.H)),
         mad(p(t.L), DEAD, yl, wl, addend),
-    ], [
+    ]
+    return head, [
         mad(p(t.X), DEAD, v(t.Q), "%[nqh]", p(t.X)),
         mad(p(t.X), DEAD, v(t.Q + 1), "%[nql]", p(t.X)),
         add32(v(t.L + 1), v(t.L + 1), v(t.X)),
@@ -193,33 +223,22 @@ def shoup_tail(t, yl, yh, w, dst, addend):
     ]
 
 
+FWD_GROW = 3  # a forward butterfly adds at most 3q to the bound of its `a` input (truncated quotient)
+INV_PROD = 3  # bound of an inverse butterfly's product output
+
+
 def fwd_stream(t, A, B, w):
-    """a' = a + T, b' = a - T + 2q with T = shoup(b, w) in [0,2q); a = v[A:A+1], b = v[B:B+1]"""
+    """a' = a + T, b' = a - T + 3q with T = shoup(b, w) in [0,3q); a = v[A:A+1], b = v[B:B+1] (any 64-bit value)"""
     head, tail = shoup_tail(t, v(B), v(B + 1), w, p(A), p(A))
-    return head + [lshladd(p(B), p(A), 1, "%[twoq]")] + tail + [
+    return head + [lshladd(p(B), p(A), 1, "%[threeq]")] + tail + [
         subco(v(B), t.c0, v(B), v(A)),
         subbco(v(B + 1), t.c0, v(B + 1), v(A + 1), t.c0),
     ]
 
 
-def inv_stream(t, A, B, w):
-    """a' = (u+v) mod 2q, b' = shoup(u - v + 2q, w); u = v[A:A+1], v = v[B:B+1]"""
-    pre = [
-        lshladd(p(t.Y), p(A), 0, "%[twoq]"),
-        lshladd(p(A), p(A), 0, p(B)),
-        subco(v(t.Y), t.c0, v(t.Y), v(B)),
-        lshladd(p(t.D), p(A), 0, "%[ntwoq]"),
-        cmplt64(t.c1, p(A), "%[twoq]"),
-        subbco(v(t.Y + 1), t.c0, v(t.Y + 1), v(B + 1), t.c0),
-    ]
-    head, tail = shoup_tail(t, v(t.Y), v(t.Y + 1), w, p(B), "0")
-    sel = [cnd(v(A), v(t.D), v(A), t.c1), cnd(v(A + 1), v(t.D + 1), v(A + 1), t.c1)]
-    return pre + head[:2] + sel + head[2:] + tail
-
-
 def inv_lazy_stream(t, A, B, w, kop):
-    """Gentleman-Sande butterfly without the reduction of the sum: a' = u + v, b' = shoup(u - v + K, w) with K = the
-    bound of v (a multiple of 2q given as the scalar operand `kop`); the caller tracks the bounds (inv_lazy_plan)"""
+    """Gentleman-Sande butterfly without the reduction of the sum: a' = u + v, b' = shoup(u - v + K, w) < 3q with K = the
+    bound of v (a multiple of q given as the scalar operand `kop`); the caller tracks the bounds (inv_plan)"""
     pre = [
         lshladd(p(t.Y), p(A), 0, kop),
         lshladd(p(A), p(A), 0, p(B)),
@@ -230,52 +249,19 @@ def inv_lazy_stream(t, A, B, w, kop):
     return pre + head + tail
 
 
-def inv_lazy_plan(bLo, bHi, ends=False):
-    """Bounds (units of q) of the 16 residues through the inverse stages bLo..bHi when the sum output is not reduced:
-    inputs < 2q; a' = u + v doubles the bound, b' = shoup(.) is < 2q again.  A pair whose bound reached 16q is brought
-    back to 8q first (u + v and u - v + K must stay below 2^64 > 16q).  Returns
-      pre[b]  = [(k, m)]: residue k gets csub(m*q) before stage b,
-      K[b]    = [m per butterfly, in stage_pairs order]: K = m*q,
-      end     = [(k, m), ...] in order: csub(m*q) bringing every residue below 2q after the last stage.
-    ends: the last stage is the transform's final multiplication stage (outputs < 2q, no end reductions)."""
-    bound = [2] * 16
-    pre, K = {}, {}
-    for b in range(bLo, bHi + 1):
-        pre[b], K[b] = [], []
-        for (k0, k1, _g) in stage_pairs(b):
-            assert bound[k0] == bound[k1]
-            if bound[k0] >= 16:
-                pre[b] += [(k0, 8), (k1, 8)]
-                bound[k0] = bound[k1] = 8
-            K[b].append(bound[k0])
-            if ends and b == bHi:
-                bound[k0] = bound[k1] = 2
-            else:
-                bound[k0], bound[k1] = 2 * bound[k0], 2
-    end = []
-    lvl = 8
-    while lvl >= 2:
-        for k in range(16):
-            if bound[k] > lvl:
-                end.append((k, lvl))
-                bound[k] = lvl
-        lvl //= 2
-    assert all(b == 2 for b in bound)
-    return pre, K, end
+def mul_stream(t, A, w):
+    """x = shoup(x, w) in place with the EXACT quotient (< 2q): last inverse stage (the caller forms u+v / u-v+K first)
+    and the fused epilogue; x is only overwritten by the last instruction, after every read of its halves"""
+    head, tail = shoup_tail(t, v(A), v(A + 1), w, p(A), "0", exact=True)
+    return head + tail
 
 
-def csub_blocks(items):
-    """[(k, m)] in execution order -> blocks of <= 4 conditional subtractions; a block never holds the same residue twice
-    (the levels of one residue are sequential) and keeps the order between levels"""
-    blocks, cur = [], []
-    for k, m in items:
-        if len(cur) == 4 or any(k == k2 for k2, _ in cur):
-            blocks.append(cur)
-            cur = []
-        cur.append((k, m))
-    if cur:
-        blocks.append(cur)
-    return blocks
+CSUB_TMP = (68, 70, 72, 74)  # pairs used by the 4 interleaved reduction chains
+
+
+def csub_stream(i, A):
+    """x = x < m ? x : x - m   (m, -m as scalar pairs); chain i of 4"""
+    return csub_chain_stream(i, A, "%[m]", "%[negm]")
 
 
 def csub_chain_stream(i, A, mop, nop):
@@ -289,25 +275,100 @@ def csub_chain_stream(i, A, mop, nop):
     ]
 
 
-def mul_stream(t, A, w):
-    """x = shoup(x, w) in place (last inverse stage: the caller forms u+v / u-v+2q first); x is only overwritten by
-    the last instruction, after every read of its halves"""
-    head, tail = shoup_tail(t, v(A), v(A + 1), w, p(A), "0")
-    return head + tail
-
-
-CSUB_TMP = (68, 70, 72, 74)  # pairs used by the 4 interleaved conditional subtractions
-
-
-def csub_stream(i, A):
-    """x = x < m ? x : x - m   (m, -m as scalar pairs); chain i of 4"""
-    D, c = CSUB_TMP[i], f"s[{42 + 2 * i}:{43 + 2 * i}]"
+def red_stream(i, A):
+    """x (any 64-bit value) -> x - k*q in [0, 2q), k = (x.hi * redM) >> (32 + redR) = floor(x/q) or one less; chain i of 4.
+    Needs bitlen(q) >= 36 (redR >= 3): the limbs below that take red_slow_stream"""
+    K = CSUB_TMP[i]
     return [
-        lshladd(p(D), p(A), 0, "%[negm]"),
-        cmplt64(c, p(A), "%[m]"),
-        cnd(v(A), v(D), v(A), c),
-        cnd(v(A + 1), v(D + 1), v(A + 1), c),
+        mulhi(v(K), v(A + 1), "%[redM]"),
+        lshr32(v(K), "%[redR]", v(K)),
+        mad(p(A), DEAD, v(K), "%[nql]", p(A)),
+        mullo(v(K), v(K), "%[nqh]"),
+        add32(v(A + 1), v(A + 1), v(K)),
     ]
+
+
+def red_slow_stream(i, A):
+    """the same contract for x < 16q by three conditional subtractions (8q, 4q, 2q): moduli below 2^35"""
+    out = []
+    for m in (8, 4, 2):
+        out += csub_chain_stream(i, A, f"%[k{m}]", f"%[n{m}]")
+    return out
+
+
+def op_stream(i, op, slow=False):
+    """reduction op ('c', k, m): csub of m*q on residue k;  ('r', k): residue k below 2q"""
+    if op[0] == "c":
+        return csub_chain_stream(i, R(op[1]), f"%[k{op[2]}]", f"%[n{op[2]}]")
+    return (red_slow_stream if slow else red_stream)(i, R(op[1]))
+
+
+COST_C, COST_R = 18, 23  # issue cycles of a conditional subtraction / a quotient-estimate reduction (profiles/r04_seqbench.json)
+
+
+def reduce_options(b):
+    """ways of lowering a bound b (units of q): (cost, new bound, op without the residue index)"""
+    opts = [(0, b, None)]
+    if b > 1:
+        opts.append((COST_C, (b + 1) // 2, ("c", (b + 1) // 2)))
+    if b > 2:
+        opts.append((COST_R, 2, ("r",)))
+    return opts
+
+
+def inv_plan(bLo, bHi, ends=False, B0=3, lazy_out=False):
+    """Bounds (units of q) of the 16 residues through the inverse stages bLo..bHi: inputs < B0*q; a' = u + v adds the bounds,
+    b' = shoup(.) is < INV_PROD*q again.  u + v and u - v + K (K = the bound of v) must stay below 2^64 > 16q: a pair
+    whose bounds add up to more than 16 is reduced first, by the cheapest of {nothing, one conditional subtraction of
+    half the bound, a quotient-estimate reduction} on either side.  Returns
+      pre[b] = reduction ops before stage b,   K[b] = [m per butterfly, in stage_pairs order],
+      end    = ops that bring every residue below B0*q after the last stage (none when lazy_out: the next PASS reduces),
+      bound  = the bounds on return.
+    ends: the last stage is the transform's final multiplication stage (exact products, outputs < 2q)."""
+    bound = [B0] * 16
+    pre, K = {}, {}
+    for b in range(bLo, bHi + 1):
+        pre[b], K[b] = [], []
+        for (k0, k1, _g) in stage_pairs(b):
+            best = None
+            for (c0, n0, o0) in reduce_options(bound[k0]):
+                for (c1, n1, o1) in reduce_options(bound[k1]):
+                    if n0 + n1 <= 16 and (best is None or (c0 + c1, n0 + n1) < best[0]):
+                        best = ((c0 + c1, n0 + n1), n0, n1, o0, o1)
+            _, n0, n1, o0, o1 = best
+            for k, o in ((k0, o0), (k1, o1)):
+                if o:
+                    pre[b].append((o[0], k) + o[1:])
+            K[b].append(n1)
+            if ends and b == bHi:
+                bound[k0] = bound[k1] = 2
+            else:
+                bound[k0], bound[k1] = n0 + n1, INV_PROD
+    end = []
+    if not lazy_out and not ends:
+        for k in range(16):
+            if bound[k] > B0:
+                if bound[k] <= 2 * B0:
+                    m = (bound[k] + 1) // 2
+                    end.append(("c", k, m))
+                    bound[k] = m
+                else:
+                    end.append(("r", k))
+                    bound[k] = 2
+    return pre, K, end, bound
+
+
+def op_blocks(items):
+    """reduction ops in execution order -> blocks of <= 4 interleaved chains (a block never holds a residue twice)"""
+    blocks, cur = [], []
+    for op in items:
+        if len(cur) == 4 or any(op[1] == o2[1] for o2 in cur):
+            blocks.append(cur)
+            cur = []
+        cur.append(op)
+    if cur:
+        blocks.append(cur)
+    return blocks
 
 
 def reduce192_stream():
@@ -406,49 +467,73 @@ def shoup_ref(y, w, wp, q):
     return (y * w - Q * q) & M64
 
 
+def shoup_trunc_ref(y, w, wp, q):
+    yl, yh, pl, ph = y & M32, y >> 32, wp & M32, wp >> 32
+    Q = yh * ph + ((yh * pl + yl * ph) >> 32)
+    return (y * w - Q * q) & M64
+
+
 def run(block, S):
     for c in block:
         c["sim"](S)
 
 
+def red_consts(q):
+    """(redM, redR) of a modulus, or None below 36 bits (ntt_static.h takes the conditional-subtraction ladder there)"""
+    L = q.bit_length()
+    if L < 36:
+        return None
+    r = L - 33
+    return (1 << (64 + r)) // q, r
+
+
+def limb_ops(S, q):
+    S.ops.update({"nql": (-q) & M32, "nqh": ((-q) & M64) >> 32, "twoq": 2 * q, "ntwoq": (-2 * q) & M64, "threeq": 3 * q})
+    for m in range(1, 17):
+        S.ops[f"k{m}"], S.ops[f"n{m}"] = (m * q) & M64, (-m * q) & M64
+    rc = red_consts(q)
+    if rc:
+        S.ops["redM"], S.ops["redR"] = rc
+
+
+def tw_ops(S, i, w, q):
+    wp = (w << 64) // q
+    S.ops.update({f"wl{i}": w & M32, f"wh{i}": w >> 32, f"pl{i}": wp & M32, f"ph{i}": wp >> 32})
+    return wp
+
+
+def rand_modulus(rnd, bits=None):
+    bits = bits or rnd.choice([60, 60, 59, 59, 55, 50, 45, 40, 36])
+    return rnd.getrandbits(bits) | (1 << (bits - 1)) | 1
+
+
 def check_blocks():
     rnd = random.Random(7)
     for it in range(4000):
-        q = rnd.getrandbits(60) | (1 << 59) | 1
+        q = rand_modulus(rnd) if it % 4 else (1 << 60) - 16383  # (the reference's largest 60-bit prime at N = 2^16: 16q = 2^64 - 262128)
         w = [rnd.randrange(q), rnd.randrange(q)]
-        wp = [(x << 64) // q for x in w]
         S = St()
-        S.ops = {"nql": (-q) & M32, "nqh": ((-q) & M64) >> 32, "twoq": 2 * q, "ntwoq": (-2 * q) & M64}
-        for i in (0, 1):
-            S.ops.update({f"wl{i}": w[i] & M32, f"wh{i}": w[i] >> 32, f"pl{i}": wp[i] & M32, f"ph{i}": wp[i] >> 32})
+        limb_ops(S, q)
+        wp = [tw_ops(S, i, w[i], q) for i in (0, 1)]
         t0, t1 = T(0), T(1)
         S.v[t0.Z + 1] = S.v[t1.Z + 1] = 0
-        # forward pair: lazy inputs a < 14q, b < 2^64
-        a = [rnd.randrange(14 * q), rnd.randrange(14 * q)]
-        b = [rnd.getrandbits(64), rnd.randrange(16 * q)]
+        # forward pair: lazy inputs a < 13q, b any 64-bit value
+        a = [rnd.randrange(13 * q), 13 * q - 1]
+        b = [rnd.getrandbits(64), M64 if it % 7 == 0 else rnd.randrange(16 * q)]
         for i, (k0, k1) in enumerate(((0, 8), (5, 13))):
             S.set64(p(R(k0)), a[i]), S.set64(p(R(k1)), b[i])
         run(schedule([fwd_stream(t0, R(0), R(8), 0), fwd_stream(t1, R(5), R(13), 1)]), S)
         for i, (k0, k1) in enumerate(((0, 8), (5, 13))):
-            Tm = shoup_ref(b[i], w[i], wp[i], q)
-            assert Tm < 2 * q
-            assert S.g64(p(R(k0))) == (a[i] + Tm) & M64, "fwd a"
-            assert S.g64(p(R(k1))) == (a[i] - Tm + 2 * q) & M64, "fwd b"
-        # inverse pair: inputs < 2q
-        u = [rnd.randrange(2 * q), rnd.randrange(2 * q)]
-        vv = [rnd.randrange(2 * q), rnd.randrange(2 * q)]
-        for i, (k0, k1) in enumerate(((2, 3), (14, 6))):
-            S.set64(p(R(k0)), u[i]), S.set64(p(R(k1)), vv[i])
-        run(schedule([inv_stream(t0, R(2), R(3), 0), inv_stream(t1, R(14), R(6), 1)]), S)
-        for i, (k0, k1) in enumerate(((2, 3), (14, 6))):
-            s = u[i] + vv[i]
-            assert S.g64(p(R(k0))) == (s if s < 2 * q else s - 2 * q), "inv a"
-            assert S.g64(p(R(k1))) == shoup_ref(u[i] - vv[i] + 2 * q, w[i], wp[i], q), "inv b"
-        # in-place multiply pair, any 64-bit input
+            Tm = shoup_trunc_ref(b[i], w[i], wp[i], q)
+            assert Tm < 3 * q and Tm % q == b[i] * w[i] % q, "truncated Shoup product"
+            assert S.g64(p(R(k0))) == a[i] + Tm < 16 * q, "fwd a"
+            assert S.g64(p(R(k1))) == a[i] - Tm + 3 * q, "fwd b"
+        # in-place multiply pair (exact quotient), any 64-bit input
         x = [rnd.getrandbits(64), rnd.randrange(4 * q)]
         S.set64(p(R(1)), x[0]), S.set64(p(R(9)), x[1])
         run(schedule([mul_stream(t0, R(1), 0), mul_stream(t1, R(9), 1)]), S)
-        assert S.g64(p(R(1))) == shoup_ref(x[0], w[0], wp[0], q) and S.g64(p(R(9))) == shoup_ref(x[1], w[1], wp[1], q)
+        for i, k in enumerate((1, 9)):
+            assert S.g64(p(R(k))) == shoup_ref(x[i], w[i], wp[i], q) < 2 * q
         # conditional subtraction, 4 residues per block
         m = q << rnd.randrange(0, 4)
         S.ops.update({"m": m, "negm": (-m) & M64})
@@ -458,55 +543,80 @@ def check_blocks():
         run(schedule([csub_stream(i, R(4 + i)) for i in range(4)]), S)
         for i, x0 in enumerate(xs):
             assert S.g64(p(R(4 + i))) == (x0 if x0 < m else x0 - m), "csub"
-    # lazy inverse steps: every (bLo, bHi), with and without the final multiplication stage
+        # quotient-estimate reduction: any 64-bit value -> [0, 2q); and the ladder for x < 16q
+        xs = [rnd.getrandbits(64), M64, rnd.randrange(16 * q), rnd.randrange(q) + rnd.randrange(16) * q]
+        if it % 3 == 0:
+            xs[3] = rnd.randrange(1, 17) * q - rnd.randrange(2)  # multiples of q and their predecessors
+        for i, x0 in enumerate(xs):
+            S.set64(p(R(4 + i)), x0)
+        run(schedule([red_stream(i, R(4 + i)) for i in range(4)]), S)
+        for i, x0 in enumerate(xs):
+            got = S.g64(p(R(4 + i)))
+            assert got < 2 * q and got % q == x0 % q, ("red", q, x0, got)
+        xs = [rnd.randrange(16 * q) for _ in range(4)]
+        for i, x0 in enumerate(xs):
+            S.set64(p(R(4 + i)), x0)
+        run(schedule([red_slow_stream(i, R(4 + i)) for i in range(4)]), S)
+        for i, x0 in enumerate(xs):
+            got = S.g64(p(R(4 + i)))
+            assert got < 2 * q and got % q == x0 % q, "red (ladder)"
+    # lazy inverse steps: every (bLo, bHi), with / without the final multiplication stage, lazy output, fast and ladder reductions
     for bLo in range(4):
         for bHi in range(bLo, 4):
-            for ends in ((False, True) if bHi == 3 else (False,)):
-                pre, K, end = inv_lazy_plan(bLo, bHi, ends)
+            for ends, lazy in (((False, False), (False, True), (True, False)) if bHi == 3 else ((False, False), (False, True))):
+                pre, K, end, final = inv_plan(bLo, bHi, ends, lazy_out=lazy)
                 for it in range(40):
-                    q = rnd.getrandbits(60) | (1 << 59) | 1
+                    q = (1 << 60) - 16383 if it < 4 else rand_modulus(rnd)
+                    slow = it % 5 == 4
                     S = St()
                     S.v[T(0).Z + 1] = S.v[T(1).Z + 1] = 0
-                    S.ops = {"nql": (-q) & M32, "nqh": ((-q) & M64) >> 32}
-                    for m in (2, 4, 8):
-                        S.ops[f"k{m}"], S.ops[f"n{m}"] = m * q, (-m * q) & M64
-                    x = [rnd.randrange(2 * q) if it else 2 * q - 1 for _ in range(16)]
+                    limb_ops(S, q)
+                    B0 = 3
+                    x = [rnd.randrange(B0 * q) if it else B0 * q - 1 for _ in range(16)]
                     ref = [v_ % q for v_ in x]
+                    bnd = [B0] * 16
                     for k in range(16):
                         S.set64(p(R(k)), x[k])
+
+                    def run_ops(ops):
+                        for grp in op_blocks(ops):
+                            run(schedule([op_stream(i, op, slow) for i, op in enumerate(grp)]), S)
+                            for op in grp:
+                                bnd[op[1]] = op[2] if op[0] == "c" else 2
                     for b in range(bLo, bHi + 1):
-                        for grp in csub_blocks(pre[b]):
-                            run(schedule([csub_chain_stream(i, R(k), f"%[k{m}]", f"%[n{m}]") for i, (k, m) in enumerate(grp)]), S)
+                        run_ops(pre[b])
                         prs = stage_pairs(b)
                         for j in range(0, 8, 2):
                             tw = [rnd.randrange(q), rnd.randrange(q)]
                             for i in (0, 1):
-                                wp_ = (tw[i] << 64) // q
-                                S.ops.update({f"wl{i}": tw[i] & M32, f"wh{i}": tw[i] >> 32, f"pl{i}": wp_ & M32, f"ph{i}": wp_ >> 32})
+                                tw_ops(S, i, tw[i], q)
                             (a0, a1, _), (b0, b1, _) = prs[j], prs[j + 1]
+                            for (u_, v_), m in (((a0, a1), K[b][j]), ((b0, b1), K[b][j + 1])):
+                                uu, vv = S.g64(p(R(u_))), S.g64(p(R(v_)))
+                                assert uu < bnd[u_] * q and vv < bnd[v_] * q and bnd[v_] <= m and bnd[u_] + m <= 16
                             if ends and b == bHi:  # final stage: sums / differences formed by the caller, then multiplied
                                 for (u_, v_), m in (((a0, a1), K[b][j]), ((b0, b1), K[b][j + 1])):
                                     uu, vv = S.g64(p(R(u_))), S.g64(p(R(v_)))
-                                    assert uu + vv < 1 << 64 and uu - vv + m * q < 1 << 64
                                     S.set64(p(R(u_)), uu + vv), S.set64(p(R(v_)), uu - vv + m * q)
                                 run(schedule([mul_stream(T(0), R(a0), 0), mul_stream(T(1), R(b0), 1)]), S)
                                 run(schedule([mul_stream(T(0), R(a1), 0), mul_stream(T(1), R(b1), 1)]), S)
                                 for (u_, v_), w_ in (((a0, a1), tw[0]), ((b0, b1), tw[1])):
                                     ru, rv = ref[u_], ref[v_]
                                     ref[u_], ref[v_] = (ru + rv) * w_ % q, (ru - rv) * w_ % q
+                                    bnd[u_] = bnd[v_] = 2
                             else:
-                                for (u_, v_) in ((a0, a1), (b0, b1)):
-                                    assert S.g64(p(R(u_))) + S.g64(p(R(v_))) < 1 << 64
                                 run(schedule([inv_lazy_stream(T(0), R(a0), R(a1), 0, f"%[k{K[b][j]}]"),
                                               inv_lazy_stream(T(1), R(b0), R(b1), 1, f"%[k{K[b][j + 1]}]")]), S)
                                 for (u_, v_), w_ in (((a0, a1), tw[0]), ((b0, b1), tw[1])):
                                     ru, rv = ref[u_], ref[v_]
                                     ref[u_], ref[v_] = (ru + rv) % q, (ru - rv) * w_ % q
-                    for grp in csub_blocks(end):
-                        run(schedule([csub_chain_stream(i, R(k), f"%[k{m}]", f"%[n{m}]") for i, (k, m) in enumerate(grp)]), S)
+                                    bnd[u_], bnd[v_] = bnd[u_] + bnd[v_], INV_PROD
+                    run_ops(end)
+                    assert bnd == final, (bnd, final)
                     for k in range(16):
                         got = S.g64(p(R(k)))
-                        assert got < 2 * q and got % q == ref[k], ("lazy inverse step", bLo, bHi, ends, k)
+                        assert got < final[k] * q and got % q == ref[k], ("lazy inverse step", bLo, bHi, ends, lazy, k)
+                        assert lazy or final[k] <= (2 if ends else 3)
     # 192-bit column sums -> canonical residue
     for it in range(4000):
         bits = rnd.choice([28, 45, 59, 60])
@@ -549,6 +659,9 @@ def check_blocks():
 
 
 # ---- emission ----------------------------------------------------------------------------------------
+import re
+
+
 def clobbers(nslots):
     regs = []
     for s in range(nslots):
@@ -558,79 +671,90 @@ def clobbers(nslots):
     return regs + ["s40", "s41"]
 
 
-def asm_block(block, outs, ins_, nslots):
-    text = "\n".join(f'        "{c["t"]}\\n\\t"' for c in block)
-    o = ", ".join(outs)
-    i = ", ".join(ins_)
+def operand(name, cls):
+    """C++ input operand of an asm block for the %[name] used in its text"""
+    m = re.fullmatch(r"(wl|wh|pl|ph)([01])", name)
+    if m:
+        return f'[{name}] "{cls}"({m.group(1)[0]}{m.group(2)}{m.group(1)[1]})'
+    fixed = {"nql": "c.nql", "nqh": "c.nqh", "twoq": "c.twoq", "ntwoq": "c.ntwoq", "threeq": "c.threeq", "redM": "c.redM",
+             "redR": "c.redR", "m": "m", "negm": "negm"}
+    if name in fixed:
+        return f'[{name}] "s"({fixed[name]})'
+    m = re.fullmatch(r"([kn])(\d+)", name)
+    assert m, name
+    mult = f"c.q * {m.group(2)}ull" if m.group(2) != "1" else "c.q"
+    return f'[{name}] "s"({mult})' if m.group(1) == "k" else f'[{name}] "s"(0 - {mult})'
+
+
+def asm_block(block, outs, nslots, cls="s", indent="    "):
+    text = "\n".join(f'{indent}    "{c["t"]}\\n\\t"' for c in block)
+    names = []
+    for c in block:
+        for n in re.findall(r"%\[(\w+)\]", c["t"]):
+            if n not in names:
+                names.append(n)
+    ins_ = [operand(n, cls) for n in names]
+    if nslots:
+        ins_ += ZERO_IN
     regs = clobbers(nslots) if nslots else [f"v{r}" for r in range(68, 76)] + [f"s{r}" for r in range(42, 50)]
     c = ", ".join(f'"{r}"' for r in regs)
-    return f"    asm volatile(\n{text}\n        : {o}\n        : {i}\n        : {c});\n"
+    return f"{indent}asm volatile(\n{text}\n{indent}    : {', '.join(outs)}\n{indent}    : {', '.join(ins_)}\n{indent}    : {c});\n"
 
 
 def pin(k, var):
     return f'"+{{v[{R(k)}:{R(k) + 1}]}}"({var})'
 
 
-def tw_in(i, cls):
-    return [f'[wl{i}] "{cls}"(w{i}l)', f'[wh{i}] "{cls}"(w{i}h)', f'[pl{i}] "{cls}"(p{i}l)', f'[ph{i}] "{cls}"(p{i}h)']
-
-
 ZERO_IN = ['"{v65}"(z.z0)', '"{v81}"(z.z1)']
-CONST_IN = ['[nql] "s"(c.nql)', '[nqh] "s"(c.nqh)', '[twoq] "s"(c.twoq)', '[ntwoq] "s"(c.ntwoq)']
+TW_ARGS = "uint64_t (&r)[16], const TwPair wa, const TwPair wb, const BflyConst c, const BflyZero z"
+TW_BODY = "".join(f"    const uint32_t w{i}l = (uint32_t)w{n}.w, w{i}h = (uint32_t)(w{n}.w >> 32), p{i}l = (uint32_t)w{n}.wp, "
+                  f"p{i}h = (uint32_t)(w{n}.wp >> 32);\n" for i, n in ((0, "a"), (1, "b")))
 
 
-def emit_pair_fn(name, kind, ka, kb, cls):
-    """two butterflies (r[ka[0]], r[ka[1]]) with twiddle 0 and (r[kb[0]], r[kb[1]]) with twiddle 1"""
-    mk = fwd_stream if kind == "fwd" else inv_stream
-    block = schedule([mk(T(0), R(ka[0]), R(ka[1]), 0), mk(T(1), R(kb[0]), R(kb[1]), 1)])
-    args = "uint64_t (&r)[16], const TwPair wa, const TwPair wb, const BflyConst c, const BflyZero z"
-    body = "".join(f"    const uint32_t w{i}l = (uint32_t)w{n}.w, w{i}h = (uint32_t)(w{n}.w >> 32), p{i}l = (uint32_t)w{n}.wp, "
-                   f"p{i}h = (uint32_t)(w{n}.wp >> 32);\n" for i, n in ((0, "a"), (1, "b")))
+def emit_pair_fn(name, ka, kb, cls):
+    """two forward butterflies (r[ka[0]], r[ka[1]]) with twiddle 0 and (r[kb[0]], r[kb[1]]) with twiddle 1"""
+    block = schedule([fwd_stream(T(0), R(ka[0]), R(ka[1]), 0), fwd_stream(T(1), R(kb[0]), R(kb[1]), 1)])
     outs = [pin(k, f"r[{k}]") for k in (ka[0], ka[1], kb[0], kb[1])]
-    return (f"__device__ __forceinline__ void {name}({args}) {{\n{body}"
-            + asm_block(block, outs, tw_in(0, cls) + tw_in(1, cls) + CONST_IN + ZERO_IN, 2) + "}\n")
-
-
-LAZY_CONST_IN = ['[nql] "s"(c.nql)', '[nqh] "s"(c.nqh)', '[k2] "s"(c.twoq)', '[k4] "s"(c.twoq << 1)', '[k8] "s"(c.twoq << 2)']
-LAZY_RED_IN = ['[k2] "s"(c.twoq)', '[k4] "s"(c.twoq << 1)', '[k8] "s"(c.twoq << 2)', '[n2] "s"(0 - c.twoq)',
-               '[n4] "s"(0 - (c.twoq << 1))', '[n8] "s"(0 - (c.twoq << 2))']
+    return f"__device__ __forceinline__ void {name}({TW_ARGS}) {{\n{TW_BODY}" + asm_block(block, outs, 2, cls) + "}\n"
 
 
 def emit_lazy_pair_fn(name, ka, kb, cls, Ka, Kb):
     block = schedule([inv_lazy_stream(T(0), R(ka[0]), R(ka[1]), 0, f"%[k{Ka}]"),
                       inv_lazy_stream(T(1), R(kb[0]), R(kb[1]), 1, f"%[k{Kb}]")])
-    args = "uint64_t (&r)[16], const TwPair wa, const TwPair wb, const BflyConst c, const BflyZero z"
-    body = "".join(f"    const uint32_t w{i}l = (uint32_t)w{n}.w, w{i}h = (uint32_t)(w{n}.w >> 32), p{i}l = (uint32_t)w{n}.wp, "
-                   f"p{i}h = (uint32_t)(w{n}.wp >> 32);\n" for i, n in ((0, "a"), (1, "b")))
     outs = [pin(k, f"r[{k}]") for k in (ka[0], ka[1], kb[0], kb[1])]
-    return (f"__device__ __forceinline__ void {name}({args}) {{\n{body}"
-            + asm_block(block, outs, tw_in(0, cls) + tw_in(1, cls) + LAZY_CONST_IN + ZERO_IN, 2) + "}\n")
+    return f"__device__ __forceinline__ void {name}({TW_ARGS}) {{\n{TW_BODY}" + asm_block(block, outs, 2, cls) + "}\n"
+
+
+def emit_ops_body(items):
+    """reduction ops as blocks of <= 4 chains; a block with quotient-estimate reductions has a second form (the ladder of
+    conditional subtractions) behind a wave-uniform branch for moduli below 2^35 (BflyConst::redR == 255)"""
+    body = ""
+    for grp in op_blocks(items):
+        outs = [pin(op[1], f"r[{op[1]}]") for op in grp]
+        fast = asm_block(schedule([op_stream(i, op) for i, op in enumerate(grp)]), outs, 0, indent="        ")
+        if any(op[0] == "r" for op in grp):
+            slow = asm_block(schedule([op_stream(i, op, True) for i, op in enumerate(grp)]), outs, 0, indent="        ")
+            body += f"    if (c.redR != 255u) {{\n{fast}    }}\n    else {{\n{slow}    }}\n"
+        else:
+            body += f"    {{\n{fast}    }}\n"
+    return body
 
 
 def emit_reduce_fn(name, items):
-    """conditional subtractions [(k, m)] (threshold m*q) as blocks of <= 4"""
-    body = ""
-    for grp in csub_blocks(items):
-        block = schedule([csub_chain_stream(i, R(k), f"%[k{m}]", f"%[n{m}]") for i, (k, m) in enumerate(grp)])
-        body += asm_block(block, [pin(k, f"r[{k}]") for k, _ in grp], LAZY_RED_IN, 0)
-    return f"__device__ __forceinline__ void {name}(uint64_t (&r)[16], const BflyConst c) {{\n(void)c;\n{body}}}\n"
+    return f"__device__ __forceinline__ void {name}(uint64_t (&r)[16], const BflyConst c) {{\n    (void)c;\n{emit_ops_body(items)}}}\n"
 
 
 def emit_mul_fn(name, ka, kb, cls):
     block = schedule([mul_stream(T(0), R(ka), 0), mul_stream(T(1), R(kb), 1)])
-    args = "uint64_t (&r)[16], const TwPair wa, const TwPair wb, const BflyConst c, const BflyZero z"
-    body = "".join(f"    const uint32_t w{i}l = (uint32_t)w{n}.w, w{i}h = (uint32_t)(w{n}.w >> 32), p{i}l = (uint32_t)w{n}.wp, "
-                   f"p{i}h = (uint32_t)(w{n}.wp >> 32);\n" for i, n in ((0, "a"), (1, "b")))
     outs = [pin(ka, f"r[{ka}]"), pin(kb, f"r[{kb}]")]
-    return (f"__device__ __forceinline__ void {name}({args}) {{\n{body}"
-            + asm_block(block, outs, tw_in(0, cls) + tw_in(1, cls) + CONST_IN[:2] + ZERO_IN, 2) + "}\n")
+    return f"__device__ __forceinline__ void {name}({TW_ARGS}) {{\n{TW_BODY}" + asm_block(block, outs, 2, cls) + "}\n"
 
 
 def emit_csub_fn(name, ks):
     block = schedule([csub_stream(i, R(k)) for i, k in enumerate(ks)])
     outs = [pin(k, f"r[{k}]") for k in ks]
     return (f"__device__ __forceinline__ void {name}(uint64_t (&r)[16], uint64_t m, uint64_t negm) {{\n"
-            + asm_block(block, outs, ['[m] "s"(m)', '[negm] "s"(negm)'], 0) + "}\n")
+            + asm_block(block, outs, 0) + "}\n")
 
 
 def stage_pairs(b):
@@ -643,45 +767,53 @@ def stage_pairs(b):
     return out
 
 
+def count(stream_or_block):
+    return sum(1 for c in stream_or_block if not c["t"].startswith("s_nop"))
+
+
 def main():
     check_blocks()
     H = []
     H.append("""// GENERATED by tools/gen_ntt_asm.py — do not edit; edit the generator and re-run it.
 // In-place gfx950 butterflies on the 16 residues of a lane pinned to v[32:63] (residue k = v[32+2k:33+2k]).
-// Arithmetic = bfly_fwd_fast / bfly_inv_fast of ntt_kernels.h (Shoup multiply of the reference's
-// ModMulFastConst, transformnat-impl.h:303-374 / 512-625, with lazy ranges); every block below was simulated against
-// that arithmetic by the generator before it was written.  Two butterflies are interleaved per asm block so that
-// the two wait states gfx950 needs between a VALU carry write and its reader are filled with the other butterfly.
+// Arithmetic: the Shoup multiply of the reference's ModMulFastConst (ubintnat.h:1464-1469) inside the butterflies of
+// transformnat-impl.h:303-374 / 512-625, with lazy ranges: the butterflies take a TRUNCATED quotient (the low product of
+// hi64(y*w') is dropped: one v_mul_hi_u32 less, products in [0,3q) instead of [0,2q)), lazily grown residues come back
+// below 2q by one quotient estimate (5 instructions) instead of a ladder of conditional subtractions, the products that
+// end a transform keep the exact quotient.  Every block below was simulated against python integers by the generator
+// before it was written.  Two butterflies are interleaved per asm block so that the two wait states gfx950 needs
+// between a VALU carry write and its reader are filled with the other butterfly.
 #ifndef FHE_NTT_BFLY_PINNED_H
 #define FHE_NTT_BFLY_PINNED_H
 #if defined(__HIP_DEVICE_COMPILE__)
 namespace fhe {
 struct BflyConst {  // wave-uniform (SGPR) constants of the limb
-    uint32_t nql, nqh;      // 2^64 - q
-    uint64_t twoq, ntwoq;   // 2q, 2^64 - 2q
+    uint32_t nql, nqh;             // 2^64 - q
+    uint64_t q, twoq, ntwoq, threeq;
+    uint32_t redM, redR;           // quotient estimate: k = (x.hi * redM) >> (32 + redR); redR == 255: modulus below 2^35, ladder instead
 };
 struct BflyZero {   // two VGPRs holding 0 (high halves of the zero-extended mul_hi results)
     uint32_t z0, z1;
 };
 """)
-    for kind in ("fwd", "inv"):
-        for b in range(4):
-            prs = stage_pairs(b)
-            for cls, tag in (("v", "v"), ("s", "s")):
-                fn = []
-                for i in range(0, 8, 2):
-                    (a0, a1, ga), (b0, b1, gb) = prs[i], prs[i + 1]
-                    name = f"bfly2_{kind}_{tag}_b{b}_{i // 2}"
-                    H.append(emit_pair_fn(name, kind, (a0, a1), (b0, b1), cls))
-                    fn.append(f"    {name}(r, w[{ga}], w[{gb}], c, z);\n")
-                H.append(f"// stage b = {b}: twiddle g serves the butterflies whose index has (k >> {b + 1}) == g\n"
-                         f"__device__ __forceinline__ void stage_{kind}_{tag}_b{b}(uint64_t (&r)[16], const TwPair (&w)[8], "
-                         f"const BflyConst c, const BflyZero z) {{\n" + "".join(fn) + "}\n")
-    # lazy inverse stages: the sum output is not reduced; bounds follow inv_lazy_plan(bLo, .)
+    for b in range(4):
+        prs = stage_pairs(b)
+        for cls, tag in (("v", "v"), ("s", "s")):
+            fn = []
+            for i in range(0, 8, 2):
+                (a0, a1, ga), (b0, b1, gb) = prs[i], prs[i + 1]
+                name = f"bfly2_fwd_{tag}_b{b}_{i // 2}"
+                H.append(emit_pair_fn(name, (a0, a1), (b0, b1), cls))
+                fn.append(f"    {name}(r, w[{ga}], w[{gb}], c, z);\n")
+            H.append(f"// stage b = {b}: twiddle g serves the butterflies whose index has (k >> {b + 1}) == g\n"
+                     f"__device__ __forceinline__ void stage_fwd_{tag}_b{b}(uint64_t (&r)[16], const TwPair (&w)[8], "
+                     f"const BflyConst c, const BflyZero z) {{\n" + "".join(fn) + "}\n")
+    # lazy inverse stages: the sum output is not reduced; bounds follow inv_plan(bLo, .)
     ktab = [[[0] * 8 for _ in range(4)] for _ in range(4)]
+    nred = {}
     for bLo in range(4):
         for b in range(bLo, 4):
-            pre, K, _ = inv_lazy_plan(bLo, b)
+            pre, K, _, _ = inv_plan(bLo, b)
             ktab[bLo][b] = K[b]
             H.append(emit_reduce_fn(f"inv_lazy_pre_b{b}_lo{bLo}", pre[b]))
             prs = stage_pairs(b)
@@ -695,13 +827,14 @@ struct BflyZero {   // two VGPRs holding 0 (high halves of the zero-extended mul
                 H.append(f"__device__ __forceinline__ void stage_invl_{tag}_b{b}_lo{bLo}(uint64_t (&r)[16], const TwPair (&w)[8], "
                          f"const BflyConst c, const BflyZero z) {{\n    inv_lazy_pre_b{b}_lo{bLo}(r, c);\n" + "".join(fn) + "}\n")
         for bHi in range(bLo, 4):
-            _, _, end = inv_lazy_plan(bLo, bHi)
+            pre, _, end, _ = inv_plan(bLo, bHi)
             H.append(emit_reduce_fn(f"inv_lazy_end_lo{bLo}_hi{bHi}", end))
+            nred[(bLo, bHi)] = (sum(len(v_) for v_ in pre.values()), len(end))
     H.append("// K multiplier (units of q) of butterfly `pair` of stage b when the step starts at stage bLo: [bLo][b][pair]\n"
              "__device__ constexpr unsigned char kInvLazyK[4][4][8] = {"
              + ", ".join("{" + ", ".join("{" + ", ".join(str(x) for x in ktab[lo][b]) + "}" for b in range(4)) + "}" for lo in range(4))
              + "};\n")
-    # last inverse stage (s == 0): residues lo and lo|8 multiplied by N^-1 and w1*N^-1
+    # last inverse stage (s == 0): residues lo and lo|8 multiplied by N^-1 and w1*N^-1 (exact quotient)
     for i in range(8):
         H.append(emit_mul_fn(f"mul2_s_{i}", i, i | 8, "s"))
     for i in range(4):
@@ -740,18 +873,12 @@ __device__ __forceinline__ uint64_t reduce192_uniform(uint64_t c0, uint64_t c1, 
     csub4_3(r, m, negm);
 }
 """)
-    # the 8 residues that are the `a` inputs of a stage on field bit b (index bit b clear): only those bound the
-    # outputs of a forward butterfly, so the lazy-reduction sweep before a step touches just them
+    # every residue below 2q (quotient estimate), and the 8 residues that are the `a` inputs of a stage on field bit b
+    # (index bit b clear): only those bound the outputs of a forward butterfly, so the lazy-reduction sweep before a
+    # forward step touches just them
+    H.append(emit_reduce_fn("red16", [("r", k) for k in range(16)]))
     for b in range(4):
-        ks = [k for k in range(16) if not (k >> b) & 1]
-        H.append(emit_csub_fn(f"csub4_a{b}_0", ks[:4]))
-        H.append(emit_csub_fn(f"csub4_a{b}_1", ks[4:]))
-        H.append(f"""__device__ __forceinline__ void csub8_a{b}(uint64_t (&r)[16], uint64_t m) {{
-    const uint64_t negm = 0 - m;
-    csub4_a{b}_0(r, m, negm);
-    csub4_a{b}_1(r, m, negm);
-}}
-""")
+        H.append(emit_reduce_fn(f"red8_a{b}", [("r", k) for k in range(16) if not (k >> b) & 1]))
     H.append("""}  // namespace fhe
 #endif
 #endif
@@ -764,9 +891,10 @@ __device__ __forceinline__ uint64_t reduce192_uniform(uint64_t c0, uint64_t c1, 
         print("ntt_bfly_pinned.h is up to date; all blocks simulated OK")
         return 0
     open(OUT, "w").write(text)
-    n = sum(1 for c in schedule([fwd_stream(T(0), R(0), R(1), 0), fwd_stream(T(1), R(2), R(3), 1)]) if not c["t"].startswith("s_nop"))
-    ni = sum(1 for c in schedule([inv_stream(T(0), R(0), R(1), 0), inv_stream(T(1), R(2), R(3), 1)]) if not c["t"].startswith("s_nop"))
-    print(f"wrote {OUT}: forward pair {n} VALU, inverse pair {ni} VALU; all blocks simulated OK")
+    n = count(fwd_stream(T(0), R(0), R(1), 0))
+    ni = count(inv_lazy_stream(T(0), R(0), R(1), 0, "%[k3]"))
+    print(f"wrote {OUT}: forward butterfly {n} VALU, lazy inverse butterfly {ni} VALU, reduction {count(red_stream(0, R(0)))} VALU; "
+          f"inverse steps (bLo, bHi): (reductions before stages, at the end) = {nred}; all blocks simulated OK")
 
 
 if __name__ == "__main__":
