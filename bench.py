@@ -50,7 +50,9 @@ def parse():
     ap.add_argument("--bootstrap-logn", type=int, default=17)
     ap.add_argument("--bootstrap-batch", type=int, default=64, help="ciphertexts per GPU in the bootstrap leg (BASELINE configs[3]: 512 over 8 GPUs = 64 per GPU; "
                                                                      "the driver's 1-GPU run is one rank's share)")
-    ap.add_argument("--bootstrap-group", type=int, default=0, help="ciphertexts per wide (lockstep) evaluation in the bootstrap leg; 0 = the rank's whole slice")
+    ap.add_argument("--bootstrap-group", type=int, default=32,
+                    help="ciphertexts per wide (lockstep) evaluation in the bootstrap leg; 0 = the rank's whole slice (64 at once exceed the "
+                         "288 GB of one GPU with the caches of the threaded pass still resident: profiles/r04_sweeps.md)")
     ap.add_argument("--bootstrap-threads", type=int, default=8, help="host threads (= HIP streams) the rank's ciphertexts are spread over")
     ap.add_argument("--no-cc-evalmult", action="store_true",
                     help="skip the leg that runs BASELINE configs[2]'s EvalMult through the reference's CryptoContext on the HIP backend")
@@ -691,22 +693,41 @@ def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev,
     os.environ["FHE_HAL_REQUIRE_DEVICE"] = "1"
     slots, total, key_threads = 1 << (logN - 1), per_gpu * world, 8
     tmp = tempfile.mkdtemp(prefix="fhe_bootbatch_")
-    r = bb.run_rank(logN, slots, total, threads, 2, device, prng, dist=dist if world > 1 else None,
-                    torch_device=tdev if tdev is not None else "cpu", dump_path=None, warmup=1, key_threads=key_threads)
+    forced = dist is not None and world == 1  # FHE_BENCH_FORCE_DIST: the replication path (RCCL, adopted key windows) on one GPU
+    r = bb.run_rank(logN, slots, total, threads, 2, device, prng, dist=dist if (world > 1 or forced) else None,
+                    torch_device=tdev if tdev is not None else "cpu", dump_path=None, warmup=1, key_threads=key_threads,
+                    force_replication=forced)
     h = r.pop("handle")
     keep_keys = r.pop("keys", None)  # (the replicated key tensor: the key towers are windows of it until h.close())
     h.save_outputs()  # the narrow (threaded) pass's outputs: the lockstep pass is compared with them word for word below
     ct0 = os.path.join(tmp, "hip_ct0.bin")
     h.dump(ct0, 0, 1)
     # latency of one bootstrap: ciphertexts of the slice on one thread, one stream (at most 8 of them: the figure is per bootstrap)
+    c0 = h.counters()
     single = h.single_thread_latency() / max(1, r["ciphertexts"])
+    c1 = h.counters()
+    nct = max(1, r["ciphertexts"])
+
+    def per_bootstrap(a, b, passes, rate_per_s):
+        """roofline of one bootstrap from the backend's counters between two readings: operand bytes = every tower / key a device
+        operation reads or writes, once per operation (the algorithmic bytes of the operation sequence pke issues)"""
+        n = passes * nct
+        gb = (b["operand_read_bytes"] - a["operand_read_bytes"] + b["operand_write_bytes"] - a["operand_write_bytes"]) / n / 1e9
+        return {"bound": "hbm", "operand_GB_per_bootstrap": round(gb, 3), "achieved": round(gb * rate_per_s, 1), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(gb * rate_per_s / HBM_PEAK_GBPS, 4),
+                "launches_per_bootstrap": round((b["launches"] - a["launches"]) / n, 1),
+                "h2d_MB_per_bootstrap": round((b["h2d_bytes"] - a["h2d_bytes"]) / n / 1e6, 2),
+                "d2h_MB_per_bootstrap": round((b["d2h_bytes"] - a["d2h_bytes"]) / n / 1e6, 2), "traffic": None}
+    narrow_roof = per_bootstrap(c0, c1, 1, 1.0 / single if single > 0 else 0.0)
     threaded_rate = r["bootstraps_per_s"]
     # the same ciphertexts in LOCKSTEP: one ciphertext whose towers hold all of the rank's towers, cc->EvalBootstrap runs once, every launch
     # works on K towers and every key is read once for all (wide towers, DESIGN.md 4.9; the passes above were the narrow first use of
     # every composite).  The rank's figure is the better of the two ways of running the batch.
     wide = None
     try:
+        w0 = h.counters()
         wsec = h.bootstrap_wide(group, 2)
+        w1 = h.counters()
         ndiff = h.compare_saved()
         wide = {"seconds_per_pass": round(wsec, 4), "bootstraps_per_s": round(r["ciphertexts"] / wsec, 2),
                 "group": group if 0 < group < r["ciphertexts"] else r["ciphertexts"],
@@ -714,7 +735,8 @@ def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev,
                 "parity": (f"all {r['ciphertexts']} outputs identical word for word to the threaded (narrow) pass's outputs of the same ciphertexts "
                            "(compared in this run, every limb on the host)" if ndiff == 0 else
                            f"MISMATCH: {ndiff} of {r['ciphertexts']} outputs differ from the narrow pass's"),
-                "how": "one cc->EvalBootstrap per group on a ciphertext of K-tower towers, one host thread"}
+                "how": "one cc->EvalBootstrap per group on a ciphertext of K-tower towers, one host thread",
+                "roofline": per_bootstrap(w0, w1, 3, r["ciphertexts"] / wsec)}  # (1 untimed + 2 timed passes between the readings)
         if ndiff != 0:
             wide["bootstraps_per_s_unverified"] = wide.pop("bootstraps_per_s")  # a figure without parity is not reported as the rate
     except Exception as e:
@@ -730,7 +752,7 @@ def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev,
                        f"{per_gpu} ciphertexts per GPU over {threads} host threads, {world} rank(s)",
            "bootstraps_per_s_per_gpu": round(rate, 2), "bootstraps_per_s_total": round(total_rate, 2),
            "bootstraps_per_s_over_host_threads": round(threaded_rate, 2), "lockstep": wide,
-           "seconds_per_bootstrap": round(single, 5), "seconds_per_pass": round(r["seconds_per_pass"], 4),
+           "seconds_per_bootstrap": round(single, 5), "one_stream_roofline": narrow_roof, "seconds_per_pass": round(r["seconds_per_pass"], 4),
            "max_abs_error_vs_message": r["max_abs_error"], "setup_s": r["setup_s"], "keygen_s_rank0": r["keygen_s"],
            "how": "reference pke (unmodified sources) on the HIP backend of DCRTPoly; 1 warm-up + 2 timed passes over the rank's ciphertexts; "
                   "seconds_per_bootstrap = the same ciphertexts on ONE host thread / stream",

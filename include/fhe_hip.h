@@ -142,6 +142,14 @@ fhe_status fhe_mul_add(fhe_ctx* ctx, uint64_t* acc, const uint64_t* a, const uin
  * array may be released as soon as the call returns. */
 fhe_status fhe_mul_const(fhe_ctx* ctx, uint64_t* out, const uint64_t* a, const uint64_t* consts,
                          const uint32_t* limbIdx, uint32_t nLimbs, uint32_t batch, void* stream);
+/* out = sum_i consts[i] (.) x[i] per limb (+ out when accumulate != 0): pke's weighted sums — internalEvalLinearWSumMutable,
+ * src/pke/lib/scheme/ckksrns/ckksrns-advancedshe.cpp:97-136: `EvalMultInPlace(ct_i, c_i); EvalAddInPlaceNoCheck(ct_0, ct_i)` for every
+ * term, the inner loops of the Chebyshev evaluation of bootstrapping (ckksrns-fhe.cpp:691-692, :786) — as one launch per 16 terms:
+ * every term is read once, the sum written once.  x: HOST array of nTerms DEVICE towers [batch][nLimbs][N] (each dense, allocated
+ * on its own); consts: HOST array [nTerms][nLimbs], reduced modulo their limbs (their device table is cached by content).  Exact
+ * modular arithmetic: the residues are the reference's whatever the order of the sum.  out may be one of the x[i]. */
+fhe_status fhe_lincomb(fhe_ctx* ctx, uint64_t* out, const uint64_t* const* x, const uint64_t* consts, uint32_t nTerms,
+                       const uint32_t* limbIdx, uint32_t nLimbs, uint32_t batch, int accumulate, void* stream);
 /* The two elements of a ciphertext in ONE launch: element e of every operand is a tower allocated on its own (o_e = a_e op b_e,
  * o_e = a_e * consts per limb).  pke applies its operations element by element (base-leveledshe.cpp:562-606,
  * ckksrns-leveledshe.cpp:748-759); one ciphertext's tower alone leaves most of the chip idle.  In-place use (o_e == a_e) is fine. */

@@ -41,6 +41,7 @@ class BootBatch:
         if hasattr(L, "fbb_bootstrap_wide"):
             L.fbb_bootstrap_wide.restype, L.fbb_bootstrap_wide.argtypes = C.c_double, [vp, u32, C.c_int]
         L.fbb_check.restype, L.fbb_check.argtypes = C.c_double, [vp, u32, C.POINTER(C.c_double)]
+        L.fbb_counters.argtypes = [C.POINTER(u64)]
         L.fbb_save_outputs.argtypes = [vp]
         L.fbb_compare_saved.restype, L.fbb_compare_saved.argtypes = C.c_long, [vp]
         L.fbb_dump.argtypes = [vp, C.c_char_p, u32, u32]
@@ -103,6 +104,13 @@ class BootBatch:
         self._ok(0 if s >= 0 else 1)
         return s
 
+    def counters(self):
+        """{operand bytes read / written by the device operations so far (every tower or key an operation touches, once per operation),
+        kernel launches, PCIe bytes host->device / device->host} of the backend in this process"""
+        c = (u64 * 5)()
+        self.L.fbb_counters(c)
+        return dict(zip(("operand_read_bytes", "operand_write_bytes", "launches", "h2d_bytes", "d2h_bytes"), (int(v) for v in c)))
+
     def save_outputs(self):
         """keeps the current outputs for compare_saved (the next pass produces new objects)"""
         self._ok(self.L.fbb_save_outputs(self.h))
@@ -127,12 +135,14 @@ class BootBatch:
 
 
 def run_rank(logN, slots, total, threads, reps, device, prng, dist=None, torch_device="cpu", budget=(4, 4), levels_after=5, so=HIP_SO,
-             dump_path=None, warmup=1, key_threads=None, keep=None, eval_threads=None):
+             dump_path=None, warmup=1, key_threads=None, keep=None, eval_threads=None, force_replication=False):
     """One rank of the sharded batch.  dist: torch.distributed (initialised) or None for a single process.  Returns a dict of
     timings; with dump_path the rank's bootstrapped ciphertexts are written there (tests).  key_threads: the OpenMP team during
     set-up, encryption and key generation (pke draws from thread-local PRNGs there: equal teams give equal keys); eval_threads: the
     team of pke's inner loops during the bootstraps (default: unchanged).  keep: bootstrap only the first `keep` ciphertexts of the
-    rank's slice (all `total` are still encrypted, so the kept ones are the batch's — the byte-comparison reference of bench.py)."""
+    rank's slice (all `total` are still encrypted, so the kept ones are the batch's — the byte-comparison reference of bench.py).
+    force_replication: run the key replication (export -> scatter + all-gather -> adoption of windows of the gathered tensor) even
+    in a world of one rank — the multi-GPU code path on one GPU's memory (tests, FHE_BENCH_FORCE_DIST)."""
     from . import shard
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
     t0 = time.perf_counter()
@@ -147,7 +157,7 @@ def run_rank(logN, slots, total, threads, reps, device, prng, dist=None, torch_d
     if rank == 0:
         bb.keygen()
     res["keygen_s"] = round(time.perf_counter() - t0, 2)
-    if world > 1:
+    if world > 1 or (force_replication and dist is not None):
         import torch
         # rank 0 tells the others which keys exist, then the packed key words travel: scatter + all-gather over xGMI
         n = torch.zeros(1, dtype=torch.int64, device=torch_device)

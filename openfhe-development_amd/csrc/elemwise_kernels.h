@@ -159,6 +159,49 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) elemwise_cv_kernel(const ElemArgs g,
     elemwise_body<OP>(g, [&](uint32_t rit) { return cv.c[rit]; });
 }
 
+// ---- linear combination of towers with per-limb constants: out = sum_i c_i (.) x_i  [+ out] ------------------------------------------
+// pke's weighted sums (internalEvalLinearWSumMutable, ckksrns-advancedshe.cpp:97-136: the inner loops of the Chebyshev evaluation of
+// bootstrapping) multiply every term by its constant and add the products one by one: 2n - 1 tower-sized launches moving 5n - 3
+// towers.  One launch reads each term once and writes the sum once (n + 1 towers).  Exact modular arithmetic: any order of the sum
+// gives the reference's residues.  Every x_i is a dense [batch][nLimbs][N] tower of its own allocation.
+constexpr int kMaxLinTerms = 16;
+struct LinCombArgs {
+    uint64_t* out;
+    const uint64_t* x[kMaxLinTerms];
+    const TwPair* consts;  // [nTerms][nLimbs] Shoup pairs (device)
+    const uint64_t* q;     // [ctxLimbs]
+    uint32_t nTerms, logN, nLimbs, rows, accumulate;
+    LimbSel sel;
+};
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) lincomb_kernel(const LinCombArgs g) {
+    const uint32_t t          = FHE_TID;
+    const uint64_t base       = (uint64_t)FHE_BID << kTileLog;
+    const uint64_t totalWords = (uint64_t)g.rows << g.logN;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const uint64_t off = base + (((uint64_t)m * kThreads + t) << 1);
+        if (off >= totalWords)
+            continue;
+        const uint32_t rit  = (uint32_t)(off >> g.logN) % g.nLimbs;
+        const uint64_t q    = g.q[g.sel.idx[rit]];
+        const uint64_t twoq = q << 1, nq = 0 - q;
+        uint64_t s0 = 0, s1 = 0;  // lazily below 2q
+        for (uint32_t i = 0; i < g.nTerms; ++i) {
+            const TwPair c    = g.consts[(size_t)i * g.nLimbs + rit];
+            const uint64_t a0 = g.x[i][off], a1 = g.x[i][off + 1];
+            s0 = csub(s0 + mul_shoup_lazy_nq(a0, c.w, c.wp, nq), twoq);
+            s1 = csub(s1 + mul_shoup_lazy_nq(a1, c.w, c.wp, nq), twoq);
+        }
+        s0 = csub(s0, q), s1 = csub(s1, q);
+        if (g.accumulate) {
+            s0 = add_mod(g.out[off], s0, q);
+            s1 = add_mod(g.out[off + 1], s1, q);
+        }
+        g.out[off]     = s0;
+        g.out[off + 1] = s1;
+    }
+}
+
 // ---- EvalMultCore tensor product: d0 = a0*b0, d1 = a0*b1 + a1*b0, d2 = a1*b1 ------------------------
 struct TensorArgs {
     const uint64_t *a0, *a1, *b0, *b1;

@@ -1037,6 +1037,37 @@ extern "C" fhe_status fhe_mul_const(fhe_ctx* c, uint64_t* o, const uint64_t* a, 
         return s;
     return elem_cv_run<OP_MUL_CONST>(c, o, a, nullptr, cv, li, nl, bt, st, "fhe_mul_const");
 }
+static fhe_status const_table(fhe_ctx* c, const uint32_t* limbIdx, const uint64_t* v, uint32_t n, const TwPair** out);
+// out = sum_i consts[i][.] (.) x[i]  (+ out when accumulate): the weighted sums of pke (ckksrns-advancedshe.cpp:97-136) as ONE launch per
+// 16 terms.  consts: HOST array [nTerms][nLimbs], reduced modulo their limbs; their device table is cached by content (the Chebyshev
+// coefficients of a bootstrap repeat), so only the first use of a table blocks for its upload.
+extern "C" fhe_status fhe_lincomb(fhe_ctx* c, uint64_t* out, const uint64_t* const* x, const uint64_t* consts, uint32_t nTerms,
+                                  const uint32_t* limbIdx, uint32_t nLimbs, uint32_t batch, int accumulate, void* stream) {
+    ARG_CHECK(c && out && x && consts && nTerms >= 1 && batch >= 1, "fhe_lincomb: bad argument");
+    LinCombArgs g;
+    if (fhe_status s = make_sel(c, limbIdx, nLimbs, &g.sel, "fhe_lincomb"))
+        return s;
+    RT_CHECK(rt::set_device(c->device));
+    std::vector<uint32_t> li((size_t)nTerms * nLimbs);
+    for (uint32_t i = 0; i < nTerms; ++i)
+        for (uint32_t r = 0; r < nLimbs; ++r)
+            li[(size_t)i * nLimbs + r] = limbIdx ? limbIdx[r] : r;
+    const TwPair* table = nullptr;
+    if (fhe_status s = const_table(c, li.data(), consts, nTerms * nLimbs, &table))
+        return s;
+    g.out = out, g.q = c->d_q, g.logN = c->logN, g.nLimbs = nLimbs, g.rows = batch * nLimbs;
+    for (uint32_t first = 0; first < nTerms; first += (uint32_t)kMaxLinTerms) {
+        const uint32_t n = std::min<uint32_t>(kMaxLinTerms, nTerms - first);
+        for (uint32_t i = 0; i < (uint32_t)kMaxLinTerms; ++i) {
+            g.x[i] = i < n ? x[first + i] : nullptr;
+            ARG_CHECK(i >= n || g.x[i], "fhe_lincomb: null term");
+        }
+        g.consts = table + (size_t)first * nLimbs, g.nTerms = n, g.accumulate = (accumulate || first) ? 1u : 0u;
+        FHE_LAUNCH(lincomb_kernel, tiles_for(c, g.rows), stream, g);
+        LAUNCH_CHECK();
+    }
+    return FHE_OK;
+}
 // ---- the two elements of a ciphertext in ONE launch: towers 0 and 1 of every operand are separately allocated buffers ----
 // (pke applies every operation element by element, base-leveledshe.cpp:562-606, ckksrns-leveledshe.cpp:748-759: at one ciphertext
 // a launch per element leaves most of the chip idle — a tower of 14 limbs at N = 2^17 is 448 workgroups for 1024 resident slots)

@@ -686,7 +686,10 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_static_kernel(const NttPassArgs 
     // more workgroups fit on a CU
     using P = SPlan<LA, INV, T>;
     constexpr bool needsLds = P::nst > 1 || P::stageFirst || P::stageLast;
-    FHE_SHARED_U64(lds, needsLds ? kLdsPadWords + kSharedTwWords : 1);
+#ifndef FHE_ABL_LDSPAD  // timing experiment: extra LDS words per workgroup (fewer workgroups per CU)
+#define FHE_ABL_LDSPAD 0
+#endif
+    FHE_SHARED_U64(lds, needsLds ? kLdsPadWords + kSharedTwWords + FHE_ABL_LDSPAD : 1);
     ntt_static_body<LA, INV, T, MODE, EPI, PRO>(a, FHE_BID, lds);
 }
 

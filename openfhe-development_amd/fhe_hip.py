@@ -136,6 +136,7 @@ class Lib:
         S("fhe_add_pair", C.c_int, [vp, vp, vp, vp, vp, vp, vp, u32p, u32, vp])
         S("fhe_sub_pair", C.c_int, [vp, vp, vp, vp, vp, vp, vp, u32p, u32, vp])
         S("fhe_mul_const_pair", C.c_int, [vp, vp, vp, vp, vp, u64p, u32p, u32, vp])
+        S("fhe_lincomb", C.c_int, [vp, vp, C.POINTER(vp), u64p, u32, u32p, u32, u32, C.c_int, vp])
         S("fhe_mod_reduce", C.c_int, [vp, vp, u32, u64, C.c_int, u32, vp, vp, C.c_size_t, vp])
         f64p = C.POINTER(C.c_double)
         S("fhe_sr_plan_create", C.c_int, [vp, u32, u32p, u32, u64p, f64p, C.POINTER(vp)])
@@ -676,6 +677,19 @@ def rescale_limbs_pair(ctx, x0, x1, scale_tab, inv_tab, stream=None):
     ctx.sync(stream)
     ctx.free(ws)
     return o0, o1
+
+
+def lincomb(ctx, towers, consts, accumulate_into=None, stream=None):
+    """fhe_lincomb: sum_i consts[i] (.) towers[i] per limb (pke's weighted sum, ckksrns-advancedshe.cpp:97-136) in one launch per 16 terms;
+    consts[i][r] = the constant of term i on limb r (reduced).  accumulate_into: a Tower the sum is added to (returned), else a new one."""
+    t0 = towers[0]
+    out = accumulate_into if accumulate_into is not None else ctx.empty(t0.batch, t0.n_limbs, t0.limb_idx, t0.fmt)
+    ptrs = (vp * len(towers))(*[t.ptr.value if hasattr(t.ptr, "value") else t.ptr for t in towers])
+    k = np.ascontiguousarray(consts, dtype=np.uint64).reshape(len(towers), t0.n_limbs)
+    ctx.lib.check(ctx.lib.L.fhe_lincomb(ctx.h, out.ptr, ptrs, k.ctypes.data_as(u64p), len(towers), t0._li(), t0.n_limbs, t0.batch,
+                                         1 if accumulate_into is not None else 0, stream))
+    ctx.sync(stream)
+    return out
 
 
 def elem_pair(ctx, kind, a0, a1, b0=None, b1=None, consts=None, in_place=False, stream=None):

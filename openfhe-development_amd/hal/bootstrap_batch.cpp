@@ -27,6 +27,9 @@ using namespace lbcrypto;
 #ifdef WITH_HIP
 #include "lattice/hal/hip/hip-runtime.h"
 extern "C" void fhe_hal_set_device(int device);
+extern "C" void fhe_hal_operand_bytes(uint64_t out[2]);
+extern "C" void fhe_hal_stats(uint64_t out[4]);
+extern "C" size_t fhe_hal_launch_stats(char* buf, size_t cap, uint64_t* total);
 #endif
 
 namespace {
@@ -371,6 +374,21 @@ long fbb_compare_saved(void* h) {
         }
     });
     return diff;
+}
+// counters of the backend since the process started: {operand bytes read, operand bytes written (every tower / key an operation touches,
+// once per operation), kernel launches, host->device bytes, device->host bytes}; all zero on the stock backend
+void fbb_counters(uint64_t out[5]) {
+    for (int i = 0; i < 5; ++i)
+        out[i] = 0;
+#ifdef WITH_HIP
+    fhe_hal_operand_bytes(out);
+    uint64_t total = 0;
+    fhe_hal_launch_stats(nullptr, 0, &total);
+    out[2] = total;
+    uint64_t st[4];
+    fhe_hal_stats(st);
+    out[3] = st[2], out[4] = st[3];
+#endif
 }
 // decrypts output i of the rank's slice: the first 8 slots into vals; returns the largest absolute error against the message
 double fbb_check(void* h, uint32_t i, double* vals) {

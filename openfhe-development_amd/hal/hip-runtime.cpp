@@ -10,6 +10,7 @@
 #include "lattice/hal/hip/hip-runtime.h"
 #include "hip-hooks.h"
 
+#include <chrono>
 #include <cxxabi.h>
 #include <dlfcn.h>
 #include <execinfo.h>
@@ -88,6 +89,13 @@ struct Runtime {
     std::mutex holderMutex;
     std::map<fhe_ctx*, CtxHolder*> holders;
     std::atomic<uint64_t> deviceOps{0}, hostFallbacks{0}, h2dBytes{0}, d2hBytes{0}, hostSmallRing{0}, hostData{0};
+    // why an operation left the device library's domain (Resolve): a ring outside [16, 2^17] or not a power of two; a modulus that is
+    // not a prime-shaped NTT modulus below 2^60; more than 128 distinct moduli in one operation; a second root of unity for a modulus
+    std::atomic<uint64_t> outRing{0}, outModulus{0}, outMoreThan128Moduli{0}, outOtherRoot{0};
+    // operand bytes of the device operations: every tower (or key, or table held in a DevBuf) an operation reads / writes, counted once
+    // per operation — what the sequence of fused operations has to move if every operand crossed HBM exactly once (the algorithmic
+    // bytes of a composite's roofline)
+    std::atomic<uint64_t> opReadBytes{0}, opWriteBytes{0};
     bool requireDevice = false;
 };
 
@@ -136,7 +144,7 @@ Runtime* build() {
                   FHE_SYM(mod_switch_round, fhe_mod_switch_round) && FHE_SYM(automorph, fhe_automorph) &&
                   FHE_SYM(switch_modulus, fhe_switch_modulus) && FHE_SYM(rescale_limbs, fhe_rescale_limbs) &&
                   FHE_SYM(rescale_limbs_pair, fhe_rescale_limbs_pair) && FHE_SYM(add_pair, fhe_add_pair) && FHE_SYM(sub_pair, fhe_sub_pair) &&
-                  FHE_SYM(mul_const_pair, fhe_mul_const_pair) &&
+                  FHE_SYM(mul_const_pair, fhe_mul_const_pair) && FHE_SYM(lincomb, fhe_lincomb) &&
                   FHE_SYM(rescale_workspace_bytes, fhe_rescale_workspace_bytes) && FHE_SYM(conv_create_custom, fhe_conv_create_custom) &&
                   FHE_SYM(approx_switch_basis, fhe_approx_switch_basis) && FHE_SYM(switch_basis_exact, fhe_switch_basis_exact) &&
                   FHE_SYM(sr_plan_create, fhe_sr_plan_create) && FHE_SYM(scale_and_round, fhe_scale_and_round) &&
@@ -289,23 +297,27 @@ ThreadState* thread_state() {  // nullptr once the thread's state has been destr
         t_holder.ts = new ThreadState;
     return t_holder.ts;
 }
-// the calling thread's later work must come after use `u` of a buffer
+// the calling thread's later work must come after use `u` of a buffer.  Never called with a buffer's mutex held: the wait below is for
+// ANOTHER thread to close the operation that made the use (its launch is enqueued when its outermost Op closes), and that thread may
+// need the same mutex on the way.  The use is recorded as ordered only up to the mark actually observed; two threads that each wait for
+// a use the other has stamped but not yet enqueued (host code racing on the same towers) end in the exception below, not in words
+// computed before their producer ran.
 void order_after(ThreadState* ts, const DevBuf::Use& u) {
     Runtime& r = rt();
     if (u.stream == 0 || u.stream == ts->id || u.seq <= ts->waited[u.stream])
         return;
     StreamState& other = r.streams[u.stream];
     uint64_t mark      = other.enqueued.load(std::memory_order_acquire);
-    for (int spin = 0; mark < u.seq; ++spin) {  // (the other thread is still inside the operation that made this use: it is about to finish)
-        if (spin > 1000000) {
-            r.api.sync(r.anyCtx, other.s);
-            break;
-        }
+    const auto t0      = std::chrono::steady_clock::now();
+    for (uint32_t spin = 0; mark < u.seq; ++spin) {  // (the other thread is still inside the operation that made this use: it is about to finish)
+        if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
+            OPENFHE_THROW("HIP backend: a use of a tower stamped by another host thread was not enqueued within 30 s (host threads racing "
+                          "on the same DCRTPoly, or a thread blocked inside a device operation)");
         sched_yield();
         mark = other.enqueued.load(std::memory_order_acquire);
     }
     Check(r.api.stream_wait(r.anyCtx, r.streams[ts->id].s, other.s), "HIP backend: ordering two host threads' streams");
-    ts->waited[u.stream] = std::max(mark, u.seq);
+    ts->waited[u.stream] = mark;  // everything the other stream had enqueued when observed (>= u.seq) precedes this thread's later work
 }
 DevBuf* root_of(DevBuf* b) {
     while (b->parent)
@@ -357,32 +369,46 @@ Op::~Op() {
         st.enqueued.store(st.issued.load(std::memory_order_relaxed), std::memory_order_release);
     }
 }
+// (both stamp the buffer under its mutex and order the calling stream behind the earlier uses AFTER releasing it: the stamp only says
+// "this stream, this sequence number will touch the words"; the launch follows when the caller returns from R / W)
 const uint64_t* Op::R(const Buf& b) {
     ThreadState* ts = thread_state();
     DevBuf* root    = root_of(b.get());
-    std::lock_guard<std::mutex> lk(root->mu);
-    order_after(ts, root->writer);
-    for (auto& u : root->readers)
-        if (u.stream == ts->id) {
-            u.seq = m_seq;
-            return b->p;
-        }
-    root->readers.push_back(DevBuf::Use{ts->id, m_seq});
+    DevBuf::Use writer;
+    {
+        std::lock_guard<std::mutex> lk(root->mu);
+        writer     = root->writer;
+        bool found = false;
+        for (auto& u : root->readers)
+            if (u.stream == ts->id) {
+                u.seq = m_seq;
+                found = true;
+                break;
+            }
+        if (!found)
+            root->readers.push_back(DevBuf::Use{ts->id, m_seq});
+    }
+    order_after(ts, writer);
+    rt().opReadBytes.fetch_add((uint64_t)b->words * 8, std::memory_order_relaxed);
     return b->p;
 }
-uint64_t* Op::W(const Buf& b) {
+uint64_t* Op::W(const Buf& b, bool operand) {
     ThreadState* ts = thread_state();
     DevBuf* root    = root_of(b.get());
     std::vector<DevBuf::Memo> history;  // (released after the lock)
+    std::vector<DevBuf::Use> before;
     {
         std::lock_guard<std::mutex> lk(root->mu);
-        order_after(ts, root->writer);
-        for (const auto& u : root->readers)
-            order_after(ts, u);
+        before.push_back(root->writer);
+        before.insert(before.end(), root->readers.begin(), root->readers.end());
         root->readers.clear();
         root->writer = DevBuf::Use{ts->id, m_seq};
         history.swap(root->memo);  // the words change: what was derived from them is history
     }
+    for (const auto& u : before)
+        order_after(ts, u);
+    if (operand)
+        rt().opWriteBytes.fetch_add((uint64_t)b->words * 8, std::memory_order_relaxed);
     return b->p;
 }
 std::atomic<uint64_t> g_memoHits{0};
@@ -478,13 +504,18 @@ Buf Alloc(size_t words) {
         if (!fl.empty()) {
             b->p = fl.back();
             fl.pop_back();
+            // Kernels of the buffer's previous life may still be pending on THIS thread's stream (free lists and inboxes hold such
+            // buffers on purpose: ~DevBuf only orders the stream).  This thread's own launches follow them in stream order; a first use
+            // by ANOTHER thread (a tower allocated here and filled by an OpenMP worker) must be ordered behind them: the new buffer
+            // starts its life written "by this stream, at everything issued so far".
+            b->writer = DevBuf::Use{ts->id, r.streams[ts->id].issued.load(std::memory_order_relaxed)};
             return b;
         }
     }
     {
         std::lock_guard<std::mutex> lk(r.poolMutex);
         auto& fl = r.orphanLists[bk];
-        if (!fl.empty()) {
+        if (!fl.empty()) {  // (orphans were parked after a host-side wait for their pending uses: nothing to order behind)
             b->p = fl.back();
             fl.pop_back();
             return b;
@@ -636,6 +667,13 @@ static void trace_site(const char* kind, const char* member, uint64_t amount) {
     (*g_traceSites)[key] += amount;
 }
 void OtherHostCounts(uint64_t out[2]) { out[0] = rt().hostSmallRing, out[1] = rt().hostData; }
+// why a device plan or a context could not be built (the member then runs on the host mirror): "<what>: <the library's message>" -> count
+static std::mutex g_declineMutex;
+static std::map<std::string, uint64_t> g_declines;
+void Declined(const char* what, const std::string& why) {
+    std::lock_guard<std::mutex> lk(g_declineMutex);
+    g_declines[std::string(what) + ": " + why] += 1;
+}
 void CountHost(const char* member, uint32_t ringDim, bool hostData) {
     Runtime& r       = rt();
     const char* name = t_scope ? t_scope : member;
@@ -651,7 +689,12 @@ void CountHost(const char* member, uint32_t ringDim, bool hostData) {
     }
     r.hostFallbacks.fetch_add(1, std::memory_order_relaxed);
     member_slot(name).host.fetch_add(1, std::memory_order_relaxed);
-    trace_site("hostop", name, 1);
+    if (t_scope && std::strcmp(t_scope, member) != 0) {  // (the trace names the member inside the scope it is attributed to)
+        const std::string both = std::string(t_scope) + "/" + member;
+        trace_site("hostop", both.c_str(), 1);
+    }
+    else
+        trace_site("hostop", name, 1);
     if (r.requireDevice && r.live && has_device_path(name))
         OPENFHE_THROW(std::string("HIP backend: DCRTPoly::") + name + " ran on the host mirror although FHE_HAL_REQUIRE_DEVICE is set");
 }
@@ -676,13 +719,19 @@ void CountD2H(size_t b) {
 // ---- contexts ----
 bool Resolve(uint32_t ringDim, const std::vector<LimbSet>& sets, Resolved* out) {
     Runtime& r = rt();
-    if (!r.live || ringDim < 16 || ringDim > (1u << 17) || (ringDim & (ringDim - 1)))
+    if (!r.live)
         return false;
+    if (ringDim < 16 || ringDim > (1u << 17) || (ringDim & (ringDim - 1))) {
+        r.outRing.fetch_add(1, std::memory_order_relaxed);
+        return false;
+    }
     const uint64_t twoN = 2ull * ringDim;
     for (const auto& s : sets)
         for (uint32_t i = 0; i < s.n; ++i)
-            if (s.q[i] < 3 || s.q[i] >= (1ull << 60) || (s.q[i] - 1) % twoN != 0 || s.psi[i] == 0)
+            if (s.q[i] < 3 || s.q[i] >= (1ull << 60) || (s.q[i] - 1) % twoN != 0 || s.psi[i] == 0) {
+                r.outModulus.fetch_add(1, std::memory_order_relaxed);
                 return false;
+            }
     std::lock_guard<std::mutex> lk(r.ctxMutex);
     auto& u = r.universes[ringDim];
     // fast path: every modulus is known (the usual case after the first few operations of a CryptoContext)
@@ -704,12 +753,17 @@ bool Resolve(uint32_t ringDim, const std::vector<LimbSet>& sets, Resolved* out) 
             // moduli of this call; towers already on the device are plain words and resolve again at their next operation
             q.clear(), psi.clear();
             add(q, psi);
-            if (q.size() > 128)
+            if (q.size() > 128) {
+                r.outMoreThan128Moduli.fetch_add(1, std::memory_order_relaxed);
+                Declined("device context", "more than 128 distinct moduli in one operation (" + std::to_string(q.size()) + ")");
                 return false;
+            }
         }
         fhe_ctx* c = nullptr;
-        if (r.api.ctx_create(log2u(ringDim), (uint32_t)q.size(), q.data(), psi.data(), r.device, &c) != FHE_OK)
+        if (r.api.ctx_create(log2u(ringDim), (uint32_t)q.size(), q.data(), psi.data(), r.device, &c) != FHE_OK) {
+            Declined("device context", r.api.last_error());
             return false;  // (e.g. a root that is not primitive: leave the operation to the host mirror)
+        }
         // the previous context lives on while operations of other threads hold it (Resolved::hold), then it is destroyed
         auto h = std::make_shared<CtxHolder>();
         h->ctx = c;
@@ -729,8 +783,10 @@ bool Resolve(uint32_t ringDim, const std::vector<LimbSet>& sets, Resolved* out) 
         out->idx[si].resize(sets[si].n);
         for (uint32_t i = 0; i < sets[si].n; ++i) {
             const uint32_t l = u.limbOf[sets[si].q[i]];
-            if (u.psi[l] != sets[si].psi[i])
+            if (u.psi[l] != sets[si].psi[i]) {
+                r.outOtherRoot.fetch_add(1, std::memory_order_relaxed);
                 return false;  // same modulus with another root of unity: another transform, not ours
+            }
             out->idx[si][i] = l;
         }
     }
@@ -817,8 +873,10 @@ fhe_behz* BehzPlan(fhe_ctx* ctx, const std::vector<uint32_t>& qIdx, const std::v
     if (it != H.behzPlans.end())
         return it->second;
     fhe_behz* p = nullptr;
-    if (r.api.behz_create(ctx, qIdx.data(), (uint32_t)numQ, bskIdx.data(), t ? t : 65537, &p) != FHE_OK)
+    if (r.api.behz_create(ctx, qIdx.data(), (uint32_t)numQ, bskIdx.data(), t ? t : 65537, &p) != FHE_OK) {
+        Declined("BEHZ plan", r.api.last_error());
         return nullptr;  // (bases the device kernels do not take: the member runs on the host mirror)
+    }
     const uint64_t* T = tables.data();
     fhe_status s;
     if (which == 0)
@@ -1070,6 +1128,8 @@ extern "C" void fhe_hal_stats_reset(void) {
     using namespace lbcrypto::hiprt;
     auto& r = rt();
     r.deviceOps = 0, r.hostFallbacks = 0, r.h2dBytes = 0, r.d2hBytes = 0, r.hostSmallRing = 0, r.hostData = 0;
+    r.outRing = 0, r.outModulus = 0, r.outMoreThan128Moduli = 0, r.outOtherRoot = 0;
+    r.opReadBytes = 0, r.opWriteBytes = 0;
     for (auto& m : g_members)
         m.device = 0, m.host = 0, m.reads = 0;
 }
@@ -1094,6 +1154,32 @@ extern "C" void fhe_hal_composite_stats(uint64_t out[3]) {
     out[0] = lbcrypto::hiprt::g_compositeCalls, out[1] = lbcrypto::hiprt::g_checksOk, out[2] = lbcrypto::hiprt::g_checksBad;
 }
 extern "C" void fhe_hal_other_host_counts(uint64_t out[2]) { lbcrypto::hiprt::OtherHostCounts(out); }
+// operations that left the device library's domain, by reason: {ring outside [16, 2^17], modulus outside the domain, more than 128
+// distinct moduli, another root of unity for a known modulus}
+// operand bytes of the device operations so far: {read, written} (see Runtime::opReadBytes)
+extern "C" void fhe_hal_operand_bytes(uint64_t out[2]) {
+    auto& r = lbcrypto::hiprt::rt();
+    out[0] = r.opReadBytes, out[1] = r.opWriteBytes;
+}
+// "<what>: <why> <count>" lines: device plans / contexts that could not be built (Declined)
+extern "C" size_t fhe_hal_decline_stats(char* buf, size_t cap) {
+    std::string s;
+    {
+        std::lock_guard<std::mutex> lk(lbcrypto::hiprt::g_declineMutex);
+        for (auto& kv : lbcrypto::hiprt::g_declines)
+            s += kv.first + " x" + std::to_string(kv.second) + "\n";
+    }
+    if (buf && cap) {
+        const size_t n = std::min(cap - 1, s.size());
+        std::memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return s.size() + 1;
+}
+extern "C" void fhe_hal_out_of_domain(uint64_t out[4]) {
+    auto& r = lbcrypto::hiprt::rt();
+    out[0] = r.outRing, out[1] = r.outModulus, out[2] = r.outMoreThan128Moduli, out[3] = r.outOtherRoot;
+}
 
 // ---- ChineseRemainderTransformFTT<NativeVector> (math/math-hal.h:60-106, math/hal/transform.h:60-163): the four transform members, declared
 // as explicit specialisations by this backend's math/hal/intnat/transformnat-impl.h.  One limb of a ring N >= 2^12 (FHE_HAL_FTT_MIN_LOGN) whose

@@ -292,7 +292,7 @@ bool CompositeKeySwitchAcc(hiprt::KsDomain& dom, uint32_t sizeQl, const std::vec
     const size_t wsB = A.ks_workspace_bytes(hiprt::DomainPlan(dom), sizeQl, width);
     auto ws          = hiprt::Alloc(wsB / 8 + 1);
     op.R(pk.b), op.R(pk.a);
-    hiprt::Check(A.keyswitch_hybrid_acc(hiprt::DomainPlan(dom), pk.key.get(), op.R(bc), sizeQl, width, op.W(b0), op.W(b1), op.W(ws), wsB, op.s),
+    hiprt::Check(A.keyswitch_hybrid_acc(hiprt::DomainPlan(dom), pk.key.get(), op.R(bc), sizeQl, width, op.W(b0), op.W(b1), op.W(ws, false), wsB, op.s),
                  "EvalMult: composite key switch");
     hiprt::CountDevice("EvalMult.KeySwitchAccumulate");
     hiprt::CountComposite();
@@ -377,7 +377,7 @@ std::shared_ptr<std::vector<DCRTPoly>> KeySwitchHYBRID::KeySwitchCore(const DCRT
         const size_t wsB     = A.ks_workspace_bytes(hiprt::DomainPlan(*dom), sizeQl, width);
         auto ws = hiprt::Alloc(wsB / 8 + 1), o0 = hiprt::Alloc((size_t)width * sizeQl * N), o1 = hiprt::Alloc((size_t)width * sizeQl * N);
         op.R(pk.b), op.R(pk.a);
-        hiprt::Check(A.keyswitch_hybrid(hiprt::DomainPlan(*dom), pk.key.get(), op.R(bc), sizeQl, width, op.W(o0), op.W(o1), op.W(ws), wsB, op.s),
+        hiprt::Check(A.keyswitch_hybrid(hiprt::DomainPlan(*dom), pk.key.get(), op.R(bc), sizeQl, width, op.W(o0), op.W(o1), op.W(ws, false), wsB, op.s),
                      "KeySwitchCore: composite key switch");
         hiprt::CountDevice("KeySwitchCore");
         hiprt::CountComposite();
@@ -712,7 +712,7 @@ bool BsgsLevelOnDevice(Ciphertext<DCRTPoly>& ct, const std::vector<int32_t>& rot
     const size_t wsB = Api.bsgs_workspace_bytes(hiprt::DomainPlan(*dom), sizeQl, width, nIn, nOut);
     auto ws = hiprt::Alloc(wsB / 8 + 1), o0 = hiprt::Alloc((size_t)width * sizeQl * N), o1 = hiprt::Alloc((size_t)width * sizeQl * N);
     if (Api.bsgs_transform(hiprt::DomainPlan(*dom), op.R(b0), op.R(b1), sizeQl, width, nIn, inK.data(), inKeys.data(), nOut, outK.data(), outKeys.data(),
-                           diag.data(), op.W(o0), op.W(o1), op.W(ws), wsB, op.s) != FHE_OK)
+                           diag.data(), op.W(o0), op.W(o1), op.W(ws, false), wsB, op.s) != FHE_OK)
         return Why(10);
     hiprt::CountDevice("Bootstrap.BsgsLevel");
     hiprt::CountComposite();

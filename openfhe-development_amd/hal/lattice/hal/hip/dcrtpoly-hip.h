@@ -78,10 +78,11 @@ public:
         return *this;
     }
     DCRTPolyHipImpl(DCRTPolyType&& e) noexcept
-        : m_h{std::move(e.m_h)}, m_d{std::move(e.m_d)}, m_hostValid{e.m_hostValid}, m_zero{e.m_zero}, m_k{e.m_k} {}
+        : m_h{std::move(e.m_h)}, m_d{std::move(e.m_d)}, m_lazy{std::move(e.m_lazy)}, m_hostValid{e.m_hostValid}, m_zero{e.m_zero}, m_k{e.m_k} {}
     DCRTPolyType& operator=(DCRTPolyType&& rhs) noexcept override {
         m_h         = std::move(rhs.m_h);
         m_d         = std::move(rhs.m_d);
+        m_lazy      = std::move(rhs.m_lazy);
         m_hostValid = rhs.m_hostValid;
         m_zero      = rhs.m_zero;
         m_k         = rhs.m_k;
@@ -166,9 +167,12 @@ public:
     // dcrtpoly-impl.h:207-214
     DCRTPolyType CloneTowers(uint32_t startTower, uint32_t endTower) const {
         FHE_HAL_MEMBER();
+        Settle();
         // (words that exist on the host only — a secret key's towers as the sampler produced them — are cloned where they are: an upload
         // here was read back limb by limb by key generation, 0.85 GB of PCIe over the reference's unit tests)
-        if (m_d && !m_hostValid && endTower < NumLimbs() && startTower <= endTower) {
+        // (a tower with a device copy is cloned on the device whether or not the mirror is valid too: the secret key during key generation
+        // has both, and its clone's next member is a transform)
+        if (m_d && endTower < NumLimbs() && startTower <= endTower) {
             const auto& P = m_h.GetParams();
             auto params   = std::make_shared<Params>(P->GetCyclotomicOrder(), P->GetParamPartition(startTower, endTower));
             const size_t N = P->GetRingDimension(), n = endTower - startTower + 1, L = NumLimbs();
@@ -197,6 +201,8 @@ public:
     // ---------------------------------------------------------------------------------------------------------------
     DCRTPolyType& operator+=(const DCRTPolyType& rhs) override {
         FHE_HAL_MEMBER();
+        if (AddLazily(rhs, false))
+            return *this;
         if (!BinaryInPlace(rhs, hiprt::api().add, false))
             Hm() += rhs.Hc();
         return *this;
@@ -216,6 +222,8 @@ public:
     }
     DCRTPolyType& operator-=(const DCRTPolyType& rhs) override {
         FHE_HAL_MEMBER();
+        if (AddLazily(rhs, true))
+            return *this;
         if (!BinaryInPlace(rhs, hiprt::api().sub, false))
             Hm() -= rhs.Hc();
         return *this;
@@ -373,6 +381,11 @@ public:
             std::vector<NativeInteger> c(NumLimbs());
             for (uint32_t i = 0; i < NumLimbs(); ++i)
                 c[i] = NativeInteger(rhs[i]);
+            if (m_k > 1) {  // a wide tower: the product is recorded, the sum it usually joins is computed in one launch (m_lazy)
+                DCRTPolyType lazy(*this);
+                if (lazy.ScaleLazily(c))
+                    return lazy;
+            }
             // (a clone multiplied by the constants its original was multiplied by before — the level adjustments of pke's weighted sums
             // — takes that result: DevBuf::memo)
             const hiprt::Buf src = m_d;
@@ -431,6 +444,8 @@ public:
     }
     DCRTPolyType TimesNoCheck(const std::vector<NativeInteger>& rhs) const {
         FHE_HAL_MEMBER();
+        // (fewer factors than limbs: the reference leaves the trailing limbs of the result UNFILLED, dcrtpoly-impl.h:594-601 — such a
+        // tower has no device form; KeySwitchGenInternal meets it with old keys that carry more limbs than [P]_q has entries)
         if (rhs.size() >= NumLimbs()) {
             DCRTPolyType out(*this);
             if (out.TimesConstInPlace(rhs))
@@ -448,7 +463,7 @@ public:
         return Hc().InverseExists();
     }
     bool IsEmpty() const override {
-        return (m_zero || (m_d && !m_hostValid)) ? false : m_h.IsEmpty();
+        return (m_zero || m_lazy || (m_d && !m_hostValid)) ? false : m_h.IsEmpty();
     }
 
     void SetValuesToZero() override {
@@ -458,6 +473,7 @@ public:
             auto P      = m_h.GetParams();
             m_h         = HostType(P, m_h.GetFormat(), false);
             m_d.reset();
+            m_lazy.reset();
             m_hostValid = false;
             m_zero      = true;
             return;
@@ -485,6 +501,7 @@ public:
     }
     // a wide tower stays dense ([m_k][limbs][N]): its towers move together when limbs are dropped
     void CompactForDrop(size_t drop) {
+        Settle();  // (a pending sum of wide towers is computed at its full height)
         if (m_k == 1 || !m_d || drop == 0 || drop >= NumLimbs())
             return;
         const size_t N = m_h.GetParams()->GetRingDimension(), L = NumLimbs(), l = L - drop;
@@ -1137,7 +1154,7 @@ public:
         const uint64_t *x0 = op.R(a0.m_d), *x1 = op.R(a1.m_d);
         const size_t wsBytes = A.rescale_workspace_bytes(r.ctx, L, 2);
         auto ws = hiprt::Alloc(wsBytes / 8), o0 = hiprt::Alloc((size_t)l * N), o1 = hiprt::Alloc((size_t)l * N);
-        hiprt::Check(A.rescale_limbs_pair(r.ctx, x0, x1, r.idx[0].data(), L, a.data(), b.data(), op.W(o0), op.W(o1), op.W(ws), wsBytes, op.s),
+        hiprt::Check(A.rescale_limbs_pair(r.ctx, x0, x1, r.idx[0].data(), L, a.data(), b.data(), op.W(o0), op.W(o1), op.W(ws, false), wsBytes, op.s),
                      "DropLastElementAndScale on both elements");
         if (remember) {
             hiprt::MemoStore(s0, memoKey, o0);
@@ -1165,7 +1182,7 @@ public:
     }
     // true while the authoritative copy of the words is the device buffer
     bool IsDeviceResident() const {
-        return m_d && !m_hostValid;
+        return (m_d || m_lazy) && !m_hostValid;
     }
     // ---- for the backend's composite hooks (hal/keyswitch-hybrid-hip.cpp: whole pke operations as ONE library call) ----
     // the tower's device words (uploaded if they are on the host), nullptr when the tower cannot live on the device
@@ -1214,6 +1231,21 @@ private:
 
     mutable HostType m_h;           // metadata always; words valid iff m_hostValid
     mutable hiprt::Buf m_d;         // device words [nLimbs][N] (may hold more rows than nLimbs after DropLastElement)
+    // A WIDE tower (lockstep evaluation) whose value is a weighted sum not yet computed: value = sum_t k_t (.) words_t per limb.  pke's
+    // weighted sums (internalEvalLinearWSumMutable, ckksrns-advancedshe.cpp:97-136: the inner loops of bootstrapping's Chebyshev
+    // evaluation) are `EvalMultInPlace(ct_i, c_i); EvalAddInPlaceNoCheck(ct_0, ct_i)` per term — Times(vector<Integer>) and operator+=
+    // here: the product and the sums are recorded, and the first member that needs the words computes the whole sum in ONE launch that
+    // reads every term once (fhe_lincomb) instead of 2n - 1 launches moving 5n - 3 towers.  While m_lazy is set m_d is null and the
+    // mirror holds (params, format) only; the terms' buffers are shared references, so nobody writes them in place meanwhile
+    // (WriteTarget / Unshare copy shared words first).  Exact modular arithmetic: the residues are the reference's.
+    struct LazyTerm {
+        hiprt::Buf words;
+        std::vector<uint64_t> k;  // factor of limb i (reduced modulo q_i), at least NumLimbs() entries
+    };
+    struct LazySum {
+        std::vector<LazyTerm> terms;
+    };
+    mutable std::shared_ptr<const LazySum> m_lazy;
     mutable bool m_hostValid{true};
     mutable bool m_zero{false};     // an all-zero tower not yet materialised on either side (then !m_hostValid && !m_d)
     // WIDE tower (hiprt::WidthScope): the device buffer holds m_k towers [m_k][nLimbs][N], dense, of m_k ciphertexts with equal metadata
@@ -1306,12 +1338,129 @@ private:
         static thread_local WideRead w;
         return w;
     }
+    // ---- pending weighted sums (m_lazy) -------------------------------------------------------------------------------
+    static bool LazySums() {
+        static const bool on = !(std::getenv("FHE_HAL_LAZY_SUMS") && std::string(std::getenv("FHE_HAL_LAZY_SUMS")) == "0");
+        return on && hiprt::Available();
+    }
+    static constexpr size_t kMaxLazyTerms = 64;
+    uint64_t LimbModulus(uint32_t i) const {
+        return m_h.GetParams()->GetParams()[i]->GetModulus().template ConvertToInt<uint64_t>();
+    }
+    // this tower as the terms of a sum: its pending terms, or its device words once
+    bool TermsOf(std::vector<LazyTerm>* out, bool negate) const {
+        const uint32_t L = NumLimbs();
+        if (m_lazy) {
+            for (const auto& t : m_lazy->terms) {
+                LazyTerm c{t.words, std::vector<uint64_t>(L)};
+                for (uint32_t i = 0; i < L; ++i)
+                    c.k[i] = (negate && t.k[i]) ? LimbModulus(i) - t.k[i] : t.k[i];
+                out->push_back(std::move(c));
+            }
+            return true;
+        }
+        if (m_zero)
+            return true;  // (nothing to add)
+        if (!Upload())
+            return false;
+        LazyTerm c{m_d, std::vector<uint64_t>(L)};
+        for (uint32_t i = 0; i < L; ++i)
+            c.k[i] = negate ? LimbModulus(i) - 1 : 1;
+        out->push_back(std::move(c));
+        return true;
+    }
+    void BecomeLazy(std::vector<LazyTerm>&& terms, uint32_t k) {
+        std::lock_guard<std::mutex> lk(m_lock.m);
+        auto sum   = std::make_shared<LazySum>();
+        sum->terms = std::move(terms);
+        auto P      = m_h.GetParams();
+        m_h         = HostType(P, m_h.GetFormat(), false);
+        m_d.reset();
+        m_lazy      = std::move(sum);
+        m_hostValid = false;
+        m_zero      = false;
+        m_k         = k;
+    }
+    // this *= k per limb, recorded (wide towers with device words or a pending sum only)
+    bool ScaleLazily(const std::vector<NativeInteger>& k) {
+        const uint32_t L = NumLimbs();
+        const auto& P    = m_h.GetParams();
+        if (!LazySums() || m_k == 1 || k.size() < L || !P || L != P->GetParams().size() || (!m_lazy && !(m_d && !m_hostValid)))
+            return false;
+        hiprt::Resolved r;
+        if (!ResolveSets(P->GetRingDimension(), {P}, &r))
+            return false;
+        std::vector<LazyTerm> terms;
+        if (!TermsOf(&terms, false))
+            return false;
+        for (auto& t : terms)
+            for (uint32_t i = 0; i < L; ++i) {
+                const uint64_t q = LimbModulus(i);
+                t.k[i] = (uint64_t)((unsigned __int128)t.k[i] * (k[i].ConvertToInt<uint64_t>() % q) % q);
+            }
+        BecomeLazy(std::move(terms), m_k);
+        return true;
+    }
+    // this += / -= rhs recorded as terms, when either side is a pending sum (wide towers)
+    bool AddLazily(const DCRTPolyType& rhs, bool minus) {
+        if (!LazySums() || (!m_lazy && !rhs.m_lazy) || !Compatible(rhs, false))
+            return false;
+        const uint32_t k = std::max(m_k, rhs.m_k);
+        if (k == 1 || (m_k != k && !m_zero) || rhs.m_k != k)
+            return false;  // (a narrow operand would have to be replicated: the plain path does that after the sums are computed)
+        std::vector<LazyTerm> terms;
+        if (!TermsOf(&terms, false) || !rhs.TermsOf(&terms, minus) || terms.empty() || terms.size() > kMaxLazyTerms)
+            return false;
+        BecomeLazy(std::move(terms), k);
+        return true;
+    }
+    // the pending sum computed: one fhe_lincomb launch per 16 terms, every term read once (m_lock held by the caller)
+    void SettleLocked() const {
+        if (!m_lazy)
+            return;
+        const auto& P    = m_h.GetParams();
+        const uint32_t L = NumLimbs();
+        const size_t N   = P->GetRingDimension();
+        hiprt::Resolved r;
+        if (!ResolveSets(N, {P}, &r))
+            OPENFHE_THROW("HIP backend: a pending weighted sum lost its device context");
+        const auto sum = m_lazy;
+        const size_t n = sum->terms.size();
+        std::vector<uint64_t> consts(n * L);
+        std::vector<const uint64_t*> ptrs(n);
+        hiprt::Op op;
+        for (size_t t = 0; t < n; ++t) {
+            ptrs[t] = op.R(sum->terms[t].words);
+            for (uint32_t i = 0; i < L; ++i)
+                consts[t * L + i] = sum->terms[t].k[i];
+        }
+        auto d = hiprt::Alloc((size_t)m_k * L * N);
+        hiprt::Check(hiprt::api().lincomb(r.ctx, op.W(d), ptrs.data(), consts.data(), (uint32_t)n, r.idx[0].data(), L, m_k, 0, op.s),
+                     "DCRTPoly weighted sum");
+        hiprt::CountDevice();
+        m_d = std::move(d);
+        m_lazy.reset();
+        m_hostValid = false;
+    }
+    void Settle() const {
+        if (!m_lazy)
+            return;
+        hiprt::MemberScope scope("WeightedSum");
+        std::lock_guard<std::mutex> lk(m_lock.m);
+        SettleLocked();
+    }
     // ---- the two copies ---------------------------------------------------------------------------------------------
     void CopyFrom(const DCRTPolyType& e) {
         std::lock_guard<std::mutex> lk(e.m_lock.m);
         m_zero = e.m_zero;
         m_k    = e.m_k;
         m_d.reset();
+        m_lazy = e.m_lazy;
+        if (m_lazy) {  // (a copy of a pending sum is the same pending sum: the description is immutable and shared)
+            m_h         = HostType(e.m_h.GetParams(), e.m_h.GetFormat(), false);
+            m_hostValid = false;
+            return;
+        }
         if (e.m_d && e.m_h.GetParams() && e.m_h.GetAllElements().size() == e.m_h.GetParams()->GetParams().size()) {
             // a source with a device copy (even next to a valid mirror): copy-on-write, the mirror of the copy holds (params,
             // format) only.  Device words are never modified while shared: every writer goes through WriteTarget / Unshare
@@ -1340,6 +1489,10 @@ private:
     // filled in — so that (params, format, limb count) can be read by other threads of a const tower while one of them synchronises
     void SyncHost(const char* who) const {
         std::lock_guard<std::mutex> lk(m_lock.m);
+        if (m_lazy) {
+            hiprt::MemberScope scope("WeightedSum");
+            SettleLocked();
+        }
         if (m_hostValid)
             return;
         const auto& P    = m_h.GetParams();
@@ -1405,6 +1558,10 @@ private:
     }
     bool Upload() const {
         std::lock_guard<std::mutex> lk(m_lock.m);
+        if (m_lazy) {
+            hiprt::MemberScope scope("WeightedSum");
+            SettleLocked();
+        }
         if (m_d)
             return true;
         const uint32_t L = NumLimbs();
@@ -1798,7 +1955,7 @@ private:
             hiprt::D2D(op, op.W(d), op.R(m_d), (size_t)numQ * N * 8, "FastBaseConvqToBskMontgomery");
             const size_t wsB = A.behz_workspace_bytes(plan, 1);
             auto ws          = hiprt::Alloc(wsB / 8 + 1);
-            hiprt::Check(A.behz_q_to_bsk(plan, d->p, wasEval ? 1 : 0, 1, op.W(ws), wsB, op.s), "FastBaseConvqToBskMontgomery");
+            hiprt::Check(A.behz_q_to_bsk(plan, d->p, wasEval ? 1 : 0, 1, op.W(ws, false), wsB, op.s), "FastBaseConvqToBskMontgomery");
             hiprt::CountDevice();
             *this = FromDevice(params, Format::EVALUATION, std::move(d));
             return true;
@@ -2036,7 +2193,7 @@ private:
         const size_t wsBytes = A.rescale_workspace_bytes(r.ctx, L, m_k);
         auto ws              = hiprt::Alloc(wsBytes / 8);
         auto tmp             = hiprt::Alloc((size_t)m_k * l * N);
-        hiprt::Check(A.rescale_limbs(r.ctx, self, r.idx[0].data(), L, a.data(), b.data(), m_k, op.W(tmp), op.W(ws), wsBytes, op.s),
+        hiprt::Check(A.rescale_limbs(r.ctx, self, r.idx[0].data(), L, a.data(), b.data(), m_k, op.W(tmp), op.W(ws, false), wsBytes, op.s),
                      "DropLastElementAndScale");
         if (!memoKey.empty())
             hiprt::MemoStore(src, std::move(memoKey), tmp);

@@ -55,6 +55,7 @@ struct Api {
     decltype(&fhe_add_pair) add_pair;
     decltype(&fhe_sub_pair) sub_pair;
     decltype(&fhe_mul_const_pair) mul_const_pair;
+    decltype(&fhe_lincomb) lincomb;
     decltype(&fhe_rescale_workspace_bytes) rescale_workspace_bytes;
     decltype(&fhe_conv_create_custom) conv_create_custom;
     decltype(&fhe_conv_destroy) conv_destroy;
@@ -158,7 +159,9 @@ public:
     Op& operator=(const Op&) = delete;
     void* s;                              // the stream the launches of this operation go to
     const uint64_t* R(const Buf& b);      // this operation reads b   (ordered after b's foreign writer)
-    uint64_t* W(const Buf& b);            // this operation writes b  (ordered after b's foreign writer and readers)
+    // this operation writes b  (ordered after b's foreign writer and readers); operand = false: a workspace of the operation, not one
+    // of its operands (left out of the operand-byte count of fhe_hal_operand_bytes)
+    uint64_t* W(const Buf& b, bool operand = true);
     void HostSync();                      // the host waits for everything this thread has enqueued so far
 private:
     uint64_t m_seq;

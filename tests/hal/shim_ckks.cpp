@@ -45,7 +45,27 @@ extern "C" void fhe_hal_composite_stats(uint64_t out[3]) __attribute__((weak));
 extern "C" void fhe_hal_other_host_counts(uint64_t out[2]) __attribute__((weak));
 // the set-up phase (context, keys, encryption: samplers and encoders produce their words on the host) ends here: the counters the
 // tests assert on cover the EVALUATION phase (and the decryptions at the end) only
+static void print_member_stats(const char* tag) {  // "<tag> <member> <device ops> <host-mirror executions> <host reads after a device->host copy>"
+    if (!fhe_hal_member_stats)
+        return;
+    std::string buf(fhe_hal_member_stats(nullptr, 0), '\0');
+    fhe_hal_member_stats(&buf[0], buf.size());
+    size_t at = 0;
+    while (at < buf.size() && buf[at]) {
+        const size_t nl = buf.find('\n', at);
+        std::cout << tag << " " << buf.substr(at, nl - at) << std::endl;
+        at = nl + 1;
+    }
+}
 static void evaluation_phase_begins() {
+    // the set-up window (key generation and encryption) is reported on its own: "halsetup <member> ..." — the tests require the
+    // backend's key generation (KeySwitchGenInternal on whole device towers) and the encryption arithmetic to have run on the device
+    print_member_stats("halsetup");
+    if (fhe_hal_stats) {
+        uint64_t st[4];
+        fhe_hal_stats(st);
+        std::cout << "halsetup: deviceOps " << st[0] << " hostOps " << st[1] << " h2dBytes " << st[2] << " d2hBytes " << st[3] << std::endl;
+    }
     if (fhe_hal_stats_reset)
         fhe_hal_stats_reset();
     if (fhe_hal_trace_reset)
@@ -650,16 +670,7 @@ int main(int argc, char** argv) {
     if (fhe_hal_stats) {
         uint64_t st[4];
         fhe_hal_stats(st);
-        if (fhe_hal_member_stats) {  // "halmember <member> <device ops> <host-mirror executions> <host reads after a device->host copy>"
-            std::string buf(fhe_hal_member_stats(nullptr, 0), '\0');
-            fhe_hal_member_stats(&buf[0], buf.size());
-            size_t at = 0;
-            while (at < buf.size() && buf[at]) {
-                const size_t nl = buf.find('\n', at);
-                std::cout << "halmember " << buf.substr(at, nl - at) << std::endl;
-                at = nl + 1;
-            }
-        }
+        print_member_stats("halmember");
         if (fhe_hal_composite_stats) {
             uint64_t cs[3];
             fhe_hal_composite_stats(cs);

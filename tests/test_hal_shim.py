@@ -62,6 +62,28 @@ def assert_ran_on_device(stdout, must_run=(), host_ops=0):
     return st
 
 
+def setup_stats(stdout):
+    """{member: (device ops, host-mirror executions, host reads)} of the SET-UP window (key generation + encryption): "halsetup" lines"""
+    return {m.group(1): tuple(int(m.group(i)) for i in (2, 3, 4)) for m in re.finditer(r"halsetup (\S+) (\d+) (\d+) (\d+)", stdout)}
+
+
+def assert_setup_on_device(stdout, must_run, keys):
+    """key generation and encryption arithmetic on the device.  The backend's KeySwitchGenInternal (whole device towers,
+    samplers on the host for PRNG parity) must have run, with no host-mirror execution inside it (round 4: the clone of the secret
+    key's limb 0 used to run on the mirror once per key), and no member with a device path may have executed on the mirror during
+    set-up."""
+    st = setup_stats(stdout)
+    assert st, "the test program printed no set-up window"
+    for m in must_run:
+        assert st.get(m, (0, 0, 0))[0] > 0, f"set-up: {m} did not run on the device: {st}"
+    on_mirror = {m: v[1] for m, v in st.items() if v[1] and m in DEVICE_MEMBERS}
+    assert not on_mirror, f"set-up: members with a device path executed on the host mirror: {on_mirror}"
+    ks = st.get("KeySwitchGenInternal", (0, 0, 0))
+    assert ks[1] == 0, f"set-up: {ks[1]} host-mirror executions inside KeySwitchGenInternal ({keys} generated keys)"
+    assert ks[0] >= 10 * keys, f"set-up: only {ks[0]} device operations inside KeySwitchGenInternal for {keys} keys"
+    return st
+
+
 def run(prog, out, mode, logN, device_lib=None, extra=(), threads=1):
     env = dict(os.environ, OMP_NUM_THREADS=str(threads))
     if device_lib:
@@ -78,7 +100,7 @@ def values(stdout, name):
     return [float(v) for v in m.group(1).replace("[", " ").replace("]", " ").split()]
 
 
-def check(tmp_path, mode, logN, device_lib, expect, extra=(), threads=1, must_run=()):
+def check(tmp_path, mode, logN, device_lib, expect, extra=(), threads=1, must_run=(), setup=None):
     ensure_built()
     so, sh = str(tmp_path / "stock.bin"), str(tmp_path / "hip.bin")
     out_stock = run(PROGS[0], so, mode, logN, extra=extra, threads=threads)
@@ -89,6 +111,8 @@ def check(tmp_path, mode, logN, device_lib, expect, extra=(), threads=1, must_ru
     a, b = open(so, "rb").read(), open(sh, "rb").read()
     assert len(a) > 1000 and a == b, "the HIP backend's ciphertext limbs differ from the default backend's"
     assert_ran_on_device(out_hip, must_run)
+    if setup:  # (members that must have run on the device during key generation + encryption, number of evaluation keys generated)
+        assert_setup_on_device(out_hip, *setup)
     # the batched composites (one library call per key switch): every first-use check against the member-by-member path matched
     cm = re.search(r"halcomposite calls (\d+) checksIdentical (\d+) checksDiffered (\d+)", out_hip)
     assert cm and int(cm.group(3)) == 0, out_hip[-600:]
@@ -134,8 +158,12 @@ HPS_MEMBERS = {"HPS": ("ExpandCRTBasis", "ScaleAndRound", "SwitchCRTBasis", "Swi
 BGV_MEMBERS = ("KeySwitchCore", "ModReduce", "SwitchFormat", "AutomorphismTransform")
 
 
+CKKS_SETUP = (("KeySwitchGenInternal", "Times", "Plus"), 3)    # EvalMultKeyGen + EvalRotateKeyGen({1, -2}); Encrypt: pk * u + e (+ m)
+BFV_SETUP = (("KeySwitchGenInternal", "TimesQovert", "Times"), 2)  # EvalMultKeyGen + EvalRotateKeyGen({1}); Encrypt: ... + [Q/t] m
+
+
 def test_shim_leveled_ckks_matches_default_backend_on_emulator(tmp_path):
-    check(tmp_path, "leveled", 11, EMU, LEVELED, must_run=CKKS_MEMBERS)
+    check(tmp_path, "leveled", 11, EMU, LEVELED, must_run=CKKS_MEMBERS, setup=CKKS_SETUP)
 
 
 @pytest.mark.parametrize("technique", ["FIXEDAUTO", "FLEXIBLEAUTOEXT"])
@@ -151,7 +179,7 @@ def test_shim_bootstrap_matches_default_backend_on_emulator(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("logN", [12, 14])
 def test_shim_leveled_ckks_matches_default_backend_on_gpu(tmp_path, logN):
-    check(tmp_path, "leveled", logN, HIP, LEVELED, must_run=CKKS_MEMBERS)
+    check(tmp_path, "leveled", logN, HIP, LEVELED, must_run=CKKS_MEMBERS, setup=CKKS_SETUP)
 
 
 @pytest.mark.gpu
@@ -189,14 +217,15 @@ def test_remembered_results_are_dropped_when_the_words_change_on_gpu(tmp_path):
 # the BEHZ trio, ExpandCRTBasis, FastExpandCRTBasisPloverQ, ScaleAndRound, SwitchCRTBasis, ExpandCRTBasisQlHat as device members
 @pytest.mark.parametrize("tech", ["BEHZ", "HPSPOVERQ", "HPS", "HPSPOVERQLEVELED"])
 def test_shim_bfv_matches_default_backend_on_emulator(tmp_path, tech):
-    ops = check(tmp_path, "bfv", 10, EMU, BFV, extra=(tech,), must_run=BEHZ_MEMBERS if tech == "BEHZ" else HPS_MEMBERS[tech])
+    ops = check(tmp_path, "bfv", 10, EMU, BFV, extra=(tech,), must_run=BEHZ_MEMBERS if tech == "BEHZ" else HPS_MEMBERS[tech], setup=BFV_SETUP)
     assert ops > 100
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("tech,logN,depth", [("BEHZ", 13, 2), ("HPSPOVERQ", 13, 2), ("HPS", 12, 3), ("HPSPOVERQLEVELED", 12, 3), ("BEHZ", 15, 5)])
 def test_shim_bfv_matches_default_backend_on_gpu(tmp_path, tech, logN, depth):
-    ops = check(tmp_path, "bfv", logN, HIP, BFV, extra=(tech, depth), must_run=BEHZ_MEMBERS if tech == "BEHZ" else HPS_MEMBERS[tech])
+    ops = check(tmp_path, "bfv", logN, HIP, BFV, extra=(tech, depth), must_run=BEHZ_MEMBERS if tech == "BEHZ" else HPS_MEMBERS[tech],
+                setup=BFV_SETUP)
     assert ops > 100
 
 

@@ -626,6 +626,48 @@ def test_pair_entries_two_separately_allocated_towers_in_one_launch(backend, ora
     ctx.close()
 
 
+@pytest.mark.parametrize("logN,L,B,terms", [(6, 3, 2, 1), (10, 4, 1, 5), (12, 3, 2, 16), (12, 2, 1, 37)])
+def test_lincomb_weighted_sum_in_one_launch(backend, oracle, logN, L, B, terms):
+    """fhe_lincomb (pke's internalEvalLinearWSumMutable, ckksrns-advancedshe.cpp:97-136: EvalMultInPlace(ct_i, c_i) + EvalAddInPlaceNoCheck
+    per term): sum_i c_i (.) x_i per limb against the oracle's per-limb products and sums (exact residues), 1 ... 37 terms (> 16: several
+    launches, the later ones accumulating), the accumulate form, and the limb-subset form"""
+    o = oracle
+    rng = np.random.default_rng(41)
+    N = 1 << logN
+    q, psi = params(o, logN, L)
+    ctx = fh.Context(backend, logN, q, psi)
+    qs = [int(v) for v in q]
+    xs = [libs.rand_tower(rng, q, N, B) for _ in range(terms)]
+    ks = [[int(rng.integers(0, qi)) if (i + r) % 7 else qi - 1 for r, qi in enumerate(qs)] for i in range(terms)]
+    want = np.zeros((B, L, N), dtype=object)
+    for i in range(terms):
+        for r in range(L):
+            want[:, r] = (want[:, r] + xs[i][:, r].astype(object) * ks[i][r]) % qs[r]
+    # (the oracle's modular product agrees with the python integers on a sample: same arithmetic as every other parity test)
+    probe = np.empty(N, np.uint64)
+    o.orc_vec_mul(probe, xs[0][0, 0], np.full(N, ks[0][0], np.uint64), N, q[0])
+    assert np.array_equal(probe.astype(object), xs[0][0, 0].astype(object) * ks[0][0] % qs[0])
+    tw = [ctx.tower(x) for x in xs]
+    got = fh.lincomb(ctx, tw, ks)
+    assert np.array_equal(got.to_host().astype(object), want)
+    # accumulate: acc + sum
+    acc_h = libs.rand_tower(rng, q, N, B)
+    acc = fh.lincomb(ctx, tw, ks, accumulate_into=ctx.tower(acc_h))
+    want2 = np.empty_like(want)
+    for r in range(L):
+        want2[:, r] = (want[:, r] + acc_h[:, r].astype(object)) % qs[r]
+    assert np.array_equal(acc.to_host().astype(object), want2)
+    # in place on the first term (allowed up to 16 terms)
+    if terms <= 16:
+        import ctypes as C
+        ptrs = (C.c_void_p * terms)(*[t.ptr.value for t in tw])
+        k = np.ascontiguousarray(ks, dtype=np.uint64)
+        ctx.lib.check(ctx.lib.L.fhe_lincomb(ctx.h, tw[0].ptr, ptrs, k.ctypes.data_as(C.POINTER(C.c_uint64)), terms, tw[0]._li(), L, B, 0, None))
+        ctx.sync(None)
+        assert np.array_equal(tw[0].to_host().astype(object), want)
+    ctx.close()
+
+
 @pytest.mark.parametrize("logN,sizeQl,t,B,ev", [(4, 3, 65537, 2, 1), (10, 4, 786433, 2, 1), (12, 3, 65537, 1, 0), (13, 3, 2, 1, 1)])
 def test_mod_reduce(backend, oracle, logN, sizeQl, t, B, ev):
     """fhe_mod_reduce (DCRTPoly::ModReduce, BGV modulus switching) vs the oracle"""
