@@ -50,7 +50,9 @@ def parse():
     ap.add_argument("--bootstrap-logn", type=int, default=17)
     ap.add_argument("--bootstrap-batch", type=int, default=64, help="ciphertexts per GPU in the bootstrap leg (BASELINE configs[3]: 512 over 8 GPUs = 64 per GPU; "
                                                                      "the driver's 1-GPU run is one rank's share)")
-    ap.add_argument("--bootstrap-group", type=int, default=32,
+    ap.add_argument("--bootstrap-wide-threads", type=int, default=2,
+                    help="host threads (= streams) the lockstep groups of the bootstrap leg are spread over")
+    ap.add_argument("--bootstrap-group", type=int, default=16,
                     help="ciphertexts per wide (lockstep) evaluation in the bootstrap leg; 0 = the rank's whole slice (64 at once exceed the "
                          "288 GB of one GPU with the caches of the threaded pass still resident: profiles/r04_sweeps.md)")
     ap.add_argument("--bootstrap-threads", type=int, default=8, help="host threads (= HIP streams) the rank's ciphertexts are spread over")
@@ -97,7 +99,7 @@ def download_tower(lib, ctx, dev, tw, n_limbs):
 
 
 def device_checksums(lib, ctx, dev, rows):
-    """{sum mod 2^64, xor} of EVERY limb-row of a resident batch (fhe_checksum: one read of the batch) -> uint64[rows][2]"""
+    """{sum, position-weighted sum} mod 2^64 of EVERY limb-row of a resident batch (fhe_checksum: one read of the batch) -> uint64[rows][2]"""
     d = ctx.malloc(rows * 16)
     lib.check(lib.L.fhe_checksum(ctx.h, dev, rows, d, None))
     out = np.empty((rows, 2), np.uint64)
@@ -109,7 +111,8 @@ def device_checksums(lib, ctx, dev, rows):
 
 def host_checksums(towers):
     """the same two words per limb-row of host towers [T][L][N] -> uint64[T][L][2]"""
-    return np.stack([towers.sum(axis=2, dtype=np.uint64), np.bitwise_xor.reduce(towers, axis=2)], axis=2)
+    w = (2 * np.arange(towers.shape[2], dtype=np.uint64) + np.uint64(1))  # (uint64 arithmetic wraps modulo 2^64, like the kernel's)
+    return np.stack([towers.sum(axis=2, dtype=np.uint64), (towers * w).sum(axis=2, dtype=np.uint64)], axis=2)
 
 
 def all_towers_match(lib, ctx, dev, batch, n_limbs, want):
@@ -675,7 +678,7 @@ def free_port():
 STOCK_BOOT_SO = os.path.join(ROOT, "tests", "hal", "_build", "libfhe_boot_batch_stock.so")  # TEST-ONLY: the same source on the stock backend
 
 
-def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev, with_cpu, libpath, group=0):
+def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev, with_cpu, libpath, group=0, wide_threads=1):
     """BASELINE configs[3] as north_star states it: a BATCH of ciphertexts bootstrapped through the reference's own API
     (cc->EvalBootstrap at N = 2^17, 2^16 slots, {4,4}, SPARSE_TERNARY, FLEXIBLEAUTO: benchmark/src/ckks-bootstrapping.cpp:70) on the HIP backend
     of DCRTPoly, `per_gpu` ciphertexts per rank spread over `threads` host threads (one HIP stream each); with several ranks the
@@ -725,9 +728,9 @@ def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev,
     # every composite).  The rank's figure is the better of the two ways of running the batch.
     wide = None
     try:
-        w0 = h.counters()
-        wsec = h.bootstrap_wide(group, 2)
-        w1 = h.counters()
+        w0, m0 = h.counters(), h.member_bytes()
+        wsec = h.bootstrap_wide(group, 2, wide_threads)
+        w1, m1 = h.counters(), h.member_bytes()
         ndiff = h.compare_saved()
         wide = {"seconds_per_pass": round(wsec, 4), "bootstraps_per_s": round(r["ciphertexts"] / wsec, 2),
                 "group": group if 0 < group < r["ciphertexts"] else r["ciphertexts"],
@@ -735,8 +738,12 @@ def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev,
                 "parity": (f"all {r['ciphertexts']} outputs identical word for word to the threaded (narrow) pass's outputs of the same ciphertexts "
                            "(compared in this run, every limb on the host)" if ndiff == 0 else
                            f"MISMATCH: {ndiff} of {r['ciphertexts']} outputs differ from the narrow pass's"),
-                "how": "one cc->EvalBootstrap per group on a ciphertext of K-tower towers, one host thread",
+                "host_threads": wide_threads,
+                "how": f"one cc->EvalBootstrap per group on a ciphertext of K-tower towers, the groups over {wide_threads} host thread(s) / stream(s)",
                 "roofline": per_bootstrap(w0, w1, 3, r["ciphertexts"] / wsec)}  # (1 untimed + 2 timed passes between the readings)
+        # the operand bytes itemised by the pke / DCRTPoly scope that issued the operations (GB per bootstrap, largest first)
+        per = {k: (m1[k] - m0.get(k, 0)) / (3.0 * nct) / 1e9 for k in m1}
+        wide["roofline"]["operand_GB_by_member"] = {k: round(v, 3) for k, v in sorted(per.items(), key=lambda kv: -kv[1])[:12] if v > 0.0005}
         if ndiff != 0:
             wide["bootstraps_per_s_unverified"] = wide.pop("bootstraps_per_s")  # a figure without parity is not reported as the rate
     except Exception as e:
@@ -1071,7 +1078,7 @@ def main():
             # HBM bytes per launch from the committed rocprofv3 PMC passes of this exact workload — quoted only when the record
             # was made with the kernels this run executes (same kernel-source identity), else null
             traffic, tsrc, wasted = None, None, None
-            for rec in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            for rec in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", rec)))
                     if pmc.get("workload") == f"logN{logN}_L{L}_B{B}" and pmc.get("kernel_source_sha") == source_sha():
@@ -1087,20 +1094,23 @@ def main():
             # the BINDING roofline of the dominant kernel is integer issue, not HBM: SQ counters of this workload (committed record)
             binding = None
             try:
-                sq = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_valu.json")))["legs"]["ntt"]
+                sqrec = next(r for r in ("r04_pmc_valu.json", "r03_pmc_valu.json") if os.path.exists(os.path.join(ROOT, "profiles", r)))
+                sq = json.load(open(os.path.join(ROOT, "profiles", sqrec)))["legs"]["ntt"]
                 ent = next(v for k, v in sq.items() if k.startswith(dom[:-3]))
                 instr, act = ent["valu_instructions_per_wave"], ent["active_valu_over_wave_cycles"]
                 simds = 256 * 4
                 ns_per_instr = per_kernel[dom] * 1e6 / (instr * ent["waves"] / simds)  # wall time per VALU instruction issued on one SIMD
-                peak_ns = 4.0 / 2.4  # a wave64 VALU instruction occupies a SIMD16 for 4 cycles; 2.4 GHz peak engine clock
-                binding = {"bound": "valu", "instr_per_wave_tile": instr, "waves_per_simd": 4,
-                           "valu_active_over_wave_cycles": act, "valu_pipe_busy": round(min(1.0, 4 * act), 3),
+                # tools/seqbench.py (profiles/r04_seqbench.json): a SIMD shared by 4 waves issues one 64-bit-class integer instruction (v_mad_u64_u32,
+                # v_mul_lo/hi_u32, v_lshl_add_u64, carry adds) per 2.77 cycles and a VGPR-only 32-bit one per 1.03; this kernel's mix prices at 2.75
+                peak_ns = 2.75 / 2.4
+                binding = {"bound": "valu+hbm overlap", "instr_per_wave_tile": instr, "waves_per_simd": 4,
+                           "valu_active_over_wave_cycles": act,
                            "ns_per_instr_per_simd": round(ns_per_instr, 3), "cycles_per_instr": round(ns_per_instr * 2.4, 2),
                            "frac_of_issue_peak": round(peak_ns / ns_per_instr, 3),
-                           "issue_peak": "4 cycles per wave64 VALU instruction per SIMD at the 2.4 GHz peak clock (the part clocks ~1.9 GHz "
-                                         "under this load: the pipe is then ~0.9 busy, which is what valu_pipe_busy = 4 waves x the active "
-                                         "fraction of a wave's cycles says)",
-                           "source": "profiles/r03_pmc_valu.json (rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES ... on this workload) "
+                           "issue_peak": "2.75 cycles per VALU instruction of this kernel's mix per SIMD (measured in isolation, tools/seqbench.py), priced "
+                                         "at the 2.4 GHz peak clock.  The row passes need ~4.9 ms of issue and ~5.5 ms of HBM time and take ~8.1 ms: "
+                                         "neither alone binds them (ablations and what was tried: profiles/r04_sweeps.md)",
+                           "source": f"profiles/{sqrec} (rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES ... on this workload) "
                                      "x this run's hipEvent kernel time"}
             except Exception as e:
                 binding = {"bound": "valu", "error": f"no SQ-counter record: {type(e).__name__}"}
@@ -1220,7 +1230,7 @@ def main():
             dog.start()
         try:  # every rank takes part: the batch is sharded, the key set travels from rank 0
             boot = bootstrap_batch_leg(a.bootstrap_logn, a.bootstrap_batch, a.bootstrap_threads, rank, world, device, dist, tdev,
-                                       not a.no_cpu_baseline, lib.path, group=a.bootstrap_group)
+                                       not a.no_cpu_baseline, lib.path, group=a.bootstrap_group, wide_threads=a.bootstrap_wide_threads)
         except Exception as e:
             boot = {"error": f"{type(e).__name__}: {e}"}
         if dog is not None:

@@ -68,6 +68,9 @@ int        fhe_ctx_device(const fhe_ctx* ctx);
 /* ---- memory / streams ---------------------------------------------------------------------------- */
 fhe_status fhe_malloc(fhe_ctx* ctx, size_t bytes, void** devPtr);
 fhe_status fhe_free(fhe_ctx* ctx, void* devPtr);
+/* free / total bytes of the context's device (hipMemGetInfo): a host runtime that caches released buffers (the HAL backend of
+ * DCRTPoly) keeps a reserve for kernel launches with it */
+fhe_status fhe_mem_info(fhe_ctx* ctx, size_t* freeBytes, size_t* totalBytes);
 fhe_status fhe_memcpy_h2d(fhe_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream);
 fhe_status fhe_memcpy_d2h(fhe_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream);
 fhe_status fhe_memcpy_d2d(fhe_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream);
@@ -470,8 +473,8 @@ fhe_status fhe_bfv_eval_mult_relin_behz(fhe_behz* plan, fhe_ks_plan* ks, const f
                                         uint32_t batch, void* ws, size_t wsBytes, void* stream);
 
 /* ---- parity helper: whole-tower checksums ----------------------------------------------------------------
- * out[row] = { sum of the row's N words mod 2^64, xor of the row's N words } for every limb-row of x[rows][N] (rows = batch *
- * nLimbs); out is DEVICE memory, uint64_t[rows][2].  One read of the batch: bench.py and the full-shape tests compare EVERY
+ * out[row] = { sum_i w_i, sum_i (2i + 1) * w_i } mod 2^64 over the row's N words, for every limb-row of x[rows][N] (rows = batch *
+ * nLimbs; the second word depends on the ORDER of the words); out is DEVICE memory, uint64_t[rows][2].  One read of the batch: bench.py and the full-shape tests compare EVERY
  * tower of a resident batch with the oracle's words summed on the host, instead of sampling a few towers. */
 fhe_status fhe_checksum(fhe_ctx* ctx, const uint64_t* x, uint32_t rows, uint64_t* out, void* stream);
 

@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Generates integration/with_hip.patch: the SOURCE-LEVEL form of the pke / core hooks of the HIP backend of lbcrypto::DCRTPoly.
+
+The build of openfhe-development_amd/hal/Makefile binds the backend's definitions of nineteen functions of pke / core by editing OBJECT
+files (objcopy --weaken-symbol / --add-symbol on mangled names, -fno-inline-functions on two translation units): the reference's sources
+stay byte-for-byte unmodified, but the binding is invisible to a maintainer and breaks silently under LTO, -fvisibility or a renamed
+overload.  This script writes what an upstream tree would carry instead — `#ifdef WITH_HIP` guards in the
+reference's own files:
+
+  * a definition the backend replaces outright is compiled out under WITH_HIP (`#ifndef WITH_HIP ... #endif`);
+  * a definition the backend keeps as its fall-back and first-use check is compiled under a second member name (`<Name>Reference`,
+    declared next to the original in the class) while the original name is left to the backend;
+  * the template members the backend specialises for DCRTPoly are DECLARED as explicit specialisations in base-leveledshe.h, so every
+    translation unit binds to them (no reliance on weak template instantiations or on the inliner).
+
+Usage (needs the reference tree):  python integration/make_patch.py [/root/reference]   -> integration/with_hip.patch
+Apply:  cd <openfhe-development> && patch -p1 < with_hip.patch ; build with -DWITH_HIP -DFHE_HIP_PATCHED_PKE and the backend's include
+directory in front (tests/test_integration_patch.py does exactly that on a copy and runs the shim tests on the result)."""
+import difflib
+import os
+import re
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ARGS = [a for a in sys.argv[1:] if not a.startswith("--")]
+REF = ARGS[0] if ARGS else "/root/reference"
+NOTE = "// HIP backend of DCRTPoly (WITH_HIP): "
+
+
+def definition_span(lines, head_re, start=0):
+    """[first, last] line indices of the top-level definition whose first line matches head_re (ends at the next line that is `}`)"""
+    for i in range(start, len(lines)):
+        if re.match(head_re, lines[i]):
+            for j in range(i, len(lines)):
+                if lines[j].rstrip("\n") == "}":
+                    return i, j
+    raise SystemExit(f"definition not found: {head_re}")
+
+
+def drop(lines, head_re, why, nth=0):
+    start = 0
+    for _ in range(nth + 1):
+        i, j = definition_span(lines, head_re, start)
+        start = j + 1
+    lines[i:j + 1] = [f"#ifndef WITH_HIP  {NOTE}{why}\n"] + lines[i:j + 1] + ["#endif\n"]
+
+
+def rename(lines, head_re, name, why):
+    i, _ = definition_span(lines, head_re)
+    assert f"::{name}(" in lines[i], lines[i]
+    lines[i:i + 1] = [f"#ifdef WITH_HIP  {NOTE}{why}\n", lines[i].replace(f"::{name}(", f"::{name}Reference("), "#else\n", lines[i], "#endif\n"]
+
+
+def insert_after(lines, anchor_re, text, nth=0):
+    hits = [i for i, l in enumerate(lines) if re.search(anchor_re, l)]
+    i = hits[nth]
+    while not lines[i].rstrip().endswith(";"):  # (the end of the declaration the anchor starts)
+        i += 1
+    lines[i + 1:i + 1] = text.splitlines(keepends=True)
+
+
+def insert_before(lines, anchor_re, text):
+    i = max(k for k, l in enumerate(lines) if re.search(anchor_re, l))
+    lines[i:i] = text.splitlines(keepends=True)
+
+
+EDITS = {}
+
+
+def edit(rel):
+    def deco(fn):
+        EDITS[rel] = fn
+        return fn
+    return deco
+
+
+@edit("src/core/lib/math/nbtheory2.cpp")
+def _(L):
+    drop(L, r"^void PrecomputeAutoMap\(", "a memoising definition with the same table (pke recomputes the map for every rotation)")
+
+
+@edit("src/pke/lib/keyswitch/keyswitch-hybrid.cpp")
+def _(L):
+    for nth in (2, 1, 0):
+        drop(L, r"^EvalKey<DCRTPoly> KeySwitchHYBRID::KeySwitchGenInternal\(", "key generation on whole device towers", nth)
+    drop(L, r"^Ciphertext<DCRTPoly> KeySwitchHYBRID::KeySwitchExt\(", "the ring extension as one tower assembly")
+    drop(L, r"^std::shared_ptr<std::vector<DCRTPoly>> KeySwitchHYBRID::EvalKeySwitchPrecomputeCore\(", "digit decomposition + ModUp on device towers")
+    drop(L, r"^std::shared_ptr<std::vector<DCRTPoly>> KeySwitchHYBRID::EvalFastKeySwitchCoreExt\(", "the inner product with the key as one kernel")
+    rename(L, r"^std::shared_ptr<std::vector<DCRTPoly>> KeySwitchHYBRID::KeySwitchCore\(", "KeySwitchCore",
+           "one composite library call; this body is its fall-back and first-use check")
+
+
+@edit("src/pke/include/keyswitch/keyswitch-hybrid.h")
+def _(L):
+    insert_after(L, r"std::shared_ptr<std::vector<DCRTPoly>> KeySwitchCore\(const DCRTPoly& a,",
+                 "#ifdef WITH_HIP  " + NOTE + "the reference's own sequence, kept as the backend's fall-back and first-use check\n"
+                 "    std::shared_ptr<std::vector<DCRTPoly>> KeySwitchCoreReference(const DCRTPoly& a, const EvalKey<DCRTPoly> evalKey) const;\n#endif\n")
+
+
+@edit("src/pke/lib/scheme/ckksrns/ckksrns-leveledshe.cpp")
+def _(L):
+    drop(L, r"^void LeveledSHECKKSRNS::EvalAddInPlace\(Ciphertext<DCRTPoly>& ciphertext, double operand\)", "constants applied to the device tower")
+    drop(L, r"^void LeveledSHECKKSRNS::EvalSubInPlace\(Ciphertext<DCRTPoly>& ciphertext, double operand\)", "constants applied to the device tower")
+    drop(L, r"^void LeveledSHECKKSRNS::ModReduceInternalInPlace\(", "both elements rescaled by one library call per level")
+    drop(L, r"^void LeveledSHECKKSRNS::EvalMultCoreInPlace\(Ciphertext<DCRTPoly>& ciphertext, double operand\)", "both elements in one launch")
+    drop(L, r"^Ciphertext<DCRTPoly> LeveledSHECKKSRNS::EvalFastRotationExt\(", "hoisted rotation in the extended basis on device towers")
+
+
+@edit("src/pke/lib/scheme/ckksrns/ckksrns-fhe.cpp")
+def _(L):
+    for name in ("EvalLinearTransform", "EvalCoeffsToSlots", "EvalSlotsToCoeffs"):
+        rename(L, rf"^Ciphertext<DCRTPoly> FHECKKSRNS::{name}\(", name,
+               "one baby-step/giant-step composite per level; this body is its fall-back and first-use check")
+
+
+@edit("src/pke/include/scheme/ckksrns/ckksrns-fhe.h")
+def _(L):
+    insert_after(L, r"Ciphertext<DCRTPoly> EvalSlotsToCoeffs\(const std::vector<std::vector<ReadOnlyPlaintext>>& A,",
+                 "#ifdef WITH_HIP  " + NOTE + "the reference's own sequences, kept as the backend's fall-back and first-use check\n"
+                 "    Ciphertext<DCRTPoly> EvalLinearTransformReference(const std::vector<ReadOnlyPlaintext>& A, ConstCiphertext<DCRTPoly>& ct) const;\n"
+                 "    Ciphertext<DCRTPoly> EvalCoeffsToSlotsReference(const std::vector<std::vector<ReadOnlyPlaintext>>& A,\n"
+                 "                                                    ConstCiphertext<DCRTPoly>& ctxt) const;\n"
+                 "    Ciphertext<DCRTPoly> EvalSlotsToCoeffsReference(const std::vector<std::vector<ReadOnlyPlaintext>>& A,\n"
+                 "                                                    ConstCiphertext<DCRTPoly>& ctxt) const;\n#endif\n")
+
+
+@edit("src/pke/include/schemebase/base-leveledshe.h")
+def _(L):
+    insert_before(L, r"^}  // namespace lbcrypto",
+                  "#ifdef WITH_HIP  " + NOTE + "whole-operation device calls; explicit specialisations defined by the backend\n"
+                  "template <>\nvoid LeveledSHEBase<DCRTPoly>::EvalAddCoreInPlace(Ciphertext<DCRTPoly>& ciphertext1, ConstCiphertext<DCRTPoly>& ciphertext2) const;\n"
+                  "template <>\nvoid LeveledSHEBase<DCRTPoly>::EvalSubCoreInPlace(Ciphertext<DCRTPoly>& ciphertext1, ConstCiphertext<DCRTPoly>& ciphertext2) const;\n"
+                  "template <>\nCiphertext<DCRTPoly> LeveledSHEBase<DCRTPoly>::EvalMultCore(ConstCiphertext<DCRTPoly>& ciphertext1,\n"
+                  "                                                            ConstCiphertext<DCRTPoly>& ciphertext2) const;\n"
+                  "template <>\nCiphertext<DCRTPoly> LeveledSHEBase<DCRTPoly>::EvalMult(ConstCiphertext<DCRTPoly>& ciphertext1, ConstCiphertext<DCRTPoly>& ciphertext2,\n"
+                  "                                                        const EvalKey<DCRTPoly> evalKey) const;\n"
+                  "template <>\nCiphertext<DCRTPoly> LeveledSHEBase<DCRTPoly>::EvalSquare(ConstCiphertext<DCRTPoly>& ciphertext, const EvalKey<DCRTPoly> evalKey) const;\n"
+                  "#endif\n\n")
+
+
+def main():
+    out = []
+    for rel, fn in EDITS.items():
+        old = open(os.path.join(REF, rel)).read().splitlines(keepends=True)
+        new = list(old)
+        fn(new)
+        out += difflib.unified_diff(old, new, "a/" + rel, "b/" + rel, n=2)
+    path = os.path.join(HERE, "with_hip.patch")
+    if "--check" in sys.argv:  # tests: the committed patch must be what this script writes
+        same = os.path.exists(path) and open(path).read() == "".join(out)
+        print("integration/with_hip.patch is " + ("up to date" if same else "STALE: run python integration/make_patch.py"))
+        sys.exit(0 if same else 1)
+    open(path, "w").write("".join(out))
+    print(f"wrote {path}: {len(EDITS)} files, {sum(1 for l in out if l.startswith('@@'))} hunks")
+
+
+if __name__ == "__main__":
+    main()

@@ -40,8 +40,10 @@ class BootBatch:
         L.fbb_bootstrap_all.restype, L.fbb_bootstrap_all.argtypes = C.c_double, [vp, C.c_int, C.c_int, C.c_int]
         if hasattr(L, "fbb_bootstrap_wide"):
             L.fbb_bootstrap_wide.restype, L.fbb_bootstrap_wide.argtypes = C.c_double, [vp, u32, C.c_int]
+            L.fbb_bootstrap_wide_mt.restype, L.fbb_bootstrap_wide_mt.argtypes = C.c_double, [vp, u32, C.c_int, C.c_int]
         L.fbb_check.restype, L.fbb_check.argtypes = C.c_double, [vp, u32, C.POINTER(C.c_double)]
         L.fbb_counters.argtypes = [C.POINTER(u64)]
+        L.fbb_member_stats.restype, L.fbb_member_stats.argtypes = C.c_size_t, [C.c_char_p, C.c_size_t]
         L.fbb_save_outputs.argtypes = [vp]
         L.fbb_compare_saved.restype, L.fbb_compare_saved.argtypes = C.c_long, [vp]
         L.fbb_dump.argtypes = [vp, C.c_char_p, u32, u32]
@@ -97,10 +99,12 @@ class BootBatch:
         self._ok(0 if s >= 0 else 1)
         return s
 
-    def bootstrap_wide(self, group, reps):
+    def bootstrap_wide(self, group, reps, threads=1):
         """the rank's ciphertexts in lockstep, `group` per wide evaluation (0 = all): one cc->EvalBootstrap on a ciphertext whose towers hold
-        `group` towers each (hal/bootstrap_batch.cpp fbb_bootstrap_wide); one narrow pass must have run before.  Seconds per pass."""
-        s = self.L.fbb_bootstrap_wide(self.h, group, reps)
+        `group` towers each (hal/bootstrap_batch.cpp fbb_bootstrap_wide); one narrow pass must have run before.  threads > 1: the groups
+        spread over that many host threads (streams), so that one group's kernels run while another's thread is in pke's host code.
+        Seconds per pass."""
+        s = self.L.fbb_bootstrap_wide_mt(self.h, group, reps, threads)
         self._ok(0 if s >= 0 else 1)
         return s
 
@@ -110,6 +114,18 @@ class BootBatch:
         c = (u64 * 5)()
         self.L.fbb_counters(c)
         return dict(zip(("operand_read_bytes", "operand_write_bytes", "launches", "h2d_bytes", "d2h_bytes"), (int(v) for v in c)))
+
+    def member_bytes(self):
+        """{member (the outermost pke / DCRTPoly scope): operand bytes of its device operations so far}"""
+        n = self.L.fbb_member_stats(None, 0)
+        buf = C.create_string_buffer(n)
+        self.L.fbb_member_stats(buf, n)
+        out = {}
+        for ln in buf.value.decode().split("\n"):
+            f = ln.split()
+            if len(f) >= 5:
+                out[f[0]] = int(f[4])
+        return out
 
     def save_outputs(self):
         """keeps the current outputs for compare_saved (the next pass produces new objects)"""

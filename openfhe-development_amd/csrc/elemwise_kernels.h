@@ -404,8 +404,10 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) mod_switch_round_kernel(const ModSwi
 }
 
 // ---- whole-tower checksums ---------------------------------------------------------------------------------------------
-// out[row] = { sum of the row's N words mod 2^64, xor of the row's N words } for every limb-row of x[rows][N]: a parity check of
-// EVERY tower of a resident batch costs one read of the batch (the oracle's words of the seed towers are summed on the host).
+// out[row] = { sum_i w_i, sum_i (2i + 1) * w_i } mod 2^64 over the row's N words w_0 .. w_{N-1}, for every limb-row of x[rows][N]: a
+// parity check of EVERY tower of a resident batch costs one read of the batch (the oracle's words of the seed towers are summed on
+// the host).  The second word is POSITION-DEPENDENT (odd weights): right residues in a wrong coefficient order — the classic layout
+// failure of a transform — change it (round 3's second word was an xor, which they would not).
 // One workgroup per 4096-word tile; the tile's partial results go to the row's two words with atomics (out is zeroed first).
 struct ChecksumArgs {
     const uint64_t* x;
@@ -425,8 +427,9 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) checksum_kernel(const ChecksumArgs g
         if (in >= (1u << tileLog) || off >= totalWords)
             continue;
         const uint64_t a = g.x[off], b = g.x[off + 1];
+        const uint64_t i = off & (((uint64_t)1 << g.logN) - 1u);  // index of `a` in its row
         s += a + b;
-        x ^= a ^ b;
+        x += a * (2u * i + 1u) + b * (2u * i + 3u);
     }
     FHE_SHARED_U64(red, 2 * kThreads);
     red[t]            = s;
@@ -435,7 +438,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) checksum_kernel(const ChecksumArgs g
     for (uint32_t w = kThreads / 2; w >= 1; w >>= 1) {
         if (t < w) {
             red[t] += red[t + w];
-            red[kThreads + t] ^= red[kThreads + t + w];
+            red[kThreads + t] += red[kThreads + t + w];
         }
         FHE_SYNC();
     }
@@ -443,10 +446,10 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) checksum_kernel(const ChecksumArgs g
         const uint64_t row = base >> g.logN;
 #ifdef FHE_EMU
         g.out[2 * row] += red[0];
-        g.out[2 * row + 1] ^= red[kThreads];
+        g.out[2 * row + 1] += red[kThreads];
 #else
         atomicAdd((unsigned long long*)&g.out[2 * row], (unsigned long long)red[0]);
-        atomicXor((unsigned long long*)&g.out[2 * row + 1], (unsigned long long)red[kThreads]);
+        atomicAdd((unsigned long long*)&g.out[2 * row + 1], (unsigned long long)red[kThreads]);
 #endif
     }
 }

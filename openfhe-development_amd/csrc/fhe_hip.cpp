@@ -389,6 +389,12 @@ extern "C" fhe_status fhe_malloc(fhe_ctx* c, size_t bytes, void** p) {
         return fail(FHE_ERR_ALLOC, std::string("fhe_malloc: ") + e);
     return FHE_OK;
 }
+extern "C" fhe_status fhe_mem_info(fhe_ctx* c, size_t* freeBytes, size_t* totalBytes) {
+    ARG_CHECK(c && freeBytes && totalBytes, "fhe_mem_info: null argument");
+    RT_CHECK(rt::set_device(c->device));
+    RT_CHECK(rt::mem_info(freeBytes, totalBytes));
+    return FHE_OK;
+}
 extern "C" fhe_status fhe_free(fhe_ctx* c, void* p) {
     ARG_CHECK(c, "fhe_free: null context");
     RT_CHECK(rt::dfree(p));
@@ -3276,7 +3282,7 @@ extern "C" fhe_status fhe_bfv_eval_mult_relin_behz(fhe_behz* bz, fhe_ks_plan* p,
     return keyswitch_run(p, key, d2, p->sizeQ, batch, c0, c1, (uint64_t*)(w + nrB), lay, st, true);
 }
 
-// whole-tower checksums (checksum_kernel): out[row] = {sum mod 2^64, xor} of every limb-row of x[rows][N]; out is DEVICE memory
+// whole-tower checksums (checksum_kernel): out[row] = {sum_i w_i, sum_i (2i + 1) w_i} mod 2^64 of every limb-row of x[rows][N]; out is DEVICE memory
 extern "C" fhe_status fhe_checksum(fhe_ctx* c, const uint64_t* x, uint32_t rows, uint64_t* out, void* st) {
     ARG_CHECK(c && x && out && rows >= 1, "fhe_checksum: bad argument");
     RT_CHECK(rt::set_device(c->device));

@@ -51,6 +51,10 @@ inline const char* dfree(void* p) {
     std::free(p);
     return nullptr;
 }
+inline const char* mem_info(size_t* freeBytes, size_t* totalBytes) {  // (the emulator's "device" is host memory: no bound reported)
+    *freeBytes = *totalBytes = (size_t)1 << 46;
+    return nullptr;
+}
 inline const char* h2d(void* d, const void* s, size_t n, stream_t) {
     std::memcpy(d, s, n);
     return nullptr;
@@ -131,6 +135,7 @@ inline uint32_t cu_count(int d) {
 }
 inline const char* dmalloc(void** p, size_t bytes) { return err(hipMalloc(p, bytes ? bytes : 1)); }
 inline const char* dfree(void* p) { return err(hipFree(p)); }
+inline const char* mem_info(size_t* freeBytes, size_t* totalBytes) { return err(hipMemGetInfo(freeBytes, totalBytes)); }
 inline const char* h2d(void* d, const void* s, size_t n, stream_t st) {
     return err(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, st));
 }

@@ -136,6 +136,7 @@ class Lib:
         S("fhe_add_pair", C.c_int, [vp, vp, vp, vp, vp, vp, vp, u32p, u32, vp])
         S("fhe_sub_pair", C.c_int, [vp, vp, vp, vp, vp, vp, vp, u32p, u32, vp])
         S("fhe_mul_const_pair", C.c_int, [vp, vp, vp, vp, vp, u64p, u32p, u32, vp])
+        S("fhe_mem_info", C.c_int, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)])
         S("fhe_lincomb", C.c_int, [vp, vp, C.POINTER(vp), u64p, u32, u32p, u32, u32, C.c_int, vp])
         S("fhe_mod_reduce", C.c_int, [vp, vp, u32, u64, C.c_int, u32, vp, vp, C.c_size_t, vp])
         f64p = C.POINTER(C.c_double)
@@ -276,7 +277,7 @@ class Context:
         self.lib.check(self.lib.L.fhe_stream_sync(self.h, stream))
 
     def checksum(self, tower, stream=None):
-        """uint64[batch * limbs][2] = {sum mod 2^64, xor} of every limb-row of the tower (fhe_checksum)"""
+        """uint64[batch * limbs][2] = {sum, position-weighted sum} mod 2^64 of every limb-row of the tower (fhe_checksum)"""
         rows = tower.batch * tower.n_limbs
         d = self.malloc(rows * 16)
         try:

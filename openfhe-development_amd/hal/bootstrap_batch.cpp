@@ -30,6 +30,7 @@ extern "C" void fhe_hal_set_device(int device);
 extern "C" void fhe_hal_operand_bytes(uint64_t out[2]);
 extern "C" void fhe_hal_stats(uint64_t out[4]);
 extern "C" size_t fhe_hal_launch_stats(char* buf, size_t cap, uint64_t* total);
+extern "C" size_t fhe_hal_member_stats(char* buf, size_t cap);
 #endif
 
 namespace {
@@ -283,7 +284,10 @@ double fbb_bootstrap_all(void* h, int threads, int reps, int warmup) {
 // runs once — every launch works on K towers, every evaluation key is read once for all of them.  `group` ciphertexts per wide
 // evaluation (0 = all of the rank's); one narrow bootstrap must have run before (fbb_bootstrap_all with a warm-up pass: the composites
 // are checked against the member-by-member path at their first use, which is a narrow evaluation).  Seconds per pass over all ciphertexts.
-double fbb_bootstrap_wide(void* h, uint32_t group, int reps) {
+// `threads` > 1: the groups are spread over that many host threads (one HIP stream each): while one group's thread is in pke's host code
+// between two launches, the other groups' kernels keep the device busy (a lockstep pass on ONE thread leaves the GPU idle for a fifth of
+// its span: profiles/r04_bootstrap_wide_kernels.txt).
+double fbb_bootstrap_wide_mt(void* h, uint32_t group, int reps, int threads) {
     auto* b    = static_cast<Batch*>(h);
     double sec = -1;
 #ifdef WITH_HIP
@@ -292,8 +296,13 @@ double fbb_bootstrap_wide(void* h, uint32_t group, int reps) {
         if (group == 0 || group > n)
             group = n;
         b->out.assign(n, nullptr);
+        const int groups = (int)((n + group - 1) / group);
+        std::string err;
         auto pass = [&] {
-            for (uint32_t first = 0; first < n; first += group) {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(std::max(1, std::min(threads, groups)))
+            for (int g = 0; g < groups; ++g) {
+              try {
+                const uint32_t first = (uint32_t)g * group;
                 const uint32_t k = std::min(group, n - first);
                 const auto& c0   = b->in[first];
                 auto wide        = c0->CloneEmpty();
@@ -324,8 +333,15 @@ double fbb_bootstrap_wide(void* h, uint32_t group, int reps) {
                     one->SetElements(std::move(el));
                     b->out[first + i] = one;
                 }
+              }
+              catch (const std::exception& e) {
+#pragma omp critical
+                err = e.what();
+              }
             }
-            for (uint32_t i = 0; i < n; ++i)  // drain the device queue (one limb of every result comes to the host)
+            if (!err.empty())
+                OPENFHE_THROW(err);
+            for (uint32_t i = 0; i < n; ++i)  // drain the device queues (one limb of every result comes to the host)
                 (void)b->out[i]->GetElements()[0].GetElementAtIndex(0);
         };
         pass();
@@ -335,11 +351,12 @@ double fbb_bootstrap_wide(void* h, uint32_t group, int reps) {
         sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / std::max(1, reps);
     });
 #else
-    (void)group, (void)reps;
+    (void)group, (void)reps, (void)threads;
     b->error = "fbb_bootstrap_wide: the stock backend has no wide towers";
 #endif
     return sec;
 }
+double fbb_bootstrap_wide(void* h, uint32_t group, int reps) { return fbb_bootstrap_wide_mt(h, group, reps, 1); }
 // keeps the current outputs (of a narrow pass) for fbb_compare_saved: the objects stay alive, the next pass produces new ones
 int fbb_save_outputs(void* h) {
     auto* b = static_cast<Batch*>(h);
@@ -388,6 +405,16 @@ void fbb_counters(uint64_t out[5]) {
     uint64_t st[4];
     fhe_hal_stats(st);
     out[3] = st[2], out[4] = st[3];
+#endif
+}
+// "<member> <device ops> <host-mirror executions> <host reads> <operand bytes>" lines of the backend (empty on the stock backend)
+size_t fbb_member_stats(char* buf, size_t cap) {
+#ifdef WITH_HIP
+    return fhe_hal_member_stats(buf, cap);
+#else
+    if (buf && cap)
+        buf[0] = 0;
+    return 1;
 #endif
 }
 // decrypts output i of the rank's slice: the first 8 slots into vals; returns the largest absolute error against the message

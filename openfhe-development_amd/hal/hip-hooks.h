@@ -32,7 +32,8 @@ PackedKey DomainKey(KsDomain& d, const std::vector<Buf>& b, const std::vector<Bu
 enum CompositeKind : uint32_t { kKeySwitchAcc = 0, kBsgs = 1, kKeySwitch = 2, kCompositeKinds = 3 };
 int DomainChecked(const KsDomain& d, CompositeKind kind, uint32_t sizeQl);
 void DomainSetChecked(KsDomain& d, CompositeKind kind, uint32_t sizeQl, bool identical);
-// {sum, xor} of every row of a device buffer [rows][N] brought to the host (fhe_checksum): the comparison of two results on the device
+// {sum, position-weighted sum} of every row of a device buffer [rows][N] brought to the host (fhe_checksum: the second word depends on the
+// ORDER of the words): the comparison of two results on the device
 std::vector<uint64_t> Checksums(fhe_ctx* ctx, const Buf& words, uint32_t rows);
 void CountComposite();
 

@@ -60,6 +60,11 @@ struct StreamState {
     std::atomic<uint32_t> inboxCount{0};
     std::mutex inboxMutex;
     std::vector<std::pair<size_t, uint64_t*>> inbox;  // {bucket, pointer}
+    // the owning thread's cache of released buffers (ThreadState::freeLists) is guarded by flMutex: under memory pressure ANOTHER
+    // thread may take it away (Alloc: a thread that cannot allocate returns every thread's cached buffers to the device — a batch
+    // evaluated first over eight host threads and then in lockstep on one would otherwise keep eight caches of tower-sized buffers)
+    std::mutex flMutex;
+    struct ThreadState* ownerState = nullptr;  // the live thread that owns the stream (under flMutex)
 };
 struct Runtime {
     Api api{};
@@ -96,6 +101,12 @@ struct Runtime {
     // per operation — what the sequence of fused operations has to move if every operand crossed HBM exactly once (the algorithmic
     // bytes of a composite's roofline)
     std::atomic<uint64_t> opReadBytes{0}, opWriteBytes{0};
+    // bytes of released buffers the threads keep for reuse (free lists, inboxes, orphans).  A batch evaluated over eight host threads and
+    // then in lockstep filled the 288 GB with caches until a kernel LAUNCH failed for want of memory (session g): an allocation that has
+    // to go to the device first checks that a reserve stays free and otherwise takes every thread's cache back (Alloc)
+    std::atomic<uint64_t> cachedBytes{0};
+    uint64_t cacheCap = ~0ull;               // FHE_HAL_CACHE_CAP_GB: a hard cap on the cached bytes (default: none)
+    uint64_t reserveBytes = 8ull << 30;       // FHE_HAL_RESERVE_GB: free device memory kept for kernel launches (scratch, kernel arguments)
     bool requireDevice = false;
 };
 
@@ -119,6 +130,10 @@ Runtime* build() {
 #else
     const std::string path = env ? env : "libfhe_hip.so";
 #endif
+    if (const char* cap = std::getenv("FHE_HAL_CACHE_CAP_GB"))
+        r->cacheCap = (uint64_t)std::max(1, std::atoi(cap)) << 30;
+    if (const char* res = std::getenv("FHE_HAL_RESERVE_GB"))
+        r->reserveBytes = (uint64_t)std::max(0, std::atoi(res)) << 30;
     r->requireDevice = std::getenv("FHE_HAL_REQUIRE_DEVICE") != nullptr && std::string(std::getenv("FHE_HAL_REQUIRE_DEVICE")) != "0";
     r->device        = g_deviceOverride.load() >= 0 ? g_deviceOverride.load() : (std::getenv("FHE_HIP_DEVICE") ? std::atoi(std::getenv("FHE_HIP_DEVICE")) : 0);
     void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
@@ -144,7 +159,7 @@ Runtime* build() {
                   FHE_SYM(mod_switch_round, fhe_mod_switch_round) && FHE_SYM(automorph, fhe_automorph) &&
                   FHE_SYM(switch_modulus, fhe_switch_modulus) && FHE_SYM(rescale_limbs, fhe_rescale_limbs) &&
                   FHE_SYM(rescale_limbs_pair, fhe_rescale_limbs_pair) && FHE_SYM(add_pair, fhe_add_pair) && FHE_SYM(sub_pair, fhe_sub_pair) &&
-                  FHE_SYM(mul_const_pair, fhe_mul_const_pair) && FHE_SYM(lincomb, fhe_lincomb) &&
+                  FHE_SYM(mul_const_pair, fhe_mul_const_pair) && FHE_SYM(lincomb, fhe_lincomb) && FHE_SYM(mem_info, fhe_mem_info) &&
                   FHE_SYM(rescale_workspace_bytes, fhe_rescale_workspace_bytes) && FHE_SYM(conv_create_custom, fhe_conv_create_custom) &&
                   FHE_SYM(approx_switch_basis, fhe_approx_switch_basis) && FHE_SYM(switch_basis_exact, fhe_switch_basis_exact) &&
                   FHE_SYM(sr_plan_create, fhe_sr_plan_create) && FHE_SYM(scale_and_round, fhe_scale_and_round) &&
@@ -245,6 +260,8 @@ struct ThreadState {
         }
         waited.assign(kMaxStreams, 0);
         st.owned.store(true);
+        std::lock_guard<std::mutex> fl(st.flMutex);
+        st.ownerState = this;
     }
     void TakeInbox() {
         StreamState& st = rt().streams[id];
@@ -256,6 +273,7 @@ struct ThreadState {
             in.swap(st.inbox);
             st.inboxCount.store(0, std::memory_order_release);
         }
+        std::lock_guard<std::mutex> fl(st.flMutex);
         for (auto& e : in)
             freeLists[e.first].push_back(e.second);
     }
@@ -270,6 +288,8 @@ struct ThreadState {
         StreamState& st = r.streams[id];
         st.owned.store(false);
         {
+            std::lock_guard<std::mutex> fl(st.flMutex);
+            st.ownerState = nullptr;
             std::lock_guard<std::mutex> lk(st.inboxMutex);
             for (auto& kv : freeLists)
                 for (uint64_t* p : kv.second)
@@ -369,6 +389,7 @@ Op::~Op() {
         st.enqueued.store(st.issued.load(std::memory_order_relaxed), std::memory_order_release);
     }
 }
+static void count_operand_bytes(uint64_t bytes, bool write);  // (per member scope, below)
 // (both stamp the buffer under its mutex and order the calling stream behind the earlier uses AFTER releasing it: the stamp only says
 // "this stream, this sequence number will touch the words"; the launch follows when the caller returns from R / W)
 const uint64_t* Op::R(const Buf& b) {
@@ -389,7 +410,7 @@ const uint64_t* Op::R(const Buf& b) {
             root->readers.push_back(DevBuf::Use{ts->id, m_seq});
     }
     order_after(ts, writer);
-    rt().opReadBytes.fetch_add((uint64_t)b->words * 8, std::memory_order_relaxed);
+    count_operand_bytes((uint64_t)b->words * 8, false);
     return b->p;
 }
 uint64_t* Op::W(const Buf& b, bool operand) {
@@ -408,7 +429,7 @@ uint64_t* Op::W(const Buf& b, bool operand) {
     for (const auto& u : before)
         order_after(ts, u);
     if (operand)
-        rt().opWriteBytes.fetch_add((uint64_t)b->words * 8, std::memory_order_relaxed);
+        count_operand_bytes((uint64_t)b->words * 8, true);
     return b->p;
 }
 std::atomic<uint64_t> g_memoHits{0};
@@ -450,13 +471,21 @@ DevBuf::~DevBuf() {
         return;
     Runtime& r      = rt();
     ThreadState* ts = thread_state();
-    if (!ts) {  // static destruction at process exit: wait for the pending uses on the host, park the buffer
+    const uint64_t bytes = (uint64_t)bucket_of(words) * 8;
+    if (!ts || r.cachedBytes.load(std::memory_order_relaxed) + bytes > r.cacheCap) {
+        // static destruction at process exit (no thread state), or the caches are full: wait for the pending uses on the host, then park
+        // the buffer with the orphans / give it back to the device
         if (writer.stream)
             r.api.sync(r.anyCtx, r.streams[writer.stream].s);
         for (const auto& u : readers)
             r.api.sync(r.anyCtx, r.streams[u.stream].s);
+        if (ts) {
+            r.api.free_(r.anyCtx, p);
+            return;
+        }
         std::lock_guard<std::mutex> lk(r.poolMutex);
         r.orphanLists[bucket_of(words)].push_back(p);
+        r.cachedBytes.fetch_add(bytes, std::memory_order_relaxed);
         return;
     }
     // Pending uses all on ONE other thread's stream (a result computed by thread A and dropped by thread B: pke's loops over
@@ -483,6 +512,7 @@ DevBuf::~DevBuf() {
             std::lock_guard<std::mutex> lk(st.inboxMutex);
             st.inbox.emplace_back(bucket_of(words), p);
             st.inboxCount.fetch_add(1, std::memory_order_release);
+            r.cachedBytes.fetch_add(bytes, std::memory_order_relaxed);
             return;
         }
     }
@@ -490,7 +520,9 @@ DevBuf::~DevBuf() {
     order_after(ts, writer);
     for (const auto& u : readers)
         order_after(ts, u);
+    std::lock_guard<std::mutex> fl(r.streams[ts->id].flMutex);
     ts->freeLists[bucket_of(words)].push_back(p);
+    r.cachedBytes.fetch_add(bytes, std::memory_order_relaxed);
 }
 Buf Alloc(size_t words) {
     Runtime& r      = rt();
@@ -500,10 +532,12 @@ Buf Alloc(size_t words) {
     b->words        = words;
     if (ts) {
         ts->TakeInbox();
+        std::lock_guard<std::mutex> flk(r.streams[ts->id].flMutex);
         auto& fl = ts->freeLists[bk];
         if (!fl.empty()) {
             b->p = fl.back();
             fl.pop_back();
+            r.cachedBytes.fetch_sub((uint64_t)bk * 8, std::memory_order_relaxed);
             // Kernels of the buffer's previous life may still be pending on THIS thread's stream (free lists and inboxes hold such
             // buffers on purpose: ~DevBuf only orders the stream).  This thread's own launches follow them in stream order; a first use
             // by ANOTHER thread (a tower allocated here and filled by an OpenMP worker) must be ordered behind them: the new buffer
@@ -518,25 +552,47 @@ Buf Alloc(size_t words) {
         if (!fl.empty()) {  // (orphans were parked after a host-side wait for their pending uses: nothing to order behind)
             b->p = fl.back();
             fl.pop_back();
+            r.cachedBytes.fetch_sub((uint64_t)bk * 8, std::memory_order_relaxed);
             return b;
         }
     }
     void* d      = nullptr;
-    fhe_status s = r.api.malloc_(r.anyCtx, bk * 8, &d);
-    if (s != FHE_OK) {  // memory pressure: give this thread's and the shared cached buffers back to the device and retry once
-        if (ts) {
-            r.api.sync(r.anyCtx, r.streams[ts->id].s);
-            for (auto& kv : ts->freeLists) {
-                for (uint64_t* q : kv.second)
-                    r.api.free_(r.anyCtx, q);
-                kv.second.clear();
+    // (the allocation goes to the device: if it would eat into the reserve kept for kernel launches while buffers sit in caches, the
+    // caches go back first — a launch that fails for want of scratch memory cannot be retried from here)
+    bool pressed = false;
+    if (r.cachedBytes.load(std::memory_order_relaxed) > 0) {
+        size_t freeB = 0, totalB = 0;
+        if (r.api.mem_info(r.anyCtx, &freeB, &totalB) == FHE_OK && freeB < (uint64_t)bk * 8 + r.reserveBytes)
+            pressed = true;
+    }
+    fhe_status s = pressed ? FHE_ERR_ALLOC : r.api.malloc_(r.anyCtx, bk * 8, &d);
+    if (s != FHE_OK) {  // memory pressure: give every thread's and the shared cached buffers back to the device and retry once
+        uint64_t freed = 0;
+        for (uint32_t i = 1; i < r.nextStreamId; ++i) {  // every live thread's cache (this thread's included)
+            StreamState& st = r.streams[i];
+            std::vector<uint64_t*> taken;
+            {
+                std::lock_guard<std::mutex> flk(st.flMutex);
+                if (!st.ownerState)
+                    continue;
+                for (auto& kv : st.ownerState->freeLists) {
+                    taken.insert(taken.end(), kv.second.begin(), kv.second.end());
+                    freed += (uint64_t)kv.first * 8 * kv.second.size();
+                    kv.second.clear();
+                }
             }
+            if (taken.empty())
+                continue;
+            r.api.sync(r.anyCtx, st.s);  // (what is still pending on the buffers is on their owner's stream)
+            for (uint64_t* q : taken)
+                r.api.free_(r.anyCtx, q);
         }
         {
             std::lock_guard<std::mutex> lk(r.poolMutex);
             for (auto& kv : r.orphanLists) {
                 for (uint64_t* q : kv.second)
                     r.api.free_(r.anyCtx, q);
+                freed += (uint64_t)kv.first * 8 * kv.second.size();
                 kv.second.clear();
             }
         }
@@ -551,9 +607,12 @@ Buf Alloc(size_t words) {
                 st.inboxCount.store(0);
             }
             r.api.sync(r.anyCtx, st.s);
-            for (auto& e : in)
+            for (auto& e : in) {
                 r.api.free_(r.anyCtx, e.second);
+                freed += (uint64_t)e.first * 8;
+            }
         }
+        r.cachedBytes.fetch_sub(std::min<uint64_t>(freed, r.cachedBytes.load()), std::memory_order_relaxed);
         s = r.api.malloc_(r.anyCtx, bk * 8, &d);
     }
     Check(s, "HIP backend: device allocation");
@@ -579,7 +638,7 @@ Buf View(const Buf& parent, size_t offsetWords, size_t words) {
 namespace {
 struct MemberCounters {
     std::atomic<const char*> name{nullptr};
-    std::atomic<uint64_t> device{0}, host{0}, reads{0};
+    std::atomic<uint64_t> device{0}, host{0}, reads{0}, bytes{0};  // bytes: operand bytes of the member's device operations
 };
 constexpr size_t kMemberSlots = 1024;
 MemberCounters g_members[kMemberSlots];
@@ -599,6 +658,13 @@ MemberCounters& member_slot(const char* name) {  // keyed by the literal's addre
 }
 thread_local const char* t_scope  = nullptr;
 thread_local const char* t_member = nullptr;
+}  // namespace
+static void count_operand_bytes(uint64_t bytes, bool write) {
+    (write ? rt().opWriteBytes : rt().opReadBytes).fetch_add(bytes, std::memory_order_relaxed);
+    static const char* const kNoScope = "(outside a member)";
+    member_slot(t_scope ? t_scope : kNoScope).bytes.fetch_add(bytes, std::memory_order_relaxed);
+}
+namespace {
 // members of the backend class that have a device path: with FHE_HAL_REQUIRE_DEVICE they may not run on the host mirror
 const char* const kDeviceMembers[] = {"SwitchFormat", "operator+=", "operator-=", "operator*=", "Plus", "Minus", "Times", "TimesNoCheck", "Negate",
                                       "operator-", "AutomorphismTransform", "ApproxSwitchCRTBasis", "ApproxModUp", "ApproxModDown", "SwitchCRTBasis",
@@ -1064,6 +1130,7 @@ PackedKey DomainKey(KsDomain& d, const std::vector<Buf>& b, const std::vector<Bu
     return out;
 }
 int DomainChecked(const KsDomain& d, CompositeKind kind, uint32_t sizeQl) {
+    std::lock_guard<std::mutex> lk(const_cast<KsDomain&>(d).mu);  // (the verdicts are written by other host threads under the same mutex)
     return sizeQl < d.checked[kind].size() ? d.checked[kind][sizeQl] : 2;
 }
 void DomainSetChecked(KsDomain& d, CompositeKind kind, uint32_t sizeQl, bool identical) {
@@ -1106,17 +1173,18 @@ extern "C" void fhe_hal_stats(uint64_t out[4]) {
 }
 extern "C" size_t fhe_hal_member_stats(char* buf, size_t cap) {
     using namespace lbcrypto::hiprt;
-    std::map<std::string, std::array<uint64_t, 3>> merged;
+    std::map<std::string, std::array<uint64_t, 4>> merged;
     for (auto& m : g_members) {
         const char* n = m.name.load();
         if (!n)
             continue;
         auto& e = merged[n];
-        e[0] += m.device.load(), e[1] += m.host.load(), e[2] += m.reads.load();
+        e[0] += m.device.load(), e[1] += m.host.load(), e[2] += m.reads.load(), e[3] += m.bytes.load();
     }
     std::string s;
     for (auto& kv : merged)
-        s += kv.first + " " + std::to_string(kv.second[0]) + " " + std::to_string(kv.second[1]) + " " + std::to_string(kv.second[2]) + "\n";
+        s += kv.first + " " + std::to_string(kv.second[0]) + " " + std::to_string(kv.second[1]) + " " + std::to_string(kv.second[2]) + " " +
+             std::to_string(kv.second[3]) + "\n";  // (<member> <device ops> <host-mirror executions> <host reads> <operand bytes>)
     if (buf && cap) {
         const size_t n = std::min(cap - 1, s.size());
         std::memcpy(buf, s.data(), n);
@@ -1131,7 +1199,7 @@ extern "C" void fhe_hal_stats_reset(void) {
     r.outRing = 0, r.outModulus = 0, r.outMoreThan128Moduli = 0, r.outOtherRoot = 0;
     r.opReadBytes = 0, r.opWriteBytes = 0;
     for (auto& m : g_members)
-        m.device = 0, m.host = 0, m.reads = 0;
+        m.device = 0, m.host = 0, m.reads = 0, m.bytes = 0;
 }
 extern "C" int fhe_hal_available(void) { return lbcrypto::hiprt::Available() ? 1 : 0; }
 extern "C" void fhe_hal_set_device(int device) { lbcrypto::hiprt::g_deviceOverride.store(device); }

@@ -227,8 +227,19 @@ void LeveledSHECKKSRNS::EvalMultCoreInPlace(Ciphertext<DCRTPoly>& ciphertext, do
 #include "hip-hooks.h"
 #include "schemebase/base-leveledshe.h"
 
+// the reference's own KeySwitchCore.  Build of hal/Makefile on the UNMODIFIED sources: a second name objcopy gives the reference's
+// definition in its object file; build on sources that carry integration/with_hip.patch (FHE_HIP_PATCHED_PKE): the member
+// KeySwitchCoreReference the patch compiles that body under.
+#ifdef FHE_HIP_PATCHED_PKE
+#include "keyswitch/keyswitch-hybrid.h"
+static inline std::shared_ptr<std::vector<lbcrypto::DCRTPoly>> fhe_ref_KeySwitchCore(const lbcrypto::KeySwitchHYBRID* self, const lbcrypto::DCRTPoly& a,
+                                                                                     const lbcrypto::EvalKey<lbcrypto::DCRTPoly> evalKey) {
+    return self->KeySwitchCoreReference(a, evalKey);
+}
+#else
 extern "C" std::shared_ptr<std::vector<lbcrypto::DCRTPoly>> fhe_ref_KeySwitchCore(const lbcrypto::KeySwitchHYBRID* self, const lbcrypto::DCRTPoly& a,
                                                                                  const lbcrypto::EvalKey<lbcrypto::DCRTPoly> evalKey);
+#endif
 
 namespace lbcrypto {
 namespace {
@@ -616,6 +627,23 @@ EvalKey<DCRTPoly> KeySwitchHYBRID::KeySwitchGenInternal(const PrivateKey<DCRTPol
 #include "scheme/ckksrns/ckksrns-fhe.h"
 #include "scheme/ckksrns/ckksrns-utils.h"
 
+#ifdef FHE_HIP_PATCHED_PKE  // (sources with integration/with_hip.patch: the reference's bodies are the *Reference members)
+static inline lbcrypto::Ciphertext<lbcrypto::DCRTPoly> fhe_ref_EvalLinearTransform(const lbcrypto::FHECKKSRNS* self,
+                                                                                   const std::vector<lbcrypto::ReadOnlyPlaintext>& A,
+                                                                                   lbcrypto::ConstCiphertext<lbcrypto::DCRTPoly>& ct) {
+    return self->EvalLinearTransformReference(A, ct);
+}
+static inline lbcrypto::Ciphertext<lbcrypto::DCRTPoly> fhe_ref_EvalCoeffsToSlots(const lbcrypto::FHECKKSRNS* self,
+                                                                                 const std::vector<std::vector<lbcrypto::ReadOnlyPlaintext>>& A,
+                                                                                 lbcrypto::ConstCiphertext<lbcrypto::DCRTPoly>& ctxt) {
+    return self->EvalCoeffsToSlotsReference(A, ctxt);
+}
+static inline lbcrypto::Ciphertext<lbcrypto::DCRTPoly> fhe_ref_EvalSlotsToCoeffs(const lbcrypto::FHECKKSRNS* self,
+                                                                                 const std::vector<std::vector<lbcrypto::ReadOnlyPlaintext>>& A,
+                                                                                 lbcrypto::ConstCiphertext<lbcrypto::DCRTPoly>& ctxt) {
+    return self->EvalSlotsToCoeffsReference(A, ctxt);
+}
+#else
 extern "C" {
 lbcrypto::Ciphertext<lbcrypto::DCRTPoly> fhe_ref_EvalLinearTransform(const lbcrypto::FHECKKSRNS* self, const std::vector<lbcrypto::ReadOnlyPlaintext>& A,
                                                                      lbcrypto::ConstCiphertext<lbcrypto::DCRTPoly>& ct);
@@ -626,6 +654,7 @@ lbcrypto::Ciphertext<lbcrypto::DCRTPoly> fhe_ref_EvalSlotsToCoeffs(const lbcrypt
                                                                    const std::vector<std::vector<lbcrypto::ReadOnlyPlaintext>>& A,
                                                                    lbcrypto::ConstCiphertext<lbcrypto::DCRTPoly>& ctxt);
 }
+#endif
 
 namespace lbcrypto {
 namespace {

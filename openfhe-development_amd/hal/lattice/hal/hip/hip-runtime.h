@@ -56,6 +56,7 @@ struct Api {
     decltype(&fhe_sub_pair) sub_pair;
     decltype(&fhe_mul_const_pair) mul_const_pair;
     decltype(&fhe_lincomb) lincomb;
+    decltype(&fhe_mem_info) mem_info;
     decltype(&fhe_rescale_workspace_bytes) rescale_workspace_bytes;
     decltype(&fhe_conv_create_custom) conv_create_custom;
     decltype(&fhe_conv_destroy) conv_destroy;

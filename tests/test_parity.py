@@ -835,7 +835,7 @@ def test_conversion_kernel_variants_on_emulator(backend, variant):
 
 
 def test_whole_tower_checksums(backend, oracle):
-    """fhe_checksum: {sum mod 2^64, xor} of every limb-row of a resident batch in one read (the all-towers parity check of bench.py
+    """fhe_checksum: {sum, position-weighted sum} mod 2^64 of every limb-row of a resident batch in one read (the all-towers parity check of bench.py
     and of the full-shape tests)"""
     rng = np.random.default_rng(23)
     for logN, L, B in [(4, 3, 2), (9, 2, 3), (12, 2, 2), (13, 3, 1)]:
@@ -844,8 +844,16 @@ def test_whole_tower_checksums(backend, oracle):
         x = libs.rand_tower(rng, q, 1 << logN, B)
         t = ctx.tower(x)
         got = ctx.checksum(t)
-        want = np.stack([x.reshape(B * L, -1).sum(axis=1, dtype=np.uint64), np.bitwise_xor.reduce(x.reshape(B * L, -1), axis=1)], axis=1)
+        rows = x.reshape(B * L, -1)
+        w = 2 * np.arange(rows.shape[1], dtype=np.uint64) + np.uint64(1)
+        want = np.stack([rows.sum(axis=1, dtype=np.uint64), (rows * w).sum(axis=1, dtype=np.uint64)], axis=1)
         assert np.array_equal(got, want)
+        # the second word depends on the order of the words: two words of a row swapped change it, the plain sum stays
+        y = x.copy()
+        y[0, 0, [1, 2]] = y[0, 0, [2, 1]]
+        if y[0, 0, 1] != y[0, 0, 2]:
+            got2 = ctx.checksum(ctx.tower(y))
+            assert got2[0, 0] == got[0, 0] and got2[0, 1] != got[0, 1]
         ctx.close()
 
 

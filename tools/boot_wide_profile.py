@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Kernel-time census of the LOCKSTEP bootstrap (config 4's headline path): run under `rocprofv3 --kernel-trace`, then summarise.
+
+  rocprofv3 --kernel-trace --output-format csv -d OUT -- python tools/boot_wide_profile.py run [cts] [group] [reps]
+  python tools/boot_wide_profile.py summarise OUT/.../*_kernel_trace.csv [reps] > profiles/r04_bootstrap_wide_kernels.txt
+
+`run` bootstraps `cts` ciphertexts once over host threads (first use of every composite), then `reps` + 1 times in lockstep groups;
+`summarise` takes the launches of the last lockstep pass (the trace's tail, cut at the longest pause before it) and prints kernel
+totals per bootstrap."""
+import csv
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(cts, group, reps):
+    sys.path.insert(0, ROOT)
+    from openfhe_amd import boot_batch as bb
+    prng = os.path.join(ROOT, "tests", "hal", "_build", "libdetprng.so")
+    os.environ.setdefault("FHE_HIP_LIB", os.path.join(ROOT, "openfhe-development_amd", "csrc", "libfhe_hip.so"))
+    r = bb.run_rank(17, 1 << 16, cts, 8, 1, 0, prng, warmup=0, key_threads=8)
+    h = r.pop("handle")
+    h.save_outputs()
+    c0 = h.counters()
+    sec = h.bootstrap_wide(group, reps)
+    c1 = h.counters()
+    n = (reps + 1) * cts
+    print(f"lockstep: {cts / sec:.2f} bootstraps/s, groups of {group}; differing outputs {h.compare_saved()}; per bootstrap: "
+          f"{(c1['launches'] - c0['launches']) / n:.1f} launches, "
+          f"{(c1['operand_read_bytes'] + c1['operand_write_bytes'] - c0['operand_read_bytes'] - c0['operand_write_bytes']) / n / 1e9:.2f} GB of operands")
+    h.close()
+
+
+def sweep(cts, configs):
+    """the same ciphertexts in lockstep under several (group, host threads) settings; every setting's outputs compared with the narrow pass"""
+    sys.path.insert(0, ROOT)
+    from openfhe_amd import boot_batch as bb
+    prng = os.path.join(ROOT, "tests", "hal", "_build", "libdetprng.so")
+    os.environ.setdefault("FHE_HIP_LIB", os.path.join(ROOT, "openfhe-development_amd", "csrc", "libfhe_hip.so"))
+    r = bb.run_rank(17, 1 << 16, cts, 8, 1, 0, prng, warmup=0, key_threads=8)
+    print(f"threaded narrow pass: {r['bootstraps_per_s']:.2f} bootstraps/s over 8 host threads (first pass: includes first-use checks)")
+    h = r.pop("handle")
+    h.save_outputs()
+    for group, threads in configs:
+        try:
+            sec = h.bootstrap_wide(group, 2, threads)
+            print(f"groups of {group} over {threads} host thread(s): {cts / sec:.2f} bootstraps/s; differing outputs {h.compare_saved()}", flush=True)
+        except Exception as e:
+            print(f"groups of {group} over {threads} host thread(s): {type(e).__name__}: {str(e)[-260:]}", flush=True)
+    h.close()
+
+
+def summarise(path, cts, reps):
+    rows = []
+    with open(path, newline="") as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    # the lockstep passes are the tail: reps + 1 equal passes; take the last one by launch count
+    total = len(rows)
+    # find the start of the lockstep phase: the longest gap in the second half of the trace precedes pack/unpack of a pass; simpler:
+    # the last pass = the last 1/(reps+1) of the launches after the narrow pass, whose launches are the first `narrow` ones
+    gaps = [(rows[i + 1][0] - rows[i][1], i) for i in range(total // 4, total - 1)]
+    gaps.sort(reverse=True)
+    cuts = sorted(i for _, i in gaps[:reps + 1])
+    # (the narrow pass ends with the longest pause — the outputs are saved, the first wide ciphertext is packed — so the tail behind
+    # the FIRST of the largest gaps holds all reps + 1 lockstep passes)
+    last = rows[cuts[0] + 1:] if cuts else rows
+    passes = reps + 1
+    busy = sum(e - s for s, e, _ in last)
+    span = last[-1][1] - last[0][0]
+    print(f"{passes} lockstep passes: {len(last)} launches, GPU busy {busy / 1e6:.1f} ms, span {span / 1e6:.1f} ms for {passes} x {cts} bootstraps "
+          f"= {busy / 1e6 / cts / passes:.2f} ms of kernel time per bootstrap")
+    cts *= passes
+    per = defaultdict(lambda: [0, 0])
+    for s, e, nm in last:
+        per[nm][0] += e - s
+        per[nm][1] += 1
+    print(f"{'ms/bootstrap':>13} {'share':>6} {'calls':>6} {'avg us':>8}  kernel")
+    for nm, (t, c) in sorted(per.items(), key=lambda kv: -kv[1][0])[:30]:
+        print(f"{t / 1e6 / cts:13.3f} {t / busy:6.3f} {c:6d} {t / c / 1e3:8.1f}  {nm[:120]}")
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "sweep":
+        sweep(int(sys.argv[2]), [tuple(int(v) for v in a.split("x")) for a in sys.argv[3:]])
+    elif sys.argv[1] == "run":
+        run(int(sys.argv[2]) if len(sys.argv) > 2 else 32, int(sys.argv[3]) if len(sys.argv) > 3 else 32, int(sys.argv[4]) if len(sys.argv) > 4 else 2)
+    else:
+        summarise(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 32, int(sys.argv[4]) if len(sys.argv) > 4 else 2)
