@@ -183,6 +183,7 @@ struct KsInnerArgs {
     uint64_t* out1;
     const LimbConst* lc;               // [ctxLimbs]; ctx limbs: Q then P
     const uint64_t* mu128;             // [ctxLimbs][2]
+    const uint64_t* red;               // [ctxLimbs] redM | redR << 32: the quotient estimate of the NTT kernels (fhe_ctx_create)
     uint32_t logN, batch, sizeQl, sizeQ, sizeP, numDigits, alpha;
     uint32_t nc[kMaxDigits];           // complement size of digit j = sizeQl - size_j + sizeP
     uint32_t j0, acc;                  // more than kMaxDigits digits: this launch covers digits j0 .. j0+numDigits-1 and, for j0 > 0,
@@ -205,11 +206,14 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ks_inner_product_kernel(const KsInne
     const uint32_t idx  = i < g.sizeQl ? i : i + (g.sizeQ - g.sizeQl);
     const LimbConst lc  = g.lc[idx];
     const uint64_t mulo = g.mu128[2 * idx], muhi = g.mu128[2 * idx + 1];
-    // The ModUp digits arrive in the NTT's lazy range (< 16q, ks_precompute_run): four conditional subtractions make them
-    // residues, after which the <= kMaxDigits = 8 products per sum fit the 64-bit column sums with one 64-bit Barrett
-    // reduction (sum8, modarith.h) -- half the instructions of a 192-bit accumulator + 128-bit Barrett per output, which
-    // is what makes this kernel HBM-bound.  (The generated MAC / reduction of the conversion kernel were tried here and
+    // The ModUp digits arrive in the NTT's lazy range (< 16q, ks_precompute_run).  One quotient estimate k = (d.hi * redM) >> (32 + redR)
+    // (floor(d / q) or one less for any 64-bit d once q has 36 bits, fhe_ctx_create) and one conditional subtraction make them residues
+    // (moduli below 36 bits: four conditional subtractions); after that the <= kMaxDigits = 8 products per sum fit the 64-bit column
+    // sums with one 64-bit Barrett reduction (sum8, modarith.h) -- half the instructions of a 192-bit accumulator + 128-bit Barrett per
+    // output, which is what makes this kernel HBM-bound.  (The generated MAC / reduction of the conversion kernel were tried here and
     // lost: 1.61 ms instead of 1.14 ms per launch at config 3's shape, the pinned temporaries cost occupancy.)
+    const uint64_t redc = g.red[idx];
+    const uint32_t redM = (uint32_t)redc, redR = (uint32_t)(redc >> 32);
     const uint32_t N    = 1u << g.logN;
     const uint32_t rEnd = ((tr + 1u) << kTileLog) < N ? ((tr + 1u) << kTileLog) : N;
     const uint64_t q = lc.q;
@@ -227,9 +231,13 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ks_inner_product_kernel(const KsInne
                 const uint32_t pos = i < start ? i : i - sz;
                 d = g.digits[j][(((uint64_t)b * g.nc[j] + pos) << g.logN) + r];
             }
-            d = csub(d, q << 3);
-            d = csub(d, q << 2);
-            d = csub(d, q << 1);
+            if (redR != 255u)
+                d -= (uint64_t)((uint32_t)(((d >> 32) * redM) >> 32) >> redR) * q;
+            else {
+                d = csub(d, q << 3);
+                d = csub(d, q << 2);
+                d = csub(d, q << 1);
+            }
             d = csub(d, q);
             const uint64_t koff = (((uint64_t)(g.j0 + j) * (g.sizeQ + g.sizeP) + idx) << g.logN) + r;
             sum8_add(s0, d, g.keyB[koff]);
@@ -243,6 +251,102 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ks_inner_product_kernel(const KsInne
         }
         g.out0[ooff] = v0;
         g.out1[ooff] = v1;
+    }
+}
+
+// The same inner product of ONE digit decomposition with SEVERAL keys (the baby-step rotations of the BSGS linear transform:
+// EvalFastRotationExt(ct, idx_j, digits, addFirst = true) for every j, ckksrns-fhe.cpp:1842-1850, ckksrns-leveledshe.cpp:534-582):
+// a lane makes the digits' residues of its coefficient canonical ONCE and walks the keys, so the digits are read once (not once per
+// rotation).  first != null: out0's Q_l rows get `+ first * firstC[i]` (cTilda[0] += c0 * [P]_{q_i}, ckksrns-leveledshe.cpp:561-570) in
+// the same store.  Exact sums and an exact reduction: the words equal ks_inner_product_kernel's followed by that element-wise pass.
+constexpr int kMaxMultiKeys = 16;
+struct KsInnerMultiArgs {
+    const uint64_t* c;                    // [batch][sizeQl][N] EVAL
+    const uint64_t* digits[kMaxDigits];   // digit j complement: [batch][nc_j][N] EVAL, lazy range
+    const uint64_t* keyB[kMaxMultiKeys];  // key t: [numPartQ][sizeQ+sizeP][N]
+    const uint64_t* keyA[kMaxMultiKeys];
+    uint64_t* out0[kMaxMultiKeys];        // result of key t: [batch][sizeQl+sizeP][N]
+    uint64_t* out1[kMaxMultiKeys];
+    const uint64_t* first;                // [batch][sizeQl][N] or null
+    const TwPair* firstC;                 // [sizeQl]
+    const LimbConst* lc;
+    const uint64_t* mu128;
+    const uint64_t* red;
+    uint32_t logN, batch, sizeQl, sizeQ, sizeP, numDigits, alpha, nKeys;
+    uint32_t nc[kMaxDigits];
+};
+// ND = compile-time bound of the number of digits (their residues live in registers)
+template <int ND>
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ks_inner_multi_kernel(const KsInnerMultiArgs g) {
+    const uint32_t t           = FHE_TID;
+    const uint32_t tilesPerRow = (1u << g.logN) >> kTileLog ? ((1u << g.logN) >> kTileLog) : 1u;
+    const uint32_t sizeQlP     = g.sizeQl + g.sizeP;
+    const uint32_t xcd = FHE_BID & 7u, slot = FHE_BID >> 3;  // (same XCD-aware order as ks_inner_product_kernel: key tiles shared by the batch)
+    const uint32_t b   = slot % g.batch;
+    const uint32_t grp = (slot / g.batch) * 8u + xcd;
+    const uint32_t tr = grp % tilesPerRow;
+    const uint32_t i  = grp / tilesPerRow;
+    if (i >= sizeQlP)
+        return;
+    const uint32_t idx  = i < g.sizeQl ? i : i + (g.sizeQ - g.sizeQl);
+    const LimbConst lc  = g.lc[idx];
+    const uint64_t mulo = g.mu128[2 * idx], muhi = g.mu128[2 * idx + 1];
+    const uint64_t redc = g.red[idx];
+    const uint32_t redM = (uint32_t)redc, redR = (uint32_t)(redc >> 32);
+    const bool addFirst = g.first != nullptr && i < g.sizeQl;
+    TwPair fc{0, 0};
+    if (addFirst)
+        fc = g.firstC[i];
+    const uint32_t N    = 1u << g.logN;
+    const uint32_t rEnd = ((tr + 1u) << kTileLog) < N ? ((tr + 1u) << kTileLog) : N;
+    const uint64_t q = lc.q;
+    const uint64_t ooff0 = ((uint64_t)b * sizeQlP + i) << g.logN;
+    for (uint32_t r = (tr << kTileLog) + t; r < rEnd; r += kThreads) {
+        uint64_t d[ND];
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const uint32_t jj    = (uint32_t)j < g.numDigits ? (uint32_t)j : g.numDigits - 1u;  // (padding re-reads the last digit; its products are skipped)
+            const uint32_t start = jj * g.alpha;
+            const uint32_t sz    = sizeQlP - g.nc[jj];
+            uint64_t v;
+            if (i >= start && i < start + sz)
+                v = g.c[(((uint64_t)b * g.sizeQl + i) << g.logN) + r];
+            else {
+                const uint32_t pos = i < start ? i : i - sz;
+                v = g.digits[jj][(((uint64_t)b * g.nc[jj] + pos) << g.logN) + r];
+            }
+            if (redR != 255u)
+                v -= (uint64_t)((uint32_t)(((v >> 32) * redM) >> 32) >> redR) * q;
+            else {
+                v = csub(v, q << 3);
+                v = csub(v, q << 2);
+                v = csub(v, q << 1);
+            }
+            d[j] = csub(v, q);
+        }
+        uint64_t f = 0;
+        if (addFirst)
+            f = mul_shoup(g.first[(((uint64_t)b * g.sizeQl + i) << g.logN) + r], fc.w, fc.wp, q);
+        for (uint32_t kk = 0; kk < g.nKeys; ++kk) {
+            const uint64_t* kB = g.keyB[kk];
+            const uint64_t* kA = g.keyA[kk];
+            sum8 s0, s1;
+            sum8_clear(s0);
+            sum8_clear(s1);
+#pragma unroll
+            for (int j = 0; j < ND; ++j)
+                if ((uint32_t)j < g.numDigits) {
+                    const uint64_t koff = (((uint64_t)j * (g.sizeQ + g.sizeP) + idx) << g.logN) + r;
+                    sum8_add(s0, d[j], kB[koff]);
+                    sum8_add(s1, d[j], kA[koff]);
+                }
+            uint64_t v0 = sum8_reduce(s0, q, lc.msb, mulo, muhi);
+            const uint64_t v1 = sum8_reduce(s1, q, lc.msb, mulo, muhi);
+            if (addFirst)
+                v0 = add_mod(v0, f, q);
+            g.out0[kk][ooff0 + r] = v0;
+            g.out1[kk][ooff0 + r] = v1;
+        }
     }
 }
 
@@ -322,13 +426,16 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) inner_rows_kernel(const InnerRowsArg
 // and ciphertext of the batch) get consecutive slots on ONE XCD, so the diagonals are fetched once per XCD L2.
 constexpr int kMaxBsgsIn = 16;  // inner rotations per launch (more are accumulated by further launches)
 struct BsgsInnerArgs {
-    const uint64_t* rot;          // [nIn][2][batch][sizeQl+sizeP][N] EVAL, canonical (already offset to the chunk's first rotation)
+    const uint64_t* rot;          // [nIn][2][batch][sizeQl+sizeP][N] EVAL, canonical (already offset to the chunk's first rotation);
+                                  // rot_j is stored BEFORE its automorphism: the kernel reads it through the index map of k[j]
     const uint64_t* const* diag;  // DEVICE table [nOut][nInPad]: plaintext rows [sizeQl+sizeP][N] EVAL; absent terms and the
                                   // padding up to a multiple of the kernel's NIN point at rows of zeros
     uint64_t* out;                // [2][nOut][batch][sizeQl+sizeP][N]
     const LimbConst* lc;          // [ctxLimbs]; ctx limbs: Q then P
     const uint64_t* mu128;        // [ctxLimbs][2]
     uint32_t logN, batch, sizeQl, sizeQ, sizeP, nIn, nInPad, j0, nOut, accumulate;
+    uint32_t k[kMaxBsgsIn];       // automorphism index of rotation j0 + j (1: none): the last step of EvalFastRotationExt
+                                  // (AutomorphismTransform, ckksrns-leveledshe.cpp:572-579) is this kernel's gather, out[r] = in[map_k(r)]
 };
 // CPL = coefficients per lane (adjacent: CPL = 2 gives 16-byte accesses); the plaintext residues of outer step i+1 are
 // loaded before the sums of step i are computed (software pipelining: the loads of a wave overlap its own arithmetic).
@@ -357,13 +464,18 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) bsgs_inner_kernel(const BsgsInnerArg
         // all loads unconditional (absent terms point at a row of zeros, missing rotations re-read the last one and meet
         // a zero row too): the compiler issues the NIN loads of a phase back to back
         uint64_t x[NIN][CPL], y[NIN][CPL], yn[NIN][CPL];
+        uint32_t jb[CPL];
+#pragma unroll
+        for (int u = 0; u < CPL; ++u)
+            jb[u] = bitrev32(r + (uint32_t)u, g.logN);
 #pragma unroll
         for (int j = 0; j < NIN; ++j) {
             const uint32_t jj  = (uint32_t)j < g.nIn ? (uint32_t)j : g.nIn - 1u;
-            const uint64_t* xp = g.rot + ((uint64_t)jj * rotStride + rotOff) + r;  // uniform base + 32-bit lane offset
+            const uint64_t* xp = g.rot + ((uint64_t)jj * rotStride + rotOff);  // uniform base + 32-bit lane offset
+            const uint32_t kj  = g.k[jj];
 #pragma unroll
-            for (int u = 0; u < CPL; ++u)
-                x[j][u] = xp[u];
+            for (int u = 0; u < CPL; ++u)  // (the map permutes inside aligned blocks: a tile reads exactly one tile's cache lines)
+                x[j][u] = xp[automorph_source(jb[u], kj, g.logN)];
         }
         const uint32_t lr = (l << g.logN) + r;  // word offset inside a plaintext: below 2^23
         {

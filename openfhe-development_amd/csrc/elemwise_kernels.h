@@ -268,7 +268,6 @@ struct AutoArgs {
     const uint64_t* in;
     const uint64_t* q;  // [ctxLimbs]
     uint32_t logN, nLimbs, rows, k, evalFormat;
-    uint32_t accumulate;  // EVALUATION only: out += Automorphism(in)  (`first += ...AutomorphismTransform(...)`, ckksrns-fhe.cpp:1873)
     LimbSel sel;
 };
 FHE_HD uint32_t bitrev32(uint32_t x, uint32_t nbits) {
@@ -280,6 +279,11 @@ FHE_HD uint32_t bitrev32(uint32_t x, uint32_t nbits) {
         r |= ((x >> i) & 1u) << (nbits - 1 - i);
     return r;
 #endif
+}
+// source index of the output index whose bit reversal is j under the EVALUATION-format automorphism k (the map above)
+FHE_HD uint32_t automorph_source(uint32_t j, uint32_t k, uint32_t logN) {
+    const uint32_t idx = (((2u * j + 1u) * k) & ((2u << logN) - 1u)) >> 1;
+    return bitrev32(idx, logN);
 }
 FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) automorph_kernel(const AutoArgs g) {
     const uint32_t t          = FHE_TID;
@@ -294,12 +298,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) automorph_kernel(const AutoArgs g) {
         const uint64_t rowBase = off & ~(uint64_t)mask;
         const uint32_t jr      = (uint32_t)off & mask;
         if (g.evalFormat) {
-            const uint32_t j   = bitrev32(jr, g.logN);
-            const uint32_t idx = (((2u * j + 1u) * g.k) & (2u * N - 1u)) >> 1;
-            uint64_t v         = g.in[rowBase + bitrev32(idx, g.logN)];
-            if (g.accumulate)
-                v = add_mod(g.out[off], v, g.q[g.sel.idx[(uint32_t)(off >> g.logN) % g.nLimbs]]);
-            g.out[off] = v;
+            g.out[off] = g.in[rowBase + automorph_source(bitrev32(jr, g.logN), g.k, g.logN)];
         }
         else {
             // gather form of the scatter in the reference: out[jk mod N] = +-in[j]  <=>  j = jr * k^-1 mod 2N
@@ -341,8 +340,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) automorph_sum_kernel(const AutoSumAr
         const uint64_t q       = g.q[g.sel.idx[(uint32_t)(off >> g.logN) % g.nLimbs]];
         uint64_t v             = g.accumulate ? g.out[off] : 0;
         for (uint32_t s = 0; s < g.nSrc; ++s) {
-            const uint32_t idx = (((2u * j + 1u) * g.k[s]) & (2u * N - 1u)) >> 1;
-            v                  = add_mod(v, g.in[s][rowBase + bitrev32(idx, g.logN)], q);
+            v = add_mod(v, g.in[s][rowBase + automorph_source(j, g.k[s], g.logN)], q);
         }
         g.out[off] = v;
     }

@@ -1234,24 +1234,10 @@ extern "C" fhe_status fhe_automorph(fhe_ctx* c, uint64_t* out, const uint64_t* i
     RT_CHECK(rt::set_device(c->device));
     g.out = out, g.in = in, g.q = c->d_q;
     g.logN = c->logN, g.nLimbs = nl, g.rows = bt * nl, g.k = k, g.evalFormat = evalFormat ? 1u : 0u;
-    g.accumulate = 0;
     FHE_LAUNCH(automorph_kernel, tiles_for(c, g.rows), st, g);
     LAUNCH_CHECK();
     return FHE_OK;
 }
-// out (+)= Automorphism_k(in) in EVALUATION format
-static fhe_status automorph_eval_run(fhe_ctx* c, uint64_t* out, const uint64_t* in, uint32_t k, const uint32_t* li, uint32_t nl,
-                                     uint32_t bt, bool accumulate, void* st) {
-    AutoArgs g;
-    if (fhe_status s = make_sel(c, li, nl, &g.sel, "automorphism"))
-        return s;
-    g.out = out, g.in = in, g.q = c->d_q;
-    g.logN = c->logN, g.nLimbs = nl, g.rows = bt * nl, g.k = k, g.evalFormat = 1u, g.accumulate = accumulate ? 1u : 0u;
-    FHE_LAUNCH(automorph_kernel, tiles_for(c, g.rows), st, g);
-    LAUNCH_CHECK();
-    return FHE_OK;
-}
-
 static fhe_status switch_modulus_run(fhe_ctx* c, uint64_t* out, const LimbSel& sel, uint32_t nl, const uint64_t* src,
                                      uint32_t srcLimbs, uint32_t srcPos, uint32_t srcCtxLimb, const TwPair* d_consts,
                                      uint32_t bt, void* st) {
@@ -1886,10 +1872,56 @@ static fhe_status ks_inner_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const fhe
         }
         g.c = cin + (((size_t)towOff * sizeQl) << c->logN), g.keyB = key->d_b, g.keyA = key->d_a;
         g.out0 = e0, g.out1 = e1;
-        g.lc = c->d_lc, g.mu128 = c->d_mu128;
+        g.lc = c->d_lc, g.mu128 = c->d_mu128, g.red = c->d_red;
         g.logN = c->logN, g.batch = batch, g.sizeQl = sizeQl, g.sizeQ = p->sizeQ, g.sizeP = sizeP;
         g.numDigits = nd, g.alpha = p->alpha, g.j0 = j0, g.acc = j0 > 0;
         FHE_LAUNCH(ks_inner_product_kernel, (((uint64_t)tilesPerRow * sizeQlP + 7) / 8) * 8 * batch, st, g);
+        LAUNCH_CHECK();
+    }
+    return FHE_OK;
+}
+// The same for SEVERAL keys on one digit decomposition (the baby-step rotations of a BSGS transform), optionally with
+// out0_t's Q_l rows += first * [P]_{q_i} (EvalFastRotationExt's addFirst, ckksrns-leveledshe.cpp:561-570): one launch per 16 keys, the
+// digits read once per launch.  More than 8 digits: key by key through ks_inner_run + the element-wise pass.
+static fhe_status ks_inner_multi_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const fhe_ks_key* const* keys, uint32_t nKeys,
+                                     const uint64_t* cin, uint32_t batch, uint64_t* const* e0, uint64_t* const* e1,
+                                     const uint64_t* first, const TwPair* dP, uint64_t* ws, const KsLayout& w, void* st) {
+    fhe_ctx* c            = p->ctx;
+    const uint32_t sizeQl = lv->sizeQl, sizeP = p->sizeP, sizeQlP = sizeQl + sizeP;
+    if (lv->numParts > (uint32_t)kMaxDigits) {
+        for (uint32_t t = 0; t < nKeys; ++t) {
+            if (fhe_status s = ks_inner_run(p, lv, keys[t], cin, batch, e0[t], e1[t], ws, w, st))
+                return s;
+            if (first)
+                if (fhe_status s = elem_run<OP_MUL_CONST_ADD>(c, e0[t], first, e0[t], dP, nullptr, sizeQl, batch, st,
+                                                              "fhe_eval_fast_rotation_ext", 0, 0, sizeQlP, 0, sizeQlP, 0))
+                    return s;
+        }
+        return FHE_OK;
+    }
+    const uint32_t tilesPerRow = c->N >= (uint32_t)kTile ? (c->N >> kTileLog) : 1u;
+    for (uint32_t t0 = 0; t0 < nKeys; t0 += (uint32_t)kMaxMultiKeys) {
+        KsInnerMultiArgs g;
+        const uint32_t nt = std::min<uint32_t>(kMaxMultiKeys, nKeys - t0);
+        for (uint32_t j = 0; j < (uint32_t)kMaxDigits; ++j) {
+            g.nc[j]     = j < lv->numParts ? (uint32_t)lv->cidx[j].size() : 0u;
+            g.digits[j] = j < lv->numParts ? ws + w.dig[j] : nullptr;
+        }
+        for (uint32_t t = 0; t < (uint32_t)kMaxMultiKeys; ++t) {
+            const uint32_t tt = t < nt ? t0 + t : t0;
+            g.keyB[t] = keys[tt]->d_b, g.keyA[t] = keys[tt]->d_a, g.out0[t] = e0[tt], g.out1[t] = e1[tt];
+        }
+        g.c = cin, g.first = first, g.firstC = dP;
+        g.lc = c->d_lc, g.mu128 = c->d_mu128, g.red = c->d_red;
+        g.logN = c->logN, g.batch = batch, g.sizeQl = sizeQl, g.sizeQ = p->sizeQ, g.sizeP = sizeP;
+        g.numDigits = lv->numParts, g.alpha = p->alpha, g.nKeys = nt;
+        const uint64_t grid = (((uint64_t)tilesPerRow * sizeQlP + 7) / 8) * 8 * batch;
+        if (lv->numParts <= 3)
+            FHE_LAUNCH((ks_inner_multi_kernel<3>), grid, st, g);
+        else if (lv->numParts <= 4)
+            FHE_LAUNCH((ks_inner_multi_kernel<4>), grid, st, g);
+        else
+            FHE_LAUNCH((ks_inner_multi_kernel<8>), grid, st, g);
         LAUNCH_CHECK();
     }
     return FHE_OK;
@@ -2126,16 +2158,16 @@ extern "C" fhe_status fhe_eval_fast_rotation_ext(fhe_ks_plan* p, const fhe_ks_ke
     fhe_ctx* c    = p->ctx;
     uint64_t* wsp = (uint64_t*)ws;
     const uint32_t sizeQlP = sizeQl + p->sizeP;
-    if (fhe_status s = ks_inner_run(p, lv, key, c1, batch, wsp + w.e0, wsp + w.e1, wsp, w, st))
-        return s;
-    if (addFirst) {  // cTilda[0] += psiC0  (:561-570): e0 rows [0, sizeQl) += c0 * PModq
+    if (addFirst) {  // cTilda[0] += psiC0  (:561-570): e0 rows [0, sizeQl) += c0 * PModq, in the inner product's own store
         TwPair* dP = nullptr;
         if (fhe_status s = ks_pmodq(p, lv, &dP))
             return s;
-        if (fhe_status s = elem_run<OP_MUL_CONST_ADD>(c, wsp + w.e0, c0, wsp + w.e0, dP, nullptr, sizeQl, batch, st,
-                                                      "fhe_eval_fast_rotation_ext", 0, 0, sizeQlP, 0, sizeQlP, 0))
+        uint64_t *e0 = wsp + w.e0, *e1 = wsp + w.e1;
+        if (fhe_status s = ks_inner_multi_run(p, lv, &key, 1, c1, batch, &e0, &e1, c0, dP, wsp, w, st))
             return s;
     }
+    else if (fhe_status s = ks_inner_run(p, lv, key, c1, batch, wsp + w.e0, wsp + w.e1, wsp, w, st))
+        return s;
     std::vector<uint32_t> idx;
     ext_limbs(p, sizeQl, idx);
     if (fhe_status s = fhe_automorph(c, out0, wsp + w.e0, k, 1, idx.data(), sizeQlP, batch, st))
@@ -2157,8 +2189,10 @@ extern "C" fhe_status fhe_ks_down(fhe_ks_plan* p, const uint64_t* x0, const uint
 // FHECKKSRNS::EvalLinearTransform (ckksrns-fhe.cpp:1832-1882) and one level of EvalCoeffsToSlots / EvalSlotsToCoeffs
 // (:1884-2198).  The reference walks the outer (giant) steps one after the other; here every stage runs ONCE over all
 // outer steps (the accumulations `first += ...` and `outer += ...` are exact modular sums, so their order is free):
-//   1. rot_j      inner rotations on one digit decomposition of c1, kept in the extended basis      (nIn launch groups)
-//   2. inner_i    all outer steps' multiply-accumulate sums in one pass over the rotated ciphertexts (1 kernel)
+//   1. rot_j      inner rotations on one digit decomposition of c1, kept in the extended basis: the inner products with all
+//                 rotation keys (+ c0 * P) in one launch, the digits read once; stored BEFORE the automorphism
+//   2. inner_i    all outer steps' multiply-accumulate sums in one pass over the rot_j, each read through its rotation's
+//                 index map (the automorphism is this kernel's gather)                               (1 kernel)
 //   3. d_i        KeySwitchDown of every inner_i as one batch of 2*nOut*batch towers                (INTT, conversion, NTT)
 //   4. first      sum_i Automorphism_{k_i}(d_i[0])                                                   (1 kernel)
 //   5. digits     ModUp of every rotated step's d_i[1] as one batch                                  (INTT, conversions, NTTs)
@@ -2305,31 +2339,31 @@ extern "C" fhe_status fhe_ckks_bsgs_transform(fhe_ks_plan* p, const uint64_t* c0
     const uint64_t* const* dTab = (const uint64_t* const*)it->second;
     bsgsLock.unlock();
 
-    // 1. inner (baby-step) rotations: one digit decomposition of c1 serves all of them (EvalFastRotationPrecompute, :1842)
+    // 1. inner (baby-step) rotations: one digit decomposition of c1 serves all of them (EvalFastRotationPrecompute, :1842), and ONE
+    //    launch computes EvalFastKeySwitchCoreExt + `cTilda[0] += c0 * P` (EvalFastRotationExt(ct, index, digits, addFirst = true)) for all
+    //    of them.  rot_j keeps the result BEFORE the rotation's AutomorphismTransform: stage 2 reads it through the index map
     const KsLayout wB = ks_layout(p, sizeQl, batch);
-    bool digitsReady  = false;
-    for (uint32_t j = 0; j < nIn; ++j) {
-        uint64_t* rj = rot + (size_t)j * 2 * ext;
-        if (inK[j] == 0) {  // KeySwitchExt(ct, true)
-            if (fhe_status s = fhe_ks_ext(p, c0, sizeQl, batch, rj, st))
-                return s;
-            if (fhe_status s = fhe_ks_ext(p, c1, sizeQl, batch, rj + ext, st))
-                return s;
-            continue;
+    {
+        std::vector<const fhe_ks_key*> keys;
+        std::vector<uint64_t*> e0, e1;
+        for (uint32_t j = 0; j < nIn; ++j) {
+            uint64_t* rj = rot + (size_t)j * 2 * ext;
+            if (inK[j] == 0) {  // KeySwitchExt(ct, true)
+                if (fhe_status s = fhe_ks_ext(p, c0, sizeQl, batch, rj, st))
+                    return s;
+                if (fhe_status s = fhe_ks_ext(p, c1, sizeQl, batch, rj + ext, st))
+                    return s;
+                continue;
+            }
+            keys.push_back(inKeys[j]), e0.push_back(rj), e1.push_back(rj + ext);
         }
-        if (!digitsReady) {
+        if (!keys.empty()) {
             if (fhe_status s = ks_precompute_run(p, lv, c1, batch, ws, wB, st))
                 return s;
-            digitsReady = true;
+            if (fhe_status s = ks_inner_multi_run(p, lv, keys.data(), (uint32_t)keys.size(), c1, batch, e0.data(), e1.data(), c0, dP, ws,
+                                                  wB, st))
+                return s;
         }
-        // EvalFastRotationExt(ct, index, digits, addFirst = true): e0, e1 are adjacent in the key-switch workspace
-        if (fhe_status s = ks_inner_run(p, lv, inKeys[j], c1, batch, ws + wB.e0, ws + wB.e1, ws, wB, st))
-            return s;
-        if (fhe_status s = elem_run<OP_MUL_CONST_ADD>(c, ws + wB.e0, c0, ws + wB.e0, dP, nullptr, sizeQl, batch, st,
-                                                      "fhe_ckks_bsgs_transform", 0, 0, sizeQlP, 0, sizeQlP, 0))
-            return s;
-        if (fhe_status s = automorph_eval_run(c, rj, ws + wB.e0, inK[j], extIdx.data(), sizeQlP, 2 * batch, false, st))
-            return s;
     }
     // 2. inner_i = sum_j rot_j * diag[i][j] for every outer step: inner is [2][nOut][batch] extended towers
     for (uint32_t j0 = 0; j0 < nIn; j0 += ninK) {
@@ -2338,6 +2372,8 @@ extern "C" fhe_status fhe_ckks_bsgs_transform(fhe_ks_plan* p, const uint64_t* c0
         g.rot = rot + (size_t)j0 * 2 * ext, g.diag = dTab, g.out = inner, g.lc = c->d_lc, g.mu128 = c->d_mu128;
         g.logN = c->logN, g.batch = batch, g.sizeQl = sizeQl, g.sizeQ = p->sizeQ, g.sizeP = p->sizeP;
         g.accumulate = j0 ? 1u : 0u;
+        for (uint32_t j = 0; j < (uint32_t)kMaxBsgsIn; ++j)
+            g.k[j] = (j < g.nIn && inK[j0 + j]) ? inK[j0 + j] : 1u;
         const uint32_t tilesPerRow = c->N >= (uint32_t)kTile ? (c->N >> kTileLog) : 1u;
         const uint64_t nGroups = (uint64_t)sizeQlP * tilesPerRow, grid = ((nGroups + 7) / 8) * 8 * 2 * batch;
         static const uint32_t cpl = env_u32("FHE_BSGS_CPL", 2);  // coefficients per lane of the 4- and 8-term instances
