@@ -51,10 +51,12 @@ def parse():
     ap.add_argument("--bootstrap-batch", type=int, default=64, help="ciphertexts per GPU in the bootstrap leg (BASELINE configs[3]: 512 over 8 GPUs = 64 per GPU; "
                                                                      "the driver's 1-GPU run is one rank's share)")
     ap.add_argument("--bootstrap-wide-threads", type=int, default=2,
-                    help="host threads (= streams) the lockstep groups of the bootstrap leg are spread over")
+                    help="host threads (= streams) the lockstep groups of the bootstrap leg are spread over (16 x 2: 47.8 / 50.2 bootstraps/s, "
+                         "32 x 1: 45.1 / 49.1 as the first / second setting after the threaded pass, the device 95-98 %% busy; about 32 "
+                         "ciphertexts in flight fit the 288 GB: profiles/r04_sweeps.md sessions g-i)")
     ap.add_argument("--bootstrap-group", type=int, default=16,
                     help="ciphertexts per wide (lockstep) evaluation in the bootstrap leg; 0 = the rank's whole slice (64 at once exceed the "
-                         "288 GB of one GPU with the caches of the threaded pass still resident: profiles/r04_sweeps.md)")
+                         "288 GB of one GPU with the buffer caches of the pass: profiles/r04_sweeps.md)")
     ap.add_argument("--bootstrap-threads", type=int, default=8, help="host threads (= HIP streams) the rank's ciphertexts are spread over")
     ap.add_argument("--no-cc-evalmult", action="store_true",
                     help="skip the leg that runs BASELINE configs[2]'s EvalMult through the reference's CryptoContext on the HIP backend")
@@ -728,8 +730,11 @@ def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev,
     # every composite).  The rank's figure is the better of the two ways of running the batch.
     wide = None
     try:
+        # (the first lockstep passes after the threaded pass run 5-10 % below the later ones — its buffer caches go back to the device on
+        # demand, profiles/r04_sweeps.md sessions h / i — so two passes precede the readings)
+        h.bootstrap_wide(group, 1, wide_threads)
         w0, m0 = h.counters(), h.member_bytes()
-        wsec = h.bootstrap_wide(group, 2, wide_threads)
+        wsec = h.bootstrap_wide(group, 3, wide_threads)
         w1, m1 = h.counters(), h.member_bytes()
         ndiff = h.compare_saved()
         wide = {"seconds_per_pass": round(wsec, 4), "bootstraps_per_s": round(r["ciphertexts"] / wsec, 2),
@@ -740,9 +745,10 @@ def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev,
                            f"MISMATCH: {ndiff} of {r['ciphertexts']} outputs differ from the narrow pass's"),
                 "host_threads": wide_threads,
                 "how": f"one cc->EvalBootstrap per group on a ciphertext of K-tower towers, the groups over {wide_threads} host thread(s) / stream(s)",
-                "roofline": per_bootstrap(w0, w1, 3, r["ciphertexts"] / wsec)}  # (1 untimed + 2 timed passes between the readings)
+                "passes": "2 untimed, then 1 untimed + 3 timed",
+                "roofline": per_bootstrap(w0, w1, 4, r["ciphertexts"] / wsec)}  # (1 untimed + 3 timed passes between the readings)
         # the operand bytes itemised by the pke / DCRTPoly scope that issued the operations (GB per bootstrap, largest first)
-        per = {k: (m1[k] - m0.get(k, 0)) / (3.0 * nct) / 1e9 for k in m1}
+        per = {k: (m1[k] - m0.get(k, 0)) / (4.0 * nct) / 1e9 for k in m1}
         wide["roofline"]["operand_GB_by_member"] = {k: round(v, 3) for k, v in sorted(per.items(), key=lambda kv: -kv[1])[:12] if v > 0.0005}
         if ndiff != 0:
             wide["bootstraps_per_s_unverified"] = wide.pop("bootstraps_per_s")  # a figure without parity is not reported as the rate

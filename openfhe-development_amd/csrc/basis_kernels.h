@@ -301,20 +301,34 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ks_inner_multi_kernel(const KsInnerM
     const uint32_t rEnd = ((tr + 1u) << kTileLog) < N ? ((tr + 1u) << kTileLog) : N;
     const uint64_t q = lc.q;
     const uint64_t ooff0 = ((uint64_t)b * sizeQlP + i) << g.logN;
+    // where digit j's residues of this row live (wave-uniform): the digit's own limbs in the input c, the others in its ModUp buffer
+    const uint64_t* src[ND];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+        const uint32_t jj    = (uint32_t)j < g.numDigits ? (uint32_t)j : g.numDigits - 1u;  // (padding re-reads the last digit; its products are skipped)
+        const uint32_t start = jj * g.alpha;
+        const uint32_t sz    = sizeQlP - g.nc[jj];
+        const bool own       = i >= start && i < start + sz;
+        const uint32_t pos   = i < start ? i : i - sz;
+        src[j] = own ? g.c + (((uint64_t)b * g.sizeQl + i) << g.logN) : g.digits[jj] + (((uint64_t)b * g.nc[jj] + pos) << g.logN);
+    }
+    const uint64_t* firstRow = addFirst ? g.first + (((uint64_t)b * g.sizeQl + i) << g.logN) : nullptr;
     for (uint32_t r = (tr << kTileLog) + t; r < rEnd; r += kThreads) {
         uint64_t d[ND];
 #pragma unroll
+        for (int j = 0; j < ND; ++j)  // (all loads of the coefficient first, back to back: digits, c0, the first key's residues)
+            d[j] = src[j][r];
+        const uint64_t fraw = addFirst ? firstRow[r] : 0;
+        uint64_t kb[ND], ka[ND], nb[ND], na[ND];
+#pragma unroll
         for (int j = 0; j < ND; ++j) {
-            const uint32_t jj    = (uint32_t)j < g.numDigits ? (uint32_t)j : g.numDigits - 1u;  // (padding re-reads the last digit; its products are skipped)
-            const uint32_t start = jj * g.alpha;
-            const uint32_t sz    = sizeQlP - g.nc[jj];
-            uint64_t v;
-            if (i >= start && i < start + sz)
-                v = g.c[(((uint64_t)b * g.sizeQl + i) << g.logN) + r];
-            else {
-                const uint32_t pos = i < start ? i : i - sz;
-                v = g.digits[jj][(((uint64_t)b * g.nc[jj] + pos) << g.logN) + r];
-            }
+            const uint32_t jj   = (uint32_t)j < g.numDigits ? (uint32_t)j : g.numDigits - 1u;
+            const uint64_t koff = (((uint64_t)jj * (g.sizeQ + g.sizeP) + idx) << g.logN) + r;
+            kb[j] = g.keyB[0][koff], ka[j] = g.keyA[0][koff];
+        }
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            uint64_t v = d[j];
             if (redR != 255u)
                 v -= (uint64_t)((uint32_t)(((v >> 32) * redM) >> 32) >> redR) * q;
             else {
@@ -324,26 +338,38 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ks_inner_multi_kernel(const KsInnerM
             }
             d[j] = csub(v, q);
         }
-        uint64_t f = 0;
-        if (addFirst)
-            f = mul_shoup(g.first[(((uint64_t)b * g.sizeQl + i) << g.logN) + r], fc.w, fc.wp, q);
+        const uint64_t f = addFirst ? mul_shoup(fraw, fc.w, fc.wp, q) : 0;
+        // the next key's residues are loaded before the sums of this key are computed (software pipelining: a wave's loads overlap its
+        // own arithmetic)
         for (uint32_t kk = 0; kk < g.nKeys; ++kk) {
-            const uint64_t* kB = g.keyB[kk];
-            const uint64_t* kA = g.keyA[kk];
+            if (kk + 1u < g.nKeys) {
+                const uint64_t* kB = g.keyB[kk + 1u];
+                const uint64_t* kA = g.keyA[kk + 1u];
+#pragma unroll
+                for (int j = 0; j < ND; ++j) {
+                    const uint32_t jj   = (uint32_t)j < g.numDigits ? (uint32_t)j : g.numDigits - 1u;
+                    const uint64_t koff = (((uint64_t)jj * (g.sizeQ + g.sizeP) + idx) << g.logN) + r;
+                    nb[j] = kB[koff], na[j] = kA[koff];
+                }
+            }
             sum8 s0, s1;
             sum8_clear(s0);
             sum8_clear(s1);
 #pragma unroll
             for (int j = 0; j < ND; ++j)
                 if ((uint32_t)j < g.numDigits) {
-                    const uint64_t koff = (((uint64_t)j * (g.sizeQ + g.sizeP) + idx) << g.logN) + r;
-                    sum8_add(s0, d[j], kB[koff]);
-                    sum8_add(s1, d[j], kA[koff]);
+                    sum8_add(s0, d[j], kb[j]);
+                    sum8_add(s1, d[j], ka[j]);
                 }
             uint64_t v0 = sum8_reduce(s0, q, lc.msb, mulo, muhi);
             const uint64_t v1 = sum8_reduce(s1, q, lc.msb, mulo, muhi);
             if (addFirst)
                 v0 = add_mod(v0, f, q);
+            if (kk + 1u < g.nKeys) {
+#pragma unroll
+                for (int j = 0; j < ND; ++j)
+                    kb[j] = nb[j], ka[j] = na[j];
+            }
             g.out0[kk][ooff0 + r] = v0;
             g.out1[kk][ooff0 + r] = v1;
         }

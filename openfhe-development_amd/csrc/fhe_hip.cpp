@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -258,7 +259,9 @@ struct fhe_ctx {
     std::vector<void*> owned;     // every device allocation made for tables (freed in destroy)
     // cached per-level rescale tables (ckksrns-cryptoparameters.cpp:60-81): sizeQl -> {A, B} device arrays
     std::map<uint32_t, std::pair<TwPair*, TwPair*>> rescaleTabs;
-    std::map<std::vector<uint64_t>, TwPair*> constTabs;  // per-limb constants of callers' tables, by content (const_table)
+    std::map<std::vector<uint64_t>, TwPair*> constTabs;  // per-limb constants of callers' tables, by content (const_table); the map owns
+                                                         // them and is emptied when it passes kMaxConstTabs entries (const_tables_trim)
+    std::shared_mutex constTabsGate;  // shared: an entry point between asking for its tables and enqueuing the launches that read them
     // cached ModReduce tables per (sizeQl, t): [0..l) = A_i, [l..2l) = B_i, [2l] = negtInvModq   (fhe_mod_reduce)
     std::map<std::pair<uint32_t, uint64_t>, TwPair*> modReduceTabs;
     std::mutex cacheMutex;        // guards the lazily filled caches above (callers may be OpenMP threads)
@@ -373,6 +376,8 @@ extern "C" void fhe_ctx_destroy(fhe_ctx* c) {
     rt::set_device(c->device);
     for (void* p : c->owned)
         rt::dfree(p);
+    for (auto& kv : c->constTabs)
+        rt::dfree(kv.second);
     delete c;
 }
 extern "C" uint32_t fhe_ctx_logn(const fhe_ctx* c) { return c ? c->logN : 0; }
@@ -664,9 +669,9 @@ static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse
         a.proMode = 1, a.proSrcLimb = *proSrcLimb;
         const int mode = static_mode(c, pp, inverse);
         if (pp.layoutA && !inverse && mode == 1 && pp.T == 4)
-            FHE_LAUNCH((ntt_static_kernel<true, false, 4, 1, false, true>), grid, stream, a);
+            FHE_LAUNCH_BARRIER((ntt_static_kernel<true, false, 4, 1, false, true>), grid, stream, a);
         else if (pp.layoutA && !inverse && mode == 1 && pp.T == 5)
-            FHE_LAUNCH((ntt_static_kernel<true, false, 5, 1, false, true>), grid, stream, a);
+            FHE_LAUNCH_BARRIER((ntt_static_kernel<true, false, 5, 1, false, true>), grid, stream, a);
         else
             return fail(FHE_ERR_UNSUPPORTED, "ntt: no prologue kernel for this pass shape");
         LAUNCH_CHECK();
@@ -681,7 +686,7 @@ static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse
         bool launched  = false;
 #define FHE_EPI_CASE(TT, MODE) \
     if (!launched && !pp.layoutA && !inverse && pp.T == TT && mode == MODE) { \
-        FHE_LAUNCH((ntt_static_kernel<false, false, TT, MODE, true>), grid, stream, a); \
+        FHE_LAUNCH_BARRIER((ntt_static_kernel<false, false, TT, MODE, true>), grid, stream, a); \
         launched = true; \
     }
         FHE_EPI_CASE(12, 9) FHE_EPI_CASE(11, 9) FHE_EPI_CASE(10, 9) FHE_EPI_CASE(9, 9) FHE_EPI_CASE(12, 1)
@@ -697,7 +702,7 @@ static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse
         bool launched  = false;
 #define FHE_STATIC_CASE(LA, INV, TT, MODE) \
     if (!launched && pp.layoutA == LA && inverse == INV && pp.T == TT && mode == MODE) { \
-        FHE_LAUNCH((ntt_static_kernel<LA, INV, TT, MODE>), grid, stream, a); \
+        FHE_LAUNCH_BARRIER((ntt_static_kernel<LA, INV, TT, MODE>), grid, stream, a); \
         launched = true; \
     }
         // column passes of logN = 13..16 (T1 = 4) and 17 (T1 = 5); row passes T2 = logN - T1; the single pass of logN = 12
@@ -717,15 +722,15 @@ static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse
     // rings below one tile (N < 4096): the generic small-ring kernel, several limbs per workgroup
     if (pp.layoutA) {
         if (inverse)
-            FHE_LAUNCH((ntt_pass_kernel<true, true>), grid, stream, a);
+            FHE_LAUNCH_BARRIER((ntt_pass_kernel<true, true>), grid, stream, a);
         else
-            FHE_LAUNCH((ntt_pass_kernel<true, false>), grid, stream, a);
+            FHE_LAUNCH_BARRIER((ntt_pass_kernel<true, false>), grid, stream, a);
     }
     else {
         if (inverse)
-            FHE_LAUNCH((ntt_pass_kernel<false, true>), grid, stream, a);
+            FHE_LAUNCH_BARRIER((ntt_pass_kernel<false, true>), grid, stream, a);
         else
-            FHE_LAUNCH((ntt_pass_kernel<false, false>), grid, stream, a);
+            FHE_LAUNCH_BARRIER((ntt_pass_kernel<false, false>), grid, stream, a);
     }
     LAUNCH_CHECK();
     return FHE_OK;
@@ -883,7 +888,7 @@ extern "C" fhe_status fhe_poly_mul(fhe_ctx* c, const uint64_t* a, const uint64_t
     g.lc = c->d_lc;
 #define FHE_PM_A(TT) \
     if (T2 == TT)    \
-        FHE_LAUNCH((poly_mul_row_a_kernel<TT>), grid, stream, g);
+        FHE_LAUNCH_BARRIER((poly_mul_row_a_kernel<TT>), grid, stream, g);
     FHE_PM_A(12) FHE_PM_A(11) FHE_PM_A(10) FHE_PM_A(9)
 #undef FHE_PM_A
     LAUNCH_CHECK();
@@ -892,7 +897,7 @@ extern "C" fhe_status fhe_poly_mul(fhe_ctx* c, const uint64_t* a, const uint64_t
     g.fwd.xcdSwizzle = g.inv.xcdSwizzle = 0;
 #define FHE_PM_B(TT) \
     if (T2 == TT)    \
-        FHE_LAUNCH((poly_mul_row_b_kernel<TT>), grid, stream, g);
+        FHE_LAUNCH_BARRIER((poly_mul_row_b_kernel<TT>), grid, stream, g);
     FHE_PM_B(12) FHE_PM_B(11) FHE_PM_B(10) FHE_PM_B(9)
 #undef FHE_PM_B
     LAUNCH_CHECK();
@@ -1044,6 +1049,7 @@ extern "C" fhe_status fhe_mul_const(fhe_ctx* c, uint64_t* o, const uint64_t* a, 
     return elem_cv_run<OP_MUL_CONST>(c, o, a, nullptr, cv, li, nl, bt, st, "fhe_mul_const");
 }
 static fhe_status const_table(fhe_ctx* c, const uint32_t* limbIdx, const uint64_t* v, uint32_t n, const TwPair** out);
+static fhe_status const_tables_trim(fhe_ctx* c);
 // out = sum_i consts[i][.] (.) x[i]  (+ out when accumulate): the weighted sums of pke (ckksrns-advancedshe.cpp:97-136) as ONE launch per
 // 16 terms.  consts: HOST array [nTerms][nLimbs], reduced modulo their limbs; their device table is cached by content (the Chebyshev
 // coefficients of a bootstrap repeat), so only the first use of a table blocks for its upload.
@@ -1059,6 +1065,9 @@ extern "C" fhe_status fhe_lincomb(fhe_ctx* c, uint64_t* out, const uint64_t* con
         for (uint32_t r = 0; r < nLimbs; ++r)
             li[(size_t)i * nLimbs + r] = limbIdx ? limbIdx[r] : r;
     const TwPair* table = nullptr;
+    if (fhe_status s = const_tables_trim(c))
+        return s;
+    std::shared_lock<std::shared_mutex> gate(c->constTabsGate);
     if (fhe_status s = const_table(c, li.data(), consts, nTerms * nLimbs, &table))
         return s;
     g.out = out, g.q = c->d_q, g.logN = c->logN, g.nLimbs = nLimbs, g.rows = batch * nLimbs;
@@ -1854,6 +1863,42 @@ static fhe_status ks_precompute_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, cons
 }
 // EvalFastKeySwitchCore (keyswitch-hybrid.cpp:381-435) on digits already in the workspace.
 // accumulate: out0/out1 += result (EvalMult's `cv[0] += ab[0]; cv[1] += ab[1]`, base-leveledshe.cpp:210-211)
+// EvalFastKeySwitchCoreExt (keyswitch-hybrid.cpp:402-435) of ONE digit decomposition with nKeys keys, at most 8 digits: one launch per 16
+// keys, every digit residue read once per launch; first != null: e0_t's Q_l rows += first * dP[i] (EvalFastRotationExt's addFirst,
+// ckksrns-leveledshe.cpp:561-570) in the same store
+static fhe_status ks_inner_multi_launch(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const fhe_ks_key* const* keys, uint32_t nKeys,
+                                        const uint64_t* cin, uint32_t batch, uint64_t* const* e0, uint64_t* const* e1,
+                                        const uint64_t* first, const TwPair* dP, uint64_t* ws, const KsLayout& w, void* st,
+                                        uint32_t towOff = 0) {
+    fhe_ctx* c            = p->ctx;
+    const uint32_t sizeQl = lv->sizeQl, sizeP = p->sizeP, sizeQlP = sizeQl + sizeP;
+    const uint32_t tilesPerRow = c->N >= (uint32_t)kTile ? (c->N >> kTileLog) : 1u;
+    for (uint32_t t0 = 0; t0 < nKeys; t0 += (uint32_t)kMaxMultiKeys) {
+        KsInnerMultiArgs g;
+        const uint32_t nt = std::min<uint32_t>(kMaxMultiKeys, nKeys - t0);
+        for (uint32_t j = 0; j < (uint32_t)kMaxDigits; ++j) {
+            g.nc[j]     = j < lv->numParts ? (uint32_t)lv->cidx[j].size() : 0u;
+            g.digits[j] = j < lv->numParts ? ws + w.dig[j] + (((size_t)towOff * g.nc[j]) << c->logN) : nullptr;
+        }
+        for (uint32_t t = 0; t < (uint32_t)kMaxMultiKeys; ++t) {
+            const uint32_t tt = t < nt ? t0 + t : t0;
+            g.keyB[t] = keys[tt]->d_b, g.keyA[t] = keys[tt]->d_a, g.out0[t] = e0[tt], g.out1[t] = e1[tt];
+        }
+        g.c = cin + (((size_t)towOff * sizeQl) << c->logN), g.first = first, g.firstC = dP;
+        g.lc = c->d_lc, g.mu128 = c->d_mu128, g.red = c->d_red;
+        g.logN = c->logN, g.batch = batch, g.sizeQl = sizeQl, g.sizeQ = p->sizeQ, g.sizeP = sizeP;
+        g.numDigits = lv->numParts, g.alpha = p->alpha, g.nKeys = nt;
+        const uint64_t grid = (((uint64_t)tilesPerRow * sizeQlP + 7) / 8) * 8 * batch;
+        if (lv->numParts <= 3)
+            FHE_LAUNCH((ks_inner_multi_kernel<3>), grid, st, g);
+        else if (lv->numParts <= 4)
+            FHE_LAUNCH((ks_inner_multi_kernel<4>), grid, st, g);
+        else
+            FHE_LAUNCH((ks_inner_multi_kernel<8>), grid, st, g);
+        LAUNCH_CHECK();
+    }
+    return FHE_OK;
+}
 // EvalFastKeySwitchCoreExt (keyswitch-hybrid.cpp:402-435): inner product of the digits in the workspace with the key, both
 // halves, result [batch][sizeQl+sizeP][N] in the extended basis
 // towOff: the `batch` towers start at tower towOff of `cin` and of every digit buffer (a slice of a larger precompute)
@@ -1863,6 +1908,10 @@ static fhe_status ks_inner_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const fhe
     fhe_ctx* c            = p->ctx;
     const uint32_t sizeQl = lv->sizeQl, sizeP = p->sizeP, sizeQlP = sizeQl + sizeP;
     const uint32_t tilesPerRow = c->N >= (uint32_t)kTile ? (c->N >> kTileLog) : 1u;
+    // at most 8 digits: the kernel that keeps the digits' residues in registers and issues every load of a coefficient up front (EvalMult
+    // composite 8440 -> 8611 op/s against the chunked kernel below, session i); more digits: chunks of 8 whose exact sums add up
+    if (lv->numParts <= (uint32_t)kMaxDigits)
+        return ks_inner_multi_launch(p, lv, &key, 1, cin, batch, &e0, &e1, nullptr, nullptr, ws, w, st, towOff);
     for (uint32_t j0 = 0; j0 < lv->numParts; j0 += (uint32_t)kMaxDigits) {  // (one launch up to 8 digits)
         KsInnerArgs g;
         const uint32_t nd = std::min<uint32_t>(kMaxDigits, lv->numParts - j0);
@@ -1880,49 +1929,21 @@ static fhe_status ks_inner_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const fhe
     }
     return FHE_OK;
 }
-// The same for SEVERAL keys on one digit decomposition (the baby-step rotations of a BSGS transform), optionally with
-// out0_t's Q_l rows += first * [P]_{q_i} (EvalFastRotationExt's addFirst, ckksrns-leveledshe.cpp:561-570): one launch per 16 keys, the
-// digits read once per launch.  More than 8 digits: key by key through ks_inner_run + the element-wise pass.
+// The same for SEVERAL keys on one digit decomposition (the baby-step rotations of a BSGS transform), optionally with addFirst.  More
+// than 8 digits: key by key through ks_inner_run + the element-wise pass.
 static fhe_status ks_inner_multi_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, const fhe_ks_key* const* keys, uint32_t nKeys,
                                      const uint64_t* cin, uint32_t batch, uint64_t* const* e0, uint64_t* const* e1,
                                      const uint64_t* first, const TwPair* dP, uint64_t* ws, const KsLayout& w, void* st) {
-    fhe_ctx* c            = p->ctx;
-    const uint32_t sizeQl = lv->sizeQl, sizeP = p->sizeP, sizeQlP = sizeQl + sizeP;
-    if (lv->numParts > (uint32_t)kMaxDigits) {
-        for (uint32_t t = 0; t < nKeys; ++t) {
-            if (fhe_status s = ks_inner_run(p, lv, keys[t], cin, batch, e0[t], e1[t], ws, w, st))
+    if (lv->numParts <= (uint32_t)kMaxDigits)
+        return ks_inner_multi_launch(p, lv, keys, nKeys, cin, batch, e0, e1, first, dP, ws, w, st);
+    const uint32_t sizeQl = lv->sizeQl, sizeQlP = sizeQl + p->sizeP;
+    for (uint32_t t = 0; t < nKeys; ++t) {
+        if (fhe_status s = ks_inner_run(p, lv, keys[t], cin, batch, e0[t], e1[t], ws, w, st))
+            return s;
+        if (first)
+            if (fhe_status s = elem_run<OP_MUL_CONST_ADD>(p->ctx, e0[t], first, e0[t], dP, nullptr, sizeQl, batch, st,
+                                                          "fhe_eval_fast_rotation_ext", 0, 0, sizeQlP, 0, sizeQlP, 0))
                 return s;
-            if (first)
-                if (fhe_status s = elem_run<OP_MUL_CONST_ADD>(c, e0[t], first, e0[t], dP, nullptr, sizeQl, batch, st,
-                                                              "fhe_eval_fast_rotation_ext", 0, 0, sizeQlP, 0, sizeQlP, 0))
-                    return s;
-        }
-        return FHE_OK;
-    }
-    const uint32_t tilesPerRow = c->N >= (uint32_t)kTile ? (c->N >> kTileLog) : 1u;
-    for (uint32_t t0 = 0; t0 < nKeys; t0 += (uint32_t)kMaxMultiKeys) {
-        KsInnerMultiArgs g;
-        const uint32_t nt = std::min<uint32_t>(kMaxMultiKeys, nKeys - t0);
-        for (uint32_t j = 0; j < (uint32_t)kMaxDigits; ++j) {
-            g.nc[j]     = j < lv->numParts ? (uint32_t)lv->cidx[j].size() : 0u;
-            g.digits[j] = j < lv->numParts ? ws + w.dig[j] : nullptr;
-        }
-        for (uint32_t t = 0; t < (uint32_t)kMaxMultiKeys; ++t) {
-            const uint32_t tt = t < nt ? t0 + t : t0;
-            g.keyB[t] = keys[tt]->d_b, g.keyA[t] = keys[tt]->d_a, g.out0[t] = e0[tt], g.out1[t] = e1[tt];
-        }
-        g.c = cin, g.first = first, g.firstC = dP;
-        g.lc = c->d_lc, g.mu128 = c->d_mu128, g.red = c->d_red;
-        g.logN = c->logN, g.batch = batch, g.sizeQl = sizeQl, g.sizeQ = p->sizeQ, g.sizeP = sizeP;
-        g.numDigits = lv->numParts, g.alpha = p->alpha, g.nKeys = nt;
-        const uint64_t grid = (((uint64_t)tilesPerRow * sizeQlP + 7) / 8) * 8 * batch;
-        if (lv->numParts <= 3)
-            FHE_LAUNCH((ks_inner_multi_kernel<3>), grid, st, g);
-        else if (lv->numParts <= 4)
-            FHE_LAUNCH((ks_inner_multi_kernel<4>), grid, st, g);
-        else
-            FHE_LAUNCH((ks_inner_multi_kernel<8>), grid, st, g);
-        LAUNCH_CHECK();
     }
     return FHE_OK;
 }
@@ -2500,6 +2521,24 @@ extern "C" size_t fhe_rescale_workspace_bytes(const fhe_ctx* c, uint32_t sizeQl,
     // last[batch][1][N] + tmp[batch][sizeQl-1][N]
     return ((size_t)batch * sizeQl << c->logN) * 8;
 }
+// A caller that keeps inventing constants (weighted sums with ever new weights) must not grow the cache without bound: an entry point
+// calls this BEFORE it asks for its tables; past the bound every table goes (after a device-wide wait: a launch on any stream may
+// still read one) and the cache refills with what is in use.
+constexpr size_t kMaxConstTabs = 8192;
+static fhe_status const_tables_trim(fhe_ctx* c) {
+    {
+        std::lock_guard<std::mutex> lock(c->cacheMutex);
+        if (c->constTabs.size() < kMaxConstTabs)
+            return FHE_OK;
+    }
+    std::unique_lock<std::shared_mutex> gate(c->constTabsGate);  // (no entry point holds a table it has not launched with yet)
+    std::lock_guard<std::mutex> lock(c->cacheMutex);
+    RT_CHECK(rt::device_sync());
+    for (auto& kv : c->constTabs)
+        rt::dfree(kv.second);
+    c->constTabs.clear();
+    return FHE_OK;
+}
 // device copy of per-limb constants {v[i], Shoup(v[i], q[limb_i])}, cached by content (the caller's tables of one level)
 static fhe_status const_table(fhe_ctx* c, const uint32_t* limbIdx, const uint64_t* v, uint32_t n, const TwPair** out) {
     std::vector<uint64_t> key(2 * (size_t)n);
@@ -2517,7 +2556,6 @@ static fhe_status const_table(fhe_ctx* c, const uint32_t* limbIdx, const uint64_
         }
         void* d = nullptr;
         RT_CHECK(rt::dmalloc(&d, n * sizeof(TwPair)));
-        c->owned.push_back(d);
         RT_CHECK(rt::h2d(d, h.data(), n * sizeof(TwPair), nullptr));
         RT_CHECK(rt::sync(nullptr));
         it = c->constTabs.emplace(std::move(key), (TwPair*)d).first;
@@ -2633,6 +2671,9 @@ static fhe_status rescale_limbs_run(fhe_ctx* c, const uint64_t* x, const uint64_
         negated           = negated && qlInvModq[i] < qi && QlQlInvModqlDivqlModq[i] == (qi - qlInvModq[i]) % qi;
     }
     const TwPair *dA = nullptr, *dB = nullptr;
+    if (fhe_status s = const_tables_trim(c))
+        return s;
+    std::shared_lock<std::shared_mutex> gate(c->constTabsGate);
     if (fhe_status s = const_table(c, limbIdx, QlQlInvModqlDivqlModq, l, &dA))
         return s;
     if (fhe_status s = const_table(c, limbIdx, qlInvModq, l, &dB))
@@ -3326,7 +3367,7 @@ extern "C" fhe_status fhe_checksum(fhe_ctx* c, const uint64_t* x, uint32_t rows,
     ChecksumArgs g;
     g.x = x, g.out = out, g.logN = c->logN, g.rows = rows;
     const uint32_t tileLog = std::min<uint32_t>(c->logN, kTileLog);
-    FHE_LAUNCH(checksum_kernel, ((uint64_t)rows << c->logN) >> tileLog, st, g);
+    FHE_LAUNCH_BARRIER(checksum_kernel, ((uint64_t)rows << c->logN) >> tileLog, st, g);
     LAUNCH_CHECK();
     return FHE_OK;
 }

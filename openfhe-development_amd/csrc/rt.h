@@ -15,7 +15,6 @@ namespace rt {
 struct LaunchSite {
     const char* kernel;
     std::atomic<uint64_t> n{0};
-    bool emuLaneThreads = false;  // (lane emulator only: the site's kernel meets barriers, tests/emu/emu_runtime.h)
     LaunchSite* next;
     static std::atomic<LaunchSite*>& head() {
         static std::atomic<LaunchSite*> h{nullptr};
@@ -108,11 +107,17 @@ struct Timer {
 };
 }  // namespace rt
 }  // namespace fhe
-#define FHE_LAUNCH(kernel, grid, stream, ...)                                              \
-    do {                                                                                   \
-        FHE_COUNT_LAUNCH(kernel);                                                          \
-        fhe_emu::launch((uint32_t)(grid), fhe::kThreads, [=]() { kernel(__VA_ARGS__); },  \
-                        &fhe_launch_site_.emuLaneThreads);                                 \
+// FHE_LAUNCH: a kernel without barriers (its lanes run one after the other on the launching thread); FHE_LAUNCH_BARRIER: a kernel whose
+// lanes exchange through LDS (one OS thread per lane).  The same launch on the device.
+#define FHE_LAUNCH(kernel, grid, stream, ...)                                                     \
+    do {                                                                                          \
+        FHE_COUNT_LAUNCH(kernel);                                                                 \
+        fhe_emu::launch((uint32_t)(grid), fhe::kThreads, [=]() { kernel(__VA_ARGS__); }, false); \
+    } while (0)
+#define FHE_LAUNCH_BARRIER(kernel, grid, stream, ...)                                            \
+    do {                                                                                         \
+        FHE_COUNT_LAUNCH(kernel);                                                                \
+        fhe_emu::launch((uint32_t)(grid), fhe::kThreads, [=]() { kernel(__VA_ARGS__); }, true); \
     } while (0)
 #else
 #include <hip/hip_runtime.h>
@@ -212,5 +217,6 @@ struct Timer {
         FHE_COUNT_LAUNCH(kernel);                                                                                        \
         hipLaunchKernelGGL(kernel, dim3((uint32_t)(grid)), dim3(fhe::kThreads), 0, (hipStream_t)(stream), __VA_ARGS__); \
     } while (0)
+#define FHE_LAUNCH_BARRIER FHE_LAUNCH  // (the distinction only matters to the lane emulator of the tests)
 #endif
 #endif

@@ -448,18 +448,45 @@ Buf MemoFind(const Buf& src, const std::vector<uint64_t>& key) {
         }
     return nullptr;
 }
+// the buffers that hold remembered results: under memory pressure Alloc drops every one of them (DropMemos) — a remembered result pins a
+// tower-sized buffer for as long as its source lives
+static std::mutex g_memoOwnersMutex;
+static std::vector<std::weak_ptr<DevBuf>> g_memoOwners;
 void MemoStore(const Buf& src, std::vector<uint64_t> key, const Buf& result) {
     if (!src || src->parent || !result)
         return;
     DevBuf::Memo evicted;
+    bool first = false;
     {
         std::lock_guard<std::mutex> lk(src->mu);
+        first = src->memo.empty();
         if (src->memo.size() >= 4) {
             evicted = std::move(src->memo.front());
             src->memo.erase(src->memo.begin());
         }
         src->memo.push_back(DevBuf::Memo{std::move(key), result});
     }
+    if (first) {
+        std::lock_guard<std::mutex> lk(g_memoOwnersMutex);
+        if (g_memoOwners.size() >= 4096 && (g_memoOwners.size() & (g_memoOwners.size() - 1)) == 0)  // (at every doubling: forget the dead)
+            g_memoOwners.erase(std::remove_if(g_memoOwners.begin(), g_memoOwners.end(), [](const std::weak_ptr<DevBuf>& w) { return w.expired(); }),
+                               g_memoOwners.end());
+        g_memoOwners.push_back(src);
+    }
+}
+// every remembered result goes (their buffers join the calling thread's free lists, which the caller returns to the device next)
+static void DropMemos() {
+    std::vector<std::weak_ptr<DevBuf>> owners;
+    {
+        std::lock_guard<std::mutex> lk(g_memoOwnersMutex);
+        owners.swap(g_memoOwners);
+    }
+    for (auto& w : owners)
+        if (Buf b = w.lock()) {
+            std::vector<DevBuf::Memo> gone;  // (released after the lock)
+            std::lock_guard<std::mutex> lk(b->mu);
+            gone.swap(b->memo);
+        }
 }
 void Op::HostSync() {
     Runtime& r = rt();
@@ -566,7 +593,8 @@ Buf Alloc(size_t words) {
             pressed = true;
     }
     fhe_status s = pressed ? FHE_ERR_ALLOC : r.api.malloc_(r.anyCtx, bk * 8, &d);
-    if (s != FHE_OK) {  // memory pressure: give every thread's and the shared cached buffers back to the device and retry once
+    if (s != FHE_OK) {  // memory pressure: give the remembered results, every thread's and the shared cached buffers back to the device and retry once
+        DropMemos();
         uint64_t freed = 0;
         for (uint32_t i = 1; i < r.nextStreamId; ++i) {  // every live thread's cache (this thread's included)
             StreamState& st = r.streams[i];

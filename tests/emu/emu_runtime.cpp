@@ -4,6 +4,7 @@
 #include <pthread.h>
 
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <thread>
@@ -53,20 +54,25 @@ Pool& pool() {
 std::mutex launchMutex;
 }  // namespace
 
-namespace {
-struct MetBarrier {};
-}  // namespace
 void block_sync() {
-    if (tls.sequential)
-        throw MetBarrier{};
+    if (tls.sequential) {
+        std::fprintf(stderr, "fhe_emu: a kernel launched with FHE_LAUNCH met a barrier (its launch site must use FHE_LAUNCH_BARRIER)\n");
+        std::abort();
+    }
     pthread_barrier_wait(&pool().sync);
 }
 void* block_shared(size_t bytes) {
     if (bytes > sizeof(pool().shared))
         std::abort();
+    if (tls.sequential) {  // (scratch of a kernel without barriers: private to the launching thread)
+        static thread_local std::vector<unsigned char> mine;
+        if (mine.size() < bytes)
+            mine.resize(bytes);
+        return mine.data();
+    }
     return pool().shared;
 }
-void launch(uint32_t grid, uint32_t threads, const std::function<void()>& body, bool* needsLaneThreads) {
+void launch(uint32_t grid, uint32_t threads, const std::function<void()>& body, bool laneThreads) {
     if (threads != kLanes)
         std::abort();
     // FHE_EMU_SKIP=1: kernels do nothing (results are garbage).  For measuring the HOST side of a call sequence — pke's and the
@@ -74,33 +80,23 @@ void launch(uint32_t grid, uint32_t threads, const std::function<void()>& body, 
     static const bool skip = std::getenv("FHE_EMU_SKIP") != nullptr;
     if (skip)
         return;
-    uint32_t first = 0;
-    if (needsLaneThreads && !*needsLaneThreads) {
-        // lanes one after the other on this thread; the first barrier (lane 0 of the first block, before it stored anything) ends the attempt
+    if (!laneThreads) {  // lanes one after the other on this thread (several host threads may do so at once)
         const Tls saved = tls;
-        try {
-            tls.sequential = true;
-            tls.nblk       = grid;
-            for (uint32_t b = 0; b < grid; ++b)
-                for (uint32_t t = 0; t < kLanes; ++t) {
-                    tls.bid = b, tls.tid = t;
-                    body();
-                }
-            tls = saved;
-            return;
-        }
-        catch (const MetBarrier&) {
-            if (tls.bid != 0 || tls.tid != 0)
-                std::abort();  // (a kernel whose lanes reach barriers data-dependently: not a kernel of this library)
-            tls               = saved;
-            *needsLaneThreads = true;
-        }
+        tls.sequential  = true;
+        tls.nblk        = grid;
+        for (uint32_t b = 0; b < grid; ++b)
+            for (uint32_t t = 0; t < kLanes; ++t) {
+                tls.bid = b, tls.tid = t;
+                body();
+            }
+        tls = saved;
+        return;
     }
     std::lock_guard<std::mutex> lk(launchMutex);
     Pool& p = pool();
     p.body  = &body;
     p.nblk  = grid;
-    for (uint32_t b = first; b < grid; ++b) {
+    for (uint32_t b = 0; b < grid; ++b) {
         p.bid = b;
         pthread_barrier_wait(&p.start);
         pthread_barrier_wait(&p.stop);
