@@ -17,17 +17,19 @@ def source_sha():  # the same identity bench.py computes: the kernel sources the
 
 
 R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+# --pmc-only: on the GPU box, between the counter passes and the bench run of a record session — the bench line then quotes the
+# counters of the very sources it runs (it keys them by kernel-source identity)
+PMC_ONLY = "--pmc-only" in sys.argv
 os.makedirs("profiles", exist_ok=True)
-shutil.copy(f"gpurun_out/bench_{R}.json", f"profiles/{R}_bench.json")
-try:
-    shutil.copy(newest(f"gpurun_out/prof_{R}/*/*kernel_stats.csv"), f"profiles/{R}_rocprof_kernel_stats_bench.csv")
-except ValueError:  # (rocprofv3 itself crashed on the whole-bench command in one session: the per-leg profiles remain)
-    pass
-shutil.copy(newest(f"gpurun_out/prof_{R}_ntt/*/*kernel_stats.csv"), f"profiles/{R}_rocprof_kernel_stats_ntt_leg.csv")
-try:
-    shutil.copy(newest(f"gpurun_out/prof_{R}_evalmult/*/*kernel_stats.csv"), f"profiles/{R}_rocprof_kernel_stats_evalmult256.csv")
-except ValueError:
-    pass
+if not PMC_ONLY:
+    shutil.copy(f"gpurun_out/bench_{R}.json", f"profiles/{R}_bench.json")
+    for src, dst in ((f"gpurun_out/prof_{R}/*/*kernel_stats.csv", f"profiles/{R}_rocprof_kernel_stats_bench.csv"),
+                     (f"gpurun_out/prof_{R}_ntt/*/*kernel_stats.csv", f"profiles/{R}_rocprof_kernel_stats_ntt_leg.csv"),
+                     (f"gpurun_out/prof_{R}_evalmult/*/*kernel_stats.csv", f"profiles/{R}_rocprof_kernel_stats_evalmult256.csv")):
+        try:
+            shutil.copy(newest(src), dst)
+        except ValueError:  # (a pass that was not part of the session)
+            pass
 names = {"<true, false,": "fwd_column_pass", "<false, false,": "fwd_row_pass", "<false, true,": "inv_row_pass",
          "<true, true,": "inv_column_pass"}
 res = {}
@@ -45,7 +47,8 @@ out = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (se
                "KiB; FETCH_SIZE is doubled (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md §HBM).",
        "workload": "logN16_L30_B1024", "per_launch_bytes": {},
        # identity of the kernel sources ON THE GPU BOX in that run (bench.py recorded it in its own line)
-       "kernel_source_sha": (json.load(open(f"profiles/{R}_bench.json")).get("roofline") or {}).get("kernel_source_sha") or source_sha()}
+       "kernel_source_sha": source_sha() if PMC_ONLY else
+       ((json.load(open(f"profiles/{R}_bench.json")).get("roofline") or {}).get("kernel_source_sha") or source_sha())}
 for k, v in res.items():
     out["per_launch_bytes"][k] = {"fetch_bytes": v["FETCH_SIZE"] * 2048, "write_bytes": v["WRITE_SIZE"] * 1024,
                                   "total": v["FETCH_SIZE"] * 2048 + v["WRITE_SIZE"] * 1024,
@@ -88,5 +91,7 @@ for leg in ("ntt", "evalmult"):
     valu["legs"][leg] = legd
 if valu["legs"]:
     json.dump(valu, open(f"profiles/{R}_pmc_valu.json", "w"), indent=1)
+if PMC_ONLY:
+    sys.exit(0)
 b = json.load(open(f"profiles/{R}_bench.json"))
 print(json.dumps({k: b[k] for k in ("value", "ms_per_step", "hbm_roofline_frac_fwd_inv", "roofline", "cpu_baseline", "evalmult")}, indent=1))
