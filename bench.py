@@ -363,8 +363,9 @@ def evalmult_leg(lib, device, logN, batch, steps, warmup, sync, dist=None, sizeQ
                          "survey_8d_frac": round(ach_survey / HBM_PEAK_GBPS, 4),
                          "byte_counts": "algorithmic_bytes_per_op itemises every stage (DESIGN.md §7); survey_8d_* is SURVEY.md 8(d)'s figure "
                                         "(limb-NTT traffic + the tensor product's 9 limb moves only)",
-                         "dominant_kernel": "ntt_static_kernel (forward row pass with the ModDown epilogue / digit transforms); "
-                                            "shares in profiles/r02_rocprof_kernel_stats_evalmult256.csv; SQ counters in profiles/r03_pmc_valu.json"}}
+                         "dominant_kernel": "ntt_static_kernel (58 % over its four pass kernels; then switch_basis_kernel 16 %, "
+                                            "ks_inner_multi_kernel 15 %, tensor_kernel 11 %): shares in "
+                                            "profiles/r04_rocprof_kernel_stats_evalmult256.csv"}}
 
 
 def linear_transform_leg(lib, device, batches, steps, warmup, with_cpu, parity=True):

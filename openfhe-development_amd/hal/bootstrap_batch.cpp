@@ -29,6 +29,7 @@ using namespace lbcrypto;
 extern "C" void fhe_hal_set_device(int device);
 extern "C" void fhe_hal_operand_bytes(uint64_t out[2]);
 extern "C" void fhe_hal_stats(uint64_t out[4]);
+extern "C" void fhe_hal_release_caches();
 extern "C" size_t fhe_hal_launch_stats(char* buf, size_t cap, uint64_t* total);
 extern "C" size_t fhe_hal_member_stats(char* buf, size_t cap);
 #endif
@@ -122,7 +123,17 @@ void fbb_set_omp_threads(int n) { omp_set_num_threads(n); }
 // 0: every OpenMP region of the process runs on its calling thread alone (the latency of ONE bootstrap on ONE host thread / stream:
 // pke's inner loops would otherwise fork inside a one-thread batch loop); 1: the default (one level of parallelism)
 void fbb_set_active_levels(int n) { omp_set_max_active_levels(n); }
-void fbb_destroy(void* h) { delete static_cast<Batch*>(h); }
+void fbb_destroy(void* h) {
+    // pke keeps evaluation keys and contexts in static registries: the harness owns the process's only context, so they go with the batch
+    // (the key towers may be windows of `external`, which the batch releases after them)
+    CryptoContextImpl<DCRTPoly>::ClearEvalMultKeys();
+    CryptoContextImpl<DCRTPoly>::ClearEvalAutomorphismKeys();
+    delete static_cast<Batch*>(h);
+    CryptoContextFactory<DCRTPoly>::ReleaseAllContexts();
+#ifdef WITH_HIP
+    fhe_hal_release_caches();  // (the batch's keys and towers went to the buffer caches: the next user of the GPU may be another process)
+#endif
+}
 // {ring dimension, Q limbs, P limbs, digits, depth}
 void fbb_shape(void* h, uint32_t out[5]) {
     auto* b       = static_cast<Batch*>(h);

@@ -551,6 +551,60 @@ DevBuf::~DevBuf() {
     ts->freeLists[bucket_of(words)].push_back(p);
     r.cachedBytes.fetch_add(bytes, std::memory_order_relaxed);
 }
+// Everything the backend holds beyond live towers goes back to the device: the remembered results, every live thread's free lists (under
+// its stream's mutex, after synchronising that stream), the orphans and what exited threads left parked.  Alloc calls it under memory
+// pressure; fhe_hal_release_caches() lets a process that is done with a batch hand the device to the next one (bench.py between legs).
+static void ReleaseCaches() {
+    Runtime& r = rt();
+    DropMemos();
+    uint64_t freed = 0;
+    for (uint32_t i = 1; i < r.nextStreamId; ++i) {  // every live thread's cache (this thread's included)
+        StreamState& st = r.streams[i];
+        std::vector<uint64_t*> taken;
+        {
+            std::lock_guard<std::mutex> flk(st.flMutex);
+            if (!st.ownerState)
+                continue;
+            for (auto& kv : st.ownerState->freeLists) {
+                taken.insert(taken.end(), kv.second.begin(), kv.second.end());
+                freed += (uint64_t)kv.first * 8 * kv.second.size();
+                kv.second.clear();
+            }
+        }
+        if (taken.empty())
+            continue;
+        r.api.sync(r.anyCtx, st.s);  // (what is still pending on the buffers is on their owner's stream)
+        for (uint64_t* q : taken)
+            r.api.free_(r.anyCtx, q);
+    }
+    {
+        std::lock_guard<std::mutex> lk(r.poolMutex);
+        for (auto& kv : r.orphanLists) {
+            for (uint64_t* q : kv.second)
+                r.api.free_(r.anyCtx, q);
+            freed += (uint64_t)kv.first * 8 * kv.second.size();
+            kv.second.clear();
+        }
+    }
+    for (uint32_t i = 1; i < r.nextStreamId; ++i) {  // what other threads sent back to a stream and its thread has not taken yet (or never will: it exited)
+        StreamState& st = r.streams[i];
+        if (st.inboxCount.load() == 0)
+            continue;
+        std::vector<std::pair<size_t, uint64_t*>> in;
+        {
+            std::lock_guard<std::mutex> lk(st.inboxMutex);
+            in.swap(st.inbox);
+            st.inboxCount.store(0);
+        }
+        r.api.sync(r.anyCtx, st.s);
+        for (auto& e : in) {
+            r.api.free_(r.anyCtx, e.second);
+            freed += (uint64_t)e.first * 8;
+        }
+    }
+    r.cachedBytes.fetch_sub(std::min<uint64_t>(freed, r.cachedBytes.load()), std::memory_order_relaxed);
+}
+void ReleaseAllCaches() { ReleaseCaches(); }
 Buf Alloc(size_t words) {
     Runtime& r      = rt();
     ThreadState* ts = thread_state();
@@ -594,53 +648,7 @@ Buf Alloc(size_t words) {
     }
     fhe_status s = pressed ? FHE_ERR_ALLOC : r.api.malloc_(r.anyCtx, bk * 8, &d);
     if (s != FHE_OK) {  // memory pressure: give the remembered results, every thread's and the shared cached buffers back to the device and retry once
-        DropMemos();
-        uint64_t freed = 0;
-        for (uint32_t i = 1; i < r.nextStreamId; ++i) {  // every live thread's cache (this thread's included)
-            StreamState& st = r.streams[i];
-            std::vector<uint64_t*> taken;
-            {
-                std::lock_guard<std::mutex> flk(st.flMutex);
-                if (!st.ownerState)
-                    continue;
-                for (auto& kv : st.ownerState->freeLists) {
-                    taken.insert(taken.end(), kv.second.begin(), kv.second.end());
-                    freed += (uint64_t)kv.first * 8 * kv.second.size();
-                    kv.second.clear();
-                }
-            }
-            if (taken.empty())
-                continue;
-            r.api.sync(r.anyCtx, st.s);  // (what is still pending on the buffers is on their owner's stream)
-            for (uint64_t* q : taken)
-                r.api.free_(r.anyCtx, q);
-        }
-        {
-            std::lock_guard<std::mutex> lk(r.poolMutex);
-            for (auto& kv : r.orphanLists) {
-                for (uint64_t* q : kv.second)
-                    r.api.free_(r.anyCtx, q);
-                freed += (uint64_t)kv.first * 8 * kv.second.size();
-                kv.second.clear();
-            }
-        }
-        for (uint32_t i = 1; i < r.nextStreamId; ++i) {  // what exited threads left parked with their streams
-            StreamState& st = r.streams[i];
-            if (st.owned.load() || st.inboxCount.load() == 0)
-                continue;
-            std::vector<std::pair<size_t, uint64_t*>> in;
-            {
-                std::lock_guard<std::mutex> lk(st.inboxMutex);
-                in.swap(st.inbox);
-                st.inboxCount.store(0);
-            }
-            r.api.sync(r.anyCtx, st.s);
-            for (auto& e : in) {
-                r.api.free_(r.anyCtx, e.second);
-                freed += (uint64_t)e.first * 8;
-            }
-        }
-        r.cachedBytes.fetch_sub(std::min<uint64_t>(freed, r.cachedBytes.load()), std::memory_order_relaxed);
+        ReleaseCaches();
         s = r.api.malloc_(r.anyCtx, bk * 8, &d);
     }
     Check(s, "HIP backend: device allocation");
@@ -1195,6 +1203,12 @@ void PrecomputeAutoMap(uint32_t n, uint32_t k, std::vector<uint32_t>* precomp) {
 }
 }  // namespace lbcrypto
 
+// hands every cached buffer and remembered result back to the device (a process that is done with a batch and shares the GPU with another
+// process: bench.py between its legs)
+extern "C" void fhe_hal_release_caches() {
+    if (lbcrypto::hiprt::Available())
+        lbcrypto::hiprt::ReleaseAllCaches();
+}
 extern "C" void fhe_hal_stats(uint64_t out[4]) {
     auto& r = lbcrypto::hiprt::rt();
     out[0] = r.deviceOps, out[1] = r.hostFallbacks, out[2] = r.h2dBytes, out[3] = r.d2hBytes;

@@ -136,6 +136,8 @@ using Buf = std::shared_ptr<DevBuf>;
 Buf MemoFind(const Buf& src, const std::vector<uint64_t>& key);
 void MemoStore(const Buf& src, std::vector<uint64_t> key, const Buf& result);
 Buf Alloc(size_t words);
+// every cached released buffer and remembered result goes back to the device (what Alloc does under memory pressure)
+void ReleaseAllCaches();
 Buf View(const Buf& parent, size_t offsetWords, size_t words);
 // device memory owned by the caller (it must outlive every tower that adopts a window of it)
 Buf WrapExternal(uint64_t* devPtr, size_t words);
