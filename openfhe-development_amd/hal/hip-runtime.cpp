@@ -605,6 +605,11 @@ static void ReleaseCaches() {
     r.cachedBytes.fetch_sub(std::min<uint64_t>(freed, r.cachedBytes.load()), std::memory_order_relaxed);
 }
 void ReleaseAllCaches() { ReleaseCaches(); }
+void SyncAllStreams() {
+    Runtime& r = rt();
+    for (uint32_t i = 1; i < r.nextStreamId; ++i)
+        Check(r.api.sync(r.anyCtx, r.streams[i].s), "HIP backend: stream synchronisation");
+}
 Buf Alloc(size_t words) {
     Runtime& r      = rt();
     ThreadState* ts = thread_state();
@@ -1208,6 +1213,11 @@ void PrecomputeAutoMap(uint32_t n, uint32_t k, std::vector<uint32_t>* precomp) {
 extern "C" void fhe_hal_release_caches() {
     if (lbcrypto::hiprt::Available())
         lbcrypto::hiprt::ReleaseAllCaches();
+}
+// the host waits until every stream of the backend has run dry (the end of a timed pass of a harness)
+extern "C" void fhe_hal_device_sync() {
+    if (lbcrypto::hiprt::Available())
+        lbcrypto::hiprt::SyncAllStreams();
 }
 extern "C" void fhe_hal_stats(uint64_t out[4]) {
     auto& r = lbcrypto::hiprt::rt();
