@@ -827,7 +827,11 @@ def cc_evalmult_leg(with_cpu, libpath):
         env["OMP_NUM_THREADS"] = str(threads)
         p = subprocess.run([exe, out, prng, "multbatch", "16", "20", str(batch), str(reps), str(group)], env=env, capture_output=True, text=True,
                            timeout=900)
-        m = re.search(r"EvalMult per second ([0-9.eE+-]+)", p.stdout)
+        m = re.search(r"multbatch seconds per pass \S+ EvalMult per second ([0-9.eE+-]+)", p.stdout)
+        # (lockstep runs also time the multiplications on operands that STAY wide, and compare those products with the packed pass's)
+        mr = re.search(r"multbatch resident seconds per pass \S+ EvalMult per second ([0-9.eE+-]+)", p.stdout)
+        md = re.search(r"resident products differing from the packed pass's: (\d+) of", p.stdout)
+        run.resident = (float(mr.group(1)), int(md.group(1))) if p.returncode == 0 and mr and md else None
         return (float(m.group(1)) if p.returncode == 0 and m else None), (p.stdout + p.stderr)[-400:]
 
     hipenv = {"FHE_HIP_LIB": libpath}
@@ -845,6 +849,10 @@ def cc_evalmult_leg(with_cpu, libpath):
         same = open(os.path.join(tmp, "w256.bin"), "rb").read() == open(os.path.join(tmp, "h256.bin"), "rb").read()
         lock = {"ops_per_s": round(wrate, 1), "group": 64, "host_threads": 1,  # (one thread issues the group's launches)
                 "parity": "first and last product identical byte for byte to the threaded run's" if same else "MISMATCH vs the threaded run"}
+        if run.resident is not None:  # the same multiplications on ciphertexts that stay wide (no PackWide / UnpackTower in the timed region)
+            lock["resident_ops_per_s"] = round(run.resident[0], 1)
+            lock["resident_parity"] = ("all 256 products identical word for word to the packed pass's (every limb on the host)" if run.resident[1] == 0
+                                       else f"MISMATCH: {run.resident[1]} products differ from the packed pass's")
         if same:
             rate = max(rate, wrate)
     else:

@@ -498,7 +498,8 @@ DevBuf::~DevBuf() {
         return;
     Runtime& r      = rt();
     ThreadState* ts = thread_state();
-    const uint64_t bytes = (uint64_t)bucket_of(words) * 8;
+    const size_t bucket  = cap ? cap : bucket_of(words);
+    const uint64_t bytes = (uint64_t)bucket * 8;
     if (!ts || r.cachedBytes.load(std::memory_order_relaxed) + bytes > r.cacheCap) {
         // static destruction at process exit (no thread state), or the caches are full: wait for the pending uses on the host, then park
         // the buffer with the orphans / give it back to the device
@@ -511,7 +512,7 @@ DevBuf::~DevBuf() {
             return;
         }
         std::lock_guard<std::mutex> lk(r.poolMutex);
-        r.orphanLists[bucket_of(words)].push_back(p);
+        r.orphanLists[bucket].push_back(p);
         r.cachedBytes.fetch_add(bytes, std::memory_order_relaxed);
         return;
     }
@@ -537,7 +538,7 @@ DevBuf::~DevBuf() {
         StreamState& st = r.streams[owner];
         if (last > ts->waited[owner] && st.owned.load()) {
             std::lock_guard<std::mutex> lk(st.inboxMutex);
-            st.inbox.emplace_back(bucket_of(words), p);
+            st.inbox.emplace_back(bucket, p);
             st.inboxCount.fetch_add(1, std::memory_order_release);
             r.cachedBytes.fetch_add(bytes, std::memory_order_relaxed);
             return;
@@ -548,7 +549,7 @@ DevBuf::~DevBuf() {
     for (const auto& u : readers)
         order_after(ts, u);
     std::lock_guard<std::mutex> fl(r.streams[ts->id].flMutex);
-    ts->freeLists[bucket_of(words)].push_back(p);
+    ts->freeLists[bucket].push_back(p);
     r.cachedBytes.fetch_add(bytes, std::memory_order_relaxed);
 }
 // Everything the backend holds beyond live towers goes back to the device: the remembered results, every live thread's free lists (under
@@ -616,14 +617,24 @@ Buf Alloc(size_t words) {
     const size_t bk = bucket_of(words);
     auto b          = std::make_shared<DevBuf>();
     b->words        = words;
+    // A released buffer of the request's size class, else of the next larger classes (up to 4x): the towers of an evaluation shrink level by
+    // level, so what the high levels released serves the low ones and the caches hold the evaluation's high-water mark in BYTES — filed
+    // by exact class only, every class keeps its own high-water mark (several times the live bytes: 32 ciphertexts in flight filled 288 GB)
+    auto take = [&](std::map<size_t, std::vector<uint64_t*>>& lists) -> bool {
+        for (auto it = lists.lower_bound(bk); it != lists.end() && it->first <= 4 * bk; ++it)
+            if (!it->second.empty()) {
+                b->p = it->second.back();
+                it->second.pop_back();
+                b->cap = it->first;
+                r.cachedBytes.fetch_sub((uint64_t)it->first * 8, std::memory_order_relaxed);
+                return true;
+            }
+        return false;
+    };
     if (ts) {
         ts->TakeInbox();
         std::lock_guard<std::mutex> flk(r.streams[ts->id].flMutex);
-        auto& fl = ts->freeLists[bk];
-        if (!fl.empty()) {
-            b->p = fl.back();
-            fl.pop_back();
-            r.cachedBytes.fetch_sub((uint64_t)bk * 8, std::memory_order_relaxed);
+        if (take(ts->freeLists)) {
             // Kernels of the buffer's previous life may still be pending on THIS thread's stream (free lists and inboxes hold such
             // buffers on purpose: ~DevBuf only orders the stream).  This thread's own launches follow them in stream order; a first use
             // by ANOTHER thread (a tower allocated here and filled by an OpenMP worker) must be ordered behind them: the new buffer
@@ -634,13 +645,8 @@ Buf Alloc(size_t words) {
     }
     {
         std::lock_guard<std::mutex> lk(r.poolMutex);
-        auto& fl = r.orphanLists[bk];
-        if (!fl.empty()) {  // (orphans were parked after a host-side wait for their pending uses: nothing to order behind)
-            b->p = fl.back();
-            fl.pop_back();
-            r.cachedBytes.fetch_sub((uint64_t)bk * 8, std::memory_order_relaxed);
+        if (take(r.orphanLists))  // (orphans were parked after a host-side wait for their pending uses: nothing to order behind)
             return b;
-        }
     }
     void* d      = nullptr;
     // (the allocation goes to the device: if it would eat into the reserve kept for kernel launches while buffers sit in caches, the
@@ -657,7 +663,8 @@ Buf Alloc(size_t words) {
         s = r.api.malloc_(r.anyCtx, bk * 8, &d);
     }
     Check(s, "HIP backend: device allocation");
-    b->p = static_cast<uint64_t*>(d);
+    b->p   = static_cast<uint64_t*>(d);
+    b->cap = bk;
     return b;
 }
 Buf WrapExternal(uint64_t* devPtr, size_t words) {

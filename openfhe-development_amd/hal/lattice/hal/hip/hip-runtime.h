@@ -112,6 +112,7 @@ fhe_ctx* AnyCtx();
 struct DevBuf {
     uint64_t* p  = nullptr;
     size_t words = 0;
+    size_t cap   = 0;  // words of the allocation behind p (its size class; a recycled buffer may be larger than `words` asks for)
     std::shared_ptr<DevBuf> parent;  // a window of another buffer (packed evaluation keys): uses are recorded on the parent
     bool external = false;           // memory the backend does not own (e.g. a tensor an RCCL collective filled): never pooled or freed
     struct Use {
