@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, session l: the bench line again as the driver runs it, after the bootstrap leg learnt to hand its buffer caches, keys and contexts
+# round 4, sessions l and o (o = the same after the best-fit buffer caches, the stream-sync drains and the resident cc->EvalMult figure): the bench line again as the driver runs it, after the bootstrap leg learnt to hand its buffer caches, keys and contexts
 # back to the device when it closes (session k: the cc->EvalMult leg, a child process, found the device full: 353 op/s, lockstep out of memory)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
