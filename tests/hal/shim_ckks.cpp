@@ -515,10 +515,12 @@ int main(int argc, char** argv) {
                 }
             int differing = 0;
             for (int i = 0; i < B; ++i) {
-                bool same = c[i]->GetElements().size() == packedPass[i]->GetElements().size();
-                for (size_t e = 0; same && e < c[i]->GetElements().size(); ++e) {
-                    const auto& x = c[i]->GetElements()[e].GetAllElements();
-                    const auto& y = packedPass[i]->GetElements()[e].GetAllElements();
+                const auto& ex = c[i]->GetElements();  // (const views: reading must not count as a host-side write access)
+                const auto& ey = packedPass[i]->GetElements();
+                bool same = ex.size() == ey.size();
+                for (size_t e = 0; same && e < ex.size(); ++e) {
+                    const auto& x = ex[e].GetAllElements();
+                    const auto& y = ey[e].GetAllElements();
                     same = x.size() == y.size();
                     for (size_t l = 0; same && l < x.size(); ++l)
                         same = x[l].GetValues() == y[l].GetValues();

@@ -117,6 +117,7 @@ def check(tmp_path, mode, logN, device_lib, expect, extra=(), threads=1, must_ru
     cm = re.search(r"halcomposite calls (\d+) checksIdentical (\d+) checksDiffered (\d+)", out_hip)
     assert cm and int(cm.group(3)) == 0, out_hip[-600:]
     check.composite_calls = int(cm.group(1))
+    check.out_hip = out_hip
     for name, want in expect.items():
         for run_out in (out_stock, out_hip):
             got = values(run_out, name)
@@ -319,12 +320,16 @@ def test_shim_batch_of_ciphertexts_in_lockstep_on_emulator(tmp_path):
     group argument)"""
     ops = check(tmp_path, "multbatch", 10, EMU, {"product 0": [0.5, 0.0, -3.0]}, extra=(4, 8, 1, 3), threads=1)
     assert ops > 20 and check.composite_calls >= 4  # (the narrow warm-up + one composite key switch per group and pass)
+    # the multiplications once more on operands that STAY wide (packed before, unpacked after): the dumped products are those, and the
+    # program compared all of them with the packed pass's
+    assert "resident products differing from the packed pass's: 0 of 8" in check.out_hip
 
 
 @pytest.mark.gpu
 def test_shim_batch_of_ciphertexts_in_lockstep_on_gpu(tmp_path):
     ops = check(tmp_path, "multbatch", 14, HIP, {"product 0": [0.5, 0.0, -3.0]}, extra=(8, 32, 1, 12), threads=1)
     assert ops > 20 and check.composite_calls >= 4
+    assert "resident products differing from the packed pass's: 0 of 32" in check.out_hip
 
 
 @pytest.mark.gpu
