@@ -771,6 +771,12 @@ def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev,
            "how": "reference pke (unmodified sources) on the HIP backend of DCRTPoly; 1 warm-up + 2 timed passes over the rank's ciphertexts; "
                   "seconds_per_bootstrap = the same ciphertexts on ONE host thread / stream",
            "parity": "every output decrypted and compared with its message; byte comparison with the stock backend not run", "cpu_baseline": None}
+    # the leg's roofline = that of the way of running the batch whose rate is reported (kernel census of the lockstep pass:
+    # profiles/r04_bootstrap_wide_kernels.txt; model and itemisation: DESIGN.md 7.2)
+    if isinstance(wide, dict) and wide.get("bootstraps_per_s", 0.0) >= threaded_rate and "roofline" in wide:
+        res["roofline"] = dict(wide["roofline"], path="lockstep groups")
+    else:
+        res["roofline"] = dict(narrow_roof, path="one stream, narrow towers")
     for k in ("key_set_GB", "key_replication_s", "key_replication_GBps"):
         if k in r:
             res[k] = r[k]
@@ -832,6 +838,10 @@ def cc_evalmult_leg(with_cpu, libpath):
         mr = re.search(r"multbatch resident seconds per pass \S+ EvalMult per second ([0-9.eE+-]+)", p.stdout)
         md = re.search(r"resident products differing from the packed pass's: (\d+) of", p.stdout)
         run.resident = (float(mr.group(1)), int(md.group(1))) if p.returncode == 0 and mr and md else None
+        # PCIe bytes of the evaluation phase (the program resets the backend's counters after key generation and encryption; the phase
+        # also downloads the two dumped products and the one decrypted for the check)
+        mp = re.search(r"hal: available 1 deviceOps \d+ hostOps \d+ h2dBytes (\d+) d2hBytes (\d+)", p.stdout)
+        run.pcie = (int(mp.group(1)), int(mp.group(2))) if p.returncode == 0 and mp else None
         return (float(m.group(1)) if p.returncode == 0 and m else None), (p.stdout + p.stderr)[-400:]
 
     hipenv = {"FHE_HIP_LIB": libpath}
@@ -841,6 +851,11 @@ def cc_evalmult_leg(with_cpu, libpath):
     if rate is None:
         shutil.rmtree(tmp, ignore_errors=True)
         return {"error": txt}
+    pcie = None
+    if run.pcie is not None:  # (1 warm-up + 10 timed passes of 256 products)
+        pcie = {"h2d_MB_per_EvalMult": round(run.pcie[0] / (11 * 256) / 1e6, 4), "d2h_MB_per_EvalMult": round(run.pcie[1] / (11 * 256) / 1e6, 4),
+                "note": "evaluation phase of the threaded run (counters reset after key generation and encryption); includes the download of the "
+                        "three products the program dumps / decrypts"}
     # the same 256 ciphertexts in lockstep: 64 at a time as one ciphertext of 64-tower towers, cc->EvalMult once per group, one host thread
     # (the same OpenMP team as the threaded run: pke's key generation draws from thread-local PRNGs, equal teams give equal keys)
     wrate, wtxt = run(hip, os.path.join(tmp, "w256.bin"), 256, 10, 8, hipenv, group=64)
@@ -860,6 +875,7 @@ def cc_evalmult_leg(with_cpu, libpath):
     res = {"workload": "cc->EvalMult(ct, ct) with HYBRID relinearisation, N=2^16, 21 Q + 7 P limbs, dnum 3, 256 ciphertexts: over 8 host threads "
                        "(one tower per operation) and in lockstep (wide towers: 64 ciphertexts per cc->EvalMult call, one host thread)",
            "ops_per_s": round(rate, 1), "ops_per_s_over_host_threads": round(threaded, 1), "lockstep": lock,
+           "pcie": pcie,
            "how": "reference pke (unmodified sources) on the HIP backend of DCRTPoly; ops_per_s = the better of the two ways of running the batch",
            "parity": "not checked", "cpu_baseline": None}
     if with_cpu and os.path.exists(stock):
