@@ -87,7 +87,7 @@ def test_reference_core_lattice_unit_tests_on_emulator():
 
 
 # Host-mirror executions per member over the reference's 1729 unit tests on the MI355X: the committed upper bounds (this round's record,
-# profiles/r04_ref_unittests_members.txt).  The mirror is the reference's own class — what runs there proves nothing — so every member is
+# profiles/r04_ref_unittests_trace.txt: the halmember lines).  The mirror is the reference's own class — what runs there proves nothing — so every member is
 # bounded by name; a member that is not listed may not run on the mirror at all.
 HOST_ALLOW = {
     # KeySwitchBV (the BV key-switching technique, not the HYBRID path of SURVEY 8(a) a13): its digit decomposition and the accumulation
