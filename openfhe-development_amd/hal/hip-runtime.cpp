@@ -606,6 +606,7 @@ static void ReleaseCaches() {
     r.cachedBytes.fetch_sub(std::min<uint64_t>(freed, r.cachedBytes.load()), std::memory_order_relaxed);
 }
 void ReleaseAllCaches() { ReleaseCaches(); }
+uint64_t CachedBytes() { return rt().cachedBytes.load(std::memory_order_relaxed); }
 void SyncAllStreams() {
     Runtime& r = rt();
     for (uint32_t i = 1; i < r.nextStreamId; ++i)
@@ -1221,6 +1222,8 @@ extern "C" void fhe_hal_release_caches() {
     if (lbcrypto::hiprt::Available())
         lbcrypto::hiprt::ReleaseAllCaches();
 }
+// bytes of released buffers the backend holds for reuse right now (free lists, inboxes, orphans)
+extern "C" uint64_t fhe_hal_cached_bytes() { return lbcrypto::hiprt::Available() ? lbcrypto::hiprt::CachedBytes() : 0; }
 // the host waits until every stream of the backend has run dry (the end of a timed pass of a harness)
 extern "C" void fhe_hal_device_sync() {
     if (lbcrypto::hiprt::Available())

@@ -139,6 +139,7 @@ void MemoStore(const Buf& src, std::vector<uint64_t> key, const Buf& result);
 Buf Alloc(size_t words);
 // every cached released buffer and remembered result goes back to the device (what Alloc does under memory pressure)
 void ReleaseAllCaches();
+uint64_t CachedBytes();
 // the calling host thread waits for every stream of the backend
 void SyncAllStreams();
 Buf View(const Buf& parent, size_t offsetWords, size_t words);

@@ -27,6 +27,8 @@ extern "C" size_t fhe_hal_member_stats(char* buf, size_t cap) __attribute__((wea
 extern "C" size_t fhe_hal_launch_stats(char* buf, size_t cap, uint64_t* total) __attribute__((weak));
 extern "C" uint64_t fhe_hal_memo_hits() __attribute__((weak));
 extern "C" void fhe_hal_device_sync(void) __attribute__((weak));
+extern "C" uint64_t fhe_hal_cached_bytes(void) __attribute__((weak));
+extern "C" void fhe_hal_release_caches(void) __attribute__((weak));
 static std::map<std::string, uint64_t> launches_by_kernel(uint64_t* total) {
     std::map<std::string, uint64_t> m;
     *total = 0;
@@ -115,6 +117,34 @@ int main(int argc, char** argv) {
     const std::string mode = argv[3];
     const uint32_t logN    = argc > 4 ? std::atoi(argv[4]) : 11;
 
+#ifdef WITH_HIP
+    if (mode == "buffers") {
+        // the backend's cache of released device buffers (hip-runtime.cpp Alloc): a released buffer serves a later request of its own or of
+        // a smaller size class (best fit up to 4x, the allocation keeps its class), never a larger one; fhe_hal_release_caches() hands
+        // everything back to the device
+        const size_t M = (size_t)1 << 20;
+        auto a           = hiprt::Alloc(3 * M);
+        const auto* pa   = a->p;
+        const size_t cap = a->cap;
+        a.reset();
+        const uint64_t cached1 = fhe_hal_cached_bytes();
+        auto b = hiprt::Alloc(M);  // a smaller class: takes the released 3 Mi-word allocation
+        std::cout << "buffers smaller request reuses the released allocation: " << (b->p == pa && b->cap == cap) << " cached " << cached1
+                  << " -> " << fhe_hal_cached_bytes() << std::endl;
+        auto c = hiprt::Alloc(3 * M);  // the same class while b holds the allocation: a fresh one
+        std::cout << "buffers same class while in use gets a fresh allocation: " << (c->p != pa) << std::endl;
+        b.reset();
+        auto d = hiprt::Alloc(16 * M);  // a larger class: the released 3 Mi-word allocation cannot serve it
+        std::cout << "buffers larger request does not take a smaller allocation: " << (d->p != pa && d->cap >= 16 * M) << std::endl;
+        auto e = hiprt::Alloc(M / 8);  // more than 4x smaller than what is cached: a fresh small allocation
+        std::cout << "buffers much smaller request leaves the large allocation alone: " << (e->p != pa) << std::endl;
+        c.reset(), d.reset(), e.reset();
+        const uint64_t cached2 = fhe_hal_cached_bytes();
+        fhe_hal_release_caches();
+        std::cout << "buffers released caches: " << cached2 << " -> " << fhe_hal_cached_bytes() << std::endl;
+        return 0;
+    }
+#endif
     if (mode == "leveled") {
         CCParams<CryptoContextCKKSRNS> p;
         p.SetSecurityLevel(HEStd_NotSet);

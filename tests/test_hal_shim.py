@@ -336,3 +336,27 @@ def test_shim_batch_of_ciphertexts_in_lockstep_on_gpu(tmp_path):
 def test_shim_batch_of_ciphertexts_over_host_threads_on_gpu(tmp_path):
     ops = check(tmp_path, "multbatch", 14, HIP, {"product 0": [0.5, 0.0, -3.0]}, extra=(8, 32, 1), threads=8)
     assert ops > 100 and check.composite_calls >= 32
+
+
+# the backend's cache of released device buffers (hip-runtime.cpp Alloc / ReleaseCaches): best-fit reuse across size classes, never a
+# smaller allocation for a larger request, everything back to the device on fhe_hal_release_caches()
+def buffer_cache_check(tmp_path, device_lib):
+    ensure_built()
+    out = run(PROGS[1], str(tmp_path / "b.bin"), "buffers", 0, device_lib)
+    lines = [l for l in out.split("\n") if l.startswith("buffers ")]
+    assert len(lines) == 5, out[-800:]
+    for l in lines[:4]:
+        assert l.split(":")[1].split()[0] == "1", l
+    m = re.search(r"buffers smaller request reuses the released allocation: 1 cached (\d+) -> (\d+)", out)
+    assert m and int(m.group(1)) == 3 * (1 << 20) * 8 and int(m.group(2)) == 0, lines[0]
+    m = re.search(r"buffers released caches: (\d+) -> (\d+)", out)
+    assert m and int(m.group(1)) > 0 and int(m.group(2)) == 0, lines[4]
+
+
+def test_released_buffers_serve_smaller_requests_and_go_back_on_release_on_emulator(tmp_path):
+    buffer_cache_check(tmp_path, EMU)
+
+
+@pytest.mark.gpu
+def test_released_buffers_serve_smaller_requests_and_go_back_on_release_on_gpu(tmp_path):
+    buffer_cache_check(tmp_path, HIP)
