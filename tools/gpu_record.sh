@@ -2,8 +2,10 @@
 # Round record on the GPU box: GPU tests, the bench line exactly as the driver runs it, rocprofv3 kernel stats of the same
 # command (whole bench, headline NTT leg alone, EvalMult leg alone), the PMC traffic passes of the headline leg (FETCH_SIZE, WRITE_SIZE, one
 # pass each) and one pass of SQ counters (VALU issue) over the headline and the EvalMult leg.
-#   usage: gpurun --timeout 1500 -- tools/gpu_record.sh [tag] [notests]      (tag = r03 ...; then tools/collect_profiles.py tag)
-R=${1:-r03}
+#   usage: gpurun --timeout 1500 -- tools/gpu_record.sh [tag] [notests]      (tag = r05 ...; then tools/collect_profiles.py tag)
+# (round 4 ran the shorter tools/gpu_session_r04_k.sh: counter passes first, `collect_profiles.py tag --pmc-only` on the box, then the bench
+# line — which so quotes the counters of the very sources it runs)
+R=${1:-r05}
 mkdir -p gpurun_out
 if [ "$2" != "notests" ]; then
   echo "== gpu tests"; timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
