@@ -314,8 +314,8 @@ if len(sys.argv) > 1:
 r = bb.run_rank({logN}, {slots}, 3, 1, 1, 0, {prng!r}, warmup=0)  # (the narrow pass: first use of every composite, checked against the members)
 h = r.pop("handle")
 h.save_outputs()
-for tag, group in (("g3", 0), ("g2", 2)):
-    h.bootstrap_wide(group, 0)
+for tag, group, threads in (("g3", 0, 1), ("g2", 2, 1), ("g2t", 2, 2)):  # (g2t: the two groups on two host threads / streams, bench.py's way)
+    h.bootstrap_wide(group, 0, threads)
     print(tag, "differing", h.compare_saved())
     h.dump({out!r} + "." + tag + ".bin", 0, 3)
     print(tag, "errors", [h.check(i)[0] for i in range(3)])
@@ -325,12 +325,12 @@ h.close()
     env.pop("FHE_HAL_ALLOW_HOST", None)
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    assert "g3 differing 0" in p.stdout and "g2 differing 0" in p.stdout, p.stdout[-600:]
+    assert all(f"{t} differing 0" in p.stdout for t in ("g3", "g2", "g2t")), p.stdout[-600:]
     ref = subprocess.run([sys.executable, "-c", code, "stock"], env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=timeout)
     assert ref.returncode == 0, ref.stdout + ref.stderr
     stock = open(out + ".stock.bin", "rb").read()
     assert len(stock) > 10000
-    for tag in ("g3", "g2"):
+    for tag in ("g3", "g2", "g2t"):
         assert open(out + "." + tag + ".bin", "rb").read() == stock, f"wide bootstrap ({tag}) differs from the stock backend's"
 
 
