@@ -150,7 +150,8 @@ fhe_status fhe_mul_const(fhe_ctx* ctx, uint64_t* out, const uint64_t* a, const u
  * term, the inner loops of the Chebyshev evaluation of bootstrapping (ckksrns-fhe.cpp:691-692, :786) — as one launch per 16 terms:
  * every term is read once, the sum written once.  x: HOST array of nTerms DEVICE towers [batch][nLimbs][N] (each dense, allocated
  * on its own); consts: HOST array [nTerms][nLimbs], reduced modulo their limbs (their device table is cached by content).  Exact
- * modular arithmetic: the residues are the reference's whatever the order of the sum.  out may be one of the x[i]. */
+ * modular arithmetic: the residues are the reference's whatever the order of the sum.  out may be one of the x[i] (with more than 16 terms the
+ * terms that alias out are summed by the first launch, before out is overwritten; at most 16 terms may alias out then). */
 fhe_status fhe_lincomb(fhe_ctx* ctx, uint64_t* out, const uint64_t* const* x, const uint64_t* consts, uint32_t nTerms,
                        const uint32_t* limbIdx, uint32_t nLimbs, uint32_t batch, int accumulate, void* stream);
 /* The two elements of a ciphertext in ONE launch: element e of every operand is a tower allocated on its own (o_e = a_e op b_e,

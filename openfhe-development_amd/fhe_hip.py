@@ -168,11 +168,22 @@ class Lib:
         S("fhe_param_dcrt_chain", C.c_int, [u32, u32, u32, u64p, u64p])
         S("fhe_param_select_p", u32, [u32, u32, u64p, u32, u32, u64p, u64p])
         S("fhe_param_find_automorphism_index_2n_complex", u32, [C.c_int32, u32])
+        S("fhe_launch_stats", C.c_size_t, [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64)])
         S("fhe_time_ntt", C.c_int, [vp, vp, u32p, u32, u32, C.c_int, C.c_int, vp, C.POINTER(C.c_float)])
 
     def check(self, status):
         if status != 0:
             raise FheError(f"fhe status {status}: {self.L.fhe_last_error().decode()}")
+
+    def launch_count(self, kernel):
+        """launches of `kernel` (name without template arguments) since the library was loaded (fhe_launch_stats)"""
+        buf = C.create_string_buffer(1 << 16)
+        self.L.fhe_launch_stats(buf, len(buf), None)
+        for line in buf.value.decode().splitlines():
+            k, n = line.rsplit(" ", 1)
+            if k.split("::")[-1] == kernel:
+                return int(n)
+        return 0
 
     def version(self):
         return self.L.fhe_version().decode()

@@ -1,0 +1,71 @@
+#!/bin/bash
+# One parameterised record script for the round's GPU sessions (replaces the per-session tools/gpu_session_rNN_x.sh files).
+#   usage: gpurun --timeout T -- tools/gpu_session.sh <session> [args...]        output: gpurun_out/<session>_*.{json,log}
+# sessions:
+#   mall          tools/mallbench (Infinity-Cache go/no-go) + the headline leg at --batch 2,4,8,16,64,1024
+#   ntt [env...]  the headline leg alone (20 steps), with optional FHE_* environment assignments
+#   abl libs...   the headline leg with each tools/ablr5/libfhe_hip_<lib>.so (timing-only ablations)
+#   tests [k]     pytest -m gpu (optionally -k <k>)
+set -u
+S=${1:-help}; shift || true
+mkdir -p gpurun_out
+NTT_ONLY="--no-bootstrap --no-cc-evalmult --no-cpu-baseline --no-evalmult --no-bfv --no-hadamard --no-lt"
+case "$S" in
+  mall)
+    timeout 600 tools/mallbench | tee gpurun_out/mall_bench.json
+    for b in 2 4 8 16 64 1024; do
+      FHE_BENCH_NO_TORCH=1 timeout 600 python bench.py $NTT_ONLY --no-parity --batch $b --steps 20 --warmup 3 2>gpurun_out/mall_b$b.err | tail -1 | tee gpurun_out/mall_b$b.json | cut -c1-400
+    done ;;
+  ntt)
+    for kv in "$@"; do export "$kv"; done
+    FHE_BENCH_NO_TORCH=1 timeout 900 python bench.py $NTT_ONLY --steps 20 --warmup 3 2>gpurun_out/ntt.err | tail -1 | tee gpurun_out/ntt.json | cut -c1-600 ;;
+  chunks)  # the two-role chunk schedule: parity test, then the headline leg at FHE_NTT_CHUNKS = 1 (off), 2, 4, 8, 16, 32, default
+    timeout 900 python -m pytest tests/test_parity.py -m gpu -q -x -k "ntt" 2>&1 | tail -3
+    for n in 1 2 4 8 16 32 0; do
+      FHE_NTT_CHUNKS=$n FHE_BENCH_NO_TORCH=1 timeout 600 python bench.py $NTT_ONLY --no-parity --steps 10 --warmup 2 2>gpurun_out/chunks_$n.err | tail -1 > gpurun_out/chunks_$n.json
+      python - "$n" <<'PY'
+import json, sys
+d = json.loads(open(f"gpurun_out/chunks_{sys.argv[1]}.json").read())
+print("chunks", sys.argv[1], d["ms_per_step"], d["value"], d.get("parity"))
+PY
+    done ;;
+  t1)   # column-pass depth with today's kernels (FHE_NTT_T1=5 at logN 16: 5 + 11 stages), and the batch-64 reading with 200 steps
+    for t in 4 5; do
+      FHE_NTT_T1=$t FHE_NTT_CHUNKS=1 FHE_BENCH_NO_TORCH=1 timeout 600 python bench.py $NTT_ONLY --steps 10 --warmup 2 2>gpurun_out/t1_$t.err | tail -1 > gpurun_out/t1_$t.json
+      python - "t1_$t" <<'PY'
+import json, sys
+d = json.loads(open(f"gpurun_out/{sys.argv[1]}.json").read())
+print(sys.argv[1], d["ms_per_step"], d["value"], d["roofline"]["per_kernel_ms"], d.get("parity"))
+PY
+    done
+    FHE_NTT_CHUNKS=1 FHE_BENCH_NO_TORCH=1 timeout 600 python bench.py $NTT_ONLY --no-parity --batch 64 --steps 200 --warmup 20 2>gpurun_out/t1_b64.err | tail -1 > gpurun_out/t1_b64.json
+    python - <<'PY'
+import json
+d = json.loads(open("gpurun_out/t1_b64.json").read())
+print("b64", d["ms_per_step"], d["value"], d["roofline"]["per_kernel_ms"])
+PY
+    ;;
+  persist)  # persistent pass kernels (no prefetch): FHE_NTT_PERSIST = workgroups of the grid
+    for n in 0 1024 2048 768 1280; do
+      FHE_NTT_PERSIST=$n FHE_NTT_CHUNKS=1 FHE_BENCH_NO_TORCH=1 timeout 600 python bench.py $NTT_ONLY --steps 10 --warmup 2 2>gpurun_out/persist_$n.err | tail -1 > gpurun_out/persist_$n.json
+      python - "persist_$n" <<'PY'
+import json, sys
+d = json.loads(open(f"gpurun_out/{sys.argv[1]}.json").read())
+print(sys.argv[1], d["ms_per_step"], d["value"], d["roofline"]["per_kernel_ms"], str(d.get("parity"))[:80])
+PY
+    done ;;
+  abl)   # timing-only ablation builds of the library (tools/ablr5/*.so, built here with -DFHE_ABL_*; results are wrong: --no-parity)
+    for lib in "" "$@"; do
+      name=${lib:-default}
+      FHE_HIP_LIB=${lib:+$PWD/tools/ablr5/libfhe_hip_$lib.so} FHE_BENCH_NO_TORCH=1 timeout 600 python bench.py $NTT_ONLY --no-parity --steps 10 --warmup 2 2>gpurun_out/abl_$name.err | tail -1 > gpurun_out/abl_$name.json
+      python - "$name" <<'PY'
+import json, sys
+d = json.loads(open(f"gpurun_out/abl_{sys.argv[1]}.json").read())
+print(sys.argv[1], d["ms_per_step"], d["roofline"]["per_kernel_ms"])
+PY
+    done ;;
+  tests)
+    if [ $# -ge 1 ]; then timeout 1500 python -m pytest tests -m gpu -q -x -k "$1" 2>&1 | tail -15 | tee gpurun_out/tests.log
+    else timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -15 | tee gpurun_out/tests.log; fi ;;
+  *) echo "sessions: mall | ntt | tests"; exit 2 ;;
+esac
