@@ -700,17 +700,6 @@ static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse
         // compile-time pass plans (ntt_static.h): in-place pinned-register butterflies, immediate-offset LDS exchange
         const int mode = static_mode(c, pp, inverse);
         bool launched  = false;
-        const uint32_t persist = env_u32("FHE_NTT_PERSIST", 0);  // round-5 experiment: workgroups of the persistent form's grid (0: off)
-        if (persist && grid > persist && c->logN == 16u) {
-#define FHE_PERSIST_CASE(LA, INV, TT, MODE) \
-    if (!launched && pp.layoutA == LA && inverse == INV && pp.T == TT && mode == MODE) { \
-        FHE_LAUNCH_BARRIER((ntt_static_persist_kernel<LA, INV, TT, MODE>), persist, stream, a, grid); \
-        launched = true; \
-    }
-            FHE_PERSIST_CASE(true, false, 4, 1) FHE_PERSIST_CASE(true, true, 4, 1)
-            FHE_PERSIST_CASE(false, false, 12, 9) FHE_PERSIST_CASE(false, true, 12, 0)
-#undef FHE_PERSIST_CASE
-        }
 #define FHE_STATIC_CASE(LA, INV, TT, MODE) \
     if (!launched && pp.layoutA == LA && inverse == INV && pp.T == TT && mode == MODE) { \
         FHE_LAUNCH_BARRIER((ntt_static_kernel<LA, INV, TT, MODE>), grid, stream, a); \
@@ -754,11 +743,7 @@ static uint32_t env_u32(const char* name, uint32_t dflt) {
 // stages of the strided column pass of a two-pass ring: as few as possible (>= 4), so that the column pass reads rows of
 // 2^(12-T1) consecutive words and, at T1 = 4, is a pure register radix-16 step; the other splits were measured slower
 // (profiles/r01_sweeps.md) and their kernel instances are gone
-static uint32_t ntt_t1(uint32_t logN) {
-    const uint32_t t1 = std::max(4u, logN - (uint32_t)kTileLog);
-    const uint32_t forced = env_u32("FHE_NTT_T1", 0);  // (measurement sweeps only: 5 at logN = 16 runs the 11-stage row pass)
-    return (logN == 16u && forced == 5u) ? forced : t1;
-}
+static uint32_t ntt_t1(uint32_t logN) { return std::max(4u, logN - (uint32_t)kTileLog); }
 
 // inStride != 0: xin is a [batch][inStride][N] view whose rows inFirst.. are transformed into the dense xout
 // outStride != 0: xout is a [batch][outStride][N] view as well (rows outFirst..)
@@ -772,52 +757,6 @@ static bool ntt_epilogue_supported(const fhe_ctx* c) {
     // row pass (logN = 16 after 4 column stages, 17 after 5, ...), shorter ones only after a 4-stage column pass
     const uint32_t t1 = ntt_t1(c->logN), t2 = c->logN - t1;
     return t2 == 12u || (t1 == 4u && t2 >= 9u && t2 <= 12u);
-}
-// ---- the chunked two-role schedule of a dense two-pass transform (ntt_dual_kernel, ntt_static.h) ----
-// How many chunks a batch is cut into (0 / 1: the plain two launches).  A chunk must fill the chip several times over in either role
-// (>= kDualMinTiles tiles), and the un-overlapped head and tail (first pass of chunk 0, second pass of the last chunk) shrink with
-// the chunk count: 8 chunks when the batch allows it.  FHE_NTT_CHUNKS overrides (measurement sweeps; 1 = off).
-constexpr uint32_t kDualMinTiles = 8192;
-static bool ntt_dual_instance(uint32_t T1, uint32_t T2) {
-    return (T1 == 4u && T2 >= 9u && T2 <= 12u) || (T1 == 5u && T2 == 12u);
-}
-static uint32_t ntt_dual_chunks(const fhe_ctx* c, uint32_t nLimbs, uint32_t batch, uint32_t T1, uint32_t T2) {
-    if (!ntt_dual_instance(T1, T2))
-        return 0;
-    const uint32_t forced = env_u32("FHE_NTT_CHUNKS", 0);
-    const uint64_t tilesPerTower = (uint64_t)nLimbs << (c->logN - (uint32_t)kTileLog);
-    if ((nLimbs << (c->logN - (uint32_t)kTileLog)) % 8u)
-        return 0;  // (a role's sub-grid is addressed in groups of 8 blocks)
-    uint32_t chunks = forced ? forced : 8u;
-    if (!forced)
-        while (chunks > 1 && (uint64_t)(batch / chunks) * tilesPerTower < kDualMinTiles)
-            --chunks;
-    return std::min(chunks, batch);
-}
-// one grid: the column pass (plan pa) of colBatch towers colIn -> colOut and the row pass (plan pb) of rowBatch towers rowIn -> rowOut;
-// forward: the row pass ends the transform (canonOut applies to it), inverse: the column pass does
-static fhe_status launch_dual(const fhe_ctx* c, const PassPlan& pa, const PassPlan& pb, bool inverse, const uint64_t* colIn, uint64_t* colOut,
-                              uint32_t colBatch, const uint64_t* rowIn, uint64_t* rowOut, uint32_t rowBatch, const LimbSel& sel,
-                              uint32_t nLimbs, bool canonOut, void* stream) {
-    NttPassArgs ca, ra;
-    const uint32_t gc = fill_pass_args(c, pa, inverse, colIn, colOut, sel, nLimbs, colBatch, inverse ? canonOut : false, 0, 0, 0, 0, ca);
-    const uint32_t gr = fill_pass_args(c, pb, inverse, rowIn, rowOut, sel, nLimbs, rowBatch, inverse ? false : canonOut, 0, 0, 0, 0, ra);
-    const uint32_t groups = (std::max(gc, gr) + 7u) / 8u, grid = groups * 16u;
-    const int mode2 = static_mode(c, pb, inverse);
-    bool launched   = false;
-#define FHE_DUAL_CASE(INV, TA, TB, MODE) \
-    if (!launched && inverse == INV && pa.T == TA && pb.T == TB && mode2 == MODE) { \
-        FHE_LAUNCH_BARRIER((ntt_dual_kernel<INV, TA, TB, MODE>), grid, stream, ca, ra); \
-        launched = true; \
-    }
-    FHE_DUAL_CASE(false, 4, 12, 9) FHE_DUAL_CASE(true, 4, 12, 0) FHE_DUAL_CASE(false, 5, 12, 9) FHE_DUAL_CASE(true, 5, 12, 0)
-    FHE_DUAL_CASE(false, 4, 11, 9) FHE_DUAL_CASE(true, 4, 11, 0) FHE_DUAL_CASE(false, 4, 10, 9) FHE_DUAL_CASE(true, 4, 10, 0)
-    FHE_DUAL_CASE(false, 4, 9, 9) FHE_DUAL_CASE(true, 4, 9, 0)
-#undef FHE_DUAL_CASE
-    if (!launched)
-        return fail(FHE_ERR_UNSUPPORTED, "ntt: no two-role kernel instance for this ring");
-    LAUNCH_CHECK();
-    return FHE_OK;
 }
 // a two-pass forward transform whose column pass can carry the load prologue (NttPassArgs::proMode)
 static bool ntt_prologue_supported(const fhe_ctx* c) {
@@ -862,41 +801,12 @@ static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_
     }
     const PassPlan& p1 = inverse ? pb : pa;
     const PassPlan& p2 = inverse ? pa : pb;
-    // Round 5: a large dense batch is cut into chunks of towers and software-pipelined — launch k runs the FIRST pass of chunk k and
-    // the SECOND pass of chunk k-1 in one grid (ntt_dual_kernel: column and row workgroups side by side on every CU, the HBM-bound
-    // column pass under the issue-bound row pass), with the first pass of chunk 0 and the second pass of the last chunk on their own.
-    // (Rejected before, on the record: both passes fused with the tower kept in an XCD's L2 — no retention, profiles/r02_sweeps.md
-    // session 3; two streams — the queues split the four workgroup slots of a CU instead of adding to them, profiles/r05_sweeps.md;
-    // per-chunk launches sized to the Infinity Cache — its bandwidth is within 15 % of HBM's, profiles/r05_mallbench.json.)
-    if (!epi && !proSrcLimb && !inDelta && !inStride && !outStride) {
-        const uint32_t chunks = ntt_dual_chunks(c, nLimbs, batch, T1, T2);
-        if (chunks >= 2) {
-            const uint32_t per = (batch + chunks - 1) / chunks;
-            const size_t towerWords = (size_t)nLimbs << logN;
-            uint32_t prevFirst = 0, prevCount = 0;
-            for (uint32_t first = 0; first < batch || prevCount; first += per) {
-                const uint32_t count = first < batch ? std::min(per, batch - first) : 0u;
-                // the first pass of towers [first, first + count) and the second pass of [prevFirst, prevFirst + prevCount)
-                const uint64_t* in1 = xin + (size_t)first * towerWords;
-                uint64_t* out1      = xout + (size_t)first * towerWords;
-                uint64_t* buf2      = xout + (size_t)prevFirst * towerWords;
-                if (count && prevCount) {
-                    if (fhe_status s = launch_dual(c, pa, pb, inverse, inverse ? buf2 : in1, inverse ? buf2 : out1, inverse ? prevCount : count,
-                                                   inverse ? in1 : buf2, inverse ? out1 : buf2, inverse ? count : prevCount, sel, nLimbs,
-                                                   canonOut, stream))
-                        return s;
-                }
-                else if (count) {
-                    if (fhe_status s = launch_pass(c, p1, inverse, in1, out1, sel, nLimbs, count, false, stream))
-                        return s;
-                }
-                else if (fhe_status s = launch_pass(c, p2, inverse, buf2, buf2, sel, nLimbs, prevCount, canonOut, stream))
-                    return s;
-                prevFirst = first, prevCount = count;
-            }
-            return FHE_OK;
-        }
-    }
+    // Both passes of the whole batch back to back on the caller's stream.  What else was built and measured, bit-exact and slower or
+    // equal, and removed again (profiles/r02_sweeps.md session 3, profiles/r05_sweeps.md): both passes in one launch with the tower
+    // kept in an XCD's L2 (no retention); launches per chunk sized to the Infinity Cache (its bandwidth is within 15 % of HBM's);
+    // the column pass of one chunk and the row pass of another on two streams (the queues split a CU's four workgroup slots: the
+    // pair takes the sum of its parts) or as one grid of alternating roles (6 % slower); persistent pass kernels (11 % slower: a
+    // fresh workgroup's loads overlap the drain of its predecessor's stores); 5 + 11 stages instead of 4 + 12 (1 % slower).
     if (fhe_status s = launch_pass(c, p1, inverse, xin, xout, sel, nLimbs, batch, false, stream, inStride, inFirst, outStride, outFirst,
                                    nullptr, proSrcLimb, inDelta))
         return s;

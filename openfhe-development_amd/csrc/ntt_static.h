@@ -458,11 +458,7 @@ FHE_DEV void ntt_static_core(const NttPassArgs& a, uint32_t bid, uint64_t* lds, 
     using P = SPlan<LA, INV, T>;
     static_assert(!(RAWIN || RAWOUT) || !LA, "register hand-over exists for row passes only");
     static_assert(!PRO || (LA && !INV && !RAWIN), "the load prologue exists for forward column passes only");
-    uint32_t t = FHE_TID;
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(t));  // (persistent form: keeps the lane-dependent addresses of a round inside the round — hoisted out
-                                 // of the loop they stay live through the whole body and cost the fourth wave per SIMD)
-#endif
+    const uint32_t t    = FHE_TID;
     const uint32_t logN = a.logN;
     const uint32_t N    = 1u << logN;
     const uint32_t tilesPerRow = N >> kTileLog;
@@ -707,50 +703,6 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_static_kernel(const NttPassArgs 
     ntt_static_body<LA, INV, T, MODE, EPI, PRO>(a, FHE_BID, lds);
 }
 
-
-// ---- persistent form (round 5 experiment): one workgroup per resident slot walks the tiles bid, bid + grid, ... ---------------------
-// (no prefetch, same registers: what a loop saves is the drain of a tile's stores and the dispatch of the next workgroup)
-template <bool LA, bool INV, int T, int MODE>
-FHE_GLOBAL void FHE_LAUNCH_BOUNDS2(kThreads, 4) ntt_static_persist_kernel(const NttPassArgs a, uint32_t nTiles) {
-    using P = SPlan<LA, INV, T>;
-    constexpr bool needsLds = P::nst > 1 || P::stageFirst || P::stageLast;
-    FHE_SHARED_U64(lds, needsLds ? kLdsPadWords + kSharedTwWords : 1);
-    for (uint32_t bid = FHE_BID; bid < nTiles; bid += FHE_NBLK) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        // the arguments are re-read (scalar loads) in every round: hoisted out of the loop they would occupy ~90 SGPRs for its whole
-        // length and spill
-        uint64_t ap = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();  // `a` is the first explicit argument: offset 0
-        asm volatile("" : "+s"(ap));
-        const NttPassArgs& ar = *(const NttPassArgs*)(const __attribute__((address_space(4))) NttPassArgs*)ap;
-        ntt_static_body<LA, INV, T, MODE>(ar, bid, lds);
-#else
-        ntt_static_body<LA, INV, T, MODE>(a, bid, lds);
-#endif
-        if constexpr (needsLds)
-            FHE_SSYNC();  // the next tile's staging / shared twiddles overwrite what this tile's last reads used
-    }
-}
-
-// ---- two passes of DIFFERENT parts of a batch in one grid (round 5) --------------------------------------------------------------
-// The column pass is HBM-bound with the integer pipe mostly idle (2.3 ms of issue in 5.5 ms), the row pass needs 5.7 ms of issue
-// and LDS time for the same bytes; run one after the other over the whole batch they take 13.7 ms per direction (profiles/
-// r05_sweeps.md: ablations without loads / stores).  Here workgroups alternate, eight at a time (one per XCD, so that a role's
-// sub-grid keeps the XCD of its block id: block b of a role's grid runs on XCD b % 8 as in its own launch), between the column pass
-// of one chunk of the batch and the row pass of another chunk: both kinds are resident on every CU and the column workgroups' loads
-// and stores fill the memory pipeline while the row workgroups compute.  The chunks are disjoint, so there is no ordering between
-// the roles inside the launch; ntt_run (fhe_hip.cpp) software-pipelines the chunks over consecutive launches.
-template <bool INV, int T1, int T2, int MODE2>
-FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_dual_kernel(const NttPassArgs col, const NttPassArgs row) {
-    FHE_SHARED_U64(lds, kLdsPadWords + kSharedTwWords);
-    const uint32_t bid = FHE_BID, sub = ((bid >> 4) << 3) | (bid & 7u);
-    const uint32_t tilesLog = col.logN - (uint32_t)kTileLog;
-    if ((bid >> 3) & 1u) {
-        if (sub < (col.rows << tilesLog))
-            ntt_static_body<true, INV, T1, 1>(col, sub, lds);
-    }
-    else if (sub < (row.rows << tilesLog))
-        ntt_static_body<false, INV, T2, MODE2>(row, sub, lds);
-}
 
 // ---- fused negacyclic polynomial product  c = a * b  (a, b, c in COEFFICIENT form; SURVEY.md 8(d) "fused fwd o mul o inv") -----
 // Per limb the reference computes INTT(NTT(a) o NTT(b)) with three transforms and a Hadamard product, each a round trip

@@ -64,51 +64,6 @@ def test_ntt_forward_inverse(backend, oracle):
         ctx.close()
 
 
-@pytest.mark.parametrize("logN,L,B,chunks", [(13, 4, 5, 3), (14, 2, 4, 2), (16, 1, 3, 2), (17, 1, 2, 2), (13, 8, 9, 8)])
-def test_ntt_chunked_two_role_schedule(backend, oracle, logN, L, B, chunks, monkeypatch):
-    """Round 5: a large dense batch runs as a software pipeline of chunks — one grid holds the column pass of chunk k and the row pass
-    of chunk k-1 (ntt_dual_kernel; fhe_hip.cpp ntt_run).  Forced here on small batches (FHE_NTT_CHUNKS; ragged last chunk, 2..8 chunks,
-    every two-pass ring family: T1 = 4 with 9..12 row stages, T1 = 5), forward and inverse, in place and out of place, against the
-    oracle's transformnat-impl.h:303-374 / 512-625 restatement word for word — and equal to the plain two-launch schedule."""
-    o = oracle
-    if is_emu(backend) and logN == 17:
-        B = 2
-    rng = np.random.default_rng(1000 + logN)
-    q, psi = params(o, logN, L)
-    N = 1 << logN
-    ctx = fh.Context(backend, logN, q, psi)
-    octx = o.orc_ctx_create(N, L, q, psi)
-    x = libs.rand_tower(rng, q, N, B)
-    x[0, :, 0] = 0
-    x[B - 1, :, N - 1] = q - np.uint64(1)
-    want = x.copy()
-    o.orc_ntt_fwd_tower(octx, want, None, L, B, 0)
-    monkeypatch.setenv("FHE_NTT_CHUNKS", "1")
-    plain = ctx.tower(x, fmt=fh.COEFFICIENT).SwitchFormat().to_host()
-    monkeypatch.setenv("FHE_NTT_CHUNKS", str(chunks))
-    launches0 = backend.launch_count("ntt_dual_kernel") if hasattr(backend, "launch_count") else None
-    t = ctx.tower(x, fmt=fh.COEFFICIENT)
-    t.SwitchFormat()
-    got = t.to_host()
-    assert np.array_equal(got, want), f"chunked forward NTT mismatch logN={logN}"
-    assert np.array_equal(got, plain)
-    t.SwitchFormat()
-    assert np.array_equal(t.to_host(), x), f"chunked round trip mismatch logN={logN}"
-    # inverse from an independent EVALUATION input, out of place
-    y = libs.rand_tower(rng, q, N, B)
-    wanti = y.copy()
-    o.orc_ntt_inv_tower(octx, wanti, None, L, B, 0)
-    ty = ctx.tower(y, fmt=fh.EVALUATION)
-    out = ctx.empty(B, L)
-    backend.check(backend.L.fhe_ntt_inv_oop(ctx.h, ty.ptr, out.ptr, None, L, B, None))
-    assert np.array_equal(out.to_host(), wanti), f"chunked inverse NTT mismatch logN={logN}"
-    assert np.array_equal(ty.to_host(), y), "out-of-place transform must not touch its input"
-    if launches0 is not None:
-        assert backend.launch_count("ntt_dual_kernel") > launches0, "the two-role grid did not run"
-    o.orc_ctx_destroy(octx)
-    ctx.close()
-
-
 def test_ntt_limb_selection_and_oop(backend, oracle):
     """towers at a lower level / arbitrary limb subsets share one context through limbIdx"""
     o = oracle

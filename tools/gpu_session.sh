@@ -1,6 +1,7 @@
 #!/bin/bash
 # One parameterised record script for the round's GPU sessions (replaces the per-session tools/gpu_session_rNN_x.sh files).
 #   usage: gpurun --timeout T -- tools/gpu_session.sh <session> [args...]        output: gpurun_out/<session>_*.{json,log}
+# (the sessions of the rejected round-5 NTT experiments — chunks, persist, t1 — are in commit 3b1f4e6 together with their kernels)
 # sessions:
 #   mall          tools/mallbench (Infinity-Cache go/no-go) + the headline leg at --batch 2,4,8,16,64,1024
 #   ntt [env...]  the headline leg alone (20 steps), with optional FHE_* environment assignments
@@ -19,41 +20,6 @@ case "$S" in
   ntt)
     for kv in "$@"; do export "$kv"; done
     FHE_BENCH_NO_TORCH=1 timeout 900 python bench.py $NTT_ONLY --steps 20 --warmup 3 2>gpurun_out/ntt.err | tail -1 | tee gpurun_out/ntt.json | cut -c1-600 ;;
-  chunks)  # the two-role chunk schedule: parity test, then the headline leg at FHE_NTT_CHUNKS = 1 (off), 2, 4, 8, 16, 32, default
-    timeout 900 python -m pytest tests/test_parity.py -m gpu -q -x -k "ntt" 2>&1 | tail -3
-    for n in 1 2 4 8 16 32 0; do
-      FHE_NTT_CHUNKS=$n FHE_BENCH_NO_TORCH=1 timeout 600 python bench.py $NTT_ONLY --no-parity --steps 10 --warmup 2 2>gpurun_out/chunks_$n.err | tail -1 > gpurun_out/chunks_$n.json
-      python - "$n" <<'PY'
-import json, sys
-d = json.loads(open(f"gpurun_out/chunks_{sys.argv[1]}.json").read())
-print("chunks", sys.argv[1], d["ms_per_step"], d["value"], d.get("parity"))
-PY
-    done ;;
-  t1)   # column-pass depth with today's kernels (FHE_NTT_T1=5 at logN 16: 5 + 11 stages), and the batch-64 reading with 200 steps
-    for t in 4 5; do
-      FHE_NTT_T1=$t FHE_NTT_CHUNKS=1 FHE_BENCH_NO_TORCH=1 timeout 600 python bench.py $NTT_ONLY --steps 10 --warmup 2 2>gpurun_out/t1_$t.err | tail -1 > gpurun_out/t1_$t.json
-      python - "t1_$t" <<'PY'
-import json, sys
-d = json.loads(open(f"gpurun_out/{sys.argv[1]}.json").read())
-print(sys.argv[1], d["ms_per_step"], d["value"], d["roofline"]["per_kernel_ms"], d.get("parity"))
-PY
-    done
-    FHE_NTT_CHUNKS=1 FHE_BENCH_NO_TORCH=1 timeout 600 python bench.py $NTT_ONLY --no-parity --batch 64 --steps 200 --warmup 20 2>gpurun_out/t1_b64.err | tail -1 > gpurun_out/t1_b64.json
-    python - <<'PY'
-import json
-d = json.loads(open("gpurun_out/t1_b64.json").read())
-print("b64", d["ms_per_step"], d["value"], d["roofline"]["per_kernel_ms"])
-PY
-    ;;
-  persist)  # persistent pass kernels (no prefetch): FHE_NTT_PERSIST = workgroups of the grid
-    for n in 0 1024 2048 768 1280; do
-      FHE_NTT_PERSIST=$n FHE_NTT_CHUNKS=1 FHE_BENCH_NO_TORCH=1 timeout 600 python bench.py $NTT_ONLY --steps 10 --warmup 2 2>gpurun_out/persist_$n.err | tail -1 > gpurun_out/persist_$n.json
-      python - "persist_$n" <<'PY'
-import json, sys
-d = json.loads(open(f"gpurun_out/{sys.argv[1]}.json").read())
-print(sys.argv[1], d["ms_per_step"], d["value"], d["roofline"]["per_kernel_ms"], str(d.get("parity"))[:80])
-PY
-    done ;;
   abl)   # timing-only ablation builds of the library (tools/ablr5/*.so, built here with -DFHE_ABL_*; results are wrong: --no-parity)
     for lib in "" "$@"; do
       name=${lib:-default}
