@@ -69,6 +69,7 @@ struct StreamState {
 struct Runtime {
     Api api{};
     size_t (*launch_stats)(char*, size_t, uint64_t*) = nullptr;  // (optional: the library's launch counters)
+    const char* (*version)() = nullptr;                           // (optional: names the test-only lane emulator build)
     bool live = false;
     std::string why;
     int device       = 0;
@@ -143,6 +144,7 @@ Runtime* build() {
     else {
         Api& a = r->api;
         r->launch_stats = reinterpret_cast<size_t (*)(char*, size_t, uint64_t*)>(dlsym(h, "fhe_launch_stats"));
+        r->version      = reinterpret_cast<const char* (*)()>(dlsym(h, "fhe_version"));
 #define FHE_SYM(field, name) sym(h, #name, &a.field)
         bool ok = FHE_SYM(last_error, fhe_last_error) && FHE_SYM(device_count, fhe_device_count) && FHE_SYM(ctx_create, fhe_ctx_create) &&
                   FHE_SYM(ctx_destroy, fhe_ctx_destroy) && FHE_SYM(conv_destroy, fhe_conv_destroy) && FHE_SYM(sr_plan_destroy, fhe_sr_plan_destroy) &&
@@ -231,6 +233,10 @@ size_t bucket_of(size_t words) {
     size_t b = 1024;
     while (b < words)
         b <<= 1;
+    if (b > (1u << 27)) {  // above 1 GiB: sixteenths of the power of two (a 34.9 GiB workspace takes 36 GiB, not 48: round 5)
+        const size_t g = b >> 4;
+        return (words + g - 1) / g * g;
+    }
     if (b > (1u << 20) && words <= b - (b >> 2))  // above 8 MiB: 3/4 steps, so that odd tower heights do not waste 2x
         b -= b >> 2;
     return b;
@@ -329,10 +335,19 @@ void order_after(ThreadState* ts, const DevBuf::Use& u) {
     StreamState& other = r.streams[u.stream];
     uint64_t mark      = other.enqueued.load(std::memory_order_acquire);
     const auto t0      = std::chrono::steady_clock::now();
+    // A slow producer is not a race: the lane emulator runs launches synchronously under one mutex, an Op may sit in Alloc while the
+    // caches go back to the device, a table upload blocks.  The limit is generous (FHE_HAL_ORDER_TIMEOUT_S, default 120 s on a device,
+    // 1800 s on the emulator) and only says "somebody stamped a use and never enqueued it".
+    static const int64_t limitS = [] {
+        if (const char* e = std::getenv("FHE_HAL_ORDER_TIMEOUT_S"))
+            return (int64_t)std::max(1, std::atoi(e));
+        const char* v = rt().version ? rt().version() : nullptr;
+        return (int64_t)((v && std::strstr(v, "emulator")) ? 1800 : 120);
+    }();
     for (uint32_t spin = 0; mark < u.seq; ++spin) {  // (the other thread is still inside the operation that made this use: it is about to finish)
-        if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
-            OPENFHE_THROW("HIP backend: a use of a tower stamped by another host thread was not enqueued within 30 s (host threads racing "
-                          "on the same DCRTPoly, or a thread blocked inside a device operation)");
+        if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(limitS))
+            OPENFHE_THROW("HIP backend: a use of a tower stamped by another host thread was not enqueued within " + std::to_string(limitS) +
+                          " s (host threads racing on the same DCRTPoly, or a thread blocked inside a device operation)");
         sched_yield();
         mark = other.enqueued.load(std::memory_order_acquire);
     }
@@ -426,8 +441,15 @@ uint64_t* Op::W(const Buf& b, bool operand) {
         root->writer = DevBuf::Use{ts->id, m_seq};
         history.swap(root->memo);  // the words change: what was derived from them is history
     }
-    for (const auto& u : before)
-        order_after(ts, u);
+    try {
+        for (const auto& u : before)
+            order_after(ts, u);
+    }
+    catch (...) {  // (the buffer keeps what it knew about its pending uses: whoever touches it next still orders behind them)
+        std::lock_guard<std::mutex> lk(root->mu);
+        root->readers.insert(root->readers.end(), before.begin(), before.end());
+        throw;
+    }
     if (operand)
         count_operand_bytes((uint64_t)b->words * 8, true);
     return b->p;
@@ -555,11 +577,17 @@ DevBuf::~DevBuf() {
 // Everything the backend holds beyond live towers goes back to the device: the remembered results, every live thread's free lists (under
 // its stream's mutex, after synchronising that stream), the orphans and what exited threads left parked.  Alloc calls it under memory
 // pressure; fhe_hal_release_caches() lets a process that is done with a batch hand the device to the next one (bench.py between legs).
-static void ReleaseCaches() {
+static void ReleaseCaches(bool dropMemos = true) {
     Runtime& r = rt();
-    DropMemos();
+    if (dropMemos)
+        DropMemos();
     uint64_t freed = 0;
-    for (uint32_t i = 1; i < r.nextStreamId; ++i) {  // every live thread's cache (this thread's included)
+    uint32_t nStreams;
+    {
+        std::lock_guard<std::mutex> lk(r.streamMutex);
+        nStreams = r.nextStreamId;
+    }
+    for (uint32_t i = 1; i < nStreams; ++i) {  // every live thread's cache (this thread's included)
         StreamState& st = r.streams[i];
         std::vector<uint64_t*> taken;
         {
@@ -587,7 +615,7 @@ static void ReleaseCaches() {
             kv.second.clear();
         }
     }
-    for (uint32_t i = 1; i < r.nextStreamId; ++i) {  // what other threads sent back to a stream and its thread has not taken yet (or never will: it exited)
+    for (uint32_t i = 1; i < nStreams; ++i) {  // what other threads sent back to a stream and its thread has not taken yet (or never will: it exited)
         StreamState& st = r.streams[i];
         if (st.inboxCount.load() == 0)
             continue;
@@ -652,16 +680,24 @@ Buf Alloc(size_t words) {
     void* d      = nullptr;
     // (the allocation goes to the device: if it would eat into the reserve kept for kernel launches while buffers sit in caches, the
     // caches go back first — a launch that fails for want of scratch memory cannot be retried from here)
+    // Taking the caches back is a global stall (every stream is synchronised, every cached buffer freed): it happens only when the
+    // caches hold enough to matter for THIS request (at least its size, or 1 GiB) — a device that is legitimately near-full with a
+    // few KB cached would otherwise pay it on every allocation — and the remembered results go only if the buffers were not enough.
     bool pressed = false;
-    if (r.cachedBytes.load(std::memory_order_relaxed) > 0) {
+    const uint64_t cached = r.cachedBytes.load(std::memory_order_relaxed);
+    if (cached >= std::min<uint64_t>((uint64_t)bk * 8, 1ull << 30)) {
         size_t freeB = 0, totalB = 0;
         if (r.api.mem_info(r.anyCtx, &freeB, &totalB) == FHE_OK && freeB < (uint64_t)bk * 8 + r.reserveBytes)
             pressed = true;
     }
     fhe_status s = pressed ? FHE_ERR_ALLOC : r.api.malloc_(r.anyCtx, bk * 8, &d);
-    if (s != FHE_OK) {  // memory pressure: give the remembered results, every thread's and the shared cached buffers back to the device and retry once
-        ReleaseCaches();
+    if (s != FHE_OK) {  // memory pressure: every thread's and the shared cached buffers go back to the device, then the remembered results
+        ReleaseCaches(false);
         s = r.api.malloc_(r.anyCtx, bk * 8, &d);
+        if (s != FHE_OK) {
+            ReleaseCaches(true);
+            s = r.api.malloc_(r.anyCtx, bk * 8, &d);
+        }
     }
     Check(s, "HIP backend: device allocation");
     b->p   = static_cast<uint64_t*>(d);

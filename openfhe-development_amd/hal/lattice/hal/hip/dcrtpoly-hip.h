@@ -830,7 +830,7 @@ public:
         if (OnDeviceWide(&r)) {
             const bool toCoeff = m_h.GetFormat() == Format::EVALUATION;
             hiprt::Op op;
-            if (m_d.use_count() > 1) {  // words shared with a copy: transform into a buffer of its own
+            if (SharedWords()) {  // words shared with a copy (or a window of a wide tower): transform into a buffer of its own
                 auto d = hiprt::Alloc(Words());
                 auto f = toCoeff ? hiprt::api().ntt_inv_oop : hiprt::api().ntt_fwd_oop;
                 hiprt::Check(f(r.ctx, op.R(m_d), op.W(d), r.idx[0].data(), NumLimbs(), m_k, op.s), "SwitchFormat");
@@ -858,6 +858,7 @@ public:
     template <class Archive>
     void load(Archive& ar, std::uint32_t const version) {
         m_d.reset();
+        m_lazy.reset();
         m_hostValid = true;
         m_zero      = false;
         m_h.load(ar, version);
@@ -1215,6 +1216,7 @@ public:
         auto P      = m_h.GetParams();
         m_h         = HostType(P, m_h.GetFormat(), false);  // (the device words are the tower now: no stale host copy stays behind)
         m_d         = std::move(d);
+        m_lazy.reset();
         m_hostValid = false;
         m_zero      = false;
     }
@@ -1348,10 +1350,16 @@ private:
         return m_h.GetParams()->GetParams()[i]->GetModulus().template ConvertToInt<uint64_t>();
     }
     // this tower as the terms of a sum: its pending terms, or its device words once
+    // (the description is read through a local reference taken under the lock: another host thread holding the same const tower may
+    // settle the sum — m_lazy.reset() — at any time)
+    std::shared_ptr<const LazySum> PendingSum() const {
+        std::lock_guard<std::mutex> lk(m_lock.m);
+        return m_lazy;
+    }
     bool TermsOf(std::vector<LazyTerm>* out, bool negate) const {
         const uint32_t L = NumLimbs();
-        if (m_lazy) {
-            for (const auto& t : m_lazy->terms) {
+        if (const auto sum = PendingSum()) {
+            for (const auto& t : sum->terms) {
                 LazyTerm c{t.words, std::vector<uint64_t>(L)};
                 for (uint32_t i = 0; i < L; ++i)
                     c.k[i] = (negate && t.k[i]) ? LimbModulus(i) - t.k[i] : t.k[i];
@@ -1385,7 +1393,7 @@ private:
     bool ScaleLazily(const std::vector<NativeInteger>& k) {
         const uint32_t L = NumLimbs();
         const auto& P    = m_h.GetParams();
-        if (!LazySums() || m_k == 1 || k.size() < L || !P || L != P->GetParams().size() || (!m_lazy && !(m_d && !m_hostValid)))
+        if (!LazySums() || m_k == 1 || k.size() < L || !P || L != P->GetParams().size() || (!PendingSum() && !(m_d && !m_hostValid)))
             return false;
         hiprt::Resolved r;
         if (!ResolveSets(P->GetRingDimension(), {P}, &r))
@@ -1403,7 +1411,7 @@ private:
     }
     // this += / -= rhs recorded as terms, when either side is a pending sum (wide towers)
     bool AddLazily(const DCRTPolyType& rhs, bool minus) {
-        if (!LazySums() || (!m_lazy && !rhs.m_lazy) || !Compatible(rhs, false))
+        if (!LazySums() || (!PendingSum() && !rhs.PendingSum()) || !Compatible(rhs, false))
             return false;
         const uint32_t k = std::max(m_k, rhs.m_k);
         if (k == 1 || (m_k != k && !m_zero) || rhs.m_k != k)
@@ -1443,7 +1451,7 @@ private:
         m_hostValid = false;
     }
     void Settle() const {
-        if (!m_lazy)
+        if (!PendingSum())
             return;
         hiprt::MemberScope scope("WeightedSum");
         std::lock_guard<std::mutex> lk(m_lock.m);
@@ -1473,12 +1481,18 @@ private:
         m_hostValid = e.m_hostValid;
     }
     // where an in-place operation writes: the tower's own buffer, or a fresh one while the words are shared with a copy
+    // Words that another tower may read: a buffer with several owners (copies), or a WINDOW of a larger buffer (a tower taken out of a
+    // wide one without a copy, UnpackTower / PackWide below; evaluation keys inside their packed buffer) — the larger buffer's other
+    // windows and the wide tower itself are other towers' words, so a window is never written in place.
+    bool SharedWords() const {
+        return m_d && (m_d.use_count() > 1 || m_d->parent);
+    }
     hiprt::Buf WriteTarget() const {
-        return m_d.use_count() > 1 ? hiprt::Alloc(Words()) : m_d;
+        return SharedWords() ? hiprt::Alloc(Words()) : m_d;
     }
     // a private copy of shared words (operations that read-modify-write in place)
     void Unshare() {
-        if (m_d.use_count() > 1) {
+        if (SharedWords()) {
             hiprt::Op op;
             auto d = hiprt::Alloc(Words());
             hiprt::D2D(op, op.W(d), op.R(m_d), Words() * 8, "DCRTPoly copy");
@@ -2247,6 +2261,11 @@ private:
     }
     // ---- wide towers: K towers with equal (params, format) as one ([K][limbs][N]) and back --------------------------------------------
 public:
+    // Wide from birth (round 5): the towers of a lockstep group live as windows of ONE allocation.  UnpackTower hands out tower i as a
+    // window of the wide buffer (no copy; the window keeps the buffer alive and is copied only if somebody writes it in place,
+    // SharedWords); PackWide of K towers that are consecutive windows of one buffer is that buffer again (no copy), and when it has to
+    // copy it leaves the K source towers behind as windows of the packed buffer, so that packing the same operands again — the next
+    // operation of a pipeline, the next pass of a benchmark — costs nothing.  Values never change: only which allocation holds them.
     static DCRTPolyType PackWide(const std::vector<const DCRTPolyType*>& towers) {
         hiprt::MemberScope scope("PackWide");
         if (towers.empty())
@@ -2257,15 +2276,40 @@ public:
             OPENFHE_THROW("PackWide: the towers cannot live on the device");
         const uint32_t k = (uint32_t)towers.size();
         const size_t w   = t0.TowerWords();
-        hiprt::Op op;
-        auto d        = hiprt::Alloc((size_t)k * w);
-        uint64_t* dst = op.W(d);
         for (uint32_t i = 0; i < k; ++i) {
             const DCRTPolyType& t = *towers[i];
             if (t.m_k != 1 || !t0.Compatible(t, false) || !t.Upload())
                 OPENFHE_THROW("PackWide: towers of different shapes");
-            hiprt::D2D(op, dst + (size_t)i * w, op.R(t.m_d), w * 8, "towers packed into a wide one");
         }
+        static const bool views = !(std::getenv("FHE_HAL_WIDE_VIEWS") && std::string(std::getenv("FHE_HAL_WIDE_VIEWS")) == "0");
+        if (views) {  // already consecutive windows of one buffer?
+            std::vector<hiprt::Buf> held(k);
+            bool contiguous = true;
+            for (uint32_t i = 0; i < k && contiguous; ++i) {
+                std::lock_guard<std::mutex> lk(towers[i]->m_lock.m);
+                held[i]    = towers[i]->m_d;
+                contiguous = held[i] && held[i]->parent && held[i]->parent == held[0]->parent && held[i]->words == w &&
+                             held[i]->p == held[0]->p + (size_t)i * w;
+            }
+            if (contiguous) {
+                const auto& parent = held[0]->parent;
+                const size_t off   = (size_t)(held[0]->p - parent->p);
+                hiprt::CountDevice();
+                auto d = (off == 0 && parent->words == (size_t)k * w && !parent->parent) ? parent : hiprt::View(parent, off, (size_t)k * w);
+                return FromDevice(t0.m_h.GetParams(), t0.m_h.GetFormat(), std::move(d), k);
+            }
+        }
+        hiprt::Op op;
+        auto d        = hiprt::Alloc((size_t)k * w);
+        uint64_t* dst = op.W(d);
+        for (uint32_t i = 0; i < k; ++i)
+            hiprt::D2D(op, dst + (size_t)i * w, op.R(towers[i]->m_d), w * 8, "towers packed into a wide one");
+        if (views)
+            for (uint32_t i = 0; i < k; ++i) {  // the sources become windows of the packed buffer (same words)
+                std::lock_guard<std::mutex> lk(towers[i]->m_lock.m);
+                if (towers[i]->m_d && !towers[i]->m_lazy)
+                    towers[i]->m_d = hiprt::View(d, (size_t)i * w, w);
+            }
         hiprt::CountDevice();
         return FromDevice(t0.m_h.GetParams(), t0.m_h.GetFormat(), std::move(d), k);
     }
@@ -2275,6 +2319,16 @@ public:
         if (i >= m_k || !OnDeviceWide(&r))
             OPENFHE_THROW("UnpackTower: no such tower");
         const size_t w = TowerWords();
+        static const bool views = !(std::getenv("FHE_HAL_WIDE_VIEWS") && std::string(std::getenv("FHE_HAL_WIDE_VIEWS")) == "0");
+        if (views) {
+            hiprt::Buf src;
+            {
+                std::lock_guard<std::mutex> lk(m_lock.m);
+                src = m_d;
+            }
+            hiprt::CountDevice();
+            return FromDevice(m_h.GetParams(), m_h.GetFormat(), hiprt::View(src, (size_t)i * w, w), 1);
+        }
         hiprt::Op op;
         auto d = hiprt::Alloc(w);
         hiprt::D2D(op, op.W(d), op.R(m_d) + (size_t)i * w, w * 8, "tower taken out of a wide one");

@@ -9,6 +9,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # TEST-ONLY: hal/bootstrap_batch.cpp compiled against the stock libraries of oracle/_ref (the byte-for-byte reference)
@@ -198,6 +199,70 @@ def test_bench_self_launches_two_ranks_on_gloo(backend):
     assert "scatter" in d["rotation_key_replication"]["how"] and d["rotation_key_replication"]["keys"] == 14
 
 
+def _bench_on_gloo(world, extra_env=None, extra_args=(), timeout=2400):
+    env = dict(os.environ, FHE_BENCH_BACKEND="gloo", FHE_HIP_LIB=os.path.join(ROOT, "tests", "emu", "libfhe_emu.so"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0", "--logn", "12", "--limbs", "2",
+           "--batch", "4", "--evalmult-logn", "10", "--evalmult-limbs", "5", "--evalmult-batch", "3", "--no-bfv", "--no-lt",
+           "--no-hadamard", "--no-cpu-baseline", *extra_args]
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+
+
+def test_bench_eight_ranks_on_gloo_with_sharded_bootstrap(backend):
+    """The 8-GPU run rehearsed on CPU: `python bench.py --gpus 8` starts eight ranks itself (gloo, the lane emulator,
+    small rings).  Checked: the JSON line carries n_gpus = 8 and eight per-rank times; the relinearisation key reaches 8 ranks; the
+    rotation-key replication (scatter + all-gather) works with a key count that does not divide by 8 (14 keys: ragged slices); the
+    bootstrap leg — config 4 in miniature, 2 ciphertexts per rank = 16 sharded over the ranks, keys generated on rank 0 only and adopted
+    from the gathered tensor by the other seven — decrypts correctly on every rank with lockstep == narrow word for word; every rank's
+    OpenMP team and stream threads are capped at cores / 8."""
+    import json
+    if "emulator" not in backend.version():
+        pytest.skip("CPU (gloo) variant only; on GPUs the same command runs with RCCL")
+    sys.path.insert(0, ROOT)
+    from openfhe_amd import boot_batch as bb
+    boot = os.path.exists(bb.HIP_SO)
+    extra = ["--bootstrap-logn", "8", "--bootstrap-batch", "2", "--bootstrap-threads", "2", "--bootstrap-group", "2", "--bootstrap-wide-threads", "1"]
+    out = _bench_on_gloo(8, {"FHE_BENCH_EMU_BOOTSTRAP": "1" if boot else "", "FHE_BENCH_BOOTSTRAP_LIMIT_S": "2000"}, extra if boot else ["--no-bootstrap"])
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and len(d["ms_per_step_per_rank"]) == 8 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 32 and "x8" in d["config"]["parallelism"]
+    assert "8 rank(s)" in d["evalmult"]["eval_key"] and d["evalmult"]["parity"].startswith("bit-exact vs oracle")
+    assert d["evalmult"]["ops_per_s_total"] >= d["evalmult"]["ops_per_s_per_gpu"]
+    rep = d["rotation_key_replication"]
+    assert rep["keys"] == 14 and "8 rank(s)" in rep["how"] and "scatter" in rep["how"]
+    if boot:
+        b = d["evalbootstrap"]
+        assert "error" not in b, b
+        cores = os.cpu_count() or 1
+        assert b["host_threads"] == {"cores": cores, "ranks": 8, "cap_per_rank": max(1, cores // 8), "stream_threads": min(2, max(1, cores // 8)),
+                                     "openmp_team_during_setup": min(8, max(1, cores // 8))}
+        assert "8 rank(s)" in b["workload"] and b["max_abs_error_vs_message"] < 1e-2
+        assert b["lockstep"]["parity"].startswith("all 2 outputs identical word for word")
+        assert b["key_set_GB"] > 0 and b["bootstraps_per_s_total"] >= b["bootstraps_per_s_per_gpu"]
+
+
+def test_bench_rank_that_stalls_in_the_bootstrap_leg_fails_the_run(backend):
+    """a rank that never reaches the leg's first collective: every rank's watchdog ends its process after the limit, rank 0 prints the headline
+    line (without the leg's figures) first, and the run's exit status is NOT zero"""
+    import json
+    if "emulator" not in backend.version():
+        pytest.skip("CPU (gloo) variant only")
+    sys.path.insert(0, ROOT)
+    from openfhe_amd import boot_batch as bb
+    if not os.path.exists(bb.HIP_SO):
+        pytest.skip("hal/_build/libfhe_boot_batch_hip.so not built")
+    out = _bench_on_gloo(3, {"FHE_BENCH_EMU_BOOTSTRAP": "1", "FHE_BENCH_BOOTSTRAP_LIMIT_S": "25", "FHE_BENCH_TEST_STALL_RANK": "2"},
+                         ["--bootstrap-logn", "8", "--bootstrap-batch", "1", "--bootstrap-threads", "1"], timeout=900)
+    assert out.returncode != 0, "a stalled rank must fail the run"
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert lines, out.stdout[-1500:] + out.stderr[-1500:]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 3 and "did not finish within 25 s" in d["evalbootstrap"]["error"]
+
+
 def test_allgather_replication_matches_broadcast(tmp_path, backend):
     """shard.allgather_words (scatter + all-gather) delivers the same words to every rank as the one-shot broadcast, also when
     the table does not divide by the world size"""
@@ -339,7 +404,6 @@ def test_wide_bootstrap_in_lockstep_matches_the_stock_backend(tmp_path):
     wide_bootstrap(tmp_path, 8, 128, EMU_LIB)
 
 
-import pytest  # noqa: E402
 
 
 @pytest.mark.gpu

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel-time census of the LOCKSTEP bootstrap (config 4's headline path): run under `rocprofv3 --kernel-trace`, then summarise.
 
-  rocprofv3 --kernel-trace --output-format csv -d OUT -- python tools/boot_wide_profile.py run [cts] [group] [reps]
+  rocprofv3 --kernel-trace --output-format csv -d OUT -- python tools/boot_wide_profile.py run [cts] [group] [reps] [host threads]
   python tools/boot_wide_profile.py summarise OUT/.../*_kernel_trace.csv [reps] > profiles/r04_bootstrap_wide_kernels.txt
 
 `run` bootstraps `cts` ciphertexts once over host threads (first use of every composite), then `reps` + 1 times in lockstep groups;
@@ -15,7 +15,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run(cts, group, reps):
+def run(cts, group, reps, threads=1):
     sys.path.insert(0, ROOT)
     from openfhe_amd import boot_batch as bb
     prng = os.path.join(ROOT, "tests", "hal", "_build", "libdetprng.so")
@@ -24,10 +24,10 @@ def run(cts, group, reps):
     h = r.pop("handle")
     h.save_outputs()
     c0 = h.counters()
-    sec = h.bootstrap_wide(group, reps)
+    sec = h.bootstrap_wide(group, reps, threads)
     c1 = h.counters()
     n = (reps + 1) * cts
-    print(f"lockstep: {cts / sec:.2f} bootstraps/s, groups of {group}; differing outputs {h.compare_saved()}; per bootstrap: "
+    print(f"lockstep: {cts / sec:.2f} bootstraps/s, groups of {group} over {threads} host thread(s); differing outputs {h.compare_saved()}; per bootstrap: "
           f"{(c1['launches'] - c0['launches']) / n:.1f} launches, "
           f"{(c1['operand_read_bytes'] + c1['operand_write_bytes'] - c0['operand_read_bytes'] - c0['operand_write_bytes']) / n / 1e9:.2f} GB of operands")
     h.close()
@@ -87,6 +87,7 @@ if __name__ == "__main__":
     if sys.argv[1] == "sweep":
         sweep(int(sys.argv[2]), [tuple(int(v) for v in a.split("x")) for a in sys.argv[3:]])
     elif sys.argv[1] == "run":
-        run(int(sys.argv[2]) if len(sys.argv) > 2 else 32, int(sys.argv[3]) if len(sys.argv) > 3 else 32, int(sys.argv[4]) if len(sys.argv) > 4 else 2)
+        run(int(sys.argv[2]) if len(sys.argv) > 2 else 32, int(sys.argv[3]) if len(sys.argv) > 3 else 32, int(sys.argv[4]) if len(sys.argv) > 4 else 2,
+            int(sys.argv[5]) if len(sys.argv) > 5 else 1)
     else:
         summarise(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 32, int(sys.argv[4]) if len(sys.argv) > 4 else 2)
