@@ -690,6 +690,10 @@ Buf Alloc(size_t words) {
         if (r.api.mem_info(r.anyCtx, &freeB, &totalB) == FHE_OK && freeB < (uint64_t)bk * 8 + r.reserveBytes)
             pressed = true;
     }
+    static const bool traceAlloc = std::getenv("FHE_HAL_TRACE_ALLOC") != nullptr;  // (tuning aid: every request that reaches the device)
+    if (traceAlloc)
+        fprintf(stderr, "halalloc: %zu MiB from the device (class of %zu words), %llu MiB cached\n", bk * 8 >> 20, words,
+                (unsigned long long)(cached >> 20));
     fhe_status s = pressed ? FHE_ERR_ALLOC : r.api.malloc_(r.anyCtx, bk * 8, &d);
     if (s != FHE_OK) {  // memory pressure: every thread's and the shared cached buffers go back to the device, then the remembered results
         ReleaseCaches(false);

@@ -28,6 +28,7 @@ extern "C" size_t fhe_hal_launch_stats(char* buf, size_t cap, uint64_t* total) _
 extern "C" uint64_t fhe_hal_memo_hits() __attribute__((weak));
 extern "C" void fhe_hal_device_sync(void) __attribute__((weak));
 extern "C" uint64_t fhe_hal_cached_bytes(void) __attribute__((weak));
+extern "C" uint64_t fhe_hal_cached_bytes(void) __attribute__((weak));
 extern "C" void fhe_hal_release_caches(void) __attribute__((weak));
 static std::map<std::string, uint64_t> launches_by_kernel(uint64_t* total) {
     std::map<std::string, uint64_t> m;
@@ -473,10 +474,17 @@ int main(int argc, char** argv) {
         // argv[8] = G > 0 (HIP backend only): the ciphertexts in LOCKSTEP, G at a time as one ciphertext whose towers hold G towers each
         // (wide towers): cc->EvalMult runs once per group, every launch works on G towers
         const int group = argc > 8 ? std::atoi(argv[8]) : 0;
+        double tPack = 0, tMult = 0, tUnpack = 0, tDrain = 0;  // host seconds of the lockstep pass's phases (printed with FHE_SHIM_TIMING)
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(now() - t).count(); };
         auto pass = [&] {
 #ifdef WITH_HIP
             if (group > 0) {
+                static const bool marks = std::getenv("FHE_SHIM_TIMING") != nullptr;
                 for (int first = 0; first < B; first += group) {
+                    if (marks)
+                        std::cerr << "shim: group " << first / group << " cached MiB " << (fhe_hal_cached_bytes ? fhe_hal_cached_bytes() >> 20 : 0) << std::endl;
+                    auto tp = now();
                     const int k = std::min(group, B - first);
                     auto packed = [&](const std::vector<Ciphertext<DCRTPoly>>& v) {
                         auto w = v[first]->CloneEmpty();
@@ -491,11 +499,13 @@ int main(int argc, char** argv) {
                         return w;
                     };
                     auto wa = packed(a), wb = packed(b);
+                    tPack += since(tp), tp = now();
                     Ciphertext<DCRTPoly> wc;
                     {
                         hiprt::WidthScope scope(k);
                         wc = cc->EvalMult(wa, wb);
                     }
+                    tMult += since(tp), tp = now();
                     for (int i = 0; i < k; ++i) {
                         auto one = wc->CloneEmpty();
                         std::vector<DCRTPoly> el;
@@ -504,9 +514,9 @@ int main(int argc, char** argv) {
                         one->SetElements(std::move(el));
                         c[first + i] = one;
                     }
+                    tUnpack += since(tp);
                 }
-                (void)c[B - 1]->GetElements()[0].GetElementAtIndex(0);  // drain the device queue
-                return;
+                return;  // (the caller drains the device queue once, behind the last timed pass: a pipeline's throughput)
             }
 #endif
 #pragma omp parallel for schedule(dynamic, 1)
@@ -519,12 +529,29 @@ int main(int argc, char** argv) {
             auto warm = cc->EvalMult(a[0], b[0]);
             (void)warm->GetElements()[0].GetElementAtIndex(0);
         }
+        // Lockstep passes are timed as a pipeline: the passes are enqueued back to back and the device queue is drained once, behind the
+        // last one (a wait after every pass lets the idle device drop into a power state it needs ~3 ms to leave: the packed pass's few
+        // hundred microseconds of host work between the wait and the first launch cost 2.9 ms per pass, profiles/r05_sweeps.md section 2)
+        auto drainAll = [&] {
+#ifdef WITH_HIP
+            if (group > 0) {
+                auto td = now();
+                fhe_hal_device_sync();
+                tDrain += since(td);
+            }
+#endif
+        };
         pass();
+        drainAll();
         auto t0 = std::chrono::steady_clock::now();
         for (int r = 0; r < reps; ++r)
             pass();
+        drainAll();
         const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps;
         std::cout << "multbatch seconds per pass " << sec << " EvalMult per second " << B / sec << std::endl;
+        if (group > 0 && std::getenv("FHE_SHIM_TIMING"))
+            std::cout << "multbatch host seconds per pass: pack " << tPack / (reps + 1) << " EvalMult " << tMult / (reps + 1) << " unpack "
+                      << tUnpack / (reps + 1) << " drain " << tDrain / (reps + 1) << std::endl;
 #ifdef WITH_HIP
         if (group > 0) {
             // the same with the operands RESIDENT as wide ciphertexts (packed before, unpacked after the timed region): what a caller that
@@ -552,12 +579,13 @@ int main(int argc, char** argv) {
                     hiprt::WidthScope scope((uint32_t)std::min(group, B - (int)g * group));
                     WC[g] = cc->EvalMult(WA[g], WB[g]);
                 }
-                fhe_hal_device_sync();
             };
             resident();
+            fhe_hal_device_sync();
             t0 = std::chrono::steady_clock::now();
             for (int r = 0; r < reps; ++r)
                 resident();
+            fhe_hal_device_sync();
             const double rsec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps;
             std::cout << "multbatch resident seconds per pass " << rsec << " EvalMult per second " << B / rsec << std::endl;
             const auto packedPass = c;  // (the products of the timed passes above: pack, multiply, unpack)

@@ -83,7 +83,11 @@ def test_reference_core_lattice_unit_tests_on_emulator():
     ran, passed, failed, dev_ops, out = run(UT_HIP, CORE, EMU)
     assert (ran, passed, failed) == (ran_s, passed_s, 0), [l for l in out.split("\n") if "FAILED" in l][:10]
     assert dev_ops > 500
-    assert run.host_ops < 0.05 * dev_ops, (run.host_ops, dev_ops)
+    # per member, as on the GPU (HOST_ALLOW below): the core lattice suite needs NO host-mirror execution of any member on a ring the
+    # device library takes (round 5: measured zero for every member; a member that appears here has lost its device path)
+    on_mirror = {m: v[1] for m, v in run.members.items() if v[1] > 0}
+    assert run.members and not on_mirror and run.host_ops == 0, (on_mirror, run.host_ops)
+    assert not run.declines, run.declines
 
 
 # Host-mirror executions per member over the reference's 1729 unit tests on the MI355X: the committed upper bounds (this round's record,

@@ -5,6 +5,7 @@
 # sessions:
 #   mall          tools/mallbench (Infinity-Cache go/no-go) + the headline leg at --batch 2,4,8,16,64,1024
 #   ntt [env...]  the headline leg alone (20 steps), with optional FHE_* environment assignments
+#   wide          lockstep tests, cc->EvalMult leg, bootstrap (group x threads) sweep
 #   abl libs...   the headline leg with each tools/ablr5/libfhe_hip_<lib>.so (timing-only ablations)
 #   tests [k]     pytest -m gpu (optionally -k <k>)
 set -u
@@ -20,6 +21,16 @@ case "$S" in
   ntt)
     for kv in "$@"; do export "$kv"; done
     FHE_BENCH_NO_TORCH=1 timeout 900 python bench.py $NTT_ONLY --steps 20 --warmup 3 2>gpurun_out/ntt.err | tail -1 | tee gpurun_out/ntt.json | cut -c1-600 ;;
+  wide)  # round-5 HAL changes: lockstep shim tests, the cc->EvalMult leg's numbers (views), the bootstrap settings that used to thrash
+    timeout 1200 python -m pytest tests/test_hal_shim.py tests/test_multi_gpu_gloo.py tests/test_multi_gpu_rccl_one_rank.py -m gpu -q -x 2>&1 | tail -4
+    timeout 900 python - <<'PY' 2>&1 | tail -5 | tee gpurun_out/wide_ccm.json
+import json, os, sys
+sys.path.insert(0, os.getcwd())
+import bench
+r = bench.cc_evalmult_leg(True, os.path.join(os.getcwd(), "openfhe-development_amd", "csrc", "libfhe_hip.so"))
+print(json.dumps(r))
+PY
+    timeout 1500 python tools/boot_wide_profile.py sweep 64 16x2 16x4 32x2 8x4 16x2 2>&1 | tail -8 | tee gpurun_out/wide_sweep.txt ;;
   abl)   # timing-only ablation builds of the library (tools/ablr5/*.so, built here with -DFHE_ABL_*; results are wrong: --no-parity)
     for lib in "" "$@"; do
       name=${lib:-default}
