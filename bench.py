@@ -850,6 +850,16 @@ def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev,
                                    "sample": f"ciphertexts 0..{nstock - 1} of the batch, the same program on the stock backend (oracle/_ref), {nstock} bootstrap(s)"}
             res["speedup_vs_cpu"] = round(rate * csec, 1)
             same = open(ct0, "rb").read() == open(sdump, "rb").read()
+            try:  # (cross-host check of the committed digests the multi-rank runs rely on: this run's stock dump against the table's entry)
+                import hashlib
+                ent = json.load(open(os.path.join(ROOT, "tests", "golden", "stock_bootstrap_digests.json"))).get(
+                    f"logN{logN}_slots{slots}_total{total}_team{key_threads}_first{nstock}")
+                if ent:
+                    res["stock_digest_check"] = ("the stock run of THIS host reproduces the committed digest (" + ent.get("made_by", "") + ")"
+                                                 if ent["sha256"] == hashlib.sha256(open(sdump, "rb").read()).hexdigest()
+                                                 else "this host's stock run differs from the committed digest: digests are host-specific here")
+            except Exception:
+                pass
             res["parity"] = (f"ciphertexts 0..{nstock - 1} of rank 0's narrow pass identical byte for byte to the stock backend's bootstraps of the same "
                              f"batch's ciphertexts (same PRNG, same OpenMP team, all {total} ciphertexts of the {world}-rank batch encrypted on both "
                              "sides); the lockstep pass's outputs — ALL of the rank's — identical word for word to the narrow pass's (lockstep.parity); "

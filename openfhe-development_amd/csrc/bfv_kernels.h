@@ -211,6 +211,7 @@ struct BehzTables {           // bfvrns-cryptoparameters.cpp:673-850; all device
     uint64_t mskMu;                          // ComputeMu(msk)
     uint32_t mskMsb;
     uint32_t numQ, numBsk;
+    uint32_t W;                              // table stride: 16 (the register-resident kernels) or kBehzWideLimbs (the wide ones below)
 };
 struct BehzArgs {
     TowerView inQ, inBsk;   // source limbs
@@ -372,6 +373,108 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) behz_conv_sk_kernel(const BehzArgs g
         const uint64_t v  = dot_row_mod<SPLIT30>(y, g.tb.BHatModq + (uint64_t)j * kMaxBfvLimbs, numB, qj,
                                         FHE_ULOAD64(g.tb.muQ, 2 * j), FHE_ULOAD64(g.tb.muQ, 2 * j + 1));
         uint64_t a        = alpha;
+        if (a > mskHalf)
+            a = (a < msk) ? a + qj - msk : a - msk;  // ModSubFast(alpha, msk, q_j) with 64-bit wrap (:1917-1918)
+        a = mul_shoup(a, c.w, c.wp, qj);
+        *tv_at(g.outQ, b, j, g.logN, ri) = sub_mod(v, a, qj);
+    }
+}
+
+
+// ---- BEHZ with 16 ... 63 Q limbs (round 5) ---------------------------------------------------------------------------------------
+// The kernels above keep one coefficient's y_i in 16 registers.  Deep BFV parameter sets (the reference's
+// UTBFVRNS TestMultiplicativeDepthLimitation: 17 ... 70 Q limbs on toy rings) have more: the same arithmetic with the y_i in a
+// per-lane array (private memory), tables of stride kBehzWideLimbs, run-time loops.  Every sum is exact (integer sums reduced in
+// chunks of 8 products, modular addition of the chunks), so the residues are the reference's whatever the chunking; throughput is
+// not a goal here — the members just must not fall back to the host mirror.
+constexpr int kBehzWideLimbs = 64;
+FHE_HD uint64_t dot_row_mod_wide(const uint64_t* y, const uint64_t* row, uint32_t n, uint64_t m, uint64_t mulo, uint64_t muhi) {
+    const uint32_t k = 64u - (uint32_t)__builtin_clzll(m);
+    uint64_t v       = 0;
+    for (uint32_t c0 = 0; c0 < n; c0 += 8) {
+        sum8 s;
+        sum8_clear(s);
+        for (uint32_t i = c0; i < c0 + 8 && i < n; ++i)
+            sum8_add(s, y[i], FHE_ULOAD64(row, i));
+        const uint64_t r = sum8_reduce(s, m, k, mulo, muhi);
+        v                = c0 ? add_mod(v, r, m) : r;
+    }
+    return v;
+}
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) behz_q_to_bsk_wide_kernel(const BehzArgs g) {
+    const uint64_t gid = (uint64_t)FHE_BID * kThreads + FHE_TID;
+    if (gid >= ((uint64_t)g.batch << g.logN))
+        return;
+    const uint32_t b = (uint32_t)(gid >> g.logN), ri = (uint32_t)gid & ((1u << g.logN) - 1u);
+    const uint64_t mtilde = (uint64_t)1 << 16, half = mtilde >> 1, mask = mtilde - 1;
+    uint64_t y[kBehzWideLimbs];
+    uint64_t rm = 0;
+    for (uint32_t i = 0; i < g.tb.numQ; ++i) {
+        const TwPair c = uload_pair(g.tb.mtQHatInv, i);
+        y[i]           = mul_shoup(*tv_at(g.inQ, b, i, g.logN, ri), c.w, c.wp, FHE_ULOAD64(g.tb.q, i));
+        rm += y[i] * FHE_ULOAD64(g.tb.QHatModmt, i);  // plain 64-bit wrap-around, :1741
+    }
+    rm &= mask;
+    rm *= g.tb.negQInvModmt;
+    rm &= mask;
+    for (uint32_t j = 0; j < g.tb.numBsk; ++j) {
+        const uint64_t bj = FHE_ULOAD64(g.tb.bsk, j);
+        const TwPair cq = uload_pair(g.tb.QModbsk, j), cm = uload_pair(g.tb.mtInvModbsk, j);
+        const uint64_t v = dot_row_mod_wide(y, g.tb.QHatModbsk + (uint64_t)j * g.tb.W, g.tb.numQ, bj, FHE_ULOAD64(g.tb.muBsk, 2 * j),
+                                            FHE_ULOAD64(g.tb.muBsk, 2 * j + 1));
+        uint64_t r = rm;
+        if (rm >= half)
+            r += bj - mtilde;  // centred remainder, :1767-1768
+        r = mul_shoup(r, cq.w, cq.wp, bj);
+        r = add_mod(r, v, bj);
+        *tv_at(g.outBsk, b, j, g.logN, ri) = mul_shoup(r, cm.w, cm.wp, bj);
+    }
+}
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) behz_floorq_wide_kernel(const BehzArgs g) {
+    const uint64_t gid = (uint64_t)FHE_BID * kThreads + FHE_TID;
+    if (gid >= ((uint64_t)g.batch << g.logN))
+        return;
+    const uint32_t b = (uint32_t)(gid >> g.logN), ri = (uint32_t)gid & ((1u << g.logN) - 1u);
+    uint64_t y[kBehzWideLimbs];
+    for (uint32_t i = 0; i < g.tb.numQ; ++i) {
+        const TwPair c = uload_pair(g.tb.tQHatInv, i);
+        y[i]           = mul_shoup(*tv_at(g.inQ, b, i, g.logN, ri), c.w, c.wp, FHE_ULOAD64(g.tb.q, i));
+    }
+    for (uint32_t j = 0; j < g.tb.numBsk; ++j) {  // (the Bsk limbs first: in place, outQ aliases inQ only row by row)
+        const uint64_t bj = FHE_ULOAD64(g.tb.bsk, j);
+        const TwPair c    = uload_pair(g.tb.tQInvModbsk, j);
+        const uint64_t s  = dot_row_mod_wide(y, g.tb.qInvModbsk + (uint64_t)j * g.tb.W, g.tb.numQ, bj, FHE_ULOAD64(g.tb.muBsk, 2 * j),
+                                            FHE_ULOAD64(g.tb.muBsk, 2 * j + 1));
+        const uint64_t v  = mul_shoup(*tv_at(g.inBsk, b, j, g.logN, ri), c.w, c.wp, bj);
+        *tv_at(g.outBsk, b, j, g.logN, ri) = sub_mod(v, s, bj);
+    }
+    for (uint32_t i = 0; i < g.tb.numQ; ++i)
+        *tv_at(g.outQ, b, i, g.logN, ri) = y[i];  // the reference updates the Q limbs in place (:1810-1816)
+}
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) behz_conv_sk_wide_kernel(const BehzArgs g) {
+    const uint64_t gid = (uint64_t)FHE_BID * kThreads + FHE_TID;
+    if (gid >= ((uint64_t)g.batch << g.logN))
+        return;
+    const uint32_t b = (uint32_t)(gid >> g.logN), ri = (uint32_t)gid & ((1u << g.logN) - 1u);
+    const uint32_t numB = g.tb.numBsk - 1;
+    const uint64_t msk = FHE_ULOAD64(g.tb.bsk, numB), mskHalf = msk >> 1;
+    uint64_t y[kBehzWideLimbs];
+    const uint64_t xsk = *tv_at(g.inBsk, b, numB, g.logN, ri);
+    uint64_t alpha     = 0;
+    for (uint32_t i = 0; i < numB; ++i) {
+        const TwPair c = uload_pair(g.tb.BHatInv, i);
+        y[i]           = mul_shoup(*tv_at(g.inBsk, b, i, g.logN, ri), c.w, c.wp, FHE_ULOAD64(g.tb.bsk, i));
+        const uint64_t yi = y[i] >= msk ? y[i] % msk : y[i];  // fully reducing ModMul / ModAddEq (:1878-1881)
+        alpha = add_mod(alpha, mul_mod_barrett(yi, FHE_ULOAD64(g.tb.BHatModmsk, i), msk, g.tb.mskMu, (int)g.tb.mskMsb), msk);
+    }
+    alpha = sub_mod(alpha, xsk, msk);
+    alpha = mul_shoup(alpha, g.tb.BInvModmsk.w, g.tb.BInvModmsk.wp, msk);
+    for (uint32_t j = 0; j < g.tb.numQ; ++j) {
+        const uint64_t qj = FHE_ULOAD64(g.tb.q, j);
+        const TwPair c    = uload_pair(g.tb.BModq, j);
+        const uint64_t v  = dot_row_mod_wide(y, g.tb.BHatModq + (uint64_t)j * g.tb.W, numB, qj, FHE_ULOAD64(g.tb.muQ, 2 * j),
+                                            FHE_ULOAD64(g.tb.muQ, 2 * j + 1));
+        uint64_t a = alpha;
         if (a > mskHalf)
             a = (a < msk) ? a + qj - msk : a - msk;  // ModSubFast(alpha, msk, q_j) with 64-bit wrap (:1917-1918)
         a = mul_shoup(a, c.w, c.wp, qj);

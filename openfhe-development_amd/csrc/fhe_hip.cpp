@@ -2979,7 +2979,7 @@ struct fhe_behz {
 // Bsk = numQ primes below q.back() then m_sk  (bfvrns-cryptoparameters.cpp:682-711)
 extern "C" uint32_t fhe_param_behz_bsk(uint32_t logN, uint32_t numQ, const uint64_t* q, uint64_t t, uint64_t* bsk,
                                        uint64_t* psiBsk) {
-    if (!q || !bsk || !psiBsk || numQ < 1 || numQ > (uint32_t)kMaxBfvLimbs - 1)
+    if (!q || !bsk || !psiBsk || numQ < 1 || numQ > (uint32_t)kBehzWideLimbs - 1)
         return 0;
     const uint64_t M = 2ull << logN;
     uint64_t cur     = q[numQ - 1];
@@ -3032,7 +3032,7 @@ extern "C" uint32_t fhe_param_behz_bsk(uint32_t logN, uint32_t numQ, const uint6
 extern "C" fhe_status fhe_behz_create(fhe_ctx* c, const uint32_t* qLimbIdx, uint32_t numQ, const uint32_t* bskLimbIdx,
                                       uint64_t t, fhe_behz** out) {
     ARG_CHECK(c && qLimbIdx && bskLimbIdx && out, "fhe_behz_create: null argument");
-    ARG_CHECK(numQ >= 1 && numQ + 1 <= (uint32_t)kMaxBfvLimbs, "fhe_behz_create: at most 15 Q limbs supported");
+    ARG_CHECK(numQ >= 1 && numQ + 1 <= (uint32_t)kBehzWideLimbs, "fhe_behz_create: at most 63 Q limbs supported");
     const uint32_t numB = numQ, numBsk = numQ + 1;
     std::vector<uint64_t> q(numQ), bsk(numBsk);
     for (uint32_t i = 0; i < numQ; ++i) {
@@ -3046,8 +3046,8 @@ extern "C" fhe_status fhe_behz_create(fhe_ctx* c, const uint32_t* qLimbIdx, uint
     RT_CHECK(rt::set_device(c->device));
     const uint64_t mtilde = 1ull << 16, msk = bsk[numB];
     std::vector<uint64_t> B(bsk.begin(), bsk.begin() + numB);
-    // vectors padded to kMaxBfvLimbs, matrices stored [target][kMaxBfvLimbs]: see bfv_kernels.h
-    constexpr size_t W = kMaxBfvLimbs;
+    // vectors padded to W, matrices stored [target][W]: 16 for the register-resident kernels, kBehzWideLimbs above 15 Q limbs (bfv_kernels.h)
+    const size_t W = numBsk <= (uint32_t)kMaxBfvLimbs ? (size_t)kMaxBfvLimbs : (size_t)kBehzWideLimbs;
     std::vector<uint64_t> muQ(2 * W, 0), muBsk(2 * W, 0), QHatModbsk(W * numBsk, 0), QHatModmt(W, 0), qInvModbsk(W * numBsk, 0),
         BHatModmsk(W, 0), BHatModq(W * numQ, 0), qPad(W, 1), bskPad(W, 1);
     std::vector<TwPair> mtQHatInv(W, TwPair{0, 0}), tQHatInv(W, TwPair{0, 0}), BModq(W, TwPair{0, 0}), QModbsk(W, TwPair{0, 0}),
@@ -3097,7 +3097,7 @@ extern "C" fhe_status fhe_behz_create(fhe_ctx* c, const uint32_t* qLimbIdx, uint
     h->allIdx = h->qIdx;
     h->allIdx.insert(h->allIdx.end(), h->bskIdx.begin(), h->bskIdx.end());
     BehzTables& tb = h->tb;
-    tb.numQ = numQ, tb.numBsk = numBsk;
+    tb.numQ = numQ, tb.numBsk = numBsk, tb.W = (uint32_t)W;
     tb.negQInvModmt = ((mtilde - 1) * inv) & (mtilde - 1);                                    // :770-773
     tb.BInvModmsk   = pair(host::invmod(host::prod_mod(B, -1, msk), msk), msk);              // :836-837
     tb.mskMu        = host::barrett_mu(msk);
@@ -3133,7 +3133,7 @@ extern "C" void fhe_behz_destroy(fhe_behz* h) {
 // indexes them).  A DCRTPoly backend receives exactly these vectors from pke (CryptoParametersBFVRNS getters): with an override the
 // member computes with the CALLER's values, whatever they are, as the reference's member does.
 static fhe_status behz_pairs(fhe_behz* h, const uint64_t* v, const uint64_t* mod, uint32_t n, const TwPair** slot) {
-    std::vector<TwPair> t(kMaxBfvLimbs, TwPair{0, 0});
+    std::vector<TwPair> t(h->tb.W, TwPair{0, 0});
     for (uint32_t i = 0; i < n; ++i) {
         const uint64_t w = v[i] % mod[i];
         t[i]             = TwPair{w, host::shoup(w, mod[i])};
@@ -3146,7 +3146,7 @@ static fhe_status behz_pairs(fhe_behz* h, const uint64_t* v, const uint64_t* mod
 }
 // matrix given as [nRow][nCol] (reference order) -> device [nCol][kMaxBfvLimbs] (one target's weights contiguous)
 static fhe_status behz_matrix(fhe_behz* h, const uint64_t* m, uint32_t nRow, uint32_t nCol, const uint64_t* colMod, const uint64_t** slot) {
-    constexpr size_t W = kMaxBfvLimbs;
+    const size_t W = h->tb.W;
     std::vector<uint64_t> t(W * nCol, 0);
     for (uint32_t i = 0; i < nRow; ++i)
         for (uint32_t j = 0; j < nCol; ++j)
@@ -3177,7 +3177,7 @@ extern "C" fhe_status fhe_behz_override_q_to_bsk(fhe_behz* h, const uint64_t* mt
         (s = behz_pairs(h, QModbsk, bsk.data(), h->numBsk, &h->tb.QModbsk)) ||
         (s = behz_pairs(h, mtildeInvModbsk, bsk.data(), h->numBsk, &h->tb.mtInvModbsk)))
         return s;
-    std::vector<uint64_t> mt(kMaxBfvLimbs, 0);
+    std::vector<uint64_t> mt(h->tb.W, 0);
     std::copy(QHatModmtilde, QHatModmtilde + h->numQ, mt.begin());
     uint64_t* d = nullptr;
     if ((s = dev_copy(h->owned, mt.data(), mt.size(), &d)))
@@ -3212,7 +3212,7 @@ extern "C" fhe_status fhe_behz_override_conv_sk(fhe_behz* h, const uint64_t* BHa
     if ((s = behz_pairs(h, BHatInvModb, bsk.data(), numB, &h->tb.BHatInv)) ||
         (s = behz_matrix(h, BHatModq, numB, h->numQ, q.data(), &h->tb.BHatModq)) || (s = behz_pairs(h, BModq, q.data(), h->numQ, &h->tb.BModq)))
         return s;
-    std::vector<uint64_t> bm(kMaxBfvLimbs, 0);
+    std::vector<uint64_t> bm(h->tb.W, 0);
     for (uint32_t i = 0; i < numB; ++i)
         bm[i] = BHatModmsk[i] % msk;
     uint64_t* d = nullptr;
@@ -3250,7 +3250,9 @@ extern "C" fhe_status fhe_behz_q_to_bsk(fhe_behz* h, uint64_t* x, int evalFormat
         if (fhe_status s = ntt_run(c, true, x, coef, h->qIdx.data(), h->numQ, batch, st, tot, 0))  // :1708-1712
             return s;
         g.inQ = TowerView{coef, h->numQ, 0};
-        if (behz_split30())
+        if (h->tb.W > (uint32_t)kMaxBfvLimbs)
+            FHE_LAUNCH(behz_q_to_bsk_wide_kernel, coeff_grid(c, batch), st, g);
+        else if (behz_split30())
             FHE_LAUNCH((behz_q_to_bsk_kernel<true>), coeff_grid(c, batch), st, g);
         else
             FHE_LAUNCH((behz_q_to_bsk_kernel<false>), coeff_grid(c, batch), st, g);
@@ -3259,7 +3261,9 @@ extern "C" fhe_status fhe_behz_q_to_bsk(fhe_behz* h, uint64_t* x, int evalFormat
         return ntt_run(c, false, x, x, h->bskIdx.data(), h->numBsk, batch, st, tot, h->numQ, tot, h->numQ);
     }
     g.inQ = TowerView{x, tot, 0};
-    if (behz_split30())
+    if (h->tb.W > (uint32_t)kMaxBfvLimbs)
+        FHE_LAUNCH(behz_q_to_bsk_wide_kernel, coeff_grid(c, batch), st, g);
+    else if (behz_split30())
         FHE_LAUNCH((behz_q_to_bsk_kernel<true>), coeff_grid(c, batch), st, g);
     else
         FHE_LAUNCH((behz_q_to_bsk_kernel<false>), coeff_grid(c, batch), st, g);
@@ -3275,7 +3279,9 @@ extern "C" fhe_status fhe_behz_floorq(fhe_behz* h, uint64_t* x, uint32_t batch, 
     g.tb = h->tb, g.logN = h->ctx->logN, g.batch = batch;
     g.inQ = g.outQ = TowerView{x, tot, 0};
     g.inBsk = g.outBsk = TowerView{x, tot, h->numQ};
-    if (behz_split30())
+    if (h->tb.W > (uint32_t)kMaxBfvLimbs)
+        FHE_LAUNCH(behz_floorq_wide_kernel, coeff_grid(h->ctx, batch), st, g);
+    else if (behz_split30())
         FHE_LAUNCH((behz_floorq_kernel<true>), coeff_grid(h->ctx, batch), st, g);
     else
         FHE_LAUNCH((behz_floorq_kernel<false>), coeff_grid(h->ctx, batch), st, g);
@@ -3292,7 +3298,9 @@ extern "C" fhe_status fhe_behz_conv_sk(fhe_behz* h, const uint64_t* x, uint64_t*
     uint64_t* xm = const_cast<uint64_t*>(x);
     g.inQ = TowerView{xm, tot, 0}, g.inBsk = TowerView{xm, tot, h->numQ};
     g.outQ = TowerView{out, h->numQ, 0}, g.outBsk = g.inBsk;
-    if (behz_split30())
+    if (h->tb.W > (uint32_t)kMaxBfvLimbs)
+        FHE_LAUNCH(behz_conv_sk_wide_kernel, coeff_grid(h->ctx, batch), st, g);
+    else if (behz_split30())
         FHE_LAUNCH((behz_conv_sk_kernel<true>), coeff_grid(h->ctx, batch), st, g);
     else
         FHE_LAUNCH((behz_conv_sk_kernel<false>), coeff_grid(h->ctx, batch), st, g);

@@ -106,6 +106,8 @@ struct Runtime {
     // then in lockstep filled the 288 GB with caches until a kernel LAUNCH failed for want of memory (session g): an allocation that has
     // to go to the device first checks that a reserve stays free and otherwise takes every thread's cache back (Alloc)
     std::atomic<uint64_t> cachedBytes{0};
+    std::atomic<uint64_t> stolen{0};          // allocations served from ANOTHER thread's free lists (Alloc)
+    std::atomic<uint64_t> deviceMallocs{0}, cacheReleases{0};  // requests that reached the device; times the caches went back to it
     uint64_t cacheCap = ~0ull;               // FHE_HAL_CACHE_CAP_GB: a hard cap on the cached bytes (default: none)
     uint64_t reserveBytes = 8ull << 30;       // FHE_HAL_RESERVE_GB: free device memory kept for kernel launches (scratch, kernel arguments)
     bool requireDevice = false;
@@ -579,6 +581,7 @@ DevBuf::~DevBuf() {
 // pressure; fhe_hal_release_caches() lets a process that is done with a batch hand the device to the next one (bench.py between legs).
 static void ReleaseCaches(bool dropMemos = true) {
     Runtime& r = rt();
+    r.cacheReleases.fetch_add(1, std::memory_order_relaxed);
     if (dropMemos)
         DropMemos();
     uint64_t freed = 0;
@@ -677,6 +680,34 @@ Buf Alloc(size_t words) {
         if (take(r.orphanLists))  // (orphans were parked after a host-side wait for their pending uses: nothing to order behind)
             return b;
     }
+    // Another thread's cache before the device (round 5): free lists are per thread, so N host threads each kept the high-water mark of
+    // their own evaluation — four lockstep groups in flight held four times the workspace of one and the device ran out while tens of
+    // GB sat cached next door (16x4 / 8x4 groups: 7-20 bootstraps/s against 50).
+    static const bool steal = !(std::getenv("FHE_HAL_STEAL") && std::string(std::getenv("FHE_HAL_STEAL")) == "0");
+    if (steal && ts) {
+        uint32_t nStreams;
+        {
+            std::lock_guard<std::mutex> lk(r.streamMutex);
+            nStreams = r.nextStreamId;
+        }
+        for (uint32_t i = 1; i < nStreams; ++i) {
+            if (i == ts->id)
+                continue;
+            StreamState& st = r.streams[i];
+            std::lock_guard<std::mutex> flk(st.flMutex);
+            if (!st.ownerState)
+                continue;
+            if (take(st.ownerState->freeLists)) {
+                // everything submitted to T's stream so far — the buffer's pending launches and whatever T's stream was made to wait for
+                // when T released it — precedes this thread's later work: a device-side wait, recorded now (no sequence stamp of T's is
+                // involved, so nobody ever spins for an operation of T's to close)
+                Check(r.api.stream_wait(r.anyCtx, r.streams[ts->id].s, st.s), "HIP backend: ordering behind the stream a cached buffer came from");
+                b->writer = DevBuf::Use{ts->id, r.streams[ts->id].issued.load(std::memory_order_relaxed)};
+                r.stolen.fetch_add(1, std::memory_order_relaxed);
+                return b;
+            }
+        }
+    }
     void* d      = nullptr;
     // (the allocation goes to the device: if it would eat into the reserve kept for kernel launches while buffers sit in caches, the
     // caches go back first — a launch that fails for want of scratch memory cannot be retried from here)
@@ -690,6 +721,7 @@ Buf Alloc(size_t words) {
         if (r.api.mem_info(r.anyCtx, &freeB, &totalB) == FHE_OK && freeB < (uint64_t)bk * 8 + r.reserveBytes)
             pressed = true;
     }
+    r.deviceMallocs.fetch_add(1, std::memory_order_relaxed);
     static const bool traceAlloc = std::getenv("FHE_HAL_TRACE_ALLOC") != nullptr;  // (tuning aid: every request that reaches the device)
     if (traceAlloc)
         fprintf(stderr, "halalloc: %zu MiB from the device (class of %zu words), %llu MiB cached\n", bk * 8 >> 20, words,
@@ -1264,6 +1296,19 @@ extern "C" void fhe_hal_release_caches() {
 }
 // bytes of released buffers the backend holds for reuse right now (free lists, inboxes, orphans)
 extern "C" uint64_t fhe_hal_cached_bytes() { return lbcrypto::hiprt::Available() ? lbcrypto::hiprt::CachedBytes() : 0; }
+// {bytes cached, allocations served from another thread's cache, requests that reached the device, times the caches went back to the
+// device, free bytes of the device, total bytes of the device}
+extern "C" void fhe_hal_alloc_stats(uint64_t out[6]) {
+    for (int i = 0; i < 6; ++i)
+        out[i] = 0;
+    if (!lbcrypto::hiprt::Available())
+        return;
+    auto& r = lbcrypto::hiprt::rt();
+    out[0] = r.cachedBytes, out[1] = r.stolen, out[2] = r.deviceMallocs, out[3] = r.cacheReleases;
+    size_t f = 0, t = 0;
+    if (r.api.mem_info(r.anyCtx, &f, &t) == FHE_OK)
+        out[4] = f, out[5] = t;
+}
 // the host waits until every stream of the backend has run dry (the end of a timed pass of a harness)
 extern "C" void fhe_hal_device_sync() {
     if (lbcrypto::hiprt::Available())

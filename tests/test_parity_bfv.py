@@ -116,7 +116,10 @@ def behz_setup(lib, o, logN, numQ, t, bits=60):
     return N, q, psiQ, bsk, psiB, hb, ctx, plan
 
 
-@pytest.mark.parametrize("logN,numQ,t,B", [(4, 2, 65537, 2), (10, 3, 65537, 2), (12, 6, 786433, 1)])
+# (numQ = 15: the last size of the register-resident kernels; 16, 20, 40, 63: the wide plans of round 5 — deep BFV parameter sets, VERDICT r4
+# item 6 — with the y_i in a per-lane array; 63 Q + 64 Bsk limbs = 127 rows is the largest tower a context of 128 limbs holds)
+@pytest.mark.parametrize("logN,numQ,t,B", [(4, 2, 65537, 2), (10, 3, 65537, 2), (12, 6, 786433, 1), (5, 15, 65537, 2), (5, 16, 65537, 2),
+                                           (6, 20, 786433, 2), (5, 40, 65537, 1), (5, 63, 65537, 1)])
 def test_behz_trio(backend, oracle, logN, numQ, t, B):
     o = oracle
     rng = np.random.default_rng(23)
@@ -156,7 +159,7 @@ def test_behz_trio(backend, oracle, logN, numQ, t, B):
     o.orc_behz_destroy(hb)
 
 
-@pytest.mark.parametrize("logN,numQ,t,B", [(4, 2, 65537, 2), (10, 3, 65537, 3), (12, 4, 786433, 1)])
+@pytest.mark.parametrize("logN,numQ,t,B", [(4, 2, 65537, 2), (10, 3, 65537, 3), (12, 4, 786433, 1), (6, 20, 65537, 2)])
 def test_bfv_eval_mult_behz(backend, oracle, logN, numQ, t, B):
     """fhe_bfv_eval_mult_behz vs the oracle's composite (itself pinned to the reference's scheme-layer EvalMultNoRelin)"""
     o = oracle

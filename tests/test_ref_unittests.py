@@ -110,7 +110,7 @@ HOST_ALLOW = {
     # too (TimesNoCheck 50 + AssembleRows 62 inside the backend's KeySwitchGenInternal; every other key generation: zero)
     "KeySwitchGenInternal": 112,
 }
-DECLINE_REASONS = ("BEHZ plan: fhe_behz_create: at most 15 Q limbs supported", "device context: more than 128 distinct moduli in one operation")
+DECLINE_REASONS = ("BEHZ plan: fhe_behz_create: at most 63 Q limbs supported", "device context: more than 128 distinct moduli in one operation")
 
 
 @pytest.mark.gpu

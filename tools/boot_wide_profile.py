@@ -43,10 +43,24 @@ def sweep(cts, configs):
     print(f"threaded narrow pass: {r['bootstraps_per_s']:.2f} bootstraps/s over 8 host threads (first pass: includes first-use checks)")
     h = r.pop("handle")
     h.save_outputs()
+    import ctypes as C
+
+    def alloc_stats():
+        try:
+            out = (C.c_uint64 * 6)()
+            h.L.fhe_hal_alloc_stats(out)
+            return list(out)
+        except Exception:
+            return [0] * 6
     for group, threads in configs:
         try:
+            a0 = alloc_stats()
             sec = h.bootstrap_wide(group, 2, threads)
-            print(f"groups of {group} over {threads} host thread(s): {cts / sec:.2f} bootstraps/s; differing outputs {h.compare_saved()}", flush=True)
+            a1 = alloc_stats()
+            print(f"groups of {group} over {threads} host thread(s): {cts / sec:.2f} bootstraps/s; differing outputs {h.compare_saved()}; device memory in use "
+                  f"{(a1[5] - a1[4]) / 2**30:.0f} GiB of {a1[5] / 2**30:.0f} ({a1[0] / 2**30:.0f} GiB of it cached released buffers); during the passes: "
+                  f"{a1[2] - a0[2]} requests reached the device, {a1[1] - a0[1]} were served from another thread's cache, the caches went back {a1[3] - a0[3]} times",
+                  flush=True)
         except Exception as e:
             print(f"groups of {group} over {threads} host thread(s): {type(e).__name__}: {str(e)[-260:]}", flush=True)
     h.close()
