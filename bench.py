@@ -777,7 +777,7 @@ def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev,
            "bootstraps_per_s_per_gpu": round(rate, 2), "bootstraps_per_s_total": round(total_rate, 2),
            "bootstraps_per_s_over_host_threads": round(threaded_rate, 2), "lockstep": wide,
            "seconds_per_bootstrap": round(single, 5), "one_stream_roofline": narrow_roof, "seconds_per_pass": round(r["seconds_per_pass"], 4),
-           "max_abs_error_vs_message": r["max_abs_error"], "setup_s": r["setup_s"], "keygen_s_rank0": r["keygen_s"],
+           "max_abs_error_vs_message": r["max_abs_error"], "setup_s": r["setup_s"], "keygen_s_rank0": r["keygen_s"], "hal_build": bb.HAL_BUILD,
            "host_threads": {"cores": os.cpu_count() or 1, "ranks": world, "cap_per_rank": team_cap, "stream_threads": threads,
                             "openmp_team_during_setup": key_threads},
            "how": "reference pke (unmodified sources) on the HIP backend of DCRTPoly; 1 warm-up + 2 timed passes over the rank's ciphertexts; "
@@ -883,6 +883,12 @@ def cc_evalmult_leg(with_cpu, libpath):
     import tempfile
     bdir = os.path.join(ROOT, "tests", "hal", "_build")
     hip, stock, prng = (os.path.join(bdir, n) for n in ("shim_ckks_hip", "shim_ckks_stock", "libdetprng.so"))
+    # the program built from the PATCHED reference sources (integration/with_hip.patch: hooks bound at source level, plain compiler flags)
+    # when it is present, else the one whose hooks are bound on object files (objcopy, hal/Makefile); FHE_HAL_BUILD=objcopy forces the latter
+    patched = os.path.join(ROOT, "integration", "_build", "shim_ckks_hip_patched")
+    which = "unmodified sources, hooks bound with objcopy (hal/Makefile)"
+    if os.path.exists(patched) and os.environ.get("FHE_HAL_BUILD", "") != "objcopy":
+        hip, which = patched, "patched sources (integration/with_hip.patch)"
     if not (os.path.exists(hip) and os.path.exists(prng)):
         return {"skipped": "tests/hal/_build/shim_ckks_hip not built (./build.sh hal needs the reference sources)"}
     tmp = tempfile.mkdtemp(prefix="fhe_ccmult_")
@@ -923,6 +929,9 @@ def cc_evalmult_leg(with_cpu, libpath):
     if wrate is not None:
         same = open(os.path.join(tmp, "w256.bin"), "rb").read() == open(os.path.join(tmp, "h256.bin"), "rb").read()
         lock = {"ops_per_s": round(wrate, 1), "group": 64, "host_threads": 1,  # (one thread issues the group's launches)
+                "how": "PackWide of the operands, cc->EvalMult and UnpackTower of the products INSIDE the timed region; towers of a lockstep group "
+                       "are windows of one allocation (wide from birth: packing operands that are already consecutive windows and unpacking cost no "
+                       "copy); the 10 timed passes are enqueued back to back and the device queue is drained once behind the last",
                 "parity": ("all 256 products identical to the threaded run's (128-bit digest of every word of every product; first and last "
                            "product byte for byte)") if same else "MISMATCH vs the threaded run"}
         if run.resident is not None:  # the same multiplications on ciphertexts that stay wide (no PackWide / UnpackTower in the timed region)
@@ -936,7 +945,7 @@ def cc_evalmult_leg(with_cpu, libpath):
     res = {"workload": "cc->EvalMult(ct, ct) with HYBRID relinearisation, N=2^16, 21 Q + 7 P limbs, dnum 3, 256 ciphertexts: over 8 host threads "
                        "(one tower per operation) and in lockstep (wide towers: 64 ciphertexts per cc->EvalMult call, one host thread)",
            "ops_per_s": round(rate, 1), "ops_per_s_over_host_threads": round(threaded, 1), "lockstep": lock,
-           "pcie": pcie,
+           "pcie": pcie, "hal_build": which,
            "how": "reference pke (unmodified sources) on the HIP backend of DCRTPoly; ops_per_s = the better of the two ways of running the batch",
            "parity": "not checked", "cpu_baseline": None}
     if with_cpu and os.path.exists(stock):

@@ -25,7 +25,8 @@ build_oracle() { make -s -C "$ROOT/oracle" oracle; }
 build_ref() { make -s -j"$(nproc)" -C "$ROOT/oracle" ref; }
 build_hal() {
   make -s -j"$(nproc)" -C "$ROOT/openfhe-development_amd/hal" && make -s -j3 -C "$ROOT/tests/hal" &&
-    make -s -j"$(nproc)" -C "$ROOT/tests/hal" -f Makefile.ut  # the reference's own pke unit tests on both backends
+    make -s -j"$(nproc)" -C "$ROOT/tests/hal" -f Makefile.ut &&  # the reference's own pke unit tests on both backends
+    "$ROOT/integration/build_patched.sh" > /dev/null  # the same backend bound at SOURCE level (integration/with_hip.patch): what bench.py prefers
 }
 case "$what" in
   hip) build_hip ;;

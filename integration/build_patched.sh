@@ -2,7 +2,8 @@
 # Applies integration/with_hip.patch to a COPY of the reference's sources and builds OpenFHE from that copy against the HIP backend of
 # DCRTPoly with plain compiler flags (-DWITH_HIP -DFHE_HIP_PATCHED_PKE, the backend's include directory in front): no objcopy, no
 # -fno-inline-functions — what an upstream tree carrying the patch would do.  Then builds the shim test program against the result.
-#   integration/build_patched.sh [/root/reference]   -> integration/_build/{tree/, lib/libOPENFHE*_hip.so, shim_ckks_hip_patched}
+#   integration/build_patched.sh [/root/reference]   -> integration/_build/{tree/, lib/libOPENFHE*_hip.so, lib/libfhe_boot_batch_hip.so,
+#                                                       shim_ckks_hip_patched}  (what bench.py and the GPU suite prefer when present)
 set -e
 REF="${1:-/root/reference}"
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
@@ -15,7 +16,7 @@ for d in core binfhe pke; do
   cp -r "$REF/src/$d/include" "$REF/src/$d/lib" "$B/tree/src/$d/"
 done
 (cd "$B/tree" && patch -p1 -s < "$HERE/with_hip.patch")
-make -s -j"$(nproc)" -C "$ROOT/openfhe-development_amd/hal" PATCHED=1 REF="$B/tree" OUT="$B/lib" "$B/lib/libOPENFHEpke_hip.so"
+make -s -j"$(nproc)" -C "$ROOT/openfhe-development_amd/hal" PATCHED=1 REF="$B/tree" OUT="$B/lib" "$B/lib/libOPENFHEpke_hip.so" "$B/lib/libfhe_boot_batch_hip.so"
 HAL="$ROOT/openfhe-development_amd/hal"
 STUB="$ROOT/third_party_stubs"
 T="$B/tree"

@@ -12,7 +12,13 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HIP_SO = os.path.join(ROOT, "openfhe-development_amd", "hal", "_build", "libfhe_boot_batch_hip.so")
+# Two builds of the same backend: the reference's sources patched at source level (integration/with_hip.patch, plain compiler flags) and
+# the unmodified sources with the hooks bound on object files (objcopy --weaken-symbol, hal/Makefile).  The patched build is the one
+# used when it is present; FHE_HAL_BUILD=objcopy selects the other.
+OBJCOPY_SO = os.path.join(ROOT, "openfhe-development_amd", "hal", "_build", "libfhe_boot_batch_hip.so")
+PATCHED_SO = os.path.join(ROOT, "integration", "_build", "lib", "libfhe_boot_batch_hip.so")
+HIP_SO = PATCHED_SO if (os.path.exists(PATCHED_SO) and os.environ.get("FHE_HAL_BUILD", "") != "objcopy") else OBJCOPY_SO
+HAL_BUILD = "patched sources (integration/with_hip.patch)" if HIP_SO == PATCHED_SO else "unmodified sources, hooks bound with objcopy (hal/Makefile)"
 u32, u64, vp = C.c_uint32, C.c_uint64, C.c_void_p
 
 

@@ -32,11 +32,11 @@ def test_patch_is_what_the_generator_writes(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
-def patched_check(tmp_path, mode, logN, expect, must_run, extra=()):
+def patched_check(tmp_path, mode, logN, expect, must_run, extra=(), device_lib=None, threads=1):
     ensure_patched_build()
     so, sh = str(tmp_path / "stock.bin"), str(tmp_path / "patched.bin")
-    out_stock = shim.run(shim.PROGS[0], so, mode, logN, extra=extra)
-    out_hip = shim.run(PATCHED, sh, mode, logN, shim.EMU, extra=extra)
+    out_stock = shim.run(shim.PROGS[0], so, mode, logN, extra=extra, threads=threads)
+    out_hip = shim.run(PATCHED, sh, mode, logN, device_lib or shim.EMU, extra=extra, threads=threads)
     a, b = open(so, "rb").read(), open(sh, "rb").read()
     assert len(a) > 1000 and a == b, "the build from the patched sources differs from the default backend"
     shim.assert_ran_on_device(out_hip, must_run)
@@ -54,3 +54,21 @@ def test_patched_sources_leveled_ckks_on_emulator(tmp_path):
 
 def test_patched_sources_bootstrap_on_emulator(tmp_path):
     patched_check(tmp_path, "bootstrap", 10, shim.BOOT, shim.BOOT_MEMBERS)
+
+
+# the same build on the MI355X (round 5: the build the benchmark's cc->EvalMult and bootstrap legs prefer)
+@pytest.mark.gpu
+def test_patched_sources_leveled_ckks_on_gpu(tmp_path):
+    patched_check(tmp_path, "leveled", 14, shim.LEVELED, shim.CKKS_MEMBERS, device_lib=shim.HIP)
+
+
+@pytest.mark.gpu
+def test_patched_sources_bootstrap_on_gpu(tmp_path):
+    patched_check(tmp_path, "bootstrap", 13, shim.BOOT, shim.BOOT_MEMBERS, device_lib=shim.HIP)
+
+
+@pytest.mark.gpu
+def test_patched_sources_lockstep_batch_on_gpu(tmp_path):
+    """cc->EvalMult on 32 ciphertexts in lockstep groups of 12 (wide towers, windows of one allocation): every product's digest and the
+    first and last product byte for byte equal to the stock backend's"""
+    patched_check(tmp_path, "multbatch", 14, {"product 0": [0.5, 0.0, -3.0]}, (), extra=(8, 32, 1, 12), device_lib=shim.HIP)
