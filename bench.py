@@ -806,18 +806,22 @@ def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev,
         res["device_memory"] = {"error": f"{type(e).__name__}: {e}"}
     h.close()
     del keep_keys
-    live_stock = with_cpu and rank == 0 and os.path.exists(STOCK_BOOT_SO) and (world == 1 or bool(os.environ.get("FHE_BENCH_STOCK_AT_SCALE")))
+    try:
+        digests = json.load(open(os.path.join(ROOT, "tests", "golden", "stock_bootstrap_digests.json")))
+    except Exception:
+        digests = {}
+    dkey = f"logN{logN}_slots{slots}_total{total}_team{key_threads}_first{nstock}"
+    # one rank: live.  Several ranks: against the committed digest of the same stock run when there is one (the other ranks do not wait
+    # for rank 0's host run), else live (about a minute on the GPU box's host: all `total` ciphertexts are encrypted there)
+    live_stock = with_cpu and rank == 0 and os.path.exists(STOCK_BOOT_SO) and (world == 1 or dkey not in digests or
+                                                                                 bool(os.environ.get("FHE_BENCH_STOCK_AT_SCALE")))
     if rank == 0 and world > 1 and not live_stock:
         # several ranks: the other ranks would wait minutes for rank 0's stock run (all `total` ciphertexts encrypted on the host, the
         # key set generated there): the byte comparison is against the COMMITTED digest of that run (tools/stock_boot_digest.py wrote
         # it with the same program on the stock backend), or live with FHE_BENCH_STOCK_AT_SCALE=1
         import hashlib
         digest = hashlib.sha256(open(ct0, "rb").read()).hexdigest()
-        key = f"logN{logN}_slots{slots}_total{total}_team{key_threads}_first{nstock}"
-        try:
-            table = json.load(open(os.path.join(ROOT, "tests", "golden", "stock_bootstrap_digests.json")))
-        except Exception:
-            table = {}
+        key, table = dkey, digests
         if key in table:
             res["parity"] = ((f"ciphertext 0 of rank 0's narrow pass identical to the stock backend's bootstrap of the same {total}-ciphertext batch's "
                               f"ciphertext 0: sha256 of the byte dump = the committed digest (tests/golden/stock_bootstrap_digests.json[{key}], "

@@ -6,6 +6,7 @@
 #   mall          tools/mallbench (Infinity-Cache go/no-go) + the headline leg at --batch 2,4,8,16,64,1024
 #   ntt [env...]  the headline leg alone (20 steps), with optional FHE_* environment assignments
 #   wide          lockstep tests, cc->EvalMult leg, bootstrap (group x threads) sweep
+#   ut            the reference's unit tests on the GPU with the per-member mirror counts
 #   abl libs...   the headline leg with each tools/ablr5/libfhe_hip_<lib>.so (timing-only ablations)
 #   tests [k]     pytest -m gpu (optionally -k <k>)
 set -u
@@ -31,6 +32,12 @@ r = bench.cc_evalmult_leg(True, os.path.join(os.getcwd(), "openfhe-development_a
 print(json.dumps(r))
 PY
     timeout 1500 python tools/boot_wide_profile.py sweep 64 16x2 16x4 32x2 8x4 16x2 2>&1 | tail -8 | tee gpurun_out/wide_sweep.txt ;;
+  ut)    # the reference's own 1729 unit tests on the backend: totals, members with host-mirror executions, decline reasons
+    cd /tmp && FHE_HIP_LIB=$GRAFT_REPO_ROOT/openfhe-development_amd/csrc/libfhe_hip.so OMP_NUM_THREADS=8 timeout 900 \
+      $GRAFT_REPO_ROOT/tests/hal/_build/ut_hip "--gtest_filter=-*SERIALIZE*:UTBinInt.GetInternalRepresentation" > $GRAFT_REPO_ROOT/gpurun_out/ut_full.log 2>&1
+    cd $GRAFT_REPO_ROOT
+    grep -E "tests ran|^hal: |halcomposite|haldecline" gpurun_out/ut_full.log | tee gpurun_out/ut_trace.txt
+    grep -E "^halmember" gpurun_out/ut_full.log | awk '$4 > 0' | sort -k4 -n -r | tee -a gpurun_out/ut_trace.txt ;;
   abl)   # timing-only ablation builds of the library (tools/ablr5/*.so, built here with -DFHE_ABL_*; results are wrong: --no-parity)
     for lib in "" "$@"; do
       name=${lib:-default}
