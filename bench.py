@@ -760,7 +760,21 @@ def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev,
                 "roofline": per_bootstrap(w0, w1, 4, r["ciphertexts"] / wsec)}  # (1 untimed + 3 timed passes between the readings)
         # the operand bytes itemised by the pke / DCRTPoly scope that issued the operations (GB per bootstrap, largest first)
         per = {k: (m1[k] - m0.get(k, 0)) / (4.0 * nct) / 1e9 for k in m1}
-        wide["roofline"]["operand_GB_by_member"] = {k: round(v, 3) for k, v in sorted(per.items(), key=lambda kv: -kv[1])[:12] if v > 0.0005}
+        # (every scope above 5 MB per bootstrap: round 4 listed twelve and left 9.6 GB as "everything else")
+        wide["roofline"]["operand_GB_by_member"] = {k: round(v, 3) for k, v in sorted(per.items(), key=lambda kv: -kv[1])[:48] if v > 0.005}
+        wide["roofline"]["operand_GB_listed"] = round(sum(wide["roofline"]["operand_GB_by_member"].values()), 3)
+        # HBM bytes per bootstrap from the committed counter passes of this setting (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over the lockstep
+        # passes, tools/boot_wide_profile.py pmc) — quoted only when recorded with the kernel sources this run executes
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", "r05_bootstrap_pmc.json")))
+            if rec.get("kernel_source_sha") == source_sha():
+                wide["roofline"]["traffic"] = round(rec["bytes_per_bootstrap"])
+                wide["roofline"]["traffic_source"] = "profiles/r05_bootstrap_pmc.json (FETCH_SIZE x2 + WRITE_SIZE over the lockstep passes, groups of 16 on 2 host threads, same kernel sources)"
+                wide["roofline"]["wasted_traffic_ratio"] = round(rec["bytes_per_bootstrap"] / 1e9 / max(wide["roofline"]["operand_GB_per_bootstrap"], 1e-9), 3)
+            else:
+                wide["roofline"]["traffic_source"] = "profiles/r05_bootstrap_pmc.json was recorded with other kernel sources: not quoted"
+        except Exception:
+            pass
         if ndiff != 0:
             wide["bootstraps_per_s_unverified"] = wide.pop("bootstraps_per_s")  # a figure without parity is not reported as the rate
     except Exception as e:

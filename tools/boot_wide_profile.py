@@ -97,9 +97,51 @@ def summarise(path, cts, reps):
         print(f"{t / 1e6 / cts:13.3f} {t / busy:6.3f} {c:6d} {t / c / 1e3:8.1f}  {nm[:120]}")
 
 
+def pmc(trace_csv, counter_csvs, cts, reps, out_json):
+    """HBM bytes per bootstrap of the lockstep passes from rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE runs of `run` (one counter
+    per run, MI355X_MICROARCH.md: separate passes; FETCH_SIZE doubled on gfx950, units KiB).  The lockstep phase is found in the kernel
+    trace of the SAME run as in summarise() (the tail behind the longest pauses) and the counters are joined by dispatch id."""
+    import hashlib
+    import json
+    tot = {}
+    for path in counter_csvs:
+        tr = path.replace("counter_collection.csv", "kernel_trace.csv")
+        rows = []
+        with open(tr if os.path.exists(tr) else trace_csv, newline="") as f:
+            for r in csv.DictReader(f):
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Dispatch_Id"])))
+        rows.sort()
+        n = len(rows)
+        gaps = sorted(((rows[i + 1][0] - rows[i][1], i) for i in range(n // 4, n - 1)), reverse=True)
+        cut = min(i for _, i in gaps[:reps + 1])
+        tail = {d for _, _, d in rows[cut + 1:]}
+        with open(path, newline="") as f:
+            for r in csv.DictReader(f):
+                if int(r["Dispatch_Id"]) in tail:
+                    tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        tot["launches_" + os.path.basename(os.path.dirname(os.path.dirname(path)))] = len(tail)
+    n = (reps + 1) * cts
+    fetch, write = tot.get("FETCH_SIZE", 0.0) * 2048, tot.get("WRITE_SIZE", 0.0) * 1024
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "openfhe-development_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    out = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs) on `python tools/boot_wide_profile.py run "
+                   f"{cts} <group> {reps} <threads>` (N = 2^17, 24 Q + 8 P limbs): counters of the launches of the {reps + 1} lockstep passes "
+                   "(the trace's tail), FETCH_SIZE x 2048 + WRITE_SIZE x 1024 bytes, per bootstrap",
+           "kernel_source_sha": h.hexdigest()[:16], "bootstraps": n, "fetch_bytes_per_bootstrap": fetch / n, "write_bytes_per_bootstrap": write / n,
+           "bytes_per_bootstrap": (fetch + write) / n, "detail": tot}
+    json.dump(out, open(out_json, "w"), indent=1)
+    print(json.dumps(out))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "sweep":
         sweep(int(sys.argv[2]), [tuple(int(v) for v in a.split("x")) for a in sys.argv[3:]])
+    elif sys.argv[1] == "pmc":  # pmc <out.json> <cts> <reps> <counter_collection.csv>...
+        pmc(None, sys.argv[5:], int(sys.argv[3]), int(sys.argv[4]), sys.argv[2])
     elif sys.argv[1] == "run":
         run(int(sys.argv[2]) if len(sys.argv) > 2 else 32, int(sys.argv[3]) if len(sys.argv) > 3 else 32, int(sys.argv[4]) if len(sys.argv) > 4 else 2,
             int(sys.argv[5]) if len(sys.argv) > 5 else 1)
