@@ -17,6 +17,7 @@ def source_sha():  # the same identity bench.py computes: the kernel sources the
 
 
 R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+SRC = os.environ.get("FHE_PROFILE_DIR", "gpurun_out")  # where the record session left the rocprofv3 output directories
 # --pmc-only: on the GPU box, between the counter passes and the bench run of a record session — the bench line then quotes the
 # counters of the very sources it runs (it keys them by kernel-source identity)
 PMC_ONLY = "--pmc-only" in sys.argv
@@ -34,7 +35,7 @@ names = {"<true, false,": "fwd_column_pass", "<false, false,": "fwd_row_pass", "
          "<true, true,": "inv_column_pass"}
 res = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = newest(f"gpurun_out/pmc_{R}_{c}/*/*counter_collection.csv")
+    f = newest(f"{SRC}/pmc_{R}_{c}/*/*counter_collection.csv")
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == c and "ntt_static_kernel" in r["Kernel_Name"]:
@@ -72,7 +73,7 @@ valu = {"_how": "rocprofv3 --kernel-trace --pmc " + " ".join(SQ) + " (one pass, 
         "kernel_source_sha": out["kernel_source_sha"], "legs": {}}
 for leg in ("ntt", "evalmult"):
     try:
-        f = newest(f"gpurun_out/pmc_{R}_sq_{leg}/*/*counter_collection.csv")
+        f = newest(f"{SRC}/pmc_{R}_sq_{leg}/*/*counter_collection.csv")
     except ValueError:
         continue
     per = collections.defaultdict(lambda: collections.defaultdict(list))

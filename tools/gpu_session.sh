@@ -45,37 +45,38 @@ PY
     export FHE_BENCH_NO_TORCH=1
     cd /tmp && export TMPDIR=/tmp
     G=$GRAFT_REPO_ROOT
+    D=/tmp/rec; mkdir -p $D   # (traces and counter files are large: only summaries go to gpurun_out, which is merged back up to 64 MiB)
     NTTLEG="--no-bootstrap --no-cc-evalmult --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-evalmult --no-bfv --no-hadamard --no-lt"
     for c in FETCH_SIZE WRITE_SIZE; do
-      timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $G/gpurun_out/pmc_${R}_$c -- python $G/bench.py $NTTLEG > $G/gpurun_out/pmc_${R}_$c.log 2>&1
+      timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $D/pmc_${R}_$c -- python $G/bench.py $NTTLEG > $D/pmc_${R}_$c.log 2>&1
     done
     SQ="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_WAVES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY"
-    timeout 600 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $G/gpurun_out/pmc_${R}_sq_ntt -- python $G/bench.py $NTTLEG > $G/gpurun_out/pmc_${R}_sq_ntt.log 2>&1
-    timeout 600 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $G/gpurun_out/pmc_${R}_sq_evalmult -- python $G/bench.py --no-bootstrap --no-cc-evalmult --batch 8 --steps 1 --warmup 0 --no-cpu-baseline --no-parity --no-bfv --no-hadamard --no-lt > $G/gpurun_out/pmc_${R}_sq_evalmult.log 2>&1
+    timeout 600 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $D/pmc_${R}_sq_ntt -- python $G/bench.py $NTTLEG > $D/pmc_${R}_sq_ntt.log 2>&1
+    timeout 600 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $D/pmc_${R}_sq_evalmult -- python $G/bench.py --no-bootstrap --no-cc-evalmult --batch 8 --steps 1 --warmup 0 --no-cpu-baseline --no-parity --no-bfv --no-hadamard --no-lt > $D/pmc_${R}_sq_evalmult.log 2>&1
     echo "== bootstrap (64 ciphertexts, groups of 16 on 2 host threads): census, then FETCH / WRITE passes"
-    timeout 900 rocprofv3 --kernel-trace --output-format csv -d $G/gpurun_out/boot_${R}_trace -- python $G/tools/boot_wide_profile.py run 64 16 2 2 > $G/gpurun_out/boot_${R}_trace.log 2>&1
-    tail -1 $G/gpurun_out/boot_${R}_trace.log
-    f=$(ls -t $G/gpurun_out/boot_${R}_trace/*/*kernel_trace.csv | head -1)
-    (echo "# rocprofv3 --kernel-trace of \`tools/boot_wide_profile.py run 64 16 2 2\` (round 5 record: 64 ciphertexts at config 4's shape, lockstep groups of 16 on 2 host threads — bench.py's setting — 3 passes)"; tail -1 $G/gpurun_out/boot_${R}_trace.log; python $G/tools/boot_wide_profile.py summarise $f 64 2) > $G/gpurun_out/${R}_bootstrap_wide_kernels.txt
+    timeout 900 rocprofv3 --kernel-trace --output-format csv -d $D/boot_${R}_trace -- python $G/tools/boot_wide_profile.py run 64 16 2 2 > $D/boot_${R}_trace.log 2>&1
+    tail -1 $D/boot_${R}_trace.log
+    f=$(ls -t $D/boot_${R}_trace/*/*kernel_trace.csv | head -1)
+    (echo "# rocprofv3 --kernel-trace of \`tools/boot_wide_profile.py run 64 16 2 2\` (round 5 record: 64 ciphertexts at config 4's shape, lockstep groups of 16 on 2 host threads — bench.py's setting — 3 passes)"; tail -1 $D/boot_${R}_trace.log; python $G/tools/boot_wide_profile.py summarise $f 64 2) > $G/gpurun_out/${R}_bootstrap_wide_kernels.txt
     head -16 $G/gpurun_out/${R}_bootstrap_wide_kernels.txt | cut -c1-150
     for c in FETCH_SIZE WRITE_SIZE; do
-      timeout 1200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $G/gpurun_out/boot_${R}_$c -- python $G/tools/boot_wide_profile.py run 64 16 2 2 > $G/gpurun_out/boot_${R}_$c.log 2>&1
-      tail -1 $G/gpurun_out/boot_${R}_$c.log | cut -c1-200
+      timeout 1200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $D/boot_${R}_$c -- python $G/tools/boot_wide_profile.py run 64 16 2 2 > $D/boot_${R}_$c.log 2>&1
+      tail -1 $D/boot_${R}_$c.log | cut -c1-200
     done
     cd $G
-    python tools/boot_wide_profile.py pmc profiles/${R}_bootstrap_pmc.json 64 2 $(ls -t gpurun_out/boot_${R}_FETCH_SIZE/*/*counter_collection.csv | head -1) $(ls -t gpurun_out/boot_${R}_WRITE_SIZE/*/*counter_collection.csv | head -1) | cut -c1-400
-    python tools/collect_profiles.py $R --pmc-only
+    python tools/boot_wide_profile.py pmc profiles/${R}_bootstrap_pmc.json 64 2 $(ls -t $D/boot_${R}_FETCH_SIZE/*/*counter_collection.csv | head -1) $(ls -t $D/boot_${R}_WRITE_SIZE/*/*counter_collection.csv | head -1) | cut -c1-400
+    FHE_PROFILE_DIR=$D python tools/collect_profiles.py $R --pmc-only
     cp profiles/${R}_pmc_traffic.json profiles/${R}_pmc_valu.json profiles/${R}_bootstrap_pmc.json gpurun_out/ 2>/dev/null
     unset FHE_BENCH_NO_TORCH
     echo "== bench (default flags, as the driver runs it)"
     timeout 1500 python bench.py 2>gpurun_out/bench_$R.err | tail -1 | tee gpurun_out/bench_$R.json | cut -c1-500
     export FHE_BENCH_NO_TORCH=1
     cd /tmp
-    timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $G/gpurun_out/prof_${R}_ntt -- python $G/bench.py --no-bootstrap --no-cc-evalmult --no-cpu-baseline --no-parity --no-evalmult --no-bfv --no-hadamard --no-lt > $G/gpurun_out/prof_${R}_ntt.log 2>&1
-    timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $G/gpurun_out/prof_${R}_evalmult -- python $G/bench.py --no-bootstrap --no-cc-evalmult --batch 8 --steps 1 --warmup 0 --no-cpu-baseline --no-parity --no-bfv --no-hadamard --no-lt > $G/gpurun_out/prof_${R}_evalmult.log 2>&1
+    timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $D/prof_${R}_ntt -- python $G/bench.py --no-bootstrap --no-cc-evalmult --no-cpu-baseline --no-parity --no-evalmult --no-bfv --no-hadamard --no-lt > $D/prof_${R}_ntt.log 2>&1
+    timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $D/prof_${R}_evalmult -- python $G/bench.py --no-bootstrap --no-cc-evalmult --batch 8 --steps 1 --warmup 0 --no-cpu-baseline --no-parity --no-bfv --no-hadamard --no-lt > $D/prof_${R}_evalmult.log 2>&1
     cd $G
-    f=$(ls -t gpurun_out/prof_${R}_ntt/*/*kernel_stats.csv | head -1); head -6 $f | cut -c1-170
-    f=$(ls -t gpurun_out/prof_${R}_evalmult/*/*kernel_stats.csv | head -1); head -10 $f | cut -c1-170 ;;
+    f=$(ls -t $D/prof_${R}_ntt/*/*kernel_stats.csv | head -1); cp $f gpurun_out/${R}_rocprof_kernel_stats_ntt_leg.csv; head -6 $f | cut -c1-170
+    f=$(ls -t $D/prof_${R}_evalmult/*/*kernel_stats.csv | head -1); cp $f gpurun_out/${R}_rocprof_kernel_stats_evalmult256.csv; head -10 $f | cut -c1-170 ;;
   abl)   # timing-only ablation builds of the library (tools/ablr5/*.so, built here with -DFHE_ABL_*; results are wrong: --no-parity)
     for lib in "" "$@"; do
       name=${lib:-default}
