@@ -129,8 +129,8 @@ class BootBatch:
         out = {}
         for ln in buf.value.decode().split("\n"):
             f = ln.split()
-            if len(f) >= 5:
-                out[f[0]] = int(f[4])
+            if len(f) >= 5:  # "<name (may hold blanks)> deviceOps hostOps hostReads operandBytes"
+                out[" ".join(f[:-4])] = int(f[-1])
         return out
 
     def save_outputs(self):
