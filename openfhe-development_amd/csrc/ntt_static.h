@@ -35,6 +35,38 @@ struct BflyZero {
 // first stage below 2q with one quotient estimate each.
 constexpr int kFwdGrow = 3;
 
+// ---- the generated code's arithmetic restated in C++ (round 5; the path of the lane emulator and of FHE_NO_BFLY_ASM builds).  Until
+// round 4 this path used exact quotients and `% 2q`: the CPU suite could not see a wrong lazy bound, a wrong pairing of SPlan with
+// schedule_fwd, or a bad quotient estimate.  Now it computes what ntt_bfly_pinned.h computes (tools/gen_ntt_asm.py: fwd_stream,
+// red_stream) and checks the bounds the schedule promises, value by value.
+// y * w - Q' * q  (mod 2^64) with the TRUNCATED Shoup quotient Q' = y_h p_h + floor((y_h p_l + y_l p_h) / 2^32): in [0, 3q)
+FHE_HD uint64_t shoup_trunc(uint64_t y, const TwPair w, uint64_t nq) {
+    const uint64_t yl = (uint32_t)y, yh = y >> 32, pl = (uint32_t)w.wp, ph = w.wp >> 32;
+    const unsigned __int128 mid = (unsigned __int128)(yh * pl) + (unsigned __int128)(yl * ph);
+    const uint64_t Q            = yh * ph + (uint64_t)(mid >> 32);
+    return y * w.w + Q * nq;
+}
+// any 64-bit x -> x - k q in [0, 2q): k = ((x >> 32) * redM >> 32) >> redR  (red_stream); limbs below 2^35 (redR == 255) take the ladder of
+// three conditional subtractions, which needs x < 16q (red_slow_stream)
+FHE_HD uint64_t red_estimate(uint64_t x, const BflyConst c) {
+    if (c.redR == 255u)
+        return csub2(csub2(csub2(x, c.q << 3), c.q << 2), c.twoq);
+    const uint64_t nq = ((uint64_t)c.nqh << 32) | c.nql;
+    const uint32_t k  = (uint32_t)(((x >> 32) * (uint64_t)c.redM) >> 32) >> c.redR;
+    return x + (uint64_t)k * nq;
+}
+#if defined(FHE_EMU)
+#define FHE_BOUND_CHECK(cond, what)                                                                  \
+    do {                                                                                             \
+        if (!(cond)) {                                                                               \
+            fprintf(stderr, "ntt_static: lazy-range violation in the emulator: %s\n", what);       \
+            abort();                                                                                 \
+        }                                                                                            \
+    } while (0)
+#else
+#define FHE_BOUND_CHECK(cond, what) ((void)0)
+#endif
+
 // compile-time plan of one pass: the same grouping of the T stages into register-resident steps as plan_pass()
 template <bool LA, bool INV, int T>
 struct SPlan {
@@ -165,11 +197,19 @@ FHE_HD void run_stage(uint64_t (&r)[16], const TwPair (&w)[8], const BflyConst c
         inv_lazy_stage_cpp(B, r, w, c, bnd);
         return;
     }
+    // fwd_stream: a' = a + T, b' = a - T + 3q with T = shoup_trunc(b, w) in [0, 3q); `bnd` = the bound (units of q) the schedule
+    // promises for every residue: the butterfly needs bound(a) + 3 <= 16 (16q < 2^64 for q < 2^60), whatever b is
     const uint64_t nq = ((uint64_t)c.nqh << 32) | c.nql;
     for (int g = 0; g < (8 >> B); ++g)
         for (int lo = 0; lo < (1 << B); ++lo) {
-            const int k0 = (g << (B + 1)) | lo;
-            bfly_fwd_fast(r[k0], r[k0 | (1 << B)], w[g], nq, c.twoq);
+            const int k0 = (g << (B + 1)) | lo, k1 = k0 | (1 << B);
+            FHE_BOUND_CHECK(bnd[k0] + (uint32_t)kFwdGrow <= 16u, "a forward butterfly whose `a` input may exceed 13q");
+            FHE_BOUND_CHECK((unsigned __int128)r[k0] < (unsigned __int128)bnd[k0] * c.q, "a residue above its scheduled bound");
+            const uint64_t a = r[k0], T = shoup_trunc(r[k1], w[g], nq);
+            FHE_BOUND_CHECK(T < c.threeq, "a truncated Shoup product of 3q or more");
+            r[k0]   = a + T;
+            r[k1]   = a - T + c.threeq;
+            bnd[k0] = bnd[k1] = bnd[k0] + (uint32_t)kFwdGrow;
         }
 #endif
 }
@@ -239,8 +279,10 @@ FHE_HD void run_red8_a(uint64_t (&r)[16], const BflyConst c) {
     if constexpr (B == 3) red8_a3(r, c);
 #else
     for (int k = 0; k < 16; ++k)
-        if (!((k >> B) & 1))
-            r[k] %= c.twoq;
+        if (!((k >> B) & 1)) {
+            r[k] = red_estimate(r[k], c);
+            FHE_BOUND_CHECK(r[k] < c.twoq, "a quotient-estimate reduction that left 2q or more");
+        }
 #endif
 }
 // every residue below 2q (any 64-bit value before)
@@ -248,8 +290,10 @@ FHE_HD void run_red16(uint64_t (&r)[16], const BflyConst c) {
 #ifdef FHE_PINNED_ASM
     red16(r, c);
 #else
-    for (int k = 0; k < 16; ++k)
-        r[k] %= c.twoq;
+    for (int k = 0; k < 16; ++k) {
+        r[k] = red_estimate(r[k], c);
+        FHE_BOUND_CHECK(r[k] < c.twoq, "a quotient-estimate reduction that left 2q or more");
+    }
 #endif
 }
 // residues I and I|8 times the Shoup pair `cw`, lazily reduced to [0,2q)
@@ -409,11 +453,14 @@ FHE_HD void exec_stage(uint64_t (&r)[16], const TwPair (&w)[8], const BflyConst 
 // the twiddle loads of a stage are issued before the butterflies of the previous stage (the asm blocks are
 // scheduling barriers, so the order written here is the order executed)
 template <bool LA, bool INV, int T, int I, bool ENDS, bool LAZYOUT>
-FHE_HD void run_step(uint64_t (&r)[16], const TwSrc ts, uint32_t j0, uint32_t logN, const BflyConst c, const BflyZero z) {
+FHE_HD void run_step(uint64_t (&r)[16], const TwSrc ts, uint32_t j0, uint32_t logN, const BflyConst c, const BflyZero z,
+                     uint32_t inBound = 2) {
     TwPair w0[8], w1[8], w2[8], w3[8];
-    uint32_t bnd[16];  // lazy bounds of an inverse step (C++ build only; every step starts below 2q)
+    // lazy bounds in units of q (C++ build only): an inverse step starts below 2q; a forward step starts with what the schedule
+    // promises for the `a` inputs of its first stage (inBound: 2 behind a sweep, else SPlan::boundBefore)
+    uint32_t bnd[16];
     for (int k = 0; k < 16; ++k)
-        bnd[k] = 2;
+        bnd[k] = INV ? 2u : inBound;
     constexpr int B0 = INV ? 0 : 3, B1 = INV ? 1 : 2, B2 = INV ? 2 : 1, B3 = INV ? 3 : 0;
     load_stage_tw<LA, INV, T, I, B0, ENDS>(w0, ts, j0, logN);
     load_stage_tw<LA, INV, T, I, B1, ENDS>(w1, ts, j0, logN);
@@ -639,7 +686,8 @@ FHE_DEV void ntt_static_core(const NttPassArgs& a, uint32_t bid, uint64_t* lds, 
            (< 2^64) is, so only the 8 `a` inputs of the step's first stage go back below 2q */                      \
         if constexpr (!INV && P::sweep(I, BIN))                                                                  \
             run_red8_a<P::bHi(I)>(r, c);                                                                          \
-        run_step<LA, INV, T, I, (INV && MODE == 1), LAZYOUT>(r, ts, jbase + jrel, logN, c, z);                     \
+        run_step<LA, INV, T, I, (INV && MODE == 1), LAZYOUT>(r, ts, jbase + jrel, logN, c, z,                      \
+                                                             (uint32_t)(P::sweep(I, BIN) ? 2 : P::boundBefore(I, BIN)));  \
         if constexpr (I == P::nst - 1) {                                                                          \
             if (canonOut) {                                                                                       \
                 if constexpr (INV)                                                                                \

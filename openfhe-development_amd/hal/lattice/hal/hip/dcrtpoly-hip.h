@@ -1411,7 +1411,9 @@ private:
     }
     // this += / -= rhs recorded as terms, when either side is a pending sum (wide towers)
     bool AddLazily(const DCRTPolyType& rhs, bool minus) {
-        if (!LazySums() || (!PendingSum() && !rhs.PendingSum()) || !Compatible(rhs, false))
+        // (FHE_HAL_LAZY_ADDS=1, round-5 experiment: EVERY sum of wide towers is recorded, not only those that join a pending sum)
+        static const bool every = std::getenv("FHE_HAL_LAZY_ADDS") && std::string(std::getenv("FHE_HAL_LAZY_ADDS")) == "1";
+        if (!LazySums() || (!every && !PendingSum() && !rhs.PendingSum()) || !Compatible(rhs, false))
             return false;
         const uint32_t k = std::max(m_k, rhs.m_k);
         if (k == 1 || (m_k != k && !m_zero) || rhs.m_k != k)
