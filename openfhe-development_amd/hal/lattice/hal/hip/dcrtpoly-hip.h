@@ -1411,9 +1411,10 @@ private:
     }
     // this += / -= rhs recorded as terms, when either side is a pending sum (wide towers)
     bool AddLazily(const DCRTPolyType& rhs, bool minus) {
-        // (FHE_HAL_LAZY_ADDS=1, round-5 experiment: EVERY sum of wide towers is recorded, not only those that join a pending sum)
-        static const bool every = std::getenv("FHE_HAL_LAZY_ADDS") && std::string(std::getenv("FHE_HAL_LAZY_ADDS")) == "1";
-        if (!LazySums() || (!every && !PendingSum() && !rhs.PendingSum()) || !Compatible(rhs, false))
+        // (only sums that join a pending sum are recorded: recording EVERY sum of wide towers was measured — 47.9 against 51.4
+        // bootstraps/s, 43.1 against 38.3 GB of operands, profiles/r05_sweeps.md: a lone a += b settles at once and pays the
+        // weighted-sum kernel for a plain addition)
+        if (!LazySums() || (!PendingSum() && !rhs.PendingSum()) || !Compatible(rhs, false))
             return false;
         const uint32_t k = std::max(m_k, rhs.m_k);
         if (k == 1 || (m_k != k && !m_zero) || rhs.m_k != k)
