@@ -429,7 +429,8 @@ fhe_status fhe_scale_and_round_behz_decrypt(fhe_ctx* ctx, const uint64_t* x, con
  * Bsk = B ∪ {m_sk} (context limbs bskLimbIdx, numQ+1 of them, m_sk last), plaintext modulus t, m̃ = 2^16.
  * fhe_param_behz_bsk returns the Bsk moduli/roots the reference would pick (:682-711) so that a caller can put them
  * into the context; it returns numQ+1, or 0 if m_sk would need more than 60 bits.
- * Towers are x[batch][numQ+numBsk][N].
+ * Towers are x[batch][numQ+numBsk][N].  numQ <= 63 (a tower of Q and Bsk limbs has at most 127 rows): up to 15 Q limbs run on kernels that
+ * keep one coefficient's residues in registers, 16 ... 63 on kernels that keep them in a per-lane array (same exact sums, same residues).
  *   fhe_behz_q_to_bsk  = FastBaseConvqToBskMontgomery (dcrtpoly-impl.h:1694-1786): Q rows in `evalFormat` on entry,
  *                        all rows EVALUATION on return (ws: fhe_behz_workspace_bytes, only needed for EVALUATION input);
  *   fhe_behz_floorq    = FastRNSFloorq (:1791-1840), COEFFICIENT, in place;
