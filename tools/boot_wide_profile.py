@@ -104,6 +104,7 @@ def pmc(trace_csv, counter_csvs, cts, reps, out_json):
     import hashlib
     import json
     tot = {}
+    expected = int(os.environ["FHE_PMC_EXPECTED_LAUNCHES"]) if os.environ.get("FHE_PMC_EXPECTED_LAUNCHES") else None
     for path in counter_csvs:
         tr = path.replace("counter_collection.csv", "kernel_trace.csv")
         rows = []
@@ -113,7 +114,12 @@ def pmc(trace_csv, counter_csvs, cts, reps, out_json):
         rows.sort()
         n = len(rows)
         gaps = sorted(((rows[i + 1][0] - rows[i][1], i) for i in range(n // 4, n - 1)), reverse=True)
-        cut = min(i for _, i in gaps[:reps + 1])
+        if expected is None:  # the first run: the tail behind the first of the longest pauses, as summarise() takes it
+            cut = min(i for _, i in gaps[:reps + 1])
+            expected = n - cut - 1
+        else:  # the other runs: the pause (of the 12 longest) whose tail has the launch count closest to the first run's — the counter passes
+            # serialise kernels and stretch other pauses (key generation, the narrow pass) beyond those between the lockstep passes
+            cut = min((i for _, i in gaps[:12]), key=lambda i: abs((n - i - 1) - expected))
         tail = {d for _, _, d in rows[cut + 1:]}
         with open(path, newline="") as f:
             for r in csv.DictReader(f):
