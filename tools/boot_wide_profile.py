@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel-time census of the LOCKSTEP bootstrap (config 4's headline path): run under `rocprofv3 --kernel-trace`, then summarise.
 
-  rocprofv3 --kernel-trace --output-format csv -d OUT -- python tools/boot_wide_profile.py run [cts] [group] [reps] [host threads]
+  rocprofv3 --kernel-trace --output-format csv -d OUT -- python tools/boot_wide_profile.py run [cts] [group] [reps] [host threads] [threads of the narrow pass]
   python tools/boot_wide_profile.py summarise OUT/.../*_kernel_trace.csv [reps] > profiles/r04_bootstrap_wide_kernels.txt
 
 `run` bootstraps `cts` ciphertexts once over host threads (first use of every composite), then `reps` + 1 times in lockstep groups;
@@ -15,17 +15,33 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run(cts, group, reps, threads=1):
+MARKER = "checksum_kernel"  # a kernel the bootstrap never launches: run() brackets the lockstep passes with it
+
+
+def run(cts, group, reps, threads=1, narrow_threads=8):
     sys.path.insert(0, ROOT)
+    import numpy as np
     from openfhe_amd import boot_batch as bb
+    from openfhe_amd import fhe_hip as fh
     prng = os.path.join(ROOT, "tests", "hal", "_build", "libdetprng.so")
     os.environ.setdefault("FHE_HIP_LIB", os.path.join(ROOT, "openfhe-development_amd", "csrc", "libfhe_hip.so"))
-    r = bb.run_rank(17, 1 << 16, cts, 8, 1, 0, prng, warmup=0, key_threads=8)
+    r = bb.run_rank(17, 1 << 16, cts, narrow_threads, 1, 0, prng, warmup=0, key_threads=8)
     h = r.pop("handle")
     h.save_outputs()
+    # phase markers for the trace readers below (summarise / pmc): one launch of fhe_checksum's kernel before and after the lockstep passes
+    mlib = fh.Lib()
+    mq, mpsi = mlib.dcrt_chain(12, 1, 60)
+    mctx = fh.Context(mlib, 12, mq, mpsi)
+    mt = mctx.tower(np.zeros((1, 1, 4096), np.uint64))
+
+    def mark():
+        mctx.checksum(mt)
+        mctx.sync()
+    mark()
     c0 = h.counters()
     sec = h.bootstrap_wide(group, reps, threads)
     c1 = h.counters()
+    mark()
     n = (reps + 1) * cts
     print(f"lockstep: {cts / sec:.2f} bootstraps/s, groups of {group} over {threads} host thread(s); differing outputs {h.compare_saved()}; per bootstrap: "
           f"{(c1['launches'] - c0['launches']) / n:.1f} launches, "
@@ -72,6 +88,12 @@ def summarise(path, cts, reps):
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
+    marks = [i for i, r in enumerate(rows) if MARKER in r[2]]
+    if len(marks) >= 2:  # (run() brackets the lockstep passes with marker launches)
+        rows = rows[marks[0] + 1:marks[-1]] + rows[:0]
+        marked = True
+    else:
+        marked = False
     # the lockstep passes are the tail: reps + 1 equal passes; take the last one by launch count
     total = len(rows)
     # find the start of the lockstep phase: the longest gap in the second half of the trace precedes pack/unpack of a pass; simpler:
@@ -81,7 +103,7 @@ def summarise(path, cts, reps):
     cuts = sorted(i for _, i in gaps[:reps + 1])
     # (the narrow pass ends with the longest pause — the outputs are saved, the first wide ciphertext is packed — so the tail behind
     # the FIRST of the largest gaps holds all reps + 1 lockstep passes)
-    last = rows[cuts[0] + 1:] if cuts else rows
+    last = rows if marked else (rows[cuts[0] + 1:] if cuts else rows)
     passes = reps + 1
     busy = sum(e - s for s, e, _ in last)
     span = last[-1][1] - last[0][0]
@@ -113,6 +135,20 @@ def pmc(trace_csv, counter_csvs, cts, reps, out_json):
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Dispatch_Id"])))
         rows.sort()
         n = len(rows)
+        names = {}
+        with open(tr if os.path.exists(tr) else trace_csv, newline="") as f:
+            for r in csv.DictReader(f):
+                if MARKER in r["Kernel_Name"]:
+                    names[int(r["Dispatch_Id"])] = 1
+        mk = [i for i, r in enumerate(rows) if r[2] in names]
+        if len(mk) >= 2:  # run()'s marker launches bracket the lockstep passes exactly
+            tail = {d for _, _, d in rows[mk[0] + 1:mk[-1]]}
+            with open(path, newline="") as f:
+                for r in csv.DictReader(f):
+                    if int(r["Dispatch_Id"]) in tail:
+                        tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+            tot["launches_" + os.path.basename(os.path.dirname(os.path.dirname(path)))] = len(tail)
+            continue
         gaps = sorted(((rows[i + 1][0] - rows[i][1], i) for i in range(n // 4, n - 1)), reverse=True)
         if expected is None:  # the first run: the tail behind the first of the longest pauses, as summarise() takes it
             cut = min(i for _, i in gaps[:reps + 1])
@@ -150,6 +186,6 @@ if __name__ == "__main__":
         pmc(None, sys.argv[5:], int(sys.argv[3]), int(sys.argv[4]), sys.argv[2])
     elif sys.argv[1] == "run":
         run(int(sys.argv[2]) if len(sys.argv) > 2 else 32, int(sys.argv[3]) if len(sys.argv) > 3 else 32, int(sys.argv[4]) if len(sys.argv) > 4 else 2,
-            int(sys.argv[5]) if len(sys.argv) > 5 else 1)
+            int(sys.argv[5]) if len(sys.argv) > 5 else 1, int(sys.argv[6]) if len(sys.argv) > 6 else 8)
     else:
         summarise(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 32, int(sys.argv[4]) if len(sys.argv) > 4 else 2)

@@ -77,13 +77,14 @@ PY
     cd $G
     f=$(ls -t $D/prof_${R}_ntt/*/*kernel_stats.csv | head -1); cp $f gpurun_out/${R}_rocprof_kernel_stats_ntt_leg.csv; head -6 $f | cut -c1-170
     f=$(ls -t $D/prof_${R}_evalmult/*/*kernel_stats.csv | head -1); cp $f gpurun_out/${R}_rocprof_kernel_stats_evalmult256.csv; head -10 $f | cut -c1-170 ;;
-  bootpmc)  # only the lockstep bootstrap's FETCH / WRITE counter passes (a pass that crashed in the record session is repeated up to 3 times)
+  bootpmc)  # only the lockstep bootstrap's FETCH / WRITE counter passes, on ONE host thread throughout (rocprofv3 --pmc segfaults on the
+            # multi-threaded program in most runs; the launches and their bytes are the same whatever the number of host threads)
     R=${1:-r05}; G=$GRAFT_REPO_ROOT; D=/tmp/rec; mkdir -p $D
     cd /tmp && export TMPDIR=/tmp
     for c in FETCH_SIZE WRITE_SIZE; do
       for try in 1 2 3; do
         rm -rf $D/boot_${R}_$c
-        timeout 1200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $D/boot_${R}_$c -- python $G/tools/boot_wide_profile.py run 64 16 2 2 > $D/boot_${R}_$c.log 2>&1 && break
+        timeout 1200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $D/boot_${R}_$c -- python $G/tools/boot_wide_profile.py run 64 16 2 1 1 > $D/boot_${R}_$c.log 2>&1 && break
         echo "pass $c failed (try $try)"
       done
       tail -1 $D/boot_${R}_$c.log | cut -c1-200
