@@ -89,8 +89,9 @@ def summarise(path, cts, reps):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
     marks = [i for i, r in enumerate(rows) if MARKER in r[2]]
-    if len(marks) >= 2:  # (run() brackets the lockstep passes with marker launches)
-        rows = rows[marks[0] + 1:marks[-1]] + rows[:0]
+    if len(marks) >= 2:  # (run() brackets the lockstep passes with marker launches: the LAST two — the first-use checks of the narrow pass
+        # launch the same kernel)
+        rows = rows[marks[-2] + 1:marks[-1]]
         marked = True
     else:
         marked = False
@@ -141,8 +142,8 @@ def pmc(trace_csv, counter_csvs, cts, reps, out_json):
                 if MARKER in r["Kernel_Name"]:
                     names[int(r["Dispatch_Id"])] = 1
         mk = [i for i, r in enumerate(rows) if r[2] in names]
-        if len(mk) >= 2:  # run()'s marker launches bracket the lockstep passes exactly
-            tail = {d for _, _, d in rows[mk[0] + 1:mk[-1]]}
+        if len(mk) >= 2:  # run()'s LAST two marker launches bracket the lockstep passes exactly (the narrow pass's first-use checks launch it too)
+            tail = {d for _, _, d in rows[mk[-2] + 1:mk[-1]]}
             with open(path, newline="") as f:
                 for r in csv.DictReader(f):
                     if int(r["Dispatch_Id"]) in tail:
