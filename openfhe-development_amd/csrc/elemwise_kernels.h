@@ -452,5 +452,29 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) checksum_kernel(const ChecksumArgs g
     }
 }
 
+
+// rows [first, first + nRows) of every tower of out[batch][stride][N] set to zero (round 5).  hipMemset2DAsync runs this shape — 16 towers
+// x 8 MiB, 8-row pitch gaps — at ~130 GB/s (1 ms per call in the lockstep bootstrap's census: 5 % of its kernel time for the P rows of
+// KeySwitchExt); one 32 KiB tile per workgroup with 16-byte stores runs at copy speed.
+struct ZeroRowsArgs {
+    uint64_t* out;
+    uint32_t logN, stride, first, nRows, batch;
+};
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) zero_rows_kernel(const ZeroRowsArgs g) {
+    const uint64_t words = ((uint64_t)g.batch * g.nRows) << g.logN;
+    const uint64_t base  = (uint64_t)FHE_BID * kTile;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {  // 16 words per lane as 8 two-word pieces, 256 lanes side by side
+        const uint64_t w = base + ((uint64_t)k * kThreads + FHE_TID) * 2;
+        if (w >= words)
+            continue;
+        const uint64_t row = w >> g.logN, col = w & (((uint64_t)1 << g.logN) - 1u);
+        const uint64_t tb = row / g.nRows, r = row % g.nRows;
+        uint64_t* d = g.out + (((tb * g.stride + g.first + r)) << g.logN) + col;
+        d[0] = 0;
+        d[1] = 0;
+    }
+}
+
 }  // namespace fhe
 #endif

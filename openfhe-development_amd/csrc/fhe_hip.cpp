@@ -1195,6 +1195,15 @@ extern "C" fhe_status fhe_mult_acc(fhe_ctx* c, uint64_t* acc, const uint64_t* v,
 }
 // DCRTPolyImpl::ExpandCRTBasisQlHat (dcrtpoly-impl.h:1167-1187): limbs [0, sizeQl) times QlHatModq[i], limbs [sizeQl, sizeQ)
 // zero; x [batch][sizeQl][N] -> out [batch][sizeQ][N] over context limbs limbIdx[0..sizeQ) (format unchanged)
+// rows [first, first + nRows) of every tower of out[batch][stride][N] = 0, at copy speed (zero_rows_kernel, elemwise_kernels.h)
+static fhe_status zero_rows(const fhe_ctx* c, uint64_t* out, uint32_t stride, uint32_t first, uint32_t nRows, uint32_t batch, void* st) {
+    if (!nRows || !batch)
+        return FHE_OK;
+    ZeroRowsArgs g{out, c->logN, stride, first, nRows, batch};
+    FHE_LAUNCH(zero_rows_kernel, tiles_for(c, (uint64_t)batch * nRows), st, g);
+    LAUNCH_CHECK();
+    return FHE_OK;
+}
 extern "C" fhe_status fhe_expand_crt_basis_ql_hat(fhe_ctx* c, const uint64_t* x, uint32_t sizeQl, const uint64_t* QlHatModq,
                                                   const uint32_t* li, uint32_t sizeQ, uint32_t bt, uint64_t* out, void* st) {
     ARG_CHECK(c && x && out && QlHatModq, "fhe_expand_crt_basis_ql_hat: null argument");
@@ -1206,9 +1215,8 @@ extern "C" fhe_status fhe_expand_crt_basis_ql_hat(fhe_ctx* c, const uint64_t* x,
     for (uint32_t i = sizeQl; i < sizeQ; ++i)
         ARG_CHECK((li ? li[i] : i) < c->L, "fhe_expand_crt_basis_ql_hat: limb index exceeds context size");
     RT_CHECK(rt::set_device(c->device));
-    const size_t rowB = (size_t)8 << c->logN;
-    if (sizeQ > sizeQl)
-        RT_CHECK(rt::dzero_2d(out + ((size_t)sizeQl << c->logN), sizeQ * rowB, (sizeQ - sizeQl) * rowB, bt, (rt::stream_t)st));
+    if (fhe_status s = zero_rows(c, out, sizeQ, sizeQl, sizeQ - sizeQl, bt, st))
+        return s;
     return elem_cv_run<OP_MUL_CONST>(c, out, x, nullptr, cv, li, sizeQl, bt, st, "fhe_expand_crt_basis_ql_hat", sizeQ, 0);
 }
 
@@ -2172,8 +2180,8 @@ extern "C" fhe_status fhe_ks_ext(fhe_ks_plan* p, const uint64_t* cin, uint32_t s
     if (fhe_status s = ks_pmodq(p, lv, &dP))
         return s;
     const uint32_t sizeQlP = sizeQl + p->sizeP;
-    const size_t rowB      = (size_t)8 << c->logN;
-    RT_CHECK(rt::dzero_2d(out + ((size_t)sizeQl << c->logN), sizeQlP * rowB, p->sizeP * rowB, batch, (rt::stream_t)st));
+    if (fhe_status s = zero_rows(c, out, sizeQlP, sizeQl, p->sizeP, batch, st))
+        return s;
     return elem_run<OP_MUL_CONST>(c, out, cin, nullptr, dP, nullptr, sizeQl, batch, st, "fhe_ks_ext", 0, 0, 0, 0, sizeQlP, 0);
 }
 // EvalFastKeySwitchCoreExt on digits already in the workspace (fhe_ks_precompute): out0/out1 [batch][sizeQl+sizeP][N]
@@ -2462,8 +2470,8 @@ extern "C" fhe_status fhe_ckks_bsgs_transform(fhe_ks_plan* p, const uint64_t* c0
         if (fhe_status s = automorph_sum_run(c, outer, src0, k0, extIdx.data(), sizeQlP, batch, st))
             return s;
     }
-    else
-        RT_CHECK(rt::dzero_2d(outer, ext * 8, ext * 8, 1, (rt::stream_t)st));
+    else if (fhe_status s = zero_rows(c, outer, sizeQlP, 0, sizeQlP, batch, st))
+        return s;
     if (fhe_status s = automorph_sum_run(c, outer + ext, src1, k1, extIdx.data(), sizeQlP, batch, st))
         return s;
     // 8. result = KeySwitchDown(outer); result[0] += first  (:1879-1880)
