@@ -60,7 +60,8 @@ PY
     (echo "# rocprofv3 --kernel-trace of \`tools/boot_wide_profile.py run 64 16 2 2\` (round 5 record: 64 ciphertexts at config 4's shape, lockstep groups of 16 on 2 host threads — bench.py's setting — 3 passes)"; tail -1 $D/boot_${R}_trace.log; python $G/tools/boot_wide_profile.py summarise $f 64 2) > $G/gpurun_out/${R}_bootstrap_wide_kernels.txt
     head -16 $G/gpurun_out/${R}_bootstrap_wide_kernels.txt | cut -c1-150
     for c in FETCH_SIZE WRITE_SIZE; do
-      timeout 1200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $D/boot_${R}_$c -- python $G/tools/boot_wide_profile.py run 64 16 2 2 > $D/boot_${R}_$c.log 2>&1
+      # (ONE host thread throughout: rocprofv3 --pmc segfaults on the multi-threaded program in most runs; same launches, same bytes)
+      timeout 1200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $D/boot_${R}_$c -- python $G/tools/boot_wide_profile.py run 64 16 2 1 1 > $D/boot_${R}_$c.log 2>&1
       tail -1 $D/boot_${R}_$c.log | cut -c1-200
     done
     cd $G
