@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""copies the judged summaries of the last `tools/gpu_record.sh <tag>` run from gpurun_out/ (scratch) into profiles/"""
+"""copies the judged summaries of the last `tools/gpu_session.sh record <tag>` run from gpurun_out/ (scratch) into profiles/"""
 import collections, csv, glob, hashlib, json, os, shutil, sys
 
 
@@ -44,7 +44,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for k, v in agg.items():
         res.setdefault(k, {})[c] = sum(v) / len(v)
 out = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --steps 2 "
-               "--warmup 1 --no-cpu-baseline --no-evalmult` (N=2^16, L=30, B=1024), tools/gpu_record.sh. Counter units are "
+               "--warmup 1 --no-cpu-baseline --no-evalmult` (N=2^16, L=30, B=1024), tools/gpu_session.sh record. Counter units are "
                "KiB; FETCH_SIZE is doubled (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md §HBM).",
        "workload": "logN16_L30_B1024", "per_launch_bytes": {},
        # identity of the kernel sources ON THE GPU BOX in that run (bench.py recorded it in its own line)
@@ -68,7 +68,7 @@ def short(name):
 
 
 valu = {"_how": "rocprofv3 --kernel-trace --pmc " + " ".join(SQ) + " (one pass, 8 SQ slots) on `python bench.py --steps 2 --warmup 1 ...` (NTT leg: "
-                "N=2^16, L=30, B=1024) and on the EvalMult leg at batch 256 (tools/gpu_record.sh). SQ_*_CYCLES and SQ_ACTIVE_INST_* count "
+                "N=2^16, L=30, B=1024) and on the EvalMult leg at batch 256 (tools/gpu_session.sh record). SQ_*_CYCLES and SQ_ACTIVE_INST_* count "
                 "quad-cycles per wave (MI355X_MICROARCH.md); values are averages per launch.",
         "kernel_source_sha": out["kernel_source_sha"], "legs": {}}
 for leg in ("ntt", "evalmult"):

@@ -1,6 +1,7 @@
 #!/bin/bash
 # One parameterised record script for the round's GPU sessions (replaces the per-session tools/gpu_session_rNN_x.sh files).
 #   usage: gpurun --timeout T -- tools/gpu_session.sh <session> [args...]        output: gpurun_out/<session>_*.{json,log}
+# (the one-shot session scripts of rounds 2-4 — gpu_session_*.sh, gpu_record.sh — are in the history: `git show 12b9d21:tools/`)
 # (the sessions of the rejected round-5 NTT experiments — chunks, persist, t1 — are in commit 3b1f4e6 together with their kernels)
 # sessions:
 #   mall          tools/mallbench (Infinity-Cache go/no-go) + the headline leg at --batch 2,4,8,16,64,1024
