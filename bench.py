@@ -51,12 +51,11 @@ def parse():
     ap.add_argument("--bootstrap-batch", type=int, default=64, help="ciphertexts per GPU in the bootstrap leg (BASELINE configs[3]: 512 over 8 GPUs = 64 per GPU; "
                                                                      "the driver's 1-GPU run is one rank's share)")
     ap.add_argument("--bootstrap-wide-threads", type=int, default=2,
-                    help="host threads (= streams) the lockstep groups of the bootstrap leg are spread over (16 x 2: 47.8 / 50.2 bootstraps/s, "
-                         "32 x 1: 45.1 / 49.1 as the first / second setting after the threaded pass, the device 95-98 %% busy; about 32 "
-                         "ciphertexts in flight fit the 288 GB: profiles/r04_sweeps.md sessions g-i)")
+                    help="host threads (= streams) the lockstep groups of the bootstrap leg are spread over (round 5: 16 x 2 50.6-51.5, 32 x 2 "
+                         "52.0-52.3, 8 x 4 50.1, 16 x 4 37-40 bootstraps/s: profiles/r05_sweeps.md section 3)")
     ap.add_argument("--bootstrap-group", type=int, default=16,
-                    help="ciphertexts per wide (lockstep) evaluation in the bootstrap leg; 0 = the rank's whole slice (64 at once exceed the "
-                         "288 GB of one GPU with the buffer caches of the pass: profiles/r04_sweeps.md)")
+                    help="ciphertexts per wide (lockstep) evaluation in the bootstrap leg; 0 = the rank's whole slice (one group of 64 needs "
+                         "BSGS workspaces of more than 100 GiB)")
     ap.add_argument("--bootstrap-threads", type=int, default=8, help="host threads (= HIP streams) the rank's ciphertexts are spread over")
     ap.add_argument("--no-cc-evalmult", action="store_true",
                     help="skip the leg that runs BASELINE configs[2]'s EvalMult through the reference's CryptoContext on the HIP backend")
@@ -363,9 +362,9 @@ def evalmult_leg(lib, device, logN, batch, steps, warmup, sync, dist=None, sizeQ
                          "survey_8d_frac": round(ach_survey / HBM_PEAK_GBPS, 4),
                          "byte_counts": "algorithmic_bytes_per_op itemises every stage (DESIGN.md §7); survey_8d_* is SURVEY.md 8(d)'s figure "
                                         "(limb-NTT traffic + the tensor product's 9 limb moves only)",
-                         "dominant_kernel": "ntt_static_kernel (58 % over its four pass kernels; then switch_basis_kernel 16 %, "
+                         "dominant_kernel": "ntt_static_kernel (57 % over its pass kernels; then switch_basis_kernel 16 %, "
                                             "ks_inner_multi_kernel 15 %, tensor_kernel 11 %): shares in "
-                                            "profiles/r04_rocprof_kernel_stats_evalmult256.csv"}}
+                                            "profiles/r05_rocprof_kernel_stats_evalmult256.csv"}}
 
 
 def linear_transform_leg(lib, device, batches, steps, warmup, with_cpu, parity=True):
@@ -798,7 +797,7 @@ def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev,
                   "seconds_per_bootstrap = the same ciphertexts on ONE host thread / stream",
            "parity": "every output decrypted and compared with its message; byte comparison with the stock backend not run", "cpu_baseline": None}
     # the leg's roofline = that of the way of running the batch whose rate is reported (kernel census of the lockstep pass:
-    # profiles/r04_bootstrap_wide_kernels.txt; model and itemisation: DESIGN.md 7.2)
+    # profiles/r05_bootstrap_wide_kernels.txt; model and itemisation: DESIGN.md 7.2 / 7.3)
     if isinstance(wide, dict) and wide.get("bootstraps_per_s", 0.0) >= threaded_rate and "roofline" in wide:
         res["roofline"] = dict(wide["roofline"], path="lockstep groups")
     else:
