@@ -2269,6 +2269,9 @@ public:
     // SharedWords); PackWide of K towers that are consecutive windows of one buffer is that buffer again (no copy), and when it has to
     // copy it leaves the K source towers behind as windows of the packed buffer, so that packing the same operands again — the next
     // operation of a pipeline, the next pass of a benchmark — costs nothing.  Values never change: only which allocation holds them.
+    // (Re-pointing a source happens under that tower's lock, but — like Upload() or any first device use of a tower — it must not run
+    // while ANOTHER host thread is inside an operation on the same tower: the groups of a lockstep evaluation pack disjoint ciphertexts;
+    // shared read-only operands such as keys and plaintexts are never packed.  FHE_HAL_WIDE_VIEWS=0 restores the copying forms.)
     static DCRTPolyType PackWide(const std::vector<const DCRTPolyType*>& towers) {
         hiprt::MemberScope scope("PackWide");
         if (towers.empty())
