@@ -5,7 +5,9 @@
 // ciphertext it produces; tests/test_hal_shim.py compares the two dumps byte for byte and checks the decryptions.
 //
 //   shim_ckks <out.bin> <prng.so> <mode> [logN]      mode: leveled | bootstrap
+#include <atomic>
 #include <chrono>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -28,6 +30,8 @@ extern "C" size_t fhe_hal_launch_stats(char* buf, size_t cap, uint64_t* total) _
 extern "C" uint64_t fhe_hal_memo_hits() __attribute__((weak));
 extern "C" void fhe_hal_device_sync(void) __attribute__((weak));
 extern "C" uint64_t fhe_hal_cached_bytes(void) __attribute__((weak));
+extern "C" void fhe_hal_alloc_stats(uint64_t out[6]) __attribute__((weak));
+static std::atomic<bool> g_release_thread{false};
 extern "C" uint64_t fhe_hal_cached_bytes(void) __attribute__((weak));
 extern "C" void fhe_hal_release_caches(void) __attribute__((weak));
 static std::map<std::string, uint64_t> launches_by_kernel(uint64_t* total) {
@@ -167,6 +171,33 @@ int main(int argc, char** argv) {
         auto e = hiprt::Alloc(M / 8);  // more than 4x smaller than what is cached: a fresh small allocation
         std::cout << "buffers much smaller request leaves the large allocation alone: " << (e->p != pa) << std::endl;
         c.reset(), d.reset(), e.reset();
+        {
+            // round 5: a buffer released by ANOTHER host thread (its free list) serves this thread's request before the device does, ordered
+            // behind that thread's stream; above 1 GiB a size class is a sixteenth of the power of two (34.9 GiB -> 36 GiB, not 48)
+            uint64_t before[6], after[6];
+            const uint64_t* other = nullptr;
+            size_t otherCap       = 0;
+            std::thread t([&] {
+                auto x   = hiprt::Alloc(40 * M);
+                other    = x->p;
+                otherCap = x->cap;
+                x.reset();  // -> that thread's free list; the thread stays alive until the main thread has taken the buffer
+                while (!g_release_thread.load())
+                    std::this_thread::yield();
+            });
+            while (!other || fhe_hal_cached_bytes() < otherCap * 8)
+                std::this_thread::yield();
+            fhe_hal_alloc_stats(before);
+            auto y = hiprt::Alloc(40 * M);
+            fhe_hal_alloc_stats(after);
+            std::cout << "buffers request served from another thread's cache: " << (y->p == other && after[1] == before[1] + 1 && after[2] == before[2])
+                      << std::endl;
+            g_release_thread.store(true);
+            t.join();
+            y.reset();
+            auto big = hiprt::Alloc((size_t)150 * M);  // 1.17 GiB: classes of 1/16 x 2 GiB = 128 MiB above 1 GiB
+            std::cout << "buffers size class above 1 GiB is a sixteenth step: " << (big->cap == (size_t)160 * M) << std::endl;
+        }
         const uint64_t cached2 = fhe_hal_cached_bytes();
         fhe_hal_release_caches();
         std::cout << "buffers released caches: " << cached2 << " -> " << fhe_hal_cached_bytes() << std::endl;
