@@ -51,8 +51,8 @@ def parse():
     ap.add_argument("--bootstrap-batch", type=int, default=64, help="ciphertexts per GPU in the bootstrap leg (BASELINE configs[3]: 512 over 8 GPUs = 64 per GPU; "
                                                                      "the driver's 1-GPU run is one rank's share)")
     ap.add_argument("--bootstrap-wide-threads", type=int, default=2,
-                    help="host threads (= streams) the lockstep groups of the bootstrap leg are spread over (round 5: 16 x 2 50.6-51.5, 32 x 2 "
-                         "52.0-52.3, 8 x 4 50.1, 16 x 4 37-40 bootstraps/s: profiles/r05_sweeps.md section 3)")
+                    help="host threads (= streams) the lockstep groups of the bootstrap leg are spread over (round 5: 16 x 2 49.2-51.5 in every "
+                         "position of a sweep, 8 x 4 50.1, 16 x 4 37-40, 32 x 2 52 with warm caches but 13-17 cold: profiles/r05_sweeps.md section 3)")
     ap.add_argument("--bootstrap-group", type=int, default=16,
                     help="ciphertexts per wide (lockstep) evaluation in the bootstrap leg; 0 = the rank's whole slice (one group of 64 needs "
                          "BSGS workspaces of more than 100 GiB)")
