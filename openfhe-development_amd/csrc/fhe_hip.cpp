@@ -24,6 +24,7 @@
 #include "host_math.h"
 #include "ntt_kernels.h"
 #include "ntt_static.h"
+#include "ntt_row8.h"
 #include "rt.h"
 
 using namespace fhe;
@@ -244,6 +245,7 @@ static uint32_t env_u32(const char* name, uint32_t dflt);
 struct fhe_ctx {
     uint32_t logN = 0, N = 0, L = 0;
     int device    = 0;
+    uint32_t cus  = 0;  // compute units of the device (grid of the persistent row pass, ntt_row8.h)
     std::vector<uint64_t> q, psi;
     // device tables
     TwPair* d_tw      = nullptr;  // [L][N] forward
@@ -297,6 +299,7 @@ extern "C" fhe_status fhe_ctx_create(uint32_t logN, uint32_t nLimbs, const uint6
     c->N       = N;
     c->L       = nLimbs;
     c->device  = device;
+    c->cus     = rt::cu_count(device);
     c->q.assign(q, q + nLimbs);
     c->psi.assign(psi, psi + nLimbs);
 
@@ -652,6 +655,15 @@ static int static_mode(const fhe_ctx* c, const PassPlan& pp, bool inverse) {
     const int fclass = pp.inBound <= 1 ? 1 : 9;  // (9 = what a column pass leaves: below 2q since round 4)
     return inverse ? ((pp.layoutA || !twoPass) ? 1 : 0) : fclass;
 }
+// FHE_NTT_ROW8 (A/B measurements): 0 = the 16-residues-per-lane row pass of ntt_static.h, 1 = ntt_row8.h with one tile per workgroup,
+// 2 (default) = ntt_row8.h persistent and software-pipelined
+static int row8_mode() {
+    static const int m = [] {
+        const char* v = std::getenv("FHE_NTT_ROW8");
+        return v && v[0] >= '0' && v[0] <= '2' ? v[0] - '0' : 2;
+    }();
+    return m;
+}
 static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse, const uint64_t* xin, uint64_t* xout,
                               const LimbSel& sel, uint32_t nLimbs, uint32_t batch, bool canonOut, void* stream,
                               uint32_t inStride = 0, uint32_t inFirst = 0, uint32_t outStride = 0, uint32_t outFirst = 0,
@@ -705,6 +717,31 @@ static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse
         FHE_LAUNCH_BARRIER((ntt_static_kernel<LA, INV, TT, MODE>), grid, stream, a); \
         launched = true; \
     }
+        // row passes of two-pass rings at 8 residues per lane (ntt_row8.h: 8 waves per SIMD, one barrier per tile)
+        if (!pp.layoutA && c->logN > (uint32_t)kTileLog && row8_mode()) {
+            // persistent grid: kPipePerCu workgroups per CU, a multiple of 8 (a workgroup keeps its XCD: tile index = blockIdx mod 8)
+            const uint32_t pgrid = std::min(grid, (r8::kPipePerCu * c->cus) & ~7u);
+            const bool pipe      = row8_mode() == 2 && pgrid >= 8;
+#define FHE_ROW8_CASE(INV, TT, MODE) \
+    if (!launched && inverse == INV && pp.T == TT && mode == MODE) { \
+        if (pipe) \
+            FHE_LAUNCH_BARRIER_N((r8::ntt_row8_pipe_kernel<INV, TT, MODE>), pgrid, r8::kThreads8, stream, a); \
+        else \
+            FHE_LAUNCH_BARRIER_N((r8::ntt_row8_kernel<INV, TT, MODE>), grid, r8::kThreads8, stream, a); \
+        launched = true; \
+    }
+#ifdef FHE_ABL_ROW8_T  // timing experiment: the 12-stage row pass runs only FHE_ABL_ROW8_T of its stages (results are wrong)
+            if (!launched && pp.T == 12 && (inverse ? mode == 0 : mode == 9)) {
+                if (inverse)
+                    FHE_LAUNCH_BARRIER_N((r8::ntt_row8_kernel<true, FHE_ABL_ROW8_T, 0>), grid, r8::kThreads8, stream, a);
+                else
+                    FHE_LAUNCH_BARRIER_N((r8::ntt_row8_kernel<false, FHE_ABL_ROW8_T, 9>), grid, r8::kThreads8, stream, a);
+                launched = true;
+            }
+#endif
+            FHE_ROW8_CASE(false, 12, 9) FHE_ROW8_CASE(true, 12, 0)
+#undef FHE_ROW8_CASE
+        }
         // column passes of logN = 13..16 (T1 = 4) and 17 (T1 = 5); row passes T2 = logN - T1; the single pass of logN = 12
         FHE_STATIC_CASE(true, false, 4, 1) FHE_STATIC_CASE(true, true, 4, 1)
         FHE_STATIC_CASE(true, false, 5, 1) FHE_STATIC_CASE(true, true, 5, 1)

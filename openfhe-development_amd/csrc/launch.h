@@ -15,6 +15,9 @@
 #define FHE_BID (fhe_emu::tls.bid)
 #define FHE_NBLK (fhe_emu::tls.nblk)
 #define FHE_SYNC() fhe_emu::block_sync()
+// exchange between the lanes of ONE wave: the device needs no instruction (LDS operations of a wave execute in order), the emulator's
+// lanes are OS threads and meet at the workgroup barrier (every lane of the workgroup reaches the same FHE_WAVE_SYNC)
+#define FHE_WAVE_SYNC() fhe_emu::block_sync()
 #define FHE_SHARED_U64(name, n) uint64_t* name = reinterpret_cast<uint64_t*>(fhe_emu::block_shared(sizeof(uint64_t) * (n)))
 #define FHE_UNIFORM(x) (x)
 #define FHE_ULOAD64(p, i) ((p)[i])
@@ -29,6 +32,12 @@
 #define FHE_BID (blockIdx.x)
 #define FHE_NBLK (gridDim.x)
 #define FHE_SYNC() __syncthreads()
+#define FHE_WAVE_SYNC()                                         \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
+        __builtin_amdgcn_wave_barrier();                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+    } while (0)
 #define FHE_SHARED_U64(name, n) __shared__ uint64_t name[n]
 #define FHE_UNIFORM(x) (__builtin_amdgcn_readfirstlane(x))
 // Read-only, wave-uniform table word.  Reading it through the constant address space tells the compiler that the

@@ -119,6 +119,12 @@ struct Timer {
         FHE_COUNT_LAUNCH(kernel);                                                                \
         fhe_emu::launch((uint32_t)(grid), fhe::kThreads, [=]() { kernel(__VA_ARGS__); }, true); \
     } while (0)
+// (a workgroup of `threads` lanes instead of fhe::kThreads: the 8-residues-per-lane row pass, ntt_row8.h)
+#define FHE_LAUNCH_BARRIER_N(kernel, grid, threads, stream, ...)                                  \
+    do {                                                                                         \
+        FHE_COUNT_LAUNCH(kernel);                                                                \
+        fhe_emu::launch((uint32_t)(grid), (uint32_t)(threads), [=]() { kernel(__VA_ARGS__); }, true); \
+    } while (0)
 #else
 #include <hip/hip_runtime.h>
 namespace fhe {
@@ -218,5 +224,10 @@ struct Timer {
         hipLaunchKernelGGL(kernel, dim3((uint32_t)(grid)), dim3(fhe::kThreads), 0, (hipStream_t)(stream), __VA_ARGS__); \
     } while (0)
 #define FHE_LAUNCH_BARRIER FHE_LAUNCH  // (the distinction only matters to the lane emulator of the tests)
+#define FHE_LAUNCH_BARRIER_N(kernel, grid, threads, stream, ...)                                                             \
+    do {                                                                                                                    \
+        FHE_COUNT_LAUNCH(kernel);                                                                                           \
+        hipLaunchKernelGGL(kernel, dim3((uint32_t)(grid)), dim3((uint32_t)(threads)), 0, (hipStream_t)(stream), __VA_ARGS__); \
+    } while (0)
 #endif
 #endif

@@ -14,15 +14,16 @@ namespace fhe_emu {
 thread_local Tls tls;
 
 namespace {
-constexpr uint32_t kLanes = 256;
+// one pool of lane threads per workgroup size: 256 (every kernel but one) and 512 (the 8-residues-per-lane row pass, ntt_row8.h)
 struct Pool {
+    const uint32_t kLanes;
     pthread_barrier_t start, stop, sync;
     std::vector<std::thread> workers;
     const std::function<void()>* body = nullptr;
     uint32_t bid = 0, nblk = 0;
     std::atomic<bool> quit{false};
     alignas(64) unsigned char shared[160 * 1024];
-    Pool() {
+    explicit Pool(uint32_t lanes) : kLanes(lanes) {
         pthread_barrier_init(&start, nullptr, kLanes + 1);
         pthread_barrier_init(&stop, nullptr, kLanes + 1);
         pthread_barrier_init(&sync, nullptr, kLanes);
@@ -33,6 +34,7 @@ struct Pool {
                     if (quit.load())
                         return;
                     tls.tid  = t;
+                    tls.pool = this;
                     tls.bid  = bid;
                     tls.nblk = nblk;
                     (*body)();
@@ -47,9 +49,13 @@ struct Pool {
             w.join();
     }
 };
-Pool& pool() {
-    static Pool p;
-    return p;
+Pool& pool(uint32_t lanes) {
+    if (lanes == 512) {
+        static Pool p512(512);
+        return p512;
+    }
+    static Pool p256(256);
+    return p256;
 }
 std::mutex launchMutex;
 }  // namespace
@@ -59,10 +65,10 @@ void block_sync() {
         std::fprintf(stderr, "fhe_emu: a kernel launched with FHE_LAUNCH met a barrier (its launch site must use FHE_LAUNCH_BARRIER)\n");
         std::abort();
     }
-    pthread_barrier_wait(&pool().sync);
+    pthread_barrier_wait(&static_cast<Pool*>(tls.pool)->sync);
 }
 void* block_shared(size_t bytes) {
-    if (bytes > sizeof(pool().shared))
+    if (bytes > sizeof(Pool::shared))
         std::abort();
     if (tls.sequential) {  // (scratch of a kernel without barriers: private to the launching thread)
         static thread_local std::vector<unsigned char> mine;
@@ -70,11 +76,12 @@ void* block_shared(size_t bytes) {
             mine.resize(bytes);
         return mine.data();
     }
-    return pool().shared;
+    return static_cast<Pool*>(tls.pool)->shared;
 }
 void launch(uint32_t grid, uint32_t threads, const std::function<void()>& body, bool laneThreads) {
-    if (threads != kLanes)
+    if (threads != 256 && threads != 512)
         std::abort();
+    const uint32_t kLanes = threads;
     // FHE_EMU_SKIP=1: kernels do nothing (results are garbage).  For measuring the HOST side of a call sequence — pke's and the
     // backend's own time per operation — on a machine without a GPU; never set by the tests.
     static const bool skip = std::getenv("FHE_EMU_SKIP") != nullptr;
@@ -93,7 +100,7 @@ void launch(uint32_t grid, uint32_t threads, const std::function<void()>& body, 
         return;
     }
     std::lock_guard<std::mutex> lk(launchMutex);
-    Pool& p = pool();
+    Pool& p = pool(threads);
     p.body  = &body;
     p.nblk  = grid;
     for (uint32_t b = 0; b < grid; ++b) {

@@ -9,7 +9,7 @@
 #   wide          lockstep tests, cc->EvalMult leg, bootstrap (group x threads) sweep
 #   ut            the reference's unit tests on the GPU with the per-member mirror counts
 #   record [tag]  the round record (PMC passes, bootstrap census + counters, bench line, rocprof kernel stats); then tools/collect_profiles.py tag
-#   abl libs...   the headline leg with each tools/ablr5/libfhe_hip_<lib>.so (timing-only ablations)
+#   abl libs...   the headline leg with each tools/abl6/libfhe_hip_<lib>.so (timing-only ablations)
 #   tests [k]     pytest -m gpu (optionally -k <k>)
 set -u
 S=${1:-help}; shift || true
@@ -93,10 +93,10 @@ PY
     done
     cd $G
     python tools/boot_wide_profile.py pmc gpurun_out/${R}_bootstrap_pmc.json 64 2 $(ls -t $D/boot_${R}_FETCH_SIZE/*/*counter_collection.csv | head -1) $(ls -t $D/boot_${R}_WRITE_SIZE/*/*counter_collection.csv | head -1) | cut -c1-600 ;;
-  abl)   # timing-only ablation builds of the library (tools/ablr5/*.so, built here with -DFHE_ABL_*; results are wrong: --no-parity)
+  abl)   # timing-only ablation builds of the library (tools/abl6/*.so, built here with -DFHE_ABL_*; results are wrong: --no-parity)
     for lib in "" "$@"; do
       name=${lib:-default}
-      FHE_HIP_LIB=${lib:+$PWD/tools/ablr5/libfhe_hip_$lib.so} FHE_BENCH_NO_TORCH=1 timeout 600 python bench.py $NTT_ONLY --no-parity --steps 10 --warmup 2 2>gpurun_out/abl_$name.err | tail -1 > gpurun_out/abl_$name.json
+      FHE_HIP_LIB=${lib:+$PWD/tools/abl6/libfhe_hip_$lib.so} FHE_BENCH_NO_TORCH=1 timeout 600 python bench.py $NTT_ONLY --no-parity --steps 10 --warmup 2 2>gpurun_out/abl_$name.err | tail -1 > gpurun_out/abl_$name.json
       python - "$name" <<'PY'
 import json, sys
 d = json.loads(open(f"gpurun_out/abl_{sys.argv[1]}.json").read())
