@@ -655,14 +655,14 @@ static int static_mode(const fhe_ctx* c, const PassPlan& pp, bool inverse) {
     const int fclass = pp.inBound <= 1 ? 1 : 9;  // (9 = what a column pass leaves: below 2q since round 4)
     return inverse ? ((pp.layoutA || !twoPass) ? 1 : 0) : fclass;
 }
-// FHE_NTT_ROW8 (A/B measurements): 0 = the 16-residues-per-lane row pass of ntt_static.h, 1 = ntt_row8.h with one tile per workgroup,
-// 2 (default) = ntt_row8.h persistent and software-pipelined
-static int row8_mode() {
-    static const int m = [] {
+// Which row pass runs (both are bit-exact; profiles/r06_sweeps.md section 4): ntt_row8.h for 9..11 stages (rings 2^13..2^15: 2-10 % faster),
+// ntt_static.h's 16-residues-per-lane kernel for 12 stages (1-3 % faster there).  FHE_NTT_ROW8 = 0 / 1 forces one of them (measurements).
+static bool row8_for(uint32_t T) {
+    static const int forced = [] {
         const char* v = std::getenv("FHE_NTT_ROW8");
-        return v && v[0] >= '0' && v[0] <= '2' ? v[0] - '0' : 2;
+        return v && (v[0] == '0' || v[0] == '1') ? v[0] - '0' : -1;
     }();
-    return m;
+    return forced >= 0 ? forced == 1 : T <= 11u;
 }
 static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse, const uint64_t* xin, uint64_t* xout,
                               const LimbSel& sel, uint32_t nLimbs, uint32_t batch, bool canonOut, void* stream,
@@ -718,28 +718,17 @@ static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse
         launched = true; \
     }
         // row passes of two-pass rings at 8 residues per lane (ntt_row8.h: 8 waves per SIMD, one barrier per tile)
-        if (!pp.layoutA && c->logN > (uint32_t)kTileLog && row8_mode()) {
-            // persistent grid: kPipePerCu workgroups per CU, a multiple of 8 (a workgroup keeps its XCD: tile index = blockIdx mod 8)
-            const uint32_t pgrid = std::min(grid, (r8::kPipePerCu * c->cus) & ~7u);
-            const bool pipe      = row8_mode() == 2 && pgrid >= 8;
+        if (!pp.layoutA && c->logN > (uint32_t)kTileLog && row8_for(pp.T)) {
+            // tiles of 2^T words on 2^(T-9) waves: grid and XCD order for that tile size
+            const uint32_t rgrid = a.rows << (c->logN - pp.T);
+            a.xcdSwizzle         = ((nLimbs << (c->logN - pp.T)) % 8u == 0) ? 1u : 0u;
 #define FHE_ROW8_CASE(INV, TT, MODE) \
     if (!launched && inverse == INV && pp.T == TT && mode == MODE) { \
-        if (pipe) \
-            FHE_LAUNCH_BARRIER_N((r8::ntt_row8_pipe_kernel<INV, TT, MODE>), pgrid, r8::kThreads8, stream, a); \
-        else \
-            FHE_LAUNCH_BARRIER_N((r8::ntt_row8_kernel<INV, TT, MODE>), grid, r8::kThreads8, stream, a); \
+        FHE_LAUNCH_BARRIER_N((r8::ntt_row8_kernel<INV, TT - 9, MODE>), rgrid, 64u << (TT - 9), stream, a); \
         launched = true; \
     }
-#ifdef FHE_ABL_ROW8_T  // timing experiment: the 12-stage row pass runs only FHE_ABL_ROW8_T of its stages (results are wrong)
-            if (!launched && pp.T == 12 && (inverse ? mode == 0 : mode == 9)) {
-                if (inverse)
-                    FHE_LAUNCH_BARRIER_N((r8::ntt_row8_kernel<true, FHE_ABL_ROW8_T, 0>), grid, r8::kThreads8, stream, a);
-                else
-                    FHE_LAUNCH_BARRIER_N((r8::ntt_row8_kernel<false, FHE_ABL_ROW8_T, 9>), grid, r8::kThreads8, stream, a);
-                launched = true;
-            }
-#endif
-            FHE_ROW8_CASE(false, 12, 9) FHE_ROW8_CASE(true, 12, 0)
+            FHE_ROW8_CASE(false, 12, 9) FHE_ROW8_CASE(true, 12, 0) FHE_ROW8_CASE(false, 11, 9) FHE_ROW8_CASE(true, 11, 0)
+            FHE_ROW8_CASE(false, 10, 9) FHE_ROW8_CASE(true, 10, 0) FHE_ROW8_CASE(false, 9, 9) FHE_ROW8_CASE(true, 9, 0)
 #undef FHE_ROW8_CASE
         }
         // column passes of logN = 13..16 (T1 = 4) and 17 (T1 = 5); row passes T2 = logN - T1; the single pass of logN = 12
@@ -780,7 +769,14 @@ static uint32_t env_u32(const char* name, uint32_t dflt) {
 // stages of the strided column pass of a two-pass ring: as few as possible (>= 4), so that the column pass reads rows of
 // 2^(12-T1) consecutive words and, at T1 = 4, is a pure register radix-16 step; the other splits were measured slower
 // (profiles/r01_sweeps.md) and their kernel instances are gone
-static uint32_t ntt_t1(uint32_t logN) { return std::max(4u, logN - (uint32_t)kTileLog); }
+static uint32_t ntt_t1(uint32_t logN) {
+    const uint32_t dflt = std::max(4u, logN - (uint32_t)kTileLog);
+    // FHE_NTT_T1 (measurements): another split of a two-pass ring, where both passes have kernel instances (column 4..5, row 9..12)
+    static const uint32_t forced = env_u32("FHE_NTT_T1", 0);
+    if (forced >= 4 && forced <= 5 && logN > (uint32_t)kTileLog && logN - forced >= 9 && logN - forced <= 12)
+        return forced;
+    return dflt;
+}
 
 // inStride != 0: xin is a [batch][inStride][N] view whose rows inFirst.. are transformed into the dense xout
 // outStride != 0: xout is a [batch][outStride][N] view as well (rows outFirst..)

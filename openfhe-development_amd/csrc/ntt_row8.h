@@ -1,24 +1,27 @@
-// ntt_row8.h — the row pass of a two-pass transform at EIGHT residues per lane (round 6).
+// ntt_row8.h — the row pass of a two-pass transform at EIGHT residues per lane, tiles of 1 / 2 / 4 / 8 waves (round 6).
 //
-// Why: the 16-residues-per-lane row pass (ntt_static.h) needs 120-124 VGPRs and 38 KiB of LDS per 256-thread workgroup: four
-// workgroups = 16 waves per CU by both limits, six workgroup barriers per tile; it ran at 8.2-8.7 ms per pass against 5.5 ms of
-// HBM time and 5.7 ms of integer issue (profiles/r05_sweeps.md 1a/1b: throughput was set by having four customers for two equally
-// loaded stations).  This kernel keeps the same tile (4096 consecutive words of one limb = 32 KiB), the same butterflies, tables and
-// lazy ranges, and changes the residency:
-//   * 512 threads x 8 residues per lane; <= 64 VGPRs per lane (ntt_bfly8_pinned.h: residues v[48:63], one butterfly slot's
-//     temporaries v[36:47], v[0:35] for addresses and the 7 per-lane twiddle pairs of a radix-8 step) => 8 waves per SIMD,
-//     32 waves (4 workgroups) per CU, 36 KiB of LDS per workgroup;
-//   * the 12-bit tile index is  w:c:k:m  (3 bits each).  Radix-8 steps act on the fields w (tile bits 9-11), c (6-8), k (3-5),
-//     m (0-2).  Only the step on w mixes the eight waves: from then on WAVE w OWNS the 512 words whose top field is w, and the
-//     exchanges between the steps on c, k and m are private to a wave — LDS instructions of one wave execute in order, so they
-//     need NO workgroup barrier.  A tile meets ONE barrier (ntt_static.h: six);
-//   * every exchange has its own additive address scheme  F1(field1) + F2(field2) + F3(field3)  inside the wave's region of 576
-//     words, chosen so that both its write and its read pattern put the 32 lanes of a half-wave on 32 distinct 8-byte bank pairs
-//     (tools/occbench.hip, profiles/r06_occbench.json: 296 ns per 64 KiB exchange and CU with the skews, 351-438 without);
-//     register indices enter as immediates (`base + imm`), as in ntt_static.h;
-//   * HBM sees 512 contiguous bytes per wave instruction on both sides (forward: load in the w-layout, store after a last
-//     wave-private exchange; inverse: the mirror image).
-// Same transform as transformnat-impl.h:303-374 (forward, stages on tile bits 11..0) / 512-625 (inverse, 0..11); twiddle of the
+// Why: the 16-residues-per-lane row pass (ntt_static.h) needs 120-124 VGPRs and 38 KiB of LDS per 4096-word tile: four tiles per CU,
+// six workgroup barriers per tile; 8.2-8.7 ms per pass against 5.5 ms of HBM time.  What round 6 measured (profiles/r06_sweeps.md):
+//   * waves per SIMD are NOT the lever: this kernel at 512 threads per 4096-word tile (64 VGPRs, 8 waves per SIMD, ONE barrier per
+//     tile) runs as fast as the 16-residue kernel, to the percent; a persistent, software-pipelined form of it was 10 % slower;
+//   * a row pass takes  HBM time + half of its compute time  (12 / 11 / 10 / 9 stages: 8.34 / 8.23 / 8.00 / 7.60 ms, compute alone
+//     5.95): what overlaps is bounded by the number of INDEPENDENT tiles a CU holds — a workgroup loads, computes and stores as one
+//     customer, and four customers keep two equally loaded stations 70 % busy;
+//   * so the tile shrinks instead: 2^(9+WB) words on 2^WB waves (WB = 0..3), eight residues per lane, <= 64 VGPRs and 4.5 KiB of LDS
+//     per wave: 32 / 2^WB tiles per CU (WB = 2: eight 2048-word tiles of 256 threads).  The row pass has 9 + WB stages, the column
+//     pass the rest (2^16: 5 + 11 — the column access pattern with the best HBM rate, profiles/r06_stridebench.json).
+// Structure (unchanged from the first form): the tile index is  w:c:k:m  (WB, 3, 3, 3 bits).  Radix-8 steps act on the fields c (tile
+// bits 6-8), k (3-5), m (0-2) and on w together with the top 3 - WB bits of c (one register field of 3 bits whose top WB bits carry
+// butterflies).  Only that step mixes the waves: from then on WAVE w OWNS the 512 words whose top field is w, and the exchanges
+// between the steps on c, k and m are private to a wave — LDS instructions of one wave execute in order, so they need NO workgroup
+// barrier.  A tile meets ONE barrier (none at WB = 0).  Every exchange has its own additive address scheme
+// F1(field1) + F2(field2) + F3(field3) inside the wave's region of 576 words, chosen so that both its write and its read pattern put
+// the 32 lanes of a half-wave on 32 distinct 8-byte bank pairs (tools/occbench.hip, profiles/r06_occbench.json: 296 ns per 64 KiB
+// exchange and CU with the skews, 351-438 without); register indices enter as immediates (`base + imm`), as in ntt_static.h.  HBM
+// sees 512 contiguous bytes per wave instruction on both sides.
+// Registers (ntt_bfly8_pinned.h): residues v[48:63], the one butterfly slot's temporaries v[36:47], v[0:35] for addresses and the
+// per-lane twiddle pairs of a radix-8 step (at most 6 of its 7 at a time).
+// Same transform as transformnat-impl.h:303-374 (forward, stages on tile bits T-1..0) / 512-625 (inverse, 0..T-1); twiddle of the
 // stage on coefficient bit P for the pair (J, J + 2^P): Table[2^(logN-1-P) + (J >> (P+1))].
 #ifndef FHE_NTT_ROW8_H
 #define FHE_NTT_ROW8_H
@@ -28,9 +31,7 @@
 namespace fhe {
 namespace r8 {
 
-constexpr int kThreads8 = 512;
-constexpr int kRegion   = 576;           // LDS words per wave (the schemes below reach word 571)
-constexpr int kLdsWords = 8 * kRegion;   // 36 KiB
+constexpr int kRegion = 576;  // LDS words per wave (the schemes below reach word 571)
 
 // address schemes of the exchanges inside a wave's region (c, k, m = the fields at tile bits 6-8, 3-5, 0-2):
 //   X1 (w-layout  <-> c-layout, through the barrier): 576 w + 64 c + 8 k + m
@@ -106,7 +107,7 @@ FHE_HD void csub_all(uint64_t (&r)[8], uint64_t m) {
 #endif
 }
 
-// the lazy-inverse plan of a step with NB stages (register bits 0..NB-1), closing reductions or not: tables of ntt_bfly8_pinned.h
+// the lazy-inverse plan of a step with NB stages (the TOP NB register bits: 3-NB..2), closing reductions or not: tables of ntt_bfly8_pinned.h
 template <int NB, bool LAZY>
 struct InvPlan;
 #define FHE_R8_PLAN(NB, LAZY, TAG)                                                      \
@@ -143,12 +144,12 @@ FHE_HD void inv_stage(uint64_t (&r)[8], const TwPair (&w)[4], const BflyConst c,
     (void)bnd;
 #define FHE_R8_INV(TAG, NBB, NAME, BB) if constexpr (NB == NBB && B == BB) stage_invl_##TAG##_##NAME##_b##BB(r, w, c);
     if constexpr (UNI) {
-        FHE_R8_INV(s, 3, full, 0) FHE_R8_INV(s, 3, full, 1) FHE_R8_INV(s, 3, full, 2) FHE_R8_INV(s, 2, two, 0) FHE_R8_INV(s, 2, two, 1)
-        FHE_R8_INV(s, 1, one, 0)
+        FHE_R8_INV(s, 3, full, 0) FHE_R8_INV(s, 3, full, 1) FHE_R8_INV(s, 3, full, 2) FHE_R8_INV(s, 2, two, 1) FHE_R8_INV(s, 2, two, 2)
+        FHE_R8_INV(s, 1, one, 2)
     }
     else {
-        FHE_R8_INV(v, 3, full, 0) FHE_R8_INV(v, 3, full, 1) FHE_R8_INV(v, 3, full, 2) FHE_R8_INV(v, 2, two, 0) FHE_R8_INV(v, 2, two, 1)
-        FHE_R8_INV(v, 1, one, 0)
+        FHE_R8_INV(v, 3, full, 0) FHE_R8_INV(v, 3, full, 1) FHE_R8_INV(v, 3, full, 2) FHE_R8_INV(v, 2, two, 1) FHE_R8_INV(v, 2, two, 2)
+        FHE_R8_INV(v, 1, one, 2)
     }
 #undef FHE_R8_INV
 #else
@@ -190,9 +191,9 @@ FHE_HD void inv_end(uint64_t (&r)[8], const BflyConst c, uint32_t (&bnd)[8]) {
 #endif
 }
 
-// ---- one radix-8 step: NB stages on the register bits 0..NB-1 of the field at tile bit F -----------------------------------
+// ---- one radix-8 step: NB stages on the TOP NB register bits (2..3-NB) of the field whose bit 0 sits at coefficient bit F ---------
 // hi = J >> (F + 3) of the lane's residues (the coefficient-index bits above the field); UNI: hi is wave-uniform (scalar loads).
-// Twiddle of stage b, group g: Table[2^(logN-1-(F+b)) + (hi << (2-b)) + g].  Forward runs b = NB-1..0, inverse b = 0..NB-1.
+// Twiddle of stage b, group g: Table[2^(logN-1-(F+b)) + (hi << (2-b)) + g].  Forward runs b = 2..3-NB, inverse b = 3-NB..2.
 template <bool UNI, int B>
 FHE_HD void load_tw(TwPair (&w)[4], const TwPair* tw, uint32_t hi, uint32_t F, uint32_t logN) {
     const uint32_t s = logN - 1u - (F + (uint32_t)B);
@@ -216,7 +217,7 @@ FHE_HD void load_tw(TwPair (&w)[4], const TwPair* tw, uint32_t hi, uint32_t F, u
         }
     }
 }
-// forward: `sweep` brings the 4 `a` inputs of the first stage below 2q first (bound in: anything below 16q)
+// forward: SWEEP brings the 4 `a` inputs of the first stage (register bit 2) below 2q first (bound in: anything below 16q)
 template <bool UNI, int NB, bool SWEEP>
 FHE_HD void fwd_step(uint64_t (&r)[8], const TwPair* tw, uint32_t hi, uint32_t F, uint32_t logN, const BflyConst c, uint32_t inBound) {
     uint32_t bnd[8];
@@ -224,15 +225,14 @@ FHE_HD void fwd_step(uint64_t (&r)[8], const TwPair* tw, uint32_t hi, uint32_t F
         bnd[k] = inBound;
     // per-lane twiddles: at most 6 pairs in registers at a time (the last stage's 4 pairs are fetched once the first stage's pair is dead)
     TwPair w2[4], w1[4], w0[4];
-    if constexpr (NB >= 3) load_tw<UNI, 2>(w2, tw, hi, F, logN);
+    if constexpr (NB >= 1) load_tw<UNI, 2>(w2, tw, hi, F, logN);
     if constexpr (NB >= 2) load_tw<UNI, 1>(w1, tw, hi, F, logN);
-    if constexpr (NB >= 1 && NB < 3) load_tw<UNI, 0>(w0, tw, hi, F, logN);
     if constexpr (SWEEP && NB >= 1)
-        red4_a<NB - 1>(r, c, bnd);
-    if constexpr (NB >= 3) fwd_stage<UNI, 2>(r, w2, c, bnd);
+        red4_a<2>(r, c, bnd);
+    if constexpr (NB >= 1) fwd_stage<UNI, 2>(r, w2, c, bnd);
     if constexpr (NB >= 3) load_tw<UNI, 0>(w0, tw, hi, F, logN);
     if constexpr (NB >= 2) fwd_stage<UNI, 1>(r, w1, c, bnd);
-    if constexpr (NB >= 1) fwd_stage<UNI, 0>(r, w0, c, bnd);
+    if constexpr (NB >= 3) fwd_stage<UNI, 0>(r, w0, c, bnd);
 }
 template <bool UNI, int NB, bool LAZY>
 FHE_HD void inv_step(uint64_t (&r)[8], const TwPair* tw, uint32_t hi, uint32_t F, uint32_t logN, const BflyConst c) {
@@ -240,21 +240,22 @@ FHE_HD void inv_step(uint64_t (&r)[8], const TwPair* tw, uint32_t hi, uint32_t F
     for (int k = 0; k < 8; ++k)
         bnd[k] = 3;
     TwPair w2[4], w1[4], w0[4];
-    if constexpr (NB >= 1) load_tw<UNI, 0>(w0, tw, hi, F, logN);
+    if constexpr (NB >= 3) load_tw<UNI, 0>(w0, tw, hi, F, logN);
     if constexpr (NB >= 2) load_tw<UNI, 1>(w1, tw, hi, F, logN);
-    if constexpr (NB >= 1) inv_stage<UNI, NB, 0>(r, w0, c, bnd);
+    if constexpr (NB >= 1 && NB < 3) load_tw<UNI, 2>(w2, tw, hi, F, logN);
+    if constexpr (NB >= 3) inv_stage<UNI, NB, 0>(r, w0, c, bnd);
     if constexpr (NB >= 3) load_tw<UNI, 2>(w2, tw, hi, F, logN);
     if constexpr (NB >= 2) inv_stage<UNI, NB, 1>(r, w1, c, bnd);
-    if constexpr (NB >= 3) inv_stage<UNI, NB, 2>(r, w2, c, bnd);
+    if constexpr (NB >= 1) inv_stage<UNI, NB, 2>(r, w2, c, bnd);
     if constexpr (!LAZY && NB >= 1)
         inv_end<NB>(r, c, bnd);
 }
 
 // forward lazy-range schedule of the pass (units of q): a radix-8 step of NB stages adds 3 NB; a step whose stages would pass 16
-// sweeps first (its first stage's `a` inputs below 2q).  Steps: w (TA = T - 9 stages), c, k, m (3 each).
-template <int T, int BIN>
+// sweeps first (its first stage's `a` inputs below 2q).  Steps: w (WB stages), c, k, m (3 each).
+template <int WB, int BIN>
 struct FwdSched {
-    static constexpr int TA = T - 9;
+    static constexpr int TA = WB;
     static constexpr int stages(int i) { return i == 0 ? TA : 3; }
     static constexpr int before(int i) {
         int b = BIN;
@@ -268,21 +269,14 @@ struct FwdSched {
 
 // MODE as in ntt_static.h: forward 9 (or 1): bound class of the pass input (below 2q / canonical); inverse 0: the column pass follows
 // (the last step's closing reductions are left to it: residues below 16q), 1: this pass ends the transform (not instantiated yet).
-//
-// PIPE: the workgroup is PERSISTENT (grid = 3 per CU) and software-pipelined: the loads of its next tile are issued before the
-// butterflies of the current one (16 more VGPRs: 80 per lane, 6 waves per SIMD, 3 workgroups per CU), the stores of the current tile
-// drain under the next one.  Why: with one tile per workgroup a CU holds four tiles by the register file AND by the 32-wave limit,
-// whatever the lane count per tile, and each of them spends 2.6 us loading and 2.3 us storing without computing — 8.1 ms per pass for
-// this kernel and for ntt_static.h's alike (profiles/r06_sweeps.md: residency in waves is not the lever, tiles in flight are).  The
-// counter of vector-memory operations is in order, so waiting for the prefetched loads (issued BEFORE the previous tile's stores)
-// does not wait for those stores.  Two barriers per tile: the cross-wave exchange X1, and one that keeps a fast wave's next X1 (or,
-// inverse, its next wave-private exchange) out of regions a slow wave still reads.
 struct TileAt {
     uint32_t tb, rit, tr;  // tower of the batch, row inside the tower, tile inside the row
 };
-FHE_DEV TileAt tile_at(const NttPassArgs& a, uint32_t vt, uint32_t trLog) {
+// blockIdx -> tile: with xcdSwizzle an XCD (blockIdx mod 8) keeps one (limb, tile of the ring) across the batch, so that the workgroups
+// it runs at a time share one slice of the twiddle tables in its L2 (as ntt_static.h)
+FHE_DEV TileAt tile_at(const NttPassArgs& a, uint32_t vt, uint32_t trLog, bool swz) {
     uint32_t tile = vt;
-    if (a.xcdSwizzle) {
+    if (swz) {
         const uint32_t xcd = vt & 7u, i = vt >> 3;
         const uint32_t b = i % a.batch, pairIdx = i / a.batch;
         const uint32_t pair = pairIdx * 8u + xcd;
@@ -291,21 +285,13 @@ FHE_DEV TileAt tile_at(const NttPassArgs& a, uint32_t vt, uint32_t trLog) {
     const uint32_t row = tile >> trLog;
     return TileAt{row / a.nLimbs, row % a.nLimbs, tile & ((1u << trLog) - 1u)};
 }
-FHE_DEV const uint64_t* tile_src(const NttPassArgs& a, const TileAt& p) {
-    const uint32_t logN = a.logN;
-    const uint64_t inRow = a.inStride ? ((uint64_t)p.tb * a.inStride + a.inFirst + p.rit) : ((uint64_t)p.tb * a.nLimbs + p.rit);
-    return (a.inDelta ? a.xin + (int64_t)p.tb * a.inDelta + ((uint64_t)(a.inFirst + p.rit) << logN) : a.xin + (inRow << logN)) +
-           ((size_t)p.tr << kTileLog);
-}
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// the value is opaque to the compiler from here on: what is derived from it is computed HERE (not hoisted out of the tile loop and
-// kept in a register for the whole tile: the kernel has 64 / 80 VGPRs and ~100 SGPRs, and they are all spoken for)
+// the value is opaque to the compiler from here on: what is derived from it is computed HERE (not early and then kept in a register for
+// the whole tile: the kernel has 64 VGPRs and they are all spoken for)
 #define FHE_R8_OPAQUE_V(x) asm volatile("" : "+v"(x))
-#define FHE_R8_OPAQUE_S(x) asm volatile("" : "+s"(x))
 #else
 #define FHE_R8_OPAQUE_V(x) ((void)0)
-#define FHE_R8_OPAQUE_S(x) ((void)0)
 #endif
 // lane coordinates, derived afresh where an exchange or a step needs them: l = lane of the wave, (lhi, llo) = its two 3-bit fields
 #define FHE_R8_LANE()                 \
@@ -314,221 +300,205 @@ FHE_DEV const uint64_t* tile_src(const NttPassArgs& a, const TileAt& p) {
     const uint32_t l = tq_ & 63u, lhi = l >> 3, llo = l & 7u; \
     (void)lhi, (void)llo
 
-template <bool INV, int T, int MODE, bool PIPE>
+// WB: the tile has 2^WB waves and 2^(9+WB) words; the pass has T = 9 + WB stages.
+template <bool INV, int WB, int MODE>
 FHE_DEV void ntt_row8_core(const NttPassArgs& a, uint64_t* lds) {
-    static_assert(T >= 9 && T <= 12, "row8: 9..12 stages");
+    static_assert(WB >= 0 && WB <= 3, "row8: 1, 2, 4 or 8 waves per tile");
     static_assert(!(INV && MODE != 0), "row8: the inverse pass that ends a transform is ntt_static.h's");
-    constexpr int TA = T - 9;
-    constexpr bool loadW = !INV && TA > 0;  // first load in the w-layout (lane t, word t + 512 k), else in the c-layout
-    constexpr uint32_t ldStep = loadW ? 512u : 64u;
+    constexpr uint32_t tileLog = 9u + (uint32_t)WB;
+    constexpr uint32_t threads = 64u << WB;
+    constexpr int WLOW         = 3 - WB;  // register bits of the w-step's field that belong to c (no butterflies on them)
     const uint32_t t     = FHE_TID;
-    const uint32_t wv    = FHE_UNIFORM(t >> 6);
+    const uint32_t wv    = WB ? FHE_UNIFORM(t >> 6) : 0u;
     const uint32_t logN  = a.logN;
-    const uint32_t trLog = logN - (uint32_t)kTileLog;
-    const uint32_t nTiles = a.rows << trLog;
-    const uint32_t stride = PIPE ? FHE_NBLK : 0u;
+    const uint32_t trLog = logN - tileLog;
     uint64_t* reg = lds + (size_t)wv * kRegion;  // this wave's region
-    uint64_t r[8], nx[8];
-    uint32_t vt = FHE_BID;
-    TileAt at   = tile_at(a, vt, trLog);
-    // word of register 0 in the load layout; register k: + ldStep k
-    auto load_tile = [&](uint64_t (&v)[8]) {
-        FHE_R8_LANE();
-        const uint64_t* s0 = tile_src(a, at) + (loadW ? tq_ : (wv << 9) + l);
+    uint64_t r[8];
+    // (xcdSwizzle of the args is the host's answer for 4096-word tiles; smaller tiles only add factors of two)
+    const TileAt at      = tile_at(a, FHE_BID, trLog, a.xcdSwizzle != 0);
+    const uint32_t jbase = at.tr << tileLog;
+    const uint32_t rit   = at.rit;
+    const uint64_t inRow  = a.inStride ? ((uint64_t)at.tb * a.inStride + a.inFirst + rit) : ((uint64_t)at.tb * a.nLimbs + rit);
+    const uint64_t outRow = a.outStride ? ((uint64_t)at.tb * a.outStride + a.outFirst + rit) : ((uint64_t)at.tb * a.nLimbs + rit);
+    const uint32_t limb = FHE_UNIFORM(a.sel.idx[rit]);
+    const uint64_t q    = FHE_ULOAD64(a.q, limb);
+    const uint64_t twoq = q << 1, nq = 0 - q;
+    const TwPair* tw    = a.tw + ((uint64_t)limb << logN);
+    const uint64_t redc = FHE_ULOAD64(a.red, limb);
+    const BflyConst c{(uint32_t)nq, (uint32_t)(nq >> 32), q, twoq, 0 - twoq, twoq + q, (uint32_t)redc, (uint32_t)(redc >> 32)};
+    const uint64_t* src = (a.inDelta ? a.xin + (int64_t)at.tb * a.inDelta + ((uint64_t)(a.inFirst + rit) << logN) : a.xin + (inRow << logN)) + jbase;
+    uint64_t* dst       = a.x + (outRow << logN) + jbase;
+    // X1 word of register rr in the w-layout: the register is (w : top 3 - WB bits of c); lane t = (low WB bits of c, k, m)
+    auto x1 = [](int rr) { return (uint32_t)kRegion * ((uint32_t)rr >> WLOW) + (64u << WB) * ((uint32_t)rr & ((1u << WLOW) - 1u)); };
+
+    if constexpr (!INV) {
+        using S = FwdSched<WB, (MODE == 9 ? 2 : MODE)>;
+        if constexpr (WB > 0) {
+            // w-layout: register rr holds word threads * rr + t of the tile (512 contiguous bytes per wave instruction); uniform twiddles
+            {
+                FHE_R8_LANE();
+                const uint64_t* s0 = src + tq_;
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            v[k] = FHE_GLD(&s0[ldStep * (uint32_t)k]);
-    };
-    if constexpr (PIPE)
-        load_tile(nx);
-    do {
-        const uint32_t jbase = at.tr << kTileLog;
-        const uint32_t rit   = at.rit;
-        const uint64_t outRow = a.outStride ? ((uint64_t)at.tb * a.outStride + a.outFirst + rit) : ((uint64_t)at.tb * a.nLimbs + rit);
-        const uint32_t limb = FHE_UNIFORM(a.sel.idx[rit]);
-        const uint64_t q    = FHE_ULOAD64(a.q, limb);
-        const uint64_t twoq = q << 1, nq = 0 - q;
-        const TwPair* tw    = a.tw + ((uint64_t)limb << logN);
-        const uint64_t redc = FHE_ULOAD64(a.red, limb);
-        const BflyConst c{(uint32_t)nq, (uint32_t)(nq >> 32), q, twoq, 0 - twoq, twoq + q, (uint32_t)redc, (uint32_t)(redc >> 32)};
-        uint64_t* dst = a.x + (outRow << logN) + jbase;
-        if constexpr (PIPE) {
+                for (int k = 0; k < 8; ++k)
+                    r[k] = FHE_GLD(&s0[threads * (uint32_t)k]);
+            }
+            fwd_step<true, WB, S::sweep(0)>(r, tw, at.tr, 6 + WB, logN, c, S::sweep(0) ? 2u : (uint32_t)S::before(0));
+            FHE_R8_LANE();
+            uint64_t* Lw = lds + tq_;  // X1: 576 w + 64 c + 8 k + m
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-                r[k] = nx[k];
-            if (vt + stride < nTiles) {  // (uniform) the next tile's loads, before this tile's butterflies
-                at = tile_at(a, vt + stride, trLog);
-                load_tile(nx);
-            }
+                FHE_LDS_ST(Lw[x1(k)], r[k]);
+            FHE_SSYNC();
+            const uint64_t* Lr = reg + l;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                FHE_LDS_LD(r[k], Lr[64 * k]);
         }
-        else
-            load_tile(r);
-        // hi* = the coefficient-index bits above a field, for the lane's residues in that step's layout
-        if constexpr (!INV) {
-            using S = FwdSched<T, (MODE == 9 ? 2 : MODE)>;
-            if constexpr (TA > 0) {
-                // w-layout: lane t = (c, k, m), register = w (loaded with 512 contiguous bytes per wave instruction); uniform twiddles
-                fwd_step<true, TA, S::sweep(0)>(r, tw, jbase >> 12, 9, logN, c, S::sweep(0) ? 2u : (uint32_t)S::before(0));
-                if constexpr (PIPE)
-                    FHE_SSYNC();  // every wave has left the previous tile's exchanges
-                FHE_R8_LANE();
-                uint64_t* Lw = lds + tq_;  // X1: 576 w + (64 c + 8 k + m)
+        else {
+            // one wave per tile: its 512 words straight from memory in the c-layout
+            FHE_R8_LANE();
+            const uint64_t* s0 = src + l;
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    FHE_LDS_ST(Lw[kRegion * k], r[k]);
-                FHE_SSYNC();
-                const uint64_t* Lr = reg + l;
+            for (int k = 0; k < 8; ++k)
+                r[k] = FHE_GLD(&s0[64u * (uint32_t)k]);
+        }
+        // c-layout: lane = (k, m), register = c; wave-uniform twiddles
+        fwd_step<true, 3, S::sweep(1)>(r, tw, (jbase >> 9) + wv, 6, logN, c, S::sweep(1) ? 2u : (uint32_t)S::before(1));
+        {   // X2: 72 c + 8 k + m
+            FHE_R8_LANE();
+            FHE_WAVE_SYNC();
+            uint64_t* Lw = reg + l;
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    FHE_LDS_LD(r[k], Lr[64 * k]);
-            }
-            // (no stage on the w field: the wave's 512 words came straight from memory in the c-layout)
-            // c-layout: lane = (k, m), register = c; wave-uniform twiddles
-            fwd_step<true, 3, S::sweep(1)>(r, tw, (jbase >> 9) + wv, 6, logN, c, S::sweep(1) ? 2u : (uint32_t)S::before(1));
-            {   // X2: 72 c + 8 k + m
-                FHE_R8_LANE();
+            for (int k = 0; k < 8; ++k)
+                FHE_LDS_ST(Lw[72 * k], r[k]);
+            FHE_WAVE_SYNC();
+            const uint64_t* Lr = reg + 72u * lhi + llo;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                FHE_LDS_LD(r[k], Lr[8 * k]);
+            // k-layout: lane = (c, m), register = k
+            fwd_step<false, 3, S::sweep(2)>(r, tw, (jbase >> 6) + (wv << 3) + lhi, 3, logN, c, S::sweep(2) ? 2u : (uint32_t)S::before(2));
+        }
+        {   // X3: FC3(c) + 33 k + m
+            FHE_R8_LANE();
+            FHE_WAVE_SYNC();
+            uint64_t* Lw = reg + fc3(lhi) + llo;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                FHE_LDS_ST(Lw[33 * k], r[k]);
+            FHE_WAVE_SYNC();
+            const uint64_t* Lr = reg + fc3(lhi) + 33u * llo;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                FHE_LDS_LD(r[k], Lr[k]);
+            // m-layout: lane = (c, k), register = m: the lane's 8 consecutive coefficients
+            fwd_step<false, 3, S::sweep(3)>(r, tw, (jbase >> 3) + (wv << 6) + l, 0, logN, c, S::sweep(3) ? 2u : (uint32_t)S::before(3));
+        }
+        if (a.canonStep != 0xffffffffu) {
+            red_all(r, c);
+            csub_all(r, q);
+        }
+        {   // X4: FC4(c) + k + 36 m, read back in the c-layout (= the store layout)
+            FHE_R8_LANE();
+            FHE_WAVE_SYNC();
+            uint64_t* Lw = reg + fc4(lhi) + llo;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                FHE_LDS_ST(Lw[36 * k], r[k]);
+            FHE_WAVE_SYNC();
+            const uint64_t* Lr = reg + lhi + 36u * llo;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                FHE_LDS_LD(r[k], Lr[fc4((uint32_t)k)]);
+            uint64_t* d0 = dst + (wv << 9) + l;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                FHE_GST(&d0[64u * (uint32_t)k], r[k]);
+        }
+    }
+    else {
+        {   // c-layout load (512 contiguous bytes per wave instruction), X4 backwards into the m-layout
+            FHE_R8_LANE();
+            const uint64_t* s0 = src + (wv << 9) + l;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                r[k] = FHE_GLD(&s0[64u * (uint32_t)k]);
+            uint64_t* Lw = reg + lhi + 36u * llo;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                FHE_LDS_ST(Lw[fc4((uint32_t)k)], r[k]);
+            FHE_WAVE_SYNC();
+            const uint64_t* Lr = reg + fc4(lhi) + llo;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                FHE_LDS_LD(r[k], Lr[36 * k]);
+            inv_step<false, 3, false>(r, tw, (jbase >> 3) + (wv << 6) + l, 0, logN, c);
+        }
+        {   // X3 backwards
+            FHE_R8_LANE();
+            FHE_WAVE_SYNC();
+            uint64_t* Lw = reg + fc3(lhi) + 33u * llo;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                FHE_LDS_ST(Lw[k], r[k]);
+            FHE_WAVE_SYNC();
+            const uint64_t* Lr = reg + fc3(lhi) + llo;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                FHE_LDS_LD(r[k], Lr[33 * k]);
+            inv_step<false, 3, false>(r, tw, (jbase >> 6) + (wv << 3) + lhi, 3, logN, c);
+        }
+        {   // X2 backwards
+            FHE_R8_LANE();
+            FHE_WAVE_SYNC();
+            uint64_t* Lw = reg + 72u * lhi + llo;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                FHE_LDS_ST(Lw[8 * k], r[k]);
+            FHE_WAVE_SYNC();
+            const uint64_t* Lr = reg + l;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                FHE_LDS_LD(r[k], Lr[72 * k]);
+        }
+        // the column pass that follows reduces on the way in (anything below 16q): the LAST step with stages skips its closing reductions
+        inv_step<true, 3, (WB == 0)>(r, tw, (jbase >> 9) + wv, 6, logN, c);
+        if constexpr (WB > 0) {
+            FHE_R8_LANE();
+            {   // X1 backwards, through the barrier
                 FHE_WAVE_SYNC();
                 uint64_t* Lw = reg + l;
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
-                    FHE_LDS_ST(Lw[72 * k], r[k]);
-                FHE_WAVE_SYNC();
-                const uint64_t* Lr = reg + 72u * lhi + llo;
+                    FHE_LDS_ST(Lw[64 * k], r[k]);
+                FHE_SSYNC();
+                const uint64_t* Lr = lds + tq_;
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
-                    FHE_LDS_LD(r[k], Lr[8 * k]);
-                // k-layout: lane = (c, m), register = k
-                fwd_step<false, 3, S::sweep(2)>(r, tw, (jbase >> 6) + (wv << 3) + lhi, 3, logN, c,
-                                                S::sweep(2) ? 2u : (uint32_t)S::before(2));
+                    FHE_LDS_LD(r[k], Lr[x1(k)]);
             }
-            {   // X3: FC3(c) + 33 k + m
-                FHE_R8_LANE();
-                FHE_WAVE_SYNC();
-                uint64_t* Lw = reg + fc3(lhi) + llo;
+            inv_step<true, WB, true>(r, tw, at.tr, 6 + WB, logN, c);
+            uint64_t* d0 = dst + tq_;
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    FHE_LDS_ST(Lw[33 * k], r[k]);
-                FHE_WAVE_SYNC();
-                const uint64_t* Lr = reg + fc3(lhi) + 33u * llo;
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    FHE_LDS_LD(r[k], Lr[k]);
-                // m-layout: lane = (c, k), register = m: the lane's 8 consecutive coefficients
-                fwd_step<false, 3, S::sweep(3)>(r, tw, (jbase >> 3) + (wv << 6) + l, 0, logN, c,
-                                                S::sweep(3) ? 2u : (uint32_t)S::before(3));
-            }
-            if (a.canonStep != 0xffffffffu) {
-                red_all(r, c);
-                csub_all(r, q);
-            }
-            {   // X4: FC4(c) + k + 36 m, read back in the c-layout (= the store layout)
-                FHE_R8_LANE();
-                FHE_WAVE_SYNC();
-                uint64_t* Lw = reg + fc4(lhi) + llo;
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    FHE_LDS_ST(Lw[36 * k], r[k]);
-                FHE_WAVE_SYNC();
-                const uint64_t* Lr = reg + lhi + 36u * llo;
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    FHE_LDS_LD(r[k], Lr[fc4((uint32_t)k)]);
-                uint64_t* d0 = dst + (wv << 9) + l;
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    FHE_GST(&d0[64u * (uint32_t)k], r[k]);
-            }
+            for (int k = 0; k < 8; ++k)
+                FHE_GST(&d0[threads * (uint32_t)k], r[k]);
         }
         else {
-            {   // c-layout load (512 contiguous bytes per wave instruction), X4 backwards into the m-layout
-                if constexpr (PIPE && TA > 0)
-                    FHE_SSYNC();  // every wave has read the previous tile's X1
-                FHE_R8_LANE();
-                uint64_t* Lw = reg + lhi + 36u * llo;
+            FHE_R8_LANE();
+            uint64_t* d0 = dst + l;
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    FHE_LDS_ST(Lw[fc4((uint32_t)k)], r[k]);
-                FHE_WAVE_SYNC();
-                const uint64_t* Lr = reg + fc4(lhi) + llo;
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    FHE_LDS_LD(r[k], Lr[36 * k]);
-                inv_step<false, 3, false>(r, tw, (jbase >> 3) + (wv << 6) + l, 0, logN, c);
-            }
-            {   // X3 backwards
-                FHE_R8_LANE();
-                FHE_WAVE_SYNC();
-                uint64_t* Lw = reg + fc3(lhi) + 33u * llo;
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    FHE_LDS_ST(Lw[k], r[k]);
-                FHE_WAVE_SYNC();
-                const uint64_t* Lr = reg + fc3(lhi) + llo;
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    FHE_LDS_LD(r[k], Lr[33 * k]);
-                inv_step<false, 3, false>(r, tw, (jbase >> 6) + (wv << 3) + lhi, 3, logN, c);
-            }
-            {   // X2 backwards
-                FHE_R8_LANE();
-                FHE_WAVE_SYNC();
-                uint64_t* Lw = reg + 72u * lhi + llo;
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    FHE_LDS_ST(Lw[8 * k], r[k]);
-                FHE_WAVE_SYNC();
-                const uint64_t* Lr = reg + l;
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    FHE_LDS_LD(r[k], Lr[72 * k]);
-            }
-            // the column pass that follows reduces on the way in (anything below 16q): the LAST step with stages skips its closing reductions
-            inv_step<true, 3, (TA == 0)>(r, tw, (jbase >> 9) + wv, 6, logN, c);
-            if constexpr (TA > 0) {
-                FHE_R8_LANE();
-                {   // X1 backwards, through the barrier
-                    FHE_WAVE_SYNC();
-                    uint64_t* Lw = reg + l;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k)
-                        FHE_LDS_ST(Lw[64 * k], r[k]);
-                    FHE_SSYNC();
-                    const uint64_t* Lr = lds + tq_;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k)
-                        FHE_LDS_LD(r[k], Lr[kRegion * k]);
-                }
-                inv_step<true, TA, true>(r, tw, jbase >> 12, 9, logN, c);
-                uint64_t* d0 = dst + tq_;
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    FHE_GST(&d0[512u * (uint32_t)k], r[k]);
-            }
-            else {
-                FHE_R8_LANE();
-                uint64_t* d0 = dst + (wv << 9) + l;
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    FHE_GST(&d0[64u * (uint32_t)k], r[k]);
-            }
+            for (int k = 0; k < 8; ++k)
+                FHE_GST(&d0[64u * (uint32_t)k], r[k]);
         }
-        vt += stride;
-    } while (PIPE && vt < nTiles);
+    }
 }
 #undef FHE_R8_LANE
 
-// one tile per workgroup: <= 64 VGPRs, 8 waves per SIMD, 4 workgroups per CU
-template <bool INV, int T, int MODE>
-FHE_GLOBAL void FHE_LAUNCH_BOUNDS2(kThreads8, 8) ntt_row8_kernel(const NttPassArgs a) {
-    FHE_SHARED_U64(lds, kLdsWords);
-    ntt_row8_core<INV, T, MODE, false>(a, lds);
-}
-// persistent and software-pipelined: <= 80 VGPRs, 6 waves per SIMD, 3 workgroups per CU (launch with kPipePerCu workgroups per CU)
-constexpr uint32_t kPipePerCu = 3;
-template <bool INV, int T, int MODE>
-FHE_GLOBAL void FHE_LAUNCH_BOUNDS2(kThreads8, 6) ntt_row8_pipe_kernel(const NttPassArgs a) {
-    FHE_SHARED_U64(lds, kLdsWords);
-    ntt_row8_core<INV, T, MODE, true>(a, lds);
+// 64 VGPRs: 8 waves per SIMD, 32 / 2^WB tiles per CU
+template <bool INV, int WB, int MODE>
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS2(64 << WB, 8) ntt_row8_kernel(const NttPassArgs a) {
+    FHE_SHARED_U64(lds, (1 << WB) * kRegion);
+    ntt_row8_core<INV, WB, MODE>(a, lds);
 }
 
 }  // namespace r8

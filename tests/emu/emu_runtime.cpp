@@ -14,7 +14,7 @@ namespace fhe_emu {
 thread_local Tls tls;
 
 namespace {
-// one pool of lane threads per workgroup size: 256 (every kernel but one) and 512 (the 8-residues-per-lane row pass, ntt_row8.h)
+// one pool of lane threads per workgroup size: 256 (every kernel but one) and 64 / 128 / 512 (the row pass of ntt_row8.h: tiles of 1 / 2 / 8 waves)
 struct Pool {
     const uint32_t kLanes;
     pthread_barrier_t start, stop, sync;
@@ -49,13 +49,12 @@ struct Pool {
             w.join();
     }
 };
-Pool& pool(uint32_t lanes) {
-    if (lanes == 512) {
-        static Pool p512(512);
-        return p512;
-    }
-    static Pool p256(256);
-    return p256;
+Pool& pool(uint32_t lanes) {  // (created on first use, under launchMutex)
+    static Pool* pools[4] = {nullptr, nullptr, nullptr, nullptr};  // 64, 128, 256, 512 lanes
+    const int i = lanes == 64 ? 0 : lanes == 128 ? 1 : lanes == 256 ? 2 : 3;
+    if (!pools[i])
+        pools[i] = new Pool(lanes);
+    return *pools[i];
 }
 std::mutex launchMutex;
 }  // namespace
@@ -79,7 +78,7 @@ void* block_shared(size_t bytes) {
     return static_cast<Pool*>(tls.pool)->shared;
 }
 void launch(uint32_t grid, uint32_t threads, const std::function<void()>& body, bool laneThreads) {
-    if (threads != 256 && threads != 512)
+    if (threads != 64 && threads != 128 && threads != 256 && threads != 512)
         std::abort();
     const uint32_t kLanes = threads;
     // FHE_EMU_SKIP=1: kernels do nothing (results are garbage).  For measuring the HOST side of a call sequence — pke's and the
