@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--no-cc-evalmult", action="store_true",
                     help="skip the leg that runs BASELINE configs[2]'s EvalMult through the reference's CryptoContext on the HIP backend")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparisons of the legs' results")
+    ap.add_argument("--no-power", action="store_true", help="skip the package-power reading of the headline leg")
     ap.add_argument("--evalmult-logn", type=int, default=16, help="ring of the EvalMult leg (config 3: 16)")
     ap.add_argument("--evalmult-limbs", type=int, default=21, help="Q limbs of the EvalMult leg (config 3: 21)")
     return ap.parse_args()
@@ -356,12 +357,13 @@ def evalmult_leg(lib, device, logN, batch, steps, warmup, sync, dist=None, sizeQ
     return {"ops_per_s_per_gpu": round(batch / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "batch": batch,
             "shape": f"N=2^{logN}, l={sizeQ}, k={len(p)}, dnum={dnum}, workspace {wsb / 2**30:.1f} GiB",
             "eval_key": key_dist, "launch": mode, "parity": par,
-            "roofline": {"bound": "hbm", "algorithmic_bytes_per_op": alg, "limb_ntts_per_op": ntt_limbs,
-                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
-                         "survey_8d_bytes_per_op": alg_survey, "survey_8d_achieved": round(ach_survey, 1),
-                         "survey_8d_frac": round(ach_survey / HBM_PEAK_GBPS, 4),
-                         "byte_counts": "algorithmic_bytes_per_op itemises every stage (DESIGN.md §7); survey_8d_* is SURVEY.md 8(d)'s figure "
-                                        "(limb-NTT traffic + the tensor product's 9 limb moves only)",
+            # frac is quoted on SURVEY.md 8(d)'s per-unit figure (the contract's byte count); the itemised count of every stage's operands
+            # (what the operation sequence has to move with each limb-NTT in two passes) is reported beside it as moved_*
+            "roofline": {"bound": "hbm", "algorithmic_bytes_per_op": alg_survey, "limb_ntts_per_op": ntt_limbs,
+                         "achieved": round(ach_survey, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach_survey / HBM_PEAK_GBPS, 4),
+                         "itemised_bytes_per_op": alg, "moved_achieved": round(ach, 1), "moved_frac": round(ach / HBM_PEAK_GBPS, 4),
+                         "byte_counts": "algorithmic_bytes_per_op = SURVEY.md 8(d)'s figure (limb-NTT traffic + the tensor product's 9 limb moves); "
+                                        "itemised_bytes_per_op counts every stage's operands once (DESIGN.md §7): moved_* is quoted on it",
                          "dominant_kernel": "ntt_static_kernel (57 % over its pass kernels; then switch_basis_kernel 16 %, "
                                             "ks_inner_multi_kernel 15 %, tensor_kernel 11 %): shares in "
                                             "profiles/r05_rocprof_kernel_stats_evalmult256.csv"}}
@@ -670,6 +672,87 @@ def bfv_leg(lib, device, batch, steps, warmup, sync, with_cpu, parity=True):
             "parity": par, "cpu_baseline": cpu}
 
 
+class PowerSampler:
+    """Package power and shader clock of the device while a leg runs (the headline leg runs at the package power cap: DESIGN.md 4.12).
+    Reads the amdgpu hwmon files when the box exposes them (a read costs microseconds, sampled from a thread every 10 ms); otherwise
+    `sample_rocm_smi()` is called once by the caller inside a longer window."""
+
+    def __init__(self, device=0):
+        import glob
+        self.files = None
+        # the hwmon directory of THIS HIP device (a host exposes every GPU of the node in sysfs): by PCI bus id
+        hw = []
+        try:
+            hip = C.CDLL("libamdhip64.so")
+            buf = C.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(device)) == 0:
+                hw = sorted(glob.glob(f"/sys/bus/pci/devices/{buf.value.decode().lower()}/hwmon/hwmon*"))
+        except Exception:
+            hw = []
+        for h in hw:
+            pw = next((os.path.join(h, n) for n in ("power1_average", "power1_input") if os.path.exists(os.path.join(h, n))), None)
+            if pw:
+                cap, fq = os.path.join(h, "power1_cap"), os.path.join(h, "freq1_input")
+                self.files = (pw, cap if os.path.exists(cap) else None, fq if os.path.exists(fq) else None)
+                break
+        self.samples, self._stop, self._thr = [], False, None
+
+    @staticmethod
+    def _read(path):
+        try:
+            return float(open(path).read().strip())
+        except Exception:
+            return None
+
+    def start(self):
+        if not self.files:
+            return
+        import threading
+
+        def loop():
+            while not self._stop:
+                w = self._read(self.files[0])
+                f = self._read(self.files[2]) if self.files[2] else None
+                if w is not None:
+                    self.samples.append((w / 1e6, f / 1e6 if f else None))
+                time.sleep(0.01)
+        self._thr = threading.Thread(target=loop, daemon=True)
+        self._thr.start()
+
+    def stop(self):
+        self._stop = True
+        if self._thr is not None:
+            self._thr.join()
+        if not self.samples:
+            return None
+        ws = [w for w, _ in self.samples]
+        fs = [f for _, f in self.samples if f]
+        cap = self._read(self.files[1]) if self.files[1] else None
+        return {"source": f"amdgpu hwmon of this device ({self.files[0]}), sampled every 10 ms over the timed steps", "samples": len(ws),
+                "package_W_mean": round(sum(ws) / len(ws), 1), "package_W_max": round(max(ws), 1),
+                "sclk_MHz_mean": round(sum(fs) / len(fs)) if fs else None, "package_cap_W": round(cap / 1e6, 1) if cap else None}
+
+    @staticmethod
+    def sample_rocm_smi():
+        import re
+        import subprocess
+        try:
+            t = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--showmaxpower"], capture_output=True, text=True, timeout=20).stdout
+        except Exception as e:
+            return {"error": f"{type(e).__name__}: {e}"}
+        w = re.search(r"Current Socket Graphics Package Power \(W\): ([0-9.]+)", t)
+        c = re.search(r"Max Graphics Package Power \(W\): ([0-9.]+)", t)
+        f = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", t)
+        return {"source": "one rocm-smi reading in the middle of a window of extra (untimed) steps of the same leg",
+                "package_W": float(w.group(1)) if w else None, "package_cap_W": float(c.group(1)) if c else None,
+                "sclk_MHz": int(f.group(1)) if f else None}
+
+
+def shutil_which(name):
+    import shutil
+    return shutil.which(name)
+
+
 def free_port():
     import socket
     with socket.socket() as sk:
@@ -743,9 +826,12 @@ def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev,
         # (the first lockstep passes after the threaded pass run 5-10 % below the later ones — its buffer caches go back to the device on
         # demand, profiles/r04_sweeps.md sessions h / i — so two passes precede the readings)
         h.bootstrap_wide(group, 1, wide_threads)
-        w0, m0 = h.counters(), h.member_bytes()
+        w0, m0, s0 = h.counters(), h.member_bytes(), h.member_stats()
         wsec = h.bootstrap_wide(group, 3, wide_threads)
-        w1, m1 = h.counters(), h.member_bytes()
+        w1, m1, s1 = h.counters(), h.member_bytes(), h.member_stats()
+        # members of DCRTPolyHipImpl that ran on its host mirror (the reference's own DCRTPolyImpl) between the two readings: the
+        # lockstep passes the rate is quoted on.  A device figure with mirror executions in it is not a device figure.
+        mirror = {k: v[1] - s0.get(k, (0, 0, 0, 0))[1] for k, v in s1.items() if v[1] - s0.get(k, (0, 0, 0, 0))[1] > 0}
         ndiff = h.compare_saved()
         wide = {"seconds_per_pass": round(wsec, 4), "bootstraps_per_s": round(r["ciphertexts"] / wsec, 2),
                 "group": group if 0 < group < r["ciphertexts"] else r["ciphertexts"],
@@ -754,6 +840,8 @@ def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev,
                            "(compared in this run, every limb on the host)" if ndiff == 0 else
                            f"MISMATCH: {ndiff} of {r['ciphertexts']} outputs differ from the narrow pass's"),
                 "host_threads": wide_threads,
+                "mirror_executions": {"total": sum(mirror.values()), "by_member": mirror,
+                                      "window": "the 1 untimed + 3 timed lockstep passes between the counter readings (fhe_hal_member_stats)"},
                 "how": f"one cc->EvalBootstrap per group on a ciphertext of K-tower towers, the groups over {wide_threads} host thread(s) / stream(s)",
                 "passes": "2 untimed, then 1 untimed + 3 timed",
                 "roofline": per_bootstrap(w0, w1, 4, r["ciphertexts"] / wsec)}  # (1 untimed + 3 timed passes between the readings)
@@ -774,7 +862,9 @@ def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev,
                 wide["roofline"]["traffic_source"] = "profiles/r05_bootstrap_pmc.json was recorded with other kernel sources: not quoted"
         except Exception:
             pass
-        if ndiff != 0:
+        if mirror:
+            wide["parity"] = f"HOST-MIRROR EXECUTIONS in the timed passes ({sum(mirror.values())}: {mirror}); " + wide["parity"]
+        if ndiff != 0 or mirror:
             wide["bootstraps_per_s_unverified"] = wide.pop("bootstraps_per_s")  # a figure without parity is not reported as the rate
     except Exception as e:
         wide = {"error": f"{type(e).__name__}: {e}"}
@@ -923,8 +1013,19 @@ def cc_evalmult_leg(with_cpu, libpath):
         run.resident = (float(mr.group(1)), int(md.group(1))) if p.returncode == 0 and mr and md else None
         # PCIe bytes of the evaluation phase (the program resets the backend's counters after key generation and encryption; the phase
         # also downloads the two dumped products and the one decrypted for the check)
-        mp = re.search(r"hal: available 1 deviceOps \d+ hostOps \d+ h2dBytes (\d+) d2hBytes (\d+)", p.stdout)
-        run.pcie = (int(mp.group(1)), int(mp.group(2))) if p.returncode == 0 and mp else None
+        mp = re.search(r"hal: available 1 deviceOps \d+ hostOps (\d+) h2dBytes (\d+) d2hBytes (\d+)", p.stdout)
+        run.pcie = (int(mp.group(2)), int(mp.group(3))) if p.returncode == 0 and mp else None
+        # host-mirror executions of the evaluation phase, by member ("halmember <member> <device ops> <mirror executions> <reads> <bytes>")
+        run.mirror = None
+        if p.returncode == 0 and mp:
+            by = {}
+            for ln in p.stdout.splitlines():
+                f = ln.split()
+                if len(f) >= 6 and f[0] == "halmember" and int(f[-3]) > 0:
+                    by[" ".join(f[1:-4])] = int(f[-3])
+            run.mirror = {"total": int(mp.group(1)), "by_member": by,
+                          "window": "the program's evaluation phase: warm-up + timed passes + the dump / decryption of the checked products "
+                                    "(counters reset after key generation and encryption)"}
         return (float(m.group(1)) if p.returncode == 0 and m else None), (p.stdout + p.stderr)[-400:]
 
     hipenv = {"FHE_HIP_LIB": libpath}
@@ -934,6 +1035,7 @@ def cc_evalmult_leg(with_cpu, libpath):
     if rate is None:
         shutil.rmtree(tmp, ignore_errors=True)
         return {"error": txt}
+    mirror_threaded = run.mirror
     pcie = None
     if run.pcie is not None:  # (1 warm-up + 10 timed passes of 256 products)
         pcie = {"h2d_MB_per_EvalMult": round(run.pcie[0] / (11 * 256) / 1e6, 4), "d2h_MB_per_EvalMult": round(run.pcie[1] / (11 * 256) / 1e6, 4),
@@ -946,6 +1048,7 @@ def cc_evalmult_leg(with_cpu, libpath):
     if wrate is not None:
         same = open(os.path.join(tmp, "w256.bin"), "rb").read() == open(os.path.join(tmp, "h256.bin"), "rb").read()
         lock = {"ops_per_s": round(wrate, 1), "group": 64, "host_threads": 1,  # (one thread issues the group's launches)
+                "mirror_executions": run.mirror,
                 "how": "PackWide of the operands, cc->EvalMult and UnpackTower of the products INSIDE the timed region; towers of a lockstep group "
                        "are windows of one allocation (wide from birth: packing operands that are already consecutive windows and unpacking cost no "
                        "copy); the 10 timed passes are enqueued back to back and the device queue is drained once behind the last",
@@ -962,9 +1065,12 @@ def cc_evalmult_leg(with_cpu, libpath):
     res = {"workload": "cc->EvalMult(ct, ct) with HYBRID relinearisation, N=2^16, 21 Q + 7 P limbs, dnum 3, 256 ciphertexts: over 8 host threads "
                        "(one tower per operation) and in lockstep (wide towers: 64 ciphertexts per cc->EvalMult call, one host thread)",
            "ops_per_s": round(rate, 1), "ops_per_s_over_host_threads": round(threaded, 1), "lockstep": lock,
-           "pcie": pcie, "hal_build": which,
+           "mirror_executions": mirror_threaded, "pcie": pcie, "hal_build": which,
            "how": "reference pke (unmodified sources) on the HIP backend of DCRTPoly; ops_per_s = the better of the two ways of running the batch",
            "parity": "not checked", "cpu_baseline": None}
+    nmirror = sum((m or {}).get("total", 0) for m in (mirror_threaded, lock.get("mirror_executions")))
+    if nmirror:
+        res["parity"] = f"HOST-MIRROR EXECUTIONS in the evaluation phase ({nmirror}); products not yet compared"
     if with_cpu and os.path.exists(stock):
         threads = min(32, os.cpu_count() or 1)
         crate, ctxt = run(stock, os.path.join(tmp, "s64.bin"), 64, 1, threads, {})
@@ -981,6 +1087,8 @@ def cc_evalmult_leg(with_cpu, libpath):
                 res["parity"] = ("ALL 64 products of the 64-ciphertext batch identical to the stock backend's, over host threads AND in lockstep "
                                  "(one group of 64): 128-bit digest of every word of every product, first and last product byte for byte"
                                  if same and lsame else f"MISMATCH vs the stock backend (threaded {same}, lockstep {lsame})")
+                if nmirror:
+                    res["parity"] = f"HOST-MIRROR EXECUTIONS in the evaluation phase ({nmirror}); " + res["parity"]
             except OSError as e:
                 res["parity"] = f"dumps unreadable: {e}"
     shutil.rmtree(tmp, ignore_errors=True)
@@ -1056,12 +1164,28 @@ def main():
         step()
     barrier()
     gpu_sync()
+    psamp = PowerSampler(device) if rank == 0 else None
+    if psamp is not None:
+        psamp.start()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     gpu_sync()
     barrier()
     dt = time.perf_counter() - t0
+    power = psamp.stop() if psamp is not None else None
+    if rank == 0 and world == 1 and power is None and not a.no_power and shutil_which("rocm-smi"):
+        # no hwmon files: ~3 s of extra steps of the same leg (untimed) with one rocm-smi reading in the middle
+        import threading
+        box = {}
+        thr = threading.Timer(1.2, lambda: box.update(PowerSampler.sample_rocm_smi()))
+        thr.start()
+        tw = time.perf_counter()
+        while time.perf_counter() - tw < 3.0:
+            step()
+            ctx.sync()
+        thr.join()
+        power = box or None
     per_rank_ms = [round(dt / a.steps * 1e3, 4)]
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=tdev)
@@ -1204,7 +1328,7 @@ def main():
             # HBM bytes per launch from the committed rocprofv3 PMC passes of this exact workload — quoted only when the record
             # was made with the kernels this run executes (same kernel-source identity), else null
             traffic, tsrc, wasted = None, None, None
-            for rec in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            for rec in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", rec)))
                     if pmc.get("workload") == f"logN{logN}_L{L}_B{B}" and pmc.get("kernel_source_sha") == source_sha():
@@ -1220,23 +1344,25 @@ def main():
             # the BINDING roofline of the dominant kernel is integer issue, not HBM: SQ counters of this workload (committed record)
             binding = None
             try:
-                sqrec = next(r for r in ("r05_pmc_valu.json", "r04_pmc_valu.json", "r03_pmc_valu.json") if os.path.exists(os.path.join(ROOT, "profiles", r)))
+                sqrec = next(r for r in ("r06_pmc_valu.json", "r05_pmc_valu.json", "r04_pmc_valu.json", "r03_pmc_valu.json") if os.path.exists(os.path.join(ROOT, "profiles", r)))
                 sq = json.load(open(os.path.join(ROOT, "profiles", sqrec)))["legs"]["ntt"]
                 ent = next(v for k, v in sq.items() if k.startswith(dom[:-3]))
                 instr, act = ent["valu_instructions_per_wave"], ent["active_valu_over_wave_cycles"]
                 simds = 256 * 4
                 ns_per_instr = per_kernel[dom] * 1e6 / (instr * ent["waves"] / simds)  # wall time per VALU instruction issued on one SIMD
-                # tools/seqbench.py (profiles/r04_seqbench.json): a SIMD shared by 4 waves issues one 64-bit-class integer instruction (v_mad_u64_u32,
-                # v_mul_lo/hi_u32, v_lshl_add_u64, carry adds) per 2.77 cycles and a VGPR-only 32-bit one per 1.03; this kernel's mix prices at 2.75
-                peak_ns = 2.75 / 2.4
-                binding = {"bound": "valu+hbm overlap", "instr_per_wave_tile": instr, "waves_per_simd": 4,
+                # what binds the leg is the PACKAGE POWER CAP (profiles/r06_sweeps.md section 2): 1386-1393 W of 1400 W in every sample, shader clock
+                # 1.93-1.96 GHz instead of 2.4; at that clock the row passes issue ~90 % of one VALU instruction per quad-cycle and SIMD
+                clk = ((power or {}).get("sclk_MHz_mean") or (power or {}).get("sclk_MHz") or 1950) / 1e3
+                peak_ns = 4.17 / clk  # the multiplier class issues once per 4.17 cycles per SIMD (tools/energybench.hip)
+                binding = {"bound": "package power cap (time = energy / cap)", "instr_per_wave_tile": instr,
                            "valu_active_over_wave_cycles": act,
-                           "ns_per_instr_per_simd": round(ns_per_instr, 3), "cycles_per_instr": round(ns_per_instr * 2.4, 2),
-                           "frac_of_issue_peak": round(peak_ns / ns_per_instr, 3),
-                           "issue_peak": "2.75 cycles per VALU instruction of this kernel's mix per SIMD (measured in isolation, tools/seqbench.py), priced "
-                                         "at the 2.4 GHz peak clock.  A row pass is 5.7 ms of compute and 5.5 ms of HBM time and takes ~8.2 ms; a step is "
-                                         "17.0 ms of compute and 22 ms of HBM time (ablations without loads / stores, the closed queueing model that "
-                                         "reproduces the pass, and the five rejected reschedulings: profiles/r05_sweeps.md section 1)",
+                           "ns_per_instr_per_simd": round(ns_per_instr, 3), "sclk_GHz_used": clk,
+                           "frac_of_issue_peak_at_that_clock": round(peak_ns / ns_per_instr, 3),
+                           "power": power,
+                           "energy_model": "per step: floor 590 W x t + HBM 128.8 GB moved x 72 pJ/B (9.3 J) + 1.0e10 VALU wave-instructions x ~1.05 nJ "
+                                           "(10.5 J) = 36.6 J against 38.6 J measured; one stage of butterflies = 0.27 J = 0.33 ms; residency (4 -> 8 waves "
+                                           "per SIMD), barriers (6 -> 1), tiles per CU (4 -> 8), software pipelining: all built bit-exact, none changed the "
+                                           "time (profiles/r06_sweeps.md sections 1-2, profiles/r06_energybench.json)",
                            "source": f"profiles/{sqrec} (rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES ... on this workload) "
                                      "x this run's hipEvent kernel time"}
             except Exception as e:
@@ -1297,6 +1423,28 @@ def main():
         except Exception as e:
             keyrep = {"error": f"{type(e).__name__}: {e}"}
 
+    # ---- what the run looked like from inside (so that the first SCALE record verifies itself): the process group as torch.distributed
+    # reports it, and every rank's device as the HIP runtime names it
+    dinfo = {"launcher_world_size": world, "backend_requested": backend if dist is not None else None, "process_group": None, "ranks": None}
+    mine = {"rank": rank, "local_rank": local, "hip_device": device, "pid": os.getpid(), "host": os.uname().nodename}
+    try:
+        if torch is not None and torch.cuda.is_available():
+            pr = torch.cuda.get_device_properties(device)
+            mine.update({"name": pr.name, "memory_GiB": round(pr.total_memory / 2**30, 1), "compute_units": pr.multi_processor_count})
+            mine["pci_bus_id"] = getattr(pr, "pci_bus_id", None)
+    except Exception as e:
+        mine["device_query_error"] = f"{type(e).__name__}: {e}"
+    if dist is not None:
+        dinfo["process_group"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rank": dist.get_rank(),
+                                  "is_nccl_available": bool(dist.is_nccl_available()),
+                                  "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None}
+        got = [None] * world
+        dist.all_gather_object(got, mine)
+        dinfo["ranks"] = got
+        dinfo["distinct_devices"] = len({(g.get("host"), g.get("hip_device")) for g in got})
+    else:
+        dinfo["ranks"] = [mine]
+
     bfv = None
     if not a.no_bfv and logN == 16:
         bfv = bfv_leg(lib, device, a.bfv_batch, max(30, a.steps * 3), 6, gpu_sync,
@@ -1321,6 +1469,8 @@ def main():
                        "parallelism": f"batch-sharded x{world}, no data-path collective"},
             "hbm_roofline_frac_fwd_inv": round(value / world / HBM_PEAK_GBPS, 4),
             "roofline": roof, "cpu_baseline": cpu, "evalmult": em,
+            # the leg runs at the package power cap (profiles/r06_sweeps.md section 2): time = energy / cap
+            "power": power,
             # the legs that run the reference's own CryptoContext on the backend need the reference-built test programs
             "hal_build": "present" if os.path.exists(os.path.join(ROOT, "tests", "hal", "_build", "shim_ckks_hip")) else "absent",
             "hadamard": hadamard, "parity_at_full_size": roundtrip, "ms_per_step_per_rank": per_rank_ms,
@@ -1331,8 +1481,12 @@ def main():
             "cpu_team_rule": "best OpenMP team of {8,16,32,64,128,all}: searched live by the in-process legs, fixed at 32 (= what the search "
                              "picks on these hosts) for the legs that run the reference as a separate program",
         }
+        out["distributed"] = dinfo
         if keyrep is not None:
             out["rotation_key_replication"] = keyrep
+            dinfo["key_replication_GB_per_s"] = keyrep.get("GB_per_s")
+        if boot is not None and isinstance(boot, dict) and boot.get("key_replication_GBps") is not None:
+            dinfo["bootstrap_key_set_replication_GB_per_s"] = boot.get("key_replication_GBps")
         if bfv is not None:
             out["bfv_evalmult"] = bfv
         if ltr is not None:

@@ -133,6 +133,18 @@ class BootBatch:
                 out[" ".join(f[:-4])] = int(f[-1])
         return out
 
+    def member_stats(self):
+        """{member: (device operations, host-mirror executions, host reads after a device->host copy, operand bytes)} so far"""
+        n = self.L.fbb_member_stats(None, 0)
+        buf = C.create_string_buffer(n)
+        self.L.fbb_member_stats(buf, n)
+        out = {}
+        for ln in buf.value.decode().split("\n"):
+            f = ln.split()
+            if len(f) >= 5:
+                out[" ".join(f[:-4])] = tuple(int(v) for v in f[-4:])
+        return out
+
     def save_outputs(self):
         """keeps the current outputs for compare_saved (the next pass produces new objects)"""
         self._ok(self.L.fbb_save_outputs(self.h))

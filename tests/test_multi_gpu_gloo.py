@@ -197,6 +197,11 @@ def test_bench_self_launches_two_ranks_on_gloo(backend):
     assert d["evalmult"]["parity"].startswith("bit-exact vs oracle")
     assert d["parity_at_full_size"].startswith("forward NTT of ALL 4 towers")
     assert "scatter" in d["rotation_key_replication"]["how"] and d["rotation_key_replication"]["keys"] == 14
+    # the line verifies its own process group: backend and world size as torch.distributed reports them, one record per rank
+    dd = d["distributed"]
+    assert dd["process_group"]["backend"] == "gloo" and dd["process_group"]["world_size"] == 2 and dd["launcher_world_size"] == 2
+    assert sorted(r["rank"] for r in dd["ranks"]) == [0, 1] and len({r["pid"] for r in dd["ranks"]}) == 2
+    assert dd["key_replication_GB_per_s"] == d["rotation_key_replication"]["GB_per_s"]
 
 
 def _bench_on_gloo(world, extra_env=None, extra_args=(), timeout=2400):
