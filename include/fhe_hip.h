@@ -506,6 +506,22 @@ uint32_t   fhe_param_select_p(uint32_t logN, uint32_t sizeQ, const uint64_t* q, 
  * rotation by `index` slots (m = 2N, a power of two); 0 on error */
 uint32_t   fhe_param_find_automorphism_index_2n_complex(int32_t index, uint32_t m);
 
+/* ---- f3: sampled towers on the device (optional) ------------------------------------
+ * The sampling constructors of DCRTPolyImpl (dcrtpoly-impl.h:126-205) as device kernels: out[batch][nLimbs][N], COEFFICIENT format,
+ *   fhe_sample_uniform   every word uniform in [0, q_limb)          DiscreteUniformGeneratorImpl::GenerateVector (discreteuniformgenerator.h:55-77)
+ *   fhe_sample_gaussian  ONE integer per coefficient, stored modulo every limb (negative k as q - |k|): Peikert's inversion over the
+ *                        reference's table (discretegaussiangenerator-impl.h:75-115), 1 < sigma < 300
+ *   fhe_sample_ternary   ONE value of {-1, 0, 1} per coefficient, uniform (TernaryUniformGeneratorImpl::GenerateVector, h = 0)
+ * Generator: Philox4x32-10 keyed by `seed`, counter = (element, draw, streamId) — NOT the reference's sequential Blake2 stream: the
+ * distributions are the reference's, the words are not (the survey marks this row "gives up bit-parity with Blake2; keep optional");
+ * the oracle restates the same construction word for word.  Give every sampled tower set its own streamId. */
+fhe_status fhe_sample_uniform(fhe_ctx* ctx, uint64_t* out, const uint32_t* limbIdx, uint32_t nLimbs, uint32_t batch, uint64_t seed,
+                              uint32_t streamId, void* stream);
+fhe_status fhe_sample_gaussian(fhe_ctx* ctx, uint64_t* out, const uint32_t* limbIdx, uint32_t nLimbs, uint32_t batch, double sigma,
+                               uint64_t seed, uint32_t streamId, void* stream);
+fhe_status fhe_sample_ternary(fhe_ctx* ctx, uint64_t* out, const uint32_t* limbIdx, uint32_t nLimbs, uint32_t batch, uint64_t seed,
+                              uint32_t streamId, void* stream);
+
 /* ---- measurement helper ----------------------------------------------------------------------------
  * Runs `iters` back-to-back launches of fwd (dir=0), inv (dir=1) or fwd+inv (dir=2) NTT on x — or of a single
  * pass kernel of a two-pass ring: 10/11 = column/row pass of the forward, 12/13 = row/column pass of the

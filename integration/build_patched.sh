@@ -15,6 +15,9 @@ for d in core binfhe pke; do
   mkdir -p "$B/tree/src/$d"
   cp -r "$REF/src/$d/include" "$REF/src/$d/lib" "$B/tree/src/$d/"
 done
+# (the patch also carries the build option: the three CMakeLists.txt it edits travel with the sources; this script builds with make)
+cp "$REF/CMakeLists.txt" "$B/tree/CMakeLists.txt"
+for d in core pke; do cp "$REF/src/$d/CMakeLists.txt" "$B/tree/src/$d/CMakeLists.txt"; done
 (cd "$B/tree" && patch -p1 -s < "$HERE/with_hip.patch")
 make -s -j"$(nproc)" -C "$ROOT/openfhe-development_amd/hal" PATCHED=1 REF="$B/tree" OUT="$B/lib" "$B/lib/libOPENFHEpke_hip.so" "$B/lib/libfhe_boot_batch_hip.so"
 HAL="$ROOT/openfhe-development_amd/hal"

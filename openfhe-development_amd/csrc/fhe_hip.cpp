@@ -26,6 +26,7 @@
 #include "ntt_static.h"
 #include "ntt_row8.h"
 #include "rt.h"
+#include "sampler_kernels.h"
 
 using namespace fhe;
 
@@ -259,6 +260,8 @@ struct fhe_ctx {
     uint64_t* d_red   = nullptr;  // [L] redM | redR << 32: quotient estimate of the static NTT kernels (ntt_static.h)
     uint64_t* d_mu128 = nullptr;  // [L][2]
     std::vector<void*> owned;     // every device allocation made for tables (freed in destroy)
+    // discrete-Gaussian inversion tables by standard deviation (fhe_sample_gaussian): {device table, length, a}
+    std::map<double, std::tuple<const double*, uint32_t, double>> dggTabs;
     // cached per-level rescale tables (ckksrns-cryptoparameters.cpp:60-81): sizeQl -> {A, B} device arrays
     std::map<uint32_t, std::pair<TwPair*, TwPair*>> rescaleTabs;
     std::map<std::vector<uint64_t>, TwPair*> constTabs;  // per-limb constants of callers' tables, by content (const_table); the map owns
@@ -1326,6 +1329,57 @@ extern "C" fhe_status fhe_switch_modulus(fhe_ctx* c, uint64_t* out, const uint32
         return s;
     RT_CHECK(rt::set_device(c->device));
     return switch_modulus_run(c, out, sel, nl, src, srcLimbs, srcPos, srcCtxLimb, nullptr, bt, st);
+}
+
+// ---- f3: sampled towers on the device (sampler_kernels.h) ----------------------------------------------------------------------
+static fhe_status sample_run(fhe_ctx* c, uint64_t* out, const uint32_t* li, uint32_t nl, uint32_t bt, uint32_t kind, double sigma,
+                             uint64_t seed, uint32_t streamId, void* st, const char* who) {
+    ARG_CHECK(c && out && bt >= 1, "fhe_sample: null argument or empty batch");
+    SampleArgs a;
+    if (fhe_status s = make_sel(c, li, nl, &a.sel, who))
+        return s;
+    RT_CHECK(rt::set_device(c->device));
+    a.out = out, a.q = c->d_q, a.logN = c->logN, a.nLimbs = nl, a.batch = bt, a.seed = seed, a.stream = streamId, a.kind = kind;
+    a.cdf = nullptr, a.cdfLen = 0, a.a = 0.0;
+    if (kind == 1) {
+        // the reference's table (DiscreteGaussianGeneratorImpl::Initialize, discretegaussiangenerator-impl.h:75-89), built once per sigma
+        ARG_CHECK(sigma > 1.000000001 && sigma < 300.0, "fhe_sample_gaussian: the inversion sampler covers 1 < sigma < 300 (the reference's Peikert range)");
+        std::lock_guard<std::mutex> lk(c->cacheMutex);
+        auto it = c->dggTabs.find(sigma);
+        if (it == c->dggTabs.end()) {
+            const double M = 12.00610553538285;
+            const int64_t fin = (int64_t)std::ceil(sigma * M);
+            std::vector<double> vals((size_t)fin);
+            const double variance = 2 * sigma * sigma;
+            double cusum = 0.0;
+            for (int64_t x = 1; x <= fin; ++x)
+                vals[(size_t)(x - 1)] = (cusum += std::exp(-((double)(x * x) / variance)));
+            const double av = 1.0 / (2 * cusum + 1.0);
+            for (auto& v : vals)
+                v *= av;
+            void* d = nullptr;
+            if (fhe_status s = upload(c, vals.data(), vals.size() * sizeof(double), &d))
+                return s;
+            it = c->dggTabs.emplace(sigma, std::make_tuple((const double*)d, (uint32_t)fin, av)).first;
+        }
+        a.cdf = std::get<0>(it->second), a.cdfLen = std::get<1>(it->second), a.a = std::get<2>(it->second);
+    }
+    const uint64_t lanes = kind == 0 ? ((uint64_t)bt * nl) << c->logN : (uint64_t)bt << c->logN;
+    FHE_LAUNCH(sample_kernel, (uint32_t)((lanes + kThreads - 1) / kThreads), st, a);
+    LAUNCH_CHECK();
+    return FHE_OK;
+}
+extern "C" fhe_status fhe_sample_uniform(fhe_ctx* c, uint64_t* out, const uint32_t* li, uint32_t nl, uint32_t bt, uint64_t seed,
+                                         uint32_t streamId, void* st) {
+    return sample_run(c, out, li, nl, bt, 0, 0.0, seed, streamId, st, "fhe_sample_uniform");
+}
+extern "C" fhe_status fhe_sample_gaussian(fhe_ctx* c, uint64_t* out, const uint32_t* li, uint32_t nl, uint32_t bt, double sigma,
+                                          uint64_t seed, uint32_t streamId, void* st) {
+    return sample_run(c, out, li, nl, bt, 1, sigma, seed, streamId, st, "fhe_sample_gaussian");
+}
+extern "C" fhe_status fhe_sample_ternary(fhe_ctx* c, uint64_t* out, const uint32_t* li, uint32_t nl, uint32_t bt, uint64_t seed,
+                                         uint32_t streamId, void* st) {
+    return sample_run(c, out, li, nl, bt, 2, 0.0, seed, streamId, st, "fhe_sample_ternary");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -96,6 +96,9 @@ class Lib:
         S("fhe_tensor", C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, u32p, u32, u32, vp])
         S("fhe_automorph", C.c_int, [vp, vp, vp, u32, C.c_int, u32p, u32, u32, vp])
         S("fhe_switch_modulus", C.c_int, [vp, vp, u32p, u32, vp, u32, u32, u32, u32, vp])
+        S("fhe_sample_uniform", C.c_int, [vp, vp, u32p, u32, u32, C.c_uint64, u32, vp])
+        S("fhe_sample_gaussian", C.c_int, [vp, vp, u32p, u32, u32, C.c_double, C.c_uint64, u32, vp])
+        S("fhe_sample_ternary", C.c_int, [vp, vp, u32p, u32, u32, C.c_uint64, u32, vp])
         S("fhe_conv_create", C.c_int, [vp, u32p, u32, u32p, u32, C.POINTER(vp)])
         S("fhe_conv_destroy", None, [vp])
         S("fhe_approx_switch_basis", C.c_int, [vp, vp, u32, u32, vp, u32, u32, u32, vp])
@@ -306,6 +309,21 @@ class Context:
 
     def empty(self, batch, n_limbs, limb_idx=None, fmt=EVALUATION):
         return Tower(self, self.malloc(batch * n_limbs * self.N * 8), batch, n_limbs, limb_idx, fmt, owned=True)
+
+    # ---- sampled towers (the sampling constructors of DCRTPolyImpl, dcrtpoly-impl.h:126-205, on the device: fhe_sample_*) ----
+    def sample(self, kind, batch, n_limbs, seed, stream_id, limb_idx=None, sigma=3.19, stream=None):
+        """kind: "uniform" (DugType), "gaussian" (DggType, standard deviation sigma) or "ternary" (TugType); COEFFICIENT format"""
+        t = self.empty(batch, n_limbs, limb_idx, COEFFICIENT)
+        L = self.lib.L
+        if kind == "uniform":
+            self.lib.check(L.fhe_sample_uniform(self.h, t.ptr, t._li(), n_limbs, batch, seed, stream_id, stream))
+        elif kind == "gaussian":
+            self.lib.check(L.fhe_sample_gaussian(self.h, t.ptr, t._li(), n_limbs, batch, sigma, seed, stream_id, stream))
+        elif kind == "ternary":
+            self.lib.check(L.fhe_sample_ternary(self.h, t.ptr, t._li(), n_limbs, batch, seed, stream_id, stream))
+        else:
+            raise ValueError(kind)
+        return t
 
 
 class Tower:

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "utils/exception.h"
+#include "math/distributiongenerator.h"  // PseudoRandomNumberGenerator (the device sampler's seed is drawn from the reference's PRNG)
 
 namespace lbcrypto {
 namespace hiprt {
@@ -162,6 +163,7 @@ Runtime* build() {
                   FHE_SYM(add_const, fhe_add_const) && FHE_SYM(sub_const, fhe_sub_const) && FHE_SYM(times_q_over_t, fhe_times_q_over_t) &&
                   FHE_SYM(mod_switch_round, fhe_mod_switch_round) && FHE_SYM(automorph, fhe_automorph) &&
                   FHE_SYM(switch_modulus, fhe_switch_modulus) && FHE_SYM(rescale_limbs, fhe_rescale_limbs) &&
+                  FHE_SYM(sample_uniform, fhe_sample_uniform) && FHE_SYM(sample_gaussian, fhe_sample_gaussian) && FHE_SYM(sample_ternary, fhe_sample_ternary) &&
                   FHE_SYM(rescale_limbs_pair, fhe_rescale_limbs_pair) && FHE_SYM(add_pair, fhe_add_pair) && FHE_SYM(sub_pair, fhe_sub_pair) &&
                   FHE_SYM(mul_const_pair, fhe_mul_const_pair) && FHE_SYM(lincomb, fhe_lincomb) && FHE_SYM(mem_info, fhe_mem_info) &&
                   FHE_SYM(rescale_workspace_bytes, fhe_rescale_workspace_bytes) && FHE_SYM(conv_create_custom, fhe_conv_create_custom) &&
@@ -380,6 +382,24 @@ CtxHolder::~CtxHolder() {
     r.api.ctx_destroy(ctx);
 }
 bool Available() { return rt().live; }
+bool DeviceSamplerEnabled() {
+    static const bool on = [] {
+        const char* v = std::getenv("FHE_HAL_DEVICE_SAMPLER");
+        return v && v[0] == '1';
+    }();
+    return on && Available();
+}
+void DeviceSamplerStream(uint64_t* seed, uint32_t* streamId) {
+    static std::once_flag once;
+    static uint64_t s = 0;
+    static std::atomic<uint32_t> next{1};
+    std::call_once(once, [] {
+        auto& g = lbcrypto::PseudoRandomNumberGenerator::GetPRNG();
+        s       = ((uint64_t)g() << 32) | (uint64_t)g();
+    });
+    *seed     = s;
+    *streamId = next.fetch_add(1, std::memory_order_relaxed);
+}
 const Api& api() { return rt().api; }
 int Device() { return rt().device; }
 fhe_ctx* AnyCtx() { return rt().anyCtx; }

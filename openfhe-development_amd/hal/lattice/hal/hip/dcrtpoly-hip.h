@@ -128,11 +128,22 @@ public:
             m_k         = hiprt::ThreadWidth();  // (an accumulator of a wide evaluation is wide)
         }
     }
-    DCRTPolyHipImpl(const DggType& dgg, const std::shared_ptr<Params>& p, Format f = Format::EVALUATION) : m_h{dgg, p, f} {}
+    // the sampling constructors (dcrtpoly-impl.h:126-205).  Default: the reference's host samplers on the reference's PRNG stream (same seed,
+    // same words as the default backend), the tower uploaded at its first device use.  FHE_HAL_DEVICE_SAMPLER=1: device kernels on a
+    // counter-based generator (SampleOnDevice below) — a bootstrapping key set is 5-6 GB of uniform words that then never cross PCIe.
+    DCRTPolyHipImpl(const DggType& dgg, const std::shared_ptr<Params>& p, Format f = Format::EVALUATION) {
+        if (!SampleOnDevice(1, p, f, dgg.GetStd()))
+            m_h = HostType(dgg, p, f);
+    }
     DCRTPolyHipImpl(const BugType& bug, const std::shared_ptr<Params>& p, Format f = Format::EVALUATION) : m_h{bug, p, f} {}
-    DCRTPolyHipImpl(const TugType& tug, const std::shared_ptr<Params>& p, Format f = Format::EVALUATION, uint32_t h = 0)
-        : m_h{tug, p, f, h} {}
-    DCRTPolyHipImpl(DugType& dug, const std::shared_ptr<Params>& p, Format f = Format::EVALUATION) : m_h{dug, p, f} {}
+    DCRTPolyHipImpl(const TugType& tug, const std::shared_ptr<Params>& p, Format f = Format::EVALUATION, uint32_t h = 0) {
+        if (h != 0 || !SampleOnDevice(2, p, f, 0.0))  // (a fixed Hamming weight is the host generator's)
+            m_h = HostType(tug, p, f, h);
+    }
+    DCRTPolyHipImpl(DugType& dug, const std::shared_ptr<Params>& p, Format f = Format::EVALUATION) {
+        if (!SampleOnDevice(0, p, f, 0.0))
+            m_h = HostType(dug, p, f);
+    }
 
     DCRTPolyType& operator=(std::initializer_list<uint64_t> rhs) override {
         FHE_HAL_MEMBER();
@@ -2218,6 +2229,39 @@ private:
         hiprt::CountDevice();
         DeviceIsNewer(Format::EVALUATION);
         DropLastMeta();  // :698 (a narrow tower's device copy keeps its leading limbs; the result buffer already has the new height)
+        return true;
+    }
+    // kind 0: uniform residues, 1: discrete Gaussian (Peikert's inversion, the reference's table), 2: uniform ternary; COEFFICIENT words on the
+    // device, transformed there when EVALUATION is asked for
+    bool SampleOnDevice(int kind, const std::shared_ptr<Params>& params, Format format, double sigma) {
+        if (!hiprt::DeviceSamplerEnabled() || !params || params->GetParams().empty() || (kind == 1 && !(sigma > 1.000000001 && sigma < 300.0)))
+            return false;
+        hiprt::Resolved r;
+        if (!ResolveSets(params->GetRingDimension(), {params}, &r))
+            return false;
+        hiprt::MemberScope scope("DeviceSampler");
+        const size_t N   = params->GetRingDimension();
+        const uint32_t L = (uint32_t)params->GetParams().size();
+        uint64_t seed;
+        uint32_t sid;
+        hiprt::DeviceSamplerStream(&seed, &sid);
+        {
+            hiprt::Op op;
+            auto d = hiprt::Alloc((size_t)L * N);
+            const auto& A = hiprt::api();
+            const fhe_status st = kind == 0   ? A.sample_uniform(r.ctx, op.W(d), r.idx[0].data(), L, 1, seed, sid, op.s)
+                                  : kind == 1 ? A.sample_gaussian(r.ctx, op.W(d), r.idx[0].data(), L, 1, sigma, seed, sid, op.s)
+                                              : A.sample_ternary(r.ctx, op.W(d), r.idx[0].data(), L, 1, seed, sid, op.s);
+            hiprt::Check(st, "DeviceSampler");
+            hiprt::CountDevice();
+            m_h         = HostType(params, Format::COEFFICIENT, false);
+            m_d         = std::move(d);
+            m_hostValid = false;
+            m_zero      = false;
+            m_k         = 1;
+        }
+        if (format == Format::EVALUATION)
+            SwitchFormat();
         return true;
     }
     bool ModRaiseOnDevice(const PolyType& e, const std::shared_ptr<Params>& params) {

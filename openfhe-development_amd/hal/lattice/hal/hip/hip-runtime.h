@@ -50,6 +50,9 @@ struct Api {
     decltype(&fhe_mod_switch_round) mod_switch_round;
     decltype(&fhe_automorph) automorph;
     decltype(&fhe_switch_modulus) switch_modulus;
+    decltype(&fhe_sample_uniform) sample_uniform;    // (optional sampling on the device: FHE_HAL_DEVICE_SAMPLER=1)
+    decltype(&fhe_sample_gaussian) sample_gaussian;
+    decltype(&fhe_sample_ternary) sample_ternary;
     decltype(&fhe_rescale_limbs) rescale_limbs;
     decltype(&fhe_rescale_limbs_pair) rescale_limbs_pair;
     decltype(&fhe_add_pair) add_pair;
@@ -96,6 +99,12 @@ struct Api {
 
 // true when the library is loaded and a device is usable; otherwise every DCRTPoly member runs on its host mirror
 bool Available();
+// FHE_HAL_DEVICE_SAMPLER=1: the sampling constructors of DCRTPoly (uniform / Gaussian / ternary) run as device kernels on a counter-based
+// generator (csrc/sampler_kernels.h): the distributions are the reference's, the words are not its Blake2 stream's.  Off by default: with
+// the reference's PRNG seeded the default backend and this one then produce the same keys and ciphertexts, word for word.
+bool DeviceSamplerEnabled();
+// the process's sampler seed (drawn once from the reference's PRNG, so a seeded PRNG gives reproducible device streams) and a fresh stream id
+void DeviceSamplerStream(uint64_t* seed, uint32_t* streamId);
 const Api& api();
 // throws (OPENFHE_THROW) with the library's message when a call failed
 void Check(fhe_status s, const char* what);

@@ -1827,3 +1827,113 @@ void orc_fast_expand_crt_basis_p_over_q(const uint64_t* x, uint32_t nQ, uint32_t
     orc_switch_crt_basis(partPl, nPl, N, pl, PlHatInvModp, PlHatInvModpPrecon, PlHatModq_qp, alphaPlModq, nQl, ql, muQl128,
                          pInv, out);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * f3: sampled towers (csrc/sampler_kernels.h) — PARITY UNPINNED against the reference's WORDS by construction.
+ * The reference draws uniform residues (math/discreteuniformgenerator.h:55-77), Peikert-inversion Gaussian integers
+ * (math/discretegaussiangenerator-impl.h:75-115) and ternary values from ONE sequential Blake2 stream per thread; a device sampler
+ * needs a counter-based generator, so for a given seed the words are not the reference's ("gives up bit-parity with
+ * Blake2; keep optional").  What IS restated from the reference, line for line: the table of Initialize() (:75-89), the inversion rule of
+ * GenerateInt() (:101-107: seed = U - 0.5, tmp = |seed| - a/2, 0 if tmp <= 0, else 1 + lower_bound index, sign of seed), the range
+ * [0, modulus) of the uniform generator and the storage of a negative integer k as q - |k| (dcrtpoly-impl.h:126-150).  The generator
+ * is Philox4x32-10 (Salmon et al., SC'11) — pinned by the Random123 known-answer vectors in tests/test_sampler.py — with
+ * key = seed, counter = (element.lo, element.hi, draw, stream).
+ * ---------------------------------------------------------------------------------------- */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+        k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+    }
+    out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
+}
+static void orc_philox_draw(uint64_t e, uint32_t d, uint32_t stream, uint64_t seed, uint32_t r[4]) {
+    const uint32_t ctr[4] = {(uint32_t)e, (uint32_t)(e >> 32), d, stream}, key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    orc_philox4x32_10(ctr, key, r);
+}
+/* out[batch][nLimbs][N]: every word uniform in [0, q[l]) */
+void orc_sample_uniform(uint64_t* out, const uint64_t* q, uint32_t nLimbs, uint32_t batch, size_t N, uint64_t seed, uint32_t stream) {
+    for (uint64_t e = 0; e < (uint64_t)batch * nLimbs * N; ++e) {
+        const uint64_t ql = q[(e / N) % nLimbs];
+        const unsigned bits = 64u - (unsigned)__builtin_clzll(ql);
+        const uint64_t mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
+        for (uint32_t d = 0;; ++d) {
+            uint32_t r[4];
+            orc_philox_draw(e, d, stream, seed, r);
+            const uint64_t x0 = (((uint64_t)r[1] << 32) | r[0]) & mask, x1 = (((uint64_t)r[3] << 32) | r[2]) & mask;
+            if (x0 < ql) { out[e] = x0; break; }
+            if (x1 < ql) { out[e] = x1; break; }
+        }
+    }
+}
+/* the table of DiscreteGaussianGeneratorImpl::Initialize (discretegaussiangenerator-impl.h:75-89); returns its length (<= cap), *a */
+uint32_t orc_dgg_table(double sigma, double* vals, uint32_t cap, double* a) {
+    const double M = 12.00610553538285;
+    const int64_t fin = (int64_t)ceil(sigma * M);
+    if (fin > (int64_t)cap)
+        return 0;
+    const double variance = 2 * sigma * sigma;
+    double cusum = 0.0;
+    for (int64_t x = 1; x <= fin; ++x)
+        vals[x - 1] = (cusum += exp(-((double)(x * x) / variance)));
+    *a = 1.0 / (2 * cusum + 1.0);
+    for (int64_t x = 0; x < fin; ++x)
+        vals[x] *= *a;
+    return (uint32_t)fin;
+}
+static void orc_store_signed(uint64_t* out, const uint64_t* q, uint32_t nLimbs, size_t N, uint32_t tb, size_t j, int64_t k) {
+    for (uint32_t l = 0; l < nLimbs; ++l)
+        out[((size_t)tb * nLimbs + l) * N + j] = k < 0 ? q[l] - (uint64_t)(-k) : (uint64_t)k;
+}
+/* GenerateInt (:101-107) per coefficient, the integer stored modulo every limb; ints (may be NULL) receives the signed integers */
+void orc_sample_gaussian(uint64_t* out, int64_t* ints, const uint64_t* q, uint32_t nLimbs, uint32_t batch, size_t N, double sigma,
+                         uint64_t seed, uint32_t stream) {
+    double vals[4096], a = 0.0;
+    const uint32_t n = orc_dgg_table(sigma, vals, 4096, &a);
+    for (uint64_t e = 0; e < (uint64_t)batch * N; ++e) {
+        uint32_t r[4];
+        orc_philox_draw(e, 0, stream, seed, r);
+        const uint64_t m = ((((uint64_t)r[1] << 32) | r[0]) >> 11);
+        const double s   = (double)m * (1.0 / 9007199254740992.0) - 0.5;
+        const double tmp = fabs(s) - a / 2;
+        int64_t k = 0;
+        if (tmp > 0.0) {
+            uint32_t lo = 0, hi = n; /* std::lower_bound */
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (vals[mid] < tmp)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            if (lo >= n)
+                lo = n - 1;
+            k = s > 0.0 ? (int64_t)lo + 1 : -((int64_t)lo + 1);
+        }
+        if (ints)
+            ints[e] = k;
+        orc_store_signed(out, q, nLimbs, N, (uint32_t)(e / N), (size_t)(e % N), k);
+    }
+}
+/* uniform in {-1, 0, 1} (TernaryUniformGeneratorImpl::GenerateVector, h = 0): two bits until they are not 3 */
+void orc_sample_ternary(uint64_t* out, int64_t* ints, const uint64_t* q, uint32_t nLimbs, uint32_t batch, size_t N, uint64_t seed,
+                        uint32_t stream) {
+    for (uint64_t e = 0; e < (uint64_t)batch * N; ++e) {
+        int64_t k = 2;
+        for (uint32_t d = 0; k == 2; ++d) {
+            uint32_t r[4];
+            orc_philox_draw(e, d, stream, seed, r);
+            for (int w = 0; w < 4 && k == 2; ++w)
+                for (int i = 0; i < 16 && k == 2; ++i) {
+                    const uint32_t t = (r[w] >> (2 * i)) & 3u;
+                    if (t != 3u)
+                        k = (int64_t)t - 1;
+                }
+        }
+        if (ints)
+            ints[e] = k;
+        orc_store_signed(out, q, nLimbs, N, (uint32_t)(e / N), (size_t)(e % N), k);
+    }
+}

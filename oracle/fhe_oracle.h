@@ -232,6 +232,17 @@ void orc_behz_fast_base_conv_sk(const orc_behz*, const uint64_t* x /*[numQ+numBs
 void orc_bfv_eval_mult_behz(const orc_behz*, const orc_ctx* ctxAll, const uint64_t* a0, const uint64_t* a1,
                             const uint64_t* b0, const uint64_t* b1, uint64_t* d0, uint64_t* d1, uint64_t* d2);
 
+/* ---- f3: sampled towers (csrc/sampler_kernels.h) on Philox4x32-10: the reference's distributions and inversion table, NOT its Blake2
+ * words (parity unpinned against the reference's stream by construction; pinned: Philox against the Random123 vectors, the table against
+ * discretegaussiangenerator-impl.h:75-89) ---- */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void orc_sample_uniform(uint64_t* out, const uint64_t* q, uint32_t nLimbs, uint32_t batch, size_t N, uint64_t seed, uint32_t stream);
+uint32_t orc_dgg_table(double sigma, double* vals, uint32_t cap, double* a);
+void orc_sample_gaussian(uint64_t* out, int64_t* ints, const uint64_t* q, uint32_t nLimbs, uint32_t batch, size_t N, double sigma,
+                         uint64_t seed, uint32_t stream);
+void orc_sample_ternary(uint64_t* out, int64_t* ints, const uint64_t* q, uint32_t nLimbs, uint32_t batch, size_t N, uint64_t seed,
+                        uint32_t stream);
+
 #ifdef __cplusplus
 }
 #endif

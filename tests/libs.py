@@ -72,6 +72,11 @@ def load_oracle():
     S("orc_ntt_inv_tower", None, [vp, P64, vp, u32, u32, C.c_int])
     for n in ("orc_vec_add", "orc_vec_sub", "orc_vec_mul"):
         S(n, None, [P64, P64, P64, C.c_size_t, u64])
+    S("orc_philox4x32_10", None, [P32, P32, P32])
+    S("orc_sample_uniform", None, [P64, P64, u32, u32, C.c_size_t, u64, u32])
+    S("orc_dgg_table", u32, [C.c_double, C.POINTER(C.c_double), u32, C.POINTER(C.c_double)])
+    S("orc_sample_gaussian", None, [P64, C.POINTER(C.c_int64), P64, u32, u32, C.c_size_t, C.c_double, u64, u32])
+    S("orc_sample_ternary", None, [P64, C.POINTER(C.c_int64), P64, u32, u32, C.c_size_t, u64, u32])
     S("orc_vec_mul_const", None, [P64, P64, u64, C.c_size_t, u64])
     S("orc_vec_mult_acc", None, [P64, P64, u64, C.c_size_t, u64])
     S("orc_vec_inner_product", None, [P64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), u32, C.c_size_t, u64])

@@ -167,6 +167,46 @@ def test_shim_leveled_ckks_matches_default_backend_on_emulator(tmp_path):
     check(tmp_path, "leveled", 11, EMU, LEVELED, must_run=CKKS_MEMBERS, setup=CKKS_SETUP)
 
 
+def device_sampler_check(tmp_path, mode, logN, device_lib, expect):
+    """FHE_HAL_DEVICE_SAMPLER=1: key generation and encryption draw their uniform / Gaussian / ternary towers with device
+    kernels on a counter-based generator.  The WORDS are then not the reference PRNG's (the ciphertext bytes differ from the default
+    backend's, checked), the computation is the reference's: every decrypted value is the expected one, the sampler ran on the device
+    inside key generation, and nothing fell back to the host mirror."""
+    ensure_built()
+    so, sh, sd = str(tmp_path / "stock.bin"), str(tmp_path / "hip.bin"), str(tmp_path / "hipdev.bin")
+    run(PROGS[0], so, mode, logN)
+    env_before = os.environ.get("FHE_HAL_DEVICE_SAMPLER")
+    os.environ["FHE_HAL_DEVICE_SAMPLER"] = "1"
+    try:
+        out = run(PROGS[1], sd, mode, logN, device_lib)
+        out2 = run(PROGS[1], sh, mode, logN, device_lib)
+    finally:
+        if env_before is None:
+            del os.environ["FHE_HAL_DEVICE_SAMPLER"]
+        else:
+            os.environ["FHE_HAL_DEVICE_SAMPLER"] = env_before
+    a, b, c = open(so, "rb").read(), open(sd, "rb").read(), open(sh, "rb").read()
+    assert len(b) == len(a) and b != a, "device-sampled keys must not reproduce the reference PRNG's words"
+    assert b == c, "the device sampler is deterministic under a seeded reference PRNG (its seed is drawn from it)"
+    for name, want in expect.items():
+        got = values(out, name)
+        assert len(got) == len(want) and all(abs(g - w) < 1e-3 for g, w in zip(got, want)), (name, got, want)
+    st = setup_stats(out)
+    assert st.get("DeviceSampler", (0, 0, 0))[0] >= 6, f"set-up: the device sampler ran {st.get('DeviceSampler')} times"
+    assert st.get("DeviceSampler", (0, 0, 0))[1] == 0
+    assert_ran_on_device(out, CKKS_MEMBERS)
+
+
+def test_shim_device_sampler_on_emulator(tmp_path):
+    device_sampler_check(tmp_path, "leveled", 11, EMU, LEVELED)
+
+
+@pytest.mark.gpu
+def test_shim_device_sampler_on_gpu(tmp_path):
+    device_sampler_check(tmp_path, "leveled", 14, HIP, LEVELED)
+    device_sampler_check(tmp_path, "bootstrap", 12, HIP, BOOT)
+
+
 @pytest.mark.parametrize("technique", ["FIXEDAUTO", "FLEXIBLEAUTOEXT"])
 def test_shim_automatic_scaling_techniques_on_emulator(tmp_path, technique):
     """the same circuit with rescaling / level adjustment done inside EvalMult / EvalAdd (FLEXIBLEAUTOEXT is the library default)"""
