@@ -800,6 +800,19 @@ def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev,
     nstock = min(3 if world == 1 else 1, per_gpu)
     ct0 = os.path.join(tmp, "hip_ct0.bin")
     h.dump(ct0, 0, nstock)
+    # EVERY output of the rank's narrow pass as one digest: compared below with the committed digest of the stock backend's bootstraps of
+    # the same 64 ciphertexts (tools/stock_boot_digest.py 64:64: 25 minutes of host time, done once; round 5 compared 3 of 64 with stock)
+    all_digest = None
+    if world == 1:
+        import hashlib
+        call = os.path.join(tmp, "hip_all.bin")
+        h.dump(call, 0, per_gpu)
+        hh = hashlib.sha256()
+        with open(call, "rb") as f:
+            for chunk in iter(lambda: f.read(1 << 24), b""):
+                hh.update(chunk)
+        all_digest = hh.hexdigest()
+        os.remove(call)
     # latency of one bootstrap: ciphertexts of the slice on one thread, one stream (at most 8 of them: the figure is per bootstrap)
     c0 = h.counters()
     single = h.single_thread_latency() / max(1, r["ciphertexts"])
@@ -974,6 +987,19 @@ def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev,
                              if same else f"MISMATCH vs the stock backend (ciphertexts 0..{nstock - 1})")
         else:
             res["parity"] = "byte comparison failed to run: " + (p.stdout + p.stderr)[-300:]
+    akey = f"logN{logN}_slots{slots}_total{total}_team{key_threads}_first{per_gpu}"
+    if all_digest is not None and akey in digests:
+        ok = digests[akey].get("sha256") == all_digest
+        res["all_outputs_vs_stock"] = (f"ALL {per_gpu} outputs of the narrow pass identical to the stock backend's bootstraps of the same ciphertexts: sha256 of the "
+                                       f"byte dump of all of them = the committed digest (tests/golden/stock_bootstrap_digests.json[{akey}], "
+                                       f"{digests[akey].get('made_by', '')})" if ok else
+                                       f"MISMATCH: sha256 of all {per_gpu} outputs ({all_digest[:16]}…) differs from the committed stock digest [{akey}]")
+        if not ok:
+            res["parity"] = res["all_outputs_vs_stock"] + "; " + res.get("parity", "")
+        elif isinstance(res.get("parity"), str) and not res["parity"].startswith("MISMATCH"):
+            res["parity"] = res["all_outputs_vs_stock"] + "; " + res["parity"]
+    elif all_digest is not None:
+        res["all_outputs_vs_stock"] = f"no committed stock digest for {akey} (sha256 of this run's {per_gpu} outputs: {all_digest})"
     import shutil
     shutil.rmtree(tmp, ignore_errors=True)
     return res

@@ -12,6 +12,7 @@
 #ifndef FHE_NTT_STATIC_H
 #define FHE_NTT_STATIC_H
 #include "ntt_kernels.h"
+#include "ntt_inv_plan16.h"
 
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(FHE_NO_BFLY_ASM)
 #include "ntt_bfly_pinned.h"
@@ -131,34 +132,49 @@ FHE_HD constexpr uint32_t lds_pad(uint32_t I) {
     return I + (I >> 4);
 }
 
-// Inverse stages are LAZY in the sum output (a' = u + v is not reduced): the bound of a residue doubles along its chain
-// of sum outputs and returns to 2q with every product output, the constant K of u - v + K is the pair's bound, a
-// pair that reached 16q is brought back to 8q first, and the step ends with the few conditional subtractions that bring
-// every residue below 2q again (16 instead of 32 subtractions per 4-stage step; tools/gen_ntt_asm.py, inv_lazy_plan).
-// `bnd` carries the bounds (units of q) through the stages of a step in the C++ build; the generated gfx950 code has
-// them folded into its constants.
-FHE_HD void inv_lazy_stage_cpp(int B, uint64_t (&r)[16], const TwPair (&w)[8], const BflyConst c, uint32_t (&bnd)[16]) {
-    const uint64_t nq = ((uint64_t)c.nqh << 32) | c.nql, q = c.q;
+// Inverse stages are LAZY in the sum output (a' = u + v is not reduced): bounds add along a residue's chain of sum outputs and return to
+// 3q with every product output, the constant K of u - v + K q is the bound of v, a pair whose bounds would pass 16q is reduced first by
+// the cheapest means, and the step ends with the reductions that bring every residue below 3q again (tools/gen_ntt_asm.py inv_plan).
+// The C++ build (lane emulator, FHE_NO_BFLY_ASM) FOLLOWS THE GENERATED PLAN (ntt_inv_plan16.h: the same tables the gfx950 blocks were
+// emitted from) op by op and checks every bound it promises, value by value — a wrong plan fails the CPU suite (round 6; until then this
+// path was a round-3 restatement with its own bound rule and exact quotients).
+FHE_HD void apply_plan_op(uint64_t (&r)[16], const plan16::RedOp op, const BflyConst c, uint32_t (&bnd)[16]) {
+    if (op.kind == 1) {
+        FHE_BOUND_CHECK(bnd[op.k] <= 2u * op.m, "inverse plan: a conditional subtraction of less than half the bound");
+        r[op.k]   = csub2(r[op.k], (uint64_t)op.m * c.q);
+        bnd[op.k] = op.m;
+    }
+    else if (op.kind == 2) {
+        r[op.k] = red_estimate(r[op.k], c);
+        FHE_BOUND_CHECK(r[op.k] < c.twoq, "inverse plan: a quotient-estimate reduction that left 2q or more");
+        bnd[op.k] = 2;
+    }
+}
+FHE_HD void inv_lazy_stage_cpp(int B, int BLO, uint64_t (&r)[16], const TwPair (&w)[8], const BflyConst c, uint32_t (&bnd)[16]) {
+    const uint64_t nq = ((uint64_t)c.nqh << 32) | c.nql;
+    for (int i = 0; i < 16; ++i)
+        apply_plan_op(r, plan16::kPre[BLO][B][i], c, bnd);
+    int j = 0;
     for (int g = 0; g < (8 >> B); ++g)
-        for (int lo = 0; lo < (1 << B); ++lo) {
+        for (int lo = 0; lo < (1 << B); ++lo, ++j) {
             const int k0 = (g << (B + 1)) | lo, k1 = k0 | (1 << B);
-            if (bnd[k0] >= 16u) {
-                r[k0] = csub2(r[k0], q << 3), r[k1] = csub2(r[k1], q << 3);
-                bnd[k0] = bnd[k1] = 8;
-            }
+            const uint32_t K = plan16::kK[BLO][B][j];
+            FHE_BOUND_CHECK(bnd[k1] <= K && bnd[k0] + K <= 16u, "inverse plan: a butterfly outside its planned bounds");
+            FHE_BOUND_CHECK((unsigned __int128)r[k0] < (unsigned __int128)bnd[k0] * c.q && (unsigned __int128)r[k1] < (unsigned __int128)bnd[k1] * c.q,
+                            "inverse plan: a residue above its planned bound");
             const uint64_t u = r[k0], v = r[k1];
-            r[k0]   = u + v;
-            r[k1]   = shoup_acc(0, u - v + (uint64_t)bnd[k0] * q, w[g], nq);
-            bnd[k0] = 2 * bnd[k0], bnd[k1] = 2;
+            r[k0] = u + v;
+            r[k1] = shoup_trunc(u - v + (uint64_t)K * c.q, w[g], nq);
+            FHE_BOUND_CHECK(r[k1] < c.threeq, "inverse plan: a truncated Shoup product of 3q or more");
+            bnd[k0] += bnd[k1];
+            bnd[k1] = 3;
         }
 }
-FHE_HD void inv_lazy_end_cpp(uint64_t (&r)[16], const BflyConst c, uint32_t (&bnd)[16]) {
-    const uint64_t q = c.q;
+FHE_HD void inv_lazy_end_cpp(int BLO, int BHI, uint64_t (&r)[16], const BflyConst c, uint32_t (&bnd)[16]) {
+    for (int i = 0; i < 16; ++i)
+        apply_plan_op(r, plan16::kEnd[BLO][BHI][i], c, bnd);
     for (int k = 0; k < 16; ++k)
-        while (bnd[k] > 2u) {
-            bnd[k] >>= 1;
-            r[k] = csub2(r[k], (uint64_t)bnd[k] * q);
-        }
+        FHE_BOUND_CHECK(bnd[k] == plan16::kOut[BLO][BHI][k] && bnd[k] <= 3u, "inverse plan: a step that does not end below 3q");
 }
 
 template <bool INV, bool UNI, int B, int BLO>
@@ -194,7 +210,7 @@ FHE_HD void run_stage(uint64_t (&r)[16], const TwPair (&w)[8], const BflyConst c
 #else
     (void)z;
     if (INV) {
-        inv_lazy_stage_cpp(B, r, w, c, bnd);
+        inv_lazy_stage_cpp(B, BLO, r, w, c, bnd);
         return;
     }
     // fwd_stream: a' = a + T, b' = a - T + 3q with T = shoup_trunc(b, w) in [0, 3q); `bnd` = the bound (units of q) the schedule
@@ -223,7 +239,7 @@ FHE_HD void run_inv_lazy_end(uint64_t (&r)[16], const BflyConst c, uint32_t (&bn
     FHE_INVE(2, 3) FHE_INVE(3, 3)
 #undef FHE_INVE
 #else
-    inv_lazy_end_cpp(r, c, bnd);
+    inv_lazy_end_cpp(BLO, BHI, r, c, bnd);
 #endif
 }
 
@@ -255,15 +271,20 @@ FHE_HD void run_last_inv_stage(uint64_t (&r)[16], const TwPair nInv, const TwPai
     mul2_s_7(r, nInv, w1n, c, z);
 #else
     (void)z;
+    // the generated plan of the step's last stage (register bit 3): its reductions, then  (u + v) * N^-1  and  (u - v + K q) * (w1 N^-1)
+    // with EXACT quotients (results below 2q), as mul2_s_* compute them
     const uint64_t nq = ((uint64_t)c.nqh << 32) | c.nql;
+    for (int i = 0; i < 16; ++i)
+        apply_plan_op(r, plan16::kPre[BLO][3][i], c, bnd);
     for (int lo = 0; lo < 8; ++lo) {
-        if (bnd[lo] >= 16u) {
-            r[lo] = csub2(r[lo], q << 3), r[lo | 8] = csub2(r[lo | 8], q << 3);
-            bnd[lo] = bnd[lo | 8] = 8;
-        }
+        const uint32_t K = plan16::kK[BLO][3][lo];
+        FHE_BOUND_CHECK(bnd[lo | 8] <= K && bnd[lo] + K <= 16u, "inverse plan: the last stage outside its planned bounds");
+        FHE_BOUND_CHECK((unsigned __int128)r[lo] < (unsigned __int128)bnd[lo] * q && (unsigned __int128)r[lo | 8] < (unsigned __int128)bnd[lo | 8] * q,
+                        "inverse plan: a residue above its planned bound before the last stage");
         const uint64_t u = r[lo], v = r[lo | 8];
         r[lo]     = shoup_acc(0, u + v, nInv, nq);
-        r[lo | 8] = shoup_acc(0, u - v + (uint64_t)bnd[lo] * q, w1n, nq);
+        r[lo | 8] = shoup_acc(0, u - v + (uint64_t)K * q, w1n, nq);
+        FHE_BOUND_CHECK(r[lo] < c.twoq && r[lo | 8] < c.twoq, "inverse plan: an exact Shoup product of 2q or more");
         bnd[lo] = bnd[lo | 8] = 2;
     }
 #endif
@@ -460,7 +481,7 @@ FHE_HD void run_step(uint64_t (&r)[16], const TwSrc ts, uint32_t j0, uint32_t lo
     // promises for the `a` inputs of its first stage (inBound: 2 behind a sweep, else SPlan::boundBefore)
     uint32_t bnd[16];
     for (int k = 0; k < 16; ++k)
-        bnd[k] = INV ? 2u : inBound;
+        bnd[k] = INV ? 3u : inBound;
     constexpr int B0 = INV ? 0 : 3, B1 = INV ? 1 : 2, B2 = INV ? 2 : 1, B3 = INV ? 3 : 0;
     load_stage_tw<LA, INV, T, I, B0, ENDS>(w0, ts, j0, logN);
     load_stage_tw<LA, INV, T, I, B1, ENDS>(w1, ts, j0, logN);

@@ -333,7 +333,7 @@ double fbb_bootstrap_wide_mt(void* h, uint32_t group, int reps, int threads) {
                             OPENFHE_THROW("fbb_bootstrap_wide: the ciphertexts of a group must have equal metadata");
                         towers.push_back(&ci->GetElements()[e]);
                     }
-                    elements.push_back(DCRTPoly::PackWide(towers));
+                    elements.push_back(DCRTPoly::PackWide(towers, /*adopt: this driver owns the group's ciphertexts*/ true));
                 }
                 wide->SetElements(std::move(elements));
                 Ciphertext<DCRTPoly> res;

@@ -538,6 +538,8 @@ void Op::HostSync() {
 }
 
 DevBuf::~DevBuf() {
+    if (parent)
+        parent->views.fetch_sub(1, std::memory_order_relaxed);
     if (!p || parent || external || g_exiting.load())
         return;
     Runtime& r      = rt();
@@ -772,6 +774,7 @@ Buf View(const Buf& parent, size_t offsetWords, size_t words) {
     b->p      = parent->p + offsetWords;
     b->words  = words;
     b->parent = parent;
+    parent->views.fetch_add(1, std::memory_order_relaxed);
     return b;
 }
 

@@ -402,7 +402,7 @@ public:
             const hiprt::Buf src = m_d;
             std::vector<uint64_t> memoKey;
             hiprt::Resolved r;
-            if (src && m_k == 1 && !m_hostValid && src.use_count() > 2 && !src->parent && OnDevice(&r)) {
+            if (src && m_k == 1 && !m_hostValid && !src->parent && src->Owners(src, 2) >= 1 && OnDevice(&r)) {
                 memoKey.reserve(2 + 2 * (size_t)NumLimbs());
                 memoKey.push_back(2), memoKey.push_back(NumLimbs());
                 memoKey.insert(memoKey.end(), r.idx[0].begin(), r.idx[0].end());
@@ -1145,9 +1145,10 @@ public:
         }
         // clones of towers rescaled before: both results remembered -> taken; one of them -> element by element (the member looks it up)
         const hiprt::Buf s0 = a0.m_d, s1 = a1.m_d;
-        const bool remember = s0.use_count() > 2 && s1.use_count() > 2 && !s0->parent && !s1->parent;
+        const bool c0 = s0->Owners(s0, 2) >= 1, c1 = s1->Owners(s1, 2) >= 1;  // another tower holds these words (windows do not count)
+        const bool remember = c0 && c1 && !s0->parent && !s1->parent;
         std::vector<uint64_t> memoKey;
-        if (s0.use_count() > 2 || s1.use_count() > 2) {
+        if (c0 || c1) {
             if (!remember)
                 return false;
             memoKey = RescaleMemoKey(r, L, a, b);
@@ -2203,7 +2204,9 @@ private:
         // every power in every sum): the same words through the same member with the same tables
         const hiprt::Buf src = m_d;
         std::vector<uint64_t> memoKey;
-        if (src.use_count() > 2 && !src->parent) {  // (src and m_d are two of the references)
+        // (a clone = another TOWER holding these words: references held by windows of a packed wide buffer do not count — round 5 counted
+        // them, so every wide buffer looked cloned, its results were remembered and a benchmark's next pass found them: round-5 advisor)
+        if (!src->parent && src->Owners(src, /*src and m_d*/ 2) >= 1) {
             memoKey = RescaleMemoKey(r, L, a, b);
             if (auto hit = hiprt::MemoFind(src, memoKey)) {
                 m_d = std::move(hit);
@@ -2313,10 +2316,12 @@ public:
     // SharedWords); PackWide of K towers that are consecutive windows of one buffer is that buffer again (no copy), and when it has to
     // copy it leaves the K source towers behind as windows of the packed buffer, so that packing the same operands again — the next
     // operation of a pipeline, the next pass of a benchmark — costs nothing.  Values never change: only which allocation holds them.
-    // (Re-pointing a source happens under that tower's lock, but — like Upload() or any first device use of a tower — it must not run
-    // while ANOTHER host thread is inside an operation on the same tower: the groups of a lockstep evaluation pack disjoint ciphertexts;
-    // shared read-only operands such as keys and plaintexts are never packed.  FHE_HAL_WIDE_VIEWS=0 restores the copying forms.)
-    static DCRTPolyType PackWide(const std::vector<const DCRTPolyType*>& towers) {
+    // Re-pointing the sources is OPT-IN (`adopt`, round-6 fix of a round-5 advisor finding): PackWide takes its sources as const, and a
+    // reader of a shared const ciphertext on another host thread (OpenFHE treats const reads as thread-safe) must never see its buffer
+    // swapped and the old one recycled under it.  Only a caller that OWNS the sources for the duration of the call — the lockstep drivers,
+    // which pack disjoint groups of their own ciphertexts — passes adopt = true; and even then a source whose buffer is shared with a copy
+    // (use_count > 1) is left alone.  FHE_HAL_WIDE_VIEWS=0 restores the copying forms everywhere.
+    static DCRTPolyType PackWide(const std::vector<const DCRTPolyType*>& towers, bool adopt = false) {
         hiprt::MemberScope scope("PackWide");
         if (towers.empty())
             OPENFHE_THROW("PackWide: no towers");
@@ -2354,10 +2359,10 @@ public:
         uint64_t* dst = op.W(d);
         for (uint32_t i = 0; i < k; ++i)
             hiprt::D2D(op, dst + (size_t)i * w, op.R(towers[i]->m_d), w * 8, "towers packed into a wide one");
-        if (views)
+        if (views && adopt)
             for (uint32_t i = 0; i < k; ++i) {  // the sources become windows of the packed buffer (same words)
                 std::lock_guard<std::mutex> lk(towers[i]->m_lock.m);
-                if (towers[i]->m_d && !towers[i]->m_lazy)
+                if (towers[i]->m_d && !towers[i]->m_lazy && towers[i]->m_d.use_count() == 1)
                     towers[i]->m_d = hiprt::View(d, (size_t)i * w, w);
             }
         hiprt::CountDevice();

@@ -8,6 +8,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -131,6 +132,11 @@ struct DevBuf {
     std::mutex mu;
     Use writer{0, 0};
     std::vector<Use> readers;
+    // windows (View) of this buffer alive right now: each holds a reference through its `parent`, so use_count() alone does not tell how
+    // many TOWERS own these words (a packed wide buffer with K windows is not a clone of anything: round-5 advisor)
+    std::atomic<uint32_t> views{0};
+    // towers (and locals) holding this buffer itself, given the caller's own extra references
+    long Owners(const std::shared_ptr<DevBuf>& self, long callersRefs) const { return self.use_count() - (long)views.load() - callersRefs; }
     // Results of pure members applied to these words (same member, same tables, same words -> same words), kept while several towers
     // share the buffer (clones): pke's weighted sums rescale a fresh clone of the same power T_i in every sum they form
     // (ckksrns-advancedshe.cpp:143-193).  Dropped when the buffer is written (Op::W).

@@ -524,7 +524,7 @@ int main(int argc, char** argv) {
                             std::vector<const DCRTPoly*> towers;
                             for (int i = 0; i < k; ++i)
                                 towers.push_back(&v[first + i]->GetElements()[e]);
-                            el.push_back(DCRTPoly::PackWide(towers));
+                            el.push_back(DCRTPoly::PackWide(towers, /*adopt: this driver owns the group's ciphertexts*/ true));
                         }
                         w->SetElements(std::move(el));
                         return w;
@@ -597,7 +597,7 @@ int main(int argc, char** argv) {
                         std::vector<const DCRTPoly*> towers;
                         for (int i = 0; i < k; ++i)
                             towers.push_back(&v[first + i]->GetElements()[e]);
-                        el.push_back(DCRTPoly::PackWide(towers));
+                        el.push_back(DCRTPoly::PackWide(towers, /*adopt: this driver owns the group's ciphertexts*/ true));
                     }
                     w->SetElements(std::move(el));
                     return w;

@@ -833,6 +833,23 @@ def test_conversion_kernel_variants_on_emulator(backend, variant):
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+@pytest.mark.gpu
+def test_conversion_kernel_variants_on_gpu():
+    """the same forced variant (carry-counted 64-bit columns, FHE_CONV_SUM8=1: 16- and 32-source-limb instances, the 1-row kernel) on
+    the MI355X: until round 6 the GPU ran these instances only where a shape happened to select them"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FHE_CONV_SUM8="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_parity.py"), "-q", "-x", "-m", "gpu",
+                          "-k", "hip and (test_approx_and_exact_switch_crt_basis or test_approx_mod_up or (test_hybrid_keyswitch_and_eval_mult and 12-6))"],
+                         env=env, capture_output=True, text=True, timeout=1200, cwd=root)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_parity_bfv.py"), "-q", "-x", "-m", "gpu",
+                          "-k", "hip and (behz or eval_mult)"], env=env, capture_output=True, text=True, timeout=1200, cwd=root)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_whole_tower_checksums(backend, oracle):
     """fhe_checksum: {sum, position-weighted sum} mod 2^64 of every limb-row of a resident batch in one read (the all-towers parity check of bench.py
     and of the full-shape tests)"""

@@ -771,6 +771,56 @@ def count(stream_or_block):
     return sum(1 for c in stream_or_block if not c["t"].startswith("s_nop"))
 
 
+OUT_PLAN = os.path.join(ROOT, "openfhe-development_amd", "csrc", "ntt_inv_plan16.h")
+
+
+def plan_header():
+    """the lazy-inverse plan of the 16-residue kernels as constexpr tables for EVERY build: the lane emulator's C++ butterflies follow it
+    op by op and check its bounds value by value (round 6; until then the emulator ran a round-3 restatement of the inverse stages and a
+    wrong bound in inv_plan was visible only on the GPU)"""
+    def ops(lst, n):
+        rows = [f"{{{1 if o[0] == 'c' else 2}, {o[1]}, {o[2] if o[0] == 'c' else 2}}}" for o in lst]
+        assert len(rows) <= n, (len(rows), n)
+        return "{" + ", ".join(rows + ["{0, 0, 0}"] * (n - len(rows))) + "}"
+    pre_t, k_t, end_t, out_t, outl_t = [], [], [], [], []
+    for bLo in range(4):
+        pre_r, k_r, end_r, out_r, outl_r = [], [], [], [], []
+        for b in range(4):
+            if b >= bLo:
+                pre, K, _, _ = inv_plan(bLo, b)
+                pre_r.append(ops(pre[b], 16))
+                k_r.append("{" + ", ".join(str(x) for x in K[b]) + "}")
+                _, _, end, final = inv_plan(bLo, b)
+                _, _, _, lazyf = inv_plan(bLo, b, lazy_out=True)
+                end_r.append(ops(end, 16))
+                out_r.append("{" + ", ".join(str(x) for x in final) + "}")
+                outl_r.append("{" + ", ".join(str(x) for x in lazyf) + "}")
+            else:
+                pre_r.append(ops([], 16)), k_r.append("{0, 0, 0, 0, 0, 0, 0, 0}"), end_r.append(ops([], 16))
+                out_r.append("{" + ", ".join(["0"] * 16) + "}"), outl_r.append("{" + ", ".join(["0"] * 16) + "}")
+        pre_t.append("{" + ", ".join(pre_r) + "}"), k_t.append("{" + ", ".join(k_r) + "}"), end_t.append("{" + ", ".join(end_r) + "}")
+        out_t.append("{" + ", ".join(out_r) + "}"), outl_t.append("{" + ", ".join(outl_r) + "}")
+    return ("""// GENERATED by tools/gen_ntt_asm.py — do not edit; edit the generator and re-run it.
+// The lazy-inverse plan (inv_plan) of the 16-residues-per-lane kernels of ntt_static.h, as tables for every build.  [bLo][b]: the step's first
+// stage is register bit bLo, the entry belongs to stage b (pre, K) or to a step that ends with stage b (end, out).
+#ifndef FHE_NTT_INV_PLAN16_H
+#define FHE_NTT_INV_PLAN16_H
+namespace fhe {
+namespace plan16 {
+struct RedOp {
+    unsigned char kind, k, m;  // kind 0: none, 1: x = x < m q ? x : x - m q, 2: quotient estimate (x below 2q afterwards); k: residue
+};
+constexpr RedOp kPre[4][4][16] = {""" + ", ".join(pre_t) + """};  // reductions before stage b
+constexpr unsigned char kK[4][4][8] = {""" + ", ".join(k_t) + """};  // K (units of q) of u - v + K, per butterfly in stage order
+constexpr RedOp kEnd[4][4][16] = {""" + ", ".join(end_t) + """};  // closing reductions of a step whose last stage is b
+constexpr unsigned char kOut[4][4][16] = {""" + ", ".join(out_t) + """};  // bounds (units of q) after them
+constexpr unsigned char kOutLazy[4][4][16] = {""" + ", ".join(outl_t) + """};  // bounds when the closing reductions are left to the next pass
+}  // namespace plan16
+}  // namespace fhe
+#endif
+""")
+
+
 def main():
     check_blocks()
     H = []
@@ -884,13 +934,15 @@ __device__ __forceinline__ uint64_t reduce192_uniform(uint64_t c0, uint64_t c1, 
 #endif
 """)
     text = "".join(H)
-    if "--check" in sys.argv:  # tests: the committed header must be what this generator (and its simulation) produces
-        if open(OUT).read() != text:
-            print("ntt_bfly_pinned.h is stale: run python tools/gen_ntt_asm.py")
+    plan = plan_header()
+    if "--check" in sys.argv:  # tests: the committed headers must be what this generator (and its simulation) produces
+        if open(OUT).read() != text or open(OUT_PLAN).read() != plan:
+            print("ntt_bfly_pinned.h / ntt_inv_plan16.h is stale: run python tools/gen_ntt_asm.py")
             return 1
-        print("ntt_bfly_pinned.h is up to date; all blocks simulated OK")
+        print("ntt_bfly_pinned.h and ntt_inv_plan16.h are up to date; all blocks simulated OK")
         return 0
     open(OUT, "w").write(text)
+    open(OUT_PLAN, "w").write(plan)
     n = count(fwd_stream(T(0), R(0), R(1), 0))
     ni = count(inv_lazy_stream(T(0), R(0), R(1), 0, "%[k3]"))
     print(f"wrote {OUT}: forward butterfly {n} VALU, lazy inverse butterfly {ni} VALU, reduction {count(red_stream(0, R(0)))} VALU; "
