@@ -920,6 +920,10 @@ def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev,
                                         "keep the evaluation's high-water mark)"}
     except Exception as e:
         res["device_memory"] = {"error": f"{type(e).__name__}: {e}"}
+    try:  # the backend's own account of its buffers: what it holds from the device, the high-water mark, how requests were served
+        res["allocator"] = h.alloc_stats()
+    except Exception as e:
+        res["allocator"] = {"error": f"{type(e).__name__}: {e}"}
     h.close()
     del keep_keys
     try:

@@ -84,6 +84,13 @@ fhe_status fhe_stream_destroy(fhe_ctx* ctx, void* stream);
 /* `stream` waits ON THE DEVICE (the host is not blocked) for everything enqueued so far on `other`: the hand-over of a tower
  * from one host thread's stream to another's (the HAL backend gives every host thread a stream of its own). */
 fhe_status fhe_stream_wait(fhe_ctx* ctx, void* stream, void* other);
+/* Completion marks: an event recorded on `stream` NOW; another stream waits for it on the device later.  Exact where fhe_stream_wait is
+ * not (that one makes the waiter follow everything the other stream has enqueued by the time of the call): the HAL backend marks every
+ * released buffer it caches, so that a host thread reusing another thread's buffer waits for that buffer's last use only. */
+fhe_status fhe_event_create(fhe_ctx* ctx, void** event);
+fhe_status fhe_event_record(fhe_ctx* ctx, void* event, void* stream);
+fhe_status fhe_stream_wait_event(fhe_ctx* ctx, void* stream, void* event);
+fhe_status fhe_event_destroy(fhe_ctx* ctx, void* event);
 fhe_status fhe_memset_zero(fhe_ctx* ctx, void* dst, size_t bytes, void* stream);
 fhe_status fhe_graph_begin(fhe_ctx* ctx, void* stream);
 fhe_status fhe_graph_end(fhe_ctx* ctx, void* stream, void** graph);

@@ -50,6 +50,9 @@ class BootBatch:
         L.fbb_check.restype, L.fbb_check.argtypes = C.c_double, [vp, u32, C.POINTER(C.c_double)]
         L.fbb_counters.argtypes = [C.POINTER(u64)]
         L.fbb_member_stats.restype, L.fbb_member_stats.argtypes = C.c_size_t, [C.c_char_p, C.c_size_t]
+        if hasattr(L, "fbb_alloc_stats"):
+            L.fbb_alloc_stats.argtypes = [C.POINTER(u64)]
+            L.fbb_reserve.restype, L.fbb_reserve.argtypes = C.c_int, [u64]
         L.fbb_save_outputs.argtypes = [vp]
         L.fbb_compare_saved.restype, L.fbb_compare_saved.argtypes = C.c_long, [vp]
         L.fbb_dump.argtypes = [vp, C.c_char_p, u32, u32]
@@ -132,6 +135,20 @@ class BootBatch:
             if len(f) >= 5:  # "<name (may hold blanks)> deviceOps hostOps hostReads operandBytes"
                 out[" ".join(f[:-4])] = int(f[-1])
         return out
+
+    def alloc_stats(self):
+        """the backend's buffer caches (fhe_hal_alloc_stats / _stats2)"""
+        if not hasattr(self.L, "fbb_alloc_stats"):
+            return None
+        c = (u64 * 9)()
+        self.L.fbb_alloc_stats(c)
+        names = ("cached_bytes", "served_from_another_threads_cache", "requests_that_reached_the_device", "cache_releases", "device_free_bytes",
+                 "device_total_bytes", "held_from_the_device_bytes", "held_high_water_bytes", "served_behind_the_buffers_own_mark")
+        return dict(zip(names, (int(v) for v in c)))
+
+    def reserve(self, nbytes):
+        """pre-sizes the calling thread's cache with one buffer of nbytes (fhe_hal_reserve)"""
+        return int(self.L.fbb_reserve(nbytes)) if hasattr(self.L, "fbb_reserve") else 1
 
     def member_stats(self):
         """{member: (device operations, host-mirror executions, host reads after a device->host copy, operand bytes)} so far"""

@@ -459,6 +459,32 @@ extern "C" fhe_status fhe_stream_wait(fhe_ctx* c, void* stream, void* other) {
     RT_CHECK(rt::stream_wait((rt::stream_t)stream, (rt::stream_t)other));
     return FHE_OK;
 }
+extern "C" fhe_status fhe_event_create(fhe_ctx* c, void** event) {
+    ARG_CHECK(c && event, "fhe_event_create: null argument");
+    RT_CHECK(rt::set_device(c->device));
+    rt::event_t e;
+    RT_CHECK(rt::event_create(&e));
+    *event = (void*)e;
+    return FHE_OK;
+}
+extern "C" fhe_status fhe_event_record(fhe_ctx* c, void* event, void* stream) {
+    ARG_CHECK(c && event, "fhe_event_record: null argument");
+    RT_CHECK(rt::set_device(c->device));
+    RT_CHECK(rt::event_record((rt::event_t)event, (rt::stream_t)stream));
+    return FHE_OK;
+}
+extern "C" fhe_status fhe_stream_wait_event(fhe_ctx* c, void* stream, void* event) {
+    ARG_CHECK(c && event, "fhe_stream_wait_event: null argument");
+    RT_CHECK(rt::set_device(c->device));
+    RT_CHECK(rt::stream_wait_event((rt::stream_t)stream, (rt::event_t)event));
+    return FHE_OK;
+}
+extern "C" fhe_status fhe_event_destroy(fhe_ctx* c, void* event) {
+    ARG_CHECK(c, "fhe_event_destroy: null context");
+    if (event)
+        RT_CHECK(rt::event_destroy((rt::event_t)event));
+    return FHE_OK;
+}
 extern "C" fhe_status fhe_memset_zero(fhe_ctx* c, void* dst, size_t bytes, void* stream) {
     ARG_CHECK(c && dst, "fhe_memset_zero: null argument");
     RT_CHECK(rt::set_device(c->device));

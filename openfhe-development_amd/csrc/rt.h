@@ -83,6 +83,14 @@ inline const char* stream_create(stream_t* s) {
 }
 inline const char* stream_destroy(stream_t) { return nullptr; }
 inline const char* stream_wait(stream_t, stream_t) { return nullptr; }  // (the emulator runs every launch synchronously)
+typedef void* event_t;
+inline const char* event_create(event_t* e) {
+    *e = (void*)1;
+    return nullptr;
+}
+inline const char* event_record(event_t, stream_t) { return nullptr; }
+inline const char* stream_wait_event(stream_t, event_t) { return nullptr; }
+inline const char* event_destroy(event_t) { return nullptr; }
 inline const char* dzero(void* d, size_t n, stream_t) {
     std::memset(d, 0, n);
     return nullptr;
@@ -181,6 +189,13 @@ inline const char* stream_wait(stream_t waiter, stream_t signaler) {
         return m;
     return err(hipStreamWaitEvent(waiter, e, 0));
 }
+// a completion mark: recorded on a stream NOW, waited for (on the device) by another stream later — exact, unlike stream_wait, which makes
+// the waiter follow everything the signaler has enqueued by the time of the call
+typedef hipEvent_t event_t;
+inline const char* event_create(event_t* e) { return err(hipEventCreateWithFlags(e, hipEventDisableTiming)); }
+inline const char* event_record(event_t e, stream_t s) { return err(hipEventRecord(e, s)); }
+inline const char* stream_wait_event(stream_t s, event_t e) { return err(hipStreamWaitEvent(s, e, 0)); }
+inline const char* event_destroy(event_t e) { return err(hipEventDestroy(e)); }
 inline const char* dzero(void* d, size_t n, stream_t st) { return err(hipMemsetAsync(d, 0, n, st)); }
 inline const char* capture_begin(stream_t s) { return err(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal)); }
 inline const char* capture_end(stream_t s, graph_t* out) {

@@ -96,6 +96,10 @@ class Lib:
         S("fhe_tensor", C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, u32p, u32, u32, vp])
         S("fhe_automorph", C.c_int, [vp, vp, vp, u32, C.c_int, u32p, u32, u32, vp])
         S("fhe_switch_modulus", C.c_int, [vp, vp, u32p, u32, vp, u32, u32, u32, u32, vp])
+        S("fhe_event_create", C.c_int, [vp, C.POINTER(vp)])
+        S("fhe_event_record", C.c_int, [vp, vp, vp])
+        S("fhe_stream_wait_event", C.c_int, [vp, vp, vp])
+        S("fhe_event_destroy", C.c_int, [vp, vp])
         S("fhe_sample_uniform", C.c_int, [vp, vp, u32p, u32, u32, C.c_uint64, u32, vp])
         S("fhe_sample_gaussian", C.c_int, [vp, vp, u32p, u32, u32, C.c_double, C.c_uint64, u32, vp])
         S("fhe_sample_ternary", C.c_int, [vp, vp, u32p, u32, u32, C.c_uint64, u32, vp])

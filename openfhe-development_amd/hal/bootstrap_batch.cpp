@@ -33,6 +33,9 @@ extern "C" void fhe_hal_release_caches();
 extern "C" void fhe_hal_device_sync();
 extern "C" size_t fhe_hal_launch_stats(char* buf, size_t cap, uint64_t* total);
 extern "C" size_t fhe_hal_member_stats(char* buf, size_t cap);
+extern "C" void fhe_hal_alloc_stats(uint64_t out[6]);
+extern "C" void fhe_hal_alloc_stats2(uint64_t out[3]);
+extern "C" int fhe_hal_reserve(uint64_t bytes);
 #endif
 
 namespace {
@@ -420,6 +423,25 @@ void fbb_counters(uint64_t out[5]) {
     uint64_t st[4];
     fhe_hal_stats(st);
     out[3] = st[2], out[4] = st[3];
+#endif
+}
+// the backend's buffer caches: {cached bytes, takes from another thread's cache, requests that reached the device, cache releases, free
+// device bytes, total device bytes, bytes held from the device, high-water mark of that, takes that waited for the buffer's own mark}
+void fbb_alloc_stats(uint64_t out[9]) {
+    for (int i = 0; i < 9; ++i)
+        out[i] = 0;
+#ifdef WITH_HIP
+    fhe_hal_alloc_stats(out);
+    fhe_hal_alloc_stats2(out + 6);
+#endif
+}
+// one buffer of `bytes` into the calling thread's cache before the evaluation (fhe_hal_reserve); 0 = done
+int fbb_reserve(uint64_t bytes) {
+#ifdef WITH_HIP
+    return fhe_hal_reserve(bytes);
+#else
+    (void)bytes;
+    return 1;
 #endif
 }
 // "<member> <device ops> <host-mirror executions> <host reads> <operand bytes>" lines of the backend (empty on the stock backend)

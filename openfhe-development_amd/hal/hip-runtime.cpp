@@ -108,6 +108,9 @@ struct Runtime {
     // to go to the device first checks that a reserve stays free and otherwise takes every thread's cache back (Alloc)
     std::atomic<uint64_t> cachedBytes{0};
     std::atomic<uint64_t> stolen{0};          // allocations served from ANOTHER thread's free lists (Alloc)
+    std::atomic<uint64_t> stolenExact{0};     // ... of which the taker waited for the buffer's own completion mark (not the owner's whole queue)
+    std::atomic<uint64_t> deviceBytes{0};     // bytes obtained from the device and not given back (live towers + every cache)
+    std::atomic<uint64_t> deviceBytesHigh{0}; // ... its high-water mark
     std::atomic<uint64_t> deviceMallocs{0}, cacheReleases{0};  // requests that reached the device; times the caches went back to it
     uint64_t cacheCap = ~0ull;               // FHE_HAL_CACHE_CAP_GB: a hard cap on the cached bytes (default: none)
     uint64_t reserveBytes = 8ull << 30;       // FHE_HAL_RESERVE_GB: free device memory kept for kernel launches (scratch, kernel arguments)
@@ -163,7 +166,8 @@ Runtime* build() {
                   FHE_SYM(add_const, fhe_add_const) && FHE_SYM(sub_const, fhe_sub_const) && FHE_SYM(times_q_over_t, fhe_times_q_over_t) &&
                   FHE_SYM(mod_switch_round, fhe_mod_switch_round) && FHE_SYM(automorph, fhe_automorph) &&
                   FHE_SYM(switch_modulus, fhe_switch_modulus) && FHE_SYM(rescale_limbs, fhe_rescale_limbs) &&
-                  FHE_SYM(sample_uniform, fhe_sample_uniform) && FHE_SYM(sample_gaussian, fhe_sample_gaussian) && FHE_SYM(sample_ternary, fhe_sample_ternary) &&
+                  FHE_SYM(event_create, fhe_event_create) && FHE_SYM(event_record, fhe_event_record) && FHE_SYM(stream_wait_event, fhe_stream_wait_event) &&
+                  FHE_SYM(event_destroy, fhe_event_destroy) && FHE_SYM(sample_uniform, fhe_sample_uniform) && FHE_SYM(sample_gaussian, fhe_sample_gaussian) && FHE_SYM(sample_ternary, fhe_sample_ternary) &&
                   FHE_SYM(rescale_limbs_pair, fhe_rescale_limbs_pair) && FHE_SYM(add_pair, fhe_add_pair) && FHE_SYM(sub_pair, fhe_sub_pair) &&
                   FHE_SYM(mul_const_pair, fhe_mul_const_pair) && FHE_SYM(lincomb, fhe_lincomb) && FHE_SYM(mem_info, fhe_mem_info) &&
                   FHE_SYM(rescale_workspace_bytes, fhe_rescale_workspace_bytes) && FHE_SYM(conv_create_custom, fhe_conv_create_custom) &&
@@ -251,6 +255,22 @@ struct ThreadState {
     uint64_t outerSeq = 0;
     std::vector<uint64_t> waited;       // per stream id: everything enqueued there up to this seq precedes this thread's later work
     std::map<size_t, std::vector<uint64_t*>> freeLists;
+    // completion mark of a cached buffer (round 6): an event recorded on THIS thread's stream when the buffer joined the free lists, i.e.
+    // behind every pending use of it.  Another thread that takes the buffer (Alloc's last resort before the device) waits for that event —
+    // not for everything this stream has enqueued by then, which made two busy lockstep groups run one behind the other (round 5: 16x4
+    // groups 37-40 bootstraps/s against 51).  Guarded by the stream's flMutex, like the lists.
+    std::unordered_map<uint64_t*, void*> marks;
+    std::vector<void*> eventPool;
+    void* NewEvent() {
+        if (!eventPool.empty()) {
+            void* e = eventPool.back();
+            eventPool.pop_back();
+            return e;
+        }
+        void* e = nullptr;
+        Runtime& r = rt();
+        return r.api.event_create(r.anyCtx, &e) == FHE_OK ? e : nullptr;
+    }
     ThreadState() {
         Runtime& r = rt();
         std::lock_guard<std::mutex> lk(r.streamMutex);
@@ -555,6 +575,7 @@ DevBuf::~DevBuf() {
             r.api.sync(r.anyCtx, r.streams[u.stream].s);
         if (ts) {
             r.api.free_(r.anyCtx, p);
+            r.deviceBytes.fetch_sub(std::min<uint64_t>(bytes, r.deviceBytes.load()), std::memory_order_relaxed);
             return;
         }
         std::lock_guard<std::mutex> lk(r.poolMutex);
@@ -596,6 +617,15 @@ DevBuf::~DevBuf() {
         order_after(ts, u);
     std::lock_guard<std::mutex> fl(r.streams[ts->id].flMutex);
     ts->freeLists[bucket].push_back(p);
+    static const bool marksOn = !(std::getenv("FHE_HAL_RELEASE_MARKS") && std::string(std::getenv("FHE_HAL_RELEASE_MARKS")) == "0");
+    if (marksOn && bytes >= (1u << 20)) {  // (small buffers are not worth an event: a taker orders behind the stream's tail, as before)
+        if (void* e = ts->NewEvent()) {
+            if (r.api.event_record(r.anyCtx, e, r.streams[ts->id].s) == FHE_OK)
+                ts->marks[p] = e;
+            else
+                ts->eventPool.push_back(e);
+        }
+    }
     r.cachedBytes.fetch_add(bytes, std::memory_order_relaxed);
 }
 // Everything the backend holds beyond live towers goes back to the device: the remembered results, every live thread's free lists (under
@@ -624,6 +654,9 @@ static void ReleaseCaches(bool dropMemos = true) {
                 freed += (uint64_t)kv.first * 8 * kv.second.size();
                 kv.second.clear();
             }
+            for (auto& mk : st.ownerState->marks)  // (the buffers go back to the device behind a host-side wait: their marks are spent)
+                st.ownerState->eventPool.push_back(mk.second);
+            st.ownerState->marks.clear();
         }
         if (taken.empty())
             continue;
@@ -657,6 +690,7 @@ static void ReleaseCaches(bool dropMemos = true) {
         }
     }
     r.cachedBytes.fetch_sub(std::min<uint64_t>(freed, r.cachedBytes.load()), std::memory_order_relaxed);
+    r.deviceBytes.fetch_sub(std::min<uint64_t>(freed, r.deviceBytes.load()), std::memory_order_relaxed);
 }
 void ReleaseAllCaches() { ReleaseCaches(); }
 uint64_t CachedBytes() { return rt().cachedBytes.load(std::memory_order_relaxed); }
@@ -689,6 +723,11 @@ Buf Alloc(size_t words) {
         ts->TakeInbox();
         std::lock_guard<std::mutex> flk(r.streams[ts->id].flMutex);
         if (take(ts->freeLists)) {
+            auto mk = ts->marks.find(b->p);
+            if (mk != ts->marks.end()) {  // (this thread's own launches follow the buffer's pending uses in stream order: the mark is not needed)
+                ts->eventPool.push_back(mk->second);
+                ts->marks.erase(mk);
+            }
             // Kernels of the buffer's previous life may still be pending on THIS thread's stream (free lists and inboxes hold such
             // buffers on purpose: ~DevBuf only orders the stream).  This thread's own launches follow them in stream order; a first use
             // by ANOTHER thread (a tower allocated here and filled by an OpenMP worker) must be ordered behind them: the new buffer
@@ -720,12 +759,31 @@ Buf Alloc(size_t words) {
             if (!st.ownerState)
                 continue;
             if (take(st.ownerState->freeLists)) {
-                // everything submitted to T's stream so far — the buffer's pending launches and whatever T's stream was made to wait for
-                // when T released it — precedes this thread's later work: a device-side wait, recorded now (no sequence stamp of T's is
-                // involved, so nobody ever spins for an operation of T's to close)
-                Check(r.api.stream_wait(r.anyCtx, r.streams[ts->id].s, st.s), "HIP backend: ordering behind the stream a cached buffer came from");
+                // The buffer's completion mark (recorded on T's stream when T cached it, behind every pending use): this thread's stream
+                // waits for exactly that.  Without a mark (small buffers, buffers that came through T's inbox) it waits for everything
+                // submitted to T's stream so far, as in round 5.  Either way a device-side wait, recorded now: nobody spins on the host.
+                void* mark = nullptr;
+                auto mk = st.ownerState->marks.find(b->p);
+                if (mk != st.ownerState->marks.end()) {
+                    mark = mk->second;
+                    st.ownerState->marks.erase(mk);
+                }
+                const fhe_status ws = mark ? r.api.stream_wait_event(r.anyCtx, r.streams[ts->id].s, mark)
+                                           : r.api.stream_wait(r.anyCtx, r.streams[ts->id].s, st.s);
+                if (mark)
+                    st.ownerState->eventPool.push_back(mark);  // (a recorded wait keeps the event's state of that moment: the object is reusable)
+                if (ws != FHE_OK) {
+                    // the wait could not be recorded: the buffer goes back where it was, with its pending uses unordered for nobody
+                    // (round-5 advisor: `b` used to die into the taker's lists with an empty writer)
+                    st.ownerState->freeLists[b->cap].push_back(b->p);
+                    r.cachedBytes.fetch_add((uint64_t)b->cap * 8, std::memory_order_relaxed);
+                    b->p = nullptr;
+                    Check(ws, "HIP backend: ordering behind the last use of a cached buffer");
+                }
                 b->writer = DevBuf::Use{ts->id, r.streams[ts->id].issued.load(std::memory_order_relaxed)};
                 r.stolen.fetch_add(1, std::memory_order_relaxed);
+                if (mark)
+                    r.stolenExact.fetch_add(1, std::memory_order_relaxed);
                 return b;
             }
         }
@@ -760,6 +818,10 @@ Buf Alloc(size_t words) {
     Check(s, "HIP backend: device allocation");
     b->p   = static_cast<uint64_t*>(d);
     b->cap = bk;
+    const uint64_t now = r.deviceBytes.fetch_add((uint64_t)bk * 8, std::memory_order_relaxed) + (uint64_t)bk * 8;
+    uint64_t hw = r.deviceBytesHigh.load(std::memory_order_relaxed);
+    while (now > hw && !r.deviceBytesHigh.compare_exchange_weak(hw, now, std::memory_order_relaxed)) {
+    }
     return b;
 }
 Buf WrapExternal(uint64_t* devPtr, size_t words) {
@@ -1331,6 +1393,30 @@ extern "C" void fhe_hal_alloc_stats(uint64_t out[6]) {
     size_t f = 0, t = 0;
     if (r.api.mem_info(r.anyCtx, &f, &t) == FHE_OK)
         out[4] = f, out[5] = t;
+}
+// {bytes the backend holds from the device now (live towers + caches), the high-water mark of that, takes from another thread's cache that
+// waited for the buffer's own completion mark}
+extern "C" void fhe_hal_alloc_stats2(uint64_t out[3]) {
+    out[0] = out[1] = out[2] = 0;
+    if (!lbcrypto::hiprt::Available())
+        return;
+    auto& r = lbcrypto::hiprt::rt();
+    out[0] = r.deviceBytes, out[1] = r.deviceBytesHigh, out[2] = r.stolenExact;
+}
+// Pre-sizes the caches: one buffer of `bytes` is obtained from the device NOW and released into the calling thread's cache, where the first
+// large request of an evaluation (a lockstep group's 35-70 GiB BSGS workspace) finds it — instead of growing it against a device that the
+// caches of other size classes have filled (round 5: a cold 32x2 run spent its first passes at 13-17 bootstraps/s doing that).
+extern "C" int fhe_hal_reserve(uint64_t bytes) {
+    if (!lbcrypto::hiprt::Available() || bytes == 0)
+        return 1;
+    try {
+        auto b = lbcrypto::hiprt::Alloc((size_t)((bytes + 7) / 8));
+        (void)b;
+    }
+    catch (...) {
+        return 2;
+    }
+    return 0;
 }
 // the host waits until every stream of the backend has run dry (the end of a timed pass of a harness)
 extern "C" void fhe_hal_device_sync() {

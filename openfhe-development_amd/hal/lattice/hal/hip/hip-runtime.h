@@ -51,6 +51,10 @@ struct Api {
     decltype(&fhe_mod_switch_round) mod_switch_round;
     decltype(&fhe_automorph) automorph;
     decltype(&fhe_switch_modulus) switch_modulus;
+    decltype(&fhe_event_create) event_create;        // completion marks of cached buffers (Alloc)
+    decltype(&fhe_event_record) event_record;
+    decltype(&fhe_stream_wait_event) stream_wait_event;
+    decltype(&fhe_event_destroy) event_destroy;
     decltype(&fhe_sample_uniform) sample_uniform;    // (optional sampling on the device: FHE_HAL_DEVICE_SAMPLER=1)
     decltype(&fhe_sample_gaussian) sample_gaussian;
     decltype(&fhe_sample_ternary) sample_ternary;

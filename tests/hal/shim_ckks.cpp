@@ -31,6 +31,8 @@ extern "C" uint64_t fhe_hal_memo_hits() __attribute__((weak));
 extern "C" void fhe_hal_device_sync(void) __attribute__((weak));
 extern "C" uint64_t fhe_hal_cached_bytes(void) __attribute__((weak));
 extern "C" void fhe_hal_alloc_stats(uint64_t out[6]) __attribute__((weak));
+extern "C" void fhe_hal_alloc_stats2(uint64_t out[3]) __attribute__((weak));
+extern "C" int fhe_hal_reserve(uint64_t bytes) __attribute__((weak));
 static std::atomic<bool> g_release_thread{false};
 extern "C" uint64_t fhe_hal_cached_bytes(void) __attribute__((weak));
 extern "C" void fhe_hal_release_caches(void) __attribute__((weak));
@@ -187,17 +189,43 @@ int main(int argc, char** argv) {
             });
             while (!other || fhe_hal_cached_bytes() < otherCap * 8)
                 std::this_thread::yield();
+            uint64_t b2[3], a2[3];
             fhe_hal_alloc_stats(before);
+            fhe_hal_alloc_stats2(b2);
             auto y = hiprt::Alloc(40 * M);
             fhe_hal_alloc_stats(after);
+            fhe_hal_alloc_stats2(a2);
             std::cout << "buffers request served from another thread's cache: " << (y->p == other && after[1] == before[1] + 1 && after[2] == before[2])
                       << std::endl;
+            // round 6: the taker waited for the buffer's own completion mark (an event the releasing thread recorded), not for that thread's queue
+            std::cout << "buffers the taker waited for the buffer's own completion mark: " << (a2[2] == b2[2] + 1) << std::endl;
             g_release_thread.store(true);
             t.join();
             y.reset();
             auto big = hiprt::Alloc((size_t)150 * M);  // 1.17 GiB: classes of 1/16 x 2 GiB = 128 MiB above 1 GiB
             std::cout << "buffers size class above 1 GiB is a sixteenth step: " << (big->cap == (size_t)160 * M) << std::endl;
         }
+        {
+            // round 6: fhe_hal_reserve pre-sizes the cache — the next request of that class does not reach the device; the backend's own
+            // account of what it holds from the device follows allocations and releases, its high-water mark stays
+            uint64_t s0[6], s1[6], h0[3], h1[3], h2[3];
+            fhe_hal_release_caches();
+            fhe_hal_alloc_stats2(h0);
+            const int rc = fhe_hal_reserve((uint64_t)200 * M * 8);
+            fhe_hal_alloc_stats(s0);
+            fhe_hal_alloc_stats2(h1);
+            auto w = hiprt::Alloc((size_t)200 * M);
+            fhe_hal_alloc_stats(s1);
+            std::cout << "buffers a reserved buffer serves the first large request: "
+                      << (rc == 0 && s1[2] == s0[2] && h1[0] >= h0[0] + (uint64_t)200 * M * 8 && h1[1] >= h1[0]) << std::endl;
+            w.reset();
+            fhe_hal_release_caches();
+            fhe_hal_alloc_stats2(h2);
+            std::cout << "buffers the held bytes go down on release and the high-water mark stays: " << (h2[0] + (uint64_t)200 * M * 8 <= h1[0] && h2[1] == h1[1])
+                      << std::endl;
+        }
+        auto keep = hiprt::Alloc(M);
+        keep.reset();
         const uint64_t cached2 = fhe_hal_cached_bytes();
         fhe_hal_release_caches();
         std::cout << "buffers released caches: " << cached2 << " -> " << fhe_hal_cached_bytes() << std::endl;
