@@ -673,7 +673,6 @@ static uint32_t fill_pass_args(const fhe_ctx* c, const PassPlan& pp, bool invers
     a.epiMode = 0, a.epiSplit = 0, a.epiAStride = 0, a.epiAFirst = 0;
     a.epiA = nullptr, a.epiC = nullptr, a.epiOut0 = a.epiOut1 = nullptr;
     a.proMode = 0, a.proSrcLimb = 0;
-    a.proHat = nullptr, a.proMu = nullptr, a.proNSrc = 0;
     a.inDelta = 0, a.epiADelta = 0;
     return grid;
 }
@@ -694,37 +693,13 @@ static bool row8_for(uint32_t T) {
     }();
     return forced >= 0 ? forced == 1 : T <= 11u;
 }
-// the first load of a forward column pass as the second half of a basis conversion (NttPassArgs::proMode 2)
-struct NttProConv {
-    const uint64_t* hat;  // [rows][8]
-    const uint64_t* mu;   // [rows][2]
-    uint32_t nSrc;
-};
 static fhe_status launch_pass(const fhe_ctx* c, const PassPlan& pp, bool inverse, const uint64_t* xin, uint64_t* xout,
                               const LimbSel& sel, uint32_t nLimbs, uint32_t batch, bool canonOut, void* stream,
                               uint32_t inStride = 0, uint32_t inFirst = 0, uint32_t outStride = 0, uint32_t outFirst = 0,
-                              const NttEpilogue* epi = nullptr, const uint32_t* proSrcLimb = nullptr, int64_t inDelta = 0,
-                              const TwPair* finOverride = nullptr, const NttProConv* proConv = nullptr) {
+                              const NttEpilogue* epi = nullptr, const uint32_t* proSrcLimb = nullptr, int64_t inDelta = 0) {
     NttPassArgs a;
     const uint32_t grid = fill_pass_args(c, pp, inverse, xin, xout, sel, nLimbs, batch, canonOut, inStride, inFirst, outStride,
                                          outFirst, a);
-    if (finOverride)
-        a.fin = finOverride;
-    if (proConv) {
-        // the forward column pass whose first load converts from proNSrc source rows (ntt_static.h PRO = 2)
-        a.proMode = 2, a.proHat = proConv->hat, a.proMu = proConv->mu, a.proNSrc = proConv->nSrc;
-        const uint32_t tilesPerRow = c->N >> kTileLog;
-        a.xcdSwizzle = ((batch * tilesPerRow) % 8u == 0) ? 1u : 0u;  // limb-fastest order needs whole groups of 8 (tower, tile) pairs
-        const int mode = static_mode(c, pp, inverse);
-        if (pp.layoutA && !inverse && mode == 1 && pp.T == 4)
-            FHE_LAUNCH_BARRIER((ntt_static_kernel<true, false, 4, 1, false, 2>), grid, stream, a);
-        else if (pp.layoutA && !inverse && mode == 1 && pp.T == 5)
-            FHE_LAUNCH_BARRIER((ntt_static_kernel<true, false, 5, 1, false, 2>), grid, stream, a);
-        else
-            return fail(FHE_ERR_UNSUPPORTED, "ntt: no conversion-prologue kernel for this pass shape");
-        LAUNCH_CHECK();
-        return FHE_OK;
-    }
     if (inDelta) {  // (the static kernels only)
         if (c->logN < (uint32_t)kTileLog)
             return fail(FHE_ERR_UNSUPPORTED, "ntt: separately allocated towers need a ring of at least 4096");
@@ -852,8 +827,7 @@ static bool ntt_prologue_supported(const fhe_ctx* c) {
 static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_t* xout, const uint32_t* limbIdx,
                           uint32_t nLimbs, uint32_t batch, void* stream, uint32_t inStride = 0, uint32_t inFirst = 0,
                           uint32_t outStride = 0, uint32_t outFirst = 0, const NttEpilogue* epi = nullptr,
-                          bool canonOut = true, const uint32_t* proSrcLimb = nullptr, int64_t inDelta = 0,
-                          const TwPair* finOverride = nullptr, const NttProConv* proConv = nullptr) {
+                          bool canonOut = true, const uint32_t* proSrcLimb = nullptr, int64_t inDelta = 0) {
     ARG_CHECK(c && xin && xout, "fhe_ntt: null argument");
     ARG_CHECK(batch >= 1, "fhe_ntt: batch must be >= 1");
     LimbSel sel;
@@ -869,10 +843,8 @@ static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_
         if (!inverse)
             schedule_fwd(p, logN, &bound);
         p.outBound = bound;
-        if (proConv)
-            return fail(FHE_ERR_UNSUPPORTED, "ntt: the conversion prologue needs a two-pass ring");
         return launch_pass(c, p, inverse, xin, xout, sel, nLimbs, batch, canonOut, stream, inStride, inFirst, outStride, outFirst, epi,
-                           nullptr, inDelta, finOverride);
+                           nullptr, inDelta);
     }
     // two passes over HBM: a strided column pass of T1 stages (the coefficient index's top bits) and a
     // contiguous row pass of T2 = logN - T1 stages.  T1 is kept minimal (>= 4) so that the column pass reads
@@ -898,11 +870,9 @@ static fhe_status ntt_run(fhe_ctx* c, bool inverse, const uint64_t* xin, uint64_
     // pair takes the sum of its parts) or as one grid of alternating roles (6 % slower); persistent pass kernels (11 % slower: a
     // fresh workgroup's loads overlap the drain of its predecessor's stores); 5 + 11 stages instead of 4 + 12 (1 % slower).
     if (fhe_status s = launch_pass(c, p1, inverse, xin, xout, sel, nLimbs, batch, false, stream, inStride, inFirst, outStride, outFirst,
-                                   nullptr, proSrcLimb, inDelta, nullptr, proConv))
+                                   nullptr, proSrcLimb, inDelta))
         return s;
-    // (the constants of the transform's last stage belong to the pass that ends it: the inverse column pass)
-    return launch_pass(c, p2, inverse, xout, xout, sel, nLimbs, batch, canonOut, stream, outStride, outFirst, outStride, outFirst, epi,
-                       nullptr, 0, finOverride);
+    return launch_pass(c, p2, inverse, xout, xout, sel, nLimbs, batch, canonOut, stream, outStride, outFirst, outStride, outFirst, epi);
 }
 
 extern "C" fhe_status fhe_ntt_fwd(fhe_ctx* c, uint64_t* x, const uint32_t* li, uint32_t nl, uint32_t b, void* st) {
@@ -1759,7 +1729,6 @@ struct fhe_ks_plan {
         std::vector<uint32_t> partSize;
         fhe_conv* down = nullptr;               // P -> Q_l
         std::map<uint64_t, fhe_conv*> downT;    // BGV: P -> Q_l with t^-1 (mod p_j) and t (mod q_i) folded in, per t
-        TwPair* d_finY = nullptr;               // [ctxLimbs][2]: the inverse transform's last-stage constants times [Qhat_i^-1]_{q_i} of limb i's digit
         TwPair* d_PInv = nullptr;               // [sizeQl] Shoup pairs of [P^-1]_{q_i}
         TwPair* d_PModq = nullptr;              // [sizeQl] Shoup pairs of [P]_{q_i} (built on first use)
     };
@@ -1881,35 +1850,6 @@ static fhe_status ks_level(fhe_ks_plan* p, uint32_t sizeQl, fhe_ks_plan::Level**
             return fail(FHE_ERR_DEVICE, std::string("fhe_keyswitch: building the level tables: ") + e);
         }
         lv->d_PInv = (TwPair*)d;
-    }
-    {
-        // ModUp fused into the forward column pass (ks_precompute_run): the inverse transform that precedes it ends with
-        // N^-1 * [Qhat_i^-1]_{q_i} instead of N^-1, so its output IS y_i = x_i * [Qhat_i^-1]_{q_i} (dcrtpoly-impl.h:897-901) at no cost
-        std::vector<TwPair> fy(c->h_fin);
-        for (uint32_t part = 0; part < lv->numParts; ++part) {
-            const uint32_t start = p->alpha * part, sz = lv->partSize[part];
-            std::vector<uint64_t> src(c->q.begin() + start, c->q.begin() + start + sz);
-            for (uint32_t i = 0; i < sz; ++i) {
-                const uint64_t qi = src[i], hinv = host::invmod(host::prod_mod(src, (int)i, qi), qi);
-                for (int k = 0; k < 2; ++k) {
-                    const uint64_t v = host::mulmod(c->h_fin[2 * (start + i) + k].w, hinv, qi);
-                    fy[2 * (start + i) + k] = TwPair{v, host::shoup(v, qi)};
-                }
-            }
-        }
-        void* d       = nullptr;
-        const char* e = rt::dmalloc(&d, fy.size() * sizeof(TwPair));
-        if (!e) {
-            p->owned.push_back(d);
-            e = rt::h2d(d, fy.data(), fy.size() * sizeof(TwPair), nullptr);
-        }
-        if (!e)
-            e = rt::sync(nullptr);
-        if (e) {
-            ks_level_free(lv);
-            return fail(FHE_ERR_DEVICE, std::string("fhe_keyswitch: building the level tables: ") + e);
-        }
-        lv->d_finY = (TwPair*)d;
     }
     p->levels[sizeQl] = lv;
     *out              = lv;
@@ -2044,27 +1984,11 @@ static fhe_status ks_precompute_run(fhe_ks_plan* p, fhe_ks_plan::Level* lv, cons
                                     uint64_t* ws, const KsLayout& w, void* st) {
     fhe_ctx* c            = p->ctx;
     const uint32_t sizeQl = lv->sizeQl;
-    // Round 6: ModUp straight into the forward column pass.  The inverse transform ends with N^-1 * [Qhat_i^-1]_{q_i} (Level::d_finY), so
-    // ws.coef holds y_i; the column pass of every digit's forward transform forms sum_i y_i * [Qhat_i]_{p_t} for its 16 rows in its
-    // load prologue (ntt_static.h PRO = 2) — the beta * (l + k - alpha) converted limbs are never written and read back in
-    // COEFFICIENT form (28 of a digit's 112 limb moves).  FHE_KS_FUSED_MODUP=0: the conversion kernel + plain transform (A/B).
-    static const bool fusedOn = env_u32("FHE_KS_FUSED_MODUP", 1) != 0;
-    bool fused = fusedOn && c->logN > (uint32_t)kTileLog && ntt_t1(c->logN) <= 5u && ((batch * (c->N >> kTileLog)) % 8u == 0);
-    for (uint32_t j = 0; j < lv->numParts && fused; ++j)
-        fused = lv->partSize[j] <= 8u;
-    if (fhe_status s = ntt_run(c, true, cin, ws + w.coef, nullptr, sizeQl, batch, st, 0, 0, 0, 0, nullptr, true, nullptr, 0,
-                               fused ? lv->d_finY : nullptr))
+    if (fhe_status s = fhe_ntt_inv_oop(c, cin, ws + w.coef, nullptr, sizeQl, batch, st))
         return s;
     for (uint32_t j = 0; j < lv->numParts; ++j) {
         const uint32_t nc = (uint32_t)lv->cidx[j].size();
         uint64_t* dj      = ws + w.dig[j];
-        if (fused) {
-            const NttProConv pc{lv->up[j]->tb.hatMod, lv->up[j]->tb.dstMu, lv->partSize[j]};
-            if (fhe_status s = ntt_run(c, false, ws + w.coef, dj, lv->cidx[j].data(), nc, batch, st, sizeQl, p->alpha * j, 0, 0, nullptr, false,
-                                       nullptr, 0, nullptr, &pc))
-                return s;
-            continue;
-        }
         if (fhe_status s = fhe_approx_switch_basis(lv->up[j], ws + w.coef, sizeQl, p->alpha * j, dj, nc, 0, batch, st))
             return s;
         // the digits are only read by the inner product, whose 128-bit accumulation takes any 64-bit operand: the

@@ -93,14 +93,6 @@ struct NttPassArgs {
     // brought to the limb's own modulus on the way in (SwitchModulus, mubintvecnat.cpp:109-122) — the `tmp[i] = lastPoly;
     // tmp[i].SwitchModulus(q_i)` of DropLastElementAndScale (dcrtpoly-impl.h:703-704) never goes to HBM.  0: off.
     uint32_t proMode, proSrcLimb;
-    // proMode 2 (round 6, PRO = 2 instances): the first load of a forward column pass IS ApproxSwitchCRTBasis's second half
-    // (dcrtpoly-impl.h:903-913).  Row r of the pass is target limb r of a conversion plan; xin holds y_i = x_i * [Qhat_i^-1]_{q_i}
-    // (rows inFirst .. inFirst + proNSrc - 1 of every tower of inStride rows, COEFFICIENT); every loaded word is
-    // sum_i y_i * [Qhat_i]_{p_r} mod p_r, formed from the proNSrc source words at the same coefficient — the converted tower never goes
-    // to HBM in COEFFICIENT form.  proHat: [rows][8] (a target's row, zero-padded), proMu: [rows][2] floor(2^128 / p_r).
-    const uint64_t* proHat;
-    const uint64_t* proMu;
-    uint32_t proNSrc;
     // != 0: consecutive towers of the pass's first load / of the epilogue's operand A are this many WORDS apart (signed: towers
     // allocated on their own — the two elements of a ciphertext); overrides inStride / epiAStride (static kernels only)
     int64_t inDelta, epiADelta;

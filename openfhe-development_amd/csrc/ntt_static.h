@@ -521,9 +521,7 @@ FHE_HD void lane_geom_s(uint32_t t, uint32_t S, uint32_t& Ib, uint32_t& jrel, ui
 // row pass whose first step both act on tile bit 0 hold the same 16 consecutive residues per lane.
 // PRO: the first load takes every limb of a tower from one COEFFICIENT row modulo another limb's modulus and switches it to the
 // limb's own modulus (NttPassArgs::proMode) — forward column passes only.
-// PRO: 0 none, 1 the first load takes every limb from ONE row modulo another limb's modulus (proMode 1), 2 the first load is a basis
-// conversion from proNSrc rows (proMode 2) — forward column passes only.
-template <bool LA, bool INV, int T, int MODE, bool EPI = false, bool RAWIN = false, bool RAWOUT = false, int PRO = 0>
+template <bool LA, bool INV, int T, int MODE, bool EPI = false, bool RAWIN = false, bool RAWOUT = false, bool PRO = false>
 FHE_DEV void ntt_static_core(const NttPassArgs& a, uint32_t bid, uint64_t* lds, uint64_t (&r)[16]) {
     using P = SPlan<LA, INV, T>;
     static_assert(!(RAWIN || RAWOUT) || !LA, "register hand-over exists for row passes only");
@@ -533,14 +531,7 @@ FHE_DEV void ntt_static_core(const NttPassArgs& a, uint32_t bid, uint64_t* lds, 
     const uint32_t N    = 1u << logN;
     const uint32_t tilesPerRow = N >> kTileLog;
     uint32_t tile = bid;
-    if (PRO == 2 && a.xcdSwizzle) {
-        // LIMB-fastest order: the nLimbs target limbs of one (tower, tile position) run back to back on ONE XCD, so that the source tiles
-        // they all read (proNSrc x 32 KiB) are fetched into that XCD's L2 once
-        const uint32_t xcd = tile & 7u, i = tile >> 3;
-        const uint32_t rit = i % a.nLimbs, grp = (i / a.nLimbs) * 8u + xcd;  // grp = tower * tilesPerRow + tile position
-        tile = ((grp / tilesPerRow) * a.nLimbs + rit) * tilesPerRow + grp % tilesPerRow;
-    }
-    else if (a.xcdSwizzle) {
+    if (a.xcdSwizzle) {
         const uint32_t xcd = tile & 7u, i = tile >> 3;
         const uint32_t b = i % a.batch, pairIdx = i / a.batch;
         const uint32_t pair = pairIdx * 8u + xcd;
@@ -651,36 +642,6 @@ FHE_DEV void ntt_static_core(const NttPassArgs& a, uint32_t bid, uint64_t* lds, 
         }
     };
 
-    // proMode 2: the pass's first load = the second half of ApproxSwitchCRTBasis (dcrtpoly-impl.h:903-913): column sums of 30-bit split
-    // factors (sum8s, modarith.h: exact, no carries) reduced with the target's Barrett constant — the arithmetic of switch_basis_kernel
-    auto pro_convert = [&](uint64_t (&v)[16], uint32_t jr, uint64_t kstr) {
-        const uint64_t* hm = a.proHat + (size_t)rit * 8;
-        uint32_t h0[8], h1[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            split30(FHE_ULOAD64(hm, i), h0[i], h1[i]);
-        const uint64_t mulo = FHE_ULOAD64(a.proMu, 2 * (size_t)rit), muhi = FHE_ULOAD64(a.proMu, 2 * (size_t)rit + 1);
-        const uint32_t kb = 64u - (uint32_t)__builtin_clzll(q);
-        const uint32_t ns = a.proNSrc;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            uint64_t y[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {  // (unconditional loads: rows beyond proNSrc re-read the last row, their factors are zero)
-                const uint32_t rowi = (uint32_t)i < ns ? (uint32_t)i : ns - 1u;
-                y[i] = FHE_GLD(&src[((uint64_t)rowi << logN) + jr + k * kstr]);
-            }
-            sum8s s8;
-            sum8s_clear(s8);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                uint32_t y0, y1;
-                split30(y[i], y0, y1);
-                sum8s_add(s8, y0, y1, h0[i], h1[i]);
-            }
-            v[k] = sum8s_reduce(s8, q, kb, mulo, muhi);
-        }
-    };
     auto pro_switch = [&](uint64_t (&v)[16]) {
         const uint64_t qs = FHE_ULOAD64(a.q, a.proSrcLimb), halfQs = qs >> 1;
 #pragma unroll
@@ -709,14 +670,10 @@ FHE_DEV void ntt_static_core(const NttPassArgs& a, uint32_t bid, uint64_t* lds, 
     }
     else if constexpr (P::stageFirst) {
         lane_geom_s<LA, T, 8>(t, S, Ib, jrel, ks);
-        if constexpr (PRO == 2)
-            pro_convert(r, jrel, ks);
-        else {
 #pragma unroll
-            for (int k = 0; k < 16; ++k)
-                r[k] = FHE_GLD(&src[jrel + k * ks]);
-        }
-        if constexpr (PRO == 1)
+        for (int k = 0; k < 16; ++k)
+            r[k] = FHE_GLD(&src[jrel + k * ks]);
+        if constexpr (PRO)
             pro_switch(r);
         FHE_SHARED_TW_TO_LDS()
         uint64_t* L = lds + lds_pad(Ib);
@@ -734,12 +691,8 @@ FHE_DEV void ntt_static_core(const NttPassArgs& a, uint32_t bid, uint64_t* lds, 
             /* residues already in r[] in this step's layout */                                                   \
         }                                                                                                         \
         else if constexpr (I == 0 && !P::stageFirst) {                                                            \
-            if constexpr (PRO == 2)                                                                               \
-                pro_convert(r, jrel, ks);                                                                         \
-            else {                                                                                                \
-                _Pragma("unroll") for (int k = 0; k < 16; ++k) r[k] = FHE_GLD(&src[jrel + k * ks]);               \
-            }                                                                                                     \
-            if constexpr (PRO == 1)                                                                               \
+            _Pragma("unroll") for (int k = 0; k < 16; ++k) r[k] = FHE_GLD(&src[jrel + k * ks]);                   \
+            if constexpr (PRO)                                                                                    \
                 pro_switch(r);                                                                                    \
             FHE_SHARED_TW_TO_LDS()                                                                                \
         }                                                                                                         \
@@ -800,13 +753,13 @@ FHE_DEV void ntt_static_core(const NttPassArgs& a, uint32_t bid, uint64_t* lds, 
     }
 }
 
-template <bool LA, bool INV, int T, int MODE, bool EPI = false, int PRO = 0>
+template <bool LA, bool INV, int T, int MODE, bool EPI = false, bool PRO = false>
 FHE_DEV void ntt_static_body(const NttPassArgs& a, uint32_t bid, uint64_t* lds) {
     uint64_t r[16];
     ntt_static_core<LA, INV, T, MODE, EPI, false, false, PRO>(a, bid, lds, r);
 }
 
-template <bool LA, bool INV, int T, int MODE, bool EPI = false, int PRO = 0>
+template <bool LA, bool INV, int T, int MODE, bool EPI = false, bool PRO = false>
 FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ntt_static_kernel(const NttPassArgs a) {
     // a single-step pass without staging (the 4-stage column pass) never touches LDS: do not reserve any, so that
     // more workgroups fit on a CU

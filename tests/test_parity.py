@@ -471,7 +471,7 @@ def ckks_like_params(o, logN, sizeQ, dnum, first_bits=60, scale_bits=50, aux_bit
 
 
 @pytest.mark.parametrize("logN,sizeQ,dnum,sizeQl,B", [(10, 4, 2, 4, 3), (8, 5, 2, 3, 2), (12, 6, 3, 6, 2), (12, 7, 2, 5, 1), (12, 5, 3, 2, 1), (13, 4, 2, 4, 1),
-                                                      (13, 4, 2, 4, 4), (14, 5, 3, 4, 2),  # whole groups of 8 (tower, tile) pairs: ModUp fused into the column pass (r6)
+                                                      (13, 4, 2, 4, 4), (14, 5, 3, 4, 2),  # two-pass rings with whole groups of 8 (tower, tile) pairs (the shapes the round-6 fused-ModUp experiment took, commit efa3a5d)
                                                       (16, 2, 2, 2, 1), (17, 2, 2, 2, 1),  # 12-stage row passes: BASELINE configs[2] / [3] rings
                                                       # shapes past the kernels' per-launch bounds: a digit and a P basis of more than 32
                                                       # limbs (dnum = 1 on a 40-limb chain: chunked conversions), more than 8 digits (chunked
