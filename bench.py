@@ -865,16 +865,17 @@ def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev,
         wide["roofline"]["operand_GB_listed"] = round(sum(wide["roofline"]["operand_GB_by_member"].values()), 3)
         # HBM bytes per bootstrap from the committed counter passes of this setting (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over the lockstep
         # passes, tools/boot_wide_profile.py pmc) — quoted only when recorded with the kernel sources this run executes
-        try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", "r05_bootstrap_pmc.json")))
+        for recname in ("r06_bootstrap_pmc.json", "r05_bootstrap_pmc.json"):
+            try:
+                rec = json.load(open(os.path.join(ROOT, "profiles", recname)))
+            except Exception:
+                continue
             if rec.get("kernel_source_sha") == source_sha():
                 wide["roofline"]["traffic"] = round(rec["bytes_per_bootstrap"])
-                wide["roofline"]["traffic_source"] = "profiles/r05_bootstrap_pmc.json (FETCH_SIZE x2 + WRITE_SIZE over the lockstep passes, groups of 16 on 2 host threads, same kernel sources)"
+                wide["roofline"]["traffic_source"] = f"profiles/{recname} (FETCH_SIZE x2 + WRITE_SIZE over the lockstep passes, groups of 16 on 2 host threads, same kernel sources)"
                 wide["roofline"]["wasted_traffic_ratio"] = round(rec["bytes_per_bootstrap"] / 1e9 / max(wide["roofline"]["operand_GB_per_bootstrap"], 1e-9), 3)
-            else:
-                wide["roofline"]["traffic_source"] = "profiles/r05_bootstrap_pmc.json was recorded with other kernel sources: not quoted"
-        except Exception:
-            pass
+                break
+            wide["roofline"]["traffic_source"] = f"profiles/{recname} was recorded with other kernel sources: not quoted"
         if mirror:
             wide["parity"] = f"HOST-MIRROR EXECUTIONS in the timed passes ({sum(mirror.values())}: {mirror}); " + wide["parity"]
         if ndiff != 0 or mirror:

@@ -96,5 +96,5 @@ def test_row8_forced_shapes_on_emulator():
 @pytest.mark.gpu
 def test_row8_forced_shapes_on_gpu():
     so = os.path.join(ROOT, "openfhe-development_amd", "csrc", "libfhe_hip.so")
-    run_child(so, [(16, 4, 3), (17, 2, 2)], {"FHE_NTT_ROW8": "1"}, 12)
+    run_child(so, [(16, 4, 3), (17, 2, 2)], {"FHE_NTT_ROW8": "1"}, 6)
     run_child(so, [(16, 3, 2)], {"FHE_NTT_ROW8": "1", "FHE_NTT_T1": "5"}, 3)

@@ -58,7 +58,7 @@ PY
     timeout 900 rocprofv3 --kernel-trace --output-format csv -d $D/boot_${R}_trace -- python $G/tools/boot_wide_profile.py run 64 16 2 2 > $D/boot_${R}_trace.log 2>&1
     tail -1 $D/boot_${R}_trace.log
     f=$(ls -t $D/boot_${R}_trace/*/*kernel_trace.csv | head -1)
-    (echo "# rocprofv3 --kernel-trace of \`tools/boot_wide_profile.py run 64 16 2 2\` (round 5 record: 64 ciphertexts at config 4's shape, lockstep groups of 16 on 2 host threads — bench.py's setting — 3 passes)"; tail -1 $D/boot_${R}_trace.log; python $G/tools/boot_wide_profile.py summarise $f 64 2) > $G/gpurun_out/${R}_bootstrap_wide_kernels.txt
+    (echo "# rocprofv3 --kernel-trace of \`tools/boot_wide_profile.py run 64 16 2 2\` (round record: 64 ciphertexts at config 4's shape, lockstep groups of 16 on 2 host threads — bench.py's setting — 3 passes)"; tail -1 $D/boot_${R}_trace.log; python $G/tools/boot_wide_profile.py summarise $f 64 2) > $G/gpurun_out/${R}_bootstrap_wide_kernels.txt
     head -16 $G/gpurun_out/${R}_bootstrap_wide_kernels.txt | cut -c1-150
     for c in FETCH_SIZE WRITE_SIZE; do
       # (ONE host thread throughout: rocprofv3 --pmc segfaults on the multi-threaded program in most runs; same launches, same bytes)
