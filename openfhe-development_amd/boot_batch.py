@@ -17,8 +17,35 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # used when it is present; FHE_HAL_BUILD=objcopy selects the other.
 OBJCOPY_SO = os.path.join(ROOT, "openfhe-development_amd", "hal", "_build", "libfhe_boot_batch_hip.so")
 PATCHED_SO = os.path.join(ROOT, "integration", "_build", "lib", "libfhe_boot_batch_hip.so")
-HIP_SO = PATCHED_SO if (os.path.exists(PATCHED_SO) and os.environ.get("FHE_HAL_BUILD", "") != "objcopy") else OBJCOPY_SO
-HAL_BUILD = "patched sources (integration/with_hip.patch)" if HIP_SO == PATCHED_SO else "unmodified sources, hooks bound with objcopy (hal/Makefile)"
+
+
+def _newest_backend_source():
+    """modification time of the newest source either build is made of (the backend's sources and headers, the C ABI): a patched build
+    older than that is STALE (round-5 advisor: after `make -C hal` alone the benchmark kept running an old patched backend)"""
+    import glob
+    hal = os.path.join(ROOT, "openfhe-development_amd", "hal")
+    files = [os.path.join(ROOT, "include", "fhe_hip.h"), os.path.join(ROOT, "integration", "with_hip.patch")]
+    for pat in ("*.cpp", "*.h", "lattice/**/*.h", "math/**/*.h"):
+        files += glob.glob(os.path.join(hal, pat), recursive=True)
+    return max((os.path.getmtime(f) for f in files if os.path.exists(f)), default=0.0)
+
+
+def _choose_build():
+    if os.environ.get("FHE_HAL_BUILD", "") == "objcopy" or not os.path.exists(PATCHED_SO):
+        return OBJCOPY_SO, "unmodified sources, hooks bound with objcopy (hal/Makefile)"
+    # (on the GPU box the snapshot's files all carry the copy's time: only a build that is older than the sources AND older than the
+    # other build is refused)
+    stale = os.path.getmtime(PATCHED_SO) < _newest_backend_source() and os.path.exists(OBJCOPY_SO) and \
+        os.path.getmtime(PATCHED_SO) < os.path.getmtime(OBJCOPY_SO)
+    if stale:
+        import sys
+        print("boot_batch: integration/_build is older than the backend's sources and than hal/_build: using the objcopy build "
+              "(run integration/build_patched.sh)", file=sys.stderr)
+        return OBJCOPY_SO, "unmodified sources, hooks bound with objcopy (hal/Makefile) — the patched build was stale"
+    return PATCHED_SO, "patched sources (integration/with_hip.patch)"
+
+
+HIP_SO, HAL_BUILD = _choose_build()
 u32, u64, vp = C.c_uint32, C.c_uint64, C.c_void_p
 
 

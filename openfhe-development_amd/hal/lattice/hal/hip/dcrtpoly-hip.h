@@ -2368,6 +2368,25 @@ public:
         hiprt::CountDevice();
         return FromDevice(t0.m_h.GetParams(), t0.m_h.GetFormat(), std::move(d), k);
     }
+    // A tower handed out by UnpackTower is a WINDOW of the wide buffer: it keeps the whole [K][limbs][N] allocation alive for as long as it
+    // lives (a caller that keeps one output of a group of 16 pins 16x its size).  Detach() gives a long-lived output a buffer of its own
+    // (one device-to-device copy); towers that are not windows are left as they are.  (Round-5 advisor.)
+    void Detach() {
+        hiprt::MemberScope scope("Detach");
+        hiprt::Buf src;
+        {
+            std::lock_guard<std::mutex> lk(m_lock.m);
+            src = m_d;
+        }
+        if (!src || !src->parent)
+            return;
+        hiprt::Op op;
+        auto d = hiprt::Alloc(src->words);
+        hiprt::D2D(op, op.W(d), op.R(src), src->words * 8, "a window detached from its wide buffer");
+        hiprt::CountDevice();
+        std::lock_guard<std::mutex> lk(m_lock.m);
+        m_d = std::move(d);
+    }
     DCRTPolyType UnpackTower(uint32_t i) const {
         hiprt::MemberScope scope("UnpackTower");
         hiprt::Resolved r;
