@@ -570,6 +570,11 @@ int main(int argc, char** argv) {
                         std::vector<DCRTPoly> el;
                         for (const auto& t : wc->GetElements())
                             el.push_back(t.UnpackTower(i));
+                        // (the first and the last product of the batch are the ones the program dumps: they get buffers of their own —
+                        // DCRTPoly::Detach, the call for outputs that outlive their group — and must still be the stock backend's bytes)
+                        if (first + i == 0 || first + i + 1 == (int)c.size())
+                            for (auto& e : el)
+                                e.Detach();
                         one->SetElements(std::move(el));
                         c[first + i] = one;
                     }
