@@ -306,11 +306,15 @@ def evalmult_leg(lib, device, logN, batch, steps, warmup, sync, dist=None, sizeQ
     for _ in range(warmup):
         step()
     lib.check(lib.L.fhe_stream_sync(ctx.h, st))
+    psamp = PowerSampler(device) if dist is None or dist.get_rank() == 0 else None
+    if psamp is not None:
+        psamp.start()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     lib.check(lib.L.fhe_stream_sync(ctx.h, st))
     dt = (time.perf_counter() - t0) / steps
+    em_power = psamp.stop() if psamp is not None else None
     # ---- parity of the TIMED launch's result: towers {0, B/2, B-1} of both output elements against the oracle on the same
     # inputs (tower t of every operand is seed tower t % 2; the key is this leg's host image)
     par = "skipped"
@@ -356,7 +360,7 @@ def evalmult_leg(lib, device, logN, batch, steps, warmup, sync, dist=None, sizeQ
     ach_survey = alg_survey * batch / dt / 1e9
     return {"ops_per_s_per_gpu": round(batch / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "batch": batch,
             "shape": f"N=2^{logN}, l={sizeQ}, k={len(p)}, dnum={dnum}, workspace {wsb / 2**30:.1f} GiB",
-            "eval_key": key_dist, "launch": mode, "parity": par,
+            "eval_key": key_dist, "launch": mode, "parity": par, "power": em_power,
             # frac is quoted on SURVEY.md 8(d)'s per-unit figure (the contract's byte count); the itemised count of every stage's operands
             # (what the operation sequence has to move with each limb-NTT in two passes) is reported beside it as moved_*
             "roofline": {"bound": "hbm", "algorithmic_bytes_per_op": alg_survey, "limb_ntts_per_op": ntt_limbs,
@@ -840,7 +844,11 @@ def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev,
         # demand, profiles/r04_sweeps.md sessions h / i — so two passes precede the readings)
         h.bootstrap_wide(group, 1, wide_threads)
         w0, m0, s0 = h.counters(), h.member_bytes(), h.member_stats()
+        bsamp = PowerSampler(device) if rank == 0 else None
+        if bsamp is not None:
+            bsamp.start()
         wsec = h.bootstrap_wide(group, 3, wide_threads)
+        boot_power = bsamp.stop() if bsamp is not None else None
         w1, m1, s1 = h.counters(), h.member_bytes(), h.member_stats()
         # members of DCRTPolyHipImpl that ran on its host mirror (the reference's own DCRTPolyImpl) between the two readings: the
         # lockstep passes the rate is quoted on.  A device figure with mirror executions in it is not a device figure.
@@ -852,7 +860,7 @@ def bootstrap_batch_leg(logN, per_gpu, threads, rank, world, device, dist, tdev,
                 "parity": (f"all {r['ciphertexts']} outputs identical word for word to the threaded (narrow) pass's outputs of the same ciphertexts "
                            "(compared in this run, every limb on the host)" if ndiff == 0 else
                            f"MISMATCH: {ndiff} of {r['ciphertexts']} outputs differ from the narrow pass's"),
-                "host_threads": wide_threads,
+                "host_threads": wide_threads, "power": boot_power,
                 "mirror_executions": {"total": sum(mirror.values()), "by_member": mirror,
                                       "window": "the 1 untimed + 3 timed lockstep passes between the counter readings (fhe_hal_member_stats)"},
                 "how": f"one cc->EvalBootstrap per group on a ciphertext of K-tower towers, the groups over {wide_threads} host thread(s) / stream(s)",

@@ -57,7 +57,7 @@ int fhe_device_count(void);
  *  ChineseRemainderTransformFTTNat::PreCompute, src/core/include/math/hal/intnat/transformnat-impl.h:714-756).
  * q[i] prime < 2^60 with q[i] = 1 mod 2N, psi[i] a primitive 2N-th root of unity mod q[i] (the reference
  * uses RootOfUnity(), the minimum one). Tables are built eagerly and are immutable afterwards.
- * logN in [4, 17]; nLimbs <= 128. */
+ * logN in [4, 17]; nLimbs <= 256 (rows of one tower and limbs of one context; round 6, until then 128). */
 fhe_status fhe_ctx_create(uint32_t logN, uint32_t nLimbs, const uint64_t* q, const uint64_t* psi, int device,
                           fhe_ctx** out);
 void       fhe_ctx_destroy(fhe_ctx* ctx);

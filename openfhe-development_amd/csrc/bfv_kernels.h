@@ -387,7 +387,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) behz_conv_sk_kernel(const BehzArgs g
 // per-lane array (private memory), tables of stride kBehzWideLimbs, run-time loops.  Every sum is exact (integer sums reduced in
 // chunks of 8 products, modular addition of the chunks), so the residues are the reference's whatever the chunking; throughput is
 // not a goal here — the members just must not fall back to the host mirror.
-constexpr int kBehzWideLimbs = 64;
+constexpr int kBehzWideLimbs = 128;
 FHE_HD uint64_t dot_row_mod_wide(const uint64_t* y, const uint64_t* row, uint32_t n, uint64_t m, uint64_t mulo, uint64_t muhi) {
     const uint32_t k = 64u - (uint32_t)__builtin_clzll(m);
     uint64_t v       = 0;

@@ -51,6 +51,7 @@ struct ElemArgs {
     uint32_t aStride, aFirst;  // aStride != 0: operand a is a [batch][aStride][N] view, rows aFirst.. of each tower
     uint32_t bStride, bFirst;  // same for b
     uint32_t oStride, oFirst;  // same for out
+    uint32_t cvFirst = 0;      // elemwise_cv_kernel: this launch takes rows [cvFirst, cvFirst + kConstVecLimbs) of every tower
     TwPair pre = {0, 0};       // OP_TIMES_QOVERT only: the first factor (Shoup pair modulo preMod) ...
     uint64_t preMod = 0;       // ... and its modulus (the plaintext modulus t)
     // != 0: consecutive towers of the operand are this many WORDS apart (signed: towers allocated on their own, e.g. the two
@@ -93,12 +94,15 @@ FHE_HD uint64_t elem_apply(uint64_t o, uint64_t a, uint64_t b, const LimbConst l
 
 // per-call constant vector passed BY VALUE in the kernel arguments (fhe_mul_const / fhe_mult_acc: the caller's host
 // constants need no device staging buffer, so the call stays asynchronous and capturable into a HIP graph)
+// (kernel arguments are limited to 4 KiB: the vector carries kConstVecLimbs rows; a tower with more rows takes one launch per window of
+// rows — `cvFirst` of ElemArgs — and the rows outside the window are left to the other launches)
+constexpr int kConstVecLimbs = 128;
 struct ConstVec {
-    TwPair c[kMaxLimbs];
+    TwPair c[kConstVecLimbs];
 };
 
-template <int OP, typename ConstAt>
-FHE_DEV void elemwise_body(const ElemArgs& g, ConstAt constAt) {
+template <int OP, typename ConstAt, typename InWindow>
+FHE_DEV void elemwise_body(const ElemArgs& g, ConstAt constAt, InWindow inWindow) {
     const uint32_t t          = FHE_TID;
     const uint64_t base       = (uint64_t)FHE_BID << kTileLog;
     const uint64_t totalWords = (uint64_t)g.rows << g.logN;
@@ -114,6 +118,8 @@ FHE_DEV void elemwise_body(const ElemArgs& g, ConstAt constAt) {
             continue;
         const uint32_t row  = (uint32_t)(off >> g.logN);
         const uint32_t rit  = row % g.nLimbs;
+        if (!inWindow(rit))
+            continue;
         const LimbConst lc  = g.lc[g.sel.idx[rit]];
         TwPair c            = {0, 0};
         if (needC)
@@ -152,11 +158,12 @@ FHE_DEV void elemwise_body(const ElemArgs& g, ConstAt constAt) {
 }
 template <int OP>
 FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) elemwise_kernel(const ElemArgs g) {
-    elemwise_body<OP>(g, [&](uint32_t rit) { return g.consts[rit]; });
+    elemwise_body<OP>(g, [&](uint32_t rit) { return g.consts[rit]; }, [](uint32_t) { return true; });
 }
 template <int OP>
 FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) elemwise_cv_kernel(const ElemArgs g, const ConstVec cv) {
-    elemwise_body<OP>(g, [&](uint32_t rit) { return cv.c[rit]; });
+    elemwise_body<OP>(g, [&](uint32_t rit) { return cv.c[rit - g.cvFirst]; },
+                      [&](uint32_t rit) { return rit - g.cvFirst < (uint32_t)kConstVecLimbs; });
 }
 
 // ---- linear combination of towers with per-limb constants: out = sum_i c_i (.) x_i  [+ out] ------------------------------------------

@@ -284,7 +284,7 @@ extern "C" fhe_status fhe_ctx_create(uint32_t logN, uint32_t nLimbs, const uint6
                                      int device, fhe_ctx** out) {
     ARG_CHECK(out != nullptr, "fhe_ctx_create: out is null");
     ARG_CHECK(logN >= 4 && logN <= 17, "fhe_ctx_create: logN must be in [4,17]");
-    ARG_CHECK(nLimbs >= 1 && nLimbs <= (uint32_t)kMaxLimbs, "fhe_ctx_create: nLimbs must be in [1,128]");
+    ARG_CHECK(nLimbs >= 1 && nLimbs <= (uint32_t)kMaxLimbs, "fhe_ctx_create: nLimbs must be in [1,256]");
     ARG_CHECK(q && psi, "fhe_ctx_create: null modulus/root array");
     if (rt::device_count() <= 0)
         return fail(FHE_ERR_DEVICE, "fhe_ctx_create: no HIP device available (there is no CPU fallback)");
@@ -1067,8 +1067,22 @@ extern "C" fhe_status fhe_neg(fhe_ctx* c, uint64_t* o, const uint64_t* a, const 
 
 // per-call constant vectors (Times(vector<NativeInteger>), MultAccEqNoCheck ...): the host constants become Shoup pairs
 // and travel BY VALUE in the kernel arguments — no staging buffer, no synchronisation, capturable into a HIP graph
+// (the whole vector on the host; a launch carries a window of kConstVecLimbs rows of it: launch_cv)
+struct HostConstVec {
+    TwPair c[kMaxLimbs];
+};
+template <int OP>
+static void launch_cv(fhe_ctx* c, ElemArgs g, const HostConstVec& cv, void* stream) {
+    for (uint32_t first = 0; first < g.nLimbs; first += (uint32_t)kConstVecLimbs) {
+        ConstVec w;
+        for (uint32_t i = 0; i < (uint32_t)kConstVecLimbs; ++i)
+            w.c[i] = first + i < (uint32_t)kMaxLimbs ? cv.c[first + i] : TwPair{0, 0};
+        g.cvFirst = first;
+        FHE_LAUNCH((elemwise_cv_kernel<OP>), tiles_for(c, g.rows), stream, g, w);
+    }
+}
 static fhe_status make_const_vec(const fhe_ctx* c, const uint64_t* consts, const uint32_t* limbIdx, uint32_t nLimbs,
-                                 ConstVec* cv, const char* who) {
+                                 HostConstVec* cv, const char* who) {
     ARG_CHECK(c && consts, std::string(who) + ": null argument");
     ARG_CHECK(nLimbs >= 1 && nLimbs <= (uint32_t)kMaxLimbs, std::string(who) + ": nLimbs out of range");
     for (uint32_t i = 0; i < (uint32_t)kMaxLimbs; ++i)
@@ -1082,7 +1096,7 @@ static fhe_status make_const_vec(const fhe_ctx* c, const uint64_t* consts, const
     return FHE_OK;
 }
 template <int OP>
-static fhe_status elem_cv_run(fhe_ctx* c, uint64_t* out, const uint64_t* a, const uint64_t* b, const ConstVec& cv,
+static fhe_status elem_cv_run(fhe_ctx* c, uint64_t* out, const uint64_t* a, const uint64_t* b, const HostConstVec& cv,
                               const uint32_t* limbIdx, uint32_t nLimbs, uint32_t batch, void* stream, const char* who,
                               uint32_t oStride = 0, uint32_t oFirst = 0, const int64_t* deltas = nullptr) {
     ARG_CHECK(c && out && a, std::string(who) + ": null argument");
@@ -1097,13 +1111,13 @@ static fhe_status elem_cv_run(fhe_ctx* c, uint64_t* out, const uint64_t* a, cons
     g.oStride = oStride, g.oFirst = oFirst;
     if (deltas)
         g.oDelta = deltas[0], g.aDelta = deltas[1], g.bDelta = deltas[2];
-    FHE_LAUNCH((elemwise_cv_kernel<OP>), tiles_for(c, g.rows), stream, g, cv);
+    launch_cv<OP>(c, g, cv, stream);
     LAUNCH_CHECK();
     return FHE_OK;
 }
 extern "C" fhe_status fhe_mul_const(fhe_ctx* c, uint64_t* o, const uint64_t* a, const uint64_t* consts,
                                     const uint32_t* li, uint32_t nl, uint32_t bt, void* st) {
-    ConstVec cv;
+    HostConstVec cv;
     if (fhe_status s = make_const_vec(c, consts, li, nl, &cv, "fhe_mul_const"))
         return s;
     return elem_cv_run<OP_MUL_CONST>(c, o, a, nullptr, cv, li, nl, bt, st, "fhe_mul_const");
@@ -1185,7 +1199,7 @@ extern "C" fhe_status fhe_mul_const_pair(fhe_ctx* c, uint64_t* o0, uint64_t* o1,
                                          const uint64_t* consts, const uint32_t* li, uint32_t nl, void* st) {
     int64_t d[3];
     ARG_CHECK(o0 && o1 && a0 && a1 && pair_deltas(o0, o1, a0, a1, nullptr, nullptr, d), "fhe_mul_const_pair: bad argument");
-    ConstVec cv;
+    HostConstVec cv;
     if (fhe_status s = make_const_vec(c, consts, li, nl, &cv, "fhe_mul_const_pair"))
         return s;
     return elem_cv_run<OP_MUL_CONST>(c, o0, a0, nullptr, cv, li, nl, 2, st, "fhe_mul_const_pair", 0, 0, d);
@@ -1194,7 +1208,7 @@ extern "C" fhe_status fhe_mul_const_pair(fhe_ctx* c, uint64_t* o0, uint64_t* o1,
 // constant polynomial consts[i] — every word in EVALUATION, coefficient 0 only in COEFFICIENT (coeff0Only)
 extern "C" fhe_status fhe_add_const(fhe_ctx* c, uint64_t* o, const uint64_t* a, const uint64_t* consts, const uint32_t* li,
                                     uint32_t nl, uint32_t bt, int coeff0Only, void* st) {
-    ConstVec cv;
+    HostConstVec cv;
     if (fhe_status s = make_const_vec(c, consts, li, nl, &cv, "fhe_add_const"))
         return s;
     if (coeff0Only)
@@ -1205,7 +1219,7 @@ extern "C" fhe_status fhe_add_const(fhe_ctx* c, uint64_t* o, const uint64_t* a, 
 // every word in both formats)
 extern "C" fhe_status fhe_sub_const(fhe_ctx* c, uint64_t* o, const uint64_t* a, const uint64_t* consts, const uint32_t* li,
                                     uint32_t nl, uint32_t bt, void* st) {
-    ConstVec cv;
+    HostConstVec cv;
     if (fhe_status s = make_const_vec(c, consts, li, nl, &cv, "fhe_sub_const"))
         return s;
     for (uint32_t i = 0; i < nl; ++i) {  // a - k = a + (q - k)
@@ -1219,7 +1233,7 @@ extern "C" fhe_status fhe_sub_const(fhe_ctx* c, uint64_t* o, const uint64_t* a, 
 extern "C" fhe_status fhe_times_q_over_t(fhe_ctx* c, uint64_t* o, const uint64_t* a, uint64_t t, uint64_t negQModt,
                                          const uint64_t* tInvModq, const uint32_t* li, uint32_t nl, uint32_t bt, void* st) {
     ARG_CHECK(c && o && a && tInvModq && t >= 2 && bt >= 1, "fhe_times_q_over_t: bad argument");
-    ConstVec cv;
+    HostConstVec cv;
     if (fhe_status s = make_const_vec(c, tInvModq, li, nl, &cv, "fhe_times_q_over_t"))
         return s;
     ElemArgs g;
@@ -1230,7 +1244,7 @@ extern "C" fhe_status fhe_times_q_over_t(fhe_ctx* c, uint64_t* o, const uint64_t
     g.logN = c->logN, g.nLimbs = nl, g.rows = bt * nl;
     g.aStride = g.aFirst = g.bStride = g.bFirst = g.oStride = g.oFirst = 0;
     g.pre = TwPair{negQModt % t, host::shoup(negQModt % t, t)}, g.preMod = t;
-    FHE_LAUNCH((elemwise_cv_kernel<OP_TIMES_QOVERT>), tiles_for(c, g.rows), st, g, cv);
+    launch_cv<OP_TIMES_QOVERT>(c, g, cv, st);
     LAUNCH_CHECK();
     return FHE_OK;
 }
@@ -1250,7 +1264,7 @@ extern "C" fhe_status fhe_mod_switch_round(fhe_ctx* c, const uint64_t* x, uint64
 // product, ModAddFastEq)
 extern "C" fhe_status fhe_mult_acc(fhe_ctx* c, uint64_t* acc, const uint64_t* v, const uint64_t* consts,
                                    const uint32_t* li, uint32_t nl, uint32_t bt, void* st) {
-    ConstVec cv;
+    HostConstVec cv;
     if (fhe_status s = make_const_vec(c, consts, li, nl, &cv, "fhe_mult_acc"))
         return s;
     return elem_cv_run<OP_MUL_CONST_ADD>(c, acc, v, acc, cv, li, nl, bt, st, "fhe_mult_acc");
@@ -1271,7 +1285,7 @@ extern "C" fhe_status fhe_expand_crt_basis_ql_hat(fhe_ctx* c, const uint64_t* x,
     ARG_CHECK(c && x && out && QlHatModq, "fhe_expand_crt_basis_ql_hat: null argument");
     ARG_CHECK(sizeQl >= 1 && sizeQl <= sizeQ && sizeQ <= (uint32_t)kMaxLimbs && bt >= 1, "fhe_expand_crt_basis_ql_hat: bad sizes");
     ARG_CHECK(out != x || sizeQl == sizeQ, "fhe_expand_crt_basis_ql_hat: in-place only when no limb is appended");
-    ConstVec cv;
+    HostConstVec cv;
     if (fhe_status s = make_const_vec(c, QlHatModq, li, sizeQl, &cv, "fhe_expand_crt_basis_ql_hat"))
         return s;
     for (uint32_t i = sizeQl; i < sizeQ; ++i)
@@ -1443,7 +1457,7 @@ static fhe_status conv_from_tables(fhe_ctx* c, const std::vector<uint64_t>& src,
                                    const double* qInvIn, fhe_conv** out) {
     const uint32_t nSrc = (uint32_t)src.size(), nDst = (uint32_t)dst.size();
     if (nSrc < 1 || nSrc > (uint32_t)kMaxLimbs || nDst < 1 || nDst > (uint32_t)kMaxLimbs)
-        return fail(FHE_ERR_ARG, "basis conversion: 1..128 source and target limbs");
+        return fail(FHE_ERR_ARG, "basis conversion: 1..256 source and target limbs");
     fhe_conv* cv = new fhe_conv;
     cv->ctx      = c;
     cv->nSrc     = nSrc;
@@ -2915,7 +2929,8 @@ static fhe_status dev_copy(std::vector<void*>& owned, const T* h, size_t n, T** 
 extern "C" fhe_status fhe_sr_plan_create(fhe_ctx* c, uint32_t sizeI, const uint32_t* outLimbIdx, uint32_t sizeO,
                                          const uint64_t* tab, const double* frac, fhe_sr_plan** out) {
     ARG_CHECK(c && outLimbIdx && tab && out, "fhe_sr_plan_create: null argument");
-    ARG_CHECK(sizeI >= 1 && sizeO >= 1 && sizeI <= 64 && sizeO <= 64, "fhe_sr_plan_create: bad basis size");
+    // (the 128-bit sums of the kernel hold sizeI + 1 products of residues below 2^60: 2^8 terms — as the reference's DoubleNativeInt sums)
+    ARG_CHECK(sizeI >= 1 && sizeO >= 1 && sizeI < (uint32_t)kMaxLimbs && sizeO <= (uint32_t)kMaxLimbs, "fhe_sr_plan_create: bad basis size");
     RT_CHECK(rt::set_device(c->device));
     std::vector<uint64_t> o(sizeO), mu(2 * (size_t)sizeO);
     for (uint32_t j = 0; j < sizeO; ++j) {
@@ -3153,7 +3168,7 @@ extern "C" uint32_t fhe_param_behz_bsk(uint32_t logN, uint32_t numQ, const uint6
 extern "C" fhe_status fhe_behz_create(fhe_ctx* c, const uint32_t* qLimbIdx, uint32_t numQ, const uint32_t* bskLimbIdx,
                                       uint64_t t, fhe_behz** out) {
     ARG_CHECK(c && qLimbIdx && bskLimbIdx && out, "fhe_behz_create: null argument");
-    ARG_CHECK(numQ >= 1 && numQ + 1 <= (uint32_t)kBehzWideLimbs, "fhe_behz_create: at most 63 Q limbs supported");
+    ARG_CHECK(numQ >= 1 && numQ + 1 <= (uint32_t)kBehzWideLimbs, "fhe_behz_create: at most 127 Q limbs supported");
     const uint32_t numB = numQ, numBsk = numQ + 1;
     std::vector<uint64_t> q(numQ), bsk(numBsk);
     for (uint32_t i = 0; i < numQ; ++i) {

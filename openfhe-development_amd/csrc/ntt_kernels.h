@@ -33,7 +33,7 @@ namespace fhe {
 constexpr int kTileLog  = 12;
 constexpr int kTile     = 1 << kTileLog;  // residues per workgroup tile
 constexpr int kThreads  = 256;            // 4 waves
-constexpr int kMaxLimbs = 128;
+constexpr int kMaxLimbs = 256;  // rows of one tower / limbs of one context (the limb map travels by value: one byte per row)
 
 struct alignas(16) TwPair {
     uint64_t w, wp;  // wp = floor(w * 2^64 / q)   (PrepModMulConst, ubintnat.h:1437-1444)

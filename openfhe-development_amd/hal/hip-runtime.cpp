@@ -97,7 +97,7 @@ struct Runtime {
     std::map<fhe_ctx*, CtxHolder*> holders;
     std::atomic<uint64_t> deviceOps{0}, hostFallbacks{0}, h2dBytes{0}, d2hBytes{0}, hostSmallRing{0}, hostData{0};
     // why an operation left the device library's domain (Resolve): a ring outside [16, 2^17] or not a power of two; a modulus that is
-    // not a prime-shaped NTT modulus below 2^60; more than 128 distinct moduli in one operation; a second root of unity for a modulus
+    // not a prime-shaped NTT modulus below 2^60; more than 256 distinct moduli in one operation; a second root of unity for a modulus
     std::atomic<uint64_t> outRing{0}, outModulus{0}, outMoreThan128Moduli{0}, outOtherRoot{0};
     // operand bytes of the device operations: every tower (or key, or table held in a DevBuf) an operation reads / writes, counted once
     // per operation — what the sequence of fused operations has to move if every operand crossed HBM exactly once (the algorithmic
@@ -1020,14 +1020,14 @@ bool Resolve(uint32_t ringDim, const std::vector<LimbSet>& sets, Resolved* out) 
                         qq.push_back(s.q[i]), pp.push_back(s.psi[i]);
         };
         add(q, psi);
-        if (q.size() > 128) {
+        if (q.size() > kMaxDeviceLimbs) {
             // more distinct moduli than one device context holds (many CryptoContexts in one process): start over with the
             // moduli of this call; towers already on the device are plain words and resolve again at their next operation
             q.clear(), psi.clear();
             add(q, psi);
-            if (q.size() > 128) {
+            if (q.size() > kMaxDeviceLimbs) {
                 r.outMoreThan128Moduli.fetch_add(1, std::memory_order_relaxed);
-                Declined("device context", "more than 128 distinct moduli in one operation (" + std::to_string(q.size()) + ")");
+                Declined("device context", "more than 256 distinct moduli in one operation (" + std::to_string(q.size()) + ")");
                 return false;
             }
         }
@@ -1235,7 +1235,7 @@ std::atomic<uint64_t> g_compositeCalls{0}, g_checksOk{0}, g_checksBad{0};
 }  // namespace
 std::shared_ptr<KsDomain> GetKsDomain(uint32_t ringDim, const LimbSet& Q, const LimbSet& P, uint32_t numPartQ) {
     Runtime& r = rt();
-    if (!r.live || ringDim < 16 || ringDim > (1u << 17) || (ringDim & (ringDim - 1)) || Q.n == 0 || P.n == 0 || Q.n + P.n > 128 || numPartQ == 0)
+    if (!r.live || ringDim < 16 || ringDim > (1u << 17) || (ringDim & (ringDim - 1)) || Q.n == 0 || P.n == 0 || Q.n + P.n > kMaxDeviceLimbs || numPartQ == 0)
         return nullptr;
     std::vector<uint64_t> key{ringDim, numPartQ, Q.n, P.n};
     key.insert(key.end(), Q.q, Q.q + Q.n);
@@ -1478,7 +1478,7 @@ extern "C" void fhe_hal_composite_stats(uint64_t out[3]) {
     out[0] = lbcrypto::hiprt::g_compositeCalls, out[1] = lbcrypto::hiprt::g_checksOk, out[2] = lbcrypto::hiprt::g_checksBad;
 }
 extern "C" void fhe_hal_other_host_counts(uint64_t out[2]) { lbcrypto::hiprt::OtherHostCounts(out); }
-// operations that left the device library's domain, by reason: {ring outside [16, 2^17], modulus outside the domain, more than 128
+// operations that left the device library's domain, by reason: {ring outside [16, 2^17], modulus outside the domain, more than 256
 // distinct moduli, another root of unity for a known modulus}
 // operand bytes of the device operations so far: {read, written} (see Runtime::opReadBytes)
 extern "C" void fhe_hal_operand_bytes(uint64_t out[2]) {

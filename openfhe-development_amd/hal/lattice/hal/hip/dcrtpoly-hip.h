@@ -1807,7 +1807,7 @@ private:
             *out       = std::move(scaled);
             return true;
         }
-        if (!hiprt::Available() || sizeO == 0 || sizeQP <= sizeO || sizeQP - sizeO > 64 || sizeO > 64)
+        if (!hiprt::Available() || sizeO == 0 || sizeQP <= sizeO || sizeQP - sizeO >= hiprt::kMaxDeviceLimbs || sizeO > hiprt::kMaxDeviceLimbs)
             return false;
         const uint32_t sizeI = sizeQP - sizeO;
         if (tab.size() < sizeO || (frac && frac->size() < sizeI))
@@ -2010,7 +2010,7 @@ private:
         // (:892: sizeQ = min(limbs of this tower, limbs of paramsQ) — the last digit of a lower level is shorter than its params)
         const uint32_t sizeQ = std::min<uint32_t>(NumLimbs(), (uint32_t)paramsQ->GetParams().size());
         const uint32_t sizeP = (uint32_t)paramsP->GetParams().size();
-        if (sizeQ == 0 || sizeQ > 128 || sizeP == 0 || sizeP > 128 || sizeQ != NumLimbs() || QHatInvModq.size() < sizeQ)
+        if (sizeQ == 0 || sizeQ > hiprt::kMaxDeviceLimbs || sizeP == 0 || sizeP > hiprt::kMaxDeviceLimbs || sizeQ != NumLimbs() || QHatInvModq.size() < sizeQ)
             return false;
         if ((transposed ? QHatModp.size() < sizeP : QHatModp.size() < sizeQ))
             return false;
@@ -2079,7 +2079,7 @@ private:
                          const std::vector<std::vector<NativeInteger>>& PHatModq, const std::vector<NativeInteger>& tInvModp,
                          const NativeInteger& t, DCRTPolyType* out) const {
         const uint32_t sizeP = (uint32_t)paramsP->GetParams().size(), L = NumLimbs();
-        if (L <= sizeP || sizeP > 128 || m_h.GetFormat() != Format::EVALUATION)
+        if (L <= sizeP || sizeP > hiprt::kMaxDeviceLimbs || m_h.GetFormat() != Format::EVALUATION)
             return false;
         const bool bgv = t > NativeInteger(0);  // BGV: the P part times -t^-1 before, the switched part times t after the conversion
         if (bgv && tInvModp.size() < sizeP)

@@ -17,6 +17,8 @@
 
 namespace lbcrypto {
 namespace hiprt {
+// rows of one tower / distinct moduli of one device context (csrc/ntt_kernels.h kMaxLimbs: the limb map of a launch is one byte per row)
+constexpr size_t kMaxDeviceLimbs = 256;
 
 // entry points of the C ABI the backend uses (resolved once with dlsym)
 struct Api {
@@ -207,7 +209,7 @@ struct Resolved {
     std::shared_ptr<CtxHolder> hold;         // keeps ctx (and its plans) alive for the duration of the operation
 };
 // registers the moduli of all sets (growing the context when new ones appear) and returns their context limbs; false when
-// the ring or a modulus is outside the device library's domain (N not 2^4..2^17, q >= 2^60, q != 1 mod 2N, > 128 limbs)
+// the ring or a modulus is outside the device library's domain (N not 2^4..2^17, q >= 2^60, q != 1 mod 2N, > 256 limbs)
 bool Resolve(uint32_t ringDim, const std::vector<LimbSet>& sets, Resolved* out);
 
 // ---- basis-conversion plans from the caller's (= the reference's CryptoParameters') tables, cached by content ----

@@ -17,6 +17,9 @@
 #include <omp.h>
 #endif
 
+/* scratch arrays of the per-coefficient loops: limbs of one tower (the reference has no bound; the tests go to 256) */
+#define ORC_MAX_LIMBS 256
+
 typedef unsigned __int128 u128;
 
 /* ------------------------------------------------------------------------------------------
@@ -617,7 +620,7 @@ void orc_approx_switch_crt_basis(const uint64_t* x, uint32_t sizeQ, uint32_t N, 
                                  const uint64_t* mu128, uint64_t* out) {
 #pragma omp parallel for
     for (uint32_t ri = 0; ri < N; ++ri) {
-        u128 sum[128];
+        u128 sum[ORC_MAX_LIMBS];
         for (uint32_t j = 0; j < sizeP; ++j)
             sum[j] = 0;
         for (uint32_t i = 0; i < sizeQ; ++i) {
@@ -642,7 +645,7 @@ void orc_switch_crt_basis(const uint64_t* x, uint32_t sizeQ, uint32_t N, const u
                           const uint64_t* p, const uint64_t* mu128, const double* qInv, uint64_t* out) {
 #pragma omp parallel for
     for (uint32_t ri = 0; ri < N; ++ri) {
-        uint64_t y[128];
+        uint64_t y[ORC_MAX_LIMBS];
         double nu = 0.5;
         for (uint32_t i = 0; i < sizeQ; ++i) {
             y[i] = orc_mod_mul_fast_const(x[(size_t)i * N + ri], QHatInvModq[i], q[i], QHatInvModqPrecon[i]);
@@ -685,7 +688,7 @@ uint32_t orc_hybrid_select_p(uint32_t N, uint32_t sizeQ, const uint64_t* q, uint
      * so multiply out in arbitrary precision (little-endian 64-bit limbs). */
     uint32_t maxBits = 0;
     for (uint32_t j = 0; j < numPartQ; ++j) {
-        uint64_t big[80];
+        uint64_t big[ORC_MAX_LIMBS + 16];
         uint32_t len = 1;
         big[0]       = 1;
         for (uint32_t i = a * j; i < (j + 1) * a && i < sizeQ; ++i) {
@@ -837,7 +840,7 @@ static uint32_t compl_basis(const orc_hybrid* h, uint32_t part, uint32_t sizeQl,
 /* [Q_part^(l)/q_i]_{c_j} over the complementary basis (:320-349) -> out[sizePartQl][sizeCompl] */
 uint32_t orc_hybrid_get_PartQlHatModp(const orc_hybrid* h, uint32_t part, uint32_t sizeQl, uint64_t* out,
                                       uint64_t* complModuli) {
-    uint32_t idx[128];
+    uint32_t idx[ORC_MAX_LIMBS];
     uint32_t nc    = compl_basis(h, part, sizeQl, idx);
     uint32_t sz    = part_size_at(h, part, sizeQl);
     uint32_t start = h->alpha * part;
@@ -865,7 +868,7 @@ uint32_t orc_hybrid_precompute_digits(const orc_hybrid* h, const uint64_t* c, ui
     for (uint32_t part = 0; part < np; ++part) {
         uint32_t sz    = part_size_at(h, part, sizeQl);
         uint32_t start = h->alpha * part;
-        uint32_t idx[128];
+        uint32_t idx[ORC_MAX_LIMBS];
         uint32_t nc = compl_basis(h, part, sizeQl, idx);
         /* partsCt = digit limbs of c, to COEFFICIENT */
         uint64_t* partsCt = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)sz * N);
@@ -873,7 +876,7 @@ uint32_t orc_hybrid_precompute_digits(const orc_hybrid* h, const uint64_t* c, ui
 #pragma omp parallel for
         for (uint32_t i = 0; i < sz; ++i)
             ctx_inv(h->ctx, partsCt + (size_t)i * N, start + i);
-        uint64_t hatInv[128], hatInvPre[128], cm[128], mu[256];
+        uint64_t hatInv[ORC_MAX_LIMBS], hatInvPre[ORC_MAX_LIMBS], cm[ORC_MAX_LIMBS], mu[2 * ORC_MAX_LIMBS];
         uint64_t* hatModp = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)sz * nc);
         orc_hybrid_get_PartQlHatInvModq(h, part, sizeQl, hatInv);
         for (uint32_t i = 0; i < sz; ++i)
@@ -1200,7 +1203,7 @@ void orc_rescale_tables(const orc_ctx* c, uint32_t sizeQl, uint64_t* QlQlInvModq
 /* dcrtpoly-impl.h:693-712, m_format == EVALUATION */
 void orc_drop_last_element_and_scale(const orc_ctx* c, const uint64_t* x, uint32_t sizeQl, uint64_t* out) {
     const uint32_t N = c->N, l = sizeQl - 1;
-    uint64_t tabA[128], tabB[128];
+    uint64_t tabA[ORC_MAX_LIMBS], tabB[ORC_MAX_LIMBS];
     orc_rescale_tables(c, sizeQl, tabA, tabB);
     uint64_t* last = (uint64_t*)malloc(sizeof(uint64_t) * N);
     memcpy(last, x + (size_t)l * N, sizeof(uint64_t) * N);
@@ -1363,7 +1366,7 @@ void orc_scale_and_round_native(const uint64_t* x, uint32_t sizeQ, uint32_t N, c
         nomod = pow2 ? (qMSB + sizeQMSB + tMSB < 63) : (qMSB + tMSB + sizeQMSB < 52);
     else
         nomod = pow2 ? (qMSBHf + tMSB + sizeQMSB < 62) : (qMSBHf + tMSB + sizeQMSB < 52);
-    uint64_t pre[128], preB[128];
+    uint64_t pre[ORC_MAX_LIMBS], preB[ORC_MAX_LIMBS];
     for (uint32_t i = 0; i < sizeQ; ++i) {
         pre[i]  = orc_prep_mod_mul_const(tabModt[i], t);
         preB[i] = tabBModt ? orc_prep_mod_mul_const(tabBModt[i], t) : 0;
@@ -1486,7 +1489,7 @@ orc_behz* orc_behz_create(uint32_t N, uint32_t numQ, const uint64_t* q, uint64_t
     uint64_t msk = orc_previous_prime(h->bsk[numB - 1], M);
     uint32_t s   = orc_get_msb(msk);
     {
-        uint64_t lhs[80], rhs[80];
+        uint64_t lhs[ORC_MAX_LIMBS + 16], rhs[ORC_MAX_LIMBS + 16];
         uint32_t ll, lr = 1;
         rhs[0] = 1;
         lr     = mp_mul_small(rhs, lr, M);
@@ -1603,7 +1606,7 @@ void orc_behz_q_to_bsk_montgomery(const orc_behz* h, const uint64_t* xq, uint64_
     const uint64_t mtilde = (uint64_t)1 << 16, half = mtilde >> 1, mask = mtilde - 1;
 #pragma omp parallel for
     for (uint32_t k = 0; k < N; ++k) {
-        uint64_t y[64];
+        uint64_t y[ORC_MAX_LIMBS];
         uint64_t rm = 0;
         for (uint32_t i = 0; i < numQ; ++i) {
             y[i] = orc_mod_mul_fast_const(xq[(size_t)i * N + k], h->mtQHatInv[i], h->q[i], h->mtQHatInvPre[i]);
@@ -1653,7 +1656,7 @@ void orc_behz_fast_base_conv_sk(const orc_behz* h, const uint64_t* x, uint64_t* 
     const uint64_t msk = h->bsk[numB], mskHalf = msk >> 1;
 #pragma omp parallel for
     for (uint32_t k = 0; k < N; ++k) {
-        uint64_t b[64];
+        uint64_t b[ORC_MAX_LIMBS];
         uint64_t alpha = 0;
         for (uint32_t i = 0; i < numB; ++i) {
             b[i] = orc_mod_mul_fast_const(x[(size_t)(numQ + i) * N + k], h->BHatInv[i], h->bsk[i], h->BHatInvPre[i]);

@@ -390,6 +390,75 @@ def test_context_argument_checks(backend, oracle):
         fh.Context(backend, 6, np.array([97, 193], np.uint64) * np.uint64(1 << 58), psi)
 
 
+@pytest.mark.parametrize("logN,L,B", [(5, 129, 2), (4, 256, 1), (12, 130, 1)])
+def test_towers_of_more_than_128_rows(backend, oracle, logN, L, B):
+    """One tower / one context with up to 256 limbs (round 6; the reference's UTBFVRNS TestMultiplicativeDepthLimitation reaches 129
+    distinct moduli in one operation, bfvrns-cryptoparameters.cpp:673-712): the limb map of a launch is one byte per row for 256 rows,
+    the by-value constant vector of Times(vector<Integer>) goes in windows of 128 rows (elemwise_kernels.h kConstVecLimbs)."""
+    o = oracle
+    rng = np.random.default_rng(1290 + L)
+    N = 1 << logN
+    q, psi = params(o, logN, L)
+    assert len(set(int(v) for v in q)) == L
+    ctx = fh.Context(backend, logN, q, psi)
+    octx = o.orc_ctx_create(N, L, q, psi)
+    x = libs.rand_tower(rng, q, N, B)
+    x[0, :, 0] = 0
+    x[0, :, 1] = q - np.uint64(1)
+    want = x.copy()
+    o.orc_ntt_fwd_tower(octx, want, None, L, B, 0)
+    t = ctx.tower(x, fmt=fh.COEFFICIENT)
+    t.SwitchFormat()
+    assert np.array_equal(t.to_host(), want), "forward NTT"
+    t.SwitchFormat()
+    assert np.array_equal(t.to_host(), x), "round trip"
+    # a selection of rows in another order than the context's (the map is what is being widened): the last 140 limbs, reversed
+    nSel = min(L, 140)
+    sel = np.arange(L - 1, L - 1 - nSel, -1).astype(np.uint32)
+    ys = libs.rand_tower(rng, q[sel], N, B)
+    wants = ys.copy()
+    o.orc_ntt_fwd_tower(octx, wants, sel.ctypes.data, nSel, B, 0)
+    ts = ctx.tower(ys, limb_idx=sel, fmt=fh.COEFFICIENT)
+    ts.SwitchFormat()
+    assert np.array_equal(ts.to_host(), wants), "forward NTT over a selection"
+    # element-wise members: tower (.) tower, and the per-limb constants in windows
+    a, b = libs.rand_tower(rng, q, N, B), libs.rand_tower(rng, q, N, B)
+    ta, tb = ctx.tower(a), ctx.tower(b)
+    for name, fn in (("Plus", o.orc_vec_add), ("Times", o.orc_vec_mul)):
+        w = np.empty_like(a)
+        for bb in range(B):
+            for l in range(L):
+                fn(w[bb, l], a[bb, l], b[bb, l], N, q[l])
+        assert np.array_equal(getattr(ta, name)(tb).to_host(), w), name
+    consts = rng.integers(1, 1 << 59, size=L, dtype=np.uint64) % q
+    w = np.empty_like(a)
+    for bb in range(B):
+        for l in range(L):
+            o.orc_vec_mul_const(w[bb, l], a[bb, l], consts[l], N, q[l])
+    assert np.array_equal(ta.Times(consts).to_host(), w), "Times(vector<Integer>)"
+    o.orc_ctx_destroy(octx)
+    # basis conversion into more than 128 target limbs (ExpandCRTBasis of a deep BFV parameter set: Q -> Q u Bsk)
+    nS = L // 2
+    nD = L - nS
+    src_idx, dst_idx = np.arange(nS, dtype=np.uint32), np.arange(nS, L, dtype=np.uint32)
+    src, dst = q[:nS], q[nS:]
+    hatInv, hatPre, hatMod, mu = conv_tables(o, src, dst)
+    xs = libs.rand_tower(rng, src, N, B)
+    conv = fh.Conv(ctx, src_idx, dst_idx)
+    wc = np.empty((B, nD, N), np.uint64)
+    for bb in range(B):
+        o.orc_approx_switch_crt_basis(xs[bb], nS, N, src, hatInv, hatPre, hatMod, nD, dst, mu, wc[bb])
+    assert np.array_equal(conv.run(ctx.tower(xs, limb_idx=src_idx, fmt=fh.COEFFICIENT)).to_host(), wc), "ApproxSwitchCRTBasis"
+    conv.close()
+    ctx.close()
+
+
+def test_context_of_more_than_256_limbs_is_refused(backend, oracle):
+    q, psi = params(oracle, 4, 257)
+    with pytest.raises(Exception, match="256"):
+        fh.Context(backend, 4, q, psi)
+
+
 def conv_tables(o, src, dst):
     """host tables exactly as the oracle's hybrid code derives them: hatInv[i], hatMod[i][j], mu128[j]"""
     nS, nD = len(src), len(dst)

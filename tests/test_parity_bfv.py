@@ -21,7 +21,9 @@ def mu128(o, mods):
 
 
 @pytest.mark.parametrize("logN,sizeI,sizeO,outputFirst,fscale,B",
-                         [(6, 3, 2, 1, 1.0, 2), (10, 4, 3, 0, 1.0, 1), (12, 3, 2, 1, 2.0 ** 60, 1), (12, 7, 8, 0, 1.0, 2)])
+                         [(6, 3, 2, 1, 1.0, 2), (10, 4, 3, 0, 1.0, 1), (12, 3, 2, 1, 2.0 ** 60, 1), (12, 7, 8, 0, 1.0, 2),
+                          # round 6: more than 64 limbs on either side (the deep BFV sets of TestMultiplicativeDepthLimitation: 65 + 64)
+                          (5, 65, 64, 0, 1.0, 1), (4, 70, 90, 1, 1.0, 1)])
 def test_scale_and_round(backend, oracle, logN, sizeI, sizeO, outputFirst, fscale, B):
     o = oracle
     N, L = 1 << logN, sizeI + sizeO
@@ -117,9 +119,11 @@ def behz_setup(lib, o, logN, numQ, t, bits=60):
 
 
 # (numQ = 15: the last size of the register-resident kernels; 16, 20, 40, 63: the wide plans of round 5 — deep BFV parameter sets, VERDICT r4
-# item 6 — with the y_i in a per-lane array; 63 Q + 64 Bsk limbs = 127 rows is the largest tower a context of 128 limbs holds)
+# item 6 — with the y_i in a per-lane array; 63 Q + 64 Bsk limbs = 127 rows was the largest tower a context of 128 limbs held)
 @pytest.mark.parametrize("logN,numQ,t,B", [(4, 2, 65537, 2), (10, 3, 65537, 2), (12, 6, 786433, 1), (5, 15, 65537, 2), (5, 16, 65537, 2),
-                                           (6, 20, 786433, 2), (5, 40, 65537, 1), (5, 63, 65537, 1)])
+                                           (6, 20, 786433, 2), (5, 40, 65537, 1), (5, 63, 65537, 1),
+                                           # round 6: 64 Q + 65 Bsk limbs = 129 rows (the case the reference's test reaches), and 100 + 101
+                                           (5, 64, 65537, 1), (4, 100, 65537, 1)])
 def test_behz_trio(backend, oracle, logN, numQ, t, B):
     o = oracle
     rng = np.random.default_rng(23)
