@@ -275,8 +275,28 @@ struct KsInnerMultiArgs {
     uint32_t logN, batch, sizeQl, sizeQ, sizeP, numDigits, alpha, nKeys;
     uint32_t nc[kMaxDigits];
 };
-// ND = compile-time bound of the number of digits (their residues live in registers)
-template <int ND>
+// ND = compile-time bound of the number of digits (their residues live in registers); CPL = adjacent coefficients per lane (2: 16-byte
+// accesses); PF: the next key's residues are loaded before the sums of this key are computed (software pipelining inside the wave)
+struct alignas(16) U64x2 {
+    uint64_t a, b;
+};
+template <int CPL>
+FHE_HD void ld_cpl(const uint64_t* p, uint64_t (&v)[CPL]) {
+    if constexpr (CPL == 2) {
+        const U64x2 w = *reinterpret_cast<const U64x2*>(p);
+        v[0] = w.a, v[1] = w.b;
+    }
+    else
+        v[0] = p[0];
+}
+template <int CPL>
+FHE_HD void st_cpl(uint64_t* p, const uint64_t (&v)[CPL]) {
+    if constexpr (CPL == 2)
+        *reinterpret_cast<U64x2*>(p) = U64x2{v[0], v[1]};
+    else
+        p[0] = v[0];
+}
+template <int ND, int CPL = 1, bool PF = true>
 FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ks_inner_multi_kernel(const KsInnerMultiArgs g) {
     const uint32_t t           = FHE_TID;
     const uint32_t tilesPerRow = (1u << g.logN) >> kTileLog ? ((1u << g.logN) >> kTileLog) : 1u;
@@ -303,6 +323,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ks_inner_multi_kernel(const KsInnerM
     const uint64_t ooff0 = ((uint64_t)b * sizeQlP + i) << g.logN;
     // where digit j's residues of this row live (wave-uniform): the digit's own limbs in the input c, the others in its ModUp buffer
     const uint64_t* src[ND];
+    uint64_t koffJ[ND];  // word offset of digit j's row inside a key element
 #pragma unroll
     for (int j = 0; j < ND; ++j) {
         const uint32_t jj    = (uint32_t)j < g.numDigits ? (uint32_t)j : g.numDigits - 1u;  // (padding re-reads the last digit; its products are skipped)
@@ -311,67 +332,88 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) ks_inner_multi_kernel(const KsInnerM
         const bool own       = i >= start && i < start + sz;
         const uint32_t pos   = i < start ? i : i - sz;
         src[j] = own ? g.c + (((uint64_t)b * g.sizeQl + i) << g.logN) : g.digits[jj] + (((uint64_t)b * g.nc[jj] + pos) << g.logN);
+        koffJ[j] = ((uint64_t)jj * (g.sizeQ + g.sizeP) + idx) << g.logN;
     }
     const uint64_t* firstRow = addFirst ? g.first + (((uint64_t)b * g.sizeQl + i) << g.logN) : nullptr;
-    for (uint32_t r = (tr << kTileLog) + t; r < rEnd; r += kThreads) {
-        uint64_t d[ND];
+    for (uint32_t r = (tr << kTileLog) + CPL * t; r < rEnd; r += CPL * kThreads) {
+        uint64_t d[ND][CPL];
 #pragma unroll
         for (int j = 0; j < ND; ++j)  // (all loads of the coefficient first, back to back: digits, c0, the first key's residues)
-            d[j] = src[j][r];
-        const uint64_t fraw = addFirst ? firstRow[r] : 0;
-        uint64_t kb[ND], ka[ND], nb[ND], na[ND];
+            ld_cpl<CPL>(src[j] + r, d[j]);
+        uint64_t fraw[CPL] = {};
+        if (addFirst)
+            ld_cpl<CPL>(firstRow + r, fraw);
+        uint64_t kb[ND][CPL], ka[ND][CPL], nb[ND][CPL], na[ND][CPL];
 #pragma unroll
         for (int j = 0; j < ND; ++j) {
-            const uint32_t jj   = (uint32_t)j < g.numDigits ? (uint32_t)j : g.numDigits - 1u;
-            const uint64_t koff = (((uint64_t)jj * (g.sizeQ + g.sizeP) + idx) << g.logN) + r;
-            kb[j] = g.keyB[0][koff], ka[j] = g.keyA[0][koff];
+            ld_cpl<CPL>(g.keyB[0] + koffJ[j] + r, kb[j]);
+            ld_cpl<CPL>(g.keyA[0] + koffJ[j] + r, ka[j]);
         }
 #pragma unroll
-        for (int j = 0; j < ND; ++j) {
-            uint64_t v = d[j];
-            if (redR != 255u)
-                v -= (uint64_t)((uint32_t)(((v >> 32) * redM) >> 32) >> redR) * q;
-            else {
-                v = csub(v, q << 3);
-                v = csub(v, q << 2);
-                v = csub(v, q << 1);
+        for (int j = 0; j < ND; ++j)
+#pragma unroll
+            for (int u = 0; u < CPL; ++u) {
+                uint64_t v = d[j][u];
+                if (redR != 255u)
+                    v -= (uint64_t)((uint32_t)(((v >> 32) * redM) >> 32) >> redR) * q;
+                else {
+                    v = csub(v, q << 3);
+                    v = csub(v, q << 2);
+                    v = csub(v, q << 1);
+                }
+                d[j][u] = csub(v, q);
             }
-            d[j] = csub(v, q);
-        }
-        const uint64_t f = addFirst ? mul_shoup(fraw, fc.w, fc.wp, q) : 0;
-        // the next key's residues are loaded before the sums of this key are computed (software pipelining: a wave's loads overlap its
-        // own arithmetic)
+        uint64_t f[CPL];
+#pragma unroll
+        for (int u = 0; u < CPL; ++u)
+            f[u] = addFirst ? mul_shoup(fraw[u], fc.w, fc.wp, q) : 0;
         for (uint32_t kk = 0; kk < g.nKeys; ++kk) {
-            if (kk + 1u < g.nKeys) {
-                const uint64_t* kB = g.keyB[kk + 1u];
-                const uint64_t* kA = g.keyA[kk + 1u];
+            if (PF) {
+                if (kk + 1u < g.nKeys) {
+                    const uint64_t* kB = g.keyB[kk + 1u];
+                    const uint64_t* kA = g.keyA[kk + 1u];
+#pragma unroll
+                    for (int j = 0; j < ND; ++j) {
+                        ld_cpl<CPL>(kB + koffJ[j] + r, nb[j]);
+                        ld_cpl<CPL>(kA + koffJ[j] + r, na[j]);
+                    }
+                }
+            }
+            else if (kk) {
+                const uint64_t* kB = g.keyB[kk];
+                const uint64_t* kA = g.keyA[kk];
 #pragma unroll
                 for (int j = 0; j < ND; ++j) {
-                    const uint32_t jj   = (uint32_t)j < g.numDigits ? (uint32_t)j : g.numDigits - 1u;
-                    const uint64_t koff = (((uint64_t)jj * (g.sizeQ + g.sizeP) + idx) << g.logN) + r;
-                    nb[j] = kB[koff], na[j] = kA[koff];
+                    ld_cpl<CPL>(kB + koffJ[j] + r, kb[j]);
+                    ld_cpl<CPL>(kA + koffJ[j] + r, ka[j]);
                 }
             }
-            sum8 s0, s1;
-            sum8_clear(s0);
-            sum8_clear(s1);
+            uint64_t v0[CPL], v1[CPL];
 #pragma unroll
-            for (int j = 0; j < ND; ++j)
-                if ((uint32_t)j < g.numDigits) {
-                    sum8_add(s0, d[j], kb[j]);
-                    sum8_add(s1, d[j], ka[j]);
-                }
-            uint64_t v0 = sum8_reduce(s0, q, lc.msb, mulo, muhi);
-            const uint64_t v1 = sum8_reduce(s1, q, lc.msb, mulo, muhi);
-            if (addFirst)
-                v0 = add_mod(v0, f, q);
-            if (kk + 1u < g.nKeys) {
+            for (int u = 0; u < CPL; ++u) {
+                sum8 s0, s1;
+                sum8_clear(s0);
+                sum8_clear(s1);
 #pragma unroll
                 for (int j = 0; j < ND; ++j)
-                    kb[j] = nb[j], ka[j] = na[j];
+                    if ((uint32_t)j < g.numDigits) {
+                        sum8_add(s0, d[j][u], kb[j][u]);
+                        sum8_add(s1, d[j][u], ka[j][u]);
+                    }
+                v0[u] = sum8_reduce(s0, q, lc.msb, mulo, muhi);
+                v1[u] = sum8_reduce(s1, q, lc.msb, mulo, muhi);
+                if (addFirst)
+                    v0[u] = add_mod(v0[u], f[u], q);
             }
-            g.out0[kk][ooff0 + r] = v0;
-            g.out1[kk][ooff0 + r] = v1;
+            if (PF && kk + 1u < g.nKeys) {
+#pragma unroll
+                for (int j = 0; j < ND; ++j)
+#pragma unroll
+                    for (int u = 0; u < CPL; ++u)
+                        kb[j][u] = nb[j][u], ka[j][u] = na[j][u];
+            }
+            st_cpl<CPL>(g.out0[kk] + ooff0 + r, v0);
+            st_cpl<CPL>(g.out1[kk] + ooff0 + r, v1);
         }
     }
 }
@@ -500,7 +542,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) bsgs_inner_kernel(const BsgsInnerArg
             const uint64_t* xp = g.rot + ((uint64_t)jj * rotStride + rotOff);  // uniform base + 32-bit lane offset
             const uint32_t kj  = g.k[jj];
 #pragma unroll
-            for (int u = 0; u < CPL; ++u)  // (the map permutes inside aligned blocks: a tile reads exactly one tile's cache lines)
+            for (int u = 0; u < CPL; ++u)  // (the map permutes inside aligned blocks: a wave reads exactly one 512-byte segment)
                 x[j][u] = xp[automorph_source(jb[u], kj, g.logN)];
         }
         const uint32_t lr = (l << g.logN) + r;  // word offset inside a plaintext: below 2^23
@@ -508,9 +550,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) bsgs_inner_kernel(const BsgsInnerArg
             const uint64_t* const* drow = g.diag + g.j0;
 #pragma unroll
             for (int j = 0; j < NIN; ++j)
-#pragma unroll
-                for (int u = 0; u < CPL; ++u)
-                    y[j][u] = (drow[j] + lr)[u];
+                ld_cpl<CPL>(drow[j] + lr, y[j]);
         }
         for (uint32_t i = 0; i < g.nOut; ++i) {
             {  // next outer step's plaintext residues (the last step re-reads its own: no branch around the loads)
@@ -518,9 +558,7 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) bsgs_inner_kernel(const BsgsInnerArg
                 const uint64_t* const* drow = g.diag + (uint64_t)in * g.nInPad + g.j0;
 #pragma unroll
                 for (int j = 0; j < NIN; ++j)
-#pragma unroll
-                    for (int u = 0; u < CPL; ++u)
-                        yn[j][u] = (drow[j] + lr)[u];
+                    ld_cpl<CPL>(drow[j] + lr, yn[j]);
             }
             uint64_t v[CPL] = {};
 #pragma unroll
@@ -537,9 +575,14 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) bsgs_inner_kernel(const BsgsInnerArg
                 }
             }
             uint64_t* op = g.out + (outOff + (uint64_t)i * outStride) + r;
+            if (g.accumulate) {
+                uint64_t ov[CPL];
+                ld_cpl<CPL>(op, ov);
 #pragma unroll
-            for (int u = 0; u < CPL; ++u)
-                op[u] = g.accumulate ? add_mod(op[u], v[u], lc.q) : v[u];
+                for (int u = 0; u < CPL; ++u)
+                    v[u] = add_mod(ov[u], v[u], lc.q);
+            }
+            st_cpl<CPL>(op, v);
 #pragma unroll
             for (int j = 0; j < NIN; ++j)
 #pragma unroll

@@ -2040,7 +2040,24 @@ static fhe_status ks_inner_multi_launch(fhe_ks_plan* p, fhe_ks_plan::Level* lv, 
         g.logN = c->logN, g.batch = batch, g.sizeQl = sizeQl, g.sizeQ = p->sizeQ, g.sizeP = sizeP;
         g.numDigits = lv->numParts, g.alpha = p->alpha, g.nKeys = nt;
         const uint64_t grid = (((uint64_t)tilesPerRow * sizeQlP + 7) / 8) * 8 * batch;
-        if (lv->numParts <= 3)
+        // three digits (the usual dnum): two adjacent coefficients per lane, 16-byte accesses — round 6: 1341 -> 1090 us per launch in the
+        // lockstep bootstrap, EvalMult composite +2-3 % (profiles/r06_sweeps.md 9).  FHE_KSM selects the other forms for A/B runs:
+        //   0 one coefficient per lane, next key prefetched (rounds 4-5) | 1 two per lane, prefetched (default) | 2 two per lane, no prefetch |
+        //   3 one per lane, no prefetch
+        static const uint32_t ksm = env_u32("FHE_KSM", 1);
+        uintptr_t bits = (uintptr_t)g.c | (uintptr_t)g.first;  // (16-byte accesses need 16-byte aligned towers: any device allocation is)
+        for (uint32_t j = 0; j < lv->numParts && j < (uint32_t)kMaxDigits; ++j)
+            bits |= (uintptr_t)g.digits[j];
+        for (uint32_t t = 0; t < nt; ++t)
+            bits |= (uintptr_t)g.keyB[t] | (uintptr_t)g.keyA[t] | (uintptr_t)g.out0[t] | (uintptr_t)g.out1[t];
+        const bool wide = (bits & 15u) == 0 && c->N >= 2;
+        if (lv->numParts <= 3 && ksm == 1 && wide)
+            FHE_LAUNCH((ks_inner_multi_kernel<3, 2, true>), grid, st, g);
+        else if (lv->numParts <= 3 && ksm == 2 && wide)
+            FHE_LAUNCH((ks_inner_multi_kernel<3, 2, false>), grid, st, g);
+        else if (lv->numParts <= 3 && ksm == 3)
+            FHE_LAUNCH((ks_inner_multi_kernel<3, 1, false>), grid, st, g);
+        else if (lv->numParts <= 3)
             FHE_LAUNCH((ks_inner_multi_kernel<3>), grid, st, g);
         else if (lv->numParts <= 4)
             FHE_LAUNCH((ks_inner_multi_kernel<4>), grid, st, g);

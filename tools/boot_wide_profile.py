@@ -127,6 +127,7 @@ def pmc(trace_csv, counter_csvs, cts, reps, out_json):
     import hashlib
     import json
     tot = {}
+    by_kernel = {}
     expected = int(os.environ["FHE_PMC_EXPECTED_LAUNCHES"]) if os.environ.get("FHE_PMC_EXPECTED_LAUNCHES") else None
     for path in counter_csvs:
         tr = path.replace("counter_collection.csv", "kernel_trace.csv")
@@ -144,10 +145,16 @@ def pmc(trace_csv, counter_csvs, cts, reps, out_json):
         mk = [i for i, r in enumerate(rows) if r[2] in names]
         if len(mk) >= 2:  # run()'s LAST two marker launches bracket the lockstep passes exactly (the narrow pass's first-use checks launch it too)
             tail = {d for _, _, d in rows[mk[-2] + 1:mk[-1]]}
+            dur = {d: e - s for s, e, d in rows[mk[-2] + 1:mk[-1]]}  # (kernels run one at a time under --pmc: stand-alone durations)
             with open(path, newline="") as f:
                 for r in csv.DictReader(f):
-                    if int(r["Dispatch_Id"]) in tail:
+                    d = int(r["Dispatch_Id"])
+                    if d in tail:
                         tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                        k = by_kernel.setdefault(r["Kernel_Name"], {})
+                        k[r["Counter_Name"]] = k.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                        k["calls_" + r["Counter_Name"]] = k.get("calls_" + r["Counter_Name"], 0) + 1
+                        k["ns_" + r["Counter_Name"]] = k.get("ns_" + r["Counter_Name"], 0) + dur.get(d, 0)
             tot["launches_" + os.path.basename(os.path.dirname(os.path.dirname(path)))] = len(tail)
             continue
         gaps = sorted(((rows[i + 1][0] - rows[i][1], i) for i in range(n // 4, n - 1)), reverse=True)
@@ -176,8 +183,72 @@ def pmc(trace_csv, counter_csvs, cts, reps, out_json):
                    "(the trace's tail), FETCH_SIZE x 2048 + WRITE_SIZE x 1024 bytes, per bootstrap",
            "kernel_source_sha": h.hexdigest()[:16], "bootstraps": n, "fetch_bytes_per_bootstrap": fetch / n, "write_bytes_per_bootstrap": write / n,
            "bytes_per_bootstrap": (fetch + write) / n, "detail": tot}
+    # per kernel: HBM bytes per launch and the rate over the kernel's stand-alone duration (serialised launches of the counter runs)
+    table = []
+    for nm, k in by_kernel.items():
+        fb, wb = k.get("FETCH_SIZE", 0.0) * 2048, k.get("WRITE_SIZE", 0.0) * 1024
+        calls = max(k.get("calls_FETCH_SIZE", 0), k.get("calls_WRITE_SIZE", 0))
+        ns = (k.get("ns_FETCH_SIZE", 0) + k.get("ns_WRITE_SIZE", 0)) / max(1, (1 if "ns_FETCH_SIZE" in k else 0) + (1 if "ns_WRITE_SIZE" in k else 0))
+        table.append({"kernel": nm[:110], "calls": calls, "ms_per_bootstrap": round(ns / 1e6 / n, 3), "GB_per_bootstrap": round((fb + wb) / 1e9 / n, 3),
+                      "fetch_MB_per_call": round(fb / 1e6 / max(1, calls), 2), "write_MB_per_call": round(wb / 1e6 / max(1, calls), 2),
+                      "HBM_GBps": round((fb + wb) / ns, 1) if ns else None})
+    table.sort(key=lambda r: -r["ms_per_bootstrap"])
+    out["by_kernel"] = table
     json.dump(out, open(out_json, "w"), indent=1)
-    print(json.dumps(out))
+    print(json.dumps({k: v for k, v in out.items() if k != "by_kernel"}))
+    for r in table[:24]:
+        print(f"{r['ms_per_bootstrap']:8.3f} ms  {r['GB_per_bootstrap']:7.3f} GB  {str(r['HBM_GBps']):>7} GB/s  {r['calls']:6d}  {r['kernel'][:90]}")
+
+
+def sq(counter_csv, cts, reps, out_json):
+    """per-kernel SQ counters of the lockstep passes (one rocprofv3 --pmc run with several SQ_* counters): VALU instructions per
+    launch, the share of wave-time spent issuing VALU work / waiting for memory, and VALU issue slots used per SIMD cycle of the kernel's
+    stand-alone duration (1024 SIMDs; a 64-lane VALU instruction occupies its SIMD for at least 4 cycles)"""
+    import json
+    tr = counter_csv.replace("counter_collection.csv", "kernel_trace.csv")
+    rows = []
+    with open(tr, newline="") as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Dispatch_Id"]), r["Kernel_Name"]))
+    rows.sort()
+    mk = [i for i, r in enumerate(rows) if MARKER in r[3]]
+    tailrows = rows[mk[-2] + 1:mk[-1]] if len(mk) >= 2 else rows
+    dur = {d: e - s for s, e, d, _ in tailrows}
+    per = {}
+    seen = {}
+    with open(counter_csv, newline="") as f:
+        for r in csv.DictReader(f):
+            d = int(r["Dispatch_Id"])
+            if d not in dur:
+                continue
+            k = per.setdefault(r["Kernel_Name"], defaultdict(float))
+            k[r["Counter_Name"]] += float(r["Counter_Value"])
+            if (d, 0) not in seen:
+                seen[(d, 0)] = 1
+                k["_calls"] += 1
+                k["_ns"] += dur[d]
+    n = (reps + 1) * cts
+    table = []
+    for nm, k in per.items():
+        ns, waves = k["_ns"], max(1.0, k.get("SQ_WAVES", 0.0))
+        table.append({"kernel": nm[:110], "calls": int(k["_calls"]), "ms_per_bootstrap": round(ns / 1e6 / n, 3),
+                      "valu_insts_per_wave": round(k.get("SQ_INSTS_VALU", 0.0) / waves, 1),
+                      "valu_issue_ns_per_inst_per_simd": round(ns * 1024 / max(1.0, k.get("SQ_INSTS_VALU", 0.0)), 2),
+                      "valu_active_share_of_wave_cycles": round(k.get("SQ_ACTIVE_INST_VALU", 0.0) / max(1.0, k.get("SQ_WAVE_CYCLES", 0.0)), 4),
+                      "wait_inst_share_of_wave_cycles": round(k.get("SQ_WAIT_INST_ANY", 0.0) / max(1.0, k.get("SQ_WAVE_CYCLES", 0.0)), 4),
+                      "waves_resident_per_simd": round(k.get("SQ_WAVE_CYCLES", 0.0) / max(1.0, k.get("SQ_BUSY_CYCLES", 0.0)) / 4.0, 2),
+                      "raw": {c: v for c, v in k.items() if not c.startswith("_")}})
+    table.sort(key=lambda r: -r["ms_per_bootstrap"])
+    json.dump({"_how": "rocprofv3 --kernel-trace --pmc SQ_* on `tools/boot_wide_profile.py run` (one host thread): launches of the lockstep passes, by kernel",
+               "bootstraps": n, "by_kernel": table}, open(out_json, "w"), indent=1)
+    if not any("SQ_INSTS_VALU" in r["raw"] for r in table):  # another counter set: per call and per second
+        for r in table[:12]:
+            ns = r["ms_per_bootstrap"] * 1e6 * n
+            print(f"{r['ms_per_bootstrap']:7.3f} ms  " + "  ".join(f"{c} {v / max(1, r['calls']):.4g}/call {v / ns:.3f}/ns" for c, v in sorted(r["raw"].items())) + f"  {r['kernel'][:50]}")
+        return
+    for r in table[:16]:
+        print(f"{r['ms_per_bootstrap']:7.3f} ms {r['valu_insts_per_wave']:8.1f} VALU/wave {r['valu_issue_ns_per_inst_per_simd']:6.2f} ns/inst/SIMD "
+              f"valu {r['valu_active_share_of_wave_cycles']:.3f} wait {r['wait_inst_share_of_wave_cycles']:.3f} waves/SIMD {r['waves_resident_per_simd']:5.2f}  {r['kernel'][:70]}")
 
 
 if __name__ == "__main__":
@@ -185,6 +256,8 @@ if __name__ == "__main__":
         sweep(int(sys.argv[2]), [tuple(int(v) for v in a.split("x")) for a in sys.argv[3:]])
     elif sys.argv[1] == "pmc":  # pmc <out.json> <cts> <reps> <counter_collection.csv>...
         pmc(None, sys.argv[5:], int(sys.argv[3]), int(sys.argv[4]), sys.argv[2])
+    elif sys.argv[1] == "sq":  # sq <out.json> <cts> <reps> <counter_collection.csv>
+        sq(sys.argv[5], int(sys.argv[3]), int(sys.argv[4]), sys.argv[2])
     elif sys.argv[1] == "run":
         run(int(sys.argv[2]) if len(sys.argv) > 2 else 32, int(sys.argv[3]) if len(sys.argv) > 3 else 32, int(sys.argv[4]) if len(sys.argv) > 4 else 2,
             int(sys.argv[5]) if len(sys.argv) > 5 else 1, int(sys.argv[6]) if len(sys.argv) > 6 else 8)

@@ -93,6 +93,18 @@ PY
     done
     cd $G
     python tools/boot_wide_profile.py pmc gpurun_out/${R}_bootstrap_pmc.json 64 2 $(ls -t $D/boot_${R}_FETCH_SIZE/*/*counter_collection.csv | head -1) $(ls -t $D/boot_${R}_WRITE_SIZE/*/*counter_collection.csv | head -1) | cut -c1-600 ;;
+  bootsq)  # SQ counters of the lockstep bootstrap by kernel (one host thread, as bootpmc)
+    R=${1:-r06}; G=$GRAFT_REPO_ROOT; D=/tmp/rec; mkdir -p $D
+    cd /tmp && export TMPDIR=/tmp
+    SQ=${FHE_BOOT_COUNTERS:-"SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_WAVES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY"}
+    for try in 1 2 3; do
+      rm -rf $D/boot_${R}_sq
+      timeout 1200 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $D/boot_${R}_sq -- python $G/tools/boot_wide_profile.py run 64 16 2 1 1 > $D/boot_${R}_sq.log 2>&1 && break
+      echo "SQ pass failed (try $try)"
+    done
+    tail -1 $D/boot_${R}_sq.log | cut -c1-200
+    cd $G
+    python tools/boot_wide_profile.py sq gpurun_out/${R}_bootstrap_${2:-sq}.json 64 2 $(ls -t $D/boot_${R}_sq/*/*counter_collection.csv | head -1) ;;
   abl)   # timing-only ablation builds of the library (tools/abl6/*.so, built here with -DFHE_ABL_*; results are wrong: --no-parity)
     for lib in "" "$@"; do
       name=${lib:-default}
