@@ -57,6 +57,10 @@ PY
     echo "== bootstrap (64 ciphertexts, groups of 16 on 2 host threads): census, then FETCH / WRITE passes"
     timeout 900 rocprofv3 --kernel-trace --output-format csv -d $D/boot_${R}_trace -- python $G/tools/boot_wide_profile.py run 64 16 2 2 > $D/boot_${R}_trace.log 2>&1
     tail -1 $D/boot_${R}_trace.log
+    if ! ls $D/boot_${R}_trace/*/*kernel_trace.csv > /dev/null 2>&1; then  # (rocprofv3 crashes on the two-thread program in some runs: one host thread, same launches)
+      timeout 900 rocprofv3 --kernel-trace --output-format csv -d $D/boot_${R}_trace -- python $G/tools/boot_wide_profile.py run 64 16 2 1 1 > $D/boot_${R}_trace.log 2>&1
+      tail -1 $D/boot_${R}_trace.log
+    fi
     f=$(ls -t $D/boot_${R}_trace/*/*kernel_trace.csv | head -1)
     (echo "# rocprofv3 --kernel-trace of \`tools/boot_wide_profile.py run 64 16 2 2\` (round record: 64 ciphertexts at config 4's shape, lockstep groups of 16 on 2 host threads — bench.py's setting — 3 passes)"; tail -1 $D/boot_${R}_trace.log; python $G/tools/boot_wide_profile.py summarise $f 64 2) > $G/gpurun_out/${R}_bootstrap_wide_kernels.txt
     head -16 $G/gpurun_out/${R}_bootstrap_wide_kernels.txt | cut -c1-150
@@ -93,6 +97,13 @@ PY
     done
     cd $G
     python tools/boot_wide_profile.py pmc gpurun_out/${R}_bootstrap_pmc.json 64 2 $(ls -t $D/boot_${R}_FETCH_SIZE/*/*counter_collection.csv | head -1) $(ls -t $D/boot_${R}_WRITE_SIZE/*/*counter_collection.csv | head -1) | cut -c1-600 ;;
+  census)  # kernel census of the lockstep bootstrap alone (one host thread)
+    R=${1:-r06}; G=$GRAFT_REPO_ROOT; D=/tmp/rec; mkdir -p $D
+    cd /tmp && export TMPDIR=/tmp
+    timeout 900 rocprofv3 --kernel-trace --output-format csv -d $D/boot_${R}_trace -- python $G/tools/boot_wide_profile.py run 64 16 2 1 1 > $D/boot_${R}_trace.log 2>&1
+    f=$(ls -t $D/boot_${R}_trace/*/*kernel_trace.csv | head -1)
+    (echo "# rocprofv3 --kernel-trace of \`tools/boot_wide_profile.py run 64 16 2 1 1\` (64 ciphertexts at config 4's shape, lockstep groups of 16, ONE host thread — rocprofv3 crashes on the two-thread program in some runs; same launches — 3 passes)"; tail -1 $D/boot_${R}_trace.log; python $G/tools/boot_wide_profile.py summarise $f 64 2) > $G/gpurun_out/${R}_bootstrap_wide_kernels.txt
+    head -30 $G/gpurun_out/${R}_bootstrap_wide_kernels.txt | cut -c1-150 ;;
   bootsq)  # SQ counters of the lockstep bootstrap by kernel (one host thread, as bootpmc)
     R=${1:-r06}; G=$GRAFT_REPO_ROOT; D=/tmp/rec; mkdir -p $D
     cd /tmp && export TMPDIR=/tmp
