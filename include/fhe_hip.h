@@ -212,6 +212,15 @@ fhe_status fhe_switch_modulus(fhe_ctx* ctx, uint64_t* out, const uint32_t* limbI
  * used by FHECKKSRNS::EvalBootstrap, ckksrns-fhe.cpp:592-601): one COEFFICIENT polynomial modulo q_0 lifted, centred, into
  * every limb of a tower. */
 
+/* DCRTPolyImpl::CRTDecompose(baseBits) (dcrtpoly-impl.h:230-285; KeySwitchBV's digit decomposition, keyswitch-bv.cpp:254): x [nLimbs][N] in
+ * COEFFICIENT format -> out [towers][nLimbs][N] in EVALUATION format, towers in the reference's order (limb 0's digits, least significant
+ * first, then limb 1's ...; baseBits == 0: one tower per limb).  fhe_crt_decompose_towers returns the number of towers, 0 when the
+ * selection is outside the device path (baseBits > 31, or a window that would leave the 64-bit word — where the reference itself is
+ * undefined). */
+uint32_t fhe_crt_decompose_towers(const fhe_ctx* ctx, const uint32_t* limbIdx, uint32_t nLimbs, uint32_t baseBits);
+fhe_status fhe_crt_decompose(fhe_ctx* ctx, const uint64_t* x, const uint32_t* limbIdx, uint32_t nLimbs, uint32_t baseBits, uint64_t* out,
+                             void* stream);
+
 /* ---- a10/a16: CRT basis conversion ------------------------------------------------------------------
  * fhe_conv_create builds the device tables for converting from the basis {srcLimbIdx} to {dstLimbIdx}
  * (context limbs). The table VALUES are computed by the library the way CryptoParametersRNS /

@@ -390,6 +390,38 @@ FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) switch_modulus_kernel(const SwitchMo
     }
 }
 
+// ---- DCRTPolyImpl::CRTDecompose (dcrtpoly-impl.h:230-285; the digit decomposition of KeySwitchBV): the nW digits of ONE source limb,
+// each lifted (centred, PolyImpl::SwitchModulus) into every limb of its own tower; COEFFICIENT in, COEFFICIENT out (the caller
+// transforms all towers in one launch).  Digit w of a word = its bits [w * baseBits, (w + 1) * baseBits) (PolyImpl::BaseDecompose,
+// poly-impl.h:524-547 -> GetDigitAtIndexForBase, ubintnat.h:1721-1729); baseBits == 0: the word itself, one tower (:237-251).
+struct CrtDigitsArgs {
+    uint64_t* out;        // [nW][nLimbs][N]: the towers of this source limb
+    const uint64_t* src;  // [N]: the source limb
+    const uint64_t* q;    // [ctxLimbs]
+    uint32_t logN, nLimbs, nW, baseBits, srcPos, srcCtxLimb;
+    LimbSel sel;
+};
+FHE_GLOBAL void FHE_LAUNCH_BOUNDS(kThreads) crt_digits_kernel(const CrtDigitsArgs g) {
+    const uint32_t t          = FHE_TID;
+    const uint64_t base       = (uint64_t)FHE_BID << kTileLog;
+    const uint64_t totalWords = ((uint64_t)g.nW * g.nLimbs) << g.logN;
+    const uint32_t mask       = (1u << g.logN) - 1u;
+    const uint64_t qs = g.q[g.srcCtxLimb], halfQ = qs >> 1;
+    const uint64_t dmask = g.baseBits ? (((uint64_t)1 << g.baseBits) - 1u) : ~(uint64_t)0;
+#pragma unroll 4
+    for (int m = 0; m < 16; ++m) {
+        const uint64_t off = base + (uint64_t)m * kThreads + t;
+        if (off >= totalWords)
+            continue;
+        const uint32_t row = (uint32_t)(off >> g.logN);
+        const uint32_t w = row / g.nLimbs, k = row % g.nLimbs;
+        uint64_t v = (g.src[(uint32_t)off & mask] >> (w * g.baseBits)) & dmask;  // (w * baseBits < 64: checked by the host)
+        if (k != g.srcPos)
+            v = switch_modulus_word(v, qs, halfQ, g.q[g.sel.idx[k]]);
+        g.out[off] = v;
+    }
+}
+
 // ---- DCRTPolyImpl::SetValuesModSwitch (dcrtpoly-impl.h:630-647): one COEFFICIENT limb modulo qFrom scaled to a modulus qTo through
 // double precision, out[j] = uint64(floor(0.5 + double(x[j]) * (double(qTo) / double(qFrom)))) mod qTo — the reference's expression,
 // one rounding per operation (no contraction: the library is compiled with -ffp-contract=off)

@@ -1371,6 +1371,51 @@ extern "C" fhe_status fhe_switch_modulus(fhe_ctx* c, uint64_t* out, const uint32
     return switch_modulus_run(c, out, sel, nl, src, srcLimbs, srcPos, srcCtxLimb, nullptr, bt, st);
 }
 
+// DCRTPolyImpl::CRTDecompose(baseBits) (dcrtpoly-impl.h:230-285): x [nLimbs][N] COEFFICIENT -> out [towers][nLimbs][N] EVALUATION, towers in the
+// reference's order (limb 0's digits, least significant first, then limb 1's ...).  One launch per source limb, ONE transform over all towers.
+static uint32_t crt_windows(const fhe_ctx* c, uint32_t limb, uint32_t baseBits) {
+    if (baseBits == 0)
+        return 1;
+    const uint32_t nBits = host::bitlen(c->q[limb]);
+    return nBits / baseBits + (nBits % baseBits != 0);
+}
+extern "C" uint32_t fhe_crt_decompose_towers(const fhe_ctx* c, const uint32_t* li, uint32_t nl, uint32_t baseBits) {
+    if (!c || nl < 1 || nl > (uint32_t)kMaxLimbs || baseBits > 31)  // (the reference's base is `1 << baseBits` in 32 bits)
+        return 0;
+    uint32_t towers = 0;
+    for (uint32_t i = 0; i < nl; ++i) {
+        const uint32_t l = li ? li[i] : i;
+        if (l >= c->L)
+            return 0;
+        const uint32_t nW = crt_windows(c, l, baseBits);
+        if ((uint64_t)nW * baseBits > 64)  // (the reference reads bits beyond the word there: undefined, left to the caller's host path)
+            return 0;
+        towers += nW;
+    }
+    return towers;
+}
+extern "C" fhe_status fhe_crt_decompose(fhe_ctx* c, const uint64_t* x, const uint32_t* li, uint32_t nl, uint32_t baseBits, uint64_t* out,
+                                        void* st) {
+    ARG_CHECK(c && x && out, "fhe_crt_decompose: null argument");
+    const uint32_t towers = fhe_crt_decompose_towers(c, li, nl, baseBits);
+    ARG_CHECK(towers >= 1, "fhe_crt_decompose: limb selection or digit size outside the device path (baseBits <= 31, every window inside the word)");
+    CrtDigitsArgs g;
+    if (fhe_status s = make_sel(c, li, nl, &g.sel, "fhe_crt_decompose"))
+        return s;
+    RT_CHECK(rt::set_device(c->device));
+    g.q = c->d_q, g.logN = c->logN, g.nLimbs = nl, g.baseBits = baseBits;
+    uint32_t t0 = 0;
+    for (uint32_t i = 0; i < nl; ++i) {
+        const uint32_t l = li ? li[i] : i;
+        g.nW = crt_windows(c, l, baseBits), g.srcPos = i, g.srcCtxLimb = l;
+        g.src = x + ((size_t)i << c->logN), g.out = out + (((size_t)t0 * nl) << c->logN);
+        FHE_LAUNCH(crt_digits_kernel, tiles_for(c, (uint64_t)g.nW * nl), st, g);
+        LAUNCH_CHECK();
+        t0 += g.nW;
+    }
+    return fhe_ntt_fwd(c, out, li, nl, towers, st);
+}
+
 // ---- f3: sampled towers on the device (sampler_kernels.h) ----------------------------------------------------------------------
 static fhe_status sample_run(fhe_ctx* c, uint64_t* out, const uint32_t* li, uint32_t nl, uint32_t bt, uint32_t kind, double sigma,
                              uint64_t seed, uint32_t streamId, void* st, const char* who) {

@@ -96,6 +96,8 @@ class Lib:
         S("fhe_tensor", C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, u32p, u32, u32, vp])
         S("fhe_automorph", C.c_int, [vp, vp, vp, u32, C.c_int, u32p, u32, u32, vp])
         S("fhe_switch_modulus", C.c_int, [vp, vp, u32p, u32, vp, u32, u32, u32, u32, vp])
+        S("fhe_crt_decompose_towers", u32, [vp, u32p, u32, u32])
+        S("fhe_crt_decompose", C.c_int, [vp, vp, u32p, u32, u32, vp, vp])
         S("fhe_event_create", C.c_int, [vp, C.POINTER(vp)])
         S("fhe_event_record", C.c_int, [vp, vp, vp])
         S("fhe_stream_wait_event", C.c_int, [vp, vp, vp])
@@ -378,6 +380,22 @@ class Tower:
         if fmt != self.fmt:
             self.SwitchFormat(stream)
         return self
+
+    # DCRTPolyImpl::CRTDecompose(baseBits) (dcrtpoly-impl.h:230-285): the towers of KeySwitchBV's digit decomposition, EVALUATION format,
+    # as ONE batch [towers][nLimbs][N] (batch must be 1; None when the digit size is outside the device path)
+    def CRTDecompose(self, base_bits, stream=None):
+        assert self.batch == 1
+        L, c = self.ctx.lib, self.ctx
+        towers = L.L.fhe_crt_decompose_towers(c.h, self._li(), self.n_limbs, base_bits)
+        if towers == 0:
+            return None
+        src = self
+        if self.fmt == EVALUATION:  # (:231-233: the coefficient copy)
+            src = c.empty(1, self.n_limbs, self.limb_idx, COEFFICIENT)
+            L.check(L.L.fhe_ntt_inv_oop(c.h, self.ptr, src.ptr, self._li(), self.n_limbs, 1, stream))
+        out = c.empty(towers, self.n_limbs, self.limb_idx, EVALUATION)
+        L.check(L.L.fhe_crt_decompose(c.h, src.ptr, self._li(), self.n_limbs, base_bits, out.ptr, stream))
+        return out
 
     def _bin(self, fn, other, stream):
         out = self.like()

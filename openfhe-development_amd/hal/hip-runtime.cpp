@@ -165,7 +165,8 @@ Runtime* build() {
                   FHE_SYM(neg, fhe_neg) && FHE_SYM(mul_add, fhe_mul_add) && FHE_SYM(mul_const, fhe_mul_const) && FHE_SYM(mult_acc, fhe_mult_acc) &&
                   FHE_SYM(add_const, fhe_add_const) && FHE_SYM(sub_const, fhe_sub_const) && FHE_SYM(times_q_over_t, fhe_times_q_over_t) &&
                   FHE_SYM(mod_switch_round, fhe_mod_switch_round) && FHE_SYM(automorph, fhe_automorph) &&
-                  FHE_SYM(switch_modulus, fhe_switch_modulus) && FHE_SYM(rescale_limbs, fhe_rescale_limbs) &&
+                  FHE_SYM(switch_modulus, fhe_switch_modulus) && FHE_SYM(crt_decompose_towers, fhe_crt_decompose_towers) &&
+                  FHE_SYM(crt_decompose, fhe_crt_decompose) && FHE_SYM(rescale_limbs, fhe_rescale_limbs) &&
                   FHE_SYM(event_create, fhe_event_create) && FHE_SYM(event_record, fhe_event_record) && FHE_SYM(stream_wait_event, fhe_stream_wait_event) &&
                   FHE_SYM(event_destroy, fhe_event_destroy) && FHE_SYM(sample_uniform, fhe_sample_uniform) && FHE_SYM(sample_gaussian, fhe_sample_gaussian) && FHE_SYM(sample_ternary, fhe_sample_ternary) &&
                   FHE_SYM(rescale_limbs_pair, fhe_rescale_limbs_pair) && FHE_SYM(add_pair, fhe_add_pair) && FHE_SYM(sub_pair, fhe_sub_pair) &&

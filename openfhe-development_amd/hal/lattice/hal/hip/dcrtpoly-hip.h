@@ -299,9 +299,41 @@ public:
         FHE_HAL_MEMBER();
         return WrapAll(Hc().PowersOfBase(baseBits));
     }
+    // dcrtpoly-impl.h:230-285 (the digit decomposition of KeySwitchBV): one launch per source limb cuts its digits and lifts each into every
+    // limb of its tower, one transform takes all towers to EVALUATION (fhe_crt_decompose); the result towers are windows of one buffer
     std::vector<DCRTPolyType> CRTDecompose(uint32_t baseBits) const {
         FHE_HAL_MEMBER();
+        std::vector<DCRTPolyType> out;
+        if (CRTDecomposeOnDevice(baseBits, &out))
+            return out;
         return WrapAll(Hc().CRTDecompose(baseBits));
+    }
+    bool CRTDecomposeOnDevice(uint32_t baseBits, std::vector<DCRTPolyType>* out) const {
+        const auto& P = m_h.GetParams();
+        if (!hiprt::Available() || m_k != 1 || !P || NumLimbs() == 0 || NumLimbs() != P->GetParams().size())
+            return false;
+        hiprt::Resolved r;
+        if (!ResolveSets(P->GetRingDimension(), {P}, &r) || !Upload())
+            return false;
+        const uint32_t L      = NumLimbs();
+        const size_t N        = P->GetRingDimension();
+        const uint32_t towers = hiprt::api().crt_decompose_towers(r.ctx, r.idx[0].data(), L, baseBits);
+        if (towers == 0)
+            return false;  // (a digit size the library leaves to the host: windows beyond the 64-bit word)
+        hiprt::Op op;
+        hiprt::Buf coef = m_d;
+        if (m_h.GetFormat() != Format::COEFFICIENT) {  // (:231-233: the coefficient copy)
+            coef = hiprt::Alloc((size_t)L * N);
+            hiprt::Check(hiprt::api().ntt_inv_oop(r.ctx, op.R(m_d), op.W(coef), r.idx[0].data(), L, 1, op.s), "CRTDecompose");
+        }
+        auto all = hiprt::Alloc((size_t)towers * L * N);
+        hiprt::Check(hiprt::api().crt_decompose(r.ctx, op.R(coef), r.idx[0].data(), L, baseBits, op.W(all), op.s), "CRTDecompose");
+        out->clear();
+        out->reserve(towers);
+        for (uint32_t t = 0; t < towers; ++t)  // (windows of the one allocation, as the towers of a wide evaluation: copy-on-write covers them)
+            out->push_back(FromDevice(P, Format::EVALUATION, hiprt::View(all, (size_t)t * L * N, (size_t)L * N)));
+        hiprt::CountDevice();
+        return true;
     }
 
     // dcrtpoly-impl.h:314-333 -> poly-impl.h:310-376 (EVALUATION: gather through PrecomputeAutoMap, COEFFICIENT: signed permutation)

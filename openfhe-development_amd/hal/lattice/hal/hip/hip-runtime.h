@@ -53,6 +53,8 @@ struct Api {
     decltype(&fhe_mod_switch_round) mod_switch_round;
     decltype(&fhe_automorph) automorph;
     decltype(&fhe_switch_modulus) switch_modulus;
+    decltype(&fhe_crt_decompose_towers) crt_decompose_towers;
+    decltype(&fhe_crt_decompose) crt_decompose;
     decltype(&fhe_event_create) event_create;        // completion marks of cached buffers (Alloc)
     decltype(&fhe_event_record) event_record;
     decltype(&fhe_stream_wait_event) stream_wait_event;

@@ -1816,6 +1816,45 @@ void orc_mod_raise(const uint64_t* x, uint32_t N, const uint64_t* q, uint32_t nL
     }
 }
 
+/* DCRTPolyImpl::CRTDecompose(baseBits) (dcrtpoly-impl.h:230-285; the digit decomposition of KeySwitchBV, keyswitch-bv.cpp:254).
+ * x [nLimbs][N] in COEFFICIENT format.  baseBits == 0 (:237-251): tower i of the result = limb i of x switched (centred,
+ * PolyImpl::SwitchModulus) into every other modulus, limb i itself kept, EVALUATION.  baseBits > 0 (:254-284): limb i is cut into
+ * ceil(msb(q_i) / baseBits) digits of baseBits bits (PolyImpl::BaseDecompose, poly-impl.h:524-547 -> GetDigitAtIndexForBase,
+ * ubintnat.h:1721-1729: bit by bit, least significant digit first), every digit switched into every other modulus, then SwitchFormat;
+ * towers in the order (limb 0's digits, limb 1's digits, ...).  Returns the number of towers; out (may be null: count only)
+ * [towers][nLimbs][N] EVALUATION. */
+uint32_t orc_crt_decompose(const orc_ctx* c, const uint64_t* x, uint32_t nLimbs, uint32_t baseBits, uint64_t* out) {
+    const uint32_t N = c->N;
+    uint32_t towers = 0;
+    for (uint32_t i = 0; i < nLimbs; ++i) {
+        const uint32_t nBits = orc_get_msb(c->q[i]);
+        const uint32_t nW = baseBits == 0 ? 1 : (nBits / baseBits + (nBits % baseBits != 0));
+        for (uint32_t w = 0; w < nW && out; ++w) {
+            uint64_t* T = out + (size_t)(towers + w) * nLimbs * N;
+            for (uint32_t k = 0; k < nLimbs; ++k) {
+                uint64_t* row = T + (size_t)k * N;
+                for (uint32_t r = 0; r < N; ++r) {
+                    const uint64_t v = x[(size_t)i * N + r];
+                    if (baseBits == 0)
+                        row[r] = v;
+                    else {
+                        uint64_t digit = 0; /* GetDigitAtIndexForBase(w + 1, 1 << baseBits): bits newIndex .. of the value, 1-based */
+                        uint32_t newIndex = 1 + w * baseBits;
+                        for (uint64_t b = 1; b < ((uint64_t)1 << baseBits); b <<= 1, ++newIndex)
+                            digit += ((v >> (newIndex - 1)) & 1u) * b; /* (newIndex - 1 < 64 for every window the callers ask for) */
+                        row[r] = digit;
+                    }
+                }
+                if (k != i)
+                    orc_switch_modulus(row, N, c->q[i], c->q[k]);
+            }
+            orc_ntt_fwd_tower(c, T, NULL, nLimbs, 1, 0);
+        }
+        towers += nW;
+    }
+    return towers;
+}
+
 /* DCRTPolyImpl::FastExpandCRTBasisPloverQ (dcrtpoly-impl.h:1151-1164), COEFFICIENT: x [nQ][N] over Q ->
  * out [(nQl+nPl)][N] = [Ql | Pl]; tables named as in CRTBasisExtensionPrecomputations. */
 void orc_fast_expand_crt_basis_p_over_q(const uint64_t* x, uint32_t nQ, uint32_t N, const uint64_t* q,

@@ -130,6 +130,7 @@ void orc_eval_square_core(const uint64_t* a0, const uint64_t* a1, uint32_t nLimb
                           uint64_t* d1, uint64_t* d2);
 /* ModRaise constructor DCRTPolyImpl(const PolyType&, params) (dcrtpoly-impl.h:87-93) */
 void orc_mod_raise(const uint64_t* x, uint32_t N, const uint64_t* q, uint32_t nLimbs, uint64_t* out);
+uint32_t orc_crt_decompose(const orc_ctx* c, const uint64_t* x, uint32_t nLimbs, uint32_t baseBits, uint64_t* out);
 typedef struct orc_hybrid orc_hybrid;
 /* Q tower (sizeQ limbs) + P tower (sizeP limbs) given explicitly; numPartQ = dnum. */
 orc_hybrid* orc_hybrid_create(uint32_t N, uint32_t sizeQ, const uint64_t* q, const uint64_t* psiQ,

@@ -315,6 +315,17 @@ void ref_mod_raise(uint32_t N, uint32_t L, const uint64_t* q, const uint64_t* ps
     DCRTPoly X(e, pq);
     export_poly(X, out);
 }
+// DCRTPolyImpl::CRTDecompose(baseBits) (dcrtpoly-impl.h:230-285): x [L][N] in the given format; out [towers][L][N] (EVALUATION), returns the
+// number of towers
+uint32_t ref_crt_decompose(uint32_t N, uint32_t L, const uint64_t* q, const uint64_t* psi, const uint64_t* x, int inEval, uint32_t baseBits,
+                           uint64_t* out) {
+    auto pq = make_params(N, L, q, psi);
+    DCRTPoly X = make_poly(pq, x, inEval ? Format::EVALUATION : Format::COEFFICIENT);
+    auto R     = X.CRTDecompose(baseBits);
+    for (size_t t = 0; t < R.size() && out; ++t)
+        export_poly(R[t], out + t * (size_t)L * N);
+    return (uint32_t)R.size();
+}
 // FastExpandCRTBasisPloverQ (COEFFICIENT): qInvModp [sizeQ][sizePl]; PlHatModq_qp [sizeQl][sizePl]; alphaPlModq
 // [sizePl+1][sizeQl]; out [(sizeQl+sizePl)][N]
 void ref_fast_expand_crt_basis_p_over_q(uint32_t N, uint32_t sizeQ, const uint64_t* q, const uint64_t* psiQ, const uint64_t* x,

@@ -133,6 +133,7 @@ def load_oracle():
     S("orc_expand_crt_basis_ql_hat", None, [P64, u32, u32, P64, P64, u32, P64])
     S("orc_eval_square_core", None, [P64, P64, u32, u32, P64, P64, P64, P64])
     S("orc_mod_raise", None, [P64, u32, P64, u32, P64])
+    S("orc_crt_decompose", u32, [vp, vp, u32, u32, vp])
     _oracle = L
     return L
 
@@ -230,6 +231,7 @@ def load_ref():
     S("ref_mult_acc", None, [u32, u32, P64, P64, P64, P64, P64])
     S("ref_plus_minus_const", None, [u32, u32, P64, P64, P64, P64, C.c_int, C.c_int, P64])
     S("ref_mod_raise", None, [u32, u32, P64, P64, P64, P64])
+    S("ref_crt_decompose", u32, [u32, u32, P64, P64, P64, C.c_int, u32, vp])
     S("ref_ckks_eval_square_no_relin", C.c_int, [vp, C.c_int])
     S("ref_bfv_create", vp, [u32, u64, u32, u32, C.c_int])
     S("ref_bfv_destroy", None, [vp])

@@ -892,3 +892,34 @@ def test_plus_minus_constants_against_live_reference(oracle, ref):
                     else:
                         o.orc_vec_add_const(got[i], a[i], consts[i], N, q[i], fmt)
                 assert np.array_equal(got, want), (logN, fmt, minus)
+
+
+@pytest.mark.parametrize("logN,L,bits,baseBits", [(4, 3, 60, 0), (5, 4, 60, 4), (6, 2, 50, 7), (5, 3, 60, 1), (4, 3, 36, 16), (5, 2, 60, 30),
+                                                  (5, 5, 45, 3)])
+def test_crt_decompose_against_live_reference(oracle, ref, logN, L, bits, baseBits):
+    """orc_crt_decompose == DCRTPolyImpl::CRTDecompose (dcrtpoly-impl.h:230-285; KeySwitchBV's digit decomposition) from both formats"""
+    o = oracle
+    N = 1 << logN
+    rng = np.random.default_rng(900 + baseBits)
+    q, psi = np.zeros(L, np.uint64), np.zeros(L, np.uint64)
+    o.orc_dcrt_params(2 * N, L, bits, q, psi)
+    x = libs.rand_tower(rng, q, N, 1)[0]
+    x[:, 0] = 0
+    x[:, 1] = q - np.uint64(1)
+    x[:, 2] = q >> np.uint64(1)
+    x[:, 3] = (q >> np.uint64(1)) + np.uint64(1)
+    octx = o.orc_ctx_create(N, L, q, psi)
+    towers = ref.ref_crt_decompose(N, L, q, psi, x, 0, baseBits, None)
+    assert towers == o.orc_crt_decompose(octx, x.ctypes.data, L, baseBits, None)
+    want = np.zeros((towers, L, N), np.uint64)
+    got = np.zeros_like(want)
+    ref.ref_crt_decompose(N, L, q, psi, x, 0, baseBits, want.ctypes.data)
+    o.orc_crt_decompose(octx, x.ctypes.data, L, baseBits, got.ctypes.data)
+    assert np.array_equal(got, want)
+    # the reference takes an EVALUATION tower too (its coefficient copy is the inverse transform): the same towers
+    xe = x.copy()
+    o.orc_ntt_fwd_tower(octx, xe, None, L, 1, 0)
+    want_e = np.zeros_like(want)
+    ref.ref_crt_decompose(N, L, q, psi, xe, 1, baseBits, want_e.ctypes.data)
+    assert np.array_equal(want_e, want)
+    o.orc_ctx_destroy(octx)

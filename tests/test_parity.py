@@ -459,6 +459,48 @@ def test_context_of_more_than_256_limbs_is_refused(backend, oracle):
         fh.Context(backend, 4, q, psi)
 
 
+@pytest.mark.parametrize("logN,L,bits,baseBits,ev", [(4, 3, 60, 0, 0), (5, 4, 60, 4, 1), (12, 2, 50, 7, 0), (13, 3, 60, 0, 1), (5, 3, 60, 1, 0),
+                                                     (6, 3, 36, 16, 1), (12, 2, 60, 30, 0), (5, 5, 45, 3, 1)])
+def test_crt_decompose(backend, oracle, logN, L, bits, baseBits, ev):
+    """fhe_crt_decompose = DCRTPolyImpl::CRTDecompose (dcrtpoly-impl.h:230-285; the digit decomposition of KeySwitchBV) from both formats;
+    the oracle function is pinned on the reference's member (tests/test_oracle_vs_ref.py)"""
+    o = oracle
+    N = 1 << logN
+    rng = np.random.default_rng(930 + baseBits)
+    q, psi = params(o, logN, L, bits)
+    ctx = fh.Context(backend, logN, q, psi)
+    octx = o.orc_ctx_create(N, L, q, psi)
+    x = libs.rand_tower(rng, q, N, 1)
+    x[0, :, 0] = 0
+    x[0, :, 1] = q - np.uint64(1)
+    x[0, :, 2] = q >> np.uint64(1)
+    x[0, :, 3] = (q >> np.uint64(1)) + np.uint64(1)
+    towers = o.orc_crt_decompose(octx, x.ctypes.data, L, baseBits, None)
+    want = np.zeros((towers, L, N), np.uint64)
+    o.orc_crt_decompose(octx, x.ctypes.data, L, baseBits, want.ctypes.data)
+    xin = x.copy()
+    if ev:
+        o.orc_ntt_fwd_tower(octx, xin, None, L, 1, 0)
+    t = ctx.tower(xin, fmt=fh.EVALUATION if ev else fh.COEFFICIENT)
+    got = t.CRTDecompose(baseBits)
+    assert got is not None and got.batch == towers
+    assert np.array_equal(got.to_host(), want)
+    assert np.array_equal(t.to_host(), xin), "the member is const"
+    o.orc_ctx_destroy(octx)
+    ctx.close()
+
+
+def test_crt_decompose_declines_windows_beyond_the_word(backend, oracle):
+    """ceil(msb(q) / baseBits) * baseBits > 64 (e.g. 60-bit moduli cut into digits of 25 bits): the reference shifts a 64-bit word by
+    64 and more there (undefined); the library reports 0 towers and the caller keeps its host path"""
+    q, psi = params(oracle, 5, 2, 60)
+    ctx = fh.Context(backend, 5, q, psi)
+    assert backend.L.fhe_crt_decompose_towers(ctx.h, None, 2, 25) == 0
+    assert backend.L.fhe_crt_decompose_towers(ctx.h, None, 2, 32) == 0
+    assert backend.L.fhe_crt_decompose_towers(ctx.h, None, 2, 20) == 6
+    ctx.close()
+
+
 def conv_tables(o, src, dst):
     """host tables exactly as the oracle's hybrid code derives them: hatInv[i], hatMod[i][j], mu128[j]"""
     nS, nD = len(src), len(dst)

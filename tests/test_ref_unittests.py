@@ -94,9 +94,9 @@ def test_reference_core_lattice_unit_tests_on_emulator():
 # profiles/r06_ref_unittests_trace.txt: the halmember lines).  The mirror is the reference's own class — what runs there proves nothing — so every member is
 # bounded by name; a member that is not listed may not run on the mirror at all.
 HOST_ALLOW = {
-    # KeySwitchBV (the BV key-switching technique, not the HYBRID path of SURVEY 8(a) a13): its digit decomposition and the accumulation
-    # of its digits run member by member on the reference's class (PRE, multiparty and the BV variants of the scheme tests)
-    "CRTDecompose": 1772, "EvalMult.KeySwitchAccumulate": 749,
+    # (KeySwitchBV — the BV key-switching technique of PRE, multiparty and the BV variants of the scheme tests — ran its digit decomposition
+    # DCRTPoly::CRTDecompose 1772 times and, on the host-resident digits, EvalMult.KeySwitchAccumulate 749 times on the mirror until
+    # round 6: fhe_crt_decompose cuts and lifts the digits on the device; no entry is left for either)
     # words produced or read on the host by pke itself: FHECKKSRNS::KeySwitchSparse fills limbs with SetElementAtIndex and adds them;
     # UnitTestMultipartyAborts reads limbs; PackedEncoding of a prime-cyclotomic plaintext transforms on the host
     "SetElementAtIndex": 128, "GetAllElements": 96, "operator+=": 64, "AssembleRows": 10, "SwitchFormat": 8,
