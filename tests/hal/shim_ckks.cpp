@@ -691,7 +691,14 @@ int main(int argc, char** argv) {
         p.SetRingDim(1u << logN);
         p.SetPlaintextModulus(65537);
         p.SetMultiplicativeDepth(3);
-        p.SetKeySwitchTechnique(HYBRID);
+        // argv[6] = "BV<digit size>": the BV key switch (DCRTPoly::CRTDecompose cuts the digits: dcrtpoly-impl.h:230-285, keyswitch-bv.cpp:254)
+        const std::string ks = argc > 6 ? argv[6] : "HYBRID";
+        if (ks.rfind("BV", 0) == 0) {
+            p.SetKeySwitchTechnique(BV);
+            p.SetDigitSize((uint32_t)std::stoul(ks.substr(2)));
+        }
+        else
+            p.SetKeySwitchTechnique(HYBRID);
         const std::string st = argc > 5 ? argv[5] : "FIXEDMANUAL";
         p.SetScalingTechnique(st == "FIXEDAUTO" ? FIXEDAUTO : st == "FLEXIBLEAUTO" ? FLEXIBLEAUTO : st == "FLEXIBLEAUTOEXT" ? FLEXIBLEAUTOEXT : FIXEDMANUAL);
         auto cc = GenCryptoContext(p);

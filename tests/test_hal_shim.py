@@ -33,7 +33,7 @@ def ensure_built():
 
 
 # the members SURVEY.md 8(a) a6-a19 name (+ the backend's row-level helpers behind pke's limb loops): no host-mirror execution allowed
-DEVICE_MEMBERS = {"SwitchFormat", "operator+=", "operator-=", "operator*=", "Plus", "Minus", "Times", "TimesNoCheck", "Negate", "operator-",
+DEVICE_MEMBERS = {"CRTDecompose", "SwitchFormat", "operator+=", "operator-=", "operator*=", "Plus", "Minus", "Times", "TimesNoCheck", "Negate", "operator-",
                   "AutomorphismTransform", "ApproxSwitchCRTBasis", "ApproxModUp", "ApproxModDown", "SwitchCRTBasis", "ExpandCRTBasis",
                   "ExpandCRTBasisReverseOrder", "FastExpandCRTBasisPloverQ", "ExpandCRTBasisQlHat", "ScaleAndRound", "ApproxScaleAndRound",
                   "ScaleAndRoundPOverQ", "FastBaseConvqToBskMontgomery", "FastRNSFloorq", "FastBaseConvSK", "DropLastElementAndScale",
@@ -344,6 +344,25 @@ def test_shim_bgv_matches_default_backend_on_emulator(tmp_path, technique):
 @pytest.mark.parametrize("technique,logN", [("FIXEDMANUAL", 13), ("FLEXIBLEAUTOEXT", 14)])
 def test_shim_bgv_matches_default_backend_on_gpu(tmp_path, technique, logN):
     ops = check(tmp_path, "bgv", logN, HIP, BGV, extra=(technique,), must_run=BGV_MEMBERS)
+    assert ops > 50
+
+
+# the BV key switch (BFV's and BGV's default technique in the reference): its digit decomposition DCRTPoly::CRTDecompose
+# (dcrtpoly-impl.h:230-285) as a device member (fhe_crt_decompose) — every dumped ciphertext byte-identical to the default backend's,
+# no host-mirror execution.  Digit sizes 0 (one tower per limb) and 4 / 16 (digits of the words).
+BV_MEMBERS = ("CRTDecompose", "ModReduce", "SwitchFormat", "AutomorphismTransform")
+
+
+@pytest.mark.parametrize("digits", ["BV0", "BV4", "BV16"])
+def test_shim_bgv_bv_key_switch_matches_default_backend_on_emulator(tmp_path, digits):
+    ops = check(tmp_path, "bgv", 10, EMU, BGV, extra=("FIXEDMANUAL", digits), must_run=BV_MEMBERS)
+    assert ops > 50
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("digits,logN", [("BV0", 13), ("BV4", 12), ("BV30", 13)])
+def test_shim_bgv_bv_key_switch_matches_default_backend_on_gpu(tmp_path, digits, logN):
+    ops = check(tmp_path, "bgv", logN, HIP, BGV, extra=("FIXEDMANUAL", digits), must_run=BV_MEMBERS)
     assert ops > 50
 
 
